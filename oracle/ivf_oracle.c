@@ -1,0 +1,1052 @@
+/*
+ * ivf_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY; see ivf_oracle.h for the parity statement).
+ *
+ * Plain-C restatement of the reference CPU algorithm.  Every function cites the reference
+ * file:line it follows (ORB/ = /root/reference/introspective_ORB_SLAM/).  OpenCV primitives the
+ * reference calls are restated from OpenCV 4.x's published plain-C++ algorithms ("frozen
+ * semantics") because OpenCV is absent from this image: PARITY UNPINNED there.
+ *
+ * Build: gcc -O3 -ffp-contract=off (no FMA contraction: SURVEY.md Appendix D-10).
+ */
+#include "ivf_oracle.h"
+#include <math.h>
+#include <float.h>
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------
+ * A-1  cvRound / cvFloor / cvCeil  (round-half-to-even; OpenCV fast_math.hpp)
+ * ---------------------------------------------------------------------------------------------- */
+int orc_cv_round_d(double v) { return (int)lrint(v); }
+int orc_cv_round_f(float v) { return (int)lrintf(v); }
+static int cv_floor_f(float v) { int i = (int)v; return i - (i > v); }
+static int cv_floor_d(double v) { int i = (int)v; return i - (i > v); }
+static int cv_ceil_d(double v) { int i = (int)v; return i + (i < v); }
+
+/* ------------------------------------------------------------------------------------------------
+ * A-8  cosf / sinf: glibc >= 2.28 single-precision sin/cos (ARM optimized-routines "sincosf"
+ * algorithm, f64 polynomial after a fast reduction by pi/2).  Restated so the SAME arithmetic
+ * runs on the device; checked exhaustively against this image's glibc 2.35 for every float in
+ * [0, 6.2832] (tests/test_oracle_primitives.py::test_trig_matches_glibc).  Called at
+ * ORB/src/ORBextractor.cc:113-114 through std::cos(float)/std::sin(float).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { double sign[4]; double hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3; } sincos_tab;
+static const sincos_tab SC[2] = {
+    {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0,
+     0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5, -0x1.6c087e89a359dp-10, 0x1.99343027bf8c3p-16,
+     -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13},
+    {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0,
+     -0x1p0, 0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5, 0x1.6c087e89a359dp-10, -0x1.99343027bf8c3p-16,
+     -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13}};
+static inline uint32_t abstop12(float x) { uint32_t u; memcpy(&u, &x, 4); return (u >> 20) & 0x7ff; }
+static inline float sincos_poly(double x, double x2, const sincos_tab* p, int n)
+{
+    if ((n & 1) == 0) {
+        double x3 = x * x2, s1 = p->s2 + x2 * p->s3, x7 = x3 * x2, s = x + x3 * p->s1;
+        return (float)(s + x7 * s1);
+    } else {
+        double x4 = x2 * x2, c2 = p->c3 + x2 * p->c4, c1 = p->c0 + x2 * p->c1, x6 = x4 * x2, c = c1 + x4 * p->c2;
+        return (float)(c + x6 * c2);
+    }
+}
+static inline double reduce_fast(double x, const sincos_tab* p, int* np)
+{
+    double r = x * p->hpi_inv;
+    int n = ((int32_t)r + 0x800000) >> 24;
+    *np = n;
+    return x - n * p->hpi;
+}
+/* valid for |y| < 120 (the path only feeds [0, 2*pi)); larger |y| falls back to libm */
+float orc_sinf(float y)
+{
+    double x = y; const sincos_tab* p = &SC[0]; int n;
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+        if (abstop12(y) < abstop12(0x1p-12f)) return y;
+        return sincos_poly(x, x * x, p, 0);
+    }
+    if (!(abstop12(y) < abstop12(120.0f))) return sinf(y);
+    x = reduce_fast(x, p, &n);
+    double s = p->sign[n & 3];
+    if (n & 2) p = &SC[1];
+    return sincos_poly(x * s, x * x, p, n);
+}
+float orc_cosf(float y)
+{
+    double x = y; const sincos_tab* p = &SC[0]; int n;
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+        if (abstop12(y) < abstop12(0x1p-12f)) return 1.0f;
+        return sincos_poly(x, x * x, p, 1);
+    }
+    if (!(abstop12(y) < abstop12(120.0f))) return cosf(y);
+    x = reduce_fast(x, p, &n);
+    double s = p->sign[n & 3];
+    if (n & 2) p = &SC[1];
+    return sincos_poly(x * s, x * x, p, n ^ 1);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A-5  cv::fastAtan2 (OpenCV 3.x/4.x mathfuncs_core: degree-7 odd polynomial, f32, degrees).
+ * Called at ORB/src/ORBextractor.cc:104.
+ * ---------------------------------------------------------------------------------------------- */
+float orc_fast_atan2(float y, float x)
+{
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A-2  cv::FAST(img, kps, t, true), TYPE_9_16 (OpenCV features2d/fast.cpp + fast_score.cpp).
+ * Called at ORB/src/ORBextractor.cc:1045,1051 on a per-cell sub-image.
+ * ---------------------------------------------------------------------------------------------- */
+static const int RING_DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+static const int RING_DY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+/* cornerScore<16>: max over the 16 arcs of 9 contiguous ring pixels, both polarities, of the
+ * minimum signed difference, floored at `threshold`, minus 1. */
+static int fast_corner_score(const uint8_t* ptr, const int* pixel, int threshold)
+{
+    int d[25], v = ptr[0], k;
+    for (k = 0; k < 25; k++) d[k] = v - ptr[pixel[k & 15]];
+    int a0 = threshold;
+    for (k = 0; k < 16; k += 2) {
+        int a = d[k + 1] < d[k + 2] ? d[k + 1] : d[k + 2];
+        if (d[k + 3] < a) a = d[k + 3];
+        if (a <= a0) continue;
+        for (int j = 4; j <= 8; j++) if (d[k + j] < a) a = d[k + j];
+        int m = a < d[k] ? a : d[k];
+        if (m > a0) a0 = m;
+        m = a < d[k + 9] ? a : d[k + 9];
+        if (m > a0) a0 = m;
+    }
+    int b0 = -a0;
+    for (k = 0; k < 16; k += 2) {
+        int b = d[k + 1] > d[k + 2] ? d[k + 1] : d[k + 2];
+        if (d[k + 3] > b) b = d[k + 3];
+        if (b >= b0) continue;
+        for (int j = 4; j <= 8; j++) if (d[k + j] > b) b = d[k + j];
+        int m = b > d[k] ? b : d[k];
+        if (m < b0) b0 = m;
+        m = b > d[k + 9] ? b : d[k + 9];
+        if (m < b0) b0 = m;
+    }
+    return -b0 - 1;
+}
+
+/* segment test: >= 9 contiguous ring pixels all < v-t or all > v+t */
+static int fast_is_corner(const uint8_t* ptr, const int* pixel, int t)
+{
+    int v = ptr[0], lo = v - t, hi = v + t;
+#define CLS(k) ((ptr[pixel[k]] < lo) ? 1 : (ptr[pixel[k]] > hi) ? 2 : 0)
+    int d = CLS(0) | CLS(8);
+    if (!d) return 0;
+    d &= CLS(2) | CLS(10); d &= CLS(4) | CLS(12); d &= CLS(6) | CLS(14);
+    if (!d) return 0;
+    d &= CLS(1) | CLS(9); d &= CLS(3) | CLS(11); d &= CLS(5) | CLS(13); d &= CLS(7) | CLS(15);
+#undef CLS
+    if (d & 1) {
+        int count = 0;
+        for (int k = 0; k < 25; k++) {
+            if (ptr[pixel[k & 15]] < lo) { if (++count > 8) return 1; } else count = 0;
+        }
+    }
+    if (d & 2) {
+        int count = 0;
+        for (int k = 0; k < 25; k++) {
+            if (ptr[pixel[k & 15]] > hi) { if (++count > 8) return 1; } else count = 0;
+        }
+    }
+    return 0;
+}
+
+void orc_fast_score_map(const uint8_t* img, int stride, int cols, int rows, int threshold, uint8_t* out)
+{
+    int pixel[16];
+    if (threshold < 0) threshold = 0;
+    if (threshold > 255) threshold = 255;
+    for (int k = 0; k < 16; k++) pixel[k] = RING_DX[k] + RING_DY[k] * stride;
+    memset(out, 0, (size_t)cols * rows);
+    for (int y = 3; y < rows - 3; y++)
+        for (int x = 3; x < cols - 3; x++) {
+            const uint8_t* p = img + (size_t)y * stride + x;
+            if (fast_is_corner(p, pixel, threshold))
+                out[(size_t)y * cols + x] = (uint8_t)fast_corner_score(p, pixel, threshold);
+        }
+}
+
+int orc_fast_detect(const uint8_t* img, int stride, int cols, int rows, int threshold, orc_keypoint* out, int cap)
+{
+    if (cols < 7 || rows < 7) return 0;
+    uint8_t* s = (uint8_t*)malloc((size_t)cols * rows);
+    orc_fast_score_map(img, stride, cols, rows, threshold, s);
+    int n = 0;
+    /* 3x3 strict non-max suppression; scores outside the detection domain are 0 (fast.cpp row buffers) */
+    for (int y = 3; y < rows - 3; y++)
+        for (int x = 3; x < cols - 3; x++) {
+            int sc = s[(size_t)y * cols + x];
+            if (!sc) continue;
+            const uint8_t* r0 = s + (size_t)(y - 1) * cols + x;
+            const uint8_t* r1 = r0 + cols;
+            const uint8_t* r2 = r1 + cols;
+            if (sc > r1[-1] && sc > r1[1] && sc > r0[-1] && sc > r0[0] && sc > r0[1] &&
+                sc > r2[-1] && sc > r2[0] && sc > r2[1]) {
+                if (n < cap) {
+                    out[n].x = (float)x; out[n].y = (float)y; out[n].size = 7.f; out[n].angle = -1.f;
+                    out[n].response = (float)sc; out[n].octave = 0;
+                }
+                n++;
+            }
+        }
+    free(s);
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A-3  cv::resize(..., INTER_LINEAR), CV_8UC1 (OpenCV imgproc/resize.cpp: 11-bit fixed-point
+ * coefficients, HResizeLinear into int, VResizeLinear<uchar,int,short,FixedPtCast<..,22>>).
+ * Called at ORB/src/ORBextractor.cc:1311,1341.
+ * ---------------------------------------------------------------------------------------------- */
+static inline short sat_short_round(float v)
+{
+    int i = orc_cv_round_f(v);
+    return (short)(i < -32768 ? -32768 : i > 32767 ? 32767 : i);
+}
+void orc_resize_linear_8u(const uint8_t* src, int sstride, int sw, int sh, uint8_t* dst, int dstride, int dw, int dh)
+{
+    double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    int* xofs = (int*)malloc(sizeof(int) * dw);
+    short* alpha = (short*)malloc(sizeof(short) * 2 * dw);
+    int* row0 = (int*)malloc(sizeof(int) * dw);
+    int* row1 = (int*)malloc(sizeof(int) * dw);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor_f(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        alpha[2 * dx] = sat_short_round((1.f - fx) * 2048.f);
+        alpha[2 * dx + 1] = sat_short_round(fx * 2048.f);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor_f(fy);
+        fy -= sy;
+        short b0 = sat_short_round((1.f - fy) * 2048.f), b1 = sat_short_round(fy * 2048.f);
+        int y0 = sy < 0 ? 0 : sy > sh - 1 ? sh - 1 : sy;
+        int y1 = sy + 1 < 0 ? 0 : sy + 1 > sh - 1 ? sh - 1 : sy + 1;
+        const uint8_t* S0 = src + (size_t)y0 * sstride;
+        const uint8_t* S1 = src + (size_t)y1 * sstride;
+        for (int dx = 0; dx < dw; dx++) {
+            int sx = xofs[dx], sx1 = sx + 1 < sw ? sx + 1 : sx;
+            row0[dx] = S0[sx] * alpha[2 * dx] + S0[sx1] * alpha[2 * dx + 1];
+            row1[dx] = S1[sx] * alpha[2 * dx] + S1[sx1] * alpha[2 * dx + 1];
+        }
+        uint8_t* D = dst + (size_t)dy * dstride;
+        for (int dx = 0; dx < dw; dx++)
+            D[dx] = (uint8_t)((((b0 * (row0[dx] >> 4)) >> 16) + ((b1 * (row1[dx] >> 4)) >> 16) + 2) >> 2);
+    }
+    free(xofs); free(alpha); free(row0); free(row1);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A-4  cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101), CV_8U (OpenCV >= 3.4.2 / 4.x fixed-point
+ * path: 8.8 kernel with error diffusion [18,34,48,56,48,34,18]/256, exact horizontal pass,
+ * 16.16 vertical pass rounded (+32768)>>16).  Called at ORB/src/ORBextractor.cc:1277.
+ * ---------------------------------------------------------------------------------------------- */
+static const int GK[7] = {18, 34, 48, 56, 48, 34, 18};
+static inline int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) { if (p < 0) p = -p; else p = 2 * (n - 1) - p; }
+    return p;
+}
+void orc_gauss7_8u(const uint8_t* src, int sstride, int w, int h, uint8_t* dst, int dstride)
+{
+    uint16_t* tmp = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)w * h);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = src + (size_t)y * sstride;
+        uint16_t* t = tmp + (size_t)y * w;
+        for (int x = 0; x < w; x++) {
+            int acc = 0;
+            if (x >= 3 && x < w - 3) for (int k = 0; k < 7; k++) acc += GK[k] * s[x + k - 3];
+            else for (int k = 0; k < 7; k++) acc += GK[k] * s[reflect101(x + k - 3, w)];
+            t[x] = (uint16_t)acc;
+        }
+    }
+    for (int y = 0; y < h; y++) {
+        const uint16_t* r[7];
+        for (int k = 0; k < 7; k++) r[k] = tmp + (size_t)reflect101(y + k - 3, h) * w;
+        uint8_t* d = dst + (size_t)y * dstride;
+        for (int x = 0; x < w; x++) {
+            uint32_t acc = 0;
+            for (int k = 0; k < 7; k++) acc += (uint32_t)GK[k] * r[k][x];
+            d[x] = (uint8_t)((acc + 32768u) >> 16);
+        }
+    }
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A-6  std::nth_element (libstdc++ bits/stl_algo.h: __introselect, median-of-3 to first,
+ * __unguarded_partition, depth limit 2*lg(n), __heap_select fallback, __insertion_sort for <= 3)
+ * with cv::KeypointResponseGreater, then cv::KeyPointsFilter::retainBest (OpenCV 4.x) and the
+ * reference's resize (ORB/src/ORBextractor.cc:1146-1148, 1164-1165).
+ * Pinned against this image's libstdc++ by oracle/stl_pin.cpp.
+ * ---------------------------------------------------------------------------------------------- */
+#define GT(a, b) ((a).response > (b).response)
+static inline void kswap(orc_keypoint* a, orc_keypoint* b) { orc_keypoint t = *a; *a = *b; *b = t; }
+
+static void move_median_to_first(orc_keypoint* result, orc_keypoint* a, orc_keypoint* b, orc_keypoint* c)
+{
+    if (GT(*a, *b)) {
+        if (GT(*b, *c)) kswap(result, b);
+        else if (GT(*a, *c)) kswap(result, c);
+        else kswap(result, a);
+    } else if (GT(*a, *c)) kswap(result, a);
+    else if (GT(*b, *c)) kswap(result, c);
+    else kswap(result, b);
+}
+static orc_keypoint* unguarded_partition(orc_keypoint* first, orc_keypoint* last, orc_keypoint* pivot)
+{
+    for (;;) {
+        while (GT(*first, *pivot)) ++first;
+        --last;
+        while (GT(*pivot, *last)) --last;
+        if (!(first < last)) return first;
+        kswap(first, last);
+        ++first;
+    }
+}
+static void push_heap_(orc_keypoint* first, long hole, long top, orc_keypoint value)
+{
+    long parent = (hole - 1) / 2;
+    while (hole > top && GT(first[parent], value)) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+static void adjust_heap_(orc_keypoint* first, long hole, long len, orc_keypoint value)
+{
+    const long top = hole;
+    long child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (GT(first[child], first[child - 1])) child--;
+        first[hole] = first[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    push_heap_(first, hole, top, value);
+}
+static void heap_select_(orc_keypoint* first, orc_keypoint* middle, orc_keypoint* last)
+{
+    long len = middle - first;
+    if (len >= 2) {
+        long parent = (len - 2) / 2;
+        for (;;) {
+            orc_keypoint v = first[parent];
+            adjust_heap_(first, parent, len, v);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    for (orc_keypoint* i = middle; i < last; ++i)
+        if (GT(*i, *first)) {
+            orc_keypoint v = *i;
+            *i = *first;
+            adjust_heap_(first, 0, len, v);
+        }
+}
+static void insertion_sort_(orc_keypoint* first, orc_keypoint* last)
+{
+    if (first == last) return;
+    for (orc_keypoint* i = first + 1; i != last; ++i) {
+        if (GT(*i, *first)) {
+            orc_keypoint v = *i;
+            memmove(first + 1, first, (size_t)(i - first) * sizeof(orc_keypoint));
+            *first = v;
+        } else {
+            orc_keypoint v = *i;
+            orc_keypoint* l = i;
+            orc_keypoint* nx = i - 1;
+            while (GT(v, *nx)) { *l = *nx; l = nx; --nx; }
+            *l = v;
+        }
+    }
+}
+void orc_nth_element_resp(orc_keypoint* v, int n, int nth)
+{
+    if (n <= 0 || nth >= n) return;
+    orc_keypoint *first = v, *last = v + n, *pn = v + nth;
+    long depth = 0;
+    for (long t = n; t > 1; t >>= 1) depth++;   /* std::__lg(n) */
+    depth *= 2;
+    while (last - first > 3) {
+        if (depth == 0) {
+            heap_select_(first, pn + 1, last);
+            kswap(first, pn);
+            return;
+        }
+        --depth;
+        orc_keypoint* mid = first + (last - first) / 2;
+        move_median_to_first(first, first + 1, mid, last - 1);
+        orc_keypoint* cut = unguarded_partition(first + 1, last, first);
+        if (cut <= pn) first = cut; else last = cut;
+    }
+    insertion_sort_(first, last);
+}
+int orc_retain_best(orc_keypoint* v, int n, int n_points)
+{
+    if (n_points >= 0 && n > n_points) {
+        if (n_points == 0) return 0;
+        orc_nth_element_resp(v, n, n_points - 1);
+        /* std::partition of the tail only reorders elements past n_points, which the reference's
+         * resize(n_points) then drops (ORBextractor.cc:1147-1148,1165): the survivors are v[0..n_points) */
+        return n_points;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a11  ORBmatcher::DescriptorDistance (ORB/src/ORBmatcher.cc:1700-1716): SWAR popcount of 8 x u32
+ * ---------------------------------------------------------------------------------------------- */
+int orc_hamming256(const uint8_t* a, const uint8_t* b)
+{
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t x, y;
+        memcpy(&x, a + 4 * i, 4); memcpy(&y, b + 4 * i, 4);
+        uint32_t v = x ^ y;
+        v = v - ((v >> 1) & 0x55555555u);
+        v = (v & 0x33333333u) + ((v >> 2) & 0x33333333u);
+        dist += (int)((((v + (v >> 4)) & 0xF0F0F0Fu) * 0x1010101u) >> 24);
+    }
+    return dist;
+}
+
+static const int8_t PATTERN31[1024] = {
+#include "../include/ivf_pattern31.inc"
+};
+const int8_t* orc_bit_pattern_31(void) { return PATTERN31; }
+
+/* ------------------------------------------------------------------------------------------------
+ * Extractor state
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { int w, h; uint8_t* data; } plane;
+struct orc_extractor {
+    orc_params p;
+    double scale_factor_d;                 /* the member is `double scaleFactor` (ORB/include/ORBextractor.h:110) */
+    float scale[ORC_MAX_LEVELS], inv_scale[ORC_MAX_LEVELS], sigma2[ORC_MAX_LEVELS], inv_sigma2[ORC_MAX_LEVELS];
+    int nfeat[ORC_MAX_LEVELS];
+    int umax[16];
+    plane pyr[ORC_MAX_LEVELS], qpyr[ORC_MAX_LEVELS];
+    int quality_available;
+    int level_count[ORC_MAX_LEVELS];
+};
+
+/* ORB/src/ORBextractor.cc:411-476 */
+orc_extractor* orc_extractor_create(const orc_params* p)
+{
+    if (!p || p->nlevels < 1 || p->nlevels > ORC_MAX_LEVELS) return NULL;
+    orc_extractor* e = (orc_extractor*)calloc(1, sizeof(*e));
+    e->p = *p;
+    e->scale_factor_d = (double)p->scale_factor;
+    const int nl = p->nlevels;
+    e->scale[0] = 1.0f; e->sigma2[0] = 1.0f;
+    for (int i = 1; i < nl; i++) {
+        e->scale[i] = (float)((double)e->scale[i - 1] * e->scale_factor_d);   /* :424 float*double */
+        e->sigma2[i] = e->scale[i] * e->scale[i];
+    }
+    for (int i = 0; i < nl; i++) {
+        e->inv_scale[i] = 1.0f / e->scale[i];
+        e->inv_sigma2[i] = 1.0f / e->sigma2[i];
+    }
+    float factor = (float)(1.0 / e->scale_factor_d);                                              /* :437 */
+    float nDesired = (float)p->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nl)); /* :438 */
+    int sum = 0;
+    for (int l = 0; l < nl - 1; l++) {
+        e->nfeat[l] = orc_cv_round_f(nDesired);
+        sum += e->nfeat[l];
+        nDesired *= factor;
+    }
+    e->nfeat[nl - 1] = p->nfeatures - sum > 0 ? p->nfeatures - sum : 0;
+    /* umax (:458-475), HALF_PATCH_SIZE = 15 */
+    int v, v0, vmax = cv_floor_d(15 * sqrtf(2.f) / 2 + 1), vmin = cv_ceil_d(15 * sqrtf(2.f) / 2);
+    const double hp2 = 15 * 15;
+    for (v = 0; v <= vmax; ++v) e->umax[v] = orc_cv_round_d(sqrt(hp2 - v * v));
+    for (v = 15, v0 = 0; v >= vmin; --v) {
+        while (e->umax[v0] == e->umax[v0 + 1]) ++v0;
+        e->umax[v] = v0;
+        ++v0;
+    }
+    return e;
+}
+void orc_extractor_destroy(orc_extractor* e)
+{
+    if (!e) return;
+    for (int l = 0; l < ORC_MAX_LEVELS; l++) { free(e->pyr[l].data); free(e->qpyr[l].data); }
+    free(e);
+}
+int orc_extractor_levels(const orc_extractor* e) { return e->p.nlevels; }
+void orc_extractor_tables(const orc_extractor* e, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                          int* features_per_level, int* umax16)
+{
+    for (int l = 0; l < e->p.nlevels; l++) {
+        if (scale) scale[l] = e->scale[l];
+        if (inv_scale) inv_scale[l] = e->inv_scale[l];
+        if (sigma2) sigma2[l] = e->sigma2[l];
+        if (inv_sigma2) inv_sigma2[l] = e->inv_sigma2[l];
+        if (features_per_level) features_per_level[l] = e->nfeat[l];
+    }
+    if (umax16) memcpy(umax16, e->umax, sizeof(int) * 16);
+}
+int orc_pyramid_level(const orc_extractor* e, int level, const uint8_t** data, int* w, int* h)
+{
+    if (level < 0 || level >= e->p.nlevels || !e->pyr[level].data) return -1;
+    *data = e->pyr[level].data; *w = e->pyr[level].w; *h = e->pyr[level].h;
+    return 0;
+}
+int orc_quality_level(const orc_extractor* e, int level, const uint8_t** data, int* w, int* h)
+{
+    if (level < 0 || level >= e->p.nlevels || !e->qpyr[level].data) return -1;
+    *data = e->qpyr[level].data; *w = e->qpyr[level].w; *h = e->qpyr[level].h;
+    return 0;
+}
+int orc_level_count(const orc_extractor* e, int level) { return e->level_count[level]; }
+
+/* ComputePyramid / ComputeQualityImagePyramid (ORB/src/ORBextractor.cc:1298-1357).  The 19-px
+ * reflect-101 border the reference adds is never read by the live path, so
+ * planes are stored un-padded. */
+static void build_pyramid(const orc_extractor* e, plane* pyr, const uint8_t* img, int w, int h, int stride)
+{
+    for (int l = 0; l < e->p.nlevels; l++) {
+        float s = e->inv_scale[l];
+        int lw = orc_cv_round_f((float)w * s), lh = orc_cv_round_f((float)h * s);
+        free(pyr[l].data);
+        pyr[l].w = lw; pyr[l].h = lh;
+        pyr[l].data = (uint8_t*)malloc((size_t)(lw > 0 ? lw : 1) * (lh > 0 ? lh : 1));
+        if (l == 0) for (int y = 0; y < h; y++) memcpy(pyr[0].data + (size_t)y * w, img + (size_t)y * stride, w);
+        else orc_resize_linear_8u(pyr[l - 1].data, pyr[l - 1].w, pyr[l - 1].w, pyr[l - 1].h, pyr[l].data, lw, lw, lh);
+    }
+}
+
+/* IC_Angle (ORB/src/ORBextractor.cc:78-105) */
+static float ic_angle(const plane* im, float px, float py, const int* umax)
+{
+    int m_01 = 0, m_10 = 0;
+    const int step = im->w;
+    const uint8_t* center = im->data + (size_t)orc_cv_round_f(py) * step + orc_cv_round_f(px);
+    for (int u = -15; u <= 15; ++u) m_10 += u * center[u];
+    for (int v = 1; v <= 15; ++v) {
+        int v_sum = 0, d = umax[v];
+        for (int u = -d; u <= d; ++u) {
+            int val_plus = center[u + v * step], val_minus = center[u - v * step];
+            v_sum += (val_plus - val_minus);
+            m_10 += u * (val_plus + val_minus);
+        }
+        m_01 += v * v_sum;
+    }
+    return orc_fast_atan2((float)m_01, (float)m_10);
+}
+
+/* computeOrbDescriptor (ORB/src/ORBextractor.cc:109-148): x*b + y*a is evaluated WITHOUT fma */
+static void orb_descriptor(const orc_keypoint* kp, const uint8_t* img, int step, uint8_t* desc)
+{
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float angle = kp->angle * factorPI;
+    float a = orc_cosf(angle), b = orc_sinf(angle);
+    const uint8_t* center = img + (size_t)orc_cv_round_f(kp->y) * step + orc_cv_round_f(kp->x);
+    const int8_t* pat = PATTERN31;
+    for (int i = 0; i < 32; ++i) {
+        int val = 0;
+        for (int k = 0; k < 8; k++, pat += 4) {
+            float x0 = pat[0], y0 = pat[1], x1 = pat[2], y1 = pat[3];
+            int t0 = center[orc_cv_round_f(x0 * b + y0 * a) * step + orc_cv_round_f(x0 * a - y0 * b)];
+            int t1 = center[orc_cv_round_f(x1 * b + y1 * a) * step + orc_cv_round_f(x1 * a - y1 * b)];
+            val |= (t0 < t1) << k;
+        }
+        desc[i] = (uint8_t)val;
+    }
+}
+
+static unsigned long roi_sum(const plane* im, int x0, int y0, int x1, int y1)
+{
+    unsigned long s = 0;
+    for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) s += im->data[(size_t)y * im->w + x];
+    return s;
+}
+
+typedef struct { orc_keypoint* v; int n, cap; } kvec;
+static void kvec_reserve(kvec* k, int cap) { if (cap > k->cap) { k->v = (orc_keypoint*)realloc(k->v, sizeof(orc_keypoint) * cap); k->cap = cap; } }
+
+/* ComputeKeyPointsOld (ORB/src/ORBextractor.cc:880-1213) for one level; returns -3 if a cell window
+ * leaves the image (OpenCV would throw there). */
+static int keypoints_level(orc_extractor* e, int level, kvec* out)
+{
+    const plane* im = &e->pyr[level];
+    const int introspect = e->quality_available && e->p.enable_introspection;
+    const float imageRatio = (float)e->pyr[0].w / e->pyr[0].h;
+    const int nDesired = e->nfeat[level];
+    const int levelCols = (int)sqrtf((float)nDesired / (5 * imageRatio));
+    const int levelRows = (int)(imageRatio * levelCols);
+    out->n = 0;
+    if (levelCols <= 0 || levelRows <= 0) return 0;
+    const int minBorderX = 19, minBorderY = 19, maxBorderX = im->w - 19, maxBorderY = im->h - 19;
+    const int W = maxBorderX - minBorderX, H = maxBorderY - minBorderY;
+    const int cellW = (int)ceilf((float)W / levelCols), cellH = (int)ceilf((float)H / levelRows);
+    const int nCells = levelRows * levelCols;
+    const int nfeaturesCell = (int)ceilf((float)nDesired / nCells);
+
+    kvec* cellKP = (kvec*)calloc(nCells, sizeof(kvec));
+    int* nToRetain = (int*)calloc(nCells, sizeof(int));
+    int* nTotal = (int*)calloc(nCells, sizeof(int));
+    char* bNoMore = (char*)calloc(nCells, 1);
+    int* iniXCol = (int*)calloc(levelCols, sizeof(int));
+    int* iniYRow = (int*)calloc(levelRows, sizeof(int));
+    float* nfeatures_cell = (float*)malloc(sizeof(float) * nCells);
+    float* cell_weights = (float*)calloc(nCells, sizeof(float));
+    for (int c = 0; c < nCells; c++) nfeatures_cell[c] = (float)nfeaturesCell;
+    int nNoMore = 0, nToDistribute = 0, rc = 0;
+    float hY = (float)(cellH + 6);            /* :935 -- NOT reset by the main loop (Appendix D-2) */
+    float cell_weights_sum = 0.0f;
+
+    if (introspect) {                          /* :946-987 */
+        const plane* q = &e->qpyr[level];
+        for (int i = 0; i < levelRows; i++) {
+            const float iniY = (float)(minBorderY + i * cellH - 3);
+            iniYRow[i] = (int)iniY;
+            if (i == levelRows - 1) { hY = maxBorderY + 3 - iniY; if (hY <= 0) continue; }
+            float hX = (float)(cellW + 6);
+            for (int j = 0; j < levelCols; j++) {
+                float iniX;
+                if (i == 0) { iniX = (float)(minBorderX + j * cellW - 3); iniXCol[j] = (int)iniX; }
+                else iniX = (float)iniXCol[j];
+                if (j == levelCols - 1) { hX = maxBorderX + 3 - iniX; if (hX <= 0) continue; }
+                int y0 = (int)iniY, y1 = (int)(iniY + hY), x0 = (int)iniX, x1 = (int)(iniX + hX);
+                if (x0 < 0 || y0 < 0 || x1 > q->w || y1 > q->h || x1 < x0 || y1 < y0) { rc = -3; goto done; }
+                unsigned long sum = roi_sum(q, x0, y0, x1, y1);
+                float cost = (float)sum / (float)(hX * hY);
+                float qual_score = (float)(1.0 / (1.0 + (double)(cost / 255)));      /* :981 double then narrowed */
+                float qual_score_norm = 2 * qual_score - 1;
+                cell_weights[i * levelCols + j] = qual_score_norm;
+                cell_weights_sum += qual_score_norm;
+            }
+        }
+    }
+
+    for (int i = 0; i < levelRows; i++) {      /* :989-1101 */
+        const float iniY = (float)(minBorderY + i * cellH - 3);
+        iniYRow[i] = (int)iniY;
+        if (i == levelRows - 1) { hY = maxBorderY + 3 - iniY; if (hY <= 0) continue; }
+        float hX = (float)(cellW + 6);
+        for (int j = 0; j < levelCols; j++) {
+            const int c = i * levelCols + j;
+            float iniX;
+            if (i == 0) { iniX = (float)(minBorderX + j * cellW - 3); iniXCol[j] = (int)iniX; }
+            else iniX = (float)iniXCol[j];
+            if (j == levelCols - 1) { hX = maxBorderX + 3 - iniX; if (hX <= 0) continue; }
+            if (introspect)
+                nfeatures_cell[c] = fmaxf(1.0f, ceilf((float)nDesired * cell_weights[c] / cell_weights_sum));
+            int y0 = (int)iniY, y1 = (int)(iniY + hY), x0 = (int)iniX, x1 = (int)(iniX + hX);
+            /* a cell whose FAST domain leaves [19, dim-19) makes the reference read outside the
+             * blurred clone (UB) or throw in rowRange/colRange: reported as unsupported geometry */
+            if (x0 < 0 || y0 < 0 || x1 > maxBorderX + 3 || y1 > maxBorderY + 3 || x1 < x0 || y1 < y0) { rc = -3; goto done; }
+            const uint8_t* cell = im->data + (size_t)y0 * im->w + x0;
+            const int cw = x1 - x0, ch = y1 - y0;
+            kvec* kv = &cellKP[c];
+            int maxk = ((cw > 6 ? cw - 6 : 0) * (ch > 6 ? ch - 6 : 0)) + 1;
+            kvec_reserve(kv, maxk);
+            kv->n = orc_fast_detect(cell, im->w, cw, ch, e->p.ini_th_fast, kv->v, kv->cap);
+            if (kv->n <= 3) kv->n = orc_fast_detect(cell, im->w, cw, ch, e->p.min_th_fast, kv->v, kv->cap);
+            if (introspect) {                  /* :1058-1080 */
+                const plane* q = &e->qpyr[level];
+                for (int k = 0; k < kv->n; k++) {
+                    float cost = (float)q->data[(size_t)(y0 + (int)kv->v[k].y) * q->w + (x0 + (int)kv->v[k].x)];
+                    kv->v[k].response *= 2 * (1.0f / (1.0f + cost / 255.0f)) - 1;
+                }
+            }
+            const int nKeys = kv->n;
+            nTotal[c] = nKeys;
+            if ((float)nKeys > nfeatures_cell[c]) { nToRetain[c] = (int)nfeatures_cell[c]; bNoMore[c] = 0; }
+            else {
+                nToRetain[c] = nKeys;
+                nToDistribute = (int)((float)nToDistribute + (nfeatures_cell[c] - (float)nKeys));
+                bNoMore[c] = 1; nNoMore++;
+            }
+        }
+    }
+
+    while (nToDistribute > 0 && nNoMore < nCells) {      /* :1103-1133 (runs at most once) */
+        for (int c = 0; c < nCells; c++) {
+            if (!bNoMore[c]) {
+                int nNew = (int)(nfeatures_cell[c] + ceilf((float)nToDistribute / (nCells - nNoMore)));
+                if (nTotal[c] > nNew) { nToRetain[c] = nNew; bNoMore[c] = 0; }
+                else {
+                    nToRetain[c] = nTotal[c];
+                    nToDistribute += nNew - nTotal[c];
+                    bNoMore[c] = 1; nNoMore++;
+                }
+            }
+        }
+        nToDistribute = 0;
+    }
+
+    {
+        int total = 0;
+        for (int c = 0; c < nCells; c++) total += cellKP[c].n;
+        kvec_reserve(out, total + 1);
+    }
+    const int scaledPatchSize = (int)(31 * e->scale[level]);          /* :1142 */
+    for (int i = 0; i < levelRows; i++)
+        for (int j = 0; j < levelCols; j++) {
+            kvec* kv = &cellKP[i * levelCols + j];
+            kv->n = orc_retain_best(kv->v, kv->n, nToRetain[i * levelCols + j]);
+            for (int k = 0; k < kv->n; k++) {
+                orc_keypoint kp = kv->v[k];
+                kp.x += iniXCol[j]; kp.y += iniYRow[i];
+                kp.octave = level; kp.size = (float)scaledPatchSize;
+                out->v[out->n++] = kp;
+            }
+        }
+    if (out->n > nDesired) out->n = orc_retain_best(out->v, out->n, nDesired);   /* :1162-1166 */
+done:
+    for (int c = 0; c < nCells; c++) free(cellKP[c].v);
+    free(cellKP); free(nToRetain); free(nTotal); free(bNoMore); free(iniXCol); free(iniYRow);
+    free(nfeatures_cell); free(cell_weights);
+    return rc;
+}
+
+/* ORBextractor::operator() (ORB/src/ORBextractor.cc:1224-1296) */
+int orc_extract(orc_extractor* e, const uint8_t* img, int w, int h, int stride,
+                const uint8_t* cost, int cost_stride, orc_keypoint* kps, uint8_t* desc, int cap, int* n_out)
+{
+    *n_out = 0;
+    if (!img || w <= 0 || h <= 0) return 0;                /* :1227 empty image -> silent return */
+    if (cost && e->p.enable_introspection) {               /* :1231-1238 */
+        e->quality_available = 1;
+        build_pyramid(e, e->qpyr, cost, w, h, cost_stride);
+    } else e->quality_available = 0;
+    build_pyramid(e, e->pyr, img, w, h, stride);
+
+    const int nl = e->p.nlevels;
+    kvec lv[ORC_MAX_LEVELS];
+    memset(lv, 0, sizeof(lv));
+    int rc = 0, total = 0;
+    for (int l = 0; l < nl && rc == 0; l++) {
+        if (e->pyr[l].w < 39 || e->pyr[l].h < 39) { e->level_count[l] = 0; continue; }
+        rc = keypoints_level(e, l, &lv[l]);
+        e->level_count[l] = lv[l].n;
+        total += lv[l].n;
+    }
+    if (rc == 0 && total > cap) rc = -2;
+    if (rc == 0) {
+        for (int l = 0; l < nl; l++)                        /* computeOrientation :1209-1210 */
+            for (int k = 0; k < lv[l].n; k++) lv[l].v[k].angle = ic_angle(&e->pyr[l], lv[l].v[k].x, lv[l].v[k].y, e->umax);
+        int offset = 0;
+        for (int l = 0; l < nl; l++) {
+            if (lv[l].n == 0) continue;
+            const plane* im = &e->pyr[l];
+            uint8_t* blur = (uint8_t*)malloc((size_t)im->w * im->h);
+            orc_gauss7_8u(im->data, im->w, im->w, im->h, blur, im->w);      /* :1276-1277 */
+            for (int k = 0; k < lv[l].n; k++) orb_descriptor(&lv[l].v[k], blur, im->w, desc + (size_t)(offset + k) * 32);
+            free(blur);
+            if (l != 0) {
+                float sc = e->scale[l];
+                for (int k = 0; k < lv[l].n; k++) { lv[l].v[k].x *= sc; lv[l].v[k].y *= sc; }
+            }
+            memcpy(kps + offset, lv[l].v, sizeof(orc_keypoint) * lv[l].n);
+            offset += lv[l].n;
+        }
+        *n_out = offset;
+    }
+    for (int l = 0; l < nl; l++) free(lv[l].v);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a12  Frame::ComputeStereoMatches (ORB/src/Frame.cc:758-932)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { int dist, idx; } dist_idx;
+static int cmp_dist_idx(const void* a, const void* b)
+{
+    const dist_idx *x = (const dist_idx*)a, *y = (const dist_idx*)b;
+    if (x->dist != y->dist) return x->dist < y->dist ? -1 : 1;
+    return x->idx < y->idx ? -1 : x->idx > y->idx;
+}
+int orc_stereo_match(const orc_extractor* eL, const orc_extractor* eR,
+                     const orc_keypoint* kpL, int nL, const uint8_t* descL,
+                     const orc_keypoint* kpR, int nR, const uint8_t* descR,
+                     float bf, float b, float* u_right, float* depth)
+{
+    for (int i = 0; i < nL; i++) { u_right[i] = -1.0f; depth[i] = -1.0f; }
+    if (!eL->pyr[0].data || !eR->pyr[0].data) return -1;
+    const int thOrbDist = (100 + 50) / 2;
+    const int nRows = eL->pyr[0].h;
+    /* row table: candidates per row in increasing iR (:767-785) */
+    int* rowCount = (int*)calloc(nRows, sizeof(int));
+    int* minr = (int*)malloc(sizeof(int) * (nR > 0 ? nR : 1));
+    int* maxr = (int*)malloc(sizeof(int) * (nR > 0 ? nR : 1));
+    for (int iR = 0; iR < nR; iR++) {
+        const float kpY = kpR[iR].y;
+        const float r = 2.0f * eL->scale[kpR[iR].octave];
+        maxr[iR] = (int)ceilf(kpY + r);
+        minr[iR] = (int)floorf(kpY - r);
+        for (int yi = minr[iR]; yi <= maxr[iR]; yi++) if (yi >= 0 && yi < nRows) rowCount[yi]++;
+    }
+    int* rowStart = (int*)malloc(sizeof(int) * (nRows + 1));
+    rowStart[0] = 0;
+    for (int y = 0; y < nRows; y++) rowStart[y + 1] = rowStart[y] + rowCount[y];
+    int* rowIdx = (int*)malloc(sizeof(int) * (rowStart[nRows] > 0 ? rowStart[nRows] : 1));
+    memset(rowCount, 0, sizeof(int) * nRows);
+    for (int iR = 0; iR < nR; iR++)
+        for (int yi = minr[iR]; yi <= maxr[iR]; yi++) if (yi >= 0 && yi < nRows) rowIdx[rowStart[yi] + rowCount[yi]++] = iR;
+
+    const float minZ = b, minD = 0, maxD = bf / minZ;
+    dist_idx* vDistIdx = (dist_idx*)malloc(sizeof(dist_idx) * (nL > 0 ? nL : 1));
+    int nDist = 0;
+
+    for (int iL = 0; iL < nL; iL++) {
+        const int levelL = kpL[iL].octave;
+        const float vL = kpL[iL].y, uL = kpL[iL].x;
+        const int row = (int)vL;
+        if (row < 0 || row >= nRows) continue;
+        const int nC = rowCount[row];
+        if (nC == 0) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = 100;                        /* ORBmatcher::TH_HIGH */
+        int bestIdxR = 0;
+        const uint8_t* dL = descL + (size_t)iL * 32;
+        for (int iC = 0; iC < nC; iC++) {
+            const int iR = rowIdx[rowStart[row] + iC];
+            if (kpR[iR].octave < levelL - 1 || kpR[iR].octave > levelL + 1) continue;
+            const float uR = kpR[iR].x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = orc_hamming256(dL, descR + (size_t)iR * 32);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        if (bestDist < thOrbDist) {                /* :844 sub-pixel match by correlation */
+            const float uR0 = kpR[bestIdxR].x;
+            const float scaleFactor = eL->inv_scale[levelL];
+            const float scaleduL = roundf(kpL[iL].x * scaleFactor);
+            const float scaledvL = roundf(kpL[iL].y * scaleFactor);
+            const float scaleduR0 = roundf(uR0 * scaleFactor);
+            const int w = 5, L = 5;
+            const plane* PL = &eL->pyr[levelL];
+            const plane* PR = &eR->pyr[levelL];
+            const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+            if (iniu < 0 || endu >= PR->w) continue;
+            const int yl = (int)(scaledvL - w), xl = (int)(scaleduL - w);
+            /* windows must lie inside the level (OpenCV would throw otherwise) */
+            if (yl < 0 || yl + 11 > PL->h || xl < 0 || xl + 11 > PL->w) continue;
+            if ((int)(scaleduR0 - L - w) < 0) continue;
+            const int cLv = PL->data[(size_t)(yl + w) * PL->w + xl + w];
+            int bestD = INT_MAX, bestincR = 0;
+            float vDists[11];
+            for (int incR = -L; incR <= L; incR++) {
+                const int xr = (int)(scaleduR0 + incR - w);
+                const int cRv = PR->data[(size_t)(yl + w) * PR->w + xr + w];
+                int acc = 0;
+                for (int yy = 0; yy < 11; yy++)
+                    for (int xx = 0; xx < 11; xx++) {
+                        int dl = PL->data[(size_t)(yl + yy) * PL->w + xl + xx] - cLv;
+                        int dr = PR->data[(size_t)(yl + yy) * PR->w + xr + xx] - cRv;
+                        acc += abs(dl - dr);
+                    }
+                float dist = (float)acc;
+                if (dist < (float)bestD) { bestD = (int)dist; bestincR = incR; }
+                vDists[L + incR] = dist;
+            }
+            if (bestincR == -L || bestincR == L) continue;
+            const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = eL->scale[levelL] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+                depth[iL] = bf / disparity;
+                u_right[iL] = bestuR;
+                vDistIdx[nDist].dist = bestD; vDistIdx[nDist].idx = iL; nDist++;
+            }
+        }
+    }
+    if (nDist > 0) {                               /* :918-931; empty list => no gate (Appendix D-8) */
+        qsort(vDistIdx, nDist, sizeof(dist_idx), cmp_dist_idx);
+        const float median = (float)vDistIdx[nDist / 2].dist;
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = nDist - 1; i >= 0; i--) {
+            if ((float)vDistIdx[i].dist < thDist) break;
+            u_right[vDistIdx[i].idx] = -1; depth[vDistIdx[i].idx] = -1;
+        }
+    }
+    free(rowCount); free(minr); free(maxr); free(rowStart); free(rowIdx); free(vDistIdx);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a16  Frame grid: AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea (ORB/src/Frame.cc:415-430,
+ * 615-680; grid 64 x 48, ORB/include/Frame.h:43-44)
+ * ---------------------------------------------------------------------------------------------- */
+#define GRID_COLS 64
+#define GRID_ROWS 48
+typedef struct { int* start; int* idx; float inv_w, inv_h; } grid_t;
+static void grid_build(grid_t* g, const orc_keypoint* kps, int n, const orc_bounds* bd)
+{
+    g->inv_w = (float)GRID_COLS / (bd->max_x - bd->min_x);
+    g->inv_h = (float)GRID_ROWS / (bd->max_y - bd->min_y);
+    g->start = (int*)calloc(GRID_COLS * GRID_ROWS + 1, sizeof(int));
+    g->idx = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+    int* cell = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) {
+        int px = (int)roundf((kps[i].x - bd->min_x) * g->inv_w), py = (int)roundf((kps[i].y - bd->min_y) * g->inv_h);
+        if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) { cell[i] = -1; continue; }
+        cell[i] = px * GRID_ROWS + py;
+        g->start[cell[i] + 1]++;
+    }
+    for (int c = 0; c < GRID_COLS * GRID_ROWS; c++) g->start[c + 1] += g->start[c];
+    int* fill = (int*)calloc(GRID_COLS * GRID_ROWS, sizeof(int));
+    for (int i = 0; i < n; i++) if (cell[i] >= 0) g->idx[g->start[cell[i]] + fill[cell[i]]++] = i;
+    free(fill); free(cell);
+}
+static void grid_free(grid_t* g) { free(g->start); free(g->idx); }
+static int grid_query(const grid_t* g, const orc_keypoint* kps, const orc_bounds* bd,
+                      float x, float y, float r, int minLevel, int maxLevel, int32_t* out, int cap)
+{
+    int n = 0;
+    int nMinCellX = (int)floorf((x - bd->min_x - r) * g->inv_w); if (nMinCellX < 0) nMinCellX = 0;
+    if (nMinCellX >= GRID_COLS) return 0;
+    int nMaxCellX = (int)ceilf((x - bd->min_x + r) * g->inv_w); if (nMaxCellX > GRID_COLS - 1) nMaxCellX = GRID_COLS - 1;
+    if (nMaxCellX < 0) return 0;
+    int nMinCellY = (int)floorf((y - bd->min_y - r) * g->inv_h); if (nMinCellY < 0) nMinCellY = 0;
+    if (nMinCellY >= GRID_ROWS) return 0;
+    int nMaxCellY = (int)ceilf((y - bd->min_y + r) * g->inv_h); if (nMaxCellY > GRID_ROWS - 1) nMaxCellY = GRID_ROWS - 1;
+    if (nMaxCellY < 0) return 0;
+    const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const int c = ix * GRID_ROWS + iy;
+            for (int j = g->start[c]; j < g->start[c + 1]; j++) {
+                const orc_keypoint* kp = &kps[g->idx[j]];
+                if (bCheckLevels) {
+                    if (kp->octave < minLevel) continue;
+                    if (maxLevel >= 0 && kp->octave > maxLevel) continue;
+                }
+                const float distx = kp->x - x, disty = kp->y - y;
+                if (fabsf(distx) < r && fabsf(disty) < r) { if (n < cap) out[n] = g->idx[j]; n++; }
+            }
+        }
+    return n;
+}
+int orc_features_in_area(const orc_keypoint* kps, int n, const orc_bounds* bounds,
+                         float x, float y, float r, int min_level, int max_level, int32_t* out, int cap)
+{
+    grid_t g;
+    grid_build(&g, kps, n, bounds);
+    int c = grid_query(&g, kps, bounds, x, y, r, min_level, max_level, out, cap);
+    grid_free(&g);
+    return c;
+}
+
+/* a17  ORBmatcher::ComputeThreeMaxima (ORB/src/ORBmatcher.cc:1654-1695) */
+void orc_three_maxima(const int* histo, int L, int* ind1, int* ind2, int* ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    *ind1 = *ind2 = *ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; *ind3 = *ind2; *ind2 = i; }
+        else if (s > max3) { max3 = s; *ind3 = i; }
+    }
+    if ((float)max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
+    else if ((float)max3 < 0.1f * (float)max1) { *ind3 = -1; }
+}
+
+/* a13  ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORB/src/ORBmatcher.cc:1372-1518)
+ * on already-projected queries.  Per query i (a last-frame map point that passed the frustum tests):
+ *   q_u,q_v   projected pixel; q_ur = u - bf*invzc; q_radius = th*scale[lastOctave];
+ *   q_min_level/q_max_level  the GetFeaturesInArea level arguments chosen at :1429-1434;
+ *   q_angle   LastFrame.mvKeysUn[i].angle; q_desc the map point descriptor;
+ *   q_blocks  1 when pMP->Observations()>0 (its assignment blocks later queries, :1447-1449).
+ * cur_assign[i2]: in/out; -1 free, -2 pre-occupied by a blocking map point, >=0 query index. */
+int orc_search_by_projection(const orc_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int n_cur,
+                             const orc_bounds* bounds,
+                             int n_q, const float* q_u, const float* q_v, const float* q_ur, const float* q_radius,
+                             const int32_t* q_min_level, const int32_t* q_max_level,
+                             const float* q_angle, const uint8_t* q_desc,
+                             const uint8_t* q_valid, const uint8_t* q_blocks,
+                             int check_orientation, int32_t* cur_assign, int* nmatches_out)
+{
+    int nmatches = 0;
+    enum { HISTO_LENGTH = 30 };
+    int* rotHist[HISTO_LENGTH]; int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int*)malloc(sizeof(int) * (n_q > 0 ? n_q : 1)); rotN[i] = 0; }
+    const float factor = 1.0f / HISTO_LENGTH;
+    grid_t g;
+    grid_build(&g, cur_kps, n_cur, bounds);
+    int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (n_cur > 0 ? n_cur : 1));
+    for (int i = 0; i < n_q; i++) {
+        if (q_valid && !q_valid[i]) continue;
+        const float u = q_u[i], v = q_v[i], radius = q_radius[i];
+        int nc = grid_query(&g, cur_kps, bounds, u, v, radius, q_min_level[i], q_max_level[i], cand, n_cur);
+        if (nc == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int k = 0; k < nc; k++) {
+            const int i2 = cand[k];
+            if (cur_assign[i2] == -2) continue;
+            if (cur_assign[i2] >= 0 && (!q_blocks || q_blocks[cur_assign[i2]])) continue;
+            if (cur_uright[i2] > 0) {
+                const float er = fabsf(q_ur[i] - cur_uright[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = orc_hamming256(q_desc + (size_t)i * 32, cur_desc + (size_t)i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= 100) {
+            cur_assign[bestIdx2] = i;
+            nmatches++;
+            if (check_orientation) {
+                float rot = q_angle[i] - cur_kps[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin][rotN[bin]++] = bestIdx2;
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1, ind2, ind3;
+        orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < rotN[i]; j++) { cur_assign[rotHist[i][j]] = -1; nmatches--; }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+    free(cand);
+    grid_free(&g);
+    *nmatches_out = nmatches;
+    return 0;
+}

@@ -1,0 +1,113 @@
+/*
+ * ivf_oracle.h -- CPU ORACLE for the IV-SLAM visual front end (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is a plain-C restatement of the reference's CPU algorithm for the hot path
+ * (ORBextractor -> stereo matcher -> Hamming matcher).  It is NOT part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * Parity status: "PARITY UNPINNED at the OpenCV boundary".  The reference's arithmetic for
+ * FAST / resize / GaussianBlur / fastAtan2 / retainBest lives in un-vendored, version-unpinned
+ * OpenCV (ORB/CMakeLists.txt:37-46) which is absent from this image, and the reference ships no
+ * tests or golden vectors for this path.  Those primitives are therefore restated from OpenCV 4.x's
+ * published plain-C++ algorithms (see DESIGN.md "Frozen primitive semantics").  What IS pinned:
+ *   - std::nth_element / std::partition order  -> checked against this image's libstdc++ (oracle/stl_pin.cpp)
+ *   - cosf / sinf                              -> checked exhaustively against this image's glibc 2.35
+ *   - the introspection FCN                    -> golden vectors from the reference's own Python model
+ *
+ * ORB/ = /root/reference/introspective_ORB_SLAM/
+ */
+#ifndef IVF_ORACLE_H
+#define IVF_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_LEVELS 16
+
+/* cv::KeyPoint subset used by the path (ORB/src/ORBextractor.cc:1155-1156, 1286-1292) */
+typedef struct {
+    float x, y;      /* pt */
+    float size;      /* 31 * scale[octave] truncated to int */
+    float angle;     /* degrees [0,360) */
+    float response;  /* FAST score (x quality factor when introspection is on) */
+    int32_t octave;
+} orc_keypoint;
+
+typedef struct {
+    int nfeatures;
+    float scale_factor;
+    int nlevels;
+    int ini_th_fast;
+    int min_th_fast;
+    int enable_introspection;
+} orc_params;
+
+typedef struct orc_extractor orc_extractor;
+
+/* ---- frozen primitives (Appendix A of SURVEY.md) ---- */
+int   orc_cv_round_f(float v);
+int   orc_cv_round_d(double v);
+float orc_fast_atan2(float y, float x);
+float orc_cosf(float x);   /* restated glibc >= 2.28 cosf (ARM optimized-routines algorithm) */
+float orc_sinf(float x);
+/* FAST-9/16 corner score map of a (sub-)image: out[y*cols+x] = score if corner at `threshold` else 0,
+ * zero outside rows [3,rows-3) x cols [3,cols-3). */
+void  orc_fast_score_map(const uint8_t* img, int stride, int cols, int rows, int threshold, uint8_t* out);
+/* cv::FAST(img, kps, threshold, nonmaxSuppression=true): returns number of keypoints written (<= cap). */
+int   orc_fast_detect(const uint8_t* img, int stride, int cols, int rows, int threshold,
+                      orc_keypoint* out, int cap);
+void  orc_resize_linear_8u(const uint8_t* src, int sstride, int sw, int sh,
+                           uint8_t* dst, int dstride, int dw, int dh);
+void  orc_gauss7_8u(const uint8_t* src, int sstride, int w, int h, uint8_t* dst, int dstride);
+/* libstdc++ std::nth_element(first, first+nth, first+n, response-greater) restated */
+void  orc_nth_element_resp(orc_keypoint* v, int n, int nth);
+/* cv::KeyPointsFilter::retainBest followed by the reference's resize(n_points); returns new size */
+int   orc_retain_best(orc_keypoint* v, int n, int n_points);
+int   orc_hamming256(const uint8_t* a, const uint8_t* b);
+const int8_t* orc_bit_pattern_31(void);   /* 1024 int8: 256 x (x0,y0,x1,y1) */
+
+/* ---- extractor (ORB/src/ORBextractor.cc:411-476, 880-1357) ---- */
+orc_extractor* orc_extractor_create(const orc_params* p);
+void  orc_extractor_destroy(orc_extractor* e);
+int   orc_extractor_levels(const orc_extractor* e);
+void  orc_extractor_tables(const orc_extractor* e, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                           int* features_per_level, int* umax16);
+/* operator(): returns 0 on success; *n_out = number of keypoints (<= cap else error -2). */
+int   orc_extract(orc_extractor* e, const uint8_t* img, int w, int h, int stride,
+                  const uint8_t* cost, int cost_stride,
+                  orc_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+/* mvImagePyramid[level] (un-padded view, contiguous) after the last orc_extract */
+int   orc_pyramid_level(const orc_extractor* e, int level, const uint8_t** data, int* w, int* h);
+int   orc_quality_level(const orc_extractor* e, int level, const uint8_t** data, int* w, int* h);
+/* per-level keypoint count of the last call (debug / stage parity) */
+int   orc_level_count(const orc_extractor* e, int level);
+
+/* ---- Frame::ComputeStereoMatches (ORB/src/Frame.cc:758-932) ---- */
+int   orc_stereo_match(const orc_extractor* eL, const orc_extractor* eR,
+                       const orc_keypoint* kpL, int nL, const uint8_t* descL,
+                       const orc_keypoint* kpR, int nR, const uint8_t* descR,
+                       float bf, float b, float* u_right, float* depth);
+
+/* ---- Frame grid (ORB/src/Frame.cc:415-430, 615-680) + ORBmatcher::SearchByProjection(cur,last)
+ *      (ORB/src/ORBmatcher.cc:1372-1518) on flat, already-projected queries ---- */
+typedef struct { float min_x, min_y, max_x, max_y; } orc_bounds;
+int   orc_search_by_projection(const orc_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int n_cur,
+                               const orc_bounds* bounds,
+                               int n_q, const float* q_u, const float* q_v, const float* q_ur, const float* q_radius,
+                               const int32_t* q_min_level, const int32_t* q_max_level,
+                               const float* q_angle, const uint8_t* q_desc,
+                               const uint8_t* q_valid, const uint8_t* q_blocks,
+                               int check_orientation, int32_t* cur_assign, int* nmatches);
+/* Frame::GetFeaturesInArea on a freshly built grid: returns count, indices in reference order */
+int   orc_features_in_area(const orc_keypoint* kps, int n, const orc_bounds* bounds,
+                           float x, float y, float r, int min_level, int max_level, int32_t* out, int cap);
+/* ORBmatcher::ComputeThreeMaxima (ORB/src/ORBmatcher.cc:1654-1695) on bin sizes */
+void  orc_three_maxima(const int* histo_sizes, int L, int* ind1, int* ind2, int* ind3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

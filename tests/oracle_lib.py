@@ -1,0 +1,212 @@
+"""ctypes bindings for oracle/libivf_oracle.so (TEST INFRASTRUCTURE: the checker, never the product)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4")])
+assert KP_DTYPE.itemsize == 24
+
+
+class Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int), ("enable_introspection", C.c_int)]
+
+
+class Bounds(C.Structure):
+    _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float)]
+
+
+def _build():
+    so = os.path.join(ORACLE_DIR, "libivf_oracle.so")
+    pin = os.path.join(ORACLE_DIR, "libstl_pin.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("ivf_oracle.c", "ivf_oracle.h", "stl_pin.cpp")]
+    newest = max(os.path.getmtime(s) for s in srcs)
+    if not (os.path.exists(so) and os.path.exists(pin)) or min(os.path.getmtime(so), os.path.getmtime(pin)) < newest:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return so, pin
+
+
+_so, _pin = _build()
+lib = C.CDLL(_so)
+pin = C.CDLL(_pin)
+
+u8p = C.POINTER(C.c_uint8)
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int32)
+vp = C.c_void_p
+
+lib.orc_cv_round_f.restype = C.c_int; lib.orc_cv_round_f.argtypes = [C.c_float]
+lib.orc_cv_round_d.restype = C.c_int; lib.orc_cv_round_d.argtypes = [C.c_double]
+lib.orc_fast_atan2.restype = C.c_float; lib.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+lib.orc_cosf.restype = C.c_float; lib.orc_cosf.argtypes = [C.c_float]
+lib.orc_sinf.restype = C.c_float; lib.orc_sinf.argtypes = [C.c_float]
+lib.orc_fast_score_map.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+lib.orc_fast_detect.restype = C.c_int
+lib.orc_fast_detect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+lib.orc_resize_linear_8u.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+lib.orc_gauss7_8u.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+lib.orc_nth_element_resp.argtypes = [vp, C.c_int, C.c_int]
+lib.orc_retain_best.restype = C.c_int; lib.orc_retain_best.argtypes = [vp, C.c_int, C.c_int]
+lib.orc_hamming256.restype = C.c_int; lib.orc_hamming256.argtypes = [vp, vp]
+lib.orc_bit_pattern_31.restype = C.POINTER(C.c_int8)
+lib.orc_extractor_create.restype = vp; lib.orc_extractor_create.argtypes = [C.POINTER(Params)]
+lib.orc_extractor_destroy.argtypes = [vp]
+lib.orc_extractor_levels.restype = C.c_int; lib.orc_extractor_levels.argtypes = [vp]
+lib.orc_extractor_tables.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+lib.orc_extract.restype = C.c_int
+lib.orc_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]
+lib.orc_pyramid_level.restype = C.c_int
+lib.orc_pyramid_level.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+lib.orc_quality_level.restype = C.c_int
+lib.orc_quality_level.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+lib.orc_level_count.restype = C.c_int; lib.orc_level_count.argtypes = [vp, C.c_int]
+lib.orc_stereo_match.restype = C.c_int
+lib.orc_stereo_match.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_float, C.c_float, vp, vp]
+lib.orc_search_by_projection.restype = C.c_int
+lib.orc_search_by_projection.argtypes = [vp, vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
+                                         vp, vp, C.c_int, vp, C.POINTER(C.c_int)]
+lib.orc_features_in_area.restype = C.c_int
+lib.orc_features_in_area.argtypes = [vp, C.c_int, C.POINTER(Bounds), C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                     vp, C.c_int]
+lib.orc_three_maxima.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+pin.stl_retain_best.restype = C.c_int; pin.stl_retain_best.argtypes = [vp, C.c_int, C.c_int]
+pin.stl_nth_element.argtypes = [vp, C.c_int, C.c_int]
+
+
+def ptr(a):
+    return a.ctypes.data_as(vp) if a is not None else None
+
+
+def fast_score_map(img, threshold):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros_like(img)
+    lib.orc_fast_score_map(ptr(img), img.shape[1], img.shape[1], img.shape[0], threshold, ptr(out))
+    return out
+
+
+def fast_detect(img, threshold):
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size
+    out = np.zeros(cap, KP_DTYPE)
+    n = lib.orc_fast_detect(ptr(img), img.shape[1], img.shape[1], img.shape[0], threshold, ptr(out), cap)
+    return out[:n]
+
+
+def resize_linear(img, dw, dh):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros((dh, dw), np.uint8)
+    lib.orc_resize_linear_8u(ptr(img), img.shape[1], img.shape[1], img.shape[0], ptr(out), dw, dw, dh)
+    return out
+
+
+def gauss7(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros_like(img)
+    lib.orc_gauss7_8u(ptr(img), img.shape[1], img.shape[1], img.shape[0], ptr(out), img.shape[1])
+    return out
+
+
+def hamming(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib.orc_hamming256(ptr(a), ptr(b))
+
+
+def pattern31():
+    return np.ctypeslib.as_array(lib.orc_bit_pattern_31(), shape=(1024,)).copy()
+
+
+class Extractor:
+    """Oracle counterpart of ORB_SLAM2::ORBextractor (ORB/include/ORBextractor.h:51-126)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, introspection=False):
+        self.params = Params(nfeatures, scale_factor, nlevels, ini_th, min_th, int(bool(introspection)))
+        self.h = lib.orc_extractor_create(C.byref(self.params))
+        if not self.h:
+            raise ValueError("bad extractor params")
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.orc_extractor_destroy(self.h)
+            self.h = None
+
+    def tables(self):
+        n = self.nlevels
+        sc = np.zeros(n, np.float32); inv = np.zeros(n, np.float32); s2 = np.zeros(n, np.float32)
+        is2 = np.zeros(n, np.float32); nf = np.zeros(n, np.int32); um = np.zeros(16, np.int32)
+        lib.orc_extractor_tables(self.h, ptr(sc), ptr(inv), ptr(s2), ptr(is2), ptr(nf), ptr(um))
+        return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, features_per_level=nf, umax=um)
+
+    def __call__(self, img, cost=None, cap=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        cap = cap or max(2 * self.nfeatures, 64)
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        if cost is not None:
+            cost = np.ascontiguousarray(cost, np.uint8)
+            assert cost.shape == img.shape
+        rc = lib.orc_extract(self.h, ptr(img), w, h, w, ptr(cost), w, ptr(kps), ptr(desc), cap, C.byref(n))
+        if rc != 0:
+            raise RuntimeError("orc_extract rc=%d" % rc)
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def _level(self, fn, level):
+        d = vp(); w = C.c_int(); h = C.c_int()
+        if fn(self.h, level, C.byref(d), C.byref(w), C.byref(h)) != 0:
+            return None
+        buf = (C.c_uint8 * (w.value * h.value)).from_address(d.value)
+        return np.frombuffer(buf, np.uint8).reshape(h.value, w.value).copy()
+
+    def pyramid(self, level):
+        return self._level(lib.orc_pyramid_level, level)
+
+    def quality_pyramid(self, level):
+        return self._level(lib.orc_quality_level, level)
+
+    def level_counts(self):
+        return [lib.orc_level_count(self.h, l) for l in range(self.nlevels)]
+
+
+def stereo_match(eL, eR, kpL, descL, kpR, descR, bf, b):
+    kpL = np.ascontiguousarray(kpL); kpR = np.ascontiguousarray(kpR)
+    descL = np.ascontiguousarray(descL); descR = np.ascontiguousarray(descR)
+    ur = np.zeros(len(kpL), np.float32); dp = np.zeros(len(kpL), np.float32)
+    rc = lib.orc_stereo_match(eL.h, eR.h, ptr(kpL), len(kpL), ptr(descL), ptr(kpR), len(kpR), ptr(descR),
+                              bf, b, ptr(ur), ptr(dp))
+    if rc != 0:
+        raise RuntimeError("orc_stereo_match rc=%d" % rc)
+    return ur, dp
+
+
+def features_in_area(kps, bounds, x, y, r, min_level, max_level):
+    kps = np.ascontiguousarray(kps)
+    out = np.zeros(max(len(kps), 1), np.int32)
+    bd = Bounds(*bounds)
+    n = lib.orc_features_in_area(ptr(kps), len(kps), C.byref(bd), x, y, r, min_level, max_level, ptr(out), len(out))
+    return out[:n].copy()
+
+
+def search_by_projection(cur_kps, cur_desc, cur_uright, bounds, q, check_orientation=True, cur_assign=None):
+    """q: dict with u,v,ur,radius,min_level,max_level,angle,desc,valid,blocks (numpy arrays)."""
+    cur_kps = np.ascontiguousarray(cur_kps); cur_desc = np.ascontiguousarray(cur_desc, np.uint8)
+    cur_uright = np.ascontiguousarray(cur_uright, np.float32)
+    n_cur = len(cur_kps); n_q = len(q["u"])
+    assign = np.full(n_cur, -1, np.int32) if cur_assign is None else np.ascontiguousarray(cur_assign, np.int32).copy()
+    arrs = dict(u=np.float32, v=np.float32, ur=np.float32, radius=np.float32, min_level=np.int32, max_level=np.int32,
+                angle=np.float32, desc=np.uint8, valid=np.uint8, blocks=np.uint8)
+    qq = {k: np.ascontiguousarray(q[k], t) for k, t in arrs.items()}
+    bd = Bounds(*bounds)
+    nm = C.c_int(0)
+    lib.orc_search_by_projection(ptr(cur_kps), ptr(cur_desc), ptr(cur_uright), n_cur, C.byref(bd), n_q,
+                                 ptr(qq["u"]), ptr(qq["v"]), ptr(qq["ur"]), ptr(qq["radius"]),
+                                 ptr(qq["min_level"]), ptr(qq["max_level"]), ptr(qq["angle"]), ptr(qq["desc"]),
+                                 ptr(qq["valid"]), ptr(qq["blocks"]), int(check_orientation), ptr(assign), C.byref(nm))
+    return assign, nm.value
