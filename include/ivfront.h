@@ -1,0 +1,172 @@
+/*
+ * ivfront.h -- flat C-ABI of the MI355X-native IV-SLAM visual front end (libivfront.so).
+ *
+ * The reference (ut-amrl/IV_SLAM) has no plugin/FFI layer for this path: its boundary is two C++
+ * classes, ORB_SLAM2::ORBextractor (ORB/include/ORBextractor.h:51-126) and ORB_SLAM2::ORBmatcher
+ * (ORB/include/ORBmatcher.h:37-108), plus Frame::ComputeStereoMatches (ORB/src/Frame.cc:758-932)
+ * which reads ORBextractor::mvImagePyramid directly.  This header is the C-ABI a maintainer binds
+ * BEHIND those class surfaces (see include/ivfront_orbslam.hpp and INTEGRATION.md); every entry
+ * point names the reference interface it replaces.  ORB/ = introspective_ORB_SLAM/.
+ *
+ * Conventions: plain pointers and sizes only; caller-allocated outputs; every function returns an
+ * int status (IVF_OK or a negative IVF_E_*), never throws; ivf_last_error() gives a thread-local
+ * message.  One handle = one non-re-entrant instance (like one ORBextractor); different handles
+ * may be used concurrently from different threads (ORB/src/Frame.cc:116-124 runs L/R on 2 threads).
+ * All compute runs in hand-written HIP kernels on gfx950; there is NO CPU fallback: without a
+ * usable GPU every compute entry point fails with IVF_E_NO_DEVICE.
+ */
+#ifndef IVFRONT_H
+#define IVFRONT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IVF_OK             0
+#define IVF_E_INVALID     -1   /* bad argument */
+#define IVF_E_CAPACITY    -2   /* caller buffer too small */
+#define IVF_E_GEOMETRY    -3   /* cell grid leaves the image (the reference would throw / read OOB) */
+#define IVF_E_NO_DEVICE   -4   /* no usable HIP device / HIP runtime error */
+#define IVF_E_STATE       -5   /* call order violated (e.g. stereo match before extract) */
+
+#define IVF_MAX_LEVELS 16
+
+/* cv::KeyPoint subset produced by ORBextractor::operator() (ORB/src/ORBextractor.cc:1155-1156,1286-1294) */
+typedef struct ivf_keypoint {
+    float x, y;        /* pt, level-0 coordinates (level coords * mvScaleFactor[octave]) */
+    float size;        /* (int)(31 * mvScaleFactor[octave]) */
+    float angle;       /* degrees, [0,360) */
+    float response;    /* FAST score, times the quality factor when introspection is active */
+    int32_t octave;
+} ivf_keypoint;
+
+/* ORBextractor constructor arguments (ORB/include/ORBextractor.h:57-58, ORB/src/ORBextractor.cc:411-415) */
+typedef struct ivf_extractor_params {
+    int32_t nfeatures;
+    float   scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    int32_t enable_introspection;   /* bool enableIntrospection */
+} ivf_extractor_params;
+
+typedef struct ivf_extractor ivf_extractor;   /* one ORB_SLAM2::ORBextractor */
+typedef struct ivf_frontend  ivf_frontend;    /* batched, device-resident stereo front end */
+
+/* ---- library ---- */
+int         ivf_version(void);
+const char* ivf_last_error(void);
+int         ivf_device_count(void);                 /* number of visible HIP devices (0 if none) */
+
+/* ---- ORBextractor ---- */
+/* ORBextractor::ORBextractor (ORB/src/ORBextractor.cc:411-476); constructed in Tracking (ORB/src/Tracking.cc:174-191) */
+int  ivf_extractor_create(const ivf_extractor_params* params, int device_id, ivf_extractor** out);
+/* ~ORBextractor / Tracking::Release (ORB/src/Tracking.cc:2617-2626) */
+void ivf_extractor_destroy(ivf_extractor* e);
+/* GetLevels / GetScaleFactor (ORB/include/ORBextractor.h:69-73) */
+int  ivf_extractor_get_levels(const ivf_extractor* e);
+float ivf_extractor_get_scale_factor(const ivf_extractor* e);
+/* GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares / GetInverseScaleSigmaSquares
+ * (ORB/include/ORBextractor.h:75-89); each array has nlevels entries; any pointer may be NULL */
+int  ivf_extractor_get_scale_tables(const ivf_extractor* e, float* scale, float* inv_scale,
+                                    float* sigma2, float* inv_sigma2);
+/* mnFeaturesPerLevel (ORB/src/ORBextractor.cc:438-452) and umax (:458-475), for tests */
+int  ivf_extractor_get_feature_tables(const ivf_extractor* e, int32_t* features_per_level, int32_t* umax16);
+/* ORBextractor::operator()(image, mask, keypoints, descriptors) (ORB/src/ORBextractor.cc:1224-1296).
+ * image: 8-bit grey, host memory.  cost: the `mask` argument = u8 cost map of the same size, or NULL
+ * (used only when the handle was created with enable_introspection, as in :1231-1238).
+ * kps[cap], desc[cap*32] caller-allocated; *n_out = number written.  Empty image -> IVF_OK, *n_out = 0. */
+int  ivf_extract(ivf_extractor* e, const uint8_t* image, int width, int height, int stride,
+                 const uint8_t* cost, int cost_stride,
+                 ivf_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+/* mvImagePyramid[level] / mvQualityImagePyramid[level] (ORB/include/ORBextractor.h:91-92): copies the
+ * un-padded level of the LAST ivf_extract into dst (rows of dst_stride bytes); dst may be NULL to query size. */
+int  ivf_extractor_pyramid_level(const ivf_extractor* e, int level, uint8_t* dst, int dst_stride, int* width, int* height);
+int  ivf_extractor_quality_level(const ivf_extractor* e, int level, uint8_t* dst, int dst_stride, int* width, int* height);
+/* keypoints per level of the last call (allKeypoints[level].size(), ORB/src/ORBextractor.cc:1253-1254) */
+int  ivf_extractor_level_counts(const ivf_extractor* e, int32_t* counts);
+
+/* ---- Frame::ComputeStereoMatches (ORB/src/Frame.cc:758-932) ----
+ * Uses the pyramids held by the two extractor handles from their last ivf_extract (as the reference
+ * reads mpORBextractorLeft/Right->mvImagePyramid, :765,855,867,872).  bf = mbf, b = mb.
+ * u_right[nL], depth[nL] receive mvuRight / mvDepth (-1 = no match). */
+int  ivf_stereo_match(const ivf_extractor* left, const ivf_extractor* right,
+                      const ivf_keypoint* kps_left, int n_left, const uint8_t* desc_left,
+                      const ivf_keypoint* kps_right, int n_right, const uint8_t* desc_right,
+                      float bf, float b, float* u_right, float* depth);
+
+/* ---- ORBmatcher ---- */
+/* ORBmatcher::DescriptorDistance (ORB/src/ORBmatcher.cc:1700-1716); host helper, 32-byte rows */
+int  ivf_hamming(const uint8_t* a, const uint8_t* b);
+/* dist[i] = DescriptorDistance(desc_a[pairs[2i]], desc_b[pairs[2i+1]]) on the device */
+int  ivf_hamming_pairs(const uint8_t* desc_a, int n_a, const uint8_t* desc_b, int n_b,
+                       const int32_t* pairs, int n_pairs, int32_t* dist, int device_id);
+
+typedef struct ivf_bounds { float min_x, min_y, max_x, max_y; } ivf_bounds;   /* Frame::mnMinX.. (ORB/src/Frame.cc:724-756) */
+/* Frame::GetFeaturesInArea on Frame::mGrid (ORB/src/Frame.cc:415-430, 615-680): host helper that
+ * returns indices in the reference's cell-major order; *n_out may exceed cap (IVF_E_CAPACITY). */
+int  ivf_features_in_area(const ivf_keypoint* kps, int n, const ivf_bounds* bounds,
+                          float x, float y, float r, int min_level, int max_level,
+                          int32_t* out, int cap, int* n_out);
+/* ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th, bMono) (ORB/src/ORBmatcher.cc:1372-1518)
+ * on flat, already-projected queries (one per last-frame map point that passed :1399-1421):
+ *   q_u,q_v  projection (:1416-1417); q_ur = u - mbf*invzc (:1453); q_radius = th*mvScaleFactors[oct] (:1427);
+ *   q_min_level,q_max_level = GetFeaturesInArea level args chosen at :1429-1434; q_angle = LastFrame.mvKeysUn[i].angle;
+ *   q_desc = pMP->GetDescriptor() (32 B each); q_valid (nullable) 0 = skip; q_blocks (nullable, default 1) =
+ *   pMP->Observations()>0.  cur_assign[n_cur] in/out: -1 free, -2 occupied by a blocking map point,
+ *   >=0 index of the query matched (CurrentFrame.mvpMapPoints).  Window Hamming distances are computed on
+ *   the device; the order-dependent greedy assignment (:1447-1472) and rotation histogram (:1475-1511) are
+ *   replayed in the reference's order. */
+int  ivf_search_by_projection(const ivf_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int n_cur,
+                              const ivf_bounds* bounds,
+                              int n_q, const float* q_u, const float* q_v, const float* q_ur, const float* q_radius,
+                              const int32_t* q_min_level, const int32_t* q_max_level,
+                              const float* q_angle, const uint8_t* q_desc,
+                              const uint8_t* q_valid, const uint8_t* q_blocks,
+                              int check_orientation, int32_t* cur_assign, int* nmatches, int device_id);
+
+/* ---- batched device-resident stereo front end (throughput path; one per GPU) ----
+ * Equivalent to, for each pair: left/right ORBextractor::operator() (ORB/src/Frame.cc:115-125),
+ * mvKeyQualScore (ORB/src/Frame.cc:130-143) and Frame::ComputeStereoMatches (:758-932), for up to
+ * max_pairs pairs per call with all inputs/outputs resident in HBM. */
+typedef struct ivf_frontend_config {
+    ivf_extractor_params left, right;   /* Tracking builds the right extractor with introspection off (ORB/src/Tracking.cc:182-183) */
+    int32_t width, height;              /* fixed image size */
+    int32_t max_pairs;                  /* batch capacity */
+    float   bf, b;                      /* Frame::mbf, Frame::mb */
+    int32_t device_id;
+} ivf_frontend_config;
+
+int  ivf_frontend_create(const ivf_frontend_config* cfg, ivf_frontend** out);
+void ivf_frontend_destroy(ivf_frontend* fe);
+/* Enqueue one batch on `hip_stream` (a hipStream_t, NULL = default stream); asynchronous.
+ * d_left/d_right: device pointers to n_pairs grey images, image i at base + i*image_stride, rows of row_stride bytes.
+ * d_cost: device pointer to n_pairs u8 cost maps (same layout) or NULL. */
+int  ivf_frontend_run(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_right, const uint8_t* d_cost,
+                      size_t image_stride, int row_stride, int n_pairs, void* hip_stream);
+/* Block until the last ivf_frontend_run on this handle has finished. */
+int  ivf_frontend_sync(ivf_frontend* fe);
+/* Device-resident results of the last run (valid until the next run).  side 0 = left, 1 = right.
+ * d_kps: [max_pairs][cap] ivf_keypoint, d_desc: [max_pairs][cap][32], d_count: [max_pairs] int32, cap = nfeatures;
+ * d_uright/d_depth/d_quality: [max_pairs][cap] float (left only).  Any out pointer may be NULL. */
+int  ivf_frontend_device_results(const ivf_frontend* fe, int side, const ivf_keypoint** d_kps, const uint8_t** d_desc,
+                                 const int32_t** d_count, const float** d_uright, const float** d_depth,
+                                 const float** d_quality, int* cap);
+/* Copy one pair's results to host (synchronises).  uright/depth/quality are left-only and may be NULL. */
+int  ivf_frontend_fetch(ivf_frontend* fe, int pair, int side, ivf_keypoint* kps, uint8_t* desc, int cap, int* n_out,
+                        float* uright, float* depth, float* quality);
+/* Elapsed milliseconds of the dominant kernel (FAST score + NMS) in the last run, from HIP events
+ * recorded on the run's stream around that launch (bench.py's roofline leg); <0 if unavailable. */
+float ivf_frontend_last_fast_ms(ivf_frontend* fe);
+/* Pack this rank's results of the last run for a descriptor all-gather: writes into d_block (device)
+ * n_pairs fixed-size records {int32 n; int32 pad[3]; ivf_keypoint kps[cap]; uint8 desc[cap][32]; float uright[cap]}
+ * and returns the record size in *record_bytes. */
+int  ivf_frontend_pack_gather_block(ivf_frontend* fe, uint8_t* d_block, size_t block_bytes, size_t* record_bytes,
+                                    void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IVFRONT_H */

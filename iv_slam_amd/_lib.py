@@ -1,0 +1,97 @@
+"""ctypes binding of libivfront.so (include/ivfront.h).  There is no Python/CPU fallback: if the HIP
+library is missing or no GPU is usable, calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libivfront.so")
+
+IVF_OK, IVF_E_INVALID, IVF_E_CAPACITY, IVF_E_GEOMETRY, IVF_E_NO_DEVICE, IVF_E_STATE = 0, -1, -2, -3, -4, -5
+MAX_LEVELS = 16
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4")])
+
+
+class ExtractorParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("enable_introspection", C.c_int32)]
+
+
+class Bounds(C.Structure):
+    _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float)]
+
+
+class FrontendConfig(C.Structure):
+    _fields_ = [("left", ExtractorParams), ("right", ExtractorParams), ("width", C.c_int32), ("height", C.c_int32),
+                ("max_pairs", C.c_int32), ("bf", C.c_float), ("b", C.c_float), ("device_id", C.c_int32)]
+
+
+class IvfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ivfront error %d: %s" % (code, msg))
+        self.code = code
+
+
+vp = C.c_void_p
+_SIGS = {
+    "ivf_version": (C.c_int, []),
+    "ivf_last_error": (C.c_char_p, []),
+    "ivf_device_count": (C.c_int, []),
+    "ivf_extractor_create": (C.c_int, [C.POINTER(ExtractorParams), C.c_int, C.POINTER(vp)]),
+    "ivf_extractor_destroy": (None, [vp]),
+    "ivf_extractor_get_levels": (C.c_int, [vp]),
+    "ivf_extractor_get_scale_factor": (C.c_float, [vp]),
+    "ivf_extractor_get_scale_tables": (C.c_int, [vp, vp, vp, vp, vp]),
+    "ivf_extractor_get_feature_tables": (C.c_int, [vp, vp, vp]),
+    "ivf_extract": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]),
+    "ivf_extractor_pyramid_level": (C.c_int, [vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ivf_extractor_quality_level": (C.c_int, [vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ivf_extractor_level_counts": (C.c_int, [vp, vp]),
+    "ivf_stereo_match": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_float, C.c_float, vp, vp]),
+    "ivf_hamming": (C.c_int, [vp, vp]),
+    "ivf_hamming_pairs": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int]),
+    "ivf_features_in_area": (C.c_int, [vp, C.c_int, C.POINTER(Bounds), C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                       vp, C.c_int, C.POINTER(C.c_int)]),
+    "ivf_search_by_projection": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
+                                           vp, vp, C.c_int, vp, C.POINTER(C.c_int), C.c_int]),
+    "ivf_frontend_create": (C.c_int, [C.POINTER(FrontendConfig), C.POINTER(vp)]),
+    "ivf_frontend_destroy": (None, [vp]),
+    "ivf_frontend_run": (C.c_int, [vp, vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]),
+    "ivf_frontend_sync": (C.c_int, [vp]),
+    "ivf_frontend_device_results": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                              C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]),
+    "ivf_frontend_fetch": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int), vp, vp, vp]),
+    "ivf_frontend_last_fast_ms": (C.c_float, [vp]),
+    "ivf_frontend_pack_gather_block": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib = None
+
+
+def load():
+    """Load libivfront.so; raises (never falls back) when the HIP extension is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libivfront.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(make -C iv_slam_amd/csrc).  There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != IVF_OK:
+        raise IvfError(rc, load().ivf_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a):
+    return a.ctypes.data_as(vp) if a is not None else None

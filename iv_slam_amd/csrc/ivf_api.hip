@@ -1,0 +1,784 @@
+// ivf_api.hip -- C-ABI of libivfront.so (include/ivfront.h): handles, geometry, launch orchestration.
+// Host side only; all image / descriptor compute is in ivf_kernels.hip.  No CPU fallback exists.
+#include "ivf_device.h"
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+using namespace ivf;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                                   \
+    do { hipError_t e_ = (expr);                                                                        \
+         if (e_ != hipSuccess) return fail(IVF_E_NO_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+inline int cvRoundF(float v) { return (int)lrintf(v); }
+inline int cvFloorF(float v) { int i = (int)v; return i - (i > v); }
+inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// ---- ORBextractor constructor tables (ORB/src/ORBextractor.cc:411-476) ----
+struct Tables {
+    ivf_extractor_params p;
+    float scale[kMaxLevels], invScale[kMaxLevels], sigma2[kMaxLevels], invSigma2[kMaxLevels];
+    int nfeat[kMaxLevels];
+    int umax[16];
+};
+int make_tables(const ivf_extractor_params& p, Tables& t)
+{
+    if (p.nlevels < 1 || p.nlevels > kMaxLevels) return fail(IVF_E_INVALID, "nlevels %d outside [1,%d]", p.nlevels, kMaxLevels);
+    if (p.nfeatures < 1 || p.nfeatures > 65534) return fail(IVF_E_INVALID, "nfeatures %d outside [1,65534]", p.nfeatures);
+    if (!(p.scale_factor > 1.0f)) return fail(IVF_E_INVALID, "scale_factor must be > 1");
+    if (p.min_th_fast < 1 || p.ini_th_fast < p.min_th_fast || p.ini_th_fast > 254)
+        return fail(IVF_E_INVALID, "need 1 <= minThFAST <= iniThFAST <= 254");
+    t.p = p;
+    const double sf = (double)p.scale_factor;            // member is `double scaleFactor` (ORBextractor.h:110)
+    t.scale[0] = 1.0f; t.sigma2[0] = 1.0f;
+    for (int i = 1; i < p.nlevels; i++) {
+        t.scale[i] = (float)((double)t.scale[i - 1] * sf);
+        t.sigma2[i] = t.scale[i] * t.scale[i];
+    }
+    for (int i = 0; i < p.nlevels; i++) { t.invScale[i] = 1.0f / t.scale[i]; t.invSigma2[i] = 1.0f / t.sigma2[i]; }
+    const float factor = (float)(1.0 / sf);
+    float nDes = (float)p.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)p.nlevels));
+    int sum = 0;
+    for (int l = 0; l < p.nlevels - 1; l++) { t.nfeat[l] = cvRoundF(nDes); sum += t.nfeat[l]; nDes *= factor; }
+    t.nfeat[p.nlevels - 1] = std::max(p.nfeatures - sum, 0);
+    const int HP = 15;
+    int v, v0;
+    const int vmax = (int)std::floor(HP * std::sqrt(2.f) / 2 + 1), vmin = (int)std::ceil(HP * std::sqrt(2.f) / 2);
+    const double hp2 = HP * HP;
+    for (v = 0; v <= vmax; ++v) t.umax[v] = (int)lrint(std::sqrt(hp2 - v * v));
+    for (v = HP, v0 = 0; v >= vmin; --v) {
+        while (t.umax[v0] == t.umax[v0 + 1]) ++v0;
+        t.umax[v] = v0;
+        ++v0;
+    }
+    return IVF_OK;
+}
+
+// ---- one batch context: geometry + device buffers for a fixed (params, image size, capacity) ----
+struct Context {
+    int device = 0, maxImg = 0, nSides = 1;
+    bool introspection = false;
+    Config hc{};
+    Config* dc = nullptr;
+    ResizeTab rtab[kMaxLevels]{};
+    int* dI32 = nullptr; short* dI16 = nullptr;
+    Buffers b{};
+    uint8_t* dStage = nullptr;          // single-image host API staging (image + cost)
+    size_t stageBytes = 0;
+    hipEvent_t evFast0 = nullptr, evFast1 = nullptr;
+    bool evValid = false;
+    hipStream_t lastStream = nullptr;
+
+    int build(const Tables& t, int w, int h, int maxImages, int sides, int dev, bool withStereo);
+    void release();
+    int run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size_t imageStride, int rowStride,
+            size_t costStride, int costRowStride, int nImg, const uint8_t* hUseCost, hipStream_t st);
+    int check_status();
+};
+
+int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int dev, bool withStereo)
+{
+    device = dev; maxImg = maxImages; nSides = sides;
+    introspection = t.p.enable_introspection != 0;
+    if (w < 1 || h < 1 || w > 65535 || h > 65535) return fail(IVF_E_INVALID, "image size %dx%d unsupported", w, h);
+    Config& c = hc;
+    memset(&c, 0, sizeof c);
+    c.nlevels = t.p.nlevels; c.w = w; c.h = h; c.nfeatures = t.p.nfeatures;
+    c.iniTh = t.p.ini_th_fast; c.minTh = t.p.min_th_fast; c.introspection = introspection ? 1 : 0;
+    memcpy(c.umax, t.umax, sizeof c.umax);
+    const float imageRatio = (float)w / h;                       // ORBextractor.cc:884
+    int off = 0, cellBase = 0, candBase = 0, kpBase = 0, tileBase = 0, btileBase = 0;
+    for (int l = 0; l < c.nlevels; l++) {
+        LevelGeom& G = c.lv[l];
+        c.scale[l] = t.scale[l]; c.invScale[l] = t.invScale[l];
+        G.scale = t.scale[l];
+        G.w = cvRoundF((float)w * t.invScale[l]);                 // :1303
+        G.h = cvRoundF((float)h * t.invScale[l]);
+        if (G.w < 1 || G.h < 1) return fail(IVF_E_GEOMETRY, "pyramid level %d is empty for %dx%d", l, w, h);
+        G.pitch = align_up(G.w, 64);
+        G.off = off; off += G.pitch * G.h;
+        G.nDesired = t.nfeat[l];
+        G.kpBase = kpBase; kpBase += G.nDesired;
+        G.scaledPatch = (int)(31 * t.scale[l]);                   // :1142
+        G.cols = (int)std::sqrt((float)G.nDesired / (5 * imageRatio));   // :890
+        G.rows = (int)(imageRatio * G.cols);                      // :891
+        G.maxBX = G.w - kEdge; G.maxBY = G.h - kEdge;
+        const int W = G.maxBX - kEdge, H = G.maxBY - kEdge;
+        G.valid = (G.cols > 0 && G.rows > 0 && W > 0 && H > 0 && G.nDesired > 0) ? 1 : 0;
+        G.btileBase = btileBase; G.btilesX = (G.w + kBlurTW - 1) / kBlurTW; G.btilesY = (G.h + kBlurTH - 1) / kBlurTH;
+        btileBase += G.btilesX * G.btilesY;
+        G.cellBase = cellBase; G.candBase = candBase; G.tileBase = tileBase;
+        if (!G.valid) continue;
+        G.cellW = (int)std::ceil((float)W / G.cols);              // :906-907
+        G.cellH = (int)std::ceil((float)H / G.rows);
+        G.nCells = G.rows * G.cols;
+        if (G.nCells > kMaxCells) return fail(IVF_E_INVALID, "level %d has %d cells (max %d)", l, G.nCells, kMaxCells);
+        G.nfeaturesCell = (int)std::ceil((float)G.nDesired / G.nCells);   // :923
+        // cell windows must stay inside [16, dim-16): otherwise the reference throws in rowRange/colRange
+        // or reads outside the blurred clone (ORBextractor.cc:1033, 1276)
+        if ((G.cols - 1) * G.cellW > W || (G.rows - 1) * G.cellH > H)
+            return fail(IVF_E_GEOMETRY, "level %d: %dx%d cells of %dx%d leave the %dx%d level", l, G.cols, G.rows,
+                        G.cellW, G.cellH, G.w, G.h);
+        G.domHLast = H - (G.rows - 1) * G.cellH;
+        G.winHLast = G.domHLast + 6;
+        G.domH[0] = G.cellH;
+        G.domH[1] = G.domHLast;                                   // stale hY
+        G.candCap = ((G.cellW + 1) / 2) * ((G.cellH + 1) / 2) + 1;
+        cellBase += G.nCells; candBase += G.nCells * G.candCap;
+        G.tilesX = (G.maxBX - 16 + kFastTW - 1) / kFastTW;
+        G.tilesY = (G.maxBY - kEdge + kFastTH - 1) / kFastTH;
+        tileBase += G.tilesX * G.tilesY;
+    }
+    c.pyrBytes = align_up(off + 64, 256);
+    c.candTotal = std::max(candBase, 1);
+    c.nTiles = tileBase;
+    c.nBlurTiles = btileBase;
+
+    // cv::resize coefficient tables (OpenCV resize.cpp, INTER_LINEAR 8U): see oracle/ DESIGN.md A-3
+    std::vector<int> i32; std::vector<short> i16;
+    auto sat = [](float v) { int i = cvRoundF(v); return (short)std::min(32767, std::max(-32768, i)); };
+    for (int l = 1; l < c.nlevels; l++) {
+        const LevelGeom &D = c.lv[l], &S = c.lv[l - 1];
+        const double sx_ = (double)S.w / D.w, sy_ = (double)S.h / D.h;
+        ResizeTab& r = rtab[l];
+        r.xofs = (int)i32.size();
+        for (int dx = 0; dx < D.w; dx++) {
+            float fx = (float)((dx + 0.5) * sx_ - 0.5);
+            int sx = cvFloorF(fx);
+            if (sx < 0) sx = 0;
+            if (sx >= S.w - 1) sx = S.w - 1;
+            i32.push_back(sx);
+        }
+        r.yofs = (int)i32.size();
+        for (int dy = 0; dy < D.h; dy++) { float fy = (float)((dy + 0.5) * sy_ - 0.5); i32.push_back(cvFloorF(fy)); }
+        r.a0 = (int)i16.size();
+        std::vector<short> a1v, b0v, b1v;
+        for (int dx = 0; dx < D.w; dx++) {
+            float fx = (float)((dx + 0.5) * sx_ - 0.5);
+            int sx = cvFloorF(fx);
+            fx -= sx;
+            if (sx < 0) { fx = 0; sx = 0; }
+            if (sx >= S.w - 1) { fx = 0; sx = S.w - 1; }
+            i16.push_back(sat((1.f - fx) * 2048.f));
+            a1v.push_back(sat(fx * 2048.f));
+        }
+        r.a1 = (int)i16.size(); i16.insert(i16.end(), a1v.begin(), a1v.end());
+        for (int dy = 0; dy < D.h; dy++) {
+            float fy = (float)((dy + 0.5) * sy_ - 0.5);
+            int sy = cvFloorF(fy);
+            fy -= sy;
+            b0v.push_back(sat((1.f - fy) * 2048.f));
+            b1v.push_back(sat(fy * 2048.f));
+        }
+        r.b0 = (int)i16.size(); i16.insert(i16.end(), b0v.begin(), b0v.end());
+        r.b1 = (int)i16.size(); i16.insert(i16.end(), b1v.begin(), b1v.end());
+    }
+    if (i32.empty()) i32.push_back(0);
+    if (i16.empty()) i16.push_back(0);
+
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMalloc(&dc, sizeof(Config)));
+    HIPCHK(hipMemcpy(dc, &hc, sizeof(Config), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&dI32, i32.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(dI32, i32.data(), i32.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&dI16, i16.size() * sizeof(short)));
+    HIPCHK(hipMemcpy(dI16, i16.data(), i16.size() * sizeof(short), hipMemcpyHostToDevice));
+    const size_t nI = (size_t)maxImg, nf = (size_t)c.nfeatures, blob = (size_t)c.pyrBytes * nI;
+    HIPCHK(hipMalloc(&b.pyr, blob));
+    HIPCHK(hipMalloc(&b.blur, blob));
+    HIPCHK(hipMalloc(&b.nms, blob));
+    HIPCHK(hipMemset(b.pyr, 0, blob));
+    HIPCHK(hipMemset(b.nms, 0, blob));
+    if (introspection) { HIPCHK(hipMalloc(&b.qpyr, blob)); HIPCHK(hipMemset(b.qpyr, 0, blob)); }
+    HIPCHK(hipMalloc(&b.cand, nI * c.candTotal * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&b.lvl, nI * c.candTotal * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&b.slotPos, nI * nf * sizeof(unsigned)));
+    HIPCHK(hipMalloc(&b.slotResp, nI * nf * sizeof(float)));
+    HIPCHK(hipMalloc(&b.lvlCount, nI * kMaxLevels * sizeof(int)));
+    HIPCHK(hipMemset(b.lvlCount, 0, nI * kMaxLevels * sizeof(int)));
+    HIPCHK(hipMalloc(&b.useCost, nI));
+    HIPCHK(hipMemset(b.useCost, 0, nI));
+    HIPCHK(hipMalloc(&b.kps, nI * nf * sizeof(ivf_keypoint)));
+    HIPCHK(hipMalloc(&b.desc, nI * nf * 32));
+    HIPCHK(hipMalloc(&b.count, nI * sizeof(int)));
+    HIPCHK(hipMemset(b.count, 0, nI * sizeof(int)));
+    HIPCHK(hipMalloc(&b.quality, nI * nf * sizeof(float)));
+    if (withStereo) {
+        const size_t nP = std::max<size_t>(nI / 2, 1);
+        HIPCHK(hipMalloc(&b.uright, nP * nf * sizeof(float)));
+        HIPCHK(hipMalloc(&b.depth, nP * nf * sizeof(float)));
+        HIPCHK(hipMalloc(&b.sad, nP * nf * sizeof(int)));
+    }
+    HIPCHK(hipMalloc(&b.status, sizeof(int)));
+    HIPCHK(hipMemset(b.status, 0, sizeof(int)));
+    HIPCHK(hipEventCreate(&evFast0));
+    HIPCHK(hipEventCreate(&evFast1));
+    return IVF_OK;
+}
+
+void Context::release()
+{
+    (void)hipSetDevice(device);
+    void* ptrs[] = {dc, dI32, dI16, b.pyr, b.qpyr, b.blur, b.nms, b.cand, b.lvl, b.slotPos, b.slotResp, b.lvlCount,
+                    b.useCost, b.kps, b.desc, b.count, b.quality, b.uright, b.depth, b.sad, b.status, dStage};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (evFast0) (void)hipEventDestroy(evFast0);
+    if (evFast1) (void)hipEventDestroy(evFast1);
+    *this = Context();
+}
+
+// Enqueue ORBextractor::operator() for nImg images (ORB/src/ORBextractor.cc:1224-1296)
+int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size_t imageStride, int rowStride,
+                 size_t costStride, int costRowStride, int nImg, const uint8_t* dUseCostSrc, hipStream_t st)
+{
+    if (nImg < 1 || nImg > maxImg) return fail(IVF_E_INVALID, "batch of %d images outside [1,%d]", nImg, maxImg);
+    HIPCHK(hipSetDevice(device));
+    lastStream = st;
+    const bool useQ = introspection && cost != nullptr;
+    if (useQ) HIPCHK(hipMemcpyAsync(b.useCost, dUseCostSrc, nImg, hipMemcpyDeviceToDevice, st));
+    else HIPCHK(hipMemsetAsync(b.useCost, 0, nImg, st));
+    launch_ingest(hc, dc, b, s0, s1, imageStride, rowStride, nImg, nSides, b.pyr, st);
+    launch_pyramid(hc, dc, rtab, dI32, dI16, b.pyr, nImg, st);
+    if (useQ) {                                                   // ComputeQualityImagePyramid :1325-1357
+        launch_ingest(hc, dc, b, cost, cost, costStride, costRowStride, nImg, nSides, b.qpyr, st);
+        launch_pyramid(hc, dc, rtab, dI32, dI16, b.qpyr, nImg, st);
+    }
+    HIPCHK(hipEventRecord(evFast0, st));
+    launch_fast(hc, dc, b, nImg, st);
+    HIPCHK(hipEventRecord(evFast1, st));
+    evValid = true;
+    launch_select(hc, dc, b, nImg, st);
+    launch_blur(hc, dc, b, nImg, st);
+    launch_describe(hc, dc, b, nullptr, 0, 0, nImg, nSides, st);
+    HIPCHK(hipGetLastError());
+    return IVF_OK;
+}
+
+int Context::check_status()
+{
+    int s = 0;
+    HIPCHK(hipMemcpy(&s, b.status, sizeof(int), hipMemcpyDeviceToHost));
+    if (s) return fail(IVF_E_STATE, "device-side consistency check failed (flags 0x%x)", s);
+    return IVF_OK;
+}
+
+int have_device(int dev)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(IVF_E_NO_DEVICE, "no HIP device available (%s); libivfront has no CPU path",
+                                               e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    if (dev < 0 || dev >= n) return fail(IVF_E_INVALID, "device_id %d outside [0,%d)", dev, n);
+    return IVF_OK;
+}
+
+}  // namespace
+
+struct ivf_extractor {
+    Tables t;
+    int device;
+    Context ctx;
+    bool haveCtx = false;
+    int w = 0, h = 0;
+    bool lastHadCost = false, extracted = false;
+    uint8_t* dOne = nullptr;            // device byte "1"
+};
+
+struct ivf_frontend {
+    ivf_frontend_config cfg;
+    Tables tl;
+    Context ctx;
+    uint8_t* dFlags = nullptr;          // useCost flags when a cost batch is given: [L,R,L,R,...]
+    int lastPairs = 0;
+    hipStream_t lastStream = nullptr;
+};
+
+// ---- Frame grid (ORB/src/Frame.cc:415-430, 615-680; 64 x 48, Frame.h:43-44) ----
+namespace {
+constexpr int GC = 64, GR = 48;
+struct Grid {
+    std::vector<int> start, idx; float invW, invH;
+    void build(const ivf_keypoint* k, int n, const ivf_bounds& bd)
+    {
+        invW = (float)GC / (bd.max_x - bd.min_x); invH = (float)GR / (bd.max_y - bd.min_y);
+        start.assign(GC * GR + 1, 0); idx.assign(std::max(n, 1), 0);
+        std::vector<int> cell(std::max(n, 1), -1);
+        for (int i = 0; i < n; i++) {
+            const int px = (int)roundf((k[i].x - bd.min_x) * invW), py = (int)roundf((k[i].y - bd.min_y) * invH);
+            if (px < 0 || px >= GC || py < 0 || py >= GR) continue;
+            cell[i] = px * GR + py; start[cell[i] + 1]++;
+        }
+        for (int c = 0; c < GC * GR; c++) start[c + 1] += start[c];
+        std::vector<int> fill(GC * GR, 0);
+        for (int i = 0; i < n; i++) if (cell[i] >= 0) idx[start[cell[i]] + fill[cell[i]]++] = i;
+    }
+    template <class F> void query(const ivf_keypoint* k, const ivf_bounds& bd, float x, float y, float r, int minL, int maxL, F f) const
+    {
+        const int x0 = std::max(0, (int)floorf((x - bd.min_x - r) * invW)); if (x0 >= GC) return;
+        const int x1 = std::min(GC - 1, (int)ceilf((x - bd.min_x + r) * invW)); if (x1 < 0) return;
+        const int y0 = std::max(0, (int)floorf((y - bd.min_y - r) * invH)); if (y0 >= GR) return;
+        const int y1 = std::min(GR - 1, (int)ceilf((y - bd.min_y + r) * invH)); if (y1 < 0) return;
+        const bool chk = (minL > 0) || (maxL >= 0);
+        for (int ix = x0; ix <= x1; ix++)
+            for (int iy = y0; iy <= y1; iy++) {
+                const int c = ix * GR + iy;
+                for (int j = start[c]; j < start[c + 1]; j++) {
+                    const ivf_keypoint& kp = k[idx[j]];
+                    if (chk) { if (kp.octave < minL) continue; if (maxL >= 0 && kp.octave > maxL) continue; }
+                    if (fabsf(kp.x - x) < r && fabsf(kp.y - y) < r) f(idx[j]);
+                }
+            }
+    }
+};
+}  // namespace
+
+extern "C" {
+
+int ivf_version(void) { return 100; }
+const char* ivf_last_error(void) { return g_err.c_str(); }
+int ivf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ivf_extractor_create(const ivf_extractor_params* params, int device_id, ivf_extractor** out)
+{
+    if (!params || !out) return fail(IVF_E_INVALID, "null argument");
+    *out = nullptr;
+    Tables t;
+    int rc = make_tables(*params, t);
+    if (rc) return rc;
+    rc = have_device(device_id);
+    if (rc) return rc;
+    ivf_extractor* e = new ivf_extractor();
+    e->t = t; e->device = device_id;
+    *out = e;
+    return IVF_OK;
+}
+
+void ivf_extractor_destroy(ivf_extractor* e)
+{
+    if (!e) return;
+    if (e->haveCtx) e->ctx.release();
+    if (e->dOne) (void)hipFree(e->dOne);
+    delete e;
+}
+
+int ivf_extractor_get_levels(const ivf_extractor* e) { return e ? e->t.p.nlevels : fail(IVF_E_INVALID, "null handle"); }
+float ivf_extractor_get_scale_factor(const ivf_extractor* e) { return e ? e->t.p.scale_factor : 0.f; }
+
+int ivf_extractor_get_scale_tables(const ivf_extractor* e, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2)
+{
+    if (!e) return fail(IVF_E_INVALID, "null handle");
+    const int n = e->t.p.nlevels;
+    if (scale) memcpy(scale, e->t.scale, n * sizeof(float));
+    if (inv_scale) memcpy(inv_scale, e->t.invScale, n * sizeof(float));
+    if (sigma2) memcpy(sigma2, e->t.sigma2, n * sizeof(float));
+    if (inv_sigma2) memcpy(inv_sigma2, e->t.invSigma2, n * sizeof(float));
+    return IVF_OK;
+}
+
+int ivf_extractor_get_feature_tables(const ivf_extractor* e, int32_t* features_per_level, int32_t* umax16)
+{
+    if (!e) return fail(IVF_E_INVALID, "null handle");
+    if (features_per_level) memcpy(features_per_level, e->t.nfeat, e->t.p.nlevels * sizeof(int));
+    if (umax16) memcpy(umax16, e->t.umax, 16 * sizeof(int));
+    return IVF_OK;
+}
+
+int ivf_extract(ivf_extractor* e, const uint8_t* image, int width, int height, int stride,
+                const uint8_t* cost, int cost_stride, ivf_keypoint* kps, uint8_t* desc, int cap, int* n_out)
+{
+    if (!e || !n_out) return fail(IVF_E_INVALID, "null argument");
+    *n_out = 0;
+    if (!image || width <= 0 || height <= 0) return IVF_OK;      // empty image: silent return (:1227-1228)
+    if (stride < width || (cost && cost_stride < width)) return fail(IVF_E_INVALID, "stride smaller than width");
+    int rc = have_device(e->device);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->haveCtx || e->w != width || e->h != height) {
+        if (e->haveCtx) { e->ctx.release(); e->haveCtx = false; }
+        rc = e->ctx.build(e->t, width, height, 1, 1, e->device, true);
+        if (rc) { e->ctx.release(); return rc; }
+        e->haveCtx = true; e->w = width; e->h = height;
+        e->ctx.stageBytes = (size_t)width * height * 2;
+        HIPCHK(hipMalloc(&e->ctx.dStage, e->ctx.stageBytes));
+        if (!e->dOne) { HIPCHK(hipMalloc(&e->dOne, 1)); HIPCHK(hipMemset(e->dOne, 1, 1)); }
+    }
+    e->extracted = false;
+    Context& c = e->ctx;
+    uint8_t* dImg = c.dStage;
+    uint8_t* dCost = c.dStage + (size_t)width * height;
+    HIPCHK(hipMemcpy2D(dImg, width, image, stride, width, height, hipMemcpyHostToDevice));
+    const bool useCost = cost && e->t.p.enable_introspection;
+    if (useCost) HIPCHK(hipMemcpy2D(dCost, width, cost, cost_stride, width, height, hipMemcpyHostToDevice));
+    rc = c.run(dImg, dImg, useCost ? dCost : nullptr, (size_t)width * height, width, (size_t)width * height, width, 1,
+               e->dOne, nullptr);
+    if (rc) return rc;
+    int n = 0;
+    HIPCHK(hipMemcpy(&n, c.b.count, sizeof(int), hipMemcpyDeviceToHost));
+    rc = c.check_status();
+    if (rc) return rc;
+    e->lastHadCost = useCost; e->extracted = true;
+    if (n > cap) { *n_out = n; return fail(IVF_E_CAPACITY, "%d keypoints exceed caller capacity %d", n, cap); }
+    if (n > 0) {
+        if (!kps || !desc) return fail(IVF_E_INVALID, "null output buffers");
+        HIPCHK(hipMemcpy(kps, c.b.kps, (size_t)n * sizeof(ivf_keypoint), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(desc, c.b.desc, (size_t)n * 32, hipMemcpyDeviceToHost));
+    }
+    *n_out = n;
+    return IVF_OK;
+}
+
+static int copy_level(const ivf_extractor* e, const uint8_t* blob, int level, uint8_t* dst, int dst_stride, int* width, int* height)
+{
+    if (!e || !e->extracted || !blob) return fail(IVF_E_STATE, "no pyramid: call ivf_extract first");
+    if (level < 0 || level >= e->t.p.nlevels) return fail(IVF_E_INVALID, "level %d out of range", level);
+    const LevelGeom& G = e->ctx.hc.lv[level];
+    if (width) *width = G.w;
+    if (height) *height = G.h;
+    if (!dst) return IVF_OK;
+    if (dst_stride < G.w) return fail(IVF_E_INVALID, "dst_stride smaller than level width");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpy2D(dst, dst_stride, blob + G.off, G.pitch, G.w, G.h, hipMemcpyDeviceToHost));
+    return IVF_OK;
+}
+int ivf_extractor_pyramid_level(const ivf_extractor* e, int level, uint8_t* dst, int dst_stride, int* width, int* height)
+{
+    return copy_level(e, e ? e->ctx.b.pyr : nullptr, level, dst, dst_stride, width, height);
+}
+int ivf_extractor_quality_level(const ivf_extractor* e, int level, uint8_t* dst, int dst_stride, int* width, int* height)
+{
+    if (e && !e->lastHadCost) return fail(IVF_E_STATE, "last extract had no cost map");
+    return copy_level(e, e ? e->ctx.b.qpyr : nullptr, level, dst, dst_stride, width, height);
+}
+int ivf_extractor_level_counts(const ivf_extractor* e, int32_t* counts)
+{
+    if (!e || !counts) return fail(IVF_E_INVALID, "null argument");
+    if (!e->extracted) return fail(IVF_E_STATE, "call ivf_extract first");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpy(counts, e->ctx.b.lvlCount, e->t.p.nlevels * sizeof(int), hipMemcpyDeviceToHost));
+    return IVF_OK;
+}
+
+int ivf_stereo_match(const ivf_extractor* left, const ivf_extractor* right,
+                     const ivf_keypoint* kps_left, int n_left, const uint8_t* desc_left,
+                     const ivf_keypoint* kps_right, int n_right, const uint8_t* desc_right,
+                     float bf, float b, float* u_right, float* depth)
+{
+    if (!left || !right || !u_right || !depth || n_left < 0 || n_right < 0) return fail(IVF_E_INVALID, "bad argument");
+    if (!left->extracted || !right->extracted) return fail(IVF_E_STATE, "both extractors must have run ivf_extract");
+    if (left->device != right->device) return fail(IVF_E_INVALID, "extractors live on different devices");
+    if (left->w != right->w || left->h != right->h || left->t.p.nlevels != right->t.p.nlevels)
+        return fail(IVF_E_INVALID, "left/right geometry differs");
+    const int nf = left->t.p.nfeatures;
+    if (n_left > nf || n_right > 65534) return fail(IVF_E_CAPACITY, "too many keypoints");
+    if (n_left == 0) return IVF_OK;
+    HIPCHK(hipSetDevice(left->device));
+    // caller-provided keypoints / descriptors are the matcher's inputs (mvKeys, mvDescriptors): upload them
+    ivf_keypoint *dKL = nullptr, *dKR = nullptr; uint8_t *dDL = nullptr, *dDR = nullptr; int* dCnt = nullptr;
+    const size_t nR = (size_t)std::max(n_right, 1);
+    HIPCHK(hipMalloc(&dKL, (size_t)nf * sizeof(ivf_keypoint)));
+    HIPCHK(hipMalloc(&dKR, nR * sizeof(ivf_keypoint)));
+    HIPCHK(hipMalloc(&dDL, (size_t)nf * 32));
+    HIPCHK(hipMalloc(&dDR, nR * 32));
+    HIPCHK(hipMalloc(&dCnt, 2 * sizeof(int)));
+    HIPCHK(hipMemcpy(dKL, kps_left, (size_t)n_left * sizeof(ivf_keypoint), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dDL, desc_left, (size_t)n_left * 32, hipMemcpyHostToDevice));
+    if (n_right) {
+        HIPCHK(hipMemcpy(dKR, kps_right, (size_t)n_right * sizeof(ivf_keypoint), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dDR, desc_right, (size_t)n_right * 32, hipMemcpyHostToDevice));
+    }
+    const int cnt[2] = {n_left, n_right};
+    HIPCHK(hipMemcpy(dCnt, cnt, sizeof cnt, hipMemcpyHostToDevice));
+    const Context& cl = left->ctx;
+    StereoArgs A;
+    A.pyrL = cl.b.pyr; A.pyrR = right->ctx.b.pyr; A.pyrStride = 0;
+    A.kpL = dKL; A.kpR = dKR; A.descL = dDL; A.descR = dDR; A.cntL = dCnt; A.cntR = dCnt + 1;
+    A.kpStride = 0; A.cntStride = 0;
+    A.uright = cl.b.uright; A.depth = cl.b.depth; A.sad = cl.b.sad; A.outStride = nf;
+    A.bf = bf; A.bb = b;
+    launch_stereo_args(cl.hc, cl.dc, A, 1, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(u_right, cl.b.uright, (size_t)n_left * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(depth, cl.b.depth, (size_t)n_left * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(dKL); (void)hipFree(dKR); (void)hipFree(dDL); (void)hipFree(dDR); (void)hipFree(dCnt);
+    return IVF_OK;
+}
+
+int ivf_hamming(const uint8_t* a, const uint8_t* b)
+{
+    int d = 0;
+    for (int i = 0; i < 32; i++) d += __builtin_popcount((unsigned)(a[i] ^ b[i]));
+    return d;
+}
+
+int ivf_hamming_pairs(const uint8_t* desc_a, int n_a, const uint8_t* desc_b, int n_b,
+                      const int32_t* pairs, int n_pairs, int32_t* dist, int device_id)
+{
+    if (n_pairs == 0) return IVF_OK;
+    if (!desc_a || !desc_b || !pairs || !dist || n_a < 1 || n_b < 1 || n_pairs < 0) return fail(IVF_E_INVALID, "bad argument");
+    for (int i = 0; i < n_pairs; i++)
+        if (pairs[2 * i] < 0 || pairs[2 * i] >= n_a || pairs[2 * i + 1] < 0 || pairs[2 * i + 1] >= n_b)
+            return fail(IVF_E_INVALID, "pair %d indexes outside the descriptor arrays", i);
+    int rc = have_device(device_id);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    uint8_t *dA = nullptr, *dB = nullptr; int *dP = nullptr, *dD = nullptr;
+    HIPCHK(hipMalloc(&dA, (size_t)n_a * 32)); HIPCHK(hipMalloc(&dB, (size_t)n_b * 32));
+    HIPCHK(hipMalloc(&dP, (size_t)n_pairs * 2 * sizeof(int))); HIPCHK(hipMalloc(&dD, (size_t)n_pairs * sizeof(int)));
+    HIPCHK(hipMemcpy(dA, desc_a, (size_t)n_a * 32, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dB, desc_b, (size_t)n_b * 32, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dP, pairs, (size_t)n_pairs * 2 * sizeof(int), hipMemcpyHostToDevice));
+    launch_hamming_pairs(dA, dB, dP, n_pairs, dD, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(dist, dD, (size_t)n_pairs * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dP); (void)hipFree(dD);
+    return IVF_OK;
+}
+
+
+int ivf_features_in_area(const ivf_keypoint* kps, int n, const ivf_bounds* bounds, float x, float y, float r,
+                         int min_level, int max_level, int32_t* out, int cap, int* n_out)
+{
+    if (!kps || !bounds || !n_out || n < 0) return fail(IVF_E_INVALID, "bad argument");
+    Grid g; g.build(kps, n, *bounds);
+    int c = 0;
+    g.query(kps, *bounds, x, y, r, min_level, max_level, [&](int i) { if (out && c < cap) out[c] = i; c++; });
+    *n_out = c;
+    return c > cap ? fail(IVF_E_CAPACITY, "%d indices exceed capacity %d", c, cap) : IVF_OK;
+}
+
+int ivf_search_by_projection(const ivf_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int n_cur,
+                             const ivf_bounds* bounds, int n_q, const float* q_u, const float* q_v, const float* q_ur,
+                             const float* q_radius, const int32_t* q_min_level, const int32_t* q_max_level,
+                             const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid, const uint8_t* q_blocks,
+                             int check_orientation, int32_t* cur_assign, int* nmatches, int device_id)
+{
+    if (!cur_kps || !cur_desc || !cur_uright || !bounds || !cur_assign || !nmatches || n_cur < 0 || n_q < 0)
+        return fail(IVF_E_INVALID, "bad argument");
+    *nmatches = 0;
+    if (n_q == 0 || n_cur == 0) return IVF_OK;
+    if (!q_u || !q_v || !q_ur || !q_radius || !q_min_level || !q_max_level || !q_angle || !q_desc)
+        return fail(IVF_E_INVALID, "null query array");
+    // 1. candidate windows in the reference's GetFeaturesInArea order (:1429-1437)
+    Grid g; g.build(cur_kps, n_cur, *bounds);
+    std::vector<int> qStart(n_q + 1, 0), pairs;
+    for (int i = 0; i < n_q; i++) {
+        qStart[i] = (int)pairs.size() / 2;
+        if (q_valid && !q_valid[i]) continue;
+        g.query(cur_kps, *bounds, q_u[i], q_v[i], q_radius[i], q_min_level[i], q_max_level[i],
+                [&](int i2) { pairs.push_back(i); pairs.push_back(i2); });
+    }
+    qStart[n_q] = (int)pairs.size() / 2;
+    const int nPairs = qStart[n_q];
+    // 2. every window distance on the device (DescriptorDistance :1459-1461)
+    std::vector<int> dist(std::max(nPairs, 1));
+    int rc = ivf_hamming_pairs(q_desc, n_q, cur_desc, n_cur, pairs.data(), nPairs, dist.data(), device_id);
+    if (rc) return rc;
+    // 3. order-dependent greedy assignment + rotation histogram, replayed in query order (:1444-1511)
+    const int HISTO_LENGTH = 30;
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nm = 0;
+    for (int i = 0; i < n_q; i++) {
+        int bestDist = 256, bestIdx2 = -1;
+        for (int p = qStart[i]; p < qStart[i + 1]; p++) {
+            const int i2 = pairs[2 * p + 1];
+            if (cur_assign[i2] == -2) continue;
+            if (cur_assign[i2] >= 0 && (!q_blocks || q_blocks[cur_assign[i2]])) continue;
+            if (cur_uright[i2] > 0) { const float er = fabsf(q_ur[i] - cur_uright[i2]); if (er > q_radius[i]) continue; }
+            if (dist[p] < bestDist) { bestDist = dist[p]; bestIdx2 = i2; }
+        }
+        if (bestIdx2 >= 0 && bestDist <= 100) {
+            cur_assign[bestIdx2] = i; nm++;
+            if (check_orientation) {
+                float rot = q_angle[i] - cur_kps[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_orientation) {                                      // ComputeThreeMaxima :1654-1695
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int s = (int)rotHist[i].size();
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j : rotHist[i]) { cur_assign[j] = -1; nm--; }
+    }
+    *nmatches = nm;
+    return IVF_OK;
+}
+
+// ---- batched stereo front end ----
+int ivf_frontend_create(const ivf_frontend_config* cfg, ivf_frontend** out)
+{
+    if (!cfg || !out) return fail(IVF_E_INVALID, "null argument");
+    *out = nullptr;
+    const ivf_extractor_params &L = cfg->left, &R = cfg->right;
+    if (L.nfeatures != R.nfeatures || L.scale_factor != R.scale_factor || L.nlevels != R.nlevels ||
+        L.ini_th_fast != R.ini_th_fast || L.min_th_fast != R.min_th_fast)
+        return fail(IVF_E_INVALID, "left/right extractor parameters may differ only in enable_introspection");
+    if (cfg->max_pairs < 1) return fail(IVF_E_INVALID, "max_pairs must be >= 1");
+    if (!(cfg->b > 0.f) || !(cfg->bf > 0.f)) return fail(IVF_E_INVALID, "bf and b must be positive");
+    Tables t;
+    ivf_extractor_params p = L;
+    p.enable_introspection = (L.enable_introspection || R.enable_introspection) ? 1 : 0;
+    int rc = make_tables(p, t);
+    if (rc) return rc;
+    rc = have_device(cfg->device_id);
+    if (rc) return rc;
+    ivf_frontend* fe = new ivf_frontend();
+    fe->cfg = *cfg; fe->tl = t;
+    rc = fe->ctx.build(t, cfg->width, cfg->height, 2 * cfg->max_pairs, 2, cfg->device_id, true);
+    if (rc) { fe->ctx.release(); delete fe; return rc; }
+    std::vector<uint8_t> flags(2 * (size_t)cfg->max_pairs);
+    for (int i = 0; i < cfg->max_pairs; i++) { flags[2 * i] = L.enable_introspection ? 1 : 0; flags[2 * i + 1] = R.enable_introspection ? 1 : 0; }
+    if (hipMalloc(&fe->dFlags, flags.size()) != hipSuccess ||
+        hipMemcpy(fe->dFlags, flags.data(), flags.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        fe->ctx.release(); delete fe;
+        return fail(IVF_E_NO_DEVICE, "flag upload failed");
+    }
+    *out = fe;
+    return IVF_OK;
+}
+
+void ivf_frontend_destroy(ivf_frontend* fe)
+{
+    if (!fe) return;
+    (void)hipSetDevice(fe->cfg.device_id);
+    (void)hipDeviceSynchronize();
+    if (fe->dFlags) (void)hipFree(fe->dFlags);
+    fe->ctx.release();
+    delete fe;
+}
+
+int ivf_frontend_run(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_right, const uint8_t* d_cost,
+                     size_t image_stride, int row_stride, int n_pairs, void* hip_stream)
+{
+    if (!fe || !d_left || !d_right) return fail(IVF_E_INVALID, "null argument");
+    if (n_pairs < 1 || n_pairs > fe->cfg.max_pairs) return fail(IVF_E_INVALID, "n_pairs %d outside [1,%d]", n_pairs, fe->cfg.max_pairs);
+    if (row_stride < fe->cfg.width || image_stride < (size_t)row_stride * (fe->cfg.height - 1) + fe->cfg.width)
+        return fail(IVF_E_INVALID, "strides too small for %dx%d", fe->cfg.width, fe->cfg.height);
+    hipStream_t st = (hipStream_t)hip_stream;
+    int rc = fe->ctx.run(d_left, d_right, d_cost, image_stride, row_stride, image_stride, row_stride, 2 * n_pairs,
+                         fe->dFlags, st);
+    if (rc) return rc;
+    launch_stereo(fe->ctx.hc, fe->ctx.dc, fe->ctx.b, n_pairs, fe->cfg.bf, fe->cfg.b, st);
+    HIPCHK(hipGetLastError());
+    fe->lastPairs = n_pairs; fe->lastStream = st;
+    return IVF_OK;
+}
+
+int ivf_frontend_sync(ivf_frontend* fe)
+{
+    if (!fe) return fail(IVF_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(fe->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(fe->lastStream));
+    return fe->ctx.check_status();
+}
+
+int ivf_frontend_device_results(const ivf_frontend* fe, int side, const ivf_keypoint** d_kps, const uint8_t** d_desc,
+                                const int32_t** d_count, const float** d_uright, const float** d_depth,
+                                const float** d_quality, int* cap)
+{
+    if (!fe || side < 0 || side > 1) return fail(IVF_E_INVALID, "bad argument");
+    const Buffers& b = fe->ctx.b;
+    const size_t nf = fe->ctx.hc.nfeatures;
+    // images are interleaved [L0,R0,L1,R1,...]: element stride between pairs is 2*cap
+    if (d_kps) *d_kps = b.kps + side * nf;
+    if (d_desc) *d_desc = b.desc + side * nf * 32;
+    if (d_count) *d_count = b.count + side;
+    if (d_uright) *d_uright = side == 0 ? b.uright : nullptr;
+    if (d_depth) *d_depth = side == 0 ? b.depth : nullptr;
+    if (d_quality) *d_quality = b.quality + side * nf;
+    if (cap) *cap = (int)nf;
+    return IVF_OK;
+}
+
+int ivf_frontend_fetch(ivf_frontend* fe, int pair, int side, ivf_keypoint* kps, uint8_t* desc, int cap, int* n_out,
+                       float* uright, float* depth, float* quality)
+{
+    if (!fe || !n_out || side < 0 || side > 1) return fail(IVF_E_INVALID, "bad argument");
+    if (pair < 0 || pair >= fe->lastPairs) return fail(IVF_E_INVALID, "pair %d outside the last batch of %d", pair, fe->lastPairs);
+    int rc = ivf_frontend_sync(fe);
+    if (rc) return rc;
+    const Buffers& b = fe->ctx.b;
+    const size_t nf = fe->ctx.hc.nfeatures, img = (size_t)pair * 2 + side;
+    int n = 0;
+    HIPCHK(hipMemcpy(&n, b.count + img, sizeof(int), hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (n > cap) return fail(IVF_E_CAPACITY, "%d keypoints exceed caller capacity %d", n, cap);
+    if (n == 0) return IVF_OK;
+    if (kps) HIPCHK(hipMemcpy(kps, b.kps + img * nf, (size_t)n * sizeof(ivf_keypoint), hipMemcpyDeviceToHost));
+    if (desc) HIPCHK(hipMemcpy(desc, b.desc + img * nf * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+    if (quality) HIPCHK(hipMemcpy(quality, b.quality + img * nf, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    if (side == 0) {
+        if (uright) HIPCHK(hipMemcpy(uright, b.uright + (size_t)pair * nf, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+        if (depth) HIPCHK(hipMemcpy(depth, b.depth + (size_t)pair * nf, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return IVF_OK;
+}
+
+float ivf_frontend_last_fast_ms(ivf_frontend* fe)
+{
+    if (!fe || !fe->ctx.evValid) return -1.f;
+    if (hipSetDevice(fe->cfg.device_id) != hipSuccess) return -1.f;
+    if (hipEventSynchronize(fe->ctx.evFast1) != hipSuccess) return -1.f;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, fe->ctx.evFast0, fe->ctx.evFast1) != hipSuccess) return -1.f;
+    return ms;
+}
+
+int ivf_frontend_pack_gather_block(ivf_frontend* fe, uint8_t* d_block, size_t block_bytes, size_t* record_bytes, void* hip_stream)
+{
+    if (!fe || !record_bytes) return fail(IVF_E_INVALID, "null argument");
+    const size_t nf = fe->ctx.hc.nfeatures;
+    const size_t rec = 16 + nf * sizeof(ivf_keypoint) + nf * 32 + nf * sizeof(float);
+    *record_bytes = rec;
+    if (!d_block) return IVF_OK;
+    const int np = fe->lastPairs;
+    if (np < 1) return fail(IVF_E_STATE, "no batch has run");
+    if (block_bytes < rec * np) return fail(IVF_E_CAPACITY, "gather block needs %zu bytes", rec * np);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const Buffers& b = fe->ctx.b;
+    HIPCHK(hipSetDevice(fe->cfg.device_id));
+    HIPCHK(hipMemsetAsync(d_block, 0, rec * np, st));
+    HIPCHK(hipMemcpy2DAsync(d_block, rec, b.count, 2 * sizeof(int), sizeof(int), np, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpy2DAsync(d_block + 16, rec, b.kps, 2 * nf * sizeof(ivf_keypoint), nf * sizeof(ivf_keypoint), np,
+                            hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpy2DAsync(d_block + 16 + nf * sizeof(ivf_keypoint), rec, b.desc, 2 * nf * 32, nf * 32, np,
+                            hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpy2DAsync(d_block + 16 + nf * sizeof(ivf_keypoint) + nf * 32, rec, b.uright, nf * sizeof(float),
+                            nf * sizeof(float), np, hipMemcpyDeviceToDevice, st));
+    return IVF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+// ivf_device.h -- shared host/device structures of the gfx950 front end (not part of the public C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ivfront.h"
+
+namespace ivf {
+
+constexpr int kMaxLevels = IVF_MAX_LEVELS;
+constexpr int kMaxCells = 1024;          // per level (LDS bookkeeping arrays in k_select)
+constexpr int kEdge = 19;                // EDGE_THRESHOLD (ORB/src/ORBextractor.cc:75)
+
+// Geometry of one pyramid level.  All of it depends only on (params, image size), so the host
+// computes it once (ORB/src/ORBextractor.cc:884-922) and the kernels read it as uniform data.
+struct LevelGeom {
+    int w, h, pitch;        // level size; row pitch in bytes (multiple of 64)
+    int off;                // byte offset of the level inside one image's pyramid blob
+    int nDesired;           // mnFeaturesPerLevel[level]
+    int cols, rows, cellW, cellH, nCells, nfeaturesCell;
+    int maxBX, maxBY;       // w-19, h-19
+    int domH[2];            // FAST rows scanned per cell in non-last cell rows: [0] plain, [1] stale-hY (Appendix D-2)
+    int domHLast;           // ... in the last cell row
+    int winHLast;           // hY of the last cell row (cost-map pre-pass window)
+    int cellBase;           // first cell of this level in per-image cell arrays
+    int candBase, candCap;  // candidate scratch: element offset of the level, capacity per cell
+    int kpBase;             // first keypoint slot of this level (prefix sum of nDesired)
+    int scaledPatch;        // (int)(31*scale)
+    int tileBase, tilesX, tilesY;   // FAST tile enumeration (scan region x>=16, y>=19)
+    int btileBase, btilesX, btilesY; // blur tile enumeration (whole plane)
+    int valid;              // 0: level yields no keypoints
+    float scale;            // mvScaleFactor[level]
+};
+
+struct Config {
+    int nlevels, w, h;
+    int nfeatures, iniTh, minTh, introspection;
+    int pyrBytes;           // bytes of one image's pyramid blob
+    int candTotal;          // candidate scratch elements per image
+    int nTiles;             // FAST tiles per image
+    int nBlurTiles;         // blur tiles per image
+    int umax[16];
+    float scale[kMaxLevels], invScale[kMaxLevels];
+    LevelGeom lv[kMaxLevels];
+};
+
+// per-level bilinear coefficient tables (cv::resize fixed point), one blob per config
+struct ResizeTab {
+    int xofs, a0, a1;       // offsets (in elements) into the int32 / int16 table blobs
+    int yofs, b0, b1;
+};
+
+constexpr int kFastTW = 64, kFastTH = 32;     // FAST/NMS output tile
+constexpr int kBlurTW = 64, kBlurTH = 16;     // blur output tile
+
+struct Buffers {            // device pointers of one batch context
+    uint8_t* pyr;           // [nImg][pyrBytes]  un-blurred pyramid (level 0 = ingested input)
+    uint8_t* qpyr;          // [nImg][pyrBytes]  cost-map pyramid (introspection) or nullptr
+    uint8_t* blur;          // [nImg][pyrBytes]  7x7 sigma-2 blurred pyramid
+    uint8_t* nms;           // [nImg][pyrBytes]  NMS-surviving FAST score map
+    unsigned long long* cand;   // [nImg][candTotal] (respbits<<32 | y<<16 | x) per cell, row-major order
+    unsigned long long* lvl;    // [nImg][candTotal] level list after per-cell retainBest
+    unsigned int* slotPos;  // [nImg][nfeatures] (y<<16|x) level coords
+    float* slotResp;        // [nImg][nfeatures]
+    int* lvlCount;          // [nImg][kMaxLevels]
+    uint8_t* useCost;       // [nImg] 1 = cost pyramid valid for this image
+    ivf_keypoint* kps;      // [nImg][nfeatures]
+    uint8_t* desc;          // [nImg][nfeatures][32]
+    int* count;             // [nImg]
+    float* quality;         // [nImg][nfeatures]  mvKeyQualScore (Frame.cc:130-143)
+    float* uright;          // [nPairs][nfeatures]
+    float* depth;           // [nPairs][nfeatures]
+    int* sad;               // [nPairs][nfeatures]  best SAD distance or -1
+    int* status;            // [1] sticky device-side error flag
+};
+
+// arguments of the stereo matcher kernels: left/right data may live in one batch context
+// (frontend: images interleaved L,R) or in two single-image contexts (two ivf_extractor handles)
+struct StereoArgs {
+    const uint8_t *pyrL, *pyrR; size_t pyrStride;          // bytes between consecutive pairs
+    const ivf_keypoint *kpL, *kpR; const uint8_t *descL, *descR; const int *cntL, *cntR;
+    size_t kpStride;        // elements (ivf_keypoint / 32-byte rows) between pairs
+    int cntStride;
+    float *uright, *depth; int* sad; int outStride;
+    float bf, bb;
+};
+
+// launchers (ivf_kernels.hip)
+void launch_stereo_args(const Config& hc, const Config* dc, const StereoArgs& A, int nPairs, hipStream_t s);
+void launch_ingest(const Config& hc, const Config* dc, const Buffers& b, const uint8_t* src0, const uint8_t* src1,
+                   size_t imageStride, int rowStride, int nImg, int nSides, uint8_t* dstBlob, hipStream_t s);
+void launch_pyramid(const Config& hc, const Config* dc, const ResizeTab* htab, const int* dI32, const short* dI16,
+                    uint8_t* blob, int nImg, hipStream_t s);
+void launch_fast(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s);
+void launch_blur(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s);
+void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s);
+void launch_describe(const Config& hc, const Config* dc, const Buffers& b, const uint8_t* cost0, size_t costStride,
+                     int costPitch, int nImg, int nSides, hipStream_t s);
+void launch_stereo(const Config& hc, const Config* dc, const Buffers& b, int nPairs, float bf, float bb, hipStream_t s);
+void launch_hamming_pairs(const uint8_t* a, const uint8_t* b, const int* pairs, int n, int* dist, hipStream_t s);
+
+}  // namespace ivf

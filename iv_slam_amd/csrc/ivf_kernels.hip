@@ -1,0 +1,942 @@
+// ivf_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the IV-SLAM visual front end.
+//
+// Path (ORB/ = introspective_ORB_SLAM/):
+//   k_ingest        input -> pitched level 0                       (ORBextractor::ComputePyramid :1298-1323, level 0)
+//   k_pyr_down      level l <- bilinear(level l-1), cv::resize 8U   (:1311, :1341)
+//   k_fast_nms      FAST-9/16 score + per-cell 3x3 NMS              (cv::FAST at :1045,:1051)
+//   k_blur7         7x7 sigma-2 Gaussian, 8.8/16.16 fixed point     (:1276-1277)
+//   k_select        per-cell threshold fallback, quotas, retainBest (ComputeKeyPointsOld :880-1213)
+//   k_describe      IC_Angle + rBRIEF + output assembly             (:78-148, :1253-1294; Frame.cc:130-143)
+//   k_stereo_match  row-band Hamming + 11x11 SAD + parabola         (Frame::ComputeStereoMatches Frame.cc:758-915)
+//   k_stereo_gate   median gate                                     (Frame.cc:918-931)
+//   k_hamming_pairs DescriptorDistance                              (ORBmatcher.cc:1700-1716)
+//
+// Everything here is integer/byte work bounded by HBM bandwidth; there is no GEMM shape in this
+// part of the path, so no MFMA.  Compiled with -ffp-contract=off: float expressions must round
+// exactly like the reference's un-fused CPU code.
+#include "ivf_device.h"
+
+namespace ivf {
+
+#define DEVINL __device__ __forceinline__
+
+static __device__ const int8_t __attribute__((aligned(16))) d_pattern[1024] = {
+#include "../../include/ivf_pattern31.inc"
+};
+
+DEVINL int wave_sum_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEVINL unsigned wave_min_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { unsigned t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_ingest: copy the caller's images (arbitrary row stride) into the pitched level-0 plane.
+// grid (ceil(pitch/256), h, nImg); image i comes from src[i % nSides] + (i / nSides) * imageStride.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_ingest(const Config* __restrict__ cfg, const uint8_t* __restrict__ src0,
+                         const uint8_t* __restrict__ src1, size_t imageStride, int rowStride, int nSides,
+                         uint8_t* __restrict__ blob)
+{
+    const LevelGeom& G = cfg->lv[0];
+    const int img = blockIdx.z, y = blockIdx.y;
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (x4 >= G.pitch) return;
+    const uint8_t* src = ((nSides == 2 && (img & 1)) ? src1 : src0) + (size_t)(img / nSides) * imageStride + (size_t)y * rowStride;
+    unsigned v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { int x = x4 + k; unsigned p = x < G.w ? src[x] : 0u; v |= p << (8 * k); }
+    *(unsigned*)(blob + (size_t)img * cfg->pyrBytes + G.off + (size_t)y * G.pitch + x4) = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pyr_down: cv::resize INTER_LINEAR 8UC1 (11-bit coefficients; horizontal pass in int,
+// vertical pass ((b0*(h0>>4))>>16) + ((b1*(h1>>4))>>16) + 2) >> 2).  One thread = 4 output pixels.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pyr_down(const Config* __restrict__ cfg, int level, const int* __restrict__ tI32,
+                           const short* __restrict__ tI16, ResizeTab tab, uint8_t* __restrict__ blob)
+{
+    const LevelGeom& D = cfg->lv[level];
+    const LevelGeom& S = cfg->lv[level - 1];
+    const int img = blockIdx.z, dy = blockIdx.y;
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (x4 >= D.pitch) return;
+    uint8_t* base = blob + (size_t)img * cfg->pyrBytes;
+    const int sy = tI32[tab.yofs + dy];
+    const int b0 = tI16[tab.b0 + dy], b1 = tI16[tab.b1 + dy];
+    const int y0 = min(max(sy, 0), S.h - 1), y1 = min(max(sy + 1, 0), S.h - 1);
+    const uint8_t* S0 = base + S.off + (size_t)y0 * S.pitch;
+    const uint8_t* S1 = base + S.off + (size_t)y1 * S.pitch;
+    unsigned out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int dx = x4 + k;
+        unsigned r = 0;
+        if (dx < D.w) {
+            const int sx = tI32[tab.xofs + dx];
+            const int sx1 = min(sx + 1, S.w - 1);
+            const int a0 = tI16[tab.a0 + dx], a1 = tI16[tab.a1 + dx];
+            const int h0 = S0[sx] * a0 + S0[sx1] * a1;
+            const int h1 = S1[sx] * a0 + S1[sx1] * a1;
+            r = (unsigned)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+        }
+        out |= r << (8 * k);
+    }
+    *(unsigned*)(base + D.off + (size_t)dy * D.pitch + x4) = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST-9/16 score of one pixel from an LDS tile.  A = max over the 16 arcs of 9 contiguous ring
+// pixels, both polarities, of the minimum signed difference; corner at t <=> A > t; score = A-1
+// (OpenCV cornerScore<16>).  Sliding 9-window min/max via a doubling tree.
+// ------------------------------------------------------------------------------------------------
+template <int P>
+DEVINL int fast_score(const uint8_t* c, int t)
+{
+    const int v = c[0];
+    int d[16];
+    d[0] = v - c[3 * P];       d[1] = v - c[3 * P + 1];   d[2] = v - c[2 * P + 2];   d[3] = v - c[P + 3];
+    d[4] = v - c[3];           d[5] = v - c[-P + 3];      d[6] = v - c[-2 * P + 2];  d[7] = v - c[-3 * P + 1];
+    d[8] = v - c[-3 * P];      d[9] = v - c[-3 * P - 1];  d[10] = v - c[-2 * P - 2]; d[11] = v - c[-P - 3];
+    d[12] = v - c[-3];         d[13] = v - c[P - 3];      d[14] = v - c[2 * P - 2];  d[15] = v - c[3 * P - 1];
+    bool dark = true, bright = true;      // every 9-arc holds one pixel of each opposite pair
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        dark &= (d[k] > t) | (d[k + 8] > t);
+        bright &= (d[k] < -t) | (d[k + 8] < -t);
+    }
+    if (!(dark | bright)) return 0;
+    int mn[16], mx[16], a[16], b[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn[k] = min(d[k], d[(k + 1) & 15]); mx[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { a[k] = min(mn[k], mn[(k + 2) & 15]); b[k] = max(mx[k], mx[(k + 2) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn[k] = min(a[k], a[(k + 4) & 15]); mx[k] = max(b[k], b[(k + 4) & 15]); }
+    int amax = -256, bmin = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        amax = max(amax, min(mn[k], d[(k + 8) & 15]));
+        bmin = min(bmin, max(mx[k], d[(k + 8) & 15]));
+    }
+    const int A = max(amax, -bmin);
+    return A > t ? A - 1 : 0;
+}
+
+// cell domain (the pixels cv::FAST actually tests inside the cell window) containing (x,y), or empty
+struct CellRect { int x0, x1, y0, y1; };
+DEVINL bool cell_rect(const LevelGeom& G, int mode, int x, int y, CellRect& r)
+{
+    if (x < kEdge || x >= G.maxBX || y < kEdge || y >= G.maxBY) return false;
+    const int j = (x - kEdge) / G.cellW;
+    int i = (y - kEdge) / G.cellH;
+    if (i > G.rows - 1) i = G.rows - 1;
+    r.x0 = kEdge + j * G.cellW;
+    r.x1 = (j == G.cols - 1) ? G.maxBX : r.x0 + G.cellW;
+    r.y0 = kEdge + i * G.cellH;
+    r.y1 = r.y0 + ((i == G.rows - 1) ? G.domHLast : G.domH[mode]);
+    return y < r.y1 && x < r.x1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_fast_nms: one workgroup = one 64x32 output tile of one level of one image.
+//   1. stage the (64+8)x(32+8) raw tile in LDS with aligned dword loads (tile origin x = 16 + 64*tx)
+//   2. FAST score for the 66x34 region (tile + 1-px NMS halo), 0 outside any cell domain
+//   3. 3x3 strict NMS against neighbours of the SAME cell (cv::FAST runs per cell sub-image, so
+//      neighbours in another cell count as 0) -> nms map, 4 pixels per dword store
+// The map keeps score >= minTh; since score >= t <=> corner at t, the same map serves iniThFAST.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRawP = kFastTW + 8;          // 72
+constexpr int kScP = kFastTW + 2 + 2;       // 68 (padded)
+__global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg, const uint8_t* __restrict__ pyr,
+                                                 const uint8_t* __restrict__ useCost, uint8_t* __restrict__ nms)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t raw[(kFastTH + 8) * kRawP];
+    __shared__ uint8_t sc[(kFastTH + 2) * kScP];
+    const int img = blockIdx.y;
+    int level = 0;
+    const int nl = cfg->nlevels;
+    for (int l = 1; l < nl; l++) if ((int)blockIdx.x >= cfg->lv[l].tileBase) level = l;
+    const LevelGeom& G = cfg->lv[level];
+    const int t = blockIdx.x - G.tileBase;
+    if (!G.valid || t >= G.tilesX * G.tilesY) return;
+    const int mode = (cfg->introspection && useCost[img]) ? 1 : 0;
+    const int tx = t % G.tilesX, ty = t / G.tilesX;
+    const int x0 = 16 + tx * kFastTW, y0 = kEdge + ty * kFastTH;
+    const uint8_t* src = pyr + (size_t)img * cfg->pyrBytes + G.off;
+    const int tid = threadIdx.x;
+
+    // 1. raw tile: rows y0-4 .. y0+TH+3, cols x0-4 .. x0+TW+3 (x0-4 is a multiple of 4)
+    for (int i = tid; i < (kFastTH + 8) * (kRawP / 4); i += 256) {
+        const int ry = i / (kRawP / 4), rx4 = (i % (kRawP / 4)) * 4;
+        const int gy = y0 - 4 + ry, gx = x0 - 4 + rx4;
+        unsigned v = 0;
+        if (gy >= 0 && gy < G.h && gx < G.pitch) v = *(const unsigned*)(src + (size_t)gy * G.pitch + gx);
+        *(unsigned*)(raw + ry * kRawP + rx4) = v;
+    }
+    __syncthreads();
+    // 2. scores on the (TW+2)x(TH+2) region
+    const int minTh = cfg->minTh;
+    for (int i = tid; i < (kFastTH + 2) * (kFastTW + 2); i += 256) {
+        const int sy = i / (kFastTW + 2), sx = i % (kFastTW + 2);
+        const int x = x0 - 1 + sx, y = y0 - 1 + sy;
+        CellRect r;
+        int s = 0;
+        if (cell_rect(G, mode, x, y, r)) s = fast_score<kRawP>(raw + (sy + 3) * kRawP + (sx + 3), minTh);
+        sc[sy * kScP + sx] = (uint8_t)s;
+    }
+    __syncthreads();
+    // 3. NMS, 4 pixels per thread
+    uint8_t* dst = nms + (size_t)img * cfg->pyrBytes + G.off;
+    for (int i = tid; i < kFastTH * (kFastTW / 4); i += 256) {
+        const int oy = i / (kFastTW / 4), ox4 = (i % (kFastTW / 4)) * 4;
+        const int y = y0 + oy;
+        if (y >= G.maxBY) continue;
+        unsigned out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = x0 + ox4 + k;
+            const uint8_t* c = sc + (oy + 1) * kScP + (ox4 + k + 1);
+            const int s = c[0];
+            unsigned keep = 0;
+            CellRect r;
+            if (s > 0 && cell_rect(G, mode, x, y, r)) {
+                const bool L = x - 1 >= r.x0, R = x + 1 < r.x1, U = y - 1 >= r.y0, D = y + 1 < r.y1;
+                bool ok = true;
+                ok &= s > ((L) ? c[-1] : 0);
+                ok &= s > ((R) ? c[1] : 0);
+                ok &= s > ((U && L) ? c[-kScP - 1] : 0);
+                ok &= s > ((U) ? c[-kScP] : 0);
+                ok &= s > ((U && R) ? c[-kScP + 1] : 0);
+                ok &= s > ((D && L) ? c[kScP - 1] : 0);
+                ok &= s > ((D) ? c[kScP] : 0);
+                ok &= s > ((D && R) ? c[kScP + 1] : 0);
+                keep = ok ? (unsigned)s : 0u;
+            }
+            out |= keep << (8 * k);
+        }
+        const int gx = x0 + ox4;
+        if (gx < G.pitch) *(unsigned*)(dst + (size_t)y * G.pitch + gx) = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_blur7: cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) in OpenCV 4.x's 8-bit fixed point:
+// kernel [18,34,48,56,48,34,18]/256, exact horizontal pass (u16), vertical pass (+32768)>>16.
+// One workgroup = one 64x16 output tile.
+// ------------------------------------------------------------------------------------------------
+DEVINL int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+}
+__global__ __launch_bounds__(256) void k_blur7(const Config* __restrict__ cfg, const uint8_t* __restrict__ pyr,
+                                              const int* __restrict__ lvlCount, uint8_t* __restrict__ blur)
+{
+    constexpr int RW = kBlurTW + 6, RH = kBlurTH + 6;
+    __shared__ uint8_t raw[RH * RW];
+    __shared__ unsigned short hp[RH * kBlurTW];
+    const int img = blockIdx.y;
+    int level = 0;
+    const int nl = cfg->nlevels;
+    for (int l = 1; l < nl; l++) if ((int)blockIdx.x >= cfg->lv[l].btileBase) level = l;
+    const LevelGeom& G = cfg->lv[level];
+    const int tilesX = G.btilesX, tilesY = G.btilesY;
+    const int t = blockIdx.x - G.btileBase;
+    if (t >= tilesX * tilesY) return;
+    if (lvlCount && lvlCount[img * kMaxLevels + level] == 0) return;   // :1270 levels without keypoints are skipped
+    const int x0 = (t % tilesX) * kBlurTW, y0 = (t / tilesX) * kBlurTH;
+    const uint8_t* src = pyr + (size_t)img * cfg->pyrBytes + G.off;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < RH * RW; i += 256) {
+        const int ry = i / RW, rx = i % RW;
+        const int gy = reflect101(y0 - 3 + ry, G.h), gx = reflect101(x0 - 3 + rx, G.w);
+        raw[i] = src[(size_t)gy * G.pitch + gx];
+    }
+    __syncthreads();
+    for (int i = tid; i < RH * kBlurTW; i += 256) {
+        const int ry = i / kBlurTW, ox = i % kBlurTW;
+        const uint8_t* r = raw + ry * RW + ox;
+        hp[i] = (unsigned short)(18 * (r[0] + r[6]) + 34 * (r[1] + r[5]) + 48 * (r[2] + r[4]) + 56 * r[3]);
+    }
+    __syncthreads();
+    uint8_t* dst = blur + (size_t)img * cfg->pyrBytes + G.off;
+    for (int i = tid; i < kBlurTH * (kBlurTW / 4); i += 256) {
+        const int oy = i / (kBlurTW / 4), ox4 = (i % (kBlurTW / 4)) * 4;
+        const int y = y0 + oy;
+        if (y >= G.h) continue;
+        unsigned out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned short* c = hp + oy * kBlurTW + ox4 + k;
+            const unsigned acc = 18u * (c[0] + c[6 * kBlurTW]) + 34u * (c[kBlurTW] + c[5 * kBlurTW]) +
+                                 48u * (c[2 * kBlurTW] + c[4 * kBlurTW]) + 56u * c[3 * kBlurTW];
+            out |= (((acc + 32768u) >> 16) & 0xffu) << (8 * k);
+        }
+        if (x0 + ox4 < G.pitch) *(unsigned*)(dst + (size_t)y * G.pitch + x0 + ox4) = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// libstdc++ std::nth_element (bits/stl_algo.h __introselect) on 64-bit keys whose high word is the
+// response as f32 bits (responses are >= 0, so unsigned compare == float compare).  Must replay the
+// exact compare/swap sequence: FAST responses tie constantly and the surviving ORDER feeds every
+// downstream index (SURVEY §7 hard part 1).  Comparator = cv::KeypointResponseGreater.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned long long u64;
+#define RGT(a, b) ((unsigned)((a) >> 32) > (unsigned)((b) >> 32))
+
+DEVINL void sel_adjust_heap(u64* f, int hole, int len, u64 value)
+{
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (RGT(f[child], f[child - 1])) child--;
+        f[hole] = f[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        f[hole] = f[child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && RGT(f[parent], value)) {
+        f[hole] = f[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    f[hole] = value;
+}
+__device__ __noinline__ void sel_nth_element(u64* v, int n, int nth)
+{
+    if (n <= 0 || nth >= n) return;
+    int first = 0, last = n;
+    int depth = 0;
+    for (int t = n; t > 1; t >>= 1) depth++;
+    depth *= 2;
+    while (last - first > 3) {
+        if (depth == 0) {
+            // __heap_select(first, nth+1, last) ; iter_swap(first, nth)
+            u64* f = v + first;
+            const int len = nth + 1 - first;
+            if (len >= 2) {
+                int parent = (len - 2) / 2;
+                for (;;) {
+                    u64 val = f[parent];
+                    sel_adjust_heap(f, parent, len, val);
+                    if (parent == 0) break;
+                    parent--;
+                }
+            }
+            for (int i = nth + 1; i < last; ++i)
+                if (RGT(v[i], f[0])) { u64 val = v[i]; v[i] = f[0]; sel_adjust_heap(f, 0, len, val); }
+            u64 tmp = v[first]; v[first] = v[nth]; v[nth] = tmp;
+            return;
+        }
+        --depth;
+        const int mid = first + (last - first) / 2;
+        // __move_median_to_first(first, first+1, mid, last-1)
+        {
+            const int a = first + 1, b = mid, c = last - 1;
+            u64 va = v[a], vb = v[b], vc = v[c];
+            int m;
+            if (RGT(va, vb)) { if (RGT(vb, vc)) m = b; else if (RGT(va, vc)) m = c; else m = a; }
+            else if (RGT(va, vc)) m = a;
+            else if (RGT(vb, vc)) m = c;
+            else m = b;
+            u64 tmp = v[first]; v[first] = v[m]; v[m] = tmp;
+        }
+        // __unguarded_partition(first+1, last, pivot = first)
+        int lo = first + 1, hi = last;
+        const u64 pivot = v[first];
+        for (;;) {
+            while (RGT(v[lo], pivot)) ++lo;
+            --hi;
+            while (RGT(pivot, v[hi])) --hi;
+            if (!(lo < hi)) break;
+            u64 tmp = v[lo]; v[lo] = v[hi]; v[hi] = tmp;
+            ++lo;
+        }
+        if (lo <= nth) first = lo; else last = lo;
+    }
+    // __insertion_sort(first, last)
+    for (int i = first + 1; i < last; ++i) {
+        const u64 val = v[i];
+        if (RGT(val, v[first])) {
+            for (int k = i; k > first; --k) v[k] = v[k - 1];
+            v[first] = val;
+        } else {
+            int l = i;
+            while (RGT(val, v[l - 1])) { v[l] = v[l - 1]; --l; }
+            v[l] = val;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_select: one workgroup = one (image, level).  ComputeKeyPointsOld :880-1213 minus the per-pixel
+// work: per-cell candidate counts at iniTh/minTh (the `<=3 -> minThFAST` fallback, :1047), cost-map
+// cell weights and quotas (:946-987, :1028-1031), the single-pass quota redistribution (:1103-1133),
+// row-major candidate compaction with response*quality (:1058-1080), per-cell retainBest (:1146),
+// concatenation in (i,j) order and the level-wide retainBest (:1162-1166).
+// ------------------------------------------------------------------------------------------------
+constexpr int kSelThreads = 512;
+__global__ __launch_bounds__(kSelThreads) void k_select(const Config* __restrict__ cfg, const uint8_t* __restrict__ nms,
+                                                       const uint8_t* __restrict__ qpyr, const uint8_t* __restrict__ useCost,
+                                                       u64* __restrict__ cand, u64* __restrict__ lvl,
+                                                       unsigned* __restrict__ slotPos, float* __restrict__ slotResp,
+                                                       int* __restrict__ lvlCount, int* __restrict__ status)
+{
+    __shared__ int s_nIni[kMaxCells], s_nMin[kMaxCells], s_nTotal[kMaxCells], s_nRetain[kMaxCells], s_prefix[kMaxCells + 1];
+    __shared__ unsigned s_qsum[kMaxCells];
+    __shared__ unsigned char s_useMin[kMaxCells];
+    __shared__ int s_total;
+    const int img = blockIdx.y, level = blockIdx.x;
+    const LevelGeom& G = cfg->lv[level];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = kSelThreads / 64;
+    if (!G.valid) { if (tid == 0) lvlCount[img * kMaxLevels + level] = 0; return; }
+    const int mode = (cfg->introspection && useCost[img]) ? 1 : 0;
+    const int nCells = G.nCells, cols = G.cols, rows = G.rows;
+    const uint8_t* M = nms + (size_t)img * cfg->pyrBytes + G.off;
+    const uint8_t* Q = mode ? qpyr + (size_t)img * cfg->pyrBytes + G.off : nullptr;
+    const int iniTh = cfg->iniTh;
+    const int pitch = G.pitch;
+
+    // phase 1: per-cell counts (and cost-window sums)
+    for (int c = wave; c < nCells; c += nw) {
+        const int i = c / cols, j = c % cols;
+        const int x0 = kEdge + j * G.cellW, x1 = (j == cols - 1) ? G.maxBX : x0 + G.cellW;
+        const int y0 = kEdge + i * G.cellH, y1 = y0 + ((i == rows - 1) ? G.domHLast : G.domH[mode]);
+        int nIni = 0, nMin = 0;
+        for (int y = y0; y < y1; y++)
+            for (int xb = x0; xb < x1; xb += 64) {
+                const int x = xb + lane;
+                const int s = x < x1 ? M[(size_t)y * pitch + x] : 0;
+                nMin += __popcll(__ballot(s > 0));
+                nIni += __popcll(__ballot(s >= iniTh));
+            }
+        unsigned qs = 0;
+        if (mode) {
+            const int wx0 = x0 - 3, wx1 = (j == cols - 1) ? G.maxBX + 3 : x0 + G.cellW + 3;
+            const int wy0 = y0 - 3, wy1 = wy0 + ((i == rows - 1) ? G.winHLast : G.cellH + 6);
+            int acc = 0;
+            for (int y = wy0; y < wy1; y++)
+                for (int x = wx0 + lane; x < wx1; x += 64) acc += Q[(size_t)y * pitch + x];
+            qs = (unsigned)wave_sum_i32(acc);
+        }
+        if (lane == 0) { s_nIni[c] = nIni; s_nMin[c] = nMin; s_qsum[c] = qs; }
+    }
+    __syncthreads();
+
+    // phase 2: quotas (sequential bookkeeping exactly in (i,j) order)
+    if (tid == 0) {
+        float wsum = 0.0f;
+        if (mode)
+            for (int c = 0; c < nCells; c++) {
+                const int i = c / cols, j = c % cols;
+                const float hX = (j == cols - 1) ? (float)(G.maxBX + 3 - (16 + j * G.cellW)) : (float)(G.cellW + 6);
+                const float hY = (i == rows - 1) ? (float)G.winHLast : (float)(G.cellH + 6);
+                const float cost = (float)s_qsum[c] / (float)(hX * hY);
+                const float q = (float)(1.0 / (1.0 + (double)(cost / 255)));
+                const float wn = 2 * q - 1;
+                s_qsum[c] = __float_as_uint(wn);
+                wsum += wn;
+            }
+        int nToDistribute = 0, nNoMore = 0;
+        for (int c = 0; c < nCells; c++) {
+            const float nfc = mode ? fmaxf(1.0f, ceilf((float)G.nDesired * __uint_as_float(s_qsum[c]) / wsum))
+                                   : (float)G.nfeaturesCell;
+            const bool useMin = s_nIni[c] <= 3;
+            const int nKeys = useMin ? s_nMin[c] : s_nIni[c];
+            s_useMin[c] = useMin;
+            s_nTotal[c] = nKeys;
+            if ((float)nKeys > nfc) { s_nRetain[c] = (int)nfc; s_prefix[c] = 0; }
+            else {
+                s_nRetain[c] = nKeys;
+                nToDistribute = (int)((float)nToDistribute + (nfc - (float)nKeys));
+                s_prefix[c] = 1; nNoMore++;             // s_prefix doubles as bNoMore here
+            }
+            s_nIni[c] = __float_as_int(nfc);            // keep nfeatures_cell for the redistribution pass
+        }
+        if (nToDistribute > 0 && nNoMore < nCells) {
+            for (int c = 0; c < nCells; c++) {
+                if (!s_prefix[c]) {
+                    const int nNew = (int)(__int_as_float(s_nIni[c]) + ceilf((float)nToDistribute / (nCells - nNoMore)));
+                    if (s_nTotal[c] > nNew) s_nRetain[c] = nNew;
+                    else { s_nRetain[c] = s_nTotal[c]; nToDistribute += nNew - s_nTotal[c]; s_prefix[c] = 1; nNoMore++; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // phase 3: row-major compaction of each cell's candidates at its threshold
+    u64* candL = cand + (size_t)img * cfg->candTotal + G.candBase;
+    for (int c = wave; c < nCells; c += nw) {
+        const int i = c / cols, j = c % cols;
+        const int x0 = kEdge + j * G.cellW, x1 = (j == cols - 1) ? G.maxBX : x0 + G.cellW;
+        const int y0 = kEdge + i * G.cellH, y1 = y0 + ((i == rows - 1) ? G.domHLast : G.domH[mode]);
+        const int th = s_useMin[c] ? 1 : iniTh;          // map already holds score >= minTh only
+        u64* out = candL + (size_t)c * G.candCap;
+        int n = 0;
+        for (int y = y0; y < y1; y++)
+            for (int xb = x0; xb < x1; xb += 64) {
+                const int x = xb + lane;
+                const int s = x < x1 ? M[(size_t)y * pitch + x] : 0;
+                const bool keep = s >= th;
+                const unsigned long long mask = __ballot(keep);
+                if (keep) {
+                    const int idx = n + __popcll(mask & ((1ull << lane) - 1ull));
+                    float resp = (float)s;
+                    if (mode) {
+                        const float cost = (float)Q[(size_t)y * pitch + x];
+                        resp *= 2 * (1.0f / (1.0f + cost / 255.0f)) - 1;
+                    }
+                    if (idx < G.candCap)
+                        out[idx] = ((u64)__float_as_uint(resp) << 32) | ((unsigned)y << 16) | (unsigned)x;
+                }
+                n += __popcll(mask);
+            }
+        if (lane == 0 && n != s_nTotal[c]) atomicOr(status, 1);     // internal consistency
+        if (lane == 0 && n > G.candCap) atomicOr(status, 2);
+    }
+    __syncthreads();
+
+    // phase 4: per-cell retainBest, one lane per cell spread over the waves
+    for (int c0 = 0; c0 < nCells; c0 += kSelThreads) {
+        const int slot = (tid & 63) * nw + (tid >> 6);      // lane-major so each wave holds few active lanes
+        const int c = c0 + slot;
+        if (c < nCells) {
+            const int nT = s_nTotal[c], nR = s_nRetain[c];
+            int kept = nT;
+            if (nR >= 0 && nT > nR) {
+                if (nR > 0) sel_nth_element(candL + (size_t)c * G.candCap, nT, nR - 1);
+                kept = nR;
+            }
+            s_nTotal[c] = kept;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int c = 0; c < nCells; c++) { s_prefix[c] = acc; acc += s_nTotal[c]; }
+        s_prefix[nCells] = acc;
+        s_total = acc;
+    }
+    __syncthreads();
+    // phase 5: concatenate in (i,j) order, level-wide retainBest
+    u64* L = lvl + (size_t)img * cfg->candTotal + G.candBase;
+    for (int c = wave; c < nCells; c += nw) {
+        const u64* in = candL + (size_t)c * G.candCap;
+        const int n = s_nTotal[c], o = s_prefix[c];
+        for (int k = lane; k < n; k += 64) L[o + k] = in[k];
+    }
+    __syncthreads();
+    int total = s_total;
+    if (total > G.nDesired) {
+        if (tid == 0) sel_nth_element(L, total, G.nDesired - 1);
+        total = G.nDesired;
+        __syncthreads();
+    }
+    // phase 6: slots
+    for (int k = tid; k < total; k += kSelThreads) {
+        const u64 e = L[k];
+        slotPos[(size_t)img * cfg->nfeatures + G.kpBase + k] = (unsigned)e;
+        slotResp[(size_t)img * cfg->nfeatures + G.kpBase + k] = __uint_as_float((unsigned)(e >> 32));
+    }
+    if (tid == 0) lvlCount[img * kMaxLevels + level] = total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// glibc >= 2.28 sinf/cosf (ARM optimized-routines sincosf: f64 polynomial after reduction by pi/2),
+// restated so the device rounds exactly like the host libm the reference calls (ORBextractor.cc:113-114).
+// ------------------------------------------------------------------------------------------------
+DEVINL float sincos_poly(double x, double x2, bool neg, int n)
+{
+    const double c0 = neg ? -0x1p0 : 0x1p0, c1 = neg ? 0x1.ffffffd0c621cp-2 : -0x1.ffffffd0c621cp-2;
+    const double c2 = neg ? -0x1.55553e1068f19p-5 : 0x1.55553e1068f19p-5, c3 = neg ? 0x1.6c087e89a359dp-10 : -0x1.6c087e89a359dp-10;
+    const double c4 = neg ? -0x1.99343027bf8c3p-16 : 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    if ((n & 1) == 0) {
+        const double x3 = x * x2, t1 = s2 + x2 * s3, x7 = x3 * x2, s = x + x3 * s1;
+        return (float)(s + x7 * t1);
+    } else {
+        const double x4 = x2 * x2, t2 = c3 + x2 * c4, t1 = c0 + x2 * c1, x6 = x4 * x2, c = t1 + x4 * c2;
+        return (float)(c + x6 * t2);
+    }
+}
+DEVINL void sincosf_glibc(float y, float& sn, float& cs)
+{
+    double x = y;
+    const unsigned top = (__float_as_uint(y) >> 20) & 0x7ff;
+    if (top < ((__float_as_uint(0x1.921FB6p-1f) >> 20) & 0x7ff)) {
+        if (top < ((__float_as_uint(0x1p-12f) >> 20) & 0x7ff)) { sn = y; cs = 1.0f; return; }
+        const double x2 = x * x;
+        sn = sincos_poly(x, x2, false, 0);
+        cs = sincos_poly(x, x2, false, 1);
+        return;
+    }
+    const double r = x * 0x1.45F306DC9C883p+23;
+    const int n = ((int)r + 0x800000) >> 24;
+    x = x - n * 0x1.921FB54442D18p0;
+    const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+    const bool neg = (n & 2) != 0;
+    const double x2 = x * x;
+    sn = sincos_poly(x * sgn, x2, neg, n);
+    cs = sincos_poly(x * sgn, x2, neg, n ^ 1);
+}
+
+// cv::fastAtan2 (OpenCV 3.x/4.x), f32, degrees
+DEVINL float fast_atan2(float y, float x)
+{
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+DEVINL int cv_round(float v) { return __float2int_rn(v); }
+
+// ------------------------------------------------------------------------------------------------
+// k_describe: one wave = one keypoint slot.  IC_Angle (:78-105) over the 749-px disc of the
+// un-blurred level, rBRIEF (:109-148) on the blurred level, then output assembly (:1253-1294):
+// keypoints of all levels concatenated in level order, pt scaled by mvScaleFactor[level] for level>0,
+// plus mvKeyQualScore (Frame.cc:130-143) from level 0 of the cost pyramid.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg, const uint8_t* __restrict__ pyr,
+                                                 const uint8_t* __restrict__ blur, const uint8_t* __restrict__ qpyr,
+                                                 const uint8_t* __restrict__ useCost,
+                                                 const unsigned* __restrict__ slotPos, const float* __restrict__ slotResp,
+                                                 const int* __restrict__ lvlCount, ivf_keypoint* __restrict__ kps,
+                                                 uint8_t* __restrict__ desc, int* __restrict__ count,
+                                                 float* __restrict__ quality)
+{
+    const int img = blockIdx.y;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nf = cfg->nfeatures, nl = cfg->nlevels;
+    if (slot >= nf) return;
+    int level = 0;
+    for (int l = 1; l < nl; l++) if (slot >= cfg->lv[l].kpBase) level = l;
+    const LevelGeom& G = cfg->lv[level];
+    const int k = slot - G.kpBase;
+    const int* lc = lvlCount + img * kMaxLevels;
+    int before = 0, total = 0;
+    for (int l = 0; l < nl; l++) { const int c = lc[l]; if (l < level) before += c; total += c; }
+    if (slot == 0 && lane == 0) count[img] = total;
+    if (k >= lc[level]) return;
+    const unsigned pos = slotPos[(size_t)img * nf + slot];
+    const int px = pos & 0xffff, py = pos >> 16;
+    const uint8_t* P = pyr + (size_t)img * cfg->pyrBytes + G.off;
+    const uint8_t* B = blur + (size_t)img * cfg->pyrBytes + G.off;
+    const int pitch = G.pitch;
+
+    // IC_Angle: 31 rows, two rows per step (lanes 0-31 / 32-63), u = lane%32 - 15
+    int m10 = 0, m01 = 0;
+    {
+        const int u = (lane & 31) - 15;
+        for (int r = 0; r < 16; r++) {
+            const int v = -15 + 2 * r + (lane >> 5);
+            if (v <= 15) {
+                const int d = cfg->umax[v < 0 ? -v : v];
+                if (u >= -d && u <= d && (lane & 31) < 31) {
+                    const int val = P[(size_t)(py + v) * pitch + px + u];
+                    m10 += u * val;
+                    m01 += v * val;
+                }
+            }
+        }
+        m10 = wave_sum_i32(m10);
+        m01 = wave_sum_i32(m01);
+    }
+    const float angle = fast_atan2((float)m01, (float)m10);
+
+    // rBRIEF: lane handles tests 4*lane .. 4*lane+3
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float a, b;
+    sincosf_glibc(angle * factorPI, b, a);
+    const int4 pw = *(const int4*)(d_pattern + lane * 16);
+    const int wv[4] = {pw.x, pw.y, pw.z, pw.w};
+    unsigned nib = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const float x0 = (float)(int8_t)(wv[t] & 0xff), y0 = (float)(int8_t)((wv[t] >> 8) & 0xff);
+        const float x1 = (float)(int8_t)((wv[t] >> 16) & 0xff), y1 = (float)(int8_t)((wv[t] >> 24) & 0xff);
+        const int t0 = B[(size_t)(py + cv_round(x0 * b + y0 * a)) * pitch + px + cv_round(x0 * a - y0 * b)];
+        const int t1 = B[(size_t)(py + cv_round(x1 * b + y1 * a)) * pitch + px + cv_round(x1 * a - y1 * b)];
+        nib |= (unsigned)(t0 < t1) << t;
+    }
+    unsigned byte = nib | (__shfl_down(nib, 1, 64) << 4);          // valid on even lanes
+    unsigned w = byte | (__shfl_down(byte, 2, 64) << 8) | (__shfl_down(byte, 4, 64) << 16) | (__shfl_down(byte, 6, 64) << 24);
+    const int oi = before + k;
+    if ((lane & 7) == 0) *(unsigned*)(desc + ((size_t)img * nf + oi) * 32 + (lane >> 3) * 4) = w;
+    if (lane == 0) {
+        ivf_keypoint kp;
+        float fx = (float)px, fy = (float)py;
+        if (level != 0) { fx *= G.scale; fy *= G.scale; }
+        kp.x = fx; kp.y = fy; kp.size = (float)G.scaledPatch; kp.angle = angle;
+        kp.response = slotResp[(size_t)img * nf + slot]; kp.octave = level;
+        kps[(size_t)img * nf + oi] = kp;
+        float q = 1.0f;
+        if (cfg->introspection && useCost[img]) {
+            const int qx = (int)roundf(fx), qy = (int)roundf(fy);
+            const LevelGeom& G0 = cfg->lv[0];
+            const float cost = (float)qpyr[(size_t)img * cfg->pyrBytes + G0.off + (size_t)min(qy, G0.h - 1) * G0.pitch + min(qx, G0.w - 1)];
+            const float qs = (float)(1.0 / (1.0 + (double)(cost / 256)));
+            q = 2 * qs - 1;
+        }
+        quality[(size_t)img * nf + oi] = q;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DescriptorDistance (ORBmatcher.cc:1700-1716): 256-bit Hamming = 8 x v_bcnt_u32_b32
+// ------------------------------------------------------------------------------------------------
+DEVINL int hamming256(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1)
+{
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+__global__ void k_hamming_pairs(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                const int* __restrict__ pairs, int n, int* __restrict__ dist)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* pa = (const uint4*)(a + (size_t)pairs[2 * i] * 32);
+    const uint4* pb = (const uint4*)(b + (size_t)pairs[2 * i + 1] * 32);
+    dist[i] = hamming256(pa[0], pa[1], pb[0], pb[1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_stereo_match: one wave = one left keypoint (Frame.cc:788-915).
+//   candidates = right keypoints whose row band [floor(y-r), ceil(y+r)], r = 2*scale[octave], holds
+//   row (int)vL, octave within +-1, uR in [uL-maxD, uL]; argmin Hamming (first minimum in increasing
+//   iR, as vRowIndices is filled in iR order) starting from TH_HIGH; accept < 75; then the 11x11 SAD
+//   over 11 shifts at the keypoint's octave, parabola refinement, disparity gate.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stereo_match(const Config* __restrict__ cfg, StereoArgs A)
+{
+    const int pair = blockIdx.y;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nL = A.cntL[pair * A.cntStride], nR = A.cntR[pair * A.cntStride];
+    if (iL >= cfg->nfeatures) return;
+    float* uright = A.uright + (size_t)pair * A.outStride;
+    float* depth = A.depth + (size_t)pair * A.outStride;
+    int* sad = A.sad + (size_t)pair * A.outStride;
+    if (iL >= nL) { if (lane == 0) { uright[iL] = -1.0f; depth[iL] = -1.0f; sad[iL] = -1; } return; }
+    const ivf_keypoint* kpL = A.kpL + (size_t)pair * A.kpStride;
+    const ivf_keypoint* kpR = A.kpR + (size_t)pair * A.kpStride;
+    const uint8_t* descL = A.descL + (size_t)pair * A.kpStride * 32;
+    const uint8_t* descR = A.descR + (size_t)pair * A.kpStride * 32;
+    float outU = -1.0f, outD = -1.0f; int outS = -1;
+
+    const ivf_keypoint kl = kpL[iL];
+    const int levelL = kl.octave;
+    const float vL = kl.y, uL = kl.x;
+    const int row = (int)vL;
+    const float minZ = A.bb, minD = 0, maxD = A.bf / minZ;
+    const float minU = uL - maxD, maxU = uL - minD;
+    const LevelGeom& G0 = cfg->lv[0];
+    bool live = row >= 0 && row < G0.h && !(maxU < 0);
+    unsigned best = (100u << 16) | 0xffffu;            // (dist << 16) | iR ; TH_HIGH start, strict <
+    if (live) {
+        const uint4* dl = (const uint4*)(descL + (size_t)iL * 32);
+        const uint4 l0 = dl[0], l1 = dl[1];
+        for (int base = 0; base < nR; base += 64) {
+            const int iR = base + lane;
+            if (iR < nR) {
+                const ivf_keypoint kr = kpR[iR];
+                const float r = 2.0f * cfg->scale[kr.octave];
+                const int maxr = (int)ceilf(kr.y + r), minr = (int)floorf(kr.y - r);
+                if (row >= minr && row <= maxr && kr.octave >= levelL - 1 && kr.octave <= levelL + 1 &&
+                    kr.x >= minU && kr.x <= maxU) {
+                    const uint4* dr = (const uint4*)(descR + (size_t)iR * 32);
+                    const unsigned d = (unsigned)hamming256(l0, l1, dr[0], dr[1]);
+                    const unsigned key = (d << 16) | (unsigned)iR;
+                    if (d < 100u && key < best) best = key;
+                }
+            }
+        }
+    }
+    best = wave_min_u32(best);
+    const int bestDist = best >> 16;
+    const int bestIdxR = best & 0xffff;
+    if (live && bestIdxR != 0xffff && bestDist < 75) {
+        const float uR0 = kpR[bestIdxR].x;
+        const float scaleFactor = cfg->invScale[levelL];
+        const float scaleduL = roundf(kl.x * scaleFactor), scaledvL = roundf(kl.y * scaleFactor);
+        const float scaleduR0 = roundf(uR0 * scaleFactor);
+        const int w = 5, L = 5;
+        const LevelGeom& G = cfg->lv[levelL];
+        const uint8_t* PL = A.pyrL + (size_t)pair * A.pyrStride + G.off;
+        const uint8_t* PR = A.pyrR + (size_t)pair * A.pyrStride + G.off;
+        const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+        const int yl = (int)(scaledvL - w), xl = (int)(scaleduL - w);
+        const bool ok = !(iniu < 0 || endu >= (float)G.w) && yl >= 0 && yl + 11 <= G.h && xl >= 0 && xl + 11 <= G.w &&
+                        (int)(scaleduR0 - L - w) >= 0;
+        if (ok) {
+            const int cL = PL[(size_t)(yl + w) * G.pitch + xl + w];
+            // lane covers window pixels lane and lane+64 (121 total)
+            int dl0 = 0, dl1 = 0; int p0y = lane / 11, p0x = lane % 11, p1y = (lane + 64) / 11, p1x = (lane + 64) % 11;
+            const bool has1 = lane + 64 < 121;
+            dl0 = PL[(size_t)(yl + p0y) * G.pitch + xl + p0x] - cL;
+            if (has1) dl1 = PL[(size_t)(yl + p1y) * G.pitch + xl + p1x] - cL;
+            int bestD = 0x7fffffff, bestinc = 0;
+            float vDists[11];
+#pragma unroll
+            for (int inc = -5; inc <= 5; inc++) {
+                const int xr = (int)(scaleduR0 + (float)inc - w);
+                const int cR = PR[(size_t)(yl + w) * G.pitch + xr + w];
+                int acc = abs(dl0 - (PR[(size_t)(yl + p0y) * G.pitch + xr + p0x] - cR));
+                if (has1) acc += abs(dl1 - (PR[(size_t)(yl + p1y) * G.pitch + xr + p1x] - cR));
+                acc = wave_sum_i32(acc);
+                const float dist = (float)acc;
+                if (dist < (float)bestD) { bestD = (int)dist; bestinc = inc; }
+                vDists[inc + 5] = dist;
+            }
+            if (!(bestinc == -L || bestinc == L)) {
+                float dist1 = 0, dist2 = 0, dist3 = 0;
+#pragma unroll
+                for (int q = 1; q < 10; q++) if (q == bestinc + 5) { dist1 = vDists[q - 1]; dist2 = vDists[q]; dist3 = vDists[q + 1]; }
+                const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+                if (!(deltaR < -1 || deltaR > 1)) {
+                    float bestuR = cfg->scale[levelL] * ((float)scaleduR0 + (float)bestinc + deltaR);
+                    float disparity = (uL - bestuR);
+                    if (disparity >= minD && disparity < maxD) {
+                        if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+                        outD = A.bf / disparity; outU = bestuR; outS = bestD;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) { uright[iL] = outU; depth[iL] = outD; sad[iL] = outS; }
+}
+
+// k_stereo_gate: one workgroup = one pair.  sort(vDistIdx); median = vDistIdx[size/2].first;
+// drop every match with dist >= 1.5f*1.4f*median (Frame.cc:918-931).  Only the median VALUE matters,
+// so it is found by rank counting instead of sorting.  Empty list => no gate (Appendix D-8).
+__global__ __launch_bounds__(256) void k_stereo_gate(const Config* __restrict__ cfg, const int* __restrict__ cntL,
+                                                    int cntStride, float* __restrict__ uright, float* __restrict__ depth,
+                                                    const int* __restrict__ sad, int outStride)
+{
+    __shared__ int s_n, s_median;
+    const int pair = blockIdx.x;
+    const int nL = cntL[pair * cntStride];
+    const int* S = sad + (size_t)pair * outStride;
+    if (threadIdx.x == 0) { s_n = 0; s_median = -1; }
+    __syncthreads();
+    int local = 0;
+    for (int i = threadIdx.x; i < nL; i += blockDim.x) local += S[i] >= 0;
+    atomicAdd(&s_n, local);
+    __syncthreads();
+    const int n = s_n;
+    if (n == 0) return;
+    const int target = n / 2;
+    for (int i = threadIdx.x; i < nL; i += blockDim.x) {
+        const int d = S[i];
+        if (d < 0) continue;
+        int lt = 0, le = 0;
+        for (int j = 0; j < nL; j++) { const int e = S[j]; if (e >= 0) { lt += e < d; le += e <= d; } }
+        if (lt <= target && target < le) s_median = d;
+    }
+    __syncthreads();
+    const float median = (float)s_median;
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = threadIdx.x; i < nL; i += blockDim.x) {
+        const int d = S[i];
+        if (d >= 0 && !((float)d < thDist)) {
+            uright[(size_t)pair * outStride + i] = -1;
+            depth[(size_t)pair * outStride + i] = -1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+void launch_ingest(const Config& hc, const Config* dc, const Buffers&, const uint8_t* src0, const uint8_t* src1,
+                   size_t imageStride, int rowStride, int nImg, int nSides, uint8_t* dstBlob, hipStream_t s)
+{
+    const LevelGeom& G = hc.lv[0];
+    dim3 grid((G.pitch / 4 + 255) / 256, G.h, nImg);
+    hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, dc, src0, src1, imageStride, rowStride, nSides, dstBlob);
+}
+void launch_pyramid(const Config& hc, const Config* dc, const ResizeTab* htab, const int* dI32, const short* dI16,
+                    uint8_t* blob, int nImg, hipStream_t s)
+{
+    for (int l = 1; l < hc.nlevels; l++) {
+        const LevelGeom& G = hc.lv[l];
+        if (G.w <= 0 || G.h <= 0) continue;
+        dim3 grid((G.pitch / 4 + 127) / 128, G.h, nImg);
+        hipLaunchKernelGGL(k_pyr_down, grid, dim3(128), 0, s, dc, l, dI32, dI16, htab[l], blob);
+    }
+}
+void launch_fast(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s)
+{
+    if (hc.nTiles <= 0) return;
+    hipLaunchKernelGGL(k_fast_nms, dim3(hc.nTiles, nImg), dim3(256), 0, s, dc, b.pyr, b.useCost, b.nms);
+}
+void launch_blur(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s)
+{
+    const int tiles = hc.nBlurTiles;
+    if (tiles <= 0) return;
+    hipLaunchKernelGGL(k_blur7, dim3(tiles, nImg), dim3(256), 0, s, dc, b.pyr, b.lvlCount, b.blur);
+}
+void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_select, dim3(hc.nlevels, nImg), dim3(kSelThreads), 0, s, dc, b.nms, b.qpyr, b.useCost,
+                       b.cand, b.lvl, b.slotPos, b.slotResp, b.lvlCount, b.status);
+}
+void launch_describe(const Config& hc, const Config* dc, const Buffers& b, const uint8_t*, size_t, int, int nImg, int,
+                     hipStream_t s)
+{
+    hipLaunchKernelGGL(k_describe, dim3((hc.nfeatures + 3) / 4, nImg), dim3(256), 0, s, dc, b.pyr, b.blur, b.qpyr,
+                       b.useCost, b.slotPos, b.slotResp, b.lvlCount, b.kps, b.desc, b.count, b.quality);
+}
+void launch_stereo_args(const Config& hc, const Config* dc, const StereoArgs& A, int nPairs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_stereo_match, dim3((hc.nfeatures + 3) / 4, nPairs), dim3(256), 0, s, dc, A);
+    hipLaunchKernelGGL(k_stereo_gate, dim3(nPairs), dim3(256), 0, s, dc, A.cntL, A.cntStride, A.uright, A.depth, A.sad,
+                       A.outStride);
+}
+void launch_stereo(const Config& hc, const Config* dc, const Buffers& b, int nPairs, float bf, float bb, hipStream_t s)
+{
+    StereoArgs A;
+    A.pyrL = b.pyr; A.pyrR = b.pyr + hc.pyrBytes; A.pyrStride = (size_t)2 * hc.pyrBytes;
+    A.kpL = b.kps; A.kpR = b.kps + hc.nfeatures; A.descL = b.desc; A.descR = b.desc + (size_t)hc.nfeatures * 32;
+    A.cntL = b.count; A.cntR = b.count + 1; A.kpStride = (size_t)2 * hc.nfeatures; A.cntStride = 2;
+    A.uright = b.uright; A.depth = b.depth; A.sad = b.sad; A.outStride = hc.nfeatures;
+    A.bf = bf; A.bb = bb;
+    launch_stereo_args(hc, dc, A, nPairs, s);
+}
+void launch_hamming_pairs(const uint8_t* a, const uint8_t* b, const int* pairs, int n, int* dist, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_hamming_pairs, dim3((n + 255) / 256), dim3(256), 0, s, a, b, pairs, n, dist);
+}
+
+}  // namespace ivf

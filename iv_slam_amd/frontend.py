@@ -1,0 +1,90 @@
+"""Batched, device-resident stereo front end (ivf_frontend_* in include/ivfront.h).
+
+PyTorch is used only as the device-memory / stream / torch.distributed plumbing: the images live in
+torch.uint8 CUDA(HIP) tensors whose raw pointers are handed to the C-ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KP_DTYPE, ExtractorParams, FrontendConfig, check, ptr
+
+
+class StereoFrontend:
+    """Per pair: ORBextractor L/R (ORB/src/Frame.cc:115-125) + mvKeyQualScore (:130-143) +
+    ComputeStereoMatches (:758-932), for up to max_pairs pairs per launch sequence."""
+
+    def __init__(self, width, height, max_pairs, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7,
+                 enableIntrospection=False, bf=386.1448, b=None, fx=718.856, device_id=0):
+        self._lib = _lib.load()
+        b = b if b is not None else bf / fx                      # mb = mbf/fx (Frame.cc:410)
+        left = ExtractorParams(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, int(bool(enableIntrospection)))
+        right = ExtractorParams(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, 0)   # Tracking.cc:182-183
+        self.cfg = FrontendConfig(left, right, width, height, max_pairs, bf, b, device_id)
+        h = C.c_void_p()
+        check(self._lib.ivf_frontend_create(C.byref(self.cfg), C.byref(h)))
+        self._h = h
+        self.width, self.height, self.max_pairs, self.nfeatures = width, height, max_pairs, nfeatures
+        self.device_id = device_id
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.ivf_frontend_destroy(self._h)
+            self._h = None
+
+    def run(self, left, right, cost=None, stream_ptr=None):
+        """left/right/cost: torch.uint8 tensors [n,H,W] on this device (contiguous).  Asynchronous."""
+        n = left.shape[0]
+        assert left.dtype == right.dtype and left.shape == right.shape and left.is_contiguous() and right.is_contiguous()
+        assert left.shape[1] == self.height and left.shape[2] == self.width
+        cp = None
+        if cost is not None:
+            assert cost.shape == left.shape and cost.is_contiguous()
+            cp = cost.data_ptr()
+        check(self._lib.ivf_frontend_run(self._h, left.data_ptr(), right.data_ptr(), cp,
+                                         self.height * self.width, self.width, n, stream_ptr))
+        self._n = n
+
+    def sync(self):
+        check(self._lib.ivf_frontend_sync(self._h))
+
+    def last_fast_ms(self):
+        return float(self._lib.ivf_frontend_last_fast_ms(self._h))
+
+    def fetch(self, pair, side):
+        cap = self.nfeatures
+        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+        ur = np.zeros(cap, np.float32); dp = np.zeros(cap, np.float32); q = np.zeros(cap, np.float32)
+        n = C.c_int(0)
+        check(self._lib.ivf_frontend_fetch(self._h, pair, side, ptr(kps), ptr(desc), cap, C.byref(n), ptr(ur), ptr(dp), ptr(q)))
+        n = n.value
+        out = dict(kps=kps[:n].copy(), desc=desc[:n].copy(), quality=q[:n].copy())
+        if side == 0:
+            out.update(uright=ur[:n].copy(), depth=dp[:n].copy())
+        return out
+
+    def gather_record_bytes(self):
+        rec = C.c_size_t(0)
+        check(self._lib.ivf_frontend_pack_gather_block(self._h, None, 0, C.byref(rec), None))
+        return rec.value
+
+    def pack_gather_block(self, block, stream_ptr=None):
+        """block: torch.uint8 tensor of >= n_pairs*record_bytes on this device."""
+        rec = C.c_size_t(0)
+        check(self._lib.ivf_frontend_pack_gather_block(self._h, block.data_ptr(), block.numel(), C.byref(rec), stream_ptr))
+        return rec.value
+
+
+def unpack_gather_records(buf, nfeatures):
+    """Decode records packed by ivf_frontend_pack_gather_block (host numpy uint8 buffer) -> list of dicts."""
+    rec = 16 + nfeatures * 24 + nfeatures * 32 + nfeatures * 4
+    buf = np.ascontiguousarray(buf, np.uint8).reshape(-1, rec)
+    out = []
+    for r in buf:
+        n = int(r[:4].view(np.int32)[0])
+        kps = r[16:16 + nfeatures * 24].view(KP_DTYPE)[:n].copy()
+        desc = r[16 + nfeatures * 24:16 + nfeatures * 56].reshape(nfeatures, 32)[:n].copy()
+        ur = r[16 + nfeatures * 56:].view(np.float32)[:n].copy()
+        out.append(dict(n=n, kps=kps, desc=desc, uright=ur))
+    return out

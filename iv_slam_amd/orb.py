@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's class surfaces for the hot path, on top of the C-ABI.
+
+Same names, argument meaning and error behaviour as
+  ORB_SLAM2::ORBextractor   (ORB/include/ORBextractor.h:51-126, ORB/src/ORBextractor.cc:411-476,1224-1296)
+  ORB_SLAM2::ORBmatcher     (ORB/include/ORBmatcher.h:37-108, ORB/src/ORBmatcher.cc:1372-1518,1700-1716)
+  Frame::ComputeStereoMatches / GetFeaturesInArea (ORB/src/Frame.cc:758-932, 615-680)
+so parity tests read like tests of the reference classes.  Every method calls libivfront.so (HIP);
+nothing here computes on the CPU except trivial glue.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KP_DTYPE, Bounds, ExtractorParams, check, ptr
+
+
+class ORBextractor:
+    """ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, enableIntrospection=False)."""
+
+    HARRIS_SCORE, FAST_SCORE = 0, 1
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, enableIntrospection=False, device_id=0):
+        self._lib = _lib.load()
+        self.params = ExtractorParams(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, int(bool(enableIntrospection)))
+        h = C.c_void_p()
+        check(self._lib.ivf_extractor_create(C.byref(self.params), device_id, C.byref(h)))
+        self._h = h
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.ivf_extractor_destroy(self._h)
+            self._h = None
+
+    # --- getters (ORBextractor.h:69-89)
+    def GetLevels(self):
+        return self._lib.ivf_extractor_get_levels(self._h)
+
+    def GetScaleFactor(self):
+        return self._lib.ivf_extractor_get_scale_factor(self._h)
+
+    def _tables(self):
+        n = self.nlevels
+        t = [np.zeros(n, np.float32) for _ in range(4)]
+        check(self._lib.ivf_extractor_get_scale_tables(self._h, *[ptr(a) for a in t]))
+        return t
+
+    def GetScaleFactors(self):
+        return self._tables()[0]
+
+    def GetInverseScaleFactors(self):
+        return self._tables()[1]
+
+    def GetScaleSigmaSquares(self):
+        return self._tables()[2]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tables()[3]
+
+    def feature_tables(self):
+        nf = np.zeros(self.nlevels, np.int32); um = np.zeros(16, np.int32)
+        check(self._lib.ivf_extractor_get_feature_tables(self._h, ptr(nf), ptr(um)))
+        return nf, um
+
+    # --- operator()(image, mask, keypoints, descriptors)
+    def __call__(self, image, mask=None, cap=None):
+        """Returns (keypoints[KP_DTYPE], descriptors[n,32] u8).  Empty image -> empty outputs (ORBextractor.cc:1227)."""
+        if image is None or image.size == 0:
+            return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        if image.dtype != np.uint8 or image.ndim != 2:
+            raise AssertionError("image.type() == CV_8UC1")              # ORBextractor.cc:1241
+        image = np.ascontiguousarray(image)
+        h, w = image.shape
+        if mask is not None and mask.size:
+            if mask.dtype != np.uint8 or mask.shape != image.shape:
+                raise AssertionError("mask.type() == CV_8UC1 and same size as the image")   # :1234
+            mask = np.ascontiguousarray(mask)
+        else:
+            mask = None
+        cap = cap or self.nfeatures
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        check(self._lib.ivf_extract(self._h, ptr(image), w, h, w, ptr(mask), w, ptr(kps), ptr(desc), cap, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    # --- public data members mvImagePyramid / mvQualityImagePyramid (ORBextractor.h:91-92)
+    def _level(self, fn, level):
+        w = C.c_int(); h = C.c_int()
+        check(fn(self._h, level, None, 0, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        check(fn(self._h, level, ptr(out), w.value, C.byref(w), C.byref(h)))
+        return out
+
+    @property
+    def mvImagePyramid(self):
+        return [self._level(self._lib.ivf_extractor_pyramid_level, l) for l in range(self.nlevels)]
+
+    @property
+    def mvQualityImagePyramid(self):
+        return [self._level(self._lib.ivf_extractor_quality_level, l) for l in range(self.nlevels)]
+
+    def level_counts(self):
+        c = np.zeros(self.nlevels, np.int32)
+        check(self._lib.ivf_extractor_level_counts(self._h, ptr(c)))
+        return c.tolist()
+
+
+def ComputeStereoMatches(extractorLeft, extractorRight, mvKeys, mDescriptors, mvKeysRight, mDescriptorsRight, mbf, mb):
+    """Frame::ComputeStereoMatches (ORB/src/Frame.cc:758-932) -> (mvuRight, mvDepth)."""
+    lib = _lib.load()
+    kl = np.ascontiguousarray(mvKeys, KP_DTYPE); kr = np.ascontiguousarray(mvKeysRight, KP_DTYPE)
+    dl = np.ascontiguousarray(mDescriptors, np.uint8); dr = np.ascontiguousarray(mDescriptorsRight, np.uint8)
+    ur = np.full(len(kl), -1.0, np.float32); dp = np.full(len(kl), -1.0, np.float32)
+    check(lib.ivf_stereo_match(extractorLeft._h, extractorRight._h, ptr(kl), len(kl), ptr(dl), ptr(kr), len(kr), ptr(dr),
+                               mbf, mb, ptr(ur), ptr(dp)))
+    return ur, dp
+
+
+def GetFeaturesInArea(mvKeysUn, bounds, x, y, r, minLevel=-1, maxLevel=-1):
+    """Frame::GetFeaturesInArea (ORB/src/Frame.cc:615-668); bounds = (mnMinX, mnMinY, mnMaxX, mnMaxY)."""
+    lib = _lib.load()
+    k = np.ascontiguousarray(mvKeysUn, KP_DTYPE)
+    out = np.zeros(max(len(k), 1), np.int32)
+    n = C.c_int(0)
+    bd = Bounds(*bounds)
+    check(lib.ivf_features_in_area(ptr(k), len(k), C.byref(bd), x, y, r, minLevel, maxLevel, ptr(out), len(out), C.byref(n)))
+    return out[:n.value].copy()
+
+
+class ORBmatcher:
+    """ORBmatcher(nnratio=0.6, checkOri=True) (ORB/include/ORBmatcher.h:41)."""
+
+    TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30
+
+    def __init__(self, nnratio=0.6, checkOri=True, device_id=0):
+        self._lib = _lib.load()
+        self.mfNNratio, self.mbCheckOrientation, self.device_id = nnratio, checkOri, device_id
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+        return _lib.load().ivf_hamming(ptr(a), ptr(b))
+
+    def DescriptorDistances(self, descA, descB, pairs):
+        """Batch of DescriptorDistance on the device: pairs[n,2] of (rowA,rowB)."""
+        a = np.ascontiguousarray(descA, np.uint8); b = np.ascontiguousarray(descB, np.uint8)
+        p = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        d = np.zeros(len(p), np.int32)
+        check(self._lib.ivf_hamming_pairs(ptr(a), len(a), ptr(b), len(b), ptr(p), len(p), ptr(d), self.device_id))
+        return d
+
+    def SearchByProjection(self, cur_kps, cur_desc, cur_uright, bounds, q, cur_assign=None):
+        """SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBmatcher.cc:1372-1518) on projected queries
+        (see include/ivfront.h).  Returns (CurrentFrame.mvpMapPoints as query indices, nmatches)."""
+        cur_kps = np.ascontiguousarray(cur_kps, KP_DTYPE); cur_desc = np.ascontiguousarray(cur_desc, np.uint8)
+        cur_uright = np.ascontiguousarray(cur_uright, np.float32)
+        n_cur = len(cur_kps); n_q = len(q["u"])
+        assign = np.full(n_cur, -1, np.int32) if cur_assign is None else np.ascontiguousarray(cur_assign, np.int32).copy()
+        types = dict(u=np.float32, v=np.float32, ur=np.float32, radius=np.float32, min_level=np.int32,
+                     max_level=np.int32, angle=np.float32, desc=np.uint8, valid=np.uint8, blocks=np.uint8)
+        qq = {k: np.ascontiguousarray(q[k], t) for k, t in types.items()}
+        nm = C.c_int(0)
+        bd = Bounds(*bounds)
+        check(self._lib.ivf_search_by_projection(ptr(cur_kps), ptr(cur_desc), ptr(cur_uright), n_cur, C.byref(bd), n_q,
+                                                 ptr(qq["u"]), ptr(qq["v"]), ptr(qq["ur"]), ptr(qq["radius"]),
+                                                 ptr(qq["min_level"]), ptr(qq["max_level"]), ptr(qq["angle"]),
+                                                 ptr(qq["desc"]), ptr(qq["valid"]), ptr(qq["blocks"]),
+                                                 int(self.mbCheckOrientation), ptr(assign), C.byref(nm), self.device_id))
+        return assign, nm.value

@@ -1,0 +1,60 @@
+"""CPU-side checks of the C-ABI: libivfront.so loads, exports every symbol include/ivfront.h declares,
+and fails loudly (no CPU fallback) when no GPU is present.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "ivfront.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ivf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from iv_slam_amd import _lib
+    lib = _lib.load()
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), "libivfront.so does not export %s" % s
+    assert sorted(_lib.EXPORTED_SYMBOLS) == syms, "python binding table and header disagree"
+    assert lib.ivf_version() >= 100
+
+
+def test_struct_layouts_match_header():
+    from iv_slam_amd import _lib
+    assert _lib.KP_DTYPE.itemsize == 24 and C.sizeof(_lib.ExtractorParams) == 24
+    assert C.sizeof(_lib.Bounds) == 16 and C.sizeof(_lib.FrontendConfig) == 24 * 2 + 6 * 4
+
+
+def test_no_cpu_fallback_without_gpu():
+    from iv_slam_amd import _lib
+    lib = _lib.load()
+    if lib.ivf_device_count() > 0:
+        pytest.skip("a GPU is present")
+    import iv_slam_amd as iv
+    with pytest.raises(iv.IvfError) as e:
+        iv.ORBextractor(1000, 1.2, 8, 20, 7)
+    assert e.value.code == _lib.IVF_E_NO_DEVICE and "no CPU path" in str(e.value)
+    p = np.zeros((4, 2), np.int32); d = np.zeros((4, 32), np.uint8); out = np.zeros(4, np.int32)
+    assert lib.ivf_hamming_pairs(_lib.ptr(d), 4, _lib.ptr(d), 4, _lib.ptr(p), 4, _lib.ptr(out), 0) == _lib.IVF_E_NO_DEVICE
+
+
+def test_argument_validation_without_gpu():
+    from iv_slam_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    bad = _lib.ExtractorParams(1000, 1.2, 99, 20, 7, 0)
+    assert lib.ivf_extractor_create(C.byref(bad), 0, C.byref(h)) == _lib.IVF_E_INVALID
+    assert b"nlevels" in lib.ivf_last_error()
+    bad = _lib.ExtractorParams(1000, 1.2, 8, 5, 7, 0)
+    assert lib.ivf_extractor_create(C.byref(bad), 0, C.byref(h)) == _lib.IVF_E_INVALID
+    # host helper: DescriptorDistance
+    a = np.arange(32, dtype=np.uint8); b = a[::-1].copy()
+    assert lib.ivf_hamming(_lib.ptr(a), _lib.ptr(b)) == int(np.unpackbits(a ^ b).sum())

@@ -1,0 +1,236 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the same
+seeded inputs.  Bar: BIT-EXACT keypoints (all 6 fields), descriptors, pyramids, mvuRight/mvDepth."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from iv_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+BF = 386.1448
+B = BF / 718.856
+
+
+@pytest.fixture(scope="module")
+def iv():
+    import iv_slam_amd
+    iv_slam_amd.load()
+    lib = iv_slam_amd.load()
+    assert lib.ivf_device_count() >= 1, "no HIP device: libivfront has no CPU fallback"
+    return iv_slam_amd
+
+
+def assert_kps_equal(a, b, what=""):
+    assert len(a) == len(b), "%s: count %d vs %d" % (what, len(a), len(b))
+    for f in a.dtype.names:
+        if not np.array_equal(a[f], b[f]):
+            bad = np.nonzero(a[f] != b[f])[0]
+            raise AssertionError("%s: field %s differs at %d positions, first %d: %r vs %r" %
+                                 (what, f, len(bad), bad[0], a[f][bad[0]], b[f][bad[0]]))
+    assert a.tobytes() == b.tobytes()
+
+
+def extract_both(iv, img, cost=None, n=1000, nlevels=8, ini=20, mn=7, sf=1.2, introspection=False):
+    g = iv.ORBextractor(n, sf, nlevels, ini, mn, introspection)
+    o = O.Extractor(n, sf, nlevels, ini, mn, introspection)
+    gk, gd = g(img, cost)
+    ok, od = o(img, cost)
+    return g, o, gk, gd, ok, od
+
+
+def test_tables_match_oracle(iv):
+    for n in (500, 1000, 2000, 4000):
+        g = iv.ORBextractor(n, 1.2, 8, 20, 7)
+        t = O.Extractor(n, 1.2, 8, 20, 7).tables()
+        assert np.array_equal(g.GetScaleFactors(), t["scale"]) and np.array_equal(g.GetInverseScaleFactors(), t["inv_scale"])
+        assert np.array_equal(g.GetScaleSigmaSquares(), t["sigma2"]) and np.array_equal(g.GetInverseScaleSigmaSquares(), t["inv_sigma2"])
+        nf, um = g.feature_tables()
+        assert np.array_equal(nf, t["features_per_level"]) and np.array_equal(um, t["umax"])
+        assert g.GetLevels() == 8 and abs(g.GetScaleFactor() - 1.2) < 1e-6
+
+
+@pytest.mark.parametrize("size,n", [((320, 200), 300), ((640, 240), 500), ((1242, 375), 1000), ((1242, 375), 2000)])
+def test_extract_bit_exact(iv, size, n):
+    w, h = size
+    for idx in range(2):
+        img = synth.make_left(w, h, seed=11, idx=idx)
+        g, o, gk, gd, ok, od = extract_both(iv, img, n=n)
+        for l in range(8):
+            assert np.array_equal(g.mvImagePyramid[l], o.pyramid(l)), "pyramid level %d" % l
+        assert g.level_counts() == o.level_counts()
+        assert_kps_equal(gk, ok, "keypoints %s n=%d idx=%d" % (size, n, idx))
+        assert np.array_equal(gd, od), "descriptors"
+        assert len(gk) > n // 2
+
+
+def test_extract_with_cost_map_bit_exact(iv):
+    w, h = 1242, 375
+    img = synth.make_left(w, h, seed=5, idx=0)
+    cost = synth.make_cost_map(w, h, seed=5, idx=0)
+    g, o, gk, gd, ok, od = extract_both(iv, img, cost, n=1000, introspection=True)
+    for l in range(8):
+        assert np.array_equal(g.mvQualityImagePyramid[l], o.quality_pyramid(l)), "quality level %d" % l
+    assert g.level_counts() == o.level_counts()
+    assert_kps_equal(gk, ok, "introspection keypoints")
+    assert np.array_equal(gd, od)
+    # the cost map must actually change the outcome (stale-hY + response weighting)
+    _, _, pk, _, _, _ = extract_both(iv, img, None, n=1000, introspection=True)
+    assert pk.tobytes() != gk.tobytes()
+    # a non-introspective extractor ignores the mask (Tracking.cc:182-183 right extractor)
+    g2 = iv.ORBextractor(1000, 1.2, 8, 20, 7, False)
+    k2, _ = g2(img, cost)
+    assert_kps_equal(k2, pk, "mask ignored")
+
+
+def test_extract_edge_cases(iv):
+    g = iv.ORBextractor(1000, 1.2, 8, 20, 7)
+    k, d = g(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0 and d.shape == (0, 32)                       # empty image: silent return
+    flat = np.full((200, 320), 77, np.uint8)
+    gk, gd = g(flat)
+    assert len(gk) == 0                                              # no corners anywhere
+    # tiny image: upper levels smaller than the 19-px border produce nothing, like the oracle
+    img = synth.make_left(120, 90, seed=2, idx=0)
+    g, o, gk, gd, ok, od = extract_both(iv, img, n=200)
+    assert_kps_equal(gk, ok, "tiny")
+    assert np.array_equal(gd, od)
+    # reuse of one handle with a different size rebuilds geometry
+    img2 = synth.make_left(400, 300, seed=2, idx=1)
+    gk2, gd2 = g(img2)
+    ok2, od2 = o(img2)
+    assert_kps_equal(gk2, ok2, "resize handle")
+    # jackal-style thresholds / other pyramid params
+    g, o, gk, gd, ok, od = extract_both(iv, img2, n=700, nlevels=6, ini=12, mn=7, sf=1.3)
+    assert_kps_equal(gk, ok, "params")
+    assert np.array_equal(gd, od)
+
+
+def test_random_noise_image_many_ties(iv):
+    rng = np.random.default_rng(9)
+    img = (rng.integers(0, 4, size=(240, 400)) * 60 + 20).astype(np.uint8)     # 4 grey levels: massive response ties
+    g, o, gk, gd, ok, od = extract_both(iv, img, n=800)
+    assert_kps_equal(gk, ok, "ties")
+    assert np.array_equal(gd, od)
+
+
+@pytest.mark.parametrize("size,n", [((640, 240), 500), ((1242, 375), 1000)])
+def test_stereo_matches_bit_exact(iv, size, n):
+    w, h = size
+    L, R = synth.make_pair(w, h, seed=21, idx=0)
+    gL = iv.ORBextractor(n, 1.2, 8, 20, 7); gR = iv.ORBextractor(n, 1.2, 8, 20, 7)
+    kL, dL = gL(L); kR, dR = gR(R)
+    oL = O.Extractor(n, 1.2, 8, 20, 7); oR = O.Extractor(n, 1.2, 8, 20, 7)
+    okL, odL = oL(L); okR, odR = oR(R)
+    assert_kps_equal(kL, okL, "L"); assert_kps_equal(kR, okR, "R")
+    ur, dp = iv.ComputeStereoMatches(gL, gR, kL, dL, kR, dR, BF, B)
+    our, odp = O.stereo_match(oL, oR, okL, odL, okR, odR, BF, B)
+    assert ur.tobytes() == our.tobytes(), "mvuRight differs at %r" % (np.nonzero(ur != our)[0][:5],)
+    assert dp.tobytes() == odp.tobytes()
+    assert (ur >= 0).sum() > n // 10                                # matching really happens
+    # no right keypoints / no candidates -> all -1, no gate (Appendix D-8)
+    ur0, dp0 = iv.ComputeStereoMatches(gL, gR, kL, dL, kR[:0], dR[:0], BF, B)
+    assert (ur0 == -1).all() and (dp0 == -1).all()
+
+
+def test_frontend_batch_matches_oracle(iv):
+    import torch
+    w, h, n, pairs = 640, 240, 500, 3
+    stream = synth.make_stream(pairs, w, h, seed=31)
+    dev = torch.device("cuda:0")
+    left = torch.from_numpy(stream[:, 0].copy()).to(dev); right = torch.from_numpy(stream[:, 1].copy()).to(dev)
+    fe = iv.StereoFrontend(w, h, 4, nfeatures=n, bf=BF, b=B)
+    fe.run(left, right)
+    fe.sync()
+    assert fe.last_fast_ms() > 0
+    for p in range(pairs):
+        oL = O.Extractor(n, 1.2, 8, 20, 7); oR = O.Extractor(n, 1.2, 8, 20, 7)
+        okL, odL = oL(stream[p, 0]); okR, odR = oR(stream[p, 1])
+        our, odp = O.stereo_match(oL, oR, okL, odL, okR, odR, BF, B)
+        rl = fe.fetch(p, 0); rr = fe.fetch(p, 1)
+        assert_kps_equal(rl["kps"], okL, "pair %d L" % p); assert_kps_equal(rr["kps"], okR, "pair %d R" % p)
+        assert np.array_equal(rl["desc"], odL) and np.array_equal(rr["desc"], odR)
+        assert rl["uright"].tobytes() == our.tobytes() and rl["depth"].tobytes() == odp.tobytes()
+        assert (rl["quality"] == 1.0).all()
+    # determinism: a second run of the same batch is identical
+    a = fe.fetch(1, 0)
+    fe.run(left, right); fe.sync()
+    b = fe.fetch(1, 0)
+    assert a["kps"].tobytes() == b["kps"].tobytes() and np.array_equal(a["desc"], b["desc"])
+
+
+def test_frontend_with_cost_maps(iv):
+    import torch
+    w, h, n, pairs = 640, 240, 500, 2
+    stream = synth.make_stream(pairs, w, h, seed=41)
+    cost = np.stack([synth.make_cost_map(w, h, seed=41, idx=i) for i in range(pairs)])
+    dev = torch.device("cuda:0")
+    fe = iv.StereoFrontend(w, h, 2, nfeatures=n, enableIntrospection=True, bf=BF, b=B)
+    fe.run(torch.from_numpy(stream[:, 0].copy()).to(dev), torch.from_numpy(stream[:, 1].copy()).to(dev),
+           torch.from_numpy(cost).to(dev))
+    fe.sync()
+    for p in range(pairs):
+        oL = O.Extractor(n, 1.2, 8, 20, 7, introspection=True); oR = O.Extractor(n, 1.2, 8, 20, 7, introspection=False)
+        okL, odL = oL(stream[p, 0], cost[p]); okR, odR = oR(stream[p, 1], cost[p])       # right ignores the map (D-7)
+        rl = fe.fetch(p, 0); rr = fe.fetch(p, 1)
+        assert_kps_equal(rl["kps"], okL, "L"); assert_kps_equal(rr["kps"], okR, "R")
+        assert np.array_equal(rl["desc"], odL) and np.array_equal(rr["desc"], odR)
+        # mvKeyQualScore (Frame.cc:130-143): cost/256, double division narrowed to float
+        px = np.rint(okL["x"]).astype(int); py = np.rint(okL["y"]).astype(int)
+        c = cost[p][py, px].astype(np.float32)
+        q = (np.float64(1.0) / (np.float64(1.0) + (c / np.float32(256)).astype(np.float64))).astype(np.float32)
+        assert np.array_equal(rl["quality"], (np.float32(2) * q - np.float32(1)).astype(np.float32))
+
+
+def test_hamming_pairs_and_search_by_projection(iv):
+    rng = np.random.default_rng(77)
+    w, h, n = 640, 240, 500
+    img = synth.make_left(w, h, seed=51, idx=0)
+    g = iv.ORBextractor(n, 1.2, 8, 20, 7)
+    kps, desc = g(img)
+    m = iv.ORBmatcher(0.9, True)
+    pairs = rng.integers(0, len(kps), (2000, 2)).astype(np.int32)
+    d = m.DescriptorDistances(desc, desc, pairs)
+    exp = np.array([O.hamming(desc[a], desc[b]) for a, b in pairs])
+    assert np.array_equal(d, exp)
+    assert iv.ORBmatcher.DescriptorDistance(desc[0], desc[1]) == O.hamming(desc[0], desc[1])
+    # queries = the frame's own keypoints displaced by a few pixels, descriptors with flipped bits
+    nq = len(kps)
+    qd = desc.copy()
+    flip = rng.integers(0, 256, (nq, 6))
+    for i in range(nq):
+        for bpos in flip[i]:
+            qd[i, bpos // 8] ^= np.uint8(1 << (bpos % 8))
+    oct_ = kps["octave"]
+    sc = g.GetScaleFactors()
+    q = dict(u=kps["x"] + rng.uniform(-3, 3, nq).astype(np.float32), v=kps["y"] + rng.uniform(-3, 3, nq).astype(np.float32),
+             ur=(kps["x"] - 20).astype(np.float32), radius=(7 * sc[oct_]).astype(np.float32),
+             min_level=(oct_ - 1).astype(np.int32), max_level=(oct_ + 1).astype(np.int32),
+             angle=(kps["angle"] + rng.choice([0, 0, 0, 90], nq)).astype(np.float32) % 360, desc=qd,
+             valid=(rng.uniform(size=nq) > 0.1).astype(np.uint8), blocks=(rng.uniform(size=nq) > 0.2).astype(np.uint8))
+    uright = np.where(rng.uniform(size=nq) > 0.5, kps["x"] - 20 + rng.uniform(-10, 10, nq), -1).astype(np.float32)
+    bounds = (0.0, 0.0, float(w), float(h))
+    pre = np.full(nq, -1, np.int32); pre[rng.integers(0, nq, 20)] = -2
+    ga, gn = m.SearchByProjection(kps, desc, uright, bounds, q, pre)
+    oa, on = O.search_by_projection(kps, desc, uright, bounds, q, True, pre)
+    assert gn == on and np.array_equal(ga, oa) and gn > nq // 4
+    for x, y, r, lo, hi in [(300, 120, 40, -1, -1), (10, 10, 30, 0, 3), (630, 230, 60, 2, 7)]:
+        assert np.array_equal(iv.GetFeaturesInArea(kps, bounds, x, y, r, lo, hi), O.features_in_area(kps, bounds, x, y, r, lo, hi))
+
+
+def test_full_size_properties(iv):
+    """BASELINE full size: properties that need no oracle (idempotence, level order, border, uniqueness)."""
+    img = synth.make_left(1242, 375, seed=61, idx=0)
+    g = iv.ORBextractor(1000, 1.2, 8, 20, 7)
+    k1, d1 = g(img); k2, d2 = g(img)
+    assert k1.tobytes() == k2.tobytes() and np.array_equal(d1, d2)           # idempotent
+    assert (np.diff(k1["octave"]) >= 0).all()                                # levels concatenated in order
+    sc = g.GetScaleFactors()
+    lw = [p.shape[1] for p in g.mvImagePyramid]; lh = [p.shape[0] for p in g.mvImagePyramid]
+    for l in range(8):
+        s = k1[k1["octave"] == l]
+        x = np.rint(s["x"] / sc[l]); y = np.rint(s["y"] / sc[l])
+        assert (x >= 19).all() and (x < lw[l] - 19).all() and (y >= 19).all() and (y < lh[l] - 19).all()
+        assert len(s) <= [217, 181, 151, 126, 105, 87, 73, 60][l]
+        assert len(set(zip(x.tolist(), y.tolist()))) == len(s)                # NMS: no duplicate positions
+    assert ((k1["angle"] >= 0) & (k1["angle"] < 360.0001)).all() and (k1["response"] >= 7).all()
