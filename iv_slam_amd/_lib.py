@@ -79,6 +79,14 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libivfront.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(make -C iv_slam_amd/csrc).  There is no CPU fallback.")
+        # PyTorch-ROCm wheels bundle their own HIP runtime under the same soname (libamdhip64.so.7).
+        # Two HIP runtimes in one process cannot both own the GPU, so when torch is installed it is
+        # imported first and libivfront.so binds to the runtime torch already loaded; without torch the
+        # system runtime in /opt/rocm/lib is used (RUNPATH of the .so).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
