@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo pairs/s of the hot path (ORB extract L+R + L/R stereo match) on MI355X.
+
+Contract: python bench.py --gpus N --steps K --warmup W  (N>1 is launched by torch.distributed.run,
+one rank per GPU).  One step = one pass of the hot path over one batch of `--pairs` synthetic
+1242x375 stereo pairs that are already resident in HBM; value = pairs all ranks processed / time
+(max over ranks).  Workload = BASELINE.json configs[1] (introspection OFF; --introspect adds cost
+maps -> configs[2]'s extractor side).  Prints ONE JSON line on rank 0, carrying `roofline` for the
+dominant kernel (k_fast_nms, HIP events on its stream inside the timed region) and `cpu_baseline`
+(the oracle = scalar port of the reference CPU path, timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "stereo pairs/s (extract+match+introspect) @1242×375, 1000 feat; 1/2/4/8 GPU"
+W, H, NFEAT = 1242, 375, 1000
+BF, FX = 386.1448, 718.856
+LEVEL_PX_SUM = 1441432            # sum of pixels over the 8 levels
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def make_device_stream(torch, dev, n_pairs, seed, base_pairs=16):
+    """>=256 distinct pairs without minutes of host synthesis: `base_pairs` seeded host pairs, each
+    expanded on the GPU by a per-image (dx,dy) roll applied to left AND right (disparity preserved)
+    plus +-1 seeded noise."""
+    from iv_slam_amd import synth
+    base = synth.make_stream(base_pairs, W, H, seed=seed)
+    bl = torch.from_numpy(base[:, 0].copy()).to(dev); br = torch.from_numpy(base[:, 1].copy()).to(dev)
+    g = torch.Generator(device=dev); g.manual_seed(1234 + seed)
+    left = torch.empty((n_pairs, H, W), dtype=torch.uint8, device=dev); right = torch.empty_like(left)
+    for i in range(n_pairs):
+        b = i % base_pairs; k = i // base_pairs
+        dx, dy = (37 * k) % 200, (11 * k) % 40
+        for src, dst in ((bl, left), (br, right)):
+            img = torch.roll(src[b], shifts=(dy, dx), dims=(0, 1)).to(torch.int16)
+            img += torch.randint(-1, 2, img.shape, generator=g, device=dev, dtype=torch.int16) * (k > 0)
+            dst[i] = img.clamp_(0, 255).to(torch.uint8)
+    return left, right
+
+
+def cpu_baseline(pairs_sample, cores):
+    """Oracle (bit-exact scalar restatement of the reference CPU path; kind = 'port') on host threads.
+    One pair per worker thread (ctypes releases the GIL); the reference itself uses 2 threads per pair."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import concurrent.futures as cf
+    import oracle_lib as O          # checker / baseline only -- never on the product path
+    from iv_slam_amd import synth
+    imgs = [synth.make_pair(W, H, seed=900, idx=i) for i in range(min(pairs_sample, 8))]
+    b = BF / FX
+
+    def work(i):
+        L, R = imgs[i % len(imgs)]
+        eL = O.Extractor(NFEAT, 1.2, 8, 20, 7); eR = O.Extractor(NFEAT, 1.2, 8, 20, 7)
+        kL, dL = eL(L); kR, dR = eR(R)
+        O.stereo_match(eL, eR, kL, dL, kR, dR, BF, b)
+        return 1
+
+    work(0)
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:
+        done = sum(ex.map(work, range(pairs_sample)))
+    dt = time.perf_counter() - t0
+    return done / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU")
+    ap.add_argument("--stream", type=int, default=256, help="distinct pairs resident per GPU")
+    ap.add_argument("--introspect", action="store_true", help="feed seeded cost maps (extractor side of configs[2])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)      # "nccl" is RCCL on ROCm
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import iv_slam_amd as iv
+    from iv_slam_amd import synth
+    P = args.pairs
+    n_stream = max(args.stream, P)
+    n_stream = (n_stream + P - 1) // P * P
+    left, right = make_device_stream(torch, dev, n_stream, seed=100 + rank)
+    cost = None
+    if args.introspect:
+        import numpy as np
+        cm = np.stack([synth.make_cost_map(W, H, seed=100 + rank, idx=i) for i in range(8)])
+        cost = torch.from_numpy(cm).to(dev).repeat((n_stream + 7) // 8, 1, 1)[:n_stream].contiguous()
+    fe = iv.StereoFrontend(W, H, P, nfeatures=NFEAT, enableIntrospection=args.introspect, bf=BF, fx=FX,
+                           device_id=local_rank)
+    stream = torch.cuda.current_stream(dev)
+    sptr = stream.cuda_stream
+    rec = fe.gather_record_bytes()
+    block = torch.empty(P * rec, dtype=torch.uint8, device=dev)
+    gathered = torch.empty(world * P * rec, dtype=torch.uint8, device=dev) if world > 1 else None
+    nslices = n_stream // P
+
+    def step(i):
+        s = (i % nslices) * P
+        fe.run(left[s:s + P], right[s:s + P], None if cost is None else cost[s:s + P], sptr)
+        if world > 1:
+            # the path's one exchange step: all-gather of {n, kps, desc, uRight} for cross-frame matching
+            fe.pack_gather_block(block, sptr)
+            dist.all_gather_into_tensor(gathered, block)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    fe.sync()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    fe.sync()                                           # also checks the device-side consistency flag
+    fast_sum_ms, fast_n = fe.fast_ms_stats(min(args.steps, 64))
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_pairs = P * args.steps * world
+    value = total_pairs / dt
+
+    # sanity on the last batch: keypoints were really produced and matched
+    r0 = fe.fetch(0, 0)
+    assert len(r0["kps"]) > NFEAT // 2 and (r0["uright"] >= 0).sum() > 20, "degenerate output"
+
+    if rank == 0:
+        imgs_per_launch = 2 * P
+        algo_bytes = (LEVEL_PX_SUM + NFEAT * 8) * imgs_per_launch      # pyramid read + candidate output
+        fast_ms = fast_sum_ms / max(fast_n, 1)
+        achieved = algo_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
+        out = {
+            "metric": METRIC, "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": ("configs[2] extractor side: 1242x375 stereo stream, cost maps gating keypoints"
+                                    if args.introspect else
+                                    "configs[1]: 1242x375 stereo pair stream, ORB extract + L/R Hamming match, introspection OFF"),
+                       "pairs_per_step_per_gpu": P, "distinct_pairs_per_gpu": n_stream, "nfeatures": NFEAT,
+                       "nlevels": 8, "scale_factor": 1.2, "fast_thresholds": [20, 7],
+                       "parallelism": "frames sharded %d-way, RCCL all-gather of descriptor blocks" % world if world > 1 else "1 GPU"},
+            "roofline": {"kernel": "k_fast_nms", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(fast_ms, 5),
+                         "launches_timed": fast_n},
+        }
+        if not args.no_cpu_baseline:
+            cores = max(1, min(os.cpu_count() or 1, 32))
+            sample = max(128, 8 * cores)
+            v, secs = cpu_baseline(sample, cores)
+            out["cpu_baseline"] = {"value": round(v, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
+                                   "sample": "%d pairs of the same 1242x375/1000-feature workload, one pair per thread, "
+                                             "%.1f s wall (oracle/libivf_oracle.so, scalar C, -O3 -ffp-contract=off)" % (sample, secs)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

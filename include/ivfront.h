@@ -160,6 +160,9 @@ int  ivf_frontend_fetch(ivf_frontend* fe, int pair, int side, ivf_keypoint* kps,
 /* Elapsed milliseconds of the dominant kernel (FAST score + NMS) in the last run, from HIP events
  * recorded on the run's stream around that launch (bench.py's roofline leg); <0 if unavailable. */
 float ivf_frontend_last_fast_ms(ivf_frontend* fe);
+/* Same measurement summed over the last `last_n` runs (<= 64 are kept; last_n < 1 = all kept):
+ * *sum_ms = total milliseconds, *n_out = number of launches summed.  Synchronises on those events. */
+int   ivf_frontend_fast_ms_stats(ivf_frontend* fe, int last_n, double* sum_ms, int* n_out);
 /* Pack this rank's results of the last run for a descriptor all-gather: writes into d_block (device)
  * n_pairs fixed-size records {int32 n; int32 pad[3]; ivf_keypoint kps[cap]; uint8 desc[cap][32]; float uright[cap]}
  * and returns the record size in *record_bytes. */

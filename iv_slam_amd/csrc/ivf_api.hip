@@ -81,8 +81,9 @@ struct Context {
     Buffers b{};
     uint8_t* dStage = nullptr;          // single-image host API staging (image + cost)
     size_t stageBytes = 0;
-    hipEvent_t evFast0 = nullptr, evFast1 = nullptr;
-    bool evValid = false;
+    static constexpr int kEvRing = 64;  // HIP event pairs around the FAST+NMS launch of the last kEvRing runs
+    hipEvent_t evFast0[kEvRing] = {}, evFast1[kEvRing] = {};
+    long long nRuns = 0;
     hipStream_t lastStream = nullptr;
 
     int build(const Tables& t, int w, int h, int maxImages, int sides, int dev, bool withStereo);
@@ -227,8 +228,7 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
     }
     HIPCHK(hipMalloc(&b.status, sizeof(int)));
     HIPCHK(hipMemset(b.status, 0, sizeof(int)));
-    HIPCHK(hipEventCreate(&evFast0));
-    HIPCHK(hipEventCreate(&evFast1));
+    for (int i = 0; i < kEvRing; i++) { HIPCHK(hipEventCreate(&evFast0[i])); HIPCHK(hipEventCreate(&evFast1[i])); }
     return IVF_OK;
 }
 
@@ -238,8 +238,10 @@ void Context::release()
     void* ptrs[] = {dc, dI32, dI16, b.pyr, b.qpyr, b.blur, b.nms, b.cand, b.lvl, b.slotPos, b.slotResp, b.lvlCount,
                     b.useCost, b.kps, b.desc, b.count, b.quality, b.uright, b.depth, b.sad, b.status, dStage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (evFast0) (void)hipEventDestroy(evFast0);
-    if (evFast1) (void)hipEventDestroy(evFast1);
+    for (int i = 0; i < kEvRing; i++) {
+        if (evFast0[i]) (void)hipEventDestroy(evFast0[i]);
+        if (evFast1[i]) (void)hipEventDestroy(evFast1[i]);
+    }
     *this = Context();
 }
 
@@ -259,10 +261,11 @@ int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size
         launch_ingest(hc, dc, b, cost, cost, costStride, costRowStride, nImg, nSides, b.qpyr, st);
         launch_pyramid(hc, dc, rtab, dI32, dI16, b.qpyr, nImg, st);
     }
-    HIPCHK(hipEventRecord(evFast0, st));
+    const int slot = (int)(nRuns % kEvRing);
+    HIPCHK(hipEventRecord(evFast0[slot], st));
     launch_fast(hc, dc, b, nImg, st);
-    HIPCHK(hipEventRecord(evFast1, st));
-    evValid = true;
+    HIPCHK(hipEventRecord(evFast1[slot], st));
+    nRuns++;
     launch_select(hc, dc, b, nImg, st);
     launch_blur(hc, dc, b, nImg, st);
     launch_describe(hc, dc, b, nullptr, 0, 0, nImg, nSides, st);
@@ -749,12 +752,27 @@ int ivf_frontend_fetch(ivf_frontend* fe, int pair, int side, ivf_keypoint* kps, 
 
 float ivf_frontend_last_fast_ms(ivf_frontend* fe)
 {
-    if (!fe || !fe->ctx.evValid) return -1.f;
-    if (hipSetDevice(fe->cfg.device_id) != hipSuccess) return -1.f;
-    if (hipEventSynchronize(fe->ctx.evFast1) != hipSuccess) return -1.f;
-    float ms = -1.f;
-    if (hipEventElapsedTime(&ms, fe->ctx.evFast0, fe->ctx.evFast1) != hipSuccess) return -1.f;
-    return ms;
+    double sum = 0; int n = 0;
+    if (ivf_frontend_fast_ms_stats(fe, 1, &sum, &n) != IVF_OK || n < 1) return -1.f;
+    return (float)sum;
+}
+
+int ivf_frontend_fast_ms_stats(ivf_frontend* fe, int last_n, double* sum_ms, int* n_out)
+{
+    if (!fe || !sum_ms || !n_out) return fail(IVF_E_INVALID, "null argument");
+    *sum_ms = 0; *n_out = 0;
+    Context& c = fe->ctx;
+    HIPCHK(hipSetDevice(fe->cfg.device_id));
+    const long long avail = std::min<long long>(c.nRuns, Context::kEvRing);
+    const long long take = std::min<long long>(avail, last_n < 1 ? avail : last_n);
+    for (long long r = c.nRuns - take; r < c.nRuns; r++) {
+        const int slot = (int)(r % Context::kEvRing);
+        HIPCHK(hipEventSynchronize(c.evFast1[slot]));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, c.evFast0[slot], c.evFast1[slot]));
+        *sum_ms += ms; (*n_out)++;
+    }
+    return IVF_OK;
 }
 
 int ivf_frontend_pack_gather_block(ivf_frontend* fe, uint8_t* d_block, size_t block_bytes, size_t* record_bytes, void* hip_stream)

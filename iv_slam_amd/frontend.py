@@ -52,6 +52,12 @@ class StereoFrontend:
     def last_fast_ms(self):
         return float(self._lib.ivf_frontend_last_fast_ms(self._h))
 
+    def fast_ms_stats(self, last_n=0):
+        """(sum_ms, n) of the FAST+NMS launch over the last `last_n` runs (HIP events on the run's stream)."""
+        s = C.c_double(0); n = C.c_int(0)
+        check(self._lib.ivf_frontend_fast_ms_stats(self._h, last_n, C.byref(s), C.byref(n)))
+        return s.value, n.value
+
     def fetch(self, pair, side):
         cap = self.nfeatures
         kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
