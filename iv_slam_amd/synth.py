@@ -41,6 +41,10 @@ def make_left(width, height, seed=0, idx=0, n_rect=400, n_dots=200, flat_rows=60
     fr = min(flat_rows, height // 4)
     img[:fr, :] = 128.0
     img[:fr, :] += 3.0 * np.sin(xx[:fr, :] / 37.0)
+    # weak corners (contrast 14 < iniThFAST=20, > minThFAST=7): only the minThFAST re-run finds them
+    for _ in range(max(6, width // 30)):
+        x = int(r.integers(20, max(21, width - 24))); y = int(r.integers(min(20, fr - 4), max(min(20, fr - 4) + 1, fr - 4)))
+        img[y:y + 3, x:x + 3] += float(r.choice([-14, 14]))
     noise = r.integers(-2, 3, size=img.shape)
     return np.clip(np.rint(img) + noise, 0, 255).astype(np.uint8)
 

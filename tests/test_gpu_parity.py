@@ -234,3 +234,28 @@ def test_full_size_properties(iv):
         assert len(s) <= [217, 181, 151, 126, 105, 87, 73, 60][l]
         assert len(set(zip(x.tolist(), y.tolist()))) == len(s)                # NMS: no duplicate positions
     assert ((k1["angle"] >= 0) & (k1["angle"] < 360.0001)).all() and (k1["response"] >= 7).all()
+
+
+def test_committed_golden_fixtures(iv):
+    """HIP path against the committed fixtures (tests/golden, frozen oracle outputs on seeded inputs)."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "mini_320x200.npz"))
+    for prefix, cost, intro in (("plain_", None, False), ("intro_", g["cost"], True)):
+        eL = iv.ORBextractor(300, 1.2, 8, 20, 7, intro); eR = iv.ORBextractor(300, 1.2, 8, 20, 7, False)
+        kL, dL = eL(g["left"], cost); kR, dR = eR(g["right"], cost)
+        ur, dp = iv.ComputeStereoMatches(eL, eR, kL, dL, kR, dR, BF, B)
+        assert kL.tobytes() == g[prefix + "kpsL"].tobytes() and kR.tobytes() == g[prefix + "kpsR"].tobytes()
+        assert np.array_equal(dL, g[prefix + "descL"]) and np.array_equal(dR, g[prefix + "descR"])
+        assert ur.tobytes() == g[prefix + "uright"].tobytes() and dp.tobytes() == g[prefix + "depth"].tobytes()
+        assert eL.level_counts() == g[prefix + "level_counts"].tolist()
+    k = np.load(os.path.join(gold, "kitti_1242x375.npz"))
+    L, R = synth.make_pair(1242, 375, seed=int(k["seed"][0]), idx=int(k["seed"][1]))
+    cost = synth.make_cost_map(1242, 375, seed=int(k["seed"][0]), idx=int(k["seed"][1]))
+    for prefix, c, intro, n in (("plain_", None, False, 1000), ("intro_", cost, True, 1000), ("n2000_", None, False, 2000)):
+        eL = iv.ORBextractor(n, 1.2, 8, 20, 7, intro); eR = iv.ORBextractor(n, 1.2, 8, 20, 7, False)
+        kL, dL = eL(L, c); kR, dR = eR(R, c)
+        ur, dp = iv.ComputeStereoMatches(eL, eR, kL, dL, kR, dR, BF, B)
+        assert kL.tobytes() == k[prefix + "kpsL"].tobytes() and np.array_equal(dL, k[prefix + "descL"])
+        assert kR.tobytes() == k[prefix + "kpsR"].tobytes() and np.array_equal(dR, k[prefix + "descR"])
+        assert ur.tobytes() == k[prefix + "uright"].tobytes() and dp.tobytes() == k[prefix + "depth"].tobytes()

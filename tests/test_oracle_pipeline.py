@@ -1,0 +1,149 @@
+"""CPU tests of the oracle pipeline: committed golden fixtures, reference quirks,
+edge cases and domain properties.  No GPU."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from iv_slam_amd import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BF, B = 386.1448, 386.1448 / 718.856
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+
+def run_case(L, R, cost, n, introspection):
+    eL = O.Extractor(n, 1.2, 8, 20, 7, introspection); eR = O.Extractor(n, 1.2, 8, 20, 7, False)
+    kL, dL = eL(L, cost); kR, dR = eR(R, cost)
+    ur, dp = O.stereo_match(eL, eR, kL, dL, kR, dR, BF, B)
+    return eL, dict(kpsL=kL, descL=dL, kpsR=kR, descR=dR, uright=ur, depth=dp,
+                    pyr_crc=np.array([crc(eL.pyramid(l)) for l in range(8)], np.uint32),
+                    level_counts=np.array(eL.level_counts(), np.int32))
+
+
+def check_against(gold, prefix, got):
+    for k, v in got.items():
+        g = gold[prefix + k]
+        assert g.dtype == v.dtype and g.shape == v.shape, k
+        assert g.tobytes() == v.tobytes(), "golden mismatch in %s%s" % (prefix, k)
+
+
+def test_golden_mini():
+    g = np.load(os.path.join(GOLD, "mini_320x200.npz"))
+    L, R, cost = g["left"], g["right"], g["cost"]
+    _, got = run_case(L, R, None, 300, False); check_against(g, "plain_", got)
+    _, got = run_case(L, R, cost, 300, True); check_against(g, "intro_", got)
+
+
+def test_golden_full_size():
+    g = np.load(os.path.join(GOLD, "kitti_1242x375.npz"))
+    seed, idx = g["seed"]
+    L, R = synth.make_pair(1242, 375, seed=int(seed), idx=int(idx))
+    cost = synth.make_cost_map(1242, 375, seed=int(seed), idx=int(idx))
+    assert [crc(L), crc(R), crc(cost)] == g["in_crc"].tolist(), "synthetic generator drifted (numpy version?)"
+    _, got = run_case(L, R, None, 1000, False); check_against(g, "plain_", got)
+    _, got = run_case(L, R, cost, 1000, True); check_against(g, "intro_", got)
+    _, got = run_case(L, R, None, 2000, False); check_against(g, "n2000_", got)
+    assert g["plain_pyr_dims"].tolist() == [[375, 1242], [312, 1035], [260, 862], [217, 719], [181, 599], [151, 499], [126, 416], [105, 347]]
+    assert g["plain_level_counts"].tolist() == [217, 181, 151, 126, 105, 87, 73, 60]
+
+
+def test_stale_hy_quirk_with_zero_cost_map():
+    """Appendix D-2: with introspection on, every cell row uses the LAST row's height, so the bottom rows of
+    each cell are never scanned.  A zero cost map leaves weights/quotas/responses untouched, isolating the quirk."""
+    img = synth.make_left(1242, 375, seed=13, idx=0)
+    zero = np.zeros_like(img)
+    plain, _ = O.Extractor(1000, 1.2, 8, 20, 7, False)(img)
+    intro, _ = O.Extractor(1000, 1.2, 8, 20, 7, True)(img, zero)
+    assert plain.tobytes() != intro.tobytes()
+    # level 0 @1242x375, N=1000: 3x9 grid, cellH=38, last row height 337-8*38 = 33
+    y0 = intro[intro["octave"] == 0]["y"].astype(int)
+    assert ((y0 - 19) % 38 < 33).all()
+    yp = plain[plain["octave"] == 0]["y"].astype(int)
+    assert ((yp - 19) % 38 >= 33).any()
+    # responses are unscaled integers (factor 2*(1/(1+0))-1 == 1)
+    assert np.array_equal(intro["response"], np.rint(intro["response"]))
+    # an extractor built WITHOUT introspection ignores the mask entirely (right extractor, D-7)
+    ign, _ = O.Extractor(1000, 1.2, 8, 20, 7, False)(img, zero)
+    assert ign.tobytes() == plain.tobytes()
+
+
+def test_cost_map_scales_responses_and_moves_quota():
+    img = synth.make_left(640, 240, seed=14, idx=0)
+    cost = np.zeros_like(img); cost[:, 320:] = 255            # right half is "unreliable"
+    k, _ = O.Extractor(500, 1.2, 8, 20, 7, True)(img, cost)
+    k0, _ = O.Extractor(500, 1.2, 8, 20, 7, True)(img, np.zeros_like(img))
+    lvl0 = k[k["octave"] == 0]; ref0 = k0[k0["octave"] == 0]
+    assert (lvl0["x"] >= 330).sum() < (ref0["x"] >= 330).sum()          # quota moved away from the costly half
+    right = lvl0[lvl0["x"] >= 330]
+    assert (right["response"] == 0).all() or len(right) == 0            # factor 2*(1/(1+255/255))-1 == 0
+
+
+def test_threshold_fallback_in_flat_band():
+    """ORBextractor.cc:1047-1052: cells with <=3 keypoints at iniThFAST are re-run at minThFAST."""
+    img = synth.make_left(1242, 375, seed=15, idx=0)
+    k, _ = O.Extractor(1000, 1.2, 8, 20, 7)(img)
+    band = k[(k["octave"] == 0) & (k["y"] < 57)]
+    assert len(band) > 0 and (band["response"] < 20).any() and (band["response"] >= 7).all()
+
+
+def test_extractor_edge_cases():
+    e = O.Extractor(1000, 1.2, 8, 20, 7)
+    k, d = e(np.full((200, 320), 9, np.uint8))
+    assert len(k) == 0 and d.shape == (0, 32)
+    tiny = synth.make_left(120, 90, seed=2, idx=0)
+    k, d = O.Extractor(200, 1.2, 8, 20, 7)(tiny)
+    assert len(k) > 0 and k["octave"].max() <= 4        # levels 5+ (48x36 ...) are smaller than the 19-px borders
+    assert (np.diff(k["octave"]) >= 0).all()
+    # capacity error is reported, not silently truncated
+    with pytest.raises(RuntimeError):
+        O.Extractor(1000, 1.2, 8, 20, 7)(synth.make_left(640, 240, 1, 0), cap=10)
+
+
+def test_stereo_properties_and_empty_inputs():
+    L, R = synth.make_pair(1242, 375, seed=16, idx=0)
+    eL = O.Extractor(1000, 1.2, 8, 20, 7); eR = O.Extractor(1000, 1.2, 8, 20, 7)
+    kL, dL = eL(L); kR, dR = eR(R)
+    ur, dp = O.stereo_match(eL, eR, kL, dL, kR, dR, BF, B)
+    m = ur >= 0
+    assert m.sum() > 150
+    disp = kL["x"][m] - ur[m]
+    assert (disp > 0).all() and (disp < BF / B).all()
+    assert np.array_equal(dp[m], (np.float32(BF) / disp.astype(np.float32)).astype(np.float32))
+    assert (dp[~m] == -1).all()
+    # the synthetic right image is the left shifted by 4..64 px per 48-row band: most matches recover it
+    assert np.mean((disp > 3) & (disp < 66)) > 0.9
+    ur0, dp0 = O.stereo_match(eL, eR, kL, dL, kR[:0], dR[:0], BF, B)
+    assert (ur0 == -1).all() and (dp0 == -1).all()                 # no candidates => no gate (Appendix D-8)
+    ur1, _ = O.stereo_match(eL, eR, kL[:0], dL[:0], kR, dR, BF, B)
+    assert len(ur1) == 0
+
+
+def test_search_by_projection_greedy_and_rotation_filter():
+    img = synth.make_left(640, 240, seed=17, idx=0)
+    kps, desc = O.Extractor(500, 1.2, 8, 20, 7)(img)
+    n = len(kps)
+    sc = O.Extractor(500, 1.2, 8, 20, 7).tables()["scale"]
+    q = dict(u=kps["x"].copy(), v=kps["y"].copy(), ur=np.zeros(n, np.float32), radius=(7 * sc[kps["octave"]]).astype(np.float32),
+             min_level=(kps["octave"] - 1).astype(np.int32), max_level=(kps["octave"] + 1).astype(np.int32),
+             angle=kps["angle"].copy(), desc=desc.copy(), valid=np.ones(n, np.uint8), blocks=np.ones(n, np.uint8))
+    ur = np.full(n, -1, np.float32)
+    a, nm = O.search_by_projection(kps, desc, ur, (0, 0, 640, 240), q, True)
+    # identical frame: every query matches itself at distance 0 (unless an earlier query took it)
+    assert nm == (a >= 0).sum() and nm > 0.9 * n
+    assert (a[a >= 0] == np.nonzero(a >= 0)[0]).mean() > 0.95
+    # rotate 4% of the queries by 90 degrees: their bin holds < 0.1*max, so the histogram filter removes them
+    q2 = dict(q); ang = q["angle"].copy(); sel = np.arange(n) % 25 == 0; ang[sel] = (ang[sel] + 90) % 360; q2["angle"] = ang
+    a2, nm2 = O.search_by_projection(kps, desc, ur, (0, 0, 640, 240), q2, True)
+    assert nm2 < nm and (a2[sel[:len(a2)]] == -1).mean() > 0.8
+    a3, nm3 = O.search_by_projection(kps, desc, ur, (0, 0, 640, 240), q2, False)
+    assert nm3 == nm
+    # pre-occupied features (-2) are never taken
+    pre = np.full(n, -1, np.int32); pre[:50] = -2
+    a4, _ = O.search_by_projection(kps, desc, ur, (0, 0, 640, 240), q, True, pre)
+    assert (a4[:50] == -2).all()
