@@ -1,0 +1,39 @@
+"""Shared helpers of the FCN tests: rebuild the seeded weights / inputs a golden fixture was made with."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def bgr_image(w, h, seed):
+    from iv_slam_amd import synth
+    return np.stack([synth.make_left(w, h, seed=seed, idx=c) for c in range(3)], axis=-1)
+
+
+def load_case(tag):
+    from iv_slam_amd import fcn_weights
+    g = np.load(os.path.join(GOLD, "fcn_%s.npz" % tag))
+    seed = int(g["seed"][0]); w, h = (int(v) for v in g["size"])
+    W = fcn_weights.make_seeded_weights(seed)
+    W["decoder.conv_last.weight"] = g["conv_last_weight"]
+    W["decoder.conv_last.bias"] = g["conv_last_bias"]
+    return g, W, bgr_image(w, h, 50 + seed), (h, w)
+
+
+def check_against_golden(g, cost, u8, tol=1e-3):
+    """cost maps within `tol` of the reference CPU path (north-star bar 1e-3); u8 = trunc(cost*255) may differ by one
+    LSB from the reference only where the reference's value sits within tol*255 of a truncation boundary."""
+    ref = g["cost_sub"]; got = cost[::6, ::6]
+    err = float(np.abs(got - ref).max())
+    assert err < tol, "cost map differs from the reference by %.3g" % err
+    ru8 = g["u8_sub"].astype(np.int32); gu8 = u8[::6, ::6].astype(np.int32)
+    d = np.abs(ru8 - gu8)
+    assert d.max() <= 1
+    frac = (ref.astype(np.float64) * 255.0) % 1.0
+    near = np.minimum(frac, 1.0 - frac) < tol * 255.0
+    assert (d[~near] == 0).all()
+    return err
