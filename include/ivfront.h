@@ -169,6 +169,25 @@ int   ivf_frontend_fast_ms_stats(ivf_frontend* fe, int last_n, double* sum_ms, i
 int  ivf_frontend_pack_gather_block(ivf_frontend* fe, uint8_t* d_block, size_t block_bytes, size_t* record_bytes,
                                     void* hip_stream);
 
+/* ---- introspection FCN forward (IF/networks/models_light/models_light.py:18-28; called at
+ * ORB/Examples/Stereo/stereo_kitti.cc:231-247 (load) and :493-514 (pre-process, forward, u8 truncation)) ----
+ * weights_blob: the model's state_dict f32 tensors in state_dict order, num_batches_tracked skipped
+ * (tools/export_fcn_weights.py; 2,189,666 floats).  Input = BGR u8 image (what cv::imread returns), in_width x
+ * in_height; output = cost map out_width x out_height (the reference sets out_size = image size because the
+ * extractor builds the cost pyramid from the mask's own dimensions, ORB/src/ORBextractor.cc:1330-1331). */
+typedef struct ivf_fcn ivf_fcn;
+int  ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int in_height, int out_width, int out_height,
+                    int max_batch, int device_id, ivf_fcn** out);
+void ivf_fcn_destroy(ivf_fcn* f);
+/* one image, host buffers: bgr rows of `stride` bytes; cost_u8 = (uint8)(cost*255) (truncation, :511), rows of
+ * cost_stride bytes; cost_f32 (nullable) = the f32 map [out_height*out_width].  Either output may be NULL. */
+int  ivf_fcn_forward(ivf_fcn* f, const uint8_t* bgr, int width, int height, int stride,
+                     uint8_t* cost_u8, int cost_stride, float* cost_f32);
+/* batch, device buffers: d_bgr = n interleaved BGR images (image i at base + i*image_stride, rows of row_stride
+ * bytes); d_cost_u8 [n][out_h][out_w] and/or d_cost_f32 [n][out_h][out_w]; asynchronous on hip_stream. */
+int  ivf_fcn_forward_device(ivf_fcn* f, const uint8_t* d_bgr, size_t image_stride, int row_stride, int n,
+                            uint8_t* d_cost_u8, float* d_cost_f32, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,10 @@ _SIGS = {
     "ivf_frontend_last_fast_ms": (C.c_float, [vp]),
     "ivf_frontend_fast_ms_stats": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "ivf_frontend_pack_gather_block": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]),
+    "ivf_fcn_create": (C.c_int, [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "ivf_fcn_destroy": (None, [vp]),
+    "ivf_fcn_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "ivf_fcn_forward_device": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp, vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 

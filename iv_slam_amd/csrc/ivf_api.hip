@@ -15,13 +15,7 @@ namespace {
 
 thread_local std::string g_err;
 
-int fail(int code, const char* fmt, ...)
-{
-    char buf[512];
-    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    g_err = buf;
-    return code;
-}
+#define fail ivf::set_error
 #define HIPCHK(expr)                                                                                   \
     do { hipError_t e_ = (expr);                                                                        \
          if (e_ != hipSuccess) return fail(IVF_E_NO_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
@@ -292,6 +286,14 @@ int have_device(int dev)
 }
 
 }  // namespace
+
+int ivf::set_error(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
 
 struct ivf_extractor {
     Tables t;

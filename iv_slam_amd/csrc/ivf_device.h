@@ -84,6 +84,9 @@ struct StereoArgs {
     float bf, bb;
 };
 
+// thread-local error message behind ivf_last_error() (ivf_api.hip)
+int set_error(int code, const char* fmt, ...);
+
 // launchers (ivf_kernels.hip)
 void launch_stereo_args(const Config& hc, const Config* dc, const StereoArgs& A, int nPairs, hipStream_t s);
 void launch_ingest(const Config& hc, const Config* dc, const Buffers& b, const uint8_t* src0, const uint8_t* src1,

@@ -1,0 +1,537 @@
+// ivf_fcn.hip -- introspection FCN forward pass on gfx950.
+//
+// Reference: IntrospectionModule.forward (IF/networks/models_light/models_light.py:18-28) = bilinear resize to
+// 512x512 -> MobileNetV2 dilated to output stride 8 (models_light.py:99-172, mobilenet.py:35-110) -> C1 decoder
+// (models_light.py:176-204) -> bilinear to out_size -> sigmoid(20(x-0.5)); called from C++ at
+// ORB/Examples/Stereo/stereo_kitti.cc:493-514 (BGR->RGB, /255, -mean, /std, NCHW; (y*255).to(u8) truncation).
+//
+// Layout: NCHW f32 planes (pixels contiguous).  That makes the activation operand of a 1x1 convolution a
+// coalesced 128-byte row per channel and needs no LDS transposes:
+//   D[cout][pixel] += W[cout][k] * X[k][pixel]   on v_mfma_f32_32x32x2_f32 (exact f32 fma chain; the 1e-3 bound
+//   after the slope-5 logistic leaves no room for bf16 inputs), A = weights pre-shuffled on the host into the
+//   MFMA A-fragment order, B = activations loaded straight from global as float/float2/float4 per lane,
+//   C/D rows = output channels, columns = pixels, so each accumulator register stores a contiguous pixel run.
+// BN (eval mode, eps 1e-5) is folded into per-channel scale/shift at load; ReLU6 / ReLU / residual add are fused
+// into the GEMM and depthwise epilogues.  Depthwise 3x3 (stride/dilation) is an HBM-bound VALU stencil.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "ivf_device.h"
+
+#define ffail ivf::set_error
+
+// kernels live in a NAMED namespace: __global__ functions with internal linkage (anonymous namespace)
+// failed to resolve at launch on ROCm 7 when the .so holds several HIP translation units
+namespace ivffcn {
+
+#define FHIP(expr)                                                                                   \
+    do { hipError_t e_ = (expr);                                                                      \
+         if (e_ != hipSuccess) return ffail(IVF_E_NO_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kEnc = 512;                      // encoder input size (IF/config: enc_input_size)
+
+// ---- pre-processing + bilinear resize to 512x512 (stereo_kitti.cc:494-506, models_light.py:19-21) ----
+__global__ void k_fcn_prep(const uint8_t* __restrict__ bgr, size_t imageStride, int rowStride, int w, int h,
+                           float* __restrict__ out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= kEnc) return;
+    const float sy_ = (float)h / (float)kEnc, sx_ = (float)w / (float)kEnc;
+    float fy = sy_ * ((float)y + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
+    float fx = sx_ * ((float)x + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
+    int y0 = (int)fy; if (y0 > h - 1) y0 = h - 1;
+    int x0 = (int)fx; if (x0 > w - 1) x0 = w - 1;
+    const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
+    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+    const uint8_t* I = bgr + (size_t)b * imageStride;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int sc = 2 - c;                       // BGR -> RGB
+        auto px = [&](int yy, int xx) { return ((float)I[(size_t)yy * rowStride + xx * 3 + sc] * (1.0f / 255.0f) - mean[c]) / stdv[c]; };
+        const float top = px(y0, x0) * lx0 + px(y0, x1) * lx1;
+        const float bot = px(y1, x0) * lx0 + px(y1, x1) * lx1;
+        out[(((size_t)b * 3 + c) * kEnc + y) * kEnc + x] = top * ly0 + bot * ly1;
+    }
+}
+
+// ---- features[0]: conv 3x3 stride 2 pad 1, 3 -> 32, + BN + ReLU6 (mobilenet.py:19-24) ----
+__global__ __launch_bounds__(256) void k_fcn_conv0(const float* __restrict__ X, const float* __restrict__ Wt,
+                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                  float* __restrict__ Y)
+{
+    __shared__ float sw[32 * 27];
+    __shared__ float ss[64];
+    for (int i = threadIdx.x; i < 32 * 27; i += 256) sw[i] = Wt[i];
+    if (threadIdx.x < 32) { ss[threadIdx.x] = scale[threadIdx.x]; ss[32 + threadIdx.x] = shift[threadIdx.x]; }
+    __syncthreads();
+    const int O = kEnc / 2;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= O) return;
+    float v[27];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                const int yy = 2 * y - 1 + ky, xx = 2 * x - 1 + kx;
+                v[(c * 3 + ky) * 3 + kx] = (yy >= 0 && yy < kEnc && xx >= 0 && xx < kEnc)
+                                               ? X[(((size_t)b * 3 + c) * kEnc + yy) * kEnc + xx] : 0.f;
+            }
+    for (int co = 0; co < 32; co++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 27; k++) acc += sw[co * 27 + k] * v[k];
+        float r = acc * ss[co] + ss[32 + co];
+        r = fminf(fmaxf(r, 0.f), 6.f);
+        Y[(((size_t)b * 32 + co) * O + y) * O + x] = r;
+    }
+}
+
+// ---- depthwise 3x3 (stride s, dilation d, pad d) + BN + ReLU6 (mobilenet.py:46,54; models_light.py:139-152) ----
+__global__ void k_fcn_dw(const float* __restrict__ X, const float* __restrict__ Wt, const float* __restrict__ scale,
+                         const float* __restrict__ shift, float* __restrict__ Y, int C, int Hi, int Wi, int Ho, int Wo,
+                         int stride, int dil)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int bc = blockIdx.z;                 // b*C + c
+    if (x >= Wo) return;
+    const int c = bc % C;
+    const float* I = X + (size_t)bc * Hi * Wi;
+    const float* wk = Wt + c * 9;
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) {
+        const int yy = y * stride - dil + ky * dil;
+        if (yy < 0 || yy >= Hi) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            const int xx = x * stride - dil + kx * dil;
+            if (xx >= 0 && xx < Wi) acc += wk[ky * 3 + kx] * I[(size_t)yy * Wi + xx];
+        }
+    }
+    float r = acc * scale[c] + shift[c];
+    r = fminf(fmaxf(r, 0.f), 6.f);
+    Y[(size_t)bc * Ho * Wo + (size_t)y * Wo + x] = r;
+}
+
+// ---- 1x1 (TAPS=1) / dense 3x3 pad 1 (TAPS=9) convolution as an MFMA GEMM ----
+//   wave tile: 32*NT output channels x 32*PT pixels; workgroup = 4 waves along the pixel axis.
+//   Wf: A fragments, index ((tap*K2 + k2) * nTiles + tile) * 64 + lane = W[tile*32 + (lane&31)][2*k2 + (lane>>5)][tap]
+//   act: 0 none, 1 ReLU6, 2 ReLU.  res: optional residual (same shape as Y).
+template <int PT> struct VecT;
+template <> struct VecT<1> { typedef float T; };
+template <> struct VecT<2> { typedef float2 T; };
+template <> struct VecT<4> { typedef float4 T; };
+template <int PT> __device__ __forceinline__ float vget(const typename VecT<PT>::T& v, int i);
+template <> __device__ __forceinline__ float vget<1>(const float& v, int) { return v; }
+template <> __device__ __forceinline__ float vget<2>(const float2& v, int i) { return i ? v.y : v.x; }
+template <> __device__ __forceinline__ float vget<4>(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+template <int PT, int NT, int TAPS>
+__global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, const float* __restrict__ Wf,
+                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                 const float* __restrict__ res, float* __restrict__ Y,
+                                                 int Cin, int Cout, int Hd, int Wd, int nTiles, int act)
+{
+    typedef typename VecT<PT>::T vec;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int HW = Hd * Wd;
+    const int b = blockIdx.z;
+    const int p0 = (blockIdx.x * 4 + wave) * 32 * PT + PT * col;      // first pixel of this lane
+    const int ct0 = blockIdx.y * NT;
+    const int K2 = Cin / 2;
+    f32x16 acc[NT][PT];
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int p = 0; p < PT; p++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[n][p][r] = 0.f;
+    const float* Xb = X + (size_t)b * Cin * HW + (size_t)half * HW;
+    const float* wp = Wf + (size_t)ct0 * 64 + lane;
+
+    if (TAPS == 1) {
+        const float* xp = Xb + p0;
+#pragma unroll 2
+        for (int k2 = 0; k2 < K2; k2++) {
+            const vec bv = *(const vec*)(xp + (size_t)2 * k2 * HW);
+            float a[NT];
+#pragma unroll
+            for (int n = 0; n < NT; n++) a[n] = wp[((size_t)k2 * nTiles + n) * 64];
+#pragma unroll
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int p = 0; p < PT; p++)
+                    acc[n][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n], vget<PT>(bv, p), acc[n][p], 0, 0, 0);
+        }
+    } else {
+        int py[PT], pxx[PT];
+#pragma unroll
+        for (int p = 0; p < PT; p++) { py[p] = (p0 + p) / Wd; pxx[p] = (p0 + p) % Wd; }
+        for (int tap = 0; tap < 9; tap++) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            int off[PT]; bool ok[PT];
+#pragma unroll
+            for (int p = 0; p < PT; p++) {
+                const int yy = py[p] + dy, xx = pxx[p] + dx;
+                ok[p] = yy >= 0 && yy < Hd && xx >= 0 && xx < Wd;
+                off[p] = ok[p] ? yy * Wd + xx : 0;
+            }
+            const float* wt = wp + (size_t)tap * K2 * nTiles * 64;
+#pragma unroll 2
+            for (int k2 = 0; k2 < K2; k2++) {
+                float bv[PT];
+#pragma unroll
+                for (int p = 0; p < PT; p++) { const float t = Xb[(size_t)2 * k2 * HW + off[p]]; bv[p] = ok[p] ? t : 0.f; }
+                float a[NT];
+#pragma unroll
+                for (int n = 0; n < NT; n++) a[n] = wt[((size_t)k2 * nTiles + n) * 64];
+#pragma unroll
+                for (int n = 0; n < NT; n++)
+#pragma unroll
+                    for (int p = 0; p < PT; p++)
+                        acc[n][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n], bv[p], acc[n][p], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: C/D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (output channel)
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = (ct0 + n) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co >= Cout) continue;
+            const float sc = scale[co], sh = shift[co];
+            float o[PT];
+#pragma unroll
+            for (int p = 0; p < PT; p++) {
+                float v = acc[n][p][r] * sc + sh;
+                if (act == 1) v = fminf(fmaxf(v, 0.f), 6.f);
+                else if (act == 2) v = fmaxf(v, 0.f);
+                o[p] = v;
+            }
+            const size_t oi = ((size_t)b * Cout + co) * HW + p0;
+            if (res) {
+#pragma unroll
+                for (int p = 0; p < PT; p++) o[p] += res[oi + p];
+            }
+            if (PT == 4) *(float4*)(Y + oi) = make_float4(o[0], o[1], o[2], o[3]);
+            else if (PT == 2) *(float2*)(Y + oi) = make_float2(o[0], o[1]);
+            else Y[oi] = o[0];
+        }
+}
+
+// ---- conv_last 1x1 80 -> 1 + bias (models_light.py:196) ----
+__global__ void k_fcn_last(const float* __restrict__ X, const float* __restrict__ w, float bias, float* __restrict__ Y,
+                           int C, int HW)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (p >= HW) return;
+    float acc = 0.f;
+    for (int c = 0; c < C; c++) acc += w[c] * X[((size_t)b * C + c) * HW + p];
+    Y[(size_t)b * HW + p] = acc + bias;
+}
+
+// ---- bilinear to out_size, logistic, u8 truncation (models_light.py:198-199, :25-26; stereo_kitti.cc:511) ----
+__global__ void k_fcn_out(const float* __restrict__ L, int lh, int lw, int oh, int ow, float* __restrict__ costF,
+                          uint8_t* __restrict__ costU)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= ow) return;
+    const float sy_ = (float)lh / (float)oh, sx_ = (float)lw / (float)ow;
+    float fy = sy_ * ((float)y + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
+    float fx = sx_ * ((float)x + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
+    int y0 = (int)fy; if (y0 > lh - 1) y0 = lh - 1;
+    int x0 = (int)fx; if (x0 > lw - 1) x0 = lw - 1;
+    const int y1 = y0 + (y0 < lh - 1), x1 = x0 + (x0 < lw - 1);
+    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+    const float* P = L + (size_t)b * lh * lw;
+    const float top = P[y0 * lw + x0] * lx0 + P[y0 * lw + x1] * lx1;
+    const float bot = P[y1 * lw + x0] * lx0 + P[y1 * lw + x1] * lx1;
+    const float v = top * ly0 + bot * ly1;
+    const float z = 20.f * (v - 0.5f);
+    const float c = 1.f / (1.f + expf(-z));
+    const size_t o = ((size_t)b * oh + y) * ow + x;
+    if (costF) costF[o] = c;
+    if (costU) costU[o] = (uint8_t)(c * 255.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: architecture walk, BN folding, A-fragment weight shuffle, launch plan
+// ------------------------------------------------------------------------------------------------
+struct Block { int inp, oup, t, stride, dil; bool res; };
+const Block kBlocks[17] = {
+    {32, 16, 1, 1, 1, false},
+    {16, 24, 6, 2, 1, false}, {24, 24, 6, 1, 1, true},
+    {24, 32, 6, 2, 1, false}, {32, 32, 6, 1, 1, true}, {32, 32, 6, 1, 1, true},
+    {32, 64, 6, 1, 1, false},
+    {64, 64, 6, 1, 2, true}, {64, 64, 6, 1, 2, true}, {64, 64, 6, 1, 2, true},
+    {64, 96, 6, 1, 2, false}, {96, 96, 6, 1, 2, true}, {96, 96, 6, 1, 2, true},
+    {96, 160, 6, 1, 2, false},
+    {160, 160, 6, 1, 4, true}, {160, 160, 6, 1, 4, true},
+    {160, 320, 6, 1, 4, false},
+};
+
+struct Gemm {            // one MFMA convolution
+    int cin, cout, taps, nTiles, NT, PT, act;
+    float *dWf, *dScale, *dShift;
+};
+struct Dw { int c, stride, dil; float *dW, *dScale, *dShift; };
+
+struct Reader {
+    const float* p; size_t left;
+    const float* take(size_t n) { if (n > left) return nullptr; const float* r = p; p += n; left -= n; return r; }
+};
+
+void fold_bn(const float* g, const float* b, const float* m, const float* v, int c, std::vector<float>& sc, std::vector<float>& sh)
+{
+    sc.resize(c); sh.resize(c);
+    for (int i = 0; i < c; i++) {
+        const float inv = 1.0f / std::sqrt(v[i] + 1e-5f);
+        sc[i] = g[i] * inv;
+        sh[i] = b[i] - m[i] * sc[i];
+    }
+}
+
+template <int PT, int NT, int TAPS>
+void launch_gemm_t(const Gemm& g, const float* X, const float* res, float* Y, int H, int W, int B, hipStream_t s)
+{
+    const int HW = H * W;
+    dim3 grid(HW / (128 * PT), g.nTiles / NT, B);
+    hipLaunchKernelGGL((k_fcn_gemm<PT, NT, TAPS>), grid, dim3(256), 0, s, X, g.dWf, g.dScale, g.dShift, res, Y, g.cin,
+                       g.cout, H, W, g.nTiles, g.act);
+}
+void launch_gemm(const Gemm& g, const float* X, const float* res, float* Y, int H, int W, int B, hipStream_t s)
+{
+    if (g.taps == 9) { launch_gemm_t<1, 3, 9>(g, X, res, Y, H, W, B, s); return; }
+    if (g.PT == 4 && g.NT == 1) launch_gemm_t<4, 1, 1>(g, X, res, Y, H, W, B, s);
+    else if (g.PT == 4 && g.NT == 2) launch_gemm_t<4, 2, 1>(g, X, res, Y, H, W, B, s);
+    else if (g.PT == 4 && g.NT == 3) launch_gemm_t<4, 3, 1>(g, X, res, Y, H, W, B, s);
+    else launch_gemm_t<2, 5, 1>(g, X, res, Y, H, W, B, s);
+}
+
+}  // namespace ivffcn
+using namespace ivffcn;
+
+struct ivf_fcn {
+    int device = 0, inW = 0, inH = 0, outW = 0, outH = 0, maxBatch = 0;
+    float *dConv0W = nullptr, *dConv0S = nullptr, *dConv0B = nullptr;
+    std::vector<Gemm> pw;        // in forward order: per block expand (t>1), project; then decoder cbr
+    std::vector<Dw> dw;
+    float* dLastW = nullptr; float lastBias = 0.f;
+    float *bufIn = nullptr, *bufA = nullptr, *bufB = nullptr, *bufH1 = nullptr, *bufH2 = nullptr, *bufLogits = nullptr;
+    uint8_t *dStageIn = nullptr, *dStageU8 = nullptr; float* dStageF = nullptr;
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+int upload(ivf_fcn* f, const std::vector<float>& h, float** d)
+{
+    FHIP(hipMalloc(d, std::max<size_t>(h.size(), 1) * sizeof(float)));
+    f->allocs.push_back(*d);
+    FHIP(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return IVF_OK;
+}
+
+int make_gemm(ivf_fcn* f, const float* w, int cout, int cin, int taps, const std::vector<float>& sc,
+              const std::vector<float>& sh, int act, Gemm& g)
+{
+    g.cin = cin; g.cout = cout; g.taps = taps; g.act = act;
+    const int tiles = (cout + 31) / 32;
+    if (taps == 9) { g.NT = 3; g.PT = 1; }
+    else if (tiles == 5) { g.NT = 5; g.PT = 2; }
+    else { g.NT = tiles >= 3 ? 3 : tiles; g.PT = 4; }
+    g.nTiles = (tiles + g.NT - 1) / g.NT * g.NT;
+    const int K2 = cin / 2;
+    std::vector<float> wf((size_t)taps * K2 * g.nTiles * 64, 0.f);
+    for (int tap = 0; tap < taps; tap++)
+        for (int k2 = 0; k2 < K2; k2++)
+            for (int t = 0; t < g.nTiles; t++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int co = t * 32 + (lane & 31), k = 2 * k2 + (lane >> 5);
+                    if (co < cout) wf[(((size_t)tap * K2 + k2) * g.nTiles + t) * 64 + lane] = w[((size_t)co * cin + k) * taps + tap];
+                }
+    int rc = upload(f, wf, &g.dWf); if (rc) return rc;
+    rc = upload(f, sc, &g.dScale); if (rc) return rc;
+    return upload(f, sh, &g.dShift);
+}
+
+// IVF_FCN_DEBUG=1: synchronise and check after every launch, naming the stage that failed
+#define STAGE(name)                                                                                          \
+    do { if (dbg) { hipError_t e_ = hipStreamSynchronize(s); if (e_ == hipSuccess) e_ = hipGetLastError();   \
+                    fprintf(stderr, "[ivf_fcn] %s: %s\n", name, hipGetErrorString(e_));                      \
+                    if (e_ != hipSuccess) return ffail(IVF_E_NO_DEVICE, "stage %s: %s", name, hipGetErrorString(e_)); } } while (0)
+
+int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowStride, int n, uint8_t* dU8, float* dF,
+                   hipStream_t s)
+{
+    static const bool dbg = getenv("IVF_FCN_DEBUG") != nullptr;
+    char nm[64];
+    hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc, n), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn);
+    STAGE("prep");
+    hipLaunchKernelGGL(k_fcn_conv0, dim3(1, kEnc / 2, n), dim3(256), 0, s, f->bufIn, f->dConv0W, f->dConv0S, f->dConv0B, f->bufA);
+    STAGE("conv0");
+    float *x = f->bufA, *y = f->bufB;
+    int H = kEnc / 2, W = kEnc / 2;
+    size_t ip = 0, id = 0;
+    for (int i = 0; i < 17; i++) {
+        const Block& bk = kBlocks[i];
+        const int hid = bk.inp * bk.t;
+        const float* h = x;
+        if (bk.t != 1) { launch_gemm(f->pw[ip++], x, nullptr, f->bufH1, H, W, n, s); h = f->bufH1; snprintf(nm, sizeof nm, "block %d expand", i + 1); STAGE(nm); }
+        const Dw& d = f->dw[id++];
+        const int Ho = (H + 2 * d.dil - 2 * d.dil - 1) / d.stride + 1, Wo = (W + 2 * d.dil - 2 * d.dil - 1) / d.stride + 1;
+        hipLaunchKernelGGL(k_fcn_dw, dim3((Wo + 63) / 64, Ho, n * hid), dim3(64), 0, s, h, d.dW, d.dScale, d.dShift, f->bufH2,
+                           hid, H, W, Ho, Wo, d.stride, d.dil);
+        snprintf(nm, sizeof nm, "block %d depthwise", i + 1); STAGE(nm);
+        H = Ho; W = Wo;
+        launch_gemm(f->pw[ip++], f->bufH2, bk.res ? x : nullptr, y, H, W, n, s);
+        snprintf(nm, sizeof nm, "block %d project", i + 1); STAGE(nm);
+        std::swap(x, y);
+    }
+    launch_gemm(f->pw[ip++], x, nullptr, f->bufH1, H, W, n, s);                 // decoder cbr: 3x3 320->80 + BN + ReLU
+    STAGE("decoder cbr");
+    hipLaunchKernelGGL(k_fcn_last, dim3((H * W + 255) / 256, n), dim3(256), 0, s, f->bufH1, f->dLastW, f->lastBias,
+                       f->bufLogits, 80, H * W);
+    STAGE("conv_last");
+    hipLaunchKernelGGL(k_fcn_out, dim3((f->outW + 255) / 256, f->outH, n), dim3(256), 0, s, f->bufLogits, H, W, f->outH, f->outW, dF, dU8);
+    FHIP(hipGetLastError());
+    return IVF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int in_height, int out_width, int out_height,
+                   int max_batch, int device_id, ivf_fcn** out)
+{
+    if (!weights_blob || !out) return ffail(IVF_E_INVALID, "null argument");
+    *out = nullptr;
+    if (in_width < 2 || in_height < 2 || out_width < 1 || out_height < 1 || max_batch < 1)
+        return ffail(IVF_E_INVALID, "bad sizes");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return ffail(IVF_E_NO_DEVICE, "no HIP device available; libivfront has no CPU path");
+    if (device_id < 0 || device_id >= ndev) return ffail(IVF_E_INVALID, "device_id %d outside [0,%d)", device_id, ndev);
+    FHIP(hipSetDevice(device_id));
+    ivf_fcn* f = new ivf_fcn();
+    f->device = device_id; f->inW = in_width; f->inH = in_height; f->outW = out_width; f->outH = out_height; f->maxBatch = max_batch;
+    Reader rd{weights_blob, n_floats};
+    auto bad = [&]() { ivf_fcn_destroy(f); return ffail(IVF_E_INVALID, "weight blob too short for the architecture"); };
+    std::vector<float> sc, sh;
+    auto read_bn = [&](int c) -> bool {
+        const float *g = rd.take(c), *b = rd.take(c), *m = rd.take(c), *v = rd.take(c);
+        if (!g || !b || !m || !v) return false;
+        fold_bn(g, b, m, v, c, sc, sh);
+        return true;
+    };
+    int rc;
+    {   // features[0]
+        const float* w = rd.take(32 * 27);
+        if (!w || !read_bn(32)) return bad();
+        std::vector<float> hw(w, w + 32 * 27);
+        if ((rc = upload(f, hw, &f->dConv0W)) || (rc = upload(f, sc, &f->dConv0S)) || (rc = upload(f, sh, &f->dConv0B))) { ivf_fcn_destroy(f); return rc; }
+    }
+    for (int i = 0; i < 17; i++) {
+        const Block& bk = kBlocks[i];
+        const int hid = bk.inp * bk.t;
+        if (bk.t != 1) {
+            const float* w = rd.take((size_t)hid * bk.inp);
+            if (!w || !read_bn(hid)) return bad();
+            Gemm g; if ((rc = make_gemm(f, w, hid, bk.inp, 1, sc, sh, 1, g))) { ivf_fcn_destroy(f); return rc; }
+            f->pw.push_back(g);
+        }
+        {
+            const float* w = rd.take((size_t)hid * 9);
+            if (!w || !read_bn(hid)) return bad();
+            Dw d; d.c = hid; d.stride = bk.stride; d.dil = bk.dil;
+            std::vector<float> hw(w, w + (size_t)hid * 9);
+            if ((rc = upload(f, hw, &d.dW)) || (rc = upload(f, sc, &d.dScale)) || (rc = upload(f, sh, &d.dShift))) { ivf_fcn_destroy(f); return rc; }
+            f->dw.push_back(d);
+        }
+        {
+            const float* w = rd.take((size_t)bk.oup * hid);
+            if (!w || !read_bn(bk.oup)) return bad();
+            Gemm g; if ((rc = make_gemm(f, w, bk.oup, hid, 1, sc, sh, 0, g))) { ivf_fcn_destroy(f); return rc; }
+            f->pw.push_back(g);
+        }
+    }
+    {   // decoder: cbr (3x3 320->80 + BN + ReLU), cbr_deepsup (unused at inference), conv_last, conv_last_deepsup (unused)
+        const float* w = rd.take((size_t)80 * 320 * 9);
+        if (!w || !read_bn(80)) return bad();
+        Gemm g; if ((rc = make_gemm(f, w, 80, 320, 9, sc, sh, 2, g))) { ivf_fcn_destroy(f); return rc; }
+        f->pw.push_back(g);
+        if (!rd.take((size_t)80 * 160 * 9) || !rd.take(4 * 80)) return bad();
+        const float* lw = rd.take(80); const float* lb = rd.take(1);
+        if (!lw || !lb) return bad();
+        std::vector<float> hw(lw, lw + 80);
+        if ((rc = upload(f, hw, &f->dLastW))) { ivf_fcn_destroy(f); return rc; }
+        f->lastBias = lb[0];
+        if (!rd.take(80) || !rd.take(1)) return bad();
+        if (rd.left != 0) { ivf_fcn_destroy(f); return ffail(IVF_E_INVALID, "weight blob has %zu trailing floats", rd.left); }
+    }
+    const size_t B = (size_t)max_batch;
+    auto dalloc = [&](float** p, size_t n) -> int { FHIP(hipMalloc(p, n * sizeof(float))); f->allocs.push_back(*p); return IVF_OK; };
+    const size_t big = (size_t)96 * 256 * 256;           // largest activation: 96 x 256 x 256
+    if ((rc = dalloc(&f->bufIn, B * 3 * kEnc * kEnc)) || (rc = dalloc(&f->bufA, B * 32 * 256 * 256)) ||
+        (rc = dalloc(&f->bufB, B * 32 * 256 * 256)) || (rc = dalloc(&f->bufH1, B * big)) || (rc = dalloc(&f->bufH2, B * big)) ||
+        (rc = dalloc(&f->bufLogits, B * 64 * 64))) { ivf_fcn_destroy(f); return rc; }
+    *out = f;
+    return IVF_OK;
+}
+
+void ivf_fcn_destroy(ivf_fcn* f)
+{
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : f->allocs) (void)hipFree(p);
+    if (f->dStageIn) (void)hipFree(f->dStageIn);
+    if (f->dStageU8) (void)hipFree(f->dStageU8);
+    if (f->dStageF) (void)hipFree(f->dStageF);
+    delete f;
+}
+
+int ivf_fcn_forward_device(ivf_fcn* f, const uint8_t* d_bgr, size_t image_stride, int row_stride, int n,
+                           uint8_t* d_cost_u8, float* d_cost_f32, void* hip_stream)
+{
+    if (!f || !d_bgr || (!d_cost_u8 && !d_cost_f32)) return ffail(IVF_E_INVALID, "null argument");
+    if (n < 1 || n > f->maxBatch) return ffail(IVF_E_INVALID, "batch %d outside [1,%d]", n, f->maxBatch);
+    if (row_stride < 3 * f->inW) return ffail(IVF_E_INVALID, "row_stride too small");
+    FHIP(hipSetDevice(f->device));
+    return forward_device(f, d_bgr, image_stride, row_stride, n, d_cost_u8, d_cost_f32, (hipStream_t)hip_stream);
+}
+
+int ivf_fcn_forward(ivf_fcn* f, const uint8_t* bgr, int width, int height, int stride, uint8_t* cost_u8, int cost_stride,
+                    float* cost_f32)
+{
+    if (!f || !bgr || (!cost_u8 && !cost_f32)) return ffail(IVF_E_INVALID, "null argument");
+    if (width != f->inW || height != f->inH) return ffail(IVF_E_INVALID, "image is %dx%d, handle was created for %dx%d", width, height, f->inW, f->inH);
+    if (stride < 3 * width || (cost_u8 && cost_stride < f->outW)) return ffail(IVF_E_INVALID, "stride too small");
+    FHIP(hipSetDevice(f->device));
+    const size_t inBytes = (size_t)width * 3 * height, outPx = (size_t)f->outW * f->outH;
+    if (!f->dStageIn) {
+        FHIP(hipMalloc(&f->dStageIn, inBytes)); FHIP(hipMalloc(&f->dStageU8, outPx)); FHIP(hipMalloc(&f->dStageF, outPx * sizeof(float)));
+    }
+    FHIP(hipMemcpy2D(f->dStageIn, (size_t)width * 3, bgr, stride, (size_t)width * 3, height, hipMemcpyHostToDevice));
+    int rc = forward_device(f, f->dStageIn, inBytes, width * 3, 1, f->dStageU8, f->dStageF, nullptr);
+    if (rc) return rc;
+    if (cost_u8) FHIP(hipMemcpy2D(cost_u8, cost_stride, f->dStageU8, f->outW, f->outW, f->outH, hipMemcpyDeviceToHost));
+    if (cost_f32) FHIP(hipMemcpy(cost_f32, f->dStageF, outPx * sizeof(float), hipMemcpyDeviceToHost));
+    return IVF_OK;
+}
+
+}  // extern "C"
