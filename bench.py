@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU")
     ap.add_argument("--stream", type=int, default=256, help="distinct pairs resident per GPU")
-    ap.add_argument("--introspect", action="store_true", help="feed seeded cost maps (extractor side of configs[2])")
+    ap.add_argument("--introspect", action="store_true", help="configs[2]: run the introspection FCN on every left image and gate keypoints with it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -101,10 +101,16 @@ def main():
     n_stream = (n_stream + P - 1) // P * P
     left, right = make_device_stream(torch, dev, n_stream, seed=100 + rank)
     cost = None
+    fcn = None
     if args.introspect:
-        import numpy as np
-        cm = np.stack([synth.make_cost_map(W, H, seed=100 + rank, idx=i) for i in range(8)])
-        cost = torch.from_numpy(cm).to(dev).repeat((n_stream + 7) // 8, 1, 1)[:n_stream].contiguous()
+        # configs[2]: the introspection FCN (random-init weights of the deployed architecture; no checkpoints
+        # exist offline) runs on the left colour image of every pair inside the timed step and its u8 cost map
+        # gates keypoint selection in the left extractor.
+        from iv_slam_amd import fcn_weights
+        blob = fcn_weights.pack_blob(fcn_weights.make_seeded_weights(7))
+        fcn = iv.IntrospectionFCN(blob, (H, W), (H, W), max_batch=P, device_id=local_rank)
+        bgr = torch.stack([left, left // 2 + 40, 255 - left // 2], dim=-1).contiguous()      # [n,H,W,3] colour-ish
+        cost = torch.empty((P, H, W), dtype=torch.uint8, device=dev)
     fe = iv.StereoFrontend(W, H, P, nfeatures=NFEAT, enableIntrospection=args.introspect, bf=BF, fx=FX,
                            device_id=local_rank)
     stream = torch.cuda.current_stream(dev)
@@ -116,7 +122,9 @@ def main():
 
     def step(i):
         s = (i % nslices) * P
-        fe.run(left[s:s + P], right[s:s + P], None if cost is None else cost[s:s + P], sptr)
+        if fcn is not None:
+            fcn.forward_device(bgr[s:s + P], cost_u8=cost, stream_ptr=sptr)
+        fe.run(left[s:s + P], right[s:s + P], cost, sptr)
         if world > 1:
             # the path's one exchange step: all-gather of {n, kps, desc, uRight} for cross-frame matching
             fe.pack_gather_block(block, sptr)
@@ -159,7 +167,7 @@ def main():
             "metric": METRIC, "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("configs[2] extractor side: 1242x375 stereo stream, cost maps gating keypoints"
+            "config": {"workload": ("configs[2]: 1242x375 stereo stream with introspection FCN cost-map forward (f32 MFMA convs) gating keypoints"
                                     if args.introspect else
                                     "configs[1]: 1242x375 stereo pair stream, ORB extract + L/R Hamming match, introspection OFF"),
                        "pairs_per_step_per_gpu": P, "distinct_pairs_per_gpu": n_stream, "nfeatures": NFEAT,
