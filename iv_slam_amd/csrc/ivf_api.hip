@@ -70,8 +70,7 @@ struct Context {
     bool introspection = false;
     Config hc{};
     Config* dc = nullptr;
-    ResizeTab rtab[kMaxLevels]{};
-    int* dI32 = nullptr; short* dI16 = nullptr;
+    ResizeCoef* dTab = nullptr;           // packed cv::resize coefficients, all levels
     Buffers b{};
     uint8_t* dStage = nullptr;          // single-image host API staging (image + cost)
     size_t stageBytes = 0;
@@ -91,7 +90,7 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
 {
     device = dev; maxImg = maxImages; nSides = sides;
     introspection = t.p.enable_introspection != 0;
-    if (w < 1 || h < 1 || w > 65535 || h > 65535) return fail(IVF_E_INVALID, "image size %dx%d unsupported", w, h);
+    if (w < 1 || h < 1 || w > 4095 || h > 4095) return fail(IVF_E_INVALID, "image size %dx%d unsupported (max 4095)", w, h);
     Config& c = hc;
     memset(&c, 0, sizeof c);
     c.nlevels = t.p.nlevels; c.w = w; c.h = h; c.nfeatures = t.p.nfeatures;
@@ -142,66 +141,54 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
     }
     c.pyrBytes = align_up(off + 64, 256);
     c.candTotal = std::max(candBase, 1);
+    c.nCellsTotal = std::max(cellBase, 1);
     c.nTiles = tileBase;
     c.nBlurTiles = btileBase;
 
-    // cv::resize coefficient tables (OpenCV resize.cpp, INTER_LINEAR 8U): see oracle/ DESIGN.md A-3
-    std::vector<int> i32; std::vector<short> i16;
-    auto sat = [](float v) { int i = cvRoundF(v); return (short)std::min(32767, std::max(-32768, i)); };
+    // cv::resize coefficient table (OpenCV resize.cpp, INTER_LINEAR 8U): per output column
+    // {clamped sx, a0, a1}, per output row {clipped sy, b0, b1}; x clamps f to 0 at the right edge, y does not.
+    std::vector<ResizeCoef> tab;
+    auto sat = [](float v) { int i = cvRoundF(v); return (unsigned)(unsigned short)std::min(32767, std::max(-32768, i)); };
     for (int l = 1; l < c.nlevels; l++) {
-        const LevelGeom &D = c.lv[l], &S = c.lv[l - 1];
+        LevelGeom& D = c.lv[l]; const LevelGeom& S = c.lv[l - 1];
         const double sx_ = (double)S.w / D.w, sy_ = (double)S.h / D.h;
-        ResizeTab& r = rtab[l];
-        r.xofs = (int)i32.size();
-        for (int dx = 0; dx < D.w; dx++) {
-            float fx = (float)((dx + 0.5) * sx_ - 0.5);
-            int sx = cvFloorF(fx);
-            if (sx < 0) sx = 0;
-            if (sx >= S.w - 1) sx = S.w - 1;
-            i32.push_back(sx);
-        }
-        r.yofs = (int)i32.size();
-        for (int dy = 0; dy < D.h; dy++) { float fy = (float)((dy + 0.5) * sy_ - 0.5); i32.push_back(cvFloorF(fy)); }
-        r.a0 = (int)i16.size();
-        std::vector<short> a1v, b0v, b1v;
+        D.rtX = (int)tab.size();
         for (int dx = 0; dx < D.w; dx++) {
             float fx = (float)((dx + 0.5) * sx_ - 0.5);
             int sx = cvFloorF(fx);
             fx -= sx;
             if (sx < 0) { fx = 0; sx = 0; }
             if (sx >= S.w - 1) { fx = 0; sx = S.w - 1; }
-            i16.push_back(sat((1.f - fx) * 2048.f));
-            a1v.push_back(sat(fx * 2048.f));
+            tab.push_back((ResizeCoef)sx | ((ResizeCoef)sat((1.f - fx) * 2048.f) << 16) | ((ResizeCoef)sat(fx * 2048.f) << 32));
         }
-        r.a1 = (int)i16.size(); i16.insert(i16.end(), a1v.begin(), a1v.end());
+        D.rtY = (int)tab.size();
         for (int dy = 0; dy < D.h; dy++) {
             float fy = (float)((dy + 0.5) * sy_ - 0.5);
             int sy = cvFloorF(fy);
             fy -= sy;
-            b0v.push_back(sat((1.f - fy) * 2048.f));
-            b1v.push_back(sat(fy * 2048.f));
+            // rows are clipped, coefficients are not (VResize reads clip(sy), clip(sy+1)); sy >= 0 for down-scaling
+            const int y0 = std::min(std::max(sy, 0), S.h - 1);
+            ResizeCoef b0 = sat((1.f - fy) * 2048.f), b1 = sat(fy * 2048.f);
+            if (sy < 0) { /* both taps clip to row 0 */ }
+            tab.push_back((ResizeCoef)y0 | (b0 << 16) | (b1 << 32));
         }
-        r.b0 = (int)i16.size(); i16.insert(i16.end(), b0v.begin(), b0v.end());
-        r.b1 = (int)i16.size(); i16.insert(i16.end(), b1v.begin(), b1v.end());
     }
-    if (i32.empty()) i32.push_back(0);
-    if (i16.empty()) i16.push_back(0);
+    if (tab.empty()) tab.push_back(0);
 
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipMalloc(&dc, sizeof(Config)));
     HIPCHK(hipMemcpy(dc, &hc, sizeof(Config), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&dI32, i32.size() * sizeof(int)));
-    HIPCHK(hipMemcpy(dI32, i32.data(), i32.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&dI16, i16.size() * sizeof(short)));
-    HIPCHK(hipMemcpy(dI16, i16.data(), i16.size() * sizeof(short), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&dTab, tab.size() * sizeof(ResizeCoef)));
+    HIPCHK(hipMemcpy(dTab, tab.data(), tab.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice));
     const size_t nI = (size_t)maxImg, nf = (size_t)c.nfeatures, blob = (size_t)c.pyrBytes * nI;
     HIPCHK(hipMalloc(&b.pyr, blob));
     HIPCHK(hipMalloc(&b.blur, blob));
-    HIPCHK(hipMalloc(&b.nms, blob));
     HIPCHK(hipMemset(b.pyr, 0, blob));
-    HIPCHK(hipMemset(b.nms, 0, blob));
     if (introspection) { HIPCHK(hipMalloc(&b.qpyr, blob)); HIPCHK(hipMemset(b.qpyr, 0, blob)); }
-    HIPCHK(hipMalloc(&b.cand, nI * c.candTotal * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&b.rawCand, nI * c.candTotal * sizeof(unsigned)));
+    HIPCHK(hipMalloc(&b.cellCnt, nI * c.nCellsTotal * 2 * sizeof(int)));
+    HIPCHK(hipMalloc(&b.cellInfo, nI * c.nCellsTotal * sizeof(int4)));
+    HIPCHK(hipMalloc(&b.lvlTotal, nI * kMaxLevels * sizeof(int)));
     HIPCHK(hipMalloc(&b.lvl, nI * c.candTotal * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&b.slotPos, nI * nf * sizeof(unsigned)));
     HIPCHK(hipMalloc(&b.slotResp, nI * nf * sizeof(float)));
@@ -229,7 +216,7 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
 void Context::release()
 {
     (void)hipSetDevice(device);
-    void* ptrs[] = {dc, dI32, dI16, b.pyr, b.qpyr, b.blur, b.nms, b.cand, b.lvl, b.slotPos, b.slotResp, b.lvlCount,
+    void* ptrs[] = {dc, dTab, b.pyr, b.qpyr, b.blur, b.rawCand, b.cellCnt, b.cellInfo, b.lvlTotal, b.lvl, b.slotPos, b.slotResp, b.lvlCount,
                     b.useCost, b.kps, b.desc, b.count, b.quality, b.uright, b.depth, b.sad, b.status, dStage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < kEvRing; i++) {
@@ -250,11 +237,12 @@ int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size
     if (useQ) HIPCHK(hipMemcpyAsync(b.useCost, dUseCostSrc, nImg, hipMemcpyDeviceToDevice, st));
     else HIPCHK(hipMemsetAsync(b.useCost, 0, nImg, st));
     launch_ingest(hc, dc, b, s0, s1, imageStride, rowStride, nImg, nSides, b.pyr, st);
-    launch_pyramid(hc, dc, rtab, dI32, dI16, b.pyr, nImg, st);
+    launch_pyramid(hc, dc, dTab, b.pyr, nImg, st);
     if (useQ) {                                                   // ComputeQualityImagePyramid :1325-1357
         launch_ingest(hc, dc, b, cost, cost, costStride, costRowStride, nImg, nSides, b.qpyr, st);
-        launch_pyramid(hc, dc, rtab, dI32, dI16, b.qpyr, nImg, st);
+        launch_pyramid(hc, dc, dTab, b.qpyr, nImg, st);
     }
+    HIPCHK(hipMemsetAsync(b.cellCnt, 0, (size_t)nImg * hc.nCellsTotal * 2 * sizeof(int), st));
     const int slot = (int)(nRuns % kEvRing);
     HIPCHK(hipEventRecord(evFast0[slot], st));
     launch_fast(hc, dc, b, nImg, st);
@@ -271,6 +259,7 @@ int Context::check_status()
 {
     int s = 0;
     HIPCHK(hipMemcpy(&s, b.status, sizeof(int), hipMemcpyDeviceToHost));
+    if (s & 4) return fail(IVF_E_CAPACITY, "a cell holds more than 4096 FAST survivors at its threshold (unsupported)");
     if (s) return fail(IVF_E_STATE, "device-side consistency check failed (flags 0x%x)", s);
     return IVF_OK;
 }

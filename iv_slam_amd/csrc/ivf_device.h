@@ -7,7 +7,7 @@
 namespace ivf {
 
 constexpr int kMaxLevels = IVF_MAX_LEVELS;
-constexpr int kMaxCells = 1024;          // per level (LDS bookkeeping arrays in k_select)
+constexpr int kMaxCells = 512;           // per level (LDS bookkeeping arrays in k_select)
 constexpr int kEdge = 19;                // EDGE_THRESHOLD (ORB/src/ORBextractor.cc:75)
 
 // Geometry of one pyramid level.  All of it depends only on (params, image size), so the host
@@ -27,6 +27,7 @@ struct LevelGeom {
     int scaledPatch;        // (int)(31*scale)
     int tileBase, tilesX, tilesY;   // FAST tile enumeration (scan region x>=16, y>=19)
     int btileBase, btilesX, btilesY; // blur tile enumeration (whole plane)
+    int rtX, rtY;           // offsets into the packed cv::resize coefficient table (level >= 1)
     int valid;              // 0: level yields no keypoints
     float scale;            // mvScaleFactor[level]
 };
@@ -36,6 +37,7 @@ struct Config {
     int nfeatures, iniTh, minTh, introspection;
     int pyrBytes;           // bytes of one image's pyramid blob
     int candTotal;          // candidate scratch elements per image
+    int nCellsTotal;        // cells per image over all levels
     int nTiles;             // FAST tiles per image
     int nBlurTiles;         // blur tiles per image
     int umax[16];
@@ -43,22 +45,21 @@ struct Config {
     LevelGeom lv[kMaxLevels];
 };
 
-// per-level bilinear coefficient tables (cv::resize fixed point), one blob per config
-struct ResizeTab {
-    int xofs, a0, a1;       // offsets (in elements) into the int32 / int16 table blobs
-    int yofs, b0, b1;
-};
+// cv::resize coefficient table entry: src index | coef0 << 16 | coef1 << 32 (11-bit fixed point, A-3)
+typedef unsigned long long ResizeCoef;
 
 constexpr int kFastTW = 64, kFastTH = 32;     // FAST/NMS output tile
-constexpr int kBlurTW = 64, kBlurTH = 16;     // blur output tile
+constexpr int kBlurTW = 64, kBlurTH = 32;     // blur output tile
 
 struct Buffers {            // device pointers of one batch context
     uint8_t* pyr;           // [nImg][pyrBytes]  un-blurred pyramid (level 0 = ingested input)
     uint8_t* qpyr;          // [nImg][pyrBytes]  cost-map pyramid (introspection) or nullptr
     uint8_t* blur;          // [nImg][pyrBytes]  7x7 sigma-2 blurred pyramid
-    uint8_t* nms;           // [nImg][pyrBytes]  NMS-surviving FAST score map
-    unsigned long long* cand;   // [nImg][candTotal] (respbits<<32 | y<<16 | x) per cell, row-major order
-    unsigned long long* lvl;    // [nImg][candTotal] level list after per-cell retainBest
+    unsigned* rawCand;      // [nImg][candTotal] unordered NMS survivors per cell: y<<20 | x<<8 | score
+    int* cellCnt;           // [nImg][nCellsTotal][2] survivors per cell: {score >= minTh, score >= iniTh}
+    unsigned long long* lvl;    // [nImg][candTotal] per level: kept keys (respbits<<32 | y<<16 | x) of all cells, (i,j) order
+    int4* cellInfo;         // [nImg][nCellsTotal] {nTotal, nRetain, prefix, useMin} from k_quota
+    int* lvlTotal;          // [nImg][kMaxLevels] length of each level list before the level-wide retainBest
     unsigned int* slotPos;  // [nImg][nfeatures] (y<<16|x) level coords
     float* slotResp;        // [nImg][nfeatures]
     int* lvlCount;          // [nImg][kMaxLevels]
@@ -91,8 +92,7 @@ int set_error(int code, const char* fmt, ...);
 void launch_stereo_args(const Config& hc, const Config* dc, const StereoArgs& A, int nPairs, hipStream_t s);
 void launch_ingest(const Config& hc, const Config* dc, const Buffers& b, const uint8_t* src0, const uint8_t* src1,
                    size_t imageStride, int rowStride, int nImg, int nSides, uint8_t* dstBlob, hipStream_t s);
-void launch_pyramid(const Config& hc, const Config* dc, const ResizeTab* htab, const int* dI32, const short* dI16,
-                    uint8_t* blob, int nImg, hipStream_t s);
+void launch_pyramid(const Config& hc, const Config* dc, const ResizeCoef* dTab, uint8_t* blob, int nImg, hipStream_t s);
 void launch_fast(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s);
 void launch_blur(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s);
 void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s);

@@ -5,7 +5,7 @@
 //   k_pyr_down      level l <- bilinear(level l-1), cv::resize 8U   (:1311, :1341)
 //   k_fast_nms      FAST-9/16 score + per-cell 3x3 NMS              (cv::FAST at :1045,:1051)
 //   k_blur7         7x7 sigma-2 Gaussian, 8.8/16.16 fixed point     (:1276-1277)
-//   k_select        per-cell threshold fallback, quotas, retainBest (ComputeKeyPointsOld :880-1213)
+//   k_quota / k_cell_select / k_level_select   threshold fallback, quotas, retainBest (ComputeKeyPointsOld :880-1213)
 //   k_describe      IC_Angle + rBRIEF + output assembly             (:78-148, :1253-1294; Frame.cc:130-143)
 //   k_stereo_match  row-band Hamming + 11x11 SAD + parabola         (Frame::ComputeStereoMatches Frame.cc:758-915)
 //   k_stereo_gate   median gate                                     (Frame.cc:918-931)
@@ -58,33 +58,64 @@ __global__ void k_ingest(const Config* __restrict__ cfg, const uint8_t* __restri
 
 // ------------------------------------------------------------------------------------------------
 // k_pyr_down: cv::resize INTER_LINEAR 8UC1 (11-bit coefficients; horizontal pass in int,
-// vertical pass ((b0*(h0>>4))>>16) + ((b1*(h1>>4))>>16) + 2) >> 2).  One thread = 4 output pixels.
+// vertical pass ((b0*(h0>>4))>>16) + ((b1*(h1>>4))>>16) + 2) >> 2).
+// One workgroup = 256 x 4 output pixels; the source rows it needs are staged in LDS with aligned
+// dword loads, every thread produces 4 horizontally adjacent pixels (one dword store).  The
+// per-column / per-row coefficients (fx = (float)((dx+0.5)*scale - 0.5), cvRound(f*2048) ...) come
+// from a packed table the host builds once per geometry exactly as OpenCV's resize does.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_pyr_down(const Config* __restrict__ cfg, int level, const int* __restrict__ tI32,
-                           const short* __restrict__ tI16, ResizeTab tab, uint8_t* __restrict__ blob)
+constexpr int kPyrTW = 256, kPyrTH = 4, kPyrSrcP = 544, kPyrSrcR = 12;     // LDS: 12 rows x 544 B (scale <= 2)
+__global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg, int level,
+                                                 const ResizeCoef* __restrict__ tab, uint8_t* __restrict__ blob)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t src[kPyrSrcR * kPyrSrcP];
     const LevelGeom& D = cfg->lv[level];
     const LevelGeom& S = cfg->lv[level - 1];
-    const int img = blockIdx.z, dy = blockIdx.y;
-    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (x4 >= D.pitch) return;
+    const int img = blockIdx.z;
+    const int dx0 = blockIdx.x * kPyrTW, dy0 = blockIdx.y * kPyrTH;
     uint8_t* base = blob + (size_t)img * cfg->pyrBytes;
-    const int sy = tI32[tab.yofs + dy];
-    const int b0 = tI16[tab.b0 + dy], b1 = tI16[tab.b1 + dy];
-    const int y0 = min(max(sy, 0), S.h - 1), y1 = min(max(sy + 1, 0), S.h - 1);
-    const uint8_t* S0 = base + S.off + (size_t)y0 * S.pitch;
-    const uint8_t* S1 = base + S.off + (size_t)y1 * S.pitch;
+    const uint8_t* SP = base + S.off;
+    const ResizeCoef* tx = tab + D.rtX;
+    const ResizeCoef* ty = tab + D.rtY;
+    const int tid = threadIdx.x;
+    // source window of this tile (table entries hold the clamped source index)
+    const int dxl = min(dx0 + kPyrTW, D.w) - 1, dyl = min(dy0 + kPyrTH, D.h) - 1;
+    const int wx0 = (int)(tx[dx0] & 0xffff) & ~3, wx1 = min((int)(tx[dxl] & 0xffff) + 1, S.w - 1);
+    const int wy0 = (int)(ty[dy0] & 0xffff), wy1 = min((int)(ty[dyl] & 0xffff) + 1, S.h - 1);
+    const int nq = (wx1 - wx0) / 4 + 1, nr = wy1 - wy0 + 1;
+    const bool fits = nq * 4 <= kPyrSrcP && nr <= kPyrSrcR;
+    if (fits) {
+        for (int i = tid; i < nq * nr; i += 256) {
+            const int r = i / nq, q = i % nq;
+            *(unsigned*)(src + r * kPyrSrcP + 4 * q) = *(const unsigned*)(SP + (size_t)(wy0 + r) * S.pitch + wx0 + 4 * q);
+        }
+    }
+    __syncthreads();
+    const int dy = dy0 + (tid >> 6), x4 = dx0 + (tid & 63) * 4;
+    if (dy >= D.h || x4 >= D.pitch) return;
+    const ResizeCoef cy = ty[dy];
+    const int y0 = (int)(cy & 0xffff), y1 = min(y0 + 1, S.h - 1);
+    const int b0 = (int)((cy >> 16) & 0xffff), b1 = (int)((cy >> 32) & 0xffff);
     unsigned out = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int dx = x4 + k;
         unsigned r = 0;
         if (dx < D.w) {
-            const int sx = tI32[tab.xofs + dx];
-            const int sx1 = min(sx + 1, S.w - 1);
-            const int a0 = tI16[tab.a0 + dx], a1 = tI16[tab.a1 + dx];
-            const int h0 = S0[sx] * a0 + S0[sx1] * a1;
-            const int h1 = S1[sx] * a0 + S1[sx1] * a1;
+            const ResizeCoef cx = tx[dx];
+            const int sx = (int)(cx & 0xffff), sx1 = min(sx + 1, S.w - 1);
+            const int a0 = (int)((cx >> 16) & 0xffff), a1 = (int)((cx >> 32) & 0xffff);
+            int p00, p01, p10, p11;
+            if (fits) {
+                const uint8_t* r0 = src + (y0 - wy0) * kPyrSrcP - wx0;
+                const uint8_t* r1 = src + (y1 - wy0) * kPyrSrcP - wx0;
+                p00 = r0[sx]; p01 = r0[sx1]; p10 = r1[sx]; p11 = r1[sx1];
+            } else {
+                const uint8_t* r0 = SP + (size_t)y0 * S.pitch;
+                const uint8_t* r1 = SP + (size_t)y1 * S.pitch;
+                p00 = r0[sx]; p01 = r0[sx1]; p10 = r1[sx]; p11 = r1[sx1];
+            }
+            const int h0 = p00 * a0 + p01 * a1, h1 = p10 * a0 + p11 * a1;
             r = (unsigned)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
         }
         out |= r << (8 * k);
@@ -150,13 +181,16 @@ DEVINL bool cell_rect(const LevelGeom& G, int mode, int x, int y, CellRect& r)
 //   1. stage the (64+8)x(32+8) raw tile in LDS with aligned dword loads (tile origin x = 16 + 64*tx)
 //   2. FAST score for the 66x34 region (tile + 1-px NMS halo), 0 outside any cell domain
 //   3. 3x3 strict NMS against neighbours of the SAME cell (cv::FAST runs per cell sub-image, so
-//      neighbours in another cell count as 0) -> nms map, 4 pixels per dword store
-// The map keeps score >= minTh; since score >= t <=> corner at t, the same map serves iniThFAST.
+//      neighbours in another cell count as 0); every survivor (score >= minTh) is APPENDED to its
+//      cell's slab as (y<<20 | x<<8 | score) and counted (total and >= iniTh).  No score map goes to
+//      HBM; k_cell_select restores cv::FAST's row-major order from the packed positions.
+// Since score >= t <=> corner at t, one pass serves both thresholds.
 // ------------------------------------------------------------------------------------------------
 constexpr int kRawP = kFastTW + 8;          // 72
 constexpr int kScP = kFastTW + 2 + 2;       // 68 (padded)
 __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg, const uint8_t* __restrict__ pyr,
-                                                 const uint8_t* __restrict__ useCost, uint8_t* __restrict__ nms)
+                                                 const uint8_t* __restrict__ useCost, unsigned* __restrict__ rawCand,
+                                                 int* __restrict__ cellCnt)
 {
     __shared__ __attribute__((aligned(16))) uint8_t raw[(kFastTH + 8) * kRawP];
     __shared__ uint8_t sc[(kFastTH + 2) * kScP];
@@ -193,37 +227,35 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
         sc[sy * kScP + sx] = (uint8_t)s;
     }
     __syncthreads();
-    // 3. NMS, 4 pixels per thread
-    uint8_t* dst = nms + (size_t)img * cfg->pyrBytes + G.off;
-    for (int i = tid; i < kFastTH * (kFastTW / 4); i += 256) {
-        const int oy = i / (kFastTW / 4), ox4 = (i % (kFastTW / 4)) * 4;
-        const int y = y0 + oy;
-        if (y >= G.maxBY) continue;
-        unsigned out = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x = x0 + ox4 + k;
-            const uint8_t* c = sc + (oy + 1) * kScP + (ox4 + k + 1);
-            const int s = c[0];
-            unsigned keep = 0;
-            CellRect r;
-            if (s > 0 && cell_rect(G, mode, x, y, r)) {
-                const bool L = x - 1 >= r.x0, R = x + 1 < r.x1, U = y - 1 >= r.y0, D = y + 1 < r.y1;
-                bool ok = true;
-                ok &= s > ((L) ? c[-1] : 0);
-                ok &= s > ((R) ? c[1] : 0);
-                ok &= s > ((U && L) ? c[-kScP - 1] : 0);
-                ok &= s > ((U) ? c[-kScP] : 0);
-                ok &= s > ((U && R) ? c[-kScP + 1] : 0);
-                ok &= s > ((D && L) ? c[kScP - 1] : 0);
-                ok &= s > ((D) ? c[kScP] : 0);
-                ok &= s > ((D && R) ? c[kScP + 1] : 0);
-                keep = ok ? (unsigned)s : 0u;
+    // 3. NMS + append
+    const int iniTh = cfg->iniTh;
+    unsigned* slab = rawCand + (size_t)img * cfg->candTotal + G.candBase;
+    int* cnt = cellCnt + (size_t)img * cfg->nCellsTotal * 2;
+    for (int i = tid; i < kFastTH * kFastTW; i += 256) {
+        const int oy = i / kFastTW, ox = i % kFastTW;
+        const int x = x0 + ox, y = y0 + oy;
+        const uint8_t* c = sc + (oy + 1) * kScP + (ox + 1);
+        const int s = c[0];
+        CellRect r;
+        if (s > 0 && cell_rect(G, mode, x, y, r)) {
+            const bool L = x - 1 >= r.x0, R = x + 1 < r.x1, U = y - 1 >= r.y0, D = y + 1 < r.y1;
+            bool ok = true;
+            ok &= s > ((L) ? c[-1] : 0);
+            ok &= s > ((R) ? c[1] : 0);
+            ok &= s > ((U && L) ? c[-kScP - 1] : 0);
+            ok &= s > ((U) ? c[-kScP] : 0);
+            ok &= s > ((U && R) ? c[-kScP + 1] : 0);
+            ok &= s > ((D && L) ? c[kScP - 1] : 0);
+            ok &= s > ((D) ? c[kScP] : 0);
+            ok &= s > ((D && R) ? c[kScP + 1] : 0);
+            if (ok) {
+                const int cell = ((r.y0 - kEdge) / G.cellH) * G.cols + (r.x0 - kEdge) / G.cellW;
+                const int gc = G.cellBase + cell;
+                const int slot = atomicAdd(&cnt[2 * gc], 1);
+                if (s >= iniTh) atomicAdd(&cnt[2 * gc + 1], 1);
+                if (slot < G.candCap) slab[(size_t)cell * G.candCap + slot] = ((unsigned)y << 20) | ((unsigned)x << 8) | (unsigned)s;
             }
-            out |= keep << (8 * k);
         }
-        const int gx = x0 + ox4;
-        if (gx < G.pitch) *(unsigned*)(dst + (size_t)y * G.pitch + gx) = out;
     }
 }
 
@@ -241,9 +273,11 @@ DEVINL int reflect101(int p, int n)
 __global__ __launch_bounds__(256) void k_blur7(const Config* __restrict__ cfg, const uint8_t* __restrict__ pyr,
                                               const int* __restrict__ lvlCount, uint8_t* __restrict__ blur)
 {
-    constexpr int RW = kBlurTW + 6, RH = kBlurTH + 6;
-    __shared__ uint8_t raw[RH * RW];
-    __shared__ unsigned short hp[RH * kBlurTW];
+    // one workgroup = one 64 x 32 output tile: raw rows staged as aligned dwords (x0-4 .. x0+67, x0 % 64 == 0),
+    // horizontal pass 4 px per thread into u16x4, vertical pass 4 px per thread, one dword store
+    constexpr int RQ = (kBlurTW + 8) / 4, RH = kBlurTH + 6, HQ = kBlurTW / 4;
+    __shared__ unsigned raw[RH * RQ];
+    __shared__ uint2 hp[RH * HQ];
     const int img = blockIdx.y;
     int level = 0;
     const int nl = cfg->nlevels;
@@ -256,32 +290,50 @@ __global__ __launch_bounds__(256) void k_blur7(const Config* __restrict__ cfg, c
     const int x0 = (t % tilesX) * kBlurTW, y0 = (t / tilesX) * kBlurTH;
     const uint8_t* src = pyr + (size_t)img * cfg->pyrBytes + G.off;
     const int tid = threadIdx.x;
-    for (int i = tid; i < RH * RW; i += 256) {
-        const int ry = i / RW, rx = i % RW;
-        const int gy = reflect101(y0 - 3 + ry, G.h), gx = reflect101(x0 - 3 + rx, G.w);
-        raw[i] = src[(size_t)gy * G.pitch + gx];
+    for (int i = tid; i < RH * RQ; i += 256) {
+        const int ry = i / RQ, rq = i % RQ;
+        const int gy = reflect101(y0 - 3 + ry, G.h), gx = x0 - 4 + 4 * rq;
+        const uint8_t* row = src + (size_t)gy * G.pitch;
+        unsigned v;
+        if (gx >= 0 && gx + 3 < G.w) v = *(const unsigned*)(row + gx);
+        else {
+            v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v |= (unsigned)row[reflect101(gx + k, G.w)] << (8 * k);
+        }
+        raw[i] = v;
     }
     __syncthreads();
-    for (int i = tid; i < RH * kBlurTW; i += 256) {
-        const int ry = i / kBlurTW, ox = i % kBlurTW;
-        const uint8_t* r = raw + ry * RW + ox;
-        hp[i] = (unsigned short)(18 * (r[0] + r[6]) + 34 * (r[1] + r[5]) + 48 * (r[2] + r[4]) + 56 * r[3]);
+    for (int i = tid; i < RH * HQ; i += 256) {
+        const int ry = i / HQ, q = i % HQ;
+        const unsigned w0 = raw[ry * RQ + q], w1 = raw[ry * RQ + q + 1], w2 = raw[ry * RQ + q + 2];
+        int b[12];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { b[k] = (w0 >> (8 * k)) & 0xff; b[4 + k] = (w1 >> (8 * k)) & 0xff; b[8 + k] = (w2 >> (8 * k)) & 0xff; }
+        unsigned h[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)       // output x0+4q+k is centred on window byte 4+k
+            h[k] = 18 * (b[1 + k] + b[7 + k]) + 34 * (b[2 + k] + b[6 + k]) + 48 * (b[3 + k] + b[5 + k]) + 56 * b[4 + k];
+        hp[i] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
     }
     __syncthreads();
     uint8_t* dst = blur + (size_t)img * cfg->pyrBytes + G.off;
-    for (int i = tid; i < kBlurTH * (kBlurTW / 4); i += 256) {
-        const int oy = i / (kBlurTW / 4), ox4 = (i % (kBlurTW / 4)) * 4;
+    for (int i = tid; i < kBlurTH * HQ; i += 256) {
+        const int oy = i / HQ, q = i % HQ;
         const int y = y0 + oy;
         if (y >= G.h) continue;
+        unsigned acc[4] = {0, 0, 0, 0};
+        const unsigned kw[7] = {18, 34, 48, 56, 48, 34, 18};
+#pragma unroll
+        for (int r = 0; r < 7; r++) {
+            const uint2 v = hp[(oy + r) * HQ + q];
+            acc[0] += kw[r] * (v.x & 0xffff); acc[1] += kw[r] * (v.x >> 16);
+            acc[2] += kw[r] * (v.y & 0xffff); acc[3] += kw[r] * (v.y >> 16);
+        }
         unsigned out = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const unsigned short* c = hp + oy * kBlurTW + ox4 + k;
-            const unsigned acc = 18u * (c[0] + c[6 * kBlurTW]) + 34u * (c[kBlurTW] + c[5 * kBlurTW]) +
-                                 48u * (c[2 * kBlurTW] + c[4 * kBlurTW]) + 56u * c[3 * kBlurTW];
-            out |= (((acc + 32768u) >> 16) & 0xffu) << (8 * k);
-        }
-        if (x0 + ox4 < G.pitch) *(unsigned*)(dst + (size_t)y * G.pitch + x0 + ox4) = out;
+        for (int k = 0; k < 4; k++) out |= (((acc[k] + 32768u) >> 16) & 0xffu) << (8 * k);
+        if (x0 + 4 * q < G.pitch) *(unsigned*)(dst + (size_t)y * G.pitch + x0 + 4 * q) = out;
     }
 }
 
@@ -384,49 +436,41 @@ __device__ __noinline__ void sel_nth_element(u64* v, int n, int nth)
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_select: one workgroup = one (image, level).  ComputeKeyPointsOld :880-1213 minus the per-pixel
-// work: per-cell candidate counts at iniTh/minTh (the `<=3 -> minThFAST` fallback, :1047), cost-map
-// cell weights and quotas (:946-987, :1028-1031), the single-pass quota redistribution (:1103-1133),
-// row-major candidate compaction with response*quality (:1058-1080), per-cell retainBest (:1146),
-// concatenation in (i,j) order and the level-wide retainBest (:1162-1166).
+// Keypoint selection = ComputeKeyPointsOld :880-1213 minus the per-pixel work, in three kernels:
+//   k_quota        per (image, level): `<=3 -> minThFAST` fallback per cell (:1047) from k_fast_nms's counters,
+//                  cost-map cell weights and quotas (:946-987, :1028-1031), the single-pass quota redistribution
+//                  (:1103-1133); what retainBest will keep per cell is data-independent, so the offsets of the
+//                  concatenated level list are fixed here too.
+//   k_cell_select  per (image, cell), one wave: restore cv::FAST's row-major order (bitonic sort of the packed
+//                  positions in LDS), response x quality (:1058-1080), retainBest (:1146-1148) = exact replay of
+//                  libstdc++ introselect by one lane on the LDS list, kept entries -> level list (i,j order).
+//   k_level_select per (image, level): level-wide retainBest (:1162-1166), keypoint slots, level count.
+// Candidate counts per cell are heavy-tailed (tens typically, >1000 on repetitive texture); one wave per cell lets
+// the hardware balance that, and keeps every sequential replay in LDS (~64-cycle steps instead of L2 round trips).
 // ------------------------------------------------------------------------------------------------
-constexpr int kSelThreads = 512;
-__global__ __launch_bounds__(kSelThreads) void k_select(const Config* __restrict__ cfg, const uint8_t* __restrict__ nms,
-                                                       const uint8_t* __restrict__ qpyr, const uint8_t* __restrict__ useCost,
-                                                       u64* __restrict__ cand, u64* __restrict__ lvl,
-                                                       unsigned* __restrict__ slotPos, float* __restrict__ slotResp,
-                                                       int* __restrict__ lvlCount, int* __restrict__ status)
+struct CellInfo { int nTotal, nRetain, prefix, useMin; };
+
+__global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, const int* __restrict__ cellCnt,
+                                              const uint8_t* __restrict__ qpyr, const uint8_t* __restrict__ useCost,
+                                              CellInfo* __restrict__ cellInfo, int* __restrict__ lvlTotal)
 {
     __shared__ int s_nIni[kMaxCells], s_nMin[kMaxCells], s_nTotal[kMaxCells], s_nRetain[kMaxCells], s_prefix[kMaxCells + 1];
     __shared__ unsigned s_qsum[kMaxCells];
     __shared__ unsigned char s_useMin[kMaxCells];
-    __shared__ int s_total;
     const int img = blockIdx.y, level = blockIdx.x;
     const LevelGeom& G = cfg->lv[level];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = kSelThreads / 64;
-    if (!G.valid) { if (tid == 0) lvlCount[img * kMaxLevels + level] = 0; return; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = 4;
+    if (!G.valid) { if (tid == 0) lvlTotal[img * kMaxLevels + level] = 0; return; }
     const int mode = (cfg->introspection && useCost[img]) ? 1 : 0;
     const int nCells = G.nCells, cols = G.cols, rows = G.rows;
-    const uint8_t* M = nms + (size_t)img * cfg->pyrBytes + G.off;
     const uint8_t* Q = mode ? qpyr + (size_t)img * cfg->pyrBytes + G.off : nullptr;
-    const int iniTh = cfg->iniTh;
     const int pitch = G.pitch;
-
-    // phase 1: per-cell counts (and cost-window sums)
+    const int* cnt = cellCnt + ((size_t)img * cfg->nCellsTotal + G.cellBase) * 2;
     for (int c = wave; c < nCells; c += nw) {
-        const int i = c / cols, j = c % cols;
-        const int x0 = kEdge + j * G.cellW, x1 = (j == cols - 1) ? G.maxBX : x0 + G.cellW;
-        const int y0 = kEdge + i * G.cellH, y1 = y0 + ((i == rows - 1) ? G.domHLast : G.domH[mode]);
-        int nIni = 0, nMin = 0;
-        for (int y = y0; y < y1; y++)
-            for (int xb = x0; xb < x1; xb += 64) {
-                const int x = xb + lane;
-                const int s = x < x1 ? M[(size_t)y * pitch + x] : 0;
-                nMin += __popcll(__ballot(s > 0));
-                nIni += __popcll(__ballot(s >= iniTh));
-            }
         unsigned qs = 0;
-        if (mode) {
+        if (mode) {                                   // cv::sum over the cell WINDOW of the cost pyramid (:977)
+            const int i = c / cols, j = c % cols;
+            const int x0 = kEdge + j * G.cellW, y0 = kEdge + i * G.cellH;
             const int wx0 = x0 - 3, wx1 = (j == cols - 1) ? G.maxBX + 3 : x0 + G.cellW + 3;
             const int wy0 = y0 - 3, wy1 = wy0 + ((i == rows - 1) ? G.winHLast : G.cellH + 6);
             int acc = 0;
@@ -434,12 +478,10 @@ __global__ __launch_bounds__(kSelThreads) void k_select(const Config* __restrict
                 for (int x = wx0 + lane; x < wx1; x += 64) acc += Q[(size_t)y * pitch + x];
             qs = (unsigned)wave_sum_i32(acc);
         }
-        if (lane == 0) { s_nIni[c] = nIni; s_nMin[c] = nMin; s_qsum[c] = qs; }
+        if (lane == 0) { s_nMin[c] = cnt[2 * c]; s_nIni[c] = cnt[2 * c + 1]; s_qsum[c] = qs; }
     }
     __syncthreads();
-
-    // phase 2: quotas (sequential bookkeeping exactly in (i,j) order)
-    if (tid == 0) {
+    if (tid == 0) {                                   // sequential bookkeeping exactly in (i,j) order
         float wsum = 0.0f;
         if (mode)
             for (int c = 0; c < nCells; c++) {
@@ -477,79 +519,128 @@ __global__ __launch_bounds__(kSelThreads) void k_select(const Config* __restrict
                 }
             }
         }
-    }
-    __syncthreads();
-
-    // phase 3: row-major compaction of each cell's candidates at its threshold
-    u64* candL = cand + (size_t)img * cfg->candTotal + G.candBase;
-    for (int c = wave; c < nCells; c += nw) {
-        const int i = c / cols, j = c % cols;
-        const int x0 = kEdge + j * G.cellW, x1 = (j == cols - 1) ? G.maxBX : x0 + G.cellW;
-        const int y0 = kEdge + i * G.cellH, y1 = y0 + ((i == rows - 1) ? G.domHLast : G.domH[mode]);
-        const int th = s_useMin[c] ? 1 : iniTh;          // map already holds score >= minTh only
-        u64* out = candL + (size_t)c * G.candCap;
-        int n = 0;
-        for (int y = y0; y < y1; y++)
-            for (int xb = x0; xb < x1; xb += 64) {
-                const int x = xb + lane;
-                const int s = x < x1 ? M[(size_t)y * pitch + x] : 0;
-                const bool keep = s >= th;
-                const unsigned long long mask = __ballot(keep);
-                if (keep) {
-                    const int idx = n + __popcll(mask & ((1ull << lane) - 1ull));
-                    float resp = (float)s;
-                    if (mode) {
-                        const float cost = (float)Q[(size_t)y * pitch + x];
-                        resp *= 2 * (1.0f / (1.0f + cost / 255.0f)) - 1;
-                    }
-                    if (idx < G.candCap)
-                        out[idx] = ((u64)__float_as_uint(resp) << 32) | ((unsigned)y << 16) | (unsigned)x;
-                }
-                n += __popcll(mask);
-            }
-        if (lane == 0 && n != s_nTotal[c]) atomicOr(status, 1);     // internal consistency
-        if (lane == 0 && n > G.candCap) atomicOr(status, 2);
-    }
-    __syncthreads();
-
-    // phase 4: per-cell retainBest, one lane per cell spread over the waves
-    for (int c0 = 0; c0 < nCells; c0 += kSelThreads) {
-        const int slot = (tid & 63) * nw + (tid >> 6);      // lane-major so each wave holds few active lanes
-        const int c = c0 + slot;
-        if (c < nCells) {
-            const int nT = s_nTotal[c], nR = s_nRetain[c];
-            int kept = nT;
-            if (nR >= 0 && nT > nR) {
-                if (nR > 0) sel_nth_element(candL + (size_t)c * G.candCap, nT, nR - 1);
-                kept = nR;
-            }
-            s_nTotal[c] = kept;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
         int acc = 0;
-        for (int c = 0; c < nCells; c++) { s_prefix[c] = acc; acc += s_nTotal[c]; }
-        s_prefix[nCells] = acc;
-        s_total = acc;
+        for (int c = 0; c < nCells; c++) {
+            const int nT = s_nTotal[c], nR = s_nRetain[c];
+            s_prefix[c] = acc;
+            acc += (nR >= 0 && nT > nR) ? nR : nT;
+        }
+        lvlTotal[img * kMaxLevels + level] = acc;
     }
     __syncthreads();
-    // phase 5: concatenate in (i,j) order, level-wide retainBest
-    u64* L = lvl + (size_t)img * cfg->candTotal + G.candBase;
-    for (int c = wave; c < nCells; c += nw) {
-        const u64* in = candL + (size_t)c * G.candCap;
-        const int n = s_nTotal[c], o = s_prefix[c];
-        for (int k = lane; k < n; k += 64) L[o + k] = in[k];
+    CellInfo* ci = cellInfo + (size_t)img * cfg->nCellsTotal + G.cellBase;
+    for (int c = tid; c < nCells; c += 256) ci[c] = CellInfo{s_nTotal[c], s_nRetain[c], s_prefix[c], (int)s_useMin[c]};
+}
+
+// pass 0 handles cells with <= kCellCapSmall candidates (12 KB LDS, many waves per CU); pass 1 the rest
+constexpr int kCellCapSmall = 1024, kCellCapBig = 4096;
+template <int CAP>
+__global__ __launch_bounds__(64) void k_cell_select(const Config* __restrict__ cfg, const unsigned* __restrict__ rawCand,
+                                                   const int* __restrict__ cellCnt, const CellInfo* __restrict__ cellInfo,
+                                                   const uint8_t* __restrict__ qpyr, const uint8_t* __restrict__ useCost,
+                                                   u64* __restrict__ lvlList, int* __restrict__ status, int pass)
+{
+    __shared__ __attribute__((aligned(16))) unsigned keys[CAP];
+    __shared__ __attribute__((aligned(16))) u64 ord[CAP];
+    const int img = blockIdx.y, gc = blockIdx.x, lane = threadIdx.x;
+    int level = 0;
+    const int nl = cfg->nlevels;
+    for (int l = 1; l < nl; l++) if (cfg->lv[l].valid && gc >= cfg->lv[l].cellBase) level = l;
+    const LevelGeom& G = cfg->lv[level];
+    const int c = gc - G.cellBase;
+    if (!G.valid || c < 0 || c >= G.nCells) return;
+    const CellInfo info = cellInfo[(size_t)img * cfg->nCellsTotal + gc];
+    const int nT = info.nTotal, nR = info.nRetain;
+    if (nT <= 0) return;
+    if (pass == 0 ? nT > kCellCapSmall : nT <= kCellCapSmall) return;
+    const int mode = (cfg->introspection && useCost[img]) ? 1 : 0;
+    const uint8_t* Q = mode ? qpyr + (size_t)img * cfg->pyrBytes + G.off : nullptr;
+    const int nAllRaw = cellCnt[((size_t)img * cfg->nCellsTotal + gc) * 2];
+    if (lane == 0 && nAllRaw > G.candCap) atomicOr(status, 2);
+    const int nAll = min(nAllRaw, G.candCap);
+    const unsigned th = info.useMin ? 1u : (unsigned)cfg->iniTh;
+    const unsigned* in = rawCand + (size_t)img * cfg->candTotal + G.candBase + (size_t)c * G.candCap;
+    const int kept = (nR >= 0 && nT > nR) ? nR : nT;
+    u64* dst = lvlList + (size_t)img * cfg->candTotal + G.candBase + info.prefix;
+    if (nT > CAP) { if (lane == 0) atomicOr(status, 4); return; }    // > kCellCapBig survivors in one cell: unsupported
+    // a) filter by the cell's threshold (order irrelevant)
+    int m = 0;
+    for (int b0 = 0; b0 < nAll; b0 += 64) {
+        const int k = b0 + lane;
+        const unsigned e = k < nAll ? in[k] : 0u;
+        const bool keep = k < nAll && (e & 0xffu) >= th;
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+            const int idx = m + __popcll(mask & ((1ull << lane) - 1ull));
+            keys[idx] = e;
+        }
+        m += __popcll(mask);
     }
-    __syncthreads();
-    int total = s_total;
+    if (lane == 0 && m != nT) atomicOr(status, 1);                   // internal consistency
+    if (m != nT) return;
+    {
+        // b) bitonic sort of the packed positions (y<<20 | x<<8 | score): ascending = row-major
+        int n2 = 64;
+        while (n2 < m) n2 <<= 1;
+        for (int k = m + lane; k < n2; k += 64) keys[k] = 0xffffffffu;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int k = 2; k <= n2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = lane; i < n2 / 2; i += 64) {
+                    const int l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                    const int r = l | j;
+                    const unsigned a = keys[l], b = keys[r];
+                    const bool up = (l & k) == 0;
+                    if ((a > b) == up) { keys[l] = b; keys[r] = a; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        // c) 64-bit keys: response (x quality factor) | y | x
+        for (int k = lane; k < m; k += 64) {
+            const unsigned e = keys[k];
+            const unsigned y = e >> 20, x = (e >> 8) & 0xfffu;
+            float resp = (float)(e & 0xffu);
+            if (mode) {
+                const float cost = (float)Q[(size_t)y * G.pitch + x];
+                resp *= 2 * (1.0f / (1.0f + cost / 255.0f)) - 1;
+            }
+            ord[k] = ((u64)__float_as_uint(resp) << 32) | (y << 16) | x;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // d) retainBest
+        if (nR > 0 && nT > nR && lane == 0) sel_nth_element(ord, nT, nR - 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < kept; k += 64) dst[k] = ord[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_level_select(const Config* __restrict__ cfg, const int* __restrict__ lvlTotal,
+                                                     u64* __restrict__ lvlList, unsigned* __restrict__ slotPos,
+                                                     float* __restrict__ slotResp, int* __restrict__ lvlCount)
+{
+    constexpr int LCAP = 4096;
+    __shared__ __attribute__((aligned(16))) u64 s_list[LCAP];
+    const int img = blockIdx.y, level = blockIdx.x, tid = threadIdx.x;
+    const LevelGeom& G = cfg->lv[level];
+    if (!G.valid) { if (tid == 0) lvlCount[img * kMaxLevels + level] = 0; return; }
+    int total = lvlTotal[img * kMaxLevels + level];
+    u64* Lg = lvlList + (size_t)img * cfg->candTotal + G.candBase;
+    u64* L = Lg;
     if (total > G.nDesired) {
-        if (tid == 0) sel_nth_element(L, total, G.nDesired - 1);
+        if (total <= LCAP) {
+            for (int k = tid; k < total; k += 256) s_list[k] = Lg[k];
+            L = s_list;
+            __syncthreads();
+        }
+        if (tid == 0) sel_nth_element(L, total, G.nDesired - 1);       // :1162-1166
         total = G.nDesired;
         __syncthreads();
     }
-    // phase 6: slots
-    for (int k = tid; k < total; k += kSelThreads) {
+    for (int k = tid; k < total; k += 256) {
         const u64 e = L[k];
         slotPos[(size_t)img * cfg->nfeatures + G.kpBase + k] = (unsigned)e;
         slotResp[(size_t)img * cfg->nfeatures + G.kpBase + k] = __uint_as_float((unsigned)(e >> 32));
@@ -885,20 +976,19 @@ void launch_ingest(const Config& hc, const Config* dc, const Buffers&, const uin
     dim3 grid((G.pitch / 4 + 255) / 256, G.h, nImg);
     hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, dc, src0, src1, imageStride, rowStride, nSides, dstBlob);
 }
-void launch_pyramid(const Config& hc, const Config* dc, const ResizeTab* htab, const int* dI32, const short* dI16,
-                    uint8_t* blob, int nImg, hipStream_t s)
+void launch_pyramid(const Config& hc, const Config* dc, const ResizeCoef* dTab, uint8_t* blob, int nImg, hipStream_t s)
 {
     for (int l = 1; l < hc.nlevels; l++) {
         const LevelGeom& G = hc.lv[l];
         if (G.w <= 0 || G.h <= 0) continue;
-        dim3 grid((G.pitch / 4 + 127) / 128, G.h, nImg);
-        hipLaunchKernelGGL(k_pyr_down, grid, dim3(128), 0, s, dc, l, dI32, dI16, htab[l], blob);
+        dim3 grid((G.pitch + kPyrTW - 1) / kPyrTW, (G.h + kPyrTH - 1) / kPyrTH, nImg);
+        hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, s, dc, l, dTab, blob);
     }
 }
 void launch_fast(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s)
 {
     if (hc.nTiles <= 0) return;
-    hipLaunchKernelGGL(k_fast_nms, dim3(hc.nTiles, nImg), dim3(256), 0, s, dc, b.pyr, b.useCost, b.nms);
+    hipLaunchKernelGGL(k_fast_nms, dim3(hc.nTiles, nImg), dim3(256), 0, s, dc, b.pyr, b.useCost, b.rawCand, b.cellCnt);
 }
 void launch_blur(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s)
 {
@@ -908,8 +998,14 @@ void launch_blur(const Config& hc, const Config* dc, const Buffers& b, int nImg,
 }
 void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_select, dim3(hc.nlevels, nImg), dim3(kSelThreads), 0, s, dc, b.nms, b.qpyr, b.useCost,
-                       b.cand, b.lvl, b.slotPos, b.slotResp, b.lvlCount, b.status);
+    hipLaunchKernelGGL(k_quota, dim3(hc.nlevels, nImg), dim3(256), 0, s, dc, b.cellCnt, b.qpyr, b.useCost,
+                       (CellInfo*)b.cellInfo, b.lvlTotal);
+    hipLaunchKernelGGL((k_cell_select<kCellCapSmall>), dim3(hc.nCellsTotal, nImg), dim3(64), 0, s, dc, b.rawCand, b.cellCnt,
+                       (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, 0);
+    hipLaunchKernelGGL((k_cell_select<kCellCapBig>), dim3(hc.nCellsTotal, nImg), dim3(64), 0, s, dc, b.rawCand, b.cellCnt,
+                       (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, 1);
+    hipLaunchKernelGGL(k_level_select, dim3(hc.nlevels, nImg), dim3(256), 0, s, dc, b.lvlTotal, b.lvl, b.slotPos, b.slotResp,
+                       b.lvlCount);
 }
 void launch_describe(const Config& hc, const Config* dc, const Buffers& b, const uint8_t*, size_t, int, int nImg, int,
                      hipStream_t s)
