@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256) void k_blur7(const Config* __restrict__ cfg, c
 typedef unsigned long long u64;
 #define RGT(a, b) ((unsigned)((a) >> 32) > (unsigned)((b) >> 32))
 
-DEVINL void sel_adjust_heap(u64* f, int hole, int len, u64 value)
+template <typename PTR>
+DEVINL void sel_adjust_heap(PTR f, int hole, int len, u64 value)
 {
     const int top = hole;
     int child = hole;
@@ -369,7 +370,8 @@ DEVINL void sel_adjust_heap(u64* f, int hole, int len, u64 value)
     }
     f[hole] = value;
 }
-__device__ __noinline__ void sel_nth_element(u64* v, int n, int nth)
+template <typename PTR>
+DEVINL void sel_nth_element(PTR v, int n, int nth)
 {
     if (n <= 0 || nth >= n) return;
     int first = 0, last = n;
@@ -379,7 +381,7 @@ __device__ __noinline__ void sel_nth_element(u64* v, int n, int nth)
     while (last - first > 3) {
         if (depth == 0) {
             // __heap_select(first, nth+1, last) ; iter_swap(first, nth)
-            u64* f = v + first;
+            PTR f = v + first;
             const int len = nth + 1 - first;
             if (len >= 2) {
                 int parent = (len - 2) / 2;
