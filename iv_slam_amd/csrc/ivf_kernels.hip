@@ -124,76 +124,83 @@ __global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg
 }
 
 // ------------------------------------------------------------------------------------------------
-// FAST-9/16 score of one pixel from an LDS tile.  A = max over the 16 arcs of 9 contiguous ring
-// pixels, both polarities, of the minimum signed difference; corner at t <=> A > t; score = A-1
-// (OpenCV cornerScore<16>).  Sliding 9-window min/max via a doubling tree.
+// FAST-9/16 score of TWO horizontally adjacent pixels, packed 2 x i16 per register (v_pk_*_i16).
+//   A = max over the 16 arcs of 9 contiguous ring pixels, both polarities, of the minimum signed
+//   difference d = centre - ring; corner at t <=> A > t; score = A - 1 (OpenCV cornerScore<16>).
+// W = the 8 bytes raw[row][x-3 .. x+4] of each of the 7 rows (x = left pixel); for ring offset dx the
+// pair of ring bytes is (W[dx+3], W[dx+4]), pulled into the two i16 halves by one v_perm_b32.
+// Quick reject first (every 9-arc holds one pixel of each opposite pair (k, k+8)); the sliding
+// 9-window min/max runs on odd starts only: w8[j] = min d[j..j+7], arcs [j-1..j+7] and [j..j+8]
+// give min(w8[j], max(d[j-1], d[j+8])) -- 47 packed ops per polarity instead of 79.
 // ------------------------------------------------------------------------------------------------
-template <int P>
-DEVINL int fast_score(const uint8_t* c, int t)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+DEVINL s16x2 pkmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+DEVINL s16x2 pkmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+DEVINL s16x2 pair_at(unsigned lo, unsigned hi, int i)      // bytes W[i], W[i+1] of the window (hi:lo) -> 2 x i16
 {
-    const int v = c[0];
-    int d[16];
-    d[0] = v - c[3 * P];       d[1] = v - c[3 * P + 1];   d[2] = v - c[2 * P + 2];   d[3] = v - c[P + 3];
-    d[4] = v - c[3];           d[5] = v - c[-P + 3];      d[6] = v - c[-2 * P + 2];  d[7] = v - c[-3 * P + 1];
-    d[8] = v - c[-3 * P];      d[9] = v - c[-3 * P - 1];  d[10] = v - c[-2 * P - 2]; d[11] = v - c[-P - 3];
-    d[12] = v - c[-3];         d[13] = v - c[P - 3];      d[14] = v - c[2 * P - 2];  d[15] = v - c[3 * P - 1];
-    bool dark = true, bright = true;      // every 9-arc holds one pixel of each opposite pair
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        dark &= (d[k] > t) | (d[k + 8] > t);
-        bright &= (d[k] < -t) | (d[k + 8] < -t);
-    }
-    if (!(dark | bright)) return 0;
-    int mn[16], mx[16], a[16], b[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { mn[k] = min(d[k], d[(k + 1) & 15]); mx[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-    for (int k = 0; k < 16; k++) { a[k] = min(mn[k], mn[(k + 2) & 15]); b[k] = max(mx[k], mx[(k + 2) & 15]); }
-#pragma unroll
-    for (int k = 0; k < 16; k++) { mn[k] = min(a[k], a[(k + 4) & 15]); mx[k] = max(b[k], b[(k + 4) & 15]); }
-    int amax = -256, bmin = 256;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        amax = max(amax, min(mn[k], d[(k + 8) & 15]));
-        bmin = min(bmin, max(mx[k], d[(k + 8) & 15]));
-    }
-    const int A = max(amax, -bmin);
-    return A > t ? A - 1 : 0;
+    return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | ((unsigned)(i + 1) << 16) | (unsigned)i));
 }
-
-// cell domain (the pixels cv::FAST actually tests inside the cell window) containing (x,y), or empty
-struct CellRect { int x0, x1, y0, y1; };
-DEVINL bool cell_rect(const LevelGeom& G, int mode, int x, int y, CellRect& r)
+// rows: 7 windows (dy = -3..3), each as (lo, hi) dwords.  Returns the two scores packed (left | right << 16).
+DEVINL unsigned fast_score_pair(const unsigned (&lo)[7], const unsigned (&hi)[7], int t)
 {
-    if (x < kEdge || x >= G.maxBX || y < kEdge || y >= G.maxBY) return false;
-    const int j = (x - kEdge) / G.cellW;
-    int i = (y - kEdge) / G.cellH;
-    if (i > G.rows - 1) i = G.rows - 1;
-    r.x0 = kEdge + j * G.cellW;
-    r.x1 = (j == G.cols - 1) ? G.maxBX : r.x0 + G.cellW;
-    r.y0 = kEdge + i * G.cellH;
-    r.y1 = r.y0 + ((i == G.rows - 1) ? G.domHLast : G.domH[mode]);
-    return y < r.y1 && x < r.x1;
+    const s16x2 v = pair_at(lo[3], hi[3], 3);
+    s16x2 d[16];
+    // ring order (dx,dy): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+    d[0] = v - pair_at(lo[6], hi[6], 3);   d[1] = v - pair_at(lo[6], hi[6], 4);   d[2] = v - pair_at(lo[5], hi[5], 5);
+    d[3] = v - pair_at(lo[4], hi[4], 6);   d[4] = v - pair_at(lo[3], hi[3], 6);   d[5] = v - pair_at(lo[2], hi[2], 6);
+    d[6] = v - pair_at(lo[1], hi[1], 5);   d[7] = v - pair_at(lo[0], hi[0], 4);   d[8] = v - pair_at(lo[0], hi[0], 3);
+    d[9] = v - pair_at(lo[0], hi[0], 2);   d[10] = v - pair_at(lo[1], hi[1], 1);  d[11] = v - pair_at(lo[2], hi[2], 0);
+    d[12] = v - pair_at(lo[3], hi[3], 0);  d[13] = v - pair_at(lo[4], hi[4], 0);  d[14] = v - pair_at(lo[5], hi[5], 1);
+    d[15] = v - pair_at(lo[6], hi[6], 2);
+    s16x2 dk = pkmax(d[0], d[8]), br = pkmin(d[0], d[8]);
+#pragma unroll
+    for (int k = 1; k < 8; k++) { dk = pkmin(dk, pkmax(d[k], d[k + 8])); br = pkmax(br, pkmin(d[k], d[k + 8])); }
+    const bool pass = (dk.x > t) | (dk.y > t) | (br.x < -t) | (br.y < -t);
+    if (!pass) return 0u;
+    s16x2 mn[8], mx[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) { const int j = 2 * q + 1; mn[q] = pkmin(d[j], d[(j + 1) & 15]); mx[q] = pkmax(d[j], d[(j + 1) & 15]); }
+    s16x2 m4[8], M4[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) { m4[q] = pkmin(mn[q], mn[(q + 1) & 7]); M4[q] = pkmax(mx[q], mx[(q + 1) & 7]); }
+    s16x2 amax, bmin;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int j = 2 * q + 1;
+        const s16x2 w8 = pkmin(m4[q], m4[(q + 2) & 7]), W8 = pkmax(M4[q], M4[(q + 2) & 7]);      // d[j..j+7]
+        const s16x2 a = pkmin(w8, pkmax(d[(j + 15) & 15], d[(j + 8) & 15]));
+        const s16x2 b = pkmax(W8, pkmin(d[(j + 15) & 15], d[(j + 8) & 15]));
+        amax = q ? pkmax(amax, a) : a;
+        bmin = q ? pkmin(bmin, b) : b;
+    }
+    const int A0 = max((int)amax.x, -(int)bmin.x), A1 = max((int)amax.y, -(int)bmin.y);
+    const unsigned s0 = A0 > t ? (unsigned)(A0 - 1) : 0u, s1 = A1 > t ? (unsigned)(A1 - 1) : 0u;
+    return s0 | (s1 << 16);
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_fast_nms: one workgroup = one 64x32 output tile of one level of one image.
-//   1. stage the (64+8)x(32+8) raw tile in LDS with aligned dword loads (tile origin x = 16 + 64*tx)
-//   2. FAST score for the 66x34 region (tile + 1-px NMS halo), 0 outside any cell domain
+//   1. stage the (64+8)x(32+8) raw tile in LDS with aligned dword loads (tile origin x = 16 + 64*tx);
+//      ~100 threads also classify the tile's 66 columns / 34 rows against the level's cell grid once
+//      (which cell, inside a FAST detection domain or not, neighbours in the same cell or not)
+//   2. FAST score for the 66x34 region (tile + 1-px NMS halo), two pixels per thread-step
 //   3. 3x3 strict NMS against neighbours of the SAME cell (cv::FAST runs per cell sub-image, so
 //      neighbours in another cell count as 0); every survivor (score >= minTh) is APPENDED to its
 //      cell's slab as (y<<20 | x<<8 | score) and counted (total and >= iniTh).  No score map goes to
 //      HBM; k_cell_select restores cv::FAST's row-major order from the packed positions.
 // Since score >= t <=> corner at t, one pass serves both thresholds.
 // ------------------------------------------------------------------------------------------------
-constexpr int kRawP = kFastTW + 8;          // 72
-constexpr int kScP = kFastTW + 2 + 2;       // 68 (padded)
+constexpr int kRawP = kFastTW + 8;          // 72 bytes per raw row (18 dwords)
+constexpr int kScW = kFastTW + 2, kScH = kFastTH + 2, kScP = kFastTW + 4;   // score region 66 x 34, pitch 68
+// per column / row of the score region: bit0 valid, bit1 previous neighbour in the same cell, bit2 next neighbour
+// in the same cell, bits 8.. = cell column / row index
 __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg, const uint8_t* __restrict__ pyr,
                                                  const uint8_t* __restrict__ useCost, unsigned* __restrict__ rawCand,
                                                  int* __restrict__ cellCnt)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t raw[(kFastTH + 8) * kRawP];
-    __shared__ uint8_t sc[(kFastTH + 2) * kScP];
+    __shared__ __attribute__((aligned(16))) unsigned raw[(kFastTH + 8) * (kRawP / 4) + 4];   // +4: the funnel read touches one dword past a window
+    __shared__ __attribute__((aligned(4))) uint8_t sc[kScH * kScP];
+    __shared__ unsigned colInfo[kScW + 2], rowInfo[kScH + 2];
     const int img = blockIdx.y;
     int level = 0;
     const int nl = cfg->nlevels;
@@ -213,18 +220,51 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
         const int gy = y0 - 4 + ry, gx = x0 - 4 + rx4;
         unsigned v = 0;
         if (gy >= 0 && gy < G.h && gx < G.pitch) v = *(const unsigned*)(src + (size_t)gy * G.pitch + gx);
-        *(unsigned*)(raw + ry * kRawP + rx4) = v;
+        raw[i] = v;
+    }
+    if (tid < kScW) {                               // column classes: x = x0-1+tid
+        const int x = x0 - 1 + tid;
+        unsigned f = 0;
+        if (x >= kEdge && x < G.maxBX) {
+            const int j = (x - kEdge) / G.cellW;
+            const int cx0 = kEdge + j * G.cellW, cx1 = (j == G.cols - 1) ? G.maxBX : cx0 + G.cellW;
+            if (x < cx1) f = 1u | ((x - 1 >= cx0) ? 2u : 0u) | ((x + 1 < cx1) ? 4u : 0u) | ((unsigned)j << 8);
+        }
+        colInfo[tid] = f;
+    } else if (tid >= 128 && tid < 128 + kScH) {    // row classes: y = y0-1+(tid-128)
+        const int y = y0 - 1 + (tid - 128);
+        unsigned f = 0;
+        if (y >= kEdge && y < G.maxBY) {
+            int i = (y - kEdge) / G.cellH;
+            if (i > G.rows - 1) i = G.rows - 1;
+            const int cy0 = kEdge + i * G.cellH, cy1 = cy0 + ((i == G.rows - 1) ? G.domHLast : G.domH[mode]);
+            if (y < cy1) f = 1u | ((y - 1 >= cy0) ? 2u : 0u) | ((y + 1 < cy1) ? 4u : 0u) | ((unsigned)i << 8);
+        }
+        rowInfo[tid - 128] = f;
     }
     __syncthreads();
-    // 2. scores on the (TW+2)x(TH+2) region
+    // 2. scores, two pixels (sx, sx+1) per step; sx even, raw column of the left pixel = sx+3
     const int minTh = cfg->minTh;
-    for (int i = tid; i < (kFastTH + 2) * (kFastTW + 2); i += 256) {
-        const int sy = i / (kFastTW + 2), sx = i % (kFastTW + 2);
-        const int x = x0 - 1 + sx, y = y0 - 1 + sy;
-        CellRect r;
-        int s = 0;
-        if (cell_rect(G, mode, x, y, r)) s = fast_score<kRawP>(raw + (sy + 3) * kRawP + (sx + 3), minTh);
-        sc[sy * kScP + sx] = (uint8_t)s;
+    for (int i = tid; i < kScH * (kScW / 2); i += 256) {
+        const int sy = i / (kScW / 2), sx = (i % (kScW / 2)) * 2;
+        const unsigned c0 = colInfo[sx] & 1u, c1 = colInfo[sx + 1] & 1u, rv = rowInfo[sy] & 1u;
+        unsigned two = 0;
+        if (rv & (c0 | c1)) {
+            // window of row r starts at raw byte (sy + r) * kRawP + sx  (= left pixel's column - 3), sx even
+            unsigned lo[7], hi[7];
+            const int sh = sx & 2;
+            const unsigned* base = raw + (sy * kRawP + (sx & ~3)) / 4;
+#pragma unroll
+            for (int r = 0; r < 7; r++) {
+                const unsigned w0 = base[r * (kRawP / 4)], w1 = base[r * (kRawP / 4) + 1], w2 = base[r * (kRawP / 4) + 2];
+                lo[r] = __builtin_amdgcn_alignbyte(w1, w0, sh);
+                hi[r] = __builtin_amdgcn_alignbyte(w2, w1, sh);
+            }
+            two = fast_score_pair(lo, hi, minTh);
+            if (!c0) two &= 0xffff0000u;
+            if (!c1) two &= 0x0000ffffu;
+        }
+        *(unsigned short*)(sc + sy * kScP + sx) = (unsigned short)((two & 0xffu) | ((two >> 8) & 0xff00u));
     }
     __syncthreads();
     // 3. NMS + append
@@ -233,28 +273,28 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     int* cnt = cellCnt + (size_t)img * cfg->nCellsTotal * 2;
     for (int i = tid; i < kFastTH * kFastTW; i += 256) {
         const int oy = i / kFastTW, ox = i % kFastTW;
-        const int x = x0 + ox, y = y0 + oy;
         const uint8_t* c = sc + (oy + 1) * kScP + (ox + 1);
         const int s = c[0];
-        CellRect r;
-        if (s > 0 && cell_rect(G, mode, x, y, r)) {
-            const bool L = x - 1 >= r.x0, R = x + 1 < r.x1, U = y - 1 >= r.y0, D = y + 1 < r.y1;
-            bool ok = true;
-            ok &= s > ((L) ? c[-1] : 0);
-            ok &= s > ((R) ? c[1] : 0);
-            ok &= s > ((U && L) ? c[-kScP - 1] : 0);
-            ok &= s > ((U) ? c[-kScP] : 0);
-            ok &= s > ((U && R) ? c[-kScP + 1] : 0);
-            ok &= s > ((D && L) ? c[kScP - 1] : 0);
-            ok &= s > ((D) ? c[kScP] : 0);
-            ok &= s > ((D && R) ? c[kScP + 1] : 0);
-            if (ok) {
-                const int cell = ((r.y0 - kEdge) / G.cellH) * G.cols + (r.x0 - kEdge) / G.cellW;
-                const int gc = G.cellBase + cell;
-                const int slot = atomicAdd(&cnt[2 * gc], 1);
-                if (s >= iniTh) atomicAdd(&cnt[2 * gc + 1], 1);
-                if (slot < G.candCap) slab[(size_t)cell * G.candCap + slot] = ((unsigned)y << 20) | ((unsigned)x << 8) | (unsigned)s;
-            }
+        if (s == 0) continue;
+        const unsigned ci = colInfo[ox + 1], ri = rowInfo[oy + 1];
+        if (!(ci & ri & 1u)) continue;
+        const bool L = ci & 2u, R = ci & 4u, U = ri & 2u, D = ri & 4u;
+        bool ok = true;
+        ok &= s > ((L) ? c[-1] : 0);
+        ok &= s > ((R) ? c[1] : 0);
+        ok &= s > ((U && L) ? c[-kScP - 1] : 0);
+        ok &= s > ((U) ? c[-kScP] : 0);
+        ok &= s > ((U && R) ? c[-kScP + 1] : 0);
+        ok &= s > ((D && L) ? c[kScP - 1] : 0);
+        ok &= s > ((D) ? c[kScP] : 0);
+        ok &= s > ((D && R) ? c[kScP + 1] : 0);
+        if (ok) {
+            const int cell = (int)(ri >> 8) * G.cols + (int)(ci >> 8);
+            const int gc = G.cellBase + cell;
+            const int slot = atomicAdd(&cnt[2 * gc], 1);
+            if (s >= iniTh) atomicAdd(&cnt[2 * gc + 1], 1);
+            const int x = x0 + ox, y = y0 + oy;
+            if (slot < G.candCap) slab[(size_t)cell * G.candCap + slot] = ((unsigned)y << 20) | ((unsigned)x << 8) | (unsigned)s;
         }
     }
 }
