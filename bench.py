@@ -132,20 +132,20 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize(dev)
     fe.sync()
+    torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
-    torch.cuda.synchronize(dev)
+    fe.sync()                                           # batches run on the front end's own streams: wait for all of
+    torch.cuda.synchronize(dev)                         # them (also checks the device-side consistency flag)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    fe.sync()                                           # also checks the device-side consistency flag
     fast_sum_ms, fast_n = fe.fast_ms_stats(min(args.steps, 64))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)

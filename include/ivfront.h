@@ -141,12 +141,16 @@ typedef struct ivf_frontend_config {
 
 int  ivf_frontend_create(const ivf_frontend_config* cfg, ivf_frontend** out);
 void ivf_frontend_destroy(ivf_frontend* fe);
-/* Enqueue one batch on `hip_stream` (a hipStream_t, NULL = default stream); asynchronous.
+/* Enqueue one batch; asynchronous.  The batch is ordered after everything already enqueued on `hip_stream`
+ * (a hipStream_t, NULL = default stream; it produced the inputs) and runs on one of the front end's two internal
+ * streams, so consecutive batches overlap; `hip_stream` itself only waits until the inputs have been ingested
+ * (the caller may overwrite them in stream order right after this call).  Results of a run stay valid until the
+ * second run after it.  Use ivf_frontend_sync / ivf_frontend_fetch / ivf_frontend_pack_gather_block to consume.
  * d_left/d_right: device pointers to n_pairs grey images, image i at base + i*image_stride, rows of row_stride bytes.
  * d_cost: device pointer to n_pairs u8 cost maps (same layout) or NULL. */
 int  ivf_frontend_run(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_right, const uint8_t* d_cost,
                       size_t image_stride, int row_stride, int n_pairs, void* hip_stream);
-/* Block until the last ivf_frontend_run on this handle has finished. */
+/* Block until every ivf_frontend_run on this handle has finished; reports device-side consistency errors. */
 int  ivf_frontend_sync(ivf_frontend* fe);
 /* Device-resident results of the last run (valid until the next run).  side 0 = left, 1 = right.
  * d_kps: [max_pairs][cap] ivf_keypoint, d_desc: [max_pairs][cap][32], d_count: [max_pairs] int32, cap = nfeatures;

@@ -82,7 +82,8 @@ struct Context {
     int build(const Tables& t, int w, int h, int maxImages, int sides, int dev, bool withStereo);
     void release();
     int run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size_t imageStride, int rowStride,
-            size_t costStride, int costRowStride, int nImg, const uint8_t* hUseCost, hipStream_t st);
+            size_t costStride, int costRowStride, int nImg, const uint8_t* hUseCost, hipStream_t st,
+            hipEvent_t inputsConsumed = nullptr);
     int check_status();
 };
 
@@ -228,7 +229,8 @@ void Context::release()
 
 // Enqueue ORBextractor::operator() for nImg images (ORB/src/ORBextractor.cc:1224-1296)
 int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size_t imageStride, int rowStride,
-                 size_t costStride, int costRowStride, int nImg, const uint8_t* dUseCostSrc, hipStream_t st)
+                 size_t costStride, int costRowStride, int nImg, const uint8_t* dUseCostSrc, hipStream_t st,
+                 hipEvent_t inputsConsumed)
 {
     if (nImg < 1 || nImg > maxImg) return fail(IVF_E_INVALID, "batch of %d images outside [1,%d]", nImg, maxImg);
     HIPCHK(hipSetDevice(device));
@@ -237,11 +239,10 @@ int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size
     if (useQ) HIPCHK(hipMemcpyAsync(b.useCost, dUseCostSrc, nImg, hipMemcpyDeviceToDevice, st));
     else HIPCHK(hipMemsetAsync(b.useCost, 0, nImg, st));
     launch_ingest(hc, dc, b, s0, s1, imageStride, rowStride, nImg, nSides, b.pyr, st);
+    if (useQ) launch_ingest(hc, dc, b, cost, cost, costStride, costRowStride, nImg, nSides, b.qpyr, st);
+    if (inputsConsumed) HIPCHK(hipEventRecord(inputsConsumed, st));   // caller buffers are free from here on
     launch_pyramid(hc, dc, dTab, b.pyr, nImg, st);
-    if (useQ) {                                                   // ComputeQualityImagePyramid :1325-1357
-        launch_ingest(hc, dc, b, cost, cost, costStride, costRowStride, nImg, nSides, b.qpyr, st);
-        launch_pyramid(hc, dc, dTab, b.qpyr, nImg, st);
-    }
+    if (useQ) launch_pyramid(hc, dc, dTab, b.qpyr, nImg, st);       // ComputeQualityImagePyramid :1325-1357
     HIPCHK(hipMemsetAsync(b.cellCnt, 0, (size_t)nImg * hc.nCellsTotal * 2 * sizeof(int), st));
     const int slot = (int)(nRuns % kEvRing);
     HIPCHK(hipEventRecord(evFast0[slot], st));
@@ -294,13 +295,19 @@ struct ivf_extractor {
     uint8_t* dOne = nullptr;            // device byte "1"
 };
 
+// Two batch contexts on two internal streams: run k uses context k%2, so the latency-bound tail of one batch
+// (per-cell selection, descriptors, stereo) overlaps the throughput-bound head (ingest, pyramid, FAST, blur) of the
+// next.  Results of a run stay valid until the second run after it.
 struct ivf_frontend {
     ivf_frontend_config cfg;
     Tables tl;
-    Context ctx;
+    Context ctx[2];
+    hipStream_t stream[2] = {nullptr, nullptr};
+    hipEvent_t evIn[2] = {nullptr, nullptr}, evConsumed[2] = {nullptr, nullptr}, evDone[2] = {nullptr, nullptr};
     uint8_t* dFlags = nullptr;          // useCost flags when a cost batch is given: [L,R,L,R,...]
     int lastPairs = 0;
-    hipStream_t lastStream = nullptr;
+    long long runs = 0;
+    int last() const { return (int)((runs + 1) % 2); }      // context of the most recent run
 };
 
 // ---- Frame grid (ORB/src/Frame.cc:415-430, 615-680; 64 x 48, Frame.h:43-44) ----
@@ -651,15 +658,21 @@ int ivf_frontend_create(const ivf_frontend_config* cfg, ivf_frontend** out)
     if (rc) return rc;
     ivf_frontend* fe = new ivf_frontend();
     fe->cfg = *cfg; fe->tl = t;
-    rc = fe->ctx.build(t, cfg->width, cfg->height, 2 * cfg->max_pairs, 2, cfg->device_id, true);
-    if (rc) { fe->ctx.release(); delete fe; return rc; }
+    auto cleanup = [&](int code) { ivf_frontend_destroy(fe); return code; };
+    for (int k = 0; k < 2; k++) {
+        rc = fe->ctx[k].build(t, cfg->width, cfg->height, 2 * cfg->max_pairs, 2, cfg->device_id, true);
+        if (rc) return cleanup(rc);
+        if (hipStreamCreateWithFlags(&fe->stream[k], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&fe->evIn[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&fe->evConsumed[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&fe->evDone[k], hipEventDisableTiming) != hipSuccess)
+            return cleanup(fail(IVF_E_NO_DEVICE, "stream/event creation failed"));
+    }
     std::vector<uint8_t> flags(2 * (size_t)cfg->max_pairs);
     for (int i = 0; i < cfg->max_pairs; i++) { flags[2 * i] = L.enable_introspection ? 1 : 0; flags[2 * i + 1] = R.enable_introspection ? 1 : 0; }
     if (hipMalloc(&fe->dFlags, flags.size()) != hipSuccess ||
-        hipMemcpy(fe->dFlags, flags.data(), flags.size(), hipMemcpyHostToDevice) != hipSuccess) {
-        fe->ctx.release(); delete fe;
-        return fail(IVF_E_NO_DEVICE, "flag upload failed");
-    }
+        hipMemcpy(fe->dFlags, flags.data(), flags.size(), hipMemcpyHostToDevice) != hipSuccess)
+        return cleanup(fail(IVF_E_NO_DEVICE, "flag upload failed"));
     *out = fe;
     return IVF_OK;
 }
@@ -670,7 +683,13 @@ void ivf_frontend_destroy(ivf_frontend* fe)
     (void)hipSetDevice(fe->cfg.device_id);
     (void)hipDeviceSynchronize();
     if (fe->dFlags) (void)hipFree(fe->dFlags);
-    fe->ctx.release();
+    for (int k = 0; k < 2; k++) {
+        fe->ctx[k].release();
+        if (fe->stream[k]) (void)hipStreamDestroy(fe->stream[k]);
+        if (fe->evIn[k]) (void)hipEventDestroy(fe->evIn[k]);
+        if (fe->evConsumed[k]) (void)hipEventDestroy(fe->evConsumed[k]);
+        if (fe->evDone[k]) (void)hipEventDestroy(fe->evDone[k]);
+    }
     delete fe;
 }
 
@@ -681,13 +700,24 @@ int ivf_frontend_run(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_r
     if (n_pairs < 1 || n_pairs > fe->cfg.max_pairs) return fail(IVF_E_INVALID, "n_pairs %d outside [1,%d]", n_pairs, fe->cfg.max_pairs);
     if (row_stride < fe->cfg.width || image_stride < (size_t)row_stride * (fe->cfg.height - 1) + fe->cfg.width)
         return fail(IVF_E_INVALID, "strides too small for %dx%d", fe->cfg.width, fe->cfg.height);
-    hipStream_t st = (hipStream_t)hip_stream;
-    int rc = fe->ctx.run(d_left, d_right, d_cost, image_stride, row_stride, image_stride, row_stride, 2 * n_pairs,
-                         fe->dFlags, st);
+    hipStream_t caller = (hipStream_t)hip_stream;
+    const int k = (int)(fe->runs % 2);
+    Context& c = fe->ctx[k];
+    hipStream_t st = fe->stream[k];
+    HIPCHK(hipSetDevice(fe->cfg.device_id));
+    // order: everything the caller enqueued so far (it produced the inputs) -> this batch
+    HIPCHK(hipEventRecord(fe->evIn[k], caller));
+    HIPCHK(hipStreamWaitEvent(st, fe->evIn[k], 0));
+    int rc = c.run(d_left, d_right, d_cost, image_stride, row_stride, image_stride, row_stride, 2 * n_pairs,
+                   fe->dFlags, st, fe->evConsumed[k]);
     if (rc) return rc;
-    launch_stereo(fe->ctx.hc, fe->ctx.dc, fe->ctx.b, n_pairs, fe->cfg.bf, fe->cfg.b, st);
+    launch_stereo(c.hc, c.dc, c.b, n_pairs, fe->cfg.bf, fe->cfg.b, st);
     HIPCHK(hipGetLastError());
-    fe->lastPairs = n_pairs; fe->lastStream = st;
+    HIPCHK(hipEventRecord(fe->evDone[k], st));
+    // the caller's stream may overwrite its input buffers once they have been ingested
+    HIPCHK(hipStreamWaitEvent(caller, fe->evConsumed[k], 0));
+    fe->lastPairs = n_pairs;
+    fe->runs++;
     return IVF_OK;
 }
 
@@ -695,8 +725,12 @@ int ivf_frontend_sync(ivf_frontend* fe)
 {
     if (!fe) return fail(IVF_E_INVALID, "null handle");
     HIPCHK(hipSetDevice(fe->cfg.device_id));
-    HIPCHK(hipStreamSynchronize(fe->lastStream));
-    return fe->ctx.check_status();
+    for (int k = 0; k < 2; k++) {
+        HIPCHK(hipStreamSynchronize(fe->stream[k]));
+        const int rc = fe->ctx[k].check_status();
+        if (rc) return rc;
+    }
+    return IVF_OK;
 }
 
 int ivf_frontend_device_results(const ivf_frontend* fe, int side, const ivf_keypoint** d_kps, const uint8_t** d_desc,
@@ -704,8 +738,8 @@ int ivf_frontend_device_results(const ivf_frontend* fe, int side, const ivf_keyp
                                 const float** d_quality, int* cap)
 {
     if (!fe || side < 0 || side > 1) return fail(IVF_E_INVALID, "bad argument");
-    const Buffers& b = fe->ctx.b;
-    const size_t nf = fe->ctx.hc.nfeatures;
+    const Buffers& b = fe->ctx[fe->last()].b;
+    const size_t nf = fe->ctx[0].hc.nfeatures;
     // images are interleaved [L0,R0,L1,R1,...]: element stride between pairs is 2*cap
     if (d_kps) *d_kps = b.kps + side * nf;
     if (d_desc) *d_desc = b.desc + side * nf * 32;
@@ -724,8 +758,8 @@ int ivf_frontend_fetch(ivf_frontend* fe, int pair, int side, ivf_keypoint* kps, 
     if (pair < 0 || pair >= fe->lastPairs) return fail(IVF_E_INVALID, "pair %d outside the last batch of %d", pair, fe->lastPairs);
     int rc = ivf_frontend_sync(fe);
     if (rc) return rc;
-    const Buffers& b = fe->ctx.b;
-    const size_t nf = fe->ctx.hc.nfeatures, img = (size_t)pair * 2 + side;
+    const Buffers& b = fe->ctx[fe->last()].b;
+    const size_t nf = fe->ctx[0].hc.nfeatures, img = (size_t)pair * 2 + side;
     int n = 0;
     HIPCHK(hipMemcpy(&n, b.count + img, sizeof(int), hipMemcpyDeviceToHost));
     *n_out = n;
@@ -752,12 +786,14 @@ int ivf_frontend_fast_ms_stats(ivf_frontend* fe, int last_n, double* sum_ms, int
 {
     if (!fe || !sum_ms || !n_out) return fail(IVF_E_INVALID, "null argument");
     *sum_ms = 0; *n_out = 0;
-    Context& c = fe->ctx;
     HIPCHK(hipSetDevice(fe->cfg.device_id));
-    const long long avail = std::min<long long>(c.nRuns, Context::kEvRing);
+    // run r used context r%2 and that context's ring slot (r/2) % kEvRing
+    const long long keep = 2 * (long long)Context::kEvRing;
+    const long long avail = std::min<long long>(fe->runs, keep);
     const long long take = std::min<long long>(avail, last_n < 1 ? avail : last_n);
-    for (long long r = c.nRuns - take; r < c.nRuns; r++) {
-        const int slot = (int)(r % Context::kEvRing);
+    for (long long r = fe->runs - take; r < fe->runs; r++) {
+        Context& c = fe->ctx[r % 2];
+        const int slot = (int)((r / 2) % Context::kEvRing);
         HIPCHK(hipEventSynchronize(c.evFast1[slot]));
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, c.evFast0[slot], c.evFast1[slot]));
@@ -769,7 +805,7 @@ int ivf_frontend_fast_ms_stats(ivf_frontend* fe, int last_n, double* sum_ms, int
 int ivf_frontend_pack_gather_block(ivf_frontend* fe, uint8_t* d_block, size_t block_bytes, size_t* record_bytes, void* hip_stream)
 {
     if (!fe || !record_bytes) return fail(IVF_E_INVALID, "null argument");
-    const size_t nf = fe->ctx.hc.nfeatures;
+    const size_t nf = fe->ctx[0].hc.nfeatures;
     const size_t rec = 16 + nf * sizeof(ivf_keypoint) + nf * 32 + nf * sizeof(float);
     *record_bytes = rec;
     if (!d_block) return IVF_OK;
@@ -777,8 +813,9 @@ int ivf_frontend_pack_gather_block(ivf_frontend* fe, uint8_t* d_block, size_t bl
     if (np < 1) return fail(IVF_E_STATE, "no batch has run");
     if (block_bytes < rec * np) return fail(IVF_E_CAPACITY, "gather block needs %zu bytes", rec * np);
     hipStream_t st = (hipStream_t)hip_stream;
-    const Buffers& b = fe->ctx.b;
+    const Buffers& b = fe->ctx[fe->last()].b;
     HIPCHK(hipSetDevice(fe->cfg.device_id));
+    HIPCHK(hipStreamWaitEvent(st, fe->evDone[fe->last()], 0));       // the batch runs on an internal stream
     HIPCHK(hipMemsetAsync(d_block, 0, rec * np, st));
     HIPCHK(hipMemcpy2DAsync(d_block, rec, b.count, 2 * sizeof(int), sizeof(int), np, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpy2DAsync(d_block + 16, rec, b.kps, 2 * nf * sizeof(ivf_keypoint), nf * sizeof(ivf_keypoint), np,
