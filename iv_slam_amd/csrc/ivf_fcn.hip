@@ -97,31 +97,49 @@ __global__ __launch_bounds__(256) void k_fcn_conv0(const float* __restrict__ X, 
 }
 
 // ---- depthwise 3x3 (stride s, dilation d, pad d) + BN + ReLU6 (mobilenet.py:46,54; models_light.py:139-152) ----
-__global__ void k_fcn_dw(const float* __restrict__ X, const float* __restrict__ Wt, const float* __restrict__ scale,
-                         const float* __restrict__ shift, float* __restrict__ Y, int C, int Hi, int Wi, int Ho, int Wo,
-                         int stride, int dil)
+// HBM-bound stencil.  One workgroup = one 64 x 16 output tile of one channel plane: the input window
+// ((16-1)*s + 2d + 1) x ((64-1)*s + 2d + 1) is staged in LDS once (zero padding materialised there), every
+// thread then produces 4 horizontally adjacent outputs and stores them as one float4.
+constexpr int kDwTW = 64, kDwTH = 16;
+template <int S>
+__global__ __launch_bounds__(256) void k_fcn_dw(const float* __restrict__ X, const float* __restrict__ Wt,
+                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                               float* __restrict__ Y, int C, int Hi, int Wi, int Ho, int Wo, int dil)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    const int bc = blockIdx.z;                 // b*C + c
-    if (x >= Wo) return;
-    const int c = bc % C;
+    extern __shared__ float tile[];
+    const int bc = blockIdx.z, c = bc % C;
+    const int ox0 = blockIdx.x * kDwTW, oy0 = blockIdx.y * kDwTH;
+    const int IW = (kDwTW - 1) * S + 2 * dil + 1, IH = (kDwTH - 1) * S + 2 * dil + 1;
+    const int IWp = IW | 1;                                   // odd pitch: conflict-free column access
+    const int ix0 = ox0 * S - dil, iy0 = oy0 * S - dil;
     const float* I = X + (size_t)bc * Hi * Wi;
-    const float* wk = Wt + c * 9;
-    float acc = 0.f;
+    for (int i = threadIdx.x; i < IH * IW; i += 256) {
+        const int r = i / IW, q = i % IW;
+        const int yy = iy0 + r, xx = ix0 + q;
+        tile[r * IWp + q] = (yy >= 0 && yy < Hi && xx >= 0 && xx < Wi) ? I[(size_t)yy * Wi + xx] : 0.f;
+    }
+    float wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) wk[k] = Wt[c * 9 + k];
+    const float sc = scale[c], sh = shift[c];
+    __syncthreads();
+    const int ty = threadIdx.x >> 4, tx4 = (threadIdx.x & 15) * 4;
+    const int oy = oy0 + ty;
+    if (oy >= Ho || ox0 + tx4 >= Wo) return;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ky = 0; ky < 3; ky++) {
-        const int yy = y * stride - dil + ky * dil;
-        if (yy < 0 || yy >= Hi) continue;
+        const float* row = tile + (ty * S + ky * dil) * IWp + tx4 * S;
 #pragma unroll
-        for (int kx = 0; kx < 3; kx++) {
-            const int xx = x * stride - dil + kx * dil;
-            if (xx >= 0 && xx < Wi) acc += wk[ky * 3 + kx] * I[(size_t)yy * Wi + xx];
-        }
+        for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+            for (int p = 0; p < 4; p++) o[p] += wk[ky * 3 + kx] * row[p * S + kx * dil];
     }
-    float r = acc * scale[c] + shift[c];
-    r = fminf(fmaxf(r, 0.f), 6.f);
-    Y[(size_t)bc * Ho * Wo + (size_t)y * Wo + x] = r;
+#pragma unroll
+    for (int p = 0; p < 4; p++) o[p] = fminf(fmaxf(o[p] * sc + sh, 0.f), 6.f);
+    float* out = Y + (size_t)bc * Ho * Wo + (size_t)oy * Wo + ox0 + tx4;
+    if (ox0 + tx4 + 3 < Wo) *(float4*)out = make_float4(o[0], o[1], o[2], o[3]);
+    else for (int p = 0; p < 4 && ox0 + tx4 + p < Wo; p++) out[p] = o[p];
 }
 
 // ---- 1x1 (TAPS=1) / dense 3x3 pad 1 (TAPS=9) convolution as an MFMA GEMM ----
@@ -162,18 +180,36 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
     const float* wp = Wf + (size_t)ct0 * 64 + lane;
 
     if (TAPS == 1) {
+        // software pipeline: operands of step k2+2 are requested before the MFMAs of step k2 issue, so the
+        // 12-20 MFMAs of two steps (64 cycles each) cover the L2/HBM latency of the loads
         const float* xp = Xb + p0;
-#pragma unroll 2
-        for (int k2 = 0; k2 < K2; k2++) {
-            const vec bv = *(const vec*)(xp + (size_t)2 * k2 * HW);
-            float a[NT];
+        vec b0 = *(const vec*)xp, b1 = b0;
+        float a0[NT], a1[NT];
 #pragma unroll
-            for (int n = 0; n < NT; n++) a[n] = wp[((size_t)k2 * nTiles + n) * 64];
+        for (int n = 0; n < NT; n++) { a0[n] = wp[(size_t)n * 64]; a1[n] = a0[n]; }
+        if (K2 > 1) {
+            b1 = *(const vec*)(xp + (size_t)2 * HW);
+#pragma unroll
+            for (int n = 0; n < NT; n++) a1[n] = wp[((size_t)nTiles + n) * 64];
+        }
+        for (int k2 = 0; k2 < K2; k2++) {
+            vec b2 = b1;
+            float a2[NT];
+#pragma unroll
+            for (int n = 0; n < NT; n++) a2[n] = a1[n];
+            if (k2 + 2 < K2) {
+                b2 = *(const vec*)(xp + (size_t)2 * (k2 + 2) * HW);
+#pragma unroll
+                for (int n = 0; n < NT; n++) a2[n] = wp[((size_t)(k2 + 2) * nTiles + n) * 64];
+            }
 #pragma unroll
             for (int n = 0; n < NT; n++)
 #pragma unroll
                 for (int p = 0; p < PT; p++)
-                    acc[n][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n], vget<PT>(bv, p), acc[n][p], 0, 0, 0);
+                    acc[n][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[n], vget<PT>(b0, p), acc[n][p], 0, 0, 0);
+            b0 = b1; b1 = b2;
+#pragma unroll
+            for (int n = 0; n < NT; n++) { a0[n] = a1[n]; a1[n] = a2[n]; }
         }
     } else {
         int py[PT], pxx[PT];
@@ -393,8 +429,15 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
         if (bk.t != 1) { launch_gemm(f->pw[ip++], x, nullptr, f->bufH1, H, W, n, s); h = f->bufH1; snprintf(nm, sizeof nm, "block %d expand", i + 1); STAGE(nm); }
         const Dw& d = f->dw[id++];
         const int Ho = (H + 2 * d.dil - 2 * d.dil - 1) / d.stride + 1, Wo = (W + 2 * d.dil - 2 * d.dil - 1) / d.stride + 1;
-        hipLaunchKernelGGL(k_fcn_dw, dim3((Wo + 63) / 64, Ho, n * hid), dim3(64), 0, s, h, d.dW, d.dScale, d.dShift, f->bufH2,
-                           hid, H, W, Ho, Wo, d.stride, d.dil);
+        {
+            const dim3 grid((Wo + kDwTW - 1) / kDwTW, (Ho + kDwTH - 1) / kDwTH, n * hid);
+            const int IW = (kDwTW - 1) * d.stride + 2 * d.dil + 1, IH = (kDwTH - 1) * d.stride + 2 * d.dil + 1;
+            const size_t lds = (size_t)IH * (IW | 1) * sizeof(float);
+            if (d.stride == 1)
+                hipLaunchKernelGGL((k_fcn_dw<1>), grid, dim3(256), lds, s, h, d.dW, d.dScale, d.dShift, f->bufH2, hid, H, W, Ho, Wo, d.dil);
+            else
+                hipLaunchKernelGGL((k_fcn_dw<2>), grid, dim3(256), lds, s, h, d.dW, d.dScale, d.dShift, f->bufH2, hid, H, W, Ho, Wo, d.dil);
+        }
         snprintf(nm, sizeof nm, "block %d depthwise", i + 1); STAGE(nm);
         H = Ho; W = Wo;
         launch_gemm(f->pw[ip++], f->bufH2, bk.res ? x : nullptr, y, H, W, n, s);
