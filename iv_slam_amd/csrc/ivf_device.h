@@ -48,7 +48,7 @@ struct Config {
 // cv::resize coefficient table entry: src index | coef0 << 16 | coef1 << 32 (11-bit fixed point, A-3)
 typedef unsigned long long ResizeCoef;
 
-constexpr int kFastTW = 64, kFastTH = 32;     // FAST/NMS output tile
+constexpr int kFastTW = 128, kFastTH = 32;    // FAST/NMS output tile (kFastTW + 2 <= 192, kFastTH + 2 <= 64: see k_fast_nms)
 constexpr int kBlurTW = 64, kBlurTH = 32;     // blur output tile
 
 struct Buffers {            // device pointers of one batch context

@@ -142,7 +142,7 @@ DEVINL s16x2 pair_at(unsigned lo, unsigned hi, int i)      // bytes W[i], W[i+1]
     return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | ((unsigned)(i + 1) << 16) | (unsigned)i));
 }
 // rows: 7 windows (dy = -3..3), each as (lo, hi) dwords.  Returns the two scores packed (left | right << 16).
-DEVINL unsigned fast_score_pair(const unsigned (&lo)[7], const unsigned (&hi)[7], int t)
+DEVINL unsigned fast_score_pair(const unsigned (&lo)[7], const unsigned (&hi)[7], int t, bool quickOnly = false)
 {
     const s16x2 v = pair_at(lo[3], hi[3], 3);
     s16x2 d[16];
@@ -158,6 +158,7 @@ DEVINL unsigned fast_score_pair(const unsigned (&lo)[7], const unsigned (&hi)[7]
     for (int k = 1; k < 8; k++) { dk = pkmin(dk, pkmax(d[k], d[k + 8])); br = pkmax(br, pkmin(d[k], d[k + 8])); }
     const bool pass = (dk.x > t) | (dk.y > t) | (br.x < -t) | (br.y < -t);
     if (!pass) return 0u;
+    if (quickOnly) return 0x00010001u;
     s16x2 mn[8], mx[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) { const int j = 2 * q + 1; mn[q] = pkmin(d[j], d[(j + 1) & 15]); mx[q] = pkmax(d[j], d[(j + 1) & 15]); }
@@ -236,8 +237,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
             if (x < cx1) f = 1u | ((x - 1 >= cx0) ? 2u : 0u) | ((x + 1 < cx1) ? 4u : 0u) | ((unsigned)j << 8);
         }
         colInfo[tid] = f;
-    } else if (tid >= 128 && tid < 128 + kScH) {    // row classes: y = y0-1+(tid-128)
-        const int y = y0 - 1 + (tid - 128);
+    } else if (tid >= 192 && tid < 192 + kScH) {    // row classes: y = y0-1+(tid-192)
+        const int y = y0 - 1 + (tid - 192);
         unsigned f = 0;
         if (y >= kEdge && y < G.maxBY) {
             int i = (y - kEdge) / G.cellH;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
             const int cy0 = kEdge + i * G.cellH, cy1 = cy0 + ((i == G.rows - 1) ? G.domHLast : G.domH[mode]);
             if (y < cy1) f = 1u | ((y - 1 >= cy0) ? 2u : 0u) | ((y + 1 < cy1) ? 4u : 0u) | ((unsigned)i << 8);
         }
-        rowInfo[tid - 128] = f;
+        rowInfo[tid - 192] = f;
     }
     __syncthreads();
     // 2. scores, two pixels (sx, sx+1) per step; sx even, raw column of the left pixel = sx+3
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
                 lo[r] = __builtin_amdgcn_alignbyte(w1, w0, sh);
                 hi[r] = __builtin_amdgcn_alignbyte(w2, w1, sh);
             }
-            two = fast_score_pair(lo, hi, minTh);
+            two = fast_score_pair(lo, hi, minTh, (ablate & 4) != 0);
             if (!c0) two &= 0xffff0000u;
             if (!c1) two &= 0x0000ffffu;
         }

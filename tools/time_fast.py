@@ -9,6 +9,6 @@ left, right = make_device_stream(torch, dev, 64, seed=100)
 fe = iv.StereoFrontend(W, H, 64)
 for i in range(6):
     fe.run(left, right)
-fe.sync()
+    fe.sync()                      # no overlap between batches: isolate the kernel
 s, n = fe.fast_ms_stats(4)
 print("IVF_FAST_ABLATE=%s k_fast_nms avg %.1f us" % (os.environ.get("IVF_FAST_ABLATE", "0"), 1e3 * s / n))
