@@ -127,6 +127,18 @@ int  ivf_search_by_projection(const ivf_keypoint* cur_kps, const uint8_t* cur_de
                               const uint8_t* q_valid, const uint8_t* q_blocks,
                               int check_orientation, int32_t* cur_assign, int* nmatches, int device_id);
 
+/* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th) (ORB/src/ORBmatcher.cc:45-135; called
+ * from Tracking::SearchLocalPoints, ORB/src/Tracking.cc:2124-2130) on flat queries, one per map point with
+ * mbTrackInView && !isBad():  q_u,q_v = mTrackProjX/Y; q_ur = mTrackProjXR; q_radius = r * mvScaleFactors[level] with
+ * r = RadiusByViewingCos(mTrackViewCos) (2.5 if viewCos > 0.998 else 4.0), times th when th != 1 (:63-70);
+ * q_level = mnTrackScaleLevel (window levels [level-1, level]); nn_ratio = mfNNratio.  Best / second best with the
+ * ratio test only when both are in the same octave (:117-121).  cur_assign / q_valid / q_blocks as above. */
+int  ivf_search_map_points(const ivf_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int n_cur,
+                           const ivf_bounds* bounds, int n_q, const float* q_u, const float* q_v, const float* q_ur,
+                           const float* q_radius, const int32_t* q_level, const uint8_t* q_desc,
+                           const uint8_t* q_valid, const uint8_t* q_blocks, float nn_ratio,
+                           int32_t* cur_assign, int* nmatches, int device_id);
+
 /* ---- batched device-resident stereo front end (throughput path; one per GPU) ----
  * Equivalent to, for each pair: left/right ORBextractor::operator() (ORB/src/Frame.cc:115-125),
  * mvKeyQualScore (ORB/src/Frame.cc:130-143) and Frame::ComputeStereoMatches (:758-932), for up to

@@ -57,6 +57,8 @@ _SIGS = {
                                        vp, C.c_int, C.POINTER(C.c_int)]),
     "ivf_search_by_projection": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                            vp, vp, C.c_int, vp, C.POINTER(C.c_int), C.c_int]),
+    "ivf_search_map_points": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
+                                        C.c_float, vp, C.POINTER(C.c_int), C.c_int]),
     "ivf_frontend_create": (C.c_int, [C.POINTER(FrontendConfig), C.POINTER(vp)]),
     "ivf_frontend_destroy": (None, [vp]),
     "ivf_frontend_run": (C.c_int, [vp, vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]),

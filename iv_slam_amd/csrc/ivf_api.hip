@@ -638,6 +638,55 @@ int ivf_search_by_projection(const ivf_keypoint* cur_kps, const uint8_t* cur_des
     return IVF_OK;
 }
 
+// ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th) (ORB/src/ORBmatcher.cc:45-135)
+int ivf_search_map_points(const ivf_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int n_cur,
+                          const ivf_bounds* bounds, int n_q, const float* q_u, const float* q_v, const float* q_ur,
+                          const float* q_radius, const int32_t* q_level, const uint8_t* q_desc,
+                          const uint8_t* q_valid, const uint8_t* q_blocks, float nn_ratio,
+                          int32_t* cur_assign, int* nmatches, int device_id)
+{
+    if (!cur_kps || !cur_desc || !cur_uright || !bounds || !cur_assign || !nmatches || n_cur < 0 || n_q < 0)
+        return fail(IVF_E_INVALID, "bad argument");
+    *nmatches = 0;
+    if (n_q == 0 || n_cur == 0) return IVF_OK;
+    if (!q_u || !q_v || !q_ur || !q_radius || !q_level || !q_desc) return fail(IVF_E_INVALID, "null query array");
+    // 1. candidate windows in GetFeaturesInArea order, levels [pred-1, pred] (:72-73)
+    Grid g; g.build(cur_kps, n_cur, *bounds);
+    std::vector<int> qStart(n_q + 1, 0), pairs;
+    for (int i = 0; i < n_q; i++) {
+        qStart[i] = (int)pairs.size() / 2;
+        if (q_valid && !q_valid[i]) continue;
+        g.query(cur_kps, *bounds, q_u[i], q_v[i], q_radius[i], q_level[i] - 1, q_level[i],
+                [&](int i2) { pairs.push_back(i); pairs.push_back(i2); });
+    }
+    qStart[n_q] = (int)pairs.size() / 2;
+    const int nPairs = qStart[n_q];
+    // 2. all window distances on the device
+    std::vector<int> dist(std::max(nPairs, 1));
+    int rc = ivf_hamming_pairs(q_desc, n_q, cur_desc, n_cur, pairs.data(), nPairs, dist.data(), device_id);
+    if (rc) return rc;
+    // 3. best / second best + ratio test, greedy in map-point order (:86-126)
+    int nm = 0;
+    for (int i = 0; i < n_q; i++) {
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int p = qStart[i]; p < qStart[i + 1]; p++) {
+            const int idx = pairs[2 * p + 1];
+            if (cur_assign[idx] == -2) continue;
+            if (cur_assign[idx] >= 0 && (!q_blocks || q_blocks[cur_assign[idx]])) continue;
+            if (cur_uright[idx] > 0) { const float er = fabsf(q_ur[i] - cur_uright[idx]); if (er > q_radius[i]) continue; }
+            const int d = dist[p];
+            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = cur_kps[idx].octave; bestIdx = idx; }
+            else if (d < bestDist2) { bestLevel2 = cur_kps[idx].octave; bestDist2 = d; }
+        }
+        if (bestIdx >= 0 && bestDist <= 100) {
+            if (bestLevel == bestLevel2 && (float)bestDist > nn_ratio * (float)bestDist2) continue;
+            cur_assign[bestIdx] = i; nm++;
+        }
+    }
+    *nmatches = nm;
+    return IVF_OK;
+}
+
 // ---- batched stereo front end ----
 int ivf_frontend_create(const ivf_frontend_config* cfg, ivf_frontend** out)
 {

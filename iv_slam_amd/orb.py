@@ -169,3 +169,26 @@ class ORBmatcher:
                                                  ptr(qq["desc"]), ptr(qq["valid"]), ptr(qq["blocks"]),
                                                  int(self.mbCheckOrientation), ptr(assign), C.byref(nm), self.device_id))
         return assign, nm.value
+
+    @staticmethod
+    def RadiusByViewingCos(viewCos):
+        """ORBmatcher::RadiusByViewingCos (ORB/src/ORBmatcher.cc:137-143)."""
+        return 2.5 if viewCos > 0.998 else 4.0
+
+    def SearchByProjectionMapPoints(self, cur_kps, cur_desc, cur_uright, bounds, q, cur_assign=None):
+        """SearchByProjection(Frame &F, const vector<MapPoint*>&, th) (ORBmatcher.cc:45-135) on projected map points:
+        q has u, v, ur, radius, level, desc, valid, blocks.  Returns (F.mvpMapPoints as query indices, nmatches)."""
+        cur_kps = np.ascontiguousarray(cur_kps, KP_DTYPE); cur_desc = np.ascontiguousarray(cur_desc, np.uint8)
+        cur_uright = np.ascontiguousarray(cur_uright, np.float32)
+        n_cur = len(cur_kps); n_q = len(q["u"])
+        assign = np.full(n_cur, -1, np.int32) if cur_assign is None else np.ascontiguousarray(cur_assign, np.int32).copy()
+        types = dict(u=np.float32, v=np.float32, ur=np.float32, radius=np.float32, level=np.int32, desc=np.uint8,
+                     valid=np.uint8, blocks=np.uint8)
+        qq = {k: np.ascontiguousarray(q[k], t) for k, t in types.items()}
+        nm = C.c_int(0)
+        bd = Bounds(*bounds)
+        check(self._lib.ivf_search_map_points(ptr(cur_kps), ptr(cur_desc), ptr(cur_uright), n_cur, C.byref(bd), n_q,
+                                              ptr(qq["u"]), ptr(qq["v"]), ptr(qq["ur"]), ptr(qq["radius"]), ptr(qq["level"]),
+                                              ptr(qq["desc"]), ptr(qq["valid"]), ptr(qq["blocks"]), self.mfNNratio,
+                                              ptr(assign), C.byref(nm), self.device_id))
+        return assign, nm.value

@@ -1050,3 +1050,54 @@ int orc_search_by_projection(const orc_keypoint* cur_kps, const uint8_t* cur_des
     *nmatches_out = nmatches;
     return 0;
 }
+
+/* a14  ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th) (ORB/src/ORBmatcher.cc:45-135)
+ * on already-projected queries.  Per query i (a map point with mbTrackInView and !isBad()):
+ *   q_u,q_v = mTrackProjX/Y; q_ur = mTrackProjXR; q_radius = r*mvScaleFactors[nPredictedLevel] with
+ *   r = RadiusByViewingCos(mTrackViewCos) (*th when th != 1) (:63-70); q_level = nPredictedLevel (window levels
+ *   [level-1, level]); best / second-best with the ratio test only when both sit in the same octave (:117-121). */
+int orc_search_map_points(const orc_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int n_cur,
+                          const orc_bounds* bounds, int n_q, const float* q_u, const float* q_v, const float* q_ur,
+                          const float* q_radius, const int32_t* q_level, const uint8_t* q_desc,
+                          const uint8_t* q_valid, const uint8_t* q_blocks, float nn_ratio,
+                          int32_t* cur_assign, int* nmatches_out)
+{
+    int nmatches = 0;
+    grid_t g;
+    grid_build(&g, cur_kps, n_cur, bounds);
+    int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (n_cur > 0 ? n_cur : 1));
+    for (int i = 0; i < n_q; i++) {
+        if (q_valid && !q_valid[i]) continue;
+        const int level = q_level[i];
+        int nc = grid_query(&g, cur_kps, bounds, q_u[i], q_v[i], q_radius[i], level - 1, level, cand, n_cur);
+        if (nc == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = 0; k < nc; k++) {
+            const int idx = cand[k];
+            if (cur_assign[idx] == -2) continue;
+            if (cur_assign[idx] >= 0 && (!q_blocks || q_blocks[cur_assign[idx]])) continue;
+            if (cur_uright[idx] > 0) {
+                const float er = fabsf(q_ur[i] - cur_uright[idx]);
+                if (er > q_radius[i]) continue;
+            }
+            const int dist = orc_hamming256(q_desc + (size_t)i * 32, cur_desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist;
+                bestLevel2 = bestLevel; bestLevel = cur_kps[idx].octave;
+                bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = cur_kps[idx].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= 100) {
+            if (bestLevel == bestLevel2 && (float)bestDist > nn_ratio * (float)bestDist2) continue;
+            cur_assign[bestIdx] = i;
+            nmatches++;
+        }
+    }
+    free(cand);
+    grid_free(&g);
+    *nmatches_out = nmatches;
+    return 0;
+}

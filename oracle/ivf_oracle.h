@@ -101,6 +101,12 @@ int   orc_search_by_projection(const orc_keypoint* cur_kps, const uint8_t* cur_d
                                const float* q_angle, const uint8_t* q_desc,
                                const uint8_t* q_valid, const uint8_t* q_blocks,
                                int check_orientation, int32_t* cur_assign, int* nmatches);
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (ORB/src/ORBmatcher.cc:45-135), flat queries */
+int   orc_search_map_points(const orc_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int n_cur,
+                            const orc_bounds* bounds, int n_q, const float* q_u, const float* q_v, const float* q_ur,
+                            const float* q_radius, const int32_t* q_level, const uint8_t* q_desc,
+                            const uint8_t* q_valid, const uint8_t* q_blocks, float nn_ratio,
+                            int32_t* cur_assign, int* nmatches);
 /* Frame::GetFeaturesInArea on a freshly built grid: returns count, indices in reference order */
 int   orc_features_in_area(const orc_keypoint* kps, int n, const orc_bounds* bounds,
                            float x, float y, float r, int min_level, int max_level, int32_t* out, int cap);

@@ -74,6 +74,9 @@ lib.orc_features_in_area.restype = C.c_int
 lib.orc_features_in_area.argtypes = [vp, C.c_int, C.POINTER(Bounds), C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
                                      vp, C.c_int]
 lib.orc_three_maxima.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+lib.orc_search_map_points.restype = C.c_int
+lib.orc_search_map_points.argtypes = [vp, vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
+                                      C.c_float, vp, C.POINTER(C.c_int)]
 pin.stl_retain_best.restype = C.c_int; pin.stl_retain_best.argtypes = [vp, C.c_int, C.c_int]
 pin.stl_nth_element.argtypes = [vp, C.c_int, C.c_int]
 
@@ -209,4 +212,21 @@ def search_by_projection(cur_kps, cur_desc, cur_uright, bounds, q, check_orienta
                                  ptr(qq["u"]), ptr(qq["v"]), ptr(qq["ur"]), ptr(qq["radius"]),
                                  ptr(qq["min_level"]), ptr(qq["max_level"]), ptr(qq["angle"]), ptr(qq["desc"]),
                                  ptr(qq["valid"]), ptr(qq["blocks"]), int(check_orientation), ptr(assign), C.byref(nm))
+    return assign, nm.value
+
+
+def search_map_points(cur_kps, cur_desc, cur_uright, bounds, q, nn_ratio, cur_assign=None):
+    """q: dict with u,v,ur,radius,level,desc,valid,blocks."""
+    cur_kps = np.ascontiguousarray(cur_kps); cur_desc = np.ascontiguousarray(cur_desc, np.uint8)
+    cur_uright = np.ascontiguousarray(cur_uright, np.float32)
+    n_cur = len(cur_kps); n_q = len(q["u"])
+    assign = np.full(n_cur, -1, np.int32) if cur_assign is None else np.ascontiguousarray(cur_assign, np.int32).copy()
+    arrs = dict(u=np.float32, v=np.float32, ur=np.float32, radius=np.float32, level=np.int32, desc=np.uint8,
+                valid=np.uint8, blocks=np.uint8)
+    qq = {k: np.ascontiguousarray(q[k], t) for k, t in arrs.items()}
+    bd = Bounds(*bounds)
+    nm = C.c_int(0)
+    lib.orc_search_map_points(ptr(cur_kps), ptr(cur_desc), ptr(cur_uright), n_cur, C.byref(bd), n_q, ptr(qq["u"]), ptr(qq["v"]),
+                              ptr(qq["ur"]), ptr(qq["radius"]), ptr(qq["level"]), ptr(qq["desc"]), ptr(qq["valid"]),
+                              ptr(qq["blocks"]), nn_ratio, ptr(assign), C.byref(nm))
     return assign, nm.value

@@ -216,6 +216,15 @@ def test_hamming_pairs_and_search_by_projection(iv):
     assert gn == on and np.array_equal(ga, oa) and gn > nq // 4
     for x, y, r, lo, hi in [(300, 120, 40, -1, -1), (10, 10, 30, 0, 3), (630, 230, 60, 2, 7)]:
         assert np.array_equal(iv.GetFeaturesInArea(kps, bounds, x, y, r, lo, hi), O.features_in_area(kps, bounds, x, y, r, lo, hi))
+    # a14: SearchByProjection(F, mapPoints) (Tracking::SearchLocalPoints) with the same perturbed queries
+    qm = dict(u=q["u"], v=q["v"], ur=q["ur"], radius=(4.0 * sc[oct_]).astype(np.float32),
+              level=np.clip(oct_ + rng.integers(-1, 2, nq), 0, 7).astype(np.int32), desc=qd, valid=q["valid"], blocks=q["blocks"])
+    for ratio in (0.6, 0.8, 1.0):
+        mm = iv.ORBmatcher(ratio, True)
+        ga, gn = mm.SearchByProjectionMapPoints(kps, desc, uright, bounds, qm, pre)
+        oa, on = O.search_map_points(kps, desc, uright, bounds, qm, ratio, pre)
+        assert gn == on and np.array_equal(ga, oa)
+    assert iv.ORBmatcher.RadiusByViewingCos(0.999) == 2.5 and iv.ORBmatcher.RadiusByViewingCos(0.9) == 4.0
 
 
 def test_full_size_properties(iv):

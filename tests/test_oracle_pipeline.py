@@ -147,3 +147,29 @@ def test_search_by_projection_greedy_and_rotation_filter():
     pre = np.full(n, -1, np.int32); pre[:50] = -2
     a4, _ = O.search_by_projection(kps, desc, ur, (0, 0, 640, 240), q, True, pre)
     assert (a4[:50] == -2).all()
+
+
+def test_search_map_points_ratio_test_and_levels():
+    """a14 SearchByProjection(F, mapPoints) (ORBmatcher.cc:45-135): window levels [pred-1, pred], best/second-best,
+    ratio test only when both are in the same octave."""
+    img = synth.make_left(640, 240, seed=18, idx=0)
+    kps, desc = O.Extractor(500, 1.2, 8, 20, 7)(img)
+    n = len(kps)
+    sc = O.Extractor(500, 1.2, 8, 20, 7).tables()["scale"]
+    q = dict(u=kps["x"].copy(), v=kps["y"].copy(), ur=np.zeros(n, np.float32), radius=(4.0 * sc[kps["octave"]]).astype(np.float32),
+             level=kps["octave"].astype(np.int32), desc=desc.copy(), valid=np.ones(n, np.uint8), blocks=np.ones(n, np.uint8))
+    ur = np.full(n, -1, np.float32)
+    a, nm = O.search_map_points(kps, desc, ur, (0, 0, 640, 240), q, 0.8)
+    assert nm == (a >= 0).sum() and nm > 0.85 * n                   # identical descriptors: dist 0 always passes the ratio
+    # a predicted level one ABOVE the keypoint's octave still finds it (window [pred-1, pred]); two above does not
+    q1 = dict(q); q1["level"] = (kps["octave"] + 1).astype(np.int32)
+    a1, nm1 = O.search_map_points(kps, desc, ur, (0, 0, 640, 240), q1, 0.8)
+    assert nm1 > 0.5 * n
+    q2 = dict(q); q2["level"] = (kps["octave"] + 2).astype(np.int32)
+    a2, nm2 = O.search_map_points(kps, desc, ur, (0, 0, 640, 240), q2, 0.8)
+    assert nm2 < nm1
+    # ratio test: make every query descriptor equally far (16 bits) from ALL candidates' descriptors by using a constant
+    qd = np.zeros_like(desc); q3 = dict(q); q3["desc"] = qd
+    a3, nm3 = O.search_map_points(kps, desc, ur, (0, 0, 640, 240), q3, 0.0)     # ratio 0: same-octave second best always rejects
+    a4, nm4 = O.search_map_points(kps, desc, ur, (0, 0, 640, 240), q3, 1.0)
+    assert nm3 <= nm4
