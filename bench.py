@@ -162,6 +162,16 @@ def main():
         imgs_per_launch = 2 * P
         algo_bytes = (LEVEL_PX_SUM + NFEAT * 8) * imgs_per_launch      # pyramid read + candidate output
         fast_ms = fast_sum_ms / max(fast_n, 1)
+        # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, raw x1024;
+        # collected separately because counters cannot be read inside this process), rescaled to this launch size
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+            k = pmc["kernels"]["ivf::k_fast_nms"]
+            traffic = int((k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]) * imgs_per_launch / pmc["images_per_launch"])
+            traffic_src = "profiles/r01_pmc_hbm_traffic.json"
+        except Exception:
+            pass
         achieved = algo_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
         out = {
             "metric": METRIC, "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
@@ -174,7 +184,7 @@ def main():
                        "nlevels": 8, "scale_factor": 1.2, "fast_thresholds": [20, 7],
                        "parallelism": "frames sharded %d-way, RCCL all-gather of descriptor blocks" % world if world > 1 else "1 GPU"},
             "roofline": {"kernel": "k_fast_nms", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(fast_ms, 5),
                          "launches_timed": fast_n},
         }
