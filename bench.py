@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--stream", type=int, default=256, help="distinct pairs resident per GPU")
     ap.add_argument("--introspect", action="store_true", help="configs[2]: run the introspection FCN on every left image and gate keypoints with it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="profiling aid: wait for each batch before enqueuing the next, so "
+                    "rocprofv3 kernel durations are not inflated by the overlap of consecutive batches")
     args = ap.parse_args()
 
     import torch
@@ -129,6 +131,8 @@ def main():
             # the path's one exchange step: all-gather of {n, kps, desc, uRight} for cross-frame matching
             fe.pack_gather_block(block, sptr)
             dist.all_gather_into_tensor(gathered, block)
+        if args.serial:
+            fe.sync()
 
     for i in range(args.warmup):
         step(i)

@@ -97,6 +97,11 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
     c.nlevels = t.p.nlevels; c.w = w; c.h = h; c.nfeatures = t.p.nfeatures;
     c.iniTh = t.p.ini_th_fast; c.minTh = t.p.min_th_fast; c.introspection = introspection ? 1 : 0;
     memcpy(c.umax, t.umax, sizeof c.umax);
+    {   // k_describe carries umax as a packed constant (HALF_PATCH_SIZE = 15 is fixed): make sure it is this table
+        const unsigned long long packed = 0x3689ABCDDEEEFFFFull;
+        for (int i = 0; i < 16; i++)
+            if ((int)((packed >> (4 * i)) & 15) != t.umax[i]) return fail(IVF_E_STATE, "umax table mismatch at %d", i);
+    }
     const float imageRatio = (float)w / h;                       // ORBextractor.cc:884
     int off = 0, cellBase = 0, candBase = 0, kpBase = 0, tileBase = 0, btileBase = 0;
     for (int l = 0; l < c.nlevels; l++) {

@@ -60,12 +60,12 @@ __global__ void k_ingest(const Config* __restrict__ cfg, const uint8_t* __restri
 // ------------------------------------------------------------------------------------------------
 // k_pyr_down: cv::resize INTER_LINEAR 8UC1 (11-bit coefficients; horizontal pass in int,
 // vertical pass ((b0*(h0>>4))>>16) + ((b1*(h1>>4))>>16) + 2) >> 2).
-// One workgroup = 256 x 4 output pixels; the source rows it needs are staged in LDS with aligned
+// One workgroup = 256 x 16 output pixels; the source rows it needs are staged in LDS with aligned
 // dword loads, every thread produces 4 horizontally adjacent pixels (one dword store).  The
 // per-column / per-row coefficients (fx = (float)((dx+0.5)*scale - 0.5), cvRound(f*2048) ...) come
 // from a packed table the host builds once per geometry exactly as OpenCV's resize does.
 // ------------------------------------------------------------------------------------------------
-constexpr int kPyrTW = 256, kPyrTH = 4, kPyrSrcP = 544, kPyrSrcR = 12;     // LDS: 12 rows x 544 B (scale <= 2)
+constexpr int kPyrTW = 256, kPyrTH = 16, kPyrSrcP = 544, kPyrSrcR = 36;    // LDS: 36 rows x 544 B (scale <= 2)
 __global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg, int level,
                                                  const ResizeCoef* __restrict__ tab, uint8_t* __restrict__ blob)
 {
@@ -92,36 +92,46 @@ __global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg
         }
     }
     __syncthreads();
-    const int dy = dy0 + (tid >> 6), x4 = dx0 + (tid & 63) * 4;
-    if (dy >= D.h || x4 >= D.pitch) return;
-    const ResizeCoef cy = ty[dy];
-    const int y0 = (int)(cy & 0xffff), y1 = min(y0 + 1, S.h - 1);
-    const int b0 = (int)((cy >> 16) & 0xffff), b1 = (int)((cy >> 32) & 0xffff);
-    unsigned out = 0;
+    const int x4 = dx0 + (tid & 63) * 4;
+    if (x4 >= D.pitch) return;
+    // the 4 column coefficients of this thread are shared by its 4 rows
+    int sxk[4], sx1k[4], a0k[4], a1k[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int dx = x4 + k;
-        unsigned r = 0;
-        if (dx < D.w) {
-            const ResizeCoef cx = tx[dx];
-            const int sx = (int)(cx & 0xffff), sx1 = min(sx + 1, S.w - 1);
-            const int a0 = (int)((cx >> 16) & 0xffff), a1 = (int)((cx >> 32) & 0xffff);
-            int p00, p01, p10, p11;
-            if (fits) {
-                const uint8_t* r0 = src + (y0 - wy0) * kPyrSrcP - wx0;
-                const uint8_t* r1 = src + (y1 - wy0) * kPyrSrcP - wx0;
-                p00 = r0[sx]; p01 = r0[sx1]; p10 = r1[sx]; p11 = r1[sx1];
-            } else {
-                const uint8_t* r0 = SP + (size_t)y0 * S.pitch;
-                const uint8_t* r1 = SP + (size_t)y1 * S.pitch;
-                p00 = r0[sx]; p01 = r0[sx1]; p10 = r1[sx]; p11 = r1[sx1];
-            }
-            const int h0 = p00 * a0 + p01 * a1, h1 = p10 * a0 + p11 * a1;
-            r = (unsigned)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
-        }
-        out |= r << (8 * k);
+        const int dx = min(x4 + k, D.w - 1);
+        const ResizeCoef cx = tx[dx];
+        sxk[k] = (int)(cx & 0xffff); sx1k[k] = min(sxk[k] + 1, S.w - 1);
+        a0k[k] = (int)((cx >> 16) & 0xffff); a1k[k] = (int)((cx >> 32) & 0xffff);
     }
-    *(unsigned*)(base + D.off + (size_t)dy * D.pitch + x4) = out;
+#pragma unroll
+    for (int rr = 0; rr < kPyrTH / 4; rr++) {
+        const int dy = dy0 + (tid >> 6) + 4 * rr;
+        if (dy >= D.h) break;
+        const ResizeCoef cy = ty[dy];
+        const int y0 = (int)(cy & 0xffff), y1 = min(y0 + 1, S.h - 1);
+        const int b0 = (int)((cy >> 16) & 0xffff), b1 = (int)((cy >> 32) & 0xffff);
+        unsigned out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            unsigned r = 0;
+            if (x4 + k < D.w) {
+                int p00, p01, p10, p11;
+                if (fits) {
+                    const uint8_t* r0 = src + (y0 - wy0) * kPyrSrcP - wx0;
+                    const uint8_t* r1 = src + (y1 - wy0) * kPyrSrcP - wx0;
+                    p00 = r0[sxk[k]]; p01 = r0[sx1k[k]]; p10 = r1[sxk[k]]; p11 = r1[sx1k[k]];
+                } else {
+                    const uint8_t* r0 = SP + (size_t)y0 * S.pitch;
+                    const uint8_t* r1 = SP + (size_t)y1 * S.pitch;
+                    p00 = r0[sxk[k]]; p01 = r0[sx1k[k]]; p10 = r1[sxk[k]]; p11 = r1[sx1k[k]];
+                }
+                const int h0 = p00 * a0k[k] + p01 * a1k[k], h1 = p10 * a0k[k] + p11 * a1k[k];
+                r = (unsigned)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+            }
+            out |= r << (8 * k);
+        }
+        *(unsigned*)(base + D.off + (size_t)dy * D.pitch + x4) = out;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -285,24 +295,32 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     for (int q = 1; q <= kFastTH; q++) if (rowInfo[q] & 1u) { fr = (int)(rowInfo[q] >> 8); break; }
     const int firstRow = fr;
     __syncthreads();
-    for (int i = tid; i < kFastTH * kFastTW; i += 256) {
-        const int oy = i / kFastTW, ox = i % kFastTW;
-        const uint8_t* c = sc + (oy + 1) * kScP + (ox + 1);
-        const int s = c[0];
-        if (s == 0) continue;
-        const unsigned ci = colInfo[ox + 1], ri = rowInfo[oy + 1];
-        if (!(ci & ri & 1u)) continue;
-        const bool L = ci & 2u, R = ci & 4u, U = ri & 2u, D = ri & 4u;
-        bool ok = true;
-        ok &= s > ((L) ? c[-1] : 0);
-        ok &= s > ((R) ? c[1] : 0);
-        ok &= s > ((U && L) ? c[-kScP - 1] : 0);
-        ok &= s > ((U) ? c[-kScP] : 0);
-        ok &= s > ((U && R) ? c[-kScP + 1] : 0);
-        ok &= s > ((D && L) ? c[kScP - 1] : 0);
-        ok &= s > ((D) ? c[kScP] : 0);
-        ok &= s > ((D && R) ? c[kScP + 1] : 0);
-        if (ok) {
+    // four pixels per step: most score bytes are 0, so one 32-bit LDS read dismisses 4 pixels at once
+    // (sc rows start at score column 0 = x0-1; tile pixel ox sits at byte ox+1, so the aligned dword at byte 4q
+    // holds tile pixels 4q-1 .. 4q+2)
+    for (int i = tid; i < kFastTH * (kFastTW / 4 + 1); i += 256) {
+        const int oy = i / (kFastTW / 4 + 1), q = i % (kFastTW / 4 + 1);
+        const unsigned four = *(const unsigned*)(sc + (oy + 1) * kScP + 4 * q);
+        if (four == 0) continue;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int ox = 4 * q - 1 + k;
+            const int s = (four >> (8 * k)) & 0xff;
+            if (s == 0 || ox < 0 || ox >= kFastTW) continue;
+            const uint8_t* c = sc + (oy + 1) * kScP + (ox + 1);
+            const unsigned ci = colInfo[ox + 1], ri = rowInfo[oy + 1];
+            if (!(ci & ri & 1u)) continue;
+            const bool L = ci & 2u, R = ci & 4u, U = ri & 2u, D = ri & 4u;
+            bool ok = true;
+            ok &= s > ((L) ? c[-1] : 0);
+            ok &= s > ((R) ? c[1] : 0);
+            ok &= s > ((U && L) ? c[-kScP - 1] : 0);
+            ok &= s > ((U) ? c[-kScP] : 0);
+            ok &= s > ((U && R) ? c[-kScP + 1] : 0);
+            ok &= s > ((D && L) ? c[kScP - 1] : 0);
+            ok &= s > ((D) ? c[kScP] : 0);
+            ok &= s > ((D && R) ? c[kScP + 1] : 0);
+            if (!ok) continue;
             const int crow = (int)(ri >> 8), ccol = (int)(ci >> 8);
             const int lr = crow - firstRow, lc = ccol - firstCol;
             const unsigned packed = ((unsigned)(y0 + oy) << 20) | ((unsigned)(x0 + ox) << 8) | (unsigned)s;
@@ -312,7 +330,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
                 const int rk = atomicAdd(&s_cnt[lid], 1);
                 if (s >= iniTh) atomicAdd(&s_ini[lid], 1);
                 s_list[idx] = packed;
-                s_tag[idx] = (unsigned short)((lid << 10) | rk);       // rk < 512 survivors per tile
+                s_tag[idx] = (unsigned short)((lid << 10) | rk);       // rk < 1024 survivors per tile
             } else {                                                    // tile spans too many cells: direct path
                 const int cell = crow * G.cols + ccol, gc = G.cellBase + cell;
                 int* cnt = cellCnt + (size_t)img * cfg->nCellsTotal * 2;
@@ -827,20 +845,28 @@ __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg
     const uint8_t* B = blur + (size_t)img * cfg->pyrBytes + G.off;
     const int pitch = G.pitch;
 
-    // IC_Angle: 31 rows, two rows per step (lanes 0-31 / 32-63), u = lane%32 - 15
+    // IC_Angle: 31 rows, two rows per step (lanes 0-31 / 32-63), u = lane%32 - 15.  umax (ORBextractor.cc:458-475)
+    // depends only on HALF_PATCH_SIZE = 15, so it is a packed constant (4 bits per row; checked against the
+    // constructor's table on the host) and all 16 loads of a lane are independent and issued together.
     int m10 = 0, m01 = 0;
     {
+        const unsigned long long kUmax = 0x3689ABCDDEEEFFFFull;
         const int u = (lane & 31) - 15;
+        const uint8_t* c0 = P + (size_t)py * pitch + px + u;
+        int val[16];
+#pragma unroll
         for (int r = 0; r < 16; r++) {
             const int v = -15 + 2 * r + (lane >> 5);
-            if (v <= 15) {
-                const int d = cfg->umax[v < 0 ? -v : v];
-                if (u >= -d && u <= d && (lane & 31) < 31) {
-                    const int val = P[(size_t)(py + v) * pitch + px + u];
-                    m10 += u * val;
-                    m01 += v * val;
-                }
-            }
+            const int av = v < 0 ? -v : v;
+            const int d = (int)((kUmax >> (4 * (av & 15))) & 15);
+            const bool in = v <= 15 && u >= -d && u <= d && (lane & 31) < 31;
+            val[r] = in ? (int)c0[(ptrdiff_t)v * pitch] : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int v = -15 + 2 * r + (lane >> 5);
+            m10 += u * val[r];
+            m01 += v * val[r];
         }
         m10 = wave_sum_i32(m10);
         m01 = wave_sum_i32(m01);
@@ -1017,30 +1043,43 @@ __global__ __launch_bounds__(256) void k_stereo_gate(const Config* __restrict__ 
                                                     int cntStride, float* __restrict__ uright, float* __restrict__ depth,
                                                     const int* __restrict__ sad, int outStride)
 {
-    __shared__ int s_n, s_median;
-    const int pair = blockIdx.x;
+    // SAD distances are integers in [0, 121*510]: the value at sorted index n/2 comes from two 256-bin histograms
+    // (high byte, then low byte inside the selected bin) instead of a sort.
+    __shared__ int s_hist[256];
+    __shared__ int s_n, s_bin, s_below, s_median;
+    const int pair = blockIdx.x, tid = threadIdx.x;
     const int nL = cntL[pair * cntStride];
     const int* S = sad + (size_t)pair * outStride;
-    if (threadIdx.x == 0) { s_n = 0; s_median = -1; }
+    s_hist[tid] = 0;
+    if (tid == 0) { s_n = 0; s_median = -1; }
     __syncthreads();
     int local = 0;
-    for (int i = threadIdx.x; i < nL; i += blockDim.x) local += S[i] >= 0;
-    atomicAdd(&s_n, local);
+    for (int i = tid; i < nL; i += 256) { const int d = S[i]; if (d >= 0) { local++; atomicAdd(&s_hist[min(d >> 8, 255)], 1); } }
+    if (local) atomicAdd(&s_n, local);
     __syncthreads();
     const int n = s_n;
     if (n == 0) return;
     const int target = n / 2;
-    for (int i = threadIdx.x; i < nL; i += blockDim.x) {
-        const int d = S[i];
-        if (d < 0) continue;
-        int lt = 0, le = 0;
-        for (int j = 0; j < nL; j++) { const int e = S[j]; if (e >= 0) { lt += e < d; le += e <= d; } }
-        if (lt <= target && target < le) s_median = d;
+    if (tid == 0) {
+        int acc = 0, b = 0;
+        for (; b < 256; b++) { if (acc + s_hist[b] > target) break; acc += s_hist[b]; }
+        s_bin = b; s_below = acc;
+    }
+    __syncthreads();
+    const int bin = s_bin, below = s_below;
+    s_hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < nL; i += 256) { const int d = S[i]; if (d >= 0 && min(d >> 8, 255) == bin) atomicAdd(&s_hist[d & 255], 1); }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = below, b = 0;
+        for (; b < 256; b++) { if (acc + s_hist[b] > target) break; acc += s_hist[b]; }
+        s_median = (bin << 8) | b;
     }
     __syncthreads();
     const float median = (float)s_median;
     const float thDist = 1.5f * 1.4f * median;
-    for (int i = threadIdx.x; i < nL; i += blockDim.x) {
+    for (int i = tid; i < nL; i += 256) {
         const int d = S[i];
         if (d >= 0 && !((float)d < thDist)) {
             uright[(size_t)pair * outStride + i] = -1;
