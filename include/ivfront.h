@@ -139,6 +139,12 @@ int  ivf_search_map_points(const ivf_keypoint* cur_kps, const uint8_t* cur_desc,
                            const uint8_t* q_valid, const uint8_t* q_blocks, float nn_ratio,
                            int32_t* cur_assign, int* nmatches, int device_id);
 
+/* ---- testing hook ----
+ * Runs the device's cv::KeyPointsFilter::retainBest core (the wave-cooperative replay of libstdc++ std::nth_element
+ * used by the keypoint selection kernels) on caller-supplied non-negative responses: order_out[i] = index of the
+ * element that ends at position i after nth_element(begin, begin+n_points-1, end, response-greater).  1 <= n <= 4096. */
+int  ivf_test_retain_best(const float* responses, int n, int n_points, int32_t* order_out, int device_id);
+
 /* ---- batched device-resident stereo front end (throughput path; one per GPU) ----
  * Equivalent to, for each pair: left/right ORBextractor::operator() (ORB/src/Frame.cc:115-125),
  * mvKeyQualScore (ORB/src/Frame.cc:130-143) and Frame::ComputeStereoMatches (:758-932), for up to

@@ -692,6 +692,23 @@ int ivf_search_map_points(const ivf_keypoint* cur_kps, const uint8_t* cur_desc, 
     return IVF_OK;
 }
 
+// testing hook (see include/ivfront.h)
+int ivf_test_retain_best(const float* responses, int n, int n_points, int32_t* order_out, int device_id)
+{
+    if (!responses || !order_out || n < 1 || n > 4096 || n_points < 0) return fail(IVF_E_INVALID, "bad argument (1 <= n <= 4096)");
+    int rc = have_device(device_id);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    float* dR = nullptr; int* dO = nullptr;
+    HIPCHK(hipMalloc(&dR, (size_t)n * sizeof(float))); HIPCHK(hipMalloc(&dO, (size_t)n * sizeof(int)));
+    HIPCHK(hipMemcpy(dR, responses, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    launch_test_retain_best(dR, n, n_points, dO, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(order_out, dO, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(dR); (void)hipFree(dO);
+    return IVF_OK;
+}
+
 // ---- batched stereo front end ----
 int ivf_frontend_create(const ivf_frontend_config* cfg, ivf_frontend** out)
 {

@@ -99,6 +99,7 @@ void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nIm
 void launch_describe(const Config& hc, const Config* dc, const Buffers& b, const uint8_t* cost0, size_t costStride,
                      int costPitch, int nImg, int nSides, hipStream_t s);
 void launch_stereo(const Config& hc, const Config* dc, const Buffers& b, int nPairs, float bf, float bb, hipStream_t s);
+void launch_test_retain_best(const float* dResp, int n, int nPoints, int* dOrder, hipStream_t s);
 void launch_hamming_pairs(const uint8_t* a, const uint8_t* b, const int* pairs, int n, int* dist, hipStream_t s);
 
 }  // namespace ivf

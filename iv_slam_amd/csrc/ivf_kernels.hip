@@ -537,6 +537,108 @@ DEVINL void sel_nth_element(PTR v, int n, int nth)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Wave-cooperative replay of the same introselect.  The sequential bottleneck of std::nth_element is
+// __unguarded_partition's two pointer scans; its outcome, however, is a pure function of the array at
+// the start of the round:
+//   a_0 < a_1 < ...  positions >= first+1 whose value is NOT greater than the pivot  (where `lo` stops)
+//   b_0 > b_1 > ...  positions <= last-1  whose value is NOT less    than the pivot  (where `hi` stops)
+//   the loop swaps (a_k, b_k) for k < K, K = first k with a_k >= b_k, and returns
+//   cut = min(a_K, b_{K-1})   (a swapped-in value <= pivot sits at b_{K-1}; b_{-1} = +inf)
+// so one round is two ordered compactions (wave ballots), a count and K independent swaps: O(range/64)
+// steps instead of O(range).  median-of-3, the <= 3 element insertion sort and the depth-limit heap-select
+// fallback stay on lane 0.  All 64 lanes call this with uniform arguments; v, A, B live in LDS.
+// ------------------------------------------------------------------------------------------------
+DEVINL void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+template <typename PTR, typename IDX>
+DEVINL void sel_nth_element_wave(PTR v, int n, int nth, IDX A, IDX B, int lane)
+{
+    if (n <= 0 || nth >= n) return;
+    int first = 0, last = n;
+    int depth = 0;
+    for (int t = n; t > 1; t >>= 1) depth++;
+    depth *= 2;
+    while (last - first > 3) {
+        if (depth == 0) {                       // rare: finish sequentially exactly as libstdc++ does
+            if (lane == 0) {
+                PTR f = v + first;
+                const int len = nth + 1 - first;
+                if (len >= 2) {
+                    int parent = (len - 2) / 2;
+                    for (;;) { u64 val = f[parent]; sel_adjust_heap(f, parent, len, val); if (parent == 0) break; parent--; }
+                }
+                for (int i = nth + 1; i < last; ++i)
+                    if (RGT(v[i], f[0])) { u64 val = v[i]; v[i] = f[0]; sel_adjust_heap(f, 0, len, val); }
+                u64 tmp = v[first]; v[first] = v[nth]; v[nth] = tmp;
+            }
+            wave_sync_lds();
+            return;
+        }
+        --depth;
+        if (lane == 0) {                        // __move_median_to_first(first, first+1, mid, last-1)
+            const int mid = first + (last - first) / 2;
+            const int a = first + 1, b = mid, c = last - 1;
+            const u64 va = v[a], vb = v[b], vc = v[c];
+            int m;
+            if (RGT(va, vb)) { if (RGT(vb, vc)) m = b; else if (RGT(va, vc)) m = c; else m = a; }
+            else if (RGT(va, vc)) m = a;
+            else if (RGT(vb, vc)) m = c;
+            else m = b;
+            const u64 tmp = v[first]; v[first] = v[m]; v[m] = tmp;
+        }
+        wave_sync_lds();
+        const unsigned pivot = (unsigned)(v[first] >> 32);
+        const int lo0 = first + 1, len = last - lo0;
+        // ordered compaction of the left stops (ascending) and right stops (descending position)
+        int nA = 0, nB = 0;
+        for (int base = 0; base < len; base += 64) {
+            const int i = lo0 + base + lane;                     // ascending walk
+            const bool inA = base + lane < len && !((unsigned)(v[i] >> 32) > pivot);
+            const unsigned long long mA = __ballot(inA);
+            if (inA) A[nA + __popcll(mA & ((1ull << lane) - 1ull))] = (unsigned short)i;
+            nA += __popcll(mA);
+            const int j = last - 1 - base - lane;                // descending walk
+            const bool inB = base + lane < len && !(pivot > (unsigned)(v[j] >> 32));
+            const unsigned long long mB = __ballot(inB);
+            if (inB) B[nB + __popcll(mB & ((1ull << lane) - 1ull))] = (unsigned short)j;
+            nB += __popcll(mB);
+        }
+        wave_sync_lds();
+        // K = number of leading pairs with a_k < b_k (monotone predicate)
+        const int nP = min(nA, nB);
+        int K = 0;
+        for (int base = 0; base < nP; base += 64) {
+            const int k = base + lane;
+            const bool ok = k < nP && (int)A[k] < (int)B[k];
+            const unsigned long long mk = __ballot(ok);
+            K += __popcll(mk);
+            if (mk != ~0ull) break;
+        }
+        const int aK = K < nA ? (int)A[K] : 0x7fffffff;
+        const int bKm1 = K > 0 ? (int)B[K - 1] : 0x7fffffff;
+        const int cut = min(aK, bKm1);
+        for (int k = lane; k < K; k += 64) {                     // the swaps touch disjoint positions
+            const int ia = A[k], ib = B[k];
+            const u64 ta = v[ia], tb = v[ib];
+            v[ia] = tb; v[ib] = ta;
+        }
+        wave_sync_lds();
+        if (cut <= nth) first = cut; else last = cut;
+    }
+    if (lane == 0) {                            // __insertion_sort(first, last), <= 3 elements
+        for (int i = first + 1; i < last; ++i) {
+            const u64 val = v[i];
+            if (RGT(val, v[first])) { for (int k = i; k > first; --k) v[k] = v[k - 1]; v[first] = val; }
+            else { int l = i; while (RGT(val, v[l - 1])) { v[l] = v[l - 1]; --l; } v[l] = val; }
+        }
+    }
+    wave_sync_lds();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Keypoint selection = ComputeKeyPointsOld :880-1213 minus the per-pixel work, in three kernels:
 //   k_quota        per (image, level): `<=3 -> minThFAST` fallback per cell (:1047) from k_fast_nms's counters,
 //                  cost-map cell weights and quotas (:946-987, :1028-1031), the single-pass quota redistribution
@@ -643,6 +745,8 @@ __global__ __launch_bounds__(64) void k_cell_select(const Config* __restrict__ c
 {
     __shared__ __attribute__((aligned(16))) unsigned keys[CAP];
     __shared__ __attribute__((aligned(16))) u64 ord[CAP];
+    unsigned short* stopA = (unsigned short*)keys;            // the sort keys are dead once `ord` is built:
+    unsigned short* stopB = stopA + CAP;                      // their space holds the partition stop lists
     const int img = blockIdx.y, gc = blockIdx.x, lane = threadIdx.x;
     int level = 0;
     const int nl = cfg->nlevels;
@@ -712,9 +816,7 @@ __global__ __launch_bounds__(64) void k_cell_select(const Config* __restrict__ c
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // d) retainBest
-        if (nR > 0 && nT > nR && lane == 0) sel_nth_element(ord, nT, nR - 1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        if (nR > 0 && nT > nR) sel_nth_element_wave(ord, nT, nR - 1, stopA, stopB, lane);
         for (int k = lane; k < kept; k += 64) dst[k] = ord[k];
     }
 }
@@ -725,6 +827,7 @@ __global__ __launch_bounds__(256) void k_level_select(const Config* __restrict__
 {
     constexpr int LCAP = 4096;
     __shared__ __attribute__((aligned(16))) u64 s_list[LCAP];
+    __shared__ unsigned short s_stopA[LCAP], s_stopB[LCAP];
     const int img = blockIdx.y, level = blockIdx.x, tid = threadIdx.x;
     const LevelGeom& G = cfg->lv[level];
     if (!G.valid) { if (tid == 0) lvlCount[img * kMaxLevels + level] = 0; return; }
@@ -737,7 +840,8 @@ __global__ __launch_bounds__(256) void k_level_select(const Config* __restrict__
             L = s_list;
             __syncthreads();
         }
-        if (tid == 0) sel_nth_element(L, total, G.nDesired - 1);       // :1162-1166
+        if (L == s_list) { if (tid < 64) sel_nth_element_wave(s_list, total, G.nDesired - 1, s_stopA, s_stopB, tid); }
+        else if (tid == 0) sel_nth_element(L, total, G.nDesired - 1);   // :1162-1166 (global fallback)
         total = G.nDesired;
         __syncthreads();
     }
@@ -1086,6 +1190,23 @@ __global__ __launch_bounds__(256) void k_stereo_gate(const Config* __restrict__ 
             depth[(size_t)pair * outStride + i] = -1;
         }
     }
+}
+
+// testing hook: the device's retainBest on caller-supplied responses (one wave, LDS), so the wave-cooperative
+// introselect can be checked against libstdc++ on arbitrary / adversarial inputs
+__global__ __launch_bounds__(64) void k_test_retain_best(const float* __restrict__ resp, int n, int nPoints, int* __restrict__ order)
+{
+    __shared__ __attribute__((aligned(16))) u64 list[kCellCapBig];
+    __shared__ unsigned short sa[kCellCapBig], sb[kCellCapBig];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < n; i += 64) list[i] = ((u64)__float_as_uint(resp[i]) << 32) | (unsigned)i;
+    wave_sync_lds();
+    if (nPoints > 0 && n > nPoints) sel_nth_element_wave(list, n, nPoints - 1, sa, sb, lane);
+    for (int i = lane; i < n; i += 64) order[i] = (int)(unsigned)list[i];
+}
+void launch_test_retain_best(const float* dResp, int n, int nPoints, int* dOrder, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_test_retain_best, dim3(1), dim3(64), 0, s, dResp, n, nPoints, dOrder);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -268,3 +268,38 @@ def test_committed_golden_fixtures(iv):
         assert kL.tobytes() == k[prefix + "kpsL"].tobytes() and np.array_equal(dL, k[prefix + "descL"])
         assert kR.tobytes() == k[prefix + "kpsR"].tobytes() and np.array_equal(dR, k[prefix + "descR"])
         assert ur.tobytes() == k[prefix + "uright"].tobytes() and dp.tobytes() == k[prefix + "depth"].tobytes()
+
+
+def test_device_retain_best_matches_libstdcxx(iv):
+    """The wave-cooperative introselect on the device against the REAL libstdc++ nth_element (oracle/stl_pin.cpp):
+    tie-heavy random inputs, sorted/reversed runs, and organ-pipe inputs that hit the depth-limit heap-select."""
+    import ctypes as C
+    from iv_slam_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(2024)
+
+    def check(resp, k):
+        n = len(resp)
+        resp = np.ascontiguousarray(resp, np.float32)
+        order = np.zeros(n, np.int32)
+        _lib.check(lib.ivf_test_retain_best(_lib.ptr(resp), n, k, _lib.ptr(order), 0))
+        v = np.zeros(n, O.KP_DTYPE); v["response"] = resp; v["x"] = np.arange(n)
+        if 0 < k < n:
+            O.pin.stl_nth_element(O.ptr(v), n, k - 1)
+        assert np.array_equal(order, v["x"].astype(np.int32)), (n, k)
+
+    for _ in range(150):
+        n = int(rng.integers(1, 3000))
+        mode = int(rng.integers(0, 4))
+        resp = rng.integers(7, 7 + int(rng.integers(1, 80)), n).astype(np.float32)
+        if mode == 1:
+            resp *= rng.choice(np.array([0.25, 0.5, 1.0], np.float32), n)
+        elif mode == 2:
+            resp = np.sort(resp)[::-1].copy() if rng.integers(0, 2) else np.sort(resp)
+        elif mode == 3:
+            resp[:] = 42.0
+        check(resp, int(rng.integers(0, n + 2)))
+    for n in (64, 257, 1000, 4096):
+        base = np.concatenate([np.arange(0, n, 2), np.arange(1, n, 2)[::-1]]).astype(np.float32)
+        for k in (1, 2, n // 3, n // 2, n - 1):
+            check(base, k)
