@@ -97,11 +97,11 @@ __global__ __launch_bounds__(256) void k_fcn_conv0(const float* __restrict__ X, 
 }
 
 // ---- depthwise 3x3 (stride s, dilation d, pad d) + BN + ReLU6 (mobilenet.py:46,54; models_light.py:139-152) ----
-// HBM-bound stencil.  One workgroup = one 64 x 16 output tile of one channel plane: the input window
-// ((16-1)*s + 2d + 1) x ((64-1)*s + 2d + 1) is staged in LDS once (zero padding materialised there), every
+// HBM-bound stencil.  One workgroup = one 64 x TH output tile of one channel plane (TH = 64 when the plane is 64 rows,
+// else 16): the input window ((TH-1)*s + 2d + 1) x ((64-1)*s + 2d + 1) is staged in LDS once (zero padding materialised there), every
 // thread then produces 4 horizontally adjacent outputs and stores them as one float4.
-constexpr int kDwTW = 64, kDwTH = 16;
-template <int S>
+constexpr int kDwTW = 64;
+template <int S, int kDwTH>
 __global__ __launch_bounds__(256) void k_fcn_dw(const float* __restrict__ X, const float* __restrict__ Wt,
                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                float* __restrict__ Y, int C, int Hi, int Wi, int Ho, int Wo, int dil)
@@ -123,23 +123,28 @@ __global__ __launch_bounds__(256) void k_fcn_dw(const float* __restrict__ X, con
     for (int k = 0; k < 9; k++) wk[k] = Wt[c * 9 + k];
     const float sc = scale[c], sh = shift[c];
     __syncthreads();
-    const int ty = threadIdx.x >> 4, tx4 = (threadIdx.x & 15) * 4;
-    const int oy = oy0 + ty;
-    if (oy >= Ho || ox0 + tx4 >= Wo) return;
-    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    const int tx4 = (threadIdx.x & 15) * 4;
+    if (ox0 + tx4 >= Wo) return;
 #pragma unroll
-    for (int ky = 0; ky < 3; ky++) {
-        const float* row = tile + (ty * S + ky * dil) * IWp + tx4 * S;
+    for (int rr = 0; rr < kDwTH / 16; rr++) {
+        const int ty = (threadIdx.x >> 4) + 16 * rr;
+        const int oy = oy0 + ty;
+        if (oy >= Ho) break;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kx = 0; kx < 3; kx++)
+        for (int ky = 0; ky < 3; ky++) {
+            const float* row = tile + (ty * S + ky * dil) * IWp + tx4 * S;
 #pragma unroll
-            for (int p = 0; p < 4; p++) o[p] += wk[ky * 3 + kx] * row[p * S + kx * dil];
+            for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+                for (int p = 0; p < 4; p++) o[p] += wk[ky * 3 + kx] * row[p * S + kx * dil];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) o[p] = fminf(fmaxf(o[p] * sc + sh, 0.f), 6.f);
+        float* out = Y + (size_t)bc * Ho * Wo + (size_t)oy * Wo + ox0 + tx4;
+        if (ox0 + tx4 + 3 < Wo) *(float4*)out = make_float4(o[0], o[1], o[2], o[3]);
+        else for (int p = 0; p < 4 && ox0 + tx4 + p < Wo; p++) out[p] = o[p];
     }
-#pragma unroll
-    for (int p = 0; p < 4; p++) o[p] = fminf(fmaxf(o[p] * sc + sh, 0.f), 6.f);
-    float* out = Y + (size_t)bc * Ho * Wo + (size_t)oy * Wo + ox0 + tx4;
-    if (ox0 + tx4 + 3 < Wo) *(float4*)out = make_float4(o[0], o[1], o[2], o[3]);
-    else for (int p = 0; p < 4 && ox0 + tx4 + p < Wo; p++) out[p] = o[p];
 }
 
 // ---- 1x1 (TAPS=1) / dense 3x3 pad 1 (TAPS=9) convolution as an MFMA GEMM ----
@@ -386,9 +391,16 @@ int make_gemm(ivf_fcn* f, const float* w, int cout, int cin, int taps, const std
 {
     g.cin = cin; g.cout = cout; g.taps = taps; g.act = act;
     const int tiles = (cout + 31) / 32;
+    // wave tile = 32*NT output channels x 32*PT pixels.  Few input channels (short K loop, output-write bound):
+    // small accumulator tiles so several waves share a SIMD and hide the load/store latency; long K loops: bigger
+    // tiles for operand reuse.  IVF_FCN_NT_SMALL / IVF_FCN_NT_BIG / IVF_FCN_USE25 override for tuning runs.
+    static const int ntSmall = getenv("IVF_FCN_NT_SMALL") ? atoi(getenv("IVF_FCN_NT_SMALL")) : 1;
+    static const int ntBig = getenv("IVF_FCN_NT_BIG") ? atoi(getenv("IVF_FCN_NT_BIG")) : 1;
+    static const int use25 = getenv("IVF_FCN_USE25") ? atoi(getenv("IVF_FCN_USE25")) : 0;
     if (taps == 9) { g.NT = 3; g.PT = 1; }
-    else if (tiles == 5) { g.NT = 5; g.PT = 2; }
-    else { g.NT = tiles >= 3 ? 3 : tiles; g.PT = 4; }
+    else if (cin <= 32) { g.NT = std::min(tiles, ntSmall); g.PT = 4; }
+    else if (tiles == 5 && use25) { g.NT = 5; g.PT = 2; }
+    else { g.NT = std::min(tiles, ntBig); g.PT = 4; }
     g.nTiles = (tiles + g.NT - 1) / g.NT * g.NT;
     const int K2 = cin / 2;
     std::vector<float> wf((size_t)taps * K2 * g.nTiles * 64, 0.f);
@@ -430,13 +442,16 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
         const Dw& d = f->dw[id++];
         const int Ho = (H + 2 * d.dil - 2 * d.dil - 1) / d.stride + 1, Wo = (W + 2 * d.dil - 2 * d.dil - 1) / d.stride + 1;
         {
-            const dim3 grid((Wo + kDwTW - 1) / kDwTW, (Ho + kDwTH - 1) / kDwTH, n * hid);
-            const int IW = (kDwTW - 1) * d.stride + 2 * d.dil + 1, IH = (kDwTH - 1) * d.stride + 2 * d.dil + 1;
+            const int TH = (d.stride == 1 && Ho <= 64) ? 64 : 16;
+            const dim3 grid((Wo + kDwTW - 1) / kDwTW, (Ho + TH - 1) / TH, n * hid);
+            const int IW = (kDwTW - 1) * d.stride + 2 * d.dil + 1, IH = (TH - 1) * d.stride + 2 * d.dil + 1;
             const size_t lds = (size_t)IH * (IW | 1) * sizeof(float);
-            if (d.stride == 1)
-                hipLaunchKernelGGL((k_fcn_dw<1>), grid, dim3(256), lds, s, h, d.dW, d.dScale, d.dShift, f->bufH2, hid, H, W, Ho, Wo, d.dil);
+            if (d.stride == 1 && TH == 64)
+                hipLaunchKernelGGL((k_fcn_dw<1, 64>), grid, dim3(256), lds, s, h, d.dW, d.dScale, d.dShift, f->bufH2, hid, H, W, Ho, Wo, d.dil);
+            else if (d.stride == 1)
+                hipLaunchKernelGGL((k_fcn_dw<1, 16>), grid, dim3(256), lds, s, h, d.dW, d.dScale, d.dShift, f->bufH2, hid, H, W, Ho, Wo, d.dil);
             else
-                hipLaunchKernelGGL((k_fcn_dw<2>), grid, dim3(256), lds, s, h, d.dW, d.dScale, d.dShift, f->bufH2, hid, H, W, Ho, Wo, d.dil);
+                hipLaunchKernelGGL((k_fcn_dw<2, 16>), grid, dim3(256), lds, s, h, d.dW, d.dScale, d.dShift, f->bufH2, hid, H, W, Ho, Wo, d.dil);
         }
         snprintf(nm, sizeof nm, "block %d depthwise", i + 1); STAGE(nm);
         H = Ho; W = Wo;
