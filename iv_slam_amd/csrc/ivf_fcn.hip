@@ -185,36 +185,34 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
     const float* wp = Wf + (size_t)ct0 * 64 + lane;
 
     if (TAPS == 1) {
-        // software pipeline: operands of step k2+2 are requested before the MFMAs of step k2 issue, so the
-        // 12-20 MFMAs of two steps (64 cycles each) cover the L2/HBM latency of the loads
+        // software pipeline, 4 steps deep: right after a step's operands have been consumed by its MFMAs, the same
+        // registers receive the loads of step k2+4, so ~4 x NT*PT MFMAs (64 cycles each) cover the L2/HBM latency.
+        // Every channel count of the network is a multiple of 8, so K2 % 4 == 0.
         const float* xp = Xb + p0;
-        vec b0 = *(const vec*)xp, b1 = b0;
-        float a0[NT], a1[NT];
+        vec bs[4];
+        float as[4][NT];
 #pragma unroll
-        for (int n = 0; n < NT; n++) { a0[n] = wp[(size_t)n * 64]; a1[n] = a0[n]; }
-        if (K2 > 1) {
-            b1 = *(const vec*)(xp + (size_t)2 * HW);
+        for (int j = 0; j < 4; j++) {
+            bs[j] = *(const vec*)(xp + (size_t)2 * j * HW);
 #pragma unroll
-            for (int n = 0; n < NT; n++) a1[n] = wp[((size_t)nTiles + n) * 64];
+            for (int n = 0; n < NT; n++) as[j][n] = wp[((size_t)j * nTiles + n) * 64];
         }
-        for (int k2 = 0; k2 < K2; k2++) {
-            vec b2 = b1;
-            float a2[NT];
+        // branch-free body (the refill index is clamped, the last refills are redundant re-loads) so that the
+        // compiler can keep counted s_waitcnt vmcnt(N) instead of draining the queue at a control-flow join
+        for (int k2 = 0; k2 < K2; k2 += 4) {
 #pragma unroll
-            for (int n = 0; n < NT; n++) a2[n] = a1[n];
-            if (k2 + 2 < K2) {
-                b2 = *(const vec*)(xp + (size_t)2 * (k2 + 2) * HW);
+            for (int j = 0; j < 4; j++) {
 #pragma unroll
-                for (int n = 0; n < NT; n++) a2[n] = wp[((size_t)(k2 + 2) * nTiles + n) * 64];
+                for (int n = 0; n < NT; n++)
+#pragma unroll
+                    for (int p = 0; p < PT; p++)
+                        acc[n][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[j][n], vget<PT>(bs[j], p), acc[n][p], 0, 0, 0);
+                const int kn = min(k2 + 4 + j, K2 - 1);
+                bs[j] = *(const vec*)(xp + (size_t)2 * kn * HW);
+#pragma unroll
+                for (int n = 0; n < NT; n++) as[j][n] = wp[((size_t)kn * nTiles + n) * 64];
+                __builtin_amdgcn_sched_barrier(0);      // keep the refill here: the scheduler otherwise sinks it to its use
             }
-#pragma unroll
-            for (int n = 0; n < NT; n++)
-#pragma unroll
-                for (int p = 0; p < PT; p++)
-                    acc[n][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[n], vget<PT>(b0, p), acc[n][p], 0, 0, 0);
-            b0 = b1; b1 = b2;
-#pragma unroll
-            for (int n = 0; n < NT; n++) { a0[n] = a1[n]; a1[n] = a2[n]; }
         }
     } else {
         int py[PT], pxx[PT];
