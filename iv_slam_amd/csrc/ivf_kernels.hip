@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     __shared__ unsigned colInfo[kScW + 2], rowInfo[kScH + 2];
     __shared__ unsigned s_list[kFastTW * kFastTH / 4];           // at most one strict 3x3 maximum per 2x2 block
     __shared__ unsigned short s_tag[kFastTW * kFastTH / 4];
-    __shared__ int s_cnt[kLocalCells], s_ini[kLocalCells], s_base[kLocalCells], s_n;
+    __shared__ int s_cnt[kLocalCells], s_ini[kLocalCells], s_base[kLocalCells], s_n, s_nq;
+    __shared__ unsigned short s_queue[kScH * ((kScW + 3) / 4) * 2];   // pairs that pass the quick test (sy << 8 | sx)
     const int img = blockIdx.y;
     int level = 0;
     const int nl = cfg->nlevels;
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
             if (x < cx1) f = 1u | ((x - 1 >= cx0) ? 2u : 0u) | ((x + 1 < cx1) ? 4u : 0u) | ((unsigned)j << 8);
         }
         colInfo[tid] = f;
+        if (tid < 2) colInfo[kScW + tid] = 0;
     } else if (tid >= 192 && tid < 192 + kScH) {    // row classes: y = y0-1+(tid-192)
         const int y = y0 - 1 + (tid - 192);
         unsigned f = 0;
@@ -259,27 +261,55 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
         rowInfo[tid - 192] = f;
     }
     __syncthreads();
-    // 2. scores, two pixels (sx, sx+1) per step; sx even, raw column of the left pixel = sx+3
+    // 2. scores, four pixels (two packed pairs) per step sharing the three aligned dwords of each of the 7 rows:
+    //    score columns sx..sx+3 (sx % 4 == 0); the window of pair A (sx, sx+1) is bytes 0..7 of the 12-byte span
+    //    starting at raw byte sx, the window of pair B (sx+2, sx+3) is bytes 2..9
     const int minTh = cfg->minTh;
-    for (int i = tid; i < kScH * (kScW / 2); i += 256) {
-        const int sy = i / (kScW / 2), sx = (i % (kScW / 2)) * 2;
-        const unsigned c0 = colInfo[sx] & 1u, c1 = colInfo[sx + 1] & 1u, rv = rowInfo[sy] & 1u;
-        unsigned two = 0;
-        if ((rv & (c0 | c1)) && !(ablate & 1)) {
-            // window of row r starts at raw byte (sy + r) * kRawP + sx  (= left pixel's column - 3), sx even
-            unsigned lo[7], hi[7];
-            const int sh = sx & 2;
-            const unsigned* base = raw + (sy * kRawP + (sx & ~3)) / 4;
+    constexpr int kQuads = (kScW + 3) / 4;
+    // pass A (all pixels): ring differences + the opposite-pair quick test only (quickOnly returns 1|1<<16 for a pair
+    // that may hold a corner).  Only ~8 % of the pairs pass, but in ~60 % of the waves at least one lane does, so
+    // the expensive 9-arc min/max tree is NOT run here: passing pairs are queued in LDS and scored densely in pass B.
+    if (tid == 0) s_nq = 0;
+    __syncthreads();
+    for (int i = tid; i < kScH * kQuads; i += 256) {
+        const int sy = i / kQuads, sx = (i % kQuads) * 4;
+        const unsigned rv = rowInfo[sy] & 1u;
+        const unsigned c0 = colInfo[sx] & 1u, c1 = colInfo[sx + 1] & 1u, c2 = colInfo[sx + 2] & 1u, c3 = colInfo[sx + 3] & 1u;
+        unsigned pA = 0, pB = 0;
+        if ((rv & (c0 | c1 | c2 | c3)) && !(ablate & 1)) {
+            unsigned w0[7], w1[7], w2[7];
+            const unsigned* base = raw + (sy * kRawP + sx) / 4;
 #pragma unroll
-            for (int r = 0; r < 7; r++) {
-                const unsigned w0 = base[r * (kRawP / 4)], w1 = base[r * (kRawP / 4) + 1], w2 = base[r * (kRawP / 4) + 2];
-                lo[r] = __builtin_amdgcn_alignbyte(w1, w0, sh);
-                hi[r] = __builtin_amdgcn_alignbyte(w2, w1, sh);
+            for (int r = 0; r < 7; r++) { w0[r] = base[r * (kRawP / 4)]; w1[r] = base[r * (kRawP / 4) + 1]; w2[r] = base[r * (kRawP / 4) + 2]; }
+            if (c0 | c1) pA = fast_score_pair(w0, w1, minTh, true);
+            if (c2 | c3) {
+                unsigned lo[7], hi[7];
+#pragma unroll
+                for (int r = 0; r < 7; r++) { lo[r] = __builtin_amdgcn_alignbyte(w1[r], w0[r], 2); hi[r] = __builtin_amdgcn_alignbyte(w2[r], w1[r], 2); }
+                pB = fast_score_pair(lo, hi, minTh, true);
             }
-            two = fast_score_pair(lo, hi, minTh, (ablate & 4) != 0);
-            if (!c0) two &= 0xffff0000u;
-            if (!c1) two &= 0x0000ffffu;
         }
+        *(unsigned*)(sc + sy * kScP + sx) = 0u;
+        if (pA) s_queue[atomicAdd(&s_nq, 1)] = (unsigned short)((sy << 8) | sx);
+        if (pB) s_queue[atomicAdd(&s_nq, 1)] = (unsigned short)((sy << 8) | (sx + 2));
+    }
+    __syncthreads();
+    // pass B (queued pairs only): full score
+    const int nq = s_nq;
+    for (int i = tid; i < nq; i += 256) {
+        const int sy = s_queue[i] >> 8, sx = s_queue[i] & 0xff;
+        unsigned lo[7], hi[7];
+        const int sh = sx & 2;
+        const unsigned* base = raw + (sy * kRawP + (sx & ~3)) / 4;
+#pragma unroll
+        for (int r = 0; r < 7; r++) {
+            const unsigned w0 = base[r * (kRawP / 4)], w1 = base[r * (kRawP / 4) + 1], w2 = base[r * (kRawP / 4) + 2];
+            lo[r] = __builtin_amdgcn_alignbyte(w1, w0, sh);
+            hi[r] = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        }
+        unsigned two = fast_score_pair(lo, hi, minTh, (ablate & 4) != 0);
+        if (!(colInfo[sx] & 1u)) two &= 0xffff0000u;
+        if (!(colInfo[sx + 1] & 1u)) two &= 0x0000ffffu;
         *(unsigned short*)(sc + sy * kScP + sx) = (unsigned short)((two & 0xffu) | ((two >> 8) & 0xff00u));
     }
     __syncthreads();
@@ -676,10 +706,20 @@ __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, c
             const int x0 = kEdge + j * G.cellW, y0 = kEdge + i * G.cellH;
             const int wx0 = x0 - 3, wx1 = (j == cols - 1) ? G.maxBX + 3 : x0 + G.cellW + 3;
             const int wy0 = y0 - 3, wy1 = wy0 + ((i == rows - 1) ? G.winHLast : G.cellH + 6);
-            int acc = 0;
-            for (int y = wy0; y < wy1; y++)
-                for (int x = wx0 + lane; x < wx1; x += 64) acc += Q[(size_t)y * pitch + x];
-            qs = (unsigned)wave_sum_i32(acc);
+            // aligned dwords covering [wx0, wx1); bytes outside the window are masked; v_sad_u8 sums 4 bytes per op
+            const int a0 = wx0 & ~3, nq = (wx1 - a0 + 3) / 4;
+            unsigned acc = 0;
+            for (int y = wy0; y < wy1; y++) {
+                const unsigned* row = (const unsigned*)(Q + (size_t)y * pitch + a0);
+                for (int q = lane; q < nq; q += 64) {
+                    unsigned v = row[q];
+                    const int bx = a0 + 4 * q;
+                    if (bx < wx0) v &= 0xffffffffu << (8 * (wx0 - bx));
+                    if (bx + 4 > wx1) v &= 0xffffffffu >> (8 * (bx + 4 - wx1));
+                    acc = __builtin_amdgcn_sad_u8(v, 0u, acc);
+                }
+            }
+            qs = (unsigned)wave_sum_i32((int)acc);
         }
         if (lane == 0) { s_nMin[c] = cnt[2 * c]; s_nIni[c] = cnt[2 * c + 1]; s_qsum[c] = qs; }
     }
