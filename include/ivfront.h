@@ -160,10 +160,10 @@ typedef struct ivf_frontend_config {
 int  ivf_frontend_create(const ivf_frontend_config* cfg, ivf_frontend** out);
 void ivf_frontend_destroy(ivf_frontend* fe);
 /* Enqueue one batch; asynchronous.  The batch is ordered after everything already enqueued on `hip_stream`
- * (a hipStream_t, NULL = default stream; it produced the inputs) and runs on one of the front end's two internal
+ * (a hipStream_t, NULL = default stream; it produced the inputs) and runs on one of the front end's three internal
  * streams, so consecutive batches overlap; `hip_stream` itself only waits until the inputs have been ingested
- * (the caller may overwrite them in stream order right after this call).  Results of a run stay valid until the
- * second run after it.  Use ivf_frontend_sync / ivf_frontend_fetch / ivf_frontend_pack_gather_block to consume.
+ * (the caller may overwrite them in stream order right after this call).  Results of a run stay valid until two
+ * further runs have been enqueued.  Use ivf_frontend_sync / ivf_frontend_fetch / ivf_frontend_pack_gather_block to consume.
  * d_left/d_right: device pointers to n_pairs grey images, image i at base + i*image_stride, rows of row_stride bytes.
  * d_cost: device pointer to n_pairs u8 cost maps (same layout) or NULL. */
 int  ivf_frontend_run(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_right, const uint8_t* d_cost,

@@ -300,19 +300,20 @@ struct ivf_extractor {
     uint8_t* dOne = nullptr;            // device byte "1"
 };
 
-// Two batch contexts on two internal streams: run k uses context k%2, so the latency-bound tail of one batch
+// kPipe batch contexts on kPipe internal streams: run k uses context k % kPipe, so the latency-bound tail of one batch
 // (per-cell selection, descriptors, stereo) overlaps the throughput-bound head (ingest, pyramid, FAST, blur) of the
-// next.  Results of a run stay valid until the second run after it.
+// next ones.  Results of a run stay valid until kPipe - 1 further runs have been enqueued.
+constexpr int kPipe = 3;                // batch contexts in flight
 struct ivf_frontend {
     ivf_frontend_config cfg;
     Tables tl;
-    Context ctx[2];
-    hipStream_t stream[2] = {nullptr, nullptr};
-    hipEvent_t evIn[2] = {nullptr, nullptr}, evConsumed[2] = {nullptr, nullptr}, evDone[2] = {nullptr, nullptr};
+    Context ctx[kPipe];
+    hipStream_t stream[kPipe] = {};
+    hipEvent_t evIn[kPipe] = {}, evConsumed[kPipe] = {}, evDone[kPipe] = {};
     uint8_t* dFlags = nullptr;          // useCost flags when a cost batch is given: [L,R,L,R,...]
     int lastPairs = 0;
     long long runs = 0;
-    int last() const { return (int)((runs + 1) % 2); }      // context of the most recent run
+    int last() const { return (int)((runs + kPipe - 1) % kPipe); }      // context of the most recent run
 };
 
 // ---- Frame grid (ORB/src/Frame.cc:415-430, 615-680; 64 x 48, Frame.h:43-44) ----
@@ -730,7 +731,7 @@ int ivf_frontend_create(const ivf_frontend_config* cfg, ivf_frontend** out)
     ivf_frontend* fe = new ivf_frontend();
     fe->cfg = *cfg; fe->tl = t;
     auto cleanup = [&](int code) { ivf_frontend_destroy(fe); return code; };
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < kPipe; k++) {
         rc = fe->ctx[k].build(t, cfg->width, cfg->height, 2 * cfg->max_pairs, 2, cfg->device_id, true);
         if (rc) return cleanup(rc);
         if (hipStreamCreateWithFlags(&fe->stream[k], hipStreamNonBlocking) != hipSuccess ||
@@ -754,7 +755,7 @@ void ivf_frontend_destroy(ivf_frontend* fe)
     (void)hipSetDevice(fe->cfg.device_id);
     (void)hipDeviceSynchronize();
     if (fe->dFlags) (void)hipFree(fe->dFlags);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < kPipe; k++) {
         fe->ctx[k].release();
         if (fe->stream[k]) (void)hipStreamDestroy(fe->stream[k]);
         if (fe->evIn[k]) (void)hipEventDestroy(fe->evIn[k]);
@@ -772,7 +773,7 @@ int ivf_frontend_run(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_r
     if (row_stride < fe->cfg.width || image_stride < (size_t)row_stride * (fe->cfg.height - 1) + fe->cfg.width)
         return fail(IVF_E_INVALID, "strides too small for %dx%d", fe->cfg.width, fe->cfg.height);
     hipStream_t caller = (hipStream_t)hip_stream;
-    const int k = (int)(fe->runs % 2);
+    const int k = (int)(fe->runs % kPipe);
     Context& c = fe->ctx[k];
     hipStream_t st = fe->stream[k];
     HIPCHK(hipSetDevice(fe->cfg.device_id));
@@ -796,7 +797,7 @@ int ivf_frontend_sync(ivf_frontend* fe)
 {
     if (!fe) return fail(IVF_E_INVALID, "null handle");
     HIPCHK(hipSetDevice(fe->cfg.device_id));
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < kPipe; k++) {
         HIPCHK(hipStreamSynchronize(fe->stream[k]));
         const int rc = fe->ctx[k].check_status();
         if (rc) return rc;
@@ -858,13 +859,13 @@ int ivf_frontend_fast_ms_stats(ivf_frontend* fe, int last_n, double* sum_ms, int
     if (!fe || !sum_ms || !n_out) return fail(IVF_E_INVALID, "null argument");
     *sum_ms = 0; *n_out = 0;
     HIPCHK(hipSetDevice(fe->cfg.device_id));
-    // run r used context r%2 and that context's ring slot (r/2) % kEvRing
-    const long long keep = 2 * (long long)Context::kEvRing;
+    // run r used context r % kPipe and that context's ring slot (r / kPipe) % kEvRing
+    const long long keep = kPipe * (long long)Context::kEvRing;
     const long long avail = std::min<long long>(fe->runs, keep);
     const long long take = std::min<long long>(avail, last_n < 1 ? avail : last_n);
     for (long long r = fe->runs - take; r < fe->runs; r++) {
-        Context& c = fe->ctx[r % 2];
-        const int slot = (int)((r / 2) % Context::kEvRing);
+        Context& c = fe->ctx[r % kPipe];
+        const int slot = (int)((r / kPipe) % Context::kEvRing);
         HIPCHK(hipEventSynchronize(c.evFast1[slot]));
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, c.evFast0[slot], c.evFast1[slot]));

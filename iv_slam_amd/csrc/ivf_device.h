@@ -49,7 +49,7 @@ struct Config {
 typedef unsigned long long ResizeCoef;
 
 constexpr int kFastTW = 128, kFastTH = 32;    // FAST/NMS output tile (kFastTW + 2 <= 192, kFastTH + 2 <= 64: see k_fast_nms)
-constexpr int kBlurTW = 64, kBlurTH = 32;     // blur output tile
+constexpr int kBlurTW = 128, kBlurTH = 32;    // blur output tile
 
 struct Buffers {            // device pointers of one batch context
     uint8_t* pyr;           // [nImg][pyrBytes]  un-blurred pyramid (level 0 = ingested input)
