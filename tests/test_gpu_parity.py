@@ -303,3 +303,66 @@ def test_device_retain_best_matches_libstdcxx(iv):
         base = np.concatenate([np.arange(0, n, 2), np.arange(1, n, 2)[::-1]]).astype(np.float32)
         for k in (1, 2, n // 3, n // 2, n - 1):
             check(base, k)
+
+
+def test_jackal_shape_4000_features(iv):
+    """BASELINE configs[4] shape: 1920x1200, 4000 features/frame, FAST 12/7, with a cost map (one image: the oracle
+    needs ~1 s for it)."""
+    w, h, n = 1920, 1200, 4000
+    img = synth.make_left(w, h, seed=71, idx=0)
+    cost = synth.make_cost_map(w, h, seed=71, idx=0)
+    g = iv.ORBextractor(n, 1.2, 8, 12, 7, True)
+    o = O.Extractor(n, 1.2, 8, 12, 7, True)
+    gk, gd = g(img, cost)
+    ok, od = o(img, cost, cap=2 * n)
+    assert g.level_counts() == o.level_counts()
+    assert_kps_equal(gk, ok, "1920x1200 N=4000")
+    assert np.array_equal(gd, od)
+    assert len(gk) > 3000
+    # and the 960x600 / 2000-feature Jackal YAML shape without a cost map
+    img2 = synth.make_left(960, 600, seed=72, idx=0)
+    g2, o2, gk2, gd2, ok2, od2 = extract_both(iv, img2, n=2000, ini=12, mn=7)
+    assert_kps_equal(gk2, ok2, "960x600 N=2000")
+    assert np.array_equal(gd2, od2)
+
+
+def test_cross_frame_matching_through_gather_records(iv):
+    """SURVEY §8(e) flow on one GPU: batch of consecutive frames -> device-packed gather records (what RCCL all-gathers)
+    -> cross-frame SearchByProjection(cur, last) on the unpacked records, against the oracle end to end."""
+    import torch
+    from iv_slam_amd.frontend import unpack_gather_records
+    w, h, n, pairs = 640, 240, 500, 3
+    base_l, base_r = synth.make_pair(w, h, seed=81, idx=0)
+    # consecutive "frames": the scene shifts 3 px per frame (left AND right), so last-frame points reproject nearby
+    lefts = np.stack([np.roll(base_l, 3 * k, axis=1) for k in range(pairs)])
+    rights = np.stack([np.roll(base_r, 3 * k, axis=1) for k in range(pairs)])
+    dev = torch.device("cuda:0")
+    fe = iv.StereoFrontend(w, h, pairs, nfeatures=n, bf=BF, b=B)
+    fe.run(torch.from_numpy(lefts).to(dev), torch.from_numpy(rights).to(dev))
+    rec = fe.gather_record_bytes()
+    block = torch.zeros(pairs * rec, dtype=torch.uint8, device=dev)
+    assert fe.pack_gather_block(block) == rec
+    torch.cuda.synchronize()
+    frames = unpack_gather_records(block.cpu().numpy(), n)
+    sc = iv.ORBextractor(n, 1.2, 8, 20, 7).GetScaleFactors()
+    m = iv.ORBmatcher(0.9, True)
+    bounds = (0.0, 0.0, float(w), float(h))
+    for k in range(1, pairs):
+        last, cur = frames[k - 1], frames[k]
+        # oracle extraction of the same frames must equal the gathered records
+        oL = O.Extractor(n, 1.2, 8, 20, 7); oR = O.Extractor(n, 1.2, 8, 20, 7)
+        okL, odL = oL(lefts[k]); okR, odR = oR(rights[k])
+        our, _ = O.stereo_match(oL, oR, okL, odL, okR, odR, BF, B)
+        assert cur["kps"].tobytes() == okL.tobytes() and np.array_equal(cur["desc"], odL) and cur["uright"].tobytes() == our.tobytes()
+        sel = last["uright"] >= 0                                     # "map points" = last frame's stereo points
+        lk = last["kps"][sel]
+        disp = lk["x"] - last["uright"][sel]
+        q = dict(u=(lk["x"] + 3).astype(np.float32), v=lk["y"].astype(np.float32),
+                 ur=(lk["x"] + 3 - disp).astype(np.float32), radius=(7 * sc[lk["octave"]]).astype(np.float32),
+                 min_level=(lk["octave"] - 1).astype(np.int32), max_level=(lk["octave"] + 1).astype(np.int32),
+                 angle=lk["angle"].copy(), desc=last["desc"][sel].copy(), valid=np.ones(len(lk), np.uint8),
+                 blocks=np.ones(len(lk), np.uint8))
+        ga, gn = m.SearchByProjection(cur["kps"], cur["desc"], cur["uright"], bounds, q)
+        oa, on = O.search_by_projection(cur["kps"], cur["desc"], cur["uright"], bounds, q, True)
+        assert gn == on and np.array_equal(ga, oa)
+        assert gn > 0.5 * len(lk)                                     # the shifted scene really re-matches
