@@ -151,6 +151,17 @@ DEVINL s16x2 pair_at(unsigned lo, unsigned hi, int i)      // bytes W[i], W[i+1]
 {
     return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | ((unsigned)(i + 1) << 16) | (unsigned)i));
 }
+// Cheap necessary condition on the 4 compass ring pixels only (rows -3, 0, +3): every 9-arc holds one pixel of each
+// opposite pair, in particular of (0,8) = (0,+-3) and (4,12) = (+-3,0).  Passes ~10 % of the pairs (the full 8-pair
+// test ~8 %) at a third of the cost.  loT/hiT = row -3, loC/hiC = centre row, loB/hiB = row +3 windows.
+DEVINL bool fast_precheck_pair(unsigned loT, unsigned hiT, unsigned loC, unsigned hiC, unsigned loB, unsigned hiB, int t)
+{
+    const s16x2 v = pair_at(loC, hiC, 3);
+    const s16x2 d0 = v - pair_at(loB, hiB, 3), d8 = v - pair_at(loT, hiT, 3);
+    const s16x2 d4 = v - pair_at(loC, hiC, 6), d12 = v - pair_at(loC, hiC, 0);
+    const s16x2 dk = pkmin(pkmax(d0, d8), pkmax(d4, d12)), br = pkmax(pkmin(d0, d8), pkmin(d4, d12));
+    return (dk.x > t) | (dk.y > t) | (br.x < -t) | (br.y < -t);
+}
 // rows: 7 windows (dy = -3..3), each as (lo, hi) dwords.  Returns the two scores packed (left | right << 16).
 DEVINL unsigned fast_score_pair(const unsigned (&lo)[7], const unsigned (&hi)[7], int t, bool quickOnly = false)
 {
@@ -266,28 +277,24 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     //    starting at raw byte sx, the window of pair B (sx+2, sx+3) is bytes 2..9
     const int minTh = cfg->minTh;
     constexpr int kQuads = (kScW + 3) / 4;
-    // pass A (all pixels): ring differences + the opposite-pair quick test only (quickOnly returns 1|1<<16 for a pair
-    // that may hold a corner).  Only ~8 % of the pairs pass, but in ~60 % of the waves at least one lane does, so
-    // the expensive 9-arc min/max tree is NOT run here: passing pairs are queued in LDS and scored densely in pass B.
+    // pass A (all pixels): compass pre-check only (3 of the 7 rows).  ~10 % of the pairs pass, but in most waves at
+    // least one lane does, so nothing expensive runs here: passing pairs are queued in LDS and scored densely in pass B.
     if (tid == 0) s_nq = 0;
     __syncthreads();
     for (int i = tid; i < kScH * kQuads; i += 256) {
         const int sy = i / kQuads, sx = (i % kQuads) * 4;
         const unsigned rv = rowInfo[sy] & 1u;
         const unsigned c0 = colInfo[sx] & 1u, c1 = colInfo[sx + 1] & 1u, c2 = colInfo[sx + 2] & 1u, c3 = colInfo[sx + 3] & 1u;
-        unsigned pA = 0, pB = 0;
+        bool pA = false, pB = false;
         if ((rv & (c0 | c1 | c2 | c3)) && !(ablate & 1)) {
-            unsigned w0[7], w1[7], w2[7];
             const unsigned* base = raw + (sy * kRawP + sx) / 4;
-#pragma unroll
-            for (int r = 0; r < 7; r++) { w0[r] = base[r * (kRawP / 4)]; w1[r] = base[r * (kRawP / 4) + 1]; w2[r] = base[r * (kRawP / 4) + 2]; }
-            if (c0 | c1) pA = fast_score_pair(w0, w1, minTh, true);
-            if (c2 | c3) {
-                unsigned lo[7], hi[7];
-#pragma unroll
-                for (int r = 0; r < 7; r++) { lo[r] = __builtin_amdgcn_alignbyte(w1[r], w0[r], 2); hi[r] = __builtin_amdgcn_alignbyte(w2[r], w1[r], 2); }
-                pB = fast_score_pair(lo, hi, minTh, true);
-            }
+            unsigned t0 = base[0], t1 = base[1], t2 = base[2];
+            unsigned m0 = base[3 * (kRawP / 4)], m1 = base[3 * (kRawP / 4) + 1], m2 = base[3 * (kRawP / 4) + 2];
+            unsigned b0 = base[6 * (kRawP / 4)], b1 = base[6 * (kRawP / 4) + 1], b2 = base[6 * (kRawP / 4) + 2];
+            if (c0 | c1) pA = fast_precheck_pair(t0, t1, m0, m1, b0, b1, minTh);
+            if (c2 | c3) pB = fast_precheck_pair(__builtin_amdgcn_alignbyte(t1, t0, 2), __builtin_amdgcn_alignbyte(t2, t1, 2),
+                                                 __builtin_amdgcn_alignbyte(m1, m0, 2), __builtin_amdgcn_alignbyte(m2, m1, 2),
+                                                 __builtin_amdgcn_alignbyte(b1, b0, 2), __builtin_amdgcn_alignbyte(b2, b1, 2), minTh);
         }
         *(unsigned*)(sc + sy * kScP + sx) = 0u;
         if (pA) s_queue[atomicAdd(&s_nq, 1)] = (unsigned short)((sy << 8) | sx);
