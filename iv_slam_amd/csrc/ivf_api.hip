@@ -191,7 +191,8 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
     HIPCHK(hipMalloc(&b.blur, blob));
     HIPCHK(hipMemset(b.pyr, 0, blob));
     if (introspection) { HIPCHK(hipMalloc(&b.qpyr, blob)); HIPCHK(hipMemset(b.qpyr, 0, blob)); }
-    HIPCHK(hipMalloc(&b.rawCand, nI * c.candTotal * sizeof(unsigned)));
+    HIPCHK(hipMalloc(&b.tileList, nI * std::max(c.nTiles, 1) * (size_t)kTileCap * sizeof(unsigned)));
+    HIPCHK(hipMalloc(&b.tileCnt, nI * std::max(c.nTiles, 1) * sizeof(int)));
     HIPCHK(hipMalloc(&b.cellCnt, nI * c.nCellsTotal * 2 * sizeof(int)));
     HIPCHK(hipMalloc(&b.cellInfo, nI * c.nCellsTotal * sizeof(int4)));
     HIPCHK(hipMalloc(&b.lvlTotal, nI * kMaxLevels * sizeof(int)));
@@ -222,7 +223,7 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
 void Context::release()
 {
     (void)hipSetDevice(device);
-    void* ptrs[] = {dc, dTab, b.pyr, b.qpyr, b.blur, b.rawCand, b.cellCnt, b.cellInfo, b.lvlTotal, b.lvl, b.slotPos, b.slotResp, b.lvlCount,
+    void* ptrs[] = {dc, dTab, b.pyr, b.qpyr, b.blur, b.tileList, b.tileCnt, b.cellCnt, b.cellInfo, b.lvlTotal, b.lvl, b.slotPos, b.slotResp, b.lvlCount,
                     b.useCost, b.kps, b.desc, b.count, b.quality, b.uright, b.depth, b.sad, b.status, dStage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < kEvRing; i++) {

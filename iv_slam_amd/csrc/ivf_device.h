@@ -50,12 +50,14 @@ typedef unsigned long long ResizeCoef;
 
 constexpr int kFastTW = 128, kFastTH = 32;    // FAST/NMS output tile (kFastTW + 2 <= 192, kFastTH + 2 <= 64: see k_fast_nms)
 constexpr int kBlurTW = 128, kBlurTH = 32;    // blur output tile
+constexpr int kTileCap = kFastTW * kFastTH / 4;   // at most one strict 3x3 maximum per 2x2 block
 
 struct Buffers {            // device pointers of one batch context
     uint8_t* pyr;           // [nImg][pyrBytes]  un-blurred pyramid (level 0 = ingested input)
     uint8_t* qpyr;          // [nImg][pyrBytes]  cost-map pyramid (introspection) or nullptr
     uint8_t* blur;          // [nImg][pyrBytes]  7x7 sigma-2 blurred pyramid
-    unsigned* rawCand;      // [nImg][candTotal] unordered NMS survivors per cell: y<<20 | x<<8 | score
+    unsigned* tileList;     // [nImg][nTiles][kTileCap] unordered NMS survivors of each FAST tile: y<<20 | x<<8 | score
+    int* tileCnt;           // [nImg][nTiles] survivors per tile
     int* cellCnt;           // [nImg][nCellsTotal][2] survivors per cell: {score >= minTh, score >= iniTh}
     unsigned long long* lvl;    // [nImg][candTotal] per level: kept keys (respbits<<32 | y<<16 | x) of all cells, (i,j) order
     int4* cellInfo;         // [nImg][nCellsTotal] {nTotal, nRetain, prefix, useMin} from k_quota

@@ -208,9 +208,10 @@ DEVINL unsigned fast_score_pair(const unsigned (&lo)[7], const unsigned (&hi)[7]
 //      (which cell, inside a FAST detection domain or not, neighbours in the same cell or not)
 //   2. FAST score for the 66x34 region (tile + 1-px NMS halo), two pixels per thread-step
 //   3. 3x3 strict NMS against neighbours of the SAME cell (cv::FAST runs per cell sub-image, so
-//      neighbours in another cell count as 0); every survivor (score >= minTh) is APPENDED to its
-//      cell's slab as (y<<20 | x<<8 | score) and counted (total and >= iniTh).  No score map goes to
-//      HBM; k_cell_select restores cv::FAST's row-major order from the packed positions.
+//      neighbours in another cell count as 0); every survivor (score >= minTh) goes to the tile's list as
+//      (y<<20 | x<<8 | score) and is counted per cell (total and >= iniTh).  No score map goes to HBM;
+//      k_cell_select collects a cell's survivors from the tiles it overlaps and restores cv::FAST's
+//      row-major order from the packed positions.
 // Since score >= t <=> corner at t, one pass serves both thresholds.
 // ------------------------------------------------------------------------------------------------
 constexpr int kRawP = kFastTW + 8;          // 72 bytes per raw row (18 dwords)
@@ -219,15 +220,14 @@ constexpr int kScW = kFastTW + 2, kScH = kFastTH + 2, kScP = kFastTW + 4;   // s
 // per column / row of the score region: bit0 valid, bit1 previous neighbour in the same cell, bit2 next neighbour
 // in the same cell, bits 8.. = cell column / row index
 __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg, const uint8_t* __restrict__ pyr,
-                                                 const uint8_t* __restrict__ useCost, unsigned* __restrict__ rawCand,
-                                                 int* __restrict__ cellCnt, int ablate)
+                                                 const uint8_t* __restrict__ useCost, unsigned* __restrict__ tileList,
+                                                 int* __restrict__ tileCnt, int* __restrict__ cellCnt, int ablate)
 {
     __shared__ __attribute__((aligned(16))) unsigned raw[(kFastTH + 8) * (kRawP / 4) + 4];   // +4: the funnel read touches one dword past a window
     __shared__ __attribute__((aligned(4))) uint8_t sc[kScH * kScP];
     __shared__ unsigned colInfo[kScW + 2], rowInfo[kScH + 2];
     __shared__ unsigned s_list[kFastTW * kFastTH / 4];           // at most one strict 3x3 maximum per 2x2 block
-    __shared__ unsigned short s_tag[kFastTW * kFastTH / 4];
-    __shared__ int s_cnt[kLocalCells], s_ini[kLocalCells], s_base[kLocalCells], s_n, s_nq;
+    __shared__ int s_cnt[kLocalCells], s_ini[kLocalCells], s_n, s_nq;
     __shared__ unsigned short s_queue[kScH * ((kScW + 3) / 4) * 2];   // pairs that pass the quick test (sy << 8 | sx)
     const int img = blockIdx.y;
     int level = 0;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     for (int l = 1; l < nl; l++) if ((int)blockIdx.x >= cfg->lv[l].tileBase) level = l;
     const LevelGeom& G = cfg->lv[level];
     const int t = blockIdx.x - G.tileBase;
-    if (!G.valid || t >= G.tilesX * G.tilesY) return;
+    if (!G.valid || t >= G.tilesX * G.tilesY) { if (threadIdx.x == 0) tileCnt[(size_t)img * cfg->nTiles + blockIdx.x] = 0; return; }
     const int mode = (cfg->introspection && useCost[img]) ? 1 : 0;
     const int tx = t % G.tilesX, ty = t / G.tilesX;
     const int x0 = 16 + tx * kFastTW, y0 = kEdge + ty * kFastTH;
@@ -320,9 +320,10 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
         *(unsigned short*)(sc + sy * kScP + sx) = (unsigned short)((two & 0xffu) | ((two >> 8) & 0xff00u));
     }
     __syncthreads();
-    if (ablate & 2) return;
-    // 3. NMS, then append.  Survivors are first gathered in LDS (LDS atomics), so that a tile costs one global
-    // atomic per cell it touches instead of one returning atomic (~1-2 us stall) per survivor.
+    if (ablate & 2) { if (tid == 0) tileCnt[(size_t)img * cfg->nTiles + blockIdx.x] = 0; return; }
+    // 3. NMS, then publish.  Survivors are gathered in an LDS list and leave as ONE coalesced copy into the tile's own
+    // slot of `tileList` (arbitrary order, count in `tileCnt`): no slot reservation, no returning atomics.  Only the
+    // per-cell counters (needed by k_quota) use global atomics, non-returning, one per cell the tile touches.
     const int iniTh = cfg->iniTh;
     if (tid < kLocalCells) { s_cnt[tid] = 0; s_ini[tid] = 0; }
     if (tid == 0) s_n = 0;
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     int fr = 0;
     for (int q = 1; q <= kFastTH; q++) if (rowInfo[q] & 1u) { fr = (int)(rowInfo[q] >> 8); break; }
     const int firstRow = fr;
+    int* cnt = cellCnt + (size_t)img * cfg->nCellsTotal * 2;
     __syncthreads();
     // four pixels per step: most score bytes are 0, so one 32-bit LDS read dismisses 4 pixels at once
     // (sc rows start at score column 0 = x0-1; tile pixel ox sits at byte ox+1, so the aligned dword at byte 4q
@@ -360,39 +362,27 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
             if (!ok) continue;
             const int crow = (int)(ri >> 8), ccol = (int)(ci >> 8);
             const int lr = crow - firstRow, lc = ccol - firstCol;
-            const unsigned packed = ((unsigned)(y0 + oy) << 20) | ((unsigned)(x0 + ox) << 8) | (unsigned)s;
+            s_list[atomicAdd(&s_n, 1)] = ((unsigned)(y0 + oy) << 20) | ((unsigned)(x0 + ox) << 8) | (unsigned)s;
             if (lr >= 0 && lr < kLocalCells / 4 && lc >= 0 && lc < 4) {
-                const int lid = lr * 4 + lc;
-                const int idx = atomicAdd(&s_n, 1);
-                const int rk = atomicAdd(&s_cnt[lid], 1);
-                if (s >= iniTh) atomicAdd(&s_ini[lid], 1);
-                s_list[idx] = packed;
-                s_tag[idx] = (unsigned short)((lid << 10) | rk);       // rk < 1024 survivors per tile
-            } else {                                                    // tile spans too many cells: direct path
-                const int cell = crow * G.cols + ccol, gc = G.cellBase + cell;
-                int* cnt = cellCnt + (size_t)img * cfg->nCellsTotal * 2;
-                const int slot = atomicAdd(&cnt[2 * gc], 1);
+                atomicAdd(&s_cnt[lr * 4 + lc], 1);
+                if (s >= iniTh) atomicAdd(&s_ini[lr * 4 + lc], 1);
+            } else {                                                    // tile spans too many cells: count directly
+                const int gc = G.cellBase + crow * G.cols + ccol;
+                atomicAdd(&cnt[2 * gc], 1);
                 if (s >= iniTh) atomicAdd(&cnt[2 * gc + 1], 1);
-                if (slot < G.candCap) rawCand[(size_t)img * cfg->candTotal + G.candBase + (size_t)cell * G.candCap + slot] = packed;
             }
         }
     }
     __syncthreads();
     if (tid < kLocalCells && s_cnt[tid] > 0) {
-        const int cell = (firstRow + tid / 4) * G.cols + firstCol + (tid & 3), gc = G.cellBase + cell;
-        int* cnt = cellCnt + (size_t)img * cfg->nCellsTotal * 2;
-        s_base[tid] = atomicAdd(&cnt[2 * gc], s_cnt[tid]);
+        const int gc = G.cellBase + (firstRow + tid / 4) * G.cols + firstCol + (tid & 3);
+        atomicAdd(&cnt[2 * gc], s_cnt[tid]);
         if (s_ini[tid]) atomicAdd(&cnt[2 * gc + 1], s_ini[tid]);
     }
-    __syncthreads();
-    unsigned* slab = rawCand + (size_t)img * cfg->candTotal + G.candBase;
     const int n = s_n;
-    for (int i = tid; i < n; i += 256) {
-        const int lid = s_tag[i] >> 10, rk = s_tag[i] & 1023;
-        const int cell = (firstRow + lid / 4) * G.cols + firstCol + (lid & 3);
-        const int slot = s_base[lid] + rk;
-        if (slot < G.candCap) slab[(size_t)cell * G.candCap + slot] = s_list[i];
-    }
+    unsigned* out = tileList + ((size_t)img * cfg->nTiles + blockIdx.x) * kTileCap;
+    for (int i = tid; i < n; i += 256) out[i] = s_list[i];
+    if (tid == 0) tileCnt[(size_t)img * cfg->nTiles + blockIdx.x] = n;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -785,8 +775,8 @@ __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, c
 // pass 0 handles cells with <= kCellCapSmall candidates (12 KB LDS, many waves per CU); pass 1 the rest
 constexpr int kCellCapSmall = 1024, kCellCapBig = 4096;
 template <int CAP>
-__global__ __launch_bounds__(64) void k_cell_select(const Config* __restrict__ cfg, const unsigned* __restrict__ rawCand,
-                                                   const int* __restrict__ cellCnt, const CellInfo* __restrict__ cellInfo,
+__global__ __launch_bounds__(64) void k_cell_select(const Config* __restrict__ cfg, const unsigned* __restrict__ tileList,
+                                                   const int* __restrict__ tileCnt, const CellInfo* __restrict__ cellInfo,
                                                    const uint8_t* __restrict__ qpyr, const uint8_t* __restrict__ useCost,
                                                    u64* __restrict__ lvlList, int* __restrict__ status, int pass)
 {
@@ -807,26 +797,37 @@ __global__ __launch_bounds__(64) void k_cell_select(const Config* __restrict__ c
     if (pass == 0 ? nT > kCellCapSmall : nT <= kCellCapSmall) return;
     const int mode = (cfg->introspection && useCost[img]) ? 1 : 0;
     const uint8_t* Q = mode ? qpyr + (size_t)img * cfg->pyrBytes + G.off : nullptr;
-    const int nAllRaw = cellCnt[((size_t)img * cfg->nCellsTotal + gc) * 2];
-    if (lane == 0 && nAllRaw > G.candCap) atomicOr(status, 2);
-    const int nAll = min(nAllRaw, G.candCap);
     const unsigned th = info.useMin ? 1u : (unsigned)cfg->iniTh;
-    const unsigned* in = rawCand + (size_t)img * cfg->candTotal + G.candBase + (size_t)c * G.candCap;
     const int kept = (nR >= 0 && nT > nR) ? nR : nT;
     u64* dst = lvlList + (size_t)img * cfg->candTotal + G.candBase + info.prefix;
     if (nT > CAP) { if (lane == 0) atomicOr(status, 4); return; }    // > kCellCapBig survivors in one cell: unsupported
-    // a) filter by the cell's threshold (order irrelevant)
+    // a) collect the cell's survivors from the FAST tiles it overlaps, filtered by its rectangle and threshold
+    //    (order irrelevant here)
+    const int ci = c / G.cols, cj = c % G.cols;
+    const int cx0 = kEdge + cj * G.cellW, cx1 = (cj == G.cols - 1) ? G.maxBX : cx0 + G.cellW;
+    const int cy0 = kEdge + ci * G.cellH, cy1 = cy0 + ((ci == G.rows - 1) ? G.domHLast : G.domH[mode]);
     int m = 0;
-    for (int b0 = 0; b0 < nAll; b0 += 64) {
-        const int k = b0 + lane;
-        const unsigned e = k < nAll ? in[k] : 0u;
-        const bool keep = k < nAll && (e & 0xffu) >= th;
-        const unsigned long long mask = __ballot(keep);
-        if (keep) {
-            const int idx = m + __popcll(mask & ((1ull << lane) - 1ull));
-            keys[idx] = e;
-        }
-        m += __popcll(mask);
+    if (cy1 > cy0 && cx1 > cx0) {
+        const int tx0 = (cx0 - 16) / kFastTW, tx1 = (cx1 - 1 - 16) / kFastTW;
+        const int ty0 = (cy0 - kEdge) / kFastTH, ty1 = (cy1 - 1 - kEdge) / kFastTH;
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) {
+                const size_t tile = (size_t)img * cfg->nTiles + G.tileBase + ty * G.tilesX + tx;
+                const int nAll = min(tileCnt[tile], kTileCap);
+                const unsigned* in = tileList + tile * kTileCap;
+                for (int b0 = 0; b0 < nAll; b0 += 64) {
+                    const int k = b0 + lane;
+                    const unsigned e = k < nAll ? in[k] : 0u;
+                    const int ex = (e >> 8) & 0xfff, ey = e >> 20;
+                    const bool keep = k < nAll && (e & 0xffu) >= th && ex >= cx0 && ex < cx1 && ey >= cy0 && ey < cy1;
+                    const unsigned long long mask = __ballot(keep);
+                    if (keep) {
+                        const int idx = m + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (idx < CAP) keys[idx] = e;
+                    }
+                    m += __popcll(mask);
+                }
+            }
     }
     if (lane == 0 && m != nT) atomicOr(status, 1);                   // internal consistency
     if (m != nT) return;
@@ -1279,7 +1280,7 @@ void launch_fast(const Config& hc, const Config* dc, const Buffers& b, int nImg,
 {
     if (hc.nTiles <= 0) return;
     static const int ablate = getenv("IVF_FAST_ABLATE") ? atoi(getenv("IVF_FAST_ABLATE")) : 0;   // timing experiments only
-    hipLaunchKernelGGL(k_fast_nms, dim3(hc.nTiles, nImg), dim3(256), 0, s, dc, b.pyr, b.useCost, b.rawCand, b.cellCnt, ablate);
+    hipLaunchKernelGGL(k_fast_nms, dim3(hc.nTiles, nImg), dim3(256), 0, s, dc, b.pyr, b.useCost, b.tileList, b.tileCnt, b.cellCnt, ablate);
 }
 void launch_blur(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s)
 {
@@ -1291,9 +1292,9 @@ void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nIm
 {
     hipLaunchKernelGGL(k_quota, dim3(hc.nlevels, nImg), dim3(256), 0, s, dc, b.cellCnt, b.qpyr, b.useCost,
                        (CellInfo*)b.cellInfo, b.lvlTotal);
-    hipLaunchKernelGGL((k_cell_select<kCellCapSmall>), dim3(hc.nCellsTotal, nImg), dim3(64), 0, s, dc, b.rawCand, b.cellCnt,
+    hipLaunchKernelGGL((k_cell_select<kCellCapSmall>), dim3(hc.nCellsTotal, nImg), dim3(64), 0, s, dc, b.tileList, b.tileCnt,
                        (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, 0);
-    hipLaunchKernelGGL((k_cell_select<kCellCapBig>), dim3(hc.nCellsTotal, nImg), dim3(64), 0, s, dc, b.rawCand, b.cellCnt,
+    hipLaunchKernelGGL((k_cell_select<kCellCapBig>), dim3(hc.nCellsTotal, nImg), dim3(64), 0, s, dc, b.tileList, b.tileCnt,
                        (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, 1);
     hipLaunchKernelGGL(k_level_select, dim3(hc.nlevels, nImg), dim3(256), 0, s, dc, b.lvlTotal, b.lvl, b.slotPos, b.slotResp,
                        b.lvlCount);
