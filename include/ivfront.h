@@ -139,6 +139,12 @@ int  ivf_search_map_points(const ivf_keypoint* cur_kps, const uint8_t* cur_desc,
                            const uint8_t* q_valid, const uint8_t* q_blocks, float nn_ratio,
                            int32_t* cur_assign, int* nmatches, int device_id);
 
+/* ORBmatcher::UpdateQualityScores(Frame &F) (ORB/src/ORBmatcher.cc:1108-1121; active only with
+ * --ivslam_propagate_keyptqual, ORB/src/ORBmatcher.cc:130,1513,1647).  assign[i] = map-point index of keypoint i or -1
+ * (F.mvpMapPoints); kp_quality = F.mvKeyQualScore (in/out); mp_quality = MapPoint quality scores (in/out).  Host-side
+ * bookkeeping: sequential by definition (later keypoints see earlier updates). */
+int  ivf_update_quality_scores(const int32_t* assign, int n, float* kp_quality, float* mp_quality, int n_map_points);
+
 /* ---- testing hook ----
  * Runs the device's cv::KeyPointsFilter::retainBest core (the wave-cooperative replay of libstdc++ std::nth_element
  * used by the keypoint selection kernels) on caller-supplied non-negative responses: order_out[i] = index of the

@@ -59,6 +59,7 @@ _SIGS = {
                                            vp, vp, C.c_int, vp, C.POINTER(C.c_int), C.c_int]),
     "ivf_search_map_points": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                         C.c_float, vp, C.POINTER(C.c_int), C.c_int]),
+    "ivf_update_quality_scores": (C.c_int, [vp, C.c_int, vp, vp, C.c_int]),
     "ivf_test_retain_best": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int]),
     "ivf_frontend_create": (C.c_int, [C.POINTER(FrontendConfig), C.POINTER(vp)]),
     "ivf_frontend_destroy": (None, [vp]),

@@ -694,6 +694,23 @@ int ivf_search_map_points(const ivf_keypoint* cur_kps, const uint8_t* cur_desc, 
     return IVF_OK;
 }
 
+// ORBmatcher::UpdateQualityScores(Frame &F) (ORB/src/ORBmatcher.cc:1108-1121): host bookkeeping, sequential by definition
+int ivf_update_quality_scores(const int32_t* assign, int n, float* kp_quality, float* mp_quality, int n_map_points)
+{
+    if (!assign || !kp_quality || !mp_quality || n < 0 || n_map_points < 0) return fail(IVF_E_INVALID, "bad argument");
+    const float kDeltaThresh = 0.01f;
+    for (int i = 0; i < n; i++) {
+        const int m = assign[i];
+        if (m < 0) continue;
+        if (m >= n_map_points) return fail(IVF_E_INVALID, "assign[%d] = %d outside the %d map points", i, m, n_map_points);
+        const float mpt = mp_quality[m];
+        const float upd = std::min(mpt, kp_quality[i]);
+        if (fabsf(upd - mpt) > kDeltaThresh) mp_quality[m] = upd;
+        kp_quality[i] = upd;
+    }
+    return IVF_OK;
+}
+
 // testing hook (see include/ivfront.h)
 int ivf_test_retain_best(const float* responses, int n, int n_points, int32_t* order_out, int device_id)
 {

@@ -192,3 +192,10 @@ class ORBmatcher:
                                               ptr(qq["desc"]), ptr(qq["valid"]), ptr(qq["blocks"]), self.mfNNratio,
                                               ptr(assign), C.byref(nm), self.device_id))
         return assign, nm.value
+
+    def UpdateQualityScores(self, mvpMapPoints, mvKeyQualScore, mapPointQuality):
+        """UpdateQualityScores(Frame &F) (ORBmatcher.cc:1108-1121): returns (mvKeyQualScore, mapPointQuality) updated."""
+        a = np.ascontiguousarray(mvpMapPoints, np.int32)
+        kq = np.ascontiguousarray(mvKeyQualScore, np.float32).copy(); mq = np.ascontiguousarray(mapPointQuality, np.float32).copy()
+        check(self._lib.ivf_update_quality_scores(ptr(a), len(a), ptr(kq), ptr(mq), len(mq)))
+        return kq, mq

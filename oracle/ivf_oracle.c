@@ -1101,3 +1101,18 @@ int orc_search_map_points(const orc_keypoint* cur_kps, const uint8_t* cur_desc, 
     *nmatches_out = nmatches;
     return 0;
 }
+
+/* a18  ORBmatcher::UpdateQualityScores(Frame &F) (ORB/src/ORBmatcher.cc:1108-1121): for every keypoint i with a map point
+ * (assign[i] >= 0 = index into mp_quality): q = min(mapPointQ, kpQ); the map point is updated only when it changes by
+ * more than 0.01; the keypoint score always becomes q.  Sequential: later keypoints see earlier updates. */
+void orc_update_quality_scores(const int32_t* assign, int n, float* kp_quality, float* mp_quality)
+{
+    const float kDeltaThresh = 0.01f;
+    for (int i = 0; i < n; i++) {
+        if (assign[i] < 0) continue;
+        const float mpt = mp_quality[assign[i]];
+        const float upd = mpt < kp_quality[i] ? mpt : kp_quality[i];
+        if (fabsf(upd - mpt) > kDeltaThresh) mp_quality[assign[i]] = upd;
+        kp_quality[i] = upd;
+    }
+}

@@ -110,6 +110,8 @@ int   orc_search_map_points(const orc_keypoint* cur_kps, const uint8_t* cur_desc
 /* Frame::GetFeaturesInArea on a freshly built grid: returns count, indices in reference order */
 int   orc_features_in_area(const orc_keypoint* kps, int n, const orc_bounds* bounds,
                            float x, float y, float r, int min_level, int max_level, int32_t* out, int cap);
+/* ORBmatcher::UpdateQualityScores(Frame&) (ORB/src/ORBmatcher.cc:1108-1121) */
+void  orc_update_quality_scores(const int32_t* assign, int n, float* kp_quality, float* mp_quality);
 /* ORBmatcher::ComputeThreeMaxima (ORB/src/ORBmatcher.cc:1654-1695) on bin sizes */
 void  orc_three_maxima(const int* histo_sizes, int L, int* ind1, int* ind2, int* ind3);
 

@@ -77,6 +77,7 @@ lib.orc_three_maxima.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_
 lib.orc_search_map_points.restype = C.c_int
 lib.orc_search_map_points.argtypes = [vp, vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                       C.c_float, vp, C.POINTER(C.c_int)]
+lib.orc_update_quality_scores.argtypes = [vp, C.c_int, vp, vp]
 pin.stl_retain_best.restype = C.c_int; pin.stl_retain_best.argtypes = [vp, C.c_int, C.c_int]
 pin.stl_nth_element.argtypes = [vp, C.c_int, C.c_int]
 

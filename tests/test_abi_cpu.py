@@ -58,3 +58,27 @@ def test_argument_validation_without_gpu():
     # host helper: DescriptorDistance
     a = np.arange(32, dtype=np.uint8); b = a[::-1].copy()
     assert lib.ivf_hamming(_lib.ptr(a), _lib.ptr(b)) == int(np.unpackbits(a ^ b).sum())
+
+
+def test_update_quality_scores_host_helper():
+    """a18 UpdateQualityScores is host bookkeeping (no GPU needed): product vs oracle, incl. the >0.01 write-back rule and
+    the sequential effect of two keypoints sharing a map point."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    import iv_slam_amd as iv
+    from iv_slam_amd import _lib
+    rng = np.random.default_rng(5)
+    n, nm = 400, 150
+    assign = rng.integers(-1, nm, n).astype(np.int32)
+    kq = rng.uniform(0, 1, n).astype(np.float32); mq = rng.uniform(0, 1, nm).astype(np.float32)
+    kq[:50] = mq[np.clip(assign[:50], 0, nm - 1)] - np.float32(0.005)          # changes below the 0.01 threshold
+    m = iv.ORBmatcher.__new__(iv.ORBmatcher); m._lib = _lib.load()
+    gk, gm = m.UpdateQualityScores(assign, kq, mq)
+    ok, om = kq.copy(), mq.copy()
+    O.lib.orc_update_quality_scores(O.ptr(assign), n, O.ptr(ok), O.ptr(om))
+    assert gk.tobytes() == ok.tobytes() and gm.tobytes() == om.tobytes()
+    assert (gm != mq).any() and (gm <= mq).all()
+    bad = assign.copy(); bad[3] = nm + 7
+    with pytest.raises(iv.IvfError):
+        m.UpdateQualityScores(bad, kq, mq)
