@@ -297,8 +297,18 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
                                                  __builtin_amdgcn_alignbyte(b1, b0, 2), __builtin_amdgcn_alignbyte(b2, b1, 2), minTh);
         }
         *(unsigned*)(sc + sy * kScP + sx) = 0u;
-        if (pA) s_queue[atomicAdd(&s_nq, 1)] = (unsigned short)((sy << 8) | sx);
-        if (pB) s_queue[atomicAdd(&s_nq, 1)] = (unsigned short)((sy << 8) | (sx + 2));
+        // wave-aggregated push: one LDS atomic per wave step instead of one per passing pair
+        const unsigned long long mA = __ballot(pA), mB = __ballot(pB);
+        if (mA | mB) {
+            const int lane = tid & 63;
+            const int nA = __popcll(mA), nB = __popcll(mB);
+            int qb = 0;
+            if (lane == __ffsll((long long)(mA | mB)) - 1) qb = atomicAdd(&s_nq, nA + nB);
+            qb = __shfl(qb, __ffsll((long long)(mA | mB)) - 1, 64);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            if (pA) s_queue[qb + __popcll(mA & lt)] = (unsigned short)((sy << 8) | sx);
+            if (pB) s_queue[qb + nA + __popcll(mB & lt)] = (unsigned short)((sy << 8) | (sx + 2));
+        }
     }
     __syncthreads();
     // pass B (queued pairs only): full score
