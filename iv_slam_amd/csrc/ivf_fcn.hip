@@ -271,6 +271,149 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
         }
 }
 
+// ---- fused depthwise 3x3 (stride 1, dilation DIL) + BN + ReLU6  ->  1x1 projection (MFMA) + BN (+ residual) ----
+// For the 64x64 stages of the encoder the depthwise output never goes to HBM: a workgroup owns 128 pixels (two image
+// rows) and TILES*32 output channels; per 16-channel chunk of the hidden tensor its 256 threads compute the depthwise
+// values (8 horizontally adjacent pixels of one channel per thread, same summation order as k_fcn_dw) into LDS, the
+// projection's A fragments of that chunk are staged beside them, and every wave multiplies its own 32 pixels against all
+// TILES channel tiles.  Both LDS stages are double buffered: loads of chunk c+1 are issued before the MFMAs of chunk c
+// and committed after them, one barrier per chunk.  Workgroups are renumbered so that the row pairs of one image run
+// on the same XCD (shared L2 for the dilation halo rows).
+template <int TILES, int DIL>
+__global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X, const float* __restrict__ dwW,
+                                                    const float* __restrict__ dwS, const float* __restrict__ dwB,
+                                                    const float* __restrict__ Wf, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, const float* __restrict__ res,
+                                                    float* __restrict__ Y, int K, int Cout, int nTiles)
+{
+    constexpr int kPitch = 160;                     // floats per hidden channel row in LDS (128 pixels + bank skew)
+    constexpr int kWr = TILES;                      // A fragments per chunk = TILES*256 float2, one per thread each
+    constexpr int HW = 64 * 64;
+    __shared__ __attribute__((aligned(16))) float sD[2][16 * kPitch];
+    __shared__ __attribute__((aligned(16))) float sW[2][8 * TILES * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
+    const int b = L / 32, rp = L % 32;
+    const int tile0 = blockIdx.y * TILES;
+    const int kc = tid >> 4, g = tid & 15, r = g >> 3, x0 = (g & 7) * 8;
+    const int y = 2 * rp + r;
+    int rowOff[3]; bool rowOk[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) {
+        const int yy = y + (ky - 1) * DIL;
+        rowOk[ky] = yy >= 0 && yy < 64;
+        rowOff[ky] = (rowOk[ky] ? yy : y) * 64;
+    }
+    const bool okL = x0 > 0, okR = x0 + 8 < 64;
+    const int xl = okL ? x0 - 4 : x0, xr = okR ? x0 + 8 : x0;
+    const float* Xb = X + (size_t)b * K * HW;
+    const int nChunks = K / 16;
+
+    float4 win[3][4];
+    float2 wreg[kWr];
+    float wk[9], dsc, dsh;
+    auto issue = [&](int c) {
+        const int ch = 16 * c + kc;
+        const float* P = Xb + (size_t)ch * HW;
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+            const float* R = P + rowOff[ky];
+            win[ky][0] = *(const float4*)(R + xl);
+            win[ky][1] = *(const float4*)(R + x0);
+            win[ky][2] = *(const float4*)(R + x0 + 4);
+            win[ky][3] = *(const float4*)(R + xr);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) wk[k] = dwW[ch * 9 + k];
+        dsc = dwS[ch]; dsh = dwB[ch];
+#pragma unroll
+        for (int j = 0; j < kWr; j++) {
+            const int i = tid + 256 * j, k2l = i / (TILES * 32), rem = i % (TILES * 32);
+            wreg[j] = *(const float2*)(Wf + ((size_t)(8 * c + k2l) * nTiles + tile0) * 64 + rem * 2);
+        }
+    };
+    float o[8];
+    auto stencil = [&]() {
+#pragma unroll
+        for (int p = 0; p < 8; p++) o[p] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+            float w16[16];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool ok = rowOk[ky] && (j == 0 ? okL : j == 3 ? okR : true);
+                const float4 v = win[ky][j];
+                w16[4 * j + 0] = ok ? v.x : 0.f; w16[4 * j + 1] = ok ? v.y : 0.f;
+                w16[4 * j + 2] = ok ? v.z : 0.f; w16[4 * j + 3] = ok ? v.w : 0.f;
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+                for (int p = 0; p < 8; p++) o[p] += wk[ky * 3 + kx] * w16[4 + p + (kx - 1) * DIL];
+        }
+#pragma unroll
+        for (int p = 0; p < 8; p++) o[p] = fminf(fmaxf(o[p] * dsc + dsh, 0.f), 6.f);
+    };
+    auto publish = [&](int buf) {
+        float* dst = &sD[buf][kc * kPitch + r * 64 + x0];
+        *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+        *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+#pragma unroll
+        for (int j = 0; j < kWr; j++) *(float2*)&sW[buf][(tid + 256 * j) * 2] = wreg[j];
+    };
+
+    f32x16 acc[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; t++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
+
+    issue(0);
+    stencil();
+    publish(0);
+    __syncthreads();
+    for (int c = 0; c < nChunks; c++) {
+        const int cur = c & 1;
+        issue(min(c + 1, nChunks - 1));             // the last refill is a redundant re-load (branch-free loop)
+        const float* dB = &sD[cur][half * kPitch + 32 * wave + col];
+        const float* wA = &sW[cur][lane];
+        // first half of the chunk's MFMAs covers the latency of the loads just issued; the stencil of the next chunk
+        // is scheduled among the second half
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++) {
+            const float bv = dB[2 * k2 * kPitch];
+#pragma unroll
+            for (int t = 0; t < TILES; t++)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[(k2 * TILES + t) * 64], bv, acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        stencil();
+#pragma unroll
+        for (int k2 = 4; k2 < 8; k2++) {
+            const float bv = dB[2 * k2 * kPitch];
+#pragma unroll
+            for (int t = 0; t < TILES; t++)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[(k2 * TILES + t) * 64], bv, acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        publish(cur ^ 1);
+        __syncthreads();
+    }
+    const int pix = 128 * rp + 32 * wave + col;
+#pragma unroll
+    for (int t = 0; t < TILES; t++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int co = (tile0 + t) * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+            if (co >= Cout) continue;
+            float v = acc[t][q] * scale[co] + shift[co];
+            const size_t oi = ((size_t)b * Cout + co) * HW + pix;
+            if (res) v += res[oi];
+            Y[oi] = v;
+        }
+}
+
 // ---- conv_last 1x1 80 -> 1 + bias (models_light.py:196) ----
 __global__ void k_fcn_last(const float* __restrict__ X, const float* __restrict__ w, float bias, float* __restrict__ Y,
                            int C, int HW)
@@ -360,6 +503,28 @@ void launch_gemm(const Gemm& g, const float* X, const float* res, float* Y, int 
     else launch_gemm_t<2, 5, 1>(g, X, res, Y, H, W, B, s);
 }
 
+// fused depthwise + projection for the 64x64 stride-1 stages; false = shape not covered, caller runs the two kernels
+bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, float* Y, int H, int W, int B, hipStream_t s)
+{
+    static const bool off = getenv("IVF_FCN_NOFUSE") != nullptr;
+    const int tiles = (g.cout + 31) / 32;
+    if (off || d.stride != 1 || H != 64 || W != 64 || d.c % 16 || g.taps != 1 || g.nTiles != tiles || g.act != 0) return false;
+    const dim3 blk(256);
+#define DWPW(T, D, GY)                                                                                              \
+    hipLaunchKernelGGL((k_fcn_dwpw<T, D>), dim3(32 * B, GY), blk, 0, s, X, d.dW, d.dScale, d.dShift, g.dWf, g.dScale, \
+                       g.dShift, res, Y, d.c, g.cout, g.nTiles)
+    if (tiles == 1 && d.dil == 1) DWPW(1, 1, 1);
+    else if (tiles == 2 && d.dil == 1) DWPW(2, 1, 1);
+    else if (tiles == 2 && d.dil == 2) DWPW(2, 2, 1);
+    else if (tiles == 3 && d.dil == 2) DWPW(3, 2, 1);
+    else if (tiles == 5 && d.dil == 2) DWPW(5, 2, 1);
+    else if (tiles == 5 && d.dil == 4) DWPW(5, 4, 1);
+    else if (tiles == 10 && d.dil == 4) DWPW(5, 4, 2);
+    else return false;
+#undef DWPW
+    return true;
+}
+
 }  // namespace ivffcn
 using namespace ivffcn;
 
@@ -438,6 +603,12 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
         const float* h = x;
         if (bk.t != 1) { launch_gemm(f->pw[ip++], x, nullptr, f->bufH1, H, W, n, s); h = f->bufH1; snprintf(nm, sizeof nm, "block %d expand", i + 1); STAGE(nm); }
         const Dw& d = f->dw[id++];
+        if (launch_dwpw(d, f->pw[ip], h, bk.res ? x : nullptr, y, H, W, n, s)) {
+            ip++;
+            snprintf(nm, sizeof nm, "block %d depthwise+project", i + 1); STAGE(nm);
+            std::swap(x, y);
+            continue;
+        }
         const int Ho = (H + 2 * d.dil - 2 * d.dil - 1) / d.stride + 1, Wo = (W + 2 * d.dil - 2 * d.dil - 1) / d.stride + 1;
         {
             const int TH = (d.stride == 1 && Ho <= 64) ? 64 : 16;
