@@ -7,10 +7,15 @@
 //
 // Layout: NCHW f32 planes (pixels contiguous).  That makes the activation operand of a 1x1 convolution a
 // coalesced 128-byte row per channel and needs no LDS transposes:
-//   D[cout][pixel] += W[cout][k] * X[k][pixel]   on v_mfma_f32_32x32x2_f32 (exact f32 fma chain; the 1e-3 bound
-//   after the slope-5 logistic leaves no room for bf16 inputs), A = weights pre-shuffled on the host into the
-//   MFMA A-fragment order, B = activations loaded straight from global as float/float2/float4 per lane,
-//   C/D rows = output channels, columns = pixels, so each accumulator register stores a contiguous pixel run.
+//   D[cout][pixel] += W[cout][k] * X[k][pixel]   on v_mfma_f32_32x32x16_f16 with BOTH operands split into two f16
+//   halves (x = hi + lo, 22 significant bits) and three MFMAs per product: hi*hi + hi*lo + lo*hi, f32 accumulate.
+//   That reproduces the f32 product to ~2^-21 (the 1e-3 bound after the slope-5 logistic leaves no room for plain
+//   f16/bf16 inputs, and three bf16 terms measure 1.1e-3), runs 4x faster than v_mfma_f32_32x32x2_f32 (measured:
+//   tools/probe/) and, unlike the f32 MFMA, lets ordinary VALU work issue underneath it.  gfx950 keeps f16
+//   subnormals in MFMA inputs (tools/probe/mfma_f16_check.hip), which the lo halves rely on.
+//   A = weights split and pre-shuffled on the host into the MFMA A-fragment order, B = activations loaded straight
+//   from global as float/float2/float4 per lane and split in registers, C/D rows = output channels, columns =
+//   pixels, so each accumulator register stores a contiguous pixel run.
 // BN (eval mode, eps 1e-5) is folded into per-channel scale/shift at load; ReLU6 / ReLU / residual add are fused
 // into the GEMM and depthwise epilogues.  Depthwise 3x3 (stride/dilation) is an HBM-bound VALU stencil.
 #include <hip/hip_runtime.h>
@@ -34,6 +39,18 @@ namespace ivffcn {
          if (e_ != hipSuccess) return ffail(IVF_E_NO_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+union HFrag { f16x8 v; uint4 q; uint32_t u[4]; };       // one lane's 8 f16 of an MFMA 32x32x16 A or B operand
+
+// two f32 -> packed f16 hi pair + packed f16 lo pair, x = hi + lo (hi, lo rounded toward zero; x - hi is exact)
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& hi, uint32_t& lo)
+{
+    const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]));
+}
 
 constexpr int kEnc = 512;                      // encoder input size (IF/config: enc_input_size)
 
@@ -149,7 +166,8 @@ __global__ __launch_bounds__(256) void k_fcn_dw(const float* __restrict__ X, con
 
 // ---- 1x1 (TAPS=1) / dense 3x3 pad 1 (TAPS=9) convolution as an MFMA GEMM ----
 //   wave tile: 32*NT output channels x 32*PT pixels; workgroup = 4 waves along the pixel axis.
-//   Wf: A fragments, index ((tap*K2 + k2) * nTiles + tile) * 64 + lane = W[tile*32 + (lane&31)][2*k2 + (lane>>5)][tap]
+//   Wq: A fragments, 16 B per lane: index ((((tap*K16 + s) * nTiles + tile) * 2 + part) * 64 + lane), part 0 = hi,
+//       1 = lo, holding W[tile*32 + (lane&31)][16*s + 8*(lane>>5) + 0..7][tap] (zero beyond Cout / Cin)
 //   act: 0 none, 1 ReLU6, 2 ReLU.  res: optional residual (same shape as Y).
 template <int PT> struct VecT;
 template <> struct VecT<1> { typedef float T; };
@@ -161,19 +179,19 @@ template <> __device__ __forceinline__ float vget<2>(const float2& v, int i) { r
 template <> __device__ __forceinline__ float vget<4>(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
 template <int PT, int NT, int TAPS>
-__global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, const float* __restrict__ Wf,
+__global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, const uint4* __restrict__ Wq,
                                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                                  const float* __restrict__ res, float* __restrict__ Y,
                                                  int Cin, int Cout, int Hd, int Wd, int nTiles, int act)
 {
     typedef typename VecT<PT>::T vec;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int half = lane >> 5, col = lane & 31;
+    const int kg = lane >> 5, col = lane & 31;
     const int HW = Hd * Wd;
     const int b = blockIdx.z;
     const int p0 = (blockIdx.x * 4 + wave) * 32 * PT + PT * col;      // first pixel of this lane
     const int ct0 = blockIdx.y * NT;
-    const int K2 = Cin / 2;
+    const int K16 = (Cin + 15) / 16;
     f32x16 acc[NT][PT];
 #pragma unroll
     for (int n = 0; n < NT; n++)
@@ -181,67 +199,87 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
         for (int p = 0; p < PT; p++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[n][p][r] = 0.f;
-    const float* Xb = X + (size_t)b * Cin * HW + (size_t)half * HW;
-    const float* wp = Wf + (size_t)ct0 * 64 + lane;
+    const float* Xb = X + (size_t)b * Cin * HW;
+    const uint4* wq = Wq + (size_t)ct0 * 128 + lane;
 
-    if (TAPS == 1) {
-        // software pipeline, 4 steps deep: right after a step's operands have been consumed by its MFMAs, the same
-        // registers receive the loads of step k2+4, so ~4 x NT*PT MFMAs (64 cycles each) cover the L2/HBM latency.
-        // Every channel count of the network is a multiple of 8, so K2 % 4 == 0.
-        const float* xp = Xb + p0;
-        vec bs[4];
-        float as[4][NT];
+    // registers of the step in flight: raw activations of the lane's 8 channels + the A fragments
+    vec xb[8];
+    uint4 aq[NT][2];
+    HFrag bh[PT], bl[PT], ah[NT], al[NT];
+    auto consume = [&]() {                          // split the loaded step into f16 operands, freeing xb / aq
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            bs[j] = *(const vec*)(xp + (size_t)2 * j * HW);
+        for (int p = 0; p < PT; p++)
 #pragma unroll
-            for (int n = 0; n < NT; n++) as[j][n] = wp[((size_t)j * nTiles + n) * 64];
-        }
-        // branch-free body (the refill index is clamped, the last refills are redundant re-loads) so that the
-        // compiler can keep counted s_waitcnt vmcnt(N) instead of draining the queue at a control-flow join
-        for (int k2 = 0; k2 < K2; k2 += 4) {
+            for (int jj = 0; jj < 4; jj++)
+                split_pair(vget<PT>(xb[2 * jj], p), vget<PT>(xb[2 * jj + 1], p), bh[p].u[jj], bl[p].u[jj]);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+        for (int n = 0; n < NT; n++) { ah[n].q = aq[n][0]; al[n].q = aq[n][1]; }
+    };
+    auto multiply = [&]() {                         // small terms first; consecutive MFMAs hit different accumulators
 #pragma unroll
-                for (int n = 0; n < NT; n++)
+        for (int n = 0; n < NT; n++)
 #pragma unroll
-                    for (int p = 0; p < PT; p++)
-                        acc[n][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[j][n], vget<PT>(bs[j], p), acc[n][p], 0, 0, 0);
-                const int kn = min(k2 + 4 + j, K2 - 1);
-                bs[j] = *(const vec*)(xp + (size_t)2 * kn * HW);
+            for (int p = 0; p < PT; p++) acc[n][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[n].v, bh[p].v, acc[n][p], 0, 0, 0);
 #pragma unroll
-                for (int n = 0; n < NT; n++) as[j][n] = wp[((size_t)kn * nTiles + n) * 64];
-                __builtin_amdgcn_sched_barrier(0);      // keep the refill here: the scheduler otherwise sinks it to its use
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int p = 0; p < PT; p++) acc[n][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[n].v, bl[p].v, acc[n][p], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int p = 0; p < PT; p++) acc[n][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[n].v, bh[p].v, acc[n][p], 0, 0, 0);
+    };
+
+    if constexpr (TAPS == 1) {
+        // channels past Cin are clamped to the last one: their weights are zero and the values finite
+        auto load = [&](int s) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int kch = min(16 * s + 8 * kg + j, Cin - 1);
+                xb[j] = *(const vec*)(Xb + (size_t)kch * HW + p0);
             }
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                aq[n][0] = wq[((size_t)s * nTiles + n) * 128];
+                aq[n][1] = wq[((size_t)s * nTiles + n) * 128 + 64];
+            }
+        };
+        load(0);
+        // branch-free body: the loads of step s+1 are issued right after step s has been split into f16 operands and
+        // stay in flight under its 3*NT*PT MFMAs (the last refill is a redundant re-load)
+        for (int s = 0; s < K16; s++) {
+            consume();
+            load(min(s + 1, K16 - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            multiply();
         }
     } else {
-        int py[PT], pxx[PT];
+        static_assert(TAPS == 1 || PT == 1, "the 3x3 path handles one pixel per lane");
+        const int py = p0 / Wd, pxx = p0 % Wd;
+        int tapN = 0, sN = 0;                       // (tap, step) the next load() fetches
+        auto load = [&]() {
+            const int yy = py + tapN / 3 - 1, xx = pxx + tapN % 3 - 1;
+            const bool ok = yy >= 0 && yy < Hd && xx >= 0 && xx < Wd;
+            const int off = ok ? yy * Wd + xx : p0;
 #pragma unroll
-        for (int p = 0; p < PT; p++) { py[p] = (p0 + p) / Wd; pxx[p] = (p0 + p) % Wd; }
-        for (int tap = 0; tap < 9; tap++) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            int off[PT]; bool ok[PT];
-#pragma unroll
-            for (int p = 0; p < PT; p++) {
-                const int yy = py[p] + dy, xx = pxx[p] + dx;
-                ok[p] = yy >= 0 && yy < Hd && xx >= 0 && xx < Wd;
-                off[p] = ok[p] ? yy * Wd + xx : 0;
+            for (int j = 0; j < 8; j++) {
+                const int kch = min(16 * sN + 8 * kg + j, Cin - 1);
+                const float t = Xb[(size_t)kch * HW + off];
+                xb[j] = ok ? t : 0.f;
             }
-            const float* wt = wp + (size_t)tap * K2 * nTiles * 64;
-#pragma unroll 2
-            for (int k2 = 0; k2 < K2; k2++) {
-                float bv[PT];
 #pragma unroll
-                for (int p = 0; p < PT; p++) { const float t = Xb[(size_t)2 * k2 * HW + off[p]]; bv[p] = ok[p] ? t : 0.f; }
-                float a[NT];
-#pragma unroll
-                for (int n = 0; n < NT; n++) a[n] = wt[((size_t)k2 * nTiles + n) * 64];
-#pragma unroll
-                for (int n = 0; n < NT; n++)
-#pragma unroll
-                    for (int p = 0; p < PT; p++)
-                        acc[n][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n], bv[p], acc[n][p], 0, 0, 0);
+            for (int n = 0; n < NT; n++) {
+                aq[n][0] = wq[((size_t)(tapN * K16 + sN) * nTiles + n) * 128];
+                aq[n][1] = wq[((size_t)(tapN * K16 + sN) * nTiles + n) * 128 + 64];
             }
+            if (++sN == K16) { sN = 0; if (tapN < 8) ++tapN; else sN = K16 - 1; }
+        };
+        load();
+        for (int i = 0; i < 9 * K16; i++) {
+            consume();
+            load();
+            __builtin_amdgcn_sched_barrier(0);
+            multiply();
         }
     }
     // epilogue: C/D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (output channel)
@@ -249,7 +287,7 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
     for (int n = 0; n < NT; n++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int co = (ct0 + n) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int co = (ct0 + n) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
             if (co >= Cout) continue;
             const float sc = scale[co], sh = shift[co];
             float o[PT];
@@ -265,33 +303,33 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
 #pragma unroll
                 for (int p = 0; p < PT; p++) o[p] += res[oi + p];
             }
-            if (PT == 4) *(float4*)(Y + oi) = make_float4(o[0], o[1], o[2], o[3]);
-            else if (PT == 2) *(float2*)(Y + oi) = make_float2(o[0], o[1]);
+            if constexpr (PT == 4) *(float4*)(Y + oi) = make_float4(o[0], o[1], o[2], o[3]);
+            else if constexpr (PT == 2) *(float2*)(Y + oi) = make_float2(o[0], o[1]);
             else Y[oi] = o[0];
         }
 }
 
 // ---- fused depthwise 3x3 (stride 1, dilation DIL) + BN + ReLU6  ->  1x1 projection (MFMA) + BN (+ residual) ----
 // For the 64x64 stages of the encoder the depthwise output never goes to HBM: a workgroup owns 128 pixels (two image
-// rows) and TILES*32 output channels; per 16-channel chunk of the hidden tensor its 256 threads compute the depthwise
-// values (8 horizontally adjacent pixels of one channel per thread, same summation order as k_fcn_dw) into LDS, the
-// projection's A fragments of that chunk are staged beside them, and every wave multiplies its own 32 pixels against all
-// TILES channel tiles.  Both LDS stages are double buffered: loads of chunk c+1 are issued before the MFMAs of chunk c
-// and committed after them, one barrier per chunk.  Workgroups are renumbered so that the row pairs of one image run
-// on the same XCD (shared L2 for the dilation halo rows).
+// rows) and TILES*32 output channels; per 16-channel chunk of the hidden tensor (= one MFMA K step) its 256 threads
+// compute the depthwise values (8 horizontally adjacent pixels of one channel per thread, packed-f32 FMAs) into LDS,
+// the projection's A fragments of that chunk are staged beside them, and every wave multiplies its own 32 pixels
+// against all TILES channel tiles.  Both LDS stages are double buffered: loads of chunk c+1 are issued before the
+// MFMAs of chunk c and committed after them, one barrier per chunk.  Workgroups are renumbered so that the row pairs
+// of one image run on the same XCD (shared L2 for the dilation halo rows).
 template <int TILES, int DIL>
 __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X, const float* __restrict__ dwW,
                                                     const float* __restrict__ dwS, const float* __restrict__ dwB,
-                                                    const float* __restrict__ Wf, const float* __restrict__ scale,
+                                                    const uint4* __restrict__ Wq, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, const float* __restrict__ res,
                                                     float* __restrict__ Y, int K, int Cout, int nTiles)
 {
-    constexpr int kPitch = 160;                     // floats per hidden channel row in LDS (128 pixels + bank skew)
-    constexpr int kWr = TILES;                      // A fragments per chunk = TILES*256 float2, one per thread each
+    constexpr int kPitch = 132;                     // floats per hidden channel row in LDS: 128 pixels + bank skew
+                                                    // (8 rows apart = 32 banks apart: the two k-groups never collide)
     constexpr int HW = 64 * 64;
     __shared__ __attribute__((aligned(16))) float sD[2][16 * kPitch];
-    __shared__ __attribute__((aligned(16))) float sW[2][8 * TILES * 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    __shared__ __attribute__((aligned(16))) float sW[2][TILES * 512];    // per tile: hi fragment, lo fragment (1 KB each)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 5, col = lane & 31;
     const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
     const int b = L / 32, rp = L % 32;
     const int tile0 = blockIdx.y * TILES;
@@ -306,11 +344,13 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     }
     const bool okL = x0 > 0, okR = x0 + 8 < 64;
     const int xl = okL ? x0 - 4 : x0, xr = okR ? x0 + 8 : x0;
+    const float mL = okL ? 1.f : 0.f, mR = okR ? 1.f : 0.f;
     const float* Xb = X + (size_t)b * K * HW;
+    const float* Wf = (const float*)Wq;
     const int nChunks = K / 16;
 
     float4 win[3][4];
-    float2 wreg[kWr];
+    float2 wreg[TILES];
     float wk[9], dsc, dsh;
     auto issue = [&](int c) {
         const int ch = 16 * c + kc;
@@ -327,39 +367,50 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
         for (int k = 0; k < 9; k++) wk[k] = dwW[ch * 9 + k];
         dsc = dwS[ch]; dsh = dwB[ch];
 #pragma unroll
-        for (int j = 0; j < kWr; j++) {
-            const int i = tid + 256 * j, k2l = i / (TILES * 32), rem = i % (TILES * 32);
-            wreg[j] = *(const float2*)(Wf + ((size_t)(8 * c + k2l) * nTiles + tile0) * 64 + rem * 2);
-        }
+        for (int j = 0; j < TILES; j++)
+            wreg[j] = *(const float2*)(Wf + ((size_t)c * nTiles + tile0) * 512 + (tid + 256 * j) * 2);
     };
-    float o[8];
+    v2f o[4];
     auto stencil = [&]() {
 #pragma unroll
-        for (int p = 0; p < 8; p++) o[p] = 0.f;
+        for (int q = 0; q < 4; q++) o[q] = (v2f){0.f, 0.f};
 #pragma unroll
         for (int ky = 0; ky < 3; ky++) {
+            // zero padding: rows through the tap weights, the left / right halo through a 0/1 factor on the data
+            const float rm = rowOk[ky] ? 1.f : 0.f;
             float w16[16];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const bool ok = rowOk[ky] && (j == 0 ? okL : j == 3 ? okR : true);
                 const float4 v = win[ky][j];
-                w16[4 * j + 0] = ok ? v.x : 0.f; w16[4 * j + 1] = ok ? v.y : 0.f;
-                w16[4 * j + 2] = ok ? v.z : 0.f; w16[4 * j + 3] = ok ? v.w : 0.f;
+                const float m = j == 0 ? mL : j == 3 ? mR : 1.f;
+                if (j == 0 || j == 3) {
+                    const v2f a = (v2f){v.x, v.y} * (v2f){m, m}, c = (v2f){v.z, v.w} * (v2f){m, m};
+                    w16[4 * j + 0] = a.x; w16[4 * j + 1] = a.y; w16[4 * j + 2] = c.x; w16[4 * j + 3] = c.y;
+                } else { w16[4 * j + 0] = v.x; w16[4 * j + 1] = v.y; w16[4 * j + 2] = v.z; w16[4 * j + 3] = v.w; }
             }
 #pragma unroll
-            for (int kx = 0; kx < 3; kx++)
+            for (int kx = 0; kx < 3; kx++) {
+                const float w = wk[ky * 3 + kx] * rm;
 #pragma unroll
-                for (int p = 0; p < 8; p++) o[p] += wk[ky * 3 + kx] * w16[4 + p + (kx - 1) * DIL];
+                for (int q = 0; q < 4; q++) {
+                    const int i = 4 + 2 * q + (kx - 1) * DIL;
+                    o[q] = __builtin_elementwise_fma((v2f){w16[i], w16[i + 1]}, (v2f){w, w}, o[q]);
+                }
+            }
         }
 #pragma unroll
-        for (int p = 0; p < 8; p++) o[p] = fminf(fmaxf(o[p] * dsc + dsh, 0.f), 6.f);
+        for (int q = 0; q < 4; q++) {
+            o[q] = __builtin_elementwise_fma(o[q], (v2f){dsc, dsc}, (v2f){dsh, dsh});
+            o[q].x = __builtin_amdgcn_fmed3f(o[q].x, 0.f, 6.f);
+            o[q].y = __builtin_amdgcn_fmed3f(o[q].y, 0.f, 6.f);
+        }
     };
     auto publish = [&](int buf) {
         float* dst = &sD[buf][kc * kPitch + r * 64 + x0];
-        *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
-        *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        *(float4*)dst = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+        *(float4*)(dst + 4) = make_float4(o[2].x, o[2].y, o[3].x, o[3].y);
 #pragma unroll
-        for (int j = 0; j < kWr; j++) *(float2*)&sW[buf][(tid + 256 * j) * 2] = wreg[j];
+        for (int j = 0; j < TILES; j++) *(float2*)&sW[buf][(tid + 256 * j) * 2] = wreg[j];
     };
 
     f32x16 acc[TILES];
@@ -375,27 +426,23 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     for (int c = 0; c < nChunks; c++) {
         const int cur = c & 1;
         issue(min(c + 1, nChunks - 1));             // the last refill is a redundant re-load (branch-free loop)
-        const float* dB = &sD[cur][half * kPitch + 32 * wave + col];
-        const float* wA = &sW[cur][lane];
-        // first half of the chunk's MFMAs covers the latency of the loads just issued; the stencil of the next chunk
-        // is scheduled among the second half
+        // B operand: this lane's pixel, hidden channels 8*kg .. 8*kg+7 of the chunk, split into f16 hi / lo
+        HFrag bh, bl;
+        const float* dB = &sD[cur][8 * kg * kPitch + 32 * wave + col];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) split_pair(dB[2 * jj * kPitch], dB[(2 * jj + 1) * kPitch], bh.u[jj], bl.u[jj]);
+        const uint4* wA = (const uint4*)&sW[cur][0] + lane;
+        HFrag ah[TILES], al[TILES];
+#pragma unroll
+        for (int t = 0; t < TILES; t++) { ah[t].q = wA[t * 128]; al[t].q = wA[t * 128 + 64]; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k2 = 0; k2 < 4; k2++) {
-            const float bv = dB[2 * k2 * kPitch];
+        for (int t = 0; t < TILES; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t].v, bh.v, acc[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < TILES; t++)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[(k2 * TILES + t) * 64], bv, acc[t], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < TILES; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t].v, bl.v, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < TILES; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t].v, bh.v, acc[t], 0, 0, 0);
         stencil();
-#pragma unroll
-        for (int k2 = 4; k2 < 8; k2++) {
-            const float bv = dB[2 * k2 * kPitch];
-#pragma unroll
-            for (int t = 0; t < TILES; t++)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[(k2 * TILES + t) * 64], bv, acc[t], 0, 0, 0);
-        }
         __builtin_amdgcn_sched_barrier(0);
         publish(cur ^ 1);
         __syncthreads();
@@ -405,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     for (int t = 0; t < TILES; t++)
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            const int co = (tile0 + t) * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+            const int co = (tile0 + t) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
             if (co >= Cout) continue;
             float v = acc[t][q] * scale[co] + shift[co];
             const size_t oi = ((size_t)b * Cout + co) * HW + pix;
@@ -467,7 +514,8 @@ const Block kBlocks[17] = {
 
 struct Gemm {            // one MFMA convolution
     int cin, cout, taps, nTiles, NT, PT, act;
-    float *dWf, *dScale, *dShift;
+    uint4* dWq;             // f16 hi / lo A fragments (see k_fcn_gemm)
+    float *dScale, *dShift;
 };
 struct Dw { int c, stride, dil; float *dW, *dScale, *dShift; };
 
@@ -475,6 +523,40 @@ struct Reader {
     const float* p; size_t left;
     const float* take(size_t n) { if (n > left) return nullptr; const float* r = p; p += n; left -= n; return r; }
 };
+
+// IEEE binary16 <-> binary32 on the host (round to nearest even, subnormals kept): the weight halves of the split
+uint16_t f32_to_f16(float f)
+{
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x47800000u) return (uint16_t)(sign | (x > 0x7F800000u ? 0x7E00u : 0x7C00u));     // overflow / inf / nan
+    if (x < 0x38800000u) {                                   // below the smallest normal half: subnormal or zero
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int e = (int)(x >> 23);
+        const uint32_t m = (x & 0x7FFFFFu) | 0x800000u;
+        const int shift = 126 - e;                           // 14 .. 24
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (r & 1))) r++;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = (x - 0x38000000u) >> 13;
+    const uint32_t rem = x & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) r++;
+    return (uint16_t)(sign | r);
+}
+float f16_to_f32(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const int e = (h >> 10) & 31; const uint32_t m = h & 0x3FFu;
+    float v;
+    if (e == 0) v = std::ldexp((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = std::ldexp((float)(m | 0x400u), e - 25);
+    uint32_t x; memcpy(&x, &v, 4); x |= sign; memcpy(&v, &x, 4);
+    return v;
+}
 
 void fold_bn(const float* g, const float* b, const float* m, const float* v, int c, std::vector<float>& sc, std::vector<float>& sh)
 {
@@ -491,7 +573,7 @@ void launch_gemm_t(const Gemm& g, const float* X, const float* res, float* Y, in
 {
     const int HW = H * W;
     dim3 grid(HW / (128 * PT), g.nTiles / NT, B);
-    hipLaunchKernelGGL((k_fcn_gemm<PT, NT, TAPS>), grid, dim3(256), 0, s, X, g.dWf, g.dScale, g.dShift, res, Y, g.cin,
+    hipLaunchKernelGGL((k_fcn_gemm<PT, NT, TAPS>), grid, dim3(256), 0, s, X, g.dWq, g.dScale, g.dShift, res, Y, g.cin,
                        g.cout, H, W, g.nTiles, g.act);
 }
 void launch_gemm(const Gemm& g, const float* X, const float* res, float* Y, int H, int W, int B, hipStream_t s)
@@ -500,6 +582,11 @@ void launch_gemm(const Gemm& g, const float* X, const float* res, float* Y, int 
     if (g.PT == 4 && g.NT == 1) launch_gemm_t<4, 1, 1>(g, X, res, Y, H, W, B, s);
     else if (g.PT == 4 && g.NT == 2) launch_gemm_t<4, 2, 1>(g, X, res, Y, H, W, B, s);
     else if (g.PT == 4 && g.NT == 3) launch_gemm_t<4, 3, 1>(g, X, res, Y, H, W, B, s);
+    else if (g.PT == 2 && g.NT == 1) launch_gemm_t<2, 1, 1>(g, X, res, Y, H, W, B, s);
+    else if (g.PT == 2 && g.NT == 2) launch_gemm_t<2, 2, 1>(g, X, res, Y, H, W, B, s);
+    else if (g.PT == 2 && g.NT == 3) launch_gemm_t<2, 3, 1>(g, X, res, Y, H, W, B, s);
+    else if (g.PT == 1 && g.NT == 1) launch_gemm_t<1, 1, 1>(g, X, res, Y, H, W, B, s);
+    else if (g.PT == 1 && g.NT == 2) launch_gemm_t<1, 2, 1>(g, X, res, Y, H, W, B, s);
     else launch_gemm_t<2, 5, 1>(g, X, res, Y, H, W, B, s);
 }
 
@@ -511,7 +598,7 @@ bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, f
     if (off || d.stride != 1 || H != 64 || W != 64 || d.c % 16 || g.taps != 1 || g.nTiles != tiles || g.act != 0) return false;
     const dim3 blk(256);
 #define DWPW(T, D, GY)                                                                                              \
-    hipLaunchKernelGGL((k_fcn_dwpw<T, D>), dim3(32 * B, GY), blk, 0, s, X, d.dW, d.dScale, d.dShift, g.dWf, g.dScale, \
+    hipLaunchKernelGGL((k_fcn_dwpw<T, D>), dim3(32 * B, GY), blk, 0, s, X, d.dW, d.dScale, d.dShift, g.dWq, g.dScale, \
                        g.dShift, res, Y, d.c, g.cout, g.nTiles)
     if (tiles == 1 && d.dil == 1) DWPW(1, 1, 1);
     else if (tiles == 2 && d.dil == 1) DWPW(2, 1, 1);
@@ -560,21 +647,33 @@ int make_gemm(ivf_fcn* f, const float* w, int cout, int cin, int taps, const std
     static const int ntSmall = getenv("IVF_FCN_NT_SMALL") ? atoi(getenv("IVF_FCN_NT_SMALL")) : 1;
     static const int ntBig = getenv("IVF_FCN_NT_BIG") ? atoi(getenv("IVF_FCN_NT_BIG")) : 1;
     static const int use25 = getenv("IVF_FCN_USE25") ? atoi(getenv("IVF_FCN_USE25")) : 0;
+    static const int ptSmall = getenv("IVF_FCN_PT_SMALL") ? atoi(getenv("IVF_FCN_PT_SMALL")) : 4;
+    static const int ptBig = getenv("IVF_FCN_PT_BIG") ? atoi(getenv("IVF_FCN_PT_BIG")) : 4;
     if (taps == 9) { g.NT = 3; g.PT = 1; }
-    else if (cin <= 32) { g.NT = std::min(tiles, ntSmall); g.PT = 4; }
+    else if (cin <= 32) { g.NT = std::min(tiles, ntSmall); g.PT = ptSmall; }
     else if (tiles == 5 && use25) { g.NT = 5; g.PT = 2; }
-    else { g.NT = std::min(tiles, ntBig); g.PT = 4; }
+    else { g.NT = std::min(tiles, ntBig); g.PT = ptBig; }
     g.nTiles = (tiles + g.NT - 1) / g.NT * g.NT;
-    const int K2 = cin / 2;
-    std::vector<float> wf((size_t)taps * K2 * g.nTiles * 64, 0.f);
+    const int K16 = (cin + 15) / 16;
+    std::vector<float> wq((size_t)taps * K16 * g.nTiles * 2 * 64 * 4, 0.f);     // 8 f16 = 4 dwords per lane and part
+    uint16_t* q = reinterpret_cast<uint16_t*>(wq.data());
     for (int tap = 0; tap < taps; tap++)
-        for (int k2 = 0; k2 < K2; k2++)
+        for (int s = 0; s < K16; s++)
             for (int t = 0; t < g.nTiles; t++)
-                for (int lane = 0; lane < 64; lane++) {
-                    const int co = t * 32 + (lane & 31), k = 2 * k2 + (lane >> 5);
-                    if (co < cout) wf[(((size_t)tap * K2 + k2) * g.nTiles + t) * 64 + lane] = w[((size_t)co * cin + k) * taps + tap];
-                }
-    int rc = upload(f, wf, &g.dWf); if (rc) return rc;
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++) {
+                        const int co = t * 32 + (lane & 31), k = 16 * s + 8 * (lane >> 5) + j;
+                        if (co >= cout || k >= cin) continue;
+                        const float v = w[((size_t)co * cin + k) * taps + tap];
+                        const uint16_t hi = f32_to_f16(v);
+                        const uint16_t lo = f32_to_f16(v - f16_to_f32(hi));
+                        const size_t frag = (((size_t)tap * K16 + s) * g.nTiles + t) * 2;
+                        q[((frag + 0) * 64 + lane) * 8 + j] = hi;
+                        q[((frag + 1) * 64 + lane) * 8 + j] = lo;
+                    }
+    float* dq = nullptr;
+    int rc = upload(f, wq, &dq); if (rc) return rc;
+    g.dWq = reinterpret_cast<uint4*>(dq);
     rc = upload(f, sc, &g.dScale); if (rc) return rc;
     return upload(f, sh, &g.dShift);
 }
