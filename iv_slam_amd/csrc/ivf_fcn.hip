@@ -282,31 +282,44 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
             multiply();
         }
     }
-    // epilogue: C/D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (output channel)
+    // epilogue: C/D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (output channel).  All loads of
+    // a tile (BN scale/shift as float4 per row quad -- the arrays are padded to whole tiles -- and the residual) are
+    // issued as one batch before the first use, so the tile costs one memory round trip instead of sixteen.
 #pragma unroll
-    for (int n = 0; n < NT; n++)
+    for (int n = 0; n < NT; n++) {
+        const int cb = (ct0 + n) * 32 + 4 * kg;
+        float4 sc4[4], sh4[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(scale + cb + 8 * g4); sh4[g4] = *(const float4*)(shift + cb + 8 * g4); }
+        const size_t ob = ((size_t)b * Cout + cb) * HW + p0;
+        vec rv[16];
+        if (res) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                if (cb + ro < Cout) rv[r] = *(const vec*)(res + ob + (size_t)ro * HW);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int co = (ct0 + n) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-            if (co >= Cout) continue;
-            const float sc = scale[co], sh = shift[co];
+            const int ro = (r & 3) + 8 * (r >> 2);
+            if (cb + ro >= Cout) continue;
+            const float sc = vget<4>(sc4[r >> 2], r & 3), sh = vget<4>(sh4[r >> 2], r & 3);
             float o[PT];
 #pragma unroll
             for (int p = 0; p < PT; p++) {
                 float v = acc[n][p][r] * sc + sh;
-                if (act == 1) v = fminf(fmaxf(v, 0.f), 6.f);
+                if (act == 1) v = __builtin_amdgcn_fmed3f(v, 0.f, 6.f);
                 else if (act == 2) v = fmaxf(v, 0.f);
+                if (res) v += vget<PT>(rv[r], p);
                 o[p] = v;
             }
-            const size_t oi = ((size_t)b * Cout + co) * HW + p0;
-            if (res) {
-#pragma unroll
-                for (int p = 0; p < PT; p++) o[p] += res[oi + p];
-            }
-            if constexpr (PT == 4) *(float4*)(Y + oi) = make_float4(o[0], o[1], o[2], o[3]);
-            else if constexpr (PT == 2) *(float2*)(Y + oi) = make_float2(o[0], o[1]);
-            else Y[oi] = o[0];
+            float* yo = Y + ob + (size_t)ro * HW;
+            if constexpr (PT == 4) *(float4*)yo = make_float4(o[0], o[1], o[2], o[3]);
+            else if constexpr (PT == 2) *(float2*)yo = make_float2(o[0], o[1]);
+            else *yo = o[0];
         }
+    }
 }
 
 // ---- fused depthwise 3x3 (stride 1, dilation DIL) + BN + ReLU6  ->  1x1 projection (MFMA) + BN (+ residual) ----
@@ -314,15 +327,20 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
 // rows) and TILES*32 output channels; per 16-channel chunk of the hidden tensor (= one MFMA K step) its 256 threads
 // compute the depthwise values (8 horizontally adjacent pixels of one channel per thread, packed-f32 FMAs) into LDS,
 // the projection's A fragments of that chunk are staged beside them, and every wave multiplies its own 32 pixels
-// against all TILES channel tiles.  Both LDS stages are double buffered: loads of chunk c+1 are issued before the
-// MFMAs of chunk c and committed after them, one barrier per chunk.  Workgroups are renumbered so that the row pairs
-// of one image run on the same XCD (shared L2 for the dilation halo rows).
+// against all TILES channel tiles.
+//   * a thread loads only its own 8 pixels of the three tap rows; the dilation halo comes from the neighbouring lanes
+//     by DPP row shifts (the 16 threads of a channel are one DPP row), which halves the L1 traffic and the registers
+//     of a window, so that TWO chunks of loads are kept in flight (register sets A/B, loop unrolled by two);
+//   * both LDS stages are double buffered, one barrier per chunk;
+//   * workgroups are renumbered so that the row pairs of one image run on the same XCD (shared L2 for halo rows).
+// dwP: per hidden channel 12 floats = 9 taps, BN scale, BN shift, pad.
+struct DwSet { float4 own[3][2]; float par; };   // par: parameter (tid & 15) of this thread's channel
+
 template <int TILES, int DIL>
-__global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X, const float* __restrict__ dwW,
-                                                    const float* __restrict__ dwS, const float* __restrict__ dwB,
+__global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X, const float* __restrict__ dwP,
                                                     const uint4* __restrict__ Wq, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, const float* __restrict__ res,
-                                                    float* __restrict__ Y, int K, int Cout, int nTiles)
+                                                    float* __restrict__ Y, int K, int Cout, int nTiles, int abl)
 {
     constexpr int kPitch = 132;                     // floats per hidden channel row in LDS: 128 pixels + bank skew
                                                     // (8 rows apart = 32 banks apart: the two k-groups never collide)
@@ -335,62 +353,77 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     const int tile0 = blockIdx.y * TILES;
     const int kc = tid >> 4, g = tid & 15, r = g >> 3, x0 = (g & 7) * 8;
     const int y = 2 * rp + r;
-    int rowOff[3]; bool rowOk[3];
+    int rowOff[3]; float rowM[3];
 #pragma unroll
     for (int ky = 0; ky < 3; ky++) {
         const int yy = y + (ky - 1) * DIL;
-        rowOk[ky] = yy >= 0 && yy < 64;
-        rowOff[ky] = (rowOk[ky] ? yy : y) * 64;
+        const bool ok = yy >= 0 && yy < 64;
+        rowM[ky] = ok ? 1.f : 0.f;
+        rowOff[ky] = (ok ? yy : y) * 64 + x0;
     }
-    const bool okL = x0 > 0, okR = x0 + 8 < 64;
-    const int xl = okL ? x0 - 4 : x0, xr = okR ? x0 + 8 : x0;
-    const float mL = okL ? 1.f : 0.f, mR = okR ? 1.f : 0.f;
+    const float mL = x0 > 0 ? 1.f : 0.f, mR = x0 + 8 < 64 ? 1.f : 0.f;
     const float* Xb = X + (size_t)b * K * HW;
     const float* Wf = (const float*)Wq;
-    const int nChunks = K / 16;
+    const int nChunks = abl >= 2 ? 24 : K / 16;     // even for every hidden width of the network (192 .. 960)
 
-    float4 win[3][4];
-    float2 wreg[TILES];
-    float wk[9], dsc, dsh;
-    auto issue = [&](int c) {
-        const int ch = 16 * c + kc;
-        const float* P = Xb + (size_t)ch * HW;
+    // window and depthwise-parameter loads run two chunks ahead; each of the 16 threads of a channel fetches ONE of its
+    // 12 parameters and the stencil broadcasts them with DPP row_share.  The A fragments (L2-resident, needed only at
+    // publish time) run one chunk ahead and are issued first so that waiting for them leaves the rest in flight.
+    const int parIdx = kc * 12 + min(g, 11);
+    auto issue = [&](DwSet& S, int c) {
+        c = min(c, nChunks - 1);                    // refills past the end are redundant re-loads (branch-free loop)
+        if (abl & 1) c = 0;
+        const float* P = Xb + (size_t)(16 * c + kc) * HW;
+        S.par = dwP[c * 192 + parIdx];
 #pragma unroll
         for (int ky = 0; ky < 3; ky++) {
-            const float* R = P + rowOff[ky];
-            win[ky][0] = *(const float4*)(R + xl);
-            win[ky][1] = *(const float4*)(R + x0);
-            win[ky][2] = *(const float4*)(R + x0 + 4);
-            win[ky][3] = *(const float4*)(R + xr);
+            S.own[ky][0] = *(const float4*)(P + rowOff[ky]);
+            S.own[ky][1] = *(const float4*)(P + rowOff[ky] + 4);
         }
-#pragma unroll
-        for (int k = 0; k < 9; k++) wk[k] = dwW[ch * 9 + k];
-        dsc = dwS[ch]; dsh = dwB[ch];
+    };
+    float2 wreg[TILES];
+    auto issue_w = [&](int c) {
+        c = min(c, nChunks - 1);
 #pragma unroll
         for (int j = 0; j < TILES; j++)
             wreg[j] = *(const float2*)(Wf + ((size_t)c * nTiles + tile0) * 512 + (tid + 256 * j) * 2);
     };
+    auto shr1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true)); };
+    auto shl1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xF, 0xF, true)); };
     v2f o[4];
-    auto stencil = [&]() {
+    auto stencil = [&](const DwSet& S) {
+        float wk[9];
+        const int pi = __builtin_bit_cast(int, S.par);
+#define ROW_SHARE(k) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, pi, 0x150 + (k), 0xF, 0xF, false))
+        wk[0] = ROW_SHARE(0); wk[1] = ROW_SHARE(1); wk[2] = ROW_SHARE(2); wk[3] = ROW_SHARE(3); wk[4] = ROW_SHARE(4);
+        wk[5] = ROW_SHARE(5); wk[6] = ROW_SHARE(6); wk[7] = ROW_SHARE(7); wk[8] = ROW_SHARE(8);
+        const float dsc = ROW_SHARE(9), dsh = ROW_SHARE(10);
+#undef ROW_SHARE
 #pragma unroll
         for (int q = 0; q < 4; q++) o[q] = (v2f){0.f, 0.f};
 #pragma unroll
         for (int ky = 0; ky < 3; ky++) {
-            // zero padding: rows through the tap weights, the left / right halo through a 0/1 factor on the data
-            const float rm = rowOk[ky] ? 1.f : 0.f;
+            // window x0-4 .. x0+11: [left halo | own a | own b | right halo]; halos arrive from lane-1 / lane+1 and are
+            // zeroed at the image border (mL / mR); rows outside the image are zeroed through the tap weights
+            const float4 a = S.own[ky][0], c4 = S.own[ky][1];
             float w16[16];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float4 v = win[ky][j];
-                const float m = j == 0 ? mL : j == 3 ? mR : 1.f;
-                if (j == 0 || j == 3) {
-                    const v2f a = (v2f){v.x, v.y} * (v2f){m, m}, c = (v2f){v.z, v.w} * (v2f){m, m};
-                    w16[4 * j + 0] = a.x; w16[4 * j + 1] = a.y; w16[4 * j + 2] = c.x; w16[4 * j + 3] = c.y;
-                } else { w16[4 * j + 0] = v.x; w16[4 * j + 1] = v.y; w16[4 * j + 2] = v.z; w16[4 * j + 3] = v.w; }
+            w16[4] = a.x; w16[5] = a.y; w16[6] = a.z; w16[7] = a.w;
+            w16[8] = c4.x; w16[9] = c4.y; w16[10] = c4.z; w16[11] = c4.w;
+            if (DIL >= 4) { w16[0] = shr1(c4.x); w16[1] = shr1(c4.y); w16[14] = shl1(a.z); w16[15] = shl1(a.w); }
+            if (DIL >= 2) { w16[2] = shr1(c4.z); w16[13] = shl1(a.y); }
+            w16[3] = shr1(c4.w); w16[12] = shl1(a.x);
+            const v2f vL = (v2f){mL, mL}, vR = (v2f){mR, mR};
+            if (DIL >= 4) {
+                const v2f t0 = (v2f){w16[0], w16[1]} * vL, t1 = (v2f){w16[14], w16[15]} * vR;
+                w16[0] = t0.x; w16[1] = t0.y; w16[14] = t1.x; w16[15] = t1.y;
             }
+            if (DIL >= 2) {
+                const v2f t0 = (v2f){w16[2], w16[3]} * vL, t1 = (v2f){w16[12], w16[13]} * vR;
+                w16[2] = t0.x; w16[3] = t0.y; w16[12] = t1.x; w16[13] = t1.y;
+            } else { w16[3] *= mL; w16[12] *= mR; }
 #pragma unroll
             for (int kx = 0; kx < 3; kx++) {
-                const float w = wk[ky * 3 + kx] * rm;
+                const float w = wk[ky * 3 + kx] * rowM[ky];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int i = 4 + 2 * q + (kx - 1) * DIL;
@@ -418,47 +451,88 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     for (int t = 0; t < TILES; t++)
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
-
-    issue(0);
-    stencil();
-    publish(0);
-    __syncthreads();
-    for (int c = 0; c < nChunks; c++) {
-        const int cur = c & 1;
-        issue(min(c + 1, nChunks - 1));             // the last refill is a redundant re-load (branch-free loop)
+    auto multiply = [&](int cur) {
         // B operand: this lane's pixel, hidden channels 8*kg .. 8*kg+7 of the chunk, split into f16 hi / lo
         HFrag bh, bl;
         const float* dB = &sD[cur][8 * kg * kPitch + 32 * wave + col];
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) split_pair(dB[2 * jj * kPitch], dB[(2 * jj + 1) * kPitch], bh.u[jj], bl.u[jj]);
         const uint4* wA = (const uint4*)&sW[cur][0] + lane;
-        HFrag ah[TILES], al[TILES];
 #pragma unroll
-        for (int t = 0; t < TILES; t++) { ah[t].q = wA[t * 128]; al[t].q = wA[t * 128 + 64]; }
+        for (int t = 0; t < TILES; t += 2) {        // two tiles at a time: consecutive MFMAs hit different accumulators
+            HFrag ah[2], al[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (t + u < TILES) { ah[u].q = wA[(t + u) * 128]; al[u].q = wA[(t + u) * 128 + 64]; }
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (t + u < TILES) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[u].v, bh.v, acc[t + u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (t + u < TILES) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u].v, bl.v, acc[t + u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (t + u < TILES) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u].v, bh.v, acc[t + u], 0, 0, 0);
+        }
+    };
+
+    DwSet SA, SB;
+    issue(SA, 0);
+    issue_w(0);
+    issue(SB, 1);
+    stencil(SA);
+    publish(0);
+    issue_w(1);                                     // weights before the window: in-order return lets the next
+    issue(SA, 2);                                   // stencil wait for them with the window loads still in flight
+    __syncthreads();
+    for (int c = 0; c < nChunks; c += 2) {
+        // buffer 0 holds chunk c; set B = window of chunk c+1, set A = window of chunk c+2 (both in flight)
+        multiply(0);
+        stencil(SB);
+        publish(1);
+        __builtin_amdgcn_sched_barrier(0);          // pin the issue order: A fragments, then the far-ahead window
+        issue_w(c + 2);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < TILES; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t].v, bh.v, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < TILES; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t].v, bl.v, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < TILES; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t].v, bh.v, acc[t], 0, 0, 0);
-        stencil();
+        issue(SB, c + 3);
         __builtin_amdgcn_sched_barrier(0);
-        publish(cur ^ 1);
+        __syncthreads();
+        multiply(1);
+        stencil(SA);
+        publish(0);
+        __builtin_amdgcn_sched_barrier(0);          // pin the issue order: A fragments, then the far-ahead window
+        issue_w(c + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(SA, c + 4);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     }
+    // epilogue: per tile, BN scale/shift (float4 per row quad, arrays padded to whole tiles) and the residual are
+    // loaded as one batch before the first use
     const int pix = 128 * rp + 32 * wave + col;
 #pragma unroll
-    for (int t = 0; t < TILES; t++)
+    for (int t = 0; t < TILES; t++) {
+        const int cb = (tile0 + t) * 32 + 4 * kg;
+        float4 sc4[4], sh4[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(scale + cb + 8 * g4); sh4[g4] = *(const float4*)(shift + cb + 8 * g4); }
+        const size_t ob = ((size_t)b * Cout + cb) * HW + pix;
+        float rv[16];
+        if (res) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int ro = (q & 3) + 8 * (q >> 2);
+                if (cb + ro < Cout) rv[q] = res[ob + (size_t)ro * HW];
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            const int co = (tile0 + t) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
-            if (co >= Cout) continue;
-            float v = acc[t][q] * scale[co] + shift[co];
-            const size_t oi = ((size_t)b * Cout + co) * HW + pix;
-            if (res) v += res[oi];
-            Y[oi] = v;
+            const int ro = (q & 3) + 8 * (q >> 2);
+            if (cb + ro >= Cout) continue;
+            float v = acc[t][q] * vget<4>(sc4[q >> 2], q & 3) + vget<4>(sh4[q >> 2], q & 3);
+            if (res) v += rv[q];
+            Y[ob + (size_t)ro * HW] = v;
         }
+    }
 }
 
 // ---- conv_last 1x1 80 -> 1 + bias (models_light.py:196) ----
@@ -517,7 +591,7 @@ struct Gemm {            // one MFMA convolution
     uint4* dWq;             // f16 hi / lo A fragments (see k_fcn_gemm)
     float *dScale, *dShift;
 };
-struct Dw { int c, stride, dil; float *dW, *dScale, *dShift; };
+struct Dw { int c, stride, dil; float *dW, *dScale, *dShift, *dPack; };   // dPack: 12 floats per channel (k_fcn_dwpw)
 
 struct Reader {
     const float* p; size_t left;
@@ -594,12 +668,13 @@ void launch_gemm(const Gemm& g, const float* X, const float* res, float* Y, int 
 bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, float* Y, int H, int W, int B, hipStream_t s)
 {
     static const bool off = getenv("IVF_FCN_NOFUSE") != nullptr;
+    static const int abl = getenv("IVF_FCN_ABL") ? atoi(getenv("IVF_FCN_ABL")) : 0;
     const int tiles = (g.cout + 31) / 32;
     if (off || d.stride != 1 || H != 64 || W != 64 || d.c % 16 || g.taps != 1 || g.nTiles != tiles || g.act != 0) return false;
     const dim3 blk(256);
 #define DWPW(T, D, GY)                                                                                              \
-    hipLaunchKernelGGL((k_fcn_dwpw<T, D>), dim3(32 * B, GY), blk, 0, s, X, d.dW, d.dScale, d.dShift, g.dWq, g.dScale, \
-                       g.dShift, res, Y, d.c, g.cout, g.nTiles)
+    hipLaunchKernelGGL((k_fcn_dwpw<T, D>), dim3(32 * B, GY), blk, 0, s, X, d.dPack, g.dWq, g.dScale, \
+                       g.dShift, res, Y, d.c, g.cout, g.nTiles, abl)
     if (tiles == 1 && d.dil == 1) DWPW(1, 1, 1);
     else if (tiles == 2 && d.dil == 1) DWPW(2, 1, 1);
     else if (tiles == 2 && d.dil == 2) DWPW(2, 2, 1);
@@ -674,8 +749,11 @@ int make_gemm(ivf_fcn* f, const float* w, int cout, int cin, int taps, const std
     float* dq = nullptr;
     int rc = upload(f, wq, &dq); if (rc) return rc;
     g.dWq = reinterpret_cast<uint4*>(dq);
-    rc = upload(f, sc, &g.dScale); if (rc) return rc;
-    return upload(f, sh, &g.dShift);
+    std::vector<float> scp((size_t)g.nTiles * 32, 0.f), shp((size_t)g.nTiles * 32, 0.f);   // padded: float4 loads per tile
+    std::copy(sc.begin(), sc.begin() + cout, scp.begin());
+    std::copy(sh.begin(), sh.begin() + cout, shp.begin());
+    rc = upload(f, scp, &g.dScale); if (rc) return rc;
+    return upload(f, shp, &g.dShift);
 }
 
 // IVF_FCN_DEBUG=1: synchronise and check after every launch, naming the stage that failed
@@ -785,7 +863,13 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
             if (!w || !read_bn(hid)) return bad();
             Dw d; d.c = hid; d.stride = bk.stride; d.dil = bk.dil;
             std::vector<float> hw(w, w + (size_t)hid * 9);
-            if ((rc = upload(f, hw, &d.dW)) || (rc = upload(f, sc, &d.dScale)) || (rc = upload(f, sh, &d.dShift))) { ivf_fcn_destroy(f); return rc; }
+            std::vector<float> pk((size_t)hid * 12, 0.f);
+            for (int c = 0; c < hid; c++) {
+                for (int q = 0; q < 9; q++) pk[(size_t)c * 12 + q] = w[(size_t)c * 9 + q];
+                pk[(size_t)c * 12 + 9] = sc[c]; pk[(size_t)c * 12 + 10] = sh[c];
+            }
+            if ((rc = upload(f, hw, &d.dW)) || (rc = upload(f, sc, &d.dScale)) || (rc = upload(f, sh, &d.dShift)) ||
+                (rc = upload(f, pk, &d.dPack))) { ivf_fcn_destroy(f); return rc; }
             f->dw.push_back(d);
         }
         {
