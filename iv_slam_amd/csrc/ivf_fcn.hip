@@ -322,6 +322,99 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
     }
 }
 
+// ---- 1x1 expansion (Cin -> 6*Cin) + BN + ReLU6 with the activation tile stationary in LDS ----
+// An expansion re-uses every activation for up to 30 output-channel tiles.  k_fcn_gemm fetches and splits the B operand
+// once per tile; here a workgroup owns 32*PXT pixels, loads X[Cin][pixels] ONCE, splits it into f16 hi/lo MFMA B
+// fragments in LDS (Cin/16 * PXT * 2 KB), and its four waves then walk the output-channel tiles (wave w: tiles w, w+4,
+// ...) with A fragments streamed from L2 and B fragments read from LDS: no redundant split VALU, no B re-reads from L2,
+// and the kernel is left with its HBM write stream.
+template <int PXT, int KS>
+__global__ __launch_bounds__(256, 2) void k_fcn_expand(const float* __restrict__ X, const uint4* __restrict__ Wq,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                   float* __restrict__ Y, int Cin, int Cout, int HW, int nTiles)
+{
+    typedef typename VecT<PXT>::T vec;
+    extern __shared__ __attribute__((aligned(16))) uint4 sB[];       // [(s*PXT + pt)*2 + part][64 lanes]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kg = lane >> 5, col = lane & 31;
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32 * PXT + PXT * col;                // this lane's PXT adjacent pixels (pixel tile pt = pixel p0+pt)
+    const float* Xb = X + (size_t)b * Cin * HW + p0;
+    // stage: wave w splits the K steps w, w+4, ...
+    for (int s = wave; s < KS; s += 4) {
+        vec xb[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) xb[j] = *(const vec*)(Xb + (size_t)min(16 * s + 8 * kg + j, Cin - 1) * HW);
+#pragma unroll
+        for (int pt = 0; pt < PXT; pt++) {
+            HFrag h, l;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) split_pair(vget<PXT>(xb[2 * jj], pt), vget<PXT>(xb[2 * jj + 1], pt), h.u[jj], l.u[jj]);
+            sB[((s * PXT + pt) * 2 + 0) * 64 + lane] = h.q;
+            sB[((s * PXT + pt) * 2 + 1) * 64 + lane] = l.q;
+        }
+    }
+    __syncthreads();
+    // A fragments stream from L2 through a ring of RD = KS/2 register slots (slot = step % RD), each refilled right
+    // after use with the step RD ahead -- across tile boundaries, clamped at the end.  The refills for the first RD
+    // steps of the next tile are therefore issued BEFORE this tile's epilogue stores: on gfx9 loads and stores share
+    // the in-order vmcnt, so a load issued behind 16 stores would wait for their write acknowledgements.  The tile
+    // body stays branch-free (counted vmcnt waits instead of drains at control-flow joins).
+    constexpr int RD = KS / 2;
+    static_assert(KS % RD == 0, "ring slots must repeat per tile");
+    const int myTiles = (nTiles - wave + 3) / 4;
+    uint4 ring[RD][2];
+    auto aload = [&](int it, int st, uint4 (&r)[2]) {
+        const uint4* w = Wq + ((size_t)st * nTiles + wave + 4 * min(it, myTiles - 1)) * 128 + lane;
+        r[0] = w[0]; r[1] = w[64];
+    };
+    if (myTiles > 0) {
+#pragma unroll
+        for (int d = 0; d < RD; d++) aload(0, d, ring[d]);
+    }
+    for (int it = 0; it < myTiles; it++) {
+        const int n = wave + 4 * it;
+        int sl = lane;                              // opaque per tile: keeps the B fragment reads inside the tile loop
+        asm volatile("" : "+v"(sl));                // (hoisted, they would pin KS*PXT*8 registers and spill)
+        f32x16 acc[PXT];
+#pragma unroll
+        for (int p = 0; p < PXT; p++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[p][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            HFrag ah, al;
+            ah.q = ring[s % RD][0]; al.q = ring[s % RD][1];
+            if (s + RD < KS) aload(it, s + RD, ring[s % RD]); else aload(it + 1, s + RD - KS, ring[s % RD]);
+            HFrag bh[PXT], bl[PXT];
+#pragma unroll
+            for (int pt = 0; pt < PXT; pt++) { bh[pt].q = sB[((s * PXT + pt) * 2 + 0) * 64 + sl]; bl[pt].q = sB[((s * PXT + pt) * 2 + 1) * 64 + sl]; }
+#pragma unroll
+            for (int pt = 0; pt < PXT; pt++) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, bh[pt].v, acc[pt], 0, 0, 0);
+#pragma unroll
+            for (int pt = 0; pt < PXT; pt++) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bl[pt].v, acc[pt], 0, 0, 0);
+#pragma unroll
+            for (int pt = 0; pt < PXT; pt++) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bh[pt].v, acc[pt], 0, 0, 0);
+        }
+        const int cb = n * 32 + 4 * kg;
+        float4 sc4[4], sh4[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(scale + cb + 8 * g4); sh4[g4] = *(const float4*)(shift + cb + 8 * g4); }
+        float* yb = Y + ((size_t)b * Cout + cb) * HW + p0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            if (cb + ro >= Cout) continue;
+            const float sc = vget<4>(sc4[r >> 2], r & 3), sh = vget<4>(sh4[r >> 2], r & 3);
+            float o[PXT];
+#pragma unroll
+            for (int p = 0; p < PXT; p++) o[p] = __builtin_amdgcn_fmed3f(acc[p][r] * sc + sh, 0.f, 6.f);
+            float* yo = yb + (size_t)ro * HW;
+            if constexpr (PXT == 4) *(float4*)yo = make_float4(o[0], o[1], o[2], o[3]);
+            else *(float2*)yo = make_float2(o[0], o[1]);
+        }
+    }
+}
+
 // ---- fused depthwise 3x3 (stride 1, dilation DIL) + BN + ReLU6  ->  1x1 projection (MFMA) + BN (+ residual) ----
 // For the 64x64 stages of the encoder the depthwise output never goes to HBM: a workgroup owns 128 pixels (two image
 // rows) and TILES*32 output channels; per 16-channel chunk of the hidden tensor (= one MFMA K step) its 256 threads
@@ -664,6 +757,31 @@ void launch_gemm(const Gemm& g, const float* X, const float* res, float* Y, int 
     else launch_gemm_t<2, 5, 1>(g, X, res, Y, H, W, B, s);
 }
 
+// expansion with the B tile stationary in LDS; false = not applicable, caller uses k_fcn_gemm
+bool launch_expand(const Gemm& g, const float* X, float* Y, int H, int W, int B, hipStream_t s)
+{
+    static const int mode = getenv("IVF_FCN_EXPAND") ? atoi(getenv("IVF_FCN_EXPAND")) : 4;     // 0 off, 2 / 4 = PXT
+    static const int minCin = getenv("IVF_FCN_EXPAND_MINCIN") ? atoi(getenv("IVF_FCN_EXPAND_MINCIN")) : 64;
+    const int tiles = (g.cout + 31) / 32, HW = H * W, K16 = (g.cin + 15) / 16;
+    if (!mode || g.taps != 1 || g.act != 1 || g.nTiles != tiles || g.cin < minCin || tiles < 4) return false;
+    int pxt = mode;
+    static const bool bigLds = [] {                             // 160 input channels x 128 pixels need 80 KB of LDS
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_expand<4, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+    }();
+    if ((size_t)K16 * pxt * 2048 > (bigLds ? 80 : 64) * 1024) pxt = 2;
+    if (HW % (32 * pxt)) return false;
+    const size_t lds = (size_t)K16 * pxt * 2048;
+#define EXPAND(P, KSV) hipLaunchKernelGGL((k_fcn_expand<P, KSV>), dim3(HW / (32 * P), 1, B), dim3(256), lds, s, X, g.dWq, \
+                                          g.dScale, g.dShift, Y, g.cin, g.cout, HW, g.nTiles)
+    if (pxt == 4 && K16 == 4) EXPAND(4, 4);
+    else if (pxt == 4 && K16 == 6) EXPAND(4, 6);
+    else if (pxt == 4 && K16 == 10) EXPAND(4, 10);
+    else if (pxt == 2 && K16 == 10) EXPAND(2, 10);
+    else return false;
+#undef EXPAND
+    return true;
+}
+
 // fused depthwise + projection for the 64x64 stride-1 stages; false = shape not covered, caller runs the two kernels
 bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, float* Y, int H, int W, int B, hipStream_t s)
 {
@@ -778,7 +896,9 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
         const Block& bk = kBlocks[i];
         const int hid = bk.inp * bk.t;
         const float* h = x;
-        if (bk.t != 1) { launch_gemm(f->pw[ip++], x, nullptr, f->bufH1, H, W, n, s); h = f->bufH1; snprintf(nm, sizeof nm, "block %d expand", i + 1); STAGE(nm); }
+        if (bk.t != 1) {
+            if (!launch_expand(f->pw[ip], x, f->bufH1, H, W, n, s)) launch_gemm(f->pw[ip], x, nullptr, f->bufH1, H, W, n, s);
+            ip++; h = f->bufH1; snprintf(nm, sizeof nm, "block %d expand", i + 1); STAGE(nm); }
         const Dw& d = f->dw[id++];
         if (launch_dwpw(d, f->pw[ip], h, bk.res ? x : nullptr, y, H, W, n, s)) {
             ip++;

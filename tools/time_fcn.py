@@ -5,7 +5,7 @@ import numpy as np, torch
 import iv_slam_amd as iv
 from iv_slam_amd import fcn_weights
 dev = torch.device("cuda:0")
-B = 32
+B = int(os.environ.get("IVF_B", "32"))
 fcn = iv.IntrospectionFCN(fcn_weights.pack_blob(fcn_weights.make_seeded_weights(7)), (375, 1242), (375, 1242), max_batch=B)
 bgr = torch.randint(0, 256, (B, 375, 1242, 3), dtype=torch.uint8, device=dev)
 out = torch.empty((B, 375, 1242), dtype=torch.uint8, device=dev)
