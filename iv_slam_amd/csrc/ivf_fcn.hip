@@ -322,6 +322,111 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
     }
 }
 
+// ---- dense 3x3, pad 1, on a 64-wide map (decoder cbr: 320 -> 80 at 64x64) + BN + ReLU ----
+// A wave owns two image rows (128 pixels) and one 32-channel output tile; a lane holds four horizontally adjacent pixels
+// of eight input channels, so the 16 lanes of a DPP row span exactly one image row.  Per (dy, K step) the lane loads its
+// eight float4 once and splits them into the four pixel-tile B fragments; the dx = -1 / +1 taps re-use the SAME
+// fragments shifted by one pixel tile, the edge tile coming from the neighbouring lane by a DPP row shift whose
+// out-of-row zero fill is the image's zero padding.  36 MFMAs per 8 loads (k_fcn_gemm<1,3,9>: 9 per 8).
+__global__ __launch_bounds__(256) void k_fcn_conv3x3(const float* __restrict__ X, const uint4* __restrict__ Wq,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    float* __restrict__ Y, int Cin, int Cout, int nTiles)
+{
+    constexpr int HW = 64 * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kg = lane >> 5, col = lane & 31;
+    // 1-D grid, renumbered so that all workgroups of an image (8 row groups x nTiles) run on one XCD and share its L2
+    const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
+    const int b = L / (8 * nTiles), n = (L / 8) % nTiles;
+    const int rp = (L % 8) * 4 + wave;                               // row pair of the image
+    const int y = 2 * rp + (col >> 4), x = 4 * (col & 15);
+    const int K16 = Cin / 16;
+    const float* Xb = X + (size_t)b * Cin * HW + (size_t)8 * kg * HW + x;
+    const uint4* wq = Wq + (size_t)n * 128 + lane;
+    f32x16 acc[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[p][r] = 0.f;
+
+    // two register sets P / Q alternate (loop unrolled by two, no copies): a set is refilled for step i+2 right after
+    // the MFMAs of step i have been issued, so every load has one whole step (36 MFMAs) to land
+    struct Set { float4 x[8]; uint4 a[3][2]; float m; };      // m: 1, or 0 when the tap row is outside the image
+    int dyN = 0, sN = 0;
+    auto load = [&](Set& S) {
+        const int yy = y + dyN - 1;
+        const bool ok = yy >= 0 && yy < 64;
+        const float* P = Xb + (size_t)16 * sN * HW + (ok ? yy : y) * 64;
+        S.m = ok ? 1.f : 0.f;                       // applied when the values are consumed: no wait on the load here
+#pragma unroll
+        for (int j = 0; j < 8; j++) S.x[j] = *(const float4*)(P + (size_t)j * HW);
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+            const uint4* w = wq + ((size_t)((dyN * 3 + dx) * K16 + sN) * nTiles) * 128;
+            S.a[dx][0] = w[0]; S.a[dx][1] = w[64];
+        }
+        if (++sN == K16) { sN = 0; if (dyN < 2) ++dyN; else sN = K16 - 1; }     // past the end: redundant re-load
+    };
+    auto dpp4 = [](const HFrag& f, int shr) {
+        HFrag o;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            o.u[i] = shr ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f.u[i], 0x111, 0xF, 0xF, true)
+                         : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f.u[i], 0x101, 0xF, 0xF, true);
+        return o;
+    };
+    auto step = [&](Set& S) {
+        HFrag bh[6], bl[6];                         // pixel tiles -1 .. 4: [0] = left neighbour's tile 3, [5] = right neighbour's tile 0
+#pragma unroll
+        for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++)
+                split_pair(vget<4>(S.x[2 * jj], pt) * S.m, vget<4>(S.x[2 * jj + 1], pt) * S.m, bh[pt + 1].u[jj], bl[pt + 1].u[jj]);
+        bh[0] = dpp4(bh[4], 1); bl[0] = dpp4(bl[4], 1);              // row_shr:1  lane c receives lane c-1
+        bh[5] = dpp4(bh[1], 0); bl[5] = dpp4(bl[1], 0);              // row_shl:1  lane c receives lane c+1
+        HFrag ah[3], al[3];
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) { ah[dx].q = S.a[dx][0]; al[dx].q = S.a[dx][1]; }
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+            for (int pt = 0; pt < 4; pt++) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[dx].v, bh[pt + dx].v, acc[pt], 0, 0, 0);
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+            for (int pt = 0; pt < 4; pt++) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[dx].v, bl[pt + dx].v, acc[pt], 0, 0, 0);
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+            for (int pt = 0; pt < 4; pt++) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[dx].v, bh[pt + dx].v, acc[pt], 0, 0, 0);
+    };
+    Set SP, SQ;
+    load(SP);
+    load(SQ);
+    for (int i = 0; i < 3 * K16; i += 2) {          // 3*K16 is even (K16 = 20)
+        step(SP);
+        __builtin_amdgcn_sched_barrier(0);
+        load(SP);
+        __builtin_amdgcn_sched_barrier(0);
+        step(SQ);
+        __builtin_amdgcn_sched_barrier(0);
+        load(SQ);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int cb = n * 32 + 4 * kg;
+    float4 sc4[4], sh4[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(scale + cb + 8 * g4); sh4[g4] = *(const float4*)(shift + cb + 8 * g4); }
+    float* yb = Y + ((size_t)b * Cout + cb) * HW + y * 64 + x;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int ro = (r & 3) + 8 * (r >> 2);
+        if (cb + ro >= Cout) continue;
+        const float sc = vget<4>(sc4[r >> 2], r & 3), sh = vget<4>(sh4[r >> 2], r & 3);
+        *(float4*)(yb + (size_t)ro * HW) = make_float4(fmaxf(acc[0][r] * sc + sh, 0.f), fmaxf(acc[1][r] * sc + sh, 0.f),
+                                                       fmaxf(acc[2][r] * sc + sh, 0.f), fmaxf(acc[3][r] * sc + sh, 0.f));
+    }
+}
+
 // ---- 1x1 expansion (Cin -> 6*Cin) + BN + ReLU6 with the activation tile stationary in LDS ----
 // An expansion re-uses every activation for up to 30 output-channel tiles.  k_fcn_gemm fetches and splits the B operand
 // once per tile; here a workgroup owns 32*PXT pixels, loads X[Cin][pixels] ONCE, splits it into f16 hi/lo MFMA B
@@ -745,7 +850,13 @@ void launch_gemm_t(const Gemm& g, const float* X, const float* res, float* Y, in
 }
 void launch_gemm(const Gemm& g, const float* X, const float* res, float* Y, int H, int W, int B, hipStream_t s)
 {
-    if (g.taps == 9) { launch_gemm_t<1, 3, 9>(g, X, res, Y, H, W, B, s); return; }
+    if (g.taps == 9) {
+        static const bool old9 = getenv("IVF_FCN_OLD3X3") != nullptr;
+        if (!old9 && H == 64 && W == 64 && g.cin % 32 == 0 && g.act == 2 && !res)
+            hipLaunchKernelGGL(k_fcn_conv3x3, dim3(8 * g.nTiles * B), dim3(256), 0, s, X, g.dWq, g.dScale, g.dShift, Y, g.cin, g.cout, g.nTiles);
+        else launch_gemm_t<1, 3, 9>(g, X, res, Y, H, W, B, s);
+        return;
+    }
     if (g.PT == 4 && g.NT == 1) launch_gemm_t<4, 1, 1>(g, X, res, Y, H, W, B, s);
     else if (g.PT == 4 && g.NT == 2) launch_gemm_t<4, 2, 1>(g, X, res, Y, H, W, B, s);
     else if (g.PT == 4 && g.NT == 3) launch_gemm_t<4, 3, 1>(g, X, res, Y, H, W, B, s);
