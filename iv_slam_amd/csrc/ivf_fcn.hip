@@ -322,6 +322,264 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
     }
 }
 
+// ---- a whole inverted-residual block for the small-Cin stages (Cin, Cout <= 32, dilation 1, stride S) ----
+//   x -> [1x1 expand + BN + ReLU6] -> 3x3 depthwise (stride S, pad 1) + BN + ReLU6 -> 1x1 project + BN (+ x)
+// At 256x256 / 128x128 the hidden tensor (6x the block's input) dominated the network's HBM traffic; here it never leaves
+// the CU.  A workgroup owns a TOH x 32 output tile.  It stages the input tile with its halo ONCE as f16 hi/lo MFMA B
+// fragments (sX); then, per 32 hidden channels: the four waves expand them over the haloed tile on the MFMA into LDS
+// (sH, f32, zero outside the image = the depthwise zero padding), all threads run the 3x3 stencil out of LDS into sD, and
+// the waves feed sD (split into f16 hi/lo on the fly) to the projection MFMAs, accumulating the block's output tile
+// in registers across the chunks.  EXP = false: expansion ratio 1 (first block), sH is the input tile itself.
+template <int S> struct BlockGeom {
+    static constexpr int TOH = S == 1 ? 4 : 2, IWq = 32 * S + (S == 1 ? 2 : 1), IH = TOH * S + (S == 1 ? 2 : 1);
+    static constexpr int INPX = IH * IWq, NPT = (INPX + 31) / 32, HP = NPT * 32 + 4, OUTPX = TOH * 32, DP = OUTPX + 4;
+};
+
+template <int S, int K16e>          // K16e: K steps of the expansion (ceil(Cin/16)); 0 = no expansion
+__global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ X, const uint4* __restrict__ W1q,
+                                                  const float* __restrict__ sc1, const float* __restrict__ sh1,
+                                                  const float* __restrict__ dwP, const uint4* __restrict__ W2q,
+                                                  const float* __restrict__ sc2, const float* __restrict__ sh2,
+                                                  const float* __restrict__ res, float* __restrict__ Y, int Cin, int hidp,
+                                                  int Cout, int H, int W, int Ho, int Wo, int nT1, int nT2)
+{
+    typedef BlockGeom<S> G;
+    constexpr int TOH = G::TOH, IWq = G::IWq, INPX = G::INPX, NPT = G::NPT, HP = G::HP, OUTPX = G::OUTPX, DP = G::DP;
+    constexpr int MYPT = (NPT + 3) / 4;             // expansion pixel tiles per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool EXP = K16e > 0;
+    uint4* sX = reinterpret_cast<uint4*>(smem);                                     // [(st*NPT + pt)*2 + part][64]
+    float* sH = reinterpret_cast<float*>(smem + (size_t)K16e * NPT * 2048);         // [32][HP]
+    float* sD = sH + 32 * HP;                                                       // [32][DP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 5, col = lane & 31;
+    const int b = blockIdx.z, ox0 = blockIdx.x * 32, oy0 = blockIdx.y * TOH;
+    const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1;
+    const size_t HWi = (size_t)H * W;
+    const float* Xb = X + (size_t)b * Cin * HWi;
+
+    // ---- phase 0: the input tile.  All loads of a thread are issued before the first one is consumed.
+    if constexpr (EXP) {
+        constexpr int NSL = (K16e * NPT * 64 + 255) / 256;
+        float v[NSL][8];
+#pragma unroll
+        for (int it = 0; it < NSL; it++) {
+            const int slot = tid + 256 * it;
+            const int sl = slot & 63, pt = (slot >> 6) % NPT, st = (slot >> 6) / NPT;
+            const int q = 32 * pt + (sl & 31), r = q / IWq, c = q - r * IWq;
+            const int gy = iy0 + r, gx = ix0 + c;
+            const bool ok = st < K16e && q < INPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const float* P = Xb + (ok ? (size_t)gy * W + gx : 0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int ch = 16 * st + 8 * (sl >> 5) + j;
+                const float t = P[(size_t)min(ch, Cin - 1) * HWi];
+                v[it][j] = (ok && ch < Cin) ? t : 0.f;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NSL; it++) {
+            const int slot = tid + 256 * it;
+            const int sl = slot & 63, pt = (slot >> 6) % NPT, st = (slot >> 6) / NPT;
+            if (st < K16e) {
+                HFrag h, l;
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) split_pair(v[it][2 * jj], v[it][2 * jj + 1], h.u[jj], l.u[jj]);
+                sX[((st * NPT + pt) * 2 + 0) * 64 + sl] = h.q;
+                sX[((st * NPT + pt) * 2 + 1) * 64 + sl] = l.q;
+            }
+        }
+    } else {
+        constexpr int NIT = (32 * INPX + 255) / 256;
+        float t[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = min(tid + 256 * it, 32 * INPX - 1);
+            const int ch = i / INPX, q = i - ch * INPX, r = q / IWq, c = q - r * IWq;
+            const int gy = iy0 + r, gx = ix0 + c;
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W && ch < Cin;
+            const float x = Xb[(ok ? (size_t)ch * HWi + (size_t)gy * W + gx : 0)];
+            t[it] = ok ? x : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = tid + 256 * it;
+            if (i < 32 * INPX) { const int ch = i / INPX, q = i - ch * INPX; sH[ch * HP + q] = t[it]; }
+        }
+    }
+    // in-image mask of this lane's pixel in each of its expansion tiles (the depthwise pads the HIDDEN map with zeros)
+    float pm[MYPT];
+#pragma unroll
+    for (int i = 0; i < MYPT; i++) {
+        const int q = 32 * (wave + 4 * i) + col, r = q / IWq, c = q - r * IWq;
+        const int gy = iy0 + r, gx = ix0 + c;
+        pm[i] = (q < INPX && gy >= 0 && gy < H && gx >= 0 && gx < W) ? 1.f : 0.f;
+    }
+    // stencil role: one hidden channel of the chunk, a run of output pixels
+    const int chl = tid >> 3, seg = tid & 7;
+    const int sr = S == 1 ? seg >> 1 : seg >> 2;                     // output row of the tile
+    const int sc0 = S == 1 ? 16 * (seg & 1) : 8 * (seg & 3);         // first output column
+    constexpr int NOUT = S == 1 ? 16 : 8, NIN = S == 1 ? 18 : 17;
+    f32x16 accO;
+#pragma unroll
+    for (int q = 0; q < 16; q++) accO[q] = 0.f;
+    __syncthreads();
+
+    // per-chunk constants (expansion / projection A fragments, this thread's depthwise parameters) are fetched one
+    // chunk ahead into registers; a chunk is only a few thousand cycles long, a fetch at its point of use would
+    // expose the L2 latency three times per chunk
+    struct Pre { uint4 w1[EXP ? K16e : 1][2], w2[2][2]; float4 p[3]; };
+    const int nChunks = hidp / 32;
+    auto fetch = [&](Pre& P, int ck) {
+        ck = min(ck, nChunks - 1);
+#pragma unroll
+        for (int st = 0; st < K16e; st++) {
+            P.w1[st][0] = W1q[(((size_t)st * nT1 + ck) * 2 + 0) * 64 + lane];
+            P.w1[st][1] = W1q[(((size_t)st * nT1 + ck) * 2 + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int st = 0; st < 2; st++) {
+            P.w2[st][0] = W2q[(((size_t)(2 * ck + st) * nT2) * 2 + 0) * 64 + lane];
+            P.w2[st][1] = W2q[(((size_t)(2 * ck + st) * nT2) * 2 + 1) * 64 + lane];
+        }
+        const float4* pp = reinterpret_cast<const float4*>(dwP + (size_t)(ck * 32 + chl) * 12);
+        P.p[0] = pp[0]; P.p[1] = pp[1]; P.p[2] = pp[2];
+    };
+    auto chunk = [&](const Pre& C, Pre& N, int ck) {
+        fetch(N, ck + 1);
+        const float4 p0 = C.p[0], p1 = C.p[1], p2 = C.p[2];
+        if constexpr (EXP) {
+            // ---- phase 1: hidden[32 ch][haloed tile] = relu6(bn(W1 x)), zero outside the image
+            f32x16 acc[MYPT];
+#pragma unroll
+            for (int i = 0; i < MYPT; i++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc[i][q] = 0.f;
+#pragma unroll
+            for (int st = 0; st < K16e; st++) {
+                HFrag ah, al;
+                ah.q = C.w1[st][0]; al.q = C.w1[st][1];
+#pragma unroll
+                for (int i = 0; i < MYPT; i++) {
+                    const int pt = wave + 4 * i;
+                    if (pt < NPT) {
+                        HFrag bh, bl;
+                        bh.q = sX[((st * NPT + pt) * 2 + 0) * 64 + lane];
+                        bl.q = sX[((st * NPT + pt) * 2 + 1) * 64 + lane];
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, bh.v, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bl.v, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bh.v, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+            float4 s4[4], h4[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                s4[g4] = *(const float4*)(sc1 + ck * 32 + 4 * kg + 8 * g4);
+                h4[g4] = *(const float4*)(sh1 + ck * 32 + 4 * kg + 8 * g4);
+            }
+#pragma unroll
+            for (int i = 0; i < MYPT; i++) {
+                const int pt = wave + 4 * i;
+                if (pt < NPT) {
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2) {
+                        const int ro = (q & 3) + 8 * (q >> 2) + 4 * kg;
+                        const v2f sc = (q & 2) ? (v2f){s4[q >> 2].z, s4[q >> 2].w} : (v2f){s4[q >> 2].x, s4[q >> 2].y};
+                        const v2f sh = (q & 2) ? (v2f){h4[q >> 2].z, h4[q >> 2].w} : (v2f){h4[q >> 2].x, h4[q >> 2].y};
+                        v2f v = __builtin_elementwise_fma((v2f){acc[i][q], acc[i][q + 1]}, sc, sh);
+                        v.x = __builtin_amdgcn_fmed3f(v.x, 0.f, 6.f); v.y = __builtin_amdgcn_fmed3f(v.y, 0.f, 6.f);
+                        v = v * (v2f){pm[i], pm[i]};
+                        sH[ro * HP + 32 * pt + col] = v.x;
+                        sH[(ro + 1) * HP + 32 * pt + col] = v.y;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- phase 2: 3x3 depthwise + BN + ReLU6 out of LDS
+        {
+            const float wk[9] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x};
+            v2f o[NOUT / 2];
+#pragma unroll
+            for (int i = 0; i < NOUT / 2; i++) o[i] = (v2f){0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++) {
+                // the row start is 8-byte aligned for S = 1 (34-float rows, even columns): 64-bit LDS reads
+                const float* row = sH + chl * HP + (sr * S + ky) * IWq + sc0 * S;
+                float in[NIN + 1];
+                if (S == 1) {
+#pragma unroll
+                    for (int i = 0; i < NIN; i += 2) { const float2 t = *(const float2*)(row + i); in[i] = t.x; in[i + 1] = t.y; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NIN; i++) in[i] = row[i];
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    const v2f w = (v2f){wk[ky * 3 + kx], wk[ky * 3 + kx]};
+#pragma unroll
+                    for (int i = 0; i < NOUT; i += 2)
+                        o[i / 2] = __builtin_elementwise_fma((v2f){in[i * S + kx], in[(i + 1) * S + kx]}, w, o[i / 2]);
+                }
+            }
+            float* dst = sD + chl * DP + sr * 32 + sc0;
+            const v2f bs = (v2f){p2.y, p2.y}, bb = (v2f){p2.z, p2.z};
+#pragma unroll
+            for (int i = 0; i < NOUT; i += 4) {
+                const v2f a = __builtin_elementwise_fma(o[i / 2], bs, bb), c2 = __builtin_elementwise_fma(o[i / 2 + 1], bs, bb);
+                *(float4*)(dst + i) = make_float4(__builtin_amdgcn_fmed3f(a.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(a.y, 0.f, 6.f),
+                                                  __builtin_amdgcn_fmed3f(c2.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(c2.y, 0.f, 6.f));
+            }
+        }
+        __syncthreads();
+        // ---- phase 3: project the chunk's 32 hidden channels; wave w owns output row w of the tile
+        if (wave < TOH) {
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                const float* dB = sD + (16 * st + 8 * kg) * DP + 32 * wave + col;
+                HFrag bh, bl, ah, al;
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) split_pair(dB[2 * jj * DP], dB[(2 * jj + 1) * DP], bh.u[jj], bl.u[jj]);
+                ah.q = C.w2[st][0];
+                al.q = C.w2[st][1];
+                accO = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, bh.v, accO, 0, 0, 0);
+                accO = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bl.v, accO, 0, 0, 0);
+                accO = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bh.v, accO, 0, 0, 0);
+            }
+        }
+    };
+    Pre PA, PB;                                     // two constant sets alternate: no register copies per chunk
+    fetch(PA, 0);
+    for (int ck = 0; ck < nChunks; ck += 2) {
+        chunk(PA, PB, ck);
+        if (ck + 1 < nChunks) chunk(PB, PA, ck + 1);
+    }
+    // ---- epilogue: BN (+ residual), rows = output channels, column = this lane's pixel of output row `wave`
+    if (wave < TOH) {
+        const size_t HWo = (size_t)Ho * Wo;
+        const size_t ob = (size_t)b * Cout * HWo + (size_t)(oy0 + wave) * Wo + ox0 + col;
+        float4 s4[4], h4[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) { s4[g4] = *(const float4*)(sc2 + 4 * kg + 8 * g4); h4[g4] = *(const float4*)(sh2 + 4 * kg + 8 * g4); }
+        float rv[16];
+        if (res) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int co = (q & 3) + 8 * (q >> 2) + 4 * kg;
+                if (co < Cout) rv[q] = res[ob + (size_t)co * HWo];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int co = (q & 3) + 8 * (q >> 2) + 4 * kg;
+            if (co >= Cout) continue;
+            float v = accO[q] * vget<4>(s4[q >> 2], q & 3) + vget<4>(h4[q >> 2], q & 3);
+            if (res) v += rv[q];
+            Y[ob + (size_t)co * HWo] = v;
+        }
+    }
+}
+
 // ---- dense 3x3, pad 1, on a 64-wide map (decoder cbr: 320 -> 80 at 64x64) + BN + ReLU ----
 // A wave owns two image rows (128 pixels) and one 32-channel output tile; a lane holds four horizontally adjacent pixels
 // of eight input channels, so the 16 lanes of a DPP row span exactly one image row.  Per (dy, K step) the lane loads its
@@ -868,6 +1126,50 @@ void launch_gemm(const Gemm& g, const float* X, const float* res, float* Y, int 
     else launch_gemm_t<2, 5, 1>(g, X, res, Y, H, W, B, s);
 }
 
+// whole-block kernel for the small-Cin stages; false = shape not covered, caller runs the layer-by-layer path
+bool launch_block(int index, const Gemm* ex, const Dw& d, const Gemm& pj, const float* X, const float* res, float* Y, int H, int W,
+                  int B, hipStream_t s)
+{
+    static const bool off = getenv("IVF_FCN_NOBLOCK") != nullptr;
+    static const unsigned mask = getenv("IVF_FCN_BLOCKMASK") ? (unsigned)strtoul(getenv("IVF_FCN_BLOCKMASK"), nullptr, 0) : 0x5u;   // measured: fusion pays for blocks 1 and 3 only
+    if (!(mask >> index & 1)) return false;
+    const int cin = ex ? ex->cin : d.c, hid = d.c, hidp = (hid + 31) / 32 * 32;
+    const int Ho = (H - 1) / d.stride + 1, Wo = (W - 1) / d.stride + 1;
+    if (off || d.dil != 1 || cin > 32 || pj.cout > 32 || pj.taps != 1 || pj.nTiles != 1 || pj.act != 0 || (d.stride != 1 && d.stride != 2) ||
+        Wo % 32 || Ho % (d.stride == 1 ? 4 : 2) || (H % d.stride) || (W % d.stride))
+        return false;
+    if (ex && (ex->taps != 1 || ex->act != 1 || ex->nTiles * 32 != hidp)) return false;
+    if (!ex && hid != 32) return false;
+    const int K16e = ex ? (cin + 15) / 16 : 0;
+    static const bool attr = [] {
+        bool ok = true;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_block<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_block<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_block<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_block<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) == hipSuccess;
+        return ok;
+    }();
+    if (!attr) return false;
+    const uint4* w1 = ex ? ex->dWq : nullptr; const float* s1 = ex ? ex->dScale : nullptr; const float* h1 = ex ? ex->dShift : nullptr;
+    const int nT1 = ex ? ex->nTiles : 1;
+#define BLOCK(SV, EV)                                                                                                   \
+    do { typedef BlockGeom<SV> G;                                                                                       \
+         static const size_t pad = getenv("IVF_FCN_LDSPAD") ? (size_t)atoi(getenv("IVF_FCN_LDSPAD")) : 0;                \
+         size_t lds = (size_t)K16e * G::NPT * 2048 + (size_t)32 * G::HP * 4 + (size_t)32 * G::DP * 4 + pad;             \
+         /* two co-resident workgroups of the stride-2 variant corrupt each other's results on gfx950 (observed with   \
+            76.8 KB each, not with padding past 80 KB; cause not found): request enough LDS to keep one per CU */      \
+         if (SV == 2 && lds < 84 * 1024) lds = 84 * 1024;                                                               \
+         hipLaunchKernelGGL((k_fcn_block<SV, EV>), dim3(Wo / 32, Ho / G::TOH, B), dim3(256), lds, s, X, w1, s1, h1, d.dPack, \
+                            pj.dWq, pj.dScale, pj.dShift, res, Y, cin, hidp, pj.cout, H, W, Ho, Wo, nT1, pj.nTiles); } while (0)
+    if (!ex && d.stride == 1) BLOCK(1, 0);
+    else if (ex && d.stride == 1 && K16e == 2) BLOCK(1, 2);
+    else if (ex && d.stride == 2 && K16e == 1) BLOCK(2, 1);
+    else if (ex && d.stride == 2 && K16e == 2) BLOCK(2, 2);
+    else return false;
+#undef BLOCK
+    return true;
+}
+
 // expansion with the B tile stationary in LDS; false = not applicable, caller uses k_fcn_gemm
 bool launch_expand(const Gemm& g, const float* X, float* Y, int H, int W, int B, hipStream_t s)
 {
@@ -959,7 +1261,8 @@ int make_gemm(ivf_fcn* f, const float* w, int cout, int cin, int taps, const std
     else { g.NT = std::min(tiles, ntBig); g.PT = ptBig; }
     g.nTiles = (tiles + g.NT - 1) / g.NT * g.NT;
     const int K16 = (cin + 15) / 16;
-    std::vector<float> wq((size_t)taps * K16 * g.nTiles * 2 * 64 * 4, 0.f);     // 8 f16 = 4 dwords per lane and part
+    // one extra all-zero K step when K16 is odd: k_fcn_block consumes the projection in 32-channel chunks
+    std::vector<float> wq((size_t)taps * (K16 + (taps == 1 ? (K16 & 1) : 0)) * g.nTiles * 2 * 64 * 4, 0.f);     // 8 f16 = 4 dwords per lane and part
     uint16_t* q = reinterpret_cast<uint16_t*>(wq.data());
     for (int tap = 0; tap < taps; tap++)
         for (int s = 0; s < K16; s++)
@@ -1007,6 +1310,18 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
         const Block& bk = kBlocks[i];
         const int hid = bk.inp * bk.t;
         const float* h = x;
+        {
+            const Gemm* ex = bk.t != 1 ? &f->pw[ip] : nullptr;
+            const Gemm& pj = f->pw[ip + (bk.t != 1 ? 1 : 0)];
+            if (launch_block(i, ex, f->dw[id], pj, x, bk.res ? x : nullptr, y, H, W, n, s)) {
+                ip += bk.t != 1 ? 2 : 1;
+                H = (H - 1) / f->dw[id].stride + 1; W = (W - 1) / f->dw[id].stride + 1;
+                id++;
+                snprintf(nm, sizeof nm, "block %d fused", i + 1); STAGE(nm);
+                std::swap(x, y);
+                continue;
+            }
+        }
         if (bk.t != 1) {
             if (!launch_expand(f->pw[ip], x, f->bufH1, H, W, n, s)) launch_gemm(f->pw[ip], x, nullptr, f->bufH1, H, W, n, s);
             ip++; h = f->bufH1; snprintf(nm, sizeof nm, "block %d expand", i + 1); STAGE(nm); }
@@ -1094,7 +1409,7 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
             if (!w || !read_bn(hid)) return bad();
             Dw d; d.c = hid; d.stride = bk.stride; d.dil = bk.dil;
             std::vector<float> hw(w, w + (size_t)hid * 9);
-            std::vector<float> pk((size_t)hid * 12, 0.f);
+            std::vector<float> pk((size_t)((hid + 31) / 32 * 32) * 12, 0.f);    // padded to whole 32-channel chunks (k_fcn_block)
             for (int c = 0; c < hid; c++) {
                 for (int q = 0; q < 9; q++) pk[(size_t)c * 12 + q] = w[(size_t)c * 9 + q];
                 pk[(size_t)c * 12 + 9] = sc[c]; pk[(size_t)c * 12 + 10] = sh[c];
