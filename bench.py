@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
-"""bench.py -- stereo pairs/s of the hot path (ORB extract L+R + L/R stereo match) on MI355X.
+"""bench.py -- stereo pairs/s of the hot path (introspection FCN + ORB extract L+R + L/R stereo match) on MI355X.
 
 Contract: python bench.py --gpus N --steps K --warmup W  (N>1 is launched by torch.distributed.run,
 one rank per GPU).  One step = one pass of the hot path over one batch of `--pairs` synthetic
 1242x375 stereo pairs that are already resident in HBM; value = pairs all ranks processed / time
-(max over ranks).  Workload = BASELINE.json configs[1] (introspection OFF; --introspect adds cost
-maps -> configs[2]'s extractor side).  Prints ONE JSON line on rank 0, carrying `roofline` for the
-dominant kernel (k_fast_nms, HIP events on its stream inside the timed region) and `cpu_baseline`
-(the oracle = scalar port of the reference CPU path, timed on this box's host cores).
+(max over ranks).  Workload = BASELINE.json configs[2], the configuration the metric "extract+match+introspect" names:
+the introspection FCN runs on every left image inside the timed step and its cost map gates the left extractor.
+--no-introspect measures configs[1] (extract + match only); the default run also reports that figure in
+`extract_match_only`, measured after the timed region.  Prints ONE JSON line on rank 0, carrying `roofline` for the
+dominant kernel (HIP events on its stream inside the timed region: the FCN's 960->160 fused depthwise+projection
+launch with introspection, k_fast_nms without) and `cpu_baseline` (the oracles = ports of the reference CPU path,
+timed on this box's host cores).
 """
 import argparse
 import json
@@ -69,6 +72,27 @@ def cpu_baseline(pairs_sample, cores):
     return done / dt, dt
 
 
+def cpu_fcn_baseline(n_images=2):
+    """numpy oracle of the introspection FCN (oracle/fcn_oracle.py, f32; BLAS uses its default threads)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import fcn_oracle               # checker / baseline only -- never on the product path
+    from iv_slam_amd import fcn_weights, synth
+    Wt = fcn_weights.make_seeded_weights(7)
+    img = np.stack([synth.make_left(W, H, seed=901, idx=c) for c in range(3)], axis=-1)
+    fcn_oracle.forward(Wt, img, (H, W))
+    t0 = time.perf_counter()
+    for _ in range(n_images):
+        fcn_oracle.forward(Wt, img, (H, W))
+    dt = time.perf_counter() - t0
+    return n_images / dt, dt
+
+
+# algorithmic HBM bytes of the probed FCN launch per image (DESIGN.md section 7): hidden tensor read once
+# (960 x 64 x 64 f32), output written and residual read (160 x 64 x 64 f32 each); weights are L2-resident
+FCN_PROBE_BYTES_PER_IMAGE = (960 + 160 + 160) * 64 * 64 * 4
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,11 +100,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU")
     ap.add_argument("--stream", type=int, default=256, help="distinct pairs resident per GPU")
-    ap.add_argument("--introspect", action="store_true", help="configs[2]: run the introspection FCN on every left image and gate keypoints with it")
+    ap.add_argument("--introspect", action="store_true", help="(default) configs[2]: run the introspection FCN on every left image and gate keypoints with it")
+    ap.add_argument("--no-introspect", action="store_true", help="configs[1]: extract + match only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="profiling aid: wait for each batch before enqueuing the next, so "
                     "rocprofv3 kernel durations are not inflated by the overlap of consecutive batches")
     args = ap.parse_args()
+    args.introspect = not args.no_introspect
 
     import torch
     import torch.distributed as dist
@@ -111,6 +137,7 @@ def main():
         from iv_slam_amd import fcn_weights
         blob = fcn_weights.pack_blob(fcn_weights.make_seeded_weights(7))
         fcn = iv.IntrospectionFCN(blob, (H, W), (H, W), max_batch=P, device_id=local_rank)
+        fcn.probe_enable()
         bgr = torch.stack([left, left // 2 + 40, 255 - left // 2], dim=-1).contiguous()      # [n,H,W,3] colour-ish
         cost = torch.empty((P, H, W), dtype=torch.uint8, device=dev)
     fe = iv.StereoFrontend(W, H, P, nfeatures=NFEAT, enableIntrospection=args.introspect, bf=BF, fx=FX,
@@ -151,13 +178,30 @@ def main():
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     fast_sum_ms, fast_n = fe.fast_ms_stats(min(args.steps, 64))
-    # The front end overlaps consecutive batches on its own streams, so inside the timed region k_fast_nms shares the
-    # GPU with other kernels and its event-measured duration is inflated.  For the kernel's own figure, 5 more steps
+    if fcn is not None:
+        probe_sum_ms, probe_n, probe_batch = fcn.probe_stats(min(args.steps, 64))
+    # The front end overlaps consecutive batches on its own streams, so inside the timed region the probed kernel shares
+    # the GPU with other kernels and its event-measured duration is inflated.  For the kernel's own figure, 5 more steps
     # are run one at a time (sync between them) AFTER the timed region and reported separately as `isolated`.
     for i in range(5):
         step(args.warmup + args.steps + i)
         fe.sync()
+        torch.cuda.synchronize(dev)
     iso_sum_ms, iso_n = fe.fast_ms_stats(5)
+    if fcn is not None:
+        iso_probe_ms, iso_probe_n, _ = fcn.probe_stats(5)
+    # configs[1] (no introspection) on the same stream of pairs, for reference next to the headline number
+    em_only = None
+    if fcn is not None and world == 1:
+        fe1 = iv.StereoFrontend(W, H, P, nfeatures=NFEAT, enableIntrospection=False, bf=BF, fx=FX, device_id=local_rank)
+        for i in range(3):
+            s0 = (i % nslices) * P; fe1.run(left[s0:s0 + P], right[s0:s0 + P], None, sptr)
+        fe1.sync(); torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(10):
+            s0 = (i % nslices) * P; fe1.run(left[s0:s0 + P], right[s0:s0 + P], None, sptr)
+        fe1.sync(); torch.cuda.synchronize(dev)
+        em_only = P * 10 / (time.perf_counter() - t1)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -170,46 +214,70 @@ def main():
     assert len(r0["kps"]) > NFEAT // 2 and (r0["uright"] >= 0).sum() > 20, "degenerate output"
 
     if rank == 0:
+        def load_pmc(kernel_key):
+            # HBM traffic from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE collected in separate runs
+            # because counters cannot be read inside this process), per image, rescaled to this launch size
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+                k = pmc["kernels"][kernel_key]
+                return (k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]) / k.get("images_per_launch", pmc["images_per_launch"]), \
+                    "profiles/r01_pmc_hbm_traffic.json"
+            except Exception:
+                return None, None
+
+        def roof(kernel, algo_bytes, sum_ms, n, iso_ms, iso_n, traffic, src):
+            ms = sum_ms / max(n, 1); ims = iso_ms / max(iso_n, 1)
+            ach = algo_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            iach = algo_bytes / (ims * 1e-3) / 1e9 if ims > 0 else 0.0
+            return {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": src,
+                    "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(ms, 5), "launches_timed": n,
+                    "isolated": {"note": "same kernel, 5 launches after the timed region with no other batch in flight",
+                                 "avg_launch_ms": round(ims, 5), "achieved": round(iach, 2), "frac": round(iach / HBM_PEAK_GBS, 5)}}
+
         imgs_per_launch = 2 * P
-        algo_bytes = (LEVEL_PX_SUM + NFEAT * 8) * imgs_per_launch      # pyramid read + candidate output
-        fast_ms = fast_sum_ms / max(fast_n, 1)
-        # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, raw x1024;
-        # collected separately because counters cannot be read inside this process), rescaled to this launch size
-        traffic, traffic_src = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-            k = pmc["kernels"]["ivf::k_fast_nms"]
-            traffic = int((k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]) * imgs_per_launch / pmc["images_per_launch"])
-            traffic_src = "profiles/r01_pmc_hbm_traffic.json"
-        except Exception:
-            pass
-        achieved = algo_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
+        fast_algo = (LEVEL_PX_SUM + NFEAT * 8) * imgs_per_launch      # pyramid read + candidate output
+        per_img, src = load_pmc("ivf::k_fast_nms")
+        fast_roof = roof("k_fast_nms", fast_algo, fast_sum_ms, fast_n, iso_sum_ms, iso_n,
+                         None if per_img is None else int(per_img * imgs_per_launch), src)
+        if fcn is not None:
+            per_img, src = load_pmc("ivffcn::k_fcn_dwpw<5, 4> 960->160")
+            roofline = roof("k_fcn_dwpw<5,4> (fused depthwise 3x3 + 1x1 projection 960->160, %d images)" % probe_batch,
+                            FCN_PROBE_BYTES_PER_IMAGE * probe_batch, probe_sum_ms, probe_n, iso_probe_ms, iso_probe_n,
+                            None if per_img is None else int(per_img * probe_batch), src)
+        else:
+            roofline = fast_roof
         out = {
             "metric": METRIC, "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("configs[2]: 1242x375 stereo stream with introspection FCN cost-map forward (f32 MFMA convs) gating keypoints"
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8 (ORB) + f32 via split-f16 MFMA (FCN)" if args.introspect else "u8",
+            "data": "synthetic",
+            "config": {"workload": ("configs[2]: 1242x375 stereo stream with introspection FCN cost-map forward (MFMA convs) gating keypoints, "
+                                    "ORB extract + L/R Hamming match"
                                     if args.introspect else
                                     "configs[1]: 1242x375 stereo pair stream, ORB extract + L/R Hamming match, introspection OFF"),
                        "pairs_per_step_per_gpu": P, "distinct_pairs_per_gpu": n_stream, "nfeatures": NFEAT,
                        "nlevels": 8, "scale_factor": 1.2, "fast_thresholds": [20, 7],
                        "parallelism": "frames sharded %d-way, RCCL all-gather of descriptor blocks" % world if world > 1 else "1 GPU"},
-            "roofline": {"kernel": "k_fast_nms", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(fast_ms, 5),
-                         "launches_timed": fast_n,
-                         "isolated": {"note": "same kernel, 5 launches after the timed region with no other batch in flight",
-                                      "avg_launch_ms": round(iso_sum_ms / max(iso_n, 1), 5),
-                                      "achieved": round(algo_bytes / (iso_sum_ms / max(iso_n, 1) * 1e-3) / 1e9, 2) if iso_sum_ms > 0 else 0.0,
-                                      "frac": round(algo_bytes / (iso_sum_ms / max(iso_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if iso_sum_ms > 0 else 0.0}},
+            "roofline": roofline,
         }
+        if fcn is not None:
+            out["roofline_fast_nms"] = fast_roof
+            if em_only is not None:
+                out["extract_match_only"] = {"value": round(em_only, 2), "unit": "pairs/s",
+                                             "note": "configs[1] (introspection OFF), 10 steps on the same resident pairs after the timed region"}
         if not args.no_cpu_baseline:
             cores = max(1, min(os.cpu_count() or 1, 32))
             sample = max(128, 8 * cores)
             v, secs = cpu_baseline(sample, cores)
-            out["cpu_baseline"] = {"value": round(v, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
-                                   "sample": "%d pairs of the same 1242x375/1000-feature workload, one pair per thread, "
-                                             "%.1f s wall (oracle/libivf_oracle.so, scalar C, -O3 -ffp-contract=off)" % (sample, secs)}
+            txt = ("%d pairs of the same 1242x375/1000-feature workload, one pair per thread, %.1f s wall "
+                   "(oracle/libivf_oracle.so, scalar C, -O3 -ffp-contract=off)" % (sample, secs))
+            if args.introspect:
+                fv, fsecs = cpu_fcn_baseline(4)
+                txt += ("; + introspection FCN: 4 forwards of the numpy oracle (oracle/fcn_oracle.py, default BLAS threads), "
+                        "%.1f s wall = %.2f images/s; extract+match alone = %.1f pairs/s; value = 1/(1/a + 1/b)" % (fsecs, fv, v))
+                v = 1.0 / (1.0 / v + 1.0 / fv)
+            out["cpu_baseline"] = {"value": round(v, 3), "unit": "pairs/s", "cores": cores, "kind": "port", "sample": txt}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -216,6 +216,12 @@ int  ivf_fcn_forward(ivf_fcn* f, const uint8_t* bgr, int width, int height, int 
 int  ivf_fcn_forward_device(ivf_fcn* f, const uint8_t* d_bgr, size_t image_stride, int row_stride, int n,
                             uint8_t* d_cost_u8, float* d_cost_f32, void* hip_stream);
 
+/* measurement aid (bench.py): HIP events bracket the network's most expensive launch (fused depthwise 3x3 + 1x1
+ * projection 960 -> 160 of block 15, k_fcn_dwpw<5,4>) on the stream each forward runs on.  probe_stats returns the summed
+ * duration of the last `last_n` probed forwards (0 = all kept, at most 64) and the batch size of the oldest of them. */
+int  ivf_fcn_probe_enable(ivf_fcn* f);
+int  ivf_fcn_probe_stats(ivf_fcn* f, int last_n, double* sum_ms, int* n_out, int* batch);
+
 #ifdef __cplusplus
 }
 #endif

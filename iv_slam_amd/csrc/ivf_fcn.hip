@@ -1230,6 +1230,12 @@ struct ivf_fcn {
     float *bufIn = nullptr, *bufA = nullptr, *bufB = nullptr, *bufH1 = nullptr, *bufH2 = nullptr, *bufLogits = nullptr;
     uint8_t *dStageIn = nullptr, *dStageU8 = nullptr; float* dStageF = nullptr;
     std::vector<void*> allocs;
+    // measurement probe: HIP events around the first 960 -> 160 fused depthwise+projection launch (block 15) of each
+    // forward, the single most expensive kernel of the network (bench.py's roofline line)
+    static constexpr int kProbe = 64;
+    hipEvent_t probe0[kProbe] = {}, probe1[kProbe] = {};
+    int probeBatch[kProbe] = {};
+    long probeCount = 0;
 };
 
 namespace {
@@ -1326,7 +1332,11 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             if (!launch_expand(f->pw[ip], x, f->bufH1, H, W, n, s)) launch_gemm(f->pw[ip], x, nullptr, f->bufH1, H, W, n, s);
             ip++; h = f->bufH1; snprintf(nm, sizeof nm, "block %d expand", i + 1); STAGE(nm); }
         const Dw& d = f->dw[id++];
+        const bool probe = i == 14 && f->probe0[0];
+        const int slot = (int)(f->probeCount % ivf_fcn::kProbe);
+        if (probe) FHIP(hipEventRecord(f->probe0[slot], s));
         if (launch_dwpw(d, f->pw[ip], h, bk.res ? x : nullptr, y, H, W, n, s)) {
+            if (probe) { FHIP(hipEventRecord(f->probe1[slot], s)); f->probeBatch[slot] = n; f->probeCount++; }
             ip++;
             snprintf(nm, sizeof nm, "block %d depthwise+project", i + 1); STAGE(nm);
             std::swap(x, y);
@@ -1454,11 +1464,46 @@ void ivf_fcn_destroy(ivf_fcn* f)
     if (!f) return;
     (void)hipSetDevice(f->device);
     (void)hipDeviceSynchronize();
+    for (int i = 0; i < ivf_fcn::kProbe; i++) {
+        if (f->probe0[i]) (void)hipEventDestroy(f->probe0[i]);
+        if (f->probe1[i]) (void)hipEventDestroy(f->probe1[i]);
+    }
     for (void* p : f->allocs) (void)hipFree(p);
     if (f->dStageIn) (void)hipFree(f->dStageIn);
     if (f->dStageU8) (void)hipFree(f->dStageU8);
     if (f->dStageF) (void)hipFree(f->dStageF);
     delete f;
+}
+
+int ivf_fcn_probe_enable(ivf_fcn* f)
+{
+    if (!f) return ffail(IVF_E_INVALID, "null argument");
+    FHIP(hipSetDevice(f->device));
+    for (int i = 0; i < ivf_fcn::kProbe; i++) {
+        if (!f->probe0[i]) FHIP(hipEventCreate(&f->probe0[i]));
+        if (!f->probe1[i]) FHIP(hipEventCreate(&f->probe1[i]));
+    }
+    f->probeCount = 0;
+    return IVF_OK;
+}
+
+int ivf_fcn_probe_stats(ivf_fcn* f, int last_n, double* sum_ms, int* n_out, int* batch)
+{
+    if (!f || !sum_ms || !n_out) return ffail(IVF_E_INVALID, "null argument");
+    FHIP(hipSetDevice(f->device));
+    const long have = std::min<long>(f->probeCount, ivf_fcn::kProbe);
+    const long take = last_n > 0 ? std::min<long>(last_n, have) : have;
+    double sum = 0; int n = 0;
+    for (long k = 0; k < take; k++) {
+        const int slot = (int)((f->probeCount - 1 - k) % ivf_fcn::kProbe);
+        FHIP(hipEventSynchronize(f->probe1[slot]));
+        float ms = 0.f;
+        FHIP(hipEventElapsedTime(&ms, f->probe0[slot], f->probe1[slot]));
+        sum += ms; n++;
+        if (batch) *batch = f->probeBatch[slot];
+    }
+    *sum_ms = sum; *n_out = n;
+    return IVF_OK;
 }
 
 int ivf_fcn_forward_device(ivf_fcn* f, const uint8_t* d_bgr, size_t image_stride, int row_stride, int n,

@@ -43,3 +43,13 @@ class IntrospectionFCN:
         check(self._lib.ivf_fcn_forward_device(self._h, bgr.data_ptr(), self.in_h * self.in_w * 3, self.in_w * 3, n,
                                                None if cost_u8 is None else cost_u8.data_ptr(),
                                                None if cost_f32 is None else cost_f32.data_ptr(), stream_ptr))
+
+    # --- measurement aid (bench.py): HIP events around the 960 -> 160 fused depthwise+projection launch
+    def probe_enable(self):
+        check(self._lib.ivf_fcn_probe_enable(self._h))
+
+    def probe_stats(self, last_n=0):
+        """(summed ms, launches, batch size) of the last `last_n` probed forwards (0 = all kept)."""
+        s = C.c_double(0); n = C.c_int(0); b = C.c_int(0)
+        check(self._lib.ivf_fcn_probe_stats(self._h, last_n, C.byref(s), C.byref(n), C.byref(b)))
+        return s.value, n.value, b.value

@@ -1,0 +1,45 @@
+"""Build profiles/*_pmc_hbm_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+
+usage: python tools/pmc_to_json.py <fetch_counter_collection.csv> <write_counter_collection.csv> <images_per_launch> <out.json> "<command>"
+
+Per kernel symbol (and, for the FCN's fused depthwise+projection kernel, per launch shape) the per-launch average of
+raw counter x 1024 bytes.  `fetch_correction` = 2.0 where the kernel's global reads are 16 B per lane: on gfx950 FETCH_SIZE
+reports half the bytes of such streams (MI355X_MICROARCH.md, HBM section); other widths are uncalibrated and left at 1.0.
+"""
+import csv, json, sys, collections
+
+WIDE = ("k_fcn_dwpw", "k_fcn_gemm", "k_fcn_expand", "k_fcn_conv3x3", "k_fcn_dw<", "k_fcn_block")
+
+
+def per_launch(path, counter):
+    acc = collections.defaultdict(float); disp = collections.defaultdict(set)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter: continue
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "k_fcn_dwpw<5, 4>" in k:
+            wgs = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
+            k += " 960->160" if wgs == 32 * (int(sys.argv[3]) // 2) else " 960->320"     # 32 row pairs per image (x2 channel halves)
+        acc[k] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
+    return {k: (v * 1024 / len(disp[k]), len(disp[k])) for k, v in acc.items()}
+
+
+def main():
+    fetch = per_launch(sys.argv[1], "FETCH_SIZE"); write = per_launch(sys.argv[2], "WRITE_SIZE")
+    n_img = int(sys.argv[3])
+    out = {"command": sys.argv[5], "images_per_launch": n_img,
+           "note": "raw counter x 1024 bytes per launch; fetch_correction = 2.0 for kernels whose reads are 16 B/lane streams "
+                   "(gfx950 FETCH_SIZE reports half of those, MI355X_MICROARCH.md HBM section), 1.0 = uncalibrated width",
+           "kernels": {}}
+    for k in sorted(set(fetch) | set(write)):
+        f, nf = fetch.get(k, (0.0, 0)); w, nw = write.get(k, (0.0, 0))
+        corr = 2.0 if any(t in k for t in WIDE) else 1.0
+        e = {"fetch_bytes_per_launch": int(f * corr), "fetch_raw_bytes_per_launch": int(f), "fetch_correction": corr,
+             "write_bytes_per_launch": int(w), "launches": max(nf, nw)}
+        if "k_fcn" in k: e["images_per_launch"] = n_img // 2          # the FCN sees the left images only
+        out["kernels"][k] = e
+    json.dump(out, open(sys.argv[4], "w"), indent=1)
+    print("wrote", sys.argv[4], len(out["kernels"]), "kernels")
+
+
+if __name__ == "__main__":
+    main()
