@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ 
                                                   const float* __restrict__ dwP, const uint4* __restrict__ W2q,
                                                   const float* __restrict__ sc2, const float* __restrict__ sh2,
                                                   const float* __restrict__ res, float* __restrict__ Y, int Cin, int hidp,
-                                                  int Cout, int H, int W, int Ho, int Wo, int nT1, int nT2)
+                                                  int Cout, int H, int W, int Ho, int Wo, int nT1, int nT2, int xbar)
 {
     typedef BlockGeom<S> G;
     constexpr int TOH = G::TOH, IWq = G::IWq, INPX = G::INPX, NPT = G::NPT, HP = G::HP, OUTPX = G::OUTPX, DP = G::DP;
@@ -547,6 +547,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ 
                 accO = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bh.v, accO, 0, 0, 0);
             }
         }
+        if (xbar) __syncthreads();
     };
     Pre PA, PB;                                     // two constant sets alternate: no register copies per chunk
     fetch(PA, 0);
@@ -846,7 +847,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     };
     auto shr1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true)); };
     auto shl1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xF, 0xF, true)); };
-    v2f o[4];
+    float o[8];
     auto stencil = [&](const DwSet& S) {
         float wk[9];
         const int pi = __builtin_bit_cast(int, S.par);
@@ -856,48 +857,34 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
         const float dsc = ROW_SHARE(9), dsh = ROW_SHARE(10);
 #undef ROW_SHARE
 #pragma unroll
-        for (int q = 0; q < 4; q++) o[q] = (v2f){0.f, 0.f};
+        for (int p = 0; p < 8; p++) o[p] = 0.f;
 #pragma unroll
         for (int ky = 0; ky < 3; ky++) {
-            // window x0-4 .. x0+11: [left halo | own a | own b | right halo]; halos arrive from lane-1 / lane+1 and are
-            // zeroed at the image border (mL / mR); rows outside the image are zeroed through the tap weights
+            // plain FMAs, one per tap and pixel.  A tap that falls outside the thread's own 8 pixels reads the neighbour
+            // lane's register through a DPP row shift folded into the FMA itself (v_fmac_f32_dpp, written as inline asm:
+            // the compiler's DPP combiner leaves MAC-type instructions alone), so the halo costs no instruction.  Zero padding: rows through the tap weights (rowM),
+            // the image's left / right border through the halo taps' weights (mL / mR; the DPP's own zero fill covers
+            // the ends of the 16-lane row).
             const float4 a = S.own[ky][0], c4 = S.own[ky][1];
-            float w16[16];
-            w16[4] = a.x; w16[5] = a.y; w16[6] = a.z; w16[7] = a.w;
-            w16[8] = c4.x; w16[9] = c4.y; w16[10] = c4.z; w16[11] = c4.w;
-            if (DIL >= 4) { w16[0] = shr1(c4.x); w16[1] = shr1(c4.y); w16[14] = shl1(a.z); w16[15] = shl1(a.w); }
-            if (DIL >= 2) { w16[2] = shr1(c4.z); w16[13] = shl1(a.y); }
-            w16[3] = shr1(c4.w); w16[12] = shl1(a.x);
-            const v2f vL = (v2f){mL, mL}, vR = (v2f){mR, mR};
-            if (DIL >= 4) {
-                const v2f t0 = (v2f){w16[0], w16[1]} * vL, t1 = (v2f){w16[14], w16[15]} * vR;
-                w16[0] = t0.x; w16[1] = t0.y; w16[14] = t1.x; w16[15] = t1.y;
-            }
-            if (DIL >= 2) {
-                const v2f t0 = (v2f){w16[2], w16[3]} * vL, t1 = (v2f){w16[12], w16[13]} * vR;
-                w16[2] = t0.x; w16[3] = t0.y; w16[12] = t1.x; w16[13] = t1.y;
-            } else { w16[3] *= mL; w16[12] *= mR; }
+            const float own[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+            const float w0 = wk[ky * 3] * rowM[ky], w1 = wk[ky * 3 + 1] * rowM[ky], w2 = wk[ky * 3 + 2] * rowM[ky];
+            const float w0L = w0 * mL, w2R = w2 * mR;
 #pragma unroll
-            for (int kx = 0; kx < 3; kx++) {
-                const float w = wk[ky * 3 + kx] * rowM[ky];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int i = 4 + 2 * q + (kx - 1) * DIL;
-                    o[q] = __builtin_elementwise_fma((v2f){w16[i], w16[i + 1]}, (v2f){w, w}, o[q]);
-                }
+            for (int p = 0; p < 8; p++) {
+                o[p] = __builtin_fmaf(own[p], w1, o[p]);
+                if (p - DIL >= 0) o[p] = __builtin_fmaf(own[p - DIL], w0, o[p]);
+                else asm("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(o[p]) : "v"(own[8 + p - DIL]), "v"(w0L));
+                if (p + DIL < 8) o[p] = __builtin_fmaf(own[p + DIL], w2, o[p]);
+                else asm("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(o[p]) : "v"(own[p + DIL - 8]), "v"(w2R));
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            o[q] = __builtin_elementwise_fma(o[q], (v2f){dsc, dsc}, (v2f){dsh, dsh});
-            o[q].x = __builtin_amdgcn_fmed3f(o[q].x, 0.f, 6.f);
-            o[q].y = __builtin_amdgcn_fmed3f(o[q].y, 0.f, 6.f);
-        }
+        for (int p = 0; p < 8; p++) o[p] = __builtin_amdgcn_fmed3f(__builtin_fmaf(o[p], dsc, dsh), 0.f, 6.f);
     };
     auto publish = [&](int buf) {
         float* dst = &sD[buf][kc * kPitch + r * 64 + x0];
-        *(float4*)dst = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
-        *(float4*)(dst + 4) = make_float4(o[2].x, o[2].y, o[3].x, o[3].y);
+        *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+        *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
 #pragma unroll
         for (int j = 0; j < TILES; j++) *(float2*)&sW[buf][(tid + 256 * j) * 2] = wreg[j];
     };
@@ -1133,6 +1120,7 @@ bool launch_block(int index, const Gemm* ex, const Dw& d, const Gemm& pj, const 
     static const bool off = getenv("IVF_FCN_NOBLOCK") != nullptr;
     static const unsigned mask = getenv("IVF_FCN_BLOCKMASK") ? (unsigned)strtoul(getenv("IVF_FCN_BLOCKMASK"), nullptr, 0) : 0x5u;   // measured: fusion pays for blocks 1 and 3 only
     if (!(mask >> index & 1)) return false;
+    static const int xbar = getenv("IVF_FCN_BLOCK_XBAR") ? atoi(getenv("IVF_FCN_BLOCK_XBAR")) : 0;
     const int cin = ex ? ex->cin : d.c, hid = d.c, hidp = (hid + 31) / 32 * 32;
     const int Ho = (H - 1) / d.stride + 1, Wo = (W - 1) / d.stride + 1;
     if (off || d.dil != 1 || cin > 32 || pj.cout > 32 || pj.taps != 1 || pj.nTiles != 1 || pj.act != 0 || (d.stride != 1 && d.stride != 2) ||
@@ -1158,9 +1146,10 @@ bool launch_block(int index, const Gemm* ex, const Dw& d, const Gemm& pj, const 
          size_t lds = (size_t)K16e * G::NPT * 2048 + (size_t)32 * G::HP * 4 + (size_t)32 * G::DP * 4 + pad;             \
          /* two co-resident workgroups of the stride-2 variant corrupt each other's results on gfx950 (observed with   \
             76.8 KB each, not with padding past 80 KB; cause not found): request enough LDS to keep one per CU */      \
-         if (SV == 2 && lds < 84 * 1024) lds = 84 * 1024;                                                               \
+         static const bool co2 = getenv("IVF_FCN_BLOCK_CO2") != nullptr;                                                \
+         if (SV == 2 && lds < 84 * 1024 && !co2) lds = 84 * 1024;                                                       \
          hipLaunchKernelGGL((k_fcn_block<SV, EV>), dim3(Wo / 32, Ho / G::TOH, B), dim3(256), lds, s, X, w1, s1, h1, d.dPack, \
-                            pj.dWq, pj.dScale, pj.dShift, res, Y, cin, hidp, pj.cout, H, W, Ho, Wo, nT1, pj.nTiles); } while (0)
+                            pj.dWq, pj.dScale, pj.dShift, res, Y, cin, hidp, pj.cout, H, W, Ho, Wo, nT1, pj.nTiles, xbar); } while (0)
     if (!ex && d.stride == 1) BLOCK(1, 0);
     else if (ex && d.stride == 1 && K16e == 2) BLOCK(1, 2);
     else if (ex && d.stride == 2 && K16e == 1) BLOCK(2, 1);
