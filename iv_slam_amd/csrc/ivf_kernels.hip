@@ -690,6 +690,40 @@ DEVINL void sel_nth_element_wave(PTR v, int n, int nth, IDX A, IDX B, int lane)
 // ------------------------------------------------------------------------------------------------
 struct CellInfo { int nTotal, nRetain, prefix, useMin; };
 
+// cv::sum over every cell WINDOW of the cost pyramid (:977), one wave per cell; the sums are parked in cellInfo[].x
+// until k_quota consumes them (introspection only).
+__global__ __launch_bounds__(256) void k_cell_qsum(const Config* __restrict__ cfg, const uint8_t* __restrict__ qpyr,
+                                                  const uint8_t* __restrict__ useCost, CellInfo* __restrict__ cellInfo)
+{
+    const int img = blockIdx.y, lane = threadIdx.x & 63;
+    const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= cfg->nCellsTotal || !(cfg->introspection && useCost[img])) return;
+    int level = 0;
+    for (int l = 1; l < cfg->nlevels; l++)
+        if (cfg->lv[l].valid && cell >= cfg->lv[l].cellBase) level = l;
+    const LevelGeom& G = cfg->lv[level];
+    const int c = cell - G.cellBase, cols = G.cols, rows = G.rows;
+    if (!G.valid || c >= G.nCells) return;
+    const uint8_t* Q = qpyr + (size_t)img * cfg->pyrBytes + G.off;
+    const int i = c / cols, j = c % cols;
+    const int x0 = kEdge + j * G.cellW, y0 = kEdge + i * G.cellH;
+    const int wx0 = x0 - 3, wx1 = (j == cols - 1) ? G.maxBX + 3 : x0 + G.cellW + 3;
+    const int wy0 = y0 - 3, wy1 = wy0 + ((i == rows - 1) ? G.winHLast : G.cellH + 6);
+    // aligned dwords covering [wx0, wx1); bytes outside the window are masked; v_sad_u8 sums 4 bytes per op
+    const int a0 = wx0 & ~3, nq = (wx1 - a0 + 3) / 4, nrow = wy1 - wy0;
+    unsigned acc = 0;
+    for (int t = lane; t < nq * nrow; t += 64) {
+        const int y = wy0 + t / nq, q = t % nq;
+        unsigned v = *(const unsigned*)(Q + (size_t)y * G.pitch + a0 + 4 * q);
+        const int bx = a0 + 4 * q;
+        if (bx < wx0) v &= 0xffffffffu << (8 * (wx0 - bx));
+        if (bx + 4 > wx1) v &= 0xffffffffu >> (8 * (bx + 4 - wx1));
+        acc = __builtin_amdgcn_sad_u8(v, 0u, acc);
+    }
+    const unsigned qs = (unsigned)wave_sum_i32((int)acc);
+    if (lane == 0) cellInfo[(size_t)img * cfg->nCellsTotal + cell].nTotal = (int)qs;
+}
+
 __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, const int* __restrict__ cellCnt,
                                               const uint8_t* __restrict__ qpyr, const uint8_t* __restrict__ useCost,
                                               CellInfo* __restrict__ cellInfo, int* __restrict__ lvlTotal)
@@ -699,36 +733,15 @@ __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, c
     __shared__ unsigned char s_useMin[kMaxCells];
     const int img = blockIdx.y, level = blockIdx.x;
     const LevelGeom& G = cfg->lv[level];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = 4;
+    const int tid = threadIdx.x;
     if (!G.valid) { if (tid == 0) lvlTotal[img * kMaxLevels + level] = 0; return; }
     const int mode = (cfg->introspection && useCost[img]) ? 1 : 0;
     const int nCells = G.nCells, cols = G.cols, rows = G.rows;
-    const uint8_t* Q = mode ? qpyr + (size_t)img * cfg->pyrBytes + G.off : nullptr;
-    const int pitch = G.pitch;
     const int* cnt = cellCnt + ((size_t)img * cfg->nCellsTotal + G.cellBase) * 2;
-    for (int c = wave; c < nCells; c += nw) {
-        unsigned qs = 0;
-        if (mode) {                                   // cv::sum over the cell WINDOW of the cost pyramid (:977)
-            const int i = c / cols, j = c % cols;
-            const int x0 = kEdge + j * G.cellW, y0 = kEdge + i * G.cellH;
-            const int wx0 = x0 - 3, wx1 = (j == cols - 1) ? G.maxBX + 3 : x0 + G.cellW + 3;
-            const int wy0 = y0 - 3, wy1 = wy0 + ((i == rows - 1) ? G.winHLast : G.cellH + 6);
-            // aligned dwords covering [wx0, wx1); bytes outside the window are masked; v_sad_u8 sums 4 bytes per op
-            const int a0 = wx0 & ~3, nq = (wx1 - a0 + 3) / 4;
-            unsigned acc = 0;
-            for (int y = wy0; y < wy1; y++) {
-                const unsigned* row = (const unsigned*)(Q + (size_t)y * pitch + a0);
-                for (int q = lane; q < nq; q += 64) {
-                    unsigned v = row[q];
-                    const int bx = a0 + 4 * q;
-                    if (bx < wx0) v &= 0xffffffffu << (8 * (wx0 - bx));
-                    if (bx + 4 > wx1) v &= 0xffffffffu >> (8 * (bx + 4 - wx1));
-                    acc = __builtin_amdgcn_sad_u8(v, 0u, acc);
-                }
-            }
-            qs = (unsigned)wave_sum_i32((int)acc);
-        }
-        if (lane == 0) { s_nMin[c] = cnt[2 * c]; s_nIni[c] = cnt[2 * c + 1]; s_qsum[c] = qs; }
+    CellInfo* ci = cellInfo + (size_t)img * cfg->nCellsTotal + G.cellBase;
+    for (int c = tid; c < nCells; c += 256) {
+        s_nMin[c] = cnt[2 * c]; s_nIni[c] = cnt[2 * c + 1];
+        s_qsum[c] = mode ? (unsigned)ci[c].nTotal : 0u;       // window sums from k_cell_qsum
     }
     __syncthreads();
     if (tid == 0) {                                   // sequential bookkeeping exactly in (i,j) order
@@ -778,7 +791,6 @@ __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, c
         lvlTotal[img * kMaxLevels + level] = acc;
     }
     __syncthreads();
-    CellInfo* ci = cellInfo + (size_t)img * cfg->nCellsTotal + G.cellBase;
     for (int c = tid; c < nCells; c += 256) ci[c] = CellInfo{s_nTotal[c], s_nRetain[c], s_prefix[c], (int)s_useMin[c]};
 }
 
@@ -1300,6 +1312,8 @@ void launch_blur(const Config& hc, const Config* dc, const Buffers& b, int nImg,
 }
 void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s)
 {
+    if (hc.introspection)
+        hipLaunchKernelGGL(k_cell_qsum, dim3((hc.nCellsTotal + 3) / 4, nImg), dim3(256), 0, s, dc, b.qpyr, b.useCost, (CellInfo*)b.cellInfo);
     hipLaunchKernelGGL(k_quota, dim3(hc.nlevels, nImg), dim3(256), 0, s, dc, b.cellCnt, b.qpyr, b.useCost,
                        (CellInfo*)b.cellInfo, b.lvlTotal);
     hipLaunchKernelGGL((k_cell_select<kCellCapSmall>), dim3(hc.nCellsTotal, nImg), dim3(64), 0, s, dc, b.tileList, b.tileCnt,
