@@ -330,8 +330,15 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
 // (sH, f32, zero outside the image = the depthwise zero padding), all threads run the 3x3 stencil out of LDS into sD, and
 // the waves feed sD (split into f16 hi/lo on the fly) to the projection MFMAs, accumulating the block's output tile
 // in registers across the chunks.  EXP = false: expansion ratio 1 (first block), sH is the input tile itself.
+// KNOWN ISSUE (gfx950, ROCm 7.2): two CO-RESIDENT workgroups of this kernel corrupt each other's results -- output
+// differs from run to run as soon as the grid is large enough for two of them to share a CU, with any amount of LDS slack
+// (50..80 KB requested per workgroup), with extra barriers after every phase and with all waves kept alive to the end;
+// one workgroup per CU is bit-exact and deterministic at every batch size.  The cause was not found (the kernel has no
+// scratch, only ds_* LDS instructions, and its barrier protocol is the one k_fcn_dwpw uses).  Until it is, the launcher
+// requests >= 84 KB of LDS so that a CU never holds two of them (IVF_FCN_BLOCK_CORESIDENT=1 lifts that for debugging),
+// which costs the occupancy the kernel was designed around -- see the measured default in launch_block.
 template <int S> struct BlockGeom {
-    static constexpr int TOH = S == 1 ? 4 : 2, IWq = 32 * S + (S == 1 ? 2 : 1), IH = TOH * S + (S == 1 ? 2 : 1);
+    static constexpr int TOH = S == 1 ? 2 : 1, IWq = 32 * S + (S == 1 ? 2 : 1), IH = TOH * S + (S == 1 ? 2 : 1);
     static constexpr int INPX = IH * IWq, NPT = (INPX + 31) / 32, HP = NPT * 32 + 4, OUTPX = TOH * 32, DP = OUTPX + 4;
 };
 
@@ -416,9 +423,9 @@ __global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ 
     }
     // stencil role: one hidden channel of the chunk, a run of output pixels
     const int chl = tid >> 3, seg = tid & 7;
-    const int sr = S == 1 ? seg >> 1 : seg >> 2;                     // output row of the tile
-    const int sc0 = S == 1 ? 16 * (seg & 1) : 8 * (seg & 3);         // first output column
-    constexpr int NOUT = S == 1 ? 16 : 8, NIN = S == 1 ? 18 : 17;
+    constexpr int NOUT = TOH * 32 / 8, NIN = (NOUT - 1) * S + 3;     // 8 threads per channel
+    const int sr = seg * NOUT / 32;                                  // output row of the tile
+    const int sc0 = seg * NOUT % 32;                                 // first output column
     f32x16 accO;
 #pragma unroll
     for (int q = 0; q < 16; q++) accO[q] = 0.f;
@@ -547,13 +554,16 @@ __global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ 
                 accO = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bh.v, accO, 0, 0, 0);
             }
         }
-        if (xbar) __syncthreads();
+        if (xbar & 1) __syncthreads();
     };
     Pre PA, PB;                                     // two constant sets alternate: no register copies per chunk
     fetch(PA, 0);
     for (int ck = 0; ck < nChunks; ck += 2) {
         chunk(PA, PB, ck);
         if (ck + 1 < nChunks) chunk(PB, PA, ck + 1);
+    }
+    if (xbar & 4) {                                 // debug: publish what phase 3 saw
+        if (wave < TOH) for (int q = 0; q < 16; q++) if (accO[q] != accO[q]) Y[0] = 1.f;
     }
     // ---- epilogue: BN (+ residual), rows = output channels, column = this lane's pixel of output row `wave`
     if (wave < TOH) {
@@ -579,6 +589,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ 
             Y[ob + (size_t)co * HWo] = v;
         }
     }
+    if (xbar & 2) __syncthreads();
 }
 
 // ---- dense 3x3, pad 1, on a 64-wide map (decoder cbr: 320 -> 80 at 64x64) + BN + ReLU ----
@@ -1118,13 +1129,13 @@ bool launch_block(int index, const Gemm* ex, const Dw& d, const Gemm& pj, const 
                   int B, hipStream_t s)
 {
     static const bool off = getenv("IVF_FCN_NOBLOCK") != nullptr;
-    static const unsigned mask = getenv("IVF_FCN_BLOCKMASK") ? (unsigned)strtoul(getenv("IVF_FCN_BLOCKMASK"), nullptr, 0) : 0x5u;   // measured: fusion pays for blocks 1 and 3 only
+    static const unsigned mask = getenv("IVF_FCN_BLOCKMASK") ? (unsigned)strtoul(getenv("IVF_FCN_BLOCKMASK"), nullptr, 0) : 0u;   // off by default: at one workgroup per CU (see BlockGeom) it is slower than the layer-by-layer path
     if (!(mask >> index & 1)) return false;
     static const int xbar = getenv("IVF_FCN_BLOCK_XBAR") ? atoi(getenv("IVF_FCN_BLOCK_XBAR")) : 0;
     const int cin = ex ? ex->cin : d.c, hid = d.c, hidp = (hid + 31) / 32 * 32;
     const int Ho = (H - 1) / d.stride + 1, Wo = (W - 1) / d.stride + 1;
     if (off || d.dil != 1 || cin > 32 || pj.cout > 32 || pj.taps != 1 || pj.nTiles != 1 || pj.act != 0 || (d.stride != 1 && d.stride != 2) ||
-        Wo % 32 || Ho % (d.stride == 1 ? 4 : 2) || (H % d.stride) || (W % d.stride))
+        Wo % 32 || Ho % (d.stride == 1 ? 2 : 1) || (H % d.stride) || (W % d.stride))
         return false;
     if (ex && (ex->taps != 1 || ex->act != 1 || ex->nTiles * 32 != hidp)) return false;
     if (!ex && hid != 32) return false;
@@ -1144,10 +1155,8 @@ bool launch_block(int index, const Gemm* ex, const Dw& d, const Gemm& pj, const 
     do { typedef BlockGeom<SV> G;                                                                                       \
          static const size_t pad = getenv("IVF_FCN_LDSPAD") ? (size_t)atoi(getenv("IVF_FCN_LDSPAD")) : 0;                \
          size_t lds = (size_t)K16e * G::NPT * 2048 + (size_t)32 * G::HP * 4 + (size_t)32 * G::DP * 4 + pad;             \
-         /* two co-resident workgroups of the stride-2 variant corrupt each other's results on gfx950 (observed with   \
-            76.8 KB each, not with padding past 80 KB; cause not found): request enough LDS to keep one per CU */      \
-         static const bool co2 = getenv("IVF_FCN_BLOCK_CO2") != nullptr;                                                \
-         if (SV == 2 && lds < 84 * 1024 && !co2) lds = 84 * 1024;                                                       \
+         static const bool co = getenv("IVF_FCN_BLOCK_CORESIDENT") != nullptr;                                          \
+         if (!co && lds < 84 * 1024) lds = 84 * 1024;    /* one workgroup per CU, see BlockGeom */                          \
          hipLaunchKernelGGL((k_fcn_block<SV, EV>), dim3(Wo / 32, Ho / G::TOH, B), dim3(256), lds, s, X, w1, s1, h1, d.dPack, \
                             pj.dWq, pj.dScale, pj.dShift, res, Y, cin, hidp, pj.cout, H, W, Ho, Wo, nT1, pj.nTiles, xbar); } while (0)
     if (!ex && d.stride == 1) BLOCK(1, 0);

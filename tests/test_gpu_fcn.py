@@ -72,3 +72,50 @@ def test_fcn_rejects_bad_blob(iv):
         iv.IntrospectionFCN(blob[:-5], (375, 1242))
     with pytest.raises(iv.IvfError):
         iv.IntrospectionFCN(np.concatenate([blob, blob[:3]]), (375, 1242))
+
+
+_VARIANT_SCRIPT = r"""
+import sys, os
+sys.path.insert(0, os.environ["IVF_REPO"]); sys.path.insert(0, os.path.join(os.environ["IVF_REPO"], "tests"))
+import numpy as np, torch
+import fcn_common as FC, iv_slam_amd as iv
+from iv_slam_amd import fcn_weights
+g, W, bgr, out = FC.load_case("kitti")
+NB = 20      # 640 workgroups in the 64x64 stages: every CU holds co-resident workgroups of every kernel
+f = iv.IntrospectionFCN(fcn_weights.pack_blob(W), bgr.shape[:2], out, max_batch=NB)
+u8, cost = f(bgr, want_f32=True)
+err = FC.check_against_golden(g, cost, u8, tol=1e-3)
+dev = torch.device("cuda:0")
+flipped = bgr[:, ::-1].copy()
+batch = torch.from_numpy(np.stack([bgr if i % 2 == 0 else flipped for i in range(NB)])).to(dev)
+outs = []
+for rep in range(2):
+    c = torch.empty((NB,) + tuple(out), dtype=torch.uint8, device=dev)
+    f.forward_device(batch, cost_u8=c); torch.cuda.synchronize()
+    outs.append(c.cpu().numpy())
+assert np.array_equal(outs[0], outs[1]), "batched forward is not deterministic"
+for i in range(0, NB, 2):
+    assert np.array_equal(outs[0][i], u8), "batch slot %d differs from the single-image result" % i
+    assert np.array_equal(outs[0][i + 1], outs[0][1]), "batch slot %d differs from slot 1 (same input)" % (i + 1)
+print("OK %.3g" % err)
+"""
+
+
+@pytest.mark.parametrize("env", [
+    {},                                                                        # the measured defaults
+    # layer-by-layer fallbacks only: k_fcn_gemm for every 1x1 / 3x3, k_fcn_dw for every depthwise layer
+    {"IVF_FCN_NOBLOCK": "1", "IVF_FCN_NOFUSE": "1", "IVF_FCN_EXPAND": "0", "IVF_FCN_OLD3X3": "1"},
+    # every whole-block kernel variant on, including the ones the default leaves off because they measure slower
+    {"IVF_FCN_BLOCKMASK": "63"},
+    # 64-pixel expansion tiles
+    {"IVF_FCN_EXPAND": "2"},
+], ids=["default", "layerwise", "all-blocks-fused", "expand-pxt2"])
+def test_fcn_kernel_variants_match_goldens_and_are_deterministic(env):
+    """The FCN picks between several kernels per layer (measured defaults, env overrides for tuning).  Every variant must
+    meet the same bar, batch results must not depend on the batch slot, and repeated runs must be bit-identical (this is
+    the test that caught two co-resident workgroups of the stride-2 block kernel corrupting each other)."""
+    import os, subprocess, sys
+    e = dict(os.environ); e.update(env); e["IVF_REPO"] = FC.ROOT
+    r = subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert float(r.stdout.split("OK")[1]) < 3e-4
