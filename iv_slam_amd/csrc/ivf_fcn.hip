@@ -332,11 +332,13 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
 // in registers across the chunks.  EXP = false: expansion ratio 1 (first block), sH is the input tile itself.
 // KNOWN ISSUE (gfx950, ROCm 7.2): two CO-RESIDENT workgroups of this kernel corrupt each other's results -- output
 // differs from run to run as soon as the grid is large enough for two of them to share a CU, with any amount of LDS slack
-// (50..80 KB requested per workgroup), with extra barriers after every phase and with all waves kept alive to the end;
+// (50..80 KB per workgroup, static or dynamic), with extra barriers after every phase, with a full s_waitcnt after the
+// constant prefetch and with all waves kept alive to the end; a SINGLE 32-channel chunk is clean, two or more are not;
 // one workgroup per CU is bit-exact and deterministic at every batch size.  The cause was not found (the kernel has no
 // scratch, only ds_* LDS instructions, and its barrier protocol is the one k_fcn_dwpw uses).  Until it is, the launcher
-// requests >= 84 KB of LDS so that a CU never holds two of them (IVF_FCN_BLOCK_CORESIDENT=1 lifts that for debugging),
-// which costs the occupancy the kernel was designed around -- see the measured default in launch_block.
+// adds 40 KB of unused dynamic LDS so that a CU never holds two of them (IVF_FCN_BLOCK_CORESIDENT=1 lifts that for
+// debugging; IVF_FCN_BLOCK_XBAR holds the experiment switches), which costs the occupancy the kernel was designed
+// around -- see the measured default in launch_block.
 template <int S> struct BlockGeom {
     static constexpr int TOH = S == 1 ? 2 : 1, IWq = 32 * S + (S == 1 ? 2 : 1), IH = TOH * S + (S == 1 ? 2 : 1);
     static constexpr int INPX = IH * IWq, NPT = (INPX + 31) / 32, HP = NPT * 32 + 4, OUTPX = TOH * 32, DP = OUTPX + 4;
@@ -353,11 +355,10 @@ __global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ 
     typedef BlockGeom<S> G;
     constexpr int TOH = G::TOH, IWq = G::IWq, INPX = G::INPX, NPT = G::NPT, HP = G::HP, OUTPX = G::OUTPX, DP = G::DP;
     constexpr int MYPT = (NPT + 3) / 4;             // expansion pixel tiles per wave
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool EXP = K16e > 0;
-    uint4* sX = reinterpret_cast<uint4*>(smem);                                     // [(st*NPT + pt)*2 + part][64]
-    float* sH = reinterpret_cast<float*>(smem + (size_t)K16e * NPT * 2048);         // [32][HP]
-    float* sD = sH + 32 * HP;                                                       // [32][DP]
+    __shared__ __attribute__((aligned(16))) uint4 sX[EXP ? K16e * NPT * 128 : 1];   // [(st*NPT + pt)*2 + part][64]
+    __shared__ __attribute__((aligned(16))) float sH[32 * HP];                       // [32][HP]
+    __shared__ __attribute__((aligned(16))) float sD[32 * DP];                       // [32][DP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 5, col = lane & 31;
     const int b = blockIdx.z, ox0 = blockIdx.x * 32, oy0 = blockIdx.y * TOH;
     const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1;
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ 
     // chunk ahead into registers; a chunk is only a few thousand cycles long, a fetch at its point of use would
     // expose the L2 latency three times per chunk
     struct Pre { uint4 w1[EXP ? K16e : 1][2], w2[2][2]; float4 p[3]; };
-    const int nChunks = hidp / 32;
+    const int nChunks = (xbar & 8) ? 1 : hidp / 32;
     auto fetch = [&](Pre& P, int ck) {
         ck = min(ck, nChunks - 1);
 #pragma unroll
@@ -453,6 +454,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ 
     };
     auto chunk = [&](const Pre& C, Pre& N, int ck) {
         fetch(N, ck + 1);
+        if (xbar & 16) __builtin_amdgcn_s_waitcnt(0);
         const float4 p0 = C.p[0], p1 = C.p[1], p2 = C.p[2];
         if constexpr (EXP) {
             // ---- phase 1: hidden[32 ch][haloed tile] = relu6(bn(W1 x)), zero outside the image
@@ -1142,10 +1144,10 @@ bool launch_block(int index, const Gemm* ex, const Dw& d, const Gemm& pj, const 
     const int K16e = ex ? (cin + 15) / 16 : 0;
     static const bool attr = [] {
         bool ok = true;
-        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_block<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) == hipSuccess;
-        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_block<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) == hipSuccess;
-        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_block<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) == hipSuccess;
-        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_block<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_block<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_block<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_block<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_block<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
         return ok;
     }();
     if (!attr) return false;
@@ -1156,7 +1158,7 @@ bool launch_block(int index, const Gemm* ex, const Dw& d, const Gemm& pj, const 
          static const size_t pad = getenv("IVF_FCN_LDSPAD") ? (size_t)atoi(getenv("IVF_FCN_LDSPAD")) : 0;                \
          size_t lds = (size_t)K16e * G::NPT * 2048 + (size_t)32 * G::HP * 4 + (size_t)32 * G::DP * 4 + pad;             \
          static const bool co = getenv("IVF_FCN_BLOCK_CORESIDENT") != nullptr;                                          \
-         if (!co && lds < 84 * 1024) lds = 84 * 1024;    /* one workgroup per CU, see BlockGeom */                          \
+         lds = co ? pad : (size_t)40 * 1024;             /* static LDS now; dynamic part only as occupancy limiter */       \
          hipLaunchKernelGGL((k_fcn_block<SV, EV>), dim3(Wo / 32, Ho / G::TOH, B), dim3(256), lds, s, X, w1, s1, h1, d.dPack, \
                             pj.dWq, pj.dScale, pj.dShift, res, Y, cin, hidp, pj.cout, H, W, Ho, Wo, nT1, pj.nTiles, xbar); } while (0)
     if (!ex && d.stride == 1) BLOCK(1, 0);
