@@ -216,6 +216,19 @@ int  ivf_fcn_forward(ivf_fcn* f, const uint8_t* bgr, int width, int height, int 
 int  ivf_fcn_forward_device(ivf_fcn* f, const uint8_t* d_bgr, size_t image_stride, int row_stride, int n,
                             uint8_t* d_cost_u8, float* d_cost_f32, void* hip_stream);
 
+/* ---- next rows of SURVEY section 8(f) ----
+ * ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORB/src/ORBmatcher.cc:410-519):
+ * kps1, desc1, kps2, desc2 = mvKeysUn and mDescriptors of the two frames, bounds2 = F2's (mnMinX, mnMinY, mnMaxX, mnMaxY);
+ * prev_matched_xy [n1][2] in/out (vbPrevMatched), matches12 [n1] out (vnMatches12), *nmatches = return value.
+ * nn_ratio / check_orientation = mfNNratio / mbCheckOrientation of the matcher. */
+int  ivf_search_for_initialization(const ivf_keypoint* kps1, const uint8_t* desc1, int n1,
+                                   const ivf_keypoint* kps2, const uint8_t* desc2, int n2, const ivf_bounds* bounds2,
+                                   float* prev_matched_xy, int window_size, float nn_ratio, int check_orientation,
+                                   int32_t* matches12, int* nmatches, int device_id);
+/* MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): desc = the n observed descriptors (rows of
+ * vDescriptors, in mObservations order); *best_index = the row to copy into mDescriptor, *best_median (nullable) its median. */
+int  ivf_distinctive_descriptor(const uint8_t* desc, int n, int* best_index, int* best_median, int device_id);
+
 /* measurement aid (bench.py): HIP events bracket the network's most expensive launch (fused depthwise 3x3 + 1x1
  * projection 960 -> 160 of block 15, k_fcn_dwpw<5,4>) on the stream each forward runs on.  probe_stats returns the summed
  * duration of the last `last_n` probed forwards (0 = all kept, at most 64) and the batch size of the oldest of them. */

@@ -10,6 +10,7 @@
 // change in the reference's CMakeLists.txt.
 #pragma once
 #include <opencv2/core/core.hpp>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -113,6 +114,31 @@ public:
         if (rc != IVF_OK) throw std::runtime_error(std::string("ivf_search_by_projection: ") + ivf_last_error());
         return nm;
     }
+    // ORB/src/ORBmatcher.cc:410-519, same arguments on the frames' public members: mvKeysUn / mDescriptors of F1 and F2,
+    // F2's image bounds (Frame::mnMinX ...).  Called from Tracking::MonocularInitialization (ORB/src/Tracking.cc:1036).
+    int SearchForInitialization(const std::vector<cv::KeyPoint>& keysUn1, const cv::Mat& descriptors1,
+                                const std::vector<cv::KeyPoint>& keysUn2, const cv::Mat& descriptors2, const ivf_bounds& bounds2,
+                                std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10,
+                                int device_id = 0) const
+    {
+        auto conv = [](const std::vector<cv::KeyPoint>& in) {
+            std::vector<ivf_keypoint> out(in.size());
+            for (size_t i = 0; i < in.size(); i++) out[i] = {in[i].pt.x, in[i].pt.y, in[i].size, in[i].angle, in[i].response, in[i].octave};
+            return out;
+        };
+        const std::vector<ivf_keypoint> k1 = conv(keysUn1), k2 = conv(keysUn2);
+        std::vector<float> prev(2 * k1.size());
+        for (size_t i = 0; i < k1.size(); i++) { prev[2 * i] = vbPrevMatched[i].x; prev[2 * i + 1] = vbPrevMatched[i].y; }
+        std::vector<int32_t> m12(k1.size(), -1);
+        int nm = 0;
+        const int rc = ivf_search_for_initialization(k1.data(), descriptors1.ptr<uint8_t>(), (int)k1.size(), k2.data(),
+                                                     descriptors2.ptr<uint8_t>(), (int)k2.size(), &bounds2, prev.data(), windowSize,
+                                                     mfNNratio, mbCheckOrientation ? 1 : 0, m12.data(), &nm, device_id);
+        if (rc != IVF_OK) throw std::runtime_error(std::string("ivf_search_for_initialization: ") + ivf_last_error());
+        vnMatches12.assign(m12.begin(), m12.end());
+        for (size_t i = 0; i < k1.size(); i++) { vbPrevMatched[i].x = prev[2 * i]; vbPrevMatched[i].y = prev[2 * i + 1]; }
+        return nm;
+    }
 
 protected:
     float mfNNratio;
@@ -140,5 +166,15 @@ inline void ComputeStereoMatches(ORB_SLAM2::ORBextractor* left, ORB_SLAM2::ORBex
                                     kr.data(), (int)kr.size(), mDescriptorsRight.ptr<uint8_t>(), mbf, mb,
                                     mvuRight.data(), mvDepth.data());
     if (rc != IVF_OK) throw std::runtime_error(std::string("ivf_stereo_match: ") + ivf_last_error());
+}
+// Core of MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): index of the observed descriptor to keep.
+inline int DistinctiveDescriptorIndex(const std::vector<cv::Mat>& vDescriptors, int device_id = 0)
+{
+    std::vector<uint8_t> flat(vDescriptors.size() * 32);
+    for (size_t i = 0; i < vDescriptors.size(); i++) std::memcpy(&flat[i * 32], vDescriptors[i].ptr<uint8_t>(), 32);
+    int best = 0;
+    const int rc = ivf_distinctive_descriptor(flat.data(), (int)vDescriptors.size(), &best, nullptr, device_id);
+    if (rc != IVF_OK) throw std::runtime_error(std::string("ivf_distinctive_descriptor: ") + ivf_last_error());
+    return best;
 }
 }  // namespace ivf

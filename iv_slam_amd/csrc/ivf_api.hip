@@ -694,6 +694,104 @@ int ivf_search_map_points(const ivf_keypoint* cur_kps, const uint8_t* cur_desc, 
     return IVF_OK;
 }
 
+// ORBmatcher::SearchForInitialization (ORB/src/ORBmatcher.cc:410-519)
+int ivf_search_for_initialization(const ivf_keypoint* kps1, const uint8_t* desc1, int n1,
+                                  const ivf_keypoint* kps2, const uint8_t* desc2, int n2, const ivf_bounds* bounds2,
+                                  float* prev_matched_xy, int window_size, float nn_ratio, int check_orientation,
+                                  int32_t* matches12, int* nmatches, int device_id)
+{
+    if (!kps1 || !desc1 || !kps2 || !desc2 || !bounds2 || !prev_matched_xy || !matches12 || !nmatches || n1 < 0 || n2 < 0)
+        return fail(IVF_E_INVALID, "bad argument");
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0 || n2 == 0) return IVF_OK;
+    // 1. windows of the octave-0 keypoints of F1 in F2's grid, GetFeaturesInArea order (:426-430)
+    Grid g; g.build(kps2, n2, *bounds2);
+    std::vector<int> qStart(n1 + 1, 0), pairs;
+    for (int i1 = 0; i1 < n1; i1++) {
+        qStart[i1] = (int)pairs.size() / 2;
+        const int level1 = kps1[i1].octave;
+        if (level1 > 0) continue;
+        g.query(kps2, *bounds2, prev_matched_xy[2 * i1], prev_matched_xy[2 * i1 + 1], (float)window_size, level1, level1,
+                [&](int i2) { pairs.push_back(i1); pairs.push_back(i2); });
+    }
+    qStart[n1] = (int)pairs.size() / 2;
+    const int nPairs = qStart[n1];
+    // 2. every window distance on the device (:445)
+    std::vector<int> dist(std::max(nPairs, 1));
+    int rc = ivf_hamming_pairs(desc1, n1, desc2, n2, pairs.data(), nPairs, dist.data(), device_id);
+    if (rc) return rc;
+    // 3. order-dependent replay: best / second best against the distances already claimed, stealing, histogram (:437-510)
+    const int HISTO_LENGTH = 30, TH_LOW = 50;
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> matchedDist(n2, INT_MAX), matches21(n2, -1);
+    int nm = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        if (qStart[i1] == qStart[i1 + 1]) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int p = qStart[i1]; p < qStart[i1 + 1]; p++) {
+            const int i2 = pairs[2 * p + 1], d = dist[p];
+            if (matchedDist[i2] <= d) continue;
+            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestIdx2 = i2; }
+            else if (d < bestDist2) bestDist2 = d;
+        }
+        if (bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * nn_ratio) {
+            if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; nm--; }
+            matches12[i1] = bestIdx2; matches21[bestIdx2] = i1; matchedDist[bestIdx2] = bestDist; nm++;
+            if (check_orientation) {
+                float rot = kps1[i1].angle - kps2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(i1);
+            }
+        }
+    }
+    if (check_orientation) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int sz = (int)rotHist[i].size();
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx1 : rotHist[i])
+                    if (matches12[idx1] >= 0) { matches12[idx1] = -1; nm--; }
+    }
+    for (int i1 = 0; i1 < n1; i1++)
+        if (matches12[i1] >= 0) { prev_matched_xy[2 * i1] = kps2[matches12[i1]].x; prev_matched_xy[2 * i1 + 1] = kps2[matches12[i1]].y; }
+    *nmatches = nm;
+    return IVF_OK;
+}
+
+// MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): all-pairs Hamming + row medians on the device,
+// first minimum on the host
+int ivf_distinctive_descriptor(const uint8_t* desc, int n, int* best_index, int* best_median, int device_id)
+{
+    if (!desc || !best_index || n < 1) return fail(IVF_E_INVALID, "bad argument");
+    int rc = have_device(device_id);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    uint8_t* dD = nullptr; int* dM = nullptr;
+    HIPCHK(hipMalloc(&dD, (size_t)n * 32)); HIPCHK(hipMalloc(&dM, (size_t)n * sizeof(int)));
+    HIPCHK(hipMemcpy(dD, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+    launch_distinct_median(dD, n, dM, nullptr);
+    HIPCHK(hipGetLastError());
+    std::vector<int> med(n);
+    HIPCHK(hipMemcpy(med.data(), dM, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(dD); (void)hipFree(dM);
+    int bm = INT_MAX, bi = 0;
+    for (int i = 0; i < n; i++) if (med[i] < bm) { bm = med[i]; bi = i; }
+    *best_index = bi;
+    if (best_median) *best_median = bm;
+    return IVF_OK;
+}
+
 // ORBmatcher::UpdateQualityScores(Frame &F) (ORB/src/ORBmatcher.cc:1108-1121): host bookkeeping, sequential by definition
 int ivf_update_quality_scores(const int32_t* assign, int n, float* kp_quality, float* mp_quality, int n_map_points)
 {

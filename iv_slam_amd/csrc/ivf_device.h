@@ -103,5 +103,6 @@ void launch_describe(const Config& hc, const Config* dc, const Buffers& b, const
 void launch_stereo(const Config& hc, const Config* dc, const Buffers& b, int nPairs, float bf, float bb, hipStream_t s);
 void launch_test_retain_best(const float* dResp, int n, int nPoints, int* dOrder, hipStream_t s);
 void launch_hamming_pairs(const uint8_t* a, const uint8_t* b, const int* pairs, int n, int* dist, hipStream_t s);
+void launch_distinct_median(const uint8_t* desc, int n, int* median, hipStream_t s);
 
 }  // namespace ivf

@@ -1345,6 +1345,38 @@ void launch_stereo(const Config& hc, const Config* dc, const Buffers& b, int nPa
     A.bf = bf; A.bb = bb;
     launch_stereo_args(hc, dc, A, nPairs, s);
 }
+// ---- MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:281-305): per observed descriptor the median of
+// its Hamming distances to all n (the 0 of the diagonal included) = sorted row [(int)(0.5*(n-1))].  Distances live in
+// 0..256, so the median is read off a 257-bin LDS histogram instead of a sort: the smallest value whose cumulative count
+// exceeds the index.  One workgroup per row.
+__global__ __launch_bounds__(256) void k_distinct_median(const uint8_t* __restrict__ desc, int n, int* __restrict__ median)
+{
+    __shared__ int hist[257 + 7];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < 264; k += 256) hist[k] = 0;
+    __syncthreads();
+    const uint4* pi = (const uint4*)(desc + (size_t)i * 32);
+    const uint4 a0 = pi[0], a1 = pi[1];
+    for (int j = tid; j < n; j += 256) {
+        const uint4* pj = (const uint4*)(desc + (size_t)j * 32);
+        const int d = j == i ? 0 : hamming256(a0, a1, pj[0], pj[1]);
+        atomicAdd(&hist[d], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int target = (int)(0.5 * (n - 1));
+        int acc = 0, v = 0;
+        for (; v < 257; v++) { acc += hist[v]; if (acc > target) break; }
+        median[i] = v;
+    }
+}
+
+void launch_distinct_median(const uint8_t* desc, int n, int* median, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_distinct_median, dim3(n), dim3(256), 0, s, desc, n, median);
+}
+
 void launch_hamming_pairs(const uint8_t* a, const uint8_t* b, const int* pairs, int n, int* dist, hipStream_t s)
 {
     if (n <= 0) return;

@@ -199,3 +199,29 @@ class ORBmatcher:
         kq = np.ascontiguousarray(mvKeyQualScore, np.float32).copy(); mq = np.ascontiguousarray(mapPointQuality, np.float32).copy()
         check(self._lib.ivf_update_quality_scores(ptr(a), len(a), ptr(kq), ptr(mq), len(mq)))
         return kq, mq
+
+    def SearchForInitialization(self, kps1, desc1, kps2, desc2, bounds2, vbPrevMatched, windowSize=10):
+        """SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:410-519) on the frames'
+        mvKeysUn / mDescriptors.  Returns (vnMatches12, vbPrevMatched updated, nmatches)."""
+        k1 = np.ascontiguousarray(kps1, KP_DTYPE); k2 = np.ascontiguousarray(kps2, KP_DTYPE)
+        d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+        prev = np.ascontiguousarray(vbPrevMatched, np.float32).reshape(-1, 2).copy()
+        if len(prev) != len(k1):
+            raise AssertionError("vbPrevMatched.size() == F1.mvKeysUn.size()")
+        m12 = np.full(len(k1), -1, np.int32); nm = C.c_int(0); bd = Bounds(*bounds2)
+        check(self._lib.ivf_search_for_initialization(ptr(k1), ptr(d1), len(k1), ptr(k2), ptr(d2), len(k2), C.byref(bd), ptr(prev),
+                                                      int(windowSize), self.mfNNratio, int(self.mbCheckOrientation), ptr(m12),
+                                                      C.byref(nm), self.device_id))
+        return m12, prev, nm.value
+
+
+def ComputeDistinctiveDescriptors(vDescriptors, device_id=0):
+    """MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312) on the observed descriptors [n,32]:
+    returns (index of the descriptor to keep, its median distance to the others)."""
+    lib = _lib.load()
+    d = np.ascontiguousarray(vDescriptors, np.uint8).reshape(-1, 32)
+    if len(d) == 0:
+        raise AssertionError("vDescriptors is empty (the reference returns before this point)")
+    bi = C.c_int(0); bm = C.c_int(0)
+    check(lib.ivf_distinctive_descriptor(ptr(d), len(d), C.byref(bi), C.byref(bm), device_id))
+    return bi.value, bm.value

@@ -1051,6 +1051,96 @@ int orc_search_by_projection(const orc_keypoint* cur_kps, const uint8_t* cur_des
     return 0;
 }
 
+/* f1  ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORB/src/ORBmatcher.cc:410-519).
+ * Only octave-0 keypoints of F1 search (:426-428), in the window of F2's grid around prev_xy[i1] at level 0 (:430);
+ * best / second best skip candidates already matched at a smaller-or-equal distance (:449-450); a match steals the
+ * candidate from its previous owner (:468-472); rotation histogram with the reference's 1/HISTO_LENGTH factor and C
+ * round() (:480-487); prev_xy is updated from the surviving matches (:514-516).  Returns nmatches. */
+int orc_search_for_initialization(const orc_keypoint* k1, const uint8_t* d1, int n1,
+                                  const orc_keypoint* k2, const uint8_t* d2, int n2, const orc_bounds* bounds2,
+                                  float* prev_xy, int window_size, float nn_ratio, int check_orientation,
+                                  int32_t* matches12, int* nmatches_out)
+{
+    enum { HISTO_LENGTH = 30, TH_LOW = 50 };
+    int nmatches = 0;
+    int* rotHist[HISTO_LENGTH]; int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int*)malloc(sizeof(int) * (n1 > 0 ? n1 : 1)); rotN[i] = 0; }
+    const float factor = 1.0f / HISTO_LENGTH;
+    int* matchedDist = (int*)malloc(sizeof(int) * (n2 > 0 ? n2 : 1));
+    int* matches21 = (int*)malloc(sizeof(int) * (n2 > 0 ? n2 : 1));
+    for (int i = 0; i < n2; i++) { matchedDist[i] = 2147483647; matches21[i] = -1; }
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    grid_t g;
+    grid_build(&g, k2, n2, bounds2);
+    int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (n2 > 0 ? n2 : 1));
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = k1[i1].octave;
+        if (level1 > 0) continue;
+        const int nc = grid_query(&g, k2, bounds2, prev_xy[2 * i1], prev_xy[2 * i1 + 1], (float)window_size, level1, level1, cand, n2);
+        if (nc == 0) continue;
+        int bestDist = 2147483647, bestDist2 = 2147483647, bestIdx2 = -1;
+        for (int k = 0; k < nc; k++) {
+            const int i2 = cand[k];
+            const int dist = orc_hamming256(d1 + (size_t)i1 * 32, d2 + (size_t)i2 * 32);
+            if (matchedDist[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * nn_ratio) {
+            if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; nmatches--; }
+            matches12[i1] = bestIdx2;
+            matches21[bestIdx2] = i1;
+            matchedDist[bestIdx2] = bestDist;
+            nmatches++;
+            if (check_orientation) {
+                float rot = k1[i1].angle - k2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin][rotN[bin]++] = i1;
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1, ind2, ind3;
+        orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < rotN[i]; j++) {
+                    const int idx1 = rotHist[i][j];
+                    if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+                }
+    }
+    for (int i1 = 0; i1 < n1; i1++)
+        if (matches12[i1] >= 0) { prev_xy[2 * i1] = k2[matches12[i1]].x; prev_xy[2 * i1 + 1] = k2[matches12[i1]].y; }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+    free(cand); free(matchedDist); free(matches21);
+    grid_free(&g);
+    *nmatches_out = nmatches;
+    return 0;
+}
+
+/* f2  MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): among n observed descriptors the one with
+ * the least median Hamming distance to the rest; median = sorted row [ (int)(0.5*(n-1)) ] (the row holds the 0 of the
+ * diagonal), first minimum wins (:294-305). */
+static int cmp_int(const void* a, const void* b) { return *(const int*)a - *(const int*)b; }
+int orc_distinctive_descriptor(const uint8_t* desc, int n, int* best_idx, int* best_median)
+{
+    if (n <= 0) return -1;
+    int* row = (int*)malloc(sizeof(int) * n);
+    int bestMedian = 2147483647, bestIdx = 0;
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) row[j] = i == j ? 0 : orc_hamming256(desc + (size_t)i * 32, desc + (size_t)j * 32);
+        qsort(row, n, sizeof(int), cmp_int);
+        const int median = row[(int)(0.5 * (n - 1))];
+        if (median < bestMedian) { bestMedian = median; bestIdx = i; }
+    }
+    free(row);
+    *best_idx = bestIdx;
+    if (best_median) *best_median = bestMedian;
+    return 0;
+}
+
 /* a14  ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th) (ORB/src/ORBmatcher.cc:45-135)
  * on already-projected queries.  Per query i (a map point with mbTrackInView and !isBad()):
  *   q_u,q_v = mTrackProjX/Y; q_ur = mTrackProjXR; q_radius = r*mvScaleFactors[nPredictedLevel] with

@@ -110,6 +110,13 @@ int   orc_search_map_points(const orc_keypoint* cur_kps, const uint8_t* cur_desc
 /* Frame::GetFeaturesInArea on a freshly built grid: returns count, indices in reference order */
 int   orc_features_in_area(const orc_keypoint* kps, int n, const orc_bounds* bounds,
                            float x, float y, float r, int min_level, int max_level, int32_t* out, int cap);
+/* ORBmatcher::SearchForInitialization (ORB/src/ORBmatcher.cc:410-519): prev_xy [n1][2] in/out, matches12 [n1] out */
+int   orc_search_for_initialization(const orc_keypoint* k1, const uint8_t* d1, int n1,
+                                    const orc_keypoint* k2, const uint8_t* d2, int n2, const orc_bounds* bounds2,
+                                    float* prev_xy, int window_size, float nn_ratio, int check_orientation,
+                                    int32_t* matches12, int* nmatches);
+/* MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): index of the least-median descriptor */
+int   orc_distinctive_descriptor(const uint8_t* desc, int n, int* best_idx, int* best_median);
 /* ORBmatcher::UpdateQualityScores(Frame&) (ORB/src/ORBmatcher.cc:1108-1121) */
 void  orc_update_quality_scores(const int32_t* assign, int n, float* kp_quality, float* mp_quality);
 /* ORBmatcher::ComputeThreeMaxima (ORB/src/ORBmatcher.cc:1654-1695) on bin sizes */

@@ -78,6 +78,9 @@ lib.orc_search_map_points.restype = C.c_int
 lib.orc_search_map_points.argtypes = [vp, vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                       C.c_float, vp, C.POINTER(C.c_int)]
 lib.orc_update_quality_scores.argtypes = [vp, C.c_int, vp, vp]
+lib.orc_search_for_initialization.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, C.c_float, C.c_int,
+                                              vp, C.POINTER(C.c_int)]
+lib.orc_distinctive_descriptor.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 pin.stl_retain_best.restype = C.c_int; pin.stl_retain_best.argtypes = [vp, C.c_int, C.c_int]
 pin.stl_nth_element.argtypes = [vp, C.c_int, C.c_int]
 
@@ -231,3 +234,23 @@ def search_map_points(cur_kps, cur_desc, cur_uright, bounds, q, nn_ratio, cur_as
                               ptr(qq["ur"]), ptr(qq["radius"]), ptr(qq["level"]), ptr(qq["desc"]), ptr(qq["valid"]),
                               ptr(qq["blocks"]), nn_ratio, ptr(assign), C.byref(nm))
     return assign, nm.value
+
+
+def search_for_initialization(kps1, desc1, kps2, desc2, bounds2, prev_matched, window_size, nn_ratio=0.9, check_orientation=True):
+    """ORBmatcher::SearchForInitialization on flat arrays -> (vnMatches12, vbPrevMatched updated, nmatches)."""
+    k1 = np.ascontiguousarray(kps1); k2 = np.ascontiguousarray(kps2)
+    d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+    prev = np.ascontiguousarray(prev_matched, np.float32).reshape(-1, 2).copy()
+    m12 = np.full(len(k1), -1, np.int32); nm = C.c_int(0); bd = Bounds(*bounds2)
+    lib.orc_search_for_initialization(ptr(k1), ptr(d1), len(k1), ptr(k2), ptr(d2), len(k2), C.byref(bd), ptr(prev), int(window_size),
+                                      nn_ratio, int(check_orientation), ptr(m12), C.byref(nm))
+    return m12, prev, nm.value
+
+
+def distinctive_descriptor(desc):
+    """MapPoint::ComputeDistinctiveDescriptors core -> (best index, its median distance)."""
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    bi = C.c_int(0); bm = C.c_int(0)
+    rc = lib.orc_distinctive_descriptor(ptr(d), len(d), C.byref(bi), C.byref(bm))
+    assert rc == 0
+    return bi.value, bm.value

@@ -227,6 +227,47 @@ def test_hamming_pairs_and_search_by_projection(iv):
     assert iv.ORBmatcher.RadiusByViewingCos(0.999) == 2.5 and iv.ORBmatcher.RadiusByViewingCos(0.9) == 4.0
 
 
+def test_search_for_initialization_and_distinctive_descriptor(iv):
+    """SearchForInitialization (ORBmatcher.cc:410-519) and the core of
+    MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:247-312), HIP path vs oracle on the same inputs."""
+    rng = np.random.default_rng(91)
+    w, h = 640, 240
+    g = iv.ORBextractor(800, 1.2, 8, 20, 7)
+    k1, d1 = g(synth.make_left(w, h, seed=52, idx=0))
+    # second frame = the first displaced by a few pixels, descriptors with a few flipped bits, order shuffled
+    perm = rng.permutation(len(k1))
+    k2 = k1[perm].copy(); d2 = d1[perm].copy()
+    k2["x"] += rng.uniform(-4, 4, len(k2)).astype(np.float32); k2["y"] += rng.uniform(-4, 4, len(k2)).astype(np.float32)
+    k2["angle"] = (k2["angle"] + rng.choice([0, 0, 0, 0, 120], len(k2))).astype(np.float32) % 360
+    for i in range(len(d2)):
+        for bpos in rng.integers(0, 256, rng.integers(0, 30)):
+            d2[i, bpos // 8] ^= np.uint8(1 << (bpos % 8))
+    prev = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32)
+    bounds = (0.0, 0.0, float(w), float(h))
+    total = 0
+    for ratio, ori, win in [(0.9, True, 10), (0.9, False, 10), (0.6, True, 25), (1.0, True, 100), (0.9, True, 0)]:
+        m = iv.ORBmatcher(ratio, ori)
+        gm, gp, gn = m.SearchForInitialization(k1, d1, k2, d2, bounds, prev, win)
+        om, op, on = O.search_for_initialization(k1, d1, k2, d2, bounds, prev, win, ratio, ori)
+        assert gn == on and np.array_equal(gm, om) and gp.tobytes() == op.tobytes()
+        total += gn
+    assert total > 300
+    # empty frames
+    gm, gp, gn = iv.ORBmatcher(0.9, True).SearchForInitialization(k1[:0], d1[:0], k2, d2, bounds, prev[:0], 10)
+    assert gn == 0 and len(gm) == 0
+    gm, gp, gn = iv.ORBmatcher(0.9, True).SearchForInitialization(k1, d1, k2[:0], d2[:0], bounds, prev, 10)
+    assert gn == 0 and (gm == -1).all()
+    # distinctive descriptor: observation sets of several sizes, with exact duplicates (median ties -> first minimum)
+    for n in (1, 2, 5, 64, 257, 1000):
+        obs = d1[rng.integers(0, min(len(d1), 40), n)].copy()
+        for i in range(n):
+            for bpos in rng.integers(0, 256, rng.integers(0, 24)):
+                obs[i, bpos // 8] ^= np.uint8(1 << (bpos % 8))
+        assert iv.ComputeDistinctiveDescriptors(obs) == O.distinctive_descriptor(obs)
+    with pytest.raises(AssertionError):
+        iv.ComputeDistinctiveDescriptors(np.zeros((0, 32), np.uint8))
+
+
 def test_full_size_properties(iv):
     """BASELINE full size: properties that need no oracle (idempotence, level order, border, uniqueness)."""
     img = synth.make_left(1242, 375, seed=61, idx=0)

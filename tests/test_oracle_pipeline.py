@@ -173,3 +173,60 @@ def test_search_map_points_ratio_test_and_levels():
     a3, nm3 = O.search_map_points(kps, desc, ur, (0, 0, 640, 240), q3, 0.0)     # ratio 0: same-octave second best always rejects
     a4, nm4 = O.search_map_points(kps, desc, ur, (0, 0, 640, 240), q3, 1.0)
     assert nm3 <= nm4
+
+
+def test_search_for_initialization_properties():
+    """f1 SearchForInitialization (ORBmatcher.cc:410-519): octave-0 keypoints only, level-0 window around vbPrevMatched,
+    best/second-best ratio, stealing from a worse earlier owner, rotation filter, vbPrevMatched update."""
+    img = synth.make_left(640, 240, seed=19, idx=0)
+    kps, desc = O.Extractor(500, 1.2, 8, 20, 7)(img)
+    n = len(kps)
+    prev = np.stack([kps["x"], kps["y"]], axis=1).astype(np.float32)
+    bounds = (0, 0, 640, 240)
+    m, prev2, nm = O.search_for_initialization(kps, desc, kps, desc, bounds, prev, 10, 0.9, True)
+    lvl0 = kps["octave"] == 0
+    assert nm == (m >= 0).sum() and (m[~lvl0] == -1).all()                 # higher octaves never search (:426-428)
+    assert nm > 0.9 * lvl0.sum() and (m[lvl0 & (m >= 0)] == np.nonzero(lvl0 & (m >= 0))[0]).all()   # identical frame: self matches
+    assert (kps["octave"][m[m >= 0]] == 0).all()                            # window restricted to level 0 (:430)
+    assert np.array_equal(prev2[m >= 0], prev[m[m >= 0]])                   # vbPrevMatched <- matched F2 point (:514-516)
+    assert np.array_equal(prev2[m < 0], prev[m < 0])
+    # a window of 0 pixels finds nothing; displaced windows beyond the radius neither
+    m0, _, nm0 = O.search_for_initialization(kps, desc, kps, desc, bounds, prev, 0, 0.9, True)
+    assert nm0 == 0 and (m0 == -1).all()
+    far = prev + np.float32(30)
+    mf, _, nmf = O.search_for_initialization(kps, desc, kps, desc, bounds, far, 10, 0.9, True)
+    assert nmf < nm // 4
+    # TH_LOW: descriptors more than 50 bits away are rejected even when they are the only candidate
+    d2 = desc.copy(); d2[:, :8] ^= np.uint8(0xFF)                           # 64 flipped bits
+    mb, _, nmb = O.search_for_initialization(kps, desc, kps, d2, bounds, prev, 10, 0.9, True)
+    assert nmb == 0
+    # rotation filter: 5 % of F1 rotated by 90 degrees lands in a weak bin and is removed only when checking orientation
+    k1 = kps.copy(); sel = (np.arange(n) % 20 == 0) & lvl0
+    k1["angle"][sel] = (k1["angle"][sel] + 90) % 360
+    mr, _, nmr = O.search_for_initialization(k1, desc, kps, desc, bounds, prev, 10, 0.9, True)
+    mn, _, nmn = O.search_for_initialization(k1, desc, kps, desc, bounds, prev, 10, 0.9, False)
+    assert nmn == nm and nmr < nmn and (mr[sel] == -1).mean() > 0.8
+    # stealing: F1 holds each level-0 keypoint twice, first a corrupted copy (8 flipped bits), then the exact one; the exact
+    # copy arrives later, beats the claimed distance and takes the match away (:449-450, :468-472)
+    idx0 = np.nonzero(lvl0)[0][:40]
+    kk = np.concatenate([kps[idx0], kps[idx0]]); dd = np.concatenate([desc[idx0], desc[idx0]])
+    dd[:len(idx0), 0] ^= np.uint8(0xFF)
+    pp = np.concatenate([prev[idx0], prev[idx0]])
+    ms, _, nms = O.search_for_initialization(kk, dd, kps, desc, bounds, pp, 2, 0.9, False)
+    stolen = ms[len(idx0):] >= 0
+    assert stolen.sum() > 30 and (ms[:len(idx0)][stolen] == -1).all() and nms == (ms >= 0).sum()
+
+
+def test_distinctive_descriptor_is_least_median():
+    """f2 MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:281-305) against a direct numpy restatement."""
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 3, 8, 33):
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        d = np.repeat(base[None], n, axis=0)
+        for i in range(n):                                   # i random bit flips of a common descriptor + ties
+            for b in rng.integers(0, 256, (i * 7) % 40):
+                d[i, b // 8] ^= np.uint8(1 << (b % 8))
+        D = np.array([[O.hamming(d[i], d[j]) for j in range(n)] for i in range(n)])
+        med = np.sort(D, axis=1)[:, int(0.5 * (n - 1))]
+        bi, bm = O.distinctive_descriptor(d)
+        assert bm == med.min() and bi == int(np.argmin(med))          # first minimum
