@@ -225,6 +225,23 @@ int  ivf_search_for_initialization(const ivf_keypoint* kps1, const uint8_t* desc
                                    const ivf_keypoint* kps2, const uint8_t* desc2, int n2, const ivf_bounds* bounds2,
                                    float* prev_matched_xy, int window_size, float nn_ratio, int check_orientation,
                                    int32_t* matches12, int* nmatches, int device_id);
+/* ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (ORB/src/ORBmatcher.cc:296-404) on projected
+ * candidates: the caller runs :318-365 (Sim3 transform, depth / IsInImage / distance-invariance / viewing-angle tests,
+ * PredictScale) and passes per surviving point u, v, radius = th * mvScaleFactors[level], level = nPredictedLevel and
+ * the map point descriptor.  matched [n_kf] in/out: -1 = vpMatched[idx] is NULL, -2 = occupied on entry, on return
+ * >= 0 = index of the query now matched there.  *nmatches = return value. */
+int  ivf_search_keyframe_points(const ivf_keypoint* kf_kps, const uint8_t* kf_desc, int n_kf, const ivf_bounds* bounds,
+                                int n_q, const float* q_u, const float* q_v, const float* q_radius, const int32_t* q_level,
+                                const uint8_t* q_desc, const uint8_t* q_valid, int32_t* matched, int* nmatches, int device_id);
+/* ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (ORB/src/ORBmatcher.cc:831-982): the matching core :893-955 on projected
+ * map points (u, v, ur = u - bf*invz, radius, level as above); kf_uright = mvuRight, inv_level_sigma2 = mvInvLevelSigma2.
+ * best_idx[i] = the keypoint to fuse query i with (-1: none within TH_LOW), best_dist[i] (nullable) its distance.  The
+ * Replace / AddObservation bookkeeping (:958-977) stays with the caller, in query order. */
+int  ivf_fuse_candidates(const ivf_keypoint* kf_kps, const uint8_t* kf_desc, const float* kf_uright, int n_kf,
+                         const ivf_bounds* bounds, const float* inv_level_sigma2, int n_levels,
+                         int n_q, const float* q_u, const float* q_v, const float* q_ur, const float* q_radius,
+                         const int32_t* q_level, const uint8_t* q_desc, const uint8_t* q_valid,
+                         int32_t* best_idx, int32_t* best_dist, int device_id);
 /* MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): desc = the n observed descriptors (rows of
  * vDescriptors, in mObservations order); *best_index = the row to copy into mDescriptor, *best_median (nullable) its median. */
 int  ivf_distinctive_descriptor(const uint8_t* desc, int n, int* best_index, int* best_median, int device_id);

@@ -63,6 +63,10 @@ _SIGS = {
     "ivf_search_for_initialization": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, C.c_float, C.c_int,
                                                 vp, C.POINTER(C.c_int), C.c_int]),
     "ivf_distinctive_descriptor": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
+    "ivf_search_keyframe_points": (C.c_int, [vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp,
+                                             C.POINTER(C.c_int), C.c_int]),
+    "ivf_fuse_candidates": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
+                                      vp, vp, C.c_int]),
     "ivf_test_retain_best": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int]),
     "ivf_frontend_create": (C.c_int, [C.POINTER(FrontendConfig), C.POINTER(vp)]),
     "ivf_frontend_destroy": (None, [vp]),

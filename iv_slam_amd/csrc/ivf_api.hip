@@ -769,6 +769,99 @@ int ivf_search_for_initialization(const ivf_keypoint* kps1, const uint8_t* desc1
     return IVF_OK;
 }
 
+// ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (ORB/src/ORBmatcher.cc:296-404), flat queries
+int ivf_search_keyframe_points(const ivf_keypoint* kf_kps, const uint8_t* kf_desc, int n_kf, const ivf_bounds* bounds,
+                               int n_q, const float* q_u, const float* q_v, const float* q_radius, const int32_t* q_level,
+                               const uint8_t* q_desc, const uint8_t* q_valid, int32_t* matched, int* nmatches, int device_id)
+{
+    if (!kf_kps || !kf_desc || !bounds || !matched || !nmatches || n_kf < 0 || n_q < 0) return fail(IVF_E_INVALID, "bad argument");
+    *nmatches = 0;
+    if (n_q == 0 || n_kf == 0) return IVF_OK;
+    if (!q_u || !q_v || !q_radius || !q_level || !q_desc) return fail(IVF_E_INVALID, "null query array");
+    // 1. windows (KeyFrame::GetFeaturesInArea, no level arguments) filtered by octave in [level-1, level] (:384-385)
+    Grid g; g.build(kf_kps, n_kf, *bounds);
+    std::vector<int> qStart(n_q + 1, 0), pairs;
+    for (int i = 0; i < n_q; i++) {
+        qStart[i] = (int)pairs.size() / 2;
+        if (q_valid && !q_valid[i]) continue;
+        g.query(kf_kps, *bounds, q_u[i], q_v[i], q_radius[i], -1, -1, [&](int idx) {
+            const int l = kf_kps[idx].octave;
+            if (l < q_level[i] - 1 || l > q_level[i]) return;
+            pairs.push_back(i); pairs.push_back(idx);
+        });
+    }
+    qStart[n_q] = (int)pairs.size() / 2;
+    const int nPairs = qStart[n_q];
+    // 2. window distances on the device
+    std::vector<int> dist(std::max(nPairs, 1));
+    int rc = ivf_hamming_pairs(q_desc, n_q, kf_desc, n_kf, pairs.data(), nPairs, dist.data(), device_id);
+    if (rc) return rc;
+    // 3. greedy replay in candidate order: occupied keypoints are skipped (:379-380)
+    int nm = 0;
+    for (int i = 0; i < n_q; i++) {
+        int bestDist = 256, bestIdx = -1;
+        for (int p = qStart[i]; p < qStart[i + 1]; p++) {
+            const int idx = pairs[2 * p + 1];
+            if (matched[idx] != -1) continue;
+            if (dist[p] < bestDist) { bestDist = dist[p]; bestIdx = idx; }
+        }
+        if (bestDist <= 50) { matched[bestIdx] = i; nm++; }
+    }
+    *nmatches = nm;
+    return IVF_OK;
+}
+
+// ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) matching core (ORB/src/ORBmatcher.cc:893-955), flat queries
+int ivf_fuse_candidates(const ivf_keypoint* kf_kps, const uint8_t* kf_desc, const float* kf_uright, int n_kf,
+                        const ivf_bounds* bounds, const float* inv_level_sigma2, int n_levels,
+                        int n_q, const float* q_u, const float* q_v, const float* q_ur, const float* q_radius,
+                        const int32_t* q_level, const uint8_t* q_desc, const uint8_t* q_valid,
+                        int32_t* best_idx, int32_t* best_dist, int device_id)
+{
+    if (!kf_kps || !kf_desc || !kf_uright || !bounds || !inv_level_sigma2 || !best_idx || n_kf < 0 || n_q < 0 || n_levels < 1)
+        return fail(IVF_E_INVALID, "bad argument");
+    for (int i = 0; i < n_q; i++) { best_idx[i] = -1; if (best_dist) best_dist[i] = 256; }
+    if (n_q == 0 || n_kf == 0) return IVF_OK;
+    if (!q_u || !q_v || !q_ur || !q_radius || !q_level || !q_desc) return fail(IVF_E_INVALID, "null query array");
+    for (int i = 0; i < n_kf; i++)
+        if (kf_kps[i].octave < 0 || kf_kps[i].octave >= n_levels) return fail(IVF_E_INVALID, "keypoint %d: octave outside the sigma table", i);
+    Grid g; g.build(kf_kps, n_kf, *bounds);
+    std::vector<int> qStart(n_q + 1, 0), pairs;
+    for (int i = 0; i < n_q; i++) {
+        qStart[i] = (int)pairs.size() / 2;
+        if (q_valid && !q_valid[i]) continue;
+        const float u = q_u[i], v = q_v[i], ur = q_ur[i];
+        g.query(kf_kps, *bounds, u, v, q_radius[i], -1, -1, [&](int idx) {
+            const ivf_keypoint& kp = kf_kps[idx];
+            const int l = kp.octave;
+            if (l < q_level[i] - 1 || l > q_level[i]) return;
+            if (kf_uright[idx] >= 0) {                               // chi-square gates (:918-938), f32 products compared in double
+                const float ex = u - kp.x, ey = v - kp.y, er = ur - kf_uright[idx];
+                const float e2 = ex * ex + ey * ey + er * er;
+                if (e2 * inv_level_sigma2[l] > 7.8) return;
+            } else {
+                const float ex = u - kp.x, ey = v - kp.y;
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * inv_level_sigma2[l] > 5.99) return;
+            }
+            pairs.push_back(i); pairs.push_back(idx);
+        });
+    }
+    qStart[n_q] = (int)pairs.size() / 2;
+    const int nPairs = qStart[n_q];
+    std::vector<int> dist(std::max(nPairs, 1));
+    int rc = ivf_hamming_pairs(q_desc, n_q, kf_desc, n_kf, pairs.data(), nPairs, dist.data(), device_id);
+    if (rc) return rc;
+    for (int i = 0; i < n_q; i++) {
+        int bestDist = 256, bestIdx = -1;
+        for (int p = qStart[i]; p < qStart[i + 1]; p++)
+            if (dist[p] < bestDist) { bestDist = dist[p]; bestIdx = pairs[2 * p + 1]; }
+        if (best_dist) best_dist[i] = bestDist;
+        if (bestDist <= 50) best_idx[i] = bestIdx;
+    }
+    return IVF_OK;
+}
+
 // MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): all-pairs Hamming + row medians on the device,
 // first minimum on the host
 int ivf_distinctive_descriptor(const uint8_t* desc, int n, int* best_index, int* best_median, int device_id)

@@ -214,6 +214,32 @@ class ORBmatcher:
                                                       C.byref(nm), self.device_id))
         return m12, prev, nm.value
 
+    def SearchByProjectionKeyFrame(self, kf_kps, kf_desc, bounds, q, vpMatched=None):
+        """SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:296-404) on projected candidates:
+        q has u, v, radius, level, desc, valid.  Returns (vpMatched as query indices, nmatches)."""
+        k = np.ascontiguousarray(kf_kps, KP_DTYPE); d = np.ascontiguousarray(kf_desc, np.uint8)
+        m = np.full(len(k), -1, np.int32) if vpMatched is None else np.ascontiguousarray(vpMatched, np.int32).copy()
+        t = dict(u=np.float32, v=np.float32, radius=np.float32, level=np.int32, desc=np.uint8, valid=np.uint8)
+        qq = {a: np.ascontiguousarray(q[a], b) for a, b in t.items()}
+        nm = C.c_int(0); bd = Bounds(*bounds)
+        check(self._lib.ivf_search_keyframe_points(ptr(k), ptr(d), len(k), C.byref(bd), len(qq["u"]), ptr(qq["u"]), ptr(qq["v"]),
+                                                   ptr(qq["radius"]), ptr(qq["level"]), ptr(qq["desc"]), ptr(qq["valid"]), ptr(m),
+                                                   C.byref(nm), self.device_id))
+        return m, nm.value
+
+    def FuseCandidates(self, kf_kps, kf_desc, kf_uright, bounds, mvInvLevelSigma2, q):
+        """Matching core of Fuse(KeyFrame*, vpMapPoints, th) (ORBmatcher.cc:893-955): q has u, v, ur, radius, level, desc,
+        valid.  Returns (best_idx, best_dist) per map point; -1 = nothing within TH_LOW."""
+        k = np.ascontiguousarray(kf_kps, KP_DTYPE); d = np.ascontiguousarray(kf_desc, np.uint8)
+        ur = np.ascontiguousarray(kf_uright, np.float32); sg = np.ascontiguousarray(mvInvLevelSigma2, np.float32)
+        t = dict(u=np.float32, v=np.float32, ur=np.float32, radius=np.float32, level=np.int32, desc=np.uint8, valid=np.uint8)
+        qq = {a: np.ascontiguousarray(q[a], b) for a, b in t.items()}
+        n = len(qq["u"]); bi = np.full(n, -1, np.int32); bdist = np.full(n, 256, np.int32); bd = Bounds(*bounds)
+        check(self._lib.ivf_fuse_candidates(ptr(k), ptr(d), ptr(ur), len(k), C.byref(bd), ptr(sg), len(sg), n, ptr(qq["u"]),
+                                            ptr(qq["v"]), ptr(qq["ur"]), ptr(qq["radius"]), ptr(qq["level"]), ptr(qq["desc"]),
+                                            ptr(qq["valid"]), ptr(bi), ptr(bdist), self.device_id))
+        return bi, bdist
+
 
 def ComputeDistinctiveDescriptors(vDescriptors, device_id=0):
     """MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312) on the observed descriptors [n,32]:

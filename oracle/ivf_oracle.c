@@ -1120,6 +1120,85 @@ int orc_search_for_initialization(const orc_keypoint* k1, const uint8_t* d1, int
     return 0;
 }
 
+/* f3  ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (ORB/src/ORBmatcher.cc:296-404) on
+ * already-projected candidates (the caller runs :318-365: Sim3 transform, depth / image / distance / viewing-angle tests,
+ * PredictScale).  Per query: window KeyFrame::GetFeaturesInArea(u, v, radius) (no level arguments, KeyFrame.cc:606-645),
+ * candidates already holding a map point are skipped (:379-380), octave in [level-1, level] (:384-385), first minimum,
+ * accepted when <= TH_LOW (:399-403).  matched[idx]: in/out, -1 free, -2 occupied on entry, >= 0 query index. */
+int orc_search_keyframe_points(const orc_keypoint* kf_kps, const uint8_t* kf_desc, int n_kf, const orc_bounds* bounds,
+                               int n_q, const float* q_u, const float* q_v, const float* q_radius, const int32_t* q_level,
+                               const uint8_t* q_desc, const uint8_t* q_valid, int32_t* matched, int* nmatches_out)
+{
+    enum { TH_LOW = 50 };
+    int nmatches = 0;
+    grid_t g;
+    grid_build(&g, kf_kps, n_kf, bounds);
+    int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (n_kf > 0 ? n_kf : 1));
+    for (int i = 0; i < n_q; i++) {
+        if (q_valid && !q_valid[i]) continue;
+        const int nc = grid_query(&g, kf_kps, bounds, q_u[i], q_v[i], q_radius[i], -1, -1, cand, n_kf);
+        int bestDist = 256, bestIdx = -1;
+        for (int k = 0; k < nc; k++) {
+            const int idx = cand[k];
+            if (matched[idx] != -1) continue;
+            const int kpLevel = kf_kps[idx].octave;
+            if (kpLevel < q_level[i] - 1 || kpLevel > q_level[i]) continue;
+            const int dist = orc_hamming256(q_desc + (size_t)i * 32, kf_desc + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) { matched[bestIdx] = i; nmatches++; }
+    }
+    free(cand);
+    grid_free(&g);
+    *nmatches_out = nmatches;
+    return 0;
+}
+
+/* f4  ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (ORB/src/ORBmatcher.cc:831-982), the matching core :893-955 on
+ * already-projected map points: window, octave in [level-1, level], chi-square gate on the reprojection error with
+ * mvInvLevelSigma2 (7.8 with a right coordinate, 5.99 without, :918-938), first minimum; best_idx = -1 unless
+ * best_dist <= TH_LOW.  The Replace / AddObservation bookkeeping (:958-977) stays with the caller. */
+int orc_fuse_candidates(const orc_keypoint* kf_kps, const uint8_t* kf_desc, const float* kf_uright, int n_kf,
+                        const orc_bounds* bounds, const float* inv_level_sigma2,
+                        int n_q, const float* q_u, const float* q_v, const float* q_ur, const float* q_radius,
+                        const int32_t* q_level, const uint8_t* q_desc, const uint8_t* q_valid,
+                        int32_t* best_idx, int32_t* best_dist)
+{
+    enum { TH_LOW = 50 };
+    grid_t g;
+    grid_build(&g, kf_kps, n_kf, bounds);
+    int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (n_kf > 0 ? n_kf : 1));
+    for (int i = 0; i < n_q; i++) {
+        best_idx[i] = -1; best_dist[i] = 256;
+        if (q_valid && !q_valid[i]) continue;
+        const float u = q_u[i], v = q_v[i], ur = q_ur[i];
+        const int nc = grid_query(&g, kf_kps, bounds, u, v, q_radius[i], -1, -1, cand, n_kf);
+        int bestDist = 256, bestIdx = -1;
+        for (int k = 0; k < nc; k++) {
+            const int idx = cand[k];
+            const orc_keypoint* kp = &kf_kps[idx];
+            const int kpLevel = kp->octave;
+            if (kpLevel < q_level[i] - 1 || kpLevel > q_level[i]) continue;
+            if (kf_uright[idx] >= 0) {
+                const float ex = u - kp->x, ey = v - kp->y, er = ur - kf_uright[idx];
+                const float e2 = ex * ex + ey * ey + er * er;
+                if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+            } else {
+                const float ex = u - kp->x, ey = v - kp->y;
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+            }
+            const int dist = orc_hamming256(q_desc + (size_t)i * 32, kf_desc + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        best_dist[i] = bestDist;
+        if (bestDist <= TH_LOW) best_idx[i] = bestIdx;
+    }
+    free(cand);
+    grid_free(&g);
+    return 0;
+}
+
 /* f2  MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): among n observed descriptors the one with
  * the least median Hamming distance to the rest; median = sorted row [ (int)(0.5*(n-1)) ] (the row holds the 0 of the
  * diagonal), first minimum wins (:294-305). */

@@ -115,6 +115,16 @@ int   orc_search_for_initialization(const orc_keypoint* k1, const uint8_t* d1, i
                                     const orc_keypoint* k2, const uint8_t* d2, int n2, const orc_bounds* bounds2,
                                     float* prev_xy, int window_size, float nn_ratio, int check_orientation,
                                     int32_t* matches12, int* nmatches);
+/* ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (ORB/src/ORBmatcher.cc:296-404), flat queries */
+int   orc_search_keyframe_points(const orc_keypoint* kf_kps, const uint8_t* kf_desc, int n_kf, const orc_bounds* bounds,
+                                 int n_q, const float* q_u, const float* q_v, const float* q_radius, const int32_t* q_level,
+                                 const uint8_t* q_desc, const uint8_t* q_valid, int32_t* matched, int* nmatches);
+/* ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) matching core (ORB/src/ORBmatcher.cc:893-955), flat queries */
+int   orc_fuse_candidates(const orc_keypoint* kf_kps, const uint8_t* kf_desc, const float* kf_uright, int n_kf,
+                          const orc_bounds* bounds, const float* inv_level_sigma2,
+                          int n_q, const float* q_u, const float* q_v, const float* q_ur, const float* q_radius,
+                          const int32_t* q_level, const uint8_t* q_desc, const uint8_t* q_valid,
+                          int32_t* best_idx, int32_t* best_dist);
 /* MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): index of the least-median descriptor */
 int   orc_distinctive_descriptor(const uint8_t* desc, int n, int* best_idx, int* best_median);
 /* ORBmatcher::UpdateQualityScores(Frame&) (ORB/src/ORBmatcher.cc:1108-1121) */

@@ -81,6 +81,8 @@ lib.orc_update_quality_scores.argtypes = [vp, C.c_int, vp, vp]
 lib.orc_search_for_initialization.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, C.c_float, C.c_int,
                                               vp, C.POINTER(C.c_int)]
 lib.orc_distinctive_descriptor.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+lib.orc_search_keyframe_points.argtypes = [vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int)]
+lib.orc_fuse_candidates.argtypes = [vp, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
 pin.stl_retain_best.restype = C.c_int; pin.stl_retain_best.argtypes = [vp, C.c_int, C.c_int]
 pin.stl_nth_element.argtypes = [vp, C.c_int, C.c_int]
 
@@ -254,3 +256,27 @@ def distinctive_descriptor(desc):
     rc = lib.orc_distinctive_descriptor(ptr(d), len(d), C.byref(bi), C.byref(bm))
     assert rc == 0
     return bi.value, bm.value
+
+
+def search_keyframe_points(kf_kps, kf_desc, bounds, q, matched=None):
+    """q: dict with u, v, radius, level, desc, valid -> (vpMatched as query indices, nmatches)."""
+    k = np.ascontiguousarray(kf_kps); d = np.ascontiguousarray(kf_desc, np.uint8)
+    m = np.full(len(k), -1, np.int32) if matched is None else np.ascontiguousarray(matched, np.int32).copy()
+    t = dict(u=np.float32, v=np.float32, radius=np.float32, level=np.int32, desc=np.uint8, valid=np.uint8)
+    qq = {a: np.ascontiguousarray(q[a], b) for a, b in t.items()}
+    nm = C.c_int(0); bd = Bounds(*bounds)
+    lib.orc_search_keyframe_points(ptr(k), ptr(d), len(k), C.byref(bd), len(qq["u"]), ptr(qq["u"]), ptr(qq["v"]), ptr(qq["radius"]),
+                                   ptr(qq["level"]), ptr(qq["desc"]), ptr(qq["valid"]), ptr(m), C.byref(nm))
+    return m, nm.value
+
+
+def fuse_candidates(kf_kps, kf_desc, kf_uright, bounds, inv_level_sigma2, q):
+    """q: dict with u, v, ur, radius, level, desc, valid -> (best_idx, best_dist) per query."""
+    k = np.ascontiguousarray(kf_kps); d = np.ascontiguousarray(kf_desc, np.uint8)
+    ur = np.ascontiguousarray(kf_uright, np.float32); sg = np.ascontiguousarray(inv_level_sigma2, np.float32)
+    t = dict(u=np.float32, v=np.float32, ur=np.float32, radius=np.float32, level=np.int32, desc=np.uint8, valid=np.uint8)
+    qq = {a: np.ascontiguousarray(q[a], b) for a, b in t.items()}
+    n = len(qq["u"]); bi = np.full(n, -1, np.int32); bdist = np.full(n, 256, np.int32); bd = Bounds(*bounds)
+    lib.orc_fuse_candidates(ptr(k), ptr(d), ptr(ur), len(k), C.byref(bd), ptr(sg), n, ptr(qq["u"]), ptr(qq["v"]), ptr(qq["ur"]),
+                            ptr(qq["radius"]), ptr(qq["level"]), ptr(qq["desc"]), ptr(qq["valid"]), ptr(bi), ptr(bdist))
+    return bi, bdist

@@ -266,6 +266,25 @@ def test_search_for_initialization_and_distinctive_descriptor(iv):
         assert iv.ComputeDistinctiveDescriptors(obs) == O.distinctive_descriptor(obs)
     with pytest.raises(AssertionError):
         iv.ComputeDistinctiveDescriptors(np.zeros((0, 32), np.uint8))
+    # SearchByProjection(KF, Scw) and the Fuse core on perturbed projections of frame 2's own keypoints
+    nq = len(k2); oct2 = k2["octave"]; sc = g.GetScaleFactors(); inv_s2 = g.GetInverseScaleSigmaSquares()
+    qd = d2.copy()
+    for i in range(nq):
+        for bpos in rng.integers(0, 256, rng.integers(0, 40)):
+            qd[i, bpos // 8] ^= np.uint8(1 << (bpos % 8))
+    q = dict(u=(k2["x"] + rng.uniform(-2, 2, nq)).astype(np.float32), v=(k2["y"] + rng.uniform(-2, 2, nq)).astype(np.float32),
+             ur=(k2["x"] - 15 + rng.uniform(-2, 2, nq)).astype(np.float32), radius=(4 * sc[oct2]).astype(np.float32),
+             level=np.clip(oct2 + rng.integers(-1, 2, nq), 0, 7).astype(np.int32), desc=qd,
+             valid=(rng.uniform(size=nq) > 0.1).astype(np.uint8))
+    pre = np.full(nq, -1, np.int32); pre[rng.integers(0, nq, 40)] = -2
+    m = iv.ORBmatcher(0.75, True)
+    gm, gn = m.SearchByProjectionKeyFrame(k2, d2, bounds, q, pre)
+    om, on = O.search_keyframe_points(k2, d2, bounds, q, pre)
+    assert gn == on and np.array_equal(gm, om) and gn > nq // 5
+    ur2 = np.where(rng.uniform(size=nq) > 0.4, k2["x"] - 15, -1).astype(np.float32)
+    gb, gd = m.FuseCandidates(k2, d2, ur2, bounds, inv_s2, q)
+    ob, od = O.fuse_candidates(k2, d2, ur2, bounds, inv_s2, q)
+    assert np.array_equal(gb, ob) and np.array_equal(gd, od) and (gb >= 0).sum() > nq // 5
 
 
 def test_full_size_properties(iv):

@@ -230,3 +230,38 @@ def test_distinctive_descriptor_is_least_median():
         med = np.sort(D, axis=1)[:, int(0.5 * (n - 1))]
         bi, bm = O.distinctive_descriptor(d)
         assert bm == med.min() and bi == int(np.argmin(med))          # first minimum
+
+
+def test_keyframe_projection_search_and_fuse_core():
+    """f3 SearchByProjection(KF, Scw) (ORBmatcher.cc:296-404) and f4 Fuse core (:893-955) on flat queries."""
+    img = synth.make_left(640, 240, seed=23, idx=0)
+    ext = O.Extractor(500, 1.2, 8, 20, 7)
+    kps, desc = ext(img)
+    n = len(kps); sc = ext.tables()["scale"]; inv_s2 = ext.tables()["inv_sigma2"]
+    bounds = (0, 0, 640, 240)
+    q = dict(u=kps["x"].copy(), v=kps["y"].copy(), radius=(3 * sc[kps["octave"]]).astype(np.float32),
+             level=kps["octave"].astype(np.int32), desc=desc.copy(), valid=np.ones(n, np.uint8))
+    m, nm = O.search_keyframe_points(kps, desc, bounds, q)
+    assert nm == (m >= 0).sum() and nm > 0.9 * n and (m[m >= 0] == np.nonzero(m >= 0)[0]).mean() > 0.95
+    # occupied keypoints are never taken (:379-380); the level window is [pred-1, pred] (:384-385)
+    pre = np.full(n, -1, np.int32); pre[::3] = -2
+    m2, nm2 = O.search_keyframe_points(kps, desc, bounds, q, pre)
+    assert (m2[::3] == -2).all() and nm2 < nm
+    q1 = dict(q); q1["level"] = (kps["octave"] + 1).astype(np.int32)
+    q2 = dict(q); q2["level"] = (kps["octave"] + 2).astype(np.int32)
+    m1, nm1 = O.search_keyframe_points(kps, desc, bounds, q1); m2b, nm2b = O.search_keyframe_points(kps, desc, bounds, q2)
+    assert nm1 > 0.5 * n and nm2b < nm1                  # own octave inside [pred-1, pred] for pred = octave+1, outside for +2
+    assert (kps["octave"][np.nonzero(m2b >= 0)[0]] >= kps["octave"][m2b[m2b >= 0]] + 1).all()
+    # TH_LOW
+    qf = dict(q); df = desc.copy(); df[:, :8] ^= np.uint8(0xFF); qf["desc"] = df
+    assert O.search_keyframe_points(kps, desc, bounds, qf)[1] == 0
+    # Fuse core: exact projections fuse with themselves; the chi-square gate rejects a projection 3 px off at level 0
+    # (9 * 1 > 5.99) but keeps it at level 4 (9 / 1.2^8 = 2.1) -- mono (no right coordinate) and stereo (7.8) alike
+    ur = np.where(np.arange(n) % 2 == 0, kps["x"] - 20, -1).astype(np.float32)
+    qz = dict(q); qz["ur"] = (kps["x"] - 20).astype(np.float32); qz["radius"] = (6 * sc[kps["octave"]]).astype(np.float32)
+    bi, bdist = O.fuse_candidates(kps, desc, ur, bounds, inv_s2, qz)
+    assert (bi == np.arange(n)).mean() > 0.95 and (bdist[bi >= 0] == 0).all()
+    qo = dict(qz); qo["u"] = (kps["x"] + 3).astype(np.float32); qo["ur"] = (kps["x"] + 3 - 20).astype(np.float32)
+    bo, _ = O.fuse_candidates(kps, desc, ur, bounds, inv_s2, qo)
+    lvl = kps["octave"]
+    assert (bo[lvl == 0] == np.arange(n)[lvl == 0]).mean() < 0.05 and (bo[lvl >= 4] == np.arange(n)[lvl >= 4]).mean() > 0.9
