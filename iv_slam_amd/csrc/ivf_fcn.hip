@@ -334,8 +334,13 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
 // differs from run to run as soon as the grid is large enough for two of them to share a CU, with any amount of LDS slack
 // (50..80 KB per workgroup, static or dynamic), with extra barriers after every phase, with a full s_waitcnt after the
 // constant prefetch and with all waves kept alive to the end; a SINGLE 32-channel chunk is clean, two or more are not;
-// one workgroup per CU is bit-exact and deterministic at every batch size.  The cause was not found (the kernel has no
-// scratch, only ds_* LDS instructions, and its barrier protocol is the one k_fcn_dwpw uses).  Until it is, the launcher
+// one workgroup per CU is bit-exact and deterministic at every batch size.  Localisation so far (IVF_FCN_BLOCK_XBAR bits,
+// each publishing a per-thread checksum instead of the block output): the expansion results written to sH are
+// deterministic (64), so are the prefetched depthwise parameters before (512) and after (2048) the stencil, and the
+// stencil with unit weights (256|32); the stencil's OUTPUT is not -- even with constant inputs instead of LDS reads
+// (1024|32), with private copies of the weights (4096) and with scalar instead of packed FMAs.  Declared VGPR / SGPR
+// counts match the ISA, there is no scratch, only ds_* LDS instructions, and the barrier protocol is the one
+// k_fcn_dwpw uses.  The cause was not found.  Until it is, the launcher
 // adds 40 KB of unused dynamic LDS so that a CU never holds two of them (IVF_FCN_BLOCK_CORESIDENT=1 lifts that for
 // debugging; IVF_FCN_BLOCK_XBAR holds the experiment switches), which costs the occupancy the kernel was designed
 // around -- see the measured default in launch_block.
@@ -430,6 +435,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ 
     f32x16 accO;
 #pragma unroll
     for (int q = 0; q < 16; q++) accO[q] = 0.f;
+    float dbgSum = 0.f;
     __syncthreads();
 
     // per-chunk constants (expansion / projection A fragments, this thread's depthwise parameters) are fetched one
@@ -498,6 +504,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ 
                         v2f v = __builtin_elementwise_fma((v2f){acc[i][q], acc[i][q + 1]}, sc, sh);
                         v.x = __builtin_amdgcn_fmed3f(v.x, 0.f, 6.f); v.y = __builtin_amdgcn_fmed3f(v.y, 0.f, 6.f);
                         v = v * (v2f){pm[i], pm[i]};
+                        if (xbar & 64) dbgSum += v.x + v.y;
                         sH[ro * HP + 32 * pt + col] = v.x;
                         sH[(ro + 1) * HP + 32 * pt + col] = v.y;
                     }
@@ -507,7 +514,10 @@ __global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ 
         }
         // ---- phase 2: 3x3 depthwise + BN + ReLU6 out of LDS
         {
-            const float wk[9] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x};
+            float wk[9] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x};
+            if (xbar & 256) { for (int k = 0; k < 9; k++) wk[k] = 1.f; }      // experiment: parameters out of the picture
+            if (xbar & 512) { for (int k = 0; k < 9; k++) dbgSum += wk[k]; dbgSum += p2.y + p2.z; }
+            if (xbar & 4096) { for (int k = 0; k < 9; k++) asm volatile("" : "+v"(wk[k])); }     // experiment: private copies
             v2f o[NOUT / 2];
 #pragma unroll
             for (int i = 0; i < NOUT / 2; i++) o[i] = (v2f){0.f, 0.f};
@@ -516,7 +526,13 @@ __global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ 
                 // the row start is 8-byte aligned for S = 1 (34-float rows, even columns): 64-bit LDS reads
                 const float* row = sH + chl * HP + (sr * S + ky) * IWq + sc0 * S;
                 float in[NIN + 1];
-                if (S == 1) {
+                if (xbar & 1024) {                // experiment: no LDS reads at all
+#pragma unroll
+                    for (int i = 0; i < NIN; i++) in[i] = 1.f + 0.001f * (float)(i + ky);
+                } else if (xbar & 128) {          // experiment: one plain ds_read_b32 per element (no ds_read2 / b64 merging)
+#pragma unroll
+                    for (int i = 0; i < NIN; i++) { const float* rp = row + i; asm volatile("" : "+v"(rp)); in[i] = *rp; }
+                } else if (S == 1) {
 #pragma unroll
                     for (int i = 0; i < NIN; i += 2) { const float2 t = *(const float2*)(row + i); in[i] = t.x; in[i + 1] = t.y; }
                 } else {
@@ -525,13 +541,20 @@ __global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ 
                 }
 #pragma unroll
                 for (int kx = 0; kx < 3; kx++) {
-                    const v2f w = (v2f){wk[ky * 3 + kx], wk[ky * 3 + kx]};
+                    const float w = wk[ky * 3 + kx];
 #pragma unroll
-                    for (int i = 0; i < NOUT; i += 2)
-                        o[i / 2] = __builtin_elementwise_fma((v2f){in[i * S + kx], in[(i + 1) * S + kx]}, w, o[i / 2]);
+                    for (int i = 0; i < NOUT; i += 2) {
+                        o[i / 2].x = __builtin_fmaf(in[i * S + kx], w, o[i / 2].x);
+                        o[i / 2].y = __builtin_fmaf(in[(i + 1) * S + kx], w, o[i / 2].y);
+                    }
                 }
             }
             float* dst = sD + chl * DP + sr * 32 + sc0;
+            if (xbar & 2048) { for (int k = 0; k < 9; k++) dbgSum += wk[k]; }                     // experiment: weights AFTER the FMAs
+            if (xbar & 32) {
+#pragma unroll
+                for (int i = 0; i < NOUT / 2; i++) dbgSum += o[i].x + o[i].y;
+            }
             const v2f bs = (v2f){p2.y, p2.y}, bb = (v2f){p2.z, p2.z};
 #pragma unroll
             for (int i = 0; i < NOUT; i += 4) {
@@ -563,6 +586,10 @@ __global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ 
     for (int ck = 0; ck < nChunks; ck += 2) {
         chunk(PA, PB, ck);
         if (ck + 1 < nChunks) chunk(PB, PA, ck + 1);
+    }
+    if (xbar & (96 | 512 | 2048)) {                        // debug: publish the stencil sums instead of the block output
+        Y[((size_t)b * Cout + (tid >> 5)) * ((size_t)Ho * Wo) + (size_t)oy0 * Wo + ox0 + (tid & 31)] = dbgSum;
+        return;
     }
     if (xbar & 4) {                                 // debug: publish what phase 3 saw
         if (wave < TOH) for (int q = 0; q < 16; q++) if (accO[q] != accO[q]) Y[0] = 1.f;
