@@ -236,7 +236,9 @@ int  ivf_search_keyframe_points(const ivf_keypoint* kf_kps, const uint8_t* kf_de
 /* ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (ORB/src/ORBmatcher.cc:831-982): the matching core :893-955 on projected
  * map points (u, v, ur = u - bf*invz, radius, level as above); kf_uright = mvuRight, inv_level_sigma2 = mvInvLevelSigma2.
  * best_idx[i] = the keypoint to fuse query i with (-1: none within TH_LOW), best_dist[i] (nullable) its distance.  The
- * Replace / AddObservation bookkeeping (:958-977) stays with the caller, in query order. */
+ * Replace / AddObservation bookkeeping (:958-977) stays with the caller, in query order.
+ * inv_level_sigma2 == NULL selects the core of Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) (:983-1106), which
+ * has no reprojection gate (kf_uright and q_ur may then be NULL as well). */
 int  ivf_fuse_candidates(const ivf_keypoint* kf_kps, const uint8_t* kf_desc, const float* kf_uright, int n_kf,
                          const ivf_bounds* bounds, const float* inv_level_sigma2, int n_levels,
                          int n_q, const float* q_u, const float* q_v, const float* q_ur, const float* q_radius,

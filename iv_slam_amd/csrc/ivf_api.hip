@@ -818,24 +818,27 @@ int ivf_fuse_candidates(const ivf_keypoint* kf_kps, const uint8_t* kf_desc, cons
                         const int32_t* q_level, const uint8_t* q_desc, const uint8_t* q_valid,
                         int32_t* best_idx, int32_t* best_dist, int device_id)
 {
-    if (!kf_kps || !kf_desc || !kf_uright || !bounds || !inv_level_sigma2 || !best_idx || n_kf < 0 || n_q < 0 || n_levels < 1)
-        return fail(IVF_E_INVALID, "bad argument");
+    if (!kf_kps || !kf_desc || !bounds || !best_idx || n_kf < 0 || n_q < 0) return fail(IVF_E_INVALID, "bad argument");
+    const bool gate = inv_level_sigma2 != nullptr;               // NULL: Fuse(KF, Scw, ...) (:983-1106) has no chi-square gate
+    if (gate && (!kf_uright || !q_ur || n_levels < 1)) return fail(IVF_E_INVALID, "the chi-square gate needs mvuRight, ur and the sigma table");
     for (int i = 0; i < n_q; i++) { best_idx[i] = -1; if (best_dist) best_dist[i] = 256; }
     if (n_q == 0 || n_kf == 0) return IVF_OK;
-    if (!q_u || !q_v || !q_ur || !q_radius || !q_level || !q_desc) return fail(IVF_E_INVALID, "null query array");
-    for (int i = 0; i < n_kf; i++)
-        if (kf_kps[i].octave < 0 || kf_kps[i].octave >= n_levels) return fail(IVF_E_INVALID, "keypoint %d: octave outside the sigma table", i);
+    if (!q_u || !q_v || !q_radius || !q_level || !q_desc) return fail(IVF_E_INVALID, "null query array");
+    if (gate)
+        for (int i = 0; i < n_kf; i++)
+            if (kf_kps[i].octave < 0 || kf_kps[i].octave >= n_levels) return fail(IVF_E_INVALID, "keypoint %d: octave outside the sigma table", i);
     Grid g; g.build(kf_kps, n_kf, *bounds);
     std::vector<int> qStart(n_q + 1, 0), pairs;
     for (int i = 0; i < n_q; i++) {
         qStart[i] = (int)pairs.size() / 2;
         if (q_valid && !q_valid[i]) continue;
-        const float u = q_u[i], v = q_v[i], ur = q_ur[i];
+        const float u = q_u[i], v = q_v[i], ur = q_ur ? q_ur[i] : 0.0f;
         g.query(kf_kps, *bounds, u, v, q_radius[i], -1, -1, [&](int idx) {
             const ivf_keypoint& kp = kf_kps[idx];
             const int l = kp.octave;
             if (l < q_level[i] - 1 || l > q_level[i]) return;
-            if (kf_uright[idx] >= 0) {                               // chi-square gates (:918-938), f32 products compared in double
+            if (!gate) {
+            } else if (kf_uright[idx] >= 0) {                               // chi-square gates (:918-938), f32 products compared in double
                 const float ex = u - kp.x, ey = v - kp.y, er = ur - kf_uright[idx];
                 const float e2 = ex * ex + ey * ey + er * er;
                 if (e2 * inv_level_sigma2[l] > 7.8) return;

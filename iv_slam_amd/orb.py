@@ -231,11 +231,15 @@ class ORBmatcher:
         """Matching core of Fuse(KeyFrame*, vpMapPoints, th) (ORBmatcher.cc:893-955): q has u, v, ur, radius, level, desc,
         valid.  Returns (best_idx, best_dist) per map point; -1 = nothing within TH_LOW."""
         k = np.ascontiguousarray(kf_kps, KP_DTYPE); d = np.ascontiguousarray(kf_desc, np.uint8)
-        ur = np.ascontiguousarray(kf_uright, np.float32); sg = np.ascontiguousarray(mvInvLevelSigma2, np.float32)
-        t = dict(u=np.float32, v=np.float32, ur=np.float32, radius=np.float32, level=np.int32, desc=np.uint8, valid=np.uint8)
+        gate = mvInvLevelSigma2 is not None          # None: Fuse(KF, Scw, ...) (:983-1106), no reprojection gate
+        ur = np.ascontiguousarray(kf_uright, np.float32) if gate else None
+        sg = np.ascontiguousarray(mvInvLevelSigma2, np.float32) if gate else None
+        t = dict(u=np.float32, v=np.float32, radius=np.float32, level=np.int32, desc=np.uint8, valid=np.uint8)
+        if gate: t["ur"] = np.float32
         qq = {a: np.ascontiguousarray(q[a], b) for a, b in t.items()}
+        qq.setdefault("ur", None)
         n = len(qq["u"]); bi = np.full(n, -1, np.int32); bdist = np.full(n, 256, np.int32); bd = Bounds(*bounds)
-        check(self._lib.ivf_fuse_candidates(ptr(k), ptr(d), ptr(ur), len(k), C.byref(bd), ptr(sg), len(sg), n, ptr(qq["u"]),
+        check(self._lib.ivf_fuse_candidates(ptr(k), ptr(d), ptr(ur), len(k), C.byref(bd), ptr(sg), len(sg) if gate else 0, n, ptr(qq["u"]),
                                             ptr(qq["v"]), ptr(qq["ur"]), ptr(qq["radius"]), ptr(qq["level"]), ptr(qq["desc"]),
                                             ptr(qq["valid"]), ptr(bi), ptr(bdist), self.device_id))
         return bi, bdist

@@ -1157,7 +1157,8 @@ int orc_search_keyframe_points(const orc_keypoint* kf_kps, const uint8_t* kf_des
 /* f4  ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (ORB/src/ORBmatcher.cc:831-982), the matching core :893-955 on
  * already-projected map points: window, octave in [level-1, level], chi-square gate on the reprojection error with
  * mvInvLevelSigma2 (7.8 with a right coordinate, 5.99 without, :918-938), first minimum; best_idx = -1 unless
- * best_dist <= TH_LOW.  The Replace / AddObservation bookkeeping (:958-977) stays with the caller. */
+ * best_dist <= TH_LOW.  inv_level_sigma2 == NULL (then kf_uright / q_ur may be NULL too): the core of
+ * Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) (:983-1106, :1064-1084), which has no gate.  The Replace / AddObservation bookkeeping (:958-977) stays with the caller. */
 int orc_fuse_candidates(const orc_keypoint* kf_kps, const uint8_t* kf_desc, const float* kf_uright, int n_kf,
                         const orc_bounds* bounds, const float* inv_level_sigma2,
                         int n_q, const float* q_u, const float* q_v, const float* q_ur, const float* q_radius,
@@ -1171,7 +1172,7 @@ int orc_fuse_candidates(const orc_keypoint* kf_kps, const uint8_t* kf_desc, cons
     for (int i = 0; i < n_q; i++) {
         best_idx[i] = -1; best_dist[i] = 256;
         if (q_valid && !q_valid[i]) continue;
-        const float u = q_u[i], v = q_v[i], ur = q_ur[i];
+        const float u = q_u[i], v = q_v[i], ur = q_ur ? q_ur[i] : 0.0f;
         const int nc = grid_query(&g, kf_kps, bounds, u, v, q_radius[i], -1, -1, cand, n_kf);
         int bestDist = 256, bestIdx = -1;
         for (int k = 0; k < nc; k++) {
@@ -1179,7 +1180,9 @@ int orc_fuse_candidates(const orc_keypoint* kf_kps, const uint8_t* kf_desc, cons
             const orc_keypoint* kp = &kf_kps[idx];
             const int kpLevel = kp->octave;
             if (kpLevel < q_level[i] - 1 || kpLevel > q_level[i]) continue;
-            if (kf_uright[idx] >= 0) {
+            if (!inv_level_sigma2) {
+                /* Fuse(KF, Scw, ...) (:983-1106): no reprojection gate */
+            } else if (kf_uright[idx] >= 0) {
                 const float ex = u - kp->x, ey = v - kp->y, er = ur - kf_uright[idx];
                 const float e2 = ex * ex + ey * ey + er * er;
                 if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;

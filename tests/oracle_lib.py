@@ -273,9 +273,13 @@ def search_keyframe_points(kf_kps, kf_desc, bounds, q, matched=None):
 def fuse_candidates(kf_kps, kf_desc, kf_uright, bounds, inv_level_sigma2, q):
     """q: dict with u, v, ur, radius, level, desc, valid -> (best_idx, best_dist) per query."""
     k = np.ascontiguousarray(kf_kps); d = np.ascontiguousarray(kf_desc, np.uint8)
-    ur = np.ascontiguousarray(kf_uright, np.float32); sg = np.ascontiguousarray(inv_level_sigma2, np.float32)
-    t = dict(u=np.float32, v=np.float32, ur=np.float32, radius=np.float32, level=np.int32, desc=np.uint8, valid=np.uint8)
+    gate = inv_level_sigma2 is not None
+    ur = np.ascontiguousarray(kf_uright, np.float32) if gate else None
+    sg = np.ascontiguousarray(inv_level_sigma2, np.float32) if gate else None
+    t = dict(u=np.float32, v=np.float32, radius=np.float32, level=np.int32, desc=np.uint8, valid=np.uint8)
+    if gate: t["ur"] = np.float32
     qq = {a: np.ascontiguousarray(q[a], b) for a, b in t.items()}
+    qq.setdefault("ur", None)
     n = len(qq["u"]); bi = np.full(n, -1, np.int32); bdist = np.full(n, 256, np.int32); bd = Bounds(*bounds)
     lib.orc_fuse_candidates(ptr(k), ptr(d), ptr(ur), len(k), C.byref(bd), ptr(sg), n, ptr(qq["u"]), ptr(qq["v"]), ptr(qq["ur"]),
                             ptr(qq["radius"]), ptr(qq["level"]), ptr(qq["desc"]), ptr(qq["valid"]), ptr(bi), ptr(bdist))

@@ -285,6 +285,9 @@ def test_search_for_initialization_and_distinctive_descriptor(iv):
     gb, gd = m.FuseCandidates(k2, d2, ur2, bounds, inv_s2, q)
     ob, od = O.fuse_candidates(k2, d2, ur2, bounds, inv_s2, q)
     assert np.array_equal(gb, ob) and np.array_equal(gd, od) and (gb >= 0).sum() > nq // 5
+    gb2, gd2 = m.FuseCandidates(k2, d2, None, bounds, None, q)              # Fuse(KF, Scw, ...): no chi-square gate
+    ob2, od2 = O.fuse_candidates(k2, d2, None, bounds, None, q)
+    assert np.array_equal(gb2, ob2) and np.array_equal(gd2, od2) and (gb2 >= 0).sum() >= (gb >= 0).sum()
 
 
 def test_full_size_properties(iv):
