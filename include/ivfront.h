@@ -244,6 +244,17 @@ int  ivf_fuse_candidates(const ivf_keypoint* kf_kps, const uint8_t* kf_desc, con
                          int n_q, const float* q_u, const float* q_v, const float* q_ur, const float* q_radius,
                          const int32_t* q_level, const uint8_t* q_desc, const uint8_t* q_valid,
                          int32_t* best_idx, int32_t* best_dist, int device_id);
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (ORB/src/ORBmatcher.cc:1145-1254).  The caller
+ * projects KF1's map points that are still unmatched into KF2 (:1193-1230) -> per keypoint slot i1 of KF1: q12_valid,
+ * u, v, radius = th * mvScaleFactors[level], level = nPredictedLevel, the map point descriptor; and KF2's into KF1
+ * (:1273-1310) -> q21_*.  matches12[i1] = keypoint index in KF2 when both directions agree (:1336-1349), else -1;
+ * *nfound = return value.  (vpMatches12[i1] = vpMapPoints2[matches12[i1]] is the caller's last step.) */
+int  ivf_search_by_sim3(const ivf_keypoint* kps1, const uint8_t* desc1, int n1, const ivf_bounds* bounds1,
+                        const ivf_keypoint* kps2, const uint8_t* desc2, int n2, const ivf_bounds* bounds2,
+                        const float* q12_u, const float* q12_v, const float* q12_radius, const int32_t* q12_level,
+                        const uint8_t* q12_desc, const uint8_t* q12_valid,
+                        const float* q21_u, const float* q21_v, const float* q21_radius, const int32_t* q21_level,
+                        const uint8_t* q21_desc, const uint8_t* q21_valid, int32_t* matches12, int* nfound, int device_id);
 /* MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): desc = the n observed descriptors (rows of
  * vDescriptors, in mObservations order); *best_index = the row to copy into mDescriptor, *best_median (nullable) its median. */
 int  ivf_distinctive_descriptor(const uint8_t* desc, int n, int* best_index, int* best_median, int device_id);

@@ -65,6 +65,8 @@ _SIGS = {
     "ivf_distinctive_descriptor": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
     "ivf_search_keyframe_points": (C.c_int, [vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp,
                                              C.POINTER(C.c_int), C.c_int]),
+    "ivf_search_by_sim3": (C.c_int, [vp, vp, C.c_int, C.POINTER(Bounds), vp, vp, C.c_int, C.POINTER(Bounds)] + [vp] * 12 +
+                           [vp, C.POINTER(C.c_int), C.c_int]),
     "ivf_fuse_candidates": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
                                       vp, vp, C.c_int]),
     "ivf_test_retain_best": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int]),

@@ -865,6 +865,67 @@ int ivf_fuse_candidates(const ivf_keypoint* kf_kps, const uint8_t* kf_desc, cons
     return IVF_OK;
 }
 
+// ORBmatcher::SearchBySim3 (ORB/src/ORBmatcher.cc:1145-1254) on the two sets of projected map points
+namespace {
+int window_best(const ivf_keypoint* kps, const uint8_t* desc, int n, const ivf_bounds& bd, int n_q, const float* q_u,
+                const float* q_v, const float* q_radius, const int32_t* q_level, const uint8_t* q_desc, const uint8_t* q_valid,
+                int th, int device_id, std::vector<int>& best)
+{
+    best.assign(n_q, -1);
+    if (n_q == 0 || n == 0) return IVF_OK;
+    Grid g; g.build(kps, n, bd);
+    std::vector<int> qStart(n_q + 1, 0), pairs;
+    for (int i = 0; i < n_q; i++) {
+        qStart[i] = (int)pairs.size() / 2;
+        if (q_valid && !q_valid[i]) continue;
+        g.query(kps, bd, q_u[i], q_v[i], q_radius[i], -1, -1, [&](int idx) {
+            if (kps[idx].octave < q_level[i] - 1 || kps[idx].octave > q_level[i]) return;
+            pairs.push_back(i); pairs.push_back(idx);
+        });
+    }
+    qStart[n_q] = (int)pairs.size() / 2;
+    const int nPairs = qStart[n_q];
+    std::vector<int> dist(std::max(nPairs, 1));
+    const int rc = ivf_hamming_pairs(q_desc, n_q, desc, n, pairs.data(), nPairs, dist.data(), device_id);
+    if (rc) return rc;
+    for (int i = 0; i < n_q; i++) {
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (int p = qStart[i]; p < qStart[i + 1]; p++)
+            if (dist[p] < bestDist) { bestDist = dist[p]; bestIdx = pairs[2 * p + 1]; }
+        if (bestDist <= th) best[i] = bestIdx;
+    }
+    return IVF_OK;
+}
+}  // namespace
+
+int ivf_search_by_sim3(const ivf_keypoint* kps1, const uint8_t* desc1, int n1, const ivf_bounds* bounds1,
+                       const ivf_keypoint* kps2, const uint8_t* desc2, int n2, const ivf_bounds* bounds2,
+                       const float* q12_u, const float* q12_v, const float* q12_radius, const int32_t* q12_level,
+                       const uint8_t* q12_desc, const uint8_t* q12_valid,
+                       const float* q21_u, const float* q21_v, const float* q21_radius, const int32_t* q21_level,
+                       const uint8_t* q21_desc, const uint8_t* q21_valid, int32_t* matches12, int* nfound, int device_id)
+{
+    if (!kps1 || !desc1 || !kps2 || !desc2 || !bounds1 || !bounds2 || !matches12 || !nfound || n1 < 0 || n2 < 0)
+        return fail(IVF_E_INVALID, "bad argument");
+    *nfound = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0 || n2 == 0) return IVF_OK;
+    if (!q12_u || !q12_v || !q12_radius || !q12_level || !q12_desc || !q21_u || !q21_v || !q21_radius || !q21_level || !q21_desc)
+        return fail(IVF_E_INVALID, "null query array");
+    std::vector<int> m1, m2;                                      // vnMatch1 / vnMatch2 (:1186-1187), TH_HIGH (:1264, :1344)
+    int rc = window_best(kps2, desc2, n2, *bounds2, n1, q12_u, q12_v, q12_radius, q12_level, q12_desc, q12_valid, 100, device_id, m1);
+    if (rc) return rc;
+    rc = window_best(kps1, desc1, n1, *bounds1, n2, q21_u, q21_v, q21_radius, q21_level, q21_desc, q21_valid, 100, device_id, m2);
+    if (rc) return rc;
+    int nf = 0;
+    for (int i1 = 0; i1 < n1; i1++) {                             // agreement check (:1336-1349)
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && m2[idx2] == i1) { matches12[i1] = idx2; nf++; }
+    }
+    *nfound = nf;
+    return IVF_OK;
+}
+
 // MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): all-pairs Hamming + row medians on the device,
 // first minimum on the host
 int ivf_distinctive_descriptor(const uint8_t* desc, int n, int* best_index, int* best_median, int device_id)

@@ -244,6 +244,22 @@ class ORBmatcher:
                                             ptr(qq["valid"]), ptr(bi), ptr(bdist), self.device_id))
         return bi, bdist
 
+    def SearchBySim3(self, kps1, desc1, bounds1, kps2, desc2, bounds2, q12, q21):
+        """SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (ORBmatcher.cc:1145-1254) on the projected map points:
+        q12 / q21 have u, v, radius, level, desc, valid per keypoint slot of KF1 / KF2.  Returns (matches12, nFound)."""
+        k1 = np.ascontiguousarray(kps1, KP_DTYPE); k2 = np.ascontiguousarray(kps2, KP_DTYPE)
+        d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+        t = dict(u=np.float32, v=np.float32, radius=np.float32, level=np.int32, desc=np.uint8, valid=np.uint8)
+        a = {x: np.ascontiguousarray(q12[x], y) for x, y in t.items()}; b = {x: np.ascontiguousarray(q21[x], y) for x, y in t.items()}
+        if len(a["u"]) != len(k1) or len(b["u"]) != len(k2):
+            raise AssertionError("one query slot per keypoint of each keyframe")
+        m = np.full(len(k1), -1, np.int32); nf = C.c_int(0); bd1 = Bounds(*bounds1); bd2 = Bounds(*bounds2)
+        check(self._lib.ivf_search_by_sim3(ptr(k1), ptr(d1), len(k1), C.byref(bd1), ptr(k2), ptr(d2), len(k2), C.byref(bd2),
+                                           ptr(a["u"]), ptr(a["v"]), ptr(a["radius"]), ptr(a["level"]), ptr(a["desc"]), ptr(a["valid"]),
+                                           ptr(b["u"]), ptr(b["v"]), ptr(b["radius"]), ptr(b["level"]), ptr(b["desc"]), ptr(b["valid"]),
+                                           ptr(m), C.byref(nf), self.device_id))
+        return m, nf.value
+
 
 def ComputeDistinctiveDescriptors(vDescriptors, device_id=0):
     """MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312) on the observed descriptors [n,32]:

@@ -1202,6 +1202,56 @@ int orc_fuse_candidates(const orc_keypoint* kf_kps, const uint8_t* kf_desc, cons
     return 0;
 }
 
+/* f5  ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (ORB/src/ORBmatcher.cc:1145-1254): the
+ * caller projects KF1's unmatched map points into KF2 and vice versa (:1193-1230, :1273-1310); each direction is a
+ * window search with octave in [level-1, level], first minimum, accepted when <= TH_HIGH (:1233-1264); a pair is a
+ * match only when both directions agree (:1336-1349).  matches12[i1] = index in KF2 or -1; returns nFound. */
+static void window_best(const grid_t* g, const orc_keypoint* kps, const uint8_t* desc, int n, const orc_bounds* bd, int n_q,
+                        const float* q_u, const float* q_v, const float* q_radius, const int32_t* q_level, const uint8_t* q_desc,
+                        const uint8_t* q_valid, int th, int32_t* cand, int32_t* best)
+{
+    for (int i = 0; i < n_q; i++) {
+        best[i] = -1;
+        if (q_valid && !q_valid[i]) continue;
+        const int nc = grid_query(g, kps, bd, q_u[i], q_v[i], q_radius[i], -1, -1, cand, n);
+        int bestDist = 2147483647, bestIdx = -1;
+        for (int k = 0; k < nc; k++) {
+            const int idx = cand[k];
+            if (kps[idx].octave < q_level[i] - 1 || kps[idx].octave > q_level[i]) continue;
+            const int dist = orc_hamming256(q_desc + (size_t)i * 32, desc + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= th) best[i] = bestIdx;
+    }
+}
+int orc_search_by_sim3(const orc_keypoint* k1, const uint8_t* d1, int n1, const orc_bounds* b1,
+                       const orc_keypoint* k2, const uint8_t* d2, int n2, const orc_bounds* b2,
+                       const float* q12_u, const float* q12_v, const float* q12_radius, const int32_t* q12_level,
+                       const uint8_t* q12_desc, const uint8_t* q12_valid,
+                       const float* q21_u, const float* q21_v, const float* q21_radius, const int32_t* q21_level,
+                       const uint8_t* q21_desc, const uint8_t* q21_valid, int32_t* matches12, int* nfound)
+{
+    enum { TH_HIGH = 100 };
+    grid_t g1, g2;
+    grid_build(&g1, k1, n1, b1); grid_build(&g2, k2, n2, b2);
+    const int nmax = n1 > n2 ? n1 : n2;
+    int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (nmax > 0 ? nmax : 1));
+    int32_t* m1 = (int32_t*)malloc(sizeof(int32_t) * (n1 > 0 ? n1 : 1));
+    int32_t* m2 = (int32_t*)malloc(sizeof(int32_t) * (n2 > 0 ? n2 : 1));
+    window_best(&g2, k2, d2, n2, b2, n1, q12_u, q12_v, q12_radius, q12_level, q12_desc, q12_valid, TH_HIGH, cand, m1);
+    window_best(&g1, k1, d1, n1, b1, n2, q21_u, q21_v, q21_radius, q21_level, q21_desc, q21_valid, TH_HIGH, cand, m2);
+    int nf = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        matches12[i1] = -1;
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && m2[idx2] == i1) { matches12[i1] = idx2; nf++; }
+    }
+    free(cand); free(m1); free(m2);
+    grid_free(&g1); grid_free(&g2);
+    *nfound = nf;
+    return 0;
+}
+
 /* f2  MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): among n observed descriptors the one with
  * the least median Hamming distance to the rest; median = sorted row [ (int)(0.5*(n-1)) ] (the row holds the 0 of the
  * diagonal), first minimum wins (:294-305). */

@@ -125,6 +125,13 @@ int   orc_fuse_candidates(const orc_keypoint* kf_kps, const uint8_t* kf_desc, co
                           int n_q, const float* q_u, const float* q_v, const float* q_ur, const float* q_radius,
                           const int32_t* q_level, const uint8_t* q_desc, const uint8_t* q_valid,
                           int32_t* best_idx, int32_t* best_dist);
+/* ORBmatcher::SearchBySim3 (ORB/src/ORBmatcher.cc:1145-1254) on the two sets of projected map points */
+int   orc_search_by_sim3(const orc_keypoint* k1, const uint8_t* d1, int n1, const orc_bounds* b1,
+                         const orc_keypoint* k2, const uint8_t* d2, int n2, const orc_bounds* b2,
+                         const float* q12_u, const float* q12_v, const float* q12_radius, const int32_t* q12_level,
+                         const uint8_t* q12_desc, const uint8_t* q12_valid,
+                         const float* q21_u, const float* q21_v, const float* q21_radius, const int32_t* q21_level,
+                         const uint8_t* q21_desc, const uint8_t* q21_valid, int32_t* matches12, int* nfound);
 /* MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): index of the least-median descriptor */
 int   orc_distinctive_descriptor(const uint8_t* desc, int n, int* best_idx, int* best_median);
 /* ORBmatcher::UpdateQualityScores(Frame&) (ORB/src/ORBmatcher.cc:1108-1121) */

@@ -82,6 +82,7 @@ lib.orc_search_for_initialization.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, 
                                               vp, C.POINTER(C.c_int)]
 lib.orc_distinctive_descriptor.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 lib.orc_search_keyframe_points.argtypes = [vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int)]
+lib.orc_search_by_sim3.argtypes = [vp, vp, C.c_int, C.POINTER(Bounds), vp, vp, C.c_int, C.POINTER(Bounds)] + [vp] * 12 + [vp, C.POINTER(C.c_int)]
 lib.orc_fuse_candidates.argtypes = [vp, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
 pin.stl_retain_best.restype = C.c_int; pin.stl_retain_best.argtypes = [vp, C.c_int, C.c_int]
 pin.stl_nth_element.argtypes = [vp, C.c_int, C.c_int]
@@ -284,3 +285,21 @@ def fuse_candidates(kf_kps, kf_desc, kf_uright, bounds, inv_level_sigma2, q):
     lib.orc_fuse_candidates(ptr(k), ptr(d), ptr(ur), len(k), C.byref(bd), ptr(sg), n, ptr(qq["u"]), ptr(qq["v"]), ptr(qq["ur"]),
                             ptr(qq["radius"]), ptr(qq["level"]), ptr(qq["desc"]), ptr(qq["valid"]), ptr(bi), ptr(bdist))
     return bi, bdist
+
+
+def _sim3_q(q):
+    t = dict(u=np.float32, v=np.float32, radius=np.float32, level=np.int32, desc=np.uint8, valid=np.uint8)
+    return {a: np.ascontiguousarray(q[a], b) for a, b in t.items()}
+
+
+def search_by_sim3(k1, d1, b1, k2, d2, b2, q12, q21):
+    """q12 / q21: dicts with u, v, radius, level, desc, valid per keypoint slot of KF1 / KF2 -> (matches12, nfound)."""
+    k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    a = _sim3_q(q12); b = _sim3_q(q21)
+    m = np.full(len(k1), -1, np.int32); nf = C.c_int(0); bd1 = Bounds(*b1); bd2 = Bounds(*b2)
+    lib.orc_search_by_sim3(ptr(k1), ptr(d1), len(k1), C.byref(bd1), ptr(k2), ptr(d2), len(k2), C.byref(bd2),
+                           ptr(a["u"]), ptr(a["v"]), ptr(a["radius"]), ptr(a["level"]), ptr(a["desc"]), ptr(a["valid"]),
+                           ptr(b["u"]), ptr(b["v"]), ptr(b["radius"]), ptr(b["level"]), ptr(b["desc"]), ptr(b["valid"]),
+                           ptr(m), C.byref(nf))
+    return m, nf.value

@@ -285,6 +285,19 @@ def test_search_for_initialization_and_distinctive_descriptor(iv):
     gb, gd = m.FuseCandidates(k2, d2, ur2, bounds, inv_s2, q)
     ob, od = O.fuse_candidates(k2, d2, ur2, bounds, inv_s2, q)
     assert np.array_equal(gb, ob) and np.array_equal(gd, od) and (gb >= 0).sum() > nq // 5
+    # SearchBySim3: KF1 = frame 1, KF2 = frame 2 (a displaced, shuffled copy): project each keypoint's map point to where its
+    # partner sits in the other frame (+ noise), partner known from the permutation
+    inv = np.argsort(perm)
+    q12 = dict(u=(k2["x"][inv] + rng.uniform(-2, 2, nq)).astype(np.float32), v=(k2["y"][inv] + rng.uniform(-2, 2, nq)).astype(np.float32),
+               radius=(7.5 * sc[k1["octave"]]).astype(np.float32), level=np.clip(k1["octave"] + rng.integers(0, 2, nq), 0, 7).astype(np.int32),
+               desc=d1, valid=(rng.uniform(size=nq) > 0.15).astype(np.uint8))
+    q21 = dict(u=(k1["x"][perm] + rng.uniform(-2, 2, nq)).astype(np.float32), v=(k1["y"][perm] + rng.uniform(-2, 2, nq)).astype(np.float32),
+               radius=(7.5 * sc[oct2]).astype(np.float32), level=np.clip(oct2 + rng.integers(0, 2, nq), 0, 7).astype(np.int32),
+               desc=qd, valid=(rng.uniform(size=nq) > 0.15).astype(np.uint8))
+    gs, gf = m.SearchBySim3(k1, d1, bounds, k2, d2, bounds, q12, q21)
+    os_, of = O.search_by_sim3(k1, d1, bounds, k2, d2, bounds, q12, q21)
+    assert gf == of and np.array_equal(gs, os_) and gf > nq // 4
+    assert (gs[gs >= 0] == inv[gs >= 0]).mean() > 0.9                       # mostly the true partners
     gb2, gd2 = m.FuseCandidates(k2, d2, None, bounds, None, q)              # Fuse(KF, Scw, ...): no chi-square gate
     ob2, od2 = O.fuse_candidates(k2, d2, None, bounds, None, q)
     assert np.array_equal(gb2, ob2) and np.array_equal(gd2, od2) and (gb2 >= 0).sum() >= (gb >= 0).sum()
