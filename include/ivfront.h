@@ -255,6 +255,17 @@ int  ivf_search_by_sim3(const ivf_keypoint* kps1, const uint8_t* desc1, int n1, 
                         const uint8_t* q12_desc, const uint8_t* q12_valid,
                         const float* q21_u, const float* q21_v, const float* q21_radius, const int32_t* q21_level,
                         const uint8_t* q21_desc, const uint8_t* q21_valid, int32_t* matches12, int* nfound, int device_id);
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vpMapPointMatches) (ORB/src/ORBmatcher.cc:165-294; used by
+ * Tracking::TrackReferenceKeyFrame and Relocalization).  DBoW2::FeatureVector of each side in CSR form: *_node[k] the
+ * node ids in std::map (ascending) order, *_idx[*_start[k] .. *_start[k+1]) the feature indices of node k.
+ * kf_has_map_point[i] = vpMapPointsKF[i] && !isBad().  kf_kps = pKF->mvKeysUn, f_kps = F.mvKeys (angles only).
+ * f_match[iF] = index i of the keyframe keypoint whose map point F's keypoint iF receives (vpMapPointMatches[iF] =
+ * vpMapPointsKF[i]) or -1; *nmatches = return value. */
+int  ivf_search_by_bow(const ivf_keypoint* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_has_map_point, int n_kf,
+                       const int32_t* kf_node, const int32_t* kf_start, const int32_t* kf_idx, int kf_nodes,
+                       const ivf_keypoint* f_kps, const uint8_t* f_desc, int n_f,
+                       const int32_t* f_node, const int32_t* f_start, const int32_t* f_idx, int f_nodes,
+                       float nn_ratio, int check_orientation, int32_t* f_match, int* nmatches, int device_id);
 /* MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): desc = the n observed descriptors (rows of
  * vDescriptors, in mObservations order); *best_index = the row to copy into mDescriptor, *best_median (nullable) its median. */
 int  ivf_distinctive_descriptor(const uint8_t* desc, int n, int* best_index, int* best_median, int device_id);

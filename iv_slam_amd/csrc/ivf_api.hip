@@ -926,6 +926,91 @@ int ivf_search_by_sim3(const ivf_keypoint* kps1, const uint8_t* desc1, int n1, c
     return IVF_OK;
 }
 
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORB/src/ORBmatcher.cc:165-294), feature vectors in CSR
+int ivf_search_by_bow(const ivf_keypoint* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_has_map_point, int n_kf,
+                      const int32_t* kf_node, const int32_t* kf_start, const int32_t* kf_idx, int kf_nodes,
+                      const ivf_keypoint* f_kps, const uint8_t* f_desc, int n_f,
+                      const int32_t* f_node, const int32_t* f_start, const int32_t* f_idx, int f_nodes,
+                      float nn_ratio, int check_orientation, int32_t* f_match, int* nmatches, int device_id)
+{
+    if (!kf_kps || !kf_desc || !kf_has_map_point || !f_kps || !f_desc || !f_match || !nmatches || n_kf < 0 || n_f < 0 ||
+        kf_nodes < 0 || f_nodes < 0)
+        return fail(IVF_E_INVALID, "bad argument");
+    *nmatches = 0;
+    for (int i = 0; i < n_f; i++) f_match[i] = -1;
+    if (kf_nodes == 0 || f_nodes == 0 || n_kf == 0 || n_f == 0) return IVF_OK;
+    if (!kf_node || !kf_start || !kf_idx || !f_node || !f_start || !f_idx) return fail(IVF_E_INVALID, "null feature-vector array");
+    for (int a = 0; a + 1 < kf_nodes; a++) if (kf_node[a] >= kf_node[a + 1]) return fail(IVF_E_INVALID, "keyframe node ids must ascend");
+    for (int b = 0; b + 1 < f_nodes; b++) if (f_node[b] >= f_node[b + 1]) return fail(IVF_E_INVALID, "frame node ids must ascend");
+    for (int p = kf_start[0]; p < kf_start[kf_nodes]; p++) if (kf_idx[p] < 0 || kf_idx[p] >= n_kf) return fail(IVF_E_INVALID, "keyframe feature index out of range");
+    for (int q = f_start[0]; q < f_start[f_nodes]; q++) if (f_idx[q] < 0 || f_idx[q] >= n_f) return fail(IVF_E_INVALID, "frame feature index out of range");
+    // 1. node merge (:187-265): per KF feature with a map point, the run of (KF, F) pairs of its node
+    struct Run { int kf, b, first; };
+    std::vector<Run> runs; std::vector<int> pairs;
+    {
+        int a = 0, b = 0;
+        while (a < kf_nodes && b < f_nodes) {
+            if (kf_node[a] == f_node[b]) {
+                for (int p = kf_start[a]; p < kf_start[a + 1]; p++) {
+                    const int i = kf_idx[p];
+                    if (!kf_has_map_point[i]) continue;
+                    runs.push_back({i, b, (int)pairs.size() / 2});
+                    for (int q = f_start[b]; q < f_start[b + 1]; q++) { pairs.push_back(i); pairs.push_back(f_idx[q]); }
+                }
+                a++; b++;
+            } else if (kf_node[a] < f_node[b]) { while (a < kf_nodes && kf_node[a] < f_node[b]) a++; }
+            else { while (b < f_nodes && f_node[b] < kf_node[a]) b++; }
+        }
+    }
+    const int nPairs = (int)pairs.size() / 2;
+    // 2. all in-node distances on the device
+    std::vector<int> dist(std::max(nPairs, 1));
+    int rc = ivf_hamming_pairs(kf_desc, n_kf, f_desc, n_f, pairs.data(), nPairs, dist.data(), device_id);
+    if (rc) return rc;
+    // 3. greedy replay (:200-259) and the rotation filter (:268-288)
+    const int HISTO_LENGTH = 30;
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nm = 0;
+    for (const Run& r : runs) {
+        const int len = f_start[r.b + 1] - f_start[r.b];
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        for (int k = 0; k < len; k++) {
+            const int iF = pairs[2 * (r.first + k) + 1], d = dist[r.first + k];
+            if (f_match[iF] >= 0) continue;
+            if (d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdxF = iF; }
+            else if (d < bestDist2) bestDist2 = d;
+        }
+        if (bestDist1 <= 50 && (float)bestDist1 < nn_ratio * (float)bestDist2) {
+            f_match[bestIdxF] = r.kf;
+            if (check_orientation) {
+                float rot = kf_kps[r.kf].angle - f_kps[bestIdxF].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(bestIdxF);
+            }
+            nm++;
+        }
+    }
+    if (check_orientation) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int sz = (int)rotHist[i].size();
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j : rotHist[i]) { f_match[j] = -1; nm--; }
+    }
+    *nmatches = nm;
+    return IVF_OK;
+}
+
 // MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): all-pairs Hamming + row medians on the device,
 // first minimum on the host
 int ivf_distinctive_descriptor(const uint8_t* desc, int n, int* best_index, int* best_median, int device_id)

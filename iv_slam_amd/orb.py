@@ -260,6 +260,28 @@ class ORBmatcher:
                                            ptr(m), C.byref(nf), self.device_id))
         return m, nf.value
 
+    @staticmethod
+    def _csr(fv):
+        nodes = sorted(fv)
+        start = np.zeros(len(nodes) + 1, np.int32); idx = []
+        for k, nd in enumerate(nodes):
+            idx.extend(fv[nd]); start[k + 1] = len(idx)
+        return np.array(nodes, np.int32), start, np.array(idx, np.int32)
+
+    def SearchByBoW(self, kf_kps, kf_desc, kf_has_map_point, kf_feat_vec, f_kps, f_desc, f_feat_vec):
+        """SearchByBoW(KeyFrame* pKF, Frame &F, vpMapPointMatches) (ORBmatcher.cc:165-294).  *_feat_vec: the
+        DBoW2::FeatureVector as {node id: [feature indices]}.  Returns (for every keypoint of F the index of the keyframe
+        keypoint whose map point it receives, or -1; nmatches)."""
+        kk = np.ascontiguousarray(kf_kps, KP_DTYPE); kd = np.ascontiguousarray(kf_desc, np.uint8)
+        hm = np.ascontiguousarray(kf_has_map_point, np.uint8)
+        fk = np.ascontiguousarray(f_kps, KP_DTYPE); fd = np.ascontiguousarray(f_desc, np.uint8)
+        kn, ks, ki = self._csr(kf_feat_vec); fn, fs, fi = self._csr(f_feat_vec)
+        m = np.full(len(fk), -1, np.int32); nm = C.c_int(0)
+        check(self._lib.ivf_search_by_bow(ptr(kk), ptr(kd), ptr(hm), len(kk), ptr(kn), ptr(ks), ptr(ki), len(kn), ptr(fk), ptr(fd),
+                                          len(fk), ptr(fn), ptr(fs), ptr(fi), len(fn), self.mfNNratio, int(self.mbCheckOrientation),
+                                          ptr(m), C.byref(nm), self.device_id))
+        return m, nm.value
+
 
 def ComputeDistinctiveDescriptors(vDescriptors, device_id=0):
     """MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312) on the observed descriptors [n,32]:

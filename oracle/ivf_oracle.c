@@ -1252,6 +1252,74 @@ int orc_search_by_sim3(const orc_keypoint* k1, const uint8_t* d1, int n1, const 
     return 0;
 }
 
+/* f6  ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vpMapPointMatches) (ORB/src/ORBmatcher.cc:165-294).
+ * DBoW2::FeatureVector (std::map<NodeId, vector<unsigned>>) of each side in CSR form: node ids ascending (map order),
+ * start offsets, feature indices.  Nodes present on both sides are walked in ascending order (:187-265); inside a node
+ * every KF feature with a good map point looks for its best / second best among the frame's features of that node
+ * that are still unmatched (:215-217), TH_LOW + ratio test (:236-238), rotation histogram of the FRAME indices with
+ * the reference's 1/HISTO_LENGTH factor (:244-253) and the final three-maxima filter (:268-288).
+ * f_match[iF] = KF keypoint index whose map point the frame keypoint receives, or -1. */
+static int rot_bin(float a1, float a2)
+{
+    float rot = a1 - a2;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * (1.0f / 30));
+    if (bin == 30) bin = 0;
+    return bin;
+}
+int orc_search_by_bow(const orc_keypoint* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_has_mp, int n_kf,
+                      const int32_t* kf_node, const int32_t* kf_start, const int32_t* kf_idx, int kf_nodes,
+                      const orc_keypoint* f_kps, const uint8_t* f_desc, int n_f,
+                      const int32_t* f_node, const int32_t* f_start, const int32_t* f_idx, int f_nodes,
+                      float nn_ratio, int check_orientation, int32_t* f_match, int* nmatches_out)
+{
+    enum { HISTO_LENGTH = 30, TH_LOW = 50 };
+    int nmatches = 0;
+    int* rotHist[HISTO_LENGTH]; int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int*)malloc(sizeof(int) * (n_f > 0 ? n_f : 1)); rotN[i] = 0; }
+    for (int i = 0; i < n_f; i++) f_match[i] = -1;
+    int a = 0, b = 0;
+    while (a < kf_nodes && b < f_nodes) {
+        if (kf_node[a] == f_node[b]) {
+            for (int p = kf_start[a]; p < kf_start[a + 1]; p++) {
+                const int realIdxKF = kf_idx[p];
+                if (!kf_has_mp[realIdxKF]) continue;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (int q = f_start[b]; q < f_start[b + 1]; q++) {
+                    const int realIdxF = f_idx[q];
+                    if (f_match[realIdxF] >= 0) continue;
+                    const int dist = orc_hamming256(kf_desc + (size_t)realIdxKF * 32, f_desc + (size_t)realIdxF * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 <= TH_LOW && (float)bestDist1 < nn_ratio * (float)bestDist2) {
+                    f_match[bestIdxF] = realIdxKF;
+                    if (check_orientation) {
+                        const int bin = rot_bin(kf_kps[realIdxKF].angle, f_kps[bestIdxF].angle);
+                        rotHist[bin][rotN[bin]++] = bestIdxF;
+                    }
+                    nmatches++;
+                }
+            }
+            a++; b++;
+        } else if (kf_node[a] < f_node[b]) {
+            while (a < kf_nodes && kf_node[a] < f_node[b]) a++;          /* lower_bound */
+        } else {
+            while (b < f_nodes && f_node[b] < kf_node[a]) b++;
+        }
+    }
+    if (check_orientation) {
+        int ind1, ind2, ind3;
+        orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < rotN[i]; j++) { f_match[rotHist[i][j]] = -1; nmatches--; }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+    *nmatches_out = nmatches;
+    return 0;
+}
+
 /* f2  MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): among n observed descriptors the one with
  * the least median Hamming distance to the rest; median = sorted row [ (int)(0.5*(n-1)) ] (the row holds the 0 of the
  * diagonal), first minimum wins (:294-305). */

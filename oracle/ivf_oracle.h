@@ -132,6 +132,12 @@ int   orc_search_by_sim3(const orc_keypoint* k1, const uint8_t* d1, int n1, cons
                          const uint8_t* q12_desc, const uint8_t* q12_valid,
                          const float* q21_u, const float* q21_v, const float* q21_radius, const int32_t* q21_level,
                          const uint8_t* q21_desc, const uint8_t* q21_valid, int32_t* matches12, int* nfound);
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORB/src/ORBmatcher.cc:165-294); feature vectors in CSR */
+int   orc_search_by_bow(const orc_keypoint* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_has_mp, int n_kf,
+                        const int32_t* kf_node, const int32_t* kf_start, const int32_t* kf_idx, int kf_nodes,
+                        const orc_keypoint* f_kps, const uint8_t* f_desc, int n_f,
+                        const int32_t* f_node, const int32_t* f_start, const int32_t* f_idx, int f_nodes,
+                        float nn_ratio, int check_orientation, int32_t* f_match, int* nmatches);
 /* MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): index of the least-median descriptor */
 int   orc_distinctive_descriptor(const uint8_t* desc, int n, int* best_idx, int* best_median);
 /* ORBmatcher::UpdateQualityScores(Frame&) (ORB/src/ORBmatcher.cc:1108-1121) */

@@ -83,6 +83,8 @@ lib.orc_search_for_initialization.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, 
 lib.orc_distinctive_descriptor.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 lib.orc_search_keyframe_points.argtypes = [vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int)]
 lib.orc_search_by_sim3.argtypes = [vp, vp, C.c_int, C.POINTER(Bounds), vp, vp, C.c_int, C.POINTER(Bounds)] + [vp] * 12 + [vp, C.POINTER(C.c_int)]
+lib.orc_search_by_bow.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_int,
+                                  vp, C.POINTER(C.c_int)]
 lib.orc_fuse_candidates.argtypes = [vp, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
 pin.stl_retain_best.restype = C.c_int; pin.stl_retain_best.argtypes = [vp, C.c_int, C.c_int]
 pin.stl_nth_element.argtypes = [vp, C.c_int, C.c_int]
@@ -303,3 +305,22 @@ def search_by_sim3(k1, d1, b1, k2, d2, b2, q12, q21):
                            ptr(b["u"]), ptr(b["v"]), ptr(b["radius"]), ptr(b["level"]), ptr(b["desc"]), ptr(b["valid"]),
                            ptr(m), C.byref(nf))
     return m, nf.value
+
+
+def feature_vector_csr(fv):
+    """{node id: [feature indices]} (a DBoW2::FeatureVector) -> (node ids ascending, starts, indices) int32 arrays."""
+    nodes = sorted(fv)
+    start = np.zeros(len(nodes) + 1, np.int32); idx = []
+    for k, nd in enumerate(nodes):
+        idx.extend(fv[nd]); start[k + 1] = len(idx)
+    return np.array(nodes, np.int32), start, np.array(idx, np.int32)
+
+
+def search_by_bow(kf_kps, kf_desc, kf_has_mp, kf_fv, f_kps, f_desc, f_fv, nn_ratio=0.7, check_orientation=True):
+    kk = np.ascontiguousarray(kf_kps); kd = np.ascontiguousarray(kf_desc, np.uint8); hm = np.ascontiguousarray(kf_has_mp, np.uint8)
+    fk = np.ascontiguousarray(f_kps); fd = np.ascontiguousarray(f_desc, np.uint8)
+    kn, ks, ki = feature_vector_csr(kf_fv); fn, fs, fi = feature_vector_csr(f_fv)
+    m = np.full(len(fk), -1, np.int32); nm = C.c_int(0)
+    lib.orc_search_by_bow(ptr(kk), ptr(kd), ptr(hm), len(kk), ptr(kn), ptr(ks), ptr(ki), len(kn), ptr(fk), ptr(fd), len(fk),
+                          ptr(fn), ptr(fs), ptr(fi), len(fn), nn_ratio, int(check_orientation), ptr(m), C.byref(nm))
+    return m, nm.value

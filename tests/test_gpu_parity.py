@@ -298,6 +298,24 @@ def test_search_for_initialization_and_distinctive_descriptor(iv):
     os_, of = O.search_by_sim3(k1, d1, bounds, k2, d2, bounds, q12, q21)
     assert gf == of and np.array_equal(gs, os_) and gf > nq // 4
     assert (gs[gs >= 0] == inv[gs >= 0]).mean() > 0.9                       # mostly the true partners
+    # SearchByBoW(KF, F): a synthetic vocabulary level = 64 nodes keyed by descriptor bits, so that most true partners share
+    # a node; frame 2's keypoints carry a few flipped bits and some land in other nodes
+    def feat_vec(desc, drop):
+        fv = {}
+        for i in range(len(desc)):
+            if drop[i]: continue
+            fv.setdefault(int(desc[i, 0] & 0x3F) * 7 + 3, []).append(i)      # sparse, non-contiguous node ids
+        return fv
+    fv1 = feat_vec(d1, rng.uniform(size=nq) < 0.05); fv2 = feat_vec(d2, rng.uniform(size=nq) < 0.05)
+    has_mp = (rng.uniform(size=nq) > 0.2).astype(np.uint8)
+    for ratio, ori in [(0.7, True), (0.9, False), (0.6, True)]:
+        mm = iv.ORBmatcher(ratio, ori)
+        gm_, gn_ = mm.SearchByBoW(k1, d1, has_mp, fv1, k2, d2, fv2)
+        om_, on_ = O.search_by_bow(k1, d1, has_mp, fv1, k2, d2, fv2, ratio, ori)
+        assert gn_ == on_ and np.array_equal(gm_, om_) and gn_ > 50
+        assert has_mp[gm_[gm_ >= 0]].all()                                  # only keyframe features that own a map point
+    gm_, gn_ = iv.ORBmatcher(0.7, True).SearchByBoW(k1, d1, has_mp, {}, k2, d2, fv2)
+    assert gn_ == 0 and (gm_ == -1).all()
     gb2, gd2 = m.FuseCandidates(k2, d2, None, bounds, None, q)              # Fuse(KF, Scw, ...): no chi-square gate
     ob2, od2 = O.fuse_candidates(k2, d2, None, bounds, None, q)
     assert np.array_equal(gb2, ob2) and np.array_equal(gd2, od2) and (gb2 >= 0).sum() >= (gb >= 0).sum()
