@@ -265,3 +265,37 @@ def test_keyframe_projection_search_and_fuse_core():
     bo, _ = O.fuse_candidates(kps, desc, ur, bounds, inv_s2, qo)
     lvl = kps["octave"]
     assert (bo[lvl == 0] == np.arange(n)[lvl == 0]).mean() < 0.05 and (bo[lvl >= 4] == np.arange(n)[lvl >= 4]).mean() > 0.9
+
+
+def test_bow_and_sim3_oracle_properties():
+    """f5 SearchBySim3 (ORBmatcher.cc:1145-1254) and f6 SearchByBoW(KF, F) (:165-294) on an identical pair of frames."""
+    img = synth.make_left(640, 240, seed=29, idx=0)
+    ext = O.Extractor(500, 1.2, 8, 20, 7)
+    kps, desc = ext(img)
+    n = len(kps); sc = ext.tables()["scale"]; bounds = (0, 0, 640, 240)
+    fv = {}
+    for i in range(n):
+        fv.setdefault(int(desc[i, 1]) % 23 + 100, []).append(i)
+    has = np.ones(n, np.uint8); has[::4] = 0
+    m, nm = O.search_by_bow(kps, desc, has, fv, kps, desc, fv, 0.7, True)
+    assert nm == (m >= 0).sum() and nm > 0.6 * has.sum()
+    assert (m[m >= 0] == np.nonzero(m >= 0)[0]).all() and not has[::4].any() and (m[::4] == -1).all()   # self matches, map points only
+    # disjoint node ids: nothing to compare
+    fv2 = {k + 1000: v for k, v in fv.items()}
+    assert O.search_by_bow(kps, desc, has, fv, kps, desc, fv2, 0.7, True)[1] == 0
+    # a frame whose descriptors are all equal: best == second best, the ratio test (strict <) rejects everything
+    same = np.repeat(desc[:1], n, axis=0)
+    assert O.search_by_bow(kps, same, has, fv, kps, same, fv, 0.7, False)[1] == 0
+    # Sim3: exact mutual projections -> every valid slot matches itself; one-sided validity -> no match (agreement check)
+    q = dict(u=kps["x"].copy(), v=kps["y"].copy(), radius=(7.5 * sc[kps["octave"]]).astype(np.float32),
+             level=kps["octave"].astype(np.int32), desc=desc.copy(), valid=np.ones(n, np.uint8))
+    ms, nf = O.search_by_sim3(kps, desc, bounds, kps, desc, bounds, q, q)
+    assert nf == (ms >= 0).sum() and nf > 0.9 * n and (ms[ms >= 0] == np.nonzero(ms >= 0)[0]).all()
+    q_half = dict(q); v = np.ones(n, np.uint8); v[: n // 2] = 0; q_half["valid"] = v
+    ms2, nf2 = O.search_by_sim3(kps, desc, bounds, kps, desc, bounds, q, q_half)
+    assert (ms2[: n // 2] == -1).all() and 0 < nf2 < nf
+    # TH_HIGH = 100: 80 flipped bits still match, 120 do not
+    d80 = desc.copy(); d80[:, :10] ^= np.uint8(0xFF); q80 = dict(q); q80["desc"] = d80
+    d120 = desc.copy(); d120[:, :15] ^= np.uint8(0xFF); q120 = dict(q); q120["desc"] = d120
+    assert O.search_by_sim3(kps, desc, bounds, kps, desc, bounds, q80, q80)[1] > 0.5 * n
+    assert O.search_by_sim3(kps, desc, bounds, kps, desc, bounds, q120, q120)[1] == 0
