@@ -266,6 +266,14 @@ int  ivf_search_by_bow(const ivf_keypoint* kf_kps, const uint8_t* kf_desc, const
                        const ivf_keypoint* f_kps, const uint8_t* f_desc, int n_f,
                        const int32_t* f_node, const int32_t* f_start, const int32_t* f_idx, int f_nodes,
                        float nn_ratio, int check_orientation, int32_t* f_match, int* nmatches, int device_id);
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12) (ORB/src/ORBmatcher.cc:528-661, loop closing):
+ * same CSR feature vectors; has_map_point* = vpMapPoints*[i] && !isBad().  matches12[idx1] = idx2 (vpMatches12[idx1] =
+ * vpMapPoints2[idx2]) or -1; acceptance is bestDist1 < TH_LOW (strict) here; *nmatches = return value. */
+int  ivf_search_by_bow_keyframes(const ivf_keypoint* kps1, const uint8_t* desc1, const uint8_t* has_map_point1, int n1,
+                                 const int32_t* node1, const int32_t* start1, const int32_t* idx1, int nodes1,
+                                 const ivf_keypoint* kps2, const uint8_t* desc2, const uint8_t* has_map_point2, int n2,
+                                 const int32_t* node2, const int32_t* start2, const int32_t* idx2, int nodes2,
+                                 float nn_ratio, int check_orientation, int32_t* matches12, int* nmatches, int device_id);
 /* MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): desc = the n observed descriptors (rows of
  * vDescriptors, in mObservations order); *best_index = the row to copy into mDescriptor, *best_median (nullable) its median. */
 int  ivf_distinctive_descriptor(const uint8_t* desc, int n, int* best_index, int* best_median, int device_id);

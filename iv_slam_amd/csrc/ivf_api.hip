@@ -1011,6 +1011,89 @@ int ivf_search_by_bow(const ivf_keypoint* kf_kps, const uint8_t* kf_desc, const 
     return IVF_OK;
 }
 
+// ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (ORB/src/ORBmatcher.cc:528-661), feature vectors in CSR
+int ivf_search_by_bow_keyframes(const ivf_keypoint* kps1, const uint8_t* desc1, const uint8_t* has_map_point1, int n1,
+                                const int32_t* node1, const int32_t* start1, const int32_t* idx1, int nodes1,
+                                const ivf_keypoint* kps2, const uint8_t* desc2, const uint8_t* has_map_point2, int n2,
+                                const int32_t* node2, const int32_t* start2, const int32_t* idx2, int nodes2,
+                                float nn_ratio, int check_orientation, int32_t* matches12, int* nmatches, int device_id)
+{
+    if (!kps1 || !desc1 || !has_map_point1 || !kps2 || !desc2 || !has_map_point2 || !matches12 || !nmatches || n1 < 0 || n2 < 0 ||
+        nodes1 < 0 || nodes2 < 0)
+        return fail(IVF_E_INVALID, "bad argument");
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (nodes1 == 0 || nodes2 == 0 || n1 == 0 || n2 == 0) return IVF_OK;
+    if (!node1 || !start1 || !idx1 || !node2 || !start2 || !idx2) return fail(IVF_E_INVALID, "null feature-vector array");
+    for (int a = 0; a + 1 < nodes1; a++) if (node1[a] >= node1[a + 1]) return fail(IVF_E_INVALID, "node ids of keyframe 1 must ascend");
+    for (int b = 0; b + 1 < nodes2; b++) if (node2[b] >= node2[b + 1]) return fail(IVF_E_INVALID, "node ids of keyframe 2 must ascend");
+    for (int p = start1[0]; p < start1[nodes1]; p++) if (idx1[p] < 0 || idx1[p] >= n1) return fail(IVF_E_INVALID, "feature index of keyframe 1 out of range");
+    for (int q = start2[0]; q < start2[nodes2]; q++) if (idx2[q] < 0 || idx2[q] >= n2) return fail(IVF_E_INVALID, "feature index of keyframe 2 out of range");
+    struct Run { int i1, b, first; };
+    std::vector<Run> runs; std::vector<int> pairs;
+    {
+        int a = 0, b = 0;
+        while (a < nodes1 && b < nodes2) {
+            if (node1[a] == node2[b]) {
+                for (int p = start1[a]; p < start1[a + 1]; p++) {
+                    const int i = idx1[p];
+                    if (!has_map_point1[i]) continue;
+                    runs.push_back({i, b, (int)pairs.size() / 2});
+                    for (int q = start2[b]; q < start2[b + 1]; q++) { pairs.push_back(i); pairs.push_back(idx2[q]); }
+                }
+                a++; b++;
+            } else if (node1[a] < node2[b]) { while (a < nodes1 && node1[a] < node2[b]) a++; }
+            else { while (b < nodes2 && node2[b] < node1[a]) b++; }
+        }
+    }
+    const int nPairs = (int)pairs.size() / 2;
+    std::vector<int> dist(std::max(nPairs, 1));
+    int rc = ivf_hamming_pairs(desc1, n1, desc2, n2, pairs.data(), nPairs, dist.data(), device_id);
+    if (rc) return rc;
+    const int HISTO_LENGTH = 30;
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<uint8_t> matched2(n2, 0);
+    int nm = 0;
+    for (const Run& r : runs) {
+        const int len = start2[r.b + 1] - start2[r.b];
+        int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+        for (int k = 0; k < len; k++) {
+            const int i2 = pairs[2 * (r.first + k) + 1], d = dist[r.first + k];
+            if (matched2[i2] || !has_map_point2[i2]) continue;
+            if (d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdx2 = i2; }
+            else if (d < bestDist2) bestDist2 = d;
+        }
+        if (bestDist1 < 50 && (float)bestDist1 < nn_ratio * (float)bestDist2) {          // strict '<' here (:598)
+            matches12[r.i1] = bestIdx2; matched2[bestIdx2] = 1;
+            if (check_orientation) {
+                float rot = kps1[r.i1].angle - kps2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(r.i1);
+            }
+            nm++;
+        }
+    }
+    if (check_orientation) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int sz = (int)rotHist[i].size();
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j : rotHist[i]) { matches12[j] = -1; nm--; }
+    }
+    *nmatches = nm;
+    return IVF_OK;
+}
+
 // MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): all-pairs Hamming + row medians on the device,
 // first minimum on the host
 int ivf_distinctive_descriptor(const uint8_t* desc, int n, int* best_index, int* best_median, int device_id)

@@ -282,6 +282,19 @@ class ORBmatcher:
                                           ptr(m), C.byref(nm), self.device_id))
         return m, nm.value
 
+    def SearchByBoWKeyFrames(self, kps1, desc1, has_map_point1, feat_vec1, kps2, desc2, has_map_point2, feat_vec2):
+        """SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12) (ORBmatcher.cc:528-661).  Returns (matches12 = index in
+        KF2 per KF1 keypoint or -1, nmatches)."""
+        k1 = np.ascontiguousarray(kps1, KP_DTYPE); k2 = np.ascontiguousarray(kps2, KP_DTYPE)
+        d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+        h1 = np.ascontiguousarray(has_map_point1, np.uint8); h2 = np.ascontiguousarray(has_map_point2, np.uint8)
+        a, b, c = self._csr(feat_vec1); e, f, g = self._csr(feat_vec2)
+        m = np.full(len(k1), -1, np.int32); nm = C.c_int(0)
+        check(self._lib.ivf_search_by_bow_keyframes(ptr(k1), ptr(d1), ptr(h1), len(k1), ptr(a), ptr(b), ptr(c), len(a), ptr(k2), ptr(d2),
+                                                    ptr(h2), len(k2), ptr(e), ptr(f), ptr(g), len(e), self.mfNNratio,
+                                                    int(self.mbCheckOrientation), ptr(m), C.byref(nm), self.device_id))
+        return m, nm.value
+
 
 def ComputeDistinctiveDescriptors(vDescriptors, device_id=0):
     """MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312) on the observed descriptors [n,32]:

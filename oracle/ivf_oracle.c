@@ -1320,6 +1320,66 @@ int orc_search_by_bow(const orc_keypoint* kf_kps, const uint8_t* kf_desc, const 
     return 0;
 }
 
+/* f7  ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12) (ORB/src/ORBmatcher.cc:528-661): as f6 but
+ * both sides need a good map point (:560-564, :577-582), side-2 features are claimed through vbMatched2 (:604), the
+ * acceptance is bestDist1 < TH_LOW (strict, :598), the histogram and the output are indexed by the KF1 feature
+ * (:606, :619).  matches12[idx1] = idx2 or -1. */
+int orc_search_by_bow_keyframes(const orc_keypoint* k1, const uint8_t* d1, const uint8_t* has_mp1, int n1,
+                                const int32_t* node1, const int32_t* start1, const int32_t* idx1v, int nodes1,
+                                const orc_keypoint* k2, const uint8_t* d2, const uint8_t* has_mp2, int n2,
+                                const int32_t* node2, const int32_t* start2, const int32_t* idx2v, int nodes2,
+                                float nn_ratio, int check_orientation, int32_t* matches12, int* nmatches_out)
+{
+    enum { HISTO_LENGTH = 30, TH_LOW = 50 };
+    int nmatches = 0;
+    int* rotHist[HISTO_LENGTH]; int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int*)malloc(sizeof(int) * (n1 > 0 ? n1 : 1)); rotN[i] = 0; }
+    uint8_t* matched2 = (uint8_t*)calloc(n2 > 0 ? n2 : 1, 1);
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    int a = 0, b = 0;
+    while (a < nodes1 && b < nodes2) {
+        if (node1[a] == node2[b]) {
+            for (int p = start1[a]; p < start1[a + 1]; p++) {
+                const int i1 = idx1v[p];
+                if (!has_mp1[i1]) continue;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int q = start2[b]; q < start2[b + 1]; q++) {
+                    const int i2 = idx2v[q];
+                    if (matched2[i2] || !has_mp2[i2]) continue;
+                    const int dist = orc_hamming256(d1 + (size_t)i1 * 32, d2 + (size_t)i2 * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = i2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < TH_LOW && (float)bestDist1 < nn_ratio * (float)bestDist2) {
+                    matches12[i1] = bestIdx2;
+                    matched2[bestIdx2] = 1;
+                    if (check_orientation) {
+                        const int bin = rot_bin(k1[i1].angle, k2[bestIdx2].angle);
+                        rotHist[bin][rotN[bin]++] = i1;
+                    }
+                    nmatches++;
+                }
+            }
+            a++; b++;
+        } else if (node1[a] < node2[b]) {
+            while (a < nodes1 && node1[a] < node2[b]) a++;
+        } else {
+            while (b < nodes2 && node2[b] < node1[a]) b++;
+        }
+    }
+    if (check_orientation) {
+        int ind1, ind2, ind3;
+        orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < rotN[i]; j++) { matches12[rotHist[i][j]] = -1; nmatches--; }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+    free(matched2);
+    *nmatches_out = nmatches;
+    return 0;
+}
+
 /* f2  MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): among n observed descriptors the one with
  * the least median Hamming distance to the rest; median = sorted row [ (int)(0.5*(n-1)) ] (the row holds the 0 of the
  * diagonal), first minimum wins (:294-305). */

@@ -138,6 +138,12 @@ int   orc_search_by_bow(const orc_keypoint* kf_kps, const uint8_t* kf_desc, cons
                         const orc_keypoint* f_kps, const uint8_t* f_desc, int n_f,
                         const int32_t* f_node, const int32_t* f_start, const int32_t* f_idx, int f_nodes,
                         float nn_ratio, int check_orientation, int32_t* f_match, int* nmatches);
+/* ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (ORB/src/ORBmatcher.cc:528-661) */
+int   orc_search_by_bow_keyframes(const orc_keypoint* k1, const uint8_t* d1, const uint8_t* has_mp1, int n1,
+                                  const int32_t* node1, const int32_t* start1, const int32_t* idx1, int nodes1,
+                                  const orc_keypoint* k2, const uint8_t* d2, const uint8_t* has_mp2, int n2,
+                                  const int32_t* node2, const int32_t* start2, const int32_t* idx2, int nodes2,
+                                  float nn_ratio, int check_orientation, int32_t* matches12, int* nmatches);
 /* MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): index of the least-median descriptor */
 int   orc_distinctive_descriptor(const uint8_t* desc, int n, int* best_idx, int* best_median);
 /* ORBmatcher::UpdateQualityScores(Frame&) (ORB/src/ORBmatcher.cc:1108-1121) */

@@ -85,6 +85,8 @@ lib.orc_search_keyframe_points.argtypes = [vp, vp, C.c_int, C.POINTER(Bounds), C
 lib.orc_search_by_sim3.argtypes = [vp, vp, C.c_int, C.POINTER(Bounds), vp, vp, C.c_int, C.POINTER(Bounds)] + [vp] * 12 + [vp, C.POINTER(C.c_int)]
 lib.orc_search_by_bow.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_int,
                                   vp, C.POINTER(C.c_int)]
+lib.orc_search_by_bow_keyframes.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
+                                            C.c_float, C.c_int, vp, C.POINTER(C.c_int)]
 lib.orc_fuse_candidates.argtypes = [vp, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
 pin.stl_retain_best.restype = C.c_int; pin.stl_retain_best.argtypes = [vp, C.c_int, C.c_int]
 pin.stl_nth_element.argtypes = [vp, C.c_int, C.c_int]
@@ -323,4 +325,16 @@ def search_by_bow(kf_kps, kf_desc, kf_has_mp, kf_fv, f_kps, f_desc, f_fv, nn_rat
     m = np.full(len(fk), -1, np.int32); nm = C.c_int(0)
     lib.orc_search_by_bow(ptr(kk), ptr(kd), ptr(hm), len(kk), ptr(kn), ptr(ks), ptr(ki), len(kn), ptr(fk), ptr(fd), len(fk),
                           ptr(fn), ptr(fs), ptr(fi), len(fn), nn_ratio, int(check_orientation), ptr(m), C.byref(nm))
+    return m, nm.value
+
+
+def search_by_bow_keyframes(k1, d1, has1, fv1, k2, d2, has2, fv2, nn_ratio=0.75, check_orientation=True):
+    k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    h1 = np.ascontiguousarray(has1, np.uint8); h2 = np.ascontiguousarray(has2, np.uint8)
+    n1_, s1_, i1_ = feature_vector_csr(fv1); n2_, s2_, i2_ = feature_vector_csr(fv2)
+    m = np.full(len(k1), -1, np.int32); nm = C.c_int(0)
+    lib.orc_search_by_bow_keyframes(ptr(k1), ptr(d1), ptr(h1), len(k1), ptr(n1_), ptr(s1_), ptr(i1_), len(n1_),
+                                    ptr(k2), ptr(d2), ptr(h2), len(k2), ptr(n2_), ptr(s2_), ptr(i2_), len(n2_),
+                                    nn_ratio, int(check_orientation), ptr(m), C.byref(nm))
     return m, nm.value

@@ -316,6 +316,14 @@ def test_search_for_initialization_and_distinctive_descriptor(iv):
         assert has_mp[gm_[gm_ >= 0]].all()                                  # only keyframe features that own a map point
     gm_, gn_ = iv.ORBmatcher(0.7, True).SearchByBoW(k1, d1, has_mp, {}, k2, d2, fv2)
     assert gn_ == 0 and (gm_ == -1).all()
+    has2 = (rng.uniform(size=nq) > 0.25).astype(np.uint8)
+    for ratio, ori in [(0.75, True), (0.9, False)]:
+        mm = iv.ORBmatcher(ratio, ori)
+        gk, gkn = mm.SearchByBoWKeyFrames(k1, d1, has_mp, fv1, k2, d2, has2, fv2)
+        ok_, okn = O.search_by_bow_keyframes(k1, d1, has_mp, fv1, k2, d2, has2, fv2, ratio, ori)
+        assert gkn == okn and np.array_equal(gk, ok_) and gkn > 30
+        assert has_mp[np.nonzero(gk >= 0)[0]].all() and has2[gk[gk >= 0]].all()
+        assert len(np.unique(gk[gk >= 0])) == (gk >= 0).sum()                # vbMatched2: a KF2 feature is claimed once
     gb2, gd2 = m.FuseCandidates(k2, d2, None, bounds, None, q)              # Fuse(KF, Scw, ...): no chi-square gate
     ob2, od2 = O.fuse_candidates(k2, d2, None, bounds, None, q)
     assert np.array_equal(gb2, ob2) and np.array_equal(gd2, od2) and (gb2 >= 0).sum() >= (gb >= 0).sum()
