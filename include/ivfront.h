@@ -274,6 +274,17 @@ int  ivf_search_by_bow_keyframes(const ivf_keypoint* kps1, const uint8_t* desc1,
                                  const ivf_keypoint* kps2, const uint8_t* desc2, const uint8_t* has_map_point2, int n2,
                                  const int32_t* node2, const int32_t* start2, const int32_t* idx2, int nodes2,
                                  float nn_ratio, int check_orientation, int32_t* matches12, int* nmatches, int device_id);
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (ORB/src/ORBmatcher.cc:663-829, local
+ * mapping's CreateNewMapPoints) including CheckDistEpipolarLine (:146-163).  has_map_point* = GetMapPoint(i) != NULL,
+ * stereo* = mvuRight[i] >= 0; F12 row-major 3x3 f32; (ex, ey) = epipole of camera 1 in image 2 (:670-676);
+ * scale_factors2 / level_sigma2_2 = pKF2->mvScaleFactors / mvLevelSigma2.  matches12[idx1] = idx2 or -1 (vMatchedPairs =
+ * the pairs with matches12 >= 0 in ascending idx1, :815-823); *nmatches = return value. */
+int  ivf_search_for_triangulation(const ivf_keypoint* kps1, const uint8_t* desc1, const uint8_t* has_map_point1, const uint8_t* stereo1, int n1,
+                                  const int32_t* node1, const int32_t* start1, const int32_t* idx1, int nodes1,
+                                  const ivf_keypoint* kps2, const uint8_t* desc2, const uint8_t* has_map_point2, const uint8_t* stereo2, int n2,
+                                  const int32_t* node2, const int32_t* start2, const int32_t* idx2, int nodes2,
+                                  const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2, int n_levels,
+                                  int only_stereo, int check_orientation, int32_t* matches12, int* nmatches, int device_id);
 /* MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): desc = the n observed descriptors (rows of
  * vDescriptors, in mObservations order); *best_index = the row to copy into mDescriptor, *best_median (nullable) its median. */
 int  ivf_distinctive_descriptor(const uint8_t* desc, int n, int* best_index, int* best_median, int device_id);

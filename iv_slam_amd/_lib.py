@@ -71,6 +71,8 @@ _SIGS = {
                                     vp, C.POINTER(C.c_int), C.c_int]),
     "ivf_search_by_bow_keyframes": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                                               C.c_float, C.c_int, vp, C.POINTER(C.c_int), C.c_int]),
+    "ivf_search_for_triangulation": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
+                                               vp, C.c_float, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(C.c_int), C.c_int]),
     "ivf_fuse_candidates": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
                                       vp, vp, C.c_int]),
     "ivf_test_retain_best": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int]),

@@ -1094,6 +1094,107 @@ int ivf_search_by_bow_keyframes(const ivf_keypoint* kps1, const uint8_t* desc1, 
     return IVF_OK;
 }
 
+// ORBmatcher::SearchForTriangulation (ORB/src/ORBmatcher.cc:663-829) + CheckDistEpipolarLine (:146-163)
+int ivf_search_for_triangulation(const ivf_keypoint* kps1, const uint8_t* desc1, const uint8_t* has_map_point1, const uint8_t* stereo1, int n1,
+                                 const int32_t* node1, const int32_t* start1, const int32_t* idx1, int nodes1,
+                                 const ivf_keypoint* kps2, const uint8_t* desc2, const uint8_t* has_map_point2, const uint8_t* stereo2, int n2,
+                                 const int32_t* node2, const int32_t* start2, const int32_t* idx2, int nodes2,
+                                 const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2, int n_levels,
+                                 int only_stereo, int check_orientation, int32_t* matches12, int* nmatches, int device_id)
+{
+    if (!kps1 || !desc1 || !has_map_point1 || !stereo1 || !kps2 || !desc2 || !has_map_point2 || !stereo2 || !F12 || !scale_factors2 ||
+        !level_sigma2_2 || !matches12 || !nmatches || n1 < 0 || n2 < 0 || nodes1 < 0 || nodes2 < 0 || n_levels < 1)
+        return fail(IVF_E_INVALID, "bad argument");
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (nodes1 == 0 || nodes2 == 0 || n1 == 0 || n2 == 0) return IVF_OK;
+    if (!node1 || !start1 || !idx1 || !node2 || !start2 || !idx2) return fail(IVF_E_INVALID, "null feature-vector array");
+    for (int a = 0; a + 1 < nodes1; a++) if (node1[a] >= node1[a + 1]) return fail(IVF_E_INVALID, "node ids of keyframe 1 must ascend");
+    for (int b = 0; b + 1 < nodes2; b++) if (node2[b] >= node2[b + 1]) return fail(IVF_E_INVALID, "node ids of keyframe 2 must ascend");
+    for (int p = start1[0]; p < start1[nodes1]; p++) if (idx1[p] < 0 || idx1[p] >= n1) return fail(IVF_E_INVALID, "feature index of keyframe 1 out of range");
+    for (int q = start2[0]; q < start2[nodes2]; q++) if (idx2[q] < 0 || idx2[q] >= n2) return fail(IVF_E_INVALID, "feature index of keyframe 2 out of range");
+    for (int i = 0; i < n2; i++) if (kps2[i].octave < 0 || kps2[i].octave >= n_levels) return fail(IVF_E_INVALID, "keypoint %d of keyframe 2: octave outside the tables", i);
+    // 1. node merge: per eligible KF1 feature the run of eligible (i1, i2) pairs of its node (:697-731)
+    struct Run { int i1, first, len; };
+    std::vector<Run> runs; std::vector<int> pairs;
+    {
+        int a = 0, b = 0;
+        while (a < nodes1 && b < nodes2) {
+            if (node1[a] == node2[b]) {
+                for (int p = start1[a]; p < start1[a + 1]; p++) {
+                    const int i1 = idx1[p];
+                    if (has_map_point1[i1] || (only_stereo && !stereo1[i1])) continue;
+                    Run r{i1, (int)pairs.size() / 2, 0};
+                    for (int q = start2[b]; q < start2[b + 1]; q++) {
+                        const int i2 = idx2[q];
+                        if (has_map_point2[i2] || (only_stereo && !stereo2[i2])) continue;
+                        pairs.push_back(i1); pairs.push_back(i2); r.len++;
+                    }
+                    runs.push_back(r);
+                }
+                a++; b++;
+            } else if (node1[a] < node2[b]) { while (a < nodes1 && node1[a] < node2[b]) a++; }
+            else { while (b < nodes2 && node2[b] < node1[a]) b++; }
+        }
+    }
+    const int nPairs = (int)pairs.size() / 2;
+    std::vector<int> dist(std::max(nPairs, 1));
+    int rc = ivf_hamming_pairs(desc1, n1, desc2, n2, pairs.data(), nPairs, dist.data(), device_id);
+    if (rc) return rc;
+    // 2. replay with the epipole and epipolar-line gates (f32 arithmetic as written in :149-162, compared in double)
+    const int HISTO_LENGTH = 30, TH_LOW = 50;
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nm = 0;
+    for (const Run& r : runs) {
+        const ivf_keypoint& kp1 = kps1[r.i1];
+        int bestDist = TH_LOW, bestIdx2 = -1;
+        for (int k = 0; k < r.len; k++) {
+            const int i2 = pairs[2 * (r.first + k) + 1], d = dist[r.first + k];
+            if (d > TH_LOW || d > bestDist) continue;
+            const ivf_keypoint& kp2 = kps2[i2];
+            if (!stereo1[r.i1] && !stereo2[i2]) {
+                const float distex = ex - kp2.x, distey = ey - kp2.y;
+                if (distex * distex + distey * distey < 100 * scale_factors2[kp2.octave]) continue;
+            }
+            const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+            const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+            const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+            const float num = a * kp2.x + b * kp2.y + c;
+            const float den = a * a + b * b;
+            if (den == 0) continue;
+            const float dsqr = num * num / den;
+            if (dsqr < 3.84 * level_sigma2_2[kp2.octave]) { bestIdx2 = i2; bestDist = d; }
+        }
+        if (bestIdx2 >= 0) {
+            matches12[r.i1] = bestIdx2; nm++;
+            if (check_orientation) {
+                float rot = kp1.angle - kps2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(r.i1);
+            }
+        }
+    }
+    if (check_orientation) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int sz = (int)rotHist[i].size();
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j : rotHist[i]) { matches12[j] = -1; nm--; }
+    }
+    *nmatches = nm;
+    return IVF_OK;
+}
+
 // MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): all-pairs Hamming + row medians on the device,
 // first minimum on the host
 int ivf_distinctive_descriptor(const uint8_t* desc, int n, int* best_index, int* best_median, int device_id)

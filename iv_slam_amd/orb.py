@@ -295,6 +295,25 @@ class ORBmatcher:
                                                     int(self.mbCheckOrientation), ptr(m), C.byref(nm), self.device_id))
         return m, nm.value
 
+    def SearchForTriangulation(self, kps1, desc1, has_map_point1, stereo1, feat_vec1, kps2, desc2, has_map_point2, stereo2, feat_vec2,
+                               F12, ex, ey, mvScaleFactors2, mvLevelSigma2_2, bOnlyStereo=False):
+        """SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (ORBmatcher.cc:663-829).  Returns
+        (matches12, nmatches); vMatchedPairs = [(i, matches12[i]) for i where matches12[i] >= 0]."""
+        k1 = np.ascontiguousarray(kps1, KP_DTYPE); k2 = np.ascontiguousarray(kps2, KP_DTYPE)
+        d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+        h1 = np.ascontiguousarray(has_map_point1, np.uint8); h2 = np.ascontiguousarray(has_map_point2, np.uint8)
+        s1 = np.ascontiguousarray(stereo1, np.uint8); s2 = np.ascontiguousarray(stereo2, np.uint8)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sc = np.ascontiguousarray(mvScaleFactors2, np.float32); sg = np.ascontiguousarray(mvLevelSigma2_2, np.float32)
+        a, b, c = self._csr(feat_vec1); e, f, g = self._csr(feat_vec2)
+        m = np.full(len(k1), -1, np.int32); nm = C.c_int(0)
+        check(self._lib.ivf_search_for_triangulation(ptr(k1), ptr(d1), ptr(h1), ptr(s1), len(k1), ptr(a), ptr(b), ptr(c), len(a),
+                                                     ptr(k2), ptr(d2), ptr(h2), ptr(s2), len(k2), ptr(e), ptr(f), ptr(g), len(e),
+                                                     ptr(F), float(ex), float(ey), ptr(sc), ptr(sg), min(len(sc), len(sg)),
+                                                     int(bool(bOnlyStereo)), int(self.mbCheckOrientation), ptr(m), C.byref(nm),
+                                                     self.device_id))
+        return m, nm.value
+
 
 def ComputeDistinctiveDescriptors(vDescriptors, device_id=0):
     """MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312) on the observed descriptors [n,32]:

@@ -1380,6 +1380,84 @@ int orc_search_by_bow_keyframes(const orc_keypoint* k1, const uint8_t* d1, const
     return 0;
 }
 
+/* f8  ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (ORB/src/ORBmatcher.cc:663-829)
+ * with CheckDistEpipolarLine (:146-163).  Features WITHOUT a map point on both sides (:697-701, :721-725); a candidate
+ * must not be worse than the best so far nor than TH_LOW (:736-737: ties replace), mono-mono pairs too close to the
+ * epipole are dropped (:741-747), the epipolar distance gate is 3.84 * mvLevelSigma2[octave2] (:162).  vbMatched2 is
+ * never set in this reference (:765-767), so several KF1 features may share a KF2 feature.  matches12[idx1] = idx2 / -1. */
+static int epipolar_ok(const orc_keypoint* kp1, const orc_keypoint* kp2, const float* F, const float* level_sigma2)
+{
+    const float a = kp1->x * F[0] + kp1->y * F[3] + F[6];
+    const float b = kp1->x * F[1] + kp1->y * F[4] + F[7];
+    const float c = kp1->x * F[2] + kp1->y * F[5] + F[8];
+    const float num = a * kp2->x + b * kp2->y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * level_sigma2[kp2->octave];
+}
+int orc_search_for_triangulation(const orc_keypoint* k1, const uint8_t* d1, const uint8_t* has_mp1, const uint8_t* stereo1, int n1,
+                                 const int32_t* node1, const int32_t* start1, const int32_t* idx1v, int nodes1,
+                                 const orc_keypoint* k2, const uint8_t* d2, const uint8_t* has_mp2, const uint8_t* stereo2, int n2,
+                                 const int32_t* node2, const int32_t* start2, const int32_t* idx2v, int nodes2,
+                                 const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2,
+                                 int only_stereo, int check_orientation, int32_t* matches12, int* nmatches_out)
+{
+    enum { HISTO_LENGTH = 30, TH_LOW = 50 };
+    int nmatches = 0;
+    int* rotHist[HISTO_LENGTH]; int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int*)malloc(sizeof(int) * (n1 > 0 ? n1 : 1)); rotN[i] = 0; }
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    int a = 0, b = 0;
+    while (a < nodes1 && b < nodes2) {
+        if (node1[a] == node2[b]) {
+            for (int p = start1[a]; p < start1[a + 1]; p++) {
+                const int i1 = idx1v[p];
+                if (has_mp1[i1]) continue;
+                const int bStereo1 = stereo1[i1];
+                if (only_stereo && !bStereo1) continue;
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int q = start2[b]; q < start2[b + 1]; q++) {
+                    const int i2 = idx2v[q];
+                    if (has_mp2[i2]) continue;
+                    const int bStereo2 = stereo2[i2];
+                    if (only_stereo && !bStereo2) continue;
+                    const int dist = orc_hamming256(d1 + (size_t)i1 * 32, d2 + (size_t)i2 * 32);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = ex - k2[i2].x, distey = ey - k2[i2].y;
+                        if (distex * distex + distey * distey < 100 * scale_factors2[k2[i2].octave]) continue;
+                    }
+                    if (epipolar_ok(&k1[i1], &k2[i2], F12, level_sigma2_2)) { bestIdx2 = i2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    matches12[i1] = bestIdx2;
+                    nmatches++;
+                    if (check_orientation) {
+                        const int bin = rot_bin(k1[i1].angle, k2[bestIdx2].angle);
+                        rotHist[bin][rotN[bin]++] = i1;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (node1[a] < node2[b]) {
+            while (a < nodes1 && node1[a] < node2[b]) a++;
+        } else {
+            while (b < nodes2 && node2[b] < node1[a]) b++;
+        }
+    }
+    if (check_orientation) {
+        int ind1, ind2, ind3;
+        orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < rotN[i]; j++) { matches12[rotHist[i][j]] = -1; nmatches--; }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+    *nmatches_out = nmatches;
+    return 0;
+}
+
 /* f2  MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): among n observed descriptors the one with
  * the least median Hamming distance to the rest; median = sorted row [ (int)(0.5*(n-1)) ] (the row holds the 0 of the
  * diagonal), first minimum wins (:294-305). */

@@ -144,6 +144,13 @@ int   orc_search_by_bow_keyframes(const orc_keypoint* k1, const uint8_t* d1, con
                                   const orc_keypoint* k2, const uint8_t* d2, const uint8_t* has_mp2, int n2,
                                   const int32_t* node2, const int32_t* start2, const int32_t* idx2, int nodes2,
                                   float nn_ratio, int check_orientation, int32_t* matches12, int* nmatches);
+/* ORBmatcher::SearchForTriangulation (ORB/src/ORBmatcher.cc:663-829) + CheckDistEpipolarLine (:146-163) */
+int   orc_search_for_triangulation(const orc_keypoint* k1, const uint8_t* d1, const uint8_t* has_mp1, const uint8_t* stereo1, int n1,
+                                   const int32_t* node1, const int32_t* start1, const int32_t* idx1, int nodes1,
+                                   const orc_keypoint* k2, const uint8_t* d2, const uint8_t* has_mp2, const uint8_t* stereo2, int n2,
+                                   const int32_t* node2, const int32_t* start2, const int32_t* idx2, int nodes2,
+                                   const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2,
+                                   int only_stereo, int check_orientation, int32_t* matches12, int* nmatches);
 /* MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): index of the least-median descriptor */
 int   orc_distinctive_descriptor(const uint8_t* desc, int n, int* best_idx, int* best_median);
 /* ORBmatcher::UpdateQualityScores(Frame&) (ORB/src/ORBmatcher.cc:1108-1121) */

@@ -87,6 +87,8 @@ lib.orc_search_by_bow.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, 
                                   vp, C.POINTER(C.c_int)]
 lib.orc_search_by_bow_keyframes.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                                             C.c_float, C.c_int, vp, C.POINTER(C.c_int)]
+lib.orc_search_for_triangulation.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
+                                             vp, C.c_float, C.c_float, vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int)]
 lib.orc_fuse_candidates.argtypes = [vp, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
 pin.stl_retain_best.restype = C.c_int; pin.stl_retain_best.argtypes = [vp, C.c_int, C.c_int]
 pin.stl_nth_element.argtypes = [vp, C.c_int, C.c_int]
@@ -337,4 +339,18 @@ def search_by_bow_keyframes(k1, d1, has1, fv1, k2, d2, has2, fv2, nn_ratio=0.75,
     lib.orc_search_by_bow_keyframes(ptr(k1), ptr(d1), ptr(h1), len(k1), ptr(n1_), ptr(s1_), ptr(i1_), len(n1_),
                                     ptr(k2), ptr(d2), ptr(h2), len(k2), ptr(n2_), ptr(s2_), ptr(i2_), len(n2_),
                                     nn_ratio, int(check_orientation), ptr(m), C.byref(nm))
+    return m, nm.value
+
+
+def search_for_triangulation(k1, d1, has1, st1, fv1, k2, d2, has2, st2, fv2, F12, ex, ey, scale2, sigma2_2, only_stereo, check_orientation):
+    k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    h1 = np.ascontiguousarray(has1, np.uint8); h2 = np.ascontiguousarray(has2, np.uint8)
+    s1 = np.ascontiguousarray(st1, np.uint8); s2 = np.ascontiguousarray(st2, np.uint8)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9); sc = np.ascontiguousarray(scale2, np.float32); sg = np.ascontiguousarray(sigma2_2, np.float32)
+    a, b, c = feature_vector_csr(fv1); e, f, g = feature_vector_csr(fv2)
+    m = np.full(len(k1), -1, np.int32); nm = C.c_int(0)
+    lib.orc_search_for_triangulation(ptr(k1), ptr(d1), ptr(h1), ptr(s1), len(k1), ptr(a), ptr(b), ptr(c), len(a),
+                                     ptr(k2), ptr(d2), ptr(h2), ptr(s2), len(k2), ptr(e), ptr(f), ptr(g), len(e),
+                                     ptr(F), ex, ey, ptr(sc), ptr(sg), int(only_stereo), int(check_orientation), ptr(m), C.byref(nm))
     return m, nm.value

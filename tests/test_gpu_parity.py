@@ -324,6 +324,22 @@ def test_search_for_initialization_and_distinctive_descriptor(iv):
         assert gkn == okn and np.array_equal(gk, ok_) and gkn > 30
         assert has_mp[np.nonzero(gk >= 0)[0]].all() and has2[gk[gk >= 0]].all()
         assert len(np.unique(gk[gk >= 0])) == (gk >= 0).sum()                # vbMatched2: a KF2 feature is claimed once
+    # SearchForTriangulation: pure horizontal translation between the cameras => F12 = [t]x with t = (1,0,0): epipolar lines are
+    # the rows y2 = y1; the epipole is at infinity (put far outside the image) -- plus a tilted F to exercise the general case
+    sig2 = g.GetScaleSigmaSquares()
+    st1 = (rng.uniform(size=nq) > 0.5).astype(np.uint8); st2 = (rng.uniform(size=nq) > 0.5).astype(np.uint8)
+    nomp1 = (rng.uniform(size=nq) > 0.4).astype(np.uint8); nomp2 = (rng.uniform(size=nq) > 0.4).astype(np.uint8)
+    for F12, ex, ey in [(np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32), 1e6, 120.0),
+                        (np.array([[0, 0, 0.002], [0, 0, -1], [-0.002, 1, 0.3]], np.float32), 320.0, 118.0)]:
+        for only_st, ori in [(False, True), (True, True), (False, False)]:
+            mm = iv.ORBmatcher(0.6, ori)
+            gt, gtn = mm.SearchForTriangulation(k1, d1, 1 - nomp1, st1, fv1, k2, d2, 1 - nomp2, st2, fv2, F12, ex, ey, sc, sig2, only_st)
+            ot, otn = O.search_for_triangulation(k1, d1, 1 - nomp1, st1, fv1, k2, d2, 1 - nomp2, st2, fv2, F12, ex, ey, sc, sig2, only_st, ori)
+            assert gtn == otn and np.array_equal(gt, ot)
+            sel = np.nonzero(gt >= 0)[0]
+            assert nomp1[sel].all() and nomp2[gt[sel]].all()                 # only features without a map point
+            if only_st: assert st1[sel].all() and st2[gt[sel]].all()
+        assert gtn > 10
     gb2, gd2 = m.FuseCandidates(k2, d2, None, bounds, None, q)              # Fuse(KF, Scw, ...): no chi-square gate
     ob2, od2 = O.fuse_candidates(k2, d2, None, bounds, None, q)
     assert np.array_equal(gb2, ob2) and np.array_equal(gd2, od2) and (gb2 >= 0).sum() >= (gb >= 0).sum()
