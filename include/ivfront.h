@@ -285,6 +285,15 @@ int  ivf_search_for_triangulation(const ivf_keypoint* kps1, const uint8_t* desc1
                                   const int32_t* node2, const int32_t* start2, const int32_t* idx2, int nodes2,
                                   const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2, int n_levels,
                                   int only_stereo, int check_orientation, int32_t* matches12, int* nmatches, int device_id);
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist)
+ * (ORB/src/ORBmatcher.cc:1520-1652, Tracking::Relocalization) on the keyframe's projected map points (caller: :1543-1569):
+ * per map point u, v, radius = th * mvScaleFactors[level], level = nPredictedLevel, q_angle = pKF->mvKeysUn[i].angle and
+ * its descriptor.  cur_assign [n_cur] in/out: -1 = mvpMapPoints[i2] is NULL, -2 = occupied on entry, >= 0 = query index
+ * matched there; orb_dist = ORBdist; *nmatches = return value.  (UpdateQualityScores at :1641: ivf_update_quality_scores.) */
+int  ivf_search_by_projection_reloc(const ivf_keypoint* cur_kps, const uint8_t* cur_desc, int n_cur, const ivf_bounds* bounds,
+                                    int n_q, const float* q_u, const float* q_v, const float* q_radius, const int32_t* q_level,
+                                    const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid,
+                                    int orb_dist, int check_orientation, int32_t* cur_assign, int* nmatches, int device_id);
 /* MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): desc = the n observed descriptors (rows of
  * vDescriptors, in mObservations order); *best_index = the row to copy into mDescriptor, *best_median (nullable) its median. */
 int  ivf_distinctive_descriptor(const uint8_t* desc, int n, int* best_index, int* best_median, int device_id);

@@ -73,6 +73,8 @@ _SIGS = {
                                               C.c_float, C.c_int, vp, C.POINTER(C.c_int), C.c_int]),
     "ivf_search_for_triangulation": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                                                vp, C.c_float, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(C.c_int), C.c_int]),
+    "ivf_search_by_projection_reloc": (C.c_int, [vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int,
+                                                 vp, C.POINTER(C.c_int), C.c_int]),
     "ivf_fuse_candidates": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
                                       vp, vp, C.c_int]),
     "ivf_test_retain_best": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int]),

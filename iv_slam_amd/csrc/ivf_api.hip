@@ -1094,6 +1094,69 @@ int ivf_search_by_bow_keyframes(const ivf_keypoint* kps1, const uint8_t* desc1, 
     return IVF_OK;
 }
 
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist) (ORB/src/ORBmatcher.cc:1520-1652)
+int ivf_search_by_projection_reloc(const ivf_keypoint* cur_kps, const uint8_t* cur_desc, int n_cur, const ivf_bounds* bounds,
+                                   int n_q, const float* q_u, const float* q_v, const float* q_radius, const int32_t* q_level,
+                                   const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid,
+                                   int orb_dist, int check_orientation, int32_t* cur_assign, int* nmatches, int device_id)
+{
+    if (!cur_kps || !cur_desc || !bounds || !cur_assign || !nmatches || n_cur < 0 || n_q < 0) return fail(IVF_E_INVALID, "bad argument");
+    *nmatches = 0;
+    if (n_q == 0 || n_cur == 0) return IVF_OK;
+    if (!q_u || !q_v || !q_radius || !q_level || !q_angle || !q_desc) return fail(IVF_E_INVALID, "null query array");
+    Grid g; g.build(cur_kps, n_cur, *bounds);
+    std::vector<int> qStart(n_q + 1, 0), pairs;
+    for (int i = 0; i < n_q; i++) {
+        qStart[i] = (int)pairs.size() / 2;
+        if (q_valid && !q_valid[i]) continue;
+        g.query(cur_kps, *bounds, q_u[i], q_v[i], q_radius[i], q_level[i] - 1, q_level[i] + 1,
+                [&](int i2) { pairs.push_back(i); pairs.push_back(i2); });
+    }
+    qStart[n_q] = (int)pairs.size() / 2;
+    const int nPairs = qStart[n_q];
+    std::vector<int> dist(std::max(nPairs, 1));
+    int rc = ivf_hamming_pairs(q_desc, n_q, cur_desc, n_cur, pairs.data(), nPairs, dist.data(), device_id);
+    if (rc) return rc;
+    const int HISTO_LENGTH = 30;
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nm = 0;
+    for (int i = 0; i < n_q; i++) {
+        int bestDist = 256, bestIdx2 = -1;
+        for (int p = qStart[i]; p < qStart[i + 1]; p++) {
+            const int i2 = pairs[2 * p + 1];
+            if (cur_assign[i2] != -1) continue;
+            if (dist[p] < bestDist) { bestDist = dist[p]; bestIdx2 = i2; }
+        }
+        if (bestDist <= orb_dist && bestIdx2 >= 0) {
+            cur_assign[bestIdx2] = i; nm++;
+            if (check_orientation) {
+                float rot = q_angle[i] - cur_kps[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_orientation) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int sz = (int)rotHist[i].size();
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j : rotHist[i]) { cur_assign[j] = -1; nm--; }
+    }
+    *nmatches = nm;
+    return IVF_OK;
+}
+
 // ORBmatcher::SearchForTriangulation (ORB/src/ORBmatcher.cc:663-829) + CheckDistEpipolarLine (:146-163)
 int ivf_search_for_triangulation(const ivf_keypoint* kps1, const uint8_t* desc1, const uint8_t* has_map_point1, const uint8_t* stereo1, int n1,
                                  const int32_t* node1, const int32_t* start1, const int32_t* idx1, int nodes1,

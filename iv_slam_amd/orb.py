@@ -314,6 +314,20 @@ class ORBmatcher:
                                                      self.device_id))
         return m, nm.value
 
+    def SearchByProjectionReloc(self, cur_kps, cur_desc, bounds, q, ORBdist, cur_assign=None):
+        """SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1520-1652): q has u, v,
+        radius, level, angle, desc, valid.  Returns (CurrentFrame.mvpMapPoints as query indices, nmatches)."""
+        k = np.ascontiguousarray(cur_kps, KP_DTYPE); d = np.ascontiguousarray(cur_desc, np.uint8)
+        a = np.full(len(k), -1, np.int32) if cur_assign is None else np.ascontiguousarray(cur_assign, np.int32).copy()
+        t = dict(u=np.float32, v=np.float32, radius=np.float32, level=np.int32, angle=np.float32, desc=np.uint8, valid=np.uint8)
+        qq = {x: np.ascontiguousarray(q[x], y) for x, y in t.items()}
+        nm = C.c_int(0); bd = Bounds(*bounds)
+        check(self._lib.ivf_search_by_projection_reloc(ptr(k), ptr(d), len(k), C.byref(bd), len(qq["u"]), ptr(qq["u"]), ptr(qq["v"]),
+                                                       ptr(qq["radius"]), ptr(qq["level"]), ptr(qq["angle"]), ptr(qq["desc"]),
+                                                       ptr(qq["valid"]), int(ORBdist), int(self.mbCheckOrientation), ptr(a),
+                                                       C.byref(nm), self.device_id))
+        return a, nm.value
+
 
 def ComputeDistinctiveDescriptors(vDescriptors, device_id=0):
     """MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312) on the observed descriptors [n,32]:

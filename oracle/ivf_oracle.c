@@ -1458,6 +1458,56 @@ int orc_search_for_triangulation(const orc_keypoint* k1, const uint8_t* d1, cons
     return 0;
 }
 
+/* f9  ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist)
+ * (ORB/src/ORBmatcher.cc:1520-1652, relocalisation) on projected map points: window with levels [pred-1, pred+1] (:1571),
+ * any occupied keypoint is skipped (:1585-1586), first minimum accepted when <= ORBdist (:1597), rotation histogram
+ * against the keyframe keypoint's angle (:1604-1612), three-maxima filter (:1618-1637).
+ * cur_assign[i2]: in/out, -1 free, -2 occupied on entry, >= 0 query index. */
+int orc_search_by_projection_reloc(const orc_keypoint* cur_kps, const uint8_t* cur_desc, int n_cur, const orc_bounds* bounds,
+                                   int n_q, const float* q_u, const float* q_v, const float* q_radius, const int32_t* q_level,
+                                   const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid,
+                                   int orb_dist, int check_orientation, int32_t* cur_assign, int* nmatches_out)
+{
+    enum { HISTO_LENGTH = 30 };
+    int nmatches = 0;
+    int* rotHist[HISTO_LENGTH]; int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int*)malloc(sizeof(int) * (n_q > 0 ? n_q : 1)); rotN[i] = 0; }
+    grid_t g;
+    grid_build(&g, cur_kps, n_cur, bounds);
+    int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (n_cur > 0 ? n_cur : 1));
+    for (int i = 0; i < n_q; i++) {
+        if (q_valid && !q_valid[i]) continue;
+        const int nc = grid_query(&g, cur_kps, bounds, q_u[i], q_v[i], q_radius[i], q_level[i] - 1, q_level[i] + 1, cand, n_cur);
+        int bestDist = 256, bestIdx2 = -1;
+        for (int k = 0; k < nc; k++) {
+            const int i2 = cand[k];
+            if (cur_assign[i2] != -1) continue;
+            const int dist = orc_hamming256(q_desc + (size_t)i * 32, cur_desc + (size_t)i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= orb_dist && bestIdx2 >= 0) {
+            cur_assign[bestIdx2] = i;
+            nmatches++;
+            if (check_orientation) {
+                const int bin = rot_bin(q_angle[i], cur_kps[bestIdx2].angle);
+                rotHist[bin][rotN[bin]++] = bestIdx2;
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1, ind2, ind3;
+        orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < rotN[i]; j++) { cur_assign[rotHist[i][j]] = -1; nmatches--; }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+    free(cand);
+    grid_free(&g);
+    *nmatches_out = nmatches;
+    return 0;
+}
+
 /* f2  MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): among n observed descriptors the one with
  * the least median Hamming distance to the rest; median = sorted row [ (int)(0.5*(n-1)) ] (the row holds the 0 of the
  * diagonal), first minimum wins (:294-305). */

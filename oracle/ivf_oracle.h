@@ -151,6 +151,11 @@ int   orc_search_for_triangulation(const orc_keypoint* k1, const uint8_t* d1, co
                                    const int32_t* node2, const int32_t* start2, const int32_t* idx2, int nodes2,
                                    const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2,
                                    int only_stereo, int check_orientation, int32_t* matches12, int* nmatches);
+/* ORBmatcher::SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) (ORB/src/ORBmatcher.cc:1520-1652) */
+int   orc_search_by_projection_reloc(const orc_keypoint* cur_kps, const uint8_t* cur_desc, int n_cur, const orc_bounds* bounds,
+                                     int n_q, const float* q_u, const float* q_v, const float* q_radius, const int32_t* q_level,
+                                     const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid,
+                                     int orb_dist, int check_orientation, int32_t* cur_assign, int* nmatches);
 /* MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): index of the least-median descriptor */
 int   orc_distinctive_descriptor(const uint8_t* desc, int n, int* best_idx, int* best_median);
 /* ORBmatcher::UpdateQualityScores(Frame&) (ORB/src/ORBmatcher.cc:1108-1121) */

@@ -89,6 +89,8 @@ lib.orc_search_by_bow_keyframes.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c
                                             C.c_float, C.c_int, vp, C.POINTER(C.c_int)]
 lib.orc_search_for_triangulation.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                                              vp, C.c_float, C.c_float, vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int)]
+lib.orc_search_by_projection_reloc.argtypes = [vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int,
+                                               vp, C.POINTER(C.c_int)]
 lib.orc_fuse_candidates.argtypes = [vp, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
 pin.stl_retain_best.restype = C.c_int; pin.stl_retain_best.argtypes = [vp, C.c_int, C.c_int]
 pin.stl_nth_element.argtypes = [vp, C.c_int, C.c_int]
@@ -354,3 +356,16 @@ def search_for_triangulation(k1, d1, has1, st1, fv1, k2, d2, has2, st2, fv2, F12
                                      ptr(k2), ptr(d2), ptr(h2), ptr(s2), len(k2), ptr(e), ptr(f), ptr(g), len(e),
                                      ptr(F), ex, ey, ptr(sc), ptr(sg), int(only_stereo), int(check_orientation), ptr(m), C.byref(nm))
     return m, nm.value
+
+
+def search_by_projection_reloc(cur_kps, cur_desc, bounds, q, orb_dist, check_orientation, cur_assign=None):
+    """q: dict with u, v, radius, level, angle, desc, valid -> (mvpMapPoints as query indices, nmatches)."""
+    k = np.ascontiguousarray(cur_kps); d = np.ascontiguousarray(cur_desc, np.uint8)
+    a = np.full(len(k), -1, np.int32) if cur_assign is None else np.ascontiguousarray(cur_assign, np.int32).copy()
+    t = dict(u=np.float32, v=np.float32, radius=np.float32, level=np.int32, angle=np.float32, desc=np.uint8, valid=np.uint8)
+    qq = {x: np.ascontiguousarray(q[x], y) for x, y in t.items()}
+    nm = C.c_int(0); bd = Bounds(*bounds)
+    lib.orc_search_by_projection_reloc(ptr(k), ptr(d), len(k), C.byref(bd), len(qq["u"]), ptr(qq["u"]), ptr(qq["v"]), ptr(qq["radius"]),
+                                       ptr(qq["level"]), ptr(qq["angle"]), ptr(qq["desc"]), ptr(qq["valid"]), int(orb_dist),
+                                       int(check_orientation), ptr(a), C.byref(nm))
+    return a, nm.value

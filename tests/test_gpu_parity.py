@@ -340,6 +340,13 @@ def test_search_for_initialization_and_distinctive_descriptor(iv):
             assert nomp1[sel].all() and nomp2[gt[sel]].all()                 # only features without a map point
             if only_st: assert st1[sel].all() and st2[gt[sel]].all()
         assert gtn > 10
+    # relocalisation SearchByProjection(CurrentFrame, KF, ...): same perturbed projections, angles from "the keyframe"
+    qr = dict(q); qr["angle"] = ((k2["angle"] + rng.choice([0, 0, 0, 0, 75], nq)) % 360).astype(np.float32)
+    for orbd, ori in [(100, True), (64, True), (64, False), (0, True)]:
+        ga_, gn2 = iv.ORBmatcher(0.9, ori).SearchByProjectionReloc(k2, d2, bounds, qr, orbd, pre)
+        oa_, on2 = O.search_by_projection_reloc(k2, d2, bounds, qr, orbd, ori, pre)
+        assert gn2 == on2 and np.array_equal(ga_, oa_)
+    assert gn2 < nq // 4 and (ga_[pre == -2] == -2).all()
     gb2, gd2 = m.FuseCandidates(k2, d2, None, bounds, None, q)              # Fuse(KF, Scw, ...): no chi-square gate
     ob2, od2 = O.fuse_candidates(k2, d2, None, bounds, None, q)
     assert np.array_equal(gb2, ob2) and np.array_equal(gd2, od2) and (gb2 >= 0).sum() >= (gb >= 0).sum()
