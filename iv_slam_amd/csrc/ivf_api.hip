@@ -550,16 +550,30 @@ int ivf_hamming_pairs(const uint8_t* desc_a, int n_a, const uint8_t* desc_b, int
     int rc = have_device(device_id);
     if (rc) return rc;
     HIPCHK(hipSetDevice(device_id));
-    uint8_t *dA = nullptr, *dB = nullptr; int *dP = nullptr, *dD = nullptr;
-    HIPCHK(hipMalloc(&dA, (size_t)n_a * 32)); HIPCHK(hipMalloc(&dB, (size_t)n_b * 32));
-    HIPCHK(hipMalloc(&dP, (size_t)n_pairs * 2 * sizeof(int))); HIPCHK(hipMalloc(&dD, (size_t)n_pairs * sizeof(int)));
-    HIPCHK(hipMemcpy(dA, desc_a, (size_t)n_a * 32, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dB, desc_b, (size_t)n_b * 32, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dP, pairs, (size_t)n_pairs * 2 * sizeof(int), hipMemcpyHostToDevice));
+    // one growable device scratch per host thread: the matchers call this once per search, a hipMalloc / hipFree quartet
+    // per call would dominate their latency
+    struct Scratch {
+        int device = -1; uint8_t* buf = nullptr; size_t cap = 0;
+        ~Scratch() { if (buf) { (void)hipSetDevice(device); (void)hipFree(buf); } }
+    };
+    static thread_local Scratch sc;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t szA = up((size_t)n_a * 32), szB = up((size_t)n_b * 32), szP = up((size_t)n_pairs * 2 * sizeof(int)),
+                 szD = up((size_t)n_pairs * sizeof(int));
+    const size_t need = szA + szB + szP + szD;
+    if (sc.device != device_id || sc.cap < need) {
+        if (sc.buf) { (void)hipSetDevice(sc.device); (void)hipFree(sc.buf); sc.buf = nullptr; sc.cap = 0; HIPCHK(hipSetDevice(device_id)); }
+        const size_t cap = std::max(need + need / 2, (size_t)1 << 20);
+        HIPCHK(hipMalloc(&sc.buf, cap));
+        sc.cap = cap; sc.device = device_id;
+    }
+    uint8_t* dA = sc.buf; uint8_t* dB = dA + szA; int* dP = (int*)(dB + szB); int* dD = (int*)((uint8_t*)dP + szP);
+    HIPCHK(hipMemcpyAsync(dA, desc_a, (size_t)n_a * 32, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(dB, desc_b, (size_t)n_b * 32, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(dP, pairs, (size_t)n_pairs * 2 * sizeof(int), hipMemcpyHostToDevice, nullptr));
     launch_hamming_pairs(dA, dB, dP, n_pairs, dD, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(dist, dD, (size_t)n_pairs * sizeof(int), hipMemcpyDeviceToHost));
-    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dP); (void)hipFree(dD);
     return IVF_OK;
 }
 
