@@ -338,7 +338,8 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
 // each publishing a per-thread checksum instead of the block output): the expansion results written to sH are
 // deterministic (64), so are the prefetched depthwise parameters before (512) and after (2048) the stencil, and the
 // stencil with unit weights (256|32); the stencil's OUTPUT is not -- even with constant inputs instead of LDS reads
-// (1024|32), with private copies of the weights (4096) and with scalar instead of packed FMAs.  Declared VGPR / SGPR
+// (1024|32), with private copies of the weights (4096), with sleeps + nops around the MFMA phases (8192) and with
+// scalar instead of packed FMAs.  Declared VGPR / SGPR
 // counts match the ISA, there is no scratch, only ds_* LDS instructions, and the barrier protocol is the one
 // k_fcn_dwpw uses.  The cause was not found.  Until it is, the launcher
 // adds 40 KB of unused dynamic LDS so that a CU never holds two of them (IVF_FCN_BLOCK_CORESIDENT=1 lifts that for
@@ -513,6 +514,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ 
             __syncthreads();
         }
         // ---- phase 2: 3x3 depthwise + BN + ReLU6 out of LDS
+        if (xbar & 8192) { __builtin_amdgcn_s_sleep(8); asm volatile("s_nop 15\n s_nop 15"); }
         {
             float wk[9] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x};
             if (xbar & 256) { for (int k = 0; k < 9; k++) wk[k] = 1.f; }      // experiment: parameters out of the picture
@@ -579,6 +581,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ 
                 accO = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bh.v, accO, 0, 0, 0);
             }
         }
+        if (xbar & 8192) { __builtin_amdgcn_s_sleep(8); asm volatile("s_nop 15\n s_nop 15"); }
         if (xbar & 1) __syncthreads();
     };
     Pre PA, PB;                                     // two constant sets alternate: no register copies per chunk
