@@ -796,8 +796,11 @@ __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, c
 
 // pass 0 handles cells with <= kCellCapSmall candidates (12 KB LDS, many waves per CU); pass 1 the rest
 constexpr int kCellCapSmall = 1024, kCellCapBig = 4096;
-template <int CAP>
-__global__ __launch_bounds__(64) void k_cell_select(const Config* __restrict__ cfg, const unsigned* __restrict__ tileList,
+// NTHR = 64: one wave per cell (the common, small cells: many cells per CU).  NTHR = 256 for the big-cell pass: gather and
+// bitonic sort run on four waves (with the introspection quirk of overlapping cell domains most level-0/1 cells hold
+// 1-4 thousand candidates and a single wave spent ~100 us per cell in the sort); the introselect stays on wave 0.
+template <int CAP, int NTHR>
+__global__ __launch_bounds__(NTHR) void k_cell_select(const Config* __restrict__ cfg, const unsigned* __restrict__ tileList,
                                                    const int* __restrict__ tileCnt, const CellInfo* __restrict__ cellInfo,
                                                    const uint8_t* __restrict__ qpyr, const uint8_t* __restrict__ useCost,
                                                    u64* __restrict__ lvlList, int* __restrict__ status, int pass)
@@ -806,7 +809,12 @@ __global__ __launch_bounds__(64) void k_cell_select(const Config* __restrict__ c
     __shared__ __attribute__((aligned(16))) u64 ord[CAP];
     unsigned short* stopA = (unsigned short*)keys;            // the sort keys are dead once `ord` is built:
     unsigned short* stopB = stopA + CAP;                      // their space holds the partition stop lists
-    const int img = blockIdx.y, gc = blockIdx.x, lane = threadIdx.x;
+    __shared__ int s_m;
+    const int img = blockIdx.y, gc = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    auto sync = [&]() {
+        if constexpr (NTHR == 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    };
     int level = 0;
     const int nl = cfg->nlevels;
     for (int l = 1; l < nl; l++) if (cfg->lv[l].valid && gc >= cfg->lv[l].cellBase) level = l;
@@ -822,13 +830,15 @@ __global__ __launch_bounds__(64) void k_cell_select(const Config* __restrict__ c
     const unsigned th = info.useMin ? 1u : (unsigned)cfg->iniTh;
     const int kept = (nR >= 0 && nT > nR) ? nR : nT;
     u64* dst = lvlList + (size_t)img * cfg->candTotal + G.candBase + info.prefix;
-    if (nT > CAP) { if (lane == 0) atomicOr(status, 4); return; }    // > kCellCapBig survivors in one cell: unsupported
+    if (nT > CAP) { if (tid == 0) atomicOr(status, 4); return; }     // > kCellCapBig survivors in one cell: unsupported
     // a) collect the cell's survivors from the FAST tiles it overlaps, filtered by its rectangle and threshold
     //    (order irrelevant here)
     const int ci = c / G.cols, cj = c % G.cols;
     const int cx0 = kEdge + cj * G.cellW, cx1 = (cj == G.cols - 1) ? G.maxBX : cx0 + G.cellW;
     const int cy0 = kEdge + ci * G.cellH, cy1 = cy0 + ((ci == G.rows - 1) ? G.domHLast : G.domH[mode]);
     int m = 0;
+    if (tid == 0) s_m = 0;
+    sync();
     if (cy1 > cy0 && cx1 > cx0) {
         const int tx0 = (cx0 - 16) / kFastTW, tx1 = (cx1 - 1 - 16) / kFastTW;
         const int ty0 = (cy0 - kEdge) / kFastTH, ty1 = (cy1 - 1 - kEdge) / kFastTH;
@@ -837,43 +847,54 @@ __global__ __launch_bounds__(64) void k_cell_select(const Config* __restrict__ c
                 const size_t tile = (size_t)img * cfg->nTiles + G.tileBase + ty * G.tilesX + tx;
                 const int nAll = min(tileCnt[tile], kTileCap);
                 const unsigned* in = tileList + tile * kTileCap;
-                for (int b0 = 0; b0 < nAll; b0 += 64) {
-                    const int k = b0 + lane;
+                for (int b0 = 0; b0 < nAll; b0 += NTHR) {
+                    const int k = b0 + tid;
                     const unsigned e = k < nAll ? in[k] : 0u;
                     const int ex = (e >> 8) & 0xfff, ey = e >> 20;
                     const bool keep = k < nAll && (e & 0xffu) >= th && ex >= cx0 && ex < cx1 && ey >= cy0 && ey < cy1;
-                    const unsigned long long mask = __ballot(keep);
-                    if (keep) {
-                        const int idx = m + __popcll(mask & ((1ull << lane) - 1ull));
-                        if (idx < CAP) keys[idx] = e;
+                    if constexpr (NTHR == 64) {
+                        const unsigned long long mask = __ballot(keep);
+                        if (keep) {
+                            const int idx = m + __popcll(mask & ((1ull << lane) - 1ull));
+                            if (idx < CAP) keys[idx] = e;
+                        }
+                        m += __popcll(mask);
+                    } else {
+                        // order is irrelevant here (the sort restores it): one LDS atomic per wave reserves its slots
+                        const unsigned long long mask = __ballot(keep);
+                        int base = 0;
+                        if (lane == 0 && mask) base = atomicAdd(&s_m, __popcll(mask));
+                        base = __shfl(base, 0);
+                        if (keep) {
+                            const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+                            if (idx < CAP) keys[idx] = e;
+                        }
                     }
-                    m += __popcll(mask);
                 }
             }
     }
-    if (lane == 0 && m != nT) atomicOr(status, 1);                   // internal consistency
+    if constexpr (NTHR != 64) { sync(); m = s_m; }
+    if (tid == 0 && m != nT) atomicOr(status, 1);                    // internal consistency
     if (m != nT) return;
     {
         // b) bitonic sort of the packed positions (y<<20 | x<<8 | score): ascending = row-major
         int n2 = 64;
         while (n2 < m) n2 <<= 1;
-        for (int k = m + lane; k < n2; k += 64) keys[k] = 0xffffffffu;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        for (int k = m + tid; k < n2; k += NTHR) keys[k] = 0xffffffffu;
+        sync();
         for (int k = 2; k <= n2; k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = lane; i < n2 / 2; i += 64) {
+                for (int i = tid; i < n2 / 2; i += NTHR) {
                     const int l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
                     const int r = l | j;
                     const unsigned a = keys[l], b = keys[r];
                     const bool up = (l & k) == 0;
                     if ((a > b) == up) { keys[l] = b; keys[r] = a; }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                sync();
             }
         // c) 64-bit keys: response (x quality factor) | y | x
-        for (int k = lane; k < m; k += 64) {
+        for (int k = tid; k < m; k += NTHR) {
             const unsigned e = keys[k];
             const unsigned y = e >> 20, x = (e >> 8) & 0xfffu;
             float resp = (float)(e & 0xffu);
@@ -883,11 +904,11 @@ __global__ __launch_bounds__(64) void k_cell_select(const Config* __restrict__ c
             }
             ord[k] = ((u64)__float_as_uint(resp) << 32) | (y << 16) | x;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // d) retainBest
-        if (nR > 0 && nT > nR) sel_nth_element_wave(ord, nT, nR - 1, stopA, stopB, lane);
-        for (int k = lane; k < kept; k += 64) dst[k] = ord[k];
+        sync();
+        // d) retainBest (wave 0; the stop lists overlay `keys`, which every wave has finished reading)
+        if (nR > 0 && nT > nR && tid < 64) sel_nth_element_wave(ord, nT, nR - 1, stopA, stopB, lane);
+        sync();
+        for (int k = tid; k < kept; k += NTHR) dst[k] = ord[k];
     }
 }
 
@@ -1316,9 +1337,9 @@ void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nIm
         hipLaunchKernelGGL(k_cell_qsum, dim3((hc.nCellsTotal + 3) / 4, nImg), dim3(256), 0, s, dc, b.qpyr, b.useCost, (CellInfo*)b.cellInfo);
     hipLaunchKernelGGL(k_quota, dim3(hc.nlevels, nImg), dim3(256), 0, s, dc, b.cellCnt, b.qpyr, b.useCost,
                        (CellInfo*)b.cellInfo, b.lvlTotal);
-    hipLaunchKernelGGL((k_cell_select<kCellCapSmall>), dim3(hc.nCellsTotal, nImg), dim3(64), 0, s, dc, b.tileList, b.tileCnt,
+    hipLaunchKernelGGL((k_cell_select<kCellCapSmall, 64>), dim3(hc.nCellsTotal, nImg), dim3(64), 0, s, dc, b.tileList, b.tileCnt,
                        (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, 0);
-    hipLaunchKernelGGL((k_cell_select<kCellCapBig>), dim3(hc.nCellsTotal, nImg), dim3(64), 0, s, dc, b.tileList, b.tileCnt,
+    hipLaunchKernelGGL((k_cell_select<kCellCapBig, 256>), dim3(hc.nCellsTotal, nImg), dim3(256), 0, s, dc, b.tileList, b.tileCnt,
                        (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, 1);
     hipLaunchKernelGGL(k_level_select, dim3(hc.nlevels, nImg), dim3(256), 0, s, dc, b.lvlTotal, b.lvl, b.slotPos, b.slotResp,
                        b.lvlCount);
