@@ -338,8 +338,9 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
 // each publishing a per-thread checksum instead of the block output): the expansion results written to sH are
 // deterministic (64), so are the prefetched depthwise parameters before (512) and after (2048) the stencil, and the
 // stencil with unit weights (256|32); the stencil's OUTPUT is not -- even with constant inputs instead of LDS reads
-// (1024|32), with private copies of the weights (4096), with sleeps + nops around the MFMA phases (8192) and with
-// scalar instead of packed FMAs.  Declared VGPR / SGPR
+// (1024|32), with private copies of the weights (4096), with the weights loaded from global memory at their point of use
+// (16384; their checksum, 16384|512, is again deterministic), with sleeps + nops around the MFMA phases (8192) and with
+// scalar instead of packed FMAs.  (The checksum runs leave most of the block's output unwritten, i.e. stale.)  Declared VGPR / SGPR
 // counts match the ISA, there is no scratch, only ds_* LDS instructions, and the barrier protocol is the one
 // k_fcn_dwpw uses.  The cause was not found.  Until it is, the launcher
 // adds 40 KB of unused dynamic LDS so that a CU never holds two of them (IVF_FCN_BLOCK_CORESIDENT=1 lifts that for
@@ -517,6 +518,10 @@ __global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ 
         if (xbar & 8192) { __builtin_amdgcn_s_sleep(8); asm volatile("s_nop 15\n s_nop 15"); }
         {
             float wk[9] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x};
+            if (xbar & 16384) {               // experiment: parameters loaded at their point of use, not through the prefetch sets
+                const float* pq = dwP + (size_t)(ck * 32 + chl) * 12;
+                for (int k = 0; k < 9; k++) wk[k] = pq[k];
+            }
             if (xbar & 256) { for (int k = 0; k < 9; k++) wk[k] = 1.f; }      // experiment: parameters out of the picture
             if (xbar & 512) { for (int k = 0; k < 9; k++) dbgSum += wk[k]; dbgSum += p2.y + p2.z; }
             if (xbar & 4096) { for (int k = 0; k < 9; k++) asm volatile("" : "+v"(wk[k])); }     // experiment: private copies
