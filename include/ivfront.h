@@ -294,6 +294,23 @@ int  ivf_search_by_projection_reloc(const ivf_keypoint* cur_kps, const uint8_t* 
                                     int n_q, const float* q_u, const float* q_v, const float* q_radius, const int32_t* q_level,
                                     const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid,
                                     int orb_dist, int check_orientation, int32_t* cur_assign, int* nmatches, int device_id);
+/* ---- DBoW2 vocabulary: Frame::ComputeBoW / KeyFrame::ComputeBoW (ORB/src/Frame.cc:683-694, KeyFrame.cc:66-77) =
+ * mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4) (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1126-1259).
+ * The tree is handed over once as flat arrays (node 0 = root; children of node i = child[child_start[i] ..
+ * child_start[i+1]); node_desc [n_nodes][32]; node_word / node_weight = Node::word_id / Node::weight, read at leaves;
+ * depth_L = m_L) and stays on the device. */
+typedef struct ivf_vocabulary ivf_vocabulary;
+int  ivf_vocabulary_create(int n_nodes, const int32_t* child_start, const int32_t* child, const uint8_t* node_desc,
+                           const int32_t* node_word, const double* node_weight, int depth_L, int device_id, ivf_vocabulary** out);
+void ivf_vocabulary_destroy(ivf_vocabulary* v);
+/* per descriptor: word id, weight and the node at level L - levelsup (:1217-1259) */
+int  ivf_bow_transform(const ivf_vocabulary* v, const uint8_t* desc, int n, int levelsup,
+                       int32_t* word_id, int32_t* node_id, double* weight);
+/* mBowVec (TF-IDF, L1-normalised; word ids ascending) and mFeatVec (CSR, node ids ascending: the form ivf_search_by_bow*
+ * and ivf_search_for_triangulation take) from those results; *_cap = capacities (n is always enough), *_n = sizes. */
+int  ivf_bow_vectors(const int32_t* word_id, const int32_t* node_id, const double* weight, int n,
+                     int32_t* bow_word, double* bow_value, int bow_cap, int* bow_n,
+                     int32_t* fv_node, int32_t* fv_start, int32_t* fv_idx, int fv_cap, int* fv_n);
 /* MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): desc = the n observed descriptors (rows of
  * vDescriptors, in mObservations order); *best_index = the row to copy into mDescriptor, *best_median (nullable) its median. */
 int  ivf_distinctive_descriptor(const uint8_t* desc, int n, int* best_index, int* best_median, int device_id);

@@ -4,6 +4,7 @@ Only what the hot path needs: csrc/ (HIP kernels + the C-ABI, built into libivfr
 mirror of the reference's ORBextractor / ORBmatcher interfaces.  No CPU fallback.
 """
 from ._lib import KP_DTYPE, IvfError, load  # noqa: F401
-from .orb import ORBextractor, ORBmatcher, ComputeStereoMatches, GetFeaturesInArea, ComputeDistinctiveDescriptors  # noqa: F401
+from .orb import (ORBextractor, ORBmatcher, ORBVocabulary, ComputeStereoMatches, GetFeaturesInArea,  # noqa: F401
+                  ComputeDistinctiveDescriptors)
 from .frontend import StereoFrontend  # noqa: F401
 from .fcn import IntrospectionFCN  # noqa: F401

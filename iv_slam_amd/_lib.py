@@ -75,6 +75,10 @@ _SIGS = {
                                                vp, C.c_float, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(C.c_int), C.c_int]),
     "ivf_search_by_projection_reloc": (C.c_int, [vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int,
                                                  vp, C.POINTER(C.c_int), C.c_int]),
+    "ivf_vocabulary_create": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(vp)]),
+    "ivf_vocabulary_destroy": (None, [vp]),
+    "ivf_bow_transform": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+    "ivf_bow_vectors": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int), vp, vp, vp, C.c_int, C.POINTER(C.c_int)]),
     "ivf_fuse_candidates": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
                                       vp, vp, C.c_int]),
     "ivf_test_retain_best": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int]),

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <map>
 #include <vector>
 #include <algorithm>
 
@@ -1269,6 +1270,117 @@ int ivf_search_for_triangulation(const ivf_keypoint* kps1, const uint8_t* desc1,
                 for (int j : rotHist[i]) { matches12[j] = -1; nm--; }
     }
     *nmatches = nm;
+    return IVF_OK;
+}
+
+// DBoW2 vocabulary (device-resident tree) and TemplatedVocabulary::transform per descriptor
+struct ivf_vocabulary {
+    int device = 0, nNodes = 0, depth = 0, maxChildren = 0;
+    int *dChildStart = nullptr, *dChild = nullptr; uint8_t* dDesc = nullptr;
+    std::vector<int> word; std::vector<double> weight; std::vector<int> childStart;
+};
+
+int ivf_vocabulary_create(int n_nodes, const int32_t* child_start, const int32_t* child, const uint8_t* node_desc,
+                          const int32_t* node_word, const double* node_weight, int depth_L, int device_id, ivf_vocabulary** out)
+{
+    if (!out) return fail(IVF_E_INVALID, "null argument");
+    *out = nullptr;
+    if (n_nodes < 2 || !child_start || !child || !node_desc || !node_word || !node_weight || depth_L < 1)
+        return fail(IVF_E_INVALID, "bad argument");
+    if (child_start[0] != 0) return fail(IVF_E_INVALID, "child_start[0] must be 0");
+    const int nChild = child_start[n_nodes];
+    if (child_start[1] == child_start[0]) return fail(IVF_E_INVALID, "the root (node 0) has no children");
+    int maxC = 0;
+    for (int i = 0; i < n_nodes; i++) {
+        if (child_start[i + 1] < child_start[i]) return fail(IVF_E_INVALID, "child_start must not decrease (node %d)", i);
+        maxC = std::max(maxC, child_start[i + 1] - child_start[i]);
+    }
+    if (maxC > 65535) return fail(IVF_E_INVALID, "more than 65535 children under one node");
+    for (int c = 0; c < nChild; c++) if (child[c] <= 0 || child[c] >= n_nodes) return fail(IVF_E_INVALID, "child %d: node id out of range", c);
+    {   // the descent kernel loops until it meets a leaf: refuse anything that is not a tree rooted at node 0
+        std::vector<char> seen(n_nodes, 0); std::vector<int> stack{0}; seen[0] = 1;
+        while (!stack.empty()) {
+            const int i = stack.back(); stack.pop_back();
+            for (int c = child_start[i]; c < child_start[i + 1]; c++) {
+                if (seen[child[c]]) return fail(IVF_E_INVALID, "node %d is reachable twice: not a tree", child[c]);
+                seen[child[c]] = 1; stack.push_back(child[c]);
+            }
+        }
+    }
+    int rc = have_device(device_id);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    ivf_vocabulary* v = new ivf_vocabulary();
+    v->device = device_id; v->nNodes = n_nodes; v->depth = depth_L; v->maxChildren = maxC;
+    v->word.assign(node_word, node_word + n_nodes); v->weight.assign(node_weight, node_weight + n_nodes);
+    v->childStart.assign(child_start, child_start + n_nodes + 1);
+    if (hipMalloc(&v->dChildStart, (size_t)(n_nodes + 1) * sizeof(int)) != hipSuccess || hipMalloc(&v->dChild, (size_t)std::max(nChild, 1) * sizeof(int)) != hipSuccess ||
+        hipMalloc(&v->dDesc, (size_t)n_nodes * 32) != hipSuccess) { ivf_vocabulary_destroy(v); return fail(IVF_E_NO_DEVICE, "hipMalloc failed for the vocabulary"); }
+    HIPCHK(hipMemcpy(v->dChildStart, child_start, (size_t)(n_nodes + 1) * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(v->dChild, child, (size_t)nChild * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(v->dDesc, node_desc, (size_t)n_nodes * 32, hipMemcpyHostToDevice));
+    *out = v;
+    return IVF_OK;
+}
+
+void ivf_vocabulary_destroy(ivf_vocabulary* v)
+{
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    if (v->dChildStart) (void)hipFree(v->dChildStart);
+    if (v->dChild) (void)hipFree(v->dChild);
+    if (v->dDesc) (void)hipFree(v->dDesc);
+    delete v;
+}
+
+int ivf_bow_transform(const ivf_vocabulary* v, const uint8_t* desc, int n, int levelsup, int32_t* word_id, int32_t* node_id, double* weight)
+{
+    if (!v || n < 0 || (n > 0 && (!desc || !word_id || !node_id || !weight))) return fail(IVF_E_INVALID, "bad argument");
+    if (n == 0) return IVF_OK;
+    HIPCHK(hipSetDevice(v->device));
+    uint8_t* dD = nullptr; int* dOut = nullptr;
+    HIPCHK(hipMalloc(&dD, (size_t)n * 32)); HIPCHK(hipMalloc(&dOut, (size_t)n * 2 * sizeof(int)));
+    HIPCHK(hipMemcpy(dD, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+    launch_bow_transform(v->dChildStart, v->dChild, v->dDesc, dD, n, v->depth - levelsup, dOut, dOut + n, nullptr);
+    HIPCHK(hipGetLastError());
+    std::vector<int> res((size_t)n * 2);
+    HIPCHK(hipMemcpy(res.data(), dOut, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(dD); (void)hipFree(dOut);
+    for (int f = 0; f < n; f++) {
+        const int leaf = res[f];
+        word_id[f] = v->word[leaf]; weight[f] = v->weight[leaf]; node_id[f] = res[(size_t)n + f];
+    }
+    return IVF_OK;
+}
+
+// BowVector / FeatureVector of one frame from the per-descriptor results (TemplatedVocabulary.h:1126-1204 with TF_IDF weights
+// and L1 normalisation, the ORB vocabulary's settings; BowVector.cpp:34-46, 62-84; FeatureVector.cpp:31-45)
+int ivf_bow_vectors(const int32_t* word_id, const int32_t* node_id, const double* weight, int n,
+                    int32_t* bow_word, double* bow_value, int bow_cap, int* bow_n,
+                    int32_t* fv_node, int32_t* fv_start, int32_t* fv_idx, int fv_cap, int* fv_n)
+{
+    if (n < 0 || !bow_n || !fv_n || (n > 0 && (!word_id || !node_id || !weight))) return fail(IVF_E_INVALID, "bad argument");
+    std::map<int, double> bow; std::map<int, std::vector<int>> fv;
+    for (int f = 0; f < n; f++) {
+        if (!(weight[f] > 0)) continue;                                  // stopped word (:1157)
+        bow[word_id[f]] += weight[f];                                    // addWeight
+        fv[node_id[f]].push_back(f);                                     // addFeature
+    }
+    double norm = 0.0;
+    for (auto& kv : bow) norm += fabs(kv.second);                        // L1 (BowVector.cpp:67-71)
+    if (norm > 0.0) for (auto& kv : bow) kv.second /= norm;
+    *bow_n = (int)bow.size(); *fv_n = (int)fv.size();
+    if ((int)bow.size() > bow_cap || (int)fv.size() > fv_cap) return fail(IVF_E_CAPACITY, "%zu words / %zu nodes exceed the capacities", bow.size(), fv.size());
+    int k = 0;
+    for (auto& kv : bow) { if (bow_word) bow_word[k] = kv.first; if (bow_value) bow_value[k] = kv.second; k++; }
+    k = 0; int pos = 0;
+    if (fv_start) fv_start[0] = 0;
+    for (auto& kv : fv) {
+        if (fv_node) fv_node[k] = kv.first;
+        for (int i : kv.second) { if (fv_idx) fv_idx[pos] = i; pos++; }
+        if (fv_start) fv_start[k + 1] = pos;
+        k++;
+    }
     return IVF_OK;
 }
 

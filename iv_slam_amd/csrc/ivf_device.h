@@ -104,5 +104,7 @@ void launch_stereo(const Config& hc, const Config* dc, const Buffers& b, int nPa
 void launch_test_retain_best(const float* dResp, int n, int nPoints, int* dOrder, hipStream_t s);
 void launch_hamming_pairs(const uint8_t* a, const uint8_t* b, const int* pairs, int n, int* dist, hipStream_t s);
 void launch_distinct_median(const uint8_t* desc, int n, int* median, hipStream_t s);
+void launch_bow_transform(const int* childStart, const int* child, const uint8_t* nodeDesc, const uint8_t* desc, int n, int nidLevel,
+                          int* leaf, int* nodeAt, hipStream_t s);
 
 }  // namespace ivf

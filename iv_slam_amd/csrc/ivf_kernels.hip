@@ -1398,6 +1398,43 @@ void launch_distinct_median(const uint8_t* desc, int n, int* median, hipStream_t
     hipLaunchKernelGGL(k_distinct_median, dim3(n), dim3(256), 0, s, desc, n, median);
 }
 
+// ---- DBoW2 vocabulary-tree descent (TemplatedVocabulary.h:1217-1259): 16 lanes per descriptor, one child per lane per
+// round, (distance << 16 | position) min-reduction across the 16 lanes = "first minimum in child order"
+__global__ __launch_bounds__(256) void k_bow_transform(const int* __restrict__ childStart, const int* __restrict__ child,
+                                                      const uint8_t* __restrict__ nodeDesc, const uint8_t* __restrict__ desc,
+                                                      int n, int nidLevel, int* __restrict__ leaf, int* __restrict__ nodeAt)
+{
+    const int f = (blockIdx.x * 256 + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+    const bool live = f < n;
+    const uint4* pf = (const uint4*)(desc + (size_t)(live ? f : 0) * 32);
+    const uint4 a0 = pf[0], a1 = pf[1];
+    int node = 0, level = 0, nid = 0;
+    for (;;) {
+        const int c0 = childStart[node], c1 = childStart[node + 1];
+        if (c1 == c0) break;                                              // leaf (uniform within the 16 lanes)
+        ++level;
+        unsigned best = 0xffffffffu;
+        for (int c = c0 + sub; c < c1; c += 16) {
+            const int id = child[c];
+            const uint4* pn = (const uint4*)(nodeDesc + (size_t)id * 32);
+            const unsigned key = ((unsigned)hamming256(a0, a1, pn[0], pn[1]) << 16) | (unsigned)(c - c0);
+            best = min(best, key);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o, 16));
+        node = child[c0 + (int)(best & 0xffffu)];
+        if (level == nidLevel) nid = node;
+    }
+    if (live && sub == 0) { leaf[f] = node; nodeAt[f] = nidLevel <= 0 ? 0 : nid; }
+}
+
+void launch_bow_transform(const int* childStart, const int* child, const uint8_t* nodeDesc, const uint8_t* desc, int n, int nidLevel,
+                          int* leaf, int* nodeAt, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_bow_transform, dim3((n * 16 + 255) / 256), dim3(256), 0, s, childStart, child, nodeDesc, desc, n, nidLevel, leaf, nodeAt);
+}
+
 void launch_hamming_pairs(const uint8_t* a, const uint8_t* b, const int* pairs, int n, int* dist, hipStream_t s)
 {
     if (n <= 0) return;

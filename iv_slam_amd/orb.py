@@ -339,3 +339,44 @@ def ComputeDistinctiveDescriptors(vDescriptors, device_id=0):
     bi = C.c_int(0); bm = C.c_int(0)
     check(lib.ivf_distinctive_descriptor(ptr(d), len(d), C.byref(bi), C.byref(bm), device_id))
     return bi.value, bm.value
+
+
+class ORBVocabulary:
+    """DBoW2 ORB vocabulary on the device (TemplatedVocabulary<FORB::TDescriptor, FORB>): transform() as
+    Frame::ComputeBoW / KeyFrame::ComputeBoW call it (ORB/src/Frame.cc:683-694)."""
+
+    def __init__(self, child_start, child, node_desc, node_word, node_weight, depth_L, device_id=0):
+        self._lib = _lib.load()
+        cs = np.ascontiguousarray(child_start, np.int32); ch = np.ascontiguousarray(child, np.int32)
+        nd = np.ascontiguousarray(node_desc, np.uint8).reshape(-1, 32)
+        wd = np.ascontiguousarray(node_word, np.int32); wt = np.ascontiguousarray(node_weight, np.float64)
+        if not (len(cs) == len(nd) + 1 == len(wd) + 1 == len(wt) + 1):
+            raise AssertionError("one child_start / descriptor / word id / weight entry per node")
+        h = C.c_void_p()
+        check(self._lib.ivf_vocabulary_create(len(nd), ptr(cs), ptr(ch), ptr(nd), ptr(wd), ptr(wt), int(depth_L), device_id, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.ivf_vocabulary_destroy(self._h)
+            self._h = None
+
+    def transform_features(self, descriptors, levelsup=4):
+        """Per descriptor (word id, node id at level L - levelsup, weight) (TemplatedVocabulary.h:1217-1259)."""
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32); n = len(d)
+        wid = np.zeros(n, np.int32); nid = np.zeros(n, np.int32); wt = np.zeros(n, np.float64)
+        check(self._lib.ivf_bow_transform(self._h, ptr(d), n, int(levelsup), ptr(wid), ptr(nid), ptr(wt)))
+        return wid, nid, wt
+
+    def transform(self, descriptors, levelsup=4):
+        """transform(features, BowVector&, FeatureVector&, levelsup) (:1126-1204): returns (mBowVec as {word: value},
+        mFeatVec as {node: [feature indices]})."""
+        wid, nid, wt = self.transform_features(descriptors, levelsup)
+        n = len(wid); cap = max(n, 1)
+        bw = np.zeros(cap, np.int32); bv = np.zeros(cap, np.float64); fn = np.zeros(cap, np.int32)
+        fs = np.zeros(cap + 1, np.int32); fi = np.zeros(cap, np.int32); nb = C.c_int(0); nf = C.c_int(0)
+        check(self._lib.ivf_bow_vectors(ptr(wid), ptr(nid), ptr(wt), n, ptr(bw), ptr(bv), cap, C.byref(nb), ptr(fn), ptr(fs), ptr(fi),
+                                        cap, C.byref(nf)))
+        bow = {int(bw[k]): float(bv[k]) for k in range(nb.value)}
+        fv = {int(fn[k]): [int(x) for x in fi[fs[k]:fs[k + 1]]] for k in range(nf.value)}
+        return bow, fv

@@ -1508,6 +1508,41 @@ int orc_search_by_projection_reloc(const orc_keypoint* cur_kps, const uint8_t* c
     return 0;
 }
 
+/* f10  DBoW2 TemplatedVocabulary<FORB>::transform(feature, word_id, weight, nid, levelsup)
+ * (ORB/Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1217-1259) as called for every descriptor by Frame::ComputeBoW /
+ * KeyFrame::ComputeBoW (ORB/src/Frame.cc:683-694, KeyFrame.cc:66-77: levelsup = 4): from the root, at every level the child
+ * with the smallest Hamming distance (first minimum, :1237-1248); the node reached at level L - levelsup is recorded
+ * (:1227-1228: root when that level is <= 0; :1250-1251); the leaf gives word id and weight (:1255-1257).
+ * The tree as flat arrays: children of node i = child[child_start[i] .. child_start[i+1]) (none = leaf). */
+int orc_bow_transform(int n_nodes, const int32_t* child_start, const int32_t* child, const uint8_t* node_desc,
+                      const int32_t* node_word, const double* node_weight, int depth_L,
+                      const uint8_t* desc, int n, int levelsup, int32_t* word_id, int32_t* node_id, double* weight)
+{
+    const int nid_level = depth_L - levelsup;
+    for (int f = 0; f < n; f++) {
+        int nid = 0, final_id = 0, current_level = 0;
+        if (child_start[1] == child_start[0]) return -1;                   /* a root without children is not a vocabulary */
+        do {
+            ++current_level;
+            const int c0 = child_start[final_id], c1 = child_start[final_id + 1];
+            int best = child[c0];
+            int best_d = orc_hamming256(desc + (size_t)f * 32, node_desc + (size_t)best * 32);
+            for (int c = c0 + 1; c < c1; c++) {
+                const int id = child[c];
+                const int d = orc_hamming256(desc + (size_t)f * 32, node_desc + (size_t)id * 32);
+                if (d < best_d) { best_d = d; best = id; }
+            }
+            final_id = best;
+            if (current_level == nid_level) nid = final_id;
+        } while (child_start[final_id + 1] != child_start[final_id]);
+        (void)n_nodes;
+        word_id[f] = node_word[final_id];
+        weight[f] = node_weight[final_id];
+        node_id[f] = nid_level <= 0 ? 0 : nid;
+    }
+    return 0;
+}
+
 /* f2  MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): among n observed descriptors the one with
  * the least median Hamming distance to the rest; median = sorted row [ (int)(0.5*(n-1)) ] (the row holds the 0 of the
  * diagonal), first minimum wins (:294-305). */

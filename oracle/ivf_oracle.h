@@ -156,6 +156,10 @@ int   orc_search_by_projection_reloc(const orc_keypoint* cur_kps, const uint8_t*
                                      int n_q, const float* q_u, const float* q_v, const float* q_radius, const int32_t* q_level,
                                      const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid,
                                      int orb_dist, int check_orientation, int32_t* cur_assign, int* nmatches);
+/* DBoW2 TemplatedVocabulary<FORB>::transform per descriptor (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1217-1259) */
+int   orc_bow_transform(int n_nodes, const int32_t* child_start, const int32_t* child, const uint8_t* node_desc,
+                        const int32_t* node_word, const double* node_weight, int depth_L,
+                        const uint8_t* desc, int n, int levelsup, int32_t* word_id, int32_t* node_id, double* weight);
 /* MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:247-312): index of the least-median descriptor */
 int   orc_distinctive_descriptor(const uint8_t* desc, int n, int* best_idx, int* best_median);
 /* ORBmatcher::UpdateQualityScores(Frame&) (ORB/src/ORBmatcher.cc:1108-1121) */

@@ -91,6 +91,7 @@ lib.orc_search_for_triangulation.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp
                                              vp, C.c_float, C.c_float, vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int)]
 lib.orc_search_by_projection_reloc.argtypes = [vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int,
                                                vp, C.POINTER(C.c_int)]
+lib.orc_bow_transform.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]
 lib.orc_fuse_candidates.argtypes = [vp, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
 pin.stl_retain_best.restype = C.c_int; pin.stl_retain_best.argtypes = [vp, C.c_int, C.c_int]
 pin.stl_nth_element.argtypes = [vp, C.c_int, C.c_int]
@@ -369,3 +370,37 @@ def search_by_projection_reloc(cur_kps, cur_desc, bounds, q, orb_dist, check_ori
                                        ptr(qq["level"]), ptr(qq["angle"]), ptr(qq["desc"]), ptr(qq["valid"]), int(orb_dist),
                                        int(check_orientation), ptr(a), C.byref(nm))
     return a, nm.value
+
+
+def make_vocabulary(k, depth, seed, early_leaf_frac=0.0, stop_frac=0.0):
+    """Synthetic DBoW2-shaped vocabulary tree as flat arrays: dict(child_start, child, desc, word, weight, depth)."""
+    rng = np.random.default_rng(seed)
+    children = [[]]; level = [0]; frontier = [0]
+    for lv in range(1, depth + 1):
+        nxt = []
+        for node in frontier:
+            if lv > 1 and rng.uniform() < early_leaf_frac: continue            # a leaf above the last level
+            kk = k if rng.uniform() > 0.3 else int(rng.integers(1, k + 1))     # ragged branching
+            for _ in range(kk):
+                children.append([]); level.append(lv); children[node].append(len(children) - 1); nxt.append(len(children) - 1)
+        frontier = nxt
+    n = len(children)
+    start = np.zeros(n + 1, np.int32); flat = []
+    for i in range(n):
+        flat.extend(children[i]); start[i + 1] = len(flat)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    word = np.full(n, -1, np.int32); weight = np.zeros(n, np.float64); w = 0
+    for i in range(n):
+        if not children[i]:
+            word[i] = w; w += 1
+            weight[i] = 0.0 if rng.uniform() < stop_frac else float(rng.uniform(0.1, 9.0))
+    return dict(child_start=start, child=np.array(flat, np.int32), desc=desc, word=word, weight=weight, depth=depth, n_words=w)
+
+
+def bow_transform(voc, desc, levelsup=4):
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); n = len(d)
+    wid = np.zeros(n, np.int32); nid = np.zeros(n, np.int32); wt = np.zeros(n, np.float64)
+    rc = lib.orc_bow_transform(len(voc["word"]), ptr(voc["child_start"]), ptr(voc["child"]), ptr(voc["desc"]), ptr(voc["word"]),
+                               ptr(voc["weight"]), voc["depth"], ptr(d), n, levelsup, ptr(wid), ptr(nid), ptr(wt))
+    assert rc == 0
+    return wid, nid, wt

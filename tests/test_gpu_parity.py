@@ -352,6 +352,47 @@ def test_search_for_initialization_and_distinctive_descriptor(iv):
     assert np.array_equal(gb2, ob2) and np.array_equal(gd2, od2) and (gb2 >= 0).sum() >= (gb >= 0).sum()
 
 
+def test_bow_transform_and_vectors(iv):
+    """DBoW2 transform (descriptor -> word / node / weight), BowVector, FeatureVector, and the
+    feature vectors feeding SearchByBoW end to end."""
+    rng = np.random.default_rng(17)
+    g = iv.ORBextractor(800, 1.2, 8, 20, 7)
+    k1, d1 = g(synth.make_left(640, 240, seed=53, idx=0))
+    for k, depth, early, levelsup in [(10, 3, 0.0, 1), (10, 4, 0.1, 4), (5, 6, 0.15, 4), (2, 1, 0.0, 4), (17, 2, 0.0, 1)]:
+        voc = O.make_vocabulary(k, depth, seed=100 + k + depth, early_leaf_frac=early, stop_frac=0.1)
+        V = iv.ORBVocabulary(voc["child_start"], voc["child"], voc["desc"], voc["word"], voc["weight"], voc["depth"])
+        desc = np.concatenate([d1, voc["desc"][rng.integers(1, len(voc["desc"]), 50)]])      # incl. exact node descriptors (ties)
+        gw, gn, gt = V.transform_features(desc, levelsup)
+        ow, on, ot = O.bow_transform(voc, desc, levelsup)
+        assert np.array_equal(gw, ow) and np.array_equal(gn, on) and np.array_equal(gt, ot)
+        bow, fv = V.transform(desc, levelsup)
+        # restatement of BowVector::addWeight + L1 normalize and FeatureVector::addFeature (DBoW2 BowVector.cpp, FeatureVector.cpp)
+        eb, ef = {}, {}
+        for f in range(len(desc)):
+            if ot[f] > 0:
+                eb[int(ow[f])] = eb.get(int(ow[f]), 0.0) + float(ot[f]); ef.setdefault(int(on[f]), []).append(f)
+        norm = 0.0
+        for w_ in sorted(eb): norm += abs(eb[w_])
+        eb = {w_: v_ / norm for w_, v_ in eb.items()} if norm > 0 else eb
+        assert bow == eb and fv == ef and abs(sum(bow.values()) - 1.0) < 1e-12
+    # end to end: two frames through the same vocabulary, then SearchByBoW on their feature vectors
+    voc = O.make_vocabulary(10, 3, seed=7)
+    V = iv.ORBVocabulary(voc["child_start"], voc["child"], voc["desc"], voc["word"], voc["weight"], voc["depth"])
+    d2 = d1.copy()
+    for i in range(len(d2)):
+        for bpos in rng.integers(0, 256, 4):
+            d2[i, bpos // 8] ^= np.uint8(1 << (bpos % 8))
+    _, fv1 = V.transform(d1, 1); _, fv2 = V.transform(d2, 1)
+    has = np.ones(len(k1), np.uint8)
+    m = iv.ORBmatcher(0.7, True)
+    gm, gn_ = m.SearchByBoW(k1, d1, has, fv1, k1, d2, fv2)
+    om, on_ = O.search_by_bow(k1, d1, has, fv1, k1, d2, fv2, 0.7, True)
+    assert gn_ == on_ and np.array_equal(gm, om) and gn_ > len(k1) // 4
+    assert (gm[gm >= 0] == np.nonzero(gm >= 0)[0]).mean() > 0.95
+    with pytest.raises(iv.IvfError):                                      # a child listed twice is not a tree
+        iv.ORBVocabulary(np.array([0, 2, 2, 2], np.int32), np.array([1, 1], np.int32), voc["desc"][:3], np.zeros(3, np.int32), np.ones(3), 1)
+
+
 def test_full_size_properties(iv):
     """BASELINE full size: properties that need no oracle (idempotence, level order, border, uniqueness)."""
     img = synth.make_left(1242, 375, seed=61, idx=0)

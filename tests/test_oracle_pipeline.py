@@ -299,3 +299,23 @@ def test_bow_and_sim3_oracle_properties():
     d120 = desc.copy(); d120[:, :15] ^= np.uint8(0xFF); q120 = dict(q); q120["desc"] = d120
     assert O.search_by_sim3(kps, desc, bounds, kps, desc, bounds, q80, q80)[1] > 0.5 * n
     assert O.search_by_sim3(kps, desc, bounds, kps, desc, bounds, q120, q120)[1] == 0
+
+
+def test_bow_transform_matches_a_direct_restatement():
+    """f10 DBoW2 transform (TemplatedVocabulary.h:1217-1259): C oracle vs a few lines of numpy on ragged synthetic trees."""
+    rng = np.random.default_rng(3)
+    for k, depth, early, levelsup in [(10, 3, 0.0, 1), (4, 5, 0.2, 2), (3, 2, 0.0, 4), (10, 4, 0.1, 4)]:
+        voc = O.make_vocabulary(k, depth, seed=k * 10 + depth, early_leaf_frac=early, stop_frac=0.1)
+        desc = rng.integers(0, 256, (200, 32), dtype=np.uint8)
+        wid, nid, wt = O.bow_transform(voc, desc, levelsup)
+        cs, ch = voc["child_start"], voc["child"]
+        for f in range(len(desc)):
+            node, lv, rec = 0, 0, 0
+            while cs[node + 1] > cs[node]:
+                lv += 1
+                kids = ch[cs[node]:cs[node + 1]]
+                d = [O.hamming(desc[f], voc["desc"][c]) for c in kids]
+                node = int(kids[int(np.argmin(d))])                       # argmin = first minimum
+                if lv == depth - levelsup: rec = node
+            assert wid[f] == voc["word"][node] and wt[f] == voc["weight"][node]
+            assert nid[f] == (0 if depth - levelsup <= 0 else rec)
