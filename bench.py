@@ -72,9 +72,11 @@ def cpu_baseline(pairs_sample, cores):
     return done / dt, dt
 
 
-def cpu_fcn_baseline(n_images=2):
-    """numpy oracle of the introspection FCN (oracle/fcn_oracle.py, f32; BLAS uses its default threads)."""
+def cpu_fcn_baseline(threads):
+    """numpy oracle of the introspection FCN (oracle/fcn_oracle.py, f32): one forward per worker thread (numpy releases
+    the GIL inside its kernels; BLAS keeps its default threading)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import concurrent.futures as cf
     import numpy as np
     import fcn_oracle               # checker / baseline only -- never on the product path
     from iv_slam_amd import fcn_weights, synth
@@ -82,10 +84,10 @@ def cpu_fcn_baseline(n_images=2):
     img = np.stack([synth.make_left(W, H, seed=901, idx=c) for c in range(3)], axis=-1)
     fcn_oracle.forward(Wt, img, (H, W))
     t0 = time.perf_counter()
-    for _ in range(n_images):
-        fcn_oracle.forward(Wt, img, (H, W))
+    with cf.ThreadPoolExecutor(threads) as ex:
+        done = sum(1 for _ in ex.map(lambda i: fcn_oracle.forward(Wt, img, (H, W)), range(threads)))
     dt = time.perf_counter() - t0
-    return n_images / dt, dt
+    return done / dt, dt
 
 
 # algorithmic HBM bytes of the probed FCN launch per image: hidden tensor read once
@@ -273,9 +275,9 @@ def main():
             txt = ("%d pairs of the same 1242x375/1000-feature workload, one pair per thread, %.1f s wall "
                    "(oracle/libivf_oracle.so, scalar C, -O3 -ffp-contract=off)" % (sample, secs))
             if args.introspect:
-                fv, fsecs = cpu_fcn_baseline(4)
-                txt += ("; + introspection FCN: 4 forwards of the numpy oracle (oracle/fcn_oracle.py, default BLAS threads), "
-                        "%.1f s wall = %.2f images/s; extract+match alone = %.1f pairs/s; value = 1/(1/a + 1/b)" % (fsecs, fv, v))
+                fv, fsecs = cpu_fcn_baseline(cores)
+                txt += ("; + introspection FCN: %d forwards of the numpy oracle (oracle/fcn_oracle.py), one per thread, "
+                        "%.1f s wall = %.2f images/s; extract+match alone = %.1f pairs/s; value = 1/(1/a + 1/b)" % (cores, fsecs, fv, v))
                 v = 1.0 / (1.0 / v + 1.0 / fv)
             out["cpu_baseline"] = {"value": round(v, 3), "unit": "pairs/s", "cores": cores, "kind": "port", "sample": txt}
         print(json.dumps(out), flush=True)
