@@ -1465,7 +1465,13 @@ int ivf_frontend_create(const ivf_frontend_config* cfg, ivf_frontend** out)
     for (int k = 0; k < kPipe; k++) {
         rc = fe->ctx[k].build(t, cfg->width, cfg->height, 2 * cfg->max_pairs, 2, cfg->device_id, true);
         if (rc) return cleanup(rc);
-        if (hipStreamCreateWithFlags(&fe->stream[k], hipStreamNonBlocking) != hipSuccess ||
+        // the front end's tail kernels are small and latency-bound: on high-priority streams they slot in beside whatever
+        // large kernels the caller's stream is running (the FCN of the next batch) instead of queueing behind them
+        int prLo = 0, prHi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prLo, &prHi);
+        static const bool noPrio = getenv("IVF_NO_STREAM_PRIORITY") != nullptr;
+        if ((noPrio ? hipStreamCreateWithFlags(&fe->stream[k], hipStreamNonBlocking)
+                    : hipStreamCreateWithPriority(&fe->stream[k], hipStreamNonBlocking, prHi)) != hipSuccess ||
             hipEventCreateWithFlags(&fe->evIn[k], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&fe->evConsumed[k], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&fe->evDone[k], hipEventDisableTiming) != hipSuccess)
