@@ -839,9 +839,10 @@ __global__ __launch_bounds__(256, 2) void k_fcn_expand(const float* __restrict__
 //   * both LDS stages are double buffered, one barrier per chunk;
 //   * workgroups are renumbered so that the row pairs of one image run on the same XCD (shared L2 for halo rows).
 // dwP: per hidden channel 12 floats = 9 taps, BN scale, BN shift, pad.
-struct DwSet { float4 own[3][2]; float par; };   // par: parameter (tid & 15) of this thread's channel
+struct DwSet { float4 own[3][2]; float par; float hl[3], hr[3]; };   // par: parameter (tid & 15) of this thread's channel;
+                                                                     // hl / hr: halo pixels across the workgroup edge (256-wide maps only)
 
-template <int TILES, int DIL>
+template <int TILES, int DIL, int LW>            // LW = log2 of the (square) map size: 6, 7 (one row per workgroup), 8 (half a row)
 __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X, const float* __restrict__ dwP,
                                                     const uint4* __restrict__ Wq, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, const float* __restrict__ res,
@@ -849,27 +850,32 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
 {
     constexpr int kPitch = 132;                     // floats per hidden channel row in LDS: 128 pixels + bank skew
                                                     // (8 rows apart = 32 banks apart: the two k-groups never collide)
-    constexpr int HW = 64 * 64;
+    static_assert(LW == 6 || DIL == 1, "the wider maps of the network are not dilated");
+    constexpr int Wd = 1 << LW, HW = Wd * Wd, WGPI = HW / 128;      // workgroups per image
     __shared__ __attribute__((aligned(16))) float sD[2][16 * kPitch];
     __shared__ __attribute__((aligned(16))) float sW[2][TILES * 512];    // per tile: hi fragment, lo fragment (1 KB each)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 5, col = lane & 31;
     const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
-    const int b = L / 32, rp = L % 32;
+    const int b = L / WGPI, p128 = L % WGPI;
     const int tile0 = blockIdx.y * TILES;
-    const int kc = tid >> 4, g = tid & 15, r = g >> 3, x0 = (g & 7) * 8;
-    const int y = 2 * rp + r;
+    const int kc = tid >> 4, g = tid & 15;
+    const int y = (128 * p128 + 8 * g) >> LW, x0 = (128 * p128 + 8 * g) & (Wd - 1);
     int rowOff[3]; float rowM[3];
 #pragma unroll
     for (int ky = 0; ky < 3; ky++) {
         const int yy = y + (ky - 1) * DIL;
-        const bool ok = yy >= 0 && yy < 64;
+        const bool ok = yy >= 0 && yy < Wd;
         rowM[ky] = ok ? 1.f : 0.f;
-        rowOff[ky] = (ok ? yy : y) * 64 + x0;
+        rowOff[ky] = (ok ? yy : y) * Wd + x0;
     }
-    const float mL = x0 > 0 ? 1.f : 0.f, mR = x0 + 8 < 64 ? 1.f : 0.f;
+    // the DPP row (16 lanes) covers two image rows (LW 6), one (LW 7) or half of one (LW 8).  mL / mR switch the halo taps off
+    // where lane-1 / lane+1 is not the horizontal neighbour (image border, or the other row of the pair); for LW 8 the
+    // neighbour across the workgroup edge is fetched from memory instead (edgeL / edgeR lanes)
+    const float mL = x0 > 0 ? 1.f : 0.f, mR = x0 + 8 < Wd ? 1.f : 0.f;
+    const bool edgeL = LW == 8 && g == 0 && x0 > 0, edgeR = LW == 8 && g == 15 && x0 + 8 < Wd;
     const float* Xb = X + (size_t)b * K * HW;
     const float* Wf = (const float*)Wq;
-    const int nChunks = abl >= 2 ? 24 : K / 16;     // even for every hidden width of the network (192 .. 960)
+    const int nChunks = abl >= 2 ? 24 : K / 16;     // odd for the 144-channel block: the loop's second half is guarded
 
     // window and depthwise-parameter loads run two chunks ahead; each of the 16 threads of a channel fetches ONE of its
     // 12 parameters and the stencil broadcasts them with DPP row_share.  The A fragments (L2-resident, needed only at
@@ -884,6 +890,10 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
         for (int ky = 0; ky < 3; ky++) {
             S.own[ky][0] = *(const float4*)(P + rowOff[ky]);
             S.own[ky][1] = *(const float4*)(P + rowOff[ky] + 4);
+            if constexpr (LW == 8) {
+                const float l = P[rowOff[ky] - (edgeL ? 1 : 0)], r8 = P[rowOff[ky] + (edgeR ? 8 : 0)];
+                S.hl[ky] = edgeL ? l : 0.f; S.hr[ky] = edgeR ? r8 : 0.f;
+            }
         }
     };
     float2 wreg[TILES];
@@ -925,12 +935,16 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
                 if (p + DIL < 8) o[p] = __builtin_fmaf(own[p + DIL], w2, o[p]);
                 else asm("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(o[p]) : "v"(own[p + DIL - 8]), "v"(w2R));
             }
+            if constexpr (LW == 8) {          // the neighbour pixel across the workgroup edge (zero in every other lane)
+                o[0] = __builtin_fmaf(S.hl[ky], w0, o[0]);
+                o[7] = __builtin_fmaf(S.hr[ky], w2, o[7]);
+            }
         }
 #pragma unroll
         for (int p = 0; p < 8; p++) o[p] = __builtin_amdgcn_fmed3f(__builtin_fmaf(o[p], dsc, dsh), 0.f, 6.f);
     };
     auto publish = [&](int buf) {
-        float* dst = &sD[buf][kc * kPitch + r * 64 + x0];
+        float* dst = &sD[buf][kc * kPitch + 8 * g];
         *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
         *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
 #pragma unroll
@@ -987,6 +1001,9 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
         issue(SB, c + 3);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        if constexpr (LW != 6) { if (c + 1 >= nChunks) break; }   // odd chunk count of the 144-channel block (uniform); kept out of
+                                                                  // the 64-wide instantiations: a mid-loop exit costs them their
+                                                                  // counted vmcnt waits (measured: 226 -> 357 us)
         multiply(1);
         stencil(SA);
         publish(0);
@@ -999,7 +1016,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     }
     // epilogue: per tile, BN scale/shift (float4 per row quad, arrays padded to whole tiles) and the residual are
     // loaded as one batch before the first use
-    const int pix = 128 * rp + 32 * wave + col;
+    const int pix = 128 * p128 + 32 * wave + col;
 #pragma unroll
     for (int t = 0; t < TILES; t++) {
         const int cb = (tile0 + t) * 32 + 4 * kg;
@@ -1236,18 +1253,25 @@ bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, f
     static const bool off = getenv("IVF_FCN_NOFUSE") != nullptr;
     static const int abl = getenv("IVF_FCN_ABL") ? atoi(getenv("IVF_FCN_ABL")) : 0;
     const int tiles = (g.cout + 31) / 32;
-    if (off || d.stride != 1 || H != 64 || W != 64 || d.c % 16 || g.taps != 1 || g.nTiles != tiles || g.act != 0) return false;
+    if (off || d.stride != 1 || H != W || (H != 64 && H != 128 && H != 256) || d.c % 16 || g.taps != 1 || g.nTiles != tiles || g.act != 0) return false;
+    static const bool wide = getenv("IVF_FCN_NOWIDE") == nullptr;           // 128-wide maps (block 3: 297 -> 114 us)
+    static const bool wide256 = getenv("IVF_FCN_WIDE256") != nullptr;       // block 1 has only two K chunks: the fused kernel is
+                                                                            // slower there (335 vs 270 us), off unless asked for
+    if (H != 64 && (!wide || d.dil != 1 || tiles != 1)) return false;
     const dim3 blk(256);
-#define DWPW(T, D, GY)                                                                                              \
-    hipLaunchKernelGGL((k_fcn_dwpw<T, D>), dim3(32 * B, GY), blk, 0, s, X, d.dPack, g.dWq, g.dScale, \
-                       g.dShift, res, Y, d.c, g.cout, g.nTiles, abl)
-    if (tiles == 1 && d.dil == 1) DWPW(1, 1, 1);
-    else if (tiles == 2 && d.dil == 1) DWPW(2, 1, 1);
-    else if (tiles == 2 && d.dil == 2) DWPW(2, 2, 1);
-    else if (tiles == 3 && d.dil == 2) DWPW(3, 2, 1);
-    else if (tiles == 5 && d.dil == 2) DWPW(5, 2, 1);
-    else if (tiles == 5 && d.dil == 4) DWPW(5, 4, 1);
-    else if (tiles == 10 && d.dil == 4) DWPW(5, 4, 2);
+    const int wgpi = H * W / 128;
+#define DWPW(T, D, LWV, GY)                                                                                               \
+    hipLaunchKernelGGL((k_fcn_dwpw<T, D, LWV>), dim3(wgpi * B, GY), blk, 0, s, X, d.dPack, g.dWq, g.dScale, g.dShift, res, Y, d.c, \
+                       g.cout, g.nTiles, abl)
+    if (H == 128) DWPW(1, 1, 7, 1);
+    else if (H == 256) { if (!wide256) return false; DWPW(1, 1, 8, 1); }
+    else if (tiles == 1 && d.dil == 1) DWPW(1, 1, 6, 1);
+    else if (tiles == 2 && d.dil == 1) DWPW(2, 1, 6, 1);
+    else if (tiles == 2 && d.dil == 2) DWPW(2, 2, 6, 1);
+    else if (tiles == 3 && d.dil == 2) DWPW(3, 2, 6, 1);
+    else if (tiles == 5 && d.dil == 2) DWPW(5, 2, 6, 1);
+    else if (tiles == 5 && d.dil == 4) DWPW(5, 4, 6, 1);
+    else if (tiles == 10 && d.dil == 4) DWPW(5, 4, 6, 2);
     else return false;
 #undef DWPW
     return true;

@@ -109,7 +109,9 @@ print("OK %.3g" % err)
     {"IVF_FCN_BLOCKMASK": "63"},
     # 64-pixel expansion tiles
     {"IVF_FCN_EXPAND": "2"},
-], ids=["default", "layerwise", "all-blocks-fused", "expand-pxt2"])
+    # fused depthwise+projection also on the 256-wide map of block 1 (off by default: slower there)
+    {"IVF_FCN_WIDE256": "1"},
+], ids=["default", "layerwise", "all-blocks-fused", "expand-pxt2", "dwpw-256"])
 def test_fcn_kernel_variants_match_goldens_and_are_deterministic(env):
     """The FCN picks between several kernels per layer (measured defaults, env overrides for tuning).  Every variant must
     meet the same bar, batch results must not depend on the batch slot, and repeated runs must be bit-identical (this is
