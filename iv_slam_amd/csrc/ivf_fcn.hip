@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     const bool edgeL = LW == 8 && g == 0 && x0 > 0, edgeR = LW == 8 && g == 15 && x0 + 8 < Wd;
     const float* Xb = X + (size_t)b * K * HW;
     const float* Wf = (const float*)Wq;
-    const int nChunks = abl >= 2 ? 24 : K / 16;     // odd for the 144-channel block: the loop's second half is guarded
+    const int nChunks = abl >= 2 ? 24 : K / 16;     // odd for the 144-channel block: see the tail after the loop
 
     // window and depthwise-parameter loads run two chunks ahead; each of the 16 threads of a channel fetches ONE of its
     // 12 parameters and the stencil broadcasts them with DPP row_share.  The A fragments (L2-resident, needed only at
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     issue_w(1);                                     // weights before the window: in-order return lets the next
     issue(SA, 2);                                   // stencil wait for them with the window loads still in flight
     __syncthreads();
-    for (int c = 0; c < nChunks; c += 2) {
+    for (int c = 0; c + 1 < nChunks; c += 2) {
         // buffer 0 holds chunk c; set B = window of chunk c+1, set A = window of chunk c+2 (both in flight)
         multiply(0);
         stencil(SB);
@@ -1001,9 +1001,6 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
         issue(SB, c + 3);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-        if constexpr (LW != 6) { if (c + 1 >= nChunks) break; }   // odd chunk count of the 144-channel block (uniform); kept out of
-                                                                  // the 64-wide instantiations: a mid-loop exit costs them their
-                                                                  // counted vmcnt waits (measured: 226 -> 357 us)
         multiply(1);
         stencil(SA);
         publish(0);
@@ -1014,6 +1011,9 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     }
+    if (nChunks & 1) multiply(0);                   // odd chunk count (the 144-channel block): the last chunk sits in buffer 0.
+                                                    // A peeled tail, not an exit inside the loop: that costs the loop its
+                                                    // counted vmcnt waits (measured on the 64-wide kernels: 226 -> 357 us)
     // epilogue: per tile, BN scale/shift (float4 per row quad, arrays padded to whole tiles) and the residual are
     // loaded as one batch before the first use
     const int pix = 128 * p128 + 32 * wave + col;
