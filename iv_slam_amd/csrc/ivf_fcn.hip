@@ -839,10 +839,11 @@ __global__ __launch_bounds__(256, 2) void k_fcn_expand(const float* __restrict__
 //   * both LDS stages are double buffered, one barrier per chunk;
 //   * workgroups are renumbered so that the row pairs of one image run on the same XCD (shared L2 for halo rows).
 // dwP: per hidden channel 12 floats = 9 taps, BN scale, BN shift, pad.
-struct DwSet { float4 own[3][2]; float par; float hl[3], hr[3]; };   // par: parameter (tid & 15) of this thread's channel;
+template <int S> struct DwSetT { float4 own[3][2 * S]; float par; float hl[3], hr[3]; };   // par: parameter (tid & 15) of this thread's channel;
                                                                      // hl / hr: halo pixels across the workgroup edge (256-wide maps only)
 
-template <int TILES, int DIL, int LW>            // LW = log2 of the (square) map size: 6, 7 (one row per workgroup), 8 (half a row)
+template <int TILES, int DIL, int LW, int S_>    // LW = log2 of the (square) OUTPUT map size: 6, 7 (one row per workgroup),
+                                                 // 8 (half a row); S_ = stride of the depthwise layer (input map = S_ x larger)
 __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X, const float* __restrict__ dwP,
                                                     const uint4* __restrict__ Wq, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, const float* __restrict__ res,
@@ -851,7 +852,10 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     constexpr int kPitch = 132;                     // floats per hidden channel row in LDS: 128 pixels + bank skew
                                                     // (8 rows apart = 32 banks apart: the two k-groups never collide)
     static_assert(LW == 6 || DIL == 1, "the wider maps of the network are not dilated");
-    constexpr int Wd = 1 << LW, HW = Wd * Wd, WGPI = HW / 128;      // workgroups per image
+    static_assert(S_ == 1 || (S_ == 2 && DIL == 1 && LW <= 7), "stride 2: blocks 2 and 4");
+    typedef DwSetT<S_> DwSet;
+    constexpr int Wd = 1 << LW, HW = Wd * Wd, WGPI = HW / 128;      // output map; workgroups per image
+    constexpr int Wi = Wd * S_, HWi = Wi * Wi;                       // input map
     __shared__ __attribute__((aligned(16))) float sD[2][16 * kPitch];
     __shared__ __attribute__((aligned(16))) float sW[2][TILES * 512];    // per tile: hi fragment, lo fragment (1 KB each)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 5, col = lane & 31;
@@ -863,17 +867,17 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     int rowOff[3]; float rowM[3];
 #pragma unroll
     for (int ky = 0; ky < 3; ky++) {
-        const int yy = y + (ky - 1) * DIL;
-        const bool ok = yy >= 0 && yy < Wd;
+        const int yy = y * S_ + (ky - 1) * DIL;     // input row of tap ky
+        const bool ok = yy >= 0 && yy < Wi;
         rowM[ky] = ok ? 1.f : 0.f;
-        rowOff[ky] = (ok ? yy : y) * Wd + x0;
+        rowOff[ky] = (ok ? yy : y * S_) * Wi + x0 * S_;
     }
     // the DPP row (16 lanes) covers two image rows (LW 6), one (LW 7) or half of one (LW 8).  mL / mR switch the halo taps off
     // where lane-1 / lane+1 is not the horizontal neighbour (image border, or the other row of the pair); for LW 8 the
     // neighbour across the workgroup edge is fetched from memory instead (edgeL / edgeR lanes)
     const float mL = x0 > 0 ? 1.f : 0.f, mR = x0 + 8 < Wd ? 1.f : 0.f;
     const bool edgeL = LW == 8 && g == 0 && x0 > 0, edgeR = LW == 8 && g == 15 && x0 + 8 < Wd;
-    const float* Xb = X + (size_t)b * K * HW;
+    const float* Xb = X + (size_t)b * K * HWi;
     const float* Wf = (const float*)Wq;
     const int nChunks = abl >= 2 ? 24 : K / 16;     // odd for the 144-channel block: see the tail after the loop
 
@@ -884,12 +888,12 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     auto issue = [&](DwSet& S, int c) {
         c = min(c, nChunks - 1);                    // refills past the end are redundant re-loads (branch-free loop)
         if (abl & 1) c = 0;
-        const float* P = Xb + (size_t)(16 * c + kc) * HW;
+        const float* P = Xb + (size_t)(16 * c + kc) * HWi;
         S.par = dwP[c * 192 + parIdx];
 #pragma unroll
         for (int ky = 0; ky < 3; ky++) {
-            S.own[ky][0] = *(const float4*)(P + rowOff[ky]);
-            S.own[ky][1] = *(const float4*)(P + rowOff[ky] + 4);
+#pragma unroll
+            for (int j = 0; j < 2 * S_; j++) S.own[ky][j] = *(const float4*)(P + rowOff[ky] + 4 * j);
             if constexpr (LW == 8) {
                 const float l = P[rowOff[ky] - (edgeL ? 1 : 0)], r8 = P[rowOff[ky] + (edgeR ? 8 : 0)];
                 S.hl[ky] = edgeL ? l : 0.f; S.hr[ky] = edgeR ? r8 : 0.f;
@@ -923,10 +927,26 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
             // the compiler's DPP combiner leaves MAC-type instructions alone), so the halo costs no instruction.  Zero padding: rows through the tap weights (rowM),
             // the image's left / right border through the halo taps' weights (mL / mR; the DPP's own zero fill covers
             // the ends of the 16-lane row).
-            const float4 a = S.own[ky][0], c4 = S.own[ky][1];
-            const float own[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
             const float w0 = wk[ky * 3] * rowM[ky], w1 = wk[ky * 3 + 1] * rowM[ky], w2 = wk[ky * 3 + 2] * rowM[ky];
             const float w0L = w0 * mL, w2R = w2 * mR;
+            if constexpr (S_ == 2) {
+                // stride 2: output pixel p reads input columns 2p-1, 2p, 2p+1 of the thread's 16; only column -1 of p = 0
+                // belongs to the left neighbour (its column 15)
+                float in16[16];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const float4 v = S.own[ky][j]; in16[4 * j] = v.x; in16[4 * j + 1] = v.y; in16[4 * j + 2] = v.z; in16[4 * j + 3] = v.w; }
+#pragma unroll
+                for (int p = 0; p < 8; p++) {
+                    o[p] = __builtin_fmaf(in16[2 * p], w1, o[p]);
+                    o[p] = __builtin_fmaf(in16[2 * p + 1], w2, o[p]);
+                    if (p > 0) o[p] = __builtin_fmaf(in16[2 * p - 1], w0, o[p]);
+                    else asm("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(o[p]) : "v"(in16[15]), "v"(w0L));
+                }
+                (void)w2R;
+                continue;
+            }
+            const float4 a = S.own[ky][0], c4 = S.own[ky][1];
+            const float own[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
             for (int p = 0; p < 8; p++) {
                 o[p] = __builtin_fmaf(own[p], w1, o[p]);
@@ -1253,7 +1273,18 @@ bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, f
     static const bool off = getenv("IVF_FCN_NOFUSE") != nullptr;
     static const int abl = getenv("IVF_FCN_ABL") ? atoi(getenv("IVF_FCN_ABL")) : 0;
     const int tiles = (g.cout + 31) / 32;
-    if (off || d.stride != 1 || H != W || (H != 64 && H != 128 && H != 256) || d.c % 16 || g.taps != 1 || g.nTiles != tiles || g.act != 0) return false;
+    if (off || H != W || (H != 64 && H != 128 && H != 256) || d.c % 16 || g.taps != 1 || g.nTiles != tiles || g.act != 0) return false;
+    if (d.stride == 2) {                                                    // blocks 2 (256 -> 128) and 4 (128 -> 64)
+        static const bool s2 = getenv("IVF_FCN_NOSTRIDE2") == nullptr;
+        if (!s2 || d.dil != 1 || tiles != 1 || (H != 256 && H != 128)) return false;
+        const int Ho = H / 2, wg = Ho * Ho / 128;
+        if (Ho == 128)
+            hipLaunchKernelGGL((k_fcn_dwpw<1, 1, 7, 2>), dim3(wg * B, 1), dim3(256), 0, s, X, d.dPack, g.dWq, g.dScale, g.dShift, res, Y, d.c, g.cout, g.nTiles, abl);
+        else
+            hipLaunchKernelGGL((k_fcn_dwpw<1, 1, 6, 2>), dim3(wg * B, 1), dim3(256), 0, s, X, d.dPack, g.dWq, g.dScale, g.dShift, res, Y, d.c, g.cout, g.nTiles, abl);
+        return true;
+    }
+    if (d.stride != 1) return false;
     static const bool wide = getenv("IVF_FCN_NOWIDE") == nullptr;           // 128-wide maps (block 3: 297 -> 114 us)
     static const bool wide256 = getenv("IVF_FCN_WIDE256") != nullptr;       // block 1 has only two K chunks: the fused kernel is
                                                                             // slower there (335 vs 270 us), off unless asked for
@@ -1261,7 +1292,7 @@ bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, f
     const dim3 blk(256);
     const int wgpi = H * W / 128;
 #define DWPW(T, D, LWV, GY)                                                                                               \
-    hipLaunchKernelGGL((k_fcn_dwpw<T, D, LWV>), dim3(wgpi * B, GY), blk, 0, s, X, d.dPack, g.dWq, g.dScale, g.dShift, res, Y, d.c, \
+    hipLaunchKernelGGL((k_fcn_dwpw<T, D, LWV, 1>), dim3(wgpi * B, GY), blk, 0, s, X, d.dPack, g.dWq, g.dScale, g.dShift, res, Y, d.c, \
                        g.cout, g.nTiles, abl)
     if (H == 128) DWPW(1, 1, 7, 1);
     else if (H == 256) { if (!wide256) return false; DWPW(1, 1, 8, 1); }
@@ -1397,6 +1428,7 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
         if (launch_dwpw(d, f->pw[ip], h, bk.res ? x : nullptr, y, H, W, n, s)) {
             if (probe) { FHIP(hipEventRecord(f->probe1[slot], s)); f->probeBatch[slot] = n; f->probeCount++; }
             ip++;
+            H = (H - 1) / d.stride + 1; W = (W - 1) / d.stride + 1;
             snprintf(nm, sizeof nm, "block %d depthwise+project", i + 1); STAGE(nm);
             std::swap(x, y);
             continue;
