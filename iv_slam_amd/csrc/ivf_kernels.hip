@@ -226,9 +226,16 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     __shared__ __attribute__((aligned(16))) unsigned raw[(kFastTH + 8) * (kRawP / 4) + 4];   // +4: the funnel read touches one dword past a window
     __shared__ __attribute__((aligned(4))) uint8_t sc[kScH * kScP];
     __shared__ unsigned colInfo[kScW + 2], rowInfo[kScH + 2];
-    __shared__ unsigned s_list[kFastTW * kFastTH / 4];           // at most one strict 3x3 maximum per 2x2 block
     __shared__ int s_cnt[kLocalCells], s_ini[kLocalCells], s_n, s_nq;
-    __shared__ unsigned short s_queue[kScH * ((kScW + 3) / 4) * 2];   // pairs that pass the quick test (sy << 8 | sx)
+    // s_queue: pairs that pass the quick test (sy << 8 | sx), dead after pass B; s_list (survivors, at most one strict
+    // 3x3 maximum per 2x2 block) reuses its storage
+    constexpr int kQueueN = kScH * ((kScW + 3) / 4) * 2;
+    __shared__ unsigned s_qmem[(kQueueN + 1) / 2 > kFastTW * kFastTH / 4 ? (kQueueN + 1) / 2 : kFastTW * kFastTH / 4];
+    unsigned short* const s_queue = (unsigned short*)s_qmem;
+    unsigned* const s_list = s_qmem;
+    constexpr int kCandCap = 1024;
+    __shared__ unsigned short s_cand[kCandCap];                       // tile pixels with a non-zero score (sy << 8 | sx)
+    __shared__ int s_nc;
     const int img = blockIdx.y;
     int level = 0;
     const int nl = cfg->nlevels;
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     constexpr int kQuads = (kScW + 3) / 4;
     // pass A (all pixels): compass pre-check only (3 of the 7 rows).  ~10 % of the pairs pass, but in most waves at
     // least one lane does, so nothing expensive runs here: passing pairs are queued in LDS and scored densely in pass B.
-    if (tid == 0) s_nq = 0;
+    if (tid == 0) { s_nq = 0; s_nc = 0; }
     __syncthreads();
     for (int i = tid; i < kScH * kQuads; i += 256) {
         const int sy = i / kQuads, sx = (i % kQuads) * 4;
@@ -327,7 +334,24 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
         unsigned two = fast_score_pair(lo, hi, minTh, (ablate & 4) != 0);
         if (!(colInfo[sx] & 1u)) two &= 0xffff0000u;
         if (!(colInfo[sx + 1] & 1u)) two &= 0x0000ffffu;
-        *(unsigned short*)(sc + sy * kScP + sx) = (unsigned short)((two & 0xffu) | ((two >> 8) & 0xff00u));
+        const unsigned packed = (two & 0xffu) | ((two >> 8) & 0xff00u);
+        *(unsigned short*)(sc + sy * kScP + sx) = (unsigned short)packed;
+        // scored pixels of the tile proper (not the 1-px halo) go to the NMS list, one LDS atomic per wave step
+        const bool rowIn = sy >= 1 && sy <= kFastTH;
+        const bool cA = rowIn && (packed & 0xffu) && sx >= 1 && sx <= kFastTW;
+        const bool cB = rowIn && (packed >> 8) && sx + 1 <= kFastTW;
+        const unsigned long long mA = __ballot(cA), mB = __ballot(cB);
+        if (mA | mB) {
+            const int lane = tid & 63, lead = __ffsll((long long)(mA | mB)) - 1;
+            const int nA = __popcll(mA);
+            int qb = 0;
+            if (lane == lead) qb = atomicAdd(&s_nc, nA + __popcll(mB));
+            qb = __shfl(qb, lead, 64);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const int iA = qb + __popcll(mA & lt), iB = qb + nA + __popcll(mB & lt);
+            if (cA && iA < kCandCap) s_cand[iA] = (unsigned short)((sy << 8) | sx);
+            if (cB && iB < kCandCap) s_cand[iB] = (unsigned short)((sy << 8) | (sx + 1));
+        }
     }
     __syncthreads();
     if (ablate & 2) { if (tid == 0) tileCnt[(size_t)img * cfg->nTiles + blockIdx.x] = 0; return; }
@@ -344,42 +368,53 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     const int firstRow = fr;
     int* cnt = cellCnt + (size_t)img * cfg->nCellsTotal * 2;
     __syncthreads();
-    // four pixels per step: most score bytes are 0, so one 32-bit LDS read dismisses 4 pixels at once
-    // (sc rows start at score column 0 = x0-1; tile pixel ox sits at byte ox+1, so the aligned dword at byte 4q
-    // holds tile pixels 4q-1 .. 4q+2)
-    for (int i = tid; i < kFastTH * (kFastTW / 4 + 1); i += 256) {
-        const int oy = i / (kFastTW / 4 + 1), q = i % (kFastTW / 4 + 1);
-        const unsigned four = *(const unsigned*)(sc + (oy + 1) * kScP + 4 * q);
-        if (four == 0) continue;
+    auto nms_one = [&](int sy, int sx, int s) {
+        const uint8_t* c = sc + sy * kScP + sx;
+        const unsigned ci = colInfo[sx], ri = rowInfo[sy];
+        if (!(ci & ri & 1u)) return;
+        const bool L = ci & 2u, R = ci & 4u, U = ri & 2u, D = ri & 4u;
+        bool ok = true;
+        ok &= s > ((L) ? c[-1] : 0);
+        ok &= s > ((R) ? c[1] : 0);
+        ok &= s > ((U && L) ? c[-kScP - 1] : 0);
+        ok &= s > ((U) ? c[-kScP] : 0);
+        ok &= s > ((U && R) ? c[-kScP + 1] : 0);
+        ok &= s > ((D && L) ? c[kScP - 1] : 0);
+        ok &= s > ((D) ? c[kScP] : 0);
+        ok &= s > ((D && R) ? c[kScP + 1] : 0);
+        if (!ok) return;
+        const int crow = (int)(ri >> 8), ccol = (int)(ci >> 8);
+        const int lr = crow - firstRow, lc = ccol - firstCol;
+        s_list[atomicAdd(&s_n, 1)] = ((unsigned)(y0 + sy - 1) << 20) | ((unsigned)(x0 + sx - 1) << 8) | (unsigned)s;
+        if (lr >= 0 && lr < kLocalCells / 4 && lc >= 0 && lc < 4) {
+            atomicAdd(&s_cnt[lr * 4 + lc], 1);
+            if (s >= iniTh) atomicAdd(&s_ini[lr * 4 + lc], 1);
+        } else {                                                    // tile spans too many cells: count directly
+            const int gc = G.cellBase + crow * G.cols + ccol;
+            atomicAdd(&cnt[2 * gc], 1);
+            if (s >= iniTh) atomicAdd(&cnt[2 * gc + 1], 1);
+        }
+    };
+    const int nc = s_nc;
+    if (nc <= kCandCap && !(ablate & 8)) {
+        // the usual case: dense over the scored pixels pass B listed, one per lane
+        for (int i = tid; i < nc; i += 256) {
+            const int sy = s_cand[i] >> 8, sx = s_cand[i] & 0xff;
+            nms_one(sy, sx, sc[sy * kScP + sx]);
+        }
+    } else {
+        // corner-dense tile (the list overflowed): scan the score plane, four pixels per 32-bit LDS read
+        // (sc rows start at score column 0 = x0-1; the aligned dword at byte 4q holds score columns 4q .. 4q+3)
+        for (int i = tid; i < kFastTH * (kFastTW / 4 + 1); i += 256) {
+            const int oy = i / (kFastTW / 4 + 1), q = i % (kFastTW / 4 + 1);
+            const unsigned four = *(const unsigned*)(sc + (oy + 1) * kScP + 4 * q);
+            if (four == 0) continue;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int ox = 4 * q - 1 + k;
-            const int s = (four >> (8 * k)) & 0xff;
-            if (s == 0 || ox < 0 || ox >= kFastTW) continue;
-            const uint8_t* c = sc + (oy + 1) * kScP + (ox + 1);
-            const unsigned ci = colInfo[ox + 1], ri = rowInfo[oy + 1];
-            if (!(ci & ri & 1u)) continue;
-            const bool L = ci & 2u, R = ci & 4u, U = ri & 2u, D = ri & 4u;
-            bool ok = true;
-            ok &= s > ((L) ? c[-1] : 0);
-            ok &= s > ((R) ? c[1] : 0);
-            ok &= s > ((U && L) ? c[-kScP - 1] : 0);
-            ok &= s > ((U) ? c[-kScP] : 0);
-            ok &= s > ((U && R) ? c[-kScP + 1] : 0);
-            ok &= s > ((D && L) ? c[kScP - 1] : 0);
-            ok &= s > ((D) ? c[kScP] : 0);
-            ok &= s > ((D && R) ? c[kScP + 1] : 0);
-            if (!ok) continue;
-            const int crow = (int)(ri >> 8), ccol = (int)(ci >> 8);
-            const int lr = crow - firstRow, lc = ccol - firstCol;
-            s_list[atomicAdd(&s_n, 1)] = ((unsigned)(y0 + oy) << 20) | ((unsigned)(x0 + ox) << 8) | (unsigned)s;
-            if (lr >= 0 && lr < kLocalCells / 4 && lc >= 0 && lc < 4) {
-                atomicAdd(&s_cnt[lr * 4 + lc], 1);
-                if (s >= iniTh) atomicAdd(&s_ini[lr * 4 + lc], 1);
-            } else {                                                    // tile spans too many cells: count directly
-                const int gc = G.cellBase + crow * G.cols + ccol;
-                atomicAdd(&cnt[2 * gc], 1);
-                if (s >= iniTh) atomicAdd(&cnt[2 * gc + 1], 1);
+            for (int k = 0; k < 4; k++) {
+                const int sx = 4 * q + k;
+                const int s = (four >> (8 * k)) & 0xff;
+                if (s == 0 || sx < 1 || sx > kFastTW) continue;
+                nms_one(oy + 1, sx, s);
             }
         }
     }

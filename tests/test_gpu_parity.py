@@ -114,6 +114,33 @@ def test_random_noise_image_many_ties(iv):
     assert np.array_equal(gd, od)
 
 
+_NMS_SCAN_SCRIPT = r"""
+import sys, os
+sys.path.insert(0, os.path.join(%r, "tests")); sys.path.insert(0, %r)
+import numpy as np
+import iv_slam_amd as iv
+from iv_slam_amd import synth
+import oracle_lib as O
+L, R = synth.make_pair(1242, 375, seed=21, idx=2)
+for img in (L, R):
+    gk, gd = iv.ORBextractor(1000, 1.2, 8, 20, 7)(img)
+    ok, od = O.Extractor(1000, 1.2, 8, 20, 7)(img)
+    assert gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
+print("OK")
+"""
+
+
+def test_fast_nms_plane_scan_path(iv):
+    """k_fast_nms walks a list of scored pixels; corner-dense tiles overflow the list and scan the score plane instead
+    (test_random_noise_image_many_ties takes that path by itself).  Force the scan on an ordinary image too."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, IVF_FAST_ABLATE="8")
+    r = subprocess.run([sys.executable, "-c", _NMS_SCAN_SCRIPT % (root, root)], env=e, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("size,n", [((640, 240), 500), ((1242, 375), 1000)])
 def test_stereo_matches_bit_exact(iv, size, n):
     w, h = size
