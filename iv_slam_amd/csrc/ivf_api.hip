@@ -151,6 +151,10 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
     c.nCellsTotal = std::max(cellBase, 1);
     c.nTiles = tileBase;
     c.nBlurTiles = btileBase;
+    for (int l = 0; l < kMaxLevels; l++) {
+        c.tileBases[l] = l < c.nlevels ? c.lv[l].tileBase : INT_MAX;
+        c.btileBases[l] = l < c.nlevels ? c.lv[l].btileBase : INT_MAX;
+    }
 
     // cv::resize coefficient table (OpenCV resize.cpp, INTER_LINEAR 8U): per output column
     // {clamped sx, a0, a1}, per output row {clipped sy, b0, b1}; x clamps f to 0 at the right edge, y does not.

@@ -42,6 +42,8 @@ struct Config {
     int nBlurTiles;         // blur tiles per image
     int umax[16];
     float scale[kMaxLevels], invScale[kMaxLevels];
+    int tileBases[kMaxLevels], btileBases[kMaxLevels];   // lv[l].tileBase / btileBase side by side (INT_MAX past nlevels):
+                                                         // a tile finds its level with one wide uniform load
     LevelGeom lv[kMaxLevels];
 };
 

@@ -237,26 +237,36 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     __shared__ unsigned short s_cand[kCandCap];                       // tile pixels with a non-zero score (sy << 8 | sx)
     __shared__ int s_nc;
     const int img = blockIdx.y;
+    const int tid = threadIdx.x;
+    if (ablate & 16) return;
+    // the prologue is latency: every load below is issued before anything waits on one.  Level lookup: all tile bases
+    // in one wide load (INT_MAX past nlevels)
+    const unsigned useC = useCost[img];
     int level = 0;
-    const int nl = cfg->nlevels;
-    for (int l = 1; l < nl; l++) if ((int)blockIdx.x >= cfg->lv[l].tileBase) level = l;
-    const LevelGeom& G = cfg->lv[level];
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; l++) level += (int)blockIdx.x >= cfg->tileBases[l] ? 1 : 0;   // bases ascend
+    const LevelGeom G = cfg->lv[level];                         // one uniform copy: two wide scalar loads
     const int t = blockIdx.x - G.tileBase;
-    if (!G.valid || t >= G.tilesX * G.tilesY) { if (threadIdx.x == 0) tileCnt[(size_t)img * cfg->nTiles + blockIdx.x] = 0; return; }
-    const int mode = (cfg->introspection && useCost[img]) ? 1 : 0;
+    if (!G.valid || t >= G.tilesX * G.tilesY) { if (tid == 0) tileCnt[(size_t)img * cfg->nTiles + blockIdx.x] = 0; return; }
     const int tx = t % G.tilesX, ty = t / G.tilesX;
     const int x0 = 16 + tx * kFastTW, y0 = kEdge + ty * kFastTH;
     const uint8_t* src = pyr + (size_t)img * cfg->pyrBytes + G.off;
-    const int tid = threadIdx.x;
 
-    // 1. raw tile: rows y0-4 .. y0+TH+3, cols x0-4 .. x0+TW+3 (x0-4 is a multiple of 4)
-    for (int i = tid; i < (kFastTH + 8) * (kRawP / 4); i += 256) {
+    // 1. raw tile: rows y0-4 .. y0+TH+3, cols x0-4 .. x0+TW+3 (x0-4 is a multiple of 4).  Branch-free clamped
+    // addresses so the loads of a thread are all in flight together; out-of-plane dwords are zeroed afterwards.
+    constexpr int kRawN = (kFastTH + 8) * (kRawP / 4), kRawIt = (kRawN + 255) / 256;
+    unsigned rv_[kRawIt];
+    bool rok[kRawIt];
+#pragma unroll
+    for (int k = 0; k < kRawIt; k++) {
+        const int i = tid + 256 * k;
         const int ry = i / (kRawP / 4), rx4 = (i % (kRawP / 4)) * 4;
         const int gy = y0 - 4 + ry, gx = x0 - 4 + rx4;
-        unsigned v = 0;
-        if (gy >= 0 && gy < G.h && gx < G.pitch) v = *(const unsigned*)(src + (size_t)gy * G.pitch + gx);
-        raw[i] = v;
+        rok[k] = i < kRawN && gy < G.h && gx < G.pitch;        // gy >= 0: y0 >= kEdge
+        rv_[k] = *(const unsigned*)(src + (size_t)(rok[k] ? gy : 0) * G.pitch + (rok[k] ? gx : 0));
     }
+    const int mode = (cfg->introspection && useC) ? 1 : 0;
+    const int domHm = mode ? G.domH[1] : G.domH[0];
     if (tid < kScW) {                               // column classes: x = x0-1+tid
         const int x = x0 - 1 + tid;
         unsigned f = 0;
@@ -273,11 +283,14 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
         if (y >= kEdge && y < G.maxBY) {
             int i = (y - kEdge) / G.cellH;
             if (i > G.rows - 1) i = G.rows - 1;
-            const int cy0 = kEdge + i * G.cellH, cy1 = cy0 + ((i == G.rows - 1) ? G.domHLast : G.domH[mode]);
+            const int cy0 = kEdge + i * G.cellH, cy1 = cy0 + ((i == G.rows - 1) ? G.domHLast : domHm);
             if (y < cy1) f = 1u | ((y - 1 >= cy0) ? 2u : 0u) | ((y + 1 < cy1) ? 4u : 0u) | ((unsigned)i << 8);
         }
         rowInfo[tid - 192] = f;
     }
+#pragma unroll
+    for (int k = 0; k < kRawIt; k++) if (tid + 256 * k < kRawN) raw[tid + 256 * k] = rok[k] ? rv_[k] : 0u;
+    if (ablate & 32) return;
     __syncthreads();
     // 2. scores, four pixels (two packed pairs) per step sharing the three aligned dwords of each of the 7 rows:
     //    score columns sx..sx+3 (sx % 4 == 0); the window of pair A (sx, sx+1) is bytes 0..7 of the 12-byte span
