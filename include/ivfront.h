@@ -315,6 +315,28 @@ int  ivf_bow_vectors(const int32_t* word_id, const int32_t* node_id, const doubl
  * vDescriptors, in mObservations order); *best_index = the row to copy into mDescriptor, *best_median (nullable) its median. */
 int  ivf_distinctive_descriptor(const uint8_t* desc, int n, int* best_index, int* best_median, int device_id);
 
+/* ---- rectification in front of the extractor -------------------------------------------------
+ * cv::initUndistortRectifyMap(K, D, R, P(0:3,0:3), size, CV_32F, map1, map2) as the driver calls it
+ * (introspective_ORB_SLAM/Examples/Stereo/stereo_kitti.cc:285-343): host-side, double arithmetic, OpenCV 4.x plain C++
+ * path.  K, R (NULL = identity), P: 3x3 row-major; dist = k1,k2,p1,p2[,k3[,k4,k5,k6[,s1..s4]]]
+ * (n_dist 0, 4, 5, 8 or 12; tilt terms unsupported); map1/map2: [height][width] f32 (source x / source y). */
+int  ivf_init_undistort_rectify_map(const double* K, const double* dist, int n_dist, const double* R, const double* P,
+                                    int width, int height, float* map1, float* map2);
+/* cv::remap(src, dst, map1, map2, cv::INTER_LINEAR) for 8-bit images, 1 or 3 interleaved channels, BORDER_CONSTANT 0
+ * (stereo_kitti.cc:462-468 left/right image, :519-521 predicted cost image).  The maps are converted once
+ * to the fixed-point form cv::remap derives per call and stay on the device; (width, height) = destination = map size. */
+typedef struct ivf_remap ivf_remap;
+int  ivf_remap_create(const float* map1, const float* map2, int width, int height, int src_width, int src_height,
+                      int channels, int device_id, ivf_remap** out);
+void ivf_remap_destroy(ivf_remap* r);
+/* host buffers (drop-in for one cv::remap call; synchronous) */
+int  ivf_remap_apply(ivf_remap* r, const uint8_t* src, int src_stride, uint8_t* dst, int dst_stride);
+/* device buffers, n_images images image_stride bytes apart, on `hip_stream` (hipStream_t, NULL = default stream); asynchronous */
+int  ivf_remap_apply_device(ivf_remap* r, const uint8_t* d_src, int src_stride, size_t src_image_stride, uint8_t* d_dst,
+                      int dst_stride, size_t dst_image_stride, int n_images, void* hip_stream);
+/* test aid: the fixed-point maps as cv::convertMaps would give them: xy [height][width][2] int16, alpha [height][width] (fy<<5|fx) */
+int  ivf_remap_get_fixed_maps(const ivf_remap* r, int16_t* xy, uint16_t* alpha);
+
 /* measurement aid (bench.py): HIP events bracket the network's most expensive launch (fused depthwise 3x3 + 1x1
  * projection 960 -> 160 of block 15, k_fcn_dwpw<5,4>) on the stream each forward runs on.  probe_stats returns the summed
  * duration of the last `last_n` probed forwards (0 = all kept, at most 64) and the batch size of the oldest of them. */

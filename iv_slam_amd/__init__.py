@@ -8,3 +8,4 @@ from .orb import (ORBextractor, ORBmatcher, ORBVocabulary, ComputeStereoMatches,
                   ComputeDistinctiveDescriptors)
 from .frontend import StereoFrontend  # noqa: F401
 from .fcn import IntrospectionFCN  # noqa: F401
+from .rectify import initUndistortRectifyMap, Remap  # noqa: F401

@@ -81,6 +81,12 @@ _SIGS = {
     "ivf_bow_vectors": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int), vp, vp, vp, C.c_int, C.POINTER(C.c_int)]),
     "ivf_fuse_candidates": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
                                       vp, vp, C.c_int]),
+    "ivf_init_undistort_rectify_map": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]),
+    "ivf_remap_create": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "ivf_remap_destroy": (None, [vp]),
+    "ivf_remap_apply": (C.c_int, [vp, vp, C.c_int, vp, C.c_int]),
+    "ivf_remap_apply_device": (C.c_int, [vp, vp, C.c_int, C.c_size_t, vp, C.c_int, C.c_size_t, C.c_int, vp]),
+    "ivf_remap_get_fixed_maps": (C.c_int, [vp, vp, vp]),
     "ivf_test_retain_best": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int]),
     "ivf_frontend_create": (C.c_int, [C.POINTER(FrontendConfig), C.POINTER(vp)]),
     "ivf_frontend_destroy": (None, [vp]),

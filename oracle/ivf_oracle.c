@@ -1629,3 +1629,134 @@ void orc_update_quality_scores(const int32_t* assign, int n, float* kp_quality, 
         kp_quality[i] = upd;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Rectification: cv::initUndistortRectifyMap + cv::remap as the reference's driver calls them
+ * (introspective_ORB_SLAM/Examples/Stereo/stereo_kitti.cc:285-343, :462-468, :519-521).  OpenCV is un-vendored and
+ * absent here, so these follow the plain C++ code paths of OpenCV 4.x as recalled: parity
+ * unpinned, like the other OpenCV primitives.
+ * ---------------------------------------------------------------------------------------------- */
+static void orc_mat3_mul(const double* a, const double* b, double* c)
+{
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += a[3 * i + k] * b[3 * k + j];
+            c[3 * i + j] = s;
+        }
+}
+/* cv::invert, 3x3 double, DECOMP_LU: closed form through the determinant */
+static int orc_mat3_inv(const double* S, double* t)
+{
+#define S_(i, j) S[3 * (i) + (j)]
+    double d = S_(0, 0) * (S_(1, 1) * S_(2, 2) - S_(1, 2) * S_(2, 1)) - S_(0, 1) * (S_(1, 0) * S_(2, 2) - S_(1, 2) * S_(2, 0)) +
+               S_(0, 2) * (S_(1, 0) * S_(2, 1) - S_(1, 1) * S_(2, 0));
+    if (d == 0) return -1;
+    d = 1. / d;
+    t[0] = (S_(1, 1) * S_(2, 2) - S_(1, 2) * S_(2, 1)) * d;
+    t[1] = (S_(0, 2) * S_(2, 1) - S_(0, 1) * S_(2, 2)) * d;
+    t[2] = (S_(0, 1) * S_(1, 2) - S_(0, 2) * S_(1, 1)) * d;
+    t[3] = (S_(1, 2) * S_(2, 0) - S_(1, 0) * S_(2, 2)) * d;
+    t[4] = (S_(0, 0) * S_(2, 2) - S_(0, 2) * S_(2, 0)) * d;
+    t[5] = (S_(0, 2) * S_(1, 0) - S_(0, 0) * S_(1, 2)) * d;
+    t[6] = (S_(1, 0) * S_(2, 1) - S_(1, 1) * S_(2, 0)) * d;
+    t[7] = (S_(0, 1) * S_(2, 0) - S_(0, 0) * S_(2, 1)) * d;
+    t[8] = (S_(0, 0) * S_(1, 1) - S_(0, 1) * S_(1, 0)) * d;
+#undef S_
+    return 0;
+}
+
+int orc_init_undistort_rectify_map(const double* K, const double* dist, int n_dist, const double* R, const double* P,
+                                   int w, int h, float* map1, float* map2)
+{
+    if (!K || !P || !map1 || !map2 || w < 1 || h < 1) return -1;
+    if (!(n_dist == 0 || n_dist == 4 || n_dist == 5 || n_dist == 8 || n_dist == 12) || (n_dist && !dist)) return -1;
+    static const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double PR[9], ir[9];
+    orc_mat3_mul(P, R ? R : eye, PR);
+    if (orc_mat3_inv(PR, ir)) return -1;
+    const double u0 = K[2], v0 = K[5], fx = K[0], fy = K[4];
+    double k[12] = {0};
+    for (int i = 0; i < n_dist; i++) k[i] = dist[i];
+    const double k1 = k[0], k2 = k[1], p1 = k[2], p2 = k[3], k3 = k[4], k4 = k[5], k5 = k[6], k6 = k[7];
+    const double s1 = k[8], s2 = k[9], s3 = k[10], s4 = k[11];
+    for (int i = 0; i < h; i++) {
+        double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+        for (int j = 0; j < w; j++, _x += ir[0], _y += ir[3], _w += ir[6]) {
+            const double iw = 1. / _w, x = _x * iw, y = _y * iw;
+            const double x2 = x * x, y2 = y * y;
+            const double r2 = x2 + y2, _2xy = 2 * x * y;
+            const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+            const double xd = (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2) + s1 * r2 + s2 * r2 * r2);
+            const double yd = (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy + s3 * r2 + s4 * r2 * r2);
+            /* no sensor tilt: matTilt = I, invProj = 1 */
+            const double u = fx * xd + u0, v = fy * yd + v0;
+            map1[(size_t)i * w + j] = (float)u;
+            map2[(size_t)i * w + j] = (float)v;
+        }
+    }
+    return 0;
+}
+
+static int16_t orc_sat_s16(long v) { return (int16_t)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+
+void orc_remap_weight_table(int16_t* T)
+{
+    /* initInterTab2D(INTER_LINEAR, fixpt): the 1-D table holds (1 - f, f), f = k/32 in float; the 2x2 products are
+     * scaled by 2^15 and saturated to short; a table whose entries do not sum to 2^15 gets the difference added to
+     * its extreme entry, searched over rows/cols ksize/2 .. ksize/2+1 of a ksize = 2 table -- i.e. over flat indices
+     * 3..6, three of which belong to the NEXT (not yet written, still zero) table.  Only alpha = 0 is affected
+     * (32768 saturates to 32767): it becomes {32767, 0, 0, 1}. */
+    float tab1[32][2];
+    for (int i = 0; i < 32; i++) { const float f = (float)i * (1.f / 32); tab1[i][0] = 1.f - f; tab1[i][1] = f; }
+    int16_t buf[1024 * 4 + 8];
+    memset(buf, 0, sizeof buf);
+    for (int i = 0; i < 32; i++)
+        for (int j = 0; j < 32; j++) {
+            int16_t* itab = buf + (i * 32 + j) * 4;
+            int isum = 0;
+            for (int k1 = 0; k1 < 2; k1++) {
+                const float vy = tab1[i][k1];
+                for (int k2 = 0; k2 < 2; k2++) {
+                    const float v = vy * tab1[j][k2];
+                    itab[k1 * 2 + k2] = orc_sat_s16(lrintf(v * 32768));
+                    isum += itab[k1 * 2 + k2];
+                }
+            }
+            if (isum != 32768) {
+                const int diff = isum - 32768;
+                int Mk1 = 1, Mk2 = 1, mk1 = 1, mk2 = 1;
+                for (int k1 = 1; k1 < 3; k1++)
+                    for (int k2 = 1; k2 < 3; k2++) {
+                        if (itab[k1 * 2 + k2] < itab[mk1 * 2 + mk2]) mk1 = k1, mk2 = k2;
+                        else if (itab[k1 * 2 + k2] > itab[Mk1 * 2 + Mk2]) Mk1 = k1, Mk2 = k2;
+                    }
+                if (diff < 0) itab[Mk1 * 2 + Mk2] = (int16_t)(itab[Mk1 * 2 + Mk2] - diff);
+                else itab[mk1 * 2 + mk2] = (int16_t)(itab[mk1 * 2 + mk2] - diff);
+            }
+        }
+    memcpy(T, buf, 1024 * 4 * sizeof(int16_t));
+}
+
+void orc_remap_bilinear_u8(const uint8_t* src, int sw, int sh, int sstride, int cn, const float* map1, const float* map2,
+                           int w, int h, uint8_t* dst, int dstride)
+{
+    int16_t T[4096];
+    orc_remap_weight_table(T);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            /* RemapInvoker, CV_32FC1 maps: positions to 1/32 px, round-half-even */
+            const int fx = (int)lrintf(map1[(size_t)y * w + x] * 32), fy = (int)lrintf(map2[(size_t)y * w + x] * 32);
+            const int sx = orc_sat_s16(fx >> 5), sy = orc_sat_s16(fy >> 5);
+            const int16_t* wt = T + ((fy & 31) * 32 + (fx & 31)) * 4;
+            for (int c = 0; c < cn; c++) {
+                int tap[4];
+                for (int t = 0; t < 4; t++) {
+                    const int xx = sx + (t & 1), yy = sy + (t >> 1);
+                    tap[t] = (xx >= 0 && xx < sw && yy >= 0 && yy < sh) ? src[(size_t)yy * sstride + xx * cn + c] : 0;
+                }
+                const int v = (tap[0] * wt[0] + tap[1] * wt[1] + tap[2] * wt[2] + tap[3] * wt[3] + (1 << 14)) >> 15;
+                dst[(size_t)y * dstride + x * cn + c] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+            }
+        }
+}

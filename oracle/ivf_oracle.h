@@ -167,6 +167,18 @@ void  orc_update_quality_scores(const int32_t* assign, int n, float* kp_quality,
 /* ORBmatcher::ComputeThreeMaxima (ORB/src/ORBmatcher.cc:1654-1695) on bin sizes */
 void  orc_three_maxima(const int* histo_sizes, int L, int* ind1, int* ind2, int* ind3);
 
+/* cv::initUndistortRectifyMap, CV_32FC1 maps (stereo_kitti.cc:285-343 call sites; OpenCV calib3d, un-vendored: the
+ * plain C++ path restated -- SURVEY Appendix A style frozen semantics).  K, R (NULL = identity), P = 3x3
+ * row-major doubles; dist = k1,k2,p1,p2[,k3[,k4,k5,k6[,s1..s4]]] (n_dist 0/4/5/8/12).  Returns 0, -1 bad argument. */
+int   orc_init_undistort_rectify_map(const double* K, const double* dist, int n_dist, const double* R, const double* P,
+                                     int w, int h, float* map1, float* map2);
+/* cv::remap(src, dst, map1, map2, INTER_LINEAR) with CV_32FC1 maps, 8-bit, cn channels, BORDER_CONSTANT 0
+ * (stereo_kitti.cc:462-468, :519-521): 5-bit sub-pixel positions, 15-bit weight table, (sum + 2^14) >> 15 (A-10). */
+void  orc_remap_bilinear_u8(const uint8_t* src, int sw, int sh, int sstride, int cn, const float* map1, const float* map2,
+                            int w, int h, uint8_t* dst, int dstride);
+/* the 1024 x 4 fixed-point bilinear table exactly as OpenCV's initInterTab2D leaves it (A-10) */
+void  orc_remap_weight_table(int16_t* tab4096);
+
 #ifdef __cplusplus
 }
 #endif

@@ -404,3 +404,33 @@ def bow_transform(voc, desc, levelsup=4):
                                ptr(voc["weight"]), voc["depth"], ptr(d), n, levelsup, ptr(wid), ptr(nid), ptr(wt))
     assert rc == 0
     return wid, nid, wt
+
+
+def init_undistort_rectify_map(K, D, R, P, size):
+    w, h = int(size[0]), int(size[1])
+    K = np.ascontiguousarray(np.asarray(K, np.float64).reshape(3, 3)); P = np.ascontiguousarray(np.asarray(P, np.float64).reshape(3, -1)[:, :3])
+    Rm = None if R is None else np.ascontiguousarray(np.asarray(R, np.float64).reshape(3, 3))
+    d = np.zeros(0, np.float64) if D is None else np.ascontiguousarray(np.asarray(D, np.float64).ravel())
+    m1 = np.empty((h, w), np.float32); m2 = np.empty((h, w), np.float32)
+    lib.orc_init_undistort_rectify_map.restype = C.c_int
+    rc = lib.orc_init_undistort_rectify_map(ptr(K), ptr(d) if len(d) else None, len(d), ptr(Rm) if Rm is not None else None, ptr(P),
+                                            w, h, ptr(m1), ptr(m2))
+    assert rc == 0
+    return m1, m2
+
+
+def remap_bilinear(img, map1, map2):
+    img = np.ascontiguousarray(img, np.uint8); cn = 1 if img.ndim == 2 else img.shape[2]
+    m1 = np.ascontiguousarray(map1, np.float32); m2 = np.ascontiguousarray(map2, np.float32)
+    out = np.empty(m1.shape + ((cn,) if img.ndim == 3 else ()), np.uint8)
+    lib.orc_remap_bilinear_u8.restype = None
+    lib.orc_remap_bilinear_u8(ptr(img), img.shape[1], img.shape[0], img.strides[0], cn, ptr(m1), ptr(m2), m1.shape[1], m1.shape[0],
+                              ptr(out), out.strides[0])
+    return out
+
+
+def remap_weight_table():
+    t = np.zeros(4096, np.int16)
+    lib.orc_remap_weight_table.restype = None
+    lib.orc_remap_weight_table(ptr(t))
+    return t.reshape(1024, 4)

@@ -1,0 +1,91 @@
+"""GPU parity of the rectification step: ivf_init_undistort_rectify_map / ivf_remap_* through the
+C-ABI against the CPU oracle.  Bar: bit-exact maps (same double arithmetic) and bit-exact remapped images."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from iv_slam_amd import synth
+from test_oracle_rectify import K_L, D_L, R_L, P_L
+
+pytestmark = pytest.mark.gpu
+
+K_R = [530.158021, 0.0, 475.540633, 0.0, 529.682234, 299.995465, 0.0, 0.0, 1.0]
+D_R = [-0.156833, 0.081841, -0.000779, -0.000356, 0.0]
+R_R = [0.999661, -0.024534, 0.008699, 0.024595, 0.999673, -0.006974, -0.008525, 0.007186, 0.999938]
+P_R = [528.955512, 0.0, 479.748173, -69.690815, 0.0, 528.955512, 298.607571, 0.0, 0.0, 0.0, 1.0, 0.0]
+
+
+@pytest.fixture(scope="module")
+def iv():
+    import iv_slam_amd
+    lib = iv_slam_amd.load()
+    assert lib.ivf_device_count() >= 1, "no HIP device: libivfront has no CPU fallback"
+    return iv_slam_amd
+
+
+def test_maps_bit_exact(iv):
+    for (K, D, R, P) in [(K_L, D_L, R_L, P_L), (K_R, D_R, R_R, P_R), (K_L, None, R_L, P_L), (K_L, D_L, None, K_L),
+                         (K_L, D_L[:4], R_L, P_L), (K_R, D_R + [0.01, -0.02, 0.003], R_R, P_R),
+                         (K_R, D_R + [0.01, -0.02, 0.003, 1e-4, -2e-4, 3e-4, -1e-4], R_R, P_R)]:
+        g1, g2 = iv.initUndistortRectifyMap(K, D, R, P, (960, 600))
+        o1, o2 = O.init_undistort_rectify_map(K, D, R, P, (960, 600))
+        assert g1.tobytes() == o1.tobytes() and g2.tobytes() == o2.tobytes()
+    with pytest.raises(iv.IvfError):
+        iv.initUndistortRectifyMap(K_L, [0.1] * 14, None, K_L, (64, 48))          # tilt terms: refused, not ignored
+    with pytest.raises(iv.IvfError):
+        iv.initUndistortRectifyMap(K_L, None, None, [1, 0, 0, 2, 0, 0, 0, 0, 1], (64, 48))   # singular P
+
+
+def test_fixed_maps_and_remap_random_maps(iv):
+    rng = np.random.default_rng(5)
+    for (sh, sw, h, w, cn) in [(64, 80, 50, 71, 1), (120, 160, 120, 160, 1), (97, 131, 63, 250, 3), (33, 35, 5, 3, 1)]:
+        shape = (sh, sw) if cn == 1 else (sh, sw, 3)
+        img = rng.integers(0, 256, size=shape).astype(np.uint8)
+        m1 = (rng.random((h, w)) * (sw + 8) - 4).astype(np.float32)
+        m2 = (rng.random((h, w)) * (sh + 8) - 4).astype(np.float32)
+        m1[0, :3] = [-1.0, sw - 0.5, 1e6]; m2[0, :3] = [0, 0, -1e6]
+        m1[1, :2] = [3 + 1 / 64, 5 + 3 / 64]; m2[1, :2] = [2.5, 7 + 1 / 64]     # ties of the 1/32-px rounding
+        r = iv.Remap(m1, m2, (sh, sw), cn)
+        xy, al = r.fixed_maps()
+        fx = np.rint(m1 * np.float32(32)).astype(np.int64); fy = np.rint(m2 * np.float32(32)).astype(np.int64)
+        assert np.array_equal(xy[..., 0], np.clip(fx >> 5, -32768, 32767)) and np.array_equal(xy[..., 1], np.clip(fy >> 5, -32768, 32767))
+        assert np.array_equal(al, ((fy & 31) << 5) | (fx & 31))
+        assert np.array_equal(r(img), O.remap_bilinear(img, m1, m2)), (sh, sw, h, w, cn)
+    with pytest.raises(iv.IvfError):
+        iv.Remap(m1, m2, (40000, 10), 1)
+    with pytest.raises(iv.IvfError):
+        iv.Remap(m1, m2, (10, 10), 2)
+
+
+def test_rectified_stereo_pair_full_size(iv):
+    """Jackal-shaped 960x600 pair: maps from the calibration, remap on the device, then the extractor -- the whole
+    chain equals the oracle chain bit for bit."""
+    L, R = synth.make_pair(960, 600, seed=31, idx=1)
+    for img, (K, D, Rm, P) in ((L, (K_L, D_L, R_L, P_L)), (R, (K_R, D_R, R_R, P_R))):
+        m1, m2 = iv.initUndistortRectifyMap(K, D, Rm, P, (960, 600))
+        g = iv.Remap(m1, m2, img.shape)(img)
+        o = O.remap_bilinear(img, m1, m2)
+        assert np.array_equal(g, o)
+        assert (g[:, :3] == 0).any() or (g[:3] == 0).any() or True          # borders may or may not be visible; no assumption
+        gk, gd = iv.ORBextractor(1200, 1.2, 8, 12, 7)(g)
+        ok, od = O.Extractor(1200, 1.2, 8, 12, 7)(o)
+        assert gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
+
+
+def test_remap_device_batch(iv):
+    import torch
+    rng = np.random.default_rng(8)
+    h, w = 375, 1242
+    m1, m2 = iv.initUndistortRectifyMap([718.856, 0, 607.1928, 0, 718.856, 185.2157, 0, 0, 1], [-0.2, 0.05, 1e-3, -1e-3, 0.0],
+                                        None, [718.856, 0, 607.1928, 0, 718.856, 185.2157, 0, 0, 1], (w, h))
+    imgs = rng.integers(0, 256, size=(6, h, w)).astype(np.uint8)
+    r = iv.Remap(m1, m2, (h, w))
+    out = r.apply_device(torch.from_numpy(imgs).cuda())
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for k in range(len(imgs)):
+        assert np.array_equal(out[k], O.remap_bilinear(imgs[k], m1, m2))
+    # size-independent property: a map of integer positions is a pure gather (weights {32767, 0, 0, 1} never change a value)
+    perm_x = rng.permutation(w).astype(np.float32)[None, :].repeat(h, 0); perm_y = rng.permutation(h).astype(np.float32)[:, None].repeat(w, 1)
+    g = iv.Remap(perm_x, perm_y, (h, w))(imgs[0])
+    assert np.array_equal(g, imgs[0][perm_y.astype(int), perm_x.astype(int)])
