@@ -44,23 +44,28 @@ __device__ __forceinline__ void remap_weights(unsigned a, int& w00, int& w01, in
     if (a == 0) { w00 = 32767; w11 = 1; }
 }
 
-// one thread = 4 horizontally adjacent destination pixels; workgroup = 256 x 4 destination pixels
+// workgroup = 256 x 4 destination pixels; a wave owns 256 consecutive pixels of one row and lane i takes pixels
+// i, i+64, i+128, i+192 of them, so that every map load, gather and store of the wave touches consecutive addresses
+// (rectification maps are smooth: neighbouring destination pixels read neighbouring source pixels)
 template <int CN>
 __global__ __launch_bounds__(256) void k_remap(const uint32_t* __restrict__ xy, const uint16_t* __restrict__ al, int wp,
                                                const uint8_t* __restrict__ src, size_t srcImage, int sstride, int sw, int sh,
                                                uint8_t* __restrict__ dst, size_t dstImage, int dstride, int w, int h)
 {
-    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x4 >= w || y >= h) return;
+    const int xb = blockIdx.x * 256 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= h) return;
     const uint8_t* S = src + (size_t)blockIdx.z * srcImage;
     uint8_t* D = dst + (size_t)blockIdx.z * dstImage + (size_t)y * dstride;
-    const uint4 p4 = *(const uint4*)(xy + (size_t)y * wp + x4);
-    const uint2 a2 = *(const uint2*)(al + (size_t)y * wp + x4);
-    const unsigned pk[4] = {p4.x, p4.y, p4.z, p4.w};
-    const unsigned ak[4] = {a2.x & 0xffffu, a2.x >> 16, a2.y & 0xffffu, a2.y >> 16};
-    unsigned out[CN] = {};
+    unsigned pk[4], ak[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
+        const int x = min(xb + 64 * k, wp - 1);                 // the padded map row is readable up to wp
+        pk[k] = xy[(size_t)y * wp + x];
+        ak[k] = al[(size_t)y * wp + x];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = xb + 64 * k;
         const int sx = (short)(pk[k] & 0xffffu), sy = (short)(pk[k] >> 16);
         int w00, w01, w10, w11;
         remap_weights(ak[k], w00, w01, w10, w11);
@@ -75,13 +80,8 @@ __global__ __launch_bounds__(256) void k_remap(const uint32_t* __restrict__ xy, 
             const int t00 = (x0 && y0) ? r0[c0 + c] : 0, t01 = (x1 && y0) ? r0[c1 + c] : 0;
             const int t10 = (x0 && y1) ? r1[c0 + c] : 0, t11 = (x1 && y1) ? r1[c1 + c] : 0;
             const unsigned v = (unsigned)(t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11 + (1 << 14)) >> 15;   // <= 255
-            if (CN == 1) out[0] |= v << (8 * k);
-            else if (x4 + k < w) D[(x4 + k) * CN + c] = (uint8_t)v;
+            if (x < w) D[x * CN + c] = (uint8_t)v;
         }
-    }
-    if (CN == 1) {
-        if (x4 + 3 < w && ((((size_t)D) | (size_t)dstride) & 3) == 0) *(unsigned*)(D + x4) = out[0];
-        else for (int k = 0; k < 4 && x4 + k < w; k++) D[x4 + k] = (uint8_t)(out[0] >> (8 * k));
     }
 }
 

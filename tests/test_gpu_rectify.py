@@ -89,3 +89,42 @@ def test_remap_device_batch(iv):
     perm_x = rng.permutation(w).astype(np.float32)[None, :].repeat(h, 0); perm_y = rng.permutation(h).astype(np.float32)[:, None].repeat(w, 1)
     g = iv.Remap(perm_x, perm_y, (h, w))(imgs[0])
     assert np.array_equal(g, imgs[0][perm_y.astype(int), perm_x.astype(int)])
+
+
+def test_replay_harness_matches_oracle_chain(iv, tmp_path):
+    """tools/replay_kitti.py on a synthetic KITTI-layout sequence (PNG files, times.txt, settings.yaml, cost images for
+    two frames out of three): load -> rectify on the device -> extract L/R (+ cost map) -> stereo match equals the oracle
+    chain frame by frame."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import replay_kitti
+    from iv_slam_amd import kitti
+    seq = str(tmp_path / "seq")
+    settings = replay_kitti.make_synthetic(seq, 6)
+    S = kitti.Settings.load(settings)
+    left, right, ts = kitti.LoadImages(seq)
+    qual, found = kitti.GetImageQualFileNames(os.path.join(seq, "qual"), len(ts))
+    assert len(ts) == 6 and found == 4
+    nf, sf, nl, ini, mn, _ = S.extractor_params(); bf, b = S.stereo()
+    maps = {}
+    for side in ("LEFT", "RIGHT"):
+        K, D, R, P, size = S.rectification(side)
+        maps[side] = O.init_undistort_rectify_map(K, D, R, P, size)
+    for introspect in (False, True):
+        rp = replay_kitti.Replay(S, rectify=True, undistort=True, introspect=introspect, batch=1 if introspect else 4)
+        for i0 in range(0, 6, rp.batch):
+            idx = list(range(i0, min(i0 + rp.batch, 6)))
+            Ls = [kitti.imread(left[i]) for i in idx]; Rs = [kitti.imread(right[i]) for i in idx]
+            Cs = [kitti.imread(qual[i]) if qual[i] else None for i in idx] if introspect else None
+            res = rp.run(Ls, Rs, Cs)
+            for k, i in enumerate(idx):
+                oL = O.remap_bilinear(Ls[k], *maps["LEFT"]); oR = O.remap_bilinear(Rs[k], *maps["RIGHT"])
+                oC = O.remap_bilinear(Cs[k], *maps["LEFT"]) if (introspect and Cs[k] is not None) else None
+                eL = O.Extractor(nf, sf, nl, ini, mn, introspection=introspect); eR = O.Extractor(nf, sf, nl, ini, mn)
+                okL, odL = eL(oL, oC); okR, odR = eR(oR)
+                our, odp = O.stereo_match(eL, eR, okL, odL, okR, odR, bf, b)
+                l, r = res[k]
+                assert l["kps"].tobytes() == okL.tobytes() and np.array_equal(l["desc"], odL), (introspect, i)
+                assert r["kps"].tobytes() == okR.tobytes() and np.array_equal(r["desc"], odR), (introspect, i)
+                assert l["uright"].tobytes() == our.tobytes() and l["depth"].tobytes() == odp.tobytes(), (introspect, i)
