@@ -196,6 +196,10 @@ int   ivf_frontend_fast_ms_stats(ivf_frontend* fe, int last_n, double* sum_ms, i
  * and returns the record size in *record_bytes. */
 int  ivf_frontend_pack_gather_block(ivf_frontend* fe, uint8_t* d_block, size_t block_bytes, size_t* record_bytes,
                                     void* hip_stream);
+/* Same for the run `age` runs back (0 = the last one ... 2 = the oldest one still held).  Note that `hip_stream` waits
+ * for that run to finish: pack on a stream of its own (bench.py does), not on the stream that feeds the next batch. */
+int  ivf_frontend_pack_gather_block_of(ivf_frontend* fe, int age, uint8_t* d_block, size_t block_bytes, size_t* record_bytes,
+                                       void* hip_stream);
 
 /* ---- introspection FCN forward (IF/networks/models_light/models_light.py:18-28; called at
  * ORB/Examples/Stereo/stereo_kitti.cc:231-247 (load) and :493-514 (pre-process, forward, u8 truncation)) ----

@@ -318,6 +318,7 @@ struct ivf_frontend {
     hipEvent_t evIn[kPipe] = {}, evConsumed[kPipe] = {}, evDone[kPipe] = {};
     uint8_t* dFlags = nullptr;          // useCost flags when a cost batch is given: [L,R,L,R,...]
     int lastPairs = 0;
+    int pairsOf[kPipe] = {};            // batch size of the run each context holds
     long long runs = 0;
     int last() const { return (int)((runs + kPipe - 1) % kPipe); }      // context of the most recent run
 };
@@ -1474,11 +1475,12 @@ int ivf_frontend_create(const ivf_frontend_config* cfg, ivf_frontend** out)
         int prLo = 0, prHi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prLo, &prHi);
         static const bool noPrio = getenv("IVF_NO_STREAM_PRIORITY") != nullptr;
+        const unsigned evFlags = hipEventDisableTiming;
         if ((noPrio ? hipStreamCreateWithFlags(&fe->stream[k], hipStreamNonBlocking)
                     : hipStreamCreateWithPriority(&fe->stream[k], hipStreamNonBlocking, prHi)) != hipSuccess ||
-            hipEventCreateWithFlags(&fe->evIn[k], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&fe->evConsumed[k], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&fe->evDone[k], hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&fe->evIn[k], evFlags) != hipSuccess ||
+            hipEventCreateWithFlags(&fe->evConsumed[k], evFlags) != hipSuccess ||
+            hipEventCreateWithFlags(&fe->evDone[k], evFlags) != hipSuccess)
             return cleanup(fail(IVF_E_NO_DEVICE, "stream/event creation failed"));
     }
     std::vector<uint8_t> flags(2 * (size_t)cfg->max_pairs);
@@ -1530,6 +1532,7 @@ int ivf_frontend_run(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_r
     // the caller's stream may overwrite its input buffers once they have been ingested
     HIPCHK(hipStreamWaitEvent(caller, fe->evConsumed[k], 0));
     fe->lastPairs = n_pairs;
+    fe->pairsOf[k] = n_pairs;
     fe->runs++;
     return IVF_OK;
 }
@@ -1615,29 +1618,31 @@ int ivf_frontend_fast_ms_stats(ivf_frontend* fe, int last_n, double* sum_ms, int
     return IVF_OK;
 }
 
-int ivf_frontend_pack_gather_block(ivf_frontend* fe, uint8_t* d_block, size_t block_bytes, size_t* record_bytes, void* hip_stream)
+int ivf_frontend_pack_gather_block_of(ivf_frontend* fe, int age, uint8_t* d_block, size_t block_bytes, size_t* record_bytes,
+                                      void* hip_stream)
 {
     if (!fe || !record_bytes) return fail(IVF_E_INVALID, "null argument");
     const size_t nf = fe->ctx[0].hc.nfeatures;
     const size_t rec = 16 + nf * sizeof(ivf_keypoint) + nf * 32 + nf * sizeof(float);
     *record_bytes = rec;
     if (!d_block) return IVF_OK;
-    const int np = fe->lastPairs;
-    if (np < 1) return fail(IVF_E_STATE, "no batch has run");
+    if (age < 0 || age >= kPipe) return fail(IVF_E_INVALID, "age %d outside [0,%d): results stay valid for %d further runs", age, kPipe, kPipe - 1);
+    if (fe->runs <= age) return fail(IVF_E_STATE, "no batch of age %d has run", age);
+    const int k = (int)((fe->runs - 1 - age) % kPipe);
+    const int np = fe->pairsOf[k];
     if (block_bytes < rec * np) return fail(IVF_E_CAPACITY, "gather block needs %zu bytes", rec * np);
+    if (((size_t)d_block & 3) != 0) return fail(IVF_E_INVALID, "gather block must be 4-byte aligned");
     hipStream_t st = (hipStream_t)hip_stream;
-    const Buffers& b = fe->ctx[fe->last()].b;
     HIPCHK(hipSetDevice(fe->cfg.device_id));
-    HIPCHK(hipStreamWaitEvent(st, fe->evDone[fe->last()], 0));       // the batch runs on an internal stream
-    HIPCHK(hipMemsetAsync(d_block, 0, rec * np, st));
-    HIPCHK(hipMemcpy2DAsync(d_block, rec, b.count, 2 * sizeof(int), sizeof(int), np, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpy2DAsync(d_block + 16, rec, b.kps, 2 * nf * sizeof(ivf_keypoint), nf * sizeof(ivf_keypoint), np,
-                            hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpy2DAsync(d_block + 16 + nf * sizeof(ivf_keypoint), rec, b.desc, 2 * nf * 32, nf * 32, np,
-                            hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpy2DAsync(d_block + 16 + nf * sizeof(ivf_keypoint) + nf * 32, rec, b.uright, nf * sizeof(float),
-                            nf * sizeof(float), np, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipStreamWaitEvent(st, fe->evDone[k], 0));                 // the batch ran on an internal stream
+    launch_pack_gather(fe->ctx[k].b, (int)nf, np, d_block, rec, st);
+    HIPCHK(hipGetLastError());
     return IVF_OK;
+}
+
+int ivf_frontend_pack_gather_block(ivf_frontend* fe, uint8_t* d_block, size_t block_bytes, size_t* record_bytes, void* hip_stream)
+{
+    return ivf_frontend_pack_gather_block_of(fe, 0, d_block, block_bytes, record_bytes, hip_stream);
 }
 
 }  // extern "C"

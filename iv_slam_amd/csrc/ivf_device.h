@@ -104,6 +104,7 @@ void launch_describe(const Config& hc, const Config* dc, const Buffers& b, const
                      int costPitch, int nImg, int nSides, hipStream_t s);
 void launch_stereo(const Config& hc, const Config* dc, const Buffers& b, int nPairs, float bf, float bb, hipStream_t s);
 void launch_test_retain_best(const float* dResp, int n, int nPoints, int* dOrder, hipStream_t s);
+void launch_pack_gather(const Buffers& b, int nf, int nPairs, uint8_t* block, size_t recBytes, hipStream_t s);
 void launch_hamming_pairs(const uint8_t* a, const uint8_t* b, const int* pairs, int n, int* dist, hipStream_t s);
 void launch_distinct_median(const uint8_t* desc, int n, int* median, hipStream_t s);
 void launch_bow_transform(const int* childStart, const int* child, const uint8_t* nodeDesc, const uint8_t* desc, int n, int nidLevel,

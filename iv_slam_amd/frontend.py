@@ -75,10 +75,10 @@ class StereoFrontend:
         check(self._lib.ivf_frontend_pack_gather_block(self._h, None, 0, C.byref(rec), None))
         return rec.value
 
-    def pack_gather_block(self, block, stream_ptr=None):
-        """block: torch.uint8 tensor of >= n_pairs*record_bytes on this device."""
+    def pack_gather_block(self, block, stream_ptr=None, age=0):
+        """block: torch.uint8 tensor of >= n_pairs*record_bytes on this device; age = which run (0 last, 1 the one before)."""
         rec = C.c_size_t(0)
-        check(self._lib.ivf_frontend_pack_gather_block(self._h, block.data_ptr(), block.numel(), C.byref(rec), stream_ptr))
+        check(self._lib.ivf_frontend_pack_gather_block_of(self._h, int(age), block.data_ptr(), block.numel(), C.byref(rec), stream_ptr))
         return rec.value
 
 

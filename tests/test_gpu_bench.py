@@ -1,0 +1,37 @@
+"""bench.py's contract on a real GPU: one JSON line with the roofline and (optionally) cpu_baseline objects, and the
+multi-GPU exchange step (RCCL all-gather of descriptor records on a side stream) exercised with a single rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", *extra],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    j = _run("--pairs", "16", "--stream", "32")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["value"] > 0 and j["unit"] == "pairs/s" and j["vs_baseline"] is None
+    rf = j["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["peak"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 * max(rf["frac"], 1e-9) + 1e-6
+    assert "workload" in j["config"]
+
+
+def test_exchange_step_single_rank():
+    j = _run("--pairs", "16", "--stream", "32", "--force-gather", "--no-introspect")
+    assert j["value"] > 0
