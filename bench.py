@@ -212,6 +212,22 @@ def main():
     iso_sum_ms, iso_n = fe.fast_ms_stats(5)
     if fcn is not None:
         iso_probe_ms, iso_probe_n, _ = fcn.probe_stats(5)
+    # the network alone (MFMA leg of north_star): 3 forwards with nothing else on the GPU, HIP events on its stream
+    fcn_alone = None
+    if fcn is not None and world == 1:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        fcn.forward_device(bgr[:P], cost_u8=cost, stream_ptr=sptr)
+        e0.record(stream)
+        for _ in range(3):
+            fcn.forward_device(bgr[:P], cost_u8=cost, stream_ptr=sptr)
+        e1.record(stream); torch.cuda.synchronize(dev)
+        us_img = e0.elapsed_time(e1) * 1e3 / 3 / P
+        # 17.229 GFLOP per forward, of which the 1x1 convs (14.61) and the decoder 3x3 (1.89) run on MFMA, each
+        # product as three f16 MFMAs (split-f16: hi*hi + hi*lo + lo*hi, f32 accumulate)
+        fcn_alone = {"us_per_image": round(us_img, 2), "batch": P,
+                     "f32_equivalent_tflops": round(17.229e9 / us_img / 1e6, 1),
+                     "mfma_f16_tflops_issued": round(3 * (14.61 + 1.89) * 1e9 / us_img / 1e6, 1), "mfma_f16_dense_peak_tflops": 2500.0,
+                     "mfma_frac": round(3 * (14.61 + 1.89) * 1e9 / us_img / 1e6 / 2500.0, 4)}
     # configs[1] (no introspection) on the same stream of pairs, for reference next to the headline number
     em_only = None
     if fcn is not None and world == 1:
@@ -285,6 +301,8 @@ def main():
         }
         if fcn is not None:
             out["roofline_fast_nms"] = fast_roof
+            if fcn_alone is not None:
+                out["fcn_forward"] = fcn_alone
             if em_only is not None:
                 out["extract_match_only"] = {"value": round(em_only, 2), "unit": "pairs/s",
                                              "note": "configs[1] (introspection OFF), 10 steps on the same resident pairs after the timed region"}
