@@ -319,6 +319,23 @@ int  ivf_bow_vectors(const int32_t* word_id, const int32_t* node_id, const doubl
  * vDescriptors, in mObservations order); *best_index = the row to copy into mDescriptor, *best_median (nullable) its median. */
 int  ivf_distinctive_descriptor(const uint8_t* desc, int n, int* best_index, int* best_median, int device_id);
 
+/* ---- device-resident frame -----------------------------------------------------------------------
+ * Frame::AssignFeaturesToGrid (ORB/src/Frame.cc:415-430) once per frame on the device: keypoints (mvKeysUn), descriptors
+ * and the 64x48 bucket grid (buckets in the reference's ix-major order, keypoints of a bucket in insertion order) stay
+ * in HBM; searches against the frame then run GetFeaturesInArea (:615-668) and DescriptorDistance for every query on
+ * the device and only replay the order-dependent assignment on the host. */
+typedef struct ivf_frame ivf_frame;
+int  ivf_frame_create(const ivf_keypoint* kps, const uint8_t* desc, const float* uright, int n, const ivf_bounds* bounds,
+                      int device_id, ivf_frame** out);
+void ivf_frame_destroy(ivf_frame* f);
+/* the grid as built on the device: cell_start [64*48+1] (cell = ix*48 + iy), cell_index [n] */
+int  ivf_frame_grid(const ivf_frame* f, int32_t* cell_start, int32_t* cell_index);
+/* ivf_search_by_projection against the resident frame (same query arrays, same results) */
+int  ivf_frame_search_by_projection(ivf_frame* f, int n_q, const float* q_u, const float* q_v, const float* q_ur,
+                                    const float* q_radius, const int32_t* q_min_level, const int32_t* q_max_level,
+                                    const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid, const uint8_t* q_blocks,
+                                    int check_orientation, int32_t* cur_assign, int* nmatches);
+
 /* ---- rectification in front of the extractor -------------------------------------------------
  * cv::initUndistortRectifyMap(K, D, R, P(0:3,0:3), size, CV_32F, map1, map2) as the driver calls it
  * (introspective_ORB_SLAM/Examples/Stereo/stereo_kitti.cc:285-343): host-side, double arithmetic, OpenCV 4.x plain C++

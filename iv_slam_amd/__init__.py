@@ -5,7 +5,7 @@ mirror of the reference's ORBextractor / ORBmatcher interfaces.  No CPU fallback
 """
 from ._lib import KP_DTYPE, IvfError, load  # noqa: F401
 from .orb import (ORBextractor, ORBmatcher, ORBVocabulary, ComputeStereoMatches, GetFeaturesInArea,  # noqa: F401
-                  ComputeDistinctiveDescriptors)
+                  ComputeDistinctiveDescriptors, DeviceFrame)
 from .frontend import StereoFrontend  # noqa: F401
 from .fcn import IntrospectionFCN  # noqa: F401
 from .rectify import initUndistortRectifyMap, Remap  # noqa: F401

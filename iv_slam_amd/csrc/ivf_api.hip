@@ -595,34 +595,12 @@ int ivf_features_in_area(const ivf_keypoint* kps, int n, const ivf_bounds* bound
     return c > cap ? fail(IVF_E_CAPACITY, "%d indices exceed capacity %d", c, cap) : IVF_OK;
 }
 
-int ivf_search_by_projection(const ivf_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int n_cur,
-                             const ivf_bounds* bounds, int n_q, const float* q_u, const float* q_v, const float* q_ur,
-                             const float* q_radius, const int32_t* q_min_level, const int32_t* q_max_level,
-                             const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid, const uint8_t* q_blocks,
-                             int check_orientation, int32_t* cur_assign, int* nmatches, int device_id)
+// order-dependent greedy assignment + rotation histogram of SearchByProjection(cur, last), replayed in query order
+// (ORBmatcher.cc:1444-1511): candidates of query i = cand[qStart[i] .. qStart[i+1]) in GetFeaturesInArea order
+static int replay_projection(const ivf_keypoint* cur_kps, const float* cur_uright, int n_q, const float* q_ur, const float* q_radius,
+                             const float* q_angle, const uint8_t* q_blocks, int check_orientation, const std::vector<int>& qStart,
+                             const std::vector<int>& cand, const std::vector<int>& dist, int32_t* cur_assign)
 {
-    if (!cur_kps || !cur_desc || !cur_uright || !bounds || !cur_assign || !nmatches || n_cur < 0 || n_q < 0)
-        return fail(IVF_E_INVALID, "bad argument");
-    *nmatches = 0;
-    if (n_q == 0 || n_cur == 0) return IVF_OK;
-    if (!q_u || !q_v || !q_ur || !q_radius || !q_min_level || !q_max_level || !q_angle || !q_desc)
-        return fail(IVF_E_INVALID, "null query array");
-    // 1. candidate windows in the reference's GetFeaturesInArea order (:1429-1437)
-    Grid g; g.build(cur_kps, n_cur, *bounds);
-    std::vector<int> qStart(n_q + 1, 0), pairs;
-    for (int i = 0; i < n_q; i++) {
-        qStart[i] = (int)pairs.size() / 2;
-        if (q_valid && !q_valid[i]) continue;
-        g.query(cur_kps, *bounds, q_u[i], q_v[i], q_radius[i], q_min_level[i], q_max_level[i],
-                [&](int i2) { pairs.push_back(i); pairs.push_back(i2); });
-    }
-    qStart[n_q] = (int)pairs.size() / 2;
-    const int nPairs = qStart[n_q];
-    // 2. every window distance on the device (DescriptorDistance :1459-1461)
-    std::vector<int> dist(std::max(nPairs, 1));
-    int rc = ivf_hamming_pairs(q_desc, n_q, cur_desc, n_cur, pairs.data(), nPairs, dist.data(), device_id);
-    if (rc) return rc;
-    // 3. order-dependent greedy assignment + rotation histogram, replayed in query order (:1444-1511)
     const int HISTO_LENGTH = 30;
     std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
     const float factor = 1.0f / HISTO_LENGTH;
@@ -630,7 +608,7 @@ int ivf_search_by_projection(const ivf_keypoint* cur_kps, const uint8_t* cur_des
     for (int i = 0; i < n_q; i++) {
         int bestDist = 256, bestIdx2 = -1;
         for (int p = qStart[i]; p < qStart[i + 1]; p++) {
-            const int i2 = pairs[2 * p + 1];
+            const int i2 = cand[p];
             if (cur_assign[i2] == -2) continue;
             if (cur_assign[i2] >= 0 && (!q_blocks || q_blocks[cur_assign[i2]])) continue;
             if (cur_uright[i2] > 0) { const float er = fabsf(q_ur[i] - cur_uright[i2]); if (er > q_radius[i]) continue; }
@@ -661,7 +639,174 @@ int ivf_search_by_projection(const ivf_keypoint* cur_kps, const uint8_t* cur_des
             if (i != ind1 && i != ind2 && i != ind3)
                 for (int j : rotHist[i]) { cur_assign[j] = -1; nm--; }
     }
+    return nm;
+}
+
+int ivf_search_by_projection(const ivf_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int n_cur,
+                             const ivf_bounds* bounds, int n_q, const float* q_u, const float* q_v, const float* q_ur,
+                             const float* q_radius, const int32_t* q_min_level, const int32_t* q_max_level,
+                             const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid, const uint8_t* q_blocks,
+                             int check_orientation, int32_t* cur_assign, int* nmatches, int device_id)
+{
+    if (!cur_kps || !cur_desc || !cur_uright || !bounds || !cur_assign || !nmatches || n_cur < 0 || n_q < 0)
+        return fail(IVF_E_INVALID, "bad argument");
+    *nmatches = 0;
+    if (n_q == 0 || n_cur == 0) return IVF_OK;
+    if (!q_u || !q_v || !q_ur || !q_radius || !q_min_level || !q_max_level || !q_angle || !q_desc)
+        return fail(IVF_E_INVALID, "null query array");
+    // 1. candidate windows in the reference's GetFeaturesInArea order (:1429-1437)
+    Grid g; g.build(cur_kps, n_cur, *bounds);
+    std::vector<int> qStart(n_q + 1, 0), pairs;
+    for (int i = 0; i < n_q; i++) {
+        qStart[i] = (int)pairs.size() / 2;
+        if (q_valid && !q_valid[i]) continue;
+        g.query(cur_kps, *bounds, q_u[i], q_v[i], q_radius[i], q_min_level[i], q_max_level[i],
+                [&](int i2) { pairs.push_back(i); pairs.push_back(i2); });
+    }
+    qStart[n_q] = (int)pairs.size() / 2;
+    const int nPairs = qStart[n_q];
+    // 2. every window distance on the device (DescriptorDistance :1459-1461)
+    std::vector<int> dist(std::max(nPairs, 1));
+    int rc = ivf_hamming_pairs(q_desc, n_q, cur_desc, n_cur, pairs.data(), nPairs, dist.data(), device_id);
+    if (rc) return rc;
+    // 3. order-dependent greedy assignment + rotation histogram, replayed in query order (:1444-1511)
+    std::vector<int> cand(std::max(nPairs, 1));
+    for (int p = 0; p < nPairs; p++) cand[p] = pairs[2 * p + 1];
+    const int nm = replay_projection(cur_kps, cur_uright, n_q, q_ur, q_radius, q_angle, q_blocks, check_orientation, qStart, cand, dist, cur_assign);
     *nmatches = nm;
+    return IVF_OK;
+}
+
+// ---- device-resident frame: keypoints, descriptors and the 64x48 grid stay in HBM between searches -----------------
+struct ivf_frame {
+    int device = 0, n = 0;
+    ivf_bounds bd{};
+    float invW = 0, invH = 0;
+    std::vector<ivf_keypoint> kps;      // host copies for the greedy replay (angle, uRight)
+    std::vector<float> uright;
+    std::vector<uint8_t> desc;          // host copy for the overflow fallback
+    ivf_keypoint* dKps = nullptr; uint8_t* dDesc = nullptr; int *dStart = nullptr, *dIdx = nullptr;
+    // query scratch, grown on demand
+    int qCap = 0, cCap = 0;
+    float *dQu = nullptr, *dQv = nullptr, *dQr = nullptr; int *dQmin = nullptr, *dQmax = nullptr; uint8_t *dQdesc = nullptr, *dQvalid = nullptr;
+    int *dCount = nullptr, *dCand = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+void ivf_frame_destroy(ivf_frame* f)
+{
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    void* ptrs[] = {f->dKps, f->dDesc, f->dStart, f->dIdx, f->dQu, f->dQv, f->dQr, f->dQmin, f->dQmax, f->dQdesc, f->dQvalid, f->dCount, f->dCand};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (f->stream) (void)hipStreamDestroy(f->stream);
+    delete f;
+}
+
+int ivf_frame_create(const ivf_keypoint* kps, const uint8_t* desc, const float* uright, int n, const ivf_bounds* bounds,
+                     int device_id, ivf_frame** out)
+{
+    if (!out) return fail(IVF_E_INVALID, "null argument");
+    *out = nullptr;
+    if (!bounds || n < 0 || (n > 0 && (!kps || !desc || !uright))) return fail(IVF_E_INVALID, "bad argument");
+    if (!(bounds->max_x > bounds->min_x) || !(bounds->max_y > bounds->min_y)) return fail(IVF_E_INVALID, "empty image bounds");
+    int rc = have_device(device_id);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    ivf_frame* f = new ivf_frame();
+    f->device = device_id; f->n = n; f->bd = *bounds;
+    f->invW = (float)GC / (bounds->max_x - bounds->min_x); f->invH = (float)GR / (bounds->max_y - bounds->min_y);   // Frame.cc:208-209
+    f->kps.assign(kps, kps + n); f->uright.assign(uright, uright + n); f->desc.assign(desc, desc + (size_t)n * 32);
+    const size_t nn = (size_t)std::max(n, 1);
+    if (hipMalloc(&f->dKps, nn * sizeof(ivf_keypoint)) != hipSuccess || hipMalloc(&f->dDesc, nn * 32) != hipSuccess ||
+        hipMalloc(&f->dStart, (GC * GR + 1) * sizeof(int)) != hipSuccess || hipMalloc(&f->dIdx, nn * sizeof(int)) != hipSuccess ||
+        hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) {
+        ivf_frame_destroy(f);
+        return fail(IVF_E_NO_DEVICE, "device allocation failed for a frame of %d keypoints", n);
+    }
+    if (n > 0) {
+        if (hipMemcpyAsync(f->dKps, kps, (size_t)n * sizeof(ivf_keypoint), hipMemcpyHostToDevice, f->stream) != hipSuccess ||
+            hipMemcpyAsync(f->dDesc, desc, (size_t)n * 32, hipMemcpyHostToDevice, f->stream) != hipSuccess) {
+            ivf_frame_destroy(f);
+            return fail(IVF_E_NO_DEVICE, "frame upload failed");
+        }
+    }
+    launch_grid_build(f->dKps, n, bounds->min_x, bounds->min_y, f->invW, f->invH, f->dStart, f->dIdx, f->stream);   // AssignFeaturesToGrid
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(f->stream) != hipSuccess) {
+        ivf_frame_destroy(f);
+        return fail(IVF_E_NO_DEVICE, "grid build failed");
+    }
+    *out = f;
+    return IVF_OK;
+}
+
+int ivf_frame_grid(const ivf_frame* f, int32_t* cell_start, int32_t* cell_index)
+{
+    if (!f || !cell_start || !cell_index) return fail(IVF_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(f->device));
+    HIPCHK(hipMemcpy(cell_start, f->dStart, (GC * GR + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    if (f->n > 0) HIPCHK(hipMemcpy(cell_index, f->dIdx, (size_t)f->n * sizeof(int), hipMemcpyDeviceToHost));
+    return IVF_OK;
+}
+
+int ivf_frame_search_by_projection(ivf_frame* f, int n_q, const float* q_u, const float* q_v, const float* q_ur,
+                                   const float* q_radius, const int32_t* q_min_level, const int32_t* q_max_level,
+                                   const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid, const uint8_t* q_blocks,
+                                   int check_orientation, int32_t* cur_assign, int* nmatches)
+{
+    if (!f || !cur_assign || !nmatches || n_q < 0) return fail(IVF_E_INVALID, "bad argument");
+    *nmatches = 0;
+    if (n_q == 0 || f->n == 0) return IVF_OK;
+    if (!q_u || !q_v || !q_ur || !q_radius || !q_min_level || !q_max_level || !q_angle || !q_desc)
+        return fail(IVF_E_INVALID, "null query array");
+    HIPCHK(hipSetDevice(f->device));
+    static const int capEnv = getenv("IVF_FRAME_WINDOW_CAP") ? atoi(getenv("IVF_FRAME_WINDOW_CAP")) : 0;   // tests: force the overflow path
+    const int cap = capEnv > 0 ? capEnv : 128;
+    if (n_q > f->qCap || cap > f->cCap) {
+        void** ptrs[] = {(void**)&f->dQu, (void**)&f->dQv, (void**)&f->dQr, (void**)&f->dQmin, (void**)&f->dQmax, (void**)&f->dQdesc,
+                         (void**)&f->dQvalid, (void**)&f->dCount, (void**)&f->dCand};
+        for (void** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
+        f->qCap = 0;
+        const size_t nq = (size_t)n_q + 256;
+        HIPCHK(hipMalloc(&f->dQu, nq * 4)); HIPCHK(hipMalloc(&f->dQv, nq * 4)); HIPCHK(hipMalloc(&f->dQr, nq * 4));
+        HIPCHK(hipMalloc(&f->dQmin, nq * 4)); HIPCHK(hipMalloc(&f->dQmax, nq * 4)); HIPCHK(hipMalloc(&f->dQdesc, nq * 32));
+        HIPCHK(hipMalloc(&f->dQvalid, nq)); HIPCHK(hipMalloc(&f->dCount, nq * 4)); HIPCHK(hipMalloc(&f->dCand, nq * cap * 8));
+        f->qCap = (int)nq; f->cCap = cap;
+    }
+    hipStream_t st = f->stream;
+    const size_t nq = (size_t)n_q;
+    HIPCHK(hipMemcpyAsync(f->dQu, q_u, nq * 4, hipMemcpyHostToDevice, st)); HIPCHK(hipMemcpyAsync(f->dQv, q_v, nq * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(f->dQr, q_radius, nq * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(f->dQmin, q_min_level, nq * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(f->dQmax, q_max_level, nq * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(f->dQdesc, q_desc, nq * 32, hipMemcpyHostToDevice, st));
+    if (q_valid) HIPCHK(hipMemcpyAsync(f->dQvalid, q_valid, nq, hipMemcpyHostToDevice, st));
+    // 1 + 2. GetFeaturesInArea windows and DescriptorDistance of every candidate, on the device (:1429-1461)
+    launch_grid_window(f->dKps, f->dDesc, f->dStart, f->dIdx, f->bd.min_x, f->bd.min_y, f->invW, f->invH, n_q, f->dQu, f->dQv, f->dQr,
+                       f->dQmin, f->dQmax, f->dQdesc, q_valid ? f->dQvalid : nullptr, f->cCap, f->dCount, f->dCand, st);
+    HIPCHK(hipGetLastError());
+    std::vector<int> count(n_q), raw(nq * f->cCap * 2);
+    HIPCHK(hipMemcpyAsync(count.data(), f->dCount, nq * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(raw.data(), f->dCand, nq * f->cCap * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<int> qStart(n_q + 1, 0), cand, dist;
+    Grid g; bool haveGrid = false;
+    for (int i = 0; i < n_q; i++) {
+        qStart[i] = (int)cand.size();
+        if (count[i] <= f->cCap) {
+            for (int k = 0; k < count[i]; k++) { cand.push_back(raw[((size_t)i * f->cCap + k) * 2]); dist.push_back(raw[((size_t)i * f->cCap + k) * 2 + 1]); }
+        } else {
+            // a window with more candidates than the device list holds: this query again through the host grid
+            if (!haveGrid) { g.build(f->kps.data(), f->n, f->bd); haveGrid = true; }
+            g.query(f->kps.data(), f->bd, q_u[i], q_v[i], q_radius[i], q_min_level[i], q_max_level[i], [&](int i2) {
+                cand.push_back(i2); dist.push_back(ivf_hamming(q_desc + (size_t)i * 32, f->desc.data() + (size_t)i2 * 32)); });
+        }
+    }
+    qStart[n_q] = (int)cand.size();
+    if (cand.empty()) { cand.push_back(0); dist.push_back(0); }
+    // 3. greedy assignment + rotation histogram on the host (:1444-1511)
+    *nmatches = replay_projection(f->kps.data(), f->uright.data(), n_q, q_ur, q_radius, q_angle, q_blocks, check_orientation, qStart,
+                                  cand, dist, cur_assign);
     return IVF_OK;
 }
 

@@ -104,6 +104,10 @@ void launch_describe(const Config& hc, const Config* dc, const Buffers& b, const
                      int costPitch, int nImg, int nSides, hipStream_t s);
 void launch_stereo(const Config& hc, const Config* dc, const Buffers& b, int nPairs, float bf, float bb, hipStream_t s);
 void launch_test_retain_best(const float* dResp, int n, int nPoints, int* dOrder, hipStream_t s);
+void launch_grid_build(const ivf_keypoint* kps, int n, float minX, float minY, float invW, float invH, int* start, int* idx, hipStream_t s);
+void launch_grid_window(const ivf_keypoint* kps, const uint8_t* desc, const int* start, const int* idx, float minX, float minY,
+                        float invW, float invH, int nq, const float* qu, const float* qv, const float* qr, const int* qminL,
+                        const int* qmaxL, const uint8_t* qdesc, const uint8_t* qvalid, int cap, int* count, int* cand, hipStream_t s);
 void launch_pack_gather(const Buffers& b, int nf, int nPairs, uint8_t* block, size_t recBytes, hipStream_t s);
 void launch_hamming_pairs(const uint8_t* a, const uint8_t* b, const int* pairs, int n, int* dist, hipStream_t s);
 void launch_distinct_median(const uint8_t* desc, int n, int* median, hipStream_t s);

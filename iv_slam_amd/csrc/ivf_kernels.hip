@@ -1515,4 +1515,132 @@ void launch_pack_gather(const Buffers& b, int nf, int nPairs, uint8_t* block, si
     hipLaunchKernelGGL(k_pack_gather, dim3(nPairs), dim3(256), 0, s, b.count, b.kps, b.desc, b.uright, nf, (unsigned*)block, recBytes / 4);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Device-resident frame grid (Frame::AssignFeaturesToGrid / GetFeaturesInArea, ORB/src/Frame.cc:415-430, 615-680).
+// k_grid_build: ONE workgroup builds the 64x48 bucket grid of a frame in CSR form with the buckets in the reference's
+//   enumeration order (cell = ix * 48 + iy) and the keypoints of a bucket in insertion order (a stable counting sort:
+//   the rank of a keypoint inside its bucket = keypoints of the same bucket in earlier 256-blocks + earlier threads of
+//   its own block).  start: [64*48 + 1], idx: [n].
+// k_grid_window: one wave per query.  The buckets of one grid column are contiguous in `idx`, so the window is at most
+//   64 contiguous runs; every run is walked 64 candidates at a time: octave / |dx| < r / |dy| < r filters as the
+//   reference applies them (:636-664), Hamming distance of the survivors against the query descriptor, and an ordered,
+//   ballot-compacted append of (index, distance) to the query's candidate list (cap entries; count may exceed cap =
+//   overflow, the host then re-does that query through the pair path).
+// ------------------------------------------------------------------------------------------------
+constexpr int kGC = 64, kGR = 48;
+__global__ __launch_bounds__(256) void k_grid_build(const ivf_keypoint* __restrict__ kps, int n, float minX, float minY,
+                                                   float invW, float invH, int* __restrict__ start, int* __restrict__ idx)
+{
+    __shared__ int cnt[kGC * kGR];
+    __shared__ int part[256];
+    __shared__ int blk[256];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < kGC * kGR; c += 256) cnt[c] = 0;
+    __syncthreads();
+    auto cell_of = [&](int i) {
+        const int px = (int)roundf((kps[i].x - minX) * invW), py = (int)roundf((kps[i].y - minY) * invH);   // Frame::PosInGrid :672-673
+        return (px < 0 || px >= kGC || py < 0 || py >= kGR) ? -1 : px * kGR + py;
+    };
+    for (int i = tid; i < n; i += 256) { const int c = cell_of(i); if (c >= 0) atomicAdd(&cnt[c], 1); }
+    __syncthreads();
+    // exclusive prefix over the 3072 buckets: 12 per thread + a block scan of the partial sums
+    constexpr int PER = kGC * kGR / 256;
+    int local[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { local[k] = sum; sum += cnt[tid * PER + k]; }
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const int base = part[tid] - sum;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { start[tid * PER + k] = base + local[k]; cnt[tid * PER + k] = base + local[k]; }   // cnt becomes the fill cursor
+    if (tid == 255) start[kGC * kGR] = part[255];
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        const int c = i < n ? cell_of(i) : -1;
+        blk[tid] = c;
+        __syncthreads();
+        if (c >= 0) {
+            int before = 0;
+            for (int t = 0; t < tid; t++) before += blk[t] == c ? 1 : 0;
+            idx[cnt[c] + before] = i;
+        }
+        __syncthreads();
+        if (c >= 0) atomicAdd(&cnt[c], 1);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_grid_window(const ivf_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                    const int* __restrict__ start, const int* __restrict__ idx,
+                                                    float minX, float minY, float invW, float invH, int nq,
+                                                    const float* __restrict__ qu, const float* __restrict__ qv,
+                                                    const float* __restrict__ qr, const int* __restrict__ qminL,
+                                                    const int* __restrict__ qmaxL, const uint8_t* __restrict__ qdesc,
+                                                    const uint8_t* __restrict__ qvalid, int cap, int* __restrict__ count,
+                                                    int2* __restrict__ cand)
+{
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    int total = 0;
+    if (!qvalid || qvalid[q]) {
+        const float x = qu[q], y = qv[q], r = qr[q];
+        const int minL = qminL[q], maxL = qmaxL[q];
+        // Frame::GetFeaturesInArea :620-634
+        const int x0 = max(0, (int)floorf((x - minX - r) * invW)), x1 = min(kGC - 1, (int)ceilf((x - minX + r) * invW));
+        const int y0 = max(0, (int)floorf((y - minY - r) * invH)), y1 = min(kGR - 1, (int)ceilf((y - minY + r) * invH));
+        if (x0 < kGC && x1 >= 0 && y0 < kGR && y1 >= 0) {
+            const bool chk = (minL > 0) || (maxL >= 0);
+            const uint4* qd = (const uint4*)(qdesc + (size_t)q * 32);
+            const uint4 qa = qd[0], qb = qd[1];
+            for (int ix = x0; ix <= x1; ix++) {
+                const int s = start[ix * kGR + y0], e = start[ix * kGR + y1 + 1];      // buckets iy = y0..y1 are contiguous
+                for (int j0 = s; j0 < e; j0 += 64) {
+                    const int j = j0 + lane;
+                    bool ok = j < e;
+                    int i2 = 0, d = 0;
+                    if (ok) {
+                        i2 = idx[j];
+                        const ivf_keypoint kp = kps[i2];
+                        if (chk) { if (kp.octave < minL) ok = false; if (maxL >= 0 && kp.octave > maxL) ok = false; }
+                        if (!(fabsf(kp.x - x) < r && fabsf(kp.y - y) < r)) ok = false;
+                        if (ok) {
+                            const uint4* cd = (const uint4*)(desc + (size_t)i2 * 32);
+                            const uint4 a = cd[0], b2 = cd[1];
+                            d = __popc(a.x ^ qa.x) + __popc(a.y ^ qa.y) + __popc(a.z ^ qa.z) + __popc(a.w ^ qa.w) +
+                                __popc(b2.x ^ qb.x) + __popc(b2.y ^ qb.y) + __popc(b2.z ^ qb.z) + __popc(b2.w ^ qb.w);
+                        }
+                    }
+                    const unsigned long long m = __ballot(ok);
+                    if (ok) {
+                        const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
+                        if (pos < cap) cand[(size_t)q * cap + pos] = make_int2(i2, d);
+                    }
+                    total += __popcll(m);
+                }
+            }
+        }
+    }
+    if (lane == 0) count[q] = total;
+}
+
+void launch_grid_build(const ivf_keypoint* kps, int n, float minX, float minY, float invW, float invH, int* start, int* idx, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, s, kps, n, minX, minY, invW, invH, start, idx);
+}
+void launch_grid_window(const ivf_keypoint* kps, const uint8_t* desc, const int* start, const int* idx, float minX, float minY,
+                        float invW, float invH, int nq, const float* qu, const float* qv, const float* qr, const int* qminL,
+                        const int* qmaxL, const uint8_t* qdesc, const uint8_t* qvalid, int cap, int* count, int* cand, hipStream_t s)
+{
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_grid_window, dim3((nq + 3) / 4), dim3(256), 0, s, kps, desc, start, idx, minX, minY, invW, invH, nq, qu, qv,
+                       qr, qminL, qmaxL, qdesc, qvalid, cap, count, (int2*)cand);
+}
+
 }  // namespace ivf

@@ -380,3 +380,41 @@ class ORBVocabulary:
         bow = {int(bw[k]): float(bv[k]) for k in range(nb.value)}
         fv = {int(fn[k]): [int(x) for x in fi[fs[k]:fs[k + 1]]] for k in range(nf.value)}
         return bow, fv
+
+
+class DeviceFrame:
+    """A frame whose mvKeysUn / mDescriptors / mGrid live on the device (Frame::AssignFeaturesToGrid, ORB/src/Frame.cc:415-430):
+    SearchByProjection against it runs the windows and distances on the GPU, the greedy replay on the host."""
+
+    def __init__(self, kps, desc, uright, bounds, device_id=0):
+        self._lib = _lib.load()
+        k = np.ascontiguousarray(kps, KP_DTYPE); d = np.ascontiguousarray(desc, np.uint8); u = np.ascontiguousarray(uright, np.float32)
+        self.n = len(k)
+        h = C.c_void_p(); bd = Bounds(*bounds)
+        check(self._lib.ivf_frame_create(ptr(k), ptr(d), ptr(u), self.n, C.byref(bd), device_id, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.ivf_frame_destroy(self._h)
+            self._h = None
+
+    def grid(self):
+        """(cell_start [64*48+1], cell_index [n]) as built on the device; cell = ix*48 + iy."""
+        st = np.zeros(64 * 48 + 1, np.int32); ix = np.zeros(max(self.n, 1), np.int32)
+        check(self._lib.ivf_frame_grid(self._h, ptr(st), ptr(ix)))
+        return st, ix[:self.n]
+
+    def SearchByProjection(self, q, check_orientation=True, cur_assign=None):
+        """Same queries and results as ORBmatcher.SearchByProjection(cur_kps, cur_desc, cur_uright, bounds, q)."""
+        n_q = len(q["u"])
+        assign = np.full(self.n, -1, np.int32) if cur_assign is None else np.ascontiguousarray(cur_assign, np.int32).copy()
+        types = dict(u=np.float32, v=np.float32, ur=np.float32, radius=np.float32, min_level=np.int32,
+                     max_level=np.int32, angle=np.float32, desc=np.uint8, valid=np.uint8, blocks=np.uint8)
+        qq = {k: np.ascontiguousarray(q[k], t) for k, t in types.items()}
+        nm = C.c_int(0)
+        check(self._lib.ivf_frame_search_by_projection(self._h, n_q, ptr(qq["u"]), ptr(qq["v"]), ptr(qq["ur"]), ptr(qq["radius"]),
+                                                       ptr(qq["min_level"]), ptr(qq["max_level"]), ptr(qq["angle"]), ptr(qq["desc"]),
+                                                       ptr(qq["valid"]), ptr(qq["blocks"]), int(bool(check_orientation)), ptr(assign),
+                                                       C.byref(nm)))
+        return assign, nm.value

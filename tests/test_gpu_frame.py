@@ -1,0 +1,111 @@
+"""Device-resident frame: the 64x48 grid built on the device and SearchByProjection against it,
+vs the oracle's AssignFeaturesToGrid / GetFeaturesInArea / SearchByProjection restatement."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from iv_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _case(iv, seed, n, w=640, h=240, radius=7.0, big=False):
+    rng = np.random.default_rng(seed)
+    img = synth.make_left(w, h, seed=seed, idx=1)
+    g = iv.ORBextractor(n, 1.2, 8, 20, 7)
+    kps, desc = g(img)
+    nq = len(kps)
+    qd = desc.copy()
+    for i in range(nq):
+        for bpos in rng.integers(0, 256, 5):
+            qd[i, bpos // 8] ^= np.uint8(1 << (bpos % 8))
+    oct_ = kps["octave"]; sc = g.GetScaleFactors()
+    q = dict(u=kps["x"] + rng.uniform(-3, 3, nq).astype(np.float32), v=kps["y"] + rng.uniform(-3, 3, nq).astype(np.float32),
+             ur=(kps["x"] - 20).astype(np.float32), radius=(radius * sc[oct_]).astype(np.float32),
+             min_level=(oct_ - 1).astype(np.int32) if not big else np.full(nq, -1, np.int32),
+             max_level=(oct_ + 1).astype(np.int32) if not big else np.full(nq, -1, np.int32),
+             angle=(kps["angle"] + rng.choice([0, 0, 0, 90], nq)).astype(np.float32) % 360, desc=qd,
+             valid=(rng.uniform(size=nq) > 0.1).astype(np.uint8), blocks=(rng.uniform(size=nq) > 0.2).astype(np.uint8))
+    q["u"][:3] = [-50.0, w + 80.0, 5.0]; q["v"][:3] = [10.0, 20.0, -40.0]          # windows partly / fully off the grid
+    uright = np.where(rng.uniform(size=nq) > 0.5, kps["x"] - 20 + rng.uniform(-10, 10, nq), -1).astype(np.float32)
+    pre = np.full(nq, -1, np.int32); pre[rng.integers(0, nq, 20)] = -2
+    return kps, desc, uright, (0.0, 0.0, float(w), float(h)), q, pre
+
+
+def _np_grid(kps, bounds):
+    """AssignFeaturesToGrid (Frame.cc:415-430) in numpy: stable by (cell, insertion index)"""
+    iw = np.float32(64) / np.float32(bounds[2] - bounds[0]); ih = np.float32(48) / np.float32(bounds[3] - bounds[1])
+    fx = (kps["x"] - np.float32(bounds[0])) * iw; fy = (kps["y"] - np.float32(bounds[1])) * ih
+    rnd = lambda v: np.where(v >= 0, np.floor(v + np.float32(0.5)), np.ceil(v - np.float32(0.5))).astype(np.int64)     # C round()
+    px = rnd(fx); py = rnd(fy)
+    ok = (px >= 0) & (px < 64) & (py >= 0) & (py < 48)
+    cell = np.where(ok, px * 48 + py, -1)
+    order = [i for i in np.argsort(cell, kind="stable") if cell[i] >= 0]
+    start = np.zeros(64 * 48 + 1, np.int64)
+    for c in cell[ok]:
+        start[c + 1] += 1
+    return np.cumsum(start), np.asarray(order, np.int64)
+
+
+def test_grid_built_on_device(iv):
+    for seed, n in ((5, 500), (6, 3000)):
+        kps, desc, uright, bounds, q, pre = _case(iv, seed, n, 1242 if n > 1000 else 640, 375 if n > 1000 else 240)
+        f = iv.DeviceFrame(kps, desc, uright, bounds)
+        st, ix = f.grid()
+        es, ei = _np_grid(kps, bounds)
+        assert np.array_equal(st, es) and np.array_equal(ix, ei)
+    # empty frame
+    f = iv.DeviceFrame(kps[:0], desc[:0], uright[:0], bounds)
+    st, ix = f.grid()
+    assert not st.any() and len(ix) == 0
+
+
+def test_search_by_projection_on_resident_frame(iv):
+    m = iv.ORBmatcher(0.9, True)
+    for seed, n, radius, big in ((11, 500, 7.0, False), (12, 1500, 15.0, False), (13, 800, 40.0, True)):
+        kps, desc, uright, bounds, q, pre = _case(iv, seed, n, radius=radius, big=big)
+        f = iv.DeviceFrame(kps, desc, uright, bounds)
+        for chk in (True, False):
+            ga, gn = f.SearchByProjection(q, chk, pre)
+            oa, on = O.search_by_projection(kps, desc, uright, bounds, q, chk, pre)
+            assert gn == on and np.array_equal(ga, oa), (seed, chk)
+        ha, hn = m.SearchByProjection(kps, desc, uright, bounds, q, pre)           # the host-grid entry point agrees too
+        ga, gn = f.SearchByProjection(q, True, pre)
+        assert hn == gn and np.array_equal(ha, ga)
+
+
+_OVERFLOW = r"""
+import sys, os
+sys.path.insert(0, os.path.join(%r, "tests")); sys.path.insert(0, %r)
+import numpy as np
+import iv_slam_amd as iv
+import oracle_lib as O
+import test_gpu_frame as T
+kps, desc, uright, bounds, q, pre = T._case(iv, 13, 800, radius=40.0, big=True)
+f = iv.DeviceFrame(kps, desc, uright, bounds)
+ga, gn = f.SearchByProjection(q, True, pre)
+oa, on = O.search_by_projection(kps, desc, uright, bounds, q, True, pre)
+assert gn == on and np.array_equal(ga, oa)
+print("OK")
+"""
+
+
+def test_window_list_overflow_falls_back_per_query():
+    """A window with more candidates than the device-side list holds is redone through the host grid for that query only:
+    force it with a list capacity of 4."""
+    e = dict(os.environ, IVF_FRAME_WINDOW_CAP="4")
+    r = subprocess.run([sys.executable, "-c", _OVERFLOW % (ROOT, ROOT)], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.fixture(scope="module")
+def iv():
+    import iv_slam_amd
+    lib = iv_slam_amd.load()
+    assert lib.ivf_device_count() >= 1, "no HIP device: libivfront has no CPU fallback"
+    return iv_slam_amd
