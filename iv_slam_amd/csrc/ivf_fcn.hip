@@ -113,6 +113,125 @@ __global__ __launch_bounds__(256) void k_fcn_conv0(const float* __restrict__ X, 
     }
 }
 
+// ---- stem: features[0] (conv 3x3 s2, 3 -> 32, BN, ReLU6) fused with block 1's depthwise 3x3 (+ BN + ReLU6) ----
+// The 32 x 256 x 256 map between the two layers (8.4 MB per image, written and read back: the largest round trip of the
+// 256x256 stage) stays in LDS.  One workgroup = a 32 x 8 output tile, all 32 channels:
+//   1. the 69 x 21 x 3 input window goes to LDS (zero outside the 512 x 512 image = the conv's padding);
+//   2. features[0] on the 34 x 10 positions the depthwise layer reads (1.33x recompute for the halo), one work item =
+//      one position x 8 output channels, results (zero outside the 256 x 256 map = the depthwise padding) to LDS;
+//   3. the depthwise stencil: thread = channel (tid >> 3) x 4 adjacent pixels ((tid & 7) * 4), rolling down the 8 rows.
+constexpr int kStemTW = 32, kStemTH = 8, kStemCW = kStemTW + 2, kStemCH = kStemTH + 2;          // conv0 positions per tile
+constexpr int kStemIW = 2 * kStemCW + 1, kStemIH = 2 * kStemCH + 1, kStemIP = 76;                // input window 69 x 21; LDS rows hold 72 floats from x = 2*ox0 - 4 (16-byte aligned), pitch 76
+constexpr int kStemCP = kStemCW * kStemCH + 4;                                                   // floats per channel plane in LDS
+__global__ __launch_bounds__(256, 2) void k_fcn_stem(const float* __restrict__ X, const float* __restrict__ W0,
+                                                 const float* __restrict__ s0, const float* __restrict__ b0,
+                                                 const float* __restrict__ Wd, const float* __restrict__ sd,
+                                                 const float* __restrict__ bd, float* __restrict__ Y)
+{
+    constexpr int O = kEnc / 2;
+    __shared__ __attribute__((aligned(16))) float sIn[3 * kStemIH * kStemIP];
+    __shared__ __attribute__((aligned(16))) float sC[32 * kStemCP];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int ox0 = blockIdx.x * kStemTW, oy0 = blockIdx.y * kStemTH;
+    const int cx0 = ox0 - 1, cy0 = oy0 - 1;                     // first conv0 position of the tile
+    const int ix0 = 2 * cx0 - 1, iy0 = 2 * cy0 - 1;             // first input pixel
+    const float* Xb = X + (size_t)b * 3 * kEnc * kEnc;
+    {   // aligned float4 loads, all of a thread's loads in flight before the first LDS store
+        constexpr int Q4 = 18, N4 = 3 * kStemIH * Q4, IT = (N4 + 255) / 256;
+        float4 v4[IT]; bool ok[IT];
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const int i = min(tid + 256 * k, N4 - 1);
+            const int c = i / (kStemIH * Q4), r = (i / Q4) % kStemIH, q4 = i % Q4;
+            const int yy = iy0 + r, xx = 2 * ox0 - 4 + 4 * q4;
+            ok[k] = yy >= 0 && yy < kEnc && xx >= 0 && xx < kEnc;
+            v4[k] = *(const float4*)(Xb + ((size_t)c * kEnc + (ok[k] ? yy : 0)) * kEnc + (ok[k] ? xx : 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const int i = tid + 256 * k;
+            if (i < N4) {
+                const int c = i / (kStemIH * Q4), r = (i / Q4) % kStemIH, q4 = i % Q4;
+                *(float4*)&sIn[(c * kStemIH + r) * kStemIP + 4 * q4] = ok[k] ? v4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    __syncthreads();
+    // 2. conv0: wave w computes channels 8w .. 8w+7 at every position (lane = position), so the weights, BN scale and
+    //    shift are wave-uniform and come through the scalar cache as SGPR operands of the FMAs
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    {
+        // the 27 inputs of each of the lane's (up to) 6 positions are read from LDS once and stay in registers; the
+        // channel loop then needs one batch of scalar loads per channel for 6 x 27 FMAs
+        constexpr int NP = (kStemCW * kStemCH + 63) / 64;
+        float v[NP][27];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const int p = min(lane + 64 * i, kStemCW * kStemCH - 1);
+            const int py = p / kStemCW, px = p % kStemCW;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++)
+                        v[i][(c * 3 + ky) * 3 + kx] = sIn[(c * kStemIH + 2 * py + ky) * kStemIP + 2 * px + kx + 1];   // window column q = LDS column q + 1
+        }
+#pragma unroll 2
+        for (int j = 0; j < 8; j++) {
+            const int co = wv * 8 + j;
+            const float* w = W0 + co * 27;
+            float wr[27];
+#pragma unroll
+            for (int k = 0; k < 27; k++) wr[k] = w[k];
+            const float sc = s0[co], sh = b0[co];
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                const int p = lane + 64 * i;
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 27; k++) acc = __builtin_fmaf(wr[k], v[i][k], acc);
+                const float r = __builtin_amdgcn_fmed3f(__builtin_fmaf(acc, sc, sh), 0.f, 6.f);
+                if (p < kStemCW * kStemCH) {
+                    const int py = p / kStemCW, px = p % kStemCW;
+                    const bool inside = (unsigned)(cy0 + py) < (unsigned)O && (unsigned)(cx0 + px) < (unsigned)O;
+                    sC[co * kStemCP + p] = inside ? r : 0.f;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // 3. depthwise 3x3 + BN + ReLU6
+    const int c = tid >> 3, x4 = (tid & 7) * 4;
+    float wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) wk[k] = Wd[c * 9 + k];
+    const float dsc = sd[c], dsh = bd[c];
+    const float* plane = sC + c * kStemCP + x4;                 // conv0 position (row r, col x4 + k) = tile pixel (r - 1, x4 + k - 1)
+    float win[3][6];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int k = 0; k < 6; k++) win[r][k] = plane[r * kStemCW + k];
+    float* out = Y + (((size_t)b * 32 + c) * O + oy0) * O + ox0 + x4;
+#pragma unroll
+    for (int y = 0; y < kStemTH; y++) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) win[(y + 2) % 3][k] = plane[(y + 2) * kStemCW + k];
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+                for (int p = 0; p < 4; p++) o[p] = __builtin_fmaf(wk[ky * 3 + kx], win[(y + ky) % 3][p + kx], o[p]);
+#pragma unroll
+        for (int p = 0; p < 4; p++) o[p] = __builtin_amdgcn_fmed3f(__builtin_fmaf(o[p], dsc, dsh), 0.f, 6.f);
+        *(float4*)(out + (size_t)y * O) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // ---- depthwise 3x3 (stride s, dilation d, pad d) + BN + ReLU6 (mobilenet.py:46,54; models_light.py:139-152) ----
 // HBM-bound stencil.  One workgroup = one 64 x TH output tile of one channel plane (TH = 64 when the plane is 64 rows,
 // else 16): the input window ((TH-1)*s + 2d + 1) x ((64-1)*s + 2d + 1) is staged in LDS once (zero padding materialised there), every
@@ -1397,8 +1516,18 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
     char nm[64];
     hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc, n), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn);
     STAGE("prep");
-    hipLaunchKernelGGL(k_fcn_conv0, dim3(1, kEnc / 2, n), dim3(256), 0, s, f->bufIn, f->dConv0W, f->dConv0S, f->dConv0B, f->bufA);
-    STAGE("conv0");
+    // conv0 + block 1's depthwise layer in one kernel, unless an experiment switch asks for another kernel on block 1
+    static const bool stem = getenv("IVF_FCN_NOSTEM") == nullptr && getenv("IVF_FCN_WIDE256") == nullptr && getenv("IVF_FCN_NOFUSE") == nullptr &&
+                             !(getenv("IVF_FCN_BLOCKMASK") && (strtoul(getenv("IVF_FCN_BLOCKMASK"), nullptr, 0) & 1));
+    if (stem) {
+        const Dw& d0 = f->dw[0];
+        hipLaunchKernelGGL(k_fcn_stem, dim3(kEnc / 2 / kStemTW, kEnc / 2 / kStemTH, n), dim3(256), 0, s, f->bufIn, f->dConv0W, f->dConv0S,
+                           f->dConv0B, d0.dW, d0.dScale, d0.dShift, f->bufH2);
+        STAGE("stem (conv0 + block 1 depthwise)");
+    } else {
+        hipLaunchKernelGGL(k_fcn_conv0, dim3(1, kEnc / 2, n), dim3(256), 0, s, f->bufIn, f->dConv0W, f->dConv0S, f->dConv0B, f->bufA);
+        STAGE("conv0");
+    }
     float *x = f->bufA, *y = f->bufB;
     int H = kEnc / 2, W = kEnc / 2;
     size_t ip = 0, id = 0;
@@ -1406,6 +1535,13 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
         const Block& bk = kBlocks[i];
         const int hid = bk.inp * bk.t;
         const float* h = x;
+        if (i == 0 && stem) {                       // block 1 (t = 1, stride 1, no residual): its depthwise output is already in bufH2
+            id++;
+            launch_gemm(f->pw[ip++], f->bufH2, nullptr, y, H, W, n, s);
+            STAGE("block 1 project");
+            std::swap(x, y);
+            continue;
+        }
         {
             const Gemm* ex = bk.t != 1 ? &f->pw[ip] : nullptr;
             const Gemm& pj = f->pw[ip + (bk.t != 1 ? 1 : 0)];

@@ -113,7 +113,8 @@ print("OK %.3g" % err)
     {"IVF_FCN_WIDE256": "1"},
     # stride-2 blocks layer by layer (the default fuses their depthwise + projection)
     {"IVF_FCN_NOSTRIDE2": "1"},
-], ids=["default", "layerwise", "all-blocks-fused", "expand-pxt2", "dwpw-256", "no-stride2-fusion"])
+    {"IVF_FCN_NOSTEM": "1"},
+], ids=["default", "layerwise", "all-blocks-fused", "expand-pxt2", "dwpw-256", "no-stride2-fusion", "no-stem-fusion"])
 def test_fcn_kernel_variants_match_goldens_and_are_deterministic(env):
     """The FCN picks between several kernels per layer (measured defaults, env overrides for tuning).  Every variant must
     meet the same bar, batch results must not depend on the batch slot, and repeated runs must be bit-identical (this is
