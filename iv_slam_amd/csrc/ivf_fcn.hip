@@ -123,25 +123,26 @@ __global__ __launch_bounds__(256) void k_fcn_conv0(const float* __restrict__ X, 
 constexpr int kStemTW = 32, kStemTH = 8, kStemCW = kStemTW + 2, kStemCH = kStemTH + 2;          // conv0 positions per tile
 constexpr int kStemIW = 2 * kStemCW + 1, kStemIH = 2 * kStemCH + 1, kStemIP = 76;                // input window 69 x 21; LDS rows hold 72 floats from x = 2*ox0 - 4 (16-byte aligned), pitch 76
 constexpr int kStemCP = kStemCW * kStemCH + 4;                                                   // floats per channel plane in LDS
-__global__ __launch_bounds__(256, 2) void k_fcn_stem(const float* __restrict__ X, const float* __restrict__ W0,
+__global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X, const float* __restrict__ W0,
                                                  const float* __restrict__ s0, const float* __restrict__ b0,
                                                  const float* __restrict__ Wd, const float* __restrict__ sd,
-                                                 const float* __restrict__ bd, float* __restrict__ Y)
+                                                 const float* __restrict__ bd, const float* __restrict__ Wp,
+                                                 const float* __restrict__ sp, const float* __restrict__ bp, float* __restrict__ Y)
 {
-    constexpr int O = kEnc / 2;
+    constexpr int O = kEnc / 2, NT = 512;
     __shared__ __attribute__((aligned(16))) float sIn[3 * kStemIH * kStemIP];
     __shared__ __attribute__((aligned(16))) float sC[32 * kStemCP];
     const int tid = threadIdx.x, b = blockIdx.z;
     const int ox0 = blockIdx.x * kStemTW, oy0 = blockIdx.y * kStemTH;
     const int cx0 = ox0 - 1, cy0 = oy0 - 1;                     // first conv0 position of the tile
-    const int ix0 = 2 * cx0 - 1, iy0 = 2 * cy0 - 1;             // first input pixel
+    const int iy0 = 2 * cy0 - 1;                                // first input row (first input column: 2 * cx0 - 1 = LDS column 1)
     const float* Xb = X + (size_t)b * 3 * kEnc * kEnc;
-    {   // aligned float4 loads, all of a thread's loads in flight before the first LDS store
-        constexpr int Q4 = 18, N4 = 3 * kStemIH * Q4, IT = (N4 + 255) / 256;
+    {   // 1. aligned float4 loads, all of a thread's loads in flight before the first LDS store
+        constexpr int Q4 = 18, N4 = 3 * kStemIH * Q4, IT = (N4 + NT - 1) / NT;
         float4 v4[IT]; bool ok[IT];
 #pragma unroll
         for (int k = 0; k < IT; k++) {
-            const int i = min(tid + 256 * k, N4 - 1);
+            const int i = min(tid + NT * k, N4 - 1);
             const int c = i / (kStemIH * Q4), r = (i / Q4) % kStemIH, q4 = i % Q4;
             const int yy = iy0 + r, xx = 2 * ox0 - 4 + 4 * q4;
             ok[k] = yy >= 0 && yy < kEnc && xx >= 0 && xx < kEnc;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_stem(const float* __restrict__ X
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < IT; k++) {
-            const int i = tid + 256 * k;
+            const int i = tid + NT * k;
             if (i < N4) {
                 const int c = i / (kStemIH * Q4), r = (i / Q4) % kStemIH, q4 = i % Q4;
                 *(float4*)&sIn[(c * kStemIH + r) * kStemIP + 4 * q4] = ok[k] ? v4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -158,17 +159,17 @@ __global__ __launch_bounds__(256, 2) void k_fcn_stem(const float* __restrict__ X
         }
     }
     __syncthreads();
-    // 2. conv0: wave w computes channels 8w .. 8w+7 at every position (lane = position), so the weights, BN scale and
-    //    shift are wave-uniform and come through the scalar cache as SGPR operands of the FMAs
+    // 2. conv0: wave w computes channels 8(w&3) .. 8(w&3)+7 on half (w>>2) of the positions (lane = position), so the
+    //    weights, BN scale and shift are wave-uniform and come through the scalar cache as SGPR operands of the FMAs; the
+    //    27 inputs of a lane's (up to) 3 positions are read from LDS once and stay in registers across the channel loop
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     {
-        // the 27 inputs of each of the lane's (up to) 6 positions are read from LDS once and stay in registers; the
-        // channel loop then needs one batch of scalar loads per channel for 6 x 27 FMAs
-        constexpr int NP = (kStemCW * kStemCH + 63) / 64;
+        constexpr int HALF = kStemCW * kStemCH / 2, NP = (HALF + 63) / 64;
+        const int p0 = (wv >> 2) * HALF, cg = wv & 3;
         float v[NP][27];
 #pragma unroll
         for (int i = 0; i < NP; i++) {
-            const int p = min(lane + 64 * i, kStemCW * kStemCH - 1);
+            const int p = p0 + min(lane + 64 * i, HALF - 1);
             const int py = p / kStemCW, px = p % kStemCW;
 #pragma unroll
             for (int c = 0; c < 3; c++)
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_stem(const float* __restrict__ X
         }
 #pragma unroll 2
         for (int j = 0; j < 8; j++) {
-            const int co = wv * 8 + j;
+            const int co = cg * 8 + j;
             const float* w = W0 + co * 27;
             float wr[27];
 #pragma unroll
@@ -188,12 +189,12 @@ __global__ __launch_bounds__(256, 2) void k_fcn_stem(const float* __restrict__ X
             const float sc = s0[co], sh = b0[co];
 #pragma unroll
             for (int i = 0; i < NP; i++) {
-                const int p = lane + 64 * i;
                 float acc = 0.f;
 #pragma unroll
                 for (int k = 0; k < 27; k++) acc = __builtin_fmaf(wr[k], v[i][k], acc);
                 const float r = __builtin_amdgcn_fmed3f(__builtin_fmaf(acc, sc, sh), 0.f, 6.f);
-                if (p < kStemCW * kStemCH) {
+                if (lane + 64 * i < HALF) {
+                    const int p = p0 + lane + 64 * i;
                     const int py = p / kStemCW, px = p % kStemCW;
                     const bool inside = (unsigned)(cy0 + py) < (unsigned)O && (unsigned)(cx0 + px) < (unsigned)O;
                     sC[co * kStemCP + p] = inside ? r : 0.f;
@@ -202,33 +203,70 @@ __global__ __launch_bounds__(256, 2) void k_fcn_stem(const float* __restrict__ X
         }
     }
     __syncthreads();
-    // 3. depthwise 3x3 + BN + ReLU6
-    const int c = tid >> 3, x4 = (tid & 7) * 4;
-    float wk[9];
+    // 3. depthwise 3x3 + BN + ReLU6: thread = channel x 4 adjacent pixels x 4 rows, rolling window down the rows.  The
+    //    results return to LDS in place (plane rows 0..7, columns 0..31) once every thread has finished reading
+    {
+        const int c = tid >> 4, x4 = (tid & 7) * 4, r0 = ((tid >> 3) & 1) * (kStemTH / 2);
+        float wk[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) wk[k] = Wd[c * 9 + k];
-    const float dsc = sd[c], dsh = bd[c];
-    const float* plane = sC + c * kStemCP + x4;                 // conv0 position (row r, col x4 + k) = tile pixel (r - 1, x4 + k - 1)
-    float win[3][6];
+        for (int k = 0; k < 9; k++) wk[k] = Wd[c * 9 + k];
+        const float dsc = sd[c], dsh = bd[c];
+        const float* plane = sC + c * kStemCP + r0 * kStemCW + x4;      // conv0 position (row r, col x4 + k) = tile pixel (r - 1, x4 + k - 1)
+        float win[3][6], o[kStemTH / 2][4];
 #pragma unroll
-    for (int r = 0; r < 2; r++)
+        for (int r = 0; r < 2; r++)
 #pragma unroll
-        for (int k = 0; k < 6; k++) win[r][k] = plane[r * kStemCW + k];
-    float* out = Y + (((size_t)b * 32 + c) * O + oy0) * O + ox0 + x4;
+            for (int k = 0; k < 6; k++) win[r][k] = plane[r * kStemCW + k];
 #pragma unroll
-    for (int y = 0; y < kStemTH; y++) {
+        for (int y = 0; y < kStemTH / 2; y++) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) win[(y + 2) % 3][k] = plane[(y + 2) * kStemCW + k];
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < 6; k++) win[(y + 2) % 3][k] = plane[(y + 2) * kStemCW + k];
 #pragma unroll
-        for (int ky = 0; ky < 3; ky++)
+            for (int p = 0; p < 4; p++) o[y][p] = 0.f;
 #pragma unroll
-            for (int kx = 0; kx < 3; kx++)
+            for (int ky = 0; ky < 3; ky++)
 #pragma unroll
-                for (int p = 0; p < 4; p++) o[p] = __builtin_fmaf(wk[ky * 3 + kx], win[(y + ky) % 3][p + kx], o[p]);
+                for (int kx = 0; kx < 3; kx++)
 #pragma unroll
-        for (int p = 0; p < 4; p++) o[p] = __builtin_amdgcn_fmed3f(__builtin_fmaf(o[p], dsc, dsh), 0.f, 6.f);
-        *(float4*)(out + (size_t)y * O) = make_float4(o[0], o[1], o[2], o[3]);
+                    for (int p = 0; p < 4; p++) o[y][p] = __builtin_fmaf(wk[ky * 3 + kx], win[(y + ky) % 3][p + kx], o[y][p]);
+        }
+        __syncthreads();
+        float* dwo = sC + c * kStemCP + r0 * kStemCW + x4;
+#pragma unroll
+        for (int y = 0; y < kStemTH / 2; y++)
+#pragma unroll
+            for (int p = 0; p < 4; p++) dwo[y * kStemCW + p] = __builtin_amdgcn_fmed3f(__builtin_fmaf(o[y][p], dsc, dsh), 0.f, 6.f);
+    }
+    __syncthreads();
+    // 4. block 1's projection 32 -> 16 + BN (no activation, no residual): lane = pixel (4 x 64 per tile), wave w = output
+    //    channels 2w, 2w+1; a pixel's 32 hidden values are read from LDS once per pair of channels
+#pragma unroll 1
+    for (int i0 = 0; i0 < 4; i0 += 2) {
+        float hv[2][32];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int p = lane + 64 * (i0 + i);
+            const float* src = sC + (p >> 5) * kStemCW + (p & 31);
+#pragma unroll
+            for (int k = 0; k < 32; k++) hv[i][k] = src[k * kStemCP];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int co = wv * 2 + j;
+            const float* w = Wp + co * 32;
+            float wr[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) wr[k] = w[k];
+            const float sc = sp[co], sh = bp[co];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int p = lane + 64 * (i0 + i);
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 32; k++) acc = __builtin_fmaf(wr[k], hv[i][k], acc);
+                Y[(((size_t)b * 16 + co) * O + oy0 + (p >> 5)) * O + ox0 + (p & 31)] = __builtin_fmaf(acc, sc, sh);
+            }
+        }
     }
 }
 
@@ -1433,6 +1471,7 @@ using namespace ivffcn;
 struct ivf_fcn {
     int device = 0, inW = 0, inH = 0, outW = 0, outH = 0, maxBatch = 0;
     float *dConv0W = nullptr, *dConv0S = nullptr, *dConv0B = nullptr;
+    float* dProj0W = nullptr;   // block 1's 16 x 32 projection in f32 (k_fcn_stem)
     std::vector<Gemm> pw;        // in forward order: per block expand (t>1), project; then decoder cbr
     std::vector<Dw> dw;
     float* dLastW = nullptr; float lastBias = 0.f;
@@ -1521,9 +1560,9 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
                              !(getenv("IVF_FCN_BLOCKMASK") && (strtoul(getenv("IVF_FCN_BLOCKMASK"), nullptr, 0) & 1));
     if (stem) {
         const Dw& d0 = f->dw[0];
-        hipLaunchKernelGGL(k_fcn_stem, dim3(kEnc / 2 / kStemTW, kEnc / 2 / kStemTH, n), dim3(256), 0, s, f->bufIn, f->dConv0W, f->dConv0S,
-                           f->dConv0B, d0.dW, d0.dScale, d0.dShift, f->bufH2);
-        STAGE("stem (conv0 + block 1 depthwise)");
+        hipLaunchKernelGGL(k_fcn_stem, dim3(kEnc / 2 / kStemTW, kEnc / 2 / kStemTH, n), dim3(512), 0, s, f->bufIn, f->dConv0W, f->dConv0S,
+                           f->dConv0B, d0.dW, d0.dScale, d0.dShift, f->dProj0W, f->pw[0].dScale, f->pw[0].dShift, f->bufB);
+        STAGE("stem (conv0 + block 1)");
     } else {
         hipLaunchKernelGGL(k_fcn_conv0, dim3(1, kEnc / 2, n), dim3(256), 0, s, f->bufIn, f->dConv0W, f->dConv0S, f->dConv0B, f->bufA);
         STAGE("conv0");
@@ -1535,10 +1574,8 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
         const Block& bk = kBlocks[i];
         const int hid = bk.inp * bk.t;
         const float* h = x;
-        if (i == 0 && stem) {                       // block 1 (t = 1, stride 1, no residual): its depthwise output is already in bufH2
-            id++;
-            launch_gemm(f->pw[ip++], f->bufH2, nullptr, y, H, W, n, s);
-            STAGE("block 1 project");
+        if (i == 0 && stem) {                       // block 1 (t = 1, stride 1, no residual) ran inside the stem kernel: its output is in y
+            id++; ip++;
             std::swap(x, y);
             continue;
         }
@@ -1659,6 +1696,10 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
             const float* w = rd.take((size_t)bk.oup * hid);
             if (!w || !read_bn(bk.oup)) return bad();
             Gemm g; if ((rc = make_gemm(f, w, bk.oup, hid, 1, sc, sh, 0, g))) { ivf_fcn_destroy(f); return rc; }
+            if (i == 0) {
+                std::vector<float> pw0(w, w + (size_t)bk.oup * hid);
+                if ((rc = upload(f, pw0, &f->dProj0W))) { ivf_fcn_destroy(f); return rc; }
+            }
             f->pw.push_back(g);
         }
     }
