@@ -159,45 +159,53 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
         }
     }
     __syncthreads();
-    // 2. conv0: wave w computes channels 8(w&3) .. 8(w&3)+7 on half (w>>2) of the positions (lane = position), so the
-    //    weights, BN scale and shift are wave-uniform and come through the scalar cache as SGPR operands of the FMAs; the
-    //    27 inputs of a lane's (up to) 3 positions are read from LDS once and stay in registers across the channel loop
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    // 2. conv0 as an MFMA GEMM (split-f16, f32 accumulate like every other convolution here): M = 32 output channels,
+    //    K = 27 taps padded to 32 (two K steps), N = the 340 positions in tiles of 32; wave w takes tiles w and w + 8.
+    //    The B operand is gathered straight from the LDS window (lane = position, 8 consecutive taps per K step and
+    //    lane half); the C/D layout (lane = position, registers = channels) is what the LDS planes want.
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, hh = lane >> 5, col = lane & 31;
     {
-        constexpr int HALF = kStemCW * kStemCH / 2, NP = (HALF + 63) / 64;
-        const int p0 = (wv >> 2) * HALF, cg = wv & 3;
-        float v[NP][27];
+        auto tap_off = [](int k) { return k < 27 ? ((k / 9) * kStemIH + (k / 3) % 3) * kStemIP + k % 3 : 0; };
+        HFrag ah[2], al[2];
 #pragma unroll
-        for (int i = 0; i < NP; i++) {
-            const int p = p0 + min(lane + 64 * i, HALF - 1);
-            const int py = p / kStemCW, px = p % kStemCW;
+        for (int st = 0; st < 2; st++)
 #pragma unroll
-            for (int c = 0; c < 3; c++)
+            for (int jj = 0; jj < 4; jj++) {
+                const int k0 = 16 * st + 8 * hh + 2 * jj;
+                const float w0 = k0 < 27 ? W0[col * 27 + k0] : 0.f, w1 = k0 + 1 < 27 ? W0[col * 27 + k0 + 1] : 0.f;
+                split_pair(w0, w1, ah[st].u[jj], al[st].u[jj]);
+            }
+        float sc[16], sh[16];
 #pragma unroll
-                for (int ky = 0; ky < 3; ky++)
+        for (int r = 0; r < 16; r++) { const int ch = (r & 3) + 8 * (r >> 2) + 4 * hh; sc[r] = s0[ch]; sh[r] = b0[ch]; }
+        constexpr int NPOS = kStemCW * kStemCH, NTILE = (NPOS + 31) / 32;
+        for (int t = wv; t < NTILE; t += 8) {
+            const int p = 32 * t + col, pc = min(p, NPOS - 1);
+            const int py = pc / kStemCW, px = pc % kStemCW;
+            const float* base = sIn + 2 * py * kStemIP + 2 * px + 1;         // window column q = LDS column q + 1
+            f32x16 acc;
 #pragma unroll
-                    for (int kx = 0; kx < 3; kx++)
-                        v[i][(c * 3 + ky) * 3 + kx] = sIn[(c * kStemIH + 2 * py + ky) * kStemIP + 2 * px + kx + 1];   // window column q = LDS column q + 1
-        }
-#pragma unroll 2
-        for (int j = 0; j < 8; j++) {
-            const int co = cg * 8 + j;
-            const float* w = W0 + co * 27;
-            float wr[27];
+            for (int q = 0; q < 16; q++) acc[q] = 0.f;
 #pragma unroll
-            for (int k = 0; k < 27; k++) wr[k] = w[k];
-            const float sc = s0[co], sh = b0[co];
+            for (int st = 0; st < 2; st++) {
+                HFrag bh, bl;
 #pragma unroll
-            for (int i = 0; i < NP; i++) {
-                float acc = 0.f;
+                for (int jj = 0; jj < 4; jj++) {
+                    const int kA = 16 * st + 2 * jj, kB = kA + 8;
+                    const float x0 = base[hh ? tap_off(kB) : tap_off(kA)], x1 = base[hh ? tap_off(kB + 1) : tap_off(kA + 1)];
+                    split_pair(x0, x1, bh.u[jj], bl.u[jj]);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st].v, bh.v, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st].v, bl.v, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st].v, bh.v, acc, 0, 0, 0);
+            }
+            if (p < NPOS) {
+                const bool inside = (unsigned)(cy0 + py) < (unsigned)O && (unsigned)(cx0 + px) < (unsigned)O;
 #pragma unroll
-                for (int k = 0; k < 27; k++) acc = __builtin_fmaf(wr[k], v[i][k], acc);
-                const float r = __builtin_amdgcn_fmed3f(__builtin_fmaf(acc, sc, sh), 0.f, 6.f);
-                if (lane + 64 * i < HALF) {
-                    const int p = p0 + lane + 64 * i;
-                    const int py = p / kStemCW, px = p % kStemCW;
-                    const bool inside = (unsigned)(cy0 + py) < (unsigned)O && (unsigned)(cx0 + px) < (unsigned)O;
-                    sC[co * kStemCP + p] = inside ? r : 0.f;
+                for (int r = 0; r < 16; r++) {
+                    const int ch = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const float v = __builtin_amdgcn_fmed3f(__builtin_fmaf(acc[r], sc[r], sh[r]), 0.f, 6.f);
+                    sC[ch * kStemCP + p] = inside ? v : 0.f;
                 }
             }
         }
@@ -238,34 +246,38 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
             for (int p = 0; p < 4; p++) dwo[y * kStemCW + p] = __builtin_amdgcn_fmed3f(__builtin_fmaf(o[y][p], dsc, dsh), 0.f, 6.f);
     }
     __syncthreads();
-    // 4. block 1's projection 32 -> 16 + BN (no activation, no residual): lane = pixel (4 x 64 per tile), wave w = output
-    //    channels 2w, 2w+1; a pixel's 32 hidden values are read from LDS once per pair of channels
-#pragma unroll 1
-    for (int i0 = 0; i0 < 4; i0 += 2) {
-        float hv[2][32];
+    // 4. block 1's projection 32 -> 16 + BN (no activation, no residual), also on MFMA: M = 16 channels (rows 16..31 of
+    //    the tile are zero weights), K = 32 hidden channels, N = the tile's 256 pixels: wave w = tile row w
+    {
+        HFrag ah[2], al[2];
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int p = lane + 64 * (i0 + i);
-            const float* src = sC + (p >> 5) * kStemCW + (p & 31);
+        for (int st = 0; st < 2; st++)
 #pragma unroll
-            for (int k = 0; k < 32; k++) hv[i][k] = src[k * kStemCP];
+            for (int jj = 0; jj < 4; jj++) {
+                const int k0 = 16 * st + 8 * hh + 2 * jj;
+                const float w0 = col < 16 ? Wp[col * 32 + k0] : 0.f, w1 = col < 16 ? Wp[col * 32 + k0 + 1] : 0.f;
+                split_pair(w0, w1, ah[st].u[jj], al[st].u[jj]);
+            }
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[q] = 0.f;
+        const float* src = sC + wv * kStemCW + col;
+#pragma unroll
+        for (int st = 0; st < 2; st++) {
+            HFrag bh, bl;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int k0 = 16 * st + 8 * hh + 2 * jj;
+                split_pair(src[k0 * kStemCP], src[(k0 + 1) * kStemCP], bh.u[jj], bl.u[jj]);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st].v, bh.v, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st].v, bl.v, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st].v, bh.v, acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int co = wv * 2 + j;
-            const float* w = Wp + co * 32;
-            float wr[32];
-#pragma unroll
-            for (int k = 0; k < 32; k++) wr[k] = w[k];
-            const float sc = sp[co], sh = bp[co];
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int p = lane + 64 * (i0 + i);
-                float acc = 0.f;
-#pragma unroll
-                for (int k = 0; k < 32; k++) acc = __builtin_fmaf(wr[k], hv[i][k], acc);
-                Y[(((size_t)b * 16 + co) * O + oy0 + (p >> 5)) * O + ox0 + (p & 31)] = __builtin_fmaf(acc, sc, sh);
-            }
+        for (int r = 0; r < 8; r++) {                       // rows (r & 3) + 8 (r >> 2) + 4 hh < 16
+            const int ch = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            Y[(((size_t)b * 16 + ch) * O + oy0 + wv) * O + ox0 + col] = __builtin_fmaf(acc[r], sp[ch], bp[ch]);
         }
     }
 }
