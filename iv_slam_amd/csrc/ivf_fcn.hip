@@ -282,6 +282,194 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
     }
 }
 
+// ---- blocks 2-4: a whole inverted-residual block (expand 1x1 -> depthwise 3x3 -> project 1x1) per launch ----
+// Same recipe as k_fcn_stem: the hidden tensor of these blocks (96 x 256 x 256 = 25 MB per image for block 2; 144
+// channels for blocks 3 and 4) never exists in HBM.  One workgroup = a 32 x TH output tile (TH = 2 at stride 2, 4 at
+// stride 1), 512 threads:
+//   A. the input window (CIN channels, the positions the stencil reads) goes to LDS with aligned float4 loads;
+//   B. per group of 32 hidden channels:  1. expansion as a split-f16 MFMA GEMM over the window positions (B operand read
+//      straight from the LDS window, lane = position), BN + ReLU6, ZERO outside the image (the depthwise layer pads
+//      the hidden map, not the input), to LDS planes;  2. depthwise stencil + BN + ReLU6, thread = channel x 4 or 8
+//      pixels, to a second LDS tile;  3. projection MFMAs of that K slice accumulate the output tile in registers
+//      (waves 0 .. TW*TH/32 - 1, one 32-pixel N tile each);
+//   C. BN, residual, store.
+// Weights: the expansion's and the projection's A operands come as the f16 hi / lo fragments k_fcn_gemm uses (one
+// 16-byte load per lane and fragment, L2-resident; the projection's are fetched at the top of a group and used after two
+// barriers, the expansion's one group ahead); depthwise taps and all BN scale / shift pairs sit in an LDS table.
+template <int S, int CIN, int HID, int COUT, bool RES, int WI, int TH>
+__global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X, const uint4* __restrict__ WqE,
+                                                const float* __restrict__ se, const float* __restrict__ be,
+                                                const float* __restrict__ Wd, const float* __restrict__ sd,
+                                                const float* __restrict__ bd, const uint4* __restrict__ WqP,
+                                                const float* __restrict__ sp, const float* __restrict__ bp, float* __restrict__ Y)
+{
+    constexpr int NT = 512, WO = WI / S, TW = 32;
+    constexpr int RW = (TW - 1) * S + 3, RH = (TH - 1) * S + 3, NPOS = RW * RH;       // window of hidden / input positions
+    constexpr int Q4 = (RW + 3 + 3) / 4, RP = 4 * Q4, XPL = RH * RP + 4;                // input rows start 3 floats left of the window (16-byte aligned)
+    constexpr int HPL = (NPOS + 3) / 4 * 4 + 4, DPL = TW * TH + 4;
+    constexpr int K16 = (CIN + 15) / 16, NG = (HID + 31) / 32, NTE = (NPOS + 31) / 32, NTP = TW * TH / 32;
+    constexpr int TP = 13;                                      // table: expansion scale, shift, 9 taps, depthwise scale, shift
+    __shared__ __attribute__((aligned(16))) float sX[CIN * XPL];
+    __shared__ __attribute__((aligned(16))) float sH[32 * HPL];
+    __shared__ __attribute__((aligned(16))) float sD[32 * DPL];
+    __shared__ float sT[NG * 32 * TP];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
+    const int rx0 = ox0 * S - 1, ry0 = oy0 * S - 1;             // window origin in the input map
+    const float* Xb = X + (size_t)b * CIN * WI * WI;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, hh = lane >> 5, col = lane & 31;
+    HFrag eh[K16], el[K16];                                     // expansion fragments of the current group
+#pragma unroll
+    for (int st = 0; st < K16; st++) { eh[st].q = WqE[((st * NG + 0) * 2 + 0) * 64 + lane]; el[st].q = WqE[((st * NG + 0) * 2 + 1) * 64 + lane]; }
+    {   // A. aligned float4 loads, all of a thread's loads in flight before the first LDS store
+        constexpr int N4 = CIN * RH * Q4, IT = (N4 + NT - 1) / NT;
+        float4 v4[IT]; bool ok[IT];
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const int i = min(tid + NT * k, N4 - 1);
+            const int c = i / (RH * Q4), r = (i / Q4) % RH, q4 = i % Q4;
+            const int yy = ry0 + r, xx = ox0 * S - 4 + 4 * q4;
+            ok[k] = yy >= 0 && yy < WI && xx >= 0 && xx < WI;
+            v4[k] = *(const float4*)(Xb + ((size_t)c * WI + (ok[k] ? yy : 0)) * WI + (ok[k] ? xx : 0));
+        }
+        for (int i = tid; i < NG * 32; i += NT) {
+            const bool v = i < HID;
+            float* t = sT + i * TP;
+            t[0] = v ? se[i] : 0.f; t[1] = v ? be[i] : 0.f; t[11] = v ? sd[i] : 0.f; t[12] = v ? bd[i] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; k++) t[2 + k] = v ? Wd[i * 9 + k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const int i = tid + NT * k;
+            if (i < N4) {
+                const int c = i / (RH * Q4), r = (i / Q4) % RH, q4 = i % Q4;
+                *(float4*)&sX[c * XPL + r * RP + 4 * q4] = ok[k] ? v4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    f32x16 accO;
+#pragma unroll
+    for (int q = 0; q < 16; q++) accO[q] = 0.f;
+    __syncthreads();
+    // the expansion's B operand (the input window, split into f16 hi / lo) is the same for every hidden group: a wave
+    // builds the fragments of its (at most TPW) position tiles once
+    constexpr int TPW = (NTE + 7) / 8;
+    HFrag xh[TPW][K16], xl[TPW][K16];
+#pragma unroll
+    for (int ti = 0; ti < TPW; ti++) {
+        const int nc = min(32 * (wv + 8 * ti) + col, NPOS - 1);
+        const float* base = sX + (nc / RW) * RP + nc % RW + 3;
+#pragma unroll
+        for (int st = 0; st < K16; st++)
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int k0 = 16 * st + 8 * hh + 2 * jj;
+                const float x0 = k0 < CIN ? base[k0 * XPL] : 0.f, x1 = k0 + 1 < CIN ? base[(k0 + 1) * XPL] : 0.f;
+                split_pair(x0, x1, xh[ti][st].u[jj], xl[ti][st].u[jj]);
+            }
+    }
+#pragma unroll 1
+    for (int g = 0; g < NG; g++) {
+        HFrag ph[2], pl[2];                                     // projection fragments of this group: needed two barriers from now
+        if (wv < NTP) {
+#pragma unroll
+            for (int st = 0; st < 2; st++) { ph[st].q = WqP[((2 * g + st) * 2 + 0) * 64 + lane]; pl[st].q = WqP[((2 * g + st) * 2 + 1) * 64 + lane]; }
+        }
+        {   // B1. expansion of hidden channels 32g .. 32g+31 at every window position
+            float sc[16], sh[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float* t = sT + (32 * g + (r & 3) + 8 * (r >> 2) + 4 * hh) * TP;
+                sc[r] = t[0]; sh[r] = t[1];
+            }
+#pragma unroll
+            for (int ti = 0; ti < TPW; ti++) {
+                const int t = wv + 8 * ti;
+                if (t >= NTE) break;
+                const int n = 32 * t + col, nc = min(n, NPOS - 1);
+                const int r_ = nc / RW, q_ = nc % RW;
+                f32x16 acc;
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc[q] = 0.f;
+#pragma unroll
+                for (int st = 0; st < K16; st++) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(el[st].v, xh[ti][st].v, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh[st].v, xl[ti][st].v, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh[st].v, xh[ti][st].v, acc, 0, 0, 0);
+                }
+                if (n < NPOS) {
+                    const bool inside = (unsigned)(ry0 + r_) < (unsigned)WI && (unsigned)(rx0 + q_) < (unsigned)WI;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const float v = __builtin_amdgcn_fmed3f(__builtin_fmaf(acc[r], sc[r], sh[r]), 0.f, 6.f);
+                        sH[((r & 3) + 8 * (r >> 2) + 4 * hh) * HPL + n] = inside ? v : 0.f;
+                    }
+                }
+            }
+            if (g + 1 < NG) {                                    // next group's expansion fragments: in flight during B2 / B3
+#pragma unroll
+                for (int st = 0; st < K16; st++) { eh[st].q = WqE[((st * NG + g + 1) * 2 + 0) * 64 + lane]; el[st].q = WqE[((st * NG + g + 1) * 2 + 1) * 64 + lane]; }
+            }
+        }
+        __syncthreads();
+        {   // B2. depthwise 3x3 (stride S) + BN + ReLU6 of the group
+            const int chl = tid >> 4, sub = tid & 15;
+            constexpr int PX = TW * TH / 16;                    // pixels per thread: 2, 4 or 8
+            const int oy = sub / (TW / PX), x0 = (sub % (TW / PX)) * PX;
+            const float* tb = sT + (32 * g + chl) * TP;
+            float wk[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) wk[k] = tb[2 + k];
+            const float dsc = tb[11], dsh = tb[12];
+            const float* hp = sH + chl * HPL + (oy * S) * RW + x0 * S;
+            float o[PX];
+#pragma unroll
+            for (int p = 0; p < PX; p++) o[p] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++) {
+                float row[(PX - 1) * S + 3];
+#pragma unroll
+                for (int k = 0; k < (PX - 1) * S + 3; k++) row[k] = hp[ky * RW + k];
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+                    for (int p = 0; p < PX; p++) o[p] = __builtin_fmaf(wk[ky * 3 + kx], row[p * S + kx], o[p]);
+            }
+            float* dp = sD + chl * DPL + oy * TW + x0;
+#pragma unroll
+            for (int p = 0; p < PX; p++) dp[p] = __builtin_amdgcn_fmed3f(__builtin_fmaf(o[p], dsc, dsh), 0.f, 6.f);
+        }
+        __syncthreads();
+        if (wv < NTP) {   // B3. projection: K slice = this group's 32 hidden channels, N tile = pixels 32 wv .. 32 wv + 31
+            const float* src = sD + 32 * wv + col;
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                HFrag bh, bl;
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const int k0 = 16 * st + 8 * hh + 2 * jj;
+                    split_pair(src[k0 * DPL], src[(k0 + 1) * DPL], bh.u[jj], bl.u[jj]);
+                }
+                accO = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl[st].v, bh.v, accO, 0, 0, 0);
+                accO = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[st].v, bl.v, accO, 0, 0, 0);
+                accO = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[st].v, bh.v, accO, 0, 0, 0);
+            }
+        }
+    }
+    if (wv < NTP) {   // C. BN (+ residual), store
+        const int n = 32 * wv + col, y = oy0 + n / TW, x = ox0 + n % TW;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ch = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (ch >= COUT) continue;
+            float v = __builtin_fmaf(accO[r], sp[ch], bp[ch]);
+            if (RES) v += Xb[((size_t)ch * WI + y) * WI + x];
+            Y[(((size_t)b * COUT + ch) * WO + y) * WO + x] = v;
+        }
+    }
+}
+
 // ---- depthwise 3x3 (stride s, dilation d, pad d) + BN + ReLU6 (mobilenet.py:46,54; models_light.py:139-152) ----
 // HBM-bound stencil.  One workgroup = one 64 x TH output tile of one channel plane (TH = 64 when the plane is 64 rows,
 // else 16): the input window ((TH-1)*s + 2d + 1) x ((64-1)*s + 2d + 1) is staged in LDS once (zero padding materialised there), every
@@ -1567,6 +1755,9 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
     char nm[64];
     hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc, n), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn);
     STAGE("prep");
+    // blocks 2-4 as whole-block kernels (bit i = block i + 2); off under the layer-by-layer / other-kernel experiment switches
+    static const unsigned irbMask = (getenv("IVF_FCN_NOFUSE") || getenv("IVF_FCN_BLOCKMASK") || getenv("IVF_FCN_NOSTRIDE2")) ? 0u
+                                    : getenv("IVF_FCN_IRBMASK") ? (unsigned)strtoul(getenv("IVF_FCN_IRBMASK"), nullptr, 0) : 7u;
     // conv0 + block 1's depthwise layer in one kernel, unless an experiment switch asks for another kernel on block 1
     static const bool stem = getenv("IVF_FCN_NOSTEM") == nullptr && getenv("IVF_FCN_WIDE256") == nullptr && getenv("IVF_FCN_NOFUSE") == nullptr &&
                              !(getenv("IVF_FCN_BLOCKMASK") && (strtoul(getenv("IVF_FCN_BLOCKMASK"), nullptr, 0) & 1));
@@ -1588,6 +1779,21 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
         const float* h = x;
         if (i == 0 && stem) {                       // block 1 (t = 1, stride 1, no residual) ran inside the stem kernel: its output is in y
             id++; ip++;
+            std::swap(x, y);
+            continue;
+        }
+        if (i >= 1 && i <= 3 && (irbMask >> (i - 1) & 1)) {      // blocks 2-4: one kernel per block, hidden tensor in LDS
+            const Gemm& ex = f->pw[ip]; const Gemm& pj = f->pw[ip + 1]; const Dw& d = f->dw[id];
+#define IRB(S_, CIN_, HID_, COUT_, RES_, WI_, TH_)                                                                          \
+            hipLaunchKernelGGL((k_fcn_irb<S_, CIN_, HID_, COUT_, RES_, WI_, TH_>), dim3(WI_ / S_ / 32, WI_ / S_ / TH_, n), dim3(512), 0, s, x, \
+                               ex.dWq, ex.dScale, ex.dShift, d.dW, d.dScale, d.dShift, pj.dWq, pj.dScale, pj.dShift, y)
+            if (i == 1) IRB(2, 16, 96, 24, false, 256, 2);
+            else if (i == 2) IRB(1, 24, 144, 24, true, 128, 4);
+            else IRB(2, 24, 144, 32, false, 128, 1);
+#undef IRB
+            ip += 2; id++;
+            H = (H - 1) / d.stride + 1; W = (W - 1) / d.stride + 1;
+            snprintf(nm, sizeof nm, "block %d whole", i + 1); STAGE(nm);
             std::swap(x, y);
             continue;
         }
