@@ -470,6 +470,160 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
     }
 }
 
+// ---- blocks 5-11 (64 x 64 maps, stride 1, dilation 1 or 2, up to 64 input channels): whole block per launch ----
+// k_fcn_irb without the LDS copy of the input window: at 64 input channels the window would not fit beside the hidden
+// planes, and it is only ever used as the expansion's B operand -- so every wave gathers the f16 hi / lo fragments of
+// its ONE tile of window positions straight from global memory (lane = position: coalesced rows) and keeps them in
+// registers for all hidden groups.  Output tile 32 x 2; window (32 + 2 DIL) x (2 + 2 DIL) positions; the depthwise
+// taps / BN table of a group is double-buffered in LDS (group g + 1 is fetched during group g).
+// Projection: wave w = N tile (w & 1) x output-channel tile (w >> 1).
+template <int DIL, int CIN, int HID, int COUT, bool RES>
+__global__ __launch_bounds__(512, 4) void k_fcn_irb64(const float* __restrict__ X, const uint4* __restrict__ WqE,
+                                                  const float* __restrict__ se, const float* __restrict__ be,
+                                                  const float* __restrict__ Wd, const float* __restrict__ sd,
+                                                  const float* __restrict__ bd, const uint4* __restrict__ WqP,
+                                                  const float* __restrict__ sp, const float* __restrict__ bp, float* __restrict__ Y)
+{
+    constexpr int NT = 512, WI = 64, TW = 32, TH = 2;
+    constexpr int RW = TW + 2 * DIL, RH = TH + 2 * DIL, NPOS = RW * RH;
+    constexpr int HPL = (NPOS + 3) / 4 * 4 + 4, DPL = TW * TH + 4;
+    constexpr int K16 = (CIN + 15) / 16, NG = (HID + 31) / 32, NTE = (NPOS + 31) / 32, MT = (COUT + 31) / 32, TP = 13;
+    static_assert(NTE <= 8, "one window tile per wave");
+    static_assert(MT <= 4, "one output-channel tile per wave");
+    __shared__ __attribute__((aligned(16))) float sH[32 * HPL];
+    __shared__ __attribute__((aligned(16))) float sD[32 * DPL];
+    __shared__ float sT[2][32 * TP];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
+    const int rx0 = ox0 - DIL, ry0 = oy0 - DIL;
+    const float* Xb = X + (size_t)b * CIN * WI * WI;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, hh = lane >> 5, col = lane & 31;
+    auto load_table = [&](int g, int buf) {                     // expansion scale / shift, 9 taps, depthwise scale / shift per channel
+        if (tid < 32 * TP) {
+            const int c = 32 * g + tid / TP, f = tid % TP;
+            float v = 0.f;
+            if (c < HID) v = f == 0 ? se[c] : f == 1 ? be[c] : f < 11 ? Wd[c * 9 + f - 2] : f == 11 ? sd[c] : bd[c];
+            sT[buf][tid] = v;
+        }
+    };
+    HFrag eh[K16], el[K16];
+#pragma unroll
+    for (int st = 0; st < K16; st++) { eh[st].q = WqE[((st * NG + 0) * 2 + 0) * 64 + lane]; el[st].q = WqE[((st * NG + 0) * 2 + 1) * 64 + lane]; }
+    load_table(0, 0);
+    // the wave's window tile: position n = 32 wv + col
+    const int n = 32 * wv + col, nc = min(n, NPOS - 1);
+    const int r_ = nc / RW, q_ = nc % RW;
+    const bool inside = (unsigned)(ry0 + r_) < (unsigned)WI && (unsigned)(rx0 + q_) < (unsigned)WI;
+    HFrag xh[K16], xl[K16];
+    {
+        const float* src = Xb + (size_t)(inside ? ry0 + r_ : 0) * WI + (inside ? rx0 + q_ : 0);
+        float xv[K16][8];
+#pragma unroll
+        for (int st = 0; st < K16; st++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int k = 16 * st + 8 * hh + j;
+                xv[st][j] = k < CIN ? src[(size_t)k * WI * WI] : 0.f;
+            }
+#pragma unroll
+        for (int st = 0; st < K16; st++)
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++)
+                split_pair(inside ? xv[st][2 * jj] : 0.f, inside ? xv[st][2 * jj + 1] : 0.f, xh[st].u[jj], xl[st].u[jj]);
+    }
+    f32x16 accO;
+#pragma unroll
+    for (int q = 0; q < 16; q++) accO[q] = 0.f;
+    const int ntP = wv & 1, mtP = wv >> 1;
+    __syncthreads();
+#pragma unroll 1
+    for (int g = 0; g < NG; g++) {
+        const float* T = sT[g & 1];
+        if (wv < NTE) {   // B1. expansion of hidden channels 32g .. 32g+31 on the wave's window tile
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[q] = 0.f;
+#pragma unroll
+            for (int st = 0; st < K16; st++) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(el[st].v, xh[st].v, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh[st].v, xl[st].v, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh[st].v, xh[st].v, acc, 0, 0, 0);
+            }
+            if (n < NPOS) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int cl = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const float v = __builtin_amdgcn_fmed3f(__builtin_fmaf(acc[r], T[cl * TP], T[cl * TP + 1]), 0.f, 6.f);
+                    sH[cl * HPL + n] = inside ? v : 0.f;        // the depthwise layer pads the HIDDEN map with zeros
+                }
+            }
+        }
+        if (g + 1 < NG) {                                        // next group's fragments and table: in flight during B2 / B3
+#pragma unroll
+            for (int st = 0; st < K16; st++) { eh[st].q = WqE[((st * NG + g + 1) * 2 + 0) * 64 + lane]; el[st].q = WqE[((st * NG + g + 1) * 2 + 1) * 64 + lane]; }
+            load_table(g + 1, (g + 1) & 1);
+        }
+        __syncthreads();
+        {   // B2. depthwise 3x3 (dilation DIL) + BN + ReLU6 of the group: thread = channel x 4 adjacent pixels
+            const int chl = tid >> 4, sub = tid & 15;
+            const int oy = sub >> 3, x0 = (sub & 7) * 4;
+            const float* tb = T + chl * TP;
+            float wk[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) wk[k] = tb[2 + k];
+            const float dsc = tb[11], dsh = tb[12];
+            const float* hp = sH + chl * HPL + oy * RW + x0;
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++) {
+                float row[4 + 2 * DIL];
+#pragma unroll
+                for (int k = 0; k < 4 + 2 * DIL; k++) row[k] = hp[ky * DIL * RW + k];
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+                    for (int p = 0; p < 4; p++) o[p] = __builtin_fmaf(wk[ky * 3 + kx], row[p + kx * DIL], o[p]);
+            }
+            float* dp = sD + chl * DPL + oy * TW + x0;
+#pragma unroll
+            for (int p = 0; p < 4; p++) dp[p] = __builtin_amdgcn_fmed3f(__builtin_fmaf(o[p], dsc, dsh), 0.f, 6.f);
+        }
+        __syncthreads();
+        if (mtP < MT) {   // B3. projection: K slice = this group's 32 hidden channels
+            HFrag ph[2], pl[2];
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                ph[st].q = WqP[(((2 * g + st) * MT + mtP) * 2 + 0) * 64 + lane];
+                pl[st].q = WqP[(((2 * g + st) * MT + mtP) * 2 + 1) * 64 + lane];
+            }
+            const float* src = sD + 32 * ntP + col;
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                HFrag bh, bl;
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const int k0 = 16 * st + 8 * hh + 2 * jj;
+                    split_pair(src[k0 * DPL], src[(k0 + 1) * DPL], bh.u[jj], bl.u[jj]);
+                }
+                accO = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl[st].v, bh.v, accO, 0, 0, 0);
+                accO = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[st].v, bl.v, accO, 0, 0, 0);
+                accO = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[st].v, bh.v, accO, 0, 0, 0);
+            }
+        }
+    }
+    if (mtP < MT) {   // C. BN (+ residual), store
+        const int m = 32 * ntP + col, y = oy0 + m / TW, x = ox0 + m % TW;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ch = 32 * mtP + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (ch >= COUT) continue;
+            float v = __builtin_fmaf(accO[r], sp[ch], bp[ch]);
+            if (RES) v += Xb[((size_t)ch * WI + y) * WI + x];
+            Y[(((size_t)b * COUT + ch) * WI + y) * WI + x] = v;
+        }
+    }
+}
+
 // ---- depthwise 3x3 (stride s, dilation d, pad d) + BN + ReLU6 (mobilenet.py:46,54; models_light.py:139-152) ----
 // HBM-bound stencil.  One workgroup = one 64 x TH output tile of one channel plane (TH = 64 when the plane is 64 rows,
 // else 16): the input window ((TH-1)*s + 2d + 1) x ((64-1)*s + 2d + 1) is staged in LDS once (zero padding materialised there), every
@@ -1755,7 +1909,9 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
     char nm[64];
     hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc, n), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn);
     STAGE("prep");
-    // blocks 2-4 as whole-block kernels (bit i = block i + 2); off under the layer-by-layer / other-kernel experiment switches
+    // whole-block kernels, bit i = block i + 2: blocks 2-4 (k_fcn_irb) by default; bits 3-9 = blocks 5-11 through k_fcn_irb64, which
+    // is correct but measures slower than expand + dwpw there (337 vs 245 us for the 64->384->64 blocks): opt-in.  Off under the
+    // layer-by-layer / other-kernel experiment switches
     static const unsigned irbMask = (getenv("IVF_FCN_NOFUSE") || getenv("IVF_FCN_BLOCKMASK") || getenv("IVF_FCN_NOSTRIDE2")) ? 0u
                                     : getenv("IVF_FCN_IRBMASK") ? (unsigned)strtoul(getenv("IVF_FCN_IRBMASK"), nullptr, 0) : 7u;
     // conv0 + block 1's depthwise layer in one kernel, unless an experiment switch asks for another kernel on block 1
@@ -1779,6 +1935,21 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
         const float* h = x;
         if (i == 0 && stem) {                       // block 1 (t = 1, stride 1, no residual) ran inside the stem kernel: its output is in y
             id++; ip++;
+            std::swap(x, y);
+            continue;
+        }
+        if (i >= 4 && i <= 10 && (irbMask >> (i - 1) & 1)) {     // blocks 5-11 (64 x 64, <= 64 input channels): one kernel per block
+            const Gemm& ex = f->pw[ip]; const Gemm& pj = f->pw[ip + 1]; const Dw& d = f->dw[id];
+#define IRB64(DIL_, CIN_, HID_, COUT_, RES_)                                                                                \
+            hipLaunchKernelGGL((k_fcn_irb64<DIL_, CIN_, HID_, COUT_, RES_>), dim3(2, 32, n), dim3(512), 0, s, x, ex.dWq, ex.dScale,      \
+                               ex.dShift, d.dW, d.dScale, d.dShift, pj.dWq, pj.dScale, pj.dShift, y)
+            if (i == 4 || i == 5) IRB64(1, 32, 192, 32, true);
+            else if (i == 6) IRB64(1, 32, 192, 64, false);
+            else if (i <= 9) IRB64(2, 64, 384, 64, true);
+            else IRB64(2, 64, 384, 96, false);
+#undef IRB64
+            ip += 2; id++;
+            snprintf(nm, sizeof nm, "block %d whole", i + 1); STAGE(nm);
             std::swap(x, y);
             continue;
         }

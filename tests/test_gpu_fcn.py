@@ -114,7 +114,12 @@ print("OK %.3g" % err)
     # stride-2 blocks layer by layer (the default fuses their depthwise + projection)
     {"IVF_FCN_NOSTRIDE2": "1"},
     {"IVF_FCN_NOSTEM": "1"},
-], ids=["default", "layerwise", "all-blocks-fused", "expand-pxt2", "dwpw-256", "no-stride2-fusion", "no-stem-fusion"])
+    # whole-block kernels also on blocks 5-11 (k_fcn_irb64; opt-in: slower than expand + dwpw there)
+    {"IVF_FCN_IRBMASK": "0x3ff"},
+    # ... and on none (blocks 2-4 through k_fcn_gemm + k_fcn_dwpw)
+    {"IVF_FCN_IRBMASK": "0"},
+], ids=["default", "layerwise", "all-blocks-fused", "expand-pxt2", "dwpw-256", "no-stride2-fusion", "no-stem-fusion", "irb-blocks-2-11",
+        "irb-none"])
 def test_fcn_kernel_variants_match_goldens_and_are_deterministic(env):
     """The FCN picks between several kernels per layer (measured defaults, env overrides for tuning).  Every variant must
     meet the same bar, batch results must not depend on the batch slot, and repeated runs must be bit-identical (this is
