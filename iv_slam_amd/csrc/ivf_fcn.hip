@@ -498,18 +498,22 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb64(const float* __restrict__ 
     const int rx0 = ox0 - DIL, ry0 = oy0 - DIL;
     const float* Xb = X + (size_t)b * CIN * WI * WI;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, hh = lane >> 5, col = lane & 31;
-    auto load_table = [&](int g, int buf) {                     // expansion scale / shift, 9 taps, depthwise scale / shift per channel
-        if (tid < 32 * TP) {
-            const int c = 32 * g + tid / TP, f = tid % TP;
-            float v = 0.f;
-            if (c < HID) v = f == 0 ? se[c] : f == 1 ? be[c] : f < 11 ? Wd[c * 9 + f - 2] : f == 11 ? sd[c] : bd[c];
-            sT[buf][tid] = v;
-        }
+    // table entry of this thread: expansion scale / shift, 9 taps, depthwise scale / shift per channel.  Fetched one group
+    // ahead into a register at the top of a group and stored to LDS at its end, so that nothing waits on the load
+    const float* tsrc; int tstride;
+    {
+        const int f = tid % TP;
+        tsrc = f == 0 ? se : f == 1 ? be : f < 11 ? Wd + (f - 2) : f == 11 ? sd : bd;
+        tstride = (f >= 2 && f < 11) ? 9 : 1;
+    }
+    auto fetch_table = [&](int g) {
+        const int c = 32 * g + tid / TP;
+        return (tid < 32 * TP && c < HID) ? tsrc[(size_t)c * tstride] : 0.f;
     };
     HFrag eh[K16], el[K16];
 #pragma unroll
     for (int st = 0; st < K16; st++) { eh[st].q = WqE[((st * NG + 0) * 2 + 0) * 64 + lane]; el[st].q = WqE[((st * NG + 0) * 2 + 1) * 64 + lane]; }
-    load_table(0, 0);
+    if (tid < 32 * TP) sT[0][tid] = fetch_table(0);
     // the wave's window tile: position n = 32 wv + col
     const int n = 32 * wv + col, nc = min(n, NPOS - 1);
     const int r_ = nc / RW, q_ = nc % RW;
@@ -539,16 +543,20 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb64(const float* __restrict__ 
 #pragma unroll 1
     for (int g = 0; g < NG; g++) {
         const float* T = sT[g & 1];
+        const float tnext = g + 1 < NG ? fetch_table(g + 1) : 0.f;
         if (wv < NTE) {   // B1. expansion of hidden channels 32g .. 32g+31 on the wave's window tile
-            f32x16 acc;
+            // two independent accumulation chains (hi*hi; the two cross terms) instead of one of 3 K16 dependent MFMAs
+            f32x16 acc, acc1;
 #pragma unroll
-            for (int q = 0; q < 16; q++) acc[q] = 0.f;
+            for (int q = 0; q < 16; q++) { acc[q] = 0.f; acc1[q] = 0.f; }
 #pragma unroll
             for (int st = 0; st < K16; st++) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(el[st].v, xh[st].v, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh[st].v, xl[st].v, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(el[st].v, xh[st].v, acc1, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh[st].v, xh[st].v, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh[st].v, xl[st].v, acc1, 0, 0, 0);
             }
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[q] += acc1[q];
             if (n < NPOS) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
@@ -561,7 +569,6 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb64(const float* __restrict__ 
         if (g + 1 < NG) {                                        // next group's fragments and table: in flight during B2 / B3
 #pragma unroll
             for (int st = 0; st < K16; st++) { eh[st].q = WqE[((st * NG + g + 1) * 2 + 0) * 64 + lane]; el[st].q = WqE[((st * NG + g + 1) * 2 + 1) * 64 + lane]; }
-            load_table(g + 1, (g + 1) & 1);
         }
         __syncthreads();
         {   // B2. depthwise 3x3 (dilation DIL) + BN + ReLU6 of the group: thread = channel x 4 adjacent pixels
@@ -588,6 +595,7 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb64(const float* __restrict__ 
 #pragma unroll
             for (int p = 0; p < 4; p++) dp[p] = __builtin_amdgcn_fmed3f(__builtin_fmaf(o[p], dsc, dsh), 0.f, 6.f);
         }
+        if (g + 1 < NG && tid < 32 * TP) sT[(g + 1) & 1][tid] = tnext;     // first read after this barrier (B1 of the next group)
         __syncthreads();
         if (mtP < MT) {   // B3. projection: K slice = this group's 32 hidden channels
             HFrag ph[2], pl[2];
