@@ -1382,14 +1382,24 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     const int b = L / WGPI, p128 = L % WGPI;
     const int tile0 = blockIdx.y * TILES;
     const int kc = tid >> 4, g = tid & 15;
-    const int y = (128 * p128 + 8 * g) >> LW, x0 = (128 * p128 + 8 * g) & (Wd - 1);
+    // PAIR (64-wide stride-1 maps): the workgroup's two rows are y and y + DIL, not y and y + 1.  Their tap rows are
+    // y-D, y, y+D and y, y+D, y+2D: four distinct rows instead of six, and the two shared ones travel between the halves
+    // of the DPP row (lane +- 8) instead of being loaded twice -- a third less traffic through the vector L1, which is
+    // what bounds this kernel.  Slot s of a thread: s = 0, 1 its two loaded rows, s = 2 the row it
+    // receives; the tap row (ky) a slot stands for depends on the half: A (g < 8): 0, 1, 2; B: 1, 2, 0.
+    constexpr bool PAIR = LW == 6 && S_ == 1;
+    const bool halfB = PAIR && g >= 8;
+    const int yPairA = PAIR ? (p128 / DIL) * 2 * DIL + p128 % DIL : 0;
+    const int y = PAIR ? yPairA + (halfB ? DIL : 0) : (128 * p128 + 8 * g) >> LW;
+    const int x0 = PAIR ? (g & 7) * 8 : (128 * p128 + 8 * g) & (Wd - 1);
     int rowOff[3]; float rowM[3];
 #pragma unroll
-    for (int ky = 0; ky < 3; ky++) {
-        const int yy = y * S_ + (ky - 1) * DIL;     // input row of tap ky
+    for (int sl = 0; sl < 3; sl++) {
+        const int ky = PAIR ? (halfB ? (sl + 1) % 3 : sl) : sl;
+        const int yy = y * S_ + (ky - 1) * DIL;     // input row of the slot's tap row
         const bool ok = yy >= 0 && yy < Wi;
-        rowM[ky] = ok ? 1.f : 0.f;
-        rowOff[ky] = (ok ? yy : y * S_) * Wi + x0 * S_;
+        rowM[sl] = ok ? 1.f : 0.f;
+        rowOff[sl] = (ok ? yy : y * S_) * Wi + x0 * S_;
     }
     // the DPP row (16 lanes) covers two image rows (LW 6), one (LW 7) or half of one (LW 8).  mL / mR switch the halo taps off
     // where lane-1 / lane+1 is not the horizontal neighbour (image border, or the other row of the pair); for LW 8 the
@@ -1410,7 +1420,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
         const float* P = Xb + (size_t)(16 * c + kc) * HWi;
         S.par = dwP[c * 192 + parIdx];
 #pragma unroll
-        for (int ky = 0; ky < 3; ky++) {
+        for (int ky = 0; ky < (PAIR ? 2 : 3); ky++) {
 #pragma unroll
             for (int j = 0; j < 2 * S_; j++) S.own[ky][j] = *(const float4*)(P + rowOff[ky] + 4 * j);
             if constexpr (LW == 8) {
@@ -1439,6 +1449,26 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
 #undef ROW_SHARE
 #pragma unroll
         for (int p = 0; p < 8; p++) o[p] = 0.f;
+        float4 part[2];
+        if constexpr (PAIR) {
+            // the received row: half A takes the centre row of B (B's slot 0) from lane + 8, half B the centre row of A
+            // (A's slot 1) from lane - 8; the DPP's zero fill makes the unused one of the two vanish
+            auto shl8 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x108, 0xF, 0xF, true)); };
+            auto shr8 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xF, 0xF, true)); };
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const float4 a0 = S.own[0][j], a1 = S.own[1][j];
+                part[j] = make_float4(shl8(a0.x) + shr8(a1.x), shl8(a0.y) + shr8(a1.y), shl8(a0.z) + shr8(a1.z), shl8(a0.w) + shr8(a1.w));
+            }
+            // tap weights by slot
+            float t[9];
+#pragma unroll
+            for (int sl = 0; sl < 3; sl++)
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) t[sl * 3 + kx] = halfB ? wk[((sl + 1) % 3) * 3 + kx] : wk[sl * 3 + kx];
+#pragma unroll
+            for (int q = 0; q < 9; q++) wk[q] = t[q];
+        }
 #pragma unroll
         for (int ky = 0; ky < 3; ky++) {
             // plain FMAs, one per tap and pixel.  A tap that falls outside the thread's own 8 pixels reads the neighbour
@@ -1464,7 +1494,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
                 (void)w2R;
                 continue;
             }
-            const float4 a = S.own[ky][0], c4 = S.own[ky][1];
+            const float4 a = (PAIR && ky == 2) ? part[0] : S.own[ky][0], c4 = (PAIR && ky == 2) ? part[1] : S.own[ky][1];
             const float own[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
             for (int p = 0; p < 8; p++) {
@@ -1555,7 +1585,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
                                                     // counted vmcnt waits (measured on the 64-wide kernels: 226 -> 357 us)
     // epilogue: per tile, BN scale/shift (float4 per row quad, arrays padded to whole tiles) and the residual are
     // loaded as one batch before the first use
-    const int pix = 128 * p128 + 32 * wave + col;
+    const int pix = PAIR ? (yPairA + (wave >> 1) * DIL) * Wd + 32 * (wave & 1) + col : 128 * p128 + 32 * wave + col;
 #pragma unroll
     for (int t = 0; t < TILES; t++) {
         const int cb = (tile0 + t) * 32 + 4 * kg;
