@@ -1408,7 +1408,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     const bool edgeL = LW == 8 && g == 0 && x0 > 0, edgeR = LW == 8 && g == 15 && x0 + 8 < Wd;
     const float* Xb = X + (size_t)b * K * HWi;
     const float* Wf = (const float*)Wq;
-    const int nChunks = abl >= 2 ? 24 : K / 16;     // odd for the 144-channel block: see the tail after the loop
+    const int nChunks = (abl & 2) ? 24 : K / 16;     // odd for the 144-channel block: see the tail after the loop
 
     // window and depthwise-parameter loads run two chunks ahead; each of the 16 threads of a channel fetches ONE of its
     // 12 parameters and the stencil broadcasts them with DPP row_share.  The A fragments (L2-resident, needed only at
@@ -1569,7 +1569,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
         __builtin_amdgcn_sched_barrier(0);
         issue(SB, c + 3);
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+        if (!(abl & 4)) __syncthreads();
         multiply(1);
         stencil(SA);
         publish(0);
@@ -1578,7 +1578,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
         __builtin_amdgcn_sched_barrier(0);
         issue(SA, c + 4);
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+        if (!(abl & 4)) __syncthreads();
     }
     if (nChunks & 1) multiply(0);                   // odd chunk count (the 144-channel block): the last chunk sits in buffer 0.
                                                     // A peeled tail, not an exit inside the loop: that costs the loop its
