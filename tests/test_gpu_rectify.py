@@ -128,3 +128,32 @@ def test_replay_harness_matches_oracle_chain(iv, tmp_path):
                 assert l["kps"].tobytes() == okL.tobytes() and np.array_equal(l["desc"], odL), (introspect, i)
                 assert r["kps"].tobytes() == okR.tobytes() and np.array_equal(r["desc"], odR), (introspect, i)
                 assert l["uright"].tobytes() == our.tobytes() and l["depth"].tobytes() == odp.tobytes(), (introspect, i)
+
+
+def test_replay_harness_online_network(iv, tmp_path):
+    """--fcn: the introspection network runs on the un-remapped left frame, its cost map is remapped like the left image
+    and gates the left extractor (stereo_kitti.cc:493-521); equals FCN (device) -> oracle remap -> oracle extractor."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import replay_kitti
+    from iv_slam_amd import kitti, fcn_weights
+    seq = str(tmp_path / "seq")
+    S = kitti.Settings.load(replay_kitti.make_synthetic(seq, 2, with_qual=False))
+    left, right, ts = kitti.LoadImages(seq)
+    blob = fcn_weights.pack_blob(fcn_weights.make_seeded_weights(5))
+    rp = replay_kitti.Replay(S, rectify=True, undistort=True, batch=2, fcn_blob=blob)
+    Ls = [kitti.imread(p) for p in left]; Rs = [kitti.imread(p) for p in right]
+    res = rp.run(Ls, Rs, None, Ls)
+    nf, sf, nl, ini, mn, _ = S.extractor_params(); bf, b = S.stereo()
+    K, D, R, P, size = S.rectification("LEFT"); mL = O.init_undistort_rectify_map(K, D, R, P, size)
+    K, D, R, P, size = S.rectification("RIGHT"); mR = O.init_undistort_rectify_map(K, D, R, P, size)
+    fcn = iv.IntrospectionFCN(blob, Ls[0].shape, Ls[0].shape)
+    for k in range(2):
+        cost = fcn(np.repeat(Ls[k][..., None], 3, axis=2))                 # u8 map; the device network itself is checked in test_gpu_fcn.py
+        oL = O.remap_bilinear(Ls[k], *mL); oR = O.remap_bilinear(Rs[k], *mR); oC = O.remap_bilinear(cost, *mL)
+        eL = O.Extractor(nf, sf, nl, ini, mn, introspection=True); eR = O.Extractor(nf, sf, nl, ini, mn)
+        okL, odL = eL(oL, oC); okR, odR = eR(oR)
+        l, r = res[k]
+        assert l["kps"].tobytes() == okL.tobytes() and np.array_equal(l["desc"], odL)
+        assert r["kps"].tobytes() == okR.tobytes() and np.array_equal(r["desc"], odR)

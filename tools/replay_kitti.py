@@ -4,7 +4,7 @@ reference's stereo driver (introspective_ORB_SLAM/Examples/Stereo/stereo_kitti.c
 System::TrackStereo would take over -- load pair, optional undistort/rectify remap, optional cost image (predicted
 heat maps from disk, remapped like the left image, :470-521), extract L/R, stereo match.
 
-  python tools/replay_kitti.py SEQUENCE_DIR SETTINGS.yaml [--rectify] [--undistort] [--qual DIR] [--batch 16]
+  python tools/replay_kitti.py SEQUENCE_DIR SETTINGS.yaml [--rectify] [--undistort] [--qual DIR | --fcn WEIGHTS.bin] [--batch 16]
   python tools/replay_kitti.py --make-synthetic DIR --frames 12        # writes a small synthetic sequence + settings
 
 Prints one line per frame (keypoints L/R, stereo matches, median depth) and the pairs/s of the device part.
@@ -107,7 +107,7 @@ def make_synthetic(root, frames, with_qual=True):
 class Replay:
     """The per-frame device work of the driver, batched: remap (optional) -> StereoFrontend."""
 
-    def __init__(self, settings, rectify=False, undistort=False, introspect=False, batch=16, device_id=0):
+    def __init__(self, settings, rectify=False, undistort=False, introspect=False, batch=16, device_id=0, fcn_blob=None):
         import torch
         import iv_slam_amd as iv
         self.torch = torch; self.iv = iv
@@ -131,19 +131,33 @@ class Replay:
             self.remapL = iv.Remap(mL[0], mL[1], (sL[1], sL[0]), 1, device_id)
             self.remapR = iv.Remap(mR[0], mR[1], (sR[1], sR[0]), 1, device_id)
             self.size = sL
-        self.fe = iv.StereoFrontend(self.size[0], self.size[1], batch, nf, sf, nl, ini, mn, enableIntrospection=introspect,
+        self.fe = iv.StereoFrontend(self.size[0], self.size[1], batch, nf, sf, nl, ini, mn, enableIntrospection=introspect or fcn_blob is not None,
                                     bf=bf, b=b, device_id=device_id)
         self.batch = batch
+        # online inference of the introspection network (stereo_kitti.cc:493-514): the UN-remapped left image goes in,
+        # the cost map comes out at the same size and is then remapped like the left image (:519-521)
+        self.fcn = None
+        if fcn_blob is not None:
+            src = (int(settings["Camera.height"]), int(settings["Camera.width"]))
+            self.fcn = iv.IntrospectionFCN(fcn_blob, src, src, max_batch=batch, device_id=device_id)
 
-    def run(self, lefts, rights, costs=None):
-        """lists of host grey images (cost entries may be None) -> list of per-pair dicts (left/right fetch results)."""
+    def run(self, lefts, rights, costs=None, raw_lefts=None):
+        """lists of host grey images (cost entries may be None; raw_lefts = the left frames as loaded, B,G,R or grey, for the
+        network) -> list of per-pair dicts (left/right fetch results)."""
         torch = self.torch
         n = len(lefts)
         L = torch.from_numpy(np.stack(lefts)).to(self.dev); R = torch.from_numpy(np.stack(rights)).to(self.dev)
         if self.remapL is not None:
             L = self.remapL.apply_device(L); R = self.remapR.apply_device(R)
         C = None
-        if costs is not None and any(c is not None for c in costs):
+        if self.fcn is not None:
+            Lraw = torch.from_numpy(np.stack(raw_lefts if raw_lefts is not None else lefts)).to(self.dev)
+            bgr = Lraw if Lraw.dim() == 4 else Lraw.unsqueeze(-1).expand(-1, -1, -1, 3)      # grey frames: the same plane three times
+            C = torch.empty(Lraw.shape[:3], dtype=torch.uint8, device=self.dev)
+            self.fcn.forward_device(bgr.contiguous(), cost_u8=C, stream_ptr=torch.cuda.current_stream().cuda_stream)
+            if self.remapL is not None:
+                C = self.remapL.apply_device(C)
+        elif costs is not None and any(c is not None for c in costs):
             if any(c is None for c in costs):
                 raise ValueError("a batch mixes frames with and without a cost image: replay those frames with --batch 1")
             C = torch.from_numpy(np.stack(costs)).to(self.dev)
@@ -160,6 +174,7 @@ def main():
     ap.add_argument("sequence", nargs="?"); ap.add_argument("settings", nargs="?")
     ap.add_argument("--rectify", action="store_true"); ap.add_argument("--undistort", action="store_true")
     ap.add_argument("--qual", help="directory of predicted cost images (%%06d.*): enables the introspection-weighted extractor")
+    ap.add_argument("--fcn", help="weights blob (tools/export_fcn_weights.py) or 'seeded': run the introspection network on every left image")
     ap.add_argument("--batch", type=int, default=16); ap.add_argument("--max-frames", type=int, default=0)
     ap.add_argument("--make-synthetic"); ap.add_argument("--frames", type=int, default=12)
     a = ap.parse_args()
@@ -177,19 +192,24 @@ def main():
         qual, found = kitti.GetImageQualFileNames(a.qual, len(ts))
         print("%d predicted cost images found for %d frames" % (found, len(ts)))
     batch = 1 if a.qual else a.batch          # frames without a cost image run the plain extractor (System ignores empty images)
-    rp = Replay(S, a.rectify, a.undistort, introspect=bool(a.qual), batch=batch)
+    blob = None
+    if a.fcn:
+        from iv_slam_amd import fcn_weights
+        blob = fcn_weights.pack_blob(fcn_weights.make_seeded_weights(7)) if a.fcn == "seeded" else np.fromfile(a.fcn, np.float32)
+    rp = Replay(S, a.rectify, a.undistort, introspect=bool(a.qual), batch=batch, fcn_blob=blob)
     t_dev = 0.0; done = 0
     for i0 in range(0, n, batch):
         idx = [i for i in range(i0, min(i0 + batch, n)) if left[i]]
         if not idx:
             continue
-        Ls = [kitti.to_gray(kitti.imread(left[i]), rp.rgb) for i in idx]
+        raw = [kitti.imread(left[i]) for i in idx]
+        Ls = [kitti.to_gray(im, rp.rgb) for im in raw]
         Rs = [kitti.to_gray(kitti.imread(right[i]), rp.rgb) for i in idx]
         Cs = None
         if qual is not None:
             Cs = [kitti.to_gray(kitti.imread(qual[i]), rp.rgb) if qual[i] else None for i in idx]
         t0 = time.perf_counter()
-        res = rp.run(Ls, Rs, Cs)
+        res = rp.run(Ls, Rs, Cs, raw)
         t_dev += time.perf_counter() - t0; done += len(idx)
         for i, (l, r) in zip(idx, res):
             m = l["uright"] >= 0
