@@ -154,13 +154,14 @@ def main():
     block = torch.empty(P * rec, dtype=torch.uint8, device=dev)
     gathered = torch.empty(world * P * rec, dtype=torch.uint8, device=dev) if exchange else None
     nslices = n_stream // P
-    # The exchange step runs on its own stream so that it overlaps the following batches (the front end keeps three
-    # batches in flight on internal streams): pack waits there for the batch's completion event and the all-gather follows
-    # it.  The main stream never waits for a batch to finish; the only coupling is the guard in front of fe.run(): the
-    # batch that reuses an internal context must come after the pack that read it three steps earlier.  The guard sits
-    # AFTER the FCN launches so that the network of step k is already queued while older batches drain.
+    # The exchange step (pack + all-gather) is enqueued on the internal stream the batch itself runs on -- in order behind
+    # it, so no stream ever waits on a batch-completion event (a stream that does costs 8 % of configs[2]: DESIGN.md
+    # section 6) and the batch that reuses the context three steps later simply queues behind the collective.  One block /
+    # gather buffer per internal stream.  IVF_BENCH_EXCHANGE=side selects the earlier variant (own stream + event waits).
     side = torch.cuda.Stream(dev) if exchange else None
     packed = [torch.cuda.Event() for _ in range(3)] if exchange else None
+    blocks3 = [torch.empty_like(block) for _ in range(3)] if exchange else None          # one per internal stream
+    gathered3 = [torch.empty_like(gathered) for _ in range(3)] if exchange else None
     nstep = [0]
 
     def step(i):
@@ -168,15 +169,23 @@ def main():
         k = nstep[0]; nstep[0] += 1
         if fcn is not None:
             fcn.forward_device(bgr[s:s + P], cost_u8=cost, stream_ptr=sptr)
-        if exchange and k >= 3:
+        mode = os.environ.get("IVF_BENCH_EXCHANGE", "batch-stream")
+        if exchange and mode == "side" and k >= 3:
             stream.wait_event(packed[k % 3])                     # the pack of three steps ago has read the context run(k) reuses
         fe.run(left[s:s + P], right[s:s + P], cost, sptr)
-        if exchange:
-            # the path's one exchange step: all-gather of {n, kps, desc, uRight} for cross-frame matching
+        if exchange and mode == "side":
             with torch.cuda.stream(side):
                 fe.pack_gather_block(block, side.cuda_stream)
                 packed[k % 3].record(side)
                 dist.all_gather_into_tensor(gathered, block)
+        elif exchange:
+            # the path's one exchange step: all-gather of {n, kps, desc, uRight} for cross-frame matching.  Pack and
+            # collective go onto the internal stream the batch itself runs on: in order behind it, so no stream ever waits
+            # on a batch-completion event, and the batch that reuses the context three steps later queues behind them
+            bs = torch.cuda.ExternalStream(fe.batch_stream(0), device=dev)
+            fe.pack_gather_block(blocks3[k % 3], fe.STREAM_OF_BATCH)
+            with torch.cuda.stream(bs):
+                dist.all_gather_into_tensor(gathered3[k % 3], blocks3[k % 3])
         if args.serial:
             fe.sync()
             if exchange:

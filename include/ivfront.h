@@ -200,6 +200,11 @@ int  ivf_frontend_pack_gather_block(ivf_frontend* fe, uint8_t* d_block, size_t b
  * for that run to finish: pack on a stream of its own (bench.py does), not on the stream that feeds the next batch. */
 int  ivf_frontend_pack_gather_block_of(ivf_frontend* fe, int age, uint8_t* d_block, size_t block_bytes, size_t* record_bytes,
                                        void* hip_stream);
+/* hip_stream value for the two functions above: pack on the internal stream the batch itself ran on (in order behind it,
+ * no cross-stream wait); ivf_frontend_batch_stream returns that stream (a hipStream_t) so that the consumer of the block
+ * -- bench.py's all-gather -- can be enqueued behind the pack. */
+#define IVF_STREAM_OF_BATCH ((void*)(intptr_t)-1)
+void* ivf_frontend_batch_stream(ivf_frontend* fe, int age);
 
 /* ---- introspection FCN forward (IF/networks/models_light/models_light.py:18-28; called at
  * ORB/Examples/Stereo/stereo_kitti.cc:231-247 (load) and :493-514 (pre-process, forward, u8 truncation)) ----

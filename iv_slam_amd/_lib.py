@@ -103,6 +103,7 @@ _SIGS = {
     "ivf_frontend_fast_ms_stats": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "ivf_frontend_pack_gather_block": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]),
     "ivf_frontend_pack_gather_block_of": (C.c_int, [vp, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]),
+    "ivf_frontend_batch_stream": (vp, [vp, C.c_int]),
     "ivf_fcn_create": (C.c_int, [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "ivf_fcn_destroy": (None, [vp]),
     "ivf_fcn_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),

@@ -1777,12 +1777,19 @@ int ivf_frontend_pack_gather_block_of(ivf_frontend* fe, int age, uint8_t* d_bloc
     const int np = fe->pairsOf[k];
     if (block_bytes < rec * np) return fail(IVF_E_CAPACITY, "gather block needs %zu bytes", rec * np);
     if (((size_t)d_block & 3) != 0) return fail(IVF_E_INVALID, "gather block must be 4-byte aligned");
-    hipStream_t st = (hipStream_t)hip_stream;
     HIPCHK(hipSetDevice(fe->cfg.device_id));
-    HIPCHK(hipStreamWaitEvent(st, fe->evDone[k], 0));                 // the batch ran on an internal stream
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (hip_stream == IVF_STREAM_OF_BATCH) st = fe->stream[k];        // in order behind the batch itself: nothing to wait for
+    else HIPCHK(hipStreamWaitEvent(st, fe->evDone[k], 0));            // the batch ran on an internal stream
     launch_pack_gather(fe->ctx[k].b, (int)nf, np, d_block, rec, st);
     HIPCHK(hipGetLastError());
     return IVF_OK;
+}
+
+void* ivf_frontend_batch_stream(ivf_frontend* fe, int age)
+{
+    if (!fe || age < 0 || age >= kPipe || fe->runs <= age) return nullptr;
+    return (void*)fe->stream[(fe->runs - 1 - age) % kPipe];
 }
 
 int ivf_frontend_pack_gather_block(ivf_frontend* fe, uint8_t* d_block, size_t block_bytes, size_t* record_bytes, void* hip_stream)

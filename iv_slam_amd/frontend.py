@@ -75,6 +75,12 @@ class StereoFrontend:
         check(self._lib.ivf_frontend_pack_gather_block(self._h, None, 0, C.byref(rec), None))
         return rec.value
 
+    STREAM_OF_BATCH = C.c_void_p(-1)        # pack on the internal stream the batch ran on (include/ivfront.h: IVF_STREAM_OF_BATCH)
+
+    def batch_stream(self, age=0):
+        """hipStream_t (as int) of the internal stream the batch `age` runs back was enqueued on."""
+        return self._lib.ivf_frontend_batch_stream(self._h, int(age))
+
     def pack_gather_block(self, block, stream_ptr=None, age=0):
         """block: torch.uint8 tensor of >= n_pairs*record_bytes on this device; age = which run (0 last, 1 the one before)."""
         rec = C.c_size_t(0)
