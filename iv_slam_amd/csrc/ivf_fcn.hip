@@ -1384,9 +1384,9 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     const int kc = tid >> 4, g = tid & 15;
     // PAIR (64-wide stride-1 maps): the workgroup's two rows are y and y + DIL, not y and y + 1.  Their tap rows are
     // y-D, y, y+D and y, y+D, y+2D: four distinct rows instead of six, and the two shared ones travel between the halves
-    // of the DPP row (lane +- 8) instead of being loaded twice -- a third less traffic through the vector L1, which is
-    // what bounds this kernel.  Slot s of a thread: s = 0, 1 its two loaded rows, s = 2 the row it
-    // receives; the tap row (ky) a slot stands for depends on the half: A (g < 8): 0, 1, 2; B: 1, 2, 0.
+    // of the DPP row (lane ^ 8) instead of being loaded twice.  A thread loads its OTHER row (slot 0: y - D for half A,
+    // y + D for half B) and its CENTRE row (slot 1); slot 2 is the partner's centre row (row_ror:8), i.e. tap row 2 for A
+    // and tap row 0 for B.  Only the tap weights of slots 0 and 2 depend on the half.
     constexpr bool PAIR = LW == 6 && S_ == 1;
     const bool halfB = PAIR && g >= 8;
     const int yPairA = PAIR ? (p128 / DIL) * 2 * DIL + p128 % DIL : 0;
@@ -1395,7 +1395,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     int rowOff[3]; float rowM[3];
 #pragma unroll
     for (int sl = 0; sl < 3; sl++) {
-        const int ky = PAIR ? (halfB ? (sl + 1) % 3 : sl) : sl;
+        const int ky = PAIR ? (sl == 1 ? 1 : ((sl == 0) != halfB ? 0 : 2)) : sl;      // slot -> tap row
         const int yy = y * S_ + (ky - 1) * DIL;     // input row of the slot's tap row
         const bool ok = yy >= 0 && yy < Wi;
         rowM[sl] = ok ? 1.f : 0.f;
@@ -1451,23 +1451,18 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
         for (int p = 0; p < 8; p++) o[p] = 0.f;
         float4 part[2];
         if constexpr (PAIR) {
-            // the received row: half A takes the centre row of B (B's slot 0) from lane + 8, half B the centre row of A
-            // (A's slot 1) from lane - 8; the DPP's zero fill makes the unused one of the two vanish
-            auto shl8 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x108, 0xF, 0xF, true)); };
-            auto shr8 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xF, 0xF, true)); };
+            auto ror8 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false)); };
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const float4 a0 = S.own[0][j], a1 = S.own[1][j];
-                part[j] = make_float4(shl8(a0.x) + shr8(a1.x), shl8(a0.y) + shr8(a1.y), shl8(a0.z) + shr8(a1.z), shl8(a0.w) + shr8(a1.w));
+                const float4 c = S.own[1][j];
+                part[j] = make_float4(ror8(c.x), ror8(c.y), ror8(c.z), ror8(c.w));
             }
-            // tap weights by slot
-            float t[9];
+            // tap weights by slot: slot 0 = tap row 0 (A) / 2 (B), slot 1 = tap row 1, slot 2 = tap row 2 (A) / 0 (B)
 #pragma unroll
-            for (int sl = 0; sl < 3; sl++)
-#pragma unroll
-                for (int kx = 0; kx < 3; kx++) t[sl * 3 + kx] = halfB ? wk[((sl + 1) % 3) * 3 + kx] : wk[sl * 3 + kx];
-#pragma unroll
-            for (int q = 0; q < 9; q++) wk[q] = t[q];
+            for (int kx = 0; kx < 3; kx++) {
+                const float lo = wk[kx], hi = wk[6 + kx];
+                wk[kx] = halfB ? hi : lo; wk[6 + kx] = halfB ? lo : hi;
+            }
         }
 #pragma unroll
         for (int ky = 0; ky < 3; ky++) {
