@@ -340,6 +340,10 @@ int  ivf_frame_search_by_projection(ivf_frame* f, int n_q, const float* q_u, con
                                     const float* q_radius, const int32_t* q_min_level, const int32_t* q_max_level,
                                     const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid, const uint8_t* q_blocks,
                                     int check_orientation, int32_t* cur_assign, int* nmatches);
+/* ivf_search_map_points (SearchByProjection(F, mapPoints), Tracking::SearchLocalPoints) against the resident frame */
+int  ivf_frame_search_map_points(ivf_frame* f, int n_q, const float* q_u, const float* q_v, const float* q_ur, const float* q_radius,
+                                 const int32_t* q_level, const uint8_t* q_desc, const uint8_t* q_valid, const uint8_t* q_blocks,
+                                 float nn_ratio, int32_t* cur_assign, int* nmatches);
 
 /* ---- rectification in front of the extractor -------------------------------------------------
  * cv::initUndistortRectifyMap(K, D, R, P(0:3,0:3), size, CV_32F, map1, map2) as the driver calls it

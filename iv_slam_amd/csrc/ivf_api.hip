@@ -642,6 +642,32 @@ static int replay_projection(const ivf_keypoint* cur_kps, const float* cur_urigh
     return nm;
 }
 
+// best / second best + ratio test of SearchByProjection(F, mapPoints), greedy in map-point order (ORBmatcher.cc:86-126):
+// candidates of map point i = cand[qStart[i] .. qStart[i+1]) in GetFeaturesInArea order
+static int replay_map_points(const ivf_keypoint* cur_kps, const float* cur_uright, int n_q, const float* q_ur, const float* q_radius,
+                             const uint8_t* q_blocks, float nn_ratio, const std::vector<int>& qStart, const std::vector<int>& cand,
+                             const std::vector<int>& dist, int32_t* cur_assign)
+{
+    int nm = 0;
+    for (int i = 0; i < n_q; i++) {
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int p = qStart[i]; p < qStart[i + 1]; p++) {
+            const int idx = cand[p];
+            if (cur_assign[idx] == -2) continue;
+            if (cur_assign[idx] >= 0 && (!q_blocks || q_blocks[cur_assign[idx]])) continue;
+            if (cur_uright[idx] > 0) { const float er = fabsf(q_ur[i] - cur_uright[idx]); if (er > q_radius[i]) continue; }
+            const int d = dist[p];
+            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = cur_kps[idx].octave; bestIdx = idx; }
+            else if (d < bestDist2) { bestLevel2 = cur_kps[idx].octave; bestDist2 = d; }
+        }
+        if (bestIdx >= 0 && bestDist <= 100) {
+            if (bestLevel == bestLevel2 && (float)bestDist > nn_ratio * (float)bestDist2) continue;
+            cur_assign[bestIdx] = i; nm++;
+        }
+    }
+    return nm;
+}
+
 int ivf_search_by_projection(const ivf_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int n_cur,
                              const ivf_bounds* bounds, int n_q, const float* q_u, const float* q_v, const float* q_ur,
                              const float* q_radius, const int32_t* q_min_level, const int32_t* q_max_level,
@@ -749,16 +775,12 @@ int ivf_frame_grid(const ivf_frame* f, int32_t* cell_start, int32_t* cell_index)
     return IVF_OK;
 }
 
-int ivf_frame_search_by_projection(ivf_frame* f, int n_q, const float* q_u, const float* q_v, const float* q_ur,
-                                   const float* q_radius, const int32_t* q_min_level, const int32_t* q_max_level,
-                                   const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid, const uint8_t* q_blocks,
-                                   int check_orientation, int32_t* cur_assign, int* nmatches)
+// windows (GetFeaturesInArea) and distances (DescriptorDistance) of every query against the resident frame, on the device:
+// candidates of query i = cand / dist [qStart[i] .. qStart[i+1]) in the reference's order
+static int frame_candidates(ivf_frame* f, int n_q, const float* q_u, const float* q_v, const float* q_radius,
+                            const int32_t* q_min_level, const int32_t* q_max_level, const uint8_t* q_desc, const uint8_t* q_valid,
+                            std::vector<int>& qStart, std::vector<int>& cand, std::vector<int>& dist)
 {
-    if (!f || !cur_assign || !nmatches || n_q < 0) return fail(IVF_E_INVALID, "bad argument");
-    *nmatches = 0;
-    if (n_q == 0 || f->n == 0) return IVF_OK;
-    if (!q_u || !q_v || !q_ur || !q_radius || !q_min_level || !q_max_level || !q_angle || !q_desc)
-        return fail(IVF_E_INVALID, "null query array");
     HIPCHK(hipSetDevice(f->device));
     static const int capEnv = getenv("IVF_FRAME_WINDOW_CAP") ? atoi(getenv("IVF_FRAME_WINDOW_CAP")) : 0;   // tests: force the overflow path
     const int cap = capEnv > 0 ? capEnv : 128;
@@ -781,7 +803,6 @@ int ivf_frame_search_by_projection(ivf_frame* f, int n_q, const float* q_u, cons
     HIPCHK(hipMemcpyAsync(f->dQmax, q_max_level, nq * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(f->dQdesc, q_desc, nq * 32, hipMemcpyHostToDevice, st));
     if (q_valid) HIPCHK(hipMemcpyAsync(f->dQvalid, q_valid, nq, hipMemcpyHostToDevice, st));
-    // 1 + 2. GetFeaturesInArea windows and DescriptorDistance of every candidate, on the device (:1429-1461)
     launch_grid_window(f->dKps, f->dDesc, f->dStart, f->dIdx, f->bd.min_x, f->bd.min_y, f->invW, f->invH, n_q, f->dQu, f->dQv, f->dQr,
                        f->dQmin, f->dQmax, f->dQdesc, q_valid ? f->dQvalid : nullptr, f->cCap, f->dCount, f->dCand, st);
     HIPCHK(hipGetLastError());
@@ -789,7 +810,7 @@ int ivf_frame_search_by_projection(ivf_frame* f, int n_q, const float* q_u, cons
     HIPCHK(hipMemcpyAsync(count.data(), f->dCount, nq * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(raw.data(), f->dCand, nq * f->cCap * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    std::vector<int> qStart(n_q + 1, 0), cand, dist;
+    qStart.assign(n_q + 1, 0); cand.clear(); dist.clear();
     Grid g; bool haveGrid = false;
     for (int i = 0; i < n_q; i++) {
         qStart[i] = (int)cand.size();
@@ -804,9 +825,42 @@ int ivf_frame_search_by_projection(ivf_frame* f, int n_q, const float* q_u, cons
     }
     qStart[n_q] = (int)cand.size();
     if (cand.empty()) { cand.push_back(0); dist.push_back(0); }
-    // 3. greedy assignment + rotation histogram on the host (:1444-1511)
+    return IVF_OK;
+}
+
+int ivf_frame_search_by_projection(ivf_frame* f, int n_q, const float* q_u, const float* q_v, const float* q_ur,
+                                   const float* q_radius, const int32_t* q_min_level, const int32_t* q_max_level,
+                                   const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid, const uint8_t* q_blocks,
+                                   int check_orientation, int32_t* cur_assign, int* nmatches)
+{
+    if (!f || !cur_assign || !nmatches || n_q < 0) return fail(IVF_E_INVALID, "bad argument");
+    *nmatches = 0;
+    if (n_q == 0 || f->n == 0) return IVF_OK;
+    if (!q_u || !q_v || !q_ur || !q_radius || !q_min_level || !q_max_level || !q_angle || !q_desc)
+        return fail(IVF_E_INVALID, "null query array");
+    std::vector<int> qStart, cand, dist;
+    int rc = frame_candidates(f, n_q, q_u, q_v, q_radius, q_min_level, q_max_level, q_desc, q_valid, qStart, cand, dist);
+    if (rc) return rc;
+    // greedy assignment + rotation histogram on the host (:1444-1511)
     *nmatches = replay_projection(f->kps.data(), f->uright.data(), n_q, q_ur, q_radius, q_angle, q_blocks, check_orientation, qStart,
                                   cand, dist, cur_assign);
+    return IVF_OK;
+}
+
+int ivf_frame_search_map_points(ivf_frame* f, int n_q, const float* q_u, const float* q_v, const float* q_ur, const float* q_radius,
+                                const int32_t* q_level, const uint8_t* q_desc, const uint8_t* q_valid, const uint8_t* q_blocks,
+                                float nn_ratio, int32_t* cur_assign, int* nmatches)
+{
+    if (!f || !cur_assign || !nmatches || n_q < 0) return fail(IVF_E_INVALID, "bad argument");
+    *nmatches = 0;
+    if (n_q == 0 || f->n == 0) return IVF_OK;
+    if (!q_u || !q_v || !q_ur || !q_radius || !q_level || !q_desc) return fail(IVF_E_INVALID, "null query array");
+    std::vector<int32_t> lo(n_q), hi(n_q);
+    for (int i = 0; i < n_q; i++) { lo[i] = q_level[i] - 1; hi[i] = q_level[i]; }       // levels [pred - 1, pred] (:72-73)
+    std::vector<int> qStart, cand, dist;
+    int rc = frame_candidates(f, n_q, q_u, q_v, q_radius, lo.data(), hi.data(), q_desc, q_valid, qStart, cand, dist);
+    if (rc) return rc;
+    *nmatches = replay_map_points(f->kps.data(), f->uright.data(), n_q, q_ur, q_radius, q_blocks, nn_ratio, qStart, cand, dist, cur_assign);
     return IVF_OK;
 }
 
@@ -838,23 +892,9 @@ int ivf_search_map_points(const ivf_keypoint* cur_kps, const uint8_t* cur_desc, 
     int rc = ivf_hamming_pairs(q_desc, n_q, cur_desc, n_cur, pairs.data(), nPairs, dist.data(), device_id);
     if (rc) return rc;
     // 3. best / second best + ratio test, greedy in map-point order (:86-126)
-    int nm = 0;
-    for (int i = 0; i < n_q; i++) {
-        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
-        for (int p = qStart[i]; p < qStart[i + 1]; p++) {
-            const int idx = pairs[2 * p + 1];
-            if (cur_assign[idx] == -2) continue;
-            if (cur_assign[idx] >= 0 && (!q_blocks || q_blocks[cur_assign[idx]])) continue;
-            if (cur_uright[idx] > 0) { const float er = fabsf(q_ur[i] - cur_uright[idx]); if (er > q_radius[i]) continue; }
-            const int d = dist[p];
-            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = cur_kps[idx].octave; bestIdx = idx; }
-            else if (d < bestDist2) { bestLevel2 = cur_kps[idx].octave; bestDist2 = d; }
-        }
-        if (bestIdx >= 0 && bestDist <= 100) {
-            if (bestLevel == bestLevel2 && (float)bestDist > nn_ratio * (float)bestDist2) continue;
-            cur_assign[bestIdx] = i; nm++;
-        }
-    }
+    std::vector<int> cand(std::max(nPairs, 1));
+    for (int p = 0; p < nPairs; p++) cand[p] = pairs[2 * p + 1];
+    const int nm = replay_map_points(cur_kps, cur_uright, n_q, q_ur, q_radius, q_blocks, nn_ratio, qStart, cand, dist, cur_assign);
     *nmatches = nm;
     return IVF_OK;
 }

@@ -418,3 +418,16 @@ class DeviceFrame:
                                                        ptr(qq["valid"]), ptr(qq["blocks"]), int(bool(check_orientation)), ptr(assign),
                                                        C.byref(nm)))
         return assign, nm.value
+
+    def SearchByProjectionMapPoints(self, q, nn_ratio=0.6, cur_assign=None):
+        """Same queries and results as ORBmatcher(nn_ratio).SearchByProjectionMapPoints(cur_kps, cur_desc, cur_uright, bounds, q)."""
+        n_q = len(q["u"])
+        assign = np.full(self.n, -1, np.int32) if cur_assign is None else np.ascontiguousarray(cur_assign, np.int32).copy()
+        types = dict(u=np.float32, v=np.float32, ur=np.float32, radius=np.float32, level=np.int32, desc=np.uint8,
+                     valid=np.uint8, blocks=np.uint8)
+        qq = {k: np.ascontiguousarray(q[k], t) for k, t in types.items()}
+        nm = C.c_int(0)
+        check(self._lib.ivf_frame_search_map_points(self._h, n_q, ptr(qq["u"]), ptr(qq["v"]), ptr(qq["ur"]), ptr(qq["radius"]),
+                                                    ptr(qq["level"]), ptr(qq["desc"]), ptr(qq["valid"]), ptr(qq["blocks"]),
+                                                    float(nn_ratio), ptr(assign), C.byref(nm)))
+        return assign, nm.value

@@ -79,6 +79,19 @@ def test_search_by_projection_on_resident_frame(iv):
         assert hn == gn and np.array_equal(ha, ga)
 
 
+def test_search_map_points_on_resident_frame(iv):
+    for seed, n, radius in ((21, 600, 4.0), (22, 1200, 10.0)):
+        kps, desc, uright, bounds, q, pre = _case(iv, seed, n, radius=radius)
+        rng = np.random.default_rng(seed)
+        qm = dict(u=q["u"], v=q["v"], ur=q["ur"], radius=q["radius"], level=np.clip(kps["octave"] + rng.integers(-1, 2, len(kps)), 0, 7).astype(np.int32),
+                  desc=q["desc"], valid=q["valid"], blocks=q["blocks"])
+        f = iv.DeviceFrame(kps, desc, uright, bounds)
+        for ratio in (0.6, 0.8, 1.0):
+            ga, gn = f.SearchByProjectionMapPoints(qm, ratio, pre)
+            oa, on = O.search_map_points(kps, desc, uright, bounds, qm, ratio, pre)
+            assert gn == on and np.array_equal(ga, oa), (seed, ratio)
+
+
 _OVERFLOW = r"""
 import sys, os
 sys.path.insert(0, os.path.join(%r, "tests")); sys.path.insert(0, %r)
