@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU")
+    ap.add_argument("--pairs", type=int, default=128, help="stereo pairs per step per GPU")
     ap.add_argument("--stream", type=int, default=256, help="distinct pairs resident per GPU")
     ap.add_argument("--introspect", action="store_true", help="(default) configs[2]: run the introspection FCN on every left image and gate keypoints with it")
     ap.add_argument("--no-introspect", action="store_true", help="configs[1]: extract + match only")
