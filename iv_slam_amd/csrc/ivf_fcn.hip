@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(256) void k_fcn_conv3x3(const float* __restrict__ X
 // fragments in LDS (Cin/16 * PXT * 2 KB), and its four waves then walk the output-channel tiles (wave w: tiles w, w+4,
 // ...) with A fragments streamed from L2 and B fragments read from LDS: no redundant split VALU, no B re-reads from L2,
 // and the kernel is left with its HBM write stream.
-template <int PXT, int KS>
+template <int PXT, int KS, int RDEPTH = 0>
 __global__ __launch_bounds__(256, 2) void k_fcn_expand(const float* __restrict__ X, const uint4* __restrict__ Wq,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    float* __restrict__ Y, int Cin, int Cout, int HW, int nTiles)
@@ -1290,7 +1290,7 @@ __global__ __launch_bounds__(256, 2) void k_fcn_expand(const float* __restrict__
     // steps of the next tile are therefore issued BEFORE this tile's epilogue stores: on gfx9 loads and stores share
     // the in-order vmcnt, so a load issued behind 16 stores would wait for their write acknowledgements.  The tile
     // body stays branch-free (counted vmcnt waits instead of drains at control-flow joins).
-    constexpr int RD = KS / 2;
+    constexpr int RD = RDEPTH ? KS : KS / 2;       // RDEPTH: a slot per K step -- every refill is for the NEXT tile (see launch_expand)
     static_assert(KS % RD == 0, "ring slots must repeat per tile");
     const int myTiles = (nTiles - wave + 3) / 4;
     uint4 ring[RD][2];
@@ -1800,8 +1800,18 @@ bool launch_expand(const Gemm& g, const float* X, float* Y, int H, int W, int B,
     if ((size_t)K16 * pxt * 2048 > (bigLds ? 80 : 64) * 1024) pxt = 2;
     if (HW % (32 * pxt)) return false;
     const size_t lds = (size_t)K16 * pxt * 2048;
-#define EXPAND(P, KSV) hipLaunchKernelGGL((k_fcn_expand<P, KSV>), dim3(HW / (32 * P), 1, B), dim3(256), lds, s, X, g.dWq, \
-                                          g.dScale, g.dShift, Y, g.cin, g.cout, HW, g.nTiles)
+    // full-depth A ring (a register slot per K step: every refill belongs to the NEXT tile and is issued before this
+    // tile's epilogue stores, so no wait for a fragment ever has to outlast those stores -- loads and stores share the
+    // in-order vmcnt); IVF_FCN_EXPAND_RING=0 selects the half-depth ring
+    static const bool fullRing = !(getenv("IVF_FCN_EXPAND_RING") && atoi(getenv("IVF_FCN_EXPAND_RING")) == 0);
+    static const bool bigLdsR = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_expand<4, 10, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+    }();
+#define EXPAND(P, KSV) do { if (fullRing && bigLdsR && KSV == 10)        /* measured: 329 -> 314 us at 10 K steps, no gain at 4 / 6 */                                                                          \
+        hipLaunchKernelGGL((k_fcn_expand<P, KSV, 1>), dim3(HW / (32 * P), 1, B), dim3(256), lds, s, X, g.dWq, g.dScale, g.dShift, Y, g.cin,   \
+                           g.cout, HW, g.nTiles);                                                                             \
+    else hipLaunchKernelGGL((k_fcn_expand<P, KSV, 0>), dim3(HW / (32 * P), 1, B), dim3(256), lds, s, X, g.dWq, g.dScale, g.dShift, Y,       \
+                            g.cin, g.cout, HW, g.nTiles); } while (0)
     if (pxt == 4 && K16 == 4) EXPAND(4, 4);
     else if (pxt == 4 && K16 == 6) EXPAND(4, 6);
     else if (pxt == 4 && K16 == 10) EXPAND(4, 10);
