@@ -1302,37 +1302,30 @@ __global__ __launch_bounds__(256, 2) void k_fcn_expand(const float* __restrict__
 #pragma unroll
         for (int d = 0; d < RD; d++) aload(0, d, ring[d]);
     }
-    for (int it = 0; it < myTiles; it++) {
-        const int n = wave + 4 * it;
-        int sl = lane;                              // opaque per tile: keeps the B fragment reads inside the tile loop
-        asm volatile("" : "+v"(sl));                // (hoisted, they would pin KS*PXT*8 registers and spill)
-        f32x16 acc[PXT];
+    // The epilogue of tile it-1 (BN, ReLU6, 16 row stores) is spread over the K steps of tile it: inside ONE wave the
+    // stores then overlap the MFMAs, whatever phase the other wave of the SIMD is in (two waves that both alternate
+    // K loop / epilogue fall into lock step: the 160-channel expansion measured 122 us of matrix pipe + 190 us of
+    // stores = 312 us, i.e. no overlap at all).  Two accumulator sets alternate; the tile loop is unrolled by two.
+    auto kstep = [&](int it, int s, int sl, f32x16 (&acc)[PXT]) {
+        HFrag ah, al;
+        ah.q = ring[s % RD][0]; al.q = ring[s % RD][1];
+        if (s + RD < KS) aload(it, s + RD, ring[s % RD]); else aload(it + 1, s + RD - KS, ring[s % RD]);
+        HFrag bh[PXT], bl[PXT];
 #pragma unroll
-        for (int p = 0; p < PXT; p++)
+        for (int pt = 0; pt < PXT; pt++) { bh[pt].q = sB[((s * PXT + pt) * 2 + 0) * 64 + sl]; bl[pt].q = sB[((s * PXT + pt) * 2 + 1) * 64 + sl]; }
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[p][r] = 0.f;
+        for (int pt = 0; pt < PXT; pt++) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, bh[pt].v, acc[pt], 0, 0, 0);
 #pragma unroll
-        for (int s = 0; s < KS; s++) {
-            HFrag ah, al;
-            ah.q = ring[s % RD][0]; al.q = ring[s % RD][1];
-            if (s + RD < KS) aload(it, s + RD, ring[s % RD]); else aload(it + 1, s + RD - KS, ring[s % RD]);
-            HFrag bh[PXT], bl[PXT];
+        for (int pt = 0; pt < PXT; pt++) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bl[pt].v, acc[pt], 0, 0, 0);
 #pragma unroll
-            for (int pt = 0; pt < PXT; pt++) { bh[pt].q = sB[((s * PXT + pt) * 2 + 0) * 64 + sl]; bl[pt].q = sB[((s * PXT + pt) * 2 + 1) * 64 + sl]; }
-#pragma unroll
-            for (int pt = 0; pt < PXT; pt++) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, bh[pt].v, acc[pt], 0, 0, 0);
-#pragma unroll
-            for (int pt = 0; pt < PXT; pt++) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bl[pt].v, acc[pt], 0, 0, 0);
-#pragma unroll
-            for (int pt = 0; pt < PXT; pt++) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bh[pt].v, acc[pt], 0, 0, 0);
-        }
+        for (int pt = 0; pt < PXT; pt++) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bh[pt].v, acc[pt], 0, 0, 0);
+    };
+    auto store_rows = [&](int n, int r0, int r1, const f32x16 (&acc)[PXT], const float4 (&sc4)[4], const float4 (&sh4)[4]) {
         const int cb = n * 32 + 4 * kg;
-        float4 sc4[4], sh4[4];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(scale + cb + 8 * g4); sh4[g4] = *(const float4*)(shift + cb + 8 * g4); }
         float* yb = Y + ((size_t)b * Cout + cb) * HW + p0;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
+            if (r < r0 || r >= r1) continue;
             const int ro = (r & 3) + 8 * (r >> 2);
             if (cb + ro >= Cout) continue;
             const float sc = vget<4>(sc4[r >> 2], r & 3), sh = vget<4>(sh4[r >> 2], r & 3);
@@ -1343,6 +1336,45 @@ __global__ __launch_bounds__(256, 2) void k_fcn_expand(const float* __restrict__
             if constexpr (PXT == 4) *(float4*)yo = make_float4(o[0], o[1], o[2], o[3]);
             else *(float2*)yo = make_float2(o[0], o[1]);
         }
+    };
+    auto load_bn = [&](int n, float4 (&sc4)[4], float4 (&sh4)[4]) {
+        const int cb = n * 32 + 4 * kg;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(scale + cb + 8 * g4); sh4[g4] = *(const float4*)(shift + cb + 8 * g4); }
+    };
+    // one tile: K loop into `cur`, with the epilogue of the previous tile (accumulators `prev`) folded in
+    auto tile = [&](int it, f32x16 (&cur)[PXT], const f32x16 (&prev)[PXT], bool havePrev) {
+        int sl = lane;                              // opaque per tile: keeps the B fragment reads inside the tile loop
+        asm volatile("" : "+v"(sl));                // (hoisted, they would pin KS*PXT*8 registers and spill)
+#pragma unroll
+        for (int p = 0; p < PXT; p++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) cur[p][r] = 0.f;
+        float4 sc4[4], sh4[4];
+        const int nPrev = wave + 4 * (it - 1);
+        if (havePrev) load_bn(nPrev, sc4, sh4);
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            kstep(it, s, sl, cur);
+            if (havePrev) store_rows(nPrev, 16 * s / KS, 16 * (s + 1) / KS, prev, sc4, sh4);
+        }
+    };
+    f32x16 accA[PXT], accB[PXT];
+    int it = 0;
+    if (myTiles > 0) { tile(0, accA, accB, false); it = 1; }
+    for (; it + 1 < myTiles; it += 2) {
+        tile(it, accB, accA, true);
+        tile(it + 1, accA, accB, true);
+    }
+    if (it < myTiles) {                             // even tile count: one more tile into B, then B is the last one
+        tile(it, accB, accA, true);
+        float4 sc4[4], sh4[4];
+        load_bn(wave + 4 * it, sc4, sh4);
+        store_rows(wave + 4 * it, 0, 16, accB, sc4, sh4);
+    } else if (myTiles > 0) {
+        float4 sc4[4], sh4[4];
+        load_bn(wave + 4 * (myTiles - 1), sc4, sh4);
+        store_rows(wave + 4 * (myTiles - 1), 0, 16, accA, sc4, sh4);
     }
 }
 
@@ -1800,14 +1832,14 @@ bool launch_expand(const Gemm& g, const float* X, float* Y, int H, int W, int B,
     if ((size_t)K16 * pxt * 2048 > (bigLds ? 80 : 64) * 1024) pxt = 2;
     if (HW % (32 * pxt)) return false;
     const size_t lds = (size_t)K16 * pxt * 2048;
-    // full-depth A ring (a register slot per K step: every refill belongs to the NEXT tile and is issued before this
-    // tile's epilogue stores, so no wait for a fragment ever has to outlast those stores -- loads and stores share the
-    // in-order vmcnt); IVF_FCN_EXPAND_RING=0 selects the half-depth ring
-    static const bool fullRing = !(getenv("IVF_FCN_EXPAND_RING") && atoi(getenv("IVF_FCN_EXPAND_RING")) == 0);
+    // IVF_FCN_EXPAND_RING=1: full-depth A ring (a register slot per K step: every refill belongs to the NEXT tile).  It
+    // helped the un-pipelined tile loop at 10 K steps (329 -> 314 us); with the epilogue folded into the next tile's K
+    // loop the second accumulator set leaves no room for it (77 spills, 424 us), so the half-depth ring is the default.
+    static const bool fullRing = getenv("IVF_FCN_EXPAND_RING") && atoi(getenv("IVF_FCN_EXPAND_RING")) == 1;
     static const bool bigLdsR = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_expand<4, 10, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
     }();
-#define EXPAND(P, KSV) do { if (fullRing && bigLdsR && KSV == 10)        /* measured: 329 -> 314 us at 10 K steps, no gain at 4 / 6 */                                                                          \
+#define EXPAND(P, KSV) do { if (fullRing && bigLdsR && KSV == 10)                                                                          \
         hipLaunchKernelGGL((k_fcn_expand<P, KSV, 1>), dim3(HW / (32 * P), 1, B), dim3(256), lds, s, X, g.dWq, g.dScale, g.dShift, Y, g.cin,   \
                            g.cout, HW, g.nTiles);                                                                             \
     else hipLaunchKernelGGL((k_fcn_expand<P, KSV, 0>), dim3(HW / (32 * P), 1, B), dim3(256), lds, s, X, g.dWq, g.dScale, g.dShift, Y,       \
