@@ -841,313 +841,6 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
     }
 }
 
-// ---- a whole inverted-residual block for the small-Cin stages (Cin, Cout <= 32, dilation 1, stride S) ----
-//   x -> [1x1 expand + BN + ReLU6] -> 3x3 depthwise (stride S, pad 1) + BN + ReLU6 -> 1x1 project + BN (+ x)
-// At 256x256 / 128x128 the hidden tensor (6x the block's input) dominated the network's HBM traffic; here it never leaves
-// the CU.  A workgroup owns a TOH x 32 output tile.  It stages the input tile with its halo ONCE as f16 hi/lo MFMA B
-// fragments (sX); then, per 32 hidden channels: the four waves expand them over the haloed tile on the MFMA into LDS
-// (sH, f32, zero outside the image = the depthwise zero padding), all threads run the 3x3 stencil out of LDS into sD, and
-// the waves feed sD (split into f16 hi/lo on the fly) to the projection MFMAs, accumulating the block's output tile
-// in registers across the chunks.  EXP = false: expansion ratio 1 (first block), sH is the input tile itself.
-// KNOWN ISSUE (gfx950, ROCm 7.2): two CO-RESIDENT workgroups of this kernel corrupt each other's results -- output
-// differs from run to run as soon as the grid is large enough for two of them to share a CU, with any amount of LDS slack
-// (50..80 KB per workgroup, static or dynamic), with extra barriers after every phase, with a full s_waitcnt after the
-// constant prefetch and with all waves kept alive to the end; a SINGLE 32-channel chunk is clean, two or more are not;
-// one workgroup per CU is bit-exact and deterministic at every batch size.  Localisation so far (IVF_FCN_BLOCK_XBAR bits,
-// each publishing a per-thread checksum instead of the block output): the expansion results written to sH are
-// deterministic (64), so are the prefetched depthwise parameters before (512) and after (2048) the stencil, and the
-// stencil with unit weights (256|32); the stencil's OUTPUT is not -- even with constant inputs instead of LDS reads
-// (1024|32), with private copies of the weights (4096), with the weights loaded from global memory at their point of use
-// (16384; their checksum, 16384|512, is again deterministic), with sleeps + nops around the MFMA phases (8192) and with
-// scalar instead of packed FMAs.  (The checksum runs leave most of the block's output unwritten, i.e. stale.)  Declared VGPR / SGPR
-// counts match the ISA, there is no scratch, only ds_* LDS instructions, and the barrier protocol is the one
-// k_fcn_dwpw uses.  The cause was not found.  Until it is, the launcher
-// adds 40 KB of unused dynamic LDS so that a CU never holds two of them (IVF_FCN_BLOCK_CORESIDENT=1 lifts that for
-// debugging; IVF_FCN_BLOCK_XBAR holds the experiment switches), which costs the occupancy the kernel was designed
-// around -- see the measured default in launch_block.
-template <int S> struct BlockGeom {
-    static constexpr int TOH = S == 1 ? 2 : 1, IWq = 32 * S + (S == 1 ? 2 : 1), IH = TOH * S + (S == 1 ? 2 : 1);
-    static constexpr int INPX = IH * IWq, NPT = (INPX + 31) / 32, HP = NPT * 32 + 4, OUTPX = TOH * 32, DP = OUTPX + 4;
-};
-
-template <int S, int K16e>          // K16e: K steps of the expansion (ceil(Cin/16)); 0 = no expansion
-__global__ __launch_bounds__(256, 2) void k_fcn_block(const float* __restrict__ X, const uint4* __restrict__ W1q,
-                                                  const float* __restrict__ sc1, const float* __restrict__ sh1,
-                                                  const float* __restrict__ dwP, const uint4* __restrict__ W2q,
-                                                  const float* __restrict__ sc2, const float* __restrict__ sh2,
-                                                  const float* __restrict__ res, float* __restrict__ Y, int Cin, int hidp,
-                                                  int Cout, int H, int W, int Ho, int Wo, int nT1, int nT2, int xbar)
-{
-    typedef BlockGeom<S> G;
-    constexpr int TOH = G::TOH, IWq = G::IWq, INPX = G::INPX, NPT = G::NPT, HP = G::HP, OUTPX = G::OUTPX, DP = G::DP;
-    constexpr int MYPT = (NPT + 3) / 4;             // expansion pixel tiles per wave
-    constexpr bool EXP = K16e > 0;
-    __shared__ __attribute__((aligned(16))) uint4 sX[EXP ? K16e * NPT * 128 : 1];   // [(st*NPT + pt)*2 + part][64]
-    __shared__ __attribute__((aligned(16))) float sH[32 * HP];                       // [32][HP]
-    __shared__ __attribute__((aligned(16))) float sD[32 * DP];                       // [32][DP]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 5, col = lane & 31;
-    const int b = blockIdx.z, ox0 = blockIdx.x * 32, oy0 = blockIdx.y * TOH;
-    const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1;
-    const size_t HWi = (size_t)H * W;
-    const float* Xb = X + (size_t)b * Cin * HWi;
-
-    // ---- phase 0: the input tile.  All loads of a thread are issued before the first one is consumed.
-    if constexpr (EXP) {
-        constexpr int NSL = (K16e * NPT * 64 + 255) / 256;
-        float v[NSL][8];
-#pragma unroll
-        for (int it = 0; it < NSL; it++) {
-            const int slot = tid + 256 * it;
-            const int sl = slot & 63, pt = (slot >> 6) % NPT, st = (slot >> 6) / NPT;
-            const int q = 32 * pt + (sl & 31), r = q / IWq, c = q - r * IWq;
-            const int gy = iy0 + r, gx = ix0 + c;
-            const bool ok = st < K16e && q < INPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const float* P = Xb + (ok ? (size_t)gy * W + gx : 0);
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int ch = 16 * st + 8 * (sl >> 5) + j;
-                const float t = P[(size_t)min(ch, Cin - 1) * HWi];
-                v[it][j] = (ok && ch < Cin) ? t : 0.f;
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < NSL; it++) {
-            const int slot = tid + 256 * it;
-            const int sl = slot & 63, pt = (slot >> 6) % NPT, st = (slot >> 6) / NPT;
-            if (st < K16e) {
-                HFrag h, l;
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) split_pair(v[it][2 * jj], v[it][2 * jj + 1], h.u[jj], l.u[jj]);
-                sX[((st * NPT + pt) * 2 + 0) * 64 + sl] = h.q;
-                sX[((st * NPT + pt) * 2 + 1) * 64 + sl] = l.q;
-            }
-        }
-    } else {
-        constexpr int NIT = (32 * INPX + 255) / 256;
-        float t[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int i = min(tid + 256 * it, 32 * INPX - 1);
-            const int ch = i / INPX, q = i - ch * INPX, r = q / IWq, c = q - r * IWq;
-            const int gy = iy0 + r, gx = ix0 + c;
-            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W && ch < Cin;
-            const float x = Xb[(ok ? (size_t)ch * HWi + (size_t)gy * W + gx : 0)];
-            t[it] = ok ? x : 0.f;
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int i = tid + 256 * it;
-            if (i < 32 * INPX) { const int ch = i / INPX, q = i - ch * INPX; sH[ch * HP + q] = t[it]; }
-        }
-    }
-    // in-image mask of this lane's pixel in each of its expansion tiles (the depthwise pads the HIDDEN map with zeros)
-    float pm[MYPT];
-#pragma unroll
-    for (int i = 0; i < MYPT; i++) {
-        const int q = 32 * (wave + 4 * i) + col, r = q / IWq, c = q - r * IWq;
-        const int gy = iy0 + r, gx = ix0 + c;
-        pm[i] = (q < INPX && gy >= 0 && gy < H && gx >= 0 && gx < W) ? 1.f : 0.f;
-    }
-    // stencil role: one hidden channel of the chunk, a run of output pixels
-    const int chl = tid >> 3, seg = tid & 7;
-    constexpr int NOUT = TOH * 32 / 8, NIN = (NOUT - 1) * S + 3;     // 8 threads per channel
-    const int sr = seg * NOUT / 32;                                  // output row of the tile
-    const int sc0 = seg * NOUT % 32;                                 // first output column
-    f32x16 accO;
-#pragma unroll
-    for (int q = 0; q < 16; q++) accO[q] = 0.f;
-    float dbgSum = 0.f;
-    __syncthreads();
-
-    // per-chunk constants (expansion / projection A fragments, this thread's depthwise parameters) are fetched one
-    // chunk ahead into registers; a chunk is only a few thousand cycles long, a fetch at its point of use would
-    // expose the L2 latency three times per chunk
-    struct Pre { uint4 w1[EXP ? K16e : 1][2], w2[2][2]; float4 p[3]; };
-    const int nChunks = (xbar & 8) ? 1 : hidp / 32;
-    auto fetch = [&](Pre& P, int ck) {
-        ck = min(ck, nChunks - 1);
-#pragma unroll
-        for (int st = 0; st < K16e; st++) {
-            P.w1[st][0] = W1q[(((size_t)st * nT1 + ck) * 2 + 0) * 64 + lane];
-            P.w1[st][1] = W1q[(((size_t)st * nT1 + ck) * 2 + 1) * 64 + lane];
-        }
-#pragma unroll
-        for (int st = 0; st < 2; st++) {
-            P.w2[st][0] = W2q[(((size_t)(2 * ck + st) * nT2) * 2 + 0) * 64 + lane];
-            P.w2[st][1] = W2q[(((size_t)(2 * ck + st) * nT2) * 2 + 1) * 64 + lane];
-        }
-        const float4* pp = reinterpret_cast<const float4*>(dwP + (size_t)(ck * 32 + chl) * 12);
-        P.p[0] = pp[0]; P.p[1] = pp[1]; P.p[2] = pp[2];
-    };
-    auto chunk = [&](const Pre& C, Pre& N, int ck) {
-        fetch(N, ck + 1);
-        if (xbar & 16) __builtin_amdgcn_s_waitcnt(0);
-        const float4 p0 = C.p[0], p1 = C.p[1], p2 = C.p[2];
-        if constexpr (EXP) {
-            // ---- phase 1: hidden[32 ch][haloed tile] = relu6(bn(W1 x)), zero outside the image
-            f32x16 acc[MYPT];
-#pragma unroll
-            for (int i = 0; i < MYPT; i++)
-#pragma unroll
-                for (int q = 0; q < 16; q++) acc[i][q] = 0.f;
-#pragma unroll
-            for (int st = 0; st < K16e; st++) {
-                HFrag ah, al;
-                ah.q = C.w1[st][0]; al.q = C.w1[st][1];
-#pragma unroll
-                for (int i = 0; i < MYPT; i++) {
-                    const int pt = wave + 4 * i;
-                    if (pt < NPT) {
-                        HFrag bh, bl;
-                        bh.q = sX[((st * NPT + pt) * 2 + 0) * 64 + lane];
-                        bl.q = sX[((st * NPT + pt) * 2 + 1) * 64 + lane];
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, bh.v, acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bl.v, acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bh.v, acc[i], 0, 0, 0);
-                    }
-                }
-            }
-            float4 s4[4], h4[4];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) {
-                s4[g4] = *(const float4*)(sc1 + ck * 32 + 4 * kg + 8 * g4);
-                h4[g4] = *(const float4*)(sh1 + ck * 32 + 4 * kg + 8 * g4);
-            }
-#pragma unroll
-            for (int i = 0; i < MYPT; i++) {
-                const int pt = wave + 4 * i;
-                if (pt < NPT) {
-#pragma unroll
-                    for (int q = 0; q < 16; q += 2) {
-                        const int ro = (q & 3) + 8 * (q >> 2) + 4 * kg;
-                        const v2f sc = (q & 2) ? (v2f){s4[q >> 2].z, s4[q >> 2].w} : (v2f){s4[q >> 2].x, s4[q >> 2].y};
-                        const v2f sh = (q & 2) ? (v2f){h4[q >> 2].z, h4[q >> 2].w} : (v2f){h4[q >> 2].x, h4[q >> 2].y};
-                        v2f v = __builtin_elementwise_fma((v2f){acc[i][q], acc[i][q + 1]}, sc, sh);
-                        v.x = __builtin_amdgcn_fmed3f(v.x, 0.f, 6.f); v.y = __builtin_amdgcn_fmed3f(v.y, 0.f, 6.f);
-                        v = v * (v2f){pm[i], pm[i]};
-                        if (xbar & 64) dbgSum += v.x + v.y;
-                        sH[ro * HP + 32 * pt + col] = v.x;
-                        sH[(ro + 1) * HP + 32 * pt + col] = v.y;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        // ---- phase 2: 3x3 depthwise + BN + ReLU6 out of LDS
-        if (xbar & 8192) { __builtin_amdgcn_s_sleep(8); asm volatile("s_nop 15\n s_nop 15"); }
-        {
-            float wk[9] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x};
-            if (xbar & 16384) {               // experiment: parameters loaded at their point of use, not through the prefetch sets
-                const float* pq = dwP + (size_t)(ck * 32 + chl) * 12;
-                for (int k = 0; k < 9; k++) wk[k] = pq[k];
-            }
-            if (xbar & 256) { for (int k = 0; k < 9; k++) wk[k] = 1.f; }      // experiment: parameters out of the picture
-            if (xbar & 512) { for (int k = 0; k < 9; k++) dbgSum += wk[k]; dbgSum += p2.y + p2.z; }
-            if (xbar & 4096) { for (int k = 0; k < 9; k++) asm volatile("" : "+v"(wk[k])); }     // experiment: private copies
-            v2f o[NOUT / 2];
-#pragma unroll
-            for (int i = 0; i < NOUT / 2; i++) o[i] = (v2f){0.f, 0.f};
-#pragma unroll
-            for (int ky = 0; ky < 3; ky++) {
-                // the row start is 8-byte aligned for S = 1 (34-float rows, even columns): 64-bit LDS reads
-                const float* row = sH + chl * HP + (sr * S + ky) * IWq + sc0 * S;
-                float in[NIN + 1];
-                if (xbar & 1024) {                // experiment: no LDS reads at all
-#pragma unroll
-                    for (int i = 0; i < NIN; i++) in[i] = 1.f + 0.001f * (float)(i + ky);
-                } else if (xbar & 128) {          // experiment: one plain ds_read_b32 per element (no ds_read2 / b64 merging)
-#pragma unroll
-                    for (int i = 0; i < NIN; i++) { const float* rp = row + i; asm volatile("" : "+v"(rp)); in[i] = *rp; }
-                } else if (S == 1) {
-#pragma unroll
-                    for (int i = 0; i < NIN; i += 2) { const float2 t = *(const float2*)(row + i); in[i] = t.x; in[i + 1] = t.y; }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NIN; i++) in[i] = row[i];
-                }
-#pragma unroll
-                for (int kx = 0; kx < 3; kx++) {
-                    const float w = wk[ky * 3 + kx];
-#pragma unroll
-                    for (int i = 0; i < NOUT; i += 2) {
-                        o[i / 2].x = __builtin_fmaf(in[i * S + kx], w, o[i / 2].x);
-                        o[i / 2].y = __builtin_fmaf(in[(i + 1) * S + kx], w, o[i / 2].y);
-                    }
-                }
-            }
-            float* dst = sD + chl * DP + sr * 32 + sc0;
-            if (xbar & 2048) { for (int k = 0; k < 9; k++) dbgSum += wk[k]; }                     // experiment: weights AFTER the FMAs
-            if (xbar & 32) {
-#pragma unroll
-                for (int i = 0; i < NOUT / 2; i++) dbgSum += o[i].x + o[i].y;
-            }
-            const v2f bs = (v2f){p2.y, p2.y}, bb = (v2f){p2.z, p2.z};
-#pragma unroll
-            for (int i = 0; i < NOUT; i += 4) {
-                const v2f a = __builtin_elementwise_fma(o[i / 2], bs, bb), c2 = __builtin_elementwise_fma(o[i / 2 + 1], bs, bb);
-                *(float4*)(dst + i) = make_float4(__builtin_amdgcn_fmed3f(a.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(a.y, 0.f, 6.f),
-                                                  __builtin_amdgcn_fmed3f(c2.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(c2.y, 0.f, 6.f));
-            }
-        }
-        __syncthreads();
-        // ---- phase 3: project the chunk's 32 hidden channels; wave w owns output row w of the tile
-        if (wave < TOH) {
-#pragma unroll
-            for (int st = 0; st < 2; st++) {
-                const float* dB = sD + (16 * st + 8 * kg) * DP + 32 * wave + col;
-                HFrag bh, bl, ah, al;
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) split_pair(dB[2 * jj * DP], dB[(2 * jj + 1) * DP], bh.u[jj], bl.u[jj]);
-                ah.q = C.w2[st][0];
-                al.q = C.w2[st][1];
-                accO = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, bh.v, accO, 0, 0, 0);
-                accO = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bl.v, accO, 0, 0, 0);
-                accO = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bh.v, accO, 0, 0, 0);
-            }
-        }
-        if (xbar & 8192) { __builtin_amdgcn_s_sleep(8); asm volatile("s_nop 15\n s_nop 15"); }
-        if (xbar & 1) __syncthreads();
-    };
-    Pre PA, PB;                                     // two constant sets alternate: no register copies per chunk
-    fetch(PA, 0);
-    for (int ck = 0; ck < nChunks; ck += 2) {
-        chunk(PA, PB, ck);
-        if (ck + 1 < nChunks) chunk(PB, PA, ck + 1);
-    }
-    if (xbar & (96 | 512 | 2048)) {                        // debug: publish the stencil sums instead of the block output
-        Y[((size_t)b * Cout + (tid >> 5)) * ((size_t)Ho * Wo) + (size_t)oy0 * Wo + ox0 + (tid & 31)] = dbgSum;
-        return;
-    }
-    if (xbar & 4) {                                 // debug: publish what phase 3 saw
-        if (wave < TOH) for (int q = 0; q < 16; q++) if (accO[q] != accO[q]) Y[0] = 1.f;
-    }
-    // ---- epilogue: BN (+ residual), rows = output channels, column = this lane's pixel of output row `wave`
-    if (wave < TOH) {
-        const size_t HWo = (size_t)Ho * Wo;
-        const size_t ob = (size_t)b * Cout * HWo + (size_t)(oy0 + wave) * Wo + ox0 + col;
-        float4 s4[4], h4[4];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; g4++) { s4[g4] = *(const float4*)(sc2 + 4 * kg + 8 * g4); h4[g4] = *(const float4*)(sh2 + 4 * kg + 8 * g4); }
-        float rv[16];
-        if (res) {
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int co = (q & 3) + 8 * (q >> 2) + 4 * kg;
-                if (co < Cout) rv[q] = res[ob + (size_t)co * HWo];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int co = (q & 3) + 8 * (q >> 2) + 4 * kg;
-            if (co >= Cout) continue;
-            float v = accO[q] * vget<4>(s4[q >> 2], q & 3) + vget<4>(h4[q >> 2], q & 3);
-            if (res) v += rv[q];
-            Y[ob + (size_t)co * HWo] = v;
-        }
-    }
-    if (xbar & 2) __syncthreads();
-}
-
 // ---- dense 3x3, pad 1, on a 64-wide map (decoder cbr: 320 -> 80 at 64x64) + BN + ReLU ----
 // A wave owns two image rows (128 pixels) and one 32-channel output tile; a lane holds four horizontally adjacent pixels
 // of eight input channels, so the 16 lanes of a DPP row span exactly one image row.  Per (dy, K step) the lane loads its
@@ -1774,50 +1467,6 @@ void launch_gemm(const Gemm& g, const float* X, const float* res, float* Y, int 
     else launch_gemm_t<2, 5, 1>(g, X, res, Y, H, W, B, s);
 }
 
-// whole-block kernel for the small-Cin stages; false = shape not covered, caller runs the layer-by-layer path
-bool launch_block(int index, const Gemm* ex, const Dw& d, const Gemm& pj, const float* X, const float* res, float* Y, int H, int W,
-                  int B, hipStream_t s)
-{
-    static const bool off = getenv("IVF_FCN_NOBLOCK") != nullptr;
-    static const unsigned mask = getenv("IVF_FCN_BLOCKMASK") ? (unsigned)strtoul(getenv("IVF_FCN_BLOCKMASK"), nullptr, 0) : 0u;   // off by default: at one workgroup per CU (see BlockGeom) it is slower than the layer-by-layer path
-    if (!(mask >> index & 1)) return false;
-    static const int xbar = getenv("IVF_FCN_BLOCK_XBAR") ? atoi(getenv("IVF_FCN_BLOCK_XBAR")) : 0;
-    const int cin = ex ? ex->cin : d.c, hid = d.c, hidp = (hid + 31) / 32 * 32;
-    const int Ho = (H - 1) / d.stride + 1, Wo = (W - 1) / d.stride + 1;
-    if (off || d.dil != 1 || cin > 32 || pj.cout > 32 || pj.taps != 1 || pj.nTiles != 1 || pj.act != 0 || (d.stride != 1 && d.stride != 2) ||
-        Wo % 32 || Ho % (d.stride == 1 ? 2 : 1) || (H % d.stride) || (W % d.stride))
-        return false;
-    if (ex && (ex->taps != 1 || ex->act != 1 || ex->nTiles * 32 != hidp)) return false;
-    if (!ex && hid != 32) return false;
-    const int K16e = ex ? (cin + 15) / 16 : 0;
-    static const bool attr = [] {
-        bool ok = true;
-        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_block<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
-        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_block<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
-        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_block<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
-        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_block<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
-        return ok;
-    }();
-    if (!attr) return false;
-    const uint4* w1 = ex ? ex->dWq : nullptr; const float* s1 = ex ? ex->dScale : nullptr; const float* h1 = ex ? ex->dShift : nullptr;
-    const int nT1 = ex ? ex->nTiles : 1;
-#define BLOCK(SV, EV)                                                                                                   \
-    do { typedef BlockGeom<SV> G;                                                                                       \
-         static const size_t pad = getenv("IVF_FCN_LDSPAD") ? (size_t)atoi(getenv("IVF_FCN_LDSPAD")) : 0;                \
-         size_t lds = (size_t)K16e * G::NPT * 2048 + (size_t)32 * G::HP * 4 + (size_t)32 * G::DP * 4 + pad;             \
-         static const bool co = getenv("IVF_FCN_BLOCK_CORESIDENT") != nullptr;                                          \
-         lds = co ? pad : (size_t)40 * 1024;             /* static LDS now; dynamic part only as occupancy limiter */       \
-         hipLaunchKernelGGL((k_fcn_block<SV, EV>), dim3(Wo / 32, Ho / G::TOH, B), dim3(256), lds, s, X, w1, s1, h1, d.dPack, \
-                            pj.dWq, pj.dScale, pj.dShift, res, Y, cin, hidp, pj.cout, H, W, Ho, Wo, nT1, pj.nTiles, xbar); } while (0)
-    if (!ex && d.stride == 1) BLOCK(1, 0);
-    else if (ex && d.stride == 1 && K16e == 2) BLOCK(1, 2);
-    else if (ex && d.stride == 2 && K16e == 1) BLOCK(2, 1);
-    else if (ex && d.stride == 2 && K16e == 2) BLOCK(2, 2);
-    else return false;
-#undef BLOCK
-    return true;
-}
-
 // expansion with the B tile stationary in LDS; false = not applicable, caller uses k_fcn_gemm
 bool launch_expand(const Gemm& g, const float* X, float* Y, int H, int W, int B, hipStream_t s)
 {
@@ -1944,7 +1593,7 @@ int make_gemm(ivf_fcn* f, const float* w, int cout, int cin, int taps, const std
     else { g.NT = std::min(tiles, ntBig); g.PT = ptBig; }
     g.nTiles = (tiles + g.NT - 1) / g.NT * g.NT;
     const int K16 = (cin + 15) / 16;
-    // one extra all-zero K step when K16 is odd: k_fcn_block consumes the projection in 32-channel chunks
+    // one extra all-zero K step when K16 is odd: k_fcn_irb / k_fcn_irb64 consume the projection in 32-channel chunks
     std::vector<float> wq((size_t)taps * (K16 + (taps == 1 ? (K16 & 1) : 0)) * g.nTiles * 2 * 64 * 4, 0.f);     // 8 f16 = 4 dwords per lane and part
     uint16_t* q = reinterpret_cast<uint16_t*>(wq.data());
     for (int tap = 0; tap < taps; tap++)
@@ -1987,11 +1636,10 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
     // whole-block kernels, bit i = block i + 2: blocks 2-4 (k_fcn_irb) by default; bits 3-9 = blocks 5-11 through k_fcn_irb64, which
     // is correct but measures slower than expand + dwpw there (337 vs 245 us for the 64->384->64 blocks): opt-in.  Off under the
     // layer-by-layer / other-kernel experiment switches
-    static const unsigned irbMask = (getenv("IVF_FCN_NOFUSE") || getenv("IVF_FCN_BLOCKMASK") || getenv("IVF_FCN_NOSTRIDE2")) ? 0u
+    static const unsigned irbMask = (getenv("IVF_FCN_NOFUSE") || getenv("IVF_FCN_NOSTRIDE2")) ? 0u
                                     : getenv("IVF_FCN_IRBMASK") ? (unsigned)strtoul(getenv("IVF_FCN_IRBMASK"), nullptr, 0) : 7u;
     // conv0 + block 1's depthwise layer in one kernel, unless an experiment switch asks for another kernel on block 1
-    static const bool stem = getenv("IVF_FCN_NOSTEM") == nullptr && getenv("IVF_FCN_WIDE256") == nullptr && getenv("IVF_FCN_NOFUSE") == nullptr &&
-                             !(getenv("IVF_FCN_BLOCKMASK") && (strtoul(getenv("IVF_FCN_BLOCKMASK"), nullptr, 0) & 1));
+    static const bool stem = getenv("IVF_FCN_NOSTEM") == nullptr && getenv("IVF_FCN_WIDE256") == nullptr && getenv("IVF_FCN_NOFUSE") == nullptr;
     if (stem) {
         const Dw& d0 = f->dw[0];
         hipLaunchKernelGGL(k_fcn_stem, dim3(kEnc / 2 / kStemTW, kEnc / 2 / kStemTH, n), dim3(512), 0, s, f->bufIn, f->dConv0W, f->dConv0S,
@@ -2042,18 +1690,6 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             snprintf(nm, sizeof nm, "block %d whole", i + 1); STAGE(nm);
             std::swap(x, y);
             continue;
-        }
-        {
-            const Gemm* ex = bk.t != 1 ? &f->pw[ip] : nullptr;
-            const Gemm& pj = f->pw[ip + (bk.t != 1 ? 1 : 0)];
-            if (launch_block(i, ex, f->dw[id], pj, x, bk.res ? x : nullptr, y, H, W, n, s)) {
-                ip += bk.t != 1 ? 2 : 1;
-                H = (H - 1) / f->dw[id].stride + 1; W = (W - 1) / f->dw[id].stride + 1;
-                id++;
-                snprintf(nm, sizeof nm, "block %d fused", i + 1); STAGE(nm);
-                std::swap(x, y);
-                continue;
-            }
         }
         if (bk.t != 1) {
             if (!launch_expand(f->pw[ip], x, f->bufH1, H, W, n, s)) launch_gemm(f->pw[ip], x, nullptr, f->bufH1, H, W, n, s);
@@ -2147,7 +1783,7 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
             if (!w || !read_bn(hid)) return bad();
             Dw d; d.c = hid; d.stride = bk.stride; d.dil = bk.dil;
             std::vector<float> hw(w, w + (size_t)hid * 9);
-            std::vector<float> pk((size_t)((hid + 31) / 32 * 32) * 12, 0.f);    // padded to whole 32-channel chunks (k_fcn_block)
+            std::vector<float> pk((size_t)((hid + 31) / 32 * 32) * 12, 0.f);    // padded to whole 32-channel chunks
             for (int c = 0; c < hid; c++) {
                 for (int q = 0; q < 9; q++) pk[(size_t)c * 12 + q] = w[(size_t)c * 9 + q];
                 pk[(size_t)c * 12 + 9] = sc[c]; pk[(size_t)c * 12 + 10] = sh[c];

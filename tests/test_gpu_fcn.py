@@ -104,9 +104,7 @@ print("OK %.3g" % err)
 @pytest.mark.parametrize("env", [
     {},                                                                        # the measured defaults
     # layer-by-layer fallbacks only: k_fcn_gemm for every 1x1 / 3x3, k_fcn_dw for every depthwise layer
-    {"IVF_FCN_NOBLOCK": "1", "IVF_FCN_NOFUSE": "1", "IVF_FCN_EXPAND": "0", "IVF_FCN_OLD3X3": "1"},
-    # every whole-block kernel variant on, including the ones the default leaves off because they measure slower
-    {"IVF_FCN_BLOCKMASK": "63"},
+    {"IVF_FCN_NOFUSE": "1", "IVF_FCN_EXPAND": "0", "IVF_FCN_OLD3X3": "1"},
     # 64-pixel expansion tiles
     {"IVF_FCN_EXPAND": "2"},
     # fused depthwise+projection also on the 256-wide map of block 1 (off by default: slower there)
@@ -118,7 +116,7 @@ print("OK %.3g" % err)
     {"IVF_FCN_IRBMASK": "0x3ff"},
     # ... and on none (blocks 2-4 through k_fcn_gemm + k_fcn_dwpw)
     {"IVF_FCN_IRBMASK": "0"},
-], ids=["default", "layerwise", "all-blocks-fused", "expand-pxt2", "dwpw-256", "no-stride2-fusion", "no-stem-fusion", "irb-blocks-2-11",
+], ids=["default", "layerwise", "expand-pxt2", "dwpw-256", "no-stride2-fusion", "no-stem-fusion", "irb-blocks-2-11",
         "irb-none"])
 def test_fcn_kernel_variants_match_goldens_and_are_deterministic(env):
     """The FCN picks between several kernels per layer (measured defaults, env overrides for tuning).  Every variant must

@@ -8,7 +8,7 @@ reports half the bytes of such streams (MI355X_MICROARCH.md, HBM section); other
 """
 import csv, json, sys, collections
 
-WIDE = ("k_fcn_dwpw", "k_fcn_gemm", "k_fcn_expand", "k_fcn_conv3x3", "k_fcn_dw<", "k_fcn_block", "k_fcn_irb<", "k_fcn_stem")
+WIDE = ("k_fcn_dwpw", "k_fcn_gemm", "k_fcn_expand", "k_fcn_conv3x3", "k_fcn_dw<", "k_fcn_irb<", "k_fcn_stem")
 
 
 def per_launch(path, counter):
