@@ -1,3 +1,5 @@
+"""Batch determinism of the FCN on the device: three forwards of the same IVF_B-image batch must be identical, and image 0
+must equal the single-image forward (the test that exposed co-residency defects in earlier whole-block kernels)."""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
@@ -15,5 +17,7 @@ for rep in range(3):
     c = torch.empty((B,) + tuple(out), dtype=torch.uint8, device=dev)
     f.forward_device(batch, cost_u8=c); torch.cuda.synchronize()
     outs.append(c.cpu().numpy())
-print("B=%d rep diffs per image:" % B, [(outs[0][i] != outs[1][i]).sum() + (outs[1][i] != outs[2][i]).sum() for i in range(B)],
-      " slot0 vs single:", (outs[0][0] != u8).sum())
+d = [int((outs[0][i] != outs[1][i]).sum() + (outs[1][i] != outs[2][i]).sum()) for i in range(B)]
+print("B=%d: pixels differing between repeats, summed over images: %d (max per image %d); image 0 vs single-image forward: %d"
+      % (B, sum(d), max(d), int((outs[0][0] != u8).sum())))
+sys.exit(1 if sum(d) or (outs[0][0] != u8).any() else 0)
