@@ -1332,6 +1332,169 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     }
 }
 
+// ---- k_fcn_dwpw with eight waves per workgroup (64 x 64 maps, stride 1) ----
+// k_fcn_dwpw<5, 4, 6, 1> covers 160 output channels per workgroup, so block 17 (320) ran it twice per pixel tile (grid
+// y = 2): the hidden tensor was read and the stencil computed twice.  Here a workgroup has EIGHT waves on the same 128 pixels
+// and splits the TT output tiles between two wave sets (each wave reads only its set's A fragments from LDS):
+// all 512 threads share the stencil of a 16-channel chunk (channel = tid >> 5, 4 adjacent pixels per thread; a DPP row of
+// 16 lanes is exactly one 64-pixel image row, so the dilation halo comes from the neighbour lanes and the DPP zero fill IS
+// the zero padding), wave w multiplies pixel tile (w & 3) against output tiles 5 (w >> 2) .. 5 (w >> 2) + 4.
+template <int DIL, int TT>
+__global__ __launch_bounds__(512, 2) void k_fcn_dwpw8(const float* __restrict__ X, const float* __restrict__ dwP,
+                                                     const uint4* __restrict__ Wq, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, const float* __restrict__ res,
+                                                     float* __restrict__ Y, int K, int Cout, int nTiles)
+{
+    static_assert(DIL == 1 || DIL == 2 || DIL == 4, "a tap at distance DIL is in this lane or the next one");
+    constexpr int kPitch = 132, Wd = 64, HW = Wd * Wd, WGPI = HW / 128, TILES = (TT + 1) / 2;     // TILES: output tiles per wave (set 0; set 1 has TT / 2)
+    __shared__ __attribute__((aligned(16))) float sD[2][16 * kPitch];
+    __shared__ __attribute__((aligned(16))) float sW[2][TT * 512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 5, col = lane & 31;
+    const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
+    const int b = L / WGPI, p128 = L % WGPI;
+    const int kc = tid >> 5, g = tid & 31;                      // channel of the chunk; 32 threads x 4 pixels = two image rows
+    const int y = 2 * p128 + (g >> 4), x0 = (g & 15) * 4;
+    int rowOff[3]; float rowM[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) {
+        const int yy = y + (ky - 1) * DIL;
+        const bool ok = yy >= 0 && yy < Wd;
+        rowM[ky] = ok ? 1.f : 0.f;
+        rowOff[ky] = (ok ? yy : y) * Wd + x0;
+    }
+    const float* Xb = X + (size_t)b * K * HW;
+    const float* Wf = (const float*)Wq;
+    const int nChunks = K / 16;                                 // even for every 64 x 64 block (12, 24, 36, 60)
+    struct Win { float4 r[3]; float par; };
+    const int parIdx = kc * 12 + min(g & 15, 11);               // the 16 lanes of a DPP row fetch the channel's 12 parameters
+    auto issue = [&](Win& S, int c) {
+        c = min(c, nChunks - 1);
+        const float* P = Xb + (size_t)(16 * c + kc) * HW;
+        S.par = dwP[c * 192 + parIdx];
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) S.r[ky] = *(const float4*)(P + rowOff[ky]);
+    };
+    static_assert(TT * 256 % 512 == 0, "whole rounds of the 512 threads stage the A fragments");
+    constexpr int NW = TT * 256 / 512;                          // float2 per thread per chunk
+    float2 wreg[NW];
+    auto issue_w = [&](int c) {
+        c = min(c, nChunks - 1);
+#pragma unroll
+        for (int j = 0; j < NW; j++) wreg[j] = *(const float2*)(Wf + (size_t)c * nTiles * 512 + (tid + 512 * j) * 2);
+    };
+    float o[4];
+    auto stencil = [&](const Win& S) {
+        const int pi = __builtin_bit_cast(int, S.par);
+#define ROW_SHARE(k) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, pi, 0x150 + (k), 0xF, 0xF, false))
+        float wk[9];
+        wk[0] = ROW_SHARE(0); wk[1] = ROW_SHARE(1); wk[2] = ROW_SHARE(2); wk[3] = ROW_SHARE(3); wk[4] = ROW_SHARE(4);
+        wk[5] = ROW_SHARE(5); wk[6] = ROW_SHARE(6); wk[7] = ROW_SHARE(7); wk[8] = ROW_SHARE(8);
+        const float dsc = ROW_SHARE(9), dsh = ROW_SHARE(10);
+#undef ROW_SHARE
+#pragma unroll
+        for (int p = 0; p < 4; p++) o[p] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+            const float w0 = wk[ky * 3] * rowM[ky], w1 = wk[ky * 3 + 1] * rowM[ky], w2 = wk[ky * 3 + 2] * rowM[ky];
+            const float own[4] = {S.r[ky].x, S.r[ky].y, S.r[ky].z, S.r[ky].w};
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                o[p] = __builtin_fmaf(own[p], w1, o[p]);
+                // a tap outside the thread's 4 pixels is a pixel of the left / right neighbour lane (zero past the ends of the
+                // image row: the DPP row IS the image row)
+                if (p - DIL >= 0) o[p] = __builtin_fmaf(own[p - DIL], w0, o[p]);
+                else asm("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(o[p]) : "v"(own[4 + p - DIL]), "v"(w0));
+                if (p + DIL < 4) o[p] = __builtin_fmaf(own[p + DIL], w2, o[p]);
+                else asm("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(o[p]) : "v"(own[p + DIL - 4]), "v"(w2));
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) o[p] = __builtin_amdgcn_fmed3f(__builtin_fmaf(o[p], dsc, dsh), 0.f, 6.f);
+    };
+    auto publish = [&](int buf) {
+        *(float4*)&sD[buf][kc * kPitch + 4 * g] = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int j = 0; j < NW; j++) *(float2*)&sW[buf][(tid + 512 * j) * 2] = wreg[j];
+    };
+    f32x16 acc[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; t++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
+    const int pt = wave & 3, ts = wave >> 2;                    // pixel tile, output tile set
+    static_assert(TT % 2 == 0, "both wave sets take TT / 2 tiles (a run-time tile count costs the MFMA schedule: 725 -> 833 us)");
+    constexpr int nT = TILES;
+    auto multiply = [&](int cur) {
+        HFrag bh, bl;
+        const float* dB = &sD[cur][8 * kg * kPitch + 32 * pt + col];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) split_pair(dB[2 * jj * kPitch], dB[(2 * jj + 1) * kPitch], bh.u[jj], bl.u[jj]);
+        const uint4* wA = (const uint4*)&sW[cur][0] + (size_t)TILES * ts * 128 + lane;
+#pragma unroll
+        for (int t = 0; t < TILES; t += 2) {
+            HFrag ah[2], al[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (t + u < TILES) { ah[u].q = wA[(t + u) * 128]; al[u].q = wA[(t + u) * 128 + 64]; }
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (t + u < TILES) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[u].v, bh.v, acc[t + u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (t + u < TILES) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u].v, bl.v, acc[t + u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (t + u < TILES) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u].v, bh.v, acc[t + u], 0, 0, 0);
+        }
+    };
+    Win SA, SB;
+    issue(SA, 0);
+    issue_w(0);
+    issue(SB, 1);
+    stencil(SA);
+    publish(0);
+    issue_w(1);
+    issue(SA, 2);
+    __syncthreads();
+    for (int c = 0; c + 1 < nChunks; c += 2) {
+        multiply(0);
+        stencil(SB);
+        publish(1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_w(c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(SB, c + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        multiply(1);
+        stencil(SA);
+        publish(0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_w(c + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(SA, c + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    const int pix = 128 * p128 + 32 * pt + col;
+#pragma unroll
+    for (int t = 0; t < TILES; t++) {
+        const int cb = (TILES * ts + t) * 32 + 4 * kg;
+        float4 sc4[4], sh4[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(scale + cb + 8 * g4); sh4[g4] = *(const float4*)(shift + cb + 8 * g4); }
+        const size_t ob = ((size_t)b * Cout + cb) * HW + pix;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int ro = (q & 3) + 8 * (q >> 2);
+            if (cb + ro >= Cout) continue;
+            float v = acc[t][q] * vget<4>(sc4[q >> 2], q & 3) + vget<4>(sh4[q >> 2], q & 3);
+            if (res) v += res[ob + (size_t)ro * HW];
+            Y[ob + (size_t)ro * HW] = v;
+        }
+    }
+}
+
 // ---- conv_last 1x1 80 -> 1 + bias (models_light.py:196) ----
 __global__ void k_fcn_last(const float* __restrict__ X, const float* __restrict__ w, float bias, float* __restrict__ Y,
                            int C, int HW)
@@ -1529,6 +1692,8 @@ bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, f
 #define DWPW(T, D, LWV, GY)                                                                                               \
     hipLaunchKernelGGL((k_fcn_dwpw<T, D, LWV, 1>), dim3(wgpi * B, GY), blk, 0, s, X, d.dPack, g.dWq, g.dScale, g.dShift, res, Y, d.c, \
                        g.cout, g.nTiles, abl)
+#define DWPW8(D, T) hipLaunchKernelGGL((k_fcn_dwpw8<D, T>), dim3(wgpi * B), dim3(512), 0, s, X, d.dPack, g.dWq, g.dScale, g.dShift, res, Y, d.c, \
+                                       g.cout, g.nTiles)
     if (H == 128) DWPW(1, 1, 7, 1);
     else if (H == 256) { if (!wide256) return false; DWPW(1, 1, 8, 1); }
     else if (tiles == 1 && d.dil == 1) DWPW(1, 1, 6, 1);
@@ -1537,9 +1702,13 @@ bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, f
     else if (tiles == 3 && d.dil == 2) DWPW(3, 2, 6, 1);
     else if (tiles == 5 && d.dil == 2) DWPW(5, 2, 6, 1);
     else if (tiles == 5 && d.dil == 4) DWPW(5, 4, 6, 1);
-    else if (tiles == 10 && d.dil == 4) DWPW(5, 4, 6, 2);
+    else if (tiles == 10 && d.dil == 4) {
+        static const bool one = getenv("IVF_FCN_NODWPW10") == nullptr;      // one pass over the hidden tensor with an 8-wave workgroup
+        if (one && !abl) DWPW8(4, 10); else DWPW(5, 4, 6, 2);
+    }
     else return false;
 #undef DWPW
+#undef DWPW8
     return true;
 }
 
