@@ -1339,16 +1339,18 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
 // all 512 threads share the stencil of a 16-channel chunk (channel = tid >> 5, 4 adjacent pixels per thread; a DPP row of
 // 16 lanes is exactly one 64-pixel image row, so the dilation halo comes from the neighbour lanes and the DPP zero fill IS
 // the zero padding), wave w multiplies pixel tile (w & 3) against output tiles 5 (w >> 2) .. 5 (w >> 2) + 4.
-template <int DIL, int TT>
-__global__ __launch_bounds__(512, 2) void k_fcn_dwpw8(const float* __restrict__ X, const float* __restrict__ dwP,
-                                                     const uint4* __restrict__ Wq, const float* __restrict__ scale,
-                                                     const float* __restrict__ shift, const float* __restrict__ res,
-                                                     float* __restrict__ Y, int K, int Cout, int nTiles)
+// The body is instantiated once per wave set (NTW = output tiles of the set, TS = its index) so that the tile count of a
+// wave is a compile-time constant: a run-time count costs the MFMA schedule (725 -> 833 us at TT = 10).
+template <int DIL, int TT, int NTW, int TS>
+__device__ __forceinline__ void dwpw8_body(float (&sD)[2][16 * 132], float* sWp, const float* __restrict__ X, const float* __restrict__ dwP,
+                                           const uint4* __restrict__ Wq, const float* __restrict__ scale,
+                                           const float* __restrict__ shift, const float* __restrict__ res,
+                                           float* __restrict__ Y, int K, int Cout, int nTiles)
 {
     static_assert(DIL == 1 || DIL == 2 || DIL == 4, "a tap at distance DIL is in this lane or the next one");
-    constexpr int kPitch = 132, Wd = 64, HW = Wd * Wd, WGPI = HW / 128, TILES = (TT + 1) / 2;     // TILES: output tiles per wave (set 0; set 1 has TT / 2)
-    __shared__ __attribute__((aligned(16))) float sD[2][16 * kPitch];
-    __shared__ __attribute__((aligned(16))) float sW[2][TT * 512];
+    static_assert(NTW >= 1, "every wave set owns at least one output tile");
+    constexpr int kPitch = 132, Wd = 64, HW = Wd * Wd, WGPI = HW / 128, TILES = NTW, T0 = (TT + 1) / 2;     // set 0 holds tiles 0 .. T0-1
+    float (&sW)[2][TT * 512] = *reinterpret_cast<float (*)[2][TT * 512]>(sWp);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 5, col = lane & 31;
     const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
     const int b = L / WGPI, p128 = L % WGPI;
@@ -1374,13 +1376,13 @@ __global__ __launch_bounds__(512, 2) void k_fcn_dwpw8(const float* __restrict__ 
 #pragma unroll
         for (int ky = 0; ky < 3; ky++) S.r[ky] = *(const float4*)(P + rowOff[ky]);
     };
-    static_assert(TT * 256 % 512 == 0, "whole rounds of the 512 threads stage the A fragments");
-    constexpr int NW = TT * 256 / 512;                          // float2 per thread per chunk
+    constexpr int NW = (TT * 256 + 511) / 512, NWF = TT * 256 / 512;   // float2 per thread per chunk: NWF full rounds (+ a half one, threads 0..255)
     float2 wreg[NW];
     auto issue_w = [&](int c) {
         c = min(c, nChunks - 1);
 #pragma unroll
-        for (int j = 0; j < NW; j++) wreg[j] = *(const float2*)(Wf + (size_t)c * nTiles * 512 + (tid + 512 * j) * 2);
+        for (int j = 0; j < NW; j++)
+            if (j < NWF || TS == 0) wreg[j] = *(const float2*)(Wf + (size_t)c * nTiles * 512 + (tid + 512 * j) * 2);      // the half round: set 0's 256 threads
     };
     float o[4];
     auto stencil = [&](const Win& S) {
@@ -1414,22 +1416,22 @@ __global__ __launch_bounds__(512, 2) void k_fcn_dwpw8(const float* __restrict__ 
     auto publish = [&](int buf) {
         *(float4*)&sD[buf][kc * kPitch + 4 * g] = make_float4(o[0], o[1], o[2], o[3]);
 #pragma unroll
-        for (int j = 0; j < NW; j++) *(float2*)&sW[buf][(tid + 512 * j) * 2] = wreg[j];
+        for (int j = 0; j < NW; j++)
+            if (j < NWF || TS == 0) *(float2*)&sW[buf][(tid + 512 * j) * 2] = wreg[j];
     };
     f32x16 acc[TILES];
 #pragma unroll
     for (int t = 0; t < TILES; t++)
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
-    const int pt = wave & 3, ts = wave >> 2;                    // pixel tile, output tile set
-    static_assert(TT % 2 == 0, "both wave sets take TT / 2 tiles (a run-time tile count costs the MFMA schedule: 725 -> 833 us)");
-    constexpr int nT = TILES;
+    const int pt = wave & 3;                                    // pixel tile
+    constexpr int ts = TS;
     auto multiply = [&](int cur) {
         HFrag bh, bl;
         const float* dB = &sD[cur][8 * kg * kPitch + 32 * pt + col];
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) split_pair(dB[2 * jj * kPitch], dB[(2 * jj + 1) * kPitch], bh.u[jj], bl.u[jj]);
-        const uint4* wA = (const uint4*)&sW[cur][0] + (size_t)TILES * ts * 128 + lane;
+        const uint4* wA = (const uint4*)&sW[cur][0] + (size_t)T0 * ts * 128 + lane;
 #pragma unroll
         for (int t = 0; t < TILES; t += 2) {
             HFrag ah[2], al[2];
@@ -1479,7 +1481,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_dwpw8(const float* __restrict__ 
     const int pix = 128 * p128 + 32 * pt + col;
 #pragma unroll
     for (int t = 0; t < TILES; t++) {
-        const int cb = (TILES * ts + t) * 32 + 4 * kg;
+        const int cb = (T0 * ts + t) * 32 + 4 * kg;
         float4 sc4[4], sh4[4];
 #pragma unroll
         for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(scale + cb + 8 * g4); sh4[g4] = *(const float4*)(shift + cb + 8 * g4); }
@@ -1493,6 +1495,18 @@ __global__ __launch_bounds__(512, 2) void k_fcn_dwpw8(const float* __restrict__ 
             Y[ob + (size_t)ro * HW] = v;
         }
     }
+}
+
+template <int DIL, int TT>
+__global__ __launch_bounds__(512, 2) void k_fcn_dwpw8(const float* __restrict__ X, const float* __restrict__ dwP,
+                                                     const uint4* __restrict__ Wq, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, const float* __restrict__ res,
+                                                     float* __restrict__ Y, int K, int Cout, int nTiles)
+{
+    __shared__ __attribute__((aligned(16))) float sD[2][16 * 132];
+    __shared__ __attribute__((aligned(16))) float sW[2 * TT * 512];
+    if (threadIdx.x < 256) dwpw8_body<DIL, TT, (TT + 1) / 2, 0>(sD, sW, X, dwP, Wq, scale, shift, res, Y, K, Cout, nTiles);
+    else dwpw8_body<DIL, TT, TT / 2, 1>(sD, sW, X, dwP, Wq, scale, shift, res, Y, K, Cout, nTiles);
 }
 
 // ---- conv_last 1x1 80 -> 1 + bias (models_light.py:196) ----
@@ -1694,6 +1708,16 @@ bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, f
                        g.cout, g.nTiles, abl)
 #define DWPW8(D, T) hipLaunchKernelGGL((k_fcn_dwpw8<D, T>), dim3(wgpi * B), dim3(512), 0, s, X, d.dPack, g.dWq, g.dScale, g.dShift, res, Y, d.c, \
                                        g.cout, g.nTiles)
+    // 8-wave kernel per shape (measured per 64 images, 4-wave vs 8-wave): 576->160 dil 2: 294 vs 258 (on by default);
+    // 960->160 dil 4: 460 vs 472, 576->96: 213 vs 228, 384->64: 148 vs 167 (off).  IVF_FCN_DWPW8 = bit mask by tile count.
+    static const int w8 = getenv("IVF_FCN_DWPW8") ? (int)strtol(getenv("IVF_FCN_DWPW8"), nullptr, 0) : -1;
+    if (H == 64 && !abl) {
+        auto on = [&](bool dflt) { return w8 < 0 ? dflt : (w8 >> tiles & 1) != 0; };
+        if (tiles == 5 && d.dil == 2 && on(true)) { DWPW8(2, 5); return true; }
+        if (tiles == 5 && d.dil == 4 && on(false)) { DWPW8(4, 5); return true; }
+        if (tiles == 3 && d.dil == 2 && on(false)) { DWPW8(2, 3); return true; }
+        if (tiles == 2 && d.dil == 2 && on(false)) { DWPW8(2, 2); return true; }
+    }
     if (H == 128) DWPW(1, 1, 7, 1);
     else if (H == 256) { if (!wide256) return false; DWPW(1, 1, 8, 1); }
     else if (tiles == 1 && d.dil == 1) DWPW(1, 1, 6, 1);

@@ -116,8 +116,11 @@ print("OK %.3g" % err)
     {"IVF_FCN_IRBMASK": "0x3ff"},
     # ... and on none (blocks 2-4 through k_fcn_gemm + k_fcn_dwpw)
     {"IVF_FCN_IRBMASK": "0"},
+    # the 8-wave depthwise + projection kernel on every shape it covers / on none (block 17 keeps it: IVF_FCN_NODWPW10 is separate)
+    {"IVF_FCN_DWPW8": "0x2c"},
+    {"IVF_FCN_DWPW8": "0", "IVF_FCN_NODWPW10": "1"},
 ], ids=["default", "layerwise", "expand-pxt2", "dwpw-256", "no-stride2-fusion", "no-stem-fusion", "irb-blocks-2-11",
-        "irb-none"])
+        "irb-none", "dwpw8-all", "dwpw8-none"])
 def test_fcn_kernel_variants_match_goldens_and_are_deterministic(env):
     """The FCN picks between several kernels per layer (measured defaults, env overrides for tuning).  Every variant must
     meet the same bar, batch results must not depend on the batch slot, and repeated runs must be bit-identical (this is
