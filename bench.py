@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- stereo pairs/s of the hot path (introspection FCN + ORB extract L+R + L/R stereo match) on MI355X.
 
-Contract: python bench.py --gpus N --steps K --warmup W  (N>1 is launched by torch.distributed.run,
-one rank per GPU).  One step = one pass of the hot path over one batch of `--pairs` synthetic
-1242x375 stereo pairs that are already resident in HBM; value = pairs all ranks processed / time
-(max over ranks).  Workload = BASELINE.json configs[2], the configuration the metric "extract+match+introspect" names:
-the introspection FCN runs on every left image inside the timed step and its cost map gates the left extractor.
---no-introspect measures configs[1] (extract + match only); the default run also reports that figure in
-`extract_match_only`, measured after the timed region.  Prints ONE JSON line on rank 0, carrying `roofline` for the
-dominant kernel (HIP events on its stream inside the timed region: the FCN's 960->160 fused depthwise+projection
-launch with introspection, k_fast_nms without) and `cpu_baseline` (the oracles = ports of the reference CPU path,
-timed on this box's host cores).
+Contract: python bench.py --gpus N --steps K --warmup W.  With N > 1 and no WORLD_SIZE in the environment bench.py starts
+the N ranks itself (a fresh `python -m torch.distributed.run` child, before this process touches the GPU); under a launcher
+it checks WORLD_SIZE == N.  One rank per GPU, RCCL ("nccl") between them.
+
+One step = one pass of the hot path over one batch of synthetic 1242x375 stereo pairs that are already resident in HBM:
+`--batches-per-step` launch sequences of `--pairs` pairs each (default 16 x 128 = 2048 pairs per step and GPU, so that the
+driver's 20 timed steps last seconds, not a third of a second).  value = pairs all ranks processed / time (max over ranks).
+Workload = BASELINE.json configs[2], the configuration the metric "extract+match+introspect" names: the introspection FCN
+runs on every left image inside the timed step and its cost map gates the left extractor.  --no-introspect measures
+configs[1] (extract + match only); the default run also reports that figure in `extract_match_only`, measured after the
+timed region.  Prints ONE JSON line on rank 0, carrying `roofline` for the dominant kernel (HIP events on its stream inside
+the timed region), `cpu_baseline` (ports of the reference CPU path timed on this box's host cores), and after the timed
+region: `latency_ms_batch1` (the per-call drop-in API on host buffers, the mode the reference runs at 10 fps) and
+`h2d_included` (the same stream fed from pinned host memory over PCIe, copies overlapped with compute).
 """
 import argparse
 import json
@@ -47,47 +51,59 @@ def make_device_stream(torch, dev, n_pairs, seed, base_pairs=16):
     return left, right
 
 
-def cpu_baseline(pairs_sample, cores):
+def cpu_baseline(pairs_sample, cores, threads_per_pair=1):
     """Oracle (bit-exact scalar restatement of the reference CPU path; kind = 'port') on host threads.
-    One pair per worker thread (ctypes releases the GIL); the reference itself uses 2 threads per pair."""
+    threads_per_pair = 1: one pair per worker thread, `cores` pairs in flight (ctypes releases the GIL).
+    threads_per_pair = 2: the reference's own threading model -- left and right extraction on two threads, joined, then
+    the stereo matcher (ORB/src/Frame.cc:116-124) -- with cores // 2 pairs in flight."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import concurrent.futures as cf
     import oracle_lib as O          # checker / baseline only -- never on the product path
     from iv_slam_amd import synth
     imgs = [synth.make_pair(W, H, seed=900, idx=i) for i in range(min(pairs_sample, 8))]
     b = BF / FX
+    inner = cf.ThreadPoolExecutor(max(cores, 2)) if threads_per_pair == 2 else None
 
     def work(i):
         L, R = imgs[i % len(imgs)]
         eL = O.Extractor(NFEAT, 1.2, 8, 20, 7); eR = O.Extractor(NFEAT, 1.2, 8, 20, 7)
-        kL, dL = eL(L); kR, dR = eR(R)
+        if inner is not None:
+            fl = inner.submit(eL, L); fr = inner.submit(eR, R)
+            (kL, dL), (kR, dR) = fl.result(), fr.result()
+        else:
+            kL, dL = eL(L); kR, dR = eR(R)
         O.stereo_match(eL, eR, kL, dL, kR, dR, BF, b)
         return 1
 
     work(0)
     t0 = time.perf_counter()
-    with cf.ThreadPoolExecutor(cores) as ex:
+    with cf.ThreadPoolExecutor(max(1, cores // threads_per_pair)) as ex:
         done = sum(ex.map(work, range(pairs_sample)))
     dt = time.perf_counter() - t0
+    if inner is not None:
+        inner.shutdown()
     return done / dt, dt
 
 
-def cpu_fcn_baseline(threads):
-    """numpy oracle of the introspection FCN (oracle/fcn_oracle.py, f32): one forward per worker thread (numpy releases
-    the GIL inside its kernels; BLAS keeps its default threading)."""
+def cpu_fcn_baseline(threads, images=8, reps=3):
+    """The introspection FCN's layer list through torch.nn.functional on host cores (oracle/fcn_oracle_torch.py: PyTorch's
+    CPU convolution kernels with `threads` intra-op threads, batch of `images` per forward) -- what the reference's libtorch
+    CPU path executes, minus TorchScript.  Returns (images/s, seconds)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import concurrent.futures as cf
     import numpy as np
-    import fcn_oracle               # checker / baseline only -- never on the product path
+    import torch
+    import fcn_oracle_torch         # checker / baseline only -- never on the product path
     from iv_slam_amd import fcn_weights, synth
-    Wt = fcn_weights.make_seeded_weights(7)
-    img = np.stack([synth.make_left(W, H, seed=901, idx=c) for c in range(3)], axis=-1)
-    fcn_oracle.forward(Wt, img, (H, W))
+    torch.set_num_threads(threads)
+    T = fcn_oracle_torch.prepare(fcn_weights.make_seeded_weights(7))
+    img = np.stack([np.stack([synth.make_left(W, H, seed=901, idx=c + 3 * k) for c in range(3)], axis=-1) for k in range(2)])
+    batch = np.concatenate([img] * (images // 2))
+    fcn_oracle_torch.forward(T, batch[:2], (H, W))
     t0 = time.perf_counter()
-    with cf.ThreadPoolExecutor(threads) as ex:
-        done = sum(1 for _ in ex.map(lambda i: fcn_oracle.forward(Wt, img, (H, W)), range(threads)))
+    for _ in range(reps):
+        fcn_oracle_torch.forward(T, batch, (H, W))
     dt = time.perf_counter() - t0
-    return done / dt, dt
+    return reps * len(batch) / dt, dt
 
 
 # algorithmic HBM bytes of the probed FCN launch per image (DESIGN.md section 7): hidden tensor read once
@@ -95,47 +111,150 @@ def cpu_fcn_baseline(threads):
 FCN_PROBE_BYTES_PER_IMAGE = (960 + 160 + 160) * 64 * 64 * 4
 
 
+def latency_batch1(iv, blob, introspect, iters=20):
+    """Single-pair latency of the DROP-IN per-call path, host buffers in and out: ivf_fcn_forward -> cost map (host) ->
+    ivf_extract left (with the map) and right on two host threads (ORB/src/Frame.cc:116-124) -> ivf_stereo_match."""
+    import threading
+    import numpy as np
+    from iv_slam_amd import synth
+    L, R = synth.make_pair(W, H, seed=77, idx=0)
+    bgr = np.stack([L, L // 2 + 40, 255 - L // 2], axis=-1).astype(np.uint8)
+    eL = iv.ORBextractor(NFEAT, 1.2, 8, 20, 7, bool(introspect)); eR = iv.ORBextractor(NFEAT, 1.2, 8, 20, 7, False)
+    fcn1 = iv.IntrospectionFCN(blob, (H, W), (H, W), max_batch=1) if introspect else None
+    ms = []
+    for it in range(iters + 3):
+        t0 = time.perf_counter()
+        cost = fcn1(bgr) if fcn1 is not None else None
+        out = {}
+        th = threading.Thread(target=lambda: out.__setitem__("R", eR(R)))
+        th.start()
+        kL, dL = eL(L, cost)
+        th.join()
+        kR, dR = out["R"]
+        ur, dp = iv.ComputeStereoMatches(eL, eR, kL, dL, kR, dR, BF, BF / FX)
+        if it >= 3:
+            ms.append((time.perf_counter() - t0) * 1e3)
+    ms.sort()
+    return {"value": round(ms[len(ms) // 2], 3), "min": round(ms[0], 3), "unit": "ms per stereo pair", "iters": iters,
+            "keypoints_left": int(len(kL)), "stereo_matches": int((ur >= 0).sum()),
+            "mode": "drop-in per-call C-ABI on host buffers: " + ("ivf_fcn_forward + " if introspect else "") +
+                    "ivf_extract x2 (two host threads) + ivf_stereo_match; blocking copies included"}
+
+
+def h2d_included(torch, iv, fe, fcn, dev, P, n_batches, left, right, bgr, cost, rec):
+    """Throughput with the inputs coming from PINNED HOST memory: per batch the grey L / R images (+ the left colour image
+    for the FCN) cross PCIe on a copy stream into one of two staging sets while the previous batch computes; the packed
+    result records {n, kps, desc, uRight} go back to pinned host memory.  Never the headline `value`."""
+    n_host = min(left.shape[0], 2 * P)
+    hl = torch.empty((n_host, H, W), dtype=torch.uint8, pin_memory=True); hl.copy_(left[:n_host])
+    hr = torch.empty((n_host, H, W), dtype=torch.uint8, pin_memory=True); hr.copy_(right[:n_host])
+    hb = None
+    if fcn is not None:
+        hb = torch.empty((n_host, H, W, 3), dtype=torch.uint8, pin_memory=True); hb.copy_(bgr[:n_host])
+    stage = [dict(l=torch.empty((P, H, W), dtype=torch.uint8, device=dev), r=torch.empty((P, H, W), dtype=torch.uint8, device=dev),
+                  b=torch.empty((P, H, W, 3), dtype=torch.uint8, device=dev) if fcn is not None else None) for _ in range(2)]
+    out_dev = [torch.empty(P * rec, dtype=torch.uint8, device=dev) for _ in range(3)]
+    out_host = [torch.empty(P * rec, dtype=torch.uint8, pin_memory=True) for _ in range(3)]
+    copy = torch.cuda.Stream(dev)
+    main = torch.cuda.current_stream(dev)
+    ready = [torch.cuda.Event() for _ in range(2)]; free = [torch.cuda.Event() for _ in range(2)]
+    nsl = n_host // P
+
+    def run(nb):
+        for k in range(nb):
+            st = stage[k % 2]; s0 = (k % nsl) * P
+            with torch.cuda.stream(copy):
+                if k >= 2:
+                    copy.wait_event(free[k % 2])
+                st["l"].copy_(hl[s0:s0 + P], non_blocking=True); st["r"].copy_(hr[s0:s0 + P], non_blocking=True)
+                if hb is not None:
+                    st["b"].copy_(hb[s0:s0 + P], non_blocking=True)
+                ready[k % 2].record(copy)
+            main.wait_event(ready[k % 2])
+            if fcn is not None:
+                fcn.forward_device(st["b"], cost_u8=cost, stream_ptr=main.cuda_stream)
+            fe.run(st["l"], st["r"], cost if fcn is not None else None, main.cuda_stream)
+            free[k % 2].record(main)                       # fe.run made `main` wait until the inputs were ingested
+            bs = torch.cuda.ExternalStream(fe.batch_stream(0), device=dev)
+            fe.pack_gather_block(out_dev[k % 3], fe.STREAM_OF_BATCH)
+            with torch.cuda.stream(bs):
+                out_host[k % 3].copy_(out_dev[k % 3], non_blocking=True)
+        fe.sync(); torch.cuda.synchronize(dev)
+
+    run(3)
+    t0 = time.perf_counter()
+    run(n_batches)
+    dt = time.perf_counter() - t0
+    in_bytes = P * H * W * (2 + (3 if fcn is not None else 0))
+    return {"value": round(P * n_batches / dt, 2), "unit": "pairs/s", "batches": n_batches, "pairs_per_batch": P,
+            "h2d_bytes_per_pair": in_bytes // P, "d2h_bytes_per_pair": rec,
+            "pcie_gb_s": round((in_bytes + P * rec) * n_batches / dt / 1e9, 2),
+            "note": "inputs in pinned host memory, H2D on a copy stream double-buffered against compute, packed result records D2H"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=128, help="stereo pairs per step per GPU")
-    ap.add_argument("--stream", type=int, default=256, help="distinct pairs resident per GPU")
+    ap.add_argument("--pairs", type=int, default=128, help="stereo pairs per launch sequence (sub-batch) per GPU")
+    ap.add_argument("--batches-per-step", type=int, default=0, help="sub-batches per step (default 16 with introspection, 64 without)")
+    ap.add_argument("--stream", type=int, default=512, help="distinct pairs resident per GPU")
     ap.add_argument("--introspect", action="store_true", help="(default) configs[2]: run the introspection FCN on every left image and gate keypoints with it")
     ap.add_argument("--no-introspect", action="store_true", help="configs[1]: extract + match only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the post-run latency / PCIe-inclusive / configs[1] measurements")
     ap.add_argument("--force-gather", action="store_true", help="test aid: run the multi-GPU exchange step (RCCL all-gather of "
                     "the descriptor records) even with one rank")
     ap.add_argument("--serial", action="store_true", help="profiling aid: wait for each batch before enqueuing the next, so "
                     "rocprofv3 kernel durations are not inflated by the overlap of consecutive batches")
     args = ap.parse_args()
     args.introspect = not args.no_introspect
+    BPS = args.batches_per_step if args.batches_per_step > 0 else (16 if args.introspect else 64)
+
+    # N>1 without a launcher: start one rank per GPU as a FRESH child (torch.distributed.run) before this process has
+    # imported torch or touched the GPU -- never re-exec a process that has initialised HIP -- and pass its exit code on.
+    # Rank 0 of the child prints the single JSON line (stdout is inherited).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python -m torch.distributed.run "
+                         "--nproc-per-node %d bench.py --gpus %d ...) or drop WORLD_SIZE and let bench.py spawn them"
+                         % (args.gpus, world, args.gpus, args.gpus))
     exchange = world > 1 or args.force_gather
     if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world)      # "nccl" is RCCL on ROCm
+        assert dist.get_world_size() == args.gpus
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import iv_slam_amd as iv
-    from iv_slam_amd import synth
     P = args.pairs
     n_stream = max(args.stream, P)
     n_stream = (n_stream + P - 1) // P * P
     left, right = make_device_stream(torch, dev, n_stream, seed=100 + rank)
     cost = None
     fcn = None
+    blob = None
+    bgr = None
     if args.introspect:
         # configs[2]: the introspection FCN (random-init weights of the deployed architecture; no checkpoints
         # exist offline) runs on the left colour image of every pair inside the timed step and its u8 cost map
@@ -151,45 +270,33 @@ def main():
     stream = torch.cuda.current_stream(dev)
     sptr = stream.cuda_stream
     rec = fe.gather_record_bytes()
-    block = torch.empty(P * rec, dtype=torch.uint8, device=dev)
-    gathered = torch.empty(world * P * rec, dtype=torch.uint8, device=dev) if exchange else None
     nslices = n_stream // P
     # The exchange step (pack + all-gather) is enqueued on the internal stream the batch itself runs on -- in order behind
     # it, so no stream ever waits on a batch-completion event (a stream that does costs 8 % of configs[2]: DESIGN.md
     # section 6) and the batch that reuses the context three steps later simply queues behind the collective.  One block /
-    # gather buffer per internal stream.  IVF_BENCH_EXCHANGE=side selects the earlier variant (own stream + event waits).
-    side = torch.cuda.Stream(dev) if exchange else None
-    packed = [torch.cuda.Event() for _ in range(3)] if exchange else None
-    blocks3 = [torch.empty_like(block) for _ in range(3)] if exchange else None          # one per internal stream
-    gathered3 = [torch.empty_like(gathered) for _ in range(3)] if exchange else None
-    nstep = [0]
+    # gather buffer per internal stream.
+    blocks3 = [torch.zeros(P * rec, dtype=torch.uint8, device=dev) for _ in range(3)] if exchange else None
+    gathered3 = [torch.zeros(world * P * rec, dtype=torch.uint8, device=dev) for _ in range(3)] if exchange else None
+    nsub = [0]
 
-    def step(i):
+    def sub_batch(i):
         s = (i % nslices) * P
-        k = nstep[0]; nstep[0] += 1
+        k = nsub[0]; nsub[0] += 1
         if fcn is not None:
             fcn.forward_device(bgr[s:s + P], cost_u8=cost, stream_ptr=sptr)
-        mode = os.environ.get("IVF_BENCH_EXCHANGE", "batch-stream")
-        if exchange and mode == "side" and k >= 3:
-            stream.wait_event(packed[k % 3])                     # the pack of three steps ago has read the context run(k) reuses
         fe.run(left[s:s + P], right[s:s + P], cost, sptr)
-        if exchange and mode == "side":
-            with torch.cuda.stream(side):
-                fe.pack_gather_block(block, side.cuda_stream)
-                packed[k % 3].record(side)
-                dist.all_gather_into_tensor(gathered, block)
-        elif exchange:
-            # the path's one exchange step: all-gather of {n, kps, desc, uRight} for cross-frame matching.  Pack and
-            # collective go onto the internal stream the batch itself runs on: in order behind it, so no stream ever waits
-            # on a batch-completion event, and the batch that reuses the context three steps later queues behind them
+        if exchange:
+            # the path's one exchange step: all-gather of {n, kps, desc, uRight} for cross-frame matching
             bs = torch.cuda.ExternalStream(fe.batch_stream(0), device=dev)
             fe.pack_gather_block(blocks3[k % 3], fe.STREAM_OF_BATCH)
             with torch.cuda.stream(bs):
                 dist.all_gather_into_tensor(gathered3[k % 3], blocks3[k % 3])
         if args.serial:
             fe.sync()
-            if exchange:
-                side.synchronize()
+
+    def step(i):
+        for j in range(BPS):
+            sub_batch(i * BPS + j)
 
     for i in range(args.warmup):
         step(i)
@@ -203,27 +310,53 @@ def main():
         step(args.warmup + i)
     host_enqueue_ms = (time.perf_counter() - t0) * 1e3 / max(args.steps, 1)      # host time to enqueue one step
     fe.sync()                                           # batches run on the front end's own streams: wait for all of
-    torch.cuda.synchronize(dev)                         # them (also checks the device-side consistency flag)
+    torch.cuda.synchronize(dev)                         # them (also checks the device-side consistency flags)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    fast_sum_ms, fast_n = fe.fast_ms_stats(min(args.steps, 64))
+    n_timed = min(args.steps * BPS, 64)
+    fast_sum_ms, fast_n = fe.fast_ms_stats(n_timed)
     if fcn is not None:
-        probe_sum_ms, probe_n, probe_batch = fcn.probe_stats(min(args.steps, 64))
+        probe_sum_ms, probe_n, probe_batch = fcn.probe_stats(n_timed)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_pairs = P * BPS * args.steps * world
+    value = total_pairs / dt
+
+    # sanity on the last batch: keypoints were really produced and matched
+    r0 = fe.fetch(0, 0)
+    assert len(r0["kps"]) > NFEAT // 2 and (r0["uright"] >= 0).sum() > 20, "degenerate output"
+    exch = None
+    if exchange:
+        # the last collective really delivered every rank's records: own slot == own block, every count plausible
+        import numpy as np
+        last = (nsub[0] - 1) % 3
+        g = gathered3[last].cpu().numpy().reshape(world, P, rec)
+        own = blocks3[last].cpu().numpy().reshape(P, rec)
+        assert np.array_equal(g[rank], own), "all-gather: own slot differs from the packed block"
+        counts = g[:, :, :4].copy().view(np.int32)[:, :, 0]
+        assert ((counts > NFEAT // 2) & (counts <= NFEAT)).all(), "all-gather: implausible keypoint counts %r" % counts
+        exch = {"world": world, "record_bytes": rec, "bytes_per_rank_per_batch": P * rec, "records_checked": int(counts.size),
+                "collective": "all_gather_into_tensor (RCCL) on the batch's own internal stream"}
+
+    # ---- after the timed region -------------------------------------------------------------------------------------
     # The front end overlaps consecutive batches on its own streams, so inside the timed region the probed kernel shares
-    # the GPU with other kernels and its event-measured duration is inflated.  For the kernel's own figure, 5 more steps
-    # are run one at a time (sync between them) AFTER the timed region and reported separately as `isolated`.
+    # the GPU with other kernels and its event-measured duration is inflated.  For the kernel's own figure, 5 more
+    # sub-batches are run one at a time (sync between them) and reported separately as `isolated`.
     for i in range(5):
-        step(args.warmup + args.steps + i)
+        sub_batch(i)
         fe.sync()
         torch.cuda.synchronize(dev)
     iso_sum_ms, iso_n = fe.fast_ms_stats(5)
     if fcn is not None:
         iso_probe_ms, iso_probe_n, _ = fcn.probe_stats(5)
+    extras = world == 1 and not args.no_extras
     # the network alone (MFMA leg of north_star): 3 forwards with nothing else on the GPU, HIP events on its stream
     fcn_alone = None
-    if fcn is not None and world == 1:
+    if fcn is not None and extras:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         fcn.forward_device(bgr[:P], cost_u8=cost, stream_ptr=sptr)
         e0.record(stream)
@@ -239,38 +372,37 @@ def main():
                      "mfma_frac": round(3 * (14.61 + 1.89) * 1e9 / us_img / 1e6 / 2500.0, 4)}
     # configs[1] (no introspection) on the same stream of pairs, for reference next to the headline number
     em_only = None
-    if fcn is not None and world == 1:
+    if fcn is not None and extras:
         fe1 = iv.StereoFrontend(W, H, P, nfeatures=NFEAT, enableIntrospection=False, bf=BF, fx=FX, device_id=local_rank)
         for i in range(3):
             s0 = (i % nslices) * P; fe1.run(left[s0:s0 + P], right[s0:s0 + P], None, sptr)
         fe1.sync(); torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
-        for i in range(10):
+        for i in range(64):
             s0 = (i % nslices) * P; fe1.run(left[s0:s0 + P], right[s0:s0 + P], None, sptr)
         fe1.sync(); torch.cuda.synchronize(dev)
-        em_only = P * 10 / (time.perf_counter() - t1)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    total_pairs = P * args.steps * world
-    value = total_pairs / dt
-
-    # sanity on the last batch: keypoints were really produced and matched
-    r0 = fe.fetch(0, 0)
-    assert len(r0["kps"]) > NFEAT // 2 and (r0["uright"] >= 0).sum() > 20, "degenerate output"
+        em_only = P * 64 / (time.perf_counter() - t1)
+        del fe1
+    h2d = None
+    lat = None
+    if extras:
+        h2d = h2d_included(torch, iv, fe, fcn, dev, P, 16 if args.introspect else 48, left, right, bgr, cost, rec)
+        lat = latency_batch1(iv, blob, args.introspect)
 
     if rank == 0:
         def load_pmc(kernel_key):
-            # HBM traffic from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE collected in separate runs
-            # because counters cannot be read inside this process), per image, rescaled to this launch size
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-                k = pmc["kernels"][kernel_key]
-                return (k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]) / k.get("images_per_launch", pmc["images_per_launch"]), \
-                    "profiles/r01_pmc_hbm_traffic.json"
-            except Exception:
-                return None, None
+            # HBM traffic from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE are collected in separate
+            # runs because counters cannot be read inside this process), per image, rescaled to this launch size.  The
+            # entry is used only when it was recorded for the kernel the probe actually timed (name match).
+            for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    k = pmc["kernels"][kernel_key]
+                    return (k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]) / k.get("images_per_launch", pmc["images_per_launch"]), \
+                        "profiles/" + name
+                except Exception:
+                    continue
+            return None, None
 
         def roof(kernel, algo_bytes, sum_ms, n, iso_ms, iso_n, traffic, src):
             ms = sum_ms / max(n, 1); ims = iso_ms / max(iso_n, 1)
@@ -288,10 +420,10 @@ def main():
         fast_roof = roof("k_fast_nms", fast_algo, fast_sum_ms, fast_n, iso_sum_ms, iso_n,
                          None if per_img is None else int(per_img * imgs_per_launch), src)
         if fcn is not None:
-            per_img, src = load_pmc("ivffcn::k_fcn_dwpw<5, 4> 960->160")
-            roofline = roof("k_fcn_dwpw<5,4> (fused depthwise 3x3 + 1x1 projection 960->160, %d images)" % probe_batch,
-                            FCN_PROBE_BYTES_PER_IMAGE * probe_batch, probe_sum_ms, probe_n, iso_probe_ms, iso_probe_n,
-                            None if per_img is None else int(per_img * probe_batch), src)
+            pname, palgo = fcn.probe_info()
+            per_img, src = load_pmc(pname)
+            roofline = roof("%s (%d images)" % (pname, probe_batch), int(palgo * probe_batch), probe_sum_ms, probe_n,
+                            iso_probe_ms, iso_probe_n, None if per_img is None else int(per_img * probe_batch), src)
         else:
             roofline = fast_roof
         out = {
@@ -303,30 +435,43 @@ def main():
                                     "ORB extract + L/R Hamming match"
                                     if args.introspect else
                                     "configs[1]: 1242x375 stereo pair stream, ORB extract + L/R Hamming match, introspection OFF"),
-                       "pairs_per_step_per_gpu": P, "distinct_pairs_per_gpu": n_stream, "nfeatures": NFEAT,
+                       "pairs_per_step_per_gpu": P * BPS, "pairs_per_launch_sequence": P, "launch_sequences_per_step": BPS,
+                       "distinct_pairs_per_gpu": n_stream, "nfeatures": NFEAT,
                        "nlevels": 8, "scale_factor": 1.2, "fast_thresholds": [20, 7],
                        "parallelism": "frames sharded %d-way, RCCL all-gather of descriptor blocks" % world if world > 1 else "1 GPU"},
+            "timed_region_s": round(dt, 3),
             "roofline": roofline,
         }
+        if exch is not None:
+            out["exchange"] = exch
         if fcn is not None:
             out["roofline_fast_nms"] = fast_roof
             if fcn_alone is not None:
                 out["fcn_forward"] = fcn_alone
             if em_only is not None:
                 out["extract_match_only"] = {"value": round(em_only, 2), "unit": "pairs/s",
-                                             "note": "configs[1] (introspection OFF), 10 steps on the same resident pairs after the timed region"}
+                                             "note": "configs[1] (introspection OFF), 64 launch sequences on the same resident pairs after the timed region"}
+        if lat is not None:
+            out["latency_ms_batch1"] = lat
+        if h2d is not None:
+            out["h2d_included"] = h2d
         if not args.no_cpu_baseline:
             cores = max(1, min(os.cpu_count() or 1, 32))
             sample = max(128, 8 * cores)
             v, secs = cpu_baseline(sample, cores)
+            v2, secs2 = cpu_baseline(max(32, 2 * cores), cores, threads_per_pair=2)
             txt = ("%d pairs of the same 1242x375/1000-feature workload, one pair per thread, %.1f s wall "
                    "(oracle/libivf_oracle.so, scalar C, -O3 -ffp-contract=off)" % (sample, secs))
+            extra = {"extract_match_all_cores": round(v, 2), "extract_match_two_threads_per_pair": round(v2, 2)}
             if args.introspect:
                 fv, fsecs = cpu_fcn_baseline(cores)
-                txt += ("; + introspection FCN: %d forwards of the numpy oracle (oracle/fcn_oracle.py), one per thread, "
-                        "%.1f s wall = %.2f images/s; extract+match alone = %.1f pairs/s; value = 1/(1/a + 1/b)" % (cores, fsecs, fv, v))
+                txt += ("; + introspection FCN: the layer list through torch.nn.functional (oracle/fcn_oracle_torch.py, PyTorch CPU "
+                        "kernels, %d intra-op threads, batches of 8), %.1f s wall = %.2f images/s; extract+match alone = %.1f pairs/s; "
+                        "value = 1/(1/a + 1/b)" % (cores, fsecs, fv, v))
+                extra["fcn_images_per_s"] = round(fv, 2)
+                extra["reference_threading_model"] = round(1.0 / (1.0 / v2 + 1.0 / fv), 3)
                 v = 1.0 / (1.0 / v + 1.0 / fv)
-            out["cpu_baseline"] = {"value": round(v, 3), "unit": "pairs/s", "cores": cores, "kind": "port", "sample": txt}
+            out["cpu_baseline"] = dict({"value": round(v, 3), "unit": "pairs/s", "cores": cores, "kind": "port", "sample": txt}, **extra)
         print(json.dumps(out), flush=True)
     if exchange:
         dist.destroy_process_group()

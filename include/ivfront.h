@@ -85,6 +85,10 @@ int  ivf_extract(ivf_extractor* e, const uint8_t* image, int width, int height, 
  * un-padded level of the LAST ivf_extract into dst (rows of dst_stride bytes); dst may be NULL to query size. */
 int  ivf_extractor_pyramid_level(const ivf_extractor* e, int level, uint8_t* dst, int dst_stride, int* width, int* height);
 int  ivf_extractor_quality_level(const ivf_extractor* e, int level, uint8_t* dst, int dst_stride, int* width, int* height);
+/* The 7x7 sigma-2 blurred copy of mvImagePyramid[level] that the descriptors of the LAST ivf_extract were sampled from
+ * (the local `workingMat` of ORB/src/ORBextractor.cc:1276-1277; the reference does not keep it).  Diagnostic / parity
+ * tests only; like the reference, levels without keypoints are not blurred (IVF_E_STATE for those). */
+int  ivf_extractor_blur_level(const ivf_extractor* e, int level, uint8_t* dst, int dst_stride, int* width, int* height);
 /* keypoints per level of the last call (allKeypoints[level].size(), ORB/src/ORBextractor.cc:1253-1254) */
 int  ivf_extractor_level_counts(const ivf_extractor* e, int32_t* counts);
 
@@ -372,6 +376,9 @@ int  ivf_remap_get_fixed_maps(const ivf_remap* r, int16_t* xy, uint16_t* alpha);
  * duration of the last `last_n` probed forwards (0 = all kept, at most 64) and the batch size of the oldest of them. */
 int  ivf_fcn_probe_enable(ivf_fcn* f);
 int  ivf_fcn_probe_stats(ivf_fcn* f, int last_n, double* sum_ms, int* n_out, int* batch);
+/* which kernel the probe bracketed, as dispatched (e.g. "ivffcn::k_fcn_dwpw<5, 4> 960->160"), and its algorithmic HBM bytes
+ * per image (hidden tensor read once + residual read + output written).  IVF_E_STATE before the first probed forward. */
+int  ivf_fcn_probe_info(const ivf_fcn* f, char* name, int name_cap, double* algorithmic_bytes_per_image);
 
 #ifdef __cplusplus
 }

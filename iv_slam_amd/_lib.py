@@ -49,6 +49,7 @@ _SIGS = {
     "ivf_extract": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]),
     "ivf_extractor_pyramid_level": (C.c_int, [vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ivf_extractor_quality_level": (C.c_int, [vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ivf_extractor_blur_level": (C.c_int, [vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ivf_extractor_level_counts": (C.c_int, [vp, vp]),
     "ivf_stereo_match": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_float, C.c_float, vp, vp]),
     "ivf_hamming": (C.c_int, [vp, vp]),
@@ -110,6 +111,7 @@ _SIGS = {
     "ivf_fcn_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "ivf_fcn_forward_device": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp, vp]),
     "ivf_fcn_probe_enable": (C.c_int, [vp]),
+    "ivf_fcn_probe_info": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_double)]),
     "ivf_fcn_probe_stats": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)

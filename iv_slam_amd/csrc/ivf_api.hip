@@ -85,7 +85,7 @@ struct Context {
     int run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size_t imageStride, int rowStride,
             size_t costStride, int costRowStride, int nImg, const uint8_t* hUseCost, hipStream_t st,
             hipEvent_t inputsConsumed = nullptr);
-    int check_status();
+    int check_status(int which = 0);
 };
 
 int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int dev, bool withStereo)
@@ -141,6 +141,7 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
         G.domH[0] = G.cellH;
         G.domH[1] = G.domHLast;                                   // stale hY
         G.candCap = ((G.cellW + 1) / 2) * ((G.cellH + 1) / 2) + 1;
+        c.maxCandCap = std::max(c.maxCandCap, G.candCap);
         cellBase += G.nCells; candBase += G.nCells * G.candCap;
         G.tilesX = (G.maxBX - 16 + kFastTW - 1) / kFastTW;
         G.tilesY = (G.maxBY - kEdge + kFastTH - 1) / kFastTH;
@@ -219,8 +220,13 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
         HIPCHK(hipMalloc(&b.depth, nP * nf * sizeof(float)));
         HIPCHK(hipMalloc(&b.sad, nP * nf * sizeof(int)));
     }
-    HIPCHK(hipMalloc(&b.status, sizeof(int)));
-    HIPCHK(hipMemset(b.status, 0, sizeof(int)));
+    HIPCHK(hipMalloc(&b.status, 2 * sizeof(int)));
+    HIPCHK(hipMemset(b.status, 0, 2 * sizeof(int)));
+    b.hugeCount = b.status + 1;
+    if (c.maxCandCap > 4096) {          // kCellCapBig: cells of this geometry can outgrow the LDS selection paths
+        HIPCHK(hipMalloc(&b.hugeList, (size_t)kHugeListCap * sizeof(int)));
+        HIPCHK(hipMalloc(&b.hugeScratch, (size_t)kHugeSlots * 6 * c.maxCandCap * sizeof(unsigned)));
+    }
     for (int i = 0; i < kEvRing; i++) { HIPCHK(hipEventCreate(&evFast0[i])); HIPCHK(hipEventCreate(&evFast1[i])); }
     return IVF_OK;
 }
@@ -229,7 +235,7 @@ void Context::release()
 {
     (void)hipSetDevice(device);
     void* ptrs[] = {dc, dTab, b.pyr, b.qpyr, b.blur, b.tileList, b.tileCnt, b.cellCnt, b.cellInfo, b.lvlTotal, b.lvl, b.slotPos, b.slotResp, b.lvlCount,
-                    b.useCost, b.kps, b.desc, b.count, b.quality, b.uright, b.depth, b.sad, b.status, dStage};
+                    b.useCost, b.kps, b.desc, b.count, b.quality, b.uright, b.depth, b.sad, b.status, b.hugeList, b.hugeScratch, dStage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < kEvRing; i++) {
         if (evFast0[i]) (void)hipEventDestroy(evFast0[i]);
@@ -247,14 +253,22 @@ int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size
     HIPCHK(hipSetDevice(device));
     lastStream = st;
     const bool useQ = introspection && cost != nullptr;
-    if (useQ) HIPCHK(hipMemcpyAsync(b.useCost, dUseCostSrc, nImg, hipMemcpyDeviceToDevice, st));
+    if (cost && !b.qpyr) {
+        // a cost image with an extractor that ignores it (enableIntrospection = 0): mvKeyQualScore still reads it
+        // (Frame.cc:130-143), so its level 0 is ingested.  One-time allocation, on the first such call.
+        const size_t blob = (size_t)hc.pyrBytes * maxImg;
+        HIPCHK(hipMalloc(&b.qpyr, blob));
+        HIPCHK(hipMemsetAsync(b.qpyr, 0, blob, st));
+    }
+    if (cost) HIPCHK(hipMemcpyAsync(b.useCost, dUseCostSrc, nImg, hipMemcpyDeviceToDevice, st));
     else HIPCHK(hipMemsetAsync(b.useCost, 0, nImg, st));
     launch_ingest(hc, dc, b, s0, s1, imageStride, rowStride, nImg, nSides, b.pyr, st);
-    if (useQ) launch_ingest(hc, dc, b, cost, cost, costStride, costRowStride, nImg, nSides, b.qpyr, st);
+    if (cost) launch_ingest(hc, dc, b, cost, cost, costStride, costRowStride, nImg, nSides, b.qpyr, st);
     if (inputsConsumed) HIPCHK(hipEventRecord(inputsConsumed, st));   // caller buffers are free from here on
     launch_pyramid(hc, dc, dTab, b.pyr, nImg, st);
     if (useQ) launch_pyramid(hc, dc, dTab, b.qpyr, nImg, st);       // ComputeQualityImagePyramid :1325-1357
     HIPCHK(hipMemsetAsync(b.cellCnt, 0, (size_t)nImg * hc.nCellsTotal * 2 * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(b.hugeCount, 0, sizeof(int), st));
     const int slot = (int)(nRuns % kEvRing);
     HIPCHK(hipEventRecord(evFast0[slot], st));
     launch_fast(hc, dc, b, nImg, st);
@@ -267,12 +281,36 @@ int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size
     return IVF_OK;
 }
 
-int Context::check_status()
+// Reads AND clears the device-side flags: an error is reported once, for the batch that raised it, and the handle stays
+// usable (the flags used to be sticky: one bad image killed a streaming front end until it was re-created).
+int Context::check_status(int which)
 {
     int s = 0;
     HIPCHK(hipMemcpy(&s, b.status, sizeof(int), hipMemcpyDeviceToHost));
-    if (s & 4) return fail(IVF_E_CAPACITY, "a cell holds more than 4096 FAST survivors at its threshold (unsupported)");
-    if (s) return fail(IVF_E_STATE, "device-side consistency check failed (flags 0x%x)", s);
+    if (!s) return IVF_OK;
+    HIPCHK(hipMemset(b.status, 0, sizeof(int)));
+    if (s & 4) return fail(IVF_E_CAPACITY, "batch context %d (run %lld): more than %d cells held over 4096 FAST survivors in one launch",
+                           which, nRuns - 1, kHugeListCap);
+    return fail(IVF_E_STATE, "batch context %d (run %lld): device-side consistency check failed (flags 0x%x)", which, nRuns - 1, s);
+}
+
+// One growable device scratch per host thread and device: the per-call entry points (ivf_stereo_match, ivf_hamming_pairs,
+// the matchers built on it) upload their inputs here instead of paying a hipMalloc / hipFree set per call.
+int thread_scratch(int device, size_t need, uint8_t** out)
+{
+    struct Scratch {
+        int device = -1; uint8_t* buf = nullptr; size_t cap = 0;
+        ~Scratch() { if (buf) { (void)hipSetDevice(device); (void)hipFree(buf); } }
+    };
+    static thread_local Scratch sc;
+    if (sc.device != device || sc.cap < need) {
+        if (sc.buf) { (void)hipSetDevice(sc.device); (void)hipDeviceSynchronize(); (void)hipFree(sc.buf); sc.buf = nullptr; sc.cap = 0; }
+        HIPCHK(hipSetDevice(device));
+        const size_t cap = std::max(need + need / 2, (size_t)1 << 20);
+        HIPCHK(hipMalloc(&sc.buf, cap));
+        sc.cap = cap; sc.device = device;
+    }
+    *out = sc.buf;
     return IVF_OK;
 }
 
@@ -484,6 +522,16 @@ int ivf_extractor_quality_level(const ivf_extractor* e, int level, uint8_t* dst,
     if (e && !e->lastHadCost) return fail(IVF_E_STATE, "last extract had no cost map");
     return copy_level(e, e ? e->ctx.b.qpyr : nullptr, level, dst, dst_stride, width, height);
 }
+int ivf_extractor_blur_level(const ivf_extractor* e, int level, uint8_t* dst, int dst_stride, int* width, int* height)
+{
+    if (e && e->extracted && level >= 0 && level < e->t.p.nlevels) {
+        int cnt = 0;
+        HIPCHK(hipSetDevice(e->device));
+        HIPCHK(hipMemcpy(&cnt, e->ctx.b.lvlCount + level, sizeof(int), hipMemcpyDeviceToHost));
+        if (cnt == 0) return fail(IVF_E_STATE, "level %d had no keypoints in the last extract: not blurred (ORBextractor.cc:1267-1268)", level);
+    }
+    return copy_level(e, e ? e->ctx.b.blur : nullptr, level, dst, dst_stride, width, height);
+}
 int ivf_extractor_level_counts(const ivf_extractor* e, int32_t* counts)
 {
     if (!e || !counts) return fail(IVF_E_INVALID, "null argument");
@@ -507,22 +555,25 @@ int ivf_stereo_match(const ivf_extractor* left, const ivf_extractor* right,
     if (n_left > nf || n_right > 65534) return fail(IVF_E_CAPACITY, "too many keypoints");
     if (n_left == 0) return IVF_OK;
     HIPCHK(hipSetDevice(left->device));
-    // caller-provided keypoints / descriptors are the matcher's inputs (mvKeys, mvDescriptors): upload them
-    ivf_keypoint *dKL = nullptr, *dKR = nullptr; uint8_t *dDL = nullptr, *dDR = nullptr; int* dCnt = nullptr;
+    // caller-provided keypoints / descriptors are the matcher's inputs (mvKeys, mvDescriptors): upload them into the
+    // calling thread's growable device scratch (no per-frame hipMalloc / hipFree, nothing to leak on an error path)
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t nR = (size_t)std::max(n_right, 1);
-    HIPCHK(hipMalloc(&dKL, (size_t)nf * sizeof(ivf_keypoint)));
-    HIPCHK(hipMalloc(&dKR, nR * sizeof(ivf_keypoint)));
-    HIPCHK(hipMalloc(&dDL, (size_t)nf * 32));
-    HIPCHK(hipMalloc(&dDR, nR * 32));
-    HIPCHK(hipMalloc(&dCnt, 2 * sizeof(int)));
-    HIPCHK(hipMemcpy(dKL, kps_left, (size_t)n_left * sizeof(ivf_keypoint), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dDL, desc_left, (size_t)n_left * 32, hipMemcpyHostToDevice));
+    const size_t szKL = up((size_t)nf * sizeof(ivf_keypoint)), szKR = up(nR * sizeof(ivf_keypoint)), szDL = up((size_t)nf * 32),
+                 szDR = up(nR * 32);
+    uint8_t* base = nullptr;
+    int rc = thread_scratch(left->device, szKL + szKR + szDL + szDR + 256, &base);
+    if (rc) return rc;
+    ivf_keypoint* dKL = (ivf_keypoint*)base; ivf_keypoint* dKR = (ivf_keypoint*)(base + szKL);
+    uint8_t* dDL = base + szKL + szKR; uint8_t* dDR = dDL + szDL; int* dCnt = (int*)(dDR + szDR);
+    HIPCHK(hipMemcpyAsync(dKL, kps_left, (size_t)n_left * sizeof(ivf_keypoint), hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(dDL, desc_left, (size_t)n_left * 32, hipMemcpyHostToDevice, nullptr));
     if (n_right) {
-        HIPCHK(hipMemcpy(dKR, kps_right, (size_t)n_right * sizeof(ivf_keypoint), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(dDR, desc_right, (size_t)n_right * 32, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(dKR, kps_right, (size_t)n_right * sizeof(ivf_keypoint), hipMemcpyHostToDevice, nullptr));
+        HIPCHK(hipMemcpyAsync(dDR, desc_right, (size_t)n_right * 32, hipMemcpyHostToDevice, nullptr));
     }
     const int cnt[2] = {n_left, n_right};
-    HIPCHK(hipMemcpy(dCnt, cnt, sizeof cnt, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(dCnt, cnt, sizeof cnt, hipMemcpyHostToDevice, nullptr));
     const Context& cl = left->ctx;
     StereoArgs A;
     A.pyrL = cl.b.pyr; A.pyrR = right->ctx.b.pyr; A.pyrStride = 0;
@@ -534,7 +585,6 @@ int ivf_stereo_match(const ivf_extractor* left, const ivf_extractor* right,
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(u_right, cl.b.uright, (size_t)n_left * sizeof(float), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(depth, cl.b.depth, (size_t)n_left * sizeof(float), hipMemcpyDeviceToHost));
-    (void)hipFree(dKL); (void)hipFree(dKR); (void)hipFree(dDL); (void)hipFree(dDR); (void)hipFree(dCnt);
     return IVF_OK;
 }
 
@@ -556,24 +606,13 @@ int ivf_hamming_pairs(const uint8_t* desc_a, int n_a, const uint8_t* desc_b, int
     int rc = have_device(device_id);
     if (rc) return rc;
     HIPCHK(hipSetDevice(device_id));
-    // one growable device scratch per host thread: the matchers call this once per search, a hipMalloc / hipFree quartet
-    // per call would dominate their latency
-    struct Scratch {
-        int device = -1; uint8_t* buf = nullptr; size_t cap = 0;
-        ~Scratch() { if (buf) { (void)hipSetDevice(device); (void)hipFree(buf); } }
-    };
-    static thread_local Scratch sc;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t szA = up((size_t)n_a * 32), szB = up((size_t)n_b * 32), szP = up((size_t)n_pairs * 2 * sizeof(int)),
                  szD = up((size_t)n_pairs * sizeof(int));
-    const size_t need = szA + szB + szP + szD;
-    if (sc.device != device_id || sc.cap < need) {
-        if (sc.buf) { (void)hipSetDevice(sc.device); (void)hipFree(sc.buf); sc.buf = nullptr; sc.cap = 0; HIPCHK(hipSetDevice(device_id)); }
-        const size_t cap = std::max(need + need / 2, (size_t)1 << 20);
-        HIPCHK(hipMalloc(&sc.buf, cap));
-        sc.cap = cap; sc.device = device_id;
-    }
-    uint8_t* dA = sc.buf; uint8_t* dB = dA + szA; int* dP = (int*)(dB + szB); int* dD = (int*)((uint8_t*)dP + szP);
+    uint8_t* scb = nullptr;
+    rc = thread_scratch(device_id, szA + szB + szP + szD, &scb);
+    if (rc) return rc;
+    uint8_t* dA = scb; uint8_t* dB = dA + szA; int* dP = (int*)(dB + szB); int* dD = (int*)((uint8_t*)dP + szP);
     HIPCHK(hipMemcpyAsync(dA, desc_a, (size_t)n_a * 32, hipMemcpyHostToDevice, nullptr));
     HIPCHK(hipMemcpyAsync(dB, desc_b, (size_t)n_b * 32, hipMemcpyHostToDevice, nullptr));
     HIPCHK(hipMemcpyAsync(dP, pairs, (size_t)n_pairs * 2 * sizeof(int), hipMemcpyHostToDevice, nullptr));
@@ -1669,7 +1708,9 @@ int ivf_frontend_create(const ivf_frontend_config* cfg, ivf_frontend** out)
             return cleanup(fail(IVF_E_NO_DEVICE, "stream/event creation failed"));
     }
     std::vector<uint8_t> flags(2 * (size_t)cfg->max_pairs);
-    for (int i = 0; i < cfg->max_pairs; i++) { flags[2 * i] = L.enable_introspection ? 1 : 0; flags[2 * i + 1] = R.enable_introspection ? 1 : 0; }
+    // bit 0: the cost pyramid gates this image's extraction; bit 1: mvKeyQualScore of the LEFT keypoints reads the cost image
+    // whenever one is passed, whatever the extractor flags say (Frame.cc:130-143 tests only !imDepth.empty())
+    for (int i = 0; i < cfg->max_pairs; i++) { flags[2 * i] = (L.enable_introspection ? 1 : 0) | 2; flags[2 * i + 1] = R.enable_introspection ? 1 : 0; }
     if (hipMalloc(&fe->dFlags, flags.size()) != hipSuccess ||
         hipMemcpy(fe->dFlags, flags.data(), flags.size(), hipMemcpyHostToDevice) != hipSuccess)
         return cleanup(fail(IVF_E_NO_DEVICE, "flag upload failed"));
@@ -1728,7 +1769,7 @@ int ivf_frontend_sync(ivf_frontend* fe)
     HIPCHK(hipSetDevice(fe->cfg.device_id));
     for (int k = 0; k < kPipe; k++) {
         HIPCHK(hipStreamSynchronize(fe->stream[k]));
-        const int rc = fe->ctx[k].check_status();
+        const int rc = fe->ctx[k].check_status(k);
         if (rc) return rc;
     }
     return IVF_OK;

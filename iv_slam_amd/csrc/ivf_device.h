@@ -40,6 +40,7 @@ struct Config {
     int nCellsTotal;        // cells per image over all levels
     int nTiles;             // FAST tiles per image
     int nBlurTiles;         // blur tiles per image
+    int maxCandCap;         // largest per-cell bound on strict 3x3 maxima over the levels (k_cell_select_huge slot size)
     int umax[16];
     float scale[kMaxLevels], invScale[kMaxLevels];
     int tileBases[kMaxLevels], btileBases[kMaxLevels];   // lv[l].tileBase / btileBase side by side (INT_MAX past nlevels):
@@ -53,6 +54,8 @@ typedef unsigned long long ResizeCoef;
 constexpr int kFastTW = 128, kFastTH = 32;    // FAST/NMS output tile (kFastTW + 2 <= 192, kFastTH + 2 <= 64: see k_fast_nms)
 constexpr int kBlurTW = 128, kBlurTH = 32;    // blur output tile
 constexpr int kTileCap = kFastTW * kFastTH / 4;   // at most one strict 3x3 maximum per 2x2 block
+constexpr int kHugeSlots = 8;            // workgroups (= global scratch slots) of k_cell_select_huge
+constexpr int kHugeListCap = 4096;       // cells with > 4096 survivors listed per launch
 
 struct Buffers {            // device pointers of one batch context
     uint8_t* pyr;           // [nImg][pyrBytes]  un-blurred pyramid (level 0 = ingested input)
@@ -67,7 +70,7 @@ struct Buffers {            // device pointers of one batch context
     unsigned int* slotPos;  // [nImg][nfeatures] (y<<16|x) level coords
     float* slotResp;        // [nImg][nfeatures]
     int* lvlCount;          // [nImg][kMaxLevels]
-    uint8_t* useCost;       // [nImg] 1 = cost pyramid valid for this image
+    uint8_t* useCost;       // [nImg] bit 0 = cost pyramid gates this image's extraction, bit 1 = level 0 of the cost image feeds mvKeyQualScore
     ivf_keypoint* kps;      // [nImg][nfeatures]
     uint8_t* desc;          // [nImg][nfeatures][32]
     int* count;             // [nImg]
@@ -75,7 +78,10 @@ struct Buffers {            // device pointers of one batch context
     float* uright;          // [nPairs][nfeatures]
     float* depth;           // [nPairs][nfeatures]
     int* sad;               // [nPairs][nfeatures]  best SAD distance or -1
-    int* status;            // [1] sticky device-side error flag
+    int* status;            // [1] device-side error flags, cleared by the host when read
+    int* hugeCount;         // [1] cells with more than 4096 survivors in this launch (k_quota -> k_cell_select_huge)
+    int* hugeList;          // [kHugeListCap] img * nCellsTotal + cell
+    unsigned* hugeScratch;  // [kHugeSlots][6 * maxCandCap] dwords, or nullptr when no cell can exceed 4096 maxima
 };
 
 // arguments of the stereo matcher kernels: left/right data may live in one batch context

@@ -1679,6 +1679,8 @@ bool launch_expand(const Gemm& g, const float* X, float* Y, int H, int W, int B,
     return true;
 }
 
+// name of the kernel the last launch_dwpw of this thread dispatched (ivf_fcn_probe_info: the probe reports what it timed)
+static thread_local char g_lastDwpw[96] = "";
 // fused depthwise + projection for the 64x64 stride-1 stages; false = shape not covered, caller runs the two kernels
 bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, float* Y, int H, int W, int B, hipStream_t s)
 {
@@ -1703,11 +1705,13 @@ bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, f
     if (H != 64 && (!wide || d.dil != 1 || tiles != 1)) return false;
     const dim3 blk(256);
     const int wgpi = H * W / 128;
-#define DWPW(T, D, LWV, GY)                                                                                               \
+#define DWPW(T, D, LWV, GY) do {                                                                                          \
+    snprintf(g_lastDwpw, sizeof g_lastDwpw, "ivffcn::k_fcn_dwpw<" #T ", " #D "> %d->%d", d.c, g.cout);                      \
     hipLaunchKernelGGL((k_fcn_dwpw<T, D, LWV, 1>), dim3(wgpi * B, GY), blk, 0, s, X, d.dPack, g.dWq, g.dScale, g.dShift, res, Y, d.c, \
-                       g.cout, g.nTiles, abl)
-#define DWPW8(D, T) hipLaunchKernelGGL((k_fcn_dwpw8<D, T>), dim3(wgpi * B), dim3(512), 0, s, X, d.dPack, g.dWq, g.dScale, g.dShift, res, Y, d.c, \
-                                       g.cout, g.nTiles)
+                       g.cout, g.nTiles, abl); } while (0)
+#define DWPW8(D, T) do { snprintf(g_lastDwpw, sizeof g_lastDwpw, "ivffcn::k_fcn_dwpw8<" #D ", " #T "> %d->%d", d.c, g.cout);             \
+    hipLaunchKernelGGL((k_fcn_dwpw8<D, T>), dim3(wgpi * B), dim3(512), 0, s, X, d.dPack, g.dWq, g.dScale, g.dShift, res, Y, d.c, \
+                       g.cout, g.nTiles); } while (0)
     // 8-wave kernel per shape (measured per 64 images, 4-wave vs 8-wave): 576->160 dil 2: 294 vs 258 (on by default);
     // 960->160 dil 4: 460 vs 472, 576->96: 213 vs 228, 384->64: 148 vs 167 (off).  IVF_FCN_DWPW8 = bit mask by tile count.
     static const int w8 = getenv("IVF_FCN_DWPW8") ? (int)strtol(getenv("IVF_FCN_DWPW8"), nullptr, 0) : -1;
@@ -1755,6 +1759,8 @@ struct ivf_fcn {
     hipEvent_t probe0[kProbe] = {}, probe1[kProbe] = {};
     int probeBatch[kProbe] = {};
     long probeCount = 0;
+    char probeName[96] = "";       // the kernel the probe brackets, as dispatched
+    double probeAlgoBytes = 0;     // its algorithmic HBM bytes per image: hidden tensor read + residual read + output written
 };
 
 namespace {
@@ -1892,7 +1898,11 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
         const int slot = (int)(f->probeCount % ivf_fcn::kProbe);
         if (probe) FHIP(hipEventRecord(f->probe0[slot], s));
         if (launch_dwpw(d, f->pw[ip], h, bk.res ? x : nullptr, y, H, W, n, s)) {
-            if (probe) { FHIP(hipEventRecord(f->probe1[slot], s)); f->probeBatch[slot] = n; f->probeCount++; }
+            if (probe) {
+                FHIP(hipEventRecord(f->probe1[slot], s)); f->probeBatch[slot] = n; f->probeCount++;
+                snprintf(f->probeName, sizeof f->probeName, "%s", g_lastDwpw);
+                f->probeAlgoBytes = (double)(hid + f->pw[ip].cout * (bk.res ? 2 : 1)) * H * W * sizeof(float);
+            }
             ip++;
             H = (H - 1) / d.stride + 1; W = (W - 1) / d.stride + 1;
             snprintf(nm, sizeof nm, "block %d depthwise+project", i + 1); STAGE(nm);
@@ -2045,6 +2055,15 @@ int ivf_fcn_probe_enable(ivf_fcn* f)
         if (!f->probe1[i]) FHIP(hipEventCreate(&f->probe1[i]));
     }
     f->probeCount = 0;
+    return IVF_OK;
+}
+
+int ivf_fcn_probe_info(const ivf_fcn* f, char* name, int name_cap, double* algorithmic_bytes_per_image)
+{
+    if (!f || !name || name_cap < 1) return ffail(IVF_E_INVALID, "bad argument");
+    if (!f->probeName[0]) return ffail(IVF_E_STATE, "no probed forward has run");
+    snprintf(name, (size_t)name_cap, "%s", f->probeName);
+    if (algorithmic_bytes_per_image) *algorithmic_bytes_per_image = f->probeAlgoBytes;
     return IVF_OK;
 }
 

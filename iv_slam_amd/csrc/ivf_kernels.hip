@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
         rok[k] = i < kRawN && gy < G.h && gx < G.pitch;        // gy >= 0: y0 >= kEdge
         rv_[k] = *(const unsigned*)(src + (size_t)(rok[k] ? gy : 0) * G.pitch + (rok[k] ? gx : 0));
     }
-    const int mode = (cfg->introspection && useC) ? 1 : 0;
+    const int mode = (cfg->introspection && (useC & 1u)) ? 1 : 0;
     const int domHm = mode ? G.domH[1] : G.domH[0];
     if (tid < kScW) {                               // column classes: x = x0-1+tid
         const int x = x0 - 1 + tid;
@@ -638,9 +638,17 @@ DEVINL void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-template <typename PTR, typename IDX>
+// GLOBAL = the lists live in global memory (k_cell_select_huge): order the wave's own stores and loads with a
+// workgroup-scope fence (s_waitcnt vmcnt(0)); the CU's L1 is write-through, so the wave then reads what it wrote
+template <bool GLOBAL> DEVINL void wave_sync_mem()
+{
+    if constexpr (GLOBAL) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    else wave_sync_lds();
+}
+template <typename PTR, typename IDX, bool GLOBAL = false>
 DEVINL void sel_nth_element_wave(PTR v, int n, int nth, IDX A, IDX B, int lane)
 {
+#define wave_sync_lds wave_sync_mem<GLOBAL>
     if (n <= 0 || nth >= n) return;
     int first = 0, last = n;
     int depth = 0;
@@ -683,12 +691,12 @@ DEVINL void sel_nth_element_wave(PTR v, int n, int nth, IDX A, IDX B, int lane)
             const int i = lo0 + base + lane;                     // ascending walk
             const bool inA = base + lane < len && !((unsigned)(v[i] >> 32) > pivot);
             const unsigned long long mA = __ballot(inA);
-            if (inA) A[nA + __popcll(mA & ((1ull << lane) - 1ull))] = (unsigned short)i;
+            if (inA) A[nA + __popcll(mA & ((1ull << lane) - 1ull))] = i;
             nA += __popcll(mA);
             const int j = last - 1 - base - lane;                // descending walk
             const bool inB = base + lane < len && !(pivot > (unsigned)(v[j] >> 32));
             const unsigned long long mB = __ballot(inB);
-            if (inB) B[nB + __popcll(mB & ((1ull << lane) - 1ull))] = (unsigned short)j;
+            if (inB) B[nB + __popcll(mB & ((1ull << lane) - 1ull))] = j;
             nB += __popcll(mB);
         }
         wave_sync_lds();
@@ -721,6 +729,7 @@ DEVINL void sel_nth_element_wave(PTR v, int n, int nth, IDX A, IDX B, int lane)
         }
     }
     wave_sync_lds();
+#undef wave_sync_lds
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -745,7 +754,7 @@ __global__ __launch_bounds__(256) void k_cell_qsum(const Config* __restrict__ cf
 {
     const int img = blockIdx.y, lane = threadIdx.x & 63;
     const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (cell >= cfg->nCellsTotal || !(cfg->introspection && useCost[img])) return;
+    if (cell >= cfg->nCellsTotal || !(cfg->introspection && (useCost[img] & 1))) return;
     int level = 0;
     for (int l = 1; l < cfg->nlevels; l++)
         if (cfg->lv[l].valid && cell >= cfg->lv[l].cellBase) level = l;
@@ -772,9 +781,11 @@ __global__ __launch_bounds__(256) void k_cell_qsum(const Config* __restrict__ cf
     if (lane == 0) cellInfo[(size_t)img * cfg->nCellsTotal + cell].nTotal = (int)qs;
 }
 
+constexpr int kCellCapSmall = 1024, kCellCapBig = 4096;
 __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, const int* __restrict__ cellCnt,
                                               const uint8_t* __restrict__ qpyr, const uint8_t* __restrict__ useCost,
-                                              CellInfo* __restrict__ cellInfo, int* __restrict__ lvlTotal)
+                                              CellInfo* __restrict__ cellInfo, int* __restrict__ lvlTotal,
+                                              int* __restrict__ hugeCount, int* __restrict__ hugeList, int* __restrict__ status)
 {
     __shared__ int s_nIni[kMaxCells], s_nMin[kMaxCells], s_nTotal[kMaxCells], s_nRetain[kMaxCells], s_prefix[kMaxCells + 1];
     __shared__ unsigned s_qsum[kMaxCells];
@@ -783,7 +794,7 @@ __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, c
     const LevelGeom& G = cfg->lv[level];
     const int tid = threadIdx.x;
     if (!G.valid) { if (tid == 0) lvlTotal[img * kMaxLevels + level] = 0; return; }
-    const int mode = (cfg->introspection && useCost[img]) ? 1 : 0;
+    const int mode = (cfg->introspection && (useCost[img] & 1)) ? 1 : 0;
     const int nCells = G.nCells, cols = G.cols, rows = G.rows;
     const int* cnt = cellCnt + ((size_t)img * cfg->nCellsTotal + G.cellBase) * 2;
     CellInfo* ci = cellInfo + (size_t)img * cfg->nCellsTotal + G.cellBase;
@@ -839,11 +850,18 @@ __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, c
         lvlTotal[img * kMaxLevels + level] = acc;
     }
     __syncthreads();
-    for (int c = tid; c < nCells; c += 256) ci[c] = CellInfo{s_nTotal[c], s_nRetain[c], s_prefix[c], (int)s_useMin[c]};
+    for (int c = tid; c < nCells; c += 256) {
+        ci[c] = CellInfo{s_nTotal[c], s_nRetain[c], s_prefix[c], (int)s_useMin[c]};
+        if (s_nTotal[c] > kCellCapBig) {                 // too many survivors for the LDS selection: k_cell_select_huge's work list
+            const int k = atomicAdd(hugeCount, 1);
+            if (hugeList && k < kHugeListCap) hugeList[k] = img * cfg->nCellsTotal + G.cellBase + c;
+            else atomicOr(status, 4);
+        }
+    }
 }
 
-// pass 0 handles cells with <= kCellCapSmall candidates (12 KB LDS, many waves per CU); pass 1 the rest
-constexpr int kCellCapSmall = 1024, kCellCapBig = 4096;
+// pass 0 handles cells with <= kCellCapSmall candidates (12 KB LDS, many waves per CU); pass 1 those up to kCellCapBig;
+// anything bigger (large images with few features: 1920x1200 at N = 500 has 627x290-pixel cells) goes to k_cell_select_huge
 // NTHR = 64: one wave per cell (the common, small cells: many cells per CU).  NTHR = 256 for the big-cell pass: gather and
 // bitonic sort run on four waves (with the introspection quirk of overlapping cell domains most level-0/1 cells hold
 // 1-4 thousand candidates and a single wave spent ~100 us per cell in the sort); the introselect stays on wave 0.
@@ -873,12 +891,12 @@ __global__ __launch_bounds__(NTHR) void k_cell_select(const Config* __restrict__
     const int nT = info.nTotal, nR = info.nRetain;
     if (nT <= 0) return;
     if (pass == 0 ? nT > kCellCapSmall : nT <= kCellCapSmall) return;
-    const int mode = (cfg->introspection && useCost[img]) ? 1 : 0;
+    const int mode = (cfg->introspection && (useCost[img] & 1)) ? 1 : 0;
     const uint8_t* Q = mode ? qpyr + (size_t)img * cfg->pyrBytes + G.off : nullptr;
     const unsigned th = info.useMin ? 1u : (unsigned)cfg->iniTh;
     const int kept = (nR >= 0 && nT > nR) ? nR : nT;
     u64* dst = lvlList + (size_t)img * cfg->candTotal + G.candBase + info.prefix;
-    if (nT > CAP) { if (tid == 0) atomicOr(status, 4); return; }     // > kCellCapBig survivors in one cell: unsupported
+    if (nT > CAP) return;                                            // > kCellCapBig survivors: k_cell_select_huge
     // a) collect the cell's survivors from the FAST tiles it overlaps, filtered by its rectangle and threshold
     //    (order irrelevant here)
     const int ci = c / G.cols, cj = c % G.cols;
@@ -957,6 +975,101 @@ __global__ __launch_bounds__(NTHR) void k_cell_select(const Config* __restrict__
         if (nR > 0 && nT > nR && tid < 64) sel_nth_element_wave(ord, nT, nR - 1, stopA, stopB, lane);
         sync();
         for (int k = tid; k < kept; k += NTHR) dst[k] = ord[k];
+    }
+}
+
+// Cells with more than kCellCapBig survivors: the same four steps with every list in a global scratch slot (one slot per
+// workgroup, kHugeSlots workgroups walk k_quota's work list).  Rare by construction -- it exists so that such an image costs
+// time instead of an error.  1024 threads gather and sort; wave 0 replays the introselect.
+__global__ __launch_bounds__(1024) void k_cell_select_huge(const Config* __restrict__ cfg, const unsigned* __restrict__ tileList,
+                                                          const int* __restrict__ tileCnt, const CellInfo* __restrict__ cellInfo,
+                                                          const uint8_t* __restrict__ qpyr, const uint8_t* __restrict__ useCost,
+                                                          u64* __restrict__ lvlList, int* __restrict__ status,
+                                                          const int* __restrict__ hugeCount, const int* __restrict__ hugeList,
+                                                          unsigned* __restrict__ scratch, int slotCap)
+{
+    __shared__ int s_m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nHuge = min(*hugeCount, kHugeListCap);
+    // slot layout: keys u32[2 * slotCap] (bitonic padding), ord u64[slotCap], stop lists u32[slotCap] x 2
+    unsigned* keys = scratch + (size_t)blockIdx.x * ((size_t)slotCap * 6);
+    u64* ord = (u64*)(keys + 2 * (size_t)slotCap);
+    unsigned* stopA = (unsigned*)(ord + slotCap);
+    unsigned* stopB = stopA + slotCap;
+    for (int w = blockIdx.x; w < nHuge; w += gridDim.x) {
+        const int img = hugeList[w] / cfg->nCellsTotal, gc = hugeList[w] % cfg->nCellsTotal;
+        int level = 0;
+        for (int l = 1; l < cfg->nlevels; l++) if (cfg->lv[l].valid && gc >= cfg->lv[l].cellBase) level = l;
+        const LevelGeom& G = cfg->lv[level];
+        const int c = gc - G.cellBase;
+        const CellInfo info = cellInfo[(size_t)img * cfg->nCellsTotal + gc];
+        const int nT = info.nTotal, nR = info.nRetain;
+        const int mode = (cfg->introspection && (useCost[img] & 1)) ? 1 : 0;
+        const uint8_t* Q = mode ? qpyr + (size_t)img * cfg->pyrBytes + G.off : nullptr;
+        const unsigned th = info.useMin ? 1u : (unsigned)cfg->iniTh;
+        const int kept = (nR >= 0 && nT > nR) ? nR : nT;
+        u64* dst = lvlList + (size_t)img * cfg->candTotal + G.candBase + info.prefix;
+        __syncthreads();                                 // previous cell done with the slot and with s_m
+        if (nT > slotCap) { if (tid == 0) atomicOr(status, 4); continue; }     // cannot happen: slotCap = max strict maxima per cell
+        const int ci = c / G.cols, cj = c % G.cols;
+        const int cx0 = kEdge + cj * G.cellW, cx1 = (cj == G.cols - 1) ? G.maxBX : cx0 + G.cellW;
+        const int cy0 = kEdge + ci * G.cellH, cy1 = cy0 + ((ci == G.rows - 1) ? G.domHLast : G.domH[mode]);
+        if (tid == 0) s_m = 0;
+        __syncthreads();
+        const int tx0 = (cx0 - 16) / kFastTW, tx1 = (cx1 - 1 - 16) / kFastTW;
+        const int ty0 = (cy0 - kEdge) / kFastTH, ty1 = (cy1 - 1 - kEdge) / kFastTH;
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) {
+                const size_t tile = (size_t)img * cfg->nTiles + G.tileBase + ty * G.tilesX + tx;
+                const int nAll = min(tileCnt[tile], kTileCap);
+                const unsigned* in = tileList + tile * kTileCap;
+                for (int b0 = 0; b0 < nAll; b0 += 1024) {
+                    const int k = b0 + tid;
+                    const unsigned e = k < nAll ? in[k] : 0u;
+                    const int ex = (e >> 8) & 0xfff, ey = e >> 20;
+                    const bool keep = k < nAll && (e & 0xffu) >= th && ex >= cx0 && ex < cx1 && ey >= cy0 && ey < cy1;
+                    const unsigned long long mask = __ballot(keep);
+                    int base = 0;
+                    if (lane == 0 && mask) base = atomicAdd(&s_m, __popcll(mask));
+                    base = __shfl(base, 0);
+                    if (keep) {
+                        const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (idx < slotCap) keys[idx] = e;
+                    }
+                }
+            }
+        __syncthreads();
+        const int m = s_m;
+        if (m != nT) { if (tid == 0) atomicOr(status, 1); continue; }
+        int n2 = 64;
+        while (n2 < m) n2 <<= 1;
+        for (int k = m + tid; k < n2; k += 1024) keys[k] = 0xffffffffu;
+        __syncthreads();
+        for (int k = 2; k <= n2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < n2 / 2; i += 1024) {
+                    const int l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                    const int r = l | j;
+                    const unsigned a = keys[l], b = keys[r];
+                    const bool up = (l & k) == 0;
+                    if ((a > b) == up) { keys[l] = b; keys[r] = a; }
+                }
+                __syncthreads();
+            }
+        for (int k = tid; k < m; k += 1024) {
+            const unsigned e = keys[k];
+            const unsigned y = e >> 20, x = (e >> 8) & 0xfffu;
+            float resp = (float)(e & 0xffu);
+            if (mode) {
+                const float cost = (float)Q[(size_t)y * G.pitch + x];
+                resp *= 2 * (1.0f / (1.0f + cost / 255.0f)) - 1;
+            }
+            ord[k] = ((u64)__float_as_uint(resp) << 32) | (y << 16) | x;
+        }
+        __syncthreads();
+        if (nR > 0 && nT > nR && tid < 64) sel_nth_element_wave<u64*, unsigned*, true>(ord, nT, nR - 1, stopA, stopB, lane);
+        __syncthreads();
+        for (int k = tid; k < kept; k += 1024) dst[k] = ord[k];
     }
 }
 
@@ -1143,7 +1256,7 @@ __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg
         kp.response = slotResp[(size_t)img * nf + slot]; kp.octave = level;
         kps[(size_t)img * nf + oi] = kp;
         float q = 1.0f;
-        if (cfg->introspection && useCost[img]) {
+        if (useCost[img] & 2) {          // Frame.cc:130-143: whenever a cost image came with the frame, whatever the extractor flag
             const int qx = (int)roundf(fx), qy = (int)roundf(fy);
             const LevelGeom& G0 = cfg->lv[0];
             const float cost = (float)qpyr[(size_t)img * cfg->pyrBytes + G0.off + (size_t)min(qy, G0.h - 1) * G0.pitch + min(qx, G0.w - 1)];
@@ -1384,11 +1497,14 @@ void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nIm
     if (hc.introspection)
         hipLaunchKernelGGL(k_cell_qsum, dim3((hc.nCellsTotal + 3) / 4, nImg), dim3(256), 0, s, dc, b.qpyr, b.useCost, (CellInfo*)b.cellInfo);
     hipLaunchKernelGGL(k_quota, dim3(hc.nlevels, nImg), dim3(256), 0, s, dc, b.cellCnt, b.qpyr, b.useCost,
-                       (CellInfo*)b.cellInfo, b.lvlTotal);
+                       (CellInfo*)b.cellInfo, b.lvlTotal, b.hugeCount, b.hugeList, b.status);
     hipLaunchKernelGGL((k_cell_select<kCellCapSmall, 64>), dim3(hc.nCellsTotal, nImg), dim3(64), 0, s, dc, b.tileList, b.tileCnt,
                        (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, 0);
     hipLaunchKernelGGL((k_cell_select<kCellCapBig, 256>), dim3(hc.nCellsTotal, nImg), dim3(256), 0, s, dc, b.tileList, b.tileCnt,
                        (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, 1);
+    if (b.hugeScratch)       // geometry allows cells with more than kCellCapBig strict maxima: walk k_quota's (usually empty) list
+        hipLaunchKernelGGL(k_cell_select_huge, dim3(kHugeSlots), dim3(1024), 0, s, dc, b.tileList, b.tileCnt, (const CellInfo*)b.cellInfo,
+                           b.qpyr, b.useCost, b.lvl, b.status, b.hugeCount, b.hugeList, b.hugeScratch, hc.maxCandCap);
     hipLaunchKernelGGL(k_level_select, dim3(hc.nlevels, nImg), dim3(256), 0, s, dc, b.lvlTotal, b.lvl, b.slotPos, b.slotResp,
                        b.lvlCount);
 }

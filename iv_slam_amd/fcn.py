@@ -53,3 +53,9 @@ class IntrospectionFCN:
         s = C.c_double(0); n = C.c_int(0); b = C.c_int(0)
         check(self._lib.ivf_fcn_probe_stats(self._h, last_n, C.byref(s), C.byref(n), C.byref(b)))
         return s.value, n.value, b.value
+
+    def probe_info(self):
+        """(kernel name as dispatched, algorithmic HBM bytes per image) of the launch the probe brackets."""
+        name = C.create_string_buffer(128); b = C.c_double(0)
+        check(self._lib.ivf_fcn_probe_info(self._h, name, 128, C.byref(b)))
+        return name.value.decode(), b.value

@@ -101,6 +101,10 @@ class ORBextractor:
     def mvQualityImagePyramid(self):
         return [self._level(self._lib.ivf_extractor_quality_level, l) for l in range(self.nlevels)]
 
+    def blur_level(self, level):
+        """7x7 sigma-2 blurred copy of mvImagePyramid[level] (the reference's local workingMat, ORBextractor.cc:1276-1277)."""
+        return self._level(self._lib.ivf_extractor_blur_level, level)
+
     def level_counts(self):
         c = np.zeros(self.nlevels, np.int32)
         check(self._lib.ivf_extractor_level_counts(self._h, ptr(c)))

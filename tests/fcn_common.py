@@ -27,10 +27,11 @@ def load_case(tag):
 def check_against_golden(g, cost, u8, tol=1e-3):
     """cost maps within `tol` of the reference CPU path (north-star bar 1e-3); u8 = trunc(cost*255) may differ by one
     LSB from the reference only where the reference's value sits within tol*255 of a truncation boundary."""
-    ref = g["cost_sub"]; got = cost[::6, ::6]
+    sub = int(g["sub"][0]) if "sub" in g.files else 6
+    ref = g["cost_sub"]; got = cost[::sub, ::sub]
     err = float(np.abs(got - ref).max())
     assert err < tol, "cost map differs from the reference by %.3g" % err
-    ru8 = g["u8_sub"].astype(np.int32); gu8 = u8[::6, ::6].astype(np.int32)
+    ru8 = g["u8_sub"].astype(np.int32); gu8 = u8[::sub, ::sub].astype(np.int32)
     d = np.abs(ru8 - gu8)
     assert d.max() <= 1
     frac = (ref.astype(np.float64) * 255.0) % 1.0

@@ -55,7 +55,12 @@ def run_reference(m, bgr):
 
 def main():
     torch.set_num_threads(8)
-    for tag, (w, h), seed in (("kitti", (1242, 375), 3), ("jackal", (960, 600), 4)):
+    # (tag, image size, seed, sub-sampling step of the committed maps); `python make_fcn_golden.py TAG...` regenerates only those
+    cases = (("kitti", (1242, 375), 3, 6), ("jackal", (960, 600), 4, 6), ("jackal_full", (1920, 1200), 6, 12))
+    only = set(sys.argv[1:])
+    for tag, (w, h), seed, sub in cases:
+        if only and tag not in only:
+            continue
         W = fcn_weights.make_seeded_weights(seed)
         bgr = bgr_image(w, h, 50 + seed)
         # calibrate conv_last so the logits straddle 0.5 (otherwise the logistic saturates to 0/1 everywhere)
@@ -78,7 +83,7 @@ def main():
         assert np.abs(oc - y).max() < 2e-4      # f32 summation-order noise x logistic slope 5; bar is 1e-3
         np.savez_compressed(os.path.join(HERE, "fcn_%s.npz" % tag), seed=np.array([seed]), size=np.array([w, h]),
                             conv_last_weight=W["decoder.conv_last.weight"], conv_last_bias=W["decoder.conv_last.bias"],
-                            cost_sub=y[::6, ::6].copy(), u8_sub=u8[::6, ::6].copy(), logits=logits.copy(),
+                            cost_sub=y[::sub, ::sub].copy(), u8_sub=u8[::sub, ::sub].copy(), sub=np.array([sub]), logits=logits.copy(),
                             tap_stats=np.array([[taps[k].mean(), np.abs(taps[k]).mean(), taps[k].std()] for k in ("f0", "f7", "f17")], np.float64),
                             f17_sub=taps["f17"][0, ::16, ::8, ::8].copy())
     for f in sorted(os.listdir(HERE)):

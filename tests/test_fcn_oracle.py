@@ -7,7 +7,7 @@ import fcn_common as FC
 from iv_slam_amd import fcn_weights
 
 
-@pytest.mark.parametrize("tag", ["kitti", "jackal"])
+@pytest.mark.parametrize("tag", ["kitti", "jackal", "jackal_full"])
 def test_oracle_matches_reference_goldens(tag):
     import fcn_oracle
     g, W, bgr, out_size = FC.load_case(tag)
@@ -45,3 +45,17 @@ def test_bilinear_and_preprocess_kats():
     p = fcn_oracle.preprocess(img)
     assert p.shape == (1, 3, 2, 2)
     assert abs(p[0, 0, 0, 0] - (1 - 0.485) / 0.229) < 1e-5 and abs(p[0, 2, 0, 0] - (0 - 0.406) / 0.225) < 1e-5
+
+
+def test_torch_baseline_graph_matches_numpy_oracle_and_golden():
+    """bench.py's CPU-baseline FCN leg (the layer list through torch.nn.functional) is the same function."""
+    import fcn_oracle
+    import fcn_oracle_torch
+    g, W, bgr, out_size = FC.load_case("kitti")
+    T = fcn_oracle_torch.prepare(W)
+    cost, u8 = fcn_oracle_torch.forward(T, bgr, out_size)
+    FC.check_against_golden(g, cost, u8, tol=2e-4)
+    oc, ou8 = fcn_oracle.forward(W, bgr, out_size)
+    assert np.abs(cost - oc).max() < 2e-4
+    cb, ub = fcn_oracle_torch.forward(T, np.stack([bgr, bgr[::-1].copy()]), out_size)
+    assert cb.shape == (2,) + tuple(out_size) and np.abs(cb[0] - cost).max() < 1e-5

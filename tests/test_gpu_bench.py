@@ -35,3 +35,33 @@ def test_bench_line_contract():
 def test_exchange_step_single_rank():
     j = _run("--pairs", "16", "--stream", "32", "--force-gather", "--no-introspect")
     assert j["value"] > 0
+
+
+def _device_count():
+    import iv_slam_amd
+    return iv_slam_amd.load().ivf_device_count()
+
+
+def test_bench_gpus_flag_spawns_ranks_nccl():
+    """`bench.py --gpus 2` with WORLD_SIZE unset must start two ranks itself (RCCL all-gather between them) and print
+    ONE line with n_gpus == 2.  Runs only where two devices are visible (the driver's 8-GPU node); skipped on 1-GPU boxes."""
+    if _device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--pairs", "16", "--stream", "32"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["exchange"]["world"] == 2 and j["exchange"]["records_checked"] > 0
+
+
+def test_bench_refuses_world_size_mismatch():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stdout + r.stderr)

@@ -559,3 +559,129 @@ def test_cross_frame_matching_through_gather_records(iv):
         oa, on = O.search_by_projection(cur["kps"], cur["desc"], cur["uright"], bounds, q, True)
         assert gn == on and np.array_equal(ga, oa)
         assert gn > 0.5 * len(lk)                                     # the shifted scene really re-matches
+
+
+@pytest.mark.parametrize("size,n,ini", [((1242, 375), 1000, 20), ((640, 240), 500, 20), ((960, 600), 2000, 12)])
+def test_blur_planes_bit_exact(iv, size, n, ini):
+    """Row a7 directly: every blurred level the descriptors were sampled from (GaussianBlur 7x7 sigma 2, REFLECT_101 of the
+    un-padded level, ORBextractor.cc:1276-1277) byte for byte against the oracle's blur of the oracle's own pyramid."""
+    w, h = size
+    img = synth.make_left(w, h, seed=91, idx=1)
+    g, o, gk, gd, ok, od = extract_both(iv, img, n=n, ini=ini)
+    counts = g.level_counts()
+    assert counts == o.level_counts()
+    checked = 0
+    for l in range(8):
+        if counts[l] == 0:
+            continue
+        want = O.gauss7(np.ascontiguousarray(o.pyramid(l)))
+        got = g.blur_level(l)
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), "blurred level %d differs at %d pixels" % (l, int((got != want).sum()))
+        checked += 1
+    assert checked >= 6
+
+
+def test_config3_batched_frontend_2000_features(iv):
+    """BASELINE configs[3] on one rank: batched 8-level pyramid at 1242x375 with 2000 features/frame through the batched
+    front end (4 pairs in one launch sequence), incl. the gather records the ranks exchange, all vs the oracle."""
+    import torch
+    from iv_slam_amd.frontend import unpack_gather_records
+    w, h, n, pairs = 1242, 375, 2000, 4
+    stream = synth.make_stream(pairs, w, h, seed=131)
+    dev = torch.device("cuda:0")
+    fe = iv.StereoFrontend(w, h, pairs, nfeatures=n, bf=BF, b=B)
+    fe.run(torch.from_numpy(stream[:, 0].copy()).to(dev), torch.from_numpy(stream[:, 1].copy()).to(dev))
+    rec = fe.gather_record_bytes()
+    assert rec == 16 + n * 60
+    block = torch.zeros(pairs * rec, dtype=torch.uint8, device=dev)
+    fe.pack_gather_block(block)
+    fe.sync()
+    torch.cuda.synchronize()
+    frames = unpack_gather_records(block.cpu().numpy(), n)
+    for p in range(pairs):
+        oL = O.Extractor(n, 1.2, 8, 20, 7); oR = O.Extractor(n, 1.2, 8, 20, 7)
+        okL, odL = oL(stream[p, 0]); okR, odR = oR(stream[p, 1])
+        our, odp = O.stereo_match(oL, oR, okL, odL, okR, odR, BF, B)
+        rl = fe.fetch(p, 0); rr = fe.fetch(p, 1)
+        assert_kps_equal(rl["kps"], okL, "pair %d L" % p); assert_kps_equal(rr["kps"], okR, "pair %d R" % p)
+        assert np.array_equal(rl["desc"], odL) and np.array_equal(rr["desc"], odR)
+        assert rl["uright"].tobytes() == our.tobytes() and rl["depth"].tobytes() == odp.tobytes()
+        assert len(okL) > 1500 and (our >= 0).sum() > 100
+        f = frames[p]
+        assert f["n"] == len(okL) and f["kps"].tobytes() == okL.tobytes() and np.array_equal(f["desc"], odL)
+        assert f["uright"].tobytes() == our.tobytes()
+
+
+def test_config4_jackal_stereo_frontend_4000_features_introspection(iv):
+    """BASELINE configs[4] on one rank: 1920x1200 stereo pairs, 4000 features/frame, FAST 12/7, cost map ON, through the
+    BATCHED front end incl. mvuRight / mvDepth / mvKeyQualScore (Frame.cc:89-230), vs the oracle."""
+    import torch
+    w, h, n, pairs = 1920, 1200, 4000, 2
+    bf, fx = 69.690815 * 2, 528.955512 * 2          # jackal_visual_odom_stereo_inference.yaml:8,27 scaled to the un-binned sensor
+    b = bf / fx
+    stream = synth.make_stream(pairs, w, h, seed=141)
+    cost = np.stack([synth.make_cost_map(w, h, seed=141, idx=i) for i in range(pairs)])
+    dev = torch.device("cuda:0")
+    fe = iv.StereoFrontend(w, h, pairs, nfeatures=n, iniThFAST=12, minThFAST=7, enableIntrospection=True, bf=bf, b=b, fx=fx)
+    fe.run(torch.from_numpy(stream[:, 0].copy()).to(dev), torch.from_numpy(stream[:, 1].copy()).to(dev),
+           torch.from_numpy(cost).to(dev))
+    fe.sync()
+    for p in range(pairs):
+        oL = O.Extractor(n, 1.2, 8, 12, 7, introspection=True); oR = O.Extractor(n, 1.2, 8, 12, 7, introspection=False)
+        okL, odL = oL(stream[p, 0], cost[p], cap=2 * n); okR, odR = oR(stream[p, 1], cost[p], cap=2 * n)
+        our, odp = O.stereo_match(oL, oR, okL, odL, okR, odR, bf, b)
+        rl = fe.fetch(p, 0); rr = fe.fetch(p, 1)
+        assert_kps_equal(rl["kps"], okL, "pair %d L" % p); assert_kps_equal(rr["kps"], okR, "pair %d R" % p)
+        assert np.array_equal(rl["desc"], odL) and np.array_equal(rr["desc"], odR)
+        assert rl["uright"].tobytes() == our.tobytes() and rl["depth"].tobytes() == odp.tobytes()
+        assert len(okL) > 3000 and (our >= 0).sum() > 200
+        px = np.rint(okL["x"]).astype(int); py = np.rint(okL["y"]).astype(int)
+        c = cost[p][py, px].astype(np.float32)
+        q = (np.float64(1.0) / (np.float64(1.0) + (c / np.float32(256)).astype(np.float64))).astype(np.float32)
+        assert np.array_equal(rl["quality"], (np.float32(2) * q - np.float32(1)).astype(np.float32))
+
+
+def test_huge_cells_take_the_global_fallback(iv):
+    """Few features on a big corner-dense image: 1920x1200 at N=500 has 627x290-pixel cells holding far more than the 4096
+    survivors the LDS selection paths handle; those cells go through k_cell_select_huge (global scratch).  The handle must
+    stay usable afterwards, and a later ordinary image must not see stale flags."""
+    rng = np.random.default_rng(19)
+    img = (rng.integers(0, 4, size=(1200, 1920)) * 60 + 20).astype(np.uint8)
+    g = iv.ORBextractor(500, 1.2, 8, 20, 7)
+    o = O.Extractor(500, 1.2, 8, 20, 7)
+    gk, gd = g(img)
+    ok, od = o(img, cap=2000)
+    assert g.level_counts() == o.level_counts()
+    assert_kps_equal(gk, ok, "huge cells")
+    assert np.array_equal(gd, od)
+    img2 = synth.make_left(1920, 1200, seed=3, idx=0)
+    gk2, gd2 = g(img2)
+    ok2, od2 = o(img2, cap=2000)
+    assert_kps_equal(gk2, ok2, "after huge")
+    assert np.array_equal(gd2, od2)
+
+
+def test_quality_scores_without_extractor_introspection(iv):
+    """Frame.cc:130-143 fills mvKeyQualScore whenever a cost image comes with the frame, also when the extractor was
+    built with enableIntrospection = 0 (then the keypoints are the plain ones and only the scores use the map)."""
+    import torch
+    w, h, n = 640, 240, 500
+    stream = synth.make_stream(1, w, h, seed=43)
+    cost = np.stack([synth.make_cost_map(w, h, seed=43, idx=0)])
+    dev = torch.device("cuda:0")
+    fe = iv.StereoFrontend(w, h, 1, nfeatures=n, enableIntrospection=False, bf=BF, b=B)
+    fe.run(torch.from_numpy(stream[:, 0].copy()).to(dev), torch.from_numpy(stream[:, 1].copy()).to(dev), torch.from_numpy(cost).to(dev))
+    fe.sync()
+    okL, odL = O.Extractor(n, 1.2, 8, 20, 7)(stream[0, 0])
+    rl = fe.fetch(0, 0)
+    assert_kps_equal(rl["kps"], okL, "plain keypoints")
+    px = np.rint(okL["x"]).astype(int); py = np.rint(okL["y"]).astype(int)
+    c = cost[0][py, px].astype(np.float32)
+    q = (np.float64(1.0) / (np.float64(1.0) + (c / np.float32(256)).astype(np.float64))).astype(np.float32)
+    assert np.array_equal(rl["quality"], (np.float32(2) * q - np.float32(1)).astype(np.float32))
+    assert (fe.fetch(0, 1)["quality"] == 1.0).all()
+    # and without a cost image the scores stay 1 (Frame.cc:137-141 else branch)
+    fe.run(torch.from_numpy(stream[:, 0].copy()).to(dev), torch.from_numpy(stream[:, 1].copy()).to(dev))
+    fe.sync()
+    assert (fe.fetch(0, 0)["quality"] == 1.0).all()
