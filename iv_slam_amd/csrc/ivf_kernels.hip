@@ -31,6 +31,13 @@ DEVINL int wave_sum_i32(int v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// LDS operations of one wave execute in order: a wavefront-scope fence (compiler ordering) is all that one lane needs to
+// read what another lane of the same wave wrote
+DEVINL void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 DEVINL unsigned wave_min_u32(unsigned v)
 {
 #pragma unroll
@@ -633,11 +640,6 @@ DEVINL void sel_nth_element(PTR v, int n, int nth)
 // steps instead of O(range).  median-of-3, the <= 3 element insertion sort and the depth-limit heap-select
 // fallback stay on lane 0.  All 64 lanes call this with uniform arguments; v, A, B live in LDS.
 // ------------------------------------------------------------------------------------------------
-DEVINL void wave_sync_lds()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
 // GLOBAL = the lists live in global memory (k_cell_select_huge): order the wave's own stores and loads with a
 // workgroup-scope fence (s_waitcnt vmcnt(0)); the CU's L1 is write-through, so the wave then reads what it wrote
 template <bool GLOBAL> DEVINL void wave_sync_mem()
