@@ -131,6 +131,17 @@ int  ivf_search_by_projection(const ivf_keypoint* cur_kps, const uint8_t* cur_de
                               const uint8_t* q_valid, const uint8_t* q_blocks,
                               int check_orientation, int32_t* cur_assign, int* nmatches, int device_id);
 
+/* Same search; additionally cur_removed[n_cur] (nullable) = 1 where a keypoint was matched in this call and then dropped by
+ * the rotation-consistency filter: the reference sets such an entry of mvpMapPoints to NULL (:1504) even if it held a map
+ * point without observations before the call, which cur_assign == -1 alone cannot tell from "never touched". */
+int  ivf_search_by_projection_ex(const ivf_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int n_cur,
+                                 const ivf_bounds* bounds,
+                                 int n_q, const float* q_u, const float* q_v, const float* q_ur, const float* q_radius,
+                                 const int32_t* q_min_level, const int32_t* q_max_level,
+                                 const float* q_angle, const uint8_t* q_desc,
+                                 const uint8_t* q_valid, const uint8_t* q_blocks,
+                                 int check_orientation, int32_t* cur_assign, uint8_t* cur_removed, int* nmatches, int device_id);
+
 /* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th) (ORB/src/ORBmatcher.cc:45-135; called
  * from Tracking::SearchLocalPoints, ORB/src/Tracking.cc:2124-2130) on flat queries, one per map point with
  * mbTrackInView && !isBad():  q_u,q_v = mTrackProjX/Y; q_ur = mTrackProjXR; q_radius = r * mvScaleFactors[level] with

@@ -58,6 +58,8 @@ _SIGS = {
                                        vp, C.c_int, C.POINTER(C.c_int)]),
     "ivf_search_by_projection": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                            vp, vp, C.c_int, vp, C.POINTER(C.c_int), C.c_int]),
+    "ivf_search_by_projection_ex": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
+                                              vp, vp, C.c_int, vp, vp, C.POINTER(C.c_int), C.c_int]),
     "ivf_search_map_points": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                         C.c_float, vp, C.POINTER(C.c_int), C.c_int]),
     "ivf_update_quality_scores": (C.c_int, [vp, C.c_int, vp, vp, C.c_int]),

@@ -638,7 +638,7 @@ int ivf_features_in_area(const ivf_keypoint* kps, int n, const ivf_bounds* bound
 // (ORBmatcher.cc:1444-1511): candidates of query i = cand[qStart[i] .. qStart[i+1]) in GetFeaturesInArea order
 static int replay_projection(const ivf_keypoint* cur_kps, const float* cur_uright, int n_q, const float* q_ur, const float* q_radius,
                              const float* q_angle, const uint8_t* q_blocks, int check_orientation, const std::vector<int>& qStart,
-                             const std::vector<int>& cand, const std::vector<int>& dist, int32_t* cur_assign)
+                             const std::vector<int>& cand, const std::vector<int>& dist, int32_t* cur_assign, uint8_t* removed = nullptr)
 {
     const int HISTO_LENGTH = 30;
     std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
@@ -676,7 +676,7 @@ static int replay_projection(const ivf_keypoint* cur_kps, const float* cur_urigh
         else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
         for (int i = 0; i < HISTO_LENGTH; i++)
             if (i != ind1 && i != ind2 && i != ind3)
-                for (int j : rotHist[i]) { cur_assign[j] = -1; nm--; }
+                for (int j : rotHist[i]) { cur_assign[j] = -1; nm--; if (removed) removed[j] = 1; }
     }
     return nm;
 }
@@ -713,6 +713,18 @@ int ivf_search_by_projection(const ivf_keypoint* cur_kps, const uint8_t* cur_des
                              const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid, const uint8_t* q_blocks,
                              int check_orientation, int32_t* cur_assign, int* nmatches, int device_id)
 {
+    return ivf_search_by_projection_ex(cur_kps, cur_desc, cur_uright, n_cur, bounds, n_q, q_u, q_v, q_ur, q_radius, q_min_level,
+                                       q_max_level, q_angle, q_desc, q_valid, q_blocks, check_orientation, cur_assign, nullptr,
+                                       nmatches, device_id);
+}
+
+int ivf_search_by_projection_ex(const ivf_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int n_cur,
+                                const ivf_bounds* bounds, int n_q, const float* q_u, const float* q_v, const float* q_ur,
+                                const float* q_radius, const int32_t* q_min_level, const int32_t* q_max_level,
+                                const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid, const uint8_t* q_blocks,
+                                int check_orientation, int32_t* cur_assign, uint8_t* cur_removed, int* nmatches, int device_id)
+{
+    if (cur_removed && n_cur > 0) memset(cur_removed, 0, (size_t)n_cur);
     if (!cur_kps || !cur_desc || !cur_uright || !bounds || !cur_assign || !nmatches || n_cur < 0 || n_q < 0)
         return fail(IVF_E_INVALID, "bad argument");
     *nmatches = 0;
@@ -737,7 +749,8 @@ int ivf_search_by_projection(const ivf_keypoint* cur_kps, const uint8_t* cur_des
     // 3. order-dependent greedy assignment + rotation histogram, replayed in query order (:1444-1511)
     std::vector<int> cand(std::max(nPairs, 1));
     for (int p = 0; p < nPairs; p++) cand[p] = pairs[2 * p + 1];
-    const int nm = replay_projection(cur_kps, cur_uright, n_q, q_ur, q_radius, q_angle, q_blocks, check_orientation, qStart, cand, dist, cur_assign);
+    const int nm = replay_projection(cur_kps, cur_uright, n_q, q_ur, q_radius, q_angle, q_blocks, check_orientation, qStart, cand, dist, cur_assign,
+                                     cur_removed);
     *nmatches = nm;
     return IVF_OK;
 }

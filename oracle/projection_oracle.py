@@ -1,0 +1,244 @@
+"""projection_oracle.py -- CPU ORACLE (TEST INFRASTRUCTURE ONLY) of the PROJECTION / BOOKKEEPING loops that surround the
+window searches of ORB_SLAM2::ORBmatcher: numpy restatement, plain Python loops (small cases), of
+
+  SearchByProjection(Frame&, const Frame&, th, bMono)            ORB/src/ORBmatcher.cc:1372-1518
+  SearchByProjection(Frame&, vector<MapPoint*>&, th)             ORB/src/ORBmatcher.cc:45-135
+  SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, d)    ORB/src/ORBmatcher.cc:1520-1652
+  SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th)    ORB/src/ORBmatcher.cc:296-404
+  Fuse(KeyFrame*, vpMapPoints, th)                               ORB/src/ORBmatcher.cc:831-981
+
+The window search + greedy replay of each is the C oracle's (oracle/ivf_oracle.c through tests/oracle_lib.py); this file adds
+what the reference does around it with cv::Mat expressions.  Those expressions' arithmetic lives in un-vendored OpenCV:
+PARITY UNPINNED, frozen as DESIGN.md A-11 (gemm: double accumulation then one narrowing; norm / dot in double; scalar scale in
+float).  Independent of include/ivfront_orbslam.hpp (different language, different structure): the adapter test compares the two.
+"""
+import math
+
+import numpy as np
+
+F = np.float32
+D = np.float64
+
+
+def mul_add(R, p, t):
+    """cv::gemm A*B + C for CV_32F: (float)(sum (double)a*(double)b + (double)c)."""
+    R = R.astype(D); p = p.astype(D); t = t.astype(D)
+    return np.array([R[i, 0] * p[0] + R[i, 1] * p[1] + R[i, 2] * p[2] + t[i] for i in range(3)], D).astype(F)
+
+
+def neg_rt_mul(R, t):
+    R = R.astype(D); t = t.astype(D)
+    return np.array([-(R[0, j] * t[0] + R[1, j] * t[1] + R[2, j] * t[2]) for j in range(3)], D).astype(F)
+
+
+def norm(v):
+    v = v.astype(D)
+    return math.sqrt(float(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]))
+
+
+def dot(a, b):
+    a = a.astype(D); b = b.astype(D)
+    return float(a[0] * b[0] + a[1] * b[1] + a[2] * b[2])
+
+
+def predict_scale(mp, dist, frame):
+    """MapPoint::PredictScale (ORB/src/MapPoint.cc:386-420)."""
+    ratio = F(mp["maxDist"]) / F(dist)
+    n = int(math.ceil(math.log(float(ratio)) / float(frame["logScale"])))        # float log in the source: the quotient is far from
+    return min(max(n, 0), len(frame["scale"]) - 1)                                # an integer in every test scenario
+
+
+def _occupancy(mps, pool, any_occupant):
+    a = np.full(len(mps), -1, np.int32)
+    for i, m in enumerate(mps):
+        if m >= 0 and (any_occupant or pool[m]["nObs"] > 0):
+            a[i] = -2
+    return a
+
+
+def _q(rows, keys):
+    return {k: np.array([r[k] for r in rows]) if rows else np.zeros((0,) + ((32,) if k == "desc" else ())) for k in keys}
+
+
+def search_cur_last(O, cur, last, pool, cur_mps, th, mono):
+    Rcw, tcw = cur["T"][:3, :3], cur["T"][:3, 3]
+    twc = neg_rt_mul(Rcw, tcw)
+    tlc = mul_add(last["T"][:3, :3], twc, last["T"][:3, 3])
+    fwd = bool(tlc[2] > F(cur["mb"])) and not mono
+    bwd = bool(-tlc[2] > F(cur["mb"])) and not mono
+    rows, src = [], []
+    for i in range(len(last["kps"])):
+        m = last["mps"][i]
+        if m < 0 or last["outlier"][i]:
+            continue
+        x = mul_add(Rcw, pool[m]["pos"], tcw)
+        invz = F(D(1.0) / D(x[2]))
+        if invz < 0:
+            continue
+        u = F(F(F(cur["fx"]) * x[0]) * invz) + F(cur["cx"]); v = F(F(F(cur["fy"]) * x[1]) * invz) + F(cur["cy"])
+        u = F(u); v = F(v)
+        if u < cur["bounds"][0] or u > cur["bounds"][2] or v < cur["bounds"][1] or v > cur["bounds"][3]:
+            continue
+        o = int(last["kps"]["octave"][i])
+        radius = F(F(th) * cur["scale"][o])
+        lo, hi = (o, -1) if fwd else (0, o) if bwd else (o - 1, o + 1)
+        ur = F(u - F(F(cur["mbf"]) * invz))
+        rows.append(dict(u=u, v=v, ur=ur, radius=radius, min_level=lo, max_level=hi, angle=last["kps"]["angle"][i],
+                         desc=pool[m]["desc"], valid=1, blocks=1 if pool[m]["nObs"] > 0 else 0))
+        src.append(i)
+    out = list(cur_mps)
+    if not rows:
+        return 0, out
+    q = _q(rows, ("u", "v", "ur", "radius", "min_level", "max_level", "angle", "desc", "valid", "blocks"))
+    occ = _occupancy(cur_mps, pool, False)
+    a0, _ = O.search_by_projection(cur["kps"], cur["desc"], cur["uright"], cur["bounds"], q, False, occ)
+    a1, nm = O.search_by_projection(cur["kps"], cur["desc"], cur["uright"], cur["bounds"], q, True, occ)
+    for i in range(len(out)):
+        if a1[i] >= 0:
+            out[i] = last["mps"][src[a1[i]]]
+        elif a0[i] >= 0:
+            out[i] = -1                     # matched, then dropped by the rotation filter: NULL (:1504)
+    return nm, out
+
+
+def search_local_points(O, cur, pool, cur_mps, local, th, nn_ratio):
+    rows, src = [], []
+    for k, m in enumerate(local):
+        p = pool[m]
+        if not p["inView"] or p["bad"]:
+            continue
+        r = F(2.5) if F(p["viewCos"]) > 0.998 else F(4.0)
+        if th != 1.0:
+            r = F(r * F(th))
+        lv = p["trackLevel"]
+        rows.append(dict(u=p["projX"], v=p["projY"], ur=p["projXR"], radius=F(r * cur["scale"][lv]), level=lv, desc=p["desc"], valid=1,
+                         blocks=1 if p["nObs"] > 0 else 0))
+        src.append(m)
+    out = list(cur_mps)
+    if not rows:
+        return 0, out
+    q = _q(rows, ("u", "v", "ur", "radius", "level", "desc", "valid", "blocks"))
+    a, nm = O.search_map_points(cur["kps"], cur["desc"], cur["uright"], cur["bounds"], q, nn_ratio, _occupancy(cur_mps, pool, False))
+    for i in range(len(out)):
+        if a[i] >= 0:
+            out[i] = src[a[i]]
+    return nm, out
+
+
+def search_reloc(O, cur, kf, pool, cur_mps, found, th, orb_dist):
+    Rcw, tcw = cur["T"][:3, :3], cur["T"][:3, 3]
+    Ow = neg_rt_mul(Rcw, tcw)
+    rows, src = [], []
+    for i, m in enumerate(kf["mps"]):
+        if m < 0 or pool[m]["bad"] or m in found:
+            continue
+        xw = pool[m]["pos"]
+        x = mul_add(Rcw, xw, tcw)
+        invz = F(D(1.0) / D(x[2]))
+        u = F(F(F(F(cur["fx"]) * x[0]) * invz) + F(cur["cx"])); v = F(F(F(F(cur["fy"]) * x[1]) * invz) + F(cur["cy"]))
+        if u < cur["bounds"][0] or u > cur["bounds"][2] or v < cur["bounds"][1] or v > cur["bounds"][3]:
+            continue
+        dist = F(norm((xw - Ow).astype(F)))
+        if dist < F(F(0.8) * F(pool[m]["minDist"])) or dist > F(F(1.2) * F(pool[m]["maxDist"])):
+            continue
+        lv = predict_scale(pool[m], dist, cur)
+        rows.append(dict(u=u, v=v, radius=F(F(th) * cur["scale"][lv]), level=lv, angle=kf["kps"]["angle"][i], desc=pool[m]["desc"], valid=1))
+        src.append(m)
+    out = list(cur_mps)
+    if not rows:
+        return 0, out
+    q = _q(rows, ("u", "v", "radius", "level", "angle", "desc", "valid"))
+    a, nm = O.search_by_projection_reloc(cur["kps"], cur["desc"], cur["bounds"], q, orb_dist, True, _occupancy(cur_mps, pool, True))
+    for i in range(len(out)):
+        if a[i] >= 0:
+            out[i] = src[a[i]]
+    return nm, out
+
+
+def _project_kf(kf, Rcw, tcw, Ow, p, invz_float_one):
+    """the common keyframe projection (:318-365, :859-905): returns (u, v, dist, p3Dc) or None."""
+    xw = p["pos"]
+    x = mul_add(Rcw, xw, tcw)
+    if x[2] < 0.0:
+        return None
+    invz = F(F(1) / x[2]) if invz_float_one else F(D(1.0) / D(x[2]))
+    u = F(F(F(kf["fx"]) * F(x[0] * invz)) + F(kf["cx"])); v = F(F(F(kf["fy"]) * F(x[1] * invz)) + F(kf["cy"]))
+    b = kf["bounds"]
+    if not (u >= b[0] and u < b[2] and v >= b[1] and v < b[3]):                     # KeyFrame::IsInImage
+        return None
+    PO = (xw - Ow).astype(F)
+    dist = F(norm(PO))
+    if dist < F(F(0.8) * F(p["minDist"])) or dist > F(F(1.2) * F(p["maxDist"])):
+        return None
+    if dot(PO, p["normal"]) < 0.5 * float(dist):
+        return None
+    return u, v, dist, x
+
+
+def search_kf_sim3(O, kf, Scw, pool, points, th):
+    s = Scw[:3, :3]
+    scw = F(math.sqrt(dot(s[0], s[0])))
+    a = F(D(1.0) / D(scw))
+    Rcw = (s * a).astype(F); tcw = (Scw[:3, 3] * a).astype(F)
+    Ow = neg_rt_mul(Rcw, tcw)
+    rows, src = [], []
+    for m in points:
+        if pool[m]["bad"]:
+            continue
+        pr = _project_kf(kf, Rcw, tcw, Ow, pool[m], True)
+        if pr is None:
+            continue
+        u, v, dist, _ = pr
+        lv = predict_scale(pool[m], dist, kf)
+        rows.append(dict(u=u, v=v, radius=F(F(th) * kf["scale"][lv]), level=lv, desc=pool[m]["desc"], valid=1))
+        src.append(m)
+    out = [-1] * len(kf["kps"])
+    if not rows:
+        return 0, out
+    q = _q(rows, ("u", "v", "radius", "level", "desc", "valid"))
+    a, nm = O.search_keyframe_points(kf["kps"], kf["desc"], kf["bounds"], q)
+    for i in range(len(out)):
+        if a[i] >= 0:
+            out[i] = src[a[i]]
+    return nm, out
+
+
+def fuse(O, kf, pool, points, th):
+    """returns (nFused, kf map points after, replacedBy per map point); mutates copies only."""
+    Rcw, tcw, Ow = kf["T"][:3, :3], kf["T"][:3, 3], kf["Ow"]
+    kf_mps = list(kf["mps"])
+    in_kf = {m: i for i, m in enumerate(kf_mps) if m >= 0}
+    nobs = {m: pool[m]["nObs"] for m in range(len(pool))}
+    bad = {m: pool[m]["bad"] for m in range(len(pool))}
+    replaced = [-1] * len(pool)
+    rows, src = [], []
+    for m in points:
+        if bad[m] or m in in_kf:
+            continue
+        pr = _project_kf(kf, Rcw, tcw, Ow, pool[m], True)
+        if pr is None:
+            continue
+        u, v, dist, x = pr
+        invz = F(F(1) / x[2])
+        lv = predict_scale(pool[m], dist, kf)
+        rows.append(dict(u=u, v=v, ur=F(u - F(F(kf["mbf"]) * invz)), radius=F(F(th) * kf["scale"][lv]), level=lv, desc=pool[m]["desc"], valid=1))
+        src.append(m)
+    if not rows:
+        return 0, kf_mps, replaced
+    q = _q(rows, ("u", "v", "ur", "radius", "level", "desc", "valid"))
+    best, _ = O.fuse_candidates(kf["kps"], kf["desc"], kf["uright"], kf["bounds"], kf["invSigma2"], q)
+    n = 0
+    for k, m in enumerate(src):
+        if best[k] < 0:
+            continue
+        other = kf_mps[best[k]]
+        if other >= 0:
+            if not bad[other]:
+                if nobs[other] > nobs[m]:
+                    replaced[m] = other; bad[m] = True
+                else:
+                    replaced[other] = m; bad[other] = True
+        else:
+            nobs[m] += 1; kf_mps[best[k]] = m
+        n += 1
+    return n, kf_mps, replaced
