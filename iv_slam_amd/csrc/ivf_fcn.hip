@@ -1773,6 +1773,27 @@ int upload(ivf_fcn* f, const std::vector<float>& h, float** d)
     return IVF_OK;
 }
 
+// Per-output-channel power-of-two pre-scaling of a convolution's weights, folded into the BatchNorm scale that follows it
+// (both exact: only exponents change).  The split-f16 products keep 22 significant bits of a weight only while its `lo`
+// half is a NORMAL f16, i.e. while |w| >~ 2^-3: the small pointwise weights of a trained checkpoint (~1e-3) would keep
+// ~14 bits (lo in f16 subnormals).  Row r is scaled so that its largest |w| lands in [1, 2); the accumulator then comes out
+// 2^e times larger and scale[r] * 2^-e undoes it in the epilogue.  Returns the scaled copy of w; sc is updated in place.
+std::vector<float> prescale_rows(const float* w, int cout, int rowLen, std::vector<float>& sc)
+{
+    std::vector<float> ws((size_t)cout * rowLen);
+    for (int co = 0; co < cout; co++) {
+        float m = 0.f;
+        for (int k = 0; k < rowLen; k++) m = std::max(m, std::fabs(w[(size_t)co * rowLen + k]));
+        int e = 0;
+        if (m > 0.f && std::isfinite(m)) { int ex; (void)std::frexp(m, &ex); e = 1 - ex; }      // m = f * 2^ex, f in [0.5, 1)
+        e = std::min(std::max(e, -100), 100);
+        for (int k = 0; k < rowLen; k++) ws[(size_t)co * rowLen + k] = std::ldexp(w[(size_t)co * rowLen + k], e);
+        sc[co] = std::ldexp(sc[co], -e);
+    }
+    return ws;
+}
+
+// w / sc: already pre-scaled (prescale_rows)
 int make_gemm(ivf_fcn* f, const float* w, int cout, int cin, int taps, const std::vector<float>& sc,
               const std::vector<float>& sh, int act, Gemm& g)
 {
@@ -1969,7 +1990,7 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
     {   // features[0]
         const float* w = rd.take(32 * 27);
         if (!w || !read_bn(32)) return bad();
-        std::vector<float> hw(w, w + 32 * 27);
+        std::vector<float> hw = prescale_rows(w, 32, 27, sc);
         if ((rc = upload(f, hw, &f->dConv0W)) || (rc = upload(f, sc, &f->dConv0S)) || (rc = upload(f, sh, &f->dConv0B))) { ivf_fcn_destroy(f); return rc; }
     }
     for (int i = 0; i < 17; i++) {
@@ -1978,7 +1999,8 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
         if (bk.t != 1) {
             const float* w = rd.take((size_t)hid * bk.inp);
             if (!w || !read_bn(hid)) return bad();
-            Gemm g; if ((rc = make_gemm(f, w, hid, bk.inp, 1, sc, sh, 1, g))) { ivf_fcn_destroy(f); return rc; }
+            const std::vector<float> ws = prescale_rows(w, hid, bk.inp, sc);
+            Gemm g; if ((rc = make_gemm(f, ws.data(), hid, bk.inp, 1, sc, sh, 1, g))) { ivf_fcn_destroy(f); return rc; }
             f->pw.push_back(g);
         }
         {
@@ -1998,18 +2020,17 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
         {
             const float* w = rd.take((size_t)bk.oup * hid);
             if (!w || !read_bn(bk.oup)) return bad();
-            Gemm g; if ((rc = make_gemm(f, w, bk.oup, hid, 1, sc, sh, 0, g))) { ivf_fcn_destroy(f); return rc; }
-            if (i == 0) {
-                std::vector<float> pw0(w, w + (size_t)bk.oup * hid);
-                if ((rc = upload(f, pw0, &f->dProj0W))) { ivf_fcn_destroy(f); return rc; }
-            }
+            const std::vector<float> ws = prescale_rows(w, bk.oup, hid, sc);
+            Gemm g; if ((rc = make_gemm(f, ws.data(), bk.oup, hid, 1, sc, sh, 0, g))) { ivf_fcn_destroy(f); return rc; }
+            if (i == 0 && (rc = upload(f, ws, &f->dProj0W))) { ivf_fcn_destroy(f); return rc; }      // same pre-scaled rows, f32 (k_fcn_stem)
             f->pw.push_back(g);
         }
     }
     {   // decoder: cbr (3x3 320->80 + BN + ReLU), cbr_deepsup (unused at inference), conv_last, conv_last_deepsup (unused)
         const float* w = rd.take((size_t)80 * 320 * 9);
         if (!w || !read_bn(80)) return bad();
-        Gemm g; if ((rc = make_gemm(f, w, 80, 320, 9, sc, sh, 2, g))) { ivf_fcn_destroy(f); return rc; }
+        const std::vector<float> ws = prescale_rows(w, 80, 320 * 9, sc);
+        Gemm g; if ((rc = make_gemm(f, ws.data(), 80, 320, 9, sc, sh, 2, g))) { ivf_fcn_destroy(f); return rc; }
         f->pw.push_back(g);
         if (!rd.take((size_t)80 * 160 * 9) || !rd.take(4 * 80)) return bad();
         const float* lw = rd.take(80); const float* lb = rd.take(1);

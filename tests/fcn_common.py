@@ -19,6 +19,17 @@ def load_case(tag):
     g = np.load(os.path.join(GOLD, "fcn_%s.npz" % tag))
     seed = int(g["seed"][0]); w, h = (int(v) for v in g["size"])
     W = fcn_weights.make_seeded_weights(seed)
+    if "bn_stats" in g.files:        # "smallw" cases: trained-checkpoint magnitudes (tests/golden/make_fcn_golden.py)
+        pw, dw = np.float32(g["pw_scale"][0]), np.float32(g["dw_scale"][0])
+        for k in W:
+            if k.endswith(".weight") and W[k].ndim == 4 and "conv_last" not in k:
+                depthwise = W[k].shape[1] == 1 and W[k].shape[2] == 3
+                W[k] = (W[k] * (dw if depthwise else pw)).astype(np.float32)
+        st = g["bn_stats"]; o = 0
+        for name, shape in fcn_weights.tensor_specs():
+            if (name.endswith("running_mean") or name.endswith("running_var")) and "deepsup" not in name:
+                n = int(np.prod(shape)); W[name] = st[o:o + n].astype(np.float32).copy(); o += n
+        assert o == st.size
     W["decoder.conv_last.weight"] = g["conv_last_weight"]
     W["decoder.conv_last.bias"] = g["conv_last_bias"]
     return g, W, bgr_image(w, h, 50 + seed), (h, w)

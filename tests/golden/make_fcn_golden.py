@@ -56,13 +56,49 @@ def run_reference(m, bgr):
 def main():
     torch.set_num_threads(8)
     # (tag, image size, seed, sub-sampling step of the committed maps); `python make_fcn_golden.py TAG...` regenerates only those
-    cases = (("kitti", (1242, 375), 3, 6), ("jackal", (960, 600), 4, 6), ("jackal_full", (1920, 1200), 6, 12))
+    # "smallw" cases: the magnitudes of a TRAINED checkpoint instead of He-normal init -- pointwise weights ~1e-3, depthwise
+    # weights ~1e-2, and every BatchNorm's running statistics set to the actual statistics of its input (one train-mode pass
+    # of the reference model with momentum 1), which puts running_var anywhere between ~1e-8 and ~1e2 and the BN scales
+    # between ~1e-1 and ~1e4.  The calibrated statistics are data produced by the reference, so they are committed.
+    cases = (("kitti", (1242, 375), 3, 6, None), ("jackal", (960, 600), 4, 6, None), ("jackal_full", (1920, 1200), 6, 12, None),
+             ("kitti_smallw", (1242, 375), 8, 6, (1e-2, 5e-2)), ("jackal_smallw", (960, 600), 9, 6, (3e-3, 2e-2)),
+             ("kitti_bigw", (1242, 375), 10, 6, (8.0, 3.0)))
     only = set(sys.argv[1:])
-    for tag, (w, h), seed, sub in cases:
+    for tag, (w, h), seed, sub, small in cases:
         if only and tag not in only:
             continue
         W = fcn_weights.make_seeded_weights(seed)
         bgr = bgr_image(w, h, 50 + seed)
+        extra = {}
+        if small is not None:
+            pw_scale, dw_scale = small
+            for k in W:
+                if k.endswith(".weight") and W[k].ndim == 4 and "conv_last" not in k:
+                    depthwise = W[k].shape[1] == 1 and W[k].shape[2] == 3
+                    W[k] = (W[k] * np.float32(dw_scale if depthwise else pw_scale)).astype(np.float32)
+            m = reference_model(W, (h, w))
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.momentum = 1.0
+            m.train()
+            with torch.no_grad():
+                m.encoder.train(); m.decoder.train()
+                x = torch.from_numpy(fcn_oracle.preprocess(bgr))
+                f = torch.nn.functional.interpolate(x, size=(512, 512), mode="bilinear", align_corners=False)
+                f = m.encoder.features(f)
+                m.decoder.cbr(f)
+            m.eval()
+            sd = m.state_dict()
+            stats = []
+            for name, _shape in fcn_weights.tensor_specs():
+                if name.endswith("running_mean") or name.endswith("running_var"):
+                    if "deepsup" in name:
+                        continue
+                    W[name] = sd[name].numpy().astype(np.float32).copy()
+                    stats.append(W[name].reshape(-1))
+            extra = dict(bn_stats=np.concatenate(stats), pw_scale=np.array([pw_scale], np.float32), dw_scale=np.array([dw_scale], np.float32))
+            rv = np.concatenate([W[k].reshape(-1) for k in W if k.endswith("running_var") and "deepsup" not in k])
+            print(tag, "running_var range %.3g .. %.3g, median %.3g" % (rv.min(), rv.max(), np.median(rv)))
         # calibrate conv_last so the logits straddle 0.5 (otherwise the logistic saturates to 0/1 everywhere)
         m = reference_model(W, (h, w))
         _, _, logits, _ = run_reference(m, bgr)
@@ -85,7 +121,7 @@ def main():
                             conv_last_weight=W["decoder.conv_last.weight"], conv_last_bias=W["decoder.conv_last.bias"],
                             cost_sub=y[::sub, ::sub].copy(), u8_sub=u8[::sub, ::sub].copy(), sub=np.array([sub]), logits=logits.copy(),
                             tap_stats=np.array([[taps[k].mean(), np.abs(taps[k]).mean(), taps[k].std()] for k in ("f0", "f7", "f17")], np.float64),
-                            f17_sub=taps["f17"][0, ::16, ::8, ::8].copy())
+                            f17_sub=taps["f17"][0, ::16, ::8, ::8].copy(), **extra)
     for f in sorted(os.listdir(HERE)):
         if f.startswith("fcn_"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

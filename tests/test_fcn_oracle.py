@@ -7,7 +7,7 @@ import fcn_common as FC
 from iv_slam_amd import fcn_weights
 
 
-@pytest.mark.parametrize("tag", ["kitti", "jackal", "jackal_full"])
+@pytest.mark.parametrize("tag", ["kitti", "jackal", "jackal_full", "kitti_smallw", "jackal_smallw", "kitti_bigw"])
 def test_oracle_matches_reference_goldens(tag):
     import fcn_oracle
     g, W, bgr, out_size = FC.load_case(tag)

@@ -16,7 +16,7 @@ def iv():
     return iv_slam_amd
 
 
-@pytest.mark.parametrize("tag", ["kitti", "jackal", "jackal_full"])
+@pytest.mark.parametrize("tag", ["kitti", "jackal", "jackal_full", "kitti_smallw", "jackal_smallw", "kitti_bigw"])
 def test_fcn_matches_reference_goldens(iv, tag):
     g, W, bgr, out_size = FC.load_case(tag)
     fcn = iv.IntrospectionFCN(fcn_weights.pack_blob(W), bgr.shape[:2], out_size)
