@@ -72,6 +72,14 @@ float ivf_extractor_get_scale_factor(const ivf_extractor* e);
  * (ORB/include/ORBextractor.h:75-89); each array has nlevels entries; any pointer may be NULL */
 int  ivf_extractor_get_scale_tables(const ivf_extractor* e, float* scale, float* inv_scale,
                                     float* sigma2, float* inv_sigma2);
+/* OpenCV-version switches for the three primitives whose arithmetic differs between OpenCV releases (the reference
+ * accepts 2.4.3 ... 4.x, ORB/CMakeLists.txt:37-46, and pins none).  0 = OpenCV >= 3.4.2 / 4.x, the default everywhere.
+ *   blur        1: cv::GaussianBlur 8U coefficients cvRound(k*256) = [18,34,49,55,49,34,18] (<= 3.4.1; saturating) (:1277)
+ *   retain_best 1: KeyPointsFilter::retainBest calls nth_element(begin, begin + n, end) instead of begin + n - 1 (2.4 / 3.x) (:1146,:1164)
+ *   atan2       1: cv::fastAtan2 = x*y/(x^2 + 0.28 y^2) in double (<= 2.4.3) instead of the degree-7 polynomial (:104)
+ * Takes effect from the next extraction / run on the handle. */
+int  ivf_extractor_set_opencv_variant(ivf_extractor* e, int blur, int retain_best, int atan2);
+int  ivf_frontend_set_opencv_variant(ivf_frontend* fe, int blur, int retain_best, int atan2);
 /* mnFeaturesPerLevel (ORB/src/ORBextractor.cc:438-452) and umax (:458-475), for tests */
 int  ivf_extractor_get_feature_tables(const ivf_extractor* e, int32_t* features_per_level, int32_t* umax16);
 /* ORBextractor::operator()(image, mask, keypoints, descriptors) (ORB/src/ORBextractor.cc:1224-1296).

@@ -42,6 +42,8 @@ _SIGS = {
     "ivf_device_count": (C.c_int, []),
     "ivf_extractor_create": (C.c_int, [C.POINTER(ExtractorParams), C.c_int, C.POINTER(vp)]),
     "ivf_extractor_destroy": (None, [vp]),
+    "ivf_extractor_set_opencv_variant": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+    "ivf_frontend_set_opencv_variant": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
     "ivf_extractor_get_levels": (C.c_int, [vp]),
     "ivf_extractor_get_scale_factor": (C.c_float, [vp]),
     "ivf_extractor_get_scale_tables": (C.c_int, [vp, vp, vp, vp, vp]),

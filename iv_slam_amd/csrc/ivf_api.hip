@@ -80,7 +80,8 @@ struct Context {
     long long nRuns = 0;
     hipStream_t lastStream = nullptr;
 
-    int build(const Tables& t, int w, int h, int maxImages, int sides, int dev, bool withStereo);
+    int build(const Tables& t, int w, int h, int maxImages, int sides, int dev, bool withStereo, const int* variant = nullptr);
+    int set_variant(const int* variant);
     void release();
     int run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size_t imageStride, int rowStride,
             size_t costStride, int costRowStride, int nImg, const uint8_t* hUseCost, hipStream_t st,
@@ -88,7 +89,14 @@ struct Context {
     int check_status(int which = 0);
 };
 
-int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int dev, bool withStereo)
+int Context::set_variant(const int* v)
+{
+    hc.varBlur = v[0] ? 1 : 0; hc.varRetain = v[1] ? 1 : 0; hc.varAtan = v[2] ? 1 : 0;
+    if (dc) { HIPCHK(hipSetDevice(device)); HIPCHK(hipDeviceSynchronize()); HIPCHK(hipMemcpy(dc, &hc, sizeof(Config), hipMemcpyHostToDevice)); }
+    return IVF_OK;
+}
+
+int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int dev, bool withStereo, const int* variant)
 {
     device = dev; maxImg = maxImages; nSides = sides;
     introspection = t.p.enable_introspection != 0;
@@ -97,6 +105,7 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
     memset(&c, 0, sizeof c);
     c.nlevels = t.p.nlevels; c.w = w; c.h = h; c.nfeatures = t.p.nfeatures;
     c.iniTh = t.p.ini_th_fast; c.minTh = t.p.min_th_fast; c.introspection = introspection ? 1 : 0;
+    if (variant) { c.varBlur = variant[0] ? 1 : 0; c.varRetain = variant[1] ? 1 : 0; c.varAtan = variant[2] ? 1 : 0; }
     memcpy(c.umax, t.umax, sizeof c.umax);
     {   // k_describe carries umax as a packed constant (HALF_PATCH_SIZE = 15 is fixed): make sure it is this table
         const unsigned long long packed = 0x3689ABCDDEEEFFFFull;
@@ -335,6 +344,7 @@ int ivf::set_error(int code, const char* fmt, ...)
 }
 
 struct ivf_extractor {
+    int var[3] = {0, 0, 0};              // OpenCV-version switches (blur, retain, atan)
     Tables t;
     int device;
     Context ctx;
@@ -434,6 +444,21 @@ void ivf_extractor_destroy(ivf_extractor* e)
     delete e;
 }
 
+int ivf_extractor_set_opencv_variant(ivf_extractor* e, int blur, int retain_best, int atan2)
+{
+    if (!e) return fail(IVF_E_INVALID, "null handle");
+    e->var[0] = blur; e->var[1] = retain_best; e->var[2] = atan2;
+    return e->haveCtx ? e->ctx.set_variant(e->var) : IVF_OK;
+}
+
+int ivf_frontend_set_opencv_variant(ivf_frontend* fe, int blur, int retain_best, int atan2)
+{
+    if (!fe) return fail(IVF_E_INVALID, "null handle");
+    const int v[3] = {blur, retain_best, atan2};
+    for (int k = 0; k < kPipe; k++) { const int rc = fe->ctx[k].set_variant(v); if (rc) return rc; }
+    return IVF_OK;
+}
+
 int ivf_extractor_get_levels(const ivf_extractor* e) { return e ? e->t.p.nlevels : fail(IVF_E_INVALID, "null handle"); }
 float ivf_extractor_get_scale_factor(const ivf_extractor* e) { return e ? e->t.p.scale_factor : 0.f; }
 
@@ -468,7 +493,7 @@ int ivf_extract(ivf_extractor* e, const uint8_t* image, int width, int height, i
     HIPCHK(hipSetDevice(e->device));
     if (!e->haveCtx || e->w != width || e->h != height) {
         if (e->haveCtx) { e->ctx.release(); e->haveCtx = false; }
-        rc = e->ctx.build(e->t, width, height, 1, 1, e->device, true);
+        rc = e->ctx.build(e->t, width, height, 1, 1, e->device, true, e->var);
         if (rc) { e->ctx.release(); return rc; }
         e->haveCtx = true; e->w = width; e->h = height;
         e->ctx.stageBytes = (size_t)width * height * 2;

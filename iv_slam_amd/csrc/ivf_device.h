@@ -40,6 +40,7 @@ struct Config {
     int nCellsTotal;        // cells per image over all levels
     int nTiles;             // FAST tiles per image
     int nBlurTiles;         // blur tiles per image
+    int varBlur, varRetain, varAtan;   // OpenCV-version switches (ivf_extractor_set_opencv_variant): 0 = OpenCV >= 3.4.2 / 4.x
     int maxCandCap;         // largest per-cell bound on strict 3x3 maxima over the levels (k_cell_select_huge slot size)
     int umax[16];
     float scale[kMaxLevels], invScale[kMaxLevels];

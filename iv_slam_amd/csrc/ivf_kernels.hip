@@ -495,6 +495,7 @@ __global__ __launch_bounds__(256) void k_blur7(const Config* __restrict__ cfg, c
         raw[i] = v;
     }
     __syncthreads();
+    const int hk2 = cfg->varBlur ? 49 : 48, hk3 = cfg->varBlur ? 55 : 56;
     for (int i = tid; i < RH * HQ; i += 256) {
         const int ry = i / HQ, q = i % HQ;
         const unsigned w0 = raw[ry * RQ + q], w1 = raw[ry * RQ + q + 1], w2 = raw[ry * RQ + q + 2];
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(256) void k_blur7(const Config* __restrict__ cfg, c
         unsigned h[4];
 #pragma unroll
         for (int k = 0; k < 4; k++)       // output x0+4q+k is centred on window byte 4+k
-            h[k] = 18 * (b[1 + k] + b[7 + k]) + 34 * (b[2 + k] + b[6 + k]) + 48 * (b[3 + k] + b[5 + k]) + 56 * b[4 + k];
+            h[k] = 18 * (b[1 + k] + b[7 + k]) + 34 * (b[2 + k] + b[6 + k]) + hk2 * (b[3 + k] + b[5 + k]) + hk3 * b[4 + k];
         hp[i] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
     }
     __syncthreads();
@@ -514,7 +515,8 @@ __global__ __launch_bounds__(256) void k_blur7(const Config* __restrict__ cfg, c
         const int y = y0 + oy;
         if (y >= G.h) continue;
         unsigned acc[4] = {0, 0, 0, 0};
-        const unsigned kw[7] = {18, 34, 48, 56, 48, 34, 18};
+        const unsigned k2 = cfg->varBlur ? 49u : 48u, k3 = cfg->varBlur ? 55u : 56u;     // A-4: <= 3.4.1 rounds each coefficient
+        const unsigned kw[7] = {18, 34, k2, k3, k2, 34, 18};
 #pragma unroll
         for (int r = 0; r < 7; r++) {
             const uint2 v = hp[(oy + r) * HQ + q];
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(256) void k_blur7(const Config* __restrict__ cfg, c
         }
         unsigned out = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) out |= (((acc[k] + 32768u) >> 16) & 0xffu) << (8 * k);
+        for (int k = 0; k < 4; k++) out |= min((acc[k] + 32768u) >> 16, 255u) << (8 * k);      // saturate: the sum-257 table can give 257
         if (x0 + 4 * q < G.pitch) *(unsigned*)(dst + (size_t)y * G.pitch + x0 + 4 * q) = out;
     }
 }
@@ -974,7 +976,7 @@ __global__ __launch_bounds__(NTHR) void k_cell_select(const Config* __restrict__
         }
         sync();
         // d) retainBest (wave 0; the stop lists overlay `keys`, which every wave has finished reading)
-        if (nR > 0 && nT > nR && tid < 64) sel_nth_element_wave(ord, nT, nR - 1, stopA, stopB, lane);
+        if (nR > 0 && nT > nR && tid < 64) sel_nth_element_wave(ord, nT, nR - 1 + cfg->varRetain, stopA, stopB, lane);
         sync();
         for (int k = tid; k < kept; k += NTHR) dst[k] = ord[k];
     }
@@ -1069,7 +1071,7 @@ __global__ __launch_bounds__(1024) void k_cell_select_huge(const Config* __restr
             ord[k] = ((u64)__float_as_uint(resp) << 32) | (y << 16) | x;
         }
         __syncthreads();
-        if (nR > 0 && nT > nR && tid < 64) sel_nth_element_wave<u64*, unsigned*, true>(ord, nT, nR - 1, stopA, stopB, lane);
+        if (nR > 0 && nT > nR && tid < 64) sel_nth_element_wave<u64*, unsigned*, true>(ord, nT, nR - 1 + cfg->varRetain, stopA, stopB, lane);
         __syncthreads();
         for (int k = tid; k < kept; k += 1024) dst[k] = ord[k];
     }
@@ -1094,8 +1096,8 @@ __global__ __launch_bounds__(256) void k_level_select(const Config* __restrict__
             L = s_list;
             __syncthreads();
         }
-        if (L == s_list) { if (tid < 64) sel_nth_element_wave(s_list, total, G.nDesired - 1, s_stopA, s_stopB, tid); }
-        else if (tid == 0) sel_nth_element(L, total, G.nDesired - 1);   // :1162-1166 (global fallback)
+        if (L == s_list) { if (tid < 64) sel_nth_element_wave(s_list, total, G.nDesired - 1 + cfg->varRetain, s_stopA, s_stopB, tid); }
+        else if (tid == 0) sel_nth_element(L, total, G.nDesired - 1 + cfg->varRetain);   // :1162-1166 (global fallback)
         total = G.nDesired;
         __syncthreads();
     }
@@ -1147,6 +1149,17 @@ DEVINL void sincosf_glibc(float y, float& sn, float& cs)
 }
 
 // cv::fastAtan2 (OpenCV 3.x/4.x), f32, degrees
+// OpenCV <= 2.4.3: x*y / (x^2 + 0.28 y^2) in double (selected by Config::varAtan)
+DEVINL float fast_atan2_legacy(float y, float x)
+{
+    double a; const double x2 = (double)x * x, y2 = (double)y * y;
+    if (y2 <= x2) {
+        a = (180. / 3.14159265358979323846) * x * y / (x2 + 0.28 * y2 + 2.2204460492503131e-16);
+        return (float)(x < 0 ? a + 180 : y >= 0 ? a : 360 + a);
+    }
+    a = (180. / 3.14159265358979323846) * x * y / (y2 + 0.28 * x2 + 2.2204460492503131e-16);
+    return (float)(y > 0 ? 90 - a : 270 - a);
+}
 DEVINL float fast_atan2(float y, float x)
 {
     const float scale = (float)(180.0 / 3.14159265358979323846);
@@ -1229,7 +1242,7 @@ __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg
         m10 = wave_sum_i32(m10);
         m01 = wave_sum_i32(m01);
     }
-    const float angle = fast_atan2((float)m01, (float)m10);
+    const float angle = cfg->varAtan ? fast_atan2_legacy((float)m01, (float)m10) : fast_atan2((float)m01, (float)m10);
 
     // rBRIEF: lane handles tests 4*lane .. 4*lane+3
     const float factorPI = (float)(3.14159265358979323846 / 180.f);

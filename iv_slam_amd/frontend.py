@@ -46,6 +46,9 @@ class StereoFrontend:
                                          self.height * self.width, self.width, n, stream_ptr))
         self._n = n
 
+    def set_opencv_variant(self, blur=0, retain_best=0, atan2=0):
+        check(self._lib.ivf_frontend_set_opencv_variant(self._h, int(blur), int(retain_best), int(atan2)))
+
     def sync(self):
         check(self._lib.ivf_frontend_sync(self._h))
 

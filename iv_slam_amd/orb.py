@@ -101,6 +101,10 @@ class ORBextractor:
     def mvQualityImagePyramid(self):
         return [self._level(self._lib.ivf_extractor_quality_level, l) for l in range(self.nlevels)]
 
+    def set_opencv_variant(self, blur=0, retain_best=0, atan2=0):
+        """OpenCV-version switches (include/ivfront.h: ivf_extractor_set_opencv_variant); 0,0,0 = OpenCV >= 3.4.2 / 4.x."""
+        check(self._lib.ivf_extractor_set_opencv_variant(self._h, int(blur), int(retain_best), int(atan2)))
+
     def blur_level(self, level):
         """7x7 sigma-2 blurred copy of mvImagePyramid[level] (the reference's local workingMat, ORBextractor.cc:1276-1277)."""
         return self._level(self._lib.ivf_extractor_blur_level, level)

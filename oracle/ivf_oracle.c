@@ -89,8 +89,28 @@ float orc_cosf(float y)
  * A-5  cv::fastAtan2 (OpenCV 3.x/4.x mathfuncs_core: degree-7 odd polynomial, f32, degrees).
  * Called at ORB/src/ORBextractor.cc:104.
  * ---------------------------------------------------------------------------------------------- */
+/* OpenCV-version switches of the un-pinned primitives: the default is OpenCV >= 3.4.2 / 4.x;
+ * the alternatives restate what older releases computed, so a maintainer whose OpenCV differs can check both sides.
+ *   blur   0: [18,34,48,56,48,34,18]/256 (error-diffused fixed point)   1: cvRound(k*256) = [18,34,49,55,49,34,18] (<= 3.4.1)
+ *   retain 0: nth_element(begin, begin + n - 1, end)                    1: nth_element(begin, begin + n, end) (2.4 / 3.x)
+ *   atan   0: degree-7 polynomial (2.4.4+, 3.x, 4.x)                    1: x*y/(x^2 + 0.28 y^2) rational form (<= 2.4.3) */
+static int g_var_blur = 0, g_var_retain = 0, g_var_atan = 0;
+void orc_set_opencv_variant(int blur, int retain, int atan) { g_var_blur = blur; g_var_retain = retain; g_var_atan = atan; }
+
+static float fast_atan2_legacy(float y, float x)
+{
+    double a, x2 = (double)x * x, y2 = (double)y * y;
+    if (y2 <= x2) {
+        a = (180. / 3.14159265358979323846) * x * y / (x2 + 0.28 * y2 + DBL_EPSILON);
+        return (float)(x < 0 ? a + 180 : y >= 0 ? a : 360 + a);
+    }
+    a = (180. / 3.14159265358979323846) * x * y / (y2 + 0.28 * x2 + DBL_EPSILON);
+    return (float)(y > 0 ? 90 - a : 270 - a);
+}
+
 float orc_fast_atan2(float y, float x)
 {
+    if (g_var_atan) return fast_atan2_legacy(y, x);
     const float scale = (float)(180.0 / 3.14159265358979323846);
     const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
     const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
@@ -268,7 +288,7 @@ void orc_resize_linear_8u(const uint8_t* src, int sstride, int sw, int sh, uint8
  * path: 8.8 kernel with error diffusion [18,34,48,56,48,34,18]/256, exact horizontal pass,
  * 16.16 vertical pass rounded (+32768)>>16).  Called at ORB/src/ORBextractor.cc:1277.
  * ---------------------------------------------------------------------------------------------- */
-static const int GK[7] = {18, 34, 48, 56, 48, 34, 18};
+static const int GK4[7] = {18, 34, 48, 56, 48, 34, 18}, GK3[7] = {18, 34, 49, 55, 49, 34, 18};
 static inline int reflect101(int p, int n)
 {
     if (n == 1) return 0;
@@ -277,6 +297,7 @@ static inline int reflect101(int p, int n)
 }
 void orc_gauss7_8u(const uint8_t* src, int sstride, int w, int h, uint8_t* dst, int dstride)
 {
+    const int* GK = g_var_blur ? GK3 : GK4;
     uint16_t* tmp = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)w * h);
     for (int y = 0; y < h; y++) {
         const uint8_t* s = src + (size_t)y * sstride;
@@ -295,7 +316,8 @@ void orc_gauss7_8u(const uint8_t* src, int sstride, int w, int h, uint8_t* dst, 
         for (int x = 0; x < w; x++) {
             uint32_t acc = 0;
             for (int k = 0; k < 7; k++) acc += (uint32_t)GK[k] * r[k][x];
-            d[x] = (uint8_t)((acc + 32768u) >> 16);
+            const uint32_t v = (acc + 32768u) >> 16;
+            d[x] = (uint8_t)(v > 255u ? 255u : v);             /* the sum-257 table can reach 257 on a 255 plateau: saturate_cast */
         }
     }
     free(tmp);
@@ -420,7 +442,7 @@ int orc_retain_best(orc_keypoint* v, int n, int n_points)
 {
     if (n_points >= 0 && n > n_points) {
         if (n_points == 0) return 0;
-        orc_nth_element_resp(v, n, n_points - 1);
+        orc_nth_element_resp(v, n, g_var_retain ? n_points : n_points - 1);
         /* std::partition of the tail only reorders elements past n_points, which the reference's
          * resize(n_points) then drops (ORBextractor.cc:1147-1148,1165): the survivors are v[0..n_points) */
         return n_points;

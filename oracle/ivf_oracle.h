@@ -50,6 +50,8 @@ typedef struct orc_extractor orc_extractor;
 /* ---- frozen primitives (Appendix A of SURVEY.md) ---- */
 int   orc_cv_round_f(float v);
 int   orc_cv_round_d(double v);
+/* OpenCV-version switches (process-wide; 0,0,0 = OpenCV >= 3.4.2 / 4.x, the default): see ivf_oracle.c */
+void  orc_set_opencv_variant(int blur, int retain, int atan);
 float orc_fast_atan2(float y, float x);
 float orc_cosf(float x);   /* restated glibc >= 2.28 cosf (ARM optimized-routines algorithm) */
 float orc_sinf(float x);

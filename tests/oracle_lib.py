@@ -51,6 +51,14 @@ lib.orc_fast_detect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_
 lib.orc_resize_linear_8u.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]
 lib.orc_gauss7_8u.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]
 lib.orc_nth_element_resp.argtypes = [vp, C.c_int, C.c_int]
+lib.orc_set_opencv_variant.argtypes = [C.c_int, C.c_int, C.c_int]; lib.orc_set_opencv_variant.restype = None
+
+
+def set_opencv_variant(blur=0, retain=0, atan=0):
+    """process-wide OpenCV-version switches of the oracle (0,0,0 = OpenCV >= 3.4.2 / 4.x)."""
+    lib.orc_set_opencv_variant(int(blur), int(retain), int(atan))
+
+
 lib.orc_retain_best.restype = C.c_int; lib.orc_retain_best.argtypes = [vp, C.c_int, C.c_int]
 lib.orc_hamming256.restype = C.c_int; lib.orc_hamming256.argtypes = [vp, vp]
 lib.orc_bit_pattern_31.restype = C.POINTER(C.c_int8)

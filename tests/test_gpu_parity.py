@@ -685,3 +685,36 @@ def test_quality_scores_without_extractor_introspection(iv):
     fe.run(torch.from_numpy(stream[:, 0].copy()).to(dev), torch.from_numpy(stream[:, 1].copy()).to(dev))
     fe.sync()
     assert (fe.fetch(0, 0)["quality"] == 1.0).all()
+
+
+@pytest.mark.parametrize("variant", [(1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 1)])
+def test_opencv_variant_switches(iv, variant):
+    """Older-OpenCV forms of the three un-pinned primitives (blur table, retainBest nth position, fastAtan2): device ==
+    oracle under each switch, and each switch really changes the result."""
+    import torch
+    w, h, n = 640, 240, 500
+    img = synth.make_left(w, h, seed=61, idx=0)
+    base_k, base_d = iv.ORBextractor(n, 1.2, 8, 20, 7)(img)
+    try:
+        O.set_opencv_variant(*variant)
+        g = iv.ORBextractor(n, 1.2, 8, 20, 7)
+        g.set_opencv_variant(*variant)
+        gk, gd = g(img)
+        ok, od = O.Extractor(n, 1.2, 8, 20, 7)(img)
+        assert_kps_equal(gk, ok, "variant %r" % (variant,))
+        assert np.array_equal(gd, od)
+        assert gk.tobytes() != base_k.tobytes() or not np.array_equal(gd, base_d)
+        # the batched front end takes the same switches
+        stream = synth.make_stream(1, w, h, seed=61)
+        fe = iv.StereoFrontend(w, h, 1, nfeatures=n, bf=BF, b=B)
+        fe.set_opencv_variant(*variant)
+        dev = torch.device("cuda:0")
+        fe.run(torch.from_numpy(stream[:, 0].copy()).to(dev), torch.from_numpy(stream[:, 1].copy()).to(dev))
+        fe.sync()
+        assert_kps_equal(fe.fetch(0, 0)["kps"], ok, "front end variant")
+        # switching back restores the default
+        g.set_opencv_variant()
+        k0, d0 = g(img)
+        assert_kps_equal(k0, base_k, "default restored") 
+    finally:
+        O.set_opencv_variant()

@@ -285,3 +285,40 @@ def test_features_in_area_order_and_filters():
                         if abs(k["x"][i] - np.float32(x)) < r and abs(k["y"][i] - np.float32(y)) < r:
                             exp.append(i)
         assert got.tolist() == exp
+
+
+def test_opencv_variant_switches_kats():
+    """The three un-pinned primitives in their older-OpenCV forms: selectable, default 4.x."""
+    import math
+    try:
+        # A-4: impulse response = the coefficient table of the selected release; a 255 plateau must stay 255 (saturation)
+        imp = np.zeros((15, 15), np.uint8); imp[7, 7] = 255
+        for var, table in ((0, [18, 34, 48, 56, 48, 34, 18]), (1, [18, 34, 49, 55, 49, 34, 18])):
+            O.set_opencv_variant(blur=var)
+            out = O.gauss7(imp)
+            want = [(t * 56 * 255 + 32768) >> 16 if var == 0 else (t * 55 * 255 + 32768) >> 16 for t in table]
+            assert out[7, 4:11].tolist() == want, (var, out[7, 4:11].tolist(), want)
+            assert (O.gauss7(np.full((20, 20), 255, np.uint8)) == 255).all()
+            assert (O.gauss7(np.full((20, 20), 7, np.uint8)) == 7).all()
+        # A-5: the <= 2.4.3 rational approximation is within 0.3 degrees of atan2 and differs from the polynomial
+        O.set_opencv_variant(atan=1)
+        worst = 0.0
+        for y, x in ((1.0, 1.0), (3.0, -2.0), (-5.0, 0.5), (-1.0, -7.0), (0.0, 2.0), (2.0, 0.0), (100.0, 33.0)):
+            a = O.lib.orc_fast_atan2(np.float32(y), np.float32(x))
+            t = math.degrees(math.atan2(y, x)) % 360.0
+            worst = max(worst, min(abs(a - t), 360 - abs(a - t)))
+        assert 0.001 < worst < 0.31, worst
+        O.set_opencv_variant()
+        a0 = O.lib.orc_fast_atan2(np.float32(3.0), np.float32(-2.0))
+        assert abs(a0 - math.degrees(math.atan2(3.0, -2.0))) < 0.02
+        # A-6: nth position n instead of n - 1 == std::nth_element at that position (libstdc++ pin)
+        rng = np.random.default_rng(4)
+        resp = rng.integers(5, 30, 300).astype(np.float32)
+        for var in (0, 1):
+            O.set_opencv_variant(retain=var)
+            a = np.zeros(len(resp), O.KP_DTYPE); a["response"] = resp; a["x"] = np.arange(len(resp)); b = a.copy()
+            na = O.lib.orc_retain_best(O.ptr(a), len(a), 100)
+            O.pin.stl_nth_element(O.ptr(b), len(b), 100 - 1 + var)
+            assert na == 100 and np.array_equal(a[:100]["x"], b[:100]["x"]), var
+    finally:
+        O.set_opencv_variant()
