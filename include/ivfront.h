@@ -368,6 +368,27 @@ int  ivf_frame_search_map_points(ivf_frame* f, int n_q, const float* q_u, const 
                                  const int32_t* q_level, const uint8_t* q_desc, const uint8_t* q_valid, const uint8_t* q_blocks,
                                  float nn_ratio, int32_t* cur_assign, int* nmatches);
 
+/* A resident frame made straight from a batch of the front end (run `age` back, pair, side 0 = left / 1 = right): keypoints,
+ * descriptors and uRight are copied device -> device and the grid is built on the device; only the keypoint count is read
+ * back.  The greedy replays' host mirror (angle, octave, uRight: 28 B per keypoint) is fetched by the first search. */
+int  ivf_frame_create_from_frontend(ivf_frontend* fe, int age, int pair, int side, const ivf_bounds* bounds, ivf_frame** out);
+/* The remaining window searches against a resident frame: same semantics as ivf_search_keyframe_points, ivf_fuse_candidates
+ * (the frame's own uRight is the keyframe's mvuRight), ivf_search_by_sim3 (two resident keyframes) and
+ * ivf_search_by_projection_reloc, with windows AND Hamming distances computed on the device (k_grid_window). */
+int  ivf_frame_search_keyframe_points(ivf_frame* f, int n_q, const float* q_u, const float* q_v, const float* q_radius,
+                                      const int32_t* q_level, const uint8_t* q_desc, const uint8_t* q_valid, int32_t* matched, int* nmatches);
+int  ivf_frame_fuse_candidates(ivf_frame* f, const float* inv_level_sigma2, int n_levels, int n_q, const float* q_u, const float* q_v,
+                               const float* q_ur, const float* q_radius, const int32_t* q_level, const uint8_t* q_desc,
+                               const uint8_t* q_valid, int32_t* best_idx, int32_t* best_dist);
+int  ivf_frame_search_by_sim3(ivf_frame* f1, ivf_frame* f2,
+                              const float* q12_u, const float* q12_v, const float* q12_radius, const int32_t* q12_level,
+                              const uint8_t* q12_desc, const uint8_t* q12_valid,
+                              const float* q21_u, const float* q21_v, const float* q21_radius, const int32_t* q21_level,
+                              const uint8_t* q21_desc, const uint8_t* q21_valid, int32_t* matches12, int* nfound);
+int  ivf_frame_search_by_projection_reloc(ivf_frame* f, int n_q, const float* q_u, const float* q_v, const float* q_radius,
+                                          const int32_t* q_level, const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid,
+                                          int orb_dist, int check_orientation, int32_t* cur_assign, int* nmatches);
+
 /* ---- rectification in front of the extractor -------------------------------------------------
  * cv::initUndistortRectifyMap(K, D, R, P(0:3,0:3), size, CV_32F, map1, map2) as the driver calls it
  * (introspective_ORB_SLAM/Examples/Stereo/stereo_kitti.cc:285-343): host-side, double arithmetic, OpenCV 4.x plain C++

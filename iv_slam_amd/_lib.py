@@ -91,6 +91,11 @@ _SIGS = {
     "ivf_frame_grid": (C.c_int, [vp, vp, vp]),
     "ivf_frame_search_by_projection": (C.c_int, [vp, C.c_int] + [vp] * 10 + [C.c_int, vp, C.POINTER(C.c_int)]),
     "ivf_frame_search_map_points": (C.c_int, [vp, C.c_int] + [vp] * 8 + [C.c_float, vp, C.POINTER(C.c_int)]),
+    "ivf_frame_create_from_frontend": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(Bounds), C.POINTER(vp)]),
+    "ivf_frame_search_keyframe_points": (C.c_int, [vp, C.c_int] + [vp] * 7 + [C.POINTER(C.c_int)]),
+    "ivf_frame_fuse_candidates": (C.c_int, [vp, vp, C.c_int, C.c_int] + [vp] * 9),
+    "ivf_frame_search_by_sim3": (C.c_int, [vp, vp] + [vp] * 12 + [vp, C.POINTER(C.c_int)]),
+    "ivf_frame_search_by_projection_reloc": (C.c_int, [vp, C.c_int] + [vp] * 7 + [C.c_int, C.c_int, vp, C.POINTER(C.c_int)]),
     "ivf_init_undistort_rectify_map": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]),
     "ivf_remap_create": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "ivf_remap_destroy": (None, [vp]),

@@ -794,13 +794,38 @@ struct ivf_frame {
     float *dQu = nullptr, *dQv = nullptr, *dQr = nullptr; int *dQmin = nullptr, *dQmax = nullptr; uint8_t *dQdesc = nullptr, *dQvalid = nullptr;
     int *dCount = nullptr, *dCand = nullptr;
     hipStream_t stream = nullptr;
+    float* dUright = nullptr;           // frames made from a front-end batch: uRight stays on the device until a replay needs it
+    bool hostKps = true, hostDesc = true;   // host mirrors present (false: fetched on first use, see frame_host)
 };
+
+// the greedy replays read angle / octave / uRight of the frame's keypoints on the host, the overflow fallback its descriptors:
+// frames created from host arrays carry them; frames created from a front-end batch fetch them on first use (28 B per keypoint)
+static int frame_host(ivf_frame* f, bool needDesc)
+{
+    if (!f->hostKps) {
+        HIPCHK(hipSetDevice(f->device));
+        f->kps.resize(std::max(f->n, 1)); f->uright.resize(std::max(f->n, 1));
+        if (f->n > 0) {
+            HIPCHK(hipMemcpyAsync(f->kps.data(), f->dKps, (size_t)f->n * sizeof(ivf_keypoint), hipMemcpyDeviceToHost, f->stream));
+            HIPCHK(hipMemcpyAsync(f->uright.data(), f->dUright, (size_t)f->n * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+            HIPCHK(hipStreamSynchronize(f->stream));
+        }
+        f->hostKps = true;
+    }
+    if (needDesc && !f->hostDesc) {
+        HIPCHK(hipSetDevice(f->device));
+        f->desc.resize((size_t)std::max(f->n, 1) * 32);
+        if (f->n > 0) HIPCHK(hipMemcpy(f->desc.data(), f->dDesc, (size_t)f->n * 32, hipMemcpyDeviceToHost));
+        f->hostDesc = true;
+    }
+    return IVF_OK;
+}
 
 void ivf_frame_destroy(ivf_frame* f)
 {
     if (!f) return;
     (void)hipSetDevice(f->device);
-    void* ptrs[] = {f->dKps, f->dDesc, f->dStart, f->dIdx, f->dQu, f->dQv, f->dQr, f->dQmin, f->dQmax, f->dQdesc, f->dQvalid, f->dCount, f->dCand};
+    void* ptrs[] = {f->dUright, f->dKps, f->dDesc, f->dStart, f->dIdx, f->dQu, f->dQv, f->dQr, f->dQmin, f->dQmax, f->dQdesc, f->dQvalid, f->dCount, f->dCand};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (f->stream) (void)hipStreamDestroy(f->stream);
     delete f;
@@ -895,7 +920,7 @@ static int frame_candidates(ivf_frame* f, int n_q, const float* q_u, const float
             for (int k = 0; k < count[i]; k++) { cand.push_back(raw[((size_t)i * f->cCap + k) * 2]); dist.push_back(raw[((size_t)i * f->cCap + k) * 2 + 1]); }
         } else {
             // a window with more candidates than the device list holds: this query again through the host grid
-            if (!haveGrid) { g.build(f->kps.data(), f->n, f->bd); haveGrid = true; }
+            if (!haveGrid) { const int hrc = frame_host(f, true); if (hrc) return hrc; g.build(f->kps.data(), f->n, f->bd); haveGrid = true; }
             g.query(f->kps.data(), f->bd, q_u[i], q_v[i], q_radius[i], q_min_level[i], q_max_level[i], [&](int i2) {
                 cand.push_back(i2); dist.push_back(ivf_hamming(q_desc + (size_t)i * 32, f->desc.data() + (size_t)i2 * 32)); });
         }
@@ -904,6 +929,50 @@ static int frame_candidates(ivf_frame* f, int n_q, const float* q_u, const float
     if (cand.empty()) { cand.push_back(0); dist.push_back(0); }
     return IVF_OK;
 }
+
+// Where the window candidates of a set of queries (Frame / KeyFrame::GetFeaturesInArea order, octave range applied) and their
+// Hamming distances come from: a frame handed over as host arrays (host grid + k_hamming_pairs), or a device-resident
+// ivf_frame (k_grid_window: windows AND distances on the device, nothing but the queries is uploaded).
+namespace {
+struct CandSource {
+    const ivf_keypoint* kps = nullptr; const uint8_t* desc = nullptr; const float* uright = nullptr; int n = 0;
+    const ivf_bounds* bd = nullptr; int device = 0; ivf_frame* frame = nullptr;
+    static CandSource host(const ivf_keypoint* k, const uint8_t* d, const float* ur, int n, const ivf_bounds* b, int dev)
+    { CandSource s; s.kps = k; s.desc = d; s.uright = ur; s.n = n; s.bd = b; s.device = dev; return s; }
+    static int resident(ivf_frame* f, CandSource& s)
+    {
+        const int rc = frame_host(f, false); if (rc) return rc;
+        s.kps = f->kps.data(); s.uright = f->uright.data(); s.n = f->n; s.bd = &f->bd; s.device = f->device; s.frame = f;
+        return IVF_OK;
+    }
+    // candidates of query i = cand / dist [qStart[i] .. qStart[i+1]); lo / hi = GetFeaturesInArea's minLevel / maxLevel per query
+    int get(int n_q, const float* q_u, const float* q_v, const float* q_radius, const int32_t* lo, const int32_t* hi,
+            const uint8_t* q_desc, const uint8_t* q_valid, std::vector<int>& qStart, std::vector<int>& cand, std::vector<int>& dist) const
+    {
+        if (frame) return frame_candidates(frame, n_q, q_u, q_v, q_radius, lo, hi, q_desc, q_valid, qStart, cand, dist);
+        Grid g; g.build(kps, n, *bd);
+        std::vector<int> pairs;
+        qStart.assign(n_q + 1, 0);
+        for (int i = 0; i < n_q; i++) {
+            qStart[i] = (int)pairs.size() / 2;
+            if (q_valid && !q_valid[i]) continue;
+            g.query(kps, *bd, q_u[i], q_v[i], q_radius[i], lo[i], hi[i], [&](int i2) { pairs.push_back(i); pairs.push_back(i2); });
+        }
+        qStart[n_q] = (int)pairs.size() / 2;
+        const int nPairs = qStart[n_q];
+        dist.assign(std::max(nPairs, 1), 0); cand.assign(std::max(nPairs, 1), 0);
+        const int rc = ivf_hamming_pairs(q_desc, n_q, desc, n, pairs.data(), nPairs, dist.data(), device);
+        if (rc) return rc;
+        for (int p = 0; p < nPairs; p++) cand[p] = pairs[2 * p + 1];
+        return IVF_OK;
+    }
+};
+inline void level_window(int n_q, const int32_t* q_level, int below, int above, std::vector<int32_t>& lo, std::vector<int32_t>& hi)
+{
+    lo.resize(std::max(n_q, 1)); hi.resize(std::max(n_q, 1));
+    for (int i = 0; i < n_q; i++) { lo[i] = q_level[i] - below; hi[i] = q_level[i] + above; }
+}
+}  // namespace
 
 int ivf_frame_search_by_projection(ivf_frame* f, int n_q, const float* q_u, const float* q_v, const float* q_ur,
                                    const float* q_radius, const int32_t* q_min_level, const int32_t* q_max_level,
@@ -916,7 +985,9 @@ int ivf_frame_search_by_projection(ivf_frame* f, int n_q, const float* q_u, cons
     if (!q_u || !q_v || !q_ur || !q_radius || !q_min_level || !q_max_level || !q_angle || !q_desc)
         return fail(IVF_E_INVALID, "null query array");
     std::vector<int> qStart, cand, dist;
-    int rc = frame_candidates(f, n_q, q_u, q_v, q_radius, q_min_level, q_max_level, q_desc, q_valid, qStart, cand, dist);
+    int rc = frame_host(f, false);
+    if (rc) return rc;
+    rc = frame_candidates(f, n_q, q_u, q_v, q_radius, q_min_level, q_max_level, q_desc, q_valid, qStart, cand, dist);
     if (rc) return rc;
     // greedy assignment + rotation histogram on the host (:1444-1511)
     *nmatches = replay_projection(f->kps.data(), f->uright.data(), n_q, q_ur, q_radius, q_angle, q_blocks, check_orientation, qStart,
@@ -935,7 +1006,9 @@ int ivf_frame_search_map_points(ivf_frame* f, int n_q, const float* q_u, const f
     std::vector<int32_t> lo(n_q), hi(n_q);
     for (int i = 0; i < n_q; i++) { lo[i] = q_level[i] - 1; hi[i] = q_level[i]; }       // levels [pred - 1, pred] (:72-73)
     std::vector<int> qStart, cand, dist;
-    int rc = frame_candidates(f, n_q, q_u, q_v, q_radius, lo.data(), hi.data(), q_desc, q_valid, qStart, cand, dist);
+    int rc = frame_host(f, false);
+    if (rc) return rc;
+    rc = frame_candidates(f, n_q, q_u, q_v, q_radius, lo.data(), hi.data(), q_desc, q_valid, qStart, cand, dist);
     if (rc) return rc;
     *nmatches = replay_map_points(f->kps.data(), f->uright.data(), n_q, q_ur, q_radius, q_blocks, nn_ratio, qStart, cand, dist, cur_assign);
     return IVF_OK;
@@ -1052,38 +1125,23 @@ int ivf_search_for_initialization(const ivf_keypoint* kps1, const uint8_t* desc1
 }
 
 // ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (ORB/src/ORBmatcher.cc:296-404), flat queries
-int ivf_search_keyframe_points(const ivf_keypoint* kf_kps, const uint8_t* kf_desc, int n_kf, const ivf_bounds* bounds,
-                               int n_q, const float* q_u, const float* q_v, const float* q_radius, const int32_t* q_level,
-                               const uint8_t* q_desc, const uint8_t* q_valid, int32_t* matched, int* nmatches, int device_id)
+static int keyframe_points_impl(const CandSource& S, int n_q, const float* q_u, const float* q_v, const float* q_radius,
+                                const int32_t* q_level, const uint8_t* q_desc, const uint8_t* q_valid, int32_t* matched, int* nmatches)
 {
-    if (!kf_kps || !kf_desc || !bounds || !matched || !nmatches || n_kf < 0 || n_q < 0) return fail(IVF_E_INVALID, "bad argument");
     *nmatches = 0;
-    if (n_q == 0 || n_kf == 0) return IVF_OK;
+    if (n_q == 0 || S.n == 0) return IVF_OK;
     if (!q_u || !q_v || !q_radius || !q_level || !q_desc) return fail(IVF_E_INVALID, "null query array");
-    // 1. windows (KeyFrame::GetFeaturesInArea, no level arguments) filtered by octave in [level-1, level] (:384-385)
-    Grid g; g.build(kf_kps, n_kf, *bounds);
-    std::vector<int> qStart(n_q + 1, 0), pairs;
-    for (int i = 0; i < n_q; i++) {
-        qStart[i] = (int)pairs.size() / 2;
-        if (q_valid && !q_valid[i]) continue;
-        g.query(kf_kps, *bounds, q_u[i], q_v[i], q_radius[i], -1, -1, [&](int idx) {
-            const int l = kf_kps[idx].octave;
-            if (l < q_level[i] - 1 || l > q_level[i]) return;
-            pairs.push_back(i); pairs.push_back(idx);
-        });
-    }
-    qStart[n_q] = (int)pairs.size() / 2;
-    const int nPairs = qStart[n_q];
-    // 2. window distances on the device
-    std::vector<int> dist(std::max(nPairs, 1));
-    int rc = ivf_hamming_pairs(q_desc, n_q, kf_desc, n_kf, pairs.data(), nPairs, dist.data(), device_id);
+    // 1. + 2. windows (KeyFrame::GetFeaturesInArea, no level arguments) filtered by octave in [level-1, level] (:384-385), distances
+    std::vector<int32_t> lo, hi; level_window(n_q, q_level, 1, 0, lo, hi);
+    std::vector<int> qStart, cand, dist;
+    const int rc = S.get(n_q, q_u, q_v, q_radius, lo.data(), hi.data(), q_desc, q_valid, qStart, cand, dist);
     if (rc) return rc;
     // 3. greedy replay in candidate order: occupied keypoints are skipped (:379-380)
     int nm = 0;
     for (int i = 0; i < n_q; i++) {
         int bestDist = 256, bestIdx = -1;
         for (int p = qStart[i]; p < qStart[i + 1]; p++) {
-            const int idx = pairs[2 * p + 1];
+            const int idx = cand[p];
             if (matched[idx] != -1) continue;
             if (dist[p] < bestDist) { bestDist = dist[p]; bestIdx = idx; }
         }
@@ -1092,8 +1150,63 @@ int ivf_search_keyframe_points(const ivf_keypoint* kf_kps, const uint8_t* kf_des
     *nmatches = nm;
     return IVF_OK;
 }
+int ivf_search_keyframe_points(const ivf_keypoint* kf_kps, const uint8_t* kf_desc, int n_kf, const ivf_bounds* bounds,
+                               int n_q, const float* q_u, const float* q_v, const float* q_radius, const int32_t* q_level,
+                               const uint8_t* q_desc, const uint8_t* q_valid, int32_t* matched, int* nmatches, int device_id)
+{
+    if (!kf_kps || !kf_desc || !bounds || !matched || !nmatches || n_kf < 0 || n_q < 0) return fail(IVF_E_INVALID, "bad argument");
+    return keyframe_points_impl(CandSource::host(kf_kps, kf_desc, nullptr, n_kf, bounds, device_id), n_q, q_u, q_v, q_radius, q_level,
+                                q_desc, q_valid, matched, nmatches);
+}
+int ivf_frame_search_keyframe_points(ivf_frame* f, int n_q, const float* q_u, const float* q_v, const float* q_radius,
+                                     const int32_t* q_level, const uint8_t* q_desc, const uint8_t* q_valid, int32_t* matched, int* nmatches)
+{
+    if (!f || !matched || !nmatches || n_q < 0) return fail(IVF_E_INVALID, "bad argument");
+    CandSource S; const int rc = CandSource::resident(f, S); if (rc) return rc;
+    return keyframe_points_impl(S, n_q, q_u, q_v, q_radius, q_level, q_desc, q_valid, matched, nmatches);
+}
 
 // ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) matching core (ORB/src/ORBmatcher.cc:893-955), flat queries
+static int fuse_impl(const CandSource& S, const float* inv_level_sigma2, int n_levels, int n_q, const float* q_u, const float* q_v,
+                     const float* q_ur, const float* q_radius, const int32_t* q_level, const uint8_t* q_desc, const uint8_t* q_valid,
+                     int32_t* best_idx, int32_t* best_dist)
+{
+    const bool gate = inv_level_sigma2 != nullptr;               // NULL: Fuse(KF, Scw, ...) (:983-1106) has no chi-square gate
+    if (gate && (!S.uright || !q_ur || n_levels < 1)) return fail(IVF_E_INVALID, "the chi-square gate needs mvuRight, ur and the sigma table");
+    for (int i = 0; i < n_q; i++) { best_idx[i] = -1; if (best_dist) best_dist[i] = 256; }
+    if (n_q == 0 || S.n == 0) return IVF_OK;
+    if (!q_u || !q_v || !q_radius || !q_level || !q_desc) return fail(IVF_E_INVALID, "null query array");
+    if (gate)
+        for (int i = 0; i < S.n; i++)
+            if (S.kps[i].octave < 0 || S.kps[i].octave >= n_levels) return fail(IVF_E_INVALID, "keypoint %d: octave outside the sigma table", i);
+    std::vector<int32_t> lo, hi; level_window(n_q, q_level, 1, 0, lo, hi);      // octave in [level-1, level] (:913-914)
+    std::vector<int> qStart, cand, dist;
+    const int rc = S.get(n_q, q_u, q_v, q_radius, lo.data(), hi.data(), q_desc, q_valid, qStart, cand, dist);
+    if (rc) return rc;
+    for (int i = 0; i < n_q; i++) {
+        const float u = q_u[i], v = q_v[i], ur = q_ur ? q_ur[i] : 0.0f;
+        int bestDist = 256, bestIdx = -1;
+        for (int p = qStart[i]; p < qStart[i + 1]; p++) {
+            const int idx = cand[p];
+            if (gate) {                                              // chi-square gates (:918-938), f32 products compared in double
+                const ivf_keypoint& kp = S.kps[idx];
+                if (S.uright[idx] >= 0) {
+                    const float ex = u - kp.x, ey = v - kp.y, er = ur - S.uright[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_level_sigma2[kp.octave] > 7.8) continue;
+                } else {
+                    const float ex = u - kp.x, ey = v - kp.y;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_level_sigma2[kp.octave] > 5.99) continue;
+                }
+            }
+            if (dist[p] < bestDist) { bestDist = dist[p]; bestIdx = idx; }
+        }
+        if (best_dist) best_dist[i] = bestDist;
+        if (bestDist <= 50) best_idx[i] = bestIdx;
+    }
+    return IVF_OK;
+}
 int ivf_fuse_candidates(const ivf_keypoint* kf_kps, const uint8_t* kf_desc, const float* kf_uright, int n_kf,
                         const ivf_bounds* bounds, const float* inv_level_sigma2, int n_levels,
                         int n_q, const float* q_u, const float* q_v, const float* q_ur, const float* q_radius,
@@ -1101,81 +1214,59 @@ int ivf_fuse_candidates(const ivf_keypoint* kf_kps, const uint8_t* kf_desc, cons
                         int32_t* best_idx, int32_t* best_dist, int device_id)
 {
     if (!kf_kps || !kf_desc || !bounds || !best_idx || n_kf < 0 || n_q < 0) return fail(IVF_E_INVALID, "bad argument");
-    const bool gate = inv_level_sigma2 != nullptr;               // NULL: Fuse(KF, Scw, ...) (:983-1106) has no chi-square gate
-    if (gate && (!kf_uright || !q_ur || n_levels < 1)) return fail(IVF_E_INVALID, "the chi-square gate needs mvuRight, ur and the sigma table");
-    for (int i = 0; i < n_q; i++) { best_idx[i] = -1; if (best_dist) best_dist[i] = 256; }
-    if (n_q == 0 || n_kf == 0) return IVF_OK;
-    if (!q_u || !q_v || !q_radius || !q_level || !q_desc) return fail(IVF_E_INVALID, "null query array");
-    if (gate)
-        for (int i = 0; i < n_kf; i++)
-            if (kf_kps[i].octave < 0 || kf_kps[i].octave >= n_levels) return fail(IVF_E_INVALID, "keypoint %d: octave outside the sigma table", i);
-    Grid g; g.build(kf_kps, n_kf, *bounds);
-    std::vector<int> qStart(n_q + 1, 0), pairs;
-    for (int i = 0; i < n_q; i++) {
-        qStart[i] = (int)pairs.size() / 2;
-        if (q_valid && !q_valid[i]) continue;
-        const float u = q_u[i], v = q_v[i], ur = q_ur ? q_ur[i] : 0.0f;
-        g.query(kf_kps, *bounds, u, v, q_radius[i], -1, -1, [&](int idx) {
-            const ivf_keypoint& kp = kf_kps[idx];
-            const int l = kp.octave;
-            if (l < q_level[i] - 1 || l > q_level[i]) return;
-            if (!gate) {
-            } else if (kf_uright[idx] >= 0) {                               // chi-square gates (:918-938), f32 products compared in double
-                const float ex = u - kp.x, ey = v - kp.y, er = ur - kf_uright[idx];
-                const float e2 = ex * ex + ey * ey + er * er;
-                if (e2 * inv_level_sigma2[l] > 7.8) return;
-            } else {
-                const float ex = u - kp.x, ey = v - kp.y;
-                const float e2 = ex * ex + ey * ey;
-                if (e2 * inv_level_sigma2[l] > 5.99) return;
-            }
-            pairs.push_back(i); pairs.push_back(idx);
-        });
-    }
-    qStart[n_q] = (int)pairs.size() / 2;
-    const int nPairs = qStart[n_q];
-    std::vector<int> dist(std::max(nPairs, 1));
-    int rc = ivf_hamming_pairs(q_desc, n_q, kf_desc, n_kf, pairs.data(), nPairs, dist.data(), device_id);
-    if (rc) return rc;
-    for (int i = 0; i < n_q; i++) {
-        int bestDist = 256, bestIdx = -1;
-        for (int p = qStart[i]; p < qStart[i + 1]; p++)
-            if (dist[p] < bestDist) { bestDist = dist[p]; bestIdx = pairs[2 * p + 1]; }
-        if (best_dist) best_dist[i] = bestDist;
-        if (bestDist <= 50) best_idx[i] = bestIdx;
-    }
-    return IVF_OK;
+    return fuse_impl(CandSource::host(kf_kps, kf_desc, kf_uright, n_kf, bounds, device_id), inv_level_sigma2, n_levels, n_q, q_u, q_v, q_ur,
+                     q_radius, q_level, q_desc, q_valid, best_idx, best_dist);
+}
+int ivf_frame_fuse_candidates(ivf_frame* f, const float* inv_level_sigma2, int n_levels, int n_q, const float* q_u, const float* q_v,
+                              const float* q_ur, const float* q_radius, const int32_t* q_level, const uint8_t* q_desc,
+                              const uint8_t* q_valid, int32_t* best_idx, int32_t* best_dist)
+{
+    if (!f || !best_idx || n_q < 0) return fail(IVF_E_INVALID, "bad argument");
+    CandSource S; const int rc = CandSource::resident(f, S); if (rc) return rc;
+    return fuse_impl(S, inv_level_sigma2, n_levels, n_q, q_u, q_v, q_ur, q_radius, q_level, q_desc, q_valid, best_idx, best_dist);
 }
 
 // ORBmatcher::SearchBySim3 (ORB/src/ORBmatcher.cc:1145-1254) on the two sets of projected map points
 namespace {
-int window_best(const ivf_keypoint* kps, const uint8_t* desc, int n, const ivf_bounds& bd, int n_q, const float* q_u,
-                const float* q_v, const float* q_radius, const int32_t* q_level, const uint8_t* q_desc, const uint8_t* q_valid,
-                int th, int device_id, std::vector<int>& best)
+int window_best(const CandSource& S, int n_q, const float* q_u, const float* q_v, const float* q_radius, const int32_t* q_level,
+                const uint8_t* q_desc, const uint8_t* q_valid, int th, std::vector<int>& best)
 {
     best.assign(n_q, -1);
-    if (n_q == 0 || n == 0) return IVF_OK;
-    Grid g; g.build(kps, n, bd);
-    std::vector<int> qStart(n_q + 1, 0), pairs;
-    for (int i = 0; i < n_q; i++) {
-        qStart[i] = (int)pairs.size() / 2;
-        if (q_valid && !q_valid[i]) continue;
-        g.query(kps, bd, q_u[i], q_v[i], q_radius[i], -1, -1, [&](int idx) {
-            if (kps[idx].octave < q_level[i] - 1 || kps[idx].octave > q_level[i]) return;
-            pairs.push_back(i); pairs.push_back(idx);
-        });
-    }
-    qStart[n_q] = (int)pairs.size() / 2;
-    const int nPairs = qStart[n_q];
-    std::vector<int> dist(std::max(nPairs, 1));
-    const int rc = ivf_hamming_pairs(q_desc, n_q, desc, n, pairs.data(), nPairs, dist.data(), device_id);
+    if (n_q == 0 || S.n == 0) return IVF_OK;
+    std::vector<int32_t> lo, hi; level_window(n_q, q_level, 1, 0, lo, hi);      // octave in [level-1, level] (:1245-1246)
+    std::vector<int> qStart, cand, dist;
+    const int rc = S.get(n_q, q_u, q_v, q_radius, lo.data(), hi.data(), q_desc, q_valid, qStart, cand, dist);
     if (rc) return rc;
     for (int i = 0; i < n_q; i++) {
         int bestDist = INT_MAX, bestIdx = -1;
         for (int p = qStart[i]; p < qStart[i + 1]; p++)
-            if (dist[p] < bestDist) { bestDist = dist[p]; bestIdx = pairs[2 * p + 1]; }
+            if (dist[p] < bestDist) { bestDist = dist[p]; bestIdx = cand[p]; }
         if (bestDist <= th) best[i] = bestIdx;
     }
+    return IVF_OK;
+}
+int sim3_impl(const CandSource& S1, const CandSource& S2,
+              const float* q12_u, const float* q12_v, const float* q12_radius, const int32_t* q12_level, const uint8_t* q12_desc,
+              const uint8_t* q12_valid, const float* q21_u, const float* q21_v, const float* q21_radius, const int32_t* q21_level,
+              const uint8_t* q21_desc, const uint8_t* q21_valid, int32_t* matches12, int* nfound)
+{
+    const int n1 = S1.n, n2 = S2.n;
+    *nfound = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0 || n2 == 0) return IVF_OK;
+    if (!q12_u || !q12_v || !q12_radius || !q12_level || !q12_desc || !q21_u || !q21_v || !q21_radius || !q21_level || !q21_desc)
+        return fail(IVF_E_INVALID, "null query array");
+    std::vector<int> m1, m2;                                      // vnMatch1 / vnMatch2 (:1186-1187), TH_HIGH (:1264, :1344)
+    int rc = window_best(S2, n1, q12_u, q12_v, q12_radius, q12_level, q12_desc, q12_valid, 100, m1);
+    if (rc) return rc;
+    rc = window_best(S1, n2, q21_u, q21_v, q21_radius, q21_level, q21_desc, q21_valid, 100, m2);
+    if (rc) return rc;
+    int nf = 0;
+    for (int i1 = 0; i1 < n1; i1++) {                             // agreement check (:1336-1349)
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && m2[idx2] == i1) { matches12[i1] = idx2; nf++; }
+    }
+    *nfound = nf;
     return IVF_OK;
 }
 }  // namespace
@@ -1189,23 +1280,22 @@ int ivf_search_by_sim3(const ivf_keypoint* kps1, const uint8_t* desc1, int n1, c
 {
     if (!kps1 || !desc1 || !kps2 || !desc2 || !bounds1 || !bounds2 || !matches12 || !nfound || n1 < 0 || n2 < 0)
         return fail(IVF_E_INVALID, "bad argument");
-    *nfound = 0;
-    for (int i = 0; i < n1; i++) matches12[i] = -1;
-    if (n1 == 0 || n2 == 0) return IVF_OK;
-    if (!q12_u || !q12_v || !q12_radius || !q12_level || !q12_desc || !q21_u || !q21_v || !q21_radius || !q21_level || !q21_desc)
-        return fail(IVF_E_INVALID, "null query array");
-    std::vector<int> m1, m2;                                      // vnMatch1 / vnMatch2 (:1186-1187), TH_HIGH (:1264, :1344)
-    int rc = window_best(kps2, desc2, n2, *bounds2, n1, q12_u, q12_v, q12_radius, q12_level, q12_desc, q12_valid, 100, device_id, m1);
-    if (rc) return rc;
-    rc = window_best(kps1, desc1, n1, *bounds1, n2, q21_u, q21_v, q21_radius, q21_level, q21_desc, q21_valid, 100, device_id, m2);
-    if (rc) return rc;
-    int nf = 0;
-    for (int i1 = 0; i1 < n1; i1++) {                             // agreement check (:1336-1349)
-        const int idx2 = m1[i1];
-        if (idx2 >= 0 && m2[idx2] == i1) { matches12[i1] = idx2; nf++; }
-    }
-    *nfound = nf;
-    return IVF_OK;
+    return sim3_impl(CandSource::host(kps1, desc1, nullptr, n1, bounds1, device_id), CandSource::host(kps2, desc2, nullptr, n2, bounds2, device_id),
+                     q12_u, q12_v, q12_radius, q12_level, q12_desc, q12_valid, q21_u, q21_v, q21_radius, q21_level, q21_desc, q21_valid,
+                     matches12, nfound);
+}
+int ivf_frame_search_by_sim3(ivf_frame* f1, ivf_frame* f2,
+                             const float* q12_u, const float* q12_v, const float* q12_radius, const int32_t* q12_level,
+                             const uint8_t* q12_desc, const uint8_t* q12_valid,
+                             const float* q21_u, const float* q21_v, const float* q21_radius, const int32_t* q21_level,
+                             const uint8_t* q21_desc, const uint8_t* q21_valid, int32_t* matches12, int* nfound)
+{
+    if (!f1 || !f2 || !matches12 || !nfound) return fail(IVF_E_INVALID, "bad argument");
+    CandSource S1, S2;
+    int rc = CandSource::resident(f1, S1); if (rc) return rc;
+    rc = CandSource::resident(f2, S2); if (rc) return rc;
+    return sim3_impl(S1, S2, q12_u, q12_v, q12_radius, q12_level, q12_desc, q12_valid, q21_u, q21_v, q21_radius, q21_level, q21_desc,
+                     q21_valid, matches12, nfound);
 }
 
 // ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORB/src/ORBmatcher.cc:165-294), feature vectors in CSR
@@ -1377,27 +1467,17 @@ int ivf_search_by_bow_keyframes(const ivf_keypoint* kps1, const uint8_t* desc1, 
 }
 
 // ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist) (ORB/src/ORBmatcher.cc:1520-1652)
-int ivf_search_by_projection_reloc(const ivf_keypoint* cur_kps, const uint8_t* cur_desc, int n_cur, const ivf_bounds* bounds,
-                                   int n_q, const float* q_u, const float* q_v, const float* q_radius, const int32_t* q_level,
-                                   const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid,
-                                   int orb_dist, int check_orientation, int32_t* cur_assign, int* nmatches, int device_id)
+static int reloc_impl(const CandSource& S, int n_q, const float* q_u, const float* q_v, const float* q_radius, const int32_t* q_level,
+                      const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid, int orb_dist, int check_orientation,
+                      int32_t* cur_assign, int* nmatches)
 {
-    if (!cur_kps || !cur_desc || !bounds || !cur_assign || !nmatches || n_cur < 0 || n_q < 0) return fail(IVF_E_INVALID, "bad argument");
+    const ivf_keypoint* cur_kps = S.kps;
     *nmatches = 0;
-    if (n_q == 0 || n_cur == 0) return IVF_OK;
+    if (n_q == 0 || S.n == 0) return IVF_OK;
     if (!q_u || !q_v || !q_radius || !q_level || !q_angle || !q_desc) return fail(IVF_E_INVALID, "null query array");
-    Grid g; g.build(cur_kps, n_cur, *bounds);
-    std::vector<int> qStart(n_q + 1, 0), pairs;
-    for (int i = 0; i < n_q; i++) {
-        qStart[i] = (int)pairs.size() / 2;
-        if (q_valid && !q_valid[i]) continue;
-        g.query(cur_kps, *bounds, q_u[i], q_v[i], q_radius[i], q_level[i] - 1, q_level[i] + 1,
-                [&](int i2) { pairs.push_back(i); pairs.push_back(i2); });
-    }
-    qStart[n_q] = (int)pairs.size() / 2;
-    const int nPairs = qStart[n_q];
-    std::vector<int> dist(std::max(nPairs, 1));
-    int rc = ivf_hamming_pairs(q_desc, n_q, cur_desc, n_cur, pairs.data(), nPairs, dist.data(), device_id);
+    std::vector<int32_t> lo, hi; level_window(n_q, q_level, 1, 1, lo, hi);      // GetFeaturesInArea(u, v, radius, level-1, level+1) (:1574)
+    std::vector<int> qStart, cand, dist;
+    int rc = S.get(n_q, q_u, q_v, q_radius, lo.data(), hi.data(), q_desc, q_valid, qStart, cand, dist);
     if (rc) return rc;
     const int HISTO_LENGTH = 30;
     std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
@@ -1406,7 +1486,7 @@ int ivf_search_by_projection_reloc(const ivf_keypoint* cur_kps, const uint8_t* c
     for (int i = 0; i < n_q; i++) {
         int bestDist = 256, bestIdx2 = -1;
         for (int p = qStart[i]; p < qStart[i + 1]; p++) {
-            const int i2 = pairs[2 * p + 1];
+            const int i2 = cand[p];
             if (cur_assign[i2] != -1) continue;
             if (dist[p] < bestDist) { bestDist = dist[p]; bestIdx2 = i2; }
         }
@@ -1437,6 +1517,24 @@ int ivf_search_by_projection_reloc(const ivf_keypoint* cur_kps, const uint8_t* c
     }
     *nmatches = nm;
     return IVF_OK;
+}
+
+int ivf_search_by_projection_reloc(const ivf_keypoint* cur_kps, const uint8_t* cur_desc, int n_cur, const ivf_bounds* bounds,
+                                   int n_q, const float* q_u, const float* q_v, const float* q_radius, const int32_t* q_level,
+                                   const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid,
+                                   int orb_dist, int check_orientation, int32_t* cur_assign, int* nmatches, int device_id)
+{
+    if (!cur_kps || !cur_desc || !bounds || !cur_assign || !nmatches || n_cur < 0 || n_q < 0) return fail(IVF_E_INVALID, "bad argument");
+    return reloc_impl(CandSource::host(cur_kps, cur_desc, nullptr, n_cur, bounds, device_id), n_q, q_u, q_v, q_radius, q_level, q_angle,
+                      q_desc, q_valid, orb_dist, check_orientation, cur_assign, nmatches);
+}
+int ivf_frame_search_by_projection_reloc(ivf_frame* f, int n_q, const float* q_u, const float* q_v, const float* q_radius,
+                                         const int32_t* q_level, const float* q_angle, const uint8_t* q_desc, const uint8_t* q_valid,
+                                         int orb_dist, int check_orientation, int32_t* cur_assign, int* nmatches)
+{
+    if (!f || !cur_assign || !nmatches || n_q < 0) return fail(IVF_E_INVALID, "bad argument");
+    CandSource S; const int rc = CandSource::resident(f, S); if (rc) return rc;
+    return reloc_impl(S, n_q, q_u, q_v, q_radius, q_level, q_angle, q_desc, q_valid, orb_dist, check_orientation, cur_assign, nmatches);
 }
 
 // ORBmatcher::SearchForTriangulation (ORB/src/ORBmatcher.cc:663-829) + CheckDistEpipolarLine (:146-163)
@@ -1909,6 +2007,49 @@ void* ivf_frontend_batch_stream(ivf_frontend* fe, int age)
 {
     if (!fe || age < 0 || age >= kPipe || fe->runs <= age) return nullptr;
     return (void*)fe->stream[(fe->runs - 1 - age) % kPipe];
+}
+
+// A resident frame straight from a batch: keypoints, descriptors and uRight of one image go device -> device, the 64x48
+// grid is built on the device; nothing but the 4-byte keypoint count crosses PCIe (the replays' small host mirror is fetched
+// lazily by the first search).  `age` as in ivf_frontend_pack_gather_block_of; side 0 = left (with uRight), 1 = right.
+int ivf_frame_create_from_frontend(ivf_frontend* fe, int age, int pair, int side, const ivf_bounds* bounds, ivf_frame** out)
+{
+    if (!out) return fail(IVF_E_INVALID, "null argument");
+    *out = nullptr;
+    if (!fe || !bounds || side < 0 || side > 1) return fail(IVF_E_INVALID, "bad argument");
+    if (!(bounds->max_x > bounds->min_x) || !(bounds->max_y > bounds->min_y)) return fail(IVF_E_INVALID, "empty image bounds");
+    if (age < 0 || age >= kPipe || fe->runs <= age) return fail(IVF_E_STATE, "no batch of age %d is held", age);
+    const int k = (int)((fe->runs - 1 - age) % kPipe);
+    if (pair < 0 || pair >= fe->pairsOf[k]) return fail(IVF_E_INVALID, "pair %d outside the batch of %d", pair, fe->pairsOf[k]);
+    const int dev = fe->cfg.device_id;
+    HIPCHK(hipSetDevice(dev));
+    const Buffers& b = fe->ctx[k].b;
+    const size_t nf = fe->ctx[k].hc.nfeatures, img = (size_t)pair * 2 + side;
+    ivf_frame* f = new ivf_frame();
+    f->device = dev; f->bd = *bounds; f->hostKps = false; f->hostDesc = false;
+    f->invW = (float)GC / (bounds->max_x - bounds->min_x); f->invH = (float)GR / (bounds->max_y - bounds->min_y);
+    auto bail = [&](const char* what) { ivf_frame_destroy(f); return fail(IVF_E_NO_DEVICE, "%s failed for a frame from the front end", what); };
+    if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) return bail("stream creation");
+    int n = 0;
+    if (hipStreamWaitEvent(f->stream, fe->evDone[k], 0) != hipSuccess ||
+        hipMemcpyAsync(&n, b.count + img, sizeof(int), hipMemcpyDeviceToHost, f->stream) != hipSuccess ||
+        hipStreamSynchronize(f->stream) != hipSuccess) return bail("count read");
+    f->n = n;
+    const size_t nn = (size_t)std::max(n, 1);
+    if (hipMalloc(&f->dKps, nn * sizeof(ivf_keypoint)) != hipSuccess || hipMalloc(&f->dDesc, nn * 32) != hipSuccess ||
+        hipMalloc(&f->dUright, nn * sizeof(float)) != hipSuccess || hipMalloc(&f->dStart, (GC * GR + 1) * sizeof(int)) != hipSuccess ||
+        hipMalloc(&f->dIdx, nn * sizeof(int)) != hipSuccess) return bail("allocation");
+    if (n > 0) {
+        if (hipMemcpyAsync(f->dKps, b.kps + img * nf, (size_t)n * sizeof(ivf_keypoint), hipMemcpyDeviceToDevice, f->stream) != hipSuccess ||
+            hipMemcpyAsync(f->dDesc, b.desc + img * nf * 32, (size_t)n * 32, hipMemcpyDeviceToDevice, f->stream) != hipSuccess)
+            return bail("device copy");
+        if (side == 0) { if (hipMemcpyAsync(f->dUright, b.uright + (size_t)pair * nf, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, f->stream) != hipSuccess) return bail("device copy"); }
+        else if (hipMemsetD32Async((hipDeviceptr_t)f->dUright, (int)0xbf800000, (size_t)n, f->stream) != hipSuccess) return bail("fill");      // -1.0f: no stereo
+    }
+    launch_grid_build(f->dKps, n, bounds->min_x, bounds->min_y, f->invW, f->invH, f->dStart, f->dIdx, f->stream);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(f->stream) != hipSuccess) return bail("grid build");
+    *out = f;
+    return IVF_OK;
 }
 
 int ivf_frontend_pack_gather_block(ivf_frontend* fe, uint8_t* d_block, size_t block_bytes, size_t* record_bytes, void* hip_stream)

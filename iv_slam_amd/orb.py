@@ -439,3 +439,65 @@ class DeviceFrame:
                                                     ptr(qq["level"]), ptr(qq["desc"]), ptr(qq["valid"]), ptr(qq["blocks"]),
                                                     float(nn_ratio), ptr(assign), C.byref(nm)))
         return assign, nm.value
+
+    # --- frames made straight from a front-end batch, and the remaining window searches on a resident frame
+    @classmethod
+    def from_frontend(cls, fe, pair, side=0, bounds=None, age=0):
+        """Resident frame of one image of a StereoFrontend batch: device-to-device, only the keypoint count is read back."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        bd = Bounds(*(bounds if bounds is not None else (0.0, 0.0, float(fe.width), float(fe.height))))
+        h = C.c_void_p()
+        check(self._lib.ivf_frame_create_from_frontend(fe._h, int(age), int(pair), int(side), C.byref(bd), C.byref(h)))
+        self._h = h
+        st = np.zeros(64 * 48 + 1, np.int32); ix = np.zeros(fe.nfeatures, np.int32)
+        check(self._lib.ivf_frame_grid(self._h, ptr(st), ptr(ix)))
+        self.n = int(st[-1])            # keypoints inside the grid = all of them for in-image keypoints
+        return self
+
+    @staticmethod
+    def _q(q, types):
+        return {k: np.ascontiguousarray(q[k], t) for k, t in types.items()}
+
+    def SearchKeyFramePoints(self, q, matched=None, n=None):
+        """ivf_frame_search_keyframe_points: q = u, v, radius, level, desc, valid."""
+        n = self.n if n is None else n
+        m = np.full(n, -1, np.int32) if matched is None else np.ascontiguousarray(matched, np.int32).copy()
+        qq = self._q(q, dict(u=np.float32, v=np.float32, radius=np.float32, level=np.int32, desc=np.uint8, valid=np.uint8))
+        nm = C.c_int(0)
+        check(self._lib.ivf_frame_search_keyframe_points(self._h, len(qq["u"]), ptr(qq["u"]), ptr(qq["v"]), ptr(qq["radius"]), ptr(qq["level"]),
+                                                         ptr(qq["desc"]), ptr(qq["valid"]), ptr(m), C.byref(nm)))
+        return m, nm.value
+
+    def FuseCandidates(self, inv_level_sigma2, q):
+        """ivf_frame_fuse_candidates: q = u, v, ur, radius, level, desc, valid -> (best_idx, best_dist)."""
+        gate = inv_level_sigma2 is not None
+        sg = np.ascontiguousarray(inv_level_sigma2, np.float32) if gate else None
+        t = dict(u=np.float32, v=np.float32, radius=np.float32, level=np.int32, desc=np.uint8, valid=np.uint8)
+        if gate:
+            t["ur"] = np.float32
+        qq = self._q(q, t); qq.setdefault("ur", None)
+        nq = len(qq["u"]); bi = np.full(nq, -1, np.int32); bd = np.full(nq, 256, np.int32)
+        check(self._lib.ivf_frame_fuse_candidates(self._h, ptr(sg), 0 if sg is None else len(sg), nq, ptr(qq["u"]), ptr(qq["v"]), ptr(qq["ur"]),
+                                                  ptr(qq["radius"]), ptr(qq["level"]), ptr(qq["desc"]), ptr(qq["valid"]), ptr(bi), ptr(bd)))
+        return bi, bd
+
+    def SearchByProjectionReloc(self, q, orb_dist, check_orientation=True, cur_assign=None, n=None):
+        n = self.n if n is None else n
+        a = np.full(n, -1, np.int32) if cur_assign is None else np.ascontiguousarray(cur_assign, np.int32).copy()
+        qq = self._q(q, dict(u=np.float32, v=np.float32, radius=np.float32, level=np.int32, angle=np.float32, desc=np.uint8, valid=np.uint8))
+        nm = C.c_int(0)
+        check(self._lib.ivf_frame_search_by_projection_reloc(self._h, len(qq["u"]), ptr(qq["u"]), ptr(qq["v"]), ptr(qq["radius"]), ptr(qq["level"]),
+                                                             ptr(qq["angle"]), ptr(qq["desc"]), ptr(qq["valid"]), int(orb_dist),
+                                                             int(bool(check_orientation)), ptr(a), C.byref(nm)))
+        return a, nm.value
+
+    def SearchBySim3(self, other, q12, q21, n1=None):
+        n1 = self.n if n1 is None else n1
+        t = dict(u=np.float32, v=np.float32, radius=np.float32, level=np.int32, desc=np.uint8, valid=np.uint8)
+        a = self._q(q12, t); b = self._q(q21, t)
+        m = np.full(max(n1, 1), -1, np.int32); nf = C.c_int(0)
+        check(self._lib.ivf_frame_search_by_sim3(self._h, other._h, ptr(a["u"]), ptr(a["v"]), ptr(a["radius"]), ptr(a["level"]), ptr(a["desc"]),
+                                                 ptr(a["valid"]), ptr(b["u"]), ptr(b["v"]), ptr(b["radius"]), ptr(b["level"]), ptr(b["desc"]),
+                                                 ptr(b["valid"]), ptr(m), C.byref(nf)))
+        return m[:n1], nf.value

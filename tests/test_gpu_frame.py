@@ -122,3 +122,59 @@ def iv():
     lib = iv_slam_amd.load()
     assert lib.ivf_device_count() >= 1, "no HIP device: libivfront has no CPU fallback"
     return iv_slam_amd
+
+
+def test_frames_straight_from_a_frontend_batch_and_all_window_searches(iv):
+    """Batch -> resident frames with no host copy (ivf_frame_create_from_frontend) -> every window search of ORBmatcher on
+    the device grid: SearchByProjection(cur,last) across two consecutive frames of the batch, and the keyframe / fuse /
+    Sim3 / relocalisation searches, each against the oracle on the fetched copies of the same frames."""
+    import torch
+    w, h, n, pairs = 640, 240, 500, 3
+    base_l, base_r = synth.make_pair(w, h, seed=83, idx=0)
+    lefts = np.stack([np.roll(base_l, 3 * k, axis=1) for k in range(pairs)])
+    rights = np.stack([np.roll(base_r, 3 * k, axis=1) for k in range(pairs)])
+    dev = torch.device("cuda:0")
+    fe = iv.StereoFrontend(w, h, pairs, nfeatures=n, bf=386.1448, b=386.1448 / 718.856)
+    fe.run(torch.from_numpy(lefts).to(dev), torch.from_numpy(rights).to(dev))
+    bounds = (0.0, 0.0, float(w), float(h))
+    frames = [iv.DeviceFrame.from_frontend(fe, p, 0, bounds) for p in range(pairs)]
+    host = [fe.fetch(p, 0) for p in range(pairs)]
+    sc = iv.ORBextractor(n, 1.2, 8, 20, 7).GetScaleFactors()
+    inv2 = (1.0 / (sc * sc)).astype(np.float32)
+    rng = np.random.default_rng(7)
+    for k in range(1, pairs):
+        last, cur = host[k - 1], host[k]
+        assert frames[k].n == len(cur["kps"])
+        sel = last["uright"] >= 0
+        lk = last["kps"][sel]
+        disp = lk["x"] - last["uright"][sel]
+        q = dict(u=(lk["x"] + 3).astype(np.float32), v=lk["y"].astype(np.float32), ur=(lk["x"] + 3 - disp).astype(np.float32),
+                 radius=(7 * sc[lk["octave"]]).astype(np.float32), min_level=(lk["octave"] - 1).astype(np.int32),
+                 max_level=(lk["octave"] + 1).astype(np.int32), angle=lk["angle"].copy(), desc=last["desc"][sel].copy(),
+                 valid=np.ones(len(lk), np.uint8), blocks=np.ones(len(lk), np.uint8), level=lk["octave"].astype(np.int32))
+        ga, gn = frames[k].SearchByProjection(q)
+        oa, on = O.search_by_projection(cur["kps"], cur["desc"], cur["uright"], bounds, q, True)
+        assert gn == on and np.array_equal(ga, oa) and gn > 0.5 * len(lk)
+        # keyframe points / fuse / reloc / sim3 on the same projected queries
+        m, nm = frames[k].SearchKeyFramePoints(q)
+        om, onm = O.search_keyframe_points(cur["kps"], cur["desc"], bounds, q)
+        assert nm == onm and np.array_equal(m, om) and nm > 20
+        bi, bd = frames[k].FuseCandidates(inv2, q)
+        obi, obd = O.fuse_candidates(cur["kps"], cur["desc"], cur["uright"], bounds, inv2, q)
+        assert np.array_equal(bi, obi) and np.array_equal(bd, obd) and (bi >= 0).sum() > 20
+        bi2, _ = frames[k].FuseCandidates(None, q)
+        obi2, _ = O.fuse_candidates(cur["kps"], cur["desc"], None, bounds, None, q)
+        assert np.array_equal(bi2, obi2)
+        pre = np.full(len(cur["kps"]), -1, np.int32); pre[rng.integers(0, len(pre), 15)] = -2
+        ra, rn = frames[k].SearchByProjectionReloc(q, 100, True, pre)
+        ora, orn = O.search_by_projection_reloc(cur["kps"], cur["desc"], bounds, q, 100, True, pre)
+        assert rn == orn and np.array_equal(ra, ora)
+    # Sim3: queries of frame 0 into frame 1 and back (one query slot per keypoint of the source keyframe)
+    def slots(src, shift):
+        kp = src["kps"]
+        return dict(u=(kp["x"] + shift).astype(np.float32), v=kp["y"].astype(np.float32), radius=(8 * sc[kp["octave"]]).astype(np.float32),
+                    level=kp["octave"].astype(np.int32), desc=src["desc"].copy(), valid=(rng.uniform(size=len(kp)) > 0.2).astype(np.uint8))
+    q12, q21 = slots(host[0], 3), slots(host[1], -3)
+    gm, gf = frames[0].SearchBySim3(frames[1], q12, q21)
+    om, of = O.search_by_sim3(host[0]["kps"], host[0]["desc"], bounds, host[1]["kps"], host[1]["desc"], bounds, q12, q21)
+    assert gf == of and np.array_equal(gm, om) and gf > 50
