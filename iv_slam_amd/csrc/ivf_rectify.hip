@@ -29,6 +29,7 @@ struct ivf_remap {
     uint32_t* dXY = nullptr;            // [h][wp] (int16 x) | (int16 y) << 16 : integer source position
     uint16_t* dA = nullptr;             // [h][wp] (fy5 << 5) | fx5 : weight index
     uint8_t *dSrc = nullptr, *dDst = nullptr;   // staging of the host-buffer entry point
+    uint8_t* hPin = nullptr;                    // ... and its pinned host twin (source rows, then destination rows)
     hipStream_t stream = nullptr;
 };
 
@@ -154,6 +155,7 @@ void ivf_remap_destroy(ivf_remap* r)
     if (r->dA) (void)hipFree(r->dA);
     if (r->dSrc) (void)hipFree(r->dSrc);
     if (r->dDst) (void)hipFree(r->dDst);
+    if (r->hPin) (void)hipHostFree(r->hPin);
     delete r;
 }
 
@@ -208,11 +210,16 @@ int ivf_remap_apply(ivf_remap* r, const uint8_t* src, int src_stride, uint8_t* d
     if (src_stride < r->sw * r->cn || dst_stride < r->w * r->cn) return rfail(IVF_E_INVALID, "stride smaller than a row");
     RHIPCHK(hipSetDevice(r->device));
     const size_t srow = (size_t)r->sw * r->cn, drow = (size_t)r->w * r->cn;
-    RHIPCHK(hipMemcpy2DAsync(r->dSrc, srow, src, src_stride, srow, r->sh, hipMemcpyHostToDevice, r->stream));
+    // caller buffers are pageable (cv::Mat): rows go through a pinned staging buffer -- a pageable 2-D copy runs row by row
+    const size_t sBytes = srow * r->sh, dBytes = drow * r->h;
+    if (!r->hPin) RHIPCHK(hipHostMalloc((void**)&r->hPin, sBytes + dBytes, hipHostMallocDefault));
+    for (int y = 0; y < r->sh; y++) memcpy(r->hPin + (size_t)y * srow, src + (size_t)y * src_stride, srow);
+    RHIPCHK(hipMemcpyAsync(r->dSrc, r->hPin, sBytes, hipMemcpyHostToDevice, r->stream));
     int rc = launch_remap(r, r->dSrc, (int)srow, 0, r->dDst, (int)drow, 0, 1, r->stream);
     if (rc) return rc;
-    RHIPCHK(hipMemcpy2DAsync(dst, dst_stride, r->dDst, drow, drow, r->h, hipMemcpyDeviceToHost, r->stream));
+    RHIPCHK(hipMemcpyAsync(r->hPin + sBytes, r->dDst, dBytes, hipMemcpyDeviceToHost, r->stream));
     RHIPCHK(hipStreamSynchronize(r->stream));
+    for (int y = 0; y < r->h; y++) memcpy(dst + (size_t)y * dst_stride, r->hPin + sBytes + (size_t)y * drow, drow);
     return IVF_OK;
 }
 
