@@ -8,7 +8,9 @@ reports half the bytes of such streams (MI355X_MICROARCH.md, HBM section); other
 """
 import csv, json, sys, collections
 
-WIDE = ("k_fcn_dwpw", "k_fcn_gemm", "k_fcn_expand", "k_fcn_conv3x3", "k_fcn_dw<", "k_fcn_irb<", "k_fcn_stem")
+# r02: tools/probe/fetch_calib.hip read 1 GiB with 4-, 8- and 16-byte loads per lane: FETCH_SIZE reported 512 MiB for ALL THREE
+# (profiles/r02_fetch_calibration.json), so the x2 applies to every streaming read of this code base, not only to 16 B/lane ones.
+WIDE = ("k_",)
 
 
 def per_launch(path, counter):
@@ -28,8 +30,9 @@ def main():
     fetch = per_launch(sys.argv[1], "FETCH_SIZE"); write = per_launch(sys.argv[2], "WRITE_SIZE")
     n_img = int(sys.argv[3])
     out = {"command": sys.argv[5], "images_per_launch": n_img,
-           "note": "raw counter x 1024 bytes per launch; fetch_correction = 2.0 for kernels whose reads are 16 B/lane streams "
-                   "(gfx950 FETCH_SIZE reports half of those, MI355X_MICROARCH.md HBM section), 1.0 = uncalibrated width",
+           "note": "raw counter x 1024 bytes per launch; fetch_correction = 2.0: gfx950 FETCH_SIZE reports half of the bytes of a streaming read "
+                   "(MI355X_MICROARCH.md HBM section; calibrated here for 4 / 8 / 16 B per lane by tools/probe/fetch_calib.hip: 512 MiB "
+                   "reported for a 1 GiB read at every width); copies / fills of the runtime are left uncorrected",
            "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         f, nf = fetch.get(k, (0.0, 0)); w, nw = write.get(k, (0.0, 0))
