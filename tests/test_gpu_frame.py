@@ -178,3 +178,33 @@ def test_frames_straight_from_a_frontend_batch_and_all_window_searches(iv):
     gm, gf = frames[0].SearchBySim3(frames[1], q12, q21)
     om, of = O.search_by_sim3(host[0]["kps"], host[0]["desc"], bounds, host[1]["kps"], host[1]["desc"], bounds, q12, q21)
     assert gf == of and np.array_equal(gm, om) and gf > 50
+
+
+def test_config4_cross_frame_matching_4000_features_on_resident_frames(iv):
+    """BASELINE configs[4] shape end to end after the front end: two consecutive 1920x1200 stereo pairs at 4000 features with
+    the cost map on, batched extraction + stereo, resident frames straight from the batch, the tracker's
+    SearchByProjection(cur, last) with th = 15 on the device grid -- against the oracle on the fetched frames."""
+    import torch
+    w, h, n = 1920, 1200, 4000
+    bf, fx = 69.690815 * 2, 528.955512 * 2
+    base_l, base_r = synth.make_pair(w, h, seed=151, idx=0)
+    cost0 = synth.make_cost_map(w, h, seed=151, idx=0)
+    lefts = np.stack([base_l, np.roll(base_l, 4, axis=1)]); rights = np.stack([base_r, np.roll(base_r, 4, axis=1)])
+    costs = np.stack([cost0, np.roll(cost0, 4, axis=1)])
+    dev = torch.device("cuda:0")
+    fe = iv.StereoFrontend(w, h, 2, nfeatures=n, iniThFAST=12, minThFAST=7, enableIntrospection=True, bf=bf, b=bf / fx, fx=fx)
+    fe.run(torch.from_numpy(lefts).to(dev), torch.from_numpy(rights).to(dev), torch.from_numpy(costs).to(dev))
+    bounds = (0.0, 0.0, float(w), float(h))
+    cur_frame = iv.DeviceFrame.from_frontend(fe, 1, 0, bounds)
+    last, cur = fe.fetch(0, 0), fe.fetch(1, 0)
+    sc = iv.ORBextractor(n, 1.2, 8, 12, 7).GetScaleFactors()
+    sel = last["uright"] >= 0
+    lk = last["kps"][sel]
+    q = dict(u=(lk["x"] + 4).astype(np.float32), v=lk["y"].astype(np.float32), ur=(last["uright"][sel] + 4).astype(np.float32),
+             radius=(15 * sc[lk["octave"]]).astype(np.float32), min_level=(lk["octave"] - 1).astype(np.int32),
+             max_level=(lk["octave"] + 1).astype(np.int32), angle=lk["angle"].copy(), desc=last["desc"][sel].copy(),
+             valid=np.ones(len(lk), np.uint8), blocks=np.ones(len(lk), np.uint8))
+    ga, gn = cur_frame.SearchByProjection(q)
+    oa, on = O.search_by_projection(cur["kps"], cur["desc"], cur["uright"], bounds, q, True)
+    assert gn == on and np.array_equal(ga, oa)
+    assert len(cur["kps"]) > 3000 and gn > 0.7 * len(lk) > 500

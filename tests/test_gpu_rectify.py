@@ -130,6 +130,47 @@ def test_replay_harness_matches_oracle_chain(iv, tmp_path):
                 assert l["uright"].tobytes() == our.tobytes() and l["depth"].tobytes() == odp.tobytes(), (introspect, i)
 
 
+def test_replay_harness_cross_frame_tracking(iv, tmp_path):
+    """--track: after each batch the tracker's matcher call (SearchByProjection(cur, last), zero-motion prior) is replayed on
+    device-resident frames made straight from the batch, also across batch boundaries; equals the oracle chain
+    (oracle extraction + stereo of both frames -> oracle SearchByProjection) frame by frame."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import replay_kitti
+    from iv_slam_amd import kitti
+    seq = str(tmp_path / "seq")
+    settings = replay_kitti.make_synthetic(seq, 5, with_qual=False)
+    S = kitti.Settings.load(settings)
+    left, right, ts = kitti.LoadImages(seq)
+    nf, sf, nl, ini, mn, _ = S.extractor_params(); bf, b = S.stereo()
+    rp = replay_kitti.Replay(S, batch=2, track=True)
+    w, h = rp.size
+    prev = None
+    for i0 in range(0, 5, 2):
+        idx = list(range(i0, min(i0 + 2, 5)))
+        Ls = [kitti.imread(left[i]) for i in idx]; Rs = [kitti.imread(right[i]) for i in idx]
+        res = rp.run(Ls, Rs)
+        for k, i in enumerate(idx):
+            eL = O.Extractor(nf, sf, nl, ini, mn); eR = O.Extractor(nf, sf, nl, ini, mn)
+            okL, odL = eL(Ls[k]); okR, odR = eR(Rs[k])
+            our, _ = O.stereo_match(eL, eR, okL, odL, okR, odR, bf, b)
+            cur = dict(kps=okL, desc=odL, uright=our)
+            assign, nm = res[k][0]["tracked"]
+            if prev is None:
+                assert nm == 0 and (assign == -1).all()
+            else:
+                oa, on = O.search_by_projection(okL, odL, our, (0.0, 0.0, float(w), float(h)), rp.track_queries(prev), True)
+                assert nm == on and np.array_equal(assign, oa), i
+            prev = cur
+    # the synthetic frames are independent scenes, so matches are few: identical frames must re-match almost everything
+    rp2 = replay_kitti.Replay(S, batch=2, track=True)
+    L0 = kitti.imread(left[0]); R0 = kitti.imread(right[0])
+    res = rp2.run([L0, L0], [R0, R0])
+    nst = int((res[0][0]["uright"] >= 0).sum())
+    assert res[1][0]["tracked"][1] > 0.9 * nst > 50
+
+
 def test_replay_harness_online_network(iv, tmp_path):
     """--fcn: the introspection network runs on the un-remapped left frame, its cost map is remapped like the left image
     and gates the left extractor (stereo_kitti.cc:493-521); equals FCN (device) -> oracle remap -> oracle extractor."""

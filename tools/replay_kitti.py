@@ -4,7 +4,7 @@ reference's stereo driver (introspective_ORB_SLAM/Examples/Stereo/stereo_kitti.c
 System::TrackStereo would take over -- load pair, optional undistort/rectify remap, optional cost image (predicted
 heat maps from disk, remapped like the left image, :470-521), extract L/R, stereo match.
 
-  python tools/replay_kitti.py SEQUENCE_DIR SETTINGS.yaml [--rectify] [--undistort] [--qual DIR | --fcn WEIGHTS.bin] [--batch 16]
+  python tools/replay_kitti.py SEQUENCE_DIR SETTINGS.yaml [--rectify] [--undistort] [--qual DIR | --fcn WEIGHTS.bin] [--batch 16] [--track]
   python tools/replay_kitti.py --make-synthetic DIR --frames 12        # writes a small synthetic sequence + settings
 
 Prints one line per frame (keypoints L/R, stereo matches, median depth) and the pairs/s of the device part.
@@ -107,10 +107,11 @@ def make_synthetic(root, frames, with_qual=True):
 class Replay:
     """The per-frame device work of the driver, batched: remap (optional) -> StereoFrontend."""
 
-    def __init__(self, settings, rectify=False, undistort=False, introspect=False, batch=16, device_id=0, fcn_blob=None):
+    def __init__(self, settings, rectify=False, undistort=False, introspect=False, batch=16, device_id=0, fcn_blob=None, track=False):
         import torch
         import iv_slam_amd as iv
         self.torch = torch; self.iv = iv
+        self.track = track; self.prev_left = None
         self.S = settings
         self.dev = torch.device("cuda:%d" % device_id)
         nf, sf, nl, ini, mn, _ = settings.extractor_params()
@@ -134,6 +135,7 @@ class Replay:
         self.fe = iv.StereoFrontend(self.size[0], self.size[1], batch, nf, sf, nl, ini, mn, enableIntrospection=introspect or fcn_blob is not None,
                                     bf=bf, b=b, device_id=device_id)
         self.batch = batch
+        self.scale_factors = iv.ORBextractor(nf, sf, nl, ini, mn).GetScaleFactors()
         # online inference of the introspection network (stereo_kitti.cc:493-514): the UN-remapped left image goes in,
         # the cost map comes out at the same size and is then remapped like the left image (:519-521)
         self.fcn = None
@@ -166,7 +168,39 @@ class Replay:
         torch.cuda.current_stream().synchronize()
         self.fe.run(L, R, C)
         self.fe.sync()
-        return [(self.fe.fetch(k, 0), self.fe.fetch(k, 1)) for k in range(n)]
+        res = [(self.fe.fetch(k, 0), self.fe.fetch(k, 1)) for k in range(n)]
+        if self.track:
+            self._track(res)
+        return res
+
+    # ---- pose-free replay of the tracker's matcher call (Tracking::TrackWithMotionModel, ORB/src/Tracking.cc:1303-1342):
+    # the previous frame's stereo points are searched for in the current frame around their OLD image position (zero-motion
+    # prior instead of the velocity model's projection; th = 15, octave window +-1, stereo consistency, rotation histogram:
+    # ORBmatcher::SearchByProjection(cur, last), ORB/src/ORBmatcher.cc:1372-1518).  The current frame is a device-resident
+    # frame made straight from the batch (no host copy of its keypoints / descriptors); results land in res[k][0]["tracked"].
+    TRACK_TH = 15.0
+
+    def track_queries(self, last):
+        """flat query arrays of SearchByProjection(cur, last) from the previous left frame's fetch() result."""
+        sel = last["uright"] >= 0
+        lk = last["kps"][sel]
+        sc = self.scale_factors
+        return dict(u=lk["x"].astype(np.float32), v=lk["y"].astype(np.float32), ur=last["uright"][sel].astype(np.float32),
+                    radius=(np.float32(self.TRACK_TH) * sc[lk["octave"]]).astype(np.float32), min_level=(lk["octave"] - 1).astype(np.int32),
+                    max_level=(lk["octave"] + 1).astype(np.int32), angle=lk["angle"].copy(), desc=last["desc"][sel].copy(),
+                    valid=np.ones(len(lk), np.uint8), blocks=np.ones(len(lk), np.uint8))
+
+    def _track(self, res):
+        bounds = (0.0, 0.0, float(self.size[0]), float(self.size[1]))
+        for k in range(len(res)):
+            last = self.prev_left if k == 0 else res[k - 1][0]
+            if last is not None and (last["uright"] >= 0).any() and len(res[k][0]["kps"]):
+                frame = self.iv.DeviceFrame.from_frontend(self.fe, k, 0, bounds)
+                assign, nm = frame.SearchByProjection(self.track_queries(last))
+                res[k][0]["tracked"] = (assign, nm)
+            else:
+                res[k][0]["tracked"] = (np.full(len(res[k][0]["kps"]), -1, np.int32), 0)
+        self.prev_left = res[-1][0]
 
 
 def main():
@@ -176,6 +210,7 @@ def main():
     ap.add_argument("--qual", help="directory of predicted cost images (%%06d.*): enables the introspection-weighted extractor")
     ap.add_argument("--fcn", help="weights blob (tools/export_fcn_weights.py) or 'seeded': run the introspection network on every left image")
     ap.add_argument("--batch", type=int, default=16); ap.add_argument("--max-frames", type=int, default=0)
+    ap.add_argument("--track", action="store_true", help="also replay the tracker's cross-frame matcher call (zero-motion prior) on resident frames")
     ap.add_argument("--make-synthetic"); ap.add_argument("--frames", type=int, default=12)
     a = ap.parse_args()
     from iv_slam_amd import kitti
@@ -196,7 +231,7 @@ def main():
     if a.fcn:
         from iv_slam_amd import fcn_weights
         blob = fcn_weights.pack_blob(fcn_weights.make_seeded_weights(7)) if a.fcn == "seeded" else np.fromfile(a.fcn, np.float32)
-    rp = Replay(S, a.rectify, a.undistort, introspect=bool(a.qual), batch=batch, fcn_blob=blob)
+    rp = Replay(S, a.rectify, a.undistort, introspect=bool(a.qual), batch=batch, fcn_blob=blob, track=a.track)
     t_dev = 0.0; done = 0
     for i0 in range(0, n, batch):
         idx = [i for i in range(i0, min(i0 + batch, n)) if left[i]]
@@ -214,8 +249,9 @@ def main():
         for i, (l, r) in zip(idx, res):
             m = l["uright"] >= 0
             med = float(np.median(l["depth"][m])) if m.any() else float("nan")
-            print("frame %6d t=%.3f  kps L/R %4d/%4d  stereo matches %4d  median depth %.2f" %
-                  (i, ts[i], len(l["kps"]), len(r["kps"]), int(m.sum()), med))
+            print("frame %6d t=%.3f  kps L/R %4d/%4d  stereo matches %4d  median depth %.2f%s" %
+                  (i, ts[i], len(l["kps"]), len(r["kps"]), int(m.sum()), med,
+                   "  tracked from previous frame %4d" % l["tracked"][1] if "tracked" in l else ""))
     if done:
         print("%d pairs, device part (upload + remap + extract + match + fetch) %.1f pairs/s" % (done, done / t_dev))
     return 0
