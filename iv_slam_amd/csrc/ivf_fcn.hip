@@ -68,13 +68,18 @@ __global__ void k_fcn_prep(const uint8_t* __restrict__ bgr, size_t imageStride, 
     const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
     const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
     const uint8_t* I = bgr + (size_t)b * imageStride;
-    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, istd[3] = {1.0f / 0.229f, 1.0f / 0.224f, 1.0f / 0.225f};
+    // the four taps' three bytes each, loaded once; the normalisation `(p/255 - mean) / std` multiplies by the reciprocal of the
+    // constant (one ulp from the true quotient, far inside the 1e-3 bar): the IEEE division sequence was most of this kernel
+    // (r01: 80 VALU lane-instructions per output element, VALU-bound)
+    const uint8_t *p00 = I + (size_t)y0 * rowStride + x0 * 3, *p01 = I + (size_t)y0 * rowStride + x1 * 3;
+    const uint8_t *p10 = I + (size_t)y1 * rowStride + x0 * 3, *p11 = I + (size_t)y1 * rowStride + x1 * 3;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const int sc = 2 - c;                       // BGR -> RGB
-        auto px = [&](int yy, int xx) { return ((float)I[(size_t)yy * rowStride + xx * 3 + sc] * (1.0f / 255.0f) - mean[c]) / stdv[c]; };
-        const float top = px(y0, x0) * lx0 + px(y0, x1) * lx1;
-        const float bot = px(y1, x0) * lx0 + px(y1, x1) * lx1;
+        auto nz = [&](const uint8_t* q) { return ((float)q[sc] * (1.0f / 255.0f) - mean[c]) * istd[c]; };
+        const float top = nz(p00) * lx0 + nz(p01) * lx1;
+        const float bot = nz(p10) * lx0 + nz(p11) * lx1;
         out[(((size_t)b * 3 + c) * kEnc + y) * kEnc + x] = top * ly0 + bot * ly1;
     }
 }
@@ -946,6 +951,127 @@ __global__ __launch_bounds__(256) void k_fcn_conv3x3(const float* __restrict__ X
     }
 }
 
+// ---- the same convolution with ALL output-channel tiles in one wave (r02) ----
+// k_fcn_conv3x3 gives every 32-channel output tile its own workgroup, so the 320-channel input is read once per tile
+// (three times) on top of the three tap rows: 5.6x its size from HBM (PMC), and the kernel ran fetch-bound at 957 us per 128
+// images against an MFMA floor of ~400.  Here a wave keeps the accumulators of all NT tiles (NT x 4 x 16 registers) and
+// multiplies the SAME B fragments against them: one pass over the input.  A fragments: one register set, each tile's slice
+// refilled for the next step right after its MFMAs have been issued (the other tiles' MFMAs cover the load); x: two sets.
+template <int NT>
+__global__ __launch_bounds__(256, 1) void k_fcn_conv3x3_all(const float* __restrict__ X, const uint4* __restrict__ Wq,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           float* __restrict__ Y, int Cin, int Cout)
+{
+    constexpr int HW = 64 * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kg = lane >> 5, col = lane & 31;
+    // 1-D grid, renumbered so that the 8 workgroups of an image run on one XCD and share its L2 (tap rows of neighbouring row groups)
+    const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
+    const int b = L / 8;
+    const int rp = (L % 8) * 4 + wave;                               // row pair of the image
+    const int y = 2 * rp + (col >> 4), x = 4 * (col & 15);
+    const int K16 = Cin / 16;
+    const float* Xb = X + (size_t)b * Cin * HW + (size_t)8 * kg * HW + x;
+    const uint4* wq = Wq + lane;
+    f32x16 acc[NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[n][p][r] = 0.f;
+    struct XSet { float4 x[8]; float m; };
+    uint4 A[NT][3][2];                                               // [tile][dx][hi, lo] of the CURRENT step
+    int dyN = 0, sN = 0;                                             // (tap row, K step) the next x load belongs to
+    auto load_x = [&](XSet& S) {
+        const int yy = y + dyN - 1;
+        const bool ok = yy >= 0 && yy < 64;
+        const float* P = Xb + (size_t)16 * sN * HW + (ok ? yy : y) * 64;
+        S.m = ok ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) S.x[j] = *(const float4*)(P + (size_t)j * HW);
+        if (++sN == K16) { sN = 0; if (dyN < 2) ++dyN; else sN = K16 - 1; }     // past the end: redundant re-load
+    };
+    auto load_a = [&](int n, int step) {                             // step = dy * K16 + s, clamped at the last one
+        step = min(step, 3 * K16 - 1);
+        const int dy = step / K16, s_ = step % K16;
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+            const uint4* w = wq + ((size_t)((dy * 3 + dx) * K16 + s_) * NT + n) * 128;
+            A[n][dx][0] = w[0]; A[n][dx][1] = w[64];
+        }
+    };
+    auto dpp4 = [](const HFrag& f, int shr) {
+        HFrag o;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            o.u[i] = shr ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f.u[i], 0x111, 0xF, 0xF, true)
+                         : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f.u[i], 0x101, 0xF, 0xF, true);
+        return o;
+    };
+    auto step = [&](XSet& S, int stepIdx) {
+        HFrag bh[6], bl[6];                         // pixel tiles -1 .. 4: [0] = left neighbour's tile 3, [5] = right neighbour's tile 0
+#pragma unroll
+        for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++)
+                split_pair(vget<4>(S.x[2 * jj], pt) * S.m, vget<4>(S.x[2 * jj + 1], pt) * S.m, bh[pt + 1].u[jj], bl[pt + 1].u[jj]);
+        bh[0] = dpp4(bh[4], 1); bl[0] = dpp4(bl[4], 1);
+        bh[5] = dpp4(bh[1], 0); bl[5] = dpp4(bl[1], 0);
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            HFrag ah[3], al[3];
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) { ah[dx].q = A[n][dx][0]; al[dx].q = A[n][dx][1]; }
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+                for (int pt = 0; pt < 4; pt++) acc[n][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[dx].v, bh[pt + dx].v, acc[n][pt], 0, 0, 0);
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+                for (int pt = 0; pt < 4; pt++) acc[n][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[dx].v, bl[pt + dx].v, acc[n][pt], 0, 0, 0);
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+                for (int pt = 0; pt < 4; pt++) acc[n][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[dx].v, bh[pt + dx].v, acc[n][pt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(n, stepIdx + 1);                 // this tile's A slice of the NEXT step: lands under the other tiles' MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    XSet SP, SQ;
+#pragma unroll
+    for (int n = 0; n < NT; n++) load_a(n, 0);
+    load_x(SP);
+    load_x(SQ);
+    for (int i = 0; i < 3 * K16; i += 2) {          // 3*K16 is even (K16 = 20)
+        step(SP, i);
+        __builtin_amdgcn_sched_barrier(0);
+        load_x(SP);
+        __builtin_amdgcn_sched_barrier(0);
+        step(SQ, i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_x(SQ);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+        const int cb = n * 32 + 4 * kg;
+        float4 sc4[4], sh4[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(scale + cb + 8 * g4); sh4[g4] = *(const float4*)(shift + cb + 8 * g4); }
+        float* yb = Y + ((size_t)b * Cout + cb) * HW + y * 64 + x;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            if (cb + ro >= Cout) continue;
+            const float sc = vget<4>(sc4[r >> 2], r & 3), sh = vget<4>(sh4[r >> 2], r & 3);
+            *(float4*)(yb + (size_t)ro * HW) = make_float4(fmaxf(acc[n][0][r] * sc + sh, 0.f), fmaxf(acc[n][1][r] * sc + sh, 0.f),
+                                                           fmaxf(acc[n][2][r] * sc + sh, 0.f), fmaxf(acc[n][3][r] * sc + sh, 0.f));
+        }
+    }
+}
+
 // ---- 1x1 expansion (Cin -> 6*Cin) + BN + ReLU6 with the activation tile stationary in LDS ----
 // An expansion re-uses every activation for up to 30 output-channel tiles.  k_fcn_gemm fetches and splits the B operand
 // once per tile; here a workgroup owns 32*PXT pixels, loads X[Cin][pixels] ONCE, splits it into f16 hi/lo MFMA B
@@ -1538,7 +1664,8 @@ __global__ void k_fcn_out(const float* __restrict__ L, int lh, int lw, int oh, i
     const float bot = P[y1 * lw + x0] * lx0 + P[y1 * lw + x1] * lx1;
     const float v = top * ly0 + bot * ly1;
     const float z = 20.f * (v - 0.5f);
-    const float c = 1.f / (1.f + expf(-z));
+    // logistic through the hardware exp2 / rcp (1 ulp each; the libm expf + IEEE division were most of this kernel's instructions)
+    const float c = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-z * 1.44269504088896341f));
     const size_t o = ((size_t)b * oh + y) * ow + x;
     if (costF) costF[o] = c;
     if (costU) costU[o] = (uint8_t)(c * 255.0f);
@@ -1628,7 +1755,10 @@ void launch_gemm(const Gemm& g, const float* X, const float* res, float* Y, int 
 {
     if (g.taps == 9) {
         static const bool old9 = getenv("IVF_FCN_OLD3X3") != nullptr;
-        if (!old9 && H == 64 && W == 64 && g.cin % 32 == 0 && g.act == 2 && !res)
+        static const bool split9 = getenv("IVF_FCN_3X3_SPLIT") != nullptr;      // the r01 kernel: one workgroup per output-channel tile
+        if (!old9 && !split9 && H == 64 && W == 64 && g.cin % 32 == 0 && g.act == 2 && !res && g.nTiles == 3)
+            hipLaunchKernelGGL((k_fcn_conv3x3_all<3>), dim3(8 * B), dim3(256), 0, s, X, g.dWq, g.dScale, g.dShift, Y, g.cin, g.cout);
+        else if (!old9 && H == 64 && W == 64 && g.cin % 32 == 0 && g.act == 2 && !res)
             hipLaunchKernelGGL(k_fcn_conv3x3, dim3(8 * g.nTiles * B), dim3(256), 0, s, X, g.dWq, g.dScale, g.dShift, Y, g.cin, g.cout, g.nTiles);
         else launch_gemm_t<1, 3, 9>(g, X, res, Y, H, W, B, s);
         return;

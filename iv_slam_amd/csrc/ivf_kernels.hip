@@ -70,8 +70,14 @@ __global__ void k_ingest(const Config* __restrict__ cfg, const uint8_t* __restri
     if (x4 >= G.pitch) return;
     const uint8_t* src = ((nSides == 2 && (img & 1)) ? src1 : src0) + (size_t)(img / nSides) * imageStride + (size_t)y * rowStride;
     unsigned v = 0;
+    if (x4 + 3 < G.w) {
+        // four pixels in one load; the caller's rows are byte-aligned at best (1242-byte KITTI rows), which global loads tolerate
+        typedef unsigned __attribute__((aligned(1))) u32_unaligned;
+        v = *(const u32_unaligned*)(src + x4);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) { int x = x4 + k; unsigned p = x < G.w ? src[x] : 0u; v |= p << (8 * k); }
+        for (int k = 0; k < 4; k++) { int x = x4 + k; unsigned p = x < G.w ? src[x] : 0u; v |= p << (8 * k); }
+    }
     *(unsigned*)(blob + (size_t)img * cfg->pyrBytes + G.off + (size_t)y * G.pitch + x4) = v;
 }
 
@@ -463,9 +469,16 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_blur7: cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) in OpenCV 4.x's 8-bit fixed point:
-// kernel [18,34,48,56,48,34,18]/256, exact horizontal pass (u16), vertical pass (+32768)>>16.
-// One workgroup = one 64x16 output tile.
+// k_blur7: cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) in OpenCV's 8-bit fixed point:
+// kernel [18,34,48,56,48,34,18]/256 (A-4; [18,34,49,55,...] under the <= 3.4.1 switch), exact horizontal pass (u16),
+// vertical pass (+32768)>>16, saturated.  One workgroup = one 128x32 output tile:
+//   1. raw rows y0-3 .. y0+34 as aligned dwords (x0-4 .. x0+131), reflect-101 at the plane's borders
+//   2. horizontal pass on BYTES with v_dot4_u32_u8: pixel x = dot4(bytes x-3..x, k0..k3) + dot4(bytes x+1..x+4, k4..k6,0); the
+//      two 4-byte windows of each of a lane's 4 pixels come out of three dwords with v_alignbyte -- 3.5 instructions per
+//      pixel instead of 12 byte extractions + 7 multiply-adds; results to LDS as u16
+//   3. vertical pass, a lane = 4 columns x 4 output rows: 10 row reads (b64 = 4 x u16) for 4 rows, v_mad_u32_u16 with
+//      op_sel picks the high / low u16 without unpacking (7 per pixel), bytes 2 of the four sums are the outputs.
+// r01's version spent 46 VALU lane-instructions per pixel (SQ counters: VALU-bound at 1.6 TB/s effective); this one ~19.
 // ------------------------------------------------------------------------------------------------
 DEVINL int reflect101(int p, int n)
 {
@@ -473,19 +486,21 @@ DEVINL int reflect101(int p, int n)
     while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
     return p;
 }
+DEVINL unsigned mad_u16_lo(unsigned a, unsigned k, unsigned c)
+{ unsigned r; asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(k), "v"(c)); return r; }
+DEVINL unsigned mad_u16_hi(unsigned a, unsigned k, unsigned c)
+{ unsigned r; asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(a), "v"(k), "v"(c)); return r; }
 __global__ __launch_bounds__(256) void k_blur7(const Config* __restrict__ cfg, const uint8_t* __restrict__ pyr,
                                               const int* __restrict__ lvlCount, uint8_t* __restrict__ blur, int nImg)
 {
-    // one workgroup = one 64 x 32 output tile: raw rows staged as aligned dwords (x0-4 .. x0+67, x0 % 64 == 0),
-    // horizontal pass 4 px per thread into u16x4, vertical pass 4 px per thread, one dword store
-    constexpr int RQ = (kBlurTW + 8) / 4, RH = kBlurTH + 6, HQ = kBlurTW / 4;
+    constexpr int RQ = (kBlurTW + 8) / 4, RH = kBlurTH + 6, HQ = kBlurTW / 4;     // 34 dwords x 38 rows raw; 32 quads per row
     __shared__ unsigned raw[RH * RQ];
-    __shared__ uint2 hp[RH * HQ];
+    __shared__ __attribute__((aligned(8))) uint2 hp[RH * HQ];                     // 4 x u16 per quad
     int img, bx;
     if (!xcd_tile_image(cfg->nBlurTiles, nImg, bx, img)) return;
     int level = 0;
-    const int nl = cfg->nlevels;
-    for (int l = 1; l < nl; l++) if (bx >= cfg->lv[l].btileBase) level = l;
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; l++) level += bx >= cfg->btileBases[l] ? 1 : 0;      // one wide uniform load (INT_MAX past nlevels)
     const LevelGeom& G = cfg->lv[level];
     const int tilesX = G.btilesX, tilesY = G.btilesY;
     const int t = bx - G.btileBase;
@@ -494,52 +509,91 @@ __global__ __launch_bounds__(256) void k_blur7(const Config* __restrict__ cfg, c
     const int x0 = (t % tilesX) * kBlurTW, y0 = (t / tilesX) * kBlurTH;
     const uint8_t* src = pyr + (size_t)img * cfg->pyrBytes + G.off;
     const int tid = threadIdx.x;
-    for (int i = tid; i < RH * RQ; i += 256) {
-        const int ry = i / RQ, rq = i % RQ;
-        const int gy = reflect101(y0 - 3 + ry, G.h), gx = x0 - 4 + 4 * rq;
-        const uint8_t* row = src + (size_t)gy * G.pitch;
-        unsigned v;
-        if (gx >= 0 && gx + 3 < G.w) v = *(const unsigned*)(row + gx);
-        else {
-            v = 0;
+    const int gw = G.w, gh = G.h, pitch = G.pitch;
+    if (gw >= 8 && gh >= 8) {
+        // the usual case: a tap leaves the plane by at most 3 (rows) / 7 (the dword past the right edge) pixels, so ONE
+        // reflection is enough -- closed form, no loops; all of a thread's loads are issued before the first LDS store
+        constexpr int IT = (RH * RQ + 255) / 256;
+        unsigned v[IT];
 #pragma unroll
-            for (int k = 0; k < 4; k++) v |= (unsigned)row[reflect101(gx + k, G.w)] << (8 * k);
+        for (int k = 0; k < IT; k++) {
+            const int i = min(tid + 256 * k, RH * RQ - 1);
+            const int ry = i / RQ, rq = i % RQ;
+            int gy = y0 - 3 + ry; gy = gy < 0 ? -gy : gy; gy = gy >= gh ? 2 * (gh - 1) - gy : gy; gy = max(gy, 0);
+            const int gx = x0 - 4 + 4 * rq;
+            const uint8_t* row = src + (size_t)gy * pitch;
+            if (gx >= 0 && gx + 3 < gw) v[k] = *(const unsigned*)(row + gx);
+            else {                                                   // first / last dword of an edge tile: bytes, reflected
+                unsigned w = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    int x = gx + b; x = x < 0 ? -x : x; x = x >= gw ? 2 * (gw - 1) - x : x; x = min(max(x, 0), gw - 1);
+                    w |= (unsigned)row[x] << (8 * b);
+                }
+                v[k] = w;
+            }
         }
-        raw[i] = v;
+#pragma unroll
+        for (int k = 0; k < IT; k++) if (tid + 256 * k < RH * RQ) raw[tid + 256 * k] = v[k];
+    } else {
+        for (int i = tid; i < RH * RQ; i += 256) {                   // tiny planes: general reflection
+            const int ry = i / RQ, rq = i % RQ;
+            const int gy = reflect101(y0 - 3 + ry, gh), gx = x0 - 4 + 4 * rq;
+            const uint8_t* row = src + (size_t)gy * pitch;
+            unsigned w = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) w |= (unsigned)row[reflect101(gx + b, gw)] << (8 * b);
+            raw[i] = w;
+        }
     }
     __syncthreads();
-    const int hk2 = cfg->varBlur ? 49 : 48, hk3 = cfg->varBlur ? 55 : 56;
+    // coefficients as bytes: taps -3..0 and +1..+3 (A-4 table or its <= 3.4.1 form)
+    const unsigned k2 = cfg->varBlur ? 49u : 48u, k3 = cfg->varBlur ? 55u : 56u;
+    const unsigned K1 = 18u | (34u << 8) | (k2 << 16) | (k3 << 24), K2 = k2 | (34u << 8) | (18u << 16);
     for (int i = tid; i < RH * HQ; i += 256) {
         const int ry = i / HQ, q = i % HQ;
-        const unsigned w0 = raw[ry * RQ + q], w1 = raw[ry * RQ + q + 1], w2 = raw[ry * RQ + q + 2];
-        int b[12];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { b[k] = (w0 >> (8 * k)) & 0xff; b[4 + k] = (w1 >> (8 * k)) & 0xff; b[8 + k] = (w2 >> (8 * k)) & 0xff; }
+        const unsigned w0 = raw[ry * RQ + q], w1 = raw[ry * RQ + q + 1], w2 = raw[ry * RQ + q + 2];   // pixels x-4.., x.., x+4.. (x = x0 + 4q)
         unsigned h[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++)       // output x0+4q+k is centred on window byte 4+k
-            h[k] = 18 * (b[1 + k] + b[7 + k]) + 34 * (b[2 + k] + b[6 + k]) + hk2 * (b[3 + k] + b[5 + k]) + hk3 * b[4 + k];
+        h[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), K2, 0u, false), false);
+        h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), K2, 0u, false), false);
+        h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), K2, 0u, false), false);
+        h[3] = __builtin_amdgcn_udot4(w1, K1, __builtin_amdgcn_udot4(w2, K2, 0u, false), false);
         hp[i] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
     }
     __syncthreads();
+    // vertical pass: thread = quad q (4 columns) x 4 consecutive output rows
     uint8_t* dst = blur + (size_t)img * cfg->pyrBytes + G.off;
-    for (int i = tid; i < kBlurTH * HQ; i += 256) {
-        const int oy = i / HQ, q = i % HQ;
-        const int y = y0 + oy;
-        if (y >= G.h) continue;
-        unsigned acc[4] = {0, 0, 0, 0};
-        const unsigned k2 = cfg->varBlur ? 49u : 48u, k3 = cfg->varBlur ? 55u : 56u;     // A-4: <= 3.4.1 rounds each coefficient
+    {
+        const int q = tid & (HQ - 1), rg = tid / HQ;                    // 32 quads x 8 row groups = 256 threads
+        const int oy0 = 4 * rg;
         const unsigned kw[7] = {18, 34, k2, k3, k2, 34, 18};
+        unsigned acc[4][4];
 #pragma unroll
-        for (int r = 0; r < 7; r++) {
-            const uint2 v = hp[(oy + r) * HQ + q];
-            acc[0] += kw[r] * (v.x & 0xffff); acc[1] += kw[r] * (v.x >> 16);
-            acc[2] += kw[r] * (v.y & 0xffff); acc[3] += kw[r] * (v.y >> 16);
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[r][k] = 32768u;
+#pragma unroll
+        for (int rr = 0; rr < 10; rr++) {                               // hp rows oy0 .. oy0+9 feed output rows oy0 .. oy0+3
+            const uint2 v = hp[(oy0 + rr) * HQ + q];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int tap = rr - r;                                 // output row oy0 + r uses hp rows oy0+r .. oy0+r+6
+                if (tap < 0 || tap > 6) continue;
+                acc[r][0] = mad_u16_lo(v.x, kw[tap], acc[r][0]); acc[r][1] = mad_u16_hi(v.x, kw[tap], acc[r][1]);
+                acc[r][2] = mad_u16_lo(v.y, kw[tap], acc[r][2]); acc[r][3] = mad_u16_hi(v.y, kw[tap], acc[r][3]);
+            }
         }
-        unsigned out = 0;
+        if (x0 + 4 * q < G.pitch) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) out |= min((acc[k] + 32768u) >> 16, 255u) << (8 * k);      // saturate: the sum-257 table can give 257
-        if (x0 + 4 * q < G.pitch) *(unsigned*)(dst + (size_t)y * G.pitch + x0 + 4 * q) = out;
+            for (int r = 0; r < 4; r++) {
+                const int y = y0 + oy0 + r;
+                if (y >= G.h) break;
+                // (acc >> 16) saturated to 255: clamp to 0x00ffffff, then byte 2 of each sum
+                const unsigned a0 = min(acc[r][0], 0xffffffu), a1 = min(acc[r][1], 0xffffffu), a2 = min(acc[r][2], 0xffffffu), a3 = min(acc[r][3], 0xffffffu);
+                const unsigned lo = __builtin_amdgcn_perm(a1, a0, 0x0c0c0602u), hi = __builtin_amdgcn_perm(a3, a2, 0x06020c0cu);
+                *(unsigned*)(dst + (size_t)y * G.pitch + x0 + 4 * q) = lo | hi;
+            }
+        }
     }
 }
 
