@@ -242,3 +242,122 @@ def fuse(O, kf, pool, points, th):
             nobs[m] += 1; kf_mps[best[k]] = m
         n += 1
     return n, kf_mps, replaced
+
+
+# ---- r02: the remaining ORBmatcher methods (restated for tests/test_gpu_adapter.py) ----------------------------------
+def feature_vector(desc):
+    """the tests' stand-in for a DBoW2::FeatureVector: node = first descriptor byte & 31, features in index order."""
+    fv = {}
+    for i, d in enumerate(desc):
+        fv.setdefault(int(d[0]) & 31, []).append(i)
+    return fv
+
+
+def epipole(kf1, kf2):
+    """ORBmatcher.cc:670-676: C2 = R2w*Cw + t2w; ex = fx*C2x*invz + cx with invz = 1.0f / C2z (float)."""
+    C2 = mul_add(kf2["T"][:3, :3], kf1["Ow"], kf2["T"][:3, 3])
+    invz = F(F(1) / C2[2])
+    return F(F(F(F(kf2["fx"]) * C2[0]) * invz) + F(kf2["cx"])), F(F(F(F(kf2["fy"]) * C2[1]) * invz) + F(kf2["cy"]))
+
+
+def _sim3_side(pts, done, pool, Ra, ta, Rb, tb, target, fx, fy, cx, cy, th):
+    """one direction of SearchBySim3 (:1193-1230 / :1273-1310): one query slot per keypoint of the source keyframe."""
+    n = len(pts)
+    q = dict(u=np.zeros(n, F), v=np.zeros(n, F), radius=np.zeros(n, F), level=np.zeros(n, np.int32), desc=np.zeros((n, 32), np.uint8),
+             valid=np.zeros(n, np.uint8))
+    b = target["bounds"]
+    for i, m in enumerate(pts):
+        if m < 0 or done[i] or pool[m]["bad"]:
+            continue
+        pa = mul_add(Ra, pool[m]["pos"], ta)
+        pb = mul_add(Rb, pa, tb)
+        if pb[2] < 0.0:
+            continue
+        invz = F(D(1.0) / D(pb[2]))
+        u = F(F(F(fx) * F(pb[0] * invz)) + F(cx)); v = F(F(F(fy) * F(pb[1] * invz)) + F(cy))
+        if not (u >= b[0] and u < b[2] and v >= b[1] and v < b[3]):
+            continue
+        dist = F(norm(pb))
+        if dist < F(F(0.8) * F(pool[m]["minDist"])) or dist > F(F(1.2) * F(pool[m]["maxDist"])):
+            continue
+        lv = predict_scale(pool[m], dist, target)
+        q["u"][i] = u; q["v"][i] = v; q["radius"][i] = F(F(th) * target["scale"][lv]); q["level"][i] = lv; q["desc"][i] = pool[m]["desc"]; q["valid"][i] = 1
+    return q
+
+
+def search_by_sim3(O, kf1, kf2, pool, pre12, s12, R12, t12, th):
+    """ORBmatcher.cc:1145-1370 -> (nFound, vpMatches12 as pool indices)."""
+    R12 = R12.astype(F); t12 = t12.astype(F)
+    sR12 = (R12 * F(s12)).astype(F)
+    sR21 = (R12.T * F(D(1.0) / D(F(s12)))).astype(F)
+    t21 = np.array([-(D(sR21[i, 0]) * D(t12[0]) + D(sR21[i, 1]) * D(t12[1]) + D(sR21[i, 2]) * D(t12[2])) for i in range(3)], D).astype(F)
+    m1, m2 = kf1["mps"], kf2["mps"]
+    done1 = [p >= 0 for p in pre12]; done2 = [False] * len(m2)
+    where2 = {}
+    for i, m in enumerate(m2):
+        if m >= 0:
+            where2[m] = i                     # GetIndexInKeyFrame: the mock keeps the LAST slot a point was registered at
+    for i, p in enumerate(pre12):
+        if p >= 0 and p in where2:
+            done2[where2[p]] = True
+    fx, fy, cx, cy = kf1["fx"], kf1["fy"], kf1["cx"], kf1["cy"]                 # KF1's intrinsics in both directions (:1148-1151)
+    q12 = _sim3_side(m1, done1, pool, kf1["T"][:3, :3], kf1["T"][:3, 3], sR21, t21, kf2, fx, fy, cx, cy, th)
+    q21 = _sim3_side(m2, done2, pool, kf2["T"][:3, :3], kf2["T"][:3, 3], sR12, t12, kf1, fx, fy, cx, cy, th)
+    m12, nf = O.search_by_sim3(kf1["kps"], kf1["desc"], kf1["bounds"], kf2["kps"], kf2["desc"], kf2["bounds"], q12, q21)
+    out = list(pre12)
+    for i in range(len(out)):
+        if m12[i] >= 0:
+            out[i] = m2[m12[i]]
+    return nf, out
+
+
+def fuse_sim3(O, kf, Scw, pool, points, th):
+    """Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (:983-1106) -> (nFused, vpReplacePoint, keyframe map points after)."""
+    s = Scw[:3, :3]
+    scw = F(math.sqrt(dot(s[0], s[0])))
+    a = F(D(1.0) / D(scw))
+    Rcw = (s * a).astype(F); tcw = (Scw[:3, 3] * a).astype(F)
+    Ow = neg_rt_mul(Rcw, tcw)
+    kf_mps = list(kf["mps"])
+    found = set(m for m in kf_mps if m >= 0 and not pool[m]["bad"])
+    rows, src = [], []
+    for k, m in enumerate(points):
+        if pool[m]["bad"] or m in found:
+            continue
+        pr = _project_kf(kf, Rcw, tcw, Ow, pool[m], False)
+        if pr is None:
+            continue
+        u, v, dist, _ = pr
+        lv = predict_scale(pool[m], dist, kf)
+        rows.append(dict(u=u, v=v, radius=F(F(th) * kf["scale"][lv]), level=lv, desc=pool[m]["desc"], valid=1))
+        src.append(k)
+    repl = [-1] * len(points)
+    if not rows:
+        return 0, repl, kf_mps
+    q = _q(rows, ("u", "v", "radius", "level", "desc", "valid"))
+    best, _ = O.fuse_candidates(kf["kps"], kf["desc"], None, kf["bounds"], None, q)
+    n = 0
+    for j, k in enumerate(src):
+        if best[j] < 0:
+            continue
+        other = kf_mps[best[j]]
+        if other >= 0:
+            if not pool[other]["bad"]:
+                repl[k] = other
+        else:
+            kf_mps[best[j]] = points[k]
+        n += 1
+    return n, repl, kf_mps
+
+
+def update_quality_scores(frame_mps, kp_quality, mp_quality):
+    """ORBmatcher::UpdateQualityScores(Frame&) (:1108-1121)."""
+    kq = np.array(kp_quality, F); mq = np.array(mp_quality, F)
+    for i, m in enumerate(frame_mps):
+        if m < 0:
+            continue
+        upd = min(mq[m], kq[i])
+        if abs(F(upd - mq[m])) > F(0.01):
+            mq[m] = upd
+        kq[i] = upd
+    return kq, mq

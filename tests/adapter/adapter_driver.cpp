@@ -114,6 +114,8 @@ int main(int argc, char** argv)
             std::vector<uint8_t> d = R.arr<uint8_t>();
             m.mDescriptor.create(1, 32, CV_8U); memcpy(m.mDescriptor.data, d.data(), 32);
         }
+        std::vector<char> poolBad0(nMP); std::vector<int> poolObs0(nMP);
+        for (int i = 0; i < nMP; i++) { poolBad0[i] = pool[i].bad; poolObs0[i] = pool[i].nObs; }
         Frame last, cur; KeyFrame kf;
         read_base(R, last); read_base(R, cur); read_base(R, kf);
         last.mTcw = mat_f(R.arr<float>(), 4, 4); cur.mTcw = mat_f(R.arr<float>(), 4, 4); kf.Tcw = mat_f(R.arr<float>(), 4, 4);
@@ -130,7 +132,7 @@ int main(int argc, char** argv)
         const float th = R.f32(); const int bMono = R.i32();
         std::vector<int32_t> localIdx = R.arr<int32_t>();       // indices of the "local map" points for SearchByProjection(F, vpMapPoints)
         std::vector<float> Scw = R.arr<float>();
-        fclose(R.f);
+        Reader& extra = R;                                           // the rest of the file feeds steps 6-11
 
         ORBmatcher matcher(0.9f, true);
         // 1. SearchByProjection(CurrentFrame, LastFrame, th, bMono)      (Tracking.cc:1303-1342 call site)
@@ -158,23 +160,74 @@ int main(int argc, char** argv)
         put_assign(kf.mvpMapPoints, pool);
         out.push_back(nMP);
         for (int i = 0; i < nMP; i++) out.push_back(pool[i].replacedBy ? (int32_t)(pool[i].replacedBy - pool.data()) : -1);
-        // 6. UpdateQualityScores(Frame&) through the flag
-        ORBmatcher::PropagateKeyptQual() = false;
+        // ---- the BoW / initialisation / triangulation / Sim3 searches: a second keyframe from the current frame's data ----
+        KeyFrame kf2;
+        static_cast<Base&>(kf2) = static_cast<const Base&>(cur);
+        kf2.Tcw = cur.mTcw;
+        { std::vector<float> ow2 = extra.arr<float>(); for (int i = 0; i < 3; i++) kf2.Ow[i] = ow2[i]; }
+        std::vector<int32_t> kf2Mp = extra.arr<int32_t>(), kfMp2 = extra.arr<int32_t>();
+        kf2.mvpMapPoints.resize(kf2.N);
+        std::vector<MapPoint> pool2(pool.size());                    // fresh copies: the Fuse above replaced / re-observed some points
+        for (size_t i = 0; i < pool.size(); i++) { pool2[i] = pool[i]; pool2[i].bad = poolBad0[i]; pool2[i].nObs = poolObs0[i]; pool2[i].obs.clear(); pool2[i].replacedBy = nullptr; }
+        for (int i = 0; i < kf.N; i++) { kf.mvpMapPoints[i] = kfMp2[i] >= 0 ? &pool2[kfMp2[i]] : nullptr; if (kfMp2[i] >= 0) pool2[kfMp2[i]].obs[&kf] = i; }
+        for (int i = 0; i < kf2.N; i++) { kf2.mvpMapPoints[i] = kf2Mp[i] >= 0 ? &pool2[kf2Mp[i]] : nullptr; if (kf2Mp[i] >= 0) pool2[kf2Mp[i]].obs[&kf2] = i; }
+        // DBoW2::FeatureVector stand-ins: node = first descriptor byte & 31, features in index order (what transform() would give)
+        auto featvec = [](Base& b) { b.mFeatVec.clear(); for (int i = 0; i < b.N; i++) b.mFeatVec[b.mDescriptors.at<uint8_t>(i, 0) & 31u].push_back((unsigned)i); };
+        featvec(kf); featvec(kf2); featvec(cur); featvec(last);
+        // 6. SearchByBoW(pKF, F, vpMapPointMatches)
+        std::vector<MapPoint*> bowF;
+        ORBmatcher m7(0.7f, true);
+        out.push_back(m7.SearchByBoW(&kf, cur, bowF));
+        put_assign(bowF, pool2);
+        // 7. SearchByBoW(pKF1, pKF2, vpMatches12)
+        std::vector<MapPoint*> bowKK;
+        ORBmatcher m75(0.75f, true);
+        out.push_back(m75.SearchByBoW(&kf, &kf2, bowKK));
+        put_assign(bowKK, pool2);
+        // 8. SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, 100)
+        std::vector<cv::Point2f> prev(last.N);
+        for (int i = 0; i < last.N; i++) prev[i] = last.mvKeysUn[i].pt;
+        std::vector<int> m12;
+        out.push_back(matcher.SearchForInitialization(last, cur, prev, m12, 100));
+        out.push_back((int32_t)m12.size());
+        for (int v : m12) out.push_back(v);
+        for (int i = 0; i < last.N; i++) { int32_t a, b2; memcpy(&a, &prev[i].x, 4); memcpy(&b2, &prev[i].y, 4); out.push_back(a); out.push_back(b2); }
+        // 9. SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, false)
+        std::vector<float> F12 = extra.arr<float>();
+        std::vector<std::pair<size_t, size_t> > pairs;
+        ORBmatcher m6(0.6f, false);
+        out.push_back(m6.SearchForTriangulation(&kf, &kf2, mat_f(F12, 3, 3), pairs, false));
+        out.push_back((int32_t)pairs.size());
+        for (auto& pr : pairs) { out.push_back((int32_t)pr.first); out.push_back((int32_t)pr.second); }
+        // 10. SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)
+        std::vector<float> s12v = extra.arr<float>();                // s12, R12 (9), t12 (3)
+        std::vector<MapPoint*> vpM12(kf.N, nullptr);
+        { std::vector<int32_t> pre = extra.arr<int32_t>(); for (int i = 0; i < kf.N; i++) if (pre[i] >= 0) vpM12[i] = &pool2[pre[i]]; }
+        out.push_back(matcher.SearchBySim3(&kf, &kf2, vpM12, s12v[0], mat_f(std::vector<float>(s12v.begin() + 1, s12v.begin() + 10), 3, 3),
+                                           mat_f(std::vector<float>(s12v.begin() + 10, s12v.begin() + 13), 3, 1), 7.5f));
+        put_assign(vpM12, pool2);
+        // 11. Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)
+        std::vector<MapPoint*> local2, repl;
+        for (int i : localIdx) local2.push_back(&pool2[i]);
+        repl.assign(local2.size(), nullptr);
+        out.push_back(matcher.Fuse(&kf2, mat_f(Scw, 4, 4), local2, 4.0f, repl));
+        put_assign(repl, pool2);
+        put_assign(kf2.mvpMapPoints, pool2);
+        // 12. UpdateQualityScores(Frame&) / (KeyFrame&) and DescriptorDistance
+        for (int i = 0; i < cur.N; i++) cur.mvKeyQualScore[i] = 0.5f + 0.001f * (i % 400);
+        for (size_t i = 0; i < pool2.size(); i++) pool2[i].quality = 0.4f + 0.002f * (i % 300);
+        set_cur();
+        for (int i = 0; i < cur.N; i++) if (cur.mvpMapPoints[i]) cur.mvpMapPoints[i] = &pool2[cur.mvpMapPoints[i] - pool.data()];
+        matcher.UpdateQualityScores(cur);
+        for (int i = 0; i < cur.N; i++) { int32_t a; memcpy(&a, &cur.mvKeyQualScore[i], 4); out.push_back(a); }
+        for (size_t i = 0; i < pool2.size(); i++) { int32_t a; memcpy(&a, &pool2[i].quality, 4); out.push_back(a); }
         out.push_back(ORBmatcher::DescriptorDistance(pool[0].mDescriptor, pool[1 % nMP].mDescriptor));
+        fclose(R.f);
     } catch (const std::exception& e) { fprintf(stderr, "adapter_driver: %s\n", e.what()); return 1; }
     FILE* o = fopen(argv[2], "wb");
     fwrite(out.data(), 4, out.size(), o); fclose(o);
     return 0;
 }
 
-// the remaining signatures must at least instantiate against the mock types (compile-time check of the duck typing)
-template int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, std::vector<MapPoint*>&);
-int instantiate_rest(ORBmatcher& m, KeyFrame* a, KeyFrame* b, Frame& f1, Frame& f2)
-{
-    std::vector<MapPoint*> v; std::vector<cv::Point2f> pm; std::vector<int> m12; std::vector<std::pair<size_t, size_t> > pairs;
-    cv::Mat F12(3, 3, CV_32F), R12(3, 3, CV_32F), t12(3, 1, CV_32F), Scw(4, 4, CV_32F);
-    int n = m.SearchByBoW(a, b, v) + m.SearchForInitialization(f1, f2, pm, m12, 10) + m.SearchForTriangulation(a, b, F12, pairs, false) +
-            m.SearchBySim3(a, b, v, 1.0f, R12, t12, 7.5f) + m.Fuse(a, Scw, v, 4.0f, v);
-    m.UpdateQualityScores(f1); m.UpdateQualityScores(*a);
-    return n;
-}
+// UpdateQualityScores(KeyFrame&) is not reached by main(): instantiate it
+void instantiate_rest(ORBmatcher& m, KeyFrame* a) { m.UpdateQualityScores(*a); }

@@ -122,6 +122,35 @@ def make(O, synth, seed, forward):
     arr(last["mps"], np.int32); arr(last["outlier"].astype(np.int32), np.int32); arr(cur_mps, np.int32); arr(kf_mps, np.int32)
     b.extend(struct.pack("<fi", S["th"], S["mono"]))
     arr(local, np.int32); arr(Scw, F)
+    # ---- second part: a second keyframe (the current frame's data), fresh map-point assignments, F12, the Sim3
+    cur["Ow"] = PO.neg_rt_mul(cur["T"][:3, :3], cur["T"][:3, 3])
+    # the current image is the last one shifted by 2 px: a current keypoint that sits on a shifted last keypoint observes the
+    # same map point (consistent observations make the two directions of SearchBySim3 agree); the rest are random
+    kf2_mps = np.full(len(kC), -1, np.int32)
+    for j in range(len(kC)):
+        near = np.nonzero((np.abs(kL["x"] + 2 - kC["x"][j]) <= 1.0) & (np.abs(kL["y"] - kC["y"][j]) <= 1.0) & (kL["octave"] == kC["octave"][j]))[0]
+        if len(near) and last_mps[near[0]] >= 0 and rng.uniform() < 0.8:
+            kf2_mps[j] = last_mps[near[0]]
+        elif rng.uniform() < 0.1:
+            kf2_mps[j] = int(rng.integers(0, len(pool)))
+    kf_mps2 = np.full(len(kL), -1, np.int32)
+    for i in range(len(kL)):
+        if rng.uniform() < 0.35:
+            kf_mps2[i] = last_mps[i] if (last_mps[i] >= 0 and rng.uniform() < 0.7) else int(rng.integers(0, len(pool)))
+    # relative pose kf2 <- kf (p2 = R21 p1 + t21) and the fundamental matrix F12 with x1^T F12 x2 = 0 (ORB-SLAM's convention)
+    T1 = kf["T"].astype(np.float64); T2 = cur["T"].astype(np.float64)
+    T12 = T1 @ np.linalg.inv(T2)                                  # p1 = R12 p2 + t12
+    R12, t12 = T12[:3, :3], T12[:3, 3]
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float64)
+    tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    F12 = (np.linalg.inv(K).T @ tx @ R12 @ np.linalg.inv(K)).astype(F)
+    s12 = F(1.05)
+    pre12 = np.full(len(kL), -1, np.int32)
+    for i in rng.choice(len(kL), size=10, replace=False):
+        pre12[i] = int(rng.integers(0, len(pool)))
+    arr(cur["Ow"], F); arr(kf2_mps, np.int32); arr(kf_mps2, np.int32); arr(F12, F)
+    arr(np.concatenate([[s12], R12.astype(F).reshape(-1), t12.astype(F)]), F); arr(pre12, np.int32)
+    S.update(kf2_mps=kf2_mps, kf_mps2=kf_mps2, F12=F12, s12=s12, R12=R12.astype(F), t12=t12.astype(F), pre12=pre12)
     return S, bytes(b)
 
 
@@ -142,5 +171,34 @@ def expected(O, S):
     out += [nm4, len(m4)] + list(m4)
     nf, kfm, rep = PO.fuse(O, kf, pool, S["local"], 3.0)
     out += [nf, len(kfm)] + list(kfm) + [len(rep)] + list(rep)
+    # ---- steps 6-12 of the driver: fresh map points (original bad / observation state), second keyframe = current frame's data
+    kf1 = dict(kf); kf1["mps"] = S["kf_mps2"]
+    kf2 = dict(cur); kf2["mps"] = S["kf2_mps"]
+    has1 = np.array([m >= 0 and not pool[m]["bad"] for m in kf1["mps"]], np.uint8)
+    has2 = np.array([m >= 0 and not pool[m]["bad"] for m in kf2["mps"]], np.uint8)
+    fv_kf, fv_cur, fv_last = PO.feature_vector(kf["desc"]), PO.feature_vector(cur["desc"]), PO.feature_vector(last["desc"])
+    fm, n6 = O.search_by_bow(kf["kps"], kf["desc"], has1, fv_kf, cur["kps"], cur["desc"], fv_cur, 0.7, True)
+    out += [n6, len(fm)] + [int(kf1["mps"][j]) if j >= 0 else -1 for j in fm]
+    m12, n7 = O.search_by_bow_keyframes(kf["kps"], kf["desc"], has1, fv_kf, cur["kps"], cur["desc"], has2, fv_cur, 0.75, True)
+    out += [n7, len(m12)] + [int(kf2["mps"][j]) if j >= 0 else -1 for j in m12]
+    prev = np.stack([last["kps"]["x"], last["kps"]["y"]], axis=1).astype(F)
+    im12, prev2, n8 = O.search_for_initialization(last["kps"], last["desc"], cur["kps"], cur["desc"], cur["bounds"], prev, 100, 0.9, True)
+    out += [n8, len(im12)] + [int(v) for v in im12] + [int(v) for v in prev2.astype(F).reshape(-1).view(np.int32)]
+    ex, ey = PO.epipole(kf, kf2)
+    st1 = (kf["uright"] >= 0).astype(np.uint8); st2 = (cur["uright"] >= 0).astype(np.uint8)
+    hm1 = (np.asarray(kf1["mps"]) >= 0).astype(np.uint8); hm2 = (np.asarray(kf2["mps"]) >= 0).astype(np.uint8)
+    tm, n9 = O.search_for_triangulation(kf["kps"], kf["desc"], hm1, st1, fv_kf, cur["kps"], cur["desc"], hm2, st2, fv_cur, S["F12"], float(ex), float(ey),
+                                        cur["scale"], cur["sigma2"], False, False)
+    prs = [(i, int(j)) for i, j in enumerate(tm) if j >= 0]
+    out += [n9, len(prs)] + [v for pr in prs for v in pr]
+    n10, vm12 = PO.search_by_sim3(O, kf1, kf2, pool, [int(v) for v in S["pre12"]], S["s12"], S["R12"], S["t12"], 7.5)
+    out += [n10, len(vm12)] + [int(v) for v in vm12]
+    n11, repl, kf2_after = PO.fuse_sim3(O, kf2, S["Scw"], pool, S["local"], 4.0)
+    out += [n11, len(repl)] + [int(v) for v in repl] + [len(kf2_after)] + [int(v) for v in kf2_after]
+    kq0 = (F(0.5) + F(0.001) * (np.arange(len(cur["kps"])) % 400).astype(F)).astype(F)
+    mq0 = (F(0.4) + F(0.002) * (np.arange(len(pool)) % 300).astype(F)).astype(F)
+    kq, mq = PO.update_quality_scores([int(v) for v in S["cur_mps"]], kq0, mq0)
+    out += [int(v) for v in kq.view(np.int32)] + [int(v) for v in mq.view(np.int32)]
     out.append(O.hamming(pool[0]["desc"], pool[1 % len(pool)]["desc"]))
-    return np.array(out, np.int64), dict(cur_last=nm1, local=nm2, reloc=nm3, kf_sim3=nm4, fused=nf)
+    counts = dict(cur_last=nm1, local=nm2, reloc=nm3, kf_sim3=nm4, fused=nf, bow=n6, bow_kf=n7, init=n8, triangulation=n9, sim3=n10, fuse_sim3=n11)
+    return np.array(out, np.int64), counts

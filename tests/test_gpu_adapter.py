@@ -1,6 +1,7 @@
 """The C++ adapter (include/ivfront_orbslam.hpp) COMPILED AND RUN against mock Frame / KeyFrame / MapPoint types that carry
-the reference's member names: ORBmatcher's reference signatures end to end -- projection loop in the adapter, window search
-on the GPU, bookkeeping on the mocks -- against oracle/projection_oracle.py + the C oracle."""
+the reference's member names: ALL of ORBmatcher's reference signatures (4 x SearchByProjection, 2 x SearchByBoW,
+SearchForInitialization, SearchForTriangulation, SearchBySim3, 2 x Fuse, UpdateQualityScores) end to end -- projection loop in
+the adapter, window search on the GPU, bookkeeping on the mocks -- against oracle/projection_oracle.py + the C oracle."""
 import subprocess
 
 import numpy as np
@@ -32,3 +33,5 @@ def test_orbmatcher_reference_signatures_end_to_end(driver, tmp_path, seed, forw
     assert np.array_equal(got, want), "first difference at %d" % int(np.nonzero(got != want)[0][0])
     # the scenario exercises every call for real
     assert counts["cur_last"] > 50 and counts["local"] > 5 and counts["reloc"] > 20 and counts["kf_sim3"] > 20 and counts["fused"] > 20, counts
+    assert counts["bow"] > 50 and counts["bow_kf"] > 20 and counts["init"] > 50 and counts["triangulation"] > 50, counts
+    assert counts["sim3"] > 5 and counts["fuse_sim3"] > 10, counts
