@@ -229,6 +229,8 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
         HIPCHK(hipMalloc(&b.uright, nP * nf * sizeof(float)));
         HIPCHK(hipMalloc(&b.depth, nP * nf * sizeof(float)));
         HIPCHK(hipMalloc(&b.sad, nP * nf * sizeof(int)));
+        HIPCHK(hipMalloc(&b.rowCnt, nP * (size_t)h * sizeof(int)));
+        HIPCHK(hipMalloc(&b.rowList, nP * (size_t)h * kRowCap * sizeof(unsigned short)));
     }
     HIPCHK(hipMalloc(&b.status, 2 * sizeof(int)));
     HIPCHK(hipMemset(b.status, 0, 2 * sizeof(int)));
@@ -245,7 +247,7 @@ void Context::release()
 {
     (void)hipSetDevice(device);
     void* ptrs[] = {dc, dTab, b.pyr, b.qpyr, b.blur, b.tileList, b.tileCnt, b.cellCnt, b.cellInfo, b.lvlTotal, b.lvl, b.slotPos, b.slotResp, b.lvlCount,
-                    b.useCost, b.kps, b.desc, b.count, b.quality, b.uright, b.depth, b.sad, b.status, b.hugeList, b.hugeScratch, dStage};
+                    b.useCost, b.kps, b.desc, b.count, b.quality, b.uright, b.depth, b.sad, b.rowCnt, b.rowList, b.status, b.hugeList, b.hugeScratch, dStage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (hStage) (void)hipHostFree(hStage);
     for (int i = 0; i < kEvRing; i++) {
@@ -638,7 +640,7 @@ int ivf_stereo_match(const ivf_extractor* left, const ivf_extractor* right,
     A.kpL = dKL; A.kpR = dKR; A.descL = dDL; A.descR = dDR; A.cntL = dCnt; A.cntR = dCnt + 1;
     A.kpStride = 0; A.cntStride = 0;
     A.uright = cl.b.uright; A.depth = cl.b.depth; A.sad = cl.b.sad; A.outStride = nf;
-    A.bf = bf; A.bb = b;
+    A.bf = bf; A.bb = b; A.rowCnt = cl.b.rowCnt; A.rowList = cl.b.rowList;
     launch_stereo_args(cl.hc, cl.dc, A, 1, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(u_right, cl.b.uright, (size_t)n_left * sizeof(float), hipMemcpyDeviceToHost));

@@ -55,6 +55,7 @@ typedef unsigned long long ResizeCoef;
 constexpr int kFastTW = 128, kFastTH = 32;    // FAST/NMS output tile (kFastTW + 2 <= 192, kFastTH + 2 <= 64: see k_fast_nms)
 constexpr int kBlurTW = 128, kBlurTH = 32;    // blur output tile
 constexpr int kTileCap = kFastTW * kFastTH / 4;   // at most one strict 3x3 maximum per 2x2 block
+constexpr int kRowCap = 96;              // right keypoints listed per image row by k_stereo_rows (more: that row falls back to the full scan)
 constexpr int kHugeSlots = 8;            // workgroups (= global scratch slots) of k_cell_select_huge
 constexpr int kHugeListCap = 4096;       // cells with > 4096 survivors listed per launch
 
@@ -79,6 +80,8 @@ struct Buffers {            // device pointers of one batch context
     float* uright;          // [nPairs][nfeatures]
     float* depth;           // [nPairs][nfeatures]
     int* sad;               // [nPairs][nfeatures]  best SAD distance or -1
+    int* rowCnt;            // [nPairs][H]  right keypoints whose row band covers the row (k_stereo_rows)
+    unsigned short* rowList;    // [nPairs][H][kRowCap]
     int* status;            // [1] device-side error flags, cleared by the host when read
     int* hugeCount;         // [1] cells with more than 4096 survivors in this launch (k_quota -> k_cell_select_huge)
     int* hugeList;          // [kHugeListCap] img * nCellsTotal + cell
@@ -94,6 +97,7 @@ struct StereoArgs {
     int cntStride;
     float *uright, *depth; int* sad; int outStride;
     float bf, bb;
+    int* rowCnt; unsigned short* rowList;                  // [nPairs][H], [nPairs][H][kRowCap]: right keypoints per image row, or null
 };
 
 // thread-local error message behind ivf_last_error() (ivf_api.hip)

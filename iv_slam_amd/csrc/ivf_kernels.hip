@@ -1374,6 +1374,30 @@ __global__ void k_hamming_pairs(const uint8_t* __restrict__ a, const uint8_t* __
 //   iR, as vRowIndices is filled in iR order) starting from TH_HIGH; accept < 75; then the 11x11 SAD
 //   over 11 shifts at the keypoint's octave, parabola refinement, disparity gate.
 // ------------------------------------------------------------------------------------------------
+// k_stereo_rows: the reference's vRowIndices (Frame.cc:775-785) -- for every image row the right keypoints whose band
+// [floor(y - r), ceil(y + r)], r = 2 * scale[octave], covers it.  One workgroup per pair; rows with more than kRowCap entries
+// are marked overflowed (count > kRowCap) and k_stereo_match scans all right keypoints for them, as it did for every row in r01.
+__global__ __launch_bounds__(256) void k_stereo_rows(const Config* __restrict__ cfg, StereoArgs A)
+{
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int H = cfg->lv[0].h;
+    const int nR = A.cntR[pair * A.cntStride];
+    int* cnt = A.rowCnt + (size_t)pair * H;
+    unsigned short* list = A.rowList + (size_t)pair * H * kRowCap;
+    for (int y = tid; y < H; y += 256) cnt[y] = 0;
+    __syncthreads();
+    const ivf_keypoint* kpR = A.kpR + (size_t)pair * A.kpStride;
+    for (int iR = tid; iR < nR; iR += 256) {
+        const ivf_keypoint kr = kpR[iR];
+        const float r = 2.0f * cfg->scale[kr.octave];
+        const int maxr = min((int)ceilf(kr.y + r), H - 1), minr = max((int)floorf(kr.y - r), 0);
+        for (int yi = minr; yi <= maxr; yi++) {
+            const int pos = atomicAdd(&cnt[yi], 1);
+            if (pos < kRowCap) list[(size_t)yi * kRowCap + pos] = (unsigned short)iR;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_stereo_match(const Config* __restrict__ cfg, StereoArgs A)
 {
     const int pair = blockIdx.y;
@@ -1403,8 +1427,15 @@ __global__ __launch_bounds__(256) void k_stereo_match(const Config* __restrict__
     if (live) {
         const uint4* dl = (const uint4*)(descL + (size_t)iL * 32);
         const uint4 l0 = dl[0], l1 = dl[1];
-        for (int base = 0; base < nR; base += 64) {
-            const int iR = base + lane;
+        // candidates: the row's list (vRowIndices[vL], Frame.cc:806) when it did not overflow, every right keypoint otherwise;
+        // the band / octave / disparity tests below are the reference's and make both enumerations equivalent
+        const int nRow = A.rowCnt ? A.rowCnt[(size_t)pair * G0.h + row] : kRowCap + 1;
+        const bool listed = nRow <= kRowCap;
+        const unsigned short* rl = listed ? A.rowList + ((size_t)pair * G0.h + row) * kRowCap : nullptr;
+        const int nCand = listed ? nRow : nR;
+        for (int base = 0; base < nCand; base += 64) {
+            const int ci = base + lane;
+            const int iR = ci < nCand ? (listed ? (int)rl[ci] : ci) : nR;
             if (iR < nR) {
                 const ivf_keypoint kr = kpR[iR];
                 const float r = 2.0f * cfg->scale[kr.octave];
@@ -1599,6 +1630,7 @@ void launch_describe(const Config& hc, const Config* dc, const Buffers& b, const
 }
 void launch_stereo_args(const Config& hc, const Config* dc, const StereoArgs& A, int nPairs, hipStream_t s)
 {
+    if (A.rowCnt) hipLaunchKernelGGL(k_stereo_rows, dim3(nPairs), dim3(256), 0, s, dc, A);
     hipLaunchKernelGGL(k_stereo_match, dim3((hc.nfeatures + 3) / 4, nPairs), dim3(256), 0, s, dc, A);
     hipLaunchKernelGGL(k_stereo_gate, dim3(nPairs), dim3(256), 0, s, dc, A.cntL, A.cntStride, A.uright, A.depth, A.sad,
                        A.outStride);
@@ -1610,7 +1642,7 @@ void launch_stereo(const Config& hc, const Config* dc, const Buffers& b, int nPa
     A.kpL = b.kps; A.kpR = b.kps + hc.nfeatures; A.descL = b.desc; A.descR = b.desc + (size_t)hc.nfeatures * 32;
     A.cntL = b.count; A.cntR = b.count + 1; A.kpStride = (size_t)2 * hc.nfeatures; A.cntStride = 2;
     A.uright = b.uright; A.depth = b.depth; A.sad = b.sad; A.outStride = hc.nfeatures;
-    A.bf = bf; A.bb = bb;
+    A.bf = bf; A.bb = bb; A.rowCnt = b.rowCnt; A.rowList = b.rowList;
     launch_stereo_args(hc, dc, A, nPairs, s);
 }
 // ---- MapPoint::ComputeDistinctiveDescriptors (ORB/src/MapPoint.cc:281-305): per observed descriptor the median of
