@@ -1209,22 +1209,46 @@ __global__ __launch_bounds__(256, 2) void k_fcn_expand(const float* __restrict__
 //   * both LDS stages are double buffered, one barrier per chunk;
 //   * workgroups are renumbered so that the row pairs of one image run on the same XCD (shared L2 for halo rows).
 // dwP: per hidden channel 12 floats = 9 taps, BN scale, BN shift, pad.
+#ifdef IVF_DWPW_TIMING
+// diagnostic build only (make TIMING=1): per-phase cycle sums of wave 0 of every workgroup of k_fcn_dwpw<5,4,6,1>
+__device__ unsigned long long g_dwpwTim[8];
+#define DWPW_TIM(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    tacc[i] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DWPW_TIM(i) do { } while (0)
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ f32x2 pkfma(f32x2 a, float w, f32x2 c) { return __builtin_elementwise_fma(a, (f32x2){w, w}, c); }
+// timing-only ablations of k_fcn_dwpw, compile-time so that the product build carries none of it (make EXTRA=-DIVF_DWPW_ABL=<mask>,
+// tools/dwpw_ablate.sh): 1 window loads hit chunk 0 (no HBM), 4 no barriers, 8 no A-fragment loads in the loop, 16 no window loads
+// in the loop, 32 no MFMAs, 64 no stencil arithmetic, 128 no A-fragment stores to LDS, 256 no B reads from LDS / split, 512 no
+// depthwise stores to LDS.  Results are wrong by construction.
+#ifndef IVF_DWPW_ABL
+#define IVF_DWPW_ABL 0
+#endif
+constexpr int kAbl = IVF_DWPW_ABL;
+#ifndef IVF_DWPW_OCC
+#define IVF_DWPW_OCC 2
+#endif
 template <int S> struct DwSetT { float4 own[3][2 * S]; float par; float hl[3], hr[3]; };   // par: parameter (tid & 15) of this thread's channel;
                                                                      // hl / hr: halo pixels across the workgroup edge (256-wide maps only)
 
-template <int TILES, int DIL, int LW, int S_>    // LW = log2 of the (square) OUTPUT map size: 6, 7 (one row per workgroup),
-                                                 // 8 (half a row); S_ = stride of the depthwise layer (input map = S_ x larger)
-__global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X, const float* __restrict__ dwP,
+template <int TILES, int DIL, int LW, int S_, int NW = 4>    // LW = log2 of the (square) OUTPUT map size: 6, 7 (one row per workgroup),
+                                                 // 8 (half a row); S_ = stride of the depthwise layer (input map = S_ x larger);
+                                                 // NW = waves = 32-pixel tiles per workgroup (8: four image rows, 64 x 64 maps only)
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (TILES >= 5 ? IVF_DWPW_OCC : 3)) void k_fcn_dwpw(const float* __restrict__ X, const float* __restrict__ dwP,
                                                     const uint4* __restrict__ Wq, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, const float* __restrict__ res,
                                                     float* __restrict__ Y, int K, int Cout, int nTiles, int abl)
 {
-    constexpr int kPitch = 132;                     // floats per hidden channel row in LDS: 128 pixels + bank skew
+    constexpr int NT = 64 * NW, NPX = 32 * NW, TPC = NPX / 8;       // threads, pixels per workgroup; threads per channel of a chunk
+    constexpr int kPitch = NPX + 4;                 // floats per hidden channel row in LDS: the pixels + bank skew
                                                     // (8 rows apart = 32 banks apart: the two k-groups never collide)
+    static_assert(NW == 4 || (NW == 8 && LW == 6 && S_ == 1), "eight waves: the row-pair layout of the 64 x 64 maps");
     static_assert(LW == 6 || DIL == 1, "the wider maps of the network are not dilated");
     static_assert(S_ == 1 || (S_ == 2 && DIL == 1 && LW <= 7), "stride 2: blocks 2 and 4");
     typedef DwSetT<S_> DwSet;
-    constexpr int Wd = 1 << LW, HW = Wd * Wd, WGPI = HW / 128;      // output map; workgroups per image
+    constexpr int Wd = 1 << LW, HW = Wd * Wd, WGPI = HW / NPX;      // output map; workgroups per image
     constexpr int Wi = Wd * S_, HWi = Wi * Wi;                       // input map
     __shared__ __attribute__((aligned(16))) float sD[2][16 * kPitch];
     __shared__ __attribute__((aligned(16))) float sW[2][TILES * 512];    // per tile: hi fragment, lo fragment (1 KB each)
@@ -1232,16 +1256,19 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
     const int b = L / WGPI, p128 = L % WGPI;
     const int tile0 = blockIdx.y * TILES;
-    const int kc = tid >> 4, g = tid & 15;
+    const int kc = tid / TPC, g = tid % TPC;
     // PAIR (64-wide stride-1 maps): the workgroup's two rows are y and y + DIL, not y and y + 1.  Their tap rows are
     // y-D, y, y+D and y, y+D, y+2D: four distinct rows instead of six, and the two shared ones travel between the halves
     // of the DPP row (lane ^ 8) instead of being loaded twice.  A thread loads its OTHER row (slot 0: y - D for half A,
     // y + D for half B) and its CENTRE row (slot 1); slot 2 is the partner's centre row (row_ror:8), i.e. tap row 2 for A
     // and tap row 0 for B.  Only the tap weights of slots 0 and 2 depend on the half.
     constexpr bool PAIR = LW == 6 && S_ == 1;
-    const bool halfB = PAIR && g >= 8;
-    const int yPairA = PAIR ? (p128 / DIL) * 2 * DIL + p128 % DIL : 0;
-    const int y = PAIR ? yPairA + (halfB ? DIL : 0) : (128 * p128 + 8 * g) >> LW;
+    // (eight waves: rows y, y + D, y + 2D, y + 3D as two such pairs; the rows the pairs share with each other are loaded by both
+    // and hit in the vector L1, so the workgroup pulls six tap rows from L2 for four output rows instead of eight, and one set
+    // of A fragments for 256 pixels instead of two)
+    const bool halfB = PAIR && (g & 8);
+    const int yPairA = PAIR ? (p128 / DIL) * (NPX / 64) * DIL + p128 % DIL : 0;       // first row of the workgroup
+    const int y = PAIR ? yPairA + (g >> 3) * DIL : (128 * p128 + 8 * g) >> LW;
     const int x0 = PAIR ? (g & 7) * 8 : (128 * p128 + 8 * g) & (Wd - 1);
     int rowOff[3]; float rowM[3];
 #pragma unroll
@@ -1259,15 +1286,19 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     const bool edgeL = LW == 8 && g == 0 && x0 > 0, edgeR = LW == 8 && g == 15 && x0 + 8 < Wd;
     const float* Xb = X + (size_t)b * K * HWi;
     const float* Wf = (const float*)Wq;
-    const int nChunks = (abl & 2) ? 24 : K / 16;     // odd for the 144-channel block: see the tail after the loop
+    const int nChunks = K / 16;                      // odd for the 144-channel block: see the tail after the loop
+#ifdef IVF_DWPW_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#endif
 
     // window and depthwise-parameter loads run two chunks ahead; each of the 16 threads of a channel fetches ONE of its
     // 12 parameters and the stencil broadcasts them with DPP row_share.  The A fragments (L2-resident, needed only at
     // publish time) run one chunk ahead and are issued first so that waiting for them leaves the rest in flight.
-    const int parIdx = kc * 12 + min(g, 11);
+    const int parIdx = kc * 12 + min(g & 15, 11);
     auto issue = [&](DwSet& S, int c) {
         c = min(c, nChunks - 1);                    // refills past the end are redundant re-loads (branch-free loop)
-        if (abl & 1) c = 0;
+        if (kAbl & 1) c = 0;
+        if ((kAbl & 16) && c >= 3) return;
         const float* P = Xb + (size_t)(16 * c + kc) * HWi;
         S.par = dwP[c * 192 + parIdx];
 #pragma unroll
@@ -1280,29 +1311,39 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
             }
         }
     };
-    float2 wreg[TILES];
+    constexpr int NWREG = (TILES * 256 + NT - 1) / NT;              // float2 of A fragments per thread and chunk
+    constexpr bool WTAIL = TILES * 256 % NT != 0;                   // the last round covers half of the threads
+    float2 wreg[NWREG];
     auto issue_w = [&](int c) {
         c = min(c, nChunks - 1);
+        if ((kAbl & 8) && c >= 2) return;
 #pragma unroll
-        for (int j = 0; j < TILES; j++)
-            wreg[j] = *(const float2*)(Wf + ((size_t)c * nTiles + tile0) * 512 + (tid + 256 * j) * 2);
+        for (int j = 0; j < NWREG; j++)
+            if (!WTAIL || j + 1 < NWREG || tid + NT * j < TILES * 256)
+                wreg[j] = *(const float2*)(Wf + ((size_t)c * nTiles + tile0) * 512 + (tid + NT * j) * 2);
     };
     auto shr1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true)); };
     auto shl1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xF, 0xF, true)); };
     float o[8];
     auto stencil = [&](const DwSet& S) {
+        if (kAbl & 64) {
+            o[0] = S.own[1][0].x; o[1] = S.own[1][0].y; o[2] = S.own[1][0].z; o[3] = S.own[1][0].w;
+            o[4] = S.own[1][1].x; o[5] = S.own[1][1].y; o[6] = S.own[1][1].z; o[7] = S.own[0][0].x + S.par;
+            return;
+        }
         float wk[9];
         const int pi = __builtin_bit_cast(int, S.par);
-#define ROW_SHARE(k) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, pi, 0x150 + (k), 0xF, 0xF, false))
+#define ROW_SHARE(k) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, pi, 0x150 + (k), 0xF, 0xF, true))
         wk[0] = ROW_SHARE(0); wk[1] = ROW_SHARE(1); wk[2] = ROW_SHARE(2); wk[3] = ROW_SHARE(3); wk[4] = ROW_SHARE(4);
         wk[5] = ROW_SHARE(5); wk[6] = ROW_SHARE(6); wk[7] = ROW_SHARE(7); wk[8] = ROW_SHARE(8);
         const float dsc = ROW_SHARE(9), dsh = ROW_SHARE(10);
 #undef ROW_SHARE
 #pragma unroll
         for (int p = 0; p < 8; p++) o[p] = 0.f;
+        f32x2 O[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
         float4 part[2];
         if constexpr (PAIR) {
-            auto ror8 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false)); };
+            auto ror8 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true)); };
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const float4 c = S.own[1][j];
@@ -1322,8 +1363,42 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
             // the compiler's DPP combiner leaves MAC-type instructions alone), so the halo costs no instruction.  Zero padding: rows through the tap weights (rowM),
             // the image's left / right border through the halo taps' weights (mL / mR; the DPP's own zero fill covers
             // the ends of the 16-lane row).
-            const float w0 = wk[ky * 3] * rowM[ky], w1 = wk[ky * 3 + 1] * rowM[ky], w2 = wk[ky * 3 + 2] * rowM[ky];
+            // PAIR: only slot 0 (the row y - D of half A, y + 2D of half B) can lie outside the image
+            const bool masked = !PAIR || ky == 0;
+            const float w0 = masked ? wk[ky * 3] * rowM[ky] : wk[ky * 3], w1 = masked ? wk[ky * 3 + 1] * rowM[ky] : wk[ky * 3 + 1],
+                        w2 = masked ? wk[ky * 3 + 2] * rowM[ky] : wk[ky * 3 + 2];
             const float w0L = w0 * mL, w2R = w2 * mR;
+            if constexpr (PAIR && (DIL == 2 || DIL == 4)) {
+                // packed-f32 FMAs (v_pk_fma_f32: two pixels per instruction, full rate) for every tap that stays inside the
+                // thread's 8 pixels; the halo taps stay DPP FMAs.  Per pixel the order centre, left, right is that of the scalar path.
+                const float4 a = ky == 2 ? part[0] : S.own[ky][0], c4 = ky == 2 ? part[1] : S.own[ky][1];
+                const float own[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+                const f32x2 A[4] = {{a.x, a.y}, {a.z, a.w}, {c4.x, c4.y}, {c4.z, c4.w}};
+                constexpr int H = DIL / 2;
+#pragma unroll
+                for (int i = 0; i < 4; i++) O[i] = pkfma(A[i], w1, O[i]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (i - H >= 0) O[i] = pkfma(A[i - H], w0, O[i]);
+                    else {
+                        float t0 = O[i].x, t1 = O[i].y;
+                        asm("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(t0) : "v"(own[8 + 2 * i - DIL]), "v"(w0L));
+                        asm("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(t1) : "v"(own[9 + 2 * i - DIL]), "v"(w0L));
+                        O[i].x = t0; O[i].y = t1;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (i + H < 4) O[i] = pkfma(A[i + H], w2, O[i]);
+                    else {
+                        float t0 = O[i].x, t1 = O[i].y;
+                        asm("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(t0) : "v"(own[2 * i + DIL - 8]), "v"(w2R));
+                        asm("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(t1) : "v"(own[2 * i + 1 + DIL - 8]), "v"(w2R));
+                        O[i].x = t0; O[i].y = t1;
+                    }
+                }
+                continue;
+            }
             if constexpr (S_ == 2) {
                 // stride 2: output pixel p reads input columns 2p-1, 2p, 2p+1 of the thread's 16; only column -1 of p = 0
                 // belongs to the left neighbour (its column 15)
@@ -1355,15 +1430,27 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
                 o[7] = __builtin_fmaf(S.hr[ky], w2, o[7]);
             }
         }
+        if constexpr (PAIR && (DIL == 2 || DIL == 4)) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const f32x2 v = pkfma(O[i], dsc, (f32x2){dsh, dsh});
+                o[2 * i] = __builtin_amdgcn_fmed3f(v.x, 0.f, 6.f); o[2 * i + 1] = __builtin_amdgcn_fmed3f(v.y, 0.f, 6.f);
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 8; p++) o[p] = __builtin_amdgcn_fmed3f(__builtin_fmaf(o[p], dsc, dsh), 0.f, 6.f);
     };
     auto publish = [&](int buf) {
         float* dst = &sD[buf][kc * kPitch + 8 * g];
-        *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
-        *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        if (!(kAbl & 512)) {
+            *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+            *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        } else asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]), "v"(o[7]));
+        if (kAbl & 128) { asm volatile("" :: "v"(wreg[0].x), "v"(wreg[NWREG - 1].y)); return; }
 #pragma unroll
-        for (int j = 0; j < TILES; j++) *(float2*)&sW[buf][(tid + 256 * j) * 2] = wreg[j];
+        for (int j = 0; j < NWREG; j++)
+            if (!WTAIL || j + 1 < NWREG || tid + NT * j < TILES * 256) *(float2*)&sW[buf][(tid + NT * j) * 2] = wreg[j];
     };
 
     f32x16 acc[TILES];
@@ -1375,9 +1462,20 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
         // B operand: this lane's pixel, hidden channels 8*kg .. 8*kg+7 of the chunk, split into f16 hi / lo
         HFrag bh, bl;
         const float* dB = &sD[cur][8 * kg * kPitch + 32 * wave + col];
+        if (kAbl & 256) {
 #pragma unroll
-        for (int jj = 0; jj < 4; jj++) split_pair(dB[2 * jj * kPitch], dB[(2 * jj + 1) * kPitch], bh.u[jj], bl.u[jj]);
+            for (int jj = 0; jj < 4; jj++) { bh.u[jj] = 0x3c003c00u + cur + lane; bl.u[jj] = 0x1c001c00u + cur; }
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) split_pair(dB[2 * jj * kPitch], dB[(2 * jj + 1) * kPitch], bh.u[jj], bl.u[jj]);
+        }
+        DWPW_TIM(5);
         const uint4* wA = (const uint4*)&sW[cur][0] + lane;
+        if (kAbl & 32) {
+            acc[0][0] += __builtin_bit_cast(float, bh.u[0] ^ bl.u[1]) + __builtin_bit_cast(float, bh.u[2] ^ bl.u[3]);
+            acc[0][1] += __builtin_bit_cast(float, bh.u[1] ^ bl.u[0]) + __builtin_bit_cast(float, bh.u[3] ^ bl.u[2]);
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < TILES; t += 2) {        // two tiles at a time: consecutive MFMAs hit different accumulators
             HFrag ah[2], al[2];
@@ -1405,33 +1503,52 @@ __global__ __launch_bounds__(256, 2) void k_fcn_dwpw(const float* __restrict__ X
     issue_w(1);                                     // weights before the window: in-order return lets the next
     issue(SA, 2);                                   // stencil wait for them with the window loads still in flight
     __syncthreads();
+#ifdef IVF_DWPW_TIMING
+    tlast = __builtin_amdgcn_s_memtime();
+#endif
     for (int c = 0; c + 1 < nChunks; c += 2) {
         // buffer 0 holds chunk c; set B = window of chunk c+1, set A = window of chunk c+2 (both in flight)
         multiply(0);
+        DWPW_TIM(0);
         stencil(SB);
+        DWPW_TIM(1);
         publish(1);
+        DWPW_TIM(4);
         __builtin_amdgcn_sched_barrier(0);          // pin the issue order: A fragments, then the far-ahead window
         issue_w(c + 2);
         __builtin_amdgcn_sched_barrier(0);
         issue(SB, c + 3);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(abl & 4)) __syncthreads();
+        DWPW_TIM(2);
+        if (!(kAbl & 4)) __syncthreads();
+        DWPW_TIM(3);
         multiply(1);
+        DWPW_TIM(0);
         stencil(SA);
+        DWPW_TIM(1);
         publish(0);
+        DWPW_TIM(4);
         __builtin_amdgcn_sched_barrier(0);          // pin the issue order: A fragments, then the far-ahead window
         issue_w(c + 3);
         __builtin_amdgcn_sched_barrier(0);
         issue(SA, c + 4);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(abl & 4)) __syncthreads();
+        DWPW_TIM(2);
+        if (!(kAbl & 4)) __syncthreads();
+        DWPW_TIM(3);
     }
+#ifdef IVF_DWPW_TIMING
+    if (TILES == 5 && DIL == 4 && tid == 0) {
+        for (int i = 0; i < 6; i++) atomicAdd(&g_dwpwTim[i], tacc[i]);
+        atomicAdd(&g_dwpwTim[7], 1ull);
+    }
+#endif
     if (nChunks & 1) multiply(0);                   // odd chunk count (the 144-channel block): the last chunk sits in buffer 0.
                                                     // A peeled tail, not an exit inside the loop: that costs the loop its
                                                     // counted vmcnt waits (measured on the 64-wide kernels: 226 -> 357 us)
     // epilogue: per tile, BN scale/shift (float4 per row quad, arrays padded to whole tiles) and the residual are
     // loaded as one batch before the first use
-    const int pix = PAIR ? (yPairA + (wave >> 1) * DIL) * Wd + 32 * (wave & 1) + col : 128 * p128 + 32 * wave + col;
+    const int pix = PAIR ? (yPairA + (wave >> 1) * DIL) * Wd + 32 * (wave & 1) + col : 128 * p128 + 32 * wave + col;   // wave = pixel tile
 #pragma unroll
     for (int t = 0; t < TILES; t++) {
         const int cb = (tile0 + t) * 32 + 4 * kg;
@@ -1513,7 +1630,7 @@ __device__ __forceinline__ void dwpw8_body(float (&sD)[2][16 * 132], float* sWp,
     float o[4];
     auto stencil = [&](const Win& S) {
         const int pi = __builtin_bit_cast(int, S.par);
-#define ROW_SHARE(k) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, pi, 0x150 + (k), 0xF, 0xF, false))
+#define ROW_SHARE(k) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, pi, 0x150 + (k), 0xF, 0xF, true))
         float wk[9];
         wk[0] = ROW_SHARE(0); wk[1] = ROW_SHARE(1); wk[2] = ROW_SHARE(2); wk[3] = ROW_SHARE(3); wk[4] = ROW_SHARE(4);
         wk[5] = ROW_SHARE(5); wk[6] = ROW_SHARE(6); wk[7] = ROW_SHARE(7); wk[8] = ROW_SHARE(8);
@@ -1815,7 +1932,7 @@ static thread_local char g_lastDwpw[96] = "";
 bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, float* Y, int H, int W, int B, hipStream_t s)
 {
     static const bool off = getenv("IVF_FCN_NOFUSE") != nullptr;
-    static const int abl = getenv("IVF_FCN_ABL") ? atoi(getenv("IVF_FCN_ABL")) : 0;
+    const int abl = kAbl;                                                   // ablation builds keep the 4-wave kernels
     const int tiles = (g.cout + 31) / 32;
     if (off || H != W || (H != 64 && H != 128 && H != 256) || d.c % 16 || g.taps != 1 || g.nTiles != tiles || g.act != 0) return false;
     if (d.stride == 2) {                                                    // blocks 2 (256 -> 128) and 4 (128 -> 64)
@@ -1835,9 +1952,15 @@ bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, f
     if (H != 64 && (!wide || d.dil != 1 || tiles != 1)) return false;
     const dim3 blk(256);
     const int wgpi = H * W / 128;
+    // eight waves (four image rows) per workgroup on the 64 x 64 maps.  Measured per 128 images, 4 vs 8 waves: 1 tile 125 -> 117,
+    // 2 tiles 263 -> 251 / 144 -> 128, 3 tiles 388 -> 395, 5 tiles 915 -> 919 us: on for <= 2 tiles; IVF_FCN_NW = 4 / 8 forces one
+    static const int nwEnv = getenv("IVF_FCN_NW") ? atoi(getenv("IVF_FCN_NW")) : 0;
 #define DWPW(T, D, LWV, GY) do {                                                                                          \
     snprintf(g_lastDwpw, sizeof g_lastDwpw, "ivffcn::k_fcn_dwpw<" #T ", " #D "> %d->%d", d.c, g.cout);                      \
-    hipLaunchKernelGGL((k_fcn_dwpw<T, D, LWV, 1>), dim3(wgpi * B, GY), blk, 0, s, X, d.dPack, g.dWq, g.dScale, g.dShift, res, Y, d.c, \
+    if (LWV == 6 && (nwEnv == 8 || (nwEnv != 4 && T <= 2)))                                                                 \
+        hipLaunchKernelGGL((k_fcn_dwpw<T, D, LWV, 1, (LWV == 6 ? 8 : 4)>), dim3(wgpi / 2 * B, GY), dim3(512), 0, s, X, d.dPack, g.dWq, g.dScale,    \
+                           g.dShift, res, Y, d.c, g.cout, g.nTiles, abl);                                                   \
+    else hipLaunchKernelGGL((k_fcn_dwpw<T, D, LWV, 1>), dim3(wgpi * B, GY), blk, 0, s, X, d.dPack, g.dWq, g.dScale, g.dShift, res, Y, d.c, \
                        g.cout, g.nTiles, abl); } while (0)
 #define DWPW8(D, T) do { snprintf(g_lastDwpw, sizeof g_lastDwpw, "ivffcn::k_fcn_dwpw8<" #D ", " #T "> %d->%d", d.c, g.cout);             \
     hipLaunchKernelGGL((k_fcn_dwpw8<D, T>), dim3(wgpi * B), dim3(512), 0, s, X, d.dPack, g.dWq, g.dScale, g.dShift, res, Y, d.c, \
@@ -2187,6 +2310,18 @@ void ivf_fcn_destroy(ivf_fcn* f)
     if (!f) return;
     (void)hipSetDevice(f->device);
     (void)hipDeviceSynchronize();
+#ifdef IVF_DWPW_TIMING
+    {
+        unsigned long long t[8] = {};
+        if (hipMemcpyFromSymbol(t, HIP_SYMBOL(ivffcn::g_dwpwTim), sizeof t) == hipSuccess && t[7]) {
+            const double n = (double)t[7];
+            fprintf(stderr, "[dwpw timing] workgroups %llu; cycles per workgroup: LDS read + split %.0f  MFMA %.0f  stencil %.0f  publish %.0f  issue %.0f  barrier %.0f\n",
+                    t[7], t[5] / n, t[0] / n, t[1] / n, t[4] / n, t[2] / n, t[3] / n);
+            unsigned long long z[8] = {};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(ivffcn::g_dwpwTim), z, sizeof z);
+        }
+    }
+#endif
     for (int i = 0; i < ivf_fcn::kProbe; i++) {
         if (f->probe0[i]) (void)hipEventDestroy(f->probe0[i]);
         if (f->probe1[i]) (void)hipEventDestroy(f->probe1[i]);
