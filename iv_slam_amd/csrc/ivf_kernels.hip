@@ -977,38 +977,58 @@ __global__ __launch_bounds__(NTHR) void k_cell_select(const Config* __restrict__
     if (tid == 0) s_m = 0;
     sync();
     if (cy1 > cy0 && cx1 > cx0) {
+        // The gather is a chain of memory round trips (a tile's count, then its list, 64 entries per step): the counts of up to
+        // 64 tiles are fetched by one wave-wide load and handed out by lane broadcast, and a tile's list is read four steps at
+        // a time (four loads in flight per lane) -- one round trip per tile instead of ~5.  (Measured: 268 -> 263 us per 256 images only -- the kernel's time is the bitonic sort,
+        // 41 %, and the introselect replay, 26 %, found by compiling each out.)
         const int tx0 = (cx0 - 16) / kFastTW, tx1 = (cx1 - 1 - 16) / kFastTW;
         const int ty0 = (cy0 - kEdge) / kFastTH, ty1 = (cy1 - 1 - kEdge) / kFastTH;
-        for (int ty = ty0; ty <= ty1; ty++)
-            for (int tx = tx0; tx <= tx1; tx++) {
-                const size_t tile = (size_t)img * cfg->nTiles + G.tileBase + ty * G.tilesX + tx;
-                const int nAll = min(tileCnt[tile], kTileCap);
-                const unsigned* in = tileList + tile * kTileCap;
-                for (int b0 = 0; b0 < nAll; b0 += NTHR) {
-                    const int k = b0 + tid;
-                    const unsigned e = k < nAll ? in[k] : 0u;
-                    const int ex = (e >> 8) & 0xfff, ey = e >> 20;
-                    const bool keep = k < nAll && (e & 0xffu) >= th && ex >= cx0 && ex < cx1 && ey >= cy0 && ey < cy1;
-                    if constexpr (NTHR == 64) {
+        const int ntx = tx1 - tx0 + 1, nt = ntx * (ty1 - ty0 + 1);
+        const size_t tileBase = (size_t)img * cfg->nTiles + G.tileBase;
+        constexpr int U = 4;
+        for (int t0 = 0; t0 < nt; t0 += 64) {
+            int myCnt = 0;
+            if (t0 + lane < nt) {
+                const int t = t0 + lane;
+                myCnt = min(tileCnt[tileBase + (ty0 + t / ntx) * G.tilesX + tx0 + t % ntx], kTileCap);
+            }
+            const int ng = min(64, nt - t0);
+            for (int j = 0; j < ng; j++) {
+                const int nAll = __shfl(myCnt, j, 64);
+                if (nAll == 0) continue;
+                const int t = t0 + j;
+                const unsigned* in = tileList + (tileBase + (ty0 + t / ntx) * G.tilesX + tx0 + t % ntx) * kTileCap;
+                for (int b0 = 0; b0 < nAll; b0 += NTHR * U) {
+                    unsigned ev[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) { const int k = b0 + u * NTHR + tid; ev[u] = k < nAll ? in[k] : 0u; }   // score 0 < th: never kept
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        if (b0 + u * NTHR >= nAll) break;               // uniform
+                        const unsigned e = ev[u];
+                        const int ex = (e >> 8) & 0xfff, ey = e >> 20;
+                        const bool keep = (e & 0xffu) >= th && ex >= cx0 && ex < cx1 && ey >= cy0 && ey < cy1;
                         const unsigned long long mask = __ballot(keep);
-                        if (keep) {
-                            const int idx = m + __popcll(mask & ((1ull << lane) - 1ull));
-                            if (idx < CAP) keys[idx] = e;
-                        }
-                        m += __popcll(mask);
-                    } else {
-                        // order is irrelevant here (the sort restores it): one LDS atomic per wave reserves its slots
-                        const unsigned long long mask = __ballot(keep);
-                        int base = 0;
-                        if (lane == 0 && mask) base = atomicAdd(&s_m, __popcll(mask));
-                        base = __shfl(base, 0);
-                        if (keep) {
-                            const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
-                            if (idx < CAP) keys[idx] = e;
+                        if constexpr (NTHR == 64) {
+                            if (keep) {
+                                const int idx = m + __popcll(mask & ((1ull << lane) - 1ull));
+                                if (idx < CAP) keys[idx] = e;
+                            }
+                            m += __popcll(mask);
+                        } else {
+                            // order is irrelevant here (the sort restores it): one LDS atomic per wave reserves its slots
+                            int base = 0;
+                            if (lane == 0 && mask) base = atomicAdd(&s_m, __popcll(mask));
+                            base = __shfl(base, 0);
+                            if (keep) {
+                                const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+                                if (idx < CAP) keys[idx] = e;
+                            }
                         }
                     }
                 }
             }
+        }
     }
     if constexpr (NTHR != 64) { sync(); m = s_m; }
     if (tid == 0 && m != nT) atomicOr(status, 1);                    // internal consistency
