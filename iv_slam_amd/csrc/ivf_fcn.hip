@@ -1114,6 +1114,9 @@ __global__ __launch_bounds__(256, 2) void k_fcn_expand(const float* __restrict__
     const int myTiles = (nTiles - wave + 3) / 4;
     uint4 ring[RD][2];
     auto aload = [&](int it, int st, uint4 (&r)[2]) {
+#if IVF_EXPAND_ABL & 4
+        if (it > 0) return;                         // timing-only: the A fragments of the first tile are reused for every tile
+#endif
         const uint4* w = Wq + ((size_t)st * nTiles + wave + 4 * min(it, myTiles - 1)) * 128 + lane;
         r[0] = w[0]; r[1] = w[64];
     };
@@ -1132,12 +1135,17 @@ __global__ __launch_bounds__(256, 2) void k_fcn_expand(const float* __restrict__
         HFrag bh[PXT], bl[PXT];
 #pragma unroll
         for (int pt = 0; pt < PXT; pt++) { bh[pt].q = sB[((s * PXT + pt) * 2 + 0) * 64 + sl]; bl[pt].q = sB[((s * PXT + pt) * 2 + 1) * 64 + sl]; }
+#if IVF_EXPAND_ABL & 2
+#pragma unroll
+        for (int pt = 0; pt < PXT; pt++) acc[pt][s & 15] += __builtin_bit_cast(float, al.u[0] ^ bh[pt].u[1] ^ ah.u[2] ^ bl[pt].u[3]);
+#else
 #pragma unroll
         for (int pt = 0; pt < PXT; pt++) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, bh[pt].v, acc[pt], 0, 0, 0);
 #pragma unroll
         for (int pt = 0; pt < PXT; pt++) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bl[pt].v, acc[pt], 0, 0, 0);
 #pragma unroll
         for (int pt = 0; pt < PXT; pt++) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bh[pt].v, acc[pt], 0, 0, 0);
+#endif
     };
     auto store_rows = [&](int n, int r0, int r1, const f32x16 (&acc)[PXT], const float4 (&sc4)[4], const float4 (&sh4)[4]) {
         const int cb = n * 32 + 4 * kg;
@@ -1152,8 +1160,12 @@ __global__ __launch_bounds__(256, 2) void k_fcn_expand(const float* __restrict__
 #pragma unroll
             for (int p = 0; p < PXT; p++) o[p] = __builtin_amdgcn_fmed3f(acc[p][r] * sc + sh, 0.f, 6.f);
             float* yo = yb + (size_t)ro * HW;
+#if IVF_EXPAND_ABL & 1
+            asm volatile("" :: "v"(o[0]), "v"(o[PXT - 1]), "v"(yo));
+#else
             if constexpr (PXT == 4) *(float4*)yo = make_float4(o[0], o[1], o[2], o[3]);
             else *(float2*)yo = make_float2(o[0], o[1]);
+#endif
         }
     };
     auto load_bn = [&](int n, float4 (&sc4)[4], float4 (&sh4)[4]) {
@@ -1225,6 +1237,9 @@ static __device__ __forceinline__ f32x2 pkfma(f32x2 a, float w, f32x2 c) { retur
 // depthwise stores to LDS.  Results are wrong by construction.
 #ifndef IVF_DWPW_ABL
 #define IVF_DWPW_ABL 0
+#endif
+#ifndef IVF_EXPAND_ABL
+#define IVF_EXPAND_ABL 0      // timing-only ablations of k_fcn_expand: 1 no stores, 2 no MFMAs, 4 no A-fragment loads after the first tile
 #endif
 constexpr int kAbl = IVF_DWPW_ABL;
 #ifndef IVF_DWPW_OCC
