@@ -27,7 +27,7 @@ extern "C" {
 #define IVF_OK             0
 #define IVF_E_INVALID     -1   /* bad argument */
 #define IVF_E_CAPACITY    -2   /* caller buffer too small */
-#define IVF_E_GEOMETRY    -3   /* cell grid leaves the image (the reference would throw / read OOB) */
+#define IVF_E_GEOMETRY    -3   /* cell grid leaves the image where the reference would throw / read OOB (with introspection: only without a cost map) */
 #define IVF_E_NO_DEVICE   -4   /* no usable HIP device / HIP runtime error */
 #define IVF_E_STATE       -5   /* call order violated (e.g. stereo match before extract) */
 

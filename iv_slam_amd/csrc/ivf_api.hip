@@ -69,6 +69,7 @@ int make_tables(const ivf_extractor_params& p, Tables& t)
 struct Context {
     int device = 0, maxImg = 0, nSides = 1;
     bool introspection = false;
+    bool needsCost = false;             // cell rows overshoot a level: only the introspection path (stale hY) is defined there
     Config hc{};
     Config* dc = nullptr;
     ResizeCoef* dTab = nullptr;           // packed cv::resize coefficients, all levels
@@ -143,9 +144,16 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
         G.nfeaturesCell = (int)std::ceil((float)G.nDesired / G.nCells);   // :923
         // cell windows must stay inside [16, dim-16): otherwise the reference throws in rowRange/colRange
         // or reads outside the blurred clone (ORBextractor.cc:1033, 1276)
-        if ((G.cols - 1) * G.cellW > W || (G.rows - 1) * G.cellH > H)
+        // With introspection the stale-hY quirk gives every row the LAST row's window height, which is
+        // negative or tiny exactly when the rows overshoot: the reference then runs (and finds nothing in those cells) as long
+        // as a cost map comes with the image.  A per-call extractor with introspection on is therefore accepted and checked
+        // per call; stereo contexts hold a non-introspective right side and are rejected here.
+        const bool colsLeave = (G.cols - 1) * G.cellW > W, rowsLeave = (G.rows - 1) * G.cellH > H;
+        const bool lastRowEmpty = H - (G.rows - 1) * G.cellH + 6 <= 0;    // hY <= 0 in the last row: stale non-positive height, rowRange throws
+        if (colsLeave || (rowsLeave && (!(introspection && sides == 1) || lastRowEmpty)))
             return fail(IVF_E_GEOMETRY, "level %d: %dx%d cells of %dx%d leave the %dx%d level", l, G.cols, G.rows,
                         G.cellW, G.cellH, G.w, G.h);
+        if (rowsLeave) needsCost = true;
         G.domHLast = H - (G.rows - 1) * G.cellH;
         G.winHLast = G.domHLast + 6;
         G.domH[0] = G.cellH;
@@ -266,6 +274,8 @@ int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size
     HIPCHK(hipSetDevice(device));
     lastStream = st;
     const bool useQ = introspection && cost != nullptr;
+    if (needsCost && !useQ)
+        return fail(IVF_E_GEOMETRY, "cell rows leave a pyramid level: this geometry is defined only with a cost map (stale hY, ORBextractor.cc:935-999)");
     if (cost && !b.qpyr) {
         // a cost image with an extractor that ignores it (enableIntrospection = 0): mvKeyQualScore still reads it
         // (Frame.cc:130-143), so its level 0 is ingested.  One-time allocation, on the first such call.

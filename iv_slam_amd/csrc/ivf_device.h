@@ -7,7 +7,7 @@
 namespace ivf {
 
 constexpr int kMaxLevels = IVF_MAX_LEVELS;
-constexpr int kMaxCells = 512;           // per level (LDS bookkeeping arrays in k_select)
+constexpr int kMaxCells = 2048;          // per level (LDS bookkeeping arrays in k_quota, 50 KB); the reference has ~N_level / 5 cells, i.e. ~10 000 features on one level
 constexpr int kEdge = 19;                // EDGE_THRESHOLD (ORB/src/ORBextractor.cc:75)
 
 // Geometry of one pyramid level.  All of it depends only on (params, image size), so the host

@@ -1,0 +1,105 @@
+"""Seeded random geometries / parameters through the per-call extractor and the batched stereo front end against the CPU
+oracle (bit-exact bar).  The fixed-size parity tests cover the benchmark shapes; this one walks the corners of the geometry
+code: odd widths and pitches, planes whose upper levels vanish, level counts and scale factors other than 8 / 1.2, thresholds,
+feature counts far below and above what the image yields, cost maps on and off."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from iv_slam_amd import synth
+from test_gpu_parity import assert_kps_equal, iv  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(rng):
+    w = int(rng.integers(97, 1400)); h = int(rng.integers(81, 620))
+    n = int(rng.choice([60, 200, 500, 1000, 2500, 6000]))
+    nlevels = int(rng.integers(1, 9))
+    sf = float(rng.choice([1.1, 1.2, 1.3, 1.5, 2.0]))
+    ini = int(rng.choice([10, 20, 35])); mn = int(rng.choice([3, 7, ini]))
+    return w, h, n, nlevels, sf, ini, min(mn, ini)
+
+
+IVF_E_GEOMETRY = -3
+
+
+def _valid_case(iv, rng, intro):
+    """draws cases until one has a cell grid the reference can run: where a cell window would leave its level the reference
+    throws in rowRange / colRange (ORBextractor.cc:1033); product and oracle must BOTH report that geometry as unsupported."""
+    from iv_slam_amd._lib import IvfError
+    for _ in range(40):
+        w, h, n, nlevels, sf, ini, mn = _case(rng)
+        img = synth.make_left(w, h, seed=int(rng.integers(0, 1 << 20)), idx=0)
+        cost = synth.make_cost_map(w, h, seed=3, idx=1) if intro else None
+        g = iv.ORBextractor(n, sf, nlevels, ini, mn, intro)
+        o = O.Extractor(n, sf, nlevels, ini, mn, intro)
+        try:
+            gk, gd = g(img, cost)
+        except IvfError as e:
+            assert e.code == IVF_E_GEOMETRY, str(e)
+            with pytest.raises(RuntimeError):
+                o(img, cost)
+            continue
+        if intro:
+            # rows that overshoot a level are defined only on the introspection path (stale hY): without the cost map both sides
+            # must refuse exactly when the oracle does
+            try:
+                o(img, None); oracle_ok = True
+            except RuntimeError:
+                oracle_ok = False
+            try:
+                g(img, None); product_ok = True
+            except IvfError as e:
+                assert e.code == IVF_E_GEOMETRY, str(e); product_ok = False
+            assert oracle_ok == product_ok, "%dx%d n=%d levels=%d sf=%.1f without cost map: oracle %s, product %s" % (w, h, n, nlevels, sf, oracle_ok, product_ok)
+            gk, gd = g(img, cost)
+        return (w, h, n, nlevels, sf, ini, mn), img, cost, g, o, gk, gd
+    raise AssertionError("no valid geometry in 40 draws")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IVF_FUZZ_EXTRACT", "10"))))
+def test_extract_random_geometry(iv, seed):
+    rng = np.random.default_rng(1000 + seed)
+    intro = bool(seed & 1)
+    (w, h, n, nlevels, sf, ini, mn), img, cost, g, o, gk, gd = _valid_case(iv, rng, intro)
+    ok, od = o(img, cost)
+    what = "%dx%d n=%d levels=%d sf=%.1f th=%d/%d intro=%d" % (w, h, n, nlevels, sf, ini, mn, intro)
+    assert g.level_counts() == o.level_counts(), what
+    assert_kps_equal(gk, ok, what)
+    assert np.array_equal(gd, od), what
+    for l in range(nlevels):
+        assert np.array_equal(g.mvImagePyramid[l], o.pyramid(l)), "%s: pyramid level %d" % (what, l)
+    if seed % 3 == 2:                                   # the same geometry on a noisy image: ties, dense corners
+        noisy = np.clip(img.astype(np.int32) + rng.integers(-40, 41, img.shape), 0, 255).astype(np.uint8)
+        gk, gd = g(noisy, cost); ok, od = o(noisy, cost)
+        assert_kps_equal(gk, ok, what + " noisy"); assert np.array_equal(gd, od), what
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IVF_FUZZ_FRONTEND", "4"))))
+def test_frontend_random_geometry(iv, seed):
+    import torch
+    rng = np.random.default_rng(2000 + seed)
+    intro = bool(seed & 1)
+    (w, h, n, nlevels, sf, ini, mn), _img, _cost, _g, _o, _gk, _gd = _valid_case(iv, rng, False)   # the right side never sees a cost map
+    pairs = 2
+    bf = 386.1448; b = bf / 718.856
+    stream = synth.make_stream(pairs, w, h, seed=70 + seed)
+    cost = np.stack([synth.make_cost_map(w, h, seed=70 + seed, idx=i) for i in range(pairs)]) if intro else None
+    dev = torch.device("cuda:0")
+    fe = iv.StereoFrontend(w, h, pairs, nfeatures=n, scaleFactor=sf, nlevels=nlevels, iniThFAST=ini, minThFAST=mn,
+                           enableIntrospection=intro, bf=bf, b=b)
+    fe.run(torch.from_numpy(stream[:, 0].copy()).to(dev), torch.from_numpy(stream[:, 1].copy()).to(dev),
+           None if cost is None else torch.from_numpy(cost).to(dev))
+    fe.sync()
+    what = "%dx%d n=%d levels=%d sf=%.1f th=%d/%d intro=%d" % (w, h, n, nlevels, sf, ini, mn, intro)
+    for p in range(pairs):
+        oL = O.Extractor(n, sf, nlevels, ini, mn, intro); oR = O.Extractor(n, sf, nlevels, ini, mn, False)
+        okL, odL = oL(stream[p, 0], None if cost is None else cost[p]); okR, odR = oR(stream[p, 1], None)
+        our, odp = O.stereo_match(oL, oR, okL, odL, okR, odR, bf, b)
+        rl = fe.fetch(p, 0); rr = fe.fetch(p, 1)
+        assert_kps_equal(rl["kps"], okL, what + " L%d" % p); assert_kps_equal(rr["kps"], okR, what + " R%d" % p)
+        assert np.array_equal(rl["desc"], odL) and np.array_equal(rr["desc"], odR), what
+        assert rl["uright"].tobytes() == our.tobytes() and rl["depth"].tobytes() == odp.tobytes(), what
