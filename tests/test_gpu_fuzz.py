@@ -103,3 +103,74 @@ def test_frontend_random_geometry(iv, seed):
         assert_kps_equal(rl["kps"], okL, what + " L%d" % p); assert_kps_equal(rr["kps"], okR, what + " R%d" % p)
         assert np.array_equal(rl["desc"], odL) and np.array_equal(rr["desc"], odR), what
         assert rl["uright"].tobytes() == our.tobytes() and rl["depth"].tobytes() == odp.tobytes(), what
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IVF_FUZZ_FCN", "3"))))
+def test_fcn_random_sizes_and_batches(iv, seed):
+    """the FCN's input / output stages (bilinear to 512 x 512, bilinear to out_size, logistic, u8 truncation) at sizes other
+    than the two benchmark shapes, batched, against the torch-CPU layer list (1e-3 bar; u8 within one LSB)."""
+    import torch
+    import fcn_common as FC
+    import fcn_oracle_torch as FT
+    from iv_slam_amd import fcn_weights
+    rng = np.random.default_rng(3000 + seed)
+    g, W, _bgr, _ = FC.load_case(["kitti", "jackal_smallw", "kitti_bigw"][seed % 3])     # weights with a calibrated conv_last
+    ih, iw = int(rng.integers(33, 900)), int(rng.integers(33, 1500))
+    oh, ow = (ih, iw) if seed % 2 == 0 else (int(rng.integers(17, 700)), int(rng.integers(17, 1300)))
+    nb = int(rng.integers(1, 4))
+    imgs = np.stack([FC.bgr_image(iw, ih, 900 + 7 * seed + k) for k in range(nb)])
+    fcn = iv.IntrospectionFCN(fcn_weights.pack_blob(W), (ih, iw), (oh, ow), max_batch=nb)
+    dev = torch.device("cuda:0")
+    cu8 = torch.empty((nb, oh, ow), dtype=torch.uint8, device=dev); cf = torch.empty((nb, oh, ow), dtype=torch.float32, device=dev)
+    fcn.forward_device(torch.from_numpy(imgs).to(dev), cost_u8=cu8, cost_f32=cf)
+    torch.cuda.synchronize()
+    T = FT.prepare(W)
+    oc, ou8 = FT.forward(T, imgs, (oh, ow))
+    err = float(np.abs(cf.cpu().numpy() - oc).max())
+    assert err < 1e-3, "in %dx%d out %dx%d batch %d: %.3g" % (iw, ih, ow, oh, nb, err)
+    d = np.abs(cu8.cpu().numpy().astype(int) - ou8.astype(int))
+    assert d.max() <= 1 and (d != 0).mean() < 0.02
+    u8_single = fcn(imgs[0])                             # the per-call host path gives the batch's first slot
+    assert np.array_equal(u8_single, cu8[0].cpu().numpy())
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IVF_FUZZ_SEARCH", "4"))))
+def test_window_searches_random_scenarios(iv, seed):
+    """SearchByProjection(cur,last) / SearchByProjection(F, mapPoints) on a resident frame, through the host-grid entry point and in
+    the oracle, on random frame sizes, feature counts, radii and level windows (incl. windows off the grid, dense windows that
+    overflow the device-side candidate lists, empty query sets)."""
+    import test_gpu_frame as TF
+    from iv_slam_amd._lib import IvfError
+    rng = np.random.default_rng(4000 + seed)
+    radius = float(rng.choice([1.0, 4.0, 7.0, 15.0, 60.0]))
+    big = bool(rng.integers(0, 2))
+    for _ in range(40):                                 # the scenario's keypoints come from the extractor: skip unsupported cell grids
+        w = int(rng.integers(200, 1300)); h = int(rng.integers(120, 500))
+        n = int(rng.choice([40, 300, 1000, 2500]))
+        try:
+            kps, desc, uright, bounds, q, pre = TF._case(iv, 500 + seed, n, w, h, radius=radius, big=big)
+            break
+        except IvfError as e:
+            assert e.code == IVF_E_GEOMETRY
+        except ValueError:                              # fewer than three keypoints: the scenario builder needs three
+            pass
+    if seed % 5 == 4:                                   # no query survives
+        q["valid"][:] = 0
+    f = iv.DeviceFrame(kps, desc, uright, bounds)
+    check_ori = bool(rng.integers(0, 2))
+    m = iv.ORBmatcher(float(rng.choice([0.6, 0.75, 0.9])), check_ori)
+    what = "%dx%d n=%d r=%.0f big=%d" % (w, h, len(kps), radius, big)
+    for chk in (True, False):
+        ga, gn = f.SearchByProjection(q, chk, pre)
+        oa, on = O.search_by_projection(kps, desc, uright, bounds, q, chk, pre)
+        assert gn == on and np.array_equal(ga, oa), what
+    ha, hn = m.SearchByProjection(kps, desc, uright, bounds, q, pre)
+    ga, gn = f.SearchByProjection(q, check_ori, pre)
+    assert hn == gn and np.array_equal(ha, ga), what
+    qm = dict(u=q["u"], v=q["v"], ur=q["ur"], radius=q["radius"],
+              level=np.clip(kps["octave"] + rng.integers(-1, 2, len(kps)), 0, 7).astype(np.int32),
+              desc=q["desc"], valid=q["valid"], blocks=q["blocks"])
+    for ratio in (0.6, 1.0):
+        ga, gn = f.SearchByProjectionMapPoints(qm, ratio, pre)
+        oa, on = O.search_map_points(kps, desc, uright, bounds, qm, ratio, pre)
+        assert gn == on and np.array_equal(ga, oa), what
