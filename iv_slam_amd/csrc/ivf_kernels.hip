@@ -85,10 +85,15 @@ __global__ void k_ingest(const Config* __restrict__ cfg, const uint8_t* __restri
 // k_pyr_down: cv::resize INTER_LINEAR 8UC1 (11-bit coefficients; horizontal pass in int,
 // vertical pass ((b0*(h0>>4))>>16) + ((b1*(h1>>4))>>16) + 2) >> 2).
 // One workgroup = 256 x 16 output pixels; the source rows it needs are staged in LDS with aligned
-// dword loads, every thread produces 4 horizontally adjacent pixels (one dword store).  The
+// dword loads.  r02: a thread produces 4 adjacent pixels of 4 CONSECUTIVE rows.  Per source row it reads three aligned dwords,
+// funnels them into the 8-byte window its four columns draw from (v_alignbyte), picks each column's two source bytes as a
+// u16 pair (v_perm with a per-column selector computed once) and gets p0*a0 + p1*a1 from one v_dot2_u32_u16; the row shared by
+// two consecutive output rows is computed once.  One dword store per row.  The
 // per-column / per-row coefficients (fx = (float)((dx+0.5)*scale - 0.5), cvRound(f*2048) ...) come
 // from a packed table the host builds once per geometry exactly as OpenCV's resize does.
+// r01's fused form cost ~45 VALU lane-instructions per output pixel (SQ counters: 0.81 of the vector issue rate).
 // ------------------------------------------------------------------------------------------------
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 constexpr int kPyrTW = 256, kPyrTH = 16, kPyrSrcP = 544, kPyrSrcR = 36;    // LDS: 36 rows x 544 B (scale <= 2)
 __global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg, int level,
                                                  const ResizeCoef* __restrict__ tab, uint8_t* __restrict__ blob)
@@ -116,6 +121,79 @@ __global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg
         }
     }
     __syncthreads();
+    if (fits) {
+        const int x4 = dx0 + (tid & 63) * 4;
+        if (x4 >= D.pitch) return;
+        // per column: the two source bytes as a zero-extended u16 pair picked out of the 8-byte window that starts at the first
+        // column's source byte, and the coefficient pair
+        unsigned sel[4], coef[4];
+        int sxs[4], sx1s[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const ResizeCoef cx = tx[min(x4 + k, D.w - 1)];
+            sxs[k] = (int)(cx & 0xffff); sx1s[k] = min(sxs[k] + 1, S.w - 1);
+            coef[k] = (unsigned)((cx >> 16) & 0xffff) | ((unsigned)((cx >> 32) & 0xffff) << 16);      // a0 | a1 << 16
+        }
+        // level-to-level ratios just above 2 (scaleFactor 2.0 with rounded level sizes) stretch the four columns over more than
+        // 8 source bytes: such a thread draws columns 2 and 3 from a second window that starts at column 2's source byte
+        const bool wide = sx1s[3] - sxs[0] > 7;
+        const int base2 = wide ? sxs[2] : sxs[0];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int b = k < 2 ? sxs[0] : base2;
+            sel[k] = (unsigned)(sxs[k] - b) | 0x0c00u | ((unsigned)(sx1s[k] - b) << 16) | 0x0c000000u;
+        }
+        const int wbyte = sxs[0] - wx0, wsh = wbyte & 3, wbyte2 = base2 - wx0, wsh2 = wbyte2 & 3;
+        const unsigned* wrow = (const unsigned*)(src + (wbyte & ~3));
+        const unsigned* wrow2 = (const unsigned*)(src + (wbyte2 & ~3));
+        // (h >> 4) of the four columns on staged row r
+        auto hpass = [&](int r, unsigned (&h)[4]) {
+            const unsigned* w = wrow + r * (kPyrSrcP / 4);
+            const unsigned d0 = w[0], d1 = w[1], d2 = w[2];
+            const unsigned lo = __builtin_amdgcn_alignbyte(d1, d0, wsh), hi = __builtin_amdgcn_alignbyte(d2, d1, wsh);
+            unsigned lo2 = lo, hi2 = hi;
+            if (wide) {
+                const unsigned* w2 = wrow2 + r * (kPyrSrcP / 4);
+                const unsigned e0 = w2[0], e1 = w2[1], e2 = w2[2];
+                lo2 = __builtin_amdgcn_alignbyte(e1, e0, wsh2); hi2 = __builtin_amdgcn_alignbyte(e2, e1, wsh2);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                h[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(k < 2 ? hi : hi2, k < 2 ? lo : lo2, sel[k])),
+                                              __builtin_bit_cast(u16x2, coef[k]), 0u, false) >> 4;
+        };
+        const unsigned colMask = x4 + 3 < D.w ? 0xffffffffu : (x4 >= D.w ? 0u : (0xffffffffu >> (8 * (x4 + 4 - D.w))));
+        // a thread takes 4 CONSECUTIVE output rows: the lower source row of one output row is usually the upper one of the
+        // next (scale 1.2), so its horizontal pass is reused (the row index is uniform across the wave)
+        const int dyFirst = dy0 + 4 * (tid >> 6);
+        unsigned hA[4], hB[4];
+        int rowA = -1, rowB = -1;                   // staged rows held in hA / hB
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int dy = dyFirst + rr;
+            if (dy >= D.h) break;
+            const ResizeCoef cy = ty[dy];
+            const int y0 = (int)(cy & 0xffff), y1 = min(y0 + 1, S.h - 1);
+            const unsigned b0 = (unsigned)((cy >> 16) & 0xffff), b1 = (unsigned)((cy >> 32) & 0xffff);
+            if (y0 - wy0 == rowB) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) hA[k] = hB[k];
+                rowA = rowB;
+            } else if (y0 - wy0 != rowA) { hpass(y0 - wy0, hA); rowA = y0 - wy0; }
+            if (y1 - wy0 == rowA) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) hB[k] = hA[k];
+                rowB = rowA;
+            } else if (y1 - wy0 != rowB) { hpass(y1 - wy0, hB); rowB = y1 - wy0; }
+            unsigned out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                out |= (((((b0 * hA[k]) >> 16) + ((b1 * hB[k]) >> 16) + 2u) >> 2) & 0xffu) << (8 * k);
+            *(unsigned*)(base + D.off + (size_t)dy * D.pitch + x4) = out & colMask;
+        }
+        return;
+    }
+    // scale factors above 2 (source window larger than the LDS tile): per-pixel evaluation straight from global memory
     const int x4 = dx0 + (tid & 63) * 4;
     if (x4 >= D.pitch) return;
     // the 4 column coefficients of this thread are shared by its 4 rows
@@ -140,15 +218,9 @@ __global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg
             unsigned r = 0;
             if (x4 + k < D.w) {
                 int p00, p01, p10, p11;
-                if (fits) {
-                    const uint8_t* r0 = src + (y0 - wy0) * kPyrSrcP - wx0;
-                    const uint8_t* r1 = src + (y1 - wy0) * kPyrSrcP - wx0;
-                    p00 = r0[sxk[k]]; p01 = r0[sx1k[k]]; p10 = r1[sxk[k]]; p11 = r1[sx1k[k]];
-                } else {
-                    const uint8_t* r0 = SP + (size_t)y0 * S.pitch;
-                    const uint8_t* r1 = SP + (size_t)y1 * S.pitch;
-                    p00 = r0[sxk[k]]; p01 = r0[sx1k[k]]; p10 = r1[sxk[k]]; p11 = r1[sx1k[k]];
-                }
+                const uint8_t* r0 = SP + (size_t)y0 * S.pitch;
+                const uint8_t* r1 = SP + (size_t)y1 * S.pitch;
+                p00 = r0[sxk[k]]; p01 = r0[sx1k[k]]; p10 = r1[sxk[k]]; p11 = r1[sx1k[k]];
                 const int h0 = p00 * a0k[k] + p01 * a1k[k], h1 = p10 * a0k[k] + p11 * a1k[k];
                 r = (unsigned)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
             }
