@@ -1353,12 +1353,15 @@ __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg
                                                  const unsigned* __restrict__ slotPos, const float* __restrict__ slotResp,
                                                  const int* __restrict__ lvlCount, ivf_keypoint* __restrict__ kps,
                                                  uint8_t* __restrict__ desc, int* __restrict__ count,
-                                                 float* __restrict__ quality)
+                                                 float* __restrict__ quality, int nImg)
 {
-    const int img = blockIdx.y;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+    // image i is described by XCD i % 8 only: a keypoint pulls ~68 cache lines out of its image's two pyramids (3.8 MB at
+    // 1242 x 375), which stay in that XCD's 4 MB L2 while its CUs walk the image
     const int nf = cfg->nfeatures, nl = cfg->nlevels;
+    int img, grp;
+    if (!xcd_tile_image((nf + 3) / 4, nImg, grp, img)) return;
+    const int slot = grp * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (slot >= nf) return;
     int level = 0;
     for (int l = 1; l < nl; l++) if (slot >= cfg->lv[l].kpBase) level = l;
@@ -1717,8 +1720,8 @@ void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nIm
 void launch_describe(const Config& hc, const Config* dc, const Buffers& b, const uint8_t*, size_t, int, int nImg, int,
                      hipStream_t s)
 {
-    hipLaunchKernelGGL(k_describe, dim3((hc.nfeatures + 3) / 4, nImg), dim3(256), 0, s, dc, b.pyr, b.blur, b.qpyr,
-                       b.useCost, b.slotPos, b.slotResp, b.lvlCount, b.kps, b.desc, b.count, b.quality);
+    hipLaunchKernelGGL(k_describe, dim3((nImg + 7) / 8 * 8 * ((hc.nfeatures + 3) / 4)), dim3(256), 0, s, dc, b.pyr, b.blur, b.qpyr,
+                       b.useCost, b.slotPos, b.slotResp, b.lvlCount, b.kps, b.desc, b.count, b.quality, nImg);
 }
 void launch_stereo_args(const Config& hc, const Config* dc, const StereoArgs& A, int nPairs, hipStream_t s)
 {
