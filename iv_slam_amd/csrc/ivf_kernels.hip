@@ -1342,11 +1342,19 @@ DEVINL float fast_atan2(float y, float x)
 DEVINL int cv_round(float v) { return __float2int_rn(v); }
 
 // ------------------------------------------------------------------------------------------------
-// k_describe: one wave = one keypoint slot.  IC_Angle (:78-105) over the 749-px disc of the
-// un-blurred level, rBRIEF (:109-148) on the blurred level, then output assembly (:1253-1294):
-// keypoints of all levels concatenated in level order, pt scaled by mvScaleFactor[level] for level>0,
-// plus mvKeyQualScore (Frame.cc:130-143) from level 0 of the cost pyramid.
+// k_describe: one workgroup = kDescKP keypoint slots (4 waves x kDescPW slots).  IC_Angle (:78-105) over the 749-px disc of
+// the un-blurred level, rBRIEF (:109-148) on the blurred level, then output assembly (:1253-1294): keypoints of all levels
+// concatenated in level order, pt scaled by mvScaleFactor[level] for level>0, plus mvKeyQualScore (Frame.cc:130-143) from
+// level 0 of the cost pyramid.
+// r01's one-wave-per-keypoint form was bound by memory LATENCY, not by instructions or bytes: a keypoint is two dependent
+// round trips (disc -> angle -> rotated samples) over ~68 distinct cache lines, and 32 waves per CU keep only 32 keypoints in
+// flight (292 us per 256 images; 184 us with every sample redirected to one cache line).  Here a wave owns kDescPW keypoints
+// and issues the loads of ALL of them before it consumes the first: 4 dword loads per keypoint for the disc (a lane reads 4
+// adjacent bytes of 4 rows; moments from v_dot4), 8 byte loads per keypoint for the samples.  Between the two phases the
+// per-keypoint scalars -- fastAtan2 and glibc's sincosf (~85 f64 instructions) -- are evaluated by ONE lane per keypoint
+// instead of redundantly by the 64 lanes of its wave.
 // ------------------------------------------------------------------------------------------------
+constexpr int kDescPW = 8, kDescKP = 4 * kDescPW;
 __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg, const uint8_t* __restrict__ pyr,
                                                  const uint8_t* __restrict__ blur, const uint8_t* __restrict__ qpyr,
                                                  const uint8_t* __restrict__ useCost,
@@ -1355,92 +1363,150 @@ __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg
                                                  uint8_t* __restrict__ desc, int* __restrict__ count,
                                                  float* __restrict__ quality, int nImg)
 {
-    // image i is described by XCD i % 8 only: a keypoint pulls ~68 cache lines out of its image's two pyramids (3.8 MB at
-    // 1242 x 375), which stay in that XCD's 4 MB L2 while its CUs walk the image
+    __shared__ int s_m10[kDescKP], s_m01[kDescKP], s_level[kDescKP], s_oi[kDescKP];      // s_level < 0: empty slot
+    __shared__ unsigned s_pos[kDescKP];
+    __shared__ float s_angle[kDescKP], s_a[kDescKP], s_b[kDescKP];
+    // image i is described by XCD i % 8 only (its two pyramids, 3.8 MB at 1242 x 375, stay in that XCD's L2)
     const int nf = cfg->nfeatures, nl = cfg->nlevels;
     int img, grp;
-    if (!xcd_tile_image((nf + 3) / 4, nImg, grp, img)) return;
-    const int slot = grp * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (slot >= nf) return;
-    int level = 0;
-    for (int l = 1; l < nl; l++) if (slot >= cfg->lv[l].kpBase) level = l;
-    const LevelGeom& G = cfg->lv[level];
-    const int k = slot - G.kpBase;
+    if (!xcd_tile_image((nf + kDescKP - 1) / kDescKP, nImg, grp, img)) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int* lc = lvlCount + img * kMaxLevels;
-    int before = 0, total = 0;
-    for (int l = 0; l < nl; l++) { const int c = lc[l]; if (l < level) before += c; total += c; }
-    if (slot == 0 && lane == 0) count[img] = total;
-    if (k >= lc[level]) return;
-    const unsigned pos = slotPos[(size_t)img * nf + slot];
-    const int px = pos & 0xffff, py = pos >> 16;
-    const uint8_t* P = pyr + (size_t)img * cfg->pyrBytes + G.off;
-    const uint8_t* B = blur + (size_t)img * cfg->pyrBytes + G.off;
-    const int pitch = G.pitch;
-
-    // IC_Angle: 31 rows, two rows per step (lanes 0-31 / 32-63), u = lane%32 - 15.  umax (ORBextractor.cc:458-475)
-    // depends only on HALF_PATCH_SIZE = 15, so it is a packed constant (4 bits per row; checked against the
-    // constructor's table on the host) and all 16 loads of a lane are independent and issued together.
-    int m10 = 0, m01 = 0;
+    // phase 0: slot -> (level, output index, position), one lane per slot
+    if (threadIdx.x < kDescKP) {
+        const int slot = grp * kDescKP + threadIdx.x;
+        int level = -1, oi = 0;
+        unsigned pos = 0;
+        if (slot < nf) {
+            int lv = 0;
+            for (int l = 1; l < nl; l++) if (slot >= cfg->lv[l].kpBase) lv = l;
+            int before = 0, total = 0;
+            for (int l = 0; l < nl; l++) { const int c = lc[l]; if (l < lv) before += c; total += c; }
+            if (slot == 0) count[img] = total;
+            const int k = slot - cfg->lv[lv].kpBase;
+            if (k < lc[lv]) { level = lv; oi = before + k; pos = slotPos[(size_t)img * nf + slot]; }
+        }
+        s_level[threadIdx.x] = level; s_oi[threadIdx.x] = oi; s_pos[threadIdx.x] = pos;
+    }
+    __syncthreads();
+    const uint8_t* Pimg = pyr + (size_t)img * cfg->pyrBytes;
+    const uint8_t* Bimg = blur + (size_t)img * cfg->pyrBytes;
+    // phase 1: IC_Angle.  umax (ORBextractor.cc:458-475) depends only on HALF_PATCH_SIZE = 15, so it is a packed constant
+    // (4 bits per row; checked against the constructor's table on the host).  Lane = 4 adjacent bytes (u0 .. u0+3,
+    // u0 = -15 + 4 (lane & 7)) of the rows v = -15 + (lane >> 3) + 8 q: sum b = dot4(bytes, 1), sum j b = dot4(bytes, (0,1,2,3)),
+    // m10 += u0 sum b + sum j b, m01 += v sum b (exact integers: the order of the sum is free).
     {
         const unsigned long long kUmax = 0x3689ABCDDEEEFFFFull;
-        const int u = (lane & 31) - 15;
-        const uint8_t* c0 = P + (size_t)py * pitch + px + u;
-        int val[16];
+        const int u0 = -15 + 4 * (lane & 7);
+        unsigned w4[kDescPW][4];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int v = -15 + 2 * r + (lane >> 5);
-            const int av = v < 0 ? -v : v;
-            const int d = (int)((kUmax >> (4 * (av & 15))) & 15);
-            const bool in = v <= 15 && u >= -d && u <= d && (lane & 31) < 31;
-            val[r] = in ? (int)c0[(ptrdiff_t)v * pitch] : 0;
+        for (int r = 0; r < kDescPW; r++) {
+            const int ls = wave * kDescPW + r;
+            const int level = s_level[ls];
+            const unsigned pos = s_pos[ls];
+#pragma unroll
+            for (int q = 0; q < 4; q++) w4[r][q] = 0;
+            if (level >= 0) {                                           // uniform per wave
+                const LevelGeom& G = cfg->lv[level];
+                const uint8_t* c0 = Pimg + G.off + (size_t)(pos >> 16) * G.pitch + (pos & 0xffff) + u0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int v = -15 + (lane >> 3) + 8 * q;
+                    if (v <= 15) __builtin_memcpy(&w4[r][q], c0 + (ptrdiff_t)v * G.pitch, 4);
+                }
+            }
         }
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int v = -15 + 2 * r + (lane >> 5);
-            m10 += u * val[r];
-            m01 += v * val[r];
+        for (int r = 0; r < kDescPW; r++) {
+            int m10 = 0, m01 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int v = -15 + (lane >> 3) + 8 * q;
+                const int av = v < 0 ? -v : v;
+                const int d = v <= 15 ? (int)((kUmax >> (4 * (av & 15))) & 15) : -1;      // |u| <= d inside the disc
+                unsigned mask = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const int u = u0 + j; if (u >= -d && u <= d) mask |= 0xffu << (8 * j); }
+                const unsigned bytes = w4[r][q] & mask;
+                const int sb = (int)__builtin_amdgcn_udot4(bytes, 0x01010101u, 0u, false);
+                const int sj = (int)__builtin_amdgcn_udot4(bytes, 0x03020100u, 0u, false);
+                m10 += u0 * sb + sj;
+                m01 += v * sb;
+            }
+            m10 = wave_sum_i32(m10);
+            m01 = wave_sum_i32(m01);
+            if (lane == 0) { s_m10[wave * kDescPW + r] = m10; s_m01[wave * kDescPW + r] = m01; }
         }
-        m10 = wave_sum_i32(m10);
-        m01 = wave_sum_i32(m01);
     }
-    const float angle = cfg->varAtan ? fast_atan2_legacy((float)m01, (float)m10) : fast_atan2((float)m01, (float)m10);
-
-    // rBRIEF: lane handles tests 4*lane .. 4*lane+3
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    float a, b;
-    sincosf_glibc(angle * factorPI, b, a);
+    __syncthreads();
+    // phase 2: angle, cos, sin -- one lane per keypoint
+    if (threadIdx.x < kDescKP && s_level[threadIdx.x] >= 0) {
+        const float m01 = (float)s_m01[threadIdx.x], m10 = (float)s_m10[threadIdx.x];
+        const float angle = cfg->varAtan ? fast_atan2_legacy(m01, m10) : fast_atan2(m01, m10);
+        const float factorPI = (float)(3.14159265358979323846 / 180.f);
+        float a, b;
+        sincosf_glibc(angle * factorPI, b, a);
+        s_angle[threadIdx.x] = angle; s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
+    }
+    __syncthreads();
+    // phase 3: rBRIEF (lane handles tests 4*lane .. 4*lane+3): the 8 samples of every keypoint of the wave first, then the bits
     const int4 pw = *(const int4*)(d_pattern + lane * 16);
     const int wv[4] = {pw.x, pw.y, pw.z, pw.w};
-    unsigned nib = 0;
+    uint8_t smp[kDescPW][8];
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const float x0 = (float)(int8_t)(wv[t] & 0xff), y0 = (float)(int8_t)((wv[t] >> 8) & 0xff);
-        const float x1 = (float)(int8_t)((wv[t] >> 16) & 0xff), y1 = (float)(int8_t)((wv[t] >> 24) & 0xff);
-        const int t0 = B[(size_t)(py + cv_round(x0 * b + y0 * a)) * pitch + px + cv_round(x0 * a - y0 * b)];
-        const int t1 = B[(size_t)(py + cv_round(x1 * b + y1 * a)) * pitch + px + cv_round(x1 * a - y1 * b)];
-        nib |= (unsigned)(t0 < t1) << t;
-    }
-    unsigned byte = nib | (__shfl_down(nib, 1, 64) << 4);          // valid on even lanes
-    unsigned w = byte | (__shfl_down(byte, 2, 64) << 8) | (__shfl_down(byte, 4, 64) << 16) | (__shfl_down(byte, 6, 64) << 24);
-    const int oi = before + k;
-    if ((lane & 7) == 0) *(unsigned*)(desc + ((size_t)img * nf + oi) * 32 + (lane >> 3) * 4) = w;
-    if (lane == 0) {
-        ivf_keypoint kp;
-        float fx = (float)px, fy = (float)py;
-        if (level != 0) { fx *= G.scale; fy *= G.scale; }
-        kp.x = fx; kp.y = fy; kp.size = (float)G.scaledPatch; kp.angle = angle;
-        kp.response = slotResp[(size_t)img * nf + slot]; kp.octave = level;
-        kps[(size_t)img * nf + oi] = kp;
-        float q = 1.0f;
-        if (useCost[img] & 2) {          // Frame.cc:130-143: whenever a cost image came with the frame, whatever the extractor flag
-            const int qx = (int)roundf(fx), qy = (int)roundf(fy);
-            const LevelGeom& G0 = cfg->lv[0];
-            const float cost = (float)qpyr[(size_t)img * cfg->pyrBytes + G0.off + (size_t)min(qy, G0.h - 1) * G0.pitch + min(qx, G0.w - 1)];
-            const float qs = (float)(1.0 / (1.0 + (double)(cost / 256)));
-            q = 2 * qs - 1;
+    for (int r = 0; r < kDescPW; r++) {
+        const int ls = wave * kDescPW + r;
+        const int level = s_level[ls];
+#pragma unroll
+        for (int t = 0; t < 8; t++) smp[r][t] = 0;
+        if (level >= 0) {
+            const LevelGeom& G = cfg->lv[level];
+            const unsigned pos = s_pos[ls];
+            const int px = pos & 0xffff, py = pos >> 16;
+            const uint8_t* B = Bimg + G.off;
+            const int pitch = G.pitch;
+            const float a = s_a[ls], b = s_b[ls];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const float x0 = (float)(int8_t)(wv[t] & 0xff), y0 = (float)(int8_t)((wv[t] >> 8) & 0xff);
+                const float x1 = (float)(int8_t)((wv[t] >> 16) & 0xff), y1 = (float)(int8_t)((wv[t] >> 24) & 0xff);
+                smp[r][2 * t] = B[(size_t)(py + cv_round(x0 * b + y0 * a)) * pitch + px + cv_round(x0 * a - y0 * b)];
+                smp[r][2 * t + 1] = B[(size_t)(py + cv_round(x1 * b + y1 * a)) * pitch + px + cv_round(x1 * a - y1 * b)];
+            }
         }
-        quality[(size_t)img * nf + oi] = q;
+    }
+#pragma unroll
+    for (int r = 0; r < kDescPW; r++) {
+        const int ls = wave * kDescPW + r;
+        const int level = s_level[ls];
+        if (level < 0) continue;
+        const LevelGeom& G = cfg->lv[level];
+        const unsigned pos = s_pos[ls];
+        const int px = pos & 0xffff, py = pos >> 16;
+        const int slot = grp * kDescKP + ls, oi = s_oi[ls];
+        unsigned nib = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) nib |= (unsigned)(smp[r][2 * t] < smp[r][2 * t + 1]) << t;
+        unsigned byte = nib | (__shfl_down(nib, 1, 64) << 4);          // valid on even lanes
+        unsigned w = byte | (__shfl_down(byte, 2, 64) << 8) | (__shfl_down(byte, 4, 64) << 16) | (__shfl_down(byte, 6, 64) << 24);
+        if ((lane & 7) == 0) *(unsigned*)(desc + ((size_t)img * nf + oi) * 32 + (lane >> 3) * 4) = w;
+        if (lane == 0) {
+            ivf_keypoint kp;
+            float fx = (float)px, fy = (float)py;
+            if (level != 0) { fx *= G.scale; fy *= G.scale; }
+            kp.x = fx; kp.y = fy; kp.size = (float)G.scaledPatch; kp.angle = s_angle[ls];
+            kp.response = slotResp[(size_t)img * nf + slot]; kp.octave = level;
+            kps[(size_t)img * nf + oi] = kp;
+            float q = 1.0f;
+            if (useCost[img] & 2) {          // Frame.cc:130-143: whenever a cost image came with the frame, whatever the extractor flag
+                const int qx = (int)roundf(fx), qy = (int)roundf(fy);
+                const LevelGeom& G0 = cfg->lv[0];
+                const float cost = (float)qpyr[(size_t)img * cfg->pyrBytes + G0.off + (size_t)min(qy, G0.h - 1) * G0.pitch + min(qx, G0.w - 1)];
+                const float qs = (float)(1.0 / (1.0 + (double)(cost / 256)));
+                q = 2 * qs - 1;
+            }
+            quality[(size_t)img * nf + oi] = q;
+        }
     }
 }
 
@@ -1720,7 +1786,7 @@ void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nIm
 void launch_describe(const Config& hc, const Config* dc, const Buffers& b, const uint8_t*, size_t, int, int nImg, int,
                      hipStream_t s)
 {
-    hipLaunchKernelGGL(k_describe, dim3((nImg + 7) / 8 * 8 * ((hc.nfeatures + 3) / 4)), dim3(256), 0, s, dc, b.pyr, b.blur, b.qpyr,
+    hipLaunchKernelGGL(k_describe, dim3((nImg + 7) / 8 * 8 * ((hc.nfeatures + kDescKP - 1) / kDescKP)), dim3(256), 0, s, dc, b.pyr, b.blur, b.qpyr,
                        b.useCost, b.slotPos, b.slotResp, b.lvlCount, b.kps, b.desc, b.count, b.quality, nImg);
 }
 void launch_stereo_args(const Config& hc, const Config* dc, const StereoArgs& A, int nPairs, hipStream_t s)
