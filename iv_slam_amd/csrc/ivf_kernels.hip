@@ -566,8 +566,9 @@ __global__ __launch_bounds__(256) void k_blur7(const Config* __restrict__ cfg, c
                                               const int* __restrict__ lvlCount, uint8_t* __restrict__ blur, int nImg)
 {
     constexpr int RQ = (kBlurTW + 8) / 4, RH = kBlurTH + 6, HQ = kBlurTW / 4;     // 34 dwords x 38 rows raw; 32 quads per row
+    static_assert(RH % 2 == 0 && HQ == 32 && kBlurTH == 32, "row pairs, 32 quads x 8 row groups");
     __shared__ unsigned raw[RH * RQ];
-    __shared__ __attribute__((aligned(8))) uint2 hp[RH * HQ];                     // 4 x u16 per quad
+    __shared__ __attribute__((aligned(16))) uint4 hp[(RH / 2) * HQ];              // per quad: 4 x (row 2p | row 2p+1 << 16), u16 each
     int img, bx;
     if (!xcd_tile_image(cfg->nBlurTiles, nImg, bx, img)) return;
     int level = 0;
@@ -584,17 +585,19 @@ __global__ __launch_bounds__(256) void k_blur7(const Config* __restrict__ cfg, c
     const int gw = G.w, gh = G.h, pitch = G.pitch;
     if (gw >= 8 && gh >= 8) {
         // the usual case: a tap leaves the plane by at most 3 (rows) / 7 (the dword past the right edge) pixels, so ONE
-        // reflection is enough -- closed form, no loops; all of a thread's loads are issued before the first LDS store
-        constexpr int IT = (RH * RQ + 255) / 256;
+        // reflection is enough -- closed form, no loops; all of a thread's loads are issued before the first LDS store.
+        // Thread = raw column dword (tid % 34) x rows (tid / 34) + 7 k: one division per thread, not one per dword.
+        constexpr int RPP = 256 / RQ, IT = (RH + RPP - 1) / RPP;     // 7 rows per pass, 6 passes
+        const int rq = tid % RQ, r0 = tid / RQ;
+        const int gx = x0 - 4 + 4 * rq;
+        const bool inner = gx >= 0 && gx + 3 < gw;
         unsigned v[IT];
 #pragma unroll
         for (int k = 0; k < IT; k++) {
-            const int i = min(tid + 256 * k, RH * RQ - 1);
-            const int ry = i / RQ, rq = i % RQ;
+            const int ry = min(r0 + RPP * k, RH - 1);
             int gy = y0 - 3 + ry; gy = gy < 0 ? -gy : gy; gy = gy >= gh ? 2 * (gh - 1) - gy : gy; gy = max(gy, 0);
-            const int gx = x0 - 4 + 4 * rq;
             const uint8_t* row = src + (size_t)gy * pitch;
-            if (gx >= 0 && gx + 3 < gw) v[k] = *(const unsigned*)(row + gx);
+            if (inner) v[k] = *(const unsigned*)(row + gx);
             else {                                                   // first / last dword of an edge tile: bytes, reflected
                 unsigned w = 0;
 #pragma unroll
@@ -606,7 +609,7 @@ __global__ __launch_bounds__(256) void k_blur7(const Config* __restrict__ cfg, c
             }
         }
 #pragma unroll
-        for (int k = 0; k < IT; k++) if (tid + 256 * k < RH * RQ) raw[tid + 256 * k] = v[k];
+        for (int k = 0; k < IT; k++) if (r0 < RPP && r0 + RPP * k < RH) raw[(r0 + RPP * k) * RQ + rq] = v[k];
     } else {
         for (int i = tid; i < RH * RQ; i += 256) {                   // tiny planes: general reflection
             const int ry = i / RQ, rq = i % RQ;
@@ -622,46 +625,51 @@ __global__ __launch_bounds__(256) void k_blur7(const Config* __restrict__ cfg, c
     // coefficients as bytes: taps -3..0 and +1..+3 (A-4 table or its <= 3.4.1 form)
     const unsigned k2 = cfg->varBlur ? 49u : 48u, k3 = cfg->varBlur ? 55u : 56u;
     const unsigned K1 = 18u | (34u << 8) | (k2 << 16) | (k3 << 24), K2 = k2 | (34u << 8) | (18u << 16);
-    for (int i = tid; i < RH * HQ; i += 256) {
-        const int ry = i / HQ, q = i % HQ;
-        const unsigned w0 = raw[ry * RQ + q], w1 = raw[ry * RQ + q + 1], w2 = raw[ry * RQ + q + 2];   // pixels x-4.., x.., x+4.. (x = x0 + 4q)
-        unsigned h[4];
-        h[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), K2, 0u, false), false);
-        h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), K2, 0u, false), false);
-        h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), K2, 0u, false), false);
-        h[3] = __builtin_amdgcn_udot4(w1, K1, __builtin_amdgcn_udot4(w2, K2, 0u, false), false);
-        hp[i] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    // horizontal pass: item = (row pair, quad); results of the two rows packed per column for the vertical pass's v_dot2
+    for (int i = tid; i < (RH / 2) * HQ; i += 256) {
+        const int p = i / HQ, q = i % HQ;
+        unsigned h[2][4];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const unsigned* rp = raw + (2 * p + rr) * RQ + q;
+            const unsigned w0 = rp[0], w1 = rp[1], w2 = rp[2];   // pixels x-4.., x.., x+4.. (x = x0 + 4q)
+            h[rr][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), K2, 0u, false), false);
+            h[rr][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), K2, 0u, false), false);
+            h[rr][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), K2, 0u, false), false);
+            h[rr][3] = __builtin_amdgcn_udot4(w1, K1, __builtin_amdgcn_udot4(w2, K2, 0u, false), false);
+        }
+        hp[i] = make_uint4(h[0][0] | (h[1][0] << 16), h[0][1] | (h[1][1] << 16), h[0][2] | (h[1][2] << 16), h[0][3] | (h[1][3] << 16));
     }
     __syncthreads();
-    // vertical pass: thread = quad q (4 columns) x 4 consecutive output rows
+    // vertical pass: thread = quad q (4 columns) x 4 consecutive output rows oy0 .. oy0+3 = hp rows oy0 .. oy0+9 = 5 row pairs.
+    // Output row oy0 + r reads hp rows oy0+r .. oy0+r+6: for even r the pairs (k0,k1)(k2,k3)(k4,k5)(k6,0) from pair r/2 on, for
+    // odd r (0,k0)(k1,k2)(k3,k4)(k5,k6) from pair (r-1)/2 on -- 4 v_dot2_u32_u16 per pixel instead of 7 multiply-adds.
     uint8_t* dst = blur + (size_t)img * cfg->pyrBytes + G.off;
     {
         const int q = tid & (HQ - 1), rg = tid / HQ;                    // 32 quads x 8 row groups = 256 threads
         const int oy0 = 4 * rg;
-        const unsigned kw[7] = {18, 34, k2, k3, k2, 34, 18};
-        unsigned acc[4][4];
+        const unsigned KE[4] = {18u | (34u << 16), k2 | (k3 << 16), k2 | (34u << 16), 18u};
+        const unsigned KO[4] = {18u << 16, 34u | (k2 << 16), k3 | (k2 << 16), 34u | (18u << 16)};
+        uint4 P[5];
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-            for (int k = 0; k < 4; k++) acc[r][k] = 32768u;
-#pragma unroll
-        for (int rr = 0; rr < 10; rr++) {                               // hp rows oy0 .. oy0+9 feed output rows oy0 .. oy0+3
-            const uint2 v = hp[(oy0 + rr) * HQ + q];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int tap = rr - r;                                 // output row oy0 + r uses hp rows oy0+r .. oy0+r+6
-                if (tap < 0 || tap > 6) continue;
-                acc[r][0] = mad_u16_lo(v.x, kw[tap], acc[r][0]); acc[r][1] = mad_u16_hi(v.x, kw[tap], acc[r][1]);
-                acc[r][2] = mad_u16_lo(v.y, kw[tap], acc[r][2]); acc[r][3] = mad_u16_hi(v.y, kw[tap], acc[r][3]);
-            }
-        }
+        for (int j = 0; j < 5; j++) P[j] = hp[(2 * rg + j) * HQ + q];
         if (x0 + 4 * q < G.pitch) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int y = y0 + oy0 + r;
                 if (y >= G.h) break;
+                unsigned acc[4] = {32768u, 32768u, 32768u, 32768u};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint4 pj = P[(r >> 1) + j];
+                    const unsigned kk = (r & 1) ? KO[j] : KE[j];
+                    acc[0] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pj.x), __builtin_bit_cast(u16x2, kk), acc[0], false);
+                    acc[1] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pj.y), __builtin_bit_cast(u16x2, kk), acc[1], false);
+                    acc[2] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pj.z), __builtin_bit_cast(u16x2, kk), acc[2], false);
+                    acc[3] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pj.w), __builtin_bit_cast(u16x2, kk), acc[3], false);
+                }
                 // (acc >> 16) saturated to 255: clamp to 0x00ffffff, then byte 2 of each sum
-                const unsigned a0 = min(acc[r][0], 0xffffffu), a1 = min(acc[r][1], 0xffffffu), a2 = min(acc[r][2], 0xffffffu), a3 = min(acc[r][3], 0xffffffu);
+                const unsigned a0 = min(acc[0], 0xffffffu), a1 = min(acc[1], 0xffffffu), a2 = min(acc[2], 0xffffffu), a3 = min(acc[3], 0xffffffu);
                 const unsigned lo = __builtin_amdgcn_perm(a1, a0, 0x0c0c0602u), hi = __builtin_amdgcn_perm(a3, a2, 0x06020c0cu);
                 *(unsigned*)(dst + (size_t)y * G.pitch + x0 + 4 * q) = lo | hi;
             }
