@@ -351,16 +351,21 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
 
     // 1. raw tile: rows y0-4 .. y0+TH+3, cols x0-4 .. x0+TW+3 (x0-4 is a multiple of 4).  Branch-free clamped
     // addresses so the loads of a thread are all in flight together; out-of-plane dwords are zeroed afterwards.
-    constexpr int kRawN = (kFastTH + 8) * (kRawP / 4), kRawIt = (kRawN + 255) / 256;
+    // thread = raw column dword (tid % 34) x rows (tid / 34) + 7 k: one division per thread instead of one per dword
+    constexpr int kRawQ = kRawP / 4, kRawRPP = 256 / kRawQ, kRawIt = (kFastTH + 8 + kRawRPP - 1) / kRawRPP;
+    const int rawQ = tid % kRawQ, rawR = tid / kRawQ;
     unsigned rv_[kRawIt];
     bool rok[kRawIt];
+    {
+        const int gx = x0 - 4 + 4 * rawQ;
+        const bool colOk = rawR < kRawRPP && gx < G.pitch;
 #pragma unroll
-    for (int k = 0; k < kRawIt; k++) {
-        const int i = tid + 256 * k;
-        const int ry = i / (kRawP / 4), rx4 = (i % (kRawP / 4)) * 4;
-        const int gy = y0 - 4 + ry, gx = x0 - 4 + rx4;
-        rok[k] = i < kRawN && gy < G.h && gx < G.pitch;        // gy >= 0: y0 >= kEdge
-        rv_[k] = *(const unsigned*)(src + (size_t)(rok[k] ? gy : 0) * G.pitch + (rok[k] ? gx : 0));
+        for (int k = 0; k < kRawIt; k++) {
+            const int ry = rawR + kRawRPP * k;
+            const int gy = y0 - 4 + ry;
+            rok[k] = colOk && ry < kFastTH + 8 && gy < G.h;        // gy >= 0: y0 >= kEdge
+            rv_[k] = *(const unsigned*)(src + (size_t)(rok[k] ? gy : 0) * G.pitch + (rok[k] ? gx : 0));
+        }
     }
     const int mode = (cfg->introspection && (useC & 1u)) ? 1 : 0;
     const int domHm = mode ? G.domH[1] : G.domH[0];
@@ -386,7 +391,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
         rowInfo[tid - 192] = f;
     }
 #pragma unroll
-    for (int k = 0; k < kRawIt; k++) if (tid + 256 * k < kRawN) raw[tid + 256 * k] = rok[k] ? rv_[k] : 0u;
+    for (int k = 0; k < kRawIt; k++)
+        if (rawR < kRawRPP && rawR + kRawRPP * k < kFastTH + 8) raw[(rawR + kRawRPP * k) * kRawQ + rawQ] = rok[k] ? rv_[k] : 0u;
     if (ablate & 32) return;
     __syncthreads();
     // 2. scores, four pixels (two packed pairs) per step sharing the three aligned dwords of each of the 7 rows:
