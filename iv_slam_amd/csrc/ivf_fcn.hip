@@ -74,12 +74,30 @@ __global__ void k_fcn_prep(const uint8_t* __restrict__ bgr, size_t imageStride, 
     // (r01: 80 VALU lane-instructions per output element, VALU-bound)
     const uint8_t *p00 = I + (size_t)y0 * rowStride + x0 * 3, *p01 = I + (size_t)y0 * rowStride + x1 * 3;
     const uint8_t *p10 = I + (size_t)y1 * rowStride + x0 * 3, *p11 = I + (size_t)y1 * rowStride + x1 * 3;
+    // r02: twelve single-byte gathers per element made this kernel address-rate-bound (4 lane addresses per clock and CU).  The
+    // two taps of a row are 6 adjacent bytes (B G R B G R) whenever x1 = x0 + 1: two unaligned dword loads per row, except in
+    // the last columns, where the second dword would run past the row
+    unsigned t0[3], t1[3], b0[3], b1[3];            // taps (row, column) per colour byte
+    if (x0 + 3 <= w - 1) {
+        unsigned a0, a1, c0, c1;
+        __builtin_memcpy(&a0, p00, 4); __builtin_memcpy(&a1, p00 + 4, 4);
+        __builtin_memcpy(&c0, p10, 4); __builtin_memcpy(&c1, p10 + 4, 4);
+        const unsigned a01 = __builtin_amdgcn_alignbyte(a1, a0, 3), c01 = __builtin_amdgcn_alignbyte(c1, c0, 3);   // bytes 3 .. 6
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            t0[k] = (a0 >> (8 * k)) & 0xffu; t1[k] = (a01 >> (8 * k)) & 0xffu;
+            b0[k] = (c0 >> (8 * k)) & 0xffu; b1[k] = (c01 >> (8 * k)) & 0xffu;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { t0[k] = p00[k]; t1[k] = p01[k]; b0[k] = p10[k]; b1[k] = p11[k]; }
+    }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const int sc = 2 - c;                       // BGR -> RGB
-        auto nz = [&](const uint8_t* q) { return ((float)q[sc] * (1.0f / 255.0f) - mean[c]) * istd[c]; };
-        const float top = nz(p00) * lx0 + nz(p01) * lx1;
-        const float bot = nz(p10) * lx0 + nz(p11) * lx1;
+        auto nz = [&](unsigned q) { return ((float)q * (1.0f / 255.0f) - mean[c]) * istd[c]; };
+        const float top = nz(t0[sc]) * lx0 + nz(t1[sc]) * lx1;
+        const float bot = nz(b0[sc]) * lx0 + nz(b1[sc]) * lx1;
         out[(((size_t)b * 3 + c) * kEnc + y) * kEnc + x] = top * ly0 + bot * ly1;
     }
 }
@@ -1779,28 +1797,51 @@ __global__ void k_fcn_last(const float* __restrict__ X, const float* __restrict_
 }
 
 // ---- bilinear to out_size, logistic, u8 truncation (models_light.py:198-199, :25-26; stereo_kitti.cc:511) ----
-__global__ void k_fcn_out(const float* __restrict__ L, int lh, int lw, int oh, int ow, float* __restrict__ costF,
-                          uint8_t* __restrict__ costU)
+__global__ __launch_bounds__(256) void k_fcn_out(const float* __restrict__ L, int lh, int lw, int oh, int ow, float sy_, float sx_,
+                                                float* __restrict__ costF, uint8_t* __restrict__ costU)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
-    if (x >= ow) return;
-    const float sy_ = (float)lh / (float)oh, sx_ = (float)lw / (float)ow;
+    // a workgroup = 1024 pixels of one output row (4 adjacent pixels per thread): they all read the same two logit rows, which
+    // go through LDS once.  sy_ = (float)lh / (float)oh and sx_ come from the host (the same IEEE f32 quotient, computed once
+    // instead of by two division sequences per thread); the u8 map leaves as one dword per thread where the row allows it.
+    // r01 / early r02: 88 VALU lane-instructions per output pixel.
+    __shared__ float rowT[kEnc / 8], rowB[kEnc / 8];
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y, b = blockIdx.z;
     float fy = sy_ * ((float)y + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
-    float fx = sx_ * ((float)x + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
     int y0 = (int)fy; if (y0 > lh - 1) y0 = lh - 1;
-    int x0 = (int)fx; if (x0 > lw - 1) x0 = lw - 1;
-    const int y1 = y0 + (y0 < lh - 1), x1 = x0 + (x0 < lw - 1);
-    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+    const int y1 = y0 + (y0 < lh - 1);
     const float* P = L + (size_t)b * lh * lw;
-    const float top = P[y0 * lw + x0] * lx0 + P[y0 * lw + x1] * lx1;
-    const float bot = P[y1 * lw + x0] * lx0 + P[y1 * lw + x1] * lx1;
-    const float v = top * ly0 + bot * ly1;
-    const float z = 20.f * (v - 0.5f);
-    // logistic through the hardware exp2 / rcp (1 ulp each; the libm expf + IEEE division were most of this kernel's instructions)
-    const float c = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-z * 1.44269504088896341f));
-    const size_t o = ((size_t)b * oh + y) * ow + x;
-    if (costF) costF[o] = c;
-    if (costU) costU[o] = (uint8_t)(c * 255.0f);
+    if ((int)threadIdx.x < lw) rowT[threadIdx.x] = P[y0 * lw + threadIdx.x];
+    else if ((int)threadIdx.x < 2 * lw) rowB[threadIdx.x - lw] = P[y1 * lw + threadIdx.x - lw];
+    __syncthreads();
+    if (x4 >= ow) return;
+    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+    float c[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = x4 + k;
+        float fx = sx_ * ((float)x + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
+        int x0 = (int)fx; if (x0 > lw - 1) x0 = lw - 1;
+        const int x1 = x0 + (x0 < lw - 1);
+        const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+        const float top = rowT[x0] * lx0 + rowT[x1] * lx1;
+        const float bot = rowB[x0] * lx0 + rowB[x1] * lx1;
+        const float v = top * ly0 + bot * ly1;
+        const float z = 20.f * (v - 0.5f);
+        // logistic through the hardware exp2 / rcp (1 ulp each; the libm expf + IEEE division were most of this kernel's instructions)
+        c[k] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-z * 1.44269504088896341f));
+    }
+    const size_t o = ((size_t)b * oh + y) * ow + x4;
+    const int nv = min(4, ow - x4);
+    if (costF) {
+        if (nv == 4 && (o & 3) == 0) *(float4*)(costF + o) = make_float4(c[0], c[1], c[2], c[3]);
+        else for (int k = 0; k < nv; k++) costF[o + k] = c[k];
+    }
+    if (costU) {
+        const unsigned u0 = (unsigned)(uint8_t)(c[0] * 255.0f), u1 = (unsigned)(uint8_t)(c[1] * 255.0f),
+                       u2 = (unsigned)(uint8_t)(c[2] * 255.0f), u3 = (unsigned)(uint8_t)(c[3] * 255.0f);
+        if (nv == 4 && (o & 3) == 0) *(unsigned*)(costU + o) = u0 | (u1 << 8) | (u2 << 16) | (u3 << 24);
+        else { const unsigned u[4] = {u0, u1, u2, u3}; for (int k = 0; k < nv; k++) costU[o + k] = (uint8_t)u[k]; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2223,7 +2264,8 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
     hipLaunchKernelGGL(k_fcn_last, dim3((H * W + 255) / 256, n), dim3(256), 0, s, f->bufH1, f->dLastW, f->lastBias,
                        f->bufLogits, 80, H * W);
     STAGE("conv_last");
-    hipLaunchKernelGGL(k_fcn_out, dim3((f->outW + 255) / 256, f->outH, n), dim3(256), 0, s, f->bufLogits, H, W, f->outH, f->outW, dF, dU8);
+    hipLaunchKernelGGL(k_fcn_out, dim3((f->outW + 1023) / 1024, f->outH, n), dim3(256), 0, s, f->bufLogits, H, W, f->outH, f->outW,
+                       (float)H / (float)f->outH, (float)W / (float)f->outW, dF, dU8);
     FHIP(hipGetLastError());
     return IVF_OK;
 }
