@@ -978,7 +978,8 @@ __global__ __launch_bounds__(256) void k_fcn_conv3x3(const float* __restrict__ X
 template <int NT>
 __global__ __launch_bounds__(256, 1) void k_fcn_conv3x3_all(const float* __restrict__ X, const uint4* __restrict__ Wq,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           float* __restrict__ Y, int Cin, int Cout)
+                                                           float* __restrict__ Y, int Cin, int Cout,
+                                                           const float* __restrict__ lastW, float lastBias, float* __restrict__ logits)
 {
     constexpr int HW = 64 * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kg = lane >> 5, col = lane & 31;
@@ -1071,6 +1072,39 @@ __global__ __launch_bounds__(256, 1) void k_fcn_conv3x3_all(const float* __restr
         __builtin_amdgcn_sched_barrier(0);
         load_x(SQ);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if (lastW) {
+        // decoder: conv_last (1x1, Cout -> 1, + bias; models_light.py:196) folded into the epilogue.  A lane holds 16 channels per
+        // tile of its 4 pixels; the other 16 sit in lane ^ 32: the Cout-channel map (1.3 MB per image written and read back) and
+        // the k_fcn_last launch disappear
+        float lg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            const int cb = n * 32 + 4 * kg;
+            float4 sc4[4], sh4[4], lw4[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                sc4[g4] = *(const float4*)(scale + cb + 8 * g4); sh4[g4] = *(const float4*)(shift + cb + 8 * g4);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {                           // lastW holds Cout entries only
+                    const int ch = cb + 8 * g4 + i;
+                    (&lw4[g4].x)[i] = ch < Cout ? lastW[ch] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                if (cb + ro >= Cout) continue;
+                const float sc = vget<4>(sc4[r >> 2], r & 3), sh = vget<4>(sh4[r >> 2], r & 3), lw = vget<4>(lw4[r >> 2], r & 3);
+#pragma unroll
+                for (int p = 0; p < 4; p++) lg[p] += lw * fmaxf(acc[n][p][r] * sc + sh, 0.f);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) lg[p] += __shfl_xor(lg[p], 32, 64);
+        if (kg == 0)
+            *(float4*)(logits + (size_t)b * HW + y * 64 + x) = make_float4(lg[0] + lastBias, lg[1] + lastBias, lg[2] + lastBias, lg[3] + lastBias);
+        return;
     }
 #pragma unroll
     for (int n = 0; n < NT; n++) {
@@ -1930,7 +1964,8 @@ void launch_gemm(const Gemm& g, const float* X, const float* res, float* Y, int 
         static const bool old9 = getenv("IVF_FCN_OLD3X3") != nullptr;
         static const bool split9 = getenv("IVF_FCN_3X3_SPLIT") != nullptr;      // the r01 kernel: one workgroup per output-channel tile
         if (!old9 && !split9 && H == 64 && W == 64 && g.cin % 32 == 0 && g.act == 2 && !res && g.nTiles == 3)
-            hipLaunchKernelGGL((k_fcn_conv3x3_all<3>), dim3(8 * B), dim3(256), 0, s, X, g.dWq, g.dScale, g.dShift, Y, g.cin, g.cout);
+            hipLaunchKernelGGL((k_fcn_conv3x3_all<3>), dim3(8 * B), dim3(256), 0, s, X, g.dWq, g.dScale, g.dShift, Y, g.cin, g.cout,
+                               (const float*)nullptr, 0.f, (float*)nullptr);
         else if (!old9 && H == 64 && W == 64 && g.cin % 32 == 0 && g.act == 2 && !res)
             hipLaunchKernelGGL(k_fcn_conv3x3, dim3(8 * g.nTiles * B), dim3(256), 0, s, X, g.dWq, g.dScale, g.dShift, Y, g.cin, g.cout, g.nTiles);
         else launch_gemm_t<1, 3, 9>(g, X, res, Y, H, W, B, s);
@@ -2259,11 +2294,23 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
         snprintf(nm, sizeof nm, "block %d project", i + 1); STAGE(nm);
         std::swap(x, y);
     }
-    launch_gemm(f->pw[ip++], x, nullptr, f->bufH1, H, W, n, s);                 // decoder cbr: 3x3 320->80 + BN + ReLU
-    STAGE("decoder cbr");
-    hipLaunchKernelGGL(k_fcn_last, dim3((H * W + 255) / 256, n), dim3(256), 0, s, f->bufH1, f->dLastW, f->lastBias,
-                       f->bufLogits, 80, H * W);
-    STAGE("conv_last");
+    {
+        // decoder cbr (3x3 320->80 + BN + ReLU) and conv_last: one kernel when the all-tiles 3x3 kernel applies
+        const Gemm& g = f->pw[ip++];
+        static const bool fuseLast = getenv("IVF_FCN_NOFUSELAST") == nullptr && getenv("IVF_FCN_OLD3X3") == nullptr &&
+                                     getenv("IVF_FCN_3X3_SPLIT") == nullptr;
+        if (fuseLast && g.taps == 9 && H == 64 && W == 64 && g.cin % 32 == 0 && g.act == 2 && g.nTiles == 3) {
+            hipLaunchKernelGGL((k_fcn_conv3x3_all<3>), dim3(8 * n), dim3(256), 0, s, x, g.dWq, g.dScale, g.dShift, f->bufH1, g.cin, g.cout,
+                               (const float*)f->dLastW, f->lastBias, f->bufLogits);
+            STAGE("decoder cbr + conv_last");
+        } else {
+            launch_gemm(g, x, nullptr, f->bufH1, H, W, n, s);
+            STAGE("decoder cbr");
+            hipLaunchKernelGGL(k_fcn_last, dim3((H * W + 255) / 256, n), dim3(256), 0, s, f->bufH1, f->dLastW, f->lastBias,
+                               f->bufLogits, 80, H * W);
+            STAGE("conv_last");
+        }
+    }
     hipLaunchKernelGGL(k_fcn_out, dim3((f->outW + 1023) / 1024, f->outH, n), dim3(256), 0, s, f->bufLogits, H, W, f->outH, f->outW,
                        (float)H / (float)f->outH, (float)W / (float)f->outW, dF, dU8);
     FHIP(hipGetLastError());

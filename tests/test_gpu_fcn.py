@@ -122,8 +122,10 @@ print("OK %.3g" % err)
     # k_fcn_dwpw with workgroups of four image rows (eight waves) on every 64 x 64 shape / on none (default: <= 2 output tiles)
     {"IVF_FCN_NW": "8", "IVF_FCN_DWPW8": "0", "IVF_FCN_NODWPW10": "1"},
     {"IVF_FCN_NW": "4"},
+    # conv_last as its own kernel after the decoder 3x3 (default: folded into its epilogue)
+    {"IVF_FCN_NOFUSELAST": "1"},
 ], ids=["default", "layerwise", "expand-pxt2", "dwpw-256", "no-stride2-fusion", "no-stem-fusion", "irb-blocks-2-11",
-        "irb-none", "dwpw8-all", "dwpw8-none", "dwpw-4rows-all", "dwpw-4rows-none"])
+        "irb-none", "dwpw8-all", "dwpw8-none", "dwpw-4rows-all", "dwpw-4rows-none", "conv-last-unfused"])
 def test_fcn_kernel_variants_match_goldens_and_are_deterministic(env):
     """The FCN picks between several kernels per layer (measured defaults, env overrides for tuning).  Every variant must
     meet the same bar, batch results must not depend on the batch slot, and repeated runs must be bit-identical (this is
