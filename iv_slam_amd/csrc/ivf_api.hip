@@ -149,7 +149,8 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
         // as a cost map comes with the image.  A per-call extractor with introspection on is therefore accepted and checked
         // per call; stereo contexts hold a non-introspective right side and are rejected here.
         const bool colsLeave = (G.cols - 1) * G.cellW > W, rowsLeave = (G.rows - 1) * G.cellH > H;
-        const bool lastRowEmpty = H - (G.rows - 1) * G.cellH + 6 <= 0;    // hY <= 0 in the last row: stale non-positive height, rowRange throws
+        const bool lastRowEmpty = H - (G.rows - 1) * G.cellH + 6 < 0;     // hY < 0 in the last row: stale negative height, rowRange throws
+                                                                          // (hY == 0: empty windows, the level yields nothing -- k_quota)
         if (colsLeave || (rowsLeave && (!(introspection && sides == 1) || lastRowEmpty)))
             return fail(IVF_E_GEOMETRY, "level %d: %dx%d cells of %dx%d leave the %dx%d level", l, G.cols, G.rows,
                         G.cellW, G.cellH, G.w, G.h);

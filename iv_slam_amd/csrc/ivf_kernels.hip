@@ -955,6 +955,13 @@ __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, c
     const int nCells = G.nCells, cols = G.cols, rows = G.rows;
     const int* cnt = cellCnt + ((size_t)img * cfg->nCellsTotal + G.cellBase) * 2;
     CellInfo* ci = cellInfo + (size_t)img * cfg->nCellsTotal + G.cellBase;
+    if (mode && G.winHLast <= 0) {
+        // the last cell row starts exactly at the bottom border: its hY is 0, the row is skipped (:953-954) and the stale hY
+        // makes every other window of the level empty too -- the level yields nothing (accepted geometry, Context::build)
+        for (int c = tid; c < nCells; c += 256) ci[c] = CellInfo{0, 0, 0, 0};
+        if (tid == 0) lvlTotal[img * kMaxLevels + level] = 0;
+        return;
+    }
     for (int c = tid; c < nCells; c += 256) {
         s_nMin[c] = cnt[2 * c]; s_nIni[c] = cnt[2 * c + 1];
         s_qsum[c] = mode ? (unsigned)ci[c].nTotal : 0u;       // window sums from k_cell_qsum
