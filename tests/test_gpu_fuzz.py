@@ -174,3 +174,21 @@ def test_window_searches_random_scenarios(iv, seed):
         ga, gn = f.SearchByProjectionMapPoints(qm, ratio, pre)
         oa, on = O.search_map_points(kps, desc, uright, bounds, qm, ratio, pre)
         assert gn == on and np.array_equal(ga, oa), what
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IVF_FUZZ_ALLSEARCH", "3"))))
+def test_remaining_searches_random_scenarios(iv, seed):
+    """SearchForInitialization, ComputeDistinctiveDescriptors, SearchByProjection(KF, Scw), Fuse x2, SearchBySim3, SearchByBoW x2,
+    SearchForTriangulation and the relocalisation search on two-frame scenarios of random size / feature count / seed: equality
+    with the oracle only (the yield checks belong to the fixed scenario of tests/test_gpu_parity.py)."""
+    import test_gpu_parity as TP
+    from iv_slam_amd._lib import IvfError
+    rng = np.random.default_rng(5000 + seed)
+    for _ in range(40):
+        w = int(rng.integers(160, 1300)); h = int(rng.integers(120, 500)); n = int(rng.choice([100, 400, 800, 2000]))
+        try:
+            if TP.all_searches_scenario(iv, 6000 + seed, w, h, n, 40 + seed, False):
+                return
+        except IvfError as e:
+            assert e.code == IVF_E_GEOMETRY
+    raise AssertionError("no usable scenario in 40 draws")

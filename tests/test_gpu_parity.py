@@ -257,10 +257,15 @@ def test_hamming_pairs_and_search_by_projection(iv):
 def test_search_for_initialization_and_distinctive_descriptor(iv):
     """SearchForInitialization (ORBmatcher.cc:410-519) and the core of
     MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:247-312), HIP path vs oracle on the same inputs."""
-    rng = np.random.default_rng(91)
-    w, h = 640, 240
-    g = iv.ORBextractor(800, 1.2, 8, 20, 7)
-    k1, d1 = g(synth.make_left(w, h, seed=52, idx=0))
+    all_searches_scenario(iv, 91, 640, 240, 800, 52, True)
+
+
+def all_searches_scenario(iv, seed, w, h, nfeat, img_seed, strict):
+    """every remaining ORBmatcher search on one two-frame scenario; `strict` adds the yield checks that hold for the 640 x 240
+    default scenario (tests/test_gpu_fuzz.py calls this with random sizes and seeds, equality checks only)"""
+    rng = np.random.default_rng(seed)
+    g = iv.ORBextractor(nfeat, 1.2, 8, 20, 7)
+    k1, d1 = g(synth.make_left(w, h, seed=img_seed, idx=0))
     # second frame = the first displaced by a few pixels, descriptors with a few flipped bits, order shuffled
     perm = rng.permutation(len(k1))
     k2 = k1[perm].copy(); d2 = d1[perm].copy()
@@ -271,6 +276,8 @@ def test_search_for_initialization_and_distinctive_descriptor(iv):
             d2[i, bpos // 8] ^= np.uint8(1 << (bpos % 8))
     prev = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32)
     bounds = (0.0, 0.0, float(w), float(h))
+    if len(k1) < 8:
+        return False                                      # too few keypoints for a scenario (random sizes only)
     total = 0
     for ratio, ori, win in [(0.9, True, 10), (0.9, False, 10), (0.6, True, 25), (1.0, True, 100), (0.9, True, 0)]:
         m = iv.ORBmatcher(ratio, ori)
@@ -278,7 +285,7 @@ def test_search_for_initialization_and_distinctive_descriptor(iv):
         om, op, on = O.search_for_initialization(k1, d1, k2, d2, bounds, prev, win, ratio, ori)
         assert gn == on and np.array_equal(gm, om) and gp.tobytes() == op.tobytes()
         total += gn
-    assert total > 300
+    assert not strict or total > 300
     # empty frames
     gm, gp, gn = iv.ORBmatcher(0.9, True).SearchForInitialization(k1[:0], d1[:0], k2, d2, bounds, prev[:0], 10)
     assert gn == 0 and len(gm) == 0
@@ -307,11 +314,11 @@ def test_search_for_initialization_and_distinctive_descriptor(iv):
     m = iv.ORBmatcher(0.75, True)
     gm, gn = m.SearchByProjectionKeyFrame(k2, d2, bounds, q, pre)
     om, on = O.search_keyframe_points(k2, d2, bounds, q, pre)
-    assert gn == on and np.array_equal(gm, om) and gn > nq // 5
+    assert gn == on and np.array_equal(gm, om) and (not strict or gn > nq // 5)
     ur2 = np.where(rng.uniform(size=nq) > 0.4, k2["x"] - 15, -1).astype(np.float32)
     gb, gd = m.FuseCandidates(k2, d2, ur2, bounds, inv_s2, q)
     ob, od = O.fuse_candidates(k2, d2, ur2, bounds, inv_s2, q)
-    assert np.array_equal(gb, ob) and np.array_equal(gd, od) and (gb >= 0).sum() > nq // 5
+    assert np.array_equal(gb, ob) and np.array_equal(gd, od) and (not strict or (gb >= 0).sum() > nq // 5)
     # SearchBySim3: KF1 = frame 1, KF2 = frame 2 (a displaced, shuffled copy): project each keypoint's map point to where its
     # partner sits in the other frame (+ noise), partner known from the permutation
     inv = np.argsort(perm)
@@ -323,8 +330,8 @@ def test_search_for_initialization_and_distinctive_descriptor(iv):
                desc=qd, valid=(rng.uniform(size=nq) > 0.15).astype(np.uint8))
     gs, gf = m.SearchBySim3(k1, d1, bounds, k2, d2, bounds, q12, q21)
     os_, of = O.search_by_sim3(k1, d1, bounds, k2, d2, bounds, q12, q21)
-    assert gf == of and np.array_equal(gs, os_) and gf > nq // 4
-    assert (gs[gs >= 0] == inv[gs >= 0]).mean() > 0.9                       # mostly the true partners
+    assert gf == of and np.array_equal(gs, os_) and (not strict or gf > nq // 4)
+    assert not strict or (gs[gs >= 0] == inv[gs >= 0]).mean() > 0.9         # mostly the true partners
     # SearchByBoW(KF, F): a synthetic vocabulary level = 64 nodes keyed by descriptor bits, so that most true partners share
     # a node; frame 2's keypoints carry a few flipped bits and some land in other nodes
     def feat_vec(desc, drop):
@@ -339,7 +346,7 @@ def test_search_for_initialization_and_distinctive_descriptor(iv):
         mm = iv.ORBmatcher(ratio, ori)
         gm_, gn_ = mm.SearchByBoW(k1, d1, has_mp, fv1, k2, d2, fv2)
         om_, on_ = O.search_by_bow(k1, d1, has_mp, fv1, k2, d2, fv2, ratio, ori)
-        assert gn_ == on_ and np.array_equal(gm_, om_) and gn_ > 50
+        assert gn_ == on_ and np.array_equal(gm_, om_) and (not strict or gn_ > 50)
         assert has_mp[gm_[gm_ >= 0]].all()                                  # only keyframe features that own a map point
     gm_, gn_ = iv.ORBmatcher(0.7, True).SearchByBoW(k1, d1, has_mp, {}, k2, d2, fv2)
     assert gn_ == 0 and (gm_ == -1).all()
@@ -348,7 +355,7 @@ def test_search_for_initialization_and_distinctive_descriptor(iv):
         mm = iv.ORBmatcher(ratio, ori)
         gk, gkn = mm.SearchByBoWKeyFrames(k1, d1, has_mp, fv1, k2, d2, has2, fv2)
         ok_, okn = O.search_by_bow_keyframes(k1, d1, has_mp, fv1, k2, d2, has2, fv2, ratio, ori)
-        assert gkn == okn and np.array_equal(gk, ok_) and gkn > 30
+        assert gkn == okn and np.array_equal(gk, ok_) and (not strict or gkn > 30)
         assert has_mp[np.nonzero(gk >= 0)[0]].all() and has2[gk[gk >= 0]].all()
         assert len(np.unique(gk[gk >= 0])) == (gk >= 0).sum()                # vbMatched2: a KF2 feature is claimed once
     # SearchForTriangulation: pure horizontal translation between the cameras => F12 = [t]x with t = (1,0,0): epipolar lines are
@@ -366,17 +373,18 @@ def test_search_for_initialization_and_distinctive_descriptor(iv):
             sel = np.nonzero(gt >= 0)[0]
             assert nomp1[sel].all() and nomp2[gt[sel]].all()                 # only features without a map point
             if only_st: assert st1[sel].all() and st2[gt[sel]].all()
-        assert gtn > 10
+        assert not strict or gtn > 10
     # relocalisation SearchByProjection(CurrentFrame, KF, ...): same perturbed projections, angles from "the keyframe"
     qr = dict(q); qr["angle"] = ((k2["angle"] + rng.choice([0, 0, 0, 0, 75], nq)) % 360).astype(np.float32)
     for orbd, ori in [(100, True), (64, True), (64, False), (0, True)]:
         ga_, gn2 = iv.ORBmatcher(0.9, ori).SearchByProjectionReloc(k2, d2, bounds, qr, orbd, pre)
         oa_, on2 = O.search_by_projection_reloc(k2, d2, bounds, qr, orbd, ori, pre)
         assert gn2 == on2 and np.array_equal(ga_, oa_)
-    assert gn2 < nq // 4 and (ga_[pre == -2] == -2).all()
+    assert (not strict or gn2 < nq // 4) and (ga_[pre == -2] == -2).all()
     gb2, gd2 = m.FuseCandidates(k2, d2, None, bounds, None, q)              # Fuse(KF, Scw, ...): no chi-square gate
     ob2, od2 = O.fuse_candidates(k2, d2, None, bounds, None, q)
     assert np.array_equal(gb2, ob2) and np.array_equal(gd2, od2) and (gb2 >= 0).sum() >= (gb >= 0).sum()
+    return True
 
 
 def test_bow_transform_and_vectors(iv):
