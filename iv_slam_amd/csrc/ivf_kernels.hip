@@ -58,27 +58,33 @@ DEVINL unsigned wave_min_u32(unsigned v)
 
 // ------------------------------------------------------------------------------------------------
 // k_ingest: copy the caller's images (arbitrary row stride) into the pitched level-0 plane.
-// grid (ceil(pitch/256), h, nImg); image i comes from src[i % nSides] + (i / nSides) * imageStride.
+// One workgroup = kIngestRows rows of one image, 16 bytes per thread and step (r01: one dword per thread and a workgroup per
+// kilobyte -- 192k workgroups for 128 pairs, 1.9 TB/s; the caller's rows are byte-aligned at best, which global loads tolerate);
+// image i comes from src[i % nSides] + (i / nSides) * imageStride.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_ingest(const Config* __restrict__ cfg, const uint8_t* __restrict__ src0,
-                         const uint8_t* __restrict__ src1, size_t imageStride, int rowStride, int nSides,
-                         uint8_t* __restrict__ blob)
+constexpr int kIngestRows = 8;
+__global__ __launch_bounds__(256) void k_ingest(const Config* __restrict__ cfg, const uint8_t* __restrict__ src0,
+                                               const uint8_t* __restrict__ src1, size_t imageStride, int rowStride, int nSides,
+                                               uint8_t* __restrict__ blob)
 {
     const LevelGeom& G = cfg->lv[0];
-    const int img = blockIdx.z, y = blockIdx.y;
-    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (x4 >= G.pitch) return;
-    const uint8_t* src = ((nSides == 2 && (img & 1)) ? src1 : src0) + (size_t)(img / nSides) * imageStride + (size_t)y * rowStride;
-    unsigned v = 0;
-    if (x4 + 3 < G.w) {
-        // four pixels in one load; the caller's rows are byte-aligned at best (1242-byte KITTI rows), which global loads tolerate
-        typedef unsigned __attribute__((aligned(1))) u32_unaligned;
-        v = *(const u32_unaligned*)(src + x4);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) { int x = x4 + k; unsigned p = x < G.w ? src[x] : 0u; v |= p << (8 * k); }
+    const int img = blockIdx.y, y0 = blockIdx.x * kIngestRows;
+    const uint8_t* src = ((nSides == 2 && (img & 1)) ? src1 : src0) + (size_t)(img / nSides) * imageStride;
+    uint8_t* dst = blob + (size_t)img * cfg->pyrBytes + G.off;
+    const int q16 = G.pitch / 16;                                    // 16-byte pieces per pitched row (pitch % 64 == 0)
+    const int rows = min(kIngestRows, G.h - y0);
+    for (int i = threadIdx.x; i < rows * q16; i += 256) {
+        const int r = i / q16, x = (i % q16) * 16;
+        const uint8_t* sp = src + (size_t)(y0 + r) * rowStride + x;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (x + 15 < G.w) __builtin_memcpy(&v, sp, 16);
+        else if (x < G.w) {                                          // the row's last piece: bytes, zero beyond the image
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+            for (int k = 0; k < 16 && x + k < G.w; k++) w[k >> 2] |= (unsigned)sp[k] << (8 * (k & 3));
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        *(uint4*)(dst + (size_t)(y0 + r) * G.pitch + x) = v;
     }
-    *(unsigned*)(blob + (size_t)img * cfg->pyrBytes + G.off + (size_t)y * G.pitch + x4) = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1763,7 +1769,7 @@ void launch_ingest(const Config& hc, const Config* dc, const Buffers&, const uin
                    size_t imageStride, int rowStride, int nImg, int nSides, uint8_t* dstBlob, hipStream_t s)
 {
     const LevelGeom& G = hc.lv[0];
-    dim3 grid((G.pitch / 4 + 255) / 256, G.h, nImg);
+    dim3 grid((G.h + kIngestRows - 1) / kIngestRows, nImg);
     hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, dc, src0, src1, imageStride, rowStride, nSides, dstBlob);
 }
 void launch_pyramid(const Config& hc, const Config* dc, const ResizeCoef* dTab, uint8_t* blob, int nImg, hipStream_t s)
