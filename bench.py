@@ -424,6 +424,24 @@ def main():
             per_img, src = load_pmc(pname)
             roofline = roof("%s (%d images)" % (pname, probe_batch), int(palgo * probe_batch), probe_sum_ms, probe_n,
                             iso_probe_ms, iso_probe_n, None if per_img is None else int(per_img * probe_batch), src)
+            # The same launch priced two more ways (r01 verdict): (i) at the BLOCK's boundary -- the hidden tensor this kernel
+            # reads is a product of the expand / depthwise split, not of the network: block input + residual + output is all an
+            # ideal whole-block kernel would move; (ii) against the matrix pipe -- three f16 MFMAs per f32 product.
+            import re
+            m = re.search(r"(\d+)->(\d+)", pname)
+            if m and roofline["avg_launch_ms"] > 0:
+                hid, cout = int(m.group(1)), int(m.group(2))
+                cin = hid // 6                                     # MobileNetV2 expansion factor (mobilenet.py:36)
+                ms = roofline["avg_launch_ms"]
+                bb = (cin + cout + cout) * 64 * 64 * 4 * probe_batch
+                fl = 2.0 * hid * cout * 64 * 64 * 3 * probe_batch
+                roofline["block_boundary"] = {
+                    "bytes_per_launch": bb, "achieved": round(bb / (ms * 1e-3) / 1e9, 2), "unit": "GB/s",
+                    "frac": round(bb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "note": "block input (%d ch) + residual + output (%d ch) at 64x64 f32; the %d-channel hidden tensor is not counted" % (cin, cout, hid)}
+                roofline["mfma"] = {"bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                                    "frac": round(fl / (ms * 1e-3) / 1e12 / 2500.0, 5), "flops_per_launch": fl,
+                                    "note": "f16 MFMA flops issued by this launch (hi*hi + hi*lo + lo*hi); sustained clock under this kernel ~1.95 GHz"}
         else:
             roofline = fast_roof
         out = {
