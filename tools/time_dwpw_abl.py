@@ -1,6 +1,6 @@
-"""Timing-only ablations of k_fcn_dwpw<5,4> (the 960 -> 160 launch the probe brackets): IVF_FCN_ABL bit mask, one process per value.
-bits: 1 window loads hit chunk 0 (no HBM), 4 no barriers, 8 no A-fragment loads in the loop, 16 no window loads in the loop,
-32 no MFMAs, 64 no stencil arithmetic.  Results are wrong by construction; only the launch time is read."""
+"""Times the 960 -> 160 launch the FCN probe brackets (k_fcn_dwpw<5,4>) at batch 128.  tools/dwpw_ablate.sh runs it once per
+ablation build (compile-time mask IVF_DWPW_ABL in ivf_fcn.hip: results of such builds are wrong by construction, only the
+launch time is read)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
