@@ -1035,6 +1035,7 @@ __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, c
 // NTHR = 64: one wave per cell (the common, small cells: many cells per CU).  NTHR = 256 for the big-cell pass: gather and
 // bitonic sort run on four waves (with the introspection quirk of overlapping cell domains most level-0/1 cells hold
 // 1-4 thousand candidates and a single wave spent ~100 us per cell in the sort); the introselect stays on wave 0.
+constexpr int kSelRows = 512;                            // tallest cell (rows) the counting sort of k_cell_select handles
 template <int CAP, int NTHR>
 __global__ __launch_bounds__(NTHR) void k_cell_select(const Config* __restrict__ cfg, const unsigned* __restrict__ tileList,
                                                    const int* __restrict__ tileCnt, const CellInfo* __restrict__ cellInfo,
@@ -1043,6 +1044,7 @@ __global__ __launch_bounds__(NTHR) void k_cell_select(const Config* __restrict__
 {
     __shared__ __attribute__((aligned(16))) unsigned keys[CAP];
     __shared__ __attribute__((aligned(16))) u64 ord[CAP];
+    __shared__ int s_row[kSelRows + 2];                       // per-row survivor counts, then their exclusive prefix
     unsigned short* stopA = (unsigned short*)keys;            // the sort keys are dead once `ord` is built:
     unsigned short* stopB = stopA + CAP;                      // their space holds the partition stop lists
     __shared__ int s_m;
@@ -1133,22 +1135,59 @@ __global__ __launch_bounds__(NTHR) void k_cell_select(const Config* __restrict__
     if (tid == 0 && m != nT) atomicOr(status, 1);                    // internal consistency
     if (m != nT) return;
     {
-        // b) bitonic sort of the packed positions (y<<20 | x<<8 | score): ascending = row-major
-        int n2 = 64;
-        while (n2 < m) n2 <<= 1;
-        for (int k = m + tid; k < n2; k += NTHR) keys[k] = 0xffffffffu;
-        sync();
-        for (int k = 2; k <= n2; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < n2 / 2; i += NTHR) {
-                    const int l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-                    const int r = l | j;
-                    const unsigned a = keys[l], b = keys[r];
-                    const bool up = (l & k) == 0;
-                    if ((a > b) == up) { keys[l] = b; keys[r] = a; }
+        // b) row-major order of the packed positions (y<<20 | x<<8 | score).  A cell is a few dozen rows with a handful of survivors
+        //    each, so a two-level counting sort -- rows by histogram + prefix sum, then every survivor's rank among the survivors
+        //    of its own row -- costs O(m * row length) comparisons instead of the bitonic network's m log^2 m (which was 41 % of this
+        //    kernel); cells taller than kSelRows rows keep the bitonic sort.
+        const int nrows = cy1 - cy0;
+        if (nrows <= kSelRows) {
+            unsigned* arrival = (unsigned*)ord;                      // `ord` is free until step c): arrival index, grouped copy
+            unsigned* grouped = arrival + CAP;
+            for (int r = tid; r <= nrows; r += NTHR) s_row[r] = 0;
+            sync();
+            for (int k = tid; k < m; k += NTHR) arrival[k] = (unsigned)atomicAdd(&s_row[(int)(keys[k] >> 20) - cy0], 1);
+            sync();
+            if (tid < 64) {                                          // exclusive prefix sum over the rows, 64 at a time
+                int carry = 0;
+                for (int b0 = 0; b0 <= nrows; b0 += 64) {
+                    const int r = b0 + lane;
+                    const int c = r < nrows ? s_row[r] : 0;
+                    int incl = c;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+                    if (r <= nrows) s_row[r] = carry + incl - c;
+                    carry += __shfl(incl, 63, 64);
                 }
-                sync();
             }
+            sync();
+            for (int k = tid; k < m; k += NTHR) { const unsigned e = keys[k]; grouped[s_row[(int)(e >> 20) - cy0] + arrival[k]] = e; }
+            sync();
+            for (int p = tid; p < m; p += NTHR) {
+                const unsigned e = grouped[p];
+                const int r = (int)(e >> 20) - cy0;
+                const int b = s_row[r], en = s_row[r + 1];
+                int rank = 0;
+                for (int j = b; j < en; j++) rank += grouped[j] < e ? 1 : 0;      // same row: the order of x (positions are unique)
+                keys[b + rank] = e;
+            }
+            sync();
+        } else {
+            int n2 = 64;
+            while (n2 < m) n2 <<= 1;
+            for (int k = m + tid; k < n2; k += NTHR) keys[k] = 0xffffffffu;
+            sync();
+            for (int k = 2; k <= n2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < n2 / 2; i += NTHR) {
+                        const int l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                        const int r = l | j;
+                        const unsigned a = keys[l], b = keys[r];
+                        const bool up = (l & k) == 0;
+                        if ((a > b) == up) { keys[l] = b; keys[r] = a; }
+                    }
+                    sync();
+                }
+        }
         // c) 64-bit keys: response (x quality factor) | y | x
         for (int k = tid; k < m; k += NTHR) {
             const unsigned e = keys[k];
