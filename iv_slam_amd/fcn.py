@@ -37,10 +37,12 @@ class IntrospectionFCN:
         return (u8, f32) if want_f32 else u8
 
     def forward_device(self, bgr, cost_u8=None, cost_f32=None, stream_ptr=None):
-        """bgr: torch.uint8 [n,H,W,3] on the device; cost_u8 [n,outH,outW] u8 and/or cost_f32 f32 tensors."""
+        """bgr: torch.uint8 [n,H,W,3] on the device (rows / images may be padded); cost_u8 [n,outH,outW] u8 and/or cost_f32 f32 tensors (contiguous)."""
         n = bgr.shape[0]
-        assert bgr.is_contiguous() and tuple(bgr.shape[1:]) == (self.in_h, self.in_w, 3)
-        check(self._lib.ivf_fcn_forward_device(self._h, bgr.data_ptr(), self.in_h * self.in_w * 3, self.in_w * 3, n,
+        assert tuple(bgr.shape[1:]) == (self.in_h, self.in_w, 3)
+        st = bgr.stride()
+        assert st[3] == 1 and st[2] == 3, "interleaved BGR pixels; rows and images may be padded (a view of a larger tensor)"
+        check(self._lib.ivf_fcn_forward_device(self._h, bgr.data_ptr(), st[0], st[1], n,
                                                None if cost_u8 is None else cost_u8.data_ptr(),
                                                None if cost_f32 is None else cost_f32.data_ptr(), stream_ptr))
 

@@ -34,16 +34,19 @@ class StereoFrontend:
             self._h = None
 
     def run(self, left, right, cost=None, stream_ptr=None):
-        """left/right/cost: torch.uint8 tensors [n,H,W] on this device (contiguous).  Asynchronous."""
+        """left/right/cost: torch.uint8 tensors [n,H,W] on this device, unit column stride; rows and images may be padded
+        (views of larger tensors) as long as the three share their strides -- the C-ABI takes one (image, row) stride pair.
+        Asynchronous."""
         n = left.shape[0]
-        assert left.dtype == right.dtype and left.shape == right.shape and left.is_contiguous() and right.is_contiguous()
+        assert left.dtype == right.dtype and left.shape == right.shape
         assert left.shape[1] == self.height and left.shape[2] == self.width
+        st = left.stride()
+        assert st[2] == 1 and right.stride() == st, "unit column stride, same strides left / right"
         cp = None
         if cost is not None:
-            assert cost.shape == left.shape and cost.is_contiguous()
+            assert cost.shape == left.shape and cost.stride() == st
             cp = cost.data_ptr()
-        check(self._lib.ivf_frontend_run(self._h, left.data_ptr(), right.data_ptr(), cp,
-                                         self.height * self.width, self.width, n, stream_ptr))
+        check(self._lib.ivf_frontend_run(self._h, left.data_ptr(), right.data_ptr(), cp, st[0], st[1], n, stream_ptr))
         self._n = n
 
     def set_opencv_variant(self, blur=0, retain_best=0, atan2=0):

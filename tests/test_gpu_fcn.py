@@ -135,3 +135,22 @@ def test_fcn_kernel_variants_match_goldens_and_are_deterministic(env):
     r = subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert float(r.stdout.split("OK")[1]) < 3e-4
+
+
+def test_fcn_strided_input(iv):
+    """the batched device path on padded rows / images (a view of a larger tensor, odd byte offsets): same result as contiguous"""
+    import torch
+    g, W, bgr, out_size = FC.load_case("kitti")
+    dev = torch.device("cuda:0")
+    h, w = bgr.shape[:2]
+    fcn = iv.IntrospectionFCN(fcn_weights.pack_blob(W), (h, w), out_size, max_batch=2)
+    batch = torch.from_numpy(np.stack([bgr, bgr[::-1].copy()])).to(dev)
+    a = torch.empty((2,) + tuple(out_size), dtype=torch.uint8, device=dev); b = torch.empty_like(a)
+    fcn.forward_device(batch, cost_u8=a)
+    big = torch.zeros((2, h + 3, w + 11, 3), dtype=torch.uint8, device=dev)
+    view = big[:, 1:1 + h, 5:5 + w]
+    view.copy_(batch)
+    assert not view.is_contiguous()
+    fcn.forward_device(view, cost_u8=b)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)

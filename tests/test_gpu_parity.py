@@ -726,3 +726,29 @@ def test_opencv_variant_switches(iv, variant):
         assert_kps_equal(k0, base_k, "default restored") 
     finally:
         O.set_opencv_variant()
+
+
+def test_frontend_strided_inputs(iv):
+    """the batched front end on padded rows / images (views of larger device tensors, odd byte offsets): k_ingest reads through
+    the caller's strides; results equal the contiguous run"""
+    import torch
+    w, h, n, pairs = 637, 241, 400, 3
+    stream = synth.make_stream(pairs, w, h, seed=77)
+    cost = np.stack([synth.make_cost_map(w, h, seed=77, idx=i) for i in range(pairs)])
+    dev = torch.device("cuda:0")
+    fe = iv.StereoFrontend(w, h, pairs, nfeatures=n, enableIntrospection=True, bf=BF, b=B)
+    L = torch.from_numpy(stream[:, 0].copy()).to(dev); R = torch.from_numpy(stream[:, 1].copy()).to(dev); Cm = torch.from_numpy(cost).to(dev)
+    fe.run(L, R, Cm); fe.sync()
+    ref = [(fe.fetch(p, 0), fe.fetch(p, 1)) for p in range(pairs)]
+    big = [torch.zeros((pairs, h + 5, w + 43), dtype=torch.uint8, device=dev) for _ in range(3)]
+    views = [b[:, 2:2 + h, 7:7 + w] for b in big]
+    for v, src in zip(views, (L, R, Cm)):
+        v.copy_(src)
+    assert not views[0].is_contiguous()
+    fe.run(views[0], views[1], views[2]); fe.sync()
+    for p in range(pairs):
+        for side in (0, 1):
+            a = fe.fetch(p, side); b_ = ref[p][side]
+            assert_kps_equal(a["kps"], b_["kps"], "strided pair %d side %d" % (p, side))
+            assert np.array_equal(a["desc"], b_["desc"]) and np.array_equal(a["quality"], b_["quality"])
+        assert fe.fetch(p, 0)["uright"].tobytes() == ref[p][0]["uright"].tobytes()
