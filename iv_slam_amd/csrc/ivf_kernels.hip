@@ -264,6 +264,15 @@ DEVINL bool fast_precheck_pair(unsigned loT, unsigned hiT, unsigned loC, unsigne
     const s16x2 dk = pkmin(pkmax(d0, d8), pkmax(d4, d12)), br = pkmax(pkmin(d0, d8), pkmin(d4, d12));
     return (dk.x > t) | (dk.y > t) | (br.x < -t) | (br.y < -t);
 }
+// the same test for the pixel pair at bytes 5, 6 of the 12-byte span (m0, m1, m2): x-3 = bytes 2, 3; x+3 = bytes 8, 9 = bytes 4, 5 of (m2:m1)
+DEVINL bool fast_precheck_pair_b(unsigned t0, unsigned t1, unsigned m0, unsigned m1, unsigned m2, unsigned b0, unsigned b1, int t)
+{
+    const s16x2 v = pair_at(m0, m1, 5);
+    const s16x2 d0 = v - pair_at(b0, b1, 5), d8 = v - pair_at(t0, t1, 5);
+    const s16x2 d4 = v - pair_at(m1, m2, 4), d12 = v - pair_at(m0, m1, 2);
+    const s16x2 dk = pkmin(pkmax(d0, d8), pkmax(d4, d12)), br = pkmax(pkmin(d0, d8), pkmin(d4, d12));
+    return (dk.x > t) | (dk.y > t) | (br.x < -t) | (br.y < -t);
+}
 // rows: 7 windows (dy = -3..3), each as (lo, hi) dwords.  Returns the two scores packed (left | right << 16).
 DEVINL unsigned fast_score_pair(const unsigned (&lo)[7], const unsigned (&hi)[7], int t, bool quickOnly = false)
 {
@@ -417,13 +426,13 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
         bool pA = false, pB = false;
         if ((rv & (c0 | c1 | c2 | c3)) && !(ablate & 1)) {
             const unsigned* base = raw + (sy * kRawP + sx) / 4;
-            unsigned t0 = base[0], t1 = base[1], t2 = base[2];
+            unsigned t0 = base[0], t1 = base[1];
             unsigned m0 = base[3 * (kRawP / 4)], m1 = base[3 * (kRawP / 4) + 1], m2 = base[3 * (kRawP / 4) + 2];
-            unsigned b0 = base[6 * (kRawP / 4)], b1 = base[6 * (kRawP / 4) + 1], b2 = base[6 * (kRawP / 4) + 2];
+            unsigned b0 = base[6 * (kRawP / 4)], b1 = base[6 * (kRawP / 4) + 1];
             if (c0 | c1) pA = fast_precheck_pair(t0, t1, m0, m1, b0, b1, minTh);
-            if (c2 | c3) pB = fast_precheck_pair(__builtin_amdgcn_alignbyte(t1, t0, 2), __builtin_amdgcn_alignbyte(t2, t1, 2),
-                                                 __builtin_amdgcn_alignbyte(m1, m0, 2), __builtin_amdgcn_alignbyte(m2, m1, 2),
-                                                 __builtin_amdgcn_alignbyte(b1, b0, 2), __builtin_amdgcn_alignbyte(b2, b1, 2), minTh);
+            // pair B sits two bytes further: its five operands are picked straight out of the same dwords (only x+3 reaches the
+            // third one) instead of funnel-shifting six windows by two bytes first
+            if (c2 | c3) pB = fast_precheck_pair_b(t0, t1, m0, m1, m2, b0, b1, minTh);
         }
         *(unsigned*)(sc + sy * kScP + sx) = 0u;
         // wave-aggregated push: one LDS atomic per wave step instead of one per passing pair
