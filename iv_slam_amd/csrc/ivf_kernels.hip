@@ -313,11 +313,11 @@ DEVINL unsigned fast_score_pair(const unsigned (&lo)[7], const unsigned (&hi)[7]
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_fast_nms: one workgroup = one 64x32 output tile of one level of one image.
-//   1. stage the (64+8)x(32+8) raw tile in LDS with aligned dword loads (tile origin x = 16 + 64*tx);
-//      ~100 threads also classify the tile's 66 columns / 34 rows against the level's cell grid once
+// k_fast_nms: one workgroup = one 128x32 output tile (kFastTW x kFastTH) of one level of one image.
+//   1. stage the (128+8)x(32+8) raw tile in LDS with aligned dword loads (tile origin x = 16 + 128*tx);
+//      ~160 threads also classify the tile's 130 columns / 34 rows against the level's cell grid once
 //      (which cell, inside a FAST detection domain or not, neighbours in the same cell or not)
-//   2. FAST score for the 66x34 region (tile + 1-px NMS halo), two pixels per thread-step
+//   2. FAST score for the 130x34 region (tile + 1-px NMS halo), two pixels per thread-step
 //   3. 3x3 strict NMS against neighbours of the SAME cell (cv::FAST runs per cell sub-image, so
 //      neighbours in another cell count as 0); every survivor (score >= minTh) goes to the tile's list as
 //      (y<<20 | x<<8 | score) and is counted per cell (total and >= iniTh).  No score map goes to HBM;
@@ -325,9 +325,9 @@ DEVINL unsigned fast_score_pair(const unsigned (&lo)[7], const unsigned (&hi)[7]
 //      row-major order from the packed positions.
 // Since score >= t <=> corner at t, one pass serves both thresholds.
 // ------------------------------------------------------------------------------------------------
-constexpr int kRawP = kFastTW + 8;          // 72 bytes per raw row (18 dwords)
+constexpr int kRawP = kFastTW + 8;          // 136 bytes per raw row (34 dwords)
 constexpr int kLocalCells = 32;             // cells a tile may touch on the aggregated path: 8 cell rows x 4 cell cols
-constexpr int kScW = kFastTW + 2, kScH = kFastTH + 2, kScP = kFastTW + 4;   // score region 66 x 34, pitch 68
+constexpr int kScW = kFastTW + 2, kScH = kFastTH + 2, kScP = kFastTW + 4;   // score region 130 x 34, pitch 132
 // per column / row of the score region: bit0 valid, bit1 previous neighbour in the same cell, bit2 next neighbour
 // in the same cell, bits 8.. = cell column / row index
 __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg, const uint8_t* __restrict__ pyr,
