@@ -162,24 +162,20 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
     const float* Xb = X + (size_t)b * 3 * kEnc * kEnc;
     {   // 1. aligned float4 loads, all of a thread's loads in flight before the first LDS store
         constexpr int Q4 = 18, N4 = 3 * kStemIH * Q4, IT = (N4 + NT - 1) / NT;
-        float4 v4[IT]; bool ok[IT];
+        float4 v4[IT]; bool ok[IT]; int dst[IT];                // the index is decomposed once per item (three divisions by constants)
 #pragma unroll
         for (int k = 0; k < IT; k++) {
             const int i = min(tid + NT * k, N4 - 1);
             const int c = i / (kStemIH * Q4), r = (i / Q4) % kStemIH, q4 = i % Q4;
             const int yy = iy0 + r, xx = 2 * ox0 - 4 + 4 * q4;
             ok[k] = yy >= 0 && yy < kEnc && xx >= 0 && xx < kEnc;
+            dst[k] = (c * kStemIH + r) * kStemIP + 4 * q4;
             v4[k] = *(const float4*)(Xb + ((size_t)c * kEnc + (ok[k] ? yy : 0)) * kEnc + (ok[k] ? xx : 0));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < IT; k++) {
-            const int i = tid + NT * k;
-            if (i < N4) {
-                const int c = i / (kStemIH * Q4), r = (i / Q4) % kStemIH, q4 = i % Q4;
-                *(float4*)&sIn[(c * kStemIH + r) * kStemIP + 4 * q4] = ok[k] ? v4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
+        for (int k = 0; k < IT; k++)
+            if (tid + NT * k < N4) *(float4*)&sIn[dst[k]] = ok[k] ? v4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     // 2. conv0 as an MFMA GEMM (split-f16, f32 accumulate like every other convolution here): M = 32 output channels,
@@ -346,13 +342,14 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
     for (int st = 0; st < K16; st++) { eh[st].q = WqE[((st * NG + 0) * 2 + 0) * 64 + lane]; el[st].q = WqE[((st * NG + 0) * 2 + 1) * 64 + lane]; }
     {   // A. aligned float4 loads, all of a thread's loads in flight before the first LDS store
         constexpr int N4 = CIN * RH * Q4, IT = (N4 + NT - 1) / NT;
-        float4 v4[IT]; bool ok[IT];
+        float4 v4[IT]; bool ok[IT]; int dst[IT];                // the index is decomposed once per item (three divisions by constants)
 #pragma unroll
         for (int k = 0; k < IT; k++) {
             const int i = min(tid + NT * k, N4 - 1);
             const int c = i / (RH * Q4), r = (i / Q4) % RH, q4 = i % Q4;
             const int yy = ry0 + r, xx = ox0 * S - 4 + 4 * q4;
             ok[k] = yy >= 0 && yy < WI && xx >= 0 && xx < WI;
+            dst[k] = c * XPL + r * RP + 4 * q4;
             v4[k] = *(const float4*)(Xb + ((size_t)c * WI + (ok[k] ? yy : 0)) * WI + (ok[k] ? xx : 0));
         }
         for (int i = tid; i < NG * 32; i += NT) {
@@ -363,13 +360,8 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
             for (int k = 0; k < 9; k++) t[2 + k] = v ? Wd[i * 9 + k] : 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < IT; k++) {
-            const int i = tid + NT * k;
-            if (i < N4) {
-                const int c = i / (RH * Q4), r = (i / Q4) % RH, q4 = i % Q4;
-                *(float4*)&sX[c * XPL + r * RP + 4 * q4] = ok[k] ? v4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
+        for (int k = 0; k < IT; k++)
+            if (tid + NT * k < N4) *(float4*)&sX[dst[k]] = ok[k] ? v4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     f32x16 accO;
 #pragma unroll
