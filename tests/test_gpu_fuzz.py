@@ -192,3 +192,40 @@ def test_remaining_searches_random_scenarios(iv, seed):
         except IvfError as e:
             assert e.code == IVF_E_GEOMETRY
     raise AssertionError("no usable scenario in 40 draws")
+
+
+@pytest.mark.parametrize("pattern", ["noise", "checker2", "checker3", "stripes", "ramp", "blobs", "salt"])
+def test_extract_stress_patterns(iv, pattern):
+    """image content at the extremes: dense corners (survivor-list / cell capacities, the plane-scan NMS path, ties everywhere),
+    none at all, saturated blobs -- KITTI-sized, 1000 and 4000 features, with and without a cost map"""
+    w, h = 1242, 375
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:h, 0:w]
+    if pattern == "noise":
+        img = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    elif pattern == "checker2":
+        img = ((((yy // 2) + (xx // 2)) & 1) * 255).astype(np.uint8)
+    elif pattern == "checker3":
+        img = ((((yy // 3) + (xx // 3)) & 1) * 200 + 20).astype(np.uint8)
+    elif pattern == "stripes":
+        img = (((xx // 5) & 1) * 180 + 30).astype(np.uint8)
+    elif pattern == "ramp":
+        img = ((xx * 255) // (w - 1)).astype(np.uint8)
+    elif pattern == "blobs":
+        img = np.zeros((h, w), np.uint8)
+        for _ in range(300):
+            cy, cx, r = rng.integers(0, h), rng.integers(0, w), rng.integers(2, 9)
+            img[max(cy - r, 0):cy + r, max(cx - r, 0):cx + r] = 255
+    else:
+        img = np.full((h, w), 128, np.uint8)
+        idx = rng.integers(0, h * w, 20000)
+        img.reshape(-1)[idx] = rng.choice([0, 255], 20000).astype(np.uint8)
+    cost = synth.make_cost_map(w, h, seed=9, idx=0)
+    for n, intro in ((1000, False), (4000, True)):
+        g = iv.ORBextractor(n, 1.2, 8, 20, 7, intro)
+        o = O.Extractor(n, 1.2, 8, 20, 7, intro)
+        gk, gd = g(img, cost if intro else None)
+        ok, od = o(img, cost if intro else None)
+        assert g.level_counts() == o.level_counts(), (pattern, n)
+        assert_kps_equal(gk, ok, "%s n=%d" % (pattern, n))
+        assert np.array_equal(gd, od), (pattern, n)
