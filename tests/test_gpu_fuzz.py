@@ -229,3 +229,35 @@ def test_extract_stress_patterns(iv, pattern):
         assert g.level_counts() == o.level_counts(), (pattern, n)
         assert_kps_equal(gk, ok, "%s n=%d" % (pattern, n))
         assert np.array_equal(gd, od), (pattern, n)
+
+
+@pytest.mark.parametrize("pattern", ["noise", "checker3", "blobs"])
+def test_stereo_stress_patterns(iv, pattern):
+    """the stereo matcher on repetitive / noisy content (Hamming ties, many candidates per row, SAD plateaus): the batched front end
+    against the oracle chain, right image = left shifted by a few pixels"""
+    import torch
+    w, h, n = 800, 300, 1500
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:h, 0:w + 16]
+    if pattern == "noise":
+        base = rng.integers(0, 256, (h, w + 16)).astype(np.uint8)
+    elif pattern == "checker3":
+        base = ((((yy // 3) + (xx // 3)) & 1) * 200 + 20).astype(np.uint8)
+    else:
+        base = np.zeros((h, w + 16), np.uint8)
+        for _ in range(400):
+            cy, cx, r = rng.integers(0, h), rng.integers(0, w + 16), rng.integers(2, 9)
+            base[max(cy - r, 0):cy + r, max(cx - r, 0):cx + r] = rng.integers(60, 256)
+    left = base[:, 16:16 + w].copy(); right = base[:, 9:9 + w].copy()       # disparity 7
+    bf = 386.1448; b = bf / 718.856
+    dev = torch.device("cuda:0")
+    fe = iv.StereoFrontend(w, h, 1, nfeatures=n, bf=bf, b=b)
+    fe.run(torch.from_numpy(left[None].copy()).to(dev), torch.from_numpy(right[None].copy()).to(dev))
+    fe.sync()
+    oL = O.Extractor(n, 1.2, 8, 20, 7); oR = O.Extractor(n, 1.2, 8, 20, 7)
+    okL, odL = oL(left); okR, odR = oR(right)
+    our, odp = O.stereo_match(oL, oR, okL, odL, okR, odR, bf, b)
+    rl = fe.fetch(0, 0); rr = fe.fetch(0, 1)
+    assert_kps_equal(rl["kps"], okL, pattern + " L"); assert_kps_equal(rr["kps"], okR, pattern + " R")
+    assert np.array_equal(rl["desc"], odL) and np.array_equal(rr["desc"], odR)
+    assert rl["uright"].tobytes() == our.tobytes() and rl["depth"].tobytes() == odp.tobytes(), pattern
