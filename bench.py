@@ -218,6 +218,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         import socket
         import subprocess
+        import torch as _t                      # device_count() alone does not initialise the GPU (no HIP context in this parent)
+        if _t.cuda.device_count() < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d device(s) are visible" % (args.gpus, _t.cuda.device_count()))
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
