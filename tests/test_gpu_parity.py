@@ -752,3 +752,41 @@ def test_frontend_strided_inputs(iv):
             assert_kps_equal(a["kps"], b_["kps"], "strided pair %d side %d" % (p, side))
             assert np.array_equal(a["desc"], b_["desc"]) and np.array_equal(a["quality"], b_["quality"])
         assert fe.fetch(p, 0)["uright"].tobytes() == ref[p][0]["uright"].tobytes()
+
+
+def test_two_front_ends_from_two_host_threads(iv):
+    """two independent handles driven concurrently from two host threads (a two-camera rig): same results as one after the
+    other (per-thread scratch, per-handle streams, no shared mutable state in the library)"""
+    import threading
+    import torch
+    w, h, n, pairs = 640, 240, 500, 2
+    dev = torch.device("cuda:0")
+    streams = [synth.make_stream(pairs, w, h, seed=s) for s in (201, 202)]
+    ten = [(torch.from_numpy(st[:, 0].copy()).to(dev), torch.from_numpy(st[:, 1].copy()).to(dev)) for st in streams]
+    fes = [iv.StereoFrontend(w, h, pairs, nfeatures=n, bf=BF, b=B) for _ in range(2)]
+    ext = [iv.ORBextractor(n, 1.2, 8, 20, 7) for _ in range(2)]
+    ref = []
+    for k in range(2):
+        fes[k].run(*ten[k]); fes[k].sync()
+        ref.append(([fes[k].fetch(p, 0) for p in range(pairs)], ext[k](streams[k][0, 0])))
+    out = [None, None]; err = []
+
+    def work(k):
+        try:
+            for _ in range(8):
+                fes[k].run(*ten[k]); fes[k].sync()
+                a = [fes[k].fetch(p, 0) for p in range(pairs)]
+                b_ = ext[k](streams[k][0, 0])
+            out[k] = (a, b_)
+        except Exception as e:                     # noqa: BLE001
+            err.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not err, err
+    for k in range(2):
+        for p in range(pairs):
+            assert out[k][0][p]["kps"].tobytes() == ref[k][0][p]["kps"].tobytes()
+            assert np.array_equal(out[k][0][p]["desc"], ref[k][0][p]["desc"])
+            assert out[k][0][p]["uright"].tobytes() == ref[k][0][p]["uright"].tobytes()
+        assert out[k][1][0].tobytes() == ref[k][1][0].tobytes() and np.array_equal(out[k][1][1], ref[k][1][1])
