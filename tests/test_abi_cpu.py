@@ -82,3 +82,22 @@ def test_update_quality_scores_host_helper():
     bad = assign.copy(); bad[3] = nm + 7
     with pytest.raises(iv.IvfError):
         m.UpdateQualityScores(bad, kq, mq)
+
+
+def test_header_is_plain_c(tmp_path):
+    """the boundary is a C ABI: include/ivfront.h must compile as C99 (no C++ types in the signatures) and link against the
+    library from a C translation unit"""
+    import subprocess
+    src = tmp_path / "c_abi.c"
+    src.write_text('#include "ivfront.h"\nint main(void) { return ivf_version() > 0 ? 0 : 1; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    obj = tmp_path / "c_abi.o"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), "-c", "-o", str(obj), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lib = os.path.join(root, "iv_slam_amd", "libivfront.so")
+    if os.path.exists(lib):
+        exe = tmp_path / "c_abi"
+        r = subprocess.run(["gcc", "-o", str(exe), str(obj), lib, "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
