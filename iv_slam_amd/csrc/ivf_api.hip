@@ -140,6 +140,8 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
         G.cellW = (int)std::ceil((float)W / G.cols);              // :906-907
         G.cellH = (int)std::ceil((float)H / G.rows);
         G.nCells = G.rows * G.cols;
+        G.cellWMagic = (unsigned)(0x100000000ull / (unsigned)G.cellW) + 1u;   // cellW, cellH >= 1 here; == 1 gives 0: see k_fast_nms
+        G.cellHMagic = (unsigned)(0x100000000ull / (unsigned)G.cellH) + 1u;
         if (G.nCells > kMaxCells) return fail(IVF_E_INVALID, "level %d has %d cells (max %d)", l, G.nCells, kMaxCells);
         G.nfeaturesCell = (int)std::ceil((float)G.nDesired / G.nCells);   // :923
         // cell windows must stay inside [16, dim-16): otherwise the reference throws in rowRange/colRange

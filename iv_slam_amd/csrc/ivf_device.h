@@ -30,6 +30,7 @@ struct LevelGeom {
     int rtX, rtY;           // offsets into the packed cv::resize coefficient table (level >= 1)
     int valid;              // 0: level yields no keypoints
     float scale;            // mvScaleFactor[level]
+    unsigned cellWMagic, cellHMagic;   // floor(2^32 / cellW) + 1: n / cellW = umulhi(n, magic), exact for n < 2^16 (cells are at most 4096 px)
 };
 
 struct Config {

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
         const int x = x0 - 1 + tid;
         unsigned f = 0;
         if (x >= kEdge && x < G.maxBX) {
-            const int j = (x - kEdge) / G.cellW;
+            const int j = G.cellW == 1 ? x - kEdge : (int)__umulhi((unsigned)(x - kEdge), G.cellWMagic);      // (x - kEdge) / cellW
             const int cx0 = kEdge + j * G.cellW, cx1 = (j == G.cols - 1) ? G.maxBX : cx0 + G.cellW;
             if (x < cx1) f = 1u | ((x - 1 >= cx0) ? 2u : 0u) | ((x + 1 < cx1) ? 4u : 0u) | ((unsigned)j << 8);
         }
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
         const int y = y0 - 1 + (tid - 192);
         unsigned f = 0;
         if (y >= kEdge && y < G.maxBY) {
-            int i = (y - kEdge) / G.cellH;
+            int i = G.cellH == 1 ? y - kEdge : (int)__umulhi((unsigned)(y - kEdge), G.cellHMagic);            // (y - kEdge) / cellH
             if (i > G.rows - 1) i = G.rows - 1;
             const int cy0 = kEdge + i * G.cellH, cy1 = cy0 + ((i == G.rows - 1) ? G.domHLast : domHm);
             if (y < cy1) f = 1u | ((y - 1 >= cy0) ? 2u : 0u) | ((y + 1 < cy1) ? 4u : 0u) | ((unsigned)i << 8);
