@@ -261,3 +261,25 @@ def test_stereo_stress_patterns(iv, pattern):
     assert_kps_equal(rl["kps"], okL, pattern + " L"); assert_kps_equal(rr["kps"], okR, pattern + " R")
     assert np.array_equal(rl["desc"], odL) and np.array_equal(rr["desc"], odR)
     assert rl["uright"].tobytes() == our.tobytes() and rl["depth"].tobytes() == odp.tobytes(), pattern
+
+
+@pytest.fixture(scope="module")
+def adapter_driver(tmp_path_factory):
+    import adapter_scenario as AS
+    return AS.build_driver(tmp_path_factory.mktemp("adapter_fuzz") / "adapter_driver")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IVF_FUZZ_ADAPTER", "3"))))
+def test_adapter_random_scenarios(iv, adapter_driver, tmp_path, seed):
+    """the compiled C++ adapter (all eleven ORBmatcher signatures on mock Frame / KeyFrame / MapPoint types) on further seeded
+    scenarios: every result equal to the projection oracle (the yield checks belong to tests/test_gpu_adapter.py)"""
+    import subprocess
+    import adapter_scenario as AS
+    S, blob = AS.make(O, synth, 100 + seed, bool(seed & 1))
+    (tmp_path / "s.bin").write_bytes(blob)
+    r = subprocess.run([adapter_driver, str(tmp_path / "s.bin"), str(tmp_path / "r.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(tmp_path / "r.bin", np.int32).astype(np.int64)
+    want, _counts = AS.expected(O, S)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), "seed %d: first difference at %d" % (seed, int(np.nonzero(got != want)[0][0]))
