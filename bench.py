@@ -106,6 +106,34 @@ def cpu_fcn_baseline(threads, images=8, reps=3):
     return reps * len(batch) / dt, dt
 
 
+def parity_spot_check(spot, introspect):
+    """The oracle (checker only) on the inputs of 4 pairs of the last TIMED sub-batch against what the timed launch sequence
+    left in HBM for them: keypoints, descriptors, mvuRight / mvDepth bit for bit, mvKeyQualScore from the same cost map."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O          # checker only -- never on the product path
+    b = BF / FX
+    bad = []
+    for s in spot:
+        oL = O.Extractor(NFEAT, 1.2, 8, 20, 7, introspection=bool(introspect)); oR = O.Extractor(NFEAT, 1.2, 8, 20, 7)
+        kL, dL = oL(s["L"], s["cost"]); kR, dR = oR(s["R"], None)
+        ur, dp = O.stereo_match(oL, oR, kL, dL, kR, dR, BF, b)
+        ok = (s["l"]["kps"].tobytes() == kL.tobytes() and s["r"]["kps"].tobytes() == kR.tobytes() and
+              np.array_equal(s["l"]["desc"], dL) and np.array_equal(s["r"]["desc"], dR) and
+              s["l"]["uright"].tobytes() == ur.tobytes() and s["l"]["depth"].tobytes() == dp.tobytes())
+        if ok and s["cost"] is not None:                                   # mvKeyQualScore (Frame.cc:130-143)
+            px = np.rint(kL["x"]).astype(int); py = np.rint(kL["y"]).astype(int)
+            c = s["cost"][py, px].astype(np.float32)
+            q = (np.float64(1.0) / (np.float64(1.0) + (c / np.float32(256)).astype(np.float64))).astype(np.float32)
+            ok = np.array_equal(s["l"]["quality"], (np.float32(2) * q - np.float32(1)).astype(np.float32))
+        if not ok:
+            bad.append(s["pair"])
+    return {"pairs": len(spot), "ok": not bad, "mismatching_pairs": bad, "sub_batch": "last timed launch sequence",
+            "compared": "keypoints (6 fields), descriptors, mvuRight, mvDepth" + (", mvKeyQualScore; left extractor gated by the FCN's u8 cost map"
+                                                                                 if introspect else ""),
+            "checker": "oracle/libivf_oracle.so"}
+
+
 # algorithmic HBM bytes of the probed FCN launch per image (DESIGN.md section 7): hidden tensor read once
 # (960 x 64 x 64 f32), output written and residual read (160 x 64 x 64 f32 each); weights are L2-resident
 FCN_PROBE_BYTES_PER_IMAGE = (960 + 160 + 160) * 64 * 64 * 4
@@ -332,6 +360,12 @@ def main():
     # sanity on the last batch: keypoints were really produced and matched
     r0 = fe.fetch(0, 0)
     assert len(r0["kps"]) > NFEAT // 2 and (r0["uright"] >= 0).sum() > 20, "degenerate output"
+    # parity spot check: 4 pairs of the LAST timed sub-batch -- results, inputs and (configs[2]) the cost maps that gated them
+    # are copied out now, before anything else runs, and compared with the oracle below (never inside the timed region)
+    s_last = ((nsub[0] - 1) % nslices) * P
+    spot_pairs = sorted({0, 1, P // 2, P - 1})
+    spot = [dict(pair=p, L=left[s_last + p].cpu().numpy(), R=right[s_last + p].cpu().numpy(),
+                 cost=cost[p].cpu().numpy() if fcn is not None else None, l=fe.fetch(p, 0), r=fe.fetch(p, 1)) for p in spot_pairs]
     exch = None
     if exchange:
         # the last collective really delivered every rank's records: own slot == own block, every count plausible
@@ -392,6 +426,10 @@ def main():
         h2d = h2d_included(torch, iv, fe, fcn, dev, P, 16 if args.introspect else 48, left, right, bgr, cost, rec)
         lat = latency_batch1(iv, blob, args.introspect)
 
+    parity = parity_spot_check(spot, args.introspect)
+    if not parity["ok"]:
+        print("bench.py: rank %d: PARITY SPOT CHECK FAILED: %s" % (rank, json.dumps(parity)), file=sys.stderr, flush=True)
+        raise SystemExit(3)
     if rank == 0:
         def load_pmc(kernel_key):
             # HBM traffic from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE are collected in separate
@@ -462,6 +500,7 @@ def main():
                        "parallelism": "frames sharded %d-way, RCCL all-gather of descriptor blocks" % world if world > 1 else "1 GPU"},
             "timed_region_s": round(dt, 3),
             "roofline": roofline,
+            "parity_spot_check": parity,
         }
         if exch is not None:
             out["exchange"] = exch

@@ -208,6 +208,10 @@ int  ivf_frontend_device_results(const ivf_frontend* fe, int side, const ivf_key
 /* Copy one pair's results to host (synchronises).  uright/depth/quality are left-only and may be NULL. */
 int  ivf_frontend_fetch(ivf_frontend* fe, int pair, int side, ivf_keypoint* kps, uint8_t* desc, int cap, int* n_out,
                         float* uright, float* depth, float* quality);
+/* Same for the run `age` runs back (0 = the last one ... 2 = the oldest one still held): results of a run stay valid until
+ * two further runs have been enqueued, so a caller that keeps three batches in flight reads each of them this way. */
+int  ivf_frontend_fetch_of(ivf_frontend* fe, int age, int pair, int side, ivf_keypoint* kps, uint8_t* desc, int cap, int* n_out,
+                           float* uright, float* depth, float* quality);
 /* Elapsed milliseconds of the dominant kernel (FAST score + NMS) in the last run, from HIP events
  * recorded on the run's stream around that launch (bench.py's roofline leg); <0 if unavailable. */
 float ivf_frontend_last_fast_ms(ivf_frontend* fe);

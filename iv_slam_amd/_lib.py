@@ -110,6 +110,7 @@ _SIGS = {
     "ivf_frontend_device_results": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                               C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]),
     "ivf_frontend_fetch": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int), vp, vp, vp]),
+    "ivf_frontend_fetch_of": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int), vp, vp, vp]),
     "ivf_frontend_last_fast_ms": (C.c_float, [vp]),
     "ivf_frontend_fast_ms_stats": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "ivf_frontend_pack_gather_block": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]),

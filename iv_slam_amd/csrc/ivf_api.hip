@@ -1977,14 +1977,16 @@ int ivf_frontend_device_results(const ivf_frontend* fe, int side, const ivf_keyp
     return IVF_OK;
 }
 
-int ivf_frontend_fetch(ivf_frontend* fe, int pair, int side, ivf_keypoint* kps, uint8_t* desc, int cap, int* n_out,
-                       float* uright, float* depth, float* quality)
+int ivf_frontend_fetch_of(ivf_frontend* fe, int age, int pair, int side, ivf_keypoint* kps, uint8_t* desc, int cap, int* n_out,
+                          float* uright, float* depth, float* quality)
 {
     if (!fe || !n_out || side < 0 || side > 1) return fail(IVF_E_INVALID, "bad argument");
-    if (pair < 0 || pair >= fe->lastPairs) return fail(IVF_E_INVALID, "pair %d outside the last batch of %d", pair, fe->lastPairs);
+    if (age < 0 || age >= kPipe || fe->runs <= age) return fail(IVF_E_STATE, "no batch of age %d is held", age);
+    const int k = (int)((fe->runs - 1 - age) % kPipe);
+    if (pair < 0 || pair >= fe->pairsOf[k]) return fail(IVF_E_INVALID, "pair %d outside the batch of %d", pair, fe->pairsOf[k]);
     int rc = ivf_frontend_sync(fe);
     if (rc) return rc;
-    const Buffers& b = fe->ctx[fe->last()].b;
+    const Buffers& b = fe->ctx[k].b;
     const size_t nf = fe->ctx[0].hc.nfeatures, img = (size_t)pair * 2 + side;
     int n = 0;
     HIPCHK(hipMemcpy(&n, b.count + img, sizeof(int), hipMemcpyDeviceToHost));
@@ -1999,6 +2001,13 @@ int ivf_frontend_fetch(ivf_frontend* fe, int pair, int side, ivf_keypoint* kps, 
         if (depth) HIPCHK(hipMemcpy(depth, b.depth + (size_t)pair * nf, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     }
     return IVF_OK;
+}
+
+int ivf_frontend_fetch(ivf_frontend* fe, int pair, int side, ivf_keypoint* kps, uint8_t* desc, int cap, int* n_out,
+                       float* uright, float* depth, float* quality)
+{
+    if (fe && fe->runs == 0) return fail(IVF_E_INVALID, "pair %d outside the last batch of 0", pair);
+    return ivf_frontend_fetch_of(fe, 0, pair, side, kps, desc, cap, n_out, uright, depth, quality);
 }
 
 float ivf_frontend_last_fast_ms(ivf_frontend* fe)

@@ -64,12 +64,13 @@ class StereoFrontend:
         check(self._lib.ivf_frontend_fast_ms_stats(self._h, last_n, C.byref(s), C.byref(n)))
         return s.value, n.value
 
-    def fetch(self, pair, side):
+    def fetch(self, pair, side, age=0):
+        """Results of one image of the run `age` runs back (0 = last; a run stays held until two further runs were enqueued)."""
         cap = self.nfeatures
         kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
         ur = np.zeros(cap, np.float32); dp = np.zeros(cap, np.float32); q = np.zeros(cap, np.float32)
         n = C.c_int(0)
-        check(self._lib.ivf_frontend_fetch(self._h, pair, side, ptr(kps), ptr(desc), cap, C.byref(n), ptr(ur), ptr(dp), ptr(q)))
+        check(self._lib.ivf_frontend_fetch_of(self._h, int(age), pair, side, ptr(kps), ptr(desc), cap, C.byref(n), ptr(ur), ptr(dp), ptr(q)))
         n = n.value
         out = dict(kps=kps[:n].copy(), desc=desc[:n].copy(), quality=q[:n].copy())
         if side == 0:
