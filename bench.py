@@ -32,23 +32,41 @@ LEVEL_PX_SUM = 1441432            # sum of pixels over the 8 levels (SURVEY Appe
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def make_device_stream(torch, dev, n_pairs, seed, base_pairs=16):
-    """>=256 distinct pairs without minutes of host synthesis: `base_pairs` seeded host pairs, each
-    expanded on the GPU by a per-image (dx,dy) roll applied to left AND right (disparity preserved)
-    plus +-1 seeded noise."""
+RUN = 32                          # consecutive frames per visit of a scene
+
+
+def make_device_stream(torch, dev, n_pairs, seed, base_pairs=16, rank=0, world=1):
+    """>=256 distinct pairs without minutes of host synthesis, as a SEQUENCE: local frame i of this rank is global frame
+    g = i * world + rank (frame k -> GPU k mod G); the global sequence visits `base_pairs` seeded host scenes for
+    RUN consecutive frames each, the scene moving 3 px per frame (left AND right: disparity preserved) with +-1 seeded noise --
+    so that consecutive frames re-match under the tracker's window search, wherever they were extracted."""
     from iv_slam_amd import synth
     base = synth.make_stream(base_pairs, W, H, seed=seed)
     bl = torch.from_numpy(base[:, 0].copy()).to(dev); br = torch.from_numpy(base[:, 1].copy()).to(dev)
-    g = torch.Generator(device=dev); g.manual_seed(1234 + seed)
+    g_ = torch.Generator(device=dev); g_.manual_seed(1234 + seed + 7919 * rank)
     left = torch.empty((n_pairs, H, W), dtype=torch.uint8, device=dev); right = torch.empty_like(left)
     for i in range(n_pairs):
-        b = i % base_pairs; k = i // base_pairs
-        dx, dy = (37 * k) % 200, (11 * k) % 40
+        g = i * world + rank
+        b = (g // RUN) % base_pairs
+        t = g % RUN + RUN * (g // (RUN * base_pairs))
+        dx, dy = (3 * t) % 240, (t // 4) % 24
         for src, dst in ((bl, left), (br, right)):
             img = torch.roll(src[b], shifts=(dy, dx), dims=(0, 1)).to(torch.int16)
-            img += torch.randint(-1, 2, img.shape, generator=g, device=dev, dtype=torch.int16) * (k > 0)
+            img += torch.randint(-1, 2, img.shape, generator=g_, device=dev, dtype=torch.int16) * (t > 0)
             dst[i] = img.clamp_(0, 255).to(torch.uint8)
     return left, right
+
+
+def track_pairs(world, rank, P):
+    """(last, cur) record indices into the all-gathered buffer [world][P] for the frames THIS rank extracted: slot (r, j) holds
+    global frame j * world + r, so the frame before (r, j) is (r - 1, j), or (world - 1, j - 1) for r = 0."""
+    out = []
+    for j in range(P):
+        if rank > 0:
+            out.append(((rank - 1) * P + j, rank * P + j))
+        elif j > 0:
+            out.append(((world - 1) * P + j - 1, j))
+    return out
 
 
 def cpu_baseline(pairs_sample, cores, threads_per_pair=1):
@@ -132,6 +150,58 @@ def parity_spot_check(spot, introspect):
             "compared": "keypoints (6 fields), descriptors, mvuRight, mvDepth" + (", mvKeyQualScore; left extractor gated by the FCN's u8 cost map"
                                                                                  if introspect else ""),
             "checker": "oracle/libivf_oracle.so"}
+
+
+def track_report(torch, iv, tracker, rec_buf, tpairs, tpairs_h, assign_h, nm_h, sc, cam, stream):
+    """The batched tracker step on the last timed sub-batch's records: (i) what it left in HBM inside the timed region against
+    the oracle for 3 frame pairs (projection loops: oracle/projection_oracle.py; window search + greedy replay: the C oracle),
+    (ii) its own duration (HIP events, 10 launch sequences, nothing else on the GPU), (iii) the C oracle's
+    SearchByProjection(cur, last) on ONE host core for the same frame pairs."""
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle_lib as O          # checker only
+    import projection_oracle as PO  # checker only
+    from iv_slam_amd.frontend import unpack_gather_records
+    F = np.float32
+    recs = unpack_gather_records(rec_buf.cpu().numpy(), NFEAT)
+    I = np.eye(4, dtype=F)
+    bounds = (0.0, 0.0, float(W), float(H))
+
+    def fd(r):
+        return dict(kps=r["kps"], desc=r["desc"], uright=r["uright"], depth=r["depth"], T=I, scale=sc, fx=F(cam["fx"]), fy=F(cam["fy"]),
+                    cx=F(cam["cx"]), cy=F(cam["cy"]), mbf=F(BF), mb=F(F(BF) / F(cam["fx"])), bounds=bounds)
+    ok = True
+    sample = sorted({0, len(tpairs_h) // 2, len(tpairs_h) - 1})
+    for k in sample:
+        a, b = tpairs_h[k]
+        onm, oa = PO.track_with_motion_model_matches(O, fd(recs[b]), fd(recs[a]), F(7.0), F(14.0), 20)
+        ok = ok and onm == int(nm_h[k]) and np.array_equal(oa, assign_h[k, :len(oa)])
+    a3 = torch.empty_like(torch.from_numpy(assign_h)).to(rec_buf.device); n3 = torch.empty(len(tpairs_h), dtype=torch.int32, device=rec_buf.device)
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    tracker.run(rec_buf, tpairs, a3, n3, stream_ptr=stream.cuda_stream)
+    e0.record(stream)
+    for _ in range(10):
+        tracker.run(rec_buf, tpairs, a3, n3, stream_ptr=stream.cuda_stream)
+    e1.record(stream); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 10 / len(tpairs_h)
+    ok = ok and np.array_equal(a3.cpu().numpy(), assign_h) and np.array_equal(n3.cpu().numpy(), nm_h[:len(tpairs_h)])
+    # one core, C oracle: flat queries of the same pairs (zero-motion prior), search + greedy + rotation filter
+    t_c = []
+    for k in sample:
+        la, cu = recs[tpairs_h[k][0]], recs[tpairs_h[k][1]]
+        sel = la["depth"] > 0; lk = la["kps"][sel]
+        q = dict(u=lk["x"], v=lk["y"], ur=la["uright"][sel], radius=(F(7.0) * sc[lk["octave"]]).astype(F), min_level=(lk["octave"] - 1).astype(np.int32),
+                 max_level=(lk["octave"] + 1).astype(np.int32), angle=lk["angle"].copy(), desc=la["desc"][sel].copy(),
+                 valid=np.ones(len(lk), np.uint8), blocks=np.ones(len(lk), np.uint8))
+        t0 = time.perf_counter()
+        for _ in range(20):
+            O.search_by_projection(cu["kps"], cu["desc"], cu["uright"], bounds, q, True)
+        t_c.append((time.perf_counter() - t0) / 20)
+    return {"us_per_frame_pair": round(us, 3), "N": NFEAT, "frame_pairs_per_launch_sequence": len(tpairs_h),
+            "mean_matches": round(float(nm_h[:len(tpairs_h)].mean()), 1), "parity_ok": bool(ok), "pairs_checked_vs_oracle": len(sample),
+            "oracle_one_core_us_per_frame_pair": round(float(np.mean(t_c)) * 1e6, 1),
+            "what": "Tracking::TrackWithMotionModel's matcher call (UpdateLastFrame stereo points -> SearchByProjection(cur, last), th 7, retry 14 "
+                    "below 20 matches) for every consecutive frame pair, device-resident (ivf_tracker_run)"}
 
 
 # algorithmic HBM bytes of the probed FCN launch per image (DESIGN.md section 7): hidden tensor read once
@@ -234,6 +304,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the post-run latency / PCIe-inclusive / configs[1] measurements")
     ap.add_argument("--force-gather", action="store_true", help="test aid: run the multi-GPU exchange step (RCCL all-gather of "
                     "the descriptor records) even with one rank")
+    ap.add_argument("--track", action="store_true", help="run the batched tracker step (SearchByProjection(cur, last) for every consecutive "
+                    "frame pair, ivf_tracker_run) on every sub-batch's records inside the timed step; always on when the exchange runs")
     ap.add_argument("--serial", action="store_true", help="profiling aid: wait for each batch before enqueuing the next, so "
                     "rocprofv3 kernel durations are not inflated by the overlap of consecutive batches")
     args = ap.parse_args()
@@ -243,17 +315,16 @@ def main():
     # N>1 without a launcher: start one rank per GPU as a FRESH child (torch.distributed.run) before this process has
     # imported torch or touched the GPU -- never re-exec a process that has initialised HIP -- and pass its exit code on.
     # Rank 0 of the child prints the single JSON line (stdout is inherited).
+    backend = os.environ.get("IVF_BENCH_BACKEND", "nccl")              # "gloo": TEST AID -- ranks may share one device, blocks cross the host
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        import socket
         import subprocess
         import torch as _t                      # device_count() alone does not initialise the GPU (no HIP context in this parent)
-        if _t.cuda.device_count() < args.gpus:
+        if _t.cuda.device_count() < args.gpus and backend != "gloo":
             raise SystemExit("bench.py: --gpus %d but only %d device(s) are visible" % (args.gpus, _t.cuda.device_count()))
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        # --standalone: torchrun picks its own rendezvous port (no bind / close / re-bind race)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     import torch
@@ -270,10 +341,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)      # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend, rank=rank, world_size=world)     # "nccl" is RCCL on ROCm
         assert dist.get_world_size() == args.gpus
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()             # test aid: ranks share the visible device(s)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -281,7 +354,7 @@ def main():
     P = args.pairs
     n_stream = max(args.stream, P)
     n_stream = (n_stream + P - 1) // P * P
-    left, right = make_device_stream(torch, dev, n_stream, seed=100 + rank)
+    left, right = make_device_stream(torch, dev, n_stream, seed=100, rank=rank, world=world)
     cost = None
     fcn = None
     blob = None
@@ -309,6 +382,35 @@ def main():
     blocks3 = [torch.zeros(P * rec, dtype=torch.uint8, device=dev) for _ in range(3)] if exchange else None
     gathered3 = [torch.zeros(world * P * rec, dtype=torch.uint8, device=dev) for _ in range(3)] if exchange else None
     nsub = [0]
+    track = args.track or exchange
+    tracker = None
+    if track:
+        # the exchange step's consumer: Tracking::TrackWithMotionModel's matcher call for every frame this rank extracted against
+        # the frame before it, wherever that one was extracted (ivf_tracker_run on the gathered records; zero-motion prior,
+        # th = 7, retry with 14 below 20 matches: Tracking.cc:1313-1330)
+        sc = iv.ORBextractor(NFEAT, 1.2, 8, 20, 7, device_id=local_rank).GetScaleFactors()
+        cam = dict(fx=FX, fy=FX, cx=W / 2 + 0.5, cy=H / 2 - 0.25)
+        tpairs_h = track_pairs(world, rank, P)
+        tracker = iv.BatchTracker(NFEAT, sc, cam["fx"], cam["fy"], cam["cx"], cam["cy"], BF, (0.0, 0.0, float(W), float(H)),
+                                  max_pairs=max(len(tpairs_h), 1), device_id=local_rank)
+        tpairs = torch.tensor(tpairs_h, dtype=torch.int32, device=dev).reshape(-1, 2)
+        if blocks3 is None:
+            blocks3 = [torch.zeros(P * rec, dtype=torch.uint8, device=dev) for _ in range(3)]
+        assign3 = [torch.full((max(len(tpairs_h), 1), NFEAT), -1, dtype=torch.int32, device=dev) for _ in range(3)]
+        nm3 = [torch.zeros(max(len(tpairs_h), 1), dtype=torch.int32, device=dev) for _ in range(3)]
+
+    def all_gather_block(bs, k):
+        if backend == "gloo":
+            # test aid: the block crosses the host (gloo has no device path); blocking, never a measured configuration
+            bs.synchronize()
+            hb = blocks3[k % 3].cpu()
+            parts = [torch.empty_like(hb) for _ in range(world)]
+            dist.all_gather(parts, hb)
+            with torch.cuda.stream(bs):
+                gathered3[k % 3].copy_(torch.cat(parts), non_blocking=False)
+        else:
+            with torch.cuda.stream(bs):
+                dist.all_gather_into_tensor(gathered3[k % 3], blocks3[k % 3])
 
     def sub_batch(i):
         s = (i % nslices) * P
@@ -316,12 +418,15 @@ def main():
         if fcn is not None:
             fcn.forward_device(bgr[s:s + P], cost_u8=cost, stream_ptr=sptr)
         fe.run(left[s:s + P], right[s:s + P], cost, sptr)
-        if exchange:
-            # the path's one exchange step: all-gather of {n, kps, desc, uRight} for cross-frame matching
+        if exchange or track:
+            # the path's one exchange step: all-gather of {n, kps, desc, uRight, depth} for cross-frame matching ...
             bs = torch.cuda.ExternalStream(fe.batch_stream(0), device=dev)
             fe.pack_gather_block(blocks3[k % 3], fe.STREAM_OF_BATCH)
-            with torch.cuda.stream(bs):
-                dist.all_gather_into_tensor(gathered3[k % 3], blocks3[k % 3])
+            if exchange:
+                all_gather_block(bs, k)
+            if track and len(tpairs_h):
+                # ... and its consumer, in order behind the collective on the batch's own stream
+                tracker.run(gathered3[k % 3] if exchange else blocks3[k % 3], tpairs, assign3[k % 3], nm3[k % 3], stream_ptr=bs.cuda_stream)
         if args.serial:
             fe.sync()
 
@@ -351,7 +456,7 @@ def main():
     if fcn is not None:
         probe_sum_ms, probe_n, probe_batch = fcn.probe_stats(n_timed)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend != "gloo" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     total_pairs = P * BPS * args.steps * world
@@ -377,7 +482,21 @@ def main():
         counts = g[:, :, :4].copy().view(np.int32)[:, :, 0]
         assert ((counts > NFEAT // 2) & (counts <= NFEAT)).all(), "all-gather: implausible keypoint counts %r" % counts
         exch = {"world": world, "record_bytes": rec, "bytes_per_rank_per_batch": P * rec, "records_checked": int(counts.size),
-                "collective": "all_gather_into_tensor (RCCL) on the batch's own internal stream"}
+                "backend": backend, "consumed": False,
+                "collective": ("all_gather_into_tensor (RCCL) on the batch's own internal stream" if backend != "gloo" else
+                               "TEST AID: gloo all_gather of host copies (ranks may share a device)")}
+    trk = None
+    if track and len(tpairs_h):
+        # what the tracker left in HBM for the LAST timed sub-batch, against the oracle on the same records (3 frame pairs)
+        last = (nsub[0] - 1) % 3
+        rec_buf = (gathered3[last] if exchange else blocks3[last]).clone()
+        trk = track_report(torch, iv, tracker, rec_buf, tpairs, tpairs_h, assign3[last].cpu().numpy(), nm3[last].cpu().numpy(), sc, cam, stream)
+        if not trk["parity_ok"]:
+            print("bench.py: rank %d: TRACKER PARITY CHECK FAILED: %s" % (rank, json.dumps(trk)), file=sys.stderr, flush=True)
+            raise SystemExit(4)
+        if exch is not None:
+            exch["consumed"] = True
+            exch["consumer"] = "ivf_tracker_run: SearchByProjection(cur, last) of every frame this rank extracted against the frame before it, out of the gathered records"
 
     # ---- after the timed region -------------------------------------------------------------------------------------
     # The front end overlaps consecutive batches on its own streams, so inside the timed region the probed kernel shares
@@ -504,6 +623,9 @@ def main():
         }
         if exch is not None:
             out["exchange"] = exch
+        if trk is not None:
+            trk["in_timed_region"] = True
+            out["track"] = trk
         if fcn is not None:
             out["roofline_fast_nms"] = fast_roof
             if fcn_alone is not None:

@@ -219,8 +219,10 @@ float ivf_frontend_last_fast_ms(ivf_frontend* fe);
  * *sum_ms = total milliseconds, *n_out = number of launches summed.  Synchronises on those events. */
 int   ivf_frontend_fast_ms_stats(ivf_frontend* fe, int last_n, double* sum_ms, int* n_out);
 /* Pack this rank's results of the last run for a descriptor all-gather: writes into d_block (device)
- * n_pairs fixed-size records {int32 n; int32 pad[3]; ivf_keypoint kps[cap]; uint8 desc[cap][32]; float uright[cap]}
- * and returns the record size in *record_bytes. */
+ * n_pairs fixed-size records {int32 n; int32 pad[3]; ivf_keypoint kps[cap]; uint8 desc[cap][32]; float uright[cap];
+ * float depth[cap]} (the LEFT frame of each pair: mvKeys, mDescriptors, mvuRight, mvDepth -- what a rank needs to run the
+ * tracker's cross-frame search against a frame extracted elsewhere, ivf_tracker_run below) and returns the record size in
+ * *record_bytes (= ivf_track_record_bytes(cap)). */
 int  ivf_frontend_pack_gather_block(ivf_frontend* fe, uint8_t* d_block, size_t block_bytes, size_t* record_bytes,
                                     void* hip_stream);
 /* Same for the run `age` runs back (0 = the last one ... 2 = the oldest one still held).  Note that `hip_stream` waits
@@ -232,6 +234,45 @@ int  ivf_frontend_pack_gather_block_of(ivf_frontend* fe, int age, uint8_t* d_blo
  * -- bench.py's all-gather -- can be enqueued behind the pack. */
 #define IVF_STREAM_OF_BATCH ((void*)(intptr_t)-1)
 void* ivf_frontend_batch_stream(ivf_frontend* fe, int age);
+
+/* ---- batched, device-resident tracker step: the consumer of the all-gather -----------------------------------------------
+ * For every (last, cur) pair of gather records, in ONE launch sequence and without leaving HBM: the matcher part of
+ * Tracking::TrackWithMotionModel (ORB/src/Tracking.cc:1303-1330) =
+ *   UpdateLastFrame's stereo points (Tracking.cc:1256-1300; Frame::UnprojectStereo, ORB/src/Frame.cc:958-972)
+ *   -> ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono = false) (ORB/src/ORBmatcher.cc:1372-1518): projection,
+ *      GetFeaturesInArea windows (ORB/src/Frame.cc:615-668), greedy assignment in last-keypoint order with the stereo check,
+ *      rotation histogram + ComputeThreeMaxima (:1654-1695)
+ *   -> the retry with th_retry when fewer than retry_below matches were found (Tracking.cc:1320-1330).
+ * Keypoints are taken as undistorted (rectified stereo: mvKeysUn == mvKeys, Frame.cc:714 is a no-op there). */
+typedef struct ivf_track_config {
+    int32_t nfeatures;                       /* capacity of a gather record (<= 4096) */
+    int32_t nlevels;
+    float   scale_factors[IVF_MAX_LEVELS];   /* mvScaleFactors (ivf_extractor_get_scale_tables) */
+    float   fx, fy, cx, cy, bf, b;           /* Frame::fx, fy, cx, cy, mbf, mb */
+    ivf_bounds bounds;                       /* mnMinX, mnMinY, mnMaxX, mnMaxY */
+    float   th;                              /* window factor: 7 for stereo, 15 otherwise (Tracking.cc:1313-1317), times the caller's multipliers */
+    float   th_retry;                        /* 2 * th in the reference (Tracking.cc:1327) */
+    int32_t retry_below;                     /* 20 (Tracking.cc:1320); 0 = never retry */
+    int32_t check_orientation;               /* mbCheckOrientation of the matcher (true at Tracking.cc:1305) */
+    float   th_depth;                        /* mThDepth: > 0 selects UpdateLastFrame's rule -- every stereo point closer than this and at
+                                              * least the 100 closest, as new points WITHOUT observations (localization mode); <= 0: every
+                                              * stereo point carries a point and points_block applies */
+    int32_t points_block;                    /* default of pMP->Observations() > 0 (:1447-1449) when no flags are passed */
+    int32_t max_pairs;                       /* (last, cur) pairs per call */
+    int32_t device_id;
+} ivf_track_config;
+typedef struct ivf_tracker ivf_tracker;
+size_t ivf_track_record_bytes(int nfeatures);
+int  ivf_tracker_create(const ivf_track_config* cfg, ivf_tracker** out);
+void ivf_tracker_destroy(ivf_tracker* t);
+/* d_records: n_records gather records, record_bytes apart, 16-byte aligned (a packed block, or the all-gathered buffer);
+ * d_pairs [n_pairs][2] int32 on the device = (last record, cur record) indices; d_poses [n_records][12] = Tcw of every
+ * record's frame, row-major 3x4, or NULL = identity everywhere (zero-motion prior); d_point_flags [n_records][nfeatures]
+ * (nullable): bit 0 = the keypoint has a map point, bit 1 = that point has observations (then th_depth is ignored).
+ * Outputs: d_assign [n_pairs][nfeatures] = for every keypoint of the current frame the index of the last-frame keypoint whose
+ * point it received (CurrentFrame.mvpMapPoints) or -1; d_nmatches [n_pairs] = the return value.  Asynchronous on hip_stream. */
+int  ivf_tracker_run(ivf_tracker* t, const uint8_t* d_records, size_t record_bytes, int n_records, const int32_t* d_pairs, int n_pairs,
+                     const float* d_poses, const uint8_t* d_point_flags, int32_t* d_assign, int32_t* d_nmatches, void* hip_stream);
 
 /* ---- introspection FCN forward (IF/networks/models_light/models_light.py:18-28; called at
  * ORB/Examples/Stereo/stereo_kitti.cc:231-247 (load) and :493-514 (pre-process, forward, u8 truncation)) ----

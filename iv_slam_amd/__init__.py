@@ -9,3 +9,4 @@ from .orb import (ORBextractor, ORBmatcher, ORBVocabulary, ComputeStereoMatches,
 from .frontend import StereoFrontend  # noqa: F401
 from .fcn import IntrospectionFCN  # noqa: F401
 from .rectify import initUndistortRectifyMap, Remap  # noqa: F401
+from .track import BatchTracker  # noqa: F401

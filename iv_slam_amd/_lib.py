@@ -29,6 +29,14 @@ class FrontendConfig(C.Structure):
                 ("max_pairs", C.c_int32), ("bf", C.c_float), ("b", C.c_float), ("device_id", C.c_int32)]
 
 
+class TrackConfig(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("nlevels", C.c_int32), ("scale_factors", C.c_float * MAX_LEVELS),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float), ("b", C.c_float),
+                ("bounds", Bounds), ("th", C.c_float), ("th_retry", C.c_float), ("retry_below", C.c_int32),
+                ("check_orientation", C.c_int32), ("th_depth", C.c_float), ("points_block", C.c_int32),
+                ("max_pairs", C.c_int32), ("device_id", C.c_int32)]
+
+
 class IvfError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("ivfront error %d: %s" % (code, msg))
@@ -116,6 +124,10 @@ _SIGS = {
     "ivf_frontend_pack_gather_block": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]),
     "ivf_frontend_pack_gather_block_of": (C.c_int, [vp, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]),
     "ivf_frontend_batch_stream": (vp, [vp, C.c_int]),
+    "ivf_track_record_bytes": (C.c_size_t, [C.c_int]),
+    "ivf_tracker_create": (C.c_int, [C.POINTER(TrackConfig), C.POINTER(vp)]),
+    "ivf_tracker_destroy": (None, [vp]),
+    "ivf_tracker_run": (C.c_int, [vp, vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]),
     "ivf_fcn_create": (C.c_int, [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "ivf_fcn_destroy": (None, [vp]),
     "ivf_fcn_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),

@@ -2042,7 +2042,7 @@ int ivf_frontend_pack_gather_block_of(ivf_frontend* fe, int age, uint8_t* d_bloc
 {
     if (!fe || !record_bytes) return fail(IVF_E_INVALID, "null argument");
     const size_t nf = fe->ctx[0].hc.nfeatures;
-    const size_t rec = 16 + nf * sizeof(ivf_keypoint) + nf * 32 + nf * sizeof(float);
+    const size_t rec = 16 + nf * sizeof(ivf_keypoint) + nf * 32 + 2 * nf * sizeof(float);
     *record_bytes = rec;
     if (!d_block) return IVF_OK;
     if (age < 0 || age >= kPipe) return fail(IVF_E_INVALID, "age %d outside [0,%d): results stay valid for %d further runs", age, kPipe, kPipe - 1);
@@ -2050,7 +2050,7 @@ int ivf_frontend_pack_gather_block_of(ivf_frontend* fe, int age, uint8_t* d_bloc
     const int k = (int)((fe->runs - 1 - age) % kPipe);
     const int np = fe->pairsOf[k];
     if (block_bytes < rec * np) return fail(IVF_E_CAPACITY, "gather block needs %zu bytes", rec * np);
-    if (((size_t)d_block & 3) != 0) return fail(IVF_E_INVALID, "gather block must be 4-byte aligned");
+    if (((size_t)d_block & 15) != 0) return fail(IVF_E_INVALID, "gather block must be 16-byte aligned");
     HIPCHK(hipSetDevice(fe->cfg.device_id));
     hipStream_t st = (hipStream_t)hip_stream;
     if (hip_stream == IVF_STREAM_OF_BATCH) st = fe->stream[k];        // in order behind the batch itself: nothing to wait for

@@ -1958,12 +1958,13 @@ void launch_hamming_pairs(const uint8_t* a, const uint8_t* b, const int* pairs, 
 
 // ------------------------------------------------------------------------------------------------
 // k_pack_gather: one workgroup = one stereo pair; copies the left frame's {count, keypoints, descriptors, uRight} into
-// one contiguous record of the all-gather block.  A kernel rather than 2-D copies so that packing
+// one contiguous record {n, kps, desc, uRight, depth} of the all-gather block (depth so that a receiving rank can
+// un-project the frame's stereo points, ivf_track.hip).  A kernel rather than 2-D copies so that packing
 // never blocks the host thread that keeps the next batches enqueued.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_gather(const int* __restrict__ count, const ivf_keypoint* __restrict__ kps,
                                                      const uint8_t* __restrict__ desc, const float* __restrict__ uright,
-                                                     int nf, unsigned* __restrict__ block, size_t recWords)
+                                                     const float* __restrict__ depth, int nf, unsigned* __restrict__ block, size_t recWords)
 {
     const int p = blockIdx.x;
     unsigned* out = block + (size_t)p * recWords;
@@ -1971,15 +1972,17 @@ __global__ __launch_bounds__(256) void k_pack_gather(const int* __restrict__ cou
     const unsigned* k = (const unsigned*)(kps + (size_t)2 * p * nf);
     const unsigned* d = (const unsigned*)(desc + (size_t)2 * p * nf * 32);
     const unsigned* u = (const unsigned*)(uright + (size_t)p * nf);
+    const unsigned* z = (const unsigned*)(depth + (size_t)p * nf);
     const int nk = nf * (int)(sizeof(ivf_keypoint) / 4), nd = nf * 8;
     for (int i = threadIdx.x; i < nk; i += 256) out[4 + i] = k[i];
     for (int i = threadIdx.x; i < nd; i += 256) out[4 + nk + i] = d[i];
     for (int i = threadIdx.x; i < nf; i += 256) out[4 + nk + nd + i] = u[i];
+    for (int i = threadIdx.x; i < nf; i += 256) out[4 + nk + nd + nf + i] = z[i];
 }
 
 void launch_pack_gather(const Buffers& b, int nf, int nPairs, uint8_t* block, size_t recBytes, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pack_gather, dim3(nPairs), dim3(256), 0, s, b.count, b.kps, b.desc, b.uright, nf, (unsigned*)block, recBytes / 4);
+    hipLaunchKernelGGL(k_pack_gather, dim3(nPairs), dim3(256), 0, s, b.count, b.kps, b.desc, b.uright, b.depth, nf, (unsigned*)block, recBytes / 4);
 }
 
 // ------------------------------------------------------------------------------------------------

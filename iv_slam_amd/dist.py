@@ -1,5 +1,5 @@
 """Multi-GPU sharding of the stereo stream: frame k -> rank k mod G, plus the path's
-one exchange step -- an all-gather of fixed-size per-pair records {n, kps, desc, uRight} so every rank can
+one exchange step -- an all-gather of fixed-size per-pair records {n, kps, desc, uRight, depth} so every rank can
 run cross-frame matching (ORBmatcher::SearchByProjection(cur,last), ORB/src/ORBmatcher.cc:1372) against the
 previous frame wherever it was extracted.  torch.distributed is the transport ("nccl" = RCCL over xGMI on
 the GPU box, "gloo" in CPU tests); the record layout is the C-ABI's (ivf_frontend_pack_gather_block).
@@ -10,7 +10,7 @@ from ._lib import KP_DTYPE
 
 
 def record_bytes(nfeatures):
-    return 16 + nfeatures * 24 + nfeatures * 32 + nfeatures * 4
+    return 16 + nfeatures * 24 + nfeatures * 32 + nfeatures * 8
 
 
 def shard_frames(n_frames, rank, world):
@@ -19,7 +19,7 @@ def shard_frames(n_frames, rank, world):
 
 
 def pack_records(results, nfeatures):
-    """Host-side twin of ivf_frontend_pack_gather_block: list of dict(kps, desc, uright) -> uint8 [n, record]."""
+    """Host-side twin of ivf_frontend_pack_gather_block: list of dict(kps, desc, uright[, depth]) -> uint8 [n, record]."""
     rec = record_bytes(nfeatures)
     out = np.zeros((len(results), rec), np.uint8)
     for i, r in enumerate(results):
@@ -29,6 +29,8 @@ def pack_records(results, nfeatures):
         out[i, 16:16 + n * 24] = np.ascontiguousarray(r["kps"], KP_DTYPE).view(np.uint8)
         out[i, 16 + nfeatures * 24:16 + nfeatures * 24 + n * 32] = np.ascontiguousarray(r["desc"], np.uint8).reshape(-1)
         out[i, 16 + nfeatures * 56:16 + nfeatures * 56 + n * 4] = np.ascontiguousarray(r["uright"], np.float32).view(np.uint8)
+        if "depth" in r:
+            out[i, 16 + nfeatures * 60:16 + nfeatures * 60 + n * 4] = np.ascontiguousarray(r["depth"], np.float32).view(np.uint8)
     return out
 
 

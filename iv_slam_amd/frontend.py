@@ -97,13 +97,14 @@ class StereoFrontend:
 
 def unpack_gather_records(buf, nfeatures):
     """Decode records packed by ivf_frontend_pack_gather_block (host numpy uint8 buffer) -> list of dicts."""
-    rec = 16 + nfeatures * 24 + nfeatures * 32 + nfeatures * 4
+    rec = 16 + nfeatures * 24 + nfeatures * 32 + nfeatures * 8
     buf = np.ascontiguousarray(buf, np.uint8).reshape(-1, rec)
     out = []
     for r in buf:
         n = int(r[:4].view(np.int32)[0])
         kps = r[16:16 + nfeatures * 24].view(KP_DTYPE)[:n].copy()
         desc = r[16 + nfeatures * 24:16 + nfeatures * 56].reshape(nfeatures, 32)[:n].copy()
-        ur = r[16 + nfeatures * 56:].view(np.float32)[:n].copy()
-        out.append(dict(n=n, kps=kps, desc=desc, uright=ur))
+        ur = r[16 + nfeatures * 56:16 + nfeatures * 60].view(np.float32)[:n].copy()
+        dp = r[16 + nfeatures * 60:].view(np.float32)[:n].copy()
+        out.append(dict(n=n, kps=kps, desc=desc, uright=ur, depth=dp))
     return out

@@ -361,3 +361,68 @@ def update_quality_scores(frame_mps, kp_quality, mp_quality):
             mq[m] = upd
         kq[i] = upd
     return kq, mq
+
+
+# ---- Tracking::TrackWithMotionModel, matcher part (ORB/src/Tracking.cc:1303-1330), on one (last, cur) frame pair ------------
+def unproject_stereo(frame, i):
+    """Frame::UnprojectStereo (ORB/src/Frame.cc:958-972): x = (u - cx) * z * invfx in float, then mRwc * x3Dc + mOw (gemm);
+    mRwc = mRcw.t(), mOw = -mRcw.t() * mtcw (Frame::UpdatePoseMatrices, Frame.cc:549-555)."""
+    z = F(frame["depth"][i])
+    u = F(frame["kps"]["x"][i]); v = F(frame["kps"]["y"][i])
+    invfx = F(F(1.0) / F(frame["fx"])); invfy = F(F(1.0) / F(frame["fy"]))          # Frame.cc:203-204
+    x = F(F(F(u - F(frame["cx"])) * z) * invfx); y = F(F(F(v - F(frame["cy"])) * z) * invfy)
+    Rcw, tcw = frame["T"][:3, :3], frame["T"][:3, 3]
+    Ow = neg_rt_mul(Rcw, tcw)
+    return mul_add(np.ascontiguousarray(Rcw.T), np.array([x, y, z], F), Ow)
+
+
+def update_last_frame_points(last, th_depth):
+    """Tracking::UpdateLastFrame's "visual odometry" points (Tracking.cc:1256-1300): stereo points sorted by (depth, index); every
+    point is taken until one lies beyond mThDepth AND more than 100 have been taken.  Returns the selected keypoint indices in
+    ascending index order.  th_depth <= 0: every stereo point."""
+    idx = [(float(last["depth"][i]), i) for i in range(len(last["kps"])) if last["depth"][i] > 0]
+    if th_depth <= 0:
+        return [i for _, i in idx]
+    idx.sort()
+    out = []
+    n_points = 0
+    for z, i in idx:
+        out.append(i); n_points += 1
+        if z > th_depth and n_points > 100:
+            break
+    return sorted(out)
+
+
+def track_with_motion_model_matches(O, cur, last, th, th_retry, retry_below, check_orientation=True, th_depth=0.0, points_block=True,
+                                    point_flags=None):
+    """(nmatches, CurrentFrame.mvpMapPoints as last-frame keypoint indices or -1) of the matcher part of TrackWithMotionModel.
+    point_flags (per last keypoint: bit 0 = has a map point, bit 1 = Observations() > 0) overrides th_depth / points_block."""
+    if point_flags is not None:
+        sel = [i for i in range(len(last["kps"])) if last["depth"][i] > 0 and (int(point_flags[i]) & 1)]
+        obs = {i: (int(point_flags[i]) >> 1) & 1 for i in sel}
+    else:
+        sel = update_last_frame_points(last, th_depth)
+        obs = {i: (0 if th_depth > 0 else int(bool(points_block))) for i in sel}       # new VO points have no observations
+    pool = [dict(pos=unproject_stereo(last, i), desc=last["desc"][i], nObs=obs[i]) for i in sel]
+    lm = dict(last)
+    mps = np.full(len(last["kps"]), -1, np.int64)
+    for k, i in enumerate(sel):
+        mps[i] = k
+    lm["mps"] = mps; lm["outlier"] = np.zeros(len(last["kps"]), bool)
+    cur_mps = [-1] * len(cur["kps"])                                                   # fill(mvpMapPoints, NULL) (Tracking.cc:1311)
+
+    def one(th_):
+        if check_orientation:
+            return search_cur_last(O, cur, lm, pool, cur_mps, th_, False)
+        return _search_cur_last_no_ori(O, cur, lm, pool, cur_mps, th_)
+    nm, out = one(th)
+    if nm < retry_below:                                                               # Tracking.cc:1320-1330
+        nm, out = one(th_retry)
+    return nm, np.array([sel[m] if m >= 0 else -1 for m in out], np.int32)
+
+
+def _search_cur_last_no_ori(O, cur, last, pool, cur_mps, th):
+    """search_cur_last with mbCheckOrientation = false (no rotation histogram)."""
+    import types
+    shim = types.SimpleNamespace(search_by_projection=lambda k, d, u, b, q, chk, occ: O.search_by_projection(k, d, u, b, q, False, occ))
+    return search_cur_last(shim, cur, last, pool, cur_mps, th, False)

@@ -23,7 +23,8 @@ def _fake_result(frame):
     k = np.zeros(n, KP_DTYPE)
     k["x"] = rng.uniform(0, 1242, n); k["y"] = rng.uniform(0, 375, n); k["octave"] = rng.integers(0, 8, n)
     k["response"] = frame
-    return dict(kps=k, desc=rng.integers(0, 256, (n, 32)).astype(np.uint8), uright=rng.uniform(-1, 900, n).astype(np.float32))
+    return dict(kps=k, desc=rng.integers(0, 256, (n, 32)).astype(np.uint8), uright=rng.uniform(-1, 900, n).astype(np.float32),
+                depth=rng.uniform(-1, 80, n).astype(np.float32))
 
 
 def _worker(rank, world, port, n_frames, q):
@@ -43,6 +44,7 @@ def _worker(rank, world, port, n_frames, q):
         exp = _fake_result(frame); got = recs[r][j]
         ok &= got["n"] == len(exp["kps"]) and got["kps"].tobytes() == exp["kps"].tobytes()
         ok &= np.array_equal(got["desc"], exp["desc"]) and got["uright"].tobytes() == exp["uright"].tobytes()
+        ok &= got["depth"].tobytes() == exp["depth"].tobytes()
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, bool(ok), mine))
@@ -64,7 +66,7 @@ def test_shard_and_all_gather_world2():
 
 def test_record_layout_matches_c_abi_formula():
     from iv_slam_amd import dist as ivd
-    assert ivd.record_bytes(1000) == 16 + 1000 * (24 + 32 + 4)
+    assert ivd.record_bytes(1000) == 16 + 1000 * (24 + 32 + 4 + 4)
     from iv_slam_amd.frontend import unpack_gather_records
     r = _fake_result(3)
     back = unpack_gather_records(ivd.pack_records([r], NF), NF)[0]

@@ -35,6 +35,36 @@ def test_bench_line_contract():
 def test_exchange_step_single_rank():
     j = _run("--pairs", "16", "--stream", "32", "--force-gather", "--no-introspect")
     assert j["value"] > 0
+    # the exchange has a consumer: the batched tracker ran on the gathered records inside the timed region and equals the oracle
+    assert j["exchange"]["consumed"] is True and j["track"]["parity_ok"] is True and j["track"]["in_timed_region"] is True
+    assert j["track"]["frame_pairs_per_launch_sequence"] == 15 and j["track"]["mean_matches"] > 50
+    assert j["parity_spot_check"]["ok"] is True
+
+
+def test_track_flag_without_exchange():
+    j = _run("--pairs", "16", "--stream", "32", "--track")
+    assert "exchange" not in j and j["track"]["parity_ok"] is True and j["track"]["us_per_frame_pair"] > 0
+
+
+def test_two_ranks_on_one_gpu_through_gloo():
+    """The N > 1 path executes on a 1-GPU box: `bench.py --gpus 2` spawns two ranks that share device 0 (IVF_BENCH_BACKEND=gloo,
+    a test aid: blocks cross the host), all-gathers the record blocks, runs the tracker on frames extracted by the OTHER rank,
+    verifies the exchange and the MAX all-reduce, and prints ONE line with n_gpus == 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", IVF_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--pairs", "16", "--stream", "32"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
+    ex = j["exchange"]
+    assert ex["world"] == 2 and ex["backend"] == "gloo" and ex["records_checked"] == 32 and ex["consumed"] is True
+    # rank 0 tracked its frames j >= 1 against rank 1's frames j - 1 (15 pairs); consecutive GLOBAL frames re-match
+    assert j["track"]["parity_ok"] is True and j["track"]["frame_pairs_per_launch_sequence"] == 15 and j["track"]["mean_matches"] > 50
+    assert j["parity_spot_check"]["ok"] is True
 
 
 def _device_count():

@@ -601,7 +601,7 @@ def test_config3_batched_frontend_2000_features(iv):
     fe = iv.StereoFrontend(w, h, pairs, nfeatures=n, bf=BF, b=B)
     fe.run(torch.from_numpy(stream[:, 0].copy()).to(dev), torch.from_numpy(stream[:, 1].copy()).to(dev))
     rec = fe.gather_record_bytes()
-    assert rec == 16 + n * 60
+    assert rec == 16 + n * 64
     block = torch.zeros(pairs * rec, dtype=torch.uint8, device=dev)
     fe.pack_gather_block(block)
     fe.sync()

@@ -1,0 +1,228 @@
+"""Batched, device-resident tracker step (ivf_tracker_run) against the oracle: the matcher part of Tracking::TrackWithMotionModel
+(ORB/src/Tracking.cc:1303-1330) = UpdateLastFrame's stereo points (Tracking.cc:1256-1300, Frame::UnprojectStereo Frame.cc:958-972)
+-> ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, false) (ORB/src/ORBmatcher.cc:1372-1518) -> retry with 2 * th.
+Oracle = oracle/projection_oracle.track_with_motion_model_matches (numpy projection loops around the C oracle's window search
+and greedy replay).  Bar: CurrentFrame.mvpMapPoints (as last-keypoint indices) and nmatches IDENTICAL for every frame pair."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from iv_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+F = np.float32
+
+
+@pytest.fixture(scope="module")
+def iv():
+    import iv_slam_amd
+    assert iv_slam_amd.load().ivf_device_count() >= 1, "no HIP device: libivfront has no CPU fallback"
+    return iv_slam_amd
+
+
+def scale_table(nlevels=8, sf=1.2):
+    s = [F(1.0)]
+    for _ in range(1, nlevels):
+        s.append(F(np.float64(s[-1]) * np.float64(sf)))                    # ORBextractor.cc:419-425
+    return np.array(s, F)
+
+
+def pose(deg_y, t, deg_x=0.0):
+    a = math.radians(deg_y); b = math.radians(deg_x)
+    Ry = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+    Rx = np.array([[1, 0, 0], [0, math.cos(b), -math.sin(b)], [0, math.sin(b), math.cos(b)]])
+    T = np.eye(4); T[:3, :3] = Ry @ Rx; T[:3, 3] = t
+    return T.astype(F)
+
+
+def frame_dict(rec, T, cam):
+    return dict(kps=rec["kps"], desc=rec["desc"], uright=rec["uright"], depth=rec["depth"], T=T, scale=cam["scale"], fx=cam["fx"],
+                fy=cam["fy"], cx=cam["cx"], cy=cam["cy"], mbf=cam["bf"], mb=cam["b"], bounds=cam["bounds"])
+
+
+def run_tracker(iv, cam, recs, pairs, poses=None, flags=None, **kw):
+    """recs: list of dict(kps, desc, uright, depth) -> (assign [n_pairs, nf], nmatches [n_pairs]) from the device."""
+    import torch
+    from iv_slam_amd import dist as ivd
+    nf = cam["nf"]
+    dev = torch.device("cuda:0")
+    block = torch.from_numpy(ivd.pack_records(recs, nf).reshape(-1)).to(dev)
+    tr = iv.BatchTracker(nf, cam["scale"], float(cam["fx"]), float(cam["fy"]), float(cam["cx"]), float(cam["cy"]), float(cam["bf"]),
+                         cam["bounds"], max_pairs=len(pairs), b=float(cam["b"]), **kw)
+    assert tr.record_bytes == ivd.record_bytes(nf)
+    dp = torch.tensor(pairs, dtype=torch.int32, device=dev).reshape(-1, 2)
+    assign = torch.full((len(pairs), nf), -7, dtype=torch.int32, device=dev); nm = torch.full((len(pairs),), -7, dtype=torch.int32, device=dev)
+    dposes = None if poses is None else torch.from_numpy(np.stack([p[:3, :4].reshape(12) for p in poses]).astype(F)).to(dev)
+    dflags = None
+    if flags is not None:
+        fl = np.zeros((len(recs), nf), np.uint8)
+        for i, f in enumerate(flags):
+            fl[i, :len(f)] = f
+        dflags = torch.from_numpy(fl).to(dev)
+    tr.run(block, dp, assign, nm, poses=dposes, point_flags=dflags)
+    torch.cuda.synchronize()
+    return assign.cpu().numpy(), nm.cpu().numpy()
+
+
+def check_pairs(cam, recs, pairs, got_assign, got_nm, poses=None, flags=None, th=7.0, th_retry=None, retry_below=20,
+                check_orientation=True, th_depth=0.0, points_block=True, what=""):
+    import projection_oracle as PO
+    I = np.eye(4, dtype=F)
+    total = 0
+    for k, (a, b) in enumerate(pairs):
+        last = frame_dict(recs[a], I if poses is None else poses[a], cam); cur = frame_dict(recs[b], I if poses is None else poses[b], cam)
+        nm, exp = PO.track_with_motion_model_matches(O, cur, last, F(th), F(2 * th if th_retry is None else th_retry), retry_below,
+                                                     check_orientation, th_depth, points_block, None if flags is None else flags[a])
+        nC = len(cur["kps"])
+        assert got_nm[k] == nm, "%s pair %d (%d -> %d): nmatches %d vs oracle %d" % (what, k, a, b, got_nm[k], nm)
+        assert np.array_equal(got_assign[k, :nC], exp), "%s pair %d: assignment differs at %r" % (what, k, np.nonzero(got_assign[k, :nC] != exp)[0][:8])
+        assert (got_assign[k, nC:] == -1).all()
+        total += nm
+    return total
+
+
+def extracted_sequence(iv, w, h, n, frames, seed, shift=3, cost=False):
+    """consecutive "frames": the scene shifts `shift` px per frame (left AND right), extracted by the batched front end and
+    packed into gather records on the device; returns the unpacked records (kps, desc, uright, depth)."""
+    import torch
+    from iv_slam_amd.frontend import unpack_gather_records
+    L, R = synth.make_pair(w, h, seed=seed, idx=0)
+    lefts = np.stack([np.roll(L, shift * k, axis=1) for k in range(frames)]); rights = np.stack([np.roll(R, shift * k, axis=1) for k in range(frames)])
+    dev = torch.device("cuda:0")
+    bf, fx = 386.1448, 718.856
+    fe = iv.StereoFrontend(w, h, frames, nfeatures=n, bf=bf, fx=fx)
+    fe.run(torch.from_numpy(lefts).to(dev), torch.from_numpy(rights).to(dev))
+    rec = fe.gather_record_bytes()
+    block = torch.zeros(frames * rec, dtype=torch.uint8, device=dev)
+    fe.pack_gather_block(block)
+    fe.sync(); torch.cuda.synchronize()
+    recs = unpack_gather_records(block.cpu().numpy(), n)
+    for k in range(frames):                                                 # the records carry mvDepth as the front end computed it
+        r = fe.fetch(k, 0)
+        assert recs[k]["depth"].tobytes() == r["depth"].tobytes() and recs[k]["uright"].tobytes() == r["uright"].tobytes()
+    cam = dict(nf=n, scale=scale_table(), fx=F(fx), fy=F(fx), cx=F(w / 2 + 0.5), cy=F(h / 2 - 0.25), bf=F(bf), b=F(F(bf) / F(fx)),
+               bounds=(0.0, 0.0, float(w), float(h)))
+    return cam, recs, block, fe
+
+
+def test_zero_motion_kitti_shape_from_a_frontend_batch(iv):
+    """configs[1]/[2] shape: 1242x375, 1000 features, 6 consecutive frames straight from a front-end batch; zero-motion prior."""
+    cam, recs, block, fe = extracted_sequence(iv, 1242, 375, 1000, 6, seed=91)
+    pairs = [(k - 1, k) for k in range(1, 6)] + [(0, 0), (5, 2)]
+    for kw in (dict(th=7.0), dict(th=15.0, retry_below=0, check_orientation=False), dict(th=7.0, th_depth=40.0), dict(th=7.0, points_block=False)):
+        a, nm = run_tracker(iv, cam, recs, pairs, **kw)
+        tot = check_pairs(cam, recs, pairs, a, nm, what=str(kw), **kw)
+        assert tot > 1000                                                   # the shifted scene really re-matches
+    # the same through the device block the front end packed itself (no host round trip of the records)
+    import torch
+    dev = torch.device("cuda:0")
+    tr = iv.BatchTracker(1000, cam["scale"], float(cam["fx"]), float(cam["fy"]), float(cam["cx"]), float(cam["cy"]), float(cam["bf"]),
+                         cam["bounds"], max_pairs=len(pairs), b=float(cam["b"]))
+    dp = torch.tensor(pairs, dtype=torch.int32, device=dev)
+    assign = torch.empty((len(pairs), 1000), dtype=torch.int32, device=dev); nmm = torch.empty(len(pairs), dtype=torch.int32, device=dev)
+    tr.run(block, dp, assign, nmm)
+    torch.cuda.synchronize()
+    check_pairs(cam, recs, pairs, assign.cpu().numpy(), nmm.cpu().numpy(), what="device block")
+
+
+def test_poses_forward_backward_and_flags(iv):
+    """supplied poses: forward motion (levels [o, inf)), backward motion ([0, o]), small motion (+-1), rotations; explicit point flags."""
+    cam, recs, _, _ = extracted_sequence(iv, 640, 240, 500, 5, seed=92, shift=2)
+    cam["fx"] = cam["fy"] = F(370.0); cam["cx"] = F(320.0); cam["cy"] = F(120.0); cam["bf"] = F(198.75); cam["b"] = F(F(198.75) / F(370.0))
+    # depths must follow the camera: recompute mvDepth = mbf / disparity for the test camera (inputs, any positive values do)
+    for r in recs:
+        d = r["kps"]["x"] - r["uright"]
+        r["depth"] = np.where(r["uright"] >= 0, cam["bf"] / np.maximum(d, F(0.01)), F(-1)).astype(F)
+    poses = [pose(0.0, [0, 0, 0]), pose(0.15, [0.03, -0.01, -0.9]), pose(0.1, [0.0, 0.0, -0.1]), pose(-0.2, [0.01, 0.02, 0.8], 0.1), pose(0.0, [0, 0, 0.8])]
+    pairs = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 2), (4, 0)]
+    rng = np.random.default_rng(5)
+    flags = [(rng.integers(0, 4, len(r["kps"]))).astype(np.uint8) for r in recs]
+    for kw, fl in ((dict(th=7.0), None), (dict(th=15.0, retry_below=1000, th_retry=25.0), None), (dict(th=10.0, th_depth=12.0), None),
+                   (dict(th=7.0), flags)):
+        a, nm = run_tracker(iv, cam, recs, pairs, poses=poses, flags=fl, **kw)
+        check_pairs(cam, recs, pairs, a, nm, poses=poses, flags=fl, what=str(kw), **kw)
+
+
+def _random_records(rng, nf, n_frames, w, h, cluster):
+    """frames of random keypoints: frame k+1 = frame k's points jittered (descriptors with a few flipped bits, many exact
+    duplicates -> distance ties), plus clutter; `cluster` squeezes them into a small region (windows of hundreds of candidates)."""
+    from iv_slam_amd._lib import KP_DTYPE
+    recs = []
+    n0 = int(rng.integers(nf // 2, nf + 1))
+    x = rng.uniform(20, (w - 20) * cluster, n0); y = rng.uniform(20, (h - 20) * cluster, n0)
+    desc = rng.integers(0, 256, (n0, 32)).astype(np.uint8)
+    desc[rng.integers(0, n0, n0 // 4)] = desc[rng.integers(0, n0, n0 // 4)]          # duplicates
+    octv = rng.integers(0, 8, n0); ang = rng.uniform(0, 360, n0)
+    for k in range(n_frames):
+        n = len(x)
+        kp = np.zeros(n, KP_DTYPE)
+        kp["x"] = x.astype(F); kp["y"] = y.astype(F); kp["octave"] = octv; kp["angle"] = ang.astype(F); kp["size"] = 31; kp["response"] = 50
+        disp = rng.uniform(2, 60, n)
+        stereo = rng.uniform(size=n) < 0.8
+        ur = np.where(stereo, kp["x"] - disp, -1).astype(F)
+        depth = np.where(stereo, F(198.75) / disp.astype(F), F(-1)).astype(F)
+        recs.append(dict(kps=kp, desc=desc.copy(), uright=ur, depth=depth))
+        # next frame: permute, jitter, flip bits, drop some, add clutter
+        perm = rng.permutation(n)[:int(n * 0.9)]
+        x = x[perm] + rng.uniform(-4, 4, len(perm)); y = y[perm] + rng.uniform(-3, 3, len(perm))
+        octv = np.clip(octv[perm] + rng.integers(-1, 2, len(perm)), 0, 7); ang = (ang[perm] + rng.choice([0, 0, 0, 2, 45, 200], len(perm))) % 360
+        desc = desc[perm].copy()
+        flip = rng.integers(0, 256, (len(perm), 3))
+        for j in range(3):
+            sel = rng.uniform(size=len(perm)) < 0.5
+            desc[sel, flip[sel, j] // 8] ^= (1 << (flip[sel, j] % 8)).astype(np.uint8)
+        extra = min(nf - len(perm), int(rng.integers(0, nf // 8 + 1)))
+        x = np.concatenate([x, rng.uniform(0, w * cluster, extra)]); y = np.concatenate([y, rng.uniform(0, h * cluster, extra)])
+        octv = np.concatenate([octv, rng.integers(0, 8, extra)]); ang = np.concatenate([ang, rng.uniform(0, 360, extra)])
+        desc = np.concatenate([desc, rng.integers(0, 256, (extra, 32)).astype(np.uint8)])
+        x = np.clip(x, 0, w - 1); y = np.clip(y, 0, h - 1)
+    return recs
+
+
+@pytest.mark.parametrize("seed,nf,cluster,th", [(1, 300, 1.0, 7.0), (2, 600, 0.25, 12.0), (3, 1500, 0.12, 30.0), (4, 64, 1.0, 7.0), (5, 4096, 0.5, 9.0)])
+def test_random_records_ties_and_overflowing_windows(iv, seed, nf, cluster, th):
+    """seeded random frames: duplicate descriptors (first-minimum tie-break), re-assignment by points without observations,
+    windows far beyond the 64-entry candidate list (re-walked against the live state), empty frames, nfeatures up to the cap."""
+    rng = np.random.default_rng(seed)
+    w, h = 640, 240
+    cam = dict(nf=nf, scale=scale_table(), fx=F(370.0), fy=F(370.0), cx=F(320.0), cy=F(120.0), bf=F(198.75), b=F(F(198.75) / F(370.0)),
+               bounds=(0.0, 0.0, float(w), float(h)))
+    recs = _random_records(rng, nf, 5, w, h, cluster)
+    from iv_slam_amd._lib import KP_DTYPE
+    recs.append(dict(kps=np.zeros(0, KP_DTYPE), desc=np.zeros((0, 32), np.uint8), uright=np.zeros(0, F), depth=np.zeros(0, F)))   # empty frame
+    pairs = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 4), (4, 5), (5, 0), (2, 2)]
+    if cluster < 0.3:
+        # these cases must really overflow the 64-entry candidate lists (the in-place re-walk of k_track_greedy)
+        k0, k1 = recs[0]["kps"], recs[1]["kps"]
+        big = max(len(O.features_in_area(k1, cam["bounds"], float(k0["x"][i]), float(k0["y"][i]), float(F(th) * cam["scale"][k0["octave"][i]]),
+                                         int(k0["octave"][i]) - 1, int(k0["octave"][i]) + 1)) for i in range(0, len(k0), 7))
+        assert big > 64, big
+    poses = [pose(0.02 * k, [0.01 * k, 0.0, -0.05 * k]) for k in range(6)]
+    for kw, ps in ((dict(th=th), None), (dict(th=th, points_block=False, retry_below=0), poses), (dict(th=th, th_depth=6.0), None)):
+        a, nm = run_tracker(iv, cam, recs, pairs, poses=ps, **kw)
+        check_pairs(cam, recs, pairs, a, nm, poses=ps, what="seed %d %r" % (seed, kw), **kw)
+
+
+def test_tracker_argument_checks(iv):
+    import torch
+    sc = scale_table()
+    with pytest.raises(iv.IvfError):
+        iv.BatchTracker(5000, sc, 700.0, 700.0, 600.0, 180.0, 386.0, (0.0, 0.0, 1242.0, 375.0), max_pairs=4)        # beyond the LDS state
+    with pytest.raises(iv.IvfError):
+        iv.BatchTracker(1000, sc, 700.0, 700.0, 600.0, 180.0, 386.0, (0.0, 0.0, 0.0, 375.0), max_pairs=4)           # empty bounds
+    tr = iv.BatchTracker(100, sc, 700.0, 700.0, 600.0, 180.0, 386.0, (0.0, 0.0, 1242.0, 375.0), max_pairs=2)
+    dev = torch.device("cuda:0")
+    blk = torch.zeros(3 * tr.record_bytes, dtype=torch.uint8, device=dev)
+    pairs = torch.zeros((3, 2), dtype=torch.int32, device=dev)
+    out = torch.zeros((3, 100), dtype=torch.int32, device=dev); nm = torch.zeros(3, dtype=torch.int32, device=dev)
+    with pytest.raises(iv.IvfError):
+        tr.run(blk, pairs, out, nm)                                         # more pairs than max_pairs
+    tr.run(blk, pairs[:2], out, nm)                                         # empty records: no matches, nothing written out of range
+    torch.cuda.synchronize()
+    assert (nm.cpu().numpy()[:2] == 0).all() and (out.cpu().numpy()[:2] == -1).all()
