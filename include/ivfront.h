@@ -401,6 +401,8 @@ typedef struct ivf_frame ivf_frame;
 int  ivf_frame_create(const ivf_keypoint* kps, const uint8_t* desc, const float* uright, int n, const ivf_bounds* bounds,
                       int device_id, ivf_frame** out);
 void ivf_frame_destroy(ivf_frame* f);
+/* number of keypoints of the frame (Frame::N) -- NOT the number that fell inside the grid */
+int  ivf_frame_count(const ivf_frame* f);
 /* the grid as built on the device: cell_start [64*48+1] (cell = ix*48 + iy), cell_index [n] */
 int  ivf_frame_grid(const ivf_frame* f, int32_t* cell_start, int32_t* cell_index);
 /* ivf_search_by_projection against the resident frame (same query arrays, same results) */

@@ -96,6 +96,7 @@ _SIGS = {
                                       vp, vp, C.c_int]),
     "ivf_frame_create": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(Bounds), C.c_int, C.POINTER(vp)]),
     "ivf_frame_destroy": (None, [vp]),
+    "ivf_frame_count": (C.c_int, [vp]),
     "ivf_frame_grid": (C.c_int, [vp, vp, vp]),
     "ivf_frame_search_by_projection": (C.c_int, [vp, C.c_int] + [vp] * 10 + [C.c_int, vp, C.POINTER(C.c_int)]),
     "ivf_frame_search_map_points": (C.c_int, [vp, C.c_int] + [vp] * 8 + [C.c_float, vp, C.POINTER(C.c_int)]),

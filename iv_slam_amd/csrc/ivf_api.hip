@@ -7,6 +7,7 @@
 #include <cstring>
 #include <string>
 #include <map>
+#include <mutex>
 #include <vector>
 #include <algorithm>
 
@@ -321,13 +322,15 @@ int Context::check_status(int which)
 }
 
 // One growable device scratch per host thread and device: the per-call entry points (ivf_stereo_match, ivf_hamming_pairs,
-// the matchers built on it) upload their inputs here instead of paying a hipMalloc / hipFree set per call.
+// the matchers built on it, ivf_bow_transform, ivf_distinctive_descriptor) upload their inputs here instead of paying a
+// hipMalloc / hipFree set per call; nothing is left to leak on an error path.
+// Ordering assumption: every user works on the NULL stream and ends with a BLOCKING copy of its results, so two users on
+// one thread can never overlap in the buffer.  The buffer is deliberately NOT freed by a thread_local destructor: for the
+// main thread that would run during static destruction, possibly after the HIP runtime has gone (it is released when the
+// buffer grows, and with the process).
 int thread_scratch(int device, size_t need, uint8_t** out)
 {
-    struct Scratch {
-        int device = -1; uint8_t* buf = nullptr; size_t cap = 0;
-        ~Scratch() { if (buf) { (void)hipSetDevice(device); (void)hipFree(buf); } }
-    };
+    struct Scratch { int device = -1; uint8_t* buf = nullptr; size_t cap = 0; };
     static thread_local Scratch sc;
     if (sc.device != device || sc.cap < need) {
         if (sc.buf) { (void)hipSetDevice(sc.device); (void)hipDeviceSynchronize(); (void)hipFree(sc.buf); sc.buf = nullptr; sc.cap = 0; }
@@ -343,7 +346,7 @@ int thread_scratch(int device, size_t need, uint8_t** out)
 // growable pinned host scratch per host thread (row-wise unpacking of pitched device planes)
 int thread_pinned(size_t need, uint8_t** out)
 {
-    struct Pin { uint8_t* p = nullptr; size_t cap = 0; ~Pin() { if (p) (void)hipHostFree(p); } };
+    struct Pin { uint8_t* p = nullptr; size_t cap = 0; };      // not freed at thread exit: see thread_scratch
     static thread_local Pin pin;
     if (pin.cap < need) {
         if (pin.p) { (void)hipHostFree(pin.p); pin.p = nullptr; pin.cap = 0; }
@@ -527,11 +530,15 @@ int ivf_extract(ivf_extractor* e, const uint8_t* image, int width, int height, i
         if (e->haveCtx) { e->ctx.release(); e->haveCtx = false; }
         rc = e->ctx.build(e->t, width, height, 1, 1, e->device, true, e->var);
         if (rc) { e->ctx.release(); return rc; }
+        // staging is part of the context: the handle only counts as built once all of it exists (release() frees what does)
+        e->ctx.stageBytes = ((size_t)width * height * 2 + 15) & ~(size_t)15;       // keypoints / counters behind it stay 16-byte aligned
+        if (hipMalloc(&e->ctx.dStage, e->ctx.stageBytes) != hipSuccess ||
+            hipHostMalloc((void**)&e->ctx.hStage, e->ctx.stageBytes + (size_t)e->t.p.nfeatures * (sizeof(ivf_keypoint) + 32) + 64, hipHostMallocDefault) != hipSuccess ||
+            (!e->dOne && (hipMalloc(&e->dOne, 1) != hipSuccess || hipMemset(e->dOne, 1, 1) != hipSuccess))) {
+            e->ctx.release();
+            return fail(IVF_E_NO_DEVICE, "staging allocation failed for a %dx%d extractor", width, height);
+        }
         e->haveCtx = true; e->w = width; e->h = height;
-        e->ctx.stageBytes = (size_t)width * height * 2;
-        HIPCHK(hipMalloc(&e->ctx.dStage, e->ctx.stageBytes));
-        HIPCHK(hipHostMalloc((void**)&e->ctx.hStage, e->ctx.stageBytes + (size_t)e->t.p.nfeatures * (sizeof(ivf_keypoint) + 32) + 64, hipHostMallocDefault));
-        if (!e->dOne) { HIPCHK(hipMalloc(&e->dOne, 1)); HIPCHK(hipMemset(e->dOne, 1, 1)); }
     }
     e->extracted = false;
     Context& c = e->ctx;
@@ -829,6 +836,46 @@ int ivf_search_by_projection_ex(const ivf_keypoint* cur_kps, const uint8_t* cur_
 }
 
 // ---- device-resident frame: keypoints, descriptors and the 64x48 grid stay in HBM between searches -----------------
+// A frame's device memory is ONE arena (keypoints | descriptors | uRight | grid start | grid index) with a stream of its own,
+// and its query scratch a second one; both come from a per-process pool and go back to it in ivf_frame_destroy, so a tracker
+// that makes a frame per image pays hipMalloc / hipStreamCreate only until the pool is warm (r02: five hipMalloc + a stream
+// per frame = 0.5 ms).
+namespace {
+struct Arena { int device = -1; uint8_t* base = nullptr; size_t cap = 0; hipStream_t stream = nullptr; };
+struct ArenaPool {
+    std::mutex m; std::vector<Arena> idle;
+    int acquire(int device, size_t need, Arena& out)
+    {
+        {
+            std::lock_guard<std::mutex> g(m);
+            int best = -1;
+            for (int i = 0; i < (int)idle.size(); i++)
+                if (idle[i].device == device && idle[i].cap >= need && (best < 0 || idle[i].cap < idle[best].cap)) best = i;
+            if (best >= 0) { out = idle[best]; idle.erase(idle.begin() + best); return IVF_OK; }
+        }
+        Arena a; a.device = device;
+        a.cap = ((need + need / 4) + 65535) & ~(size_t)65535;         // slack: frames of slightly different sizes share arenas
+        if (hipMalloc(&a.base, a.cap) != hipSuccess) return fail(IVF_E_NO_DEVICE, "hipMalloc of a %zu-byte frame arena failed", a.cap);
+        if (hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipFree(a.base); return fail(IVF_E_NO_DEVICE, "stream creation failed"); }
+        out = a;
+        return IVF_OK;
+    }
+    void release(Arena& a)
+    {
+        if (!a.base) return;
+        (void)hipStreamSynchronize(a.stream);                         // nothing of the old owner may still be in flight
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (idle.size() < 64) { idle.push_back(a); a = Arena(); return; }
+        }
+        (void)hipFree(a.base); (void)hipStreamDestroy(a.stream);
+        a = Arena();
+    }
+};
+ArenaPool* frame_pool_ptr() { static ArenaPool* p = new ArenaPool(); return p; }   // never destroyed: no HIP calls during static destruction
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+}  // namespace
+
 struct ivf_frame {
     int device = 0, n = 0;
     ivf_bounds bd{};
@@ -836,6 +883,7 @@ struct ivf_frame {
     std::vector<ivf_keypoint> kps;      // host copies for the greedy replay (angle, uRight)
     std::vector<float> uright;
     std::vector<uint8_t> desc;          // host copy for the overflow fallback
+    Arena mem, qmem;                    // frame data / query scratch (pooled)
     ivf_keypoint* dKps = nullptr; uint8_t* dDesc = nullptr; int *dStart = nullptr, *dIdx = nullptr;
     // query scratch, grown on demand
     int qCap = 0, cCap = 0;
@@ -845,6 +893,20 @@ struct ivf_frame {
     float* dUright = nullptr;           // frames made from a front-end batch: uRight stays on the device until a replay needs it
     bool hostKps = true, hostDesc = true;   // host mirrors present (false: fetched on first use, see frame_host)
 };
+
+// carve the frame arena for n keypoints
+static int frame_alloc(ivf_frame* f, int n)
+{
+    const size_t nn = (size_t)std::max(n, 1);
+    const size_t oK = 0, oD = oK + up256(nn * sizeof(ivf_keypoint)), oU = oD + up256(nn * 32), oS = oU + up256(nn * sizeof(float)),
+                 oI = oS + up256((GC * GR + 1) * sizeof(int)), total = oI + up256(nn * sizeof(int));
+    const int rc = frame_pool_ptr()->acquire(f->device, total, f->mem);
+    if (rc) return rc;
+    uint8_t* b = f->mem.base;
+    f->dKps = (ivf_keypoint*)(b + oK); f->dDesc = b + oD; f->dUright = (float*)(b + oU); f->dStart = (int*)(b + oS); f->dIdx = (int*)(b + oI);
+    f->stream = f->mem.stream;
+    return IVF_OK;
+}
 
 // the greedy replays read angle / octave / uRight of the frame's keypoints on the host, the overflow fallback its descriptors:
 // frames created from host arrays carry them; frames created from a front-end batch fetch them on first use (28 B per keypoint)
@@ -873,10 +935,14 @@ void ivf_frame_destroy(ivf_frame* f)
 {
     if (!f) return;
     (void)hipSetDevice(f->device);
-    void* ptrs[] = {f->dUright, f->dKps, f->dDesc, f->dStart, f->dIdx, f->dQu, f->dQv, f->dQr, f->dQmin, f->dQmax, f->dQdesc, f->dQvalid, f->dCount, f->dCand};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (f->stream) (void)hipStreamDestroy(f->stream);
+    frame_pool_ptr()->release(f->mem);
+    frame_pool_ptr()->release(f->qmem);
     delete f;
+}
+
+int ivf_frame_count(const ivf_frame* f)
+{
+    return f ? f->n : fail(IVF_E_INVALID, "null handle");
 }
 
 int ivf_frame_create(const ivf_keypoint* kps, const uint8_t* desc, const float* uright, int n, const ivf_bounds* bounds,
@@ -893,13 +959,8 @@ int ivf_frame_create(const ivf_keypoint* kps, const uint8_t* desc, const float* 
     f->device = device_id; f->n = n; f->bd = *bounds;
     f->invW = (float)GC / (bounds->max_x - bounds->min_x); f->invH = (float)GR / (bounds->max_y - bounds->min_y);   // Frame.cc:208-209
     f->kps.assign(kps, kps + n); f->uright.assign(uright, uright + n); f->desc.assign(desc, desc + (size_t)n * 32);
-    const size_t nn = (size_t)std::max(n, 1);
-    if (hipMalloc(&f->dKps, nn * sizeof(ivf_keypoint)) != hipSuccess || hipMalloc(&f->dDesc, nn * 32) != hipSuccess ||
-        hipMalloc(&f->dStart, (GC * GR + 1) * sizeof(int)) != hipSuccess || hipMalloc(&f->dIdx, nn * sizeof(int)) != hipSuccess ||
-        hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) {
-        ivf_frame_destroy(f);
-        return fail(IVF_E_NO_DEVICE, "device allocation failed for a frame of %d keypoints", n);
-    }
+    rc = frame_alloc(f, n);
+    if (rc) { ivf_frame_destroy(f); return rc; }
     if (n > 0) {
         if (hipMemcpyAsync(f->dKps, kps, (size_t)n * sizeof(ivf_keypoint), hipMemcpyHostToDevice, f->stream) != hipSuccess ||
             hipMemcpyAsync(f->dDesc, desc, (size_t)n * 32, hipMemcpyHostToDevice, f->stream) != hipSuccess) {
@@ -935,14 +996,16 @@ static int frame_candidates(ivf_frame* f, int n_q, const float* q_u, const float
     static const int capEnv = getenv("IVF_FRAME_WINDOW_CAP") ? atoi(getenv("IVF_FRAME_WINDOW_CAP")) : 0;   // tests: force the overflow path
     const int cap = capEnv > 0 ? capEnv : 128;
     if (n_q > f->qCap || cap > f->cCap) {
-        void** ptrs[] = {(void**)&f->dQu, (void**)&f->dQv, (void**)&f->dQr, (void**)&f->dQmin, (void**)&f->dQmax, (void**)&f->dQdesc,
-                         (void**)&f->dQvalid, (void**)&f->dCount, (void**)&f->dCand};
-        for (void** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
+        frame_pool_ptr()->release(f->qmem);
         f->qCap = 0;
         const size_t nq = (size_t)n_q + 256;
-        HIPCHK(hipMalloc(&f->dQu, nq * 4)); HIPCHK(hipMalloc(&f->dQv, nq * 4)); HIPCHK(hipMalloc(&f->dQr, nq * 4));
-        HIPCHK(hipMalloc(&f->dQmin, nq * 4)); HIPCHK(hipMalloc(&f->dQmax, nq * 4)); HIPCHK(hipMalloc(&f->dQdesc, nq * 32));
-        HIPCHK(hipMalloc(&f->dQvalid, nq)); HIPCHK(hipMalloc(&f->dCount, nq * 4)); HIPCHK(hipMalloc(&f->dCand, nq * cap * 8));
+        const size_t o1 = up256(nq * 4), oDesc = 5 * o1, oValid = oDesc + up256(nq * 32), oCount = oValid + up256(nq), oCand = oCount + o1,
+                     total = oCand + up256(nq * cap * 8);
+        const int prc = frame_pool_ptr()->acquire(f->device, total, f->qmem);
+        if (prc) return prc;
+        uint8_t* b = f->qmem.base;
+        f->dQu = (float*)b; f->dQv = (float*)(b + o1); f->dQr = (float*)(b + 2 * o1); f->dQmin = (int*)(b + 3 * o1); f->dQmax = (int*)(b + 4 * o1);
+        f->dQdesc = b + oDesc; f->dQvalid = b + oValid; f->dCount = (int*)(b + oCount); f->dCand = (int*)(b + oCand);
         f->qCap = (int)nq; f->cCap = cap;
     }
     hipStream_t st = f->stream;
@@ -1729,9 +1792,12 @@ int ivf_vocabulary_create(int n_nodes, const int32_t* child_start, const int32_t
     v->childStart.assign(child_start, child_start + n_nodes + 1);
     if (hipMalloc(&v->dChildStart, (size_t)(n_nodes + 1) * sizeof(int)) != hipSuccess || hipMalloc(&v->dChild, (size_t)std::max(nChild, 1) * sizeof(int)) != hipSuccess ||
         hipMalloc(&v->dDesc, (size_t)n_nodes * 32) != hipSuccess) { ivf_vocabulary_destroy(v); return fail(IVF_E_NO_DEVICE, "hipMalloc failed for the vocabulary"); }
-    HIPCHK(hipMemcpy(v->dChildStart, child_start, (size_t)(n_nodes + 1) * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(v->dChild, child, (size_t)nChild * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(v->dDesc, node_desc, (size_t)n_nodes * 32, hipMemcpyHostToDevice));
+    if (hipMemcpy(v->dChildStart, child_start, (size_t)(n_nodes + 1) * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(v->dChild, child, (size_t)nChild * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(v->dDesc, node_desc, (size_t)n_nodes * 32, hipMemcpyHostToDevice) != hipSuccess) {
+        ivf_vocabulary_destroy(v);
+        return fail(IVF_E_NO_DEVICE, "vocabulary upload failed");
+    }
     *out = v;
     return IVF_OK;
 }
@@ -1751,14 +1817,15 @@ int ivf_bow_transform(const ivf_vocabulary* v, const uint8_t* desc, int n, int l
     if (!v || n < 0 || (n > 0 && (!desc || !word_id || !node_id || !weight))) return fail(IVF_E_INVALID, "bad argument");
     if (n == 0) return IVF_OK;
     HIPCHK(hipSetDevice(v->device));
-    uint8_t* dD = nullptr; int* dOut = nullptr;
-    HIPCHK(hipMalloc(&dD, (size_t)n * 32)); HIPCHK(hipMalloc(&dOut, (size_t)n * 2 * sizeof(int)));
-    HIPCHK(hipMemcpy(dD, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+    uint8_t* scb = nullptr;
+    const int src = thread_scratch(v->device, (size_t)n * 32 + 256 + (size_t)n * 2 * sizeof(int), &scb);
+    if (src) return src;
+    uint8_t* dD = scb; int* dOut = (int*)(scb + (((size_t)n * 32 + 255) & ~(size_t)255));
+    HIPCHK(hipMemcpyAsync(dD, desc, (size_t)n * 32, hipMemcpyHostToDevice, nullptr));
     launch_bow_transform(v->dChildStart, v->dChild, v->dDesc, dD, n, v->depth - levelsup, dOut, dOut + n, nullptr);
     HIPCHK(hipGetLastError());
     std::vector<int> res((size_t)n * 2);
     HIPCHK(hipMemcpy(res.data(), dOut, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost));
-    (void)hipFree(dD); (void)hipFree(dOut);
     for (int f = 0; f < n; f++) {
         const int leaf = res[f];
         word_id[f] = v->word[leaf]; weight[f] = v->weight[leaf]; node_id[f] = res[(size_t)n + f];
@@ -1805,14 +1872,15 @@ int ivf_distinctive_descriptor(const uint8_t* desc, int n, int* best_index, int*
     int rc = have_device(device_id);
     if (rc) return rc;
     HIPCHK(hipSetDevice(device_id));
-    uint8_t* dD = nullptr; int* dM = nullptr;
-    HIPCHK(hipMalloc(&dD, (size_t)n * 32)); HIPCHK(hipMalloc(&dM, (size_t)n * sizeof(int)));
-    HIPCHK(hipMemcpy(dD, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+    uint8_t* scb = nullptr;
+    rc = thread_scratch(device_id, (size_t)n * 32 + 256 + (size_t)n * sizeof(int), &scb);
+    if (rc) return rc;
+    uint8_t* dD = scb; int* dM = (int*)(scb + (((size_t)n * 32 + 255) & ~(size_t)255));
+    HIPCHK(hipMemcpyAsync(dD, desc, (size_t)n * 32, hipMemcpyHostToDevice, nullptr));
     launch_distinct_median(dD, n, dM, nullptr);
     HIPCHK(hipGetLastError());
     std::vector<int> med(n);
     HIPCHK(hipMemcpy(med.data(), dM, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-    (void)hipFree(dD); (void)hipFree(dM);
     int bm = INT_MAX, bi = 0;
     for (int i = 0; i < n; i++) if (med[i] < bm) { bm = med[i]; bi = i; }
     *best_index = bi;
@@ -1844,13 +1912,14 @@ int ivf_test_retain_best(const float* responses, int n, int n_points, int32_t* o
     int rc = have_device(device_id);
     if (rc) return rc;
     HIPCHK(hipSetDevice(device_id));
-    float* dR = nullptr; int* dO = nullptr;
-    HIPCHK(hipMalloc(&dR, (size_t)n * sizeof(float))); HIPCHK(hipMalloc(&dO, (size_t)n * sizeof(int)));
-    HIPCHK(hipMemcpy(dR, responses, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    uint8_t* scb = nullptr;
+    rc = thread_scratch(device_id, (size_t)n * 8 + 256, &scb);
+    if (rc) return rc;
+    float* dR = (float*)scb; int* dO = (int*)(scb + (((size_t)n * 4 + 255) & ~(size_t)255));
+    HIPCHK(hipMemcpyAsync(dR, responses, (size_t)n * sizeof(float), hipMemcpyHostToDevice, nullptr));
     launch_test_retain_best(dR, n, n_points, dO, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(order_out, dO, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-    (void)hipFree(dR); (void)hipFree(dO);
     return IVF_OK;
 }
 
@@ -2086,16 +2155,13 @@ int ivf_frame_create_from_frontend(ivf_frontend* fe, int age, int pair, int side
     f->device = dev; f->bd = *bounds; f->hostKps = false; f->hostDesc = false;
     f->invW = (float)GC / (bounds->max_x - bounds->min_x); f->invH = (float)GR / (bounds->max_y - bounds->min_y);
     auto bail = [&](const char* what) { ivf_frame_destroy(f); return fail(IVF_E_NO_DEVICE, "%s failed for a frame from the front end", what); };
-    if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) return bail("stream creation");
+    // sized for the batch's capacity: the (pooled) arena is acquired before the keypoint count is known
+    if (frame_alloc(f, (int)nf) != IVF_OK) { ivf_frame_destroy(f); return IVF_E_NO_DEVICE; }
     int n = 0;
     if (hipStreamWaitEvent(f->stream, fe->evDone[k], 0) != hipSuccess ||
         hipMemcpyAsync(&n, b.count + img, sizeof(int), hipMemcpyDeviceToHost, f->stream) != hipSuccess ||
         hipStreamSynchronize(f->stream) != hipSuccess) return bail("count read");
     f->n = n;
-    const size_t nn = (size_t)std::max(n, 1);
-    if (hipMalloc(&f->dKps, nn * sizeof(ivf_keypoint)) != hipSuccess || hipMalloc(&f->dDesc, nn * 32) != hipSuccess ||
-        hipMalloc(&f->dUright, nn * sizeof(float)) != hipSuccess || hipMalloc(&f->dStart, (GC * GR + 1) * sizeof(int)) != hipSuccess ||
-        hipMalloc(&f->dIdx, nn * sizeof(int)) != hipSuccess) return bail("allocation");
     if (n > 0) {
         if (hipMemcpyAsync(f->dKps, b.kps + img * nf, (size_t)n * sizeof(ivf_keypoint), hipMemcpyDeviceToDevice, f->stream) != hipSuccess ||
             hipMemcpyAsync(f->dDesc, b.desc + img * nf * 32, (size_t)n * 32, hipMemcpyDeviceToDevice, f->stream) != hipSuccess)

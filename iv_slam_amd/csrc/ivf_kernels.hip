@@ -516,7 +516,11 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
         if (!ok) return;
         const int crow = (int)(ri >> 8), ccol = (int)(ci >> 8);
         const int lr = crow - firstRow, lc = ccol - firstCol;
-        s_list[atomicAdd(&s_n, 1)] = ((unsigned)(y0 + sy - 1) << 20) | ((unsigned)(x0 + sx - 1) << 8) | (unsigned)s;
+        // kTileCap (one strict maximum per 2x2 block) is not a strict bound: maxima on both sides of a CELL border do not see each
+        // other.  A tile that exceeds it keeps its true count in tileCnt, so the selection kernels' consistency check (survivors
+        // gathered != survivors counted) reports the batch instead of LDS being overrun here.
+        const int pos = atomicAdd(&s_n, 1);
+        if (pos < kTileCap) s_list[pos] = ((unsigned)(y0 + sy - 1) << 20) | ((unsigned)(x0 + sx - 1) << 8) | (unsigned)s;
         if (lr >= 0 && lr < kLocalCells / 4 && lc >= 0 && lc < 4) {
             atomicAdd(&s_cnt[lr * 4 + lc], 1);
             if (s >= iniTh) atomicAdd(&s_ini[lr * 4 + lc], 1);
@@ -557,7 +561,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     }
     const int n = s_n;
     unsigned* out = tileList + ((size_t)img * cfg->nTiles + bx) * kTileCap;
-    for (int i = tid; i < n; i += 256) out[i] = s_list[i];
+    for (int i = tid; i < min(n, kTileCap); i += 256) out[i] = s_list[i];
     if (tid == 0) tileCnt[(size_t)img * cfg->nTiles + bx] = n;
 }
 

@@ -450,9 +450,9 @@ class DeviceFrame:
         h = C.c_void_p()
         check(self._lib.ivf_frame_create_from_frontend(fe._h, int(age), int(pair), int(side), C.byref(bd), C.byref(h)))
         self._h = h
-        st = np.zeros(64 * 48 + 1, np.int32); ix = np.zeros(fe.nfeatures, np.int32)
-        check(self._lib.ivf_frame_grid(self._h, ptr(st), ptr(ix)))
-        self.n = int(st[-1])            # keypoints inside the grid = all of them for in-image keypoints
+        self.n = int(self._lib.ivf_frame_count(self._h))     # Frame::N: every keypoint, also those PosInGrid leaves out of the grid
+        if self.n < 0:
+            check(self.n)
         return self
 
     @staticmethod
