@@ -104,9 +104,10 @@ def cpu_baseline(pairs_sample, cores, threads_per_pair=1):
 
 
 def cpu_fcn_baseline(threads, images=8, reps=3):
-    """The introspection FCN's layer list through torch.nn.functional on host cores (oracle/fcn_oracle_torch.py: PyTorch's
-    CPU convolution kernels with `threads` intra-op threads, batch of `images` per forward) -- what the reference's libtorch
-    CPU path executes, minus TorchScript.  Returns (images/s, seconds)."""
+    """The introspection FCN on host cores the way the reference runs it: a FROZEN TorchScript module (torch.jit.trace +
+    torch.jit.freeze of the layer list, oracle/fcn_oracle_torch.frozen -- what torch::jit::load + forward execute at
+    ORB/Examples/Stereo/stereo_kitti.cc:236, :508), PyTorch's CPU kernels with `threads` intra-op threads, batches of `images`.
+    Returns (images/s, seconds)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import torch
@@ -116,12 +117,80 @@ def cpu_fcn_baseline(threads, images=8, reps=3):
     T = fcn_oracle_torch.prepare(fcn_weights.make_seeded_weights(7))
     img = np.stack([np.stack([synth.make_left(W, H, seed=901, idx=c + 3 * k) for c in range(3)], axis=-1) for k in range(2)])
     batch = np.concatenate([img] * (images // 2))
-    fcn_oracle_torch.forward(T, batch[:2], (H, W))
+    run = fcn_oracle_torch.frozen(T, batch, (H, W))
+    run(batch)
     t0 = time.perf_counter()
     for _ in range(reps):
-        fcn_oracle_torch.forward(T, batch, (H, W))
+        run(batch)
     dt = time.perf_counter() - t0
     return reps * len(batch) / dt, dt
+
+
+def oracle_checksum():
+    """sha1 over what the loaded oracle produces for one seeded pair: the -march=native build must equal the portable one."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hashlib
+    import oracle_lib as O
+    from iv_slam_amd import synth
+    L, R = synth.make_pair(W, H, seed=900, idx=0)
+    eL = O.Extractor(NFEAT, 1.2, 8, 20, 7); eR = O.Extractor(NFEAT, 1.2, 8, 20, 7)
+    kL, dL = eL(L); kR, dR = eR(R)
+    ur, dp = O.stereo_match(eL, eR, kL, dL, kR, dR, BF, BF / FX)
+    return hashlib.sha1(kL.tobytes() + dL.tobytes() + kR.tobytes() + dR.tobytes() + ur.tobytes() + dp.tobytes()).hexdigest()
+
+
+def cpu_baseline_worker(introspect):
+    """Runs in a FRESH process (bench.py --cpu-baseline-worker): the oracle library named by IVF_ORACLE_SO -- the reference's
+    own build flags, -O3 -march=native (ORB/CMakeLists.txt:16-17), compiled on this host -- and the frozen-TorchScript FCN leg."""
+    cores = max(1, min(os.cpu_count() or 1, 32))
+    sample = max(128, 8 * cores)
+    v, secs = cpu_baseline(sample, cores)
+    v2, secs2 = cpu_baseline(max(32, 2 * cores), cores, threads_per_pair=2)
+    out = {"cores": cores, "sample_pairs": sample, "extract_match_all_cores": v, "secs": secs, "extract_match_two_threads_per_pair": v2,
+           "checksum": oracle_checksum(), "oracle_so": os.environ.get("IVF_ORACLE_SO", "oracle/libivf_oracle.so")}
+    if introspect:
+        fv, fsecs = cpu_fcn_baseline(cores)
+        out.update(fcn_images_per_s=fv, fcn_secs=fsecs)
+    print("CPU_BASELINE " + json.dumps(out), flush=True)
+
+
+def run_cpu_baseline(introspect):
+    """cpu_baseline object of the JSON line: builds the oracle -march=native for THIS host (fallback: the portable -march=x86-64-v2
+    library that travels with the repo), times it in a fresh process, checks the native build against the portable one."""
+    import subprocess
+    native = os.path.join(ROOT, "oracle", "_native")
+    so = os.path.join(native, "libivf_oracle.so")
+    flags = "-O3 -march=native -ffp-contract=off"
+    try:
+        os.makedirs(native, exist_ok=True)
+        subprocess.check_call(["gcc"] + flags.split() + ["-fPIC", "-std=gnu11", "-shared", "-o", so, os.path.join(ROOT, "oracle", "ivf_oracle.c"), "-lm"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        so, flags = None, "-O3 -march=x86-64-v2 -ffp-contract=off (no compiler on this host: the portable build)"
+    env = dict(os.environ)
+    if so:
+        env["IVF_ORACLE_SO"] = so
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"] + ([] if introspect else ["--no-introspect"]),
+                       env=env, capture_output=True, text=True, timeout=1200)
+    line = [l for l in r.stdout.splitlines() if l.startswith("CPU_BASELINE ")]
+    if r.returncode != 0 or not line:
+        raise RuntimeError("cpu baseline worker failed: " + r.stderr[-1500:])
+    w = json.loads(line[0][len("CPU_BASELINE "):])
+    same = w["checksum"] == oracle_checksum()
+    v = w["extract_match_all_cores"]
+    txt = ("%d pairs of the same 1242x375/1000-feature workload, one pair per thread, %.1f s wall (oracle/ivf_oracle.c, scalar C, %s)"
+           % (w["sample_pairs"], w["secs"], flags))
+    extra = {"extract_match_all_cores": round(v, 2), "extract_match_two_threads_per_pair": round(w["extract_match_two_threads_per_pair"], 2),
+             "oracle_build": flags, "native_build_equals_portable_build": bool(same)}
+    if introspect:
+        fv = w["fcn_images_per_s"]
+        txt += ("; + introspection FCN as a frozen TorchScript module (torch.jit.trace + freeze of the layer list, oracle/fcn_oracle_torch.py; "
+                "PyTorch CPU kernels, %d intra-op threads, batches of 8), %.1f s wall = %.2f images/s; extract+match alone = %.1f pairs/s; "
+                "value = 1/(1/a + 1/b)" % (w["cores"], w["fcn_secs"], fv, v))
+        extra["fcn_images_per_s"] = round(fv, 2); extra["fcn_threads"] = w["cores"]
+        extra["reference_threading_model"] = round(1.0 / (1.0 / w["extract_match_two_threads_per_pair"] + 1.0 / fv), 3)
+        v = 1.0 / (1.0 / v + 1.0 / fv)
+    return dict({"value": round(v, 3), "unit": "pairs/s", "cores": w["cores"], "kind": "port", "sample": txt}, **extra)
 
 
 def parity_spot_check(spot, introspect):
@@ -301,6 +370,7 @@ def main():
     ap.add_argument("--introspect", action="store_true", help="(default) configs[2]: run the introspection FCN on every left image and gate keypoints with it")
     ap.add_argument("--no-introspect", action="store_true", help="configs[1]: extract + match only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-extras", action="store_true", help="skip the post-run latency / PCIe-inclusive / configs[1] measurements")
     ap.add_argument("--force-gather", action="store_true", help="test aid: run the multi-GPU exchange step (RCCL all-gather of "
                     "the descriptor records) even with one rank")
@@ -310,6 +380,8 @@ def main():
                     "rocprofv3 kernel durations are not inflated by the overlap of consecutive batches")
     args = ap.parse_args()
     args.introspect = not args.no_introspect
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker(args.introspect)
     BPS = args.batches_per_step if args.batches_per_step > 0 else (16 if args.introspect else 64)
 
     # N>1 without a launcher: start one rank per GPU as a FRESH child (torch.distributed.run) before this process has
@@ -441,10 +513,12 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
+    launches0 = iv.load().ivf_debug_launch_count()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
-    host_enqueue_ms = (time.perf_counter() - t0) * 1e3 / max(args.steps, 1)      # host time to enqueue one step
+    host_enqueue_bp_ms = (time.perf_counter() - t0) * 1e3 / max(args.steps, 1)   # host time in the enqueue loop of one step: includes
+    launches = iv.load().ivf_debug_launch_count() - launches0                    # waiting on the full HIP queue (back-pressure)
     fe.sync()                                           # batches run on the front end's own streams: wait for all of
     torch.cuda.synchronize(dev)                         # them (also checks the device-side consistency flags)
     if world > 1:
@@ -497,6 +571,16 @@ def main():
         if exch is not None:
             exch["consumed"] = True
             exch["consumer"] = "ivf_tracker_run: SearchByProjection(cur, last) of every frame this rank extracted against the frame before it, out of the gathered records"
+
+    # host cost of enqueuing one step when nothing pushes back: two launch sequences into EMPTY queues (they fit), timed on the host
+    fe.sync(); torch.cuda.synchronize(dev)
+    enq = []
+    for rep in range(3):
+        t1 = time.perf_counter()
+        sub_batch(2 * rep); sub_batch(2 * rep + 1)
+        enq.append((time.perf_counter() - t1) / 2)
+        fe.sync(); torch.cuda.synchronize(dev)
+    host_enqueue_ms = min(enq) * 1e3 * BPS
 
     # ---- after the timed region -------------------------------------------------------------------------------------
     # The front end overlaps consecutive batches on its own streams, so inside the timed region the probed kernel shares
@@ -551,15 +635,20 @@ def main():
         raise SystemExit(3)
     if rank == 0:
         def load_pmc(kernel_key):
-            # HBM traffic from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE are collected in separate
+            # HBM traffic REPLAYED from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE are collected in separate
             # runs because counters cannot be read inside this process), per image, rescaled to this launch size.  The
-            # entry is used only when it was recorded for the kernel the probe actually timed (name match).
-            for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+            # entry is used only when it was recorded for the kernel the probe actually timed (name match); the source string
+            # names the file, the commit it was collected at (when recorded) and the file's own hash.
+            import hashlib
+            for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
                 try:
-                    pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    path = os.path.join(ROOT, "profiles", name)
+                    raw = open(path, "rb").read()
+                    pmc = json.loads(raw)
                     k = pmc["kernels"][kernel_key]
-                    return (k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]) / k.get("images_per_launch", pmc["images_per_launch"]), \
-                        "profiles/" + name
+                    src = "replayed from profiles/%s (sha1 %s%s): separate rocprofv3 --pmc passes, not measured in this run" % (
+                        name, hashlib.sha1(raw).hexdigest()[:12], ", collected at commit %s" % pmc["commit"] if "commit" in pmc else "")
+                    return (k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]) / k.get("images_per_launch", pmc["images_per_launch"]), src
                 except Exception:
                     continue
             return None, None
@@ -606,7 +695,10 @@ def main():
             roofline = fast_roof
         out = {
             "metric": METRIC, "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "host_enqueue_ms_per_step": round(host_enqueue_ms, 4), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),
+            "host_enqueue_ms_per_step_incl_backpressure": round(host_enqueue_bp_ms, 4),
+            "launches_per_step": round(launches / max(args.steps, 1), 1), "launches_per_launch_sequence": round(launches / max(args.steps * BPS, 1), 1),
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 (ORB) + f32 via split-f16 MFMA (FCN)" if args.introspect else "u8",
             "data": "synthetic",
             "config": {"workload": ("configs[2]: 1242x375 stereo stream with introspection FCN cost-map forward (MFMA convs) gating keypoints, "
@@ -638,22 +730,7 @@ def main():
         if h2d is not None:
             out["h2d_included"] = h2d
         if not args.no_cpu_baseline:
-            cores = max(1, min(os.cpu_count() or 1, 32))
-            sample = max(128, 8 * cores)
-            v, secs = cpu_baseline(sample, cores)
-            v2, secs2 = cpu_baseline(max(32, 2 * cores), cores, threads_per_pair=2)
-            txt = ("%d pairs of the same 1242x375/1000-feature workload, one pair per thread, %.1f s wall "
-                   "(oracle/libivf_oracle.so, scalar C, -O3 -ffp-contract=off)" % (sample, secs))
-            extra = {"extract_match_all_cores": round(v, 2), "extract_match_two_threads_per_pair": round(v2, 2)}
-            if args.introspect:
-                fv, fsecs = cpu_fcn_baseline(cores)
-                txt += ("; + introspection FCN: the layer list through torch.nn.functional (oracle/fcn_oracle_torch.py, PyTorch CPU "
-                        "kernels, %d intra-op threads, batches of 8), %.1f s wall = %.2f images/s; extract+match alone = %.1f pairs/s; "
-                        "value = 1/(1/a + 1/b)" % (cores, fsecs, fv, v))
-                extra["fcn_images_per_s"] = round(fv, 2)
-                extra["reference_threading_model"] = round(1.0 / (1.0 / v2 + 1.0 / fv), 3)
-                v = 1.0 / (1.0 / v + 1.0 / fv)
-            out["cpu_baseline"] = dict({"value": round(v, 3), "unit": "pairs/s", "cores": cores, "kind": "port", "sample": txt}, **extra)
+            out["cpu_baseline"] = run_cpu_baseline(args.introspect)
         print(json.dumps(out), flush=True)
     if exchange:
         dist.destroy_process_group()

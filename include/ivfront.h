@@ -59,6 +59,7 @@ typedef struct ivf_frontend  ivf_frontend;    /* batched, device-resident stereo
 int         ivf_version(void);
 const char* ivf_last_error(void);
 int         ivf_device_count(void);                 /* number of visible HIP devices (0 if none) */
+long long   ivf_debug_launch_count(void);           /* measurement aid: kernel launches this process has issued through the library */
 
 /* ---- ORBextractor ---- */
 /* ORBextractor::ORBextractor (ORB/src/ORBextractor.cc:411-476); constructed in Tracking (ORB/src/Tracking.cc:174-191) */

@@ -48,6 +48,7 @@ _SIGS = {
     "ivf_version": (C.c_int, []),
     "ivf_last_error": (C.c_char_p, []),
     "ivf_device_count": (C.c_int, []),
+    "ivf_debug_launch_count": (C.c_longlong, []),
     "ivf_extractor_create": (C.c_int, [C.POINTER(ExtractorParams), C.c_int, C.POINTER(vp)]),
     "ivf_extractor_destroy": (None, [vp]),
     "ivf_extractor_set_opencv_variant": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -370,6 +371,9 @@ int have_device(int dev)
 
 }  // namespace
 
+static std::atomic<long long> g_launches{0};
+void ivf::count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
+
 int ivf::set_error(int code, const char* fmt, ...)
 {
     char buf[512];
@@ -448,6 +452,7 @@ struct Grid {
 extern "C" {
 
 int ivf_version(void) { return 100; }
+long long ivf_debug_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
 const char* ivf_last_error(void) { return g_err.c_str(); }
 int ivf_device_count(void)
 {

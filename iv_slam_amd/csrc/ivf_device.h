@@ -101,6 +101,13 @@ struct StereoArgs {
     int* rowCnt; unsigned short* rowList;                  // [nPairs][H], [nPairs][H][kRowCap]: right keypoints per image row, or null
 };
 
+// every kernel launch of the library goes through hipLaunchKernelGGL: counted for bench.py's launches_per_step
+void count_launch();
+}  // namespace ivf
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...) do { ivf::count_launch(); hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__); } while (0)
+namespace ivf {
+
 // thread-local error message behind ivf_last_error() (ivf_api.hip)
 int set_error(int code, const char* fmt, ...);
 

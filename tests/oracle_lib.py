@@ -22,6 +22,9 @@ class Bounds(C.Structure):
 
 
 def _build():
+    if os.environ.get("IVF_ORACLE_SO"):
+        # bench.py's cpu_baseline worker: the same source built -march=native for the host it is timed on
+        return os.environ["IVF_ORACLE_SO"], os.path.join(ORACLE_DIR, "libstl_pin.so")
     so = os.path.join(ORACLE_DIR, "libivf_oracle.so")
     pin = os.path.join(ORACLE_DIR, "libstl_pin.so")
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("ivf_oracle.c", "ivf_oracle.h", "stl_pin.cpp")]
