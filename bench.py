@@ -463,8 +463,10 @@ def main():
         sc = iv.ORBextractor(NFEAT, 1.2, 8, 20, 7, device_id=local_rank).GetScaleFactors()
         cam = dict(fx=FX, fy=FX, cx=W / 2 + 0.5, cy=H / 2 - 0.25)
         tpairs_h = track_pairs(world, rank, P)
-        tracker = iv.BatchTracker(NFEAT, sc, cam["fx"], cam["fy"], cam["cx"], cam["cy"], BF, (0.0, 0.0, float(W), float(H)),
-                                  max_pairs=max(len(tpairs_h), 1), device_id=local_rank)
+        # one tracker per internal stream of the front end: a handle owns the scratch of one run at a time
+        trackers = [iv.BatchTracker(NFEAT, sc, cam["fx"], cam["fy"], cam["cx"], cam["cy"], BF, (0.0, 0.0, float(W), float(H)),
+                                    max_pairs=max(len(tpairs_h), 1), device_id=local_rank) for _ in range(3)]
+        tracker = trackers[0]
         tpairs = torch.tensor(tpairs_h, dtype=torch.int32, device=dev).reshape(-1, 2)
         if blocks3 is None:
             blocks3 = [torch.zeros(P * rec, dtype=torch.uint8, device=dev) for _ in range(3)]
@@ -498,7 +500,7 @@ def main():
                 all_gather_block(bs, k)
             if track and len(tpairs_h):
                 # ... and its consumer, in order behind the collective on the batch's own stream
-                tracker.run(gathered3[k % 3] if exchange else blocks3[k % 3], tpairs, assign3[k % 3], nm3[k % 3], stream_ptr=bs.cuda_stream)
+                trackers[k % 3].run(gathered3[k % 3] if exchange else blocks3[k % 3], tpairs, assign3[k % 3], nm3[k % 3], stream_ptr=bs.cuda_stream)
         if args.serial:
             fe.sync()
 

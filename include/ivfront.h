@@ -271,7 +271,9 @@ void ivf_tracker_destroy(ivf_tracker* t);
  * record's frame, row-major 3x4, or NULL = identity everywhere (zero-motion prior); d_point_flags [n_records][nfeatures]
  * (nullable): bit 0 = the keypoint has a map point, bit 1 = that point has observations (then th_depth is ignored).
  * Outputs: d_assign [n_pairs][nfeatures] = for every keypoint of the current frame the index of the last-frame keypoint whose
- * point it received (CurrentFrame.mvpMapPoints) or -1; d_nmatches [n_pairs] = the return value.  Asynchronous on hip_stream. */
+ * point it received (CurrentFrame.mvpMapPoints) or -1; d_nmatches [n_pairs] = the return value.  Asynchronous on hip_stream.
+ * The handle owns the scratch of ONE run: a run enqueued on a different stream than the previous one waits for it (an event);
+ * use one tracker per stream to let runs overlap. */
 int  ivf_tracker_run(ivf_tracker* t, const uint8_t* d_records, size_t record_bytes, int n_records, const int32_t* d_pairs, int n_pairs,
                      const float* d_poses, const uint8_t* d_point_flags, int32_t* d_assign, int32_t* d_nmatches, void* hip_stream);
 

@@ -479,6 +479,8 @@ struct ivf_tracker {
     Query* dQ = nullptr;
     unsigned* dLists = nullptr;
     size_t ldsBytes = 0;
+    hipEvent_t evDone = nullptr;          // end of the previous run: the scratch above belongs to ONE run at a time
+    bool ran = false;
 };
 
 extern "C" {
@@ -494,6 +496,7 @@ void ivf_tracker_destroy(ivf_tracker* t)
     (void)hipSetDevice(t->cfg.device_id);
     void* ptrs[] = {t->dStart, t->dCount, t->dRetry, t->dIdx, t->dQ, t->dLists};
     for (void* q : ptrs) if (q) (void)hipFree(q);
+    if (t->evDone) (void)hipEventDestroy(t->evDone);
     delete t;
 }
 
@@ -532,6 +535,10 @@ int ivf_tracker_create(const ivf_track_config* cfg, ivf_tracker** out)
         ivf_tracker_destroy(t);
         return fail(IVF_E_NO_DEVICE, "device allocation failed for a tracker of %d pairs x %d features", cfg->max_pairs, cfg->nfeatures);
     }
+    if (hipEventCreateWithFlags(&t->evDone, hipEventDisableTiming) != hipSuccess) {
+        ivf_tracker_destroy(t);
+        return fail(IVF_E_NO_DEVICE, "event creation failed");
+    }
     if (t->ldsBytes > 48 * 1024 &&
         hipFuncSetAttribute((const void*)k_track_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->ldsBytes) != hipSuccess) {
         ivf_tracker_destroy(t);
@@ -554,6 +561,9 @@ int ivf_tracker_run(ivf_tracker* t, const uint8_t* d_records, size_t record_byte
     hipStream_t st = (hipStream_t)hip_stream;
     const TrackParams& P = t->P;
     const int2* pairs = (const int2*)d_pairs;
+    // the per-pair grids, query tables and candidate lists are scratch of the HANDLE: a run enqueued on another stream than the
+    // previous one queues behind it (use one tracker per stream to let runs overlap)
+    if (t->ran) HIPCHK(hipStreamWaitEvent(st, t->evDone, 0));
     hipLaunchKernelGGL(k_track_prepare, dim3(n_pairs), dim3(256), 0, st, P, d_records, pairs, d_poses, d_point_flags, t->dStart, t->dIdx, t->dQ, t->dRetry);
     const dim3 wg((P.nf + 3) / 4, n_pairs);
     for (int pass = 0; pass < (t->cfg.retry_below > 0 ? 2 : 1); pass++) {
@@ -563,6 +573,8 @@ int ivf_tracker_run(ivf_tracker* t, const uint8_t* d_records, size_t record_byte
                            t->cfg.retry_below, t->dCount, t->dLists, d_assign, d_nmatches);
     }
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(t->evDone, st));
+    t->ran = true;
     return IVF_OK;
 }
 

@@ -226,3 +226,33 @@ def test_tracker_argument_checks(iv):
     tr.run(blk, pairs[:2], out, nm)                                         # empty records: no matches, nothing written out of range
     torch.cuda.synchronize()
     assert (nm.cpu().numpy()[:2] == 0).all() and (out.cpu().numpy()[:2] == -1).all()
+
+
+def test_one_handle_on_several_streams_serialises_its_runs(iv):
+    """the handle's scratch belongs to one run at a time: runs enqueued back to back on DIFFERENT streams (what a pipelined
+    caller does) must not overlap in it -- same results as one run at a time."""
+    import torch
+    from iv_slam_amd import dist as ivd
+    rng = np.random.default_rng(77)
+    nf, w, h = 1200, 640, 240
+    cam = dict(nf=nf, scale=scale_table(), fx=F(370.0), fy=F(370.0), cx=F(320.0), cy=F(120.0), bf=F(198.75), b=F(F(198.75) / F(370.0)),
+               bounds=(0.0, 0.0, float(w), float(h)))
+    dev = torch.device("cuda:0")
+    sets = [_random_records(np.random.default_rng(100 + s), nf, 9, w, h, 0.6) for s in range(3)]
+    blocks = [torch.from_numpy(ivd.pack_records(r, nf).reshape(-1)).to(dev) for r in sets]
+    pairs = torch.tensor([(k, k + 1) for k in range(8)], dtype=torch.int32, device=dev)
+    tr = iv.BatchTracker(nf, cam["scale"], 370.0, 370.0, 320.0, 120.0, 198.75, cam["bounds"], max_pairs=8, b=float(cam["b"]), th=12.0)
+    ref = []
+    for b in blocks:
+        a = torch.empty((8, nf), dtype=torch.int32, device=dev); n = torch.empty(8, dtype=torch.int32, device=dev)
+        tr.run(b, pairs, a, n); torch.cuda.synchronize()
+        ref.append((a.cpu().numpy(), n.cpu().numpy()))
+    streams = [torch.cuda.Stream(dev) for _ in range(3)]
+    for rep in range(5):
+        outs = [(torch.empty((8, nf), dtype=torch.int32, device=dev), torch.empty(8, dtype=torch.int32, device=dev)) for _ in range(3)]
+        for i in range(3):
+            tr.run(blocks[i], pairs, outs[i][0], outs[i][1], stream_ptr=streams[i].cuda_stream)
+        torch.cuda.synchronize()
+        for i in range(3):
+            assert np.array_equal(outs[i][0].cpu().numpy(), ref[i][0]) and np.array_equal(outs[i][1].cpu().numpy(), ref[i][1]), (rep, i)
+    assert sum(int(r[1].sum()) for r in ref) > 1000
