@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libivfront.so")
+LIB_PATH = os.environ.get("IVFRONT_LIB") or os.path.join(_HERE, "libivfront.so")      # IVFRONT_LIB: experiment builds (tools/)
 
 IVF_OK, IVF_E_INVALID, IVF_E_CAPACITY, IVF_E_GEOMETRY, IVF_E_NO_DEVICE, IVF_E_STATE = 0, -1, -2, -3, -4, -5
 MAX_LEVELS = 16

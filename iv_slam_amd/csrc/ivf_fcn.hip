@@ -1289,6 +1289,11 @@ constexpr int kAbl = IVF_DWPW_ABL;
 #ifndef IVF_DWPW_OCC
 #define IVF_DWPW_OCC 2
 #endif
+#ifndef IVF_DWPW_PACKED
+#define IVF_DWPW_PACKED 1     // 0: the stencil's in-thread taps as plain v_fma_f32 instead of v_pk_fma_f32 (tools/probe/issue_model.hip:
+                              // packed f32 VALU does not hide under MFMAs; in THIS kernel the stencil and the MFMAs of a workgroup are
+                              // separated by barriers anyway, measured 100.7 vs 101.1 us per image, so the packed form stays)
+#endif
 template <int S> struct DwSetT { float4 own[3][2 * S]; float par; float hl[3], hr[3]; };   // par: parameter (tid & 15) of this thread's channel;
                                                                      // hl / hr: halo pixels across the workgroup edge (256-wide maps only)
 
@@ -1427,7 +1432,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (TILES >= 5 ? IVF_DWPW_OCC :
             const float w0 = masked ? wk[ky * 3] * rowM[ky] : wk[ky * 3], w1 = masked ? wk[ky * 3 + 1] * rowM[ky] : wk[ky * 3 + 1],
                         w2 = masked ? wk[ky * 3 + 2] * rowM[ky] : wk[ky * 3 + 2];
             const float w0L = w0 * mL, w2R = w2 * mR;
-            if constexpr (PAIR && (DIL == 2 || DIL == 4)) {
+            if constexpr (IVF_DWPW_PACKED && PAIR && (DIL == 2 || DIL == 4)) {
                 // packed-f32 FMAs (v_pk_fma_f32: two pixels per instruction, full rate) for every tap that stays inside the
                 // thread's 8 pixels; the halo taps stay DPP FMAs.  Per pixel the order centre, left, right is that of the scalar path.
                 const float4 a = ky == 2 ? part[0] : S.own[ky][0], c4 = ky == 2 ? part[1] : S.own[ky][1];
@@ -1489,7 +1494,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (TILES >= 5 ? IVF_DWPW_OCC :
                 o[7] = __builtin_fmaf(S.hr[ky], w2, o[7]);
             }
         }
-        if constexpr (PAIR && (DIL == 2 || DIL == 4)) {
+        if constexpr (IVF_DWPW_PACKED && PAIR && (DIL == 2 || DIL == 4)) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const f32x2 v = pkfma(O[i], dsc, (f32x2){dsh, dsh});
@@ -1811,6 +1816,266 @@ __global__ __launch_bounds__(512, 2) void k_fcn_dwpw8(const float* __restrict__ 
     else dwpw8_body<DIL, TT, TT / 2, 1>(sD, sW, X, dwP, Wq, scale, shift, res, Y, K, Cout, nTiles);
 }
 
+// ---- blocks 15 - 17 as ONE kernel each: expand 160 -> 960, depthwise 3x3 dilation 4, project 960 -> 160 / 320 (+ residual) ----
+// (IF/networks/models_light/mobilenet.py:35-64 with the dilation of models_light.py:139-152.)  The 960-channel hidden tensors of
+// these blocks (15.7 MB per image, written by k_fcn_expand and read back by k_fcn_dwpw*: 94 MB per image for the three blocks)
+// never exist: a depthwise 3x3 with DILATION 4 on a 64 x 64 map only ever combines pixels of the same residue (y mod 4, x mod 4),
+// i.e. it is sixteen independent plain 3x3 convolutions on 16 x 16 sub-images with zero padding -- no halo between them.  One
+// workgroup owns one sub-image (256 pixels) of one image for all 960 hidden channels:
+//   * the input tile X[160][256] is gathered once and kept in REGISTERS as split-f16 B fragments (80 VGPRs per lane);
+//   * per group of 16 hidden channels (60 groups): E = expansion on v_mfma_f32_16x16x32_f16 (M = the 16 hidden channels) + BN +
+//     ReLU6 -> LDS planes; S = the 3x3 stencil on the 16 x 16 planes (thread = channel x sub-row x half row, halo pixel by DPP) +
+//     BN + ReLU6 -> LDS; P = projection on v_mfma_f32_32x32x16_f16 (the group is one K step) into 5 resident accumulator tiles;
+//   * software pipeline over the groups, ONE barrier per interval: E(g), S(g - 1), P(g - 2) work on different LDS buffers;
+//   * the weights of the next interval (10 KB expansion + 10 KB projection fragments + 768 B of depthwise / BN parameters) arrive by
+//     LDS-DMA (global_load_lds_dwordx4), no registers, no VALU;
+//   * waves 0-3 run [MFMA phase, stencil phase], waves 4-7 [stencil phase, MFMA phase]: wave w and w + 4 share a SIMD, so one
+//     partner's VALU issues under the other's MFMAs (tools/probe/issue_model.hip: 5 four-cycle VALU instructions hide per
+//     32-cycle MFMA slot, also across the two waves of a SIMD; packed-f32 VALU does not -- the stencil uses plain v_fma_f32).
+// Output / residual: the sub-image's pixels are 4 apart in x, so stores are 4-byte pieces of rows that the three sibling workgroups
+// (same image, same y phase, same XCD) complete in L2.
+#ifdef IVF_F4_TIMING
+__device__ unsigned long long g_f4Tim[16];      // diagnostic build (make EXTRA=-DIVF_F4_TIMING): cycle sums per phase, waves 0 and 4
+#define F4_TIM(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                       tacc[i] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define F4_TIM(i) do { } while (0)
+#endif
+#ifndef IVF_F4_ABL
+#define IVF_F4_ABL 0          // timing-only ablations (results wrong): 1 A fragments read from LDS only for the first step of each product,
+#endif                        // 2 no weight DMA after the prologue, 4 no stencil phase, 8 no MFMAs
+constexpr int kF4Cin = 160, kF4Hid = 960, kF4Groups = 60;
+constexpr int kF4HP = 20;                         // floats per 16-pixel sub-row of a hidden plane in LDS (80 B: conflict-free b128 rows)
+constexpr int kF4DP = 260;                        // floats per channel of the depthwise output in LDS
+constexpr int kF4ParB = 1024;                     // bytes per parameter slot (16 channels x 12 floats = 768 used)
+constexpr size_t kF4Lds = (size_t)2 * 16 * 16 * kF4HP * 4 + (size_t)2 * 16 * kF4DP * 4 + 4 * 10240 + 3 * kF4ParB;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool RES>
+__global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ X, const uint4* __restrict__ WE, const float* __restrict__ par,
+                                                     const uint4* __restrict__ WP, const float* __restrict__ scP, const float* __restrict__ shP,
+                                                     const float* __restrict__ res, float* __restrict__ Y, int Cout, int tilesP)
+{
+    extern __shared__ __attribute__((aligned(16))) uint4 f4smem[];
+    float* const sH = (float*)f4smem;                               // [2][16 ch][16 rows][kF4HP]
+    float* const sD = sH + 2 * 16 * 16 * kF4HP;                     // [2][16 ch][kF4DP]
+    uint4* const sWE = (uint4*)(sD + 2 * 16 * kF4DP);               // [2][5 K steps][hi, lo][64 lanes]
+    uint4* const sWP = sWE + 2 * 640;                               // [2][5 tiles][hi, lo][64 lanes]
+    float* const sPar = (float*)(sWP + 2 * 640);                    // [3][16 ch][12]: 9 taps (x dw BN scale), dw BN shift, expansion BN scale, shift
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;     // consecutive L on one XCD (grid x = 16 * images)
+    const int b = L >> 4, py = (L >> 2) & 3, px = L & 3;
+    const int tile0 = blockIdx.y * 5;
+    constexpr int HW = 4096;
+
+    // ---- weights / parameters of one interval by LDS-DMA: 21 pieces of <= 1 KB, piece c by wave c % 8.  Issued through inline
+    // asm: the compiler's wait-count pass treats its own LDS-DMA builtin as a store to ALL of LDS and puts s_waitcnt vmcnt(0) in
+    // front of every later ds_read, which would expose the whole L2 latency of the prefetch every interval.  Here the only
+    // consumer-side wait is the explicit vmcnt(0) in front of the interval's barrier (extra in-flight VMEM operations can only make
+    // the compiler's own counted waits longer, never too short: vmcnt retires in order).
+    const unsigned ldsBase = (unsigned)(uintptr_t)f4smem;
+    const unsigned ldsWE = ldsBase + (unsigned)((uint8_t*)sWE - (uint8_t*)f4smem), ldsWP = ldsBase + (unsigned)((uint8_t*)sWP - (uint8_t*)f4smem),
+                   ldsPar = ldsBase + (unsigned)((uint8_t*)sPar - (uint8_t*)f4smem);
+    auto dma16 = [](const void* src, unsigned ldsAddr) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(ldsAddr) : "memory");
+    };
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    auto dma = [&](int it) {                    // what interval `it` consumes: WE[it], par[it] (kept two intervals), WP[it - 2]
+        if ((IVF_F4_ABL & 2) && it > 1) return;
+        const int nb = it & 1;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int c = uwave + 8 * r;
+            if (c < 10) {
+                if (it < kF4Groups) dma16(WE + ((size_t)it * 10 + c) * 64 + lane, ldsWE + (unsigned)(nb * 640 + c * 64) * 16u);
+            } else if (c < 20) {
+                const int c2 = c - 10, gp = it - 2;
+                if (gp >= 0 && gp < kF4Groups)
+                    dma16(WP + (((size_t)gp * tilesP + tile0) * 2 + c2) * 64 + lane, ldsWP + (unsigned)(nb * 640 + c2 * 64) * 16u);
+            } else if (c == 20) {
+                if (it < kF4Groups && lane < 48) dma16(par + (size_t)it * 192 + lane * 4, ldsPar + (unsigned)((it % 3) * kF4ParB));
+            }
+        }
+    };
+    dma(0);
+
+    // ---- the input tile: this wave's 32 sub-image pixels (sub-rows 2w, 2w+1) x 160 channels as B fragments of the 16x16x32 MFMA
+    // lane: column n = lane & 15 (sub-column), k = 8 (lane >> 4) + j
+    HFrag bh[5][2], bl[5][2];
+    {
+        const float* Xb = X + (size_t)b * kF4Cin * HW;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int pix = (4 * (2 * wave + u) + py) * 64 + 4 * (lane & 15) + px;
+#pragma unroll
+            for (int s5 = 0; s5 < 5; s5++) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = Xb[(size_t)(32 * s5 + 8 * (lane >> 4) + j) * HW + pix];
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) split_pair(v[2 * jj], v[2 * jj + 1], bh[s5][u].u[jj], bl[s5][u].u[jj]);
+            }
+        }
+    }
+    f32x16 pacc[5];
+#pragma unroll
+    for (int t = 0; t < 5; t++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) pacc[t][q] = 0.f;
+
+    // stencil thread: channel sch (0..15), sub-row ssr, half row sh_
+    const int sch = tid >> 5, ssr = (tid >> 1) & 15, sh_ = tid & 1;
+    const float rowM0 = ssr > 0 ? 1.f : 0.f, rowM2 = ssr < 15 ? 1.f : 0.f;
+    const int srow0 = (sch * 16 + (ssr > 0 ? ssr - 1 : ssr)) * kF4HP + 8 * sh_, srow1 = (sch * 16 + ssr) * kF4HP + 8 * sh_,
+              srow2 = (sch * 16 + (ssr < 15 ? ssr + 1 : ssr)) * kF4HP + 8 * sh_;
+    const float mL = sh_ ? 1.f : 0.f, mR = sh_ ? 0.f : 1.f;          // the halo pixel comes from the row's other half (lane -1 / +1)
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto mfma_phase = [&](int it) {
+        const int cur = it & 1;
+        const bool doE = it < kF4Groups, doP = it >= 2;
+        // every LDS read of the phase that does not depend on an MFMA is requested up front: P's B values (8 dwords), E's BN
+        // parameters, the first A fragments of both products; later fragments are requested one step ahead of their MFMAs
+        const float* dB = sD + cur * (16 * kF4DP) + (8 * (lane >> 5)) * kF4DP + 32 * wave + (lane & 31);
+        float dv[8];
+        if (doP) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) dv[j] = dB[j * kF4DP];
+        }
+        const uint4* wE = sWE + cur * 640 + lane;
+        const uint4* wPq = sWP + cur * 640 + lane;
+        const float* pp = sPar + (it % 3) * (kF4ParB / 4) + (4 * (lane >> 4)) * 12 + 10;
+        float2 eb[4];
+        HFrag ea[2][2], pa[2][2];
+        if (doE) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) eb[r] = *(const float2*)(pp + r * 12);
+            ea[0][0].q = wE[0]; ea[0][1].q = wE[64];
+        }
+        if (doP) { pa[0][0].q = wPq[0]; pa[0][1].q = wPq[64]; }
+        f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
+        if (doE) {                              // E(it): hidden group `it` = W_E[16 x 160] . X[160 x 32 pixels of this wave]
+#pragma unroll
+            for (int s5 = 0; s5 < 5; s5++) {
+                if (s5 + 1 < 5 && !(IVF_F4_ABL & 1)) { ea[(s5 + 1) & 1][0].q = wE[(2 * s5 + 2) * 64]; ea[(s5 + 1) & 1][1].q = wE[(2 * s5 + 3) * 64]; }
+                __builtin_amdgcn_sched_barrier(0);
+                const HFrag &ah = ea[(IVF_F4_ABL & 1) ? 0 : (s5 & 1)][0], &al = ea[(IVF_F4_ABL & 1) ? 0 : (s5 & 1)][1];
+                if (!(IVF_F4_ABL & 8)) {
+                    e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, bh[s5][0].v, e0, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, bh[s5][1].v, e1, 0, 0, 0);
+                    e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bl[s5][0].v, e0, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bl[s5][1].v, e1, 0, 0, 0);
+                    e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[s5][0].v, e0, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[s5][1].v, e1, 0, 0, 0);
+                } else { e0[0] += __builtin_bit_cast(float, ah.u[0] ^ bh[s5][0].u[1]); e1[0] += __builtin_bit_cast(float, al.u[1] ^ bl[s5][1].u[0]); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (doP) {                              // P(it - 2): out[160 x 32 pixels] += W_P[160 x 16] . D[16 x 32 pixels]; its split and
+            HFrag ph, pl;                       // its MFMAs are issued while E's are still in the matrix pipe
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) split_pair(dv[2 * jj], dv[2 * jj + 1], ph.u[jj], pl.u[jj]);
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                if (t + 1 < 5 && !(IVF_F4_ABL & 1)) { pa[(t + 1) & 1][0].q = wPq[(2 * t + 2) * 64]; pa[(t + 1) & 1][1].q = wPq[(2 * t + 3) * 64]; }
+                __builtin_amdgcn_sched_barrier(0);
+                const HFrag &ah = pa[(IVF_F4_ABL & 1) ? 0 : (t & 1)][0], &al = pa[(IVF_F4_ABL & 1) ? 0 : (t & 1)][1];
+                if (!(IVF_F4_ABL & 8)) {
+                    pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, ph.v, pacc[t], 0, 0, 0);
+                    pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, pl.v, pacc[t], 0, 0, 0);
+                    pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, ph.v, pacc[t], 0, 0, 0);
+                } else pacc[t][0] += __builtin_bit_cast(float, ah.u[0] ^ ph.u[1] ^ al.u[2] ^ pl.u[3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (doE) {                              // E's epilogue under P's MFMAs: BN + ReLU6 -> hidden planes
+            // C layout: column = lane & 15 (sub-column), row = 4 (lane >> 4) + r (hidden channel of the group)
+            float* hp = sH + cur * (16 * 16 * kF4HP) + ((4 * (lane >> 4)) * 16 + 2 * wave) * kF4HP + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                hp[(r * 16) * kF4HP] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e0[r], eb[r].x, eb[r].y), 0.f, 6.f);
+                hp[(r * 16 + 1) * kF4HP] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e1[r], eb[r].x, eb[r].y), 0.f, 6.f);
+            }
+        }
+    };
+    auto stencil_phase = [&](int it) {          // S(it - 1): 3x3 on the 16 x 16 planes of group it - 1, + BN + ReLU6
+        const int g = it - 1;
+        if (g < 0 || g >= kF4Groups || (IVF_F4_ABL & 4)) return;
+        const float* hp = sH + (g & 1) * (16 * 16 * kF4HP);
+        const float4* pq = (const float4*)(sPar + (g % 3) * (kF4ParB / 4) + sch * 12);
+        const float4 w03 = pq[0], w47 = pq[1], w8s = pq[2];          // taps 0-3 | 4-7 | tap 8, shift, (expansion BN)
+        float o[8];
+#pragma unroll
+        for (int p8 = 0; p8 < 8; p8++) o[p8] = w8s.y;
+        const int ro[3] = {srow0, srow1, srow2};
+        const float wk[9] = {w03.x * rowM0, w03.y * rowM0, w03.z * rowM0, w03.w, w47.x, w47.y, w47.z * rowM2, w47.w * rowM2, w8s.x * rowM2};
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+            const float4 a = *(const float4*)(hp + ro[ky]), c4 = *(const float4*)(hp + ro[ky] + 4);
+            const float own[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+            const float w0 = wk[3 * ky], w1 = wk[3 * ky + 1], w2 = wk[3 * ky + 2];
+            const float w0L = w0 * mL, w2R = w2 * mR;
+#pragma unroll
+            for (int p8 = 0; p8 < 8; p8++) {
+                o[p8] = __builtin_fmaf(own[p8], w1, o[p8]);
+                if (p8 > 0) o[p8] = __builtin_fmaf(own[p8 - 1], w0, o[p8]);
+                else asm("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(o[p8]) : "v"(own[7]), "v"(w0L));
+                if (p8 < 7) o[p8] = __builtin_fmaf(own[p8 + 1], w2, o[p8]);
+                else asm("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(o[p8]) : "v"(own[0]), "v"(w2R));
+            }
+        }
+        float* dp = sD + (g & 1) * (16 * kF4DP) + sch * kF4DP + ssr * 16 + 8 * sh_;
+        *(float4*)dp = make_float4(__builtin_amdgcn_fmed3f(o[0], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[1], 0.f, 6.f),
+                                   __builtin_amdgcn_fmed3f(o[2], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[3], 0.f, 6.f));
+        *(float4*)(dp + 4) = make_float4(__builtin_amdgcn_fmed3f(o[4], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[5], 0.f, 6.f),
+                                         __builtin_amdgcn_fmed3f(o[6], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[7], 0.f, 6.f));
+    };
+
+#ifdef IVF_F4_TIMING
+    unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
+    for (int it = 0; it < kF4Groups + 2; it++) {
+        dma(it + 1);                            // lands during this interval, consumed in the next one
+        F4_TIM(0);
+        if (wave < 4) { mfma_phase(it); F4_TIM(1); stencil_phase(it); F4_TIM(2); }
+        else { stencil_phase(it); F4_TIM(2); mfma_phase(it); F4_TIM(1); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        F4_TIM(3);
+    }
+#ifdef IVF_F4_TIMING
+    if (lane == 0 && (wave == 0 || wave == 4)) {
+        for (int i = 0; i < 4; i++) atomicAdd(&g_f4Tim[(wave ? 8 : 0) + i], tacc[i]);
+        atomicAdd(&g_f4Tim[(wave ? 8 : 0) + 7], 1ull);
+    }
+#endif
+
+    // ---- epilogue: BN (+ residual) of the projection, 4-byte pieces (the sub-image's pixels are 4 apart)
+    const int n = lane & 31;
+    const int pix = (4 * (2 * wave + (n >> 4)) + py) * 64 + 4 * (n & 15) + px;
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+        const int cb = (tile0 + t) * 32 + 4 * (lane >> 5);
+        float4 sc4[4], sh4[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(scP + cb + 8 * g4); sh4[g4] = *(const float4*)(shP + cb + 8 * g4); }
+        const size_t ob = ((size_t)b * Cout + cb) * HW + pix;
+        float rv[16];
+        if (RES) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) rv[q] = res[ob + (size_t)((q & 3) + 8 * (q >> 2)) * HW];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            float v = pacc[t][q] * vget<4>(sc4[q >> 2], q & 3) + vget<4>(sh4[q >> 2], q & 3);
+            if (RES) v += rv[q];
+            Y[ob + (size_t)((q & 3) + 8 * (q >> 2)) * HW] = v;
+        }
+    }
+}
+
 // ---- conv_last 1x1 80 -> 1 + bias (models_light.py:196) ----
 __global__ void k_fcn_last(const float* __restrict__ X, const float* __restrict__ w, float bias, float* __restrict__ Y,
                            int C, int HW)
@@ -2086,6 +2351,7 @@ struct ivf_fcn {
     std::vector<Gemm> pw;        // in forward order: per block expand (t>1), project; then decoder cbr
     std::vector<Dw> dw;
     float* dLastW = nullptr; float lastBias = 0.f;
+    struct Fused4 { uint4 *dWE = nullptr, *dWP = nullptr; float* dPar = nullptr; int cout = 0, tilesP = 0; } f4[3];   // blocks 15-17 (k_fcn_irbd4)
     float *bufIn = nullptr, *bufA = nullptr, *bufB = nullptr, *bufH1 = nullptr, *bufH2 = nullptr, *bufLogits = nullptr;
     uint8_t *dStageIn = nullptr, *dStageU8 = nullptr; float* dStageF = nullptr;
     void* hPin = nullptr;        // pinned host staging of the per-call path (ivf_fcn_forward)
@@ -2177,6 +2443,42 @@ int make_gemm(ivf_fcn* f, const float* w, int cout, int cin, int taps, const std
     return upload(f, shp, &g.dShift);
 }
 
+// Operands of k_fcn_irbd4 (blocks 15-17): expansion rows as A fragments of v_mfma_f32_16x16x32_f16 (lane: row = lane & 15,
+// k = 8 (lane >> 4) + j) per group of 16 hidden channels and K step of 32 input channels; projection rows as A fragments of
+// v_mfma_f32_32x32x16_f16 (lane: row = lane & 31, k = 8 (lane >> 5) + j) per group (= one K step) and output tile; per hidden
+// channel 12 parameters: the nine depthwise taps times the depthwise BN scale, its shift, the expansion's BN scale and shift.
+// we / wp: the pre-scaled rows (prescale_rows), scE: the expansion's BN scale after the pre-scaling.
+int make_fused4(ivf_fcn* f, ivf_fcn::Fused4& F, const float* we, const std::vector<float>& scE, const std::vector<float>& shE, const float* wd,
+                const std::vector<float>& scD, const std::vector<float>& shD, const float* wp, int cout)
+{
+    auto put = [](uint16_t* q, size_t frag, int lane, int j, float v) {
+        const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
+        q[((frag + 0) * 64 + lane) * 8 + j] = hi; q[((frag + 1) * 64 + lane) * 8 + j] = lo;
+    };
+    F.cout = cout; F.tilesP = cout / 32;
+    std::vector<float> qe((size_t)kF4Groups * 5 * 2 * 64 * 4, 0.f), qp((size_t)kF4Groups * F.tilesP * 2 * 64 * 4, 0.f), par((size_t)kF4Hid * 12, 0.f);
+    uint16_t* e16 = reinterpret_cast<uint16_t*>(qe.data()); uint16_t* p16 = reinterpret_cast<uint16_t*>(qp.data());
+    for (int g = 0; g < kF4Groups; g++) {
+        for (int s5 = 0; s5 < 5; s5++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++)
+                    put(e16, ((size_t)g * 5 + s5) * 2, lane, j, we[(size_t)(16 * g + (lane & 15)) * kF4Cin + 32 * s5 + 8 * (lane >> 4) + j]);
+        for (int t = 0; t < F.tilesP; t++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++)
+                    put(p16, ((size_t)g * F.tilesP + t) * 2, lane, j, wp[(size_t)(32 * t + (lane & 31)) * kF4Hid + 16 * g + 8 * (lane >> 5) + j]);
+    }
+    for (int c = 0; c < kF4Hid; c++) {
+        for (int q = 0; q < 9; q++) par[(size_t)c * 12 + q] = wd[(size_t)c * 9 + q] * scD[c];
+        par[(size_t)c * 12 + 9] = shD[c]; par[(size_t)c * 12 + 10] = scE[c]; par[(size_t)c * 12 + 11] = shE[c];
+    }
+    float *de = nullptr, *dp = nullptr;
+    int rc;
+    if ((rc = upload(f, qe, &de)) || (rc = upload(f, qp, &dp)) || (rc = upload(f, par, &F.dPar))) return rc;
+    F.dWE = reinterpret_cast<uint4*>(de); F.dWP = reinterpret_cast<uint4*>(dp);
+    return IVF_OK;
+}
+
 // IVF_FCN_DEBUG=1: synchronise and check after every launch, naming the stage that failed
 #define STAGE(name)                                                                                          \
     do { if (dbg) { hipError_t e_ = hipStreamSynchronize(s); if (e_ == hipSuccess) e_ = hipGetLastError();   \
@@ -2245,6 +2547,31 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             ip += 2; id++;
             H = (H - 1) / d.stride + 1; W = (W - 1) / d.stride + 1;
             snprintf(nm, sizeof nm, "block %d whole", i + 1); STAGE(nm);
+            std::swap(x, y);
+            continue;
+        }
+        static const bool fused4 = getenv("IVF_FCN_NOFUSE") == nullptr && (getenv("IVF_FCN_FUSED4") == nullptr || atoi(getenv("IVF_FCN_FUSED4")) != 0);
+        if (fused4 && i >= 14 && f->f4[i - 14].dWE && H == 64 && W == 64) {      // blocks 15-17: one kernel, no hidden tensor in HBM
+            const ivf_fcn::Fused4& F = f->f4[i - 14];
+            const Gemm& pj = f->pw[ip + 1];
+            static const bool ldsOk = [] {
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_irbd4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF4Lds) == hipSuccess &&
+                       hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_irbd4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF4Lds) == hipSuccess;
+            }();
+            if (!ldsOk) return ffail(IVF_E_NO_DEVICE, "cannot reserve %zu bytes of LDS for k_fcn_irbd4", kF4Lds);
+            const bool probe4 = i == 14 && f->probe0[0];
+            const int slot4 = (int)(f->probeCount % ivf_fcn::kProbe);
+            if (probe4) FHIP(hipEventRecord(f->probe0[slot4], s));
+            const dim3 grid(16 * n, F.cout / 160);
+            if (bk.res) hipLaunchKernelGGL((k_fcn_irbd4<true>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, x, y, F.cout, F.tilesP);
+            else hipLaunchKernelGGL((k_fcn_irbd4<false>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y, F.cout, F.tilesP);
+            if (probe4) {
+                FHIP(hipEventRecord(f->probe1[slot4], s)); f->probeBatch[slot4] = n; f->probeCount++;
+                snprintf(f->probeName, sizeof f->probeName, "ivffcn::k_fcn_irbd4<%s> %d->%d->%d", bk.res ? "true" : "false", bk.inp, hid, bk.oup);
+                f->probeAlgoBytes = (double)(bk.inp + bk.oup * (bk.res ? 2 : 1)) * H * W * sizeof(float);
+            }
+            ip += 2; id++;
+            snprintf(nm, sizeof nm, "block %d whole (dilation-4 phases)", i + 1); STAGE(nm);
             std::swap(x, y);
             continue;
         }
@@ -2346,16 +2673,20 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
     for (int i = 0; i < 17; i++) {
         const Block& bk = kBlocks[i];
         const int hid = bk.inp * bk.t;
+        const bool f4 = i >= 14 && bk.inp == kF4Cin && hid == kF4Hid && bk.dil == 4 && bk.stride == 1 && bk.oup % 160 == 0;   // blocks 15-17
+        std::vector<float> f4we, f4scE, f4shE, f4scD, f4shD; const float* f4wd = nullptr;
         if (bk.t != 1) {
             const float* w = rd.take((size_t)hid * bk.inp);
             if (!w || !read_bn(hid)) return bad();
             const std::vector<float> ws = prescale_rows(w, hid, bk.inp, sc);
             Gemm g; if ((rc = make_gemm(f, ws.data(), hid, bk.inp, 1, sc, sh, 1, g))) { ivf_fcn_destroy(f); return rc; }
             f->pw.push_back(g);
+            if (f4) { f4we = ws; f4scE = sc; f4shE = sh; }
         }
         {
             const float* w = rd.take((size_t)hid * 9);
             if (!w || !read_bn(hid)) return bad();
+            if (f4) { f4wd = w; f4scD = sc; f4shD = sh; }
             Dw d; d.c = hid; d.stride = bk.stride; d.dil = bk.dil;
             std::vector<float> hw(w, w + (size_t)hid * 9);
             std::vector<float> pk((size_t)((hid + 31) / 32 * 32) * 12, 0.f);    // padded to whole 32-channel chunks
@@ -2374,6 +2705,7 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
             Gemm g; if ((rc = make_gemm(f, ws.data(), bk.oup, hid, 1, sc, sh, 0, g))) { ivf_fcn_destroy(f); return rc; }
             if (i == 0 && (rc = upload(f, ws, &f->dProj0W))) { ivf_fcn_destroy(f); return rc; }      // same pre-scaled rows, f32 (k_fcn_stem)
             f->pw.push_back(g);
+            if (f4 && (rc = make_fused4(f, f->f4[i - 14], f4we.data(), f4scE, f4shE, f4wd, f4scD, f4shD, ws.data(), bk.oup))) { ivf_fcn_destroy(f); return rc; }
         }
     }
     {   // decoder: cbr (3x3 320->80 + BN + ReLU), cbr_deepsup (unused at inference), conv_last, conv_last_deepsup (unused)
@@ -2406,6 +2738,20 @@ void ivf_fcn_destroy(ivf_fcn* f)
     if (!f) return;
     (void)hipSetDevice(f->device);
     (void)hipDeviceSynchronize();
+#ifdef IVF_F4_TIMING
+    {
+        unsigned long long t[16] = {};
+        if (hipMemcpyFromSymbol(t, HIP_SYMBOL(ivffcn::g_f4Tim), sizeof t) == hipSuccess && t[7]) {
+            for (int w = 0; w < 2; w++) {
+                const double n = (double)t[8 * w + 7];
+                fprintf(stderr, "[irbd4 timing] wave %d: workgroups %.0f; cycles per workgroup: dma issue %.0f  mfma phase %.0f  stencil phase %.0f  wait + barrier %.0f\n",
+                        4 * w, n, t[8 * w] / n, t[8 * w + 1] / n, t[8 * w + 2] / n, t[8 * w + 3] / n);
+            }
+            unsigned long long z[16] = {};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(ivffcn::g_f4Tim), z, sizeof z);
+        }
+    }
+#endif
 #ifdef IVF_DWPW_TIMING
     {
         unsigned long long t[8] = {};
