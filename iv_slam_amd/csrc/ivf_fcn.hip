@@ -2550,7 +2550,7 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             std::swap(x, y);
             continue;
         }
-        static const bool fused4 = getenv("IVF_FCN_NOFUSE") == nullptr && (getenv("IVF_FCN_FUSED4") == nullptr || atoi(getenv("IVF_FCN_FUSED4")) != 0);
+        static const int fused4 = getenv("IVF_FCN_NOFUSE") ? 0 : getenv("IVF_FCN_FUSED4") ? atoi(getenv("IVF_FCN_FUSED4")) : 1;
         if (fused4 && i >= 14 && f->f4[i - 14].dWE && H == 64 && W == 64) {      // blocks 15-17: one kernel, no hidden tensor in HBM
             const ivf_fcn::Fused4& F = f->f4[i - 14];
             const Gemm& pj = f->pw[ip + 1];
@@ -2572,6 +2572,26 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             }
             ip += 2; id++;
             snprintf(nm, sizeof nm, "block %d whole (dilation-4 phases)", i + 1); STAGE(nm);
+            std::swap(x, y);
+            continue;
+        }
+        // IVF_FCN_CHUNK = images per chunk (0 = off): expansion and fused depthwise + projection of a 64 x 64 block run chunk by chunk,
+        // back to back, through ONE hidden-tensor region of `chunk` images that every chunk reuses -- the region (8 images x 15.7 MB
+        // for the 960-channel blocks) stays in the 256 MB Infinity Cache between its write and its read
+        static const int chunkEnv = getenv("IVF_FCN_CHUNK") ? atoi(getenv("IVF_FCN_CHUNK")) : 0;
+        if (chunkEnv > 0 && bk.t != 1 && H == 64 && W == 64 && n > chunkEnv && bk.stride == 1) {
+            const Dw& d = f->dw[id];
+            bool ok = true;
+            for (int c0 = 0; c0 < n && ok; c0 += chunkEnv) {
+                const int nb = std::min(chunkEnv, n - c0);
+                const float* xo = x + (size_t)c0 * bk.inp * H * W;
+                float* yo = y + (size_t)c0 * bk.oup * H * W;
+                if (!launch_expand(f->pw[ip], xo, f->bufH1, H, W, nb, s)) launch_gemm(f->pw[ip], xo, nullptr, f->bufH1, H, W, nb, s);
+                ok = launch_dwpw(d, f->pw[ip + 1], f->bufH1, bk.res ? xo : nullptr, yo, H, W, nb, s);
+            }
+            if (!ok) return ffail(IVF_E_STATE, "chunked schedule: block %d has no fused depthwise + projection kernel", i + 1);
+            ip += 2; id++;
+            snprintf(nm, sizeof nm, "block %d chunked", i + 1); STAGE(nm);
             std::swap(x, y);
             continue;
         }
