@@ -679,8 +679,25 @@ def main():
             # reads is a product of the expand / depthwise split, not of the network: block input + residual + output is all an
             # ideal whole-block kernel would move; (ii) against the matrix pipe -- three f16 MFMAs per f32 product.
             import re
+            m3 = re.search(r"(\d+)->(\d+)->(\d+)", pname)
             m = re.search(r"(\d+)->(\d+)", pname)
-            if m and roofline["avg_launch_ms"] > 0:
+            if m3 and roofline["avg_launch_ms"] > 0:
+                # a whole inverted-residual block in one kernel (k_fcn_irbd4): the hidden tensor never reaches HBM, the launch moves
+                # only the block's input, residual and output (a few percent of the HBM roofline by construction) -- it is priced
+                # against the MATRIX pipe: both 1x1 convolutions, three f16 MFMAs per f32 product (hi*hi + hi*lo + lo*hi).
+                cin, hid, cout = (int(v) for v in m3.groups())
+                ms = roofline["avg_launch_ms"]; ims = roofline["isolated"]["avg_launch_ms"]
+                fl = 2.0 * (cin * hid + hid * cout) * 64 * 64 * 3 * probe_batch
+                hbm = {k: roofline[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")}
+                hbm["note"] = "block input + residual + output at 64x64 f32: what this launch moves algorithmically"
+                roofline.update({"bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                                 "frac": round(fl / (ms * 1e-3) / 1e12 / 2500.0, 5), "flops_per_launch": fl,
+                                 "note": "f16 MFMA flops issued by this launch (expansion + projection, hi*hi + hi*lo + lo*hi) against the 2.5 PFLOP/s "
+                                         "dense f16 peak; the launch is neither HBM- nor matrix-bound: DESIGN.md section 7 (r03) has its phase timing",
+                                 "hbm": hbm})
+                roofline["isolated"].update({"achieved": round(fl / (ims * 1e-3) / 1e12, 1) if ims > 0 else 0.0,
+                                             "frac": round(fl / (ims * 1e-3) / 1e12 / 2500.0, 5) if ims > 0 else 0.0})
+            elif m and roofline["avg_launch_ms"] > 0:
                 hid, cout = int(m.group(1)), int(m.group(2))
                 cin = hid // 6                                     # MobileNetV2 expansion factor (mobilenet.py:36)
                 ms = roofline["avg_launch_ms"]
