@@ -53,7 +53,10 @@ struct Config {
 // cv::resize coefficient table entry: src index | coef0 << 16 | coef1 << 32 (11-bit fixed point, A-3)
 typedef unsigned long long ResizeCoef;
 
-constexpr int kFastTW = 128, kFastTH = 32;    // FAST/NMS output tile (kFastTW + 2 <= 192, kFastTH + 2 <= 64: see k_fast_nms)
+#ifndef IVF_FAST_TH
+#define IVF_FAST_TH 32        // 64 measured slower: 405 vs 348 us per 128 images (occupancy: 32 KB of LDS per workgroup, ragged level edges)
+#endif
+constexpr int kFastTW = 128, kFastTH = IVF_FAST_TH;    // FAST/NMS output tile (kFastTW + 2 <= 160, kFastTH + 2 <= 96: see k_fast_nms)
 constexpr int kBlurTW = 128, kBlurTH = 32;    // blur output tile
 constexpr int kTileCap = kFastTW * kFastTH / 4;   // at most one strict 3x3 maximum per 2x2 block
 constexpr int kRowCap = 96;              // right keypoints listed per image row by k_stereo_rows (more: that row falls back to the full scan)

@@ -344,7 +344,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     __shared__ unsigned s_qmem[(kQueueN + 1) / 2 > kFastTW * kFastTH / 4 ? (kQueueN + 1) / 2 : kFastTW * kFastTH / 4];
     unsigned short* const s_queue = (unsigned short*)s_qmem;
     unsigned* const s_list = s_qmem;
-    constexpr int kCandCap = 1024;
+    constexpr int kCandCap = 32 * kFastTH;
+    static_assert(kScW <= 160 && 160 + kScH <= 256, "column classes: threads 0..kScW-1, row classes: threads 160..160+kScH-1");
     __shared__ unsigned short s_cand[kCandCap];                       // tile pixels with a non-zero score (sy << 8 | sx)
     __shared__ int s_nc;
     int img, bx;
@@ -394,8 +395,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
         }
         colInfo[tid] = f;
         if (tid < 2) colInfo[kScW + tid] = 0;
-    } else if (tid >= 192 && tid < 192 + kScH) {    // row classes: y = y0-1+(tid-192)
-        const int y = y0 - 1 + (tid - 192);
+    } else if (tid >= 160 && tid < 160 + kScH) {    // row classes: y = y0-1+(tid-160)
+        const int y = y0 - 1 + (tid - 160);
         unsigned f = 0;
         if (y >= kEdge && y < G.maxBY) {
             int i = G.cellH == 1 ? y - kEdge : (int)__umulhi((unsigned)(y - kEdge), G.cellHMagic);            // (y - kEdge) / cellH
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
             const int cy0 = kEdge + i * G.cellH, cy1 = cy0 + ((i == G.rows - 1) ? G.domHLast : domHm);
             if (y < cy1) f = 1u | ((y - 1 >= cy0) ? 2u : 0u) | ((y + 1 < cy1) ? 4u : 0u) | ((unsigned)i << 8);
         }
-        rowInfo[tid - 192] = f;
+        rowInfo[tid - 160] = f;
     }
 #pragma unroll
     for (int k = 0; k < kRawIt; k++)
