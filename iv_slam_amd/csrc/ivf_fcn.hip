@@ -1841,6 +1841,9 @@ __device__ unsigned long long g_f4Tim[16];      // diagnostic build (make EXTRA=
 #else
 #define F4_TIM(i) do { } while (0)
 #endif
+#ifndef IVF_F4_ORDER
+#define IVF_F4_ORDER 0        // experiment: 1 = every wave runs [MFMA phase, stencil phase], 2 = [stencil, MFMA]; 0 = the two halves staggered
+#endif
 #ifndef IVF_F4_ABL
 #define IVF_F4_ABL 0          // timing-only ablations (results wrong): 1 A fragments read from LDS only for the first step of each product,
 #endif                        // 2 no weight DMA after the prologue, 4 no stencil phase, 8 no MFMAs
@@ -2039,8 +2042,14 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     for (int it = 0; it < kF4Groups + 2; it++) {
         dma(it + 1);                            // lands during this interval, consumed in the next one
         F4_TIM(0);
+#if IVF_F4_ORDER == 1
+        mfma_phase(it); F4_TIM(1); stencil_phase(it); F4_TIM(2);
+#elif IVF_F4_ORDER == 2
+        stencil_phase(it); F4_TIM(2); mfma_phase(it); F4_TIM(1);
+#else
         if (wave < 4) { mfma_phase(it); F4_TIM(1); stencil_phase(it); F4_TIM(2); }
         else { stencil_phase(it); F4_TIM(2); mfma_phase(it); F4_TIM(1); }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         F4_TIM(3);

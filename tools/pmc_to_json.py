@@ -22,6 +22,8 @@ def per_launch(path, counter):
             k = "ivffcn::k_fcn_dwpw<5, 4>"
             wgs = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
             k += " 960->160" if wgs == 32 * (int(sys.argv[3]) // 2) else " 960->320"     # 32 row pairs per image (x2 channel halves)
+        if k.endswith("k_fcn_irbd4<true>"): k = "ivffcn::k_fcn_irbd4<true> 160->960->160"        # r03: the probe's name for blocks 15 / 16
+        if k.endswith("k_fcn_irbd4<false>"): k = "ivffcn::k_fcn_irbd4<false> 160->960->320"     # block 17
         acc[k] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
     return {k: (v * 1024 / len(disp[k]), len(disp[k])) for k, v in acc.items()}
 
@@ -29,7 +31,12 @@ def per_launch(path, counter):
 def main():
     fetch = per_launch(sys.argv[1], "FETCH_SIZE"); write = per_launch(sys.argv[2], "WRITE_SIZE")
     n_img = int(sys.argv[3])
-    out = {"command": sys.argv[5], "images_per_launch": n_img,
+    import subprocess, os
+    try:
+        commit = subprocess.check_output(["git", "-C", os.path.dirname(os.path.abspath(__file__)), "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
+    except Exception:
+        commit = os.environ.get("IVF_COMMIT", "unknown")          # the GPU box has no .git: tools/pmc_traffic.sh passes IVF_COMMIT
+    out = {"command": sys.argv[5], "images_per_launch": n_img, "commit": commit,
            "note": "raw counter x 1024 bytes per launch; fetch_correction = 2.0: gfx950 FETCH_SIZE reports half of the bytes of a streaming read "
                    "(MI355X_MICROARCH.md HBM section; calibrated here for 4 / 8 / 16 B per lane by tools/probe/fetch_calib.hip: 512 MiB "
                    "reported for a 1 GiB read at every width); copies / fills of the runtime are left uncorrected",
