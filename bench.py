@@ -103,7 +103,7 @@ def cpu_baseline(pairs_sample, cores, threads_per_pair=1):
     return done / dt, dt
 
 
-def cpu_fcn_baseline(threads, images=8, reps=3):
+def cpu_fcn_baseline(threads, images=8, reps=8):
     """The introspection FCN on host cores the way the reference runs it: a FROZEN TorchScript module (torch.jit.trace +
     torch.jit.freeze of the layer list, oracle/fcn_oracle_torch.frozen -- what torch::jit::load + forward execute at
     ORB/Examples/Stereo/stereo_kitti.cc:236, :508), PyTorch's CPU kernels with `threads` intra-op threads, batches of `images`.
@@ -143,9 +143,9 @@ def cpu_baseline_worker(introspect):
     """Runs in a FRESH process (bench.py --cpu-baseline-worker): the oracle library named by IVF_ORACLE_SO -- the reference's
     own build flags, -O3 -march=native (ORB/CMakeLists.txt:16-17), compiled on this host -- and the frozen-TorchScript FCN leg."""
     cores = max(1, min(os.cpu_count() or 1, 32))
-    sample = max(128, 8 * cores)
+    sample = max(256, 64 * cores)                 # ~4 s on 32 cores: with the FCN leg (~9 s) a bounded sample of 10-30 s of CPU work
     v, secs = cpu_baseline(sample, cores)
-    v2, secs2 = cpu_baseline(max(32, 2 * cores), cores, threads_per_pair=2)
+    v2, secs2 = cpu_baseline(max(64, 8 * cores), cores, threads_per_pair=2)
     out = {"cores": cores, "sample_pairs": sample, "extract_match_all_cores": v, "secs": secs, "extract_match_two_threads_per_pair": v2,
            "checksum": oracle_checksum(), "oracle_so": os.environ.get("IVF_ORACLE_SO", "oracle/libivf_oracle.so")}
     if introspect:
@@ -625,6 +625,25 @@ def main():
         fe1.sync(); torch.cuda.synchronize(dev)
         em_only = P * 64 / (time.perf_counter() - t1)
         del fe1
+    if trk is None and extras:
+        # the tracker step on its own (not part of `value`): the records of the batch the front end holds, consecutive frames of the
+        # stream, against the oracle and next to the oracle's search on one core
+        sc = iv.ORBextractor(NFEAT, 1.2, 8, 20, 7, device_id=local_rank).GetScaleFactors()
+        cam = dict(fx=FX, fy=FX, cx=W / 2 + 0.5, cy=H / 2 - 0.25)
+        tp_h = track_pairs(1, 0, P)
+        tr1 = iv.BatchTracker(NFEAT, sc, cam["fx"], cam["fy"], cam["cx"], cam["cy"], BF, (0.0, 0.0, float(W), float(H)), max_pairs=len(tp_h), device_id=local_rank)
+        tp = torch.tensor(tp_h, dtype=torch.int32, device=dev).reshape(-1, 2)
+        blk = torch.zeros(P * rec, dtype=torch.uint8, device=dev)
+        a1 = torch.full((len(tp_h), NFEAT), -1, dtype=torch.int32, device=dev); n1 = torch.zeros(len(tp_h), dtype=torch.int32, device=dev)
+        fe.sync()
+        fe.pack_gather_block(blk, sptr)
+        tr1.run(blk, tp, a1, n1, stream_ptr=sptr)
+        torch.cuda.synchronize(dev)
+        trk = track_report(torch, iv, tr1, blk, tp, tp_h, a1.cpu().numpy(), n1.cpu().numpy(), sc, cam, stream)
+        trk["in_timed_region"] = False
+        if not trk["parity_ok"]:
+            print("bench.py: rank %d: TRACKER PARITY CHECK FAILED: %s" % (rank, json.dumps(trk)), file=sys.stderr, flush=True)
+            raise SystemExit(4)
     h2d = None
     lat = None
     if extras:
@@ -735,7 +754,7 @@ def main():
         if exch is not None:
             out["exchange"] = exch
         if trk is not None:
-            trk["in_timed_region"] = True
+            trk.setdefault("in_timed_region", True)
             out["track"] = trk
         if fcn is not None:
             out["roofline_fast_nms"] = fast_roof
