@@ -1849,9 +1849,23 @@ __device__ unsigned long long g_f4Tim[16];      // diagnostic build (make EXTRA=
 #endif                        // 2 no weight DMA after the prologue, 4 no stencil phase, 8 no MFMAs
 constexpr int kF4Cin = 160, kF4Hid = 960, kF4Groups = 60;
 constexpr int kF4HP = 20;                         // floats per 16-pixel sub-row of a hidden plane in LDS (80 B: conflict-free b128 rows)
+#ifndef IVF_F4_CS
+#define IVF_F4_CS 324         // floats per channel plane of sH: 16 rows x kF4HP + 4, so that the four 16-lane groups of E's b32 stores hit different banks
+#endif
+constexpr int kF4CS = IVF_F4_CS;
 constexpr int kF4DP = 260;                        // floats per channel of the depthwise output in LDS
 constexpr int kF4ParB = 1024;                     // bytes per parameter slot (16 channels x 12 floats = 768 used)
-constexpr size_t kF4Lds = (size_t)2 * 16 * 16 * kF4HP * 4 + (size_t)2 * 16 * kF4DP * 4 + 4 * 10240 + 3 * kF4ParB;
+#ifndef IVF_F4_LATE
+#define IVF_F4_LATE 1         // 1: the weights of interval it + 2 are requested at the END of interval it (by the waves about to idle at the
+#endif                        // barrier) into a third buffer; 0: weights of it + 1 requested at the start of it (two buffers, r03-a)
+#ifndef IVF_F4_DMA_A
+#define IVF_F4_DMA_A 5        // pieces per wave of the half that finishes early (waves 0-3); the other half shares the rest
+#endif
+#ifndef IVF_F4_STAGE
+#define IVF_F4_STAGE 0        // 1: no LDS-DMA; the weights of interval it + 2 are loaded into 12 VGPRs when a wave's stencil phase of interval
+#endif                        // it starts and written to LDS when it ends (three-slot scheme of IVF_F4_LATE)
+constexpr int kF4WSlots = (IVF_F4_LATE || IVF_F4_STAGE) ? 3 : 2, kF4PSlots = (IVF_F4_LATE || IVF_F4_STAGE) ? 4 : 3;
+constexpr size_t kF4Lds = (size_t)2 * 16 * kF4CS * 4 + (size_t)2 * 16 * kF4DP * 4 + 2 * kF4WSlots * 10240 + kF4PSlots * kF4ParB;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <bool RES>
@@ -1860,11 +1874,11 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
                                                      const float* __restrict__ res, float* __restrict__ Y, int Cout, int tilesP)
 {
     extern __shared__ __attribute__((aligned(16))) uint4 f4smem[];
-    float* const sH = (float*)f4smem;                               // [2][16 ch][16 rows][kF4HP]
-    float* const sD = sH + 2 * 16 * 16 * kF4HP;                     // [2][16 ch][kF4DP]
-    uint4* const sWE = (uint4*)(sD + 2 * 16 * kF4DP);               // [2][5 K steps][hi, lo][64 lanes]
-    uint4* const sWP = sWE + 2 * 640;                               // [2][5 tiles][hi, lo][64 lanes]
-    float* const sPar = (float*)(sWP + 2 * 640);                    // [3][16 ch][12]: 9 taps (x dw BN scale), dw BN shift, expansion BN scale, shift
+    float* const sH = (float*)f4smem;                               // [2][16 ch][kF4CS >= 16 rows x kF4HP]
+    float* const sD = sH + 2 * 16 * kF4CS;                          // [2][16 ch][kF4DP]
+    uint4* const sWE = (uint4*)(sD + 2 * 16 * kF4DP);               // [slots][5 K steps][hi, lo][64 lanes]
+    uint4* const sWP = sWE + kF4WSlots * 640;                       // [slots][5 tiles][hi, lo][64 lanes]
+    float* const sPar = (float*)(sWP + kF4WSlots * 640);            // [slots][16 ch][12]: 9 taps (x dw BN scale), dw BN shift, expansion BN scale, shift
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;     // consecutive L on one XCD (grid x = 16 * images)
     const int b = L >> 4, py = (L >> 2) & 3, px = L & 3;
@@ -1883,24 +1897,53 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(ldsAddr) : "memory");
     };
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
-    auto dma = [&](int it) {                    // what interval `it` consumes: WE[it], par[it] (kept two intervals), WP[it - 2]
-        if ((IVF_F4_ABL & 2) && it > 1) return;
-        const int nb = it & 1;
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            const int c = uwave + 8 * r;
-            if (c < 10) {
-                if (it < kF4Groups) dma16(WE + ((size_t)it * 10 + c) * 64 + lane, ldsWE + (unsigned)(nb * 640 + c * 64) * 16u);
-            } else if (c < 20) {
-                const int c2 = c - 10, gp = it - 2;
-                if (gp >= 0 && gp < kF4Groups)
-                    dma16(WP + (((size_t)gp * tilesP + tile0) * 2 + c2) * 64 + lane, ldsWP + (unsigned)(nb * 640 + c2 * 64) * 16u);
-            } else if (c == 20) {
-                if (it < kF4Groups && lane < 48) dma16(par + (size_t)it * 192 + lane * 4, ldsPar + (unsigned)((it % 3) * kF4ParB));
-            }
+    auto piece = [&](int it, int c) {           // piece c of what interval `it` consumes: WE[it] (c < 10), WP[it - 2] (c < 20), par[it] (c = 20)
+        const int nb = it % kF4WSlots;
+        if (c < 10) {
+            if (it < kF4Groups) dma16(WE + ((size_t)it * 10 + c) * 64 + lane, ldsWE + (unsigned)(nb * 640 + c * 64) * 16u);
+        } else if (c < 20) {
+            const int c2 = c - 10, gp = it - 2;
+            if (gp >= 0 && gp < kF4Groups)
+                dma16(WP + (((size_t)gp * tilesP + tile0) * 2 + c2) * 64 + lane, ldsWP + (unsigned)(nb * 640 + c2 * 64) * 16u);
+        } else if (c == 20) {
+            if (it < kF4Groups && lane < 48) dma16(par + (size_t)it * 192 + lane * 4, ldsPar + (unsigned)((it % kF4PSlots) * kF4ParB));
         }
     };
-    dma(0);
+    auto dma = [&](int it) {                    // all 21 pieces (<= 1 KB each), piece c by wave c % 8
+        if ((IVF_F4_ABL & 2) && it > 1) return;
+#pragma unroll
+        for (int r = 0; r < 3; r++) piece(it, uwave + 8 * r);
+    };
+    auto dma_late = [&](int it) {               // the same pieces, most of them by waves 0-3, which reach the barrier first
+        if ((IVF_F4_ABL & 2) && it > 1) return;
+        constexpr int NA = IVF_F4_DMA_A, NB = 4 * NA >= 21 ? 0 : (21 - 4 * NA + 3) / 4;
+        if (uwave < 4) {
+#pragma unroll
+            for (int r = 0; r < NA; r++) { const int c = uwave + 4 * r; if (c < 21) piece(it, c); }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NB; r++) { const int c = 4 * NA + (uwave - 4) + 4 * r; if (c < 21) piece(it, c); }
+        }
+    };
+    // register staging (IVF_F4_STAGE): piece c = wave + 8 r of what interval it2 consumes
+    auto stage_src = [&](int it2, int r) -> const uint4* {
+        const int ie = it2 < kF4Groups ? it2 : kF4Groups - 1;          // clamped: a slot nobody consumes may hold anything
+        int gp = it2 - 2; gp = gp < 0 ? 0 : (gp >= kF4Groups ? kF4Groups - 1 : gp);
+        const int c = uwave + 8 * r;
+        return c < 10 ? WE + ((size_t)ie * 10 + c) * 64 + lane
+             : c < 20 ? WP + (((size_t)gp * tilesP + tile0) * 2 + (c - 10)) * 64 + lane
+                      : (const uint4*)par + (size_t)ie * 48 + (lane < 48 ? lane : 47);
+    };
+    auto stage_dst = [&](int it2, int r) -> uint4* {
+        const int ws = it2 % kF4WSlots, c = uwave + 8 * r;
+        return c < 10 ? sWE + ws * 640 + c * 64 + lane
+             : c < 20 ? sWP + ws * 640 + (c - 10) * 64 + lane
+                      : (uint4*)(sPar + (it2 % kF4PSlots) * (kF4ParB / 4)) + (lane < 48 ? lane : 47);
+    };
+#define F4_STAGE_LOAD(it2) uint4 sg0 = *stage_src(it2, 0), sg1 = *stage_src(it2, 1), sg2 = sg1; if (uwave < 5) sg2 = *stage_src(it2, 2)
+#define F4_STAGE_STORE(it2) do { *stage_dst(it2, 0) = sg0; *stage_dst(it2, 1) = sg1; if (uwave < 5) *stage_dst(it2, 2) = sg2; } while (0)
+    if (IVF_F4_STAGE) { { F4_STAGE_LOAD(0); F4_STAGE_STORE(0); } { F4_STAGE_LOAD(1); F4_STAGE_STORE(1); } }
+    else { dma(0); if (IVF_F4_LATE) dma(1); }
 
     // ---- the input tile: this wave's 32 sub-image pixels (sub-rows 2w, 2w+1) x 160 channels as B fragments of the 16x16x32 MFMA
     // lane: column n = lane & 15 (sub-column), k = 8 (lane >> 4) + j
@@ -1929,13 +1972,16 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     // stencil thread: channel sch (0..15), sub-row ssr, half row sh_
     const int sch = tid >> 5, ssr = (tid >> 1) & 15, sh_ = tid & 1;
     const float rowM0 = ssr > 0 ? 1.f : 0.f, rowM2 = ssr < 15 ? 1.f : 0.f;
-    const int srow0 = (sch * 16 + (ssr > 0 ? ssr - 1 : ssr)) * kF4HP + 8 * sh_, srow1 = (sch * 16 + ssr) * kF4HP + 8 * sh_,
-              srow2 = (sch * 16 + (ssr < 15 ? ssr + 1 : ssr)) * kF4HP + 8 * sh_;
+    const int srow0 = sch * kF4CS + (ssr > 0 ? ssr - 1 : ssr) * kF4HP + 8 * sh_, srow1 = sch * kF4CS + ssr * kF4HP + 8 * sh_,
+              srow2 = sch * kF4CS + (ssr < 15 ? ssr + 1 : ssr) * kF4HP + 8 * sh_;
     const float mL = sh_ ? 1.f : 0.f, mR = sh_ ? 0.f : 1.f;          // the halo pixel comes from the row's other half (lane -1 / +1)
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+#ifdef IVF_F4_TIMING
+    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
     auto mfma_phase = [&](int it) {
         const int cur = it & 1;
         const bool doE = it < kF4Groups, doP = it >= 2;
@@ -1947,9 +1993,10 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
 #pragma unroll
             for (int j = 0; j < 8; j++) dv[j] = dB[j * kF4DP];
         }
-        const uint4* wE = sWE + cur * 640 + lane;
-        const uint4* wPq = sWP + cur * 640 + lane;
-        const float* pp = sPar + (it % 3) * (kF4ParB / 4) + (4 * (lane >> 4)) * 12 + 10;
+        const int ws = it % kF4WSlots;
+        const uint4* wE = sWE + ws * 640 + lane;
+        const uint4* wPq = sWP + ws * 640 + lane;
+        const float* pp = sPar + (it % kF4PSlots) * (kF4ParB / 4) + (4 * (lane >> 4)) * 12 + 10;
         float2 eb[4];
         HFrag ea[2][2], pa[2][2];
         if (doE) {
@@ -1959,6 +2006,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
         }
         if (doP) { pa[0][0].q = wPq[0]; pa[0][1].q = wPq[64]; }
         f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
+        F4_TIM(4);
         if (doE) {                              // E(it): hidden group `it` = W_E[16 x 160] . X[160 x 32 pixels of this wave]
 #pragma unroll
             for (int s5 = 0; s5 < 5; s5++) {
@@ -1976,6 +2024,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        F4_TIM(5);
         if (doP) {                              // P(it - 2): out[160 x 32 pixels] += W_P[160 x 16] . D[16 x 32 pixels]; its split and
             HFrag ph, pl;                       // its MFMAs are issued while E's are still in the matrix pipe
 #pragma unroll
@@ -1993,21 +2042,22 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        F4_TIM(6);
         if (doE) {                              // E's epilogue under P's MFMAs: BN + ReLU6 -> hidden planes
             // C layout: column = lane & 15 (sub-column), row = 4 (lane >> 4) + r (hidden channel of the group)
-            float* hp = sH + cur * (16 * 16 * kF4HP) + ((4 * (lane >> 4)) * 16 + 2 * wave) * kF4HP + (lane & 15);
+            float* hp = sH + cur * (16 * kF4CS) + (4 * (lane >> 4)) * kF4CS + (2 * wave) * kF4HP + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                hp[(r * 16) * kF4HP] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e0[r], eb[r].x, eb[r].y), 0.f, 6.f);
-                hp[(r * 16 + 1) * kF4HP] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e1[r], eb[r].x, eb[r].y), 0.f, 6.f);
+                hp[r * kF4CS] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e0[r], eb[r].x, eb[r].y), 0.f, 6.f);
+                hp[r * kF4CS + kF4HP] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e1[r], eb[r].x, eb[r].y), 0.f, 6.f);
             }
         }
     };
     auto stencil_phase = [&](int it) {          // S(it - 1): 3x3 on the 16 x 16 planes of group it - 1, + BN + ReLU6
         const int g = it - 1;
         if (g < 0 || g >= kF4Groups || (IVF_F4_ABL & 4)) return;
-        const float* hp = sH + (g & 1) * (16 * 16 * kF4HP);
-        const float4* pq = (const float4*)(sPar + (g % 3) * (kF4ParB / 4) + sch * 12);
+        const float* hp = sH + (g & 1) * (16 * kF4CS);
+        const float4* pq = (const float4*)(sPar + (g % kF4PSlots) * (kF4ParB / 4) + sch * 12);
         const float4 w03 = pq[0], w47 = pq[1], w8s = pq[2];          // taps 0-3 | 4-7 | tap 8, shift, (expansion BN)
         float o[8];
 #pragma unroll
@@ -2036,11 +2086,23 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
                                          __builtin_amdgcn_fmed3f(o[6], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[7], 0.f, 6.f));
     };
 
-#ifdef IVF_F4_TIMING
-    unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#endif
     for (int it = 0; it < kF4Groups + 2; it++) {
-        dma(it + 1);                            // lands during this interval, consumed in the next one
+#if IVF_F4_STAGE
+        if (wave < 4) {
+            mfma_phase(it); F4_TIM(1);
+            F4_STAGE_LOAD(it + 2); __builtin_amdgcn_sched_barrier(0);
+            stencil_phase(it); __builtin_amdgcn_sched_barrier(0);
+            F4_STAGE_STORE(it + 2); F4_TIM(2);
+        } else {
+            F4_STAGE_LOAD(it + 2); __builtin_amdgcn_sched_barrier(0);
+            stencil_phase(it); __builtin_amdgcn_sched_barrier(0);
+            F4_STAGE_STORE(it + 2); F4_TIM(2);
+            mfma_phase(it); F4_TIM(1);
+        }
+        __syncthreads();
+        F4_TIM(3);
+#else
+        if (!IVF_F4_LATE) dma(it + 1);          // lands during this interval, consumed in the next one
         F4_TIM(0);
 #if IVF_F4_ORDER == 1
         mfma_phase(it); F4_TIM(1); stencil_phase(it); F4_TIM(2);
@@ -2050,13 +2112,16 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
         if (wave < 4) { mfma_phase(it); F4_TIM(1); stencil_phase(it); F4_TIM(2); }
         else { stencil_phase(it); F4_TIM(2); mfma_phase(it); F4_TIM(1); }
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // LATE: the pieces of it + 1, requested an interval ago
+        if (IVF_F4_LATE) { dma_late(it + 2); F4_TIM(0); }        // land during it + 1; their slots were last read in it - 1
         __syncthreads();
         F4_TIM(3);
+#endif
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef IVF_F4_TIMING
     if (lane == 0 && (wave == 0 || wave == 4)) {
-        for (int i = 0; i < 4; i++) atomicAdd(&g_f4Tim[(wave ? 8 : 0) + i], tacc[i]);
+        for (int i = 0; i < 7; i++) atomicAdd(&g_f4Tim[(wave ? 8 : 0) + i], tacc[i]);
         atomicAdd(&g_f4Tim[(wave ? 8 : 0) + 7], 1ull);
     }
 #endif
@@ -2773,8 +2838,8 @@ void ivf_fcn_destroy(ivf_fcn* f)
         if (hipMemcpyFromSymbol(t, HIP_SYMBOL(ivffcn::g_f4Tim), sizeof t) == hipSuccess && t[7]) {
             for (int w = 0; w < 2; w++) {
                 const double n = (double)t[8 * w + 7];
-                fprintf(stderr, "[irbd4 timing] wave %d: workgroups %.0f; cycles per workgroup: dma issue %.0f  mfma phase %.0f  stencil phase %.0f  wait + barrier %.0f\n",
-                        4 * w, n, t[8 * w] / n, t[8 * w + 1] / n, t[8 * w + 2] / n, t[8 * w + 3] / n);
+                fprintf(stderr, "[irbd4 timing] wave %d: workgroups %.0f; cycles per workgroup: dma issue %.0f  mfma phase %.0f (first reads %.0f, E loop %.0f, split + P loop %.0f, epilogue %.0f)  stencil phase %.0f  wait + barrier %.0f\n",
+                        4 * w, n, t[8 * w] / n, (t[8 * w + 1] + t[8 * w + 4] + t[8 * w + 5] + t[8 * w + 6]) / n, t[8 * w + 4] / n, t[8 * w + 5] / n, t[8 * w + 6] / n, t[8 * w + 1] / n, t[8 * w + 2] / n, t[8 * w + 3] / n);
             }
             unsigned long long z[16] = {};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(ivffcn::g_f4Tim), z, sizeof z);
