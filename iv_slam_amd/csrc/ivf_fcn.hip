@@ -1861,10 +1861,10 @@ constexpr int kF4ParB = 1024;                     // bytes per parameter slot (1
 #ifndef IVF_F4_DMA_A
 #define IVF_F4_DMA_A 5        // pieces per wave of the half that finishes early (waves 0-3); the other half shares the rest
 #endif
-#ifndef IVF_F4_STAGE
-#define IVF_F4_STAGE 0        // 1: no LDS-DMA; the weights of interval it + 2 are loaded into 12 VGPRs when a wave's stencil phase of interval
-#endif                        // it starts and written to LDS when it ends (three-slot scheme of IVF_F4_LATE)
-constexpr int kF4WSlots = (IVF_F4_LATE || IVF_F4_STAGE) ? 3 : 2, kF4PSlots = (IVF_F4_LATE || IVF_F4_STAGE) ? 4 : 3;
+#ifndef IVF_F4_IL
+#define IVF_F4_IL 1           // 1: branch-free MFMA phase with the f16 splits and E's epilogue placed between its MFMAs; waves 4-7 request the
+#endif                        // phase's first LDS reads before their stencil phase
+constexpr int kF4WSlots = IVF_F4_LATE ? 3 : 2, kF4PSlots = IVF_F4_LATE ? 4 : 3;
 constexpr size_t kF4Lds = (size_t)2 * 16 * kF4CS * 4 + (size_t)2 * 16 * kF4DP * 4 + 2 * kF4WSlots * 10240 + kF4PSlots * kF4ParB;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -1925,25 +1925,8 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
             for (int r = 0; r < NB; r++) { const int c = 4 * NA + (uwave - 4) + 4 * r; if (c < 21) piece(it, c); }
         }
     };
-    // register staging (IVF_F4_STAGE): piece c = wave + 8 r of what interval it2 consumes
-    auto stage_src = [&](int it2, int r) -> const uint4* {
-        const int ie = it2 < kF4Groups ? it2 : kF4Groups - 1;          // clamped: a slot nobody consumes may hold anything
-        int gp = it2 - 2; gp = gp < 0 ? 0 : (gp >= kF4Groups ? kF4Groups - 1 : gp);
-        const int c = uwave + 8 * r;
-        return c < 10 ? WE + ((size_t)ie * 10 + c) * 64 + lane
-             : c < 20 ? WP + (((size_t)gp * tilesP + tile0) * 2 + (c - 10)) * 64 + lane
-                      : (const uint4*)par + (size_t)ie * 48 + (lane < 48 ? lane : 47);
-    };
-    auto stage_dst = [&](int it2, int r) -> uint4* {
-        const int ws = it2 % kF4WSlots, c = uwave + 8 * r;
-        return c < 10 ? sWE + ws * 640 + c * 64 + lane
-             : c < 20 ? sWP + ws * 640 + (c - 10) * 64 + lane
-                      : (uint4*)(sPar + (it2 % kF4PSlots) * (kF4ParB / 4)) + (lane < 48 ? lane : 47);
-    };
-#define F4_STAGE_LOAD(it2) uint4 sg0 = *stage_src(it2, 0), sg1 = *stage_src(it2, 1), sg2 = sg1; if (uwave < 5) sg2 = *stage_src(it2, 2)
-#define F4_STAGE_STORE(it2) do { *stage_dst(it2, 0) = sg0; *stage_dst(it2, 1) = sg1; if (uwave < 5) *stage_dst(it2, 2) = sg2; } while (0)
-    if (IVF_F4_STAGE) { { F4_STAGE_LOAD(0); F4_STAGE_STORE(0); } { F4_STAGE_LOAD(1); F4_STAGE_STORE(1); } }
-    else { dma(0); if (IVF_F4_LATE) dma(1); }
+    dma(0);
+    if (IVF_F4_LATE) dma(1);
 
     // ---- the input tile: this wave's 32 sub-image pixels (sub-rows 2w, 2w+1) x 160 channels as B fragments of the 16x16x32 MFMA
     // lane: column n = lane & 15 (sub-column), k = 8 (lane >> 4) + j
@@ -1976,6 +1959,10 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
               srow2 = sch * kF4CS + (ssr < 15 ? ssr + 1 : ssr) * kF4HP + 8 * sh_;
     const float mL = sh_ ? 1.f : 0.f, mR = sh_ ? 0.f : 1.f;          // the halo pixel comes from the row's other half (lane -1 / +1)
 
+#if IVF_F4_IL
+    for (int i = tid; i < 2 * 16 * kF4DP / 4; i += 512) ((uint4*)sD)[i] = make_uint4(0u, 0u, 0u, 0u);      // P(-2), P(-1): zero operands
+    for (int i = tid; i < 2 * 640; i += 512) sWP[i] = make_uint4(0u, 0u, 0u, 0u);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -2053,6 +2040,72 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
             }
         }
     };
+#if IVF_F4_IL
+    // ---- MFMA phase, branch-free form.  Intervals 0, 1 run P on zeroed operands (sD and the first two sWP slots are cleared in the
+    // prologue), intervals 60, 61 run E into planes nobody reads: no `it`-dependent control flow inside the phase.
+    struct MPre { float dv[8]; float2 eb[4]; HFrag ea0[2], pa0[2]; };
+    auto mfma_pre = [&](int it, MPre& m) {      // every LDS read of the phase that depends on no MFMA
+        const int cur = it & 1, ws = it % kF4WSlots;
+        const float* dB = sD + cur * (16 * kF4DP) + (8 * (lane >> 5)) * kF4DP + 32 * wave + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 8; j++) m.dv[j] = dB[j * kF4DP];
+        const float* pp = sPar + (it % kF4PSlots) * (kF4ParB / 4) + (4 * (lane >> 4)) * 12 + 10;
+#pragma unroll
+        for (int r = 0; r < 4; r++) m.eb[r] = *(const float2*)(pp + r * 12);
+        const uint4* wE = sWE + ws * 640 + lane;
+        const uint4* wPq = sWP + ws * 640 + lane;
+        m.ea0[0].q = wE[0]; m.ea0[1].q = wE[64];
+        m.pa0[0].q = wPq[0]; m.pa0[1].q = wPq[64];
+    };
+    auto mfma_main = [&](int it, MPre& m) {
+        const int cur = it & 1, ws = it % kF4WSlots;
+        const uint4* wE = sWE + ws * 640 + lane;
+        const uint4* wPq = sWP + ws * 640 + lane;
+        HFrag ea[2][2], pa[2][2], ph, pl;
+        ea[0][0] = m.ea0[0]; ea[0][1] = m.ea0[1]; pa[0][0] = m.pa0[0]; pa[0][1] = m.pa0[1];
+        f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
+        F4_TIM(4);
+#pragma unroll
+        for (int s5 = 0; s5 < 5; s5++) {        // E(it): hidden group `it` = W_E[16 x 160] . X[160 x 32 pixels of this wave]
+            if (s5 + 1 < 5) { ea[(s5 + 1) & 1][0].q = wE[(2 * s5 + 2) * 64]; ea[(s5 + 1) & 1][1].q = wE[(2 * s5 + 3) * 64]; }
+            const HFrag &ah = ea[s5 & 1][0], &al = ea[s5 & 1][1];
+            e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, bh[s5][0].v, e0, 0, 0, 0);
+            e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, bh[s5][1].v, e1, 0, 0, 0);
+            e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bl[s5][0].v, e0, 0, 0, 0);
+            e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bl[s5][1].v, e1, 0, 0, 0);
+            e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[s5][0].v, e0, 0, 0, 0);
+            e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[s5][1].v, e1, 0, 0, 0);
+            if (s5 < 4) split_pair(m.dv[2 * s5], m.dv[2 * s5 + 1], ph.u[s5], pl.u[s5]);      // P's B fragment, one pair per step
+            // order inside the step: the next fragments' reads first, then one VALU instruction behind each MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int i = 0; i < 6; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        F4_TIM(5);
+        // C layout of E: column = lane & 15 (sub-column), row = 4 (lane >> 4) + r (hidden channel of the group)
+        float* hp = sH + cur * (16 * kF4CS) + (4 * (lane >> 4)) * kF4CS + (2 * wave) * kF4HP + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < 5; t++) {           // P(it - 2): out[160 x 32 pixels] += W_P[160 x 16] . D[16 x 32 pixels]
+            if (t + 1 < 5) { pa[(t + 1) & 1][0].q = wPq[(2 * t + 2) * 64]; pa[(t + 1) & 1][1].q = wPq[(2 * t + 3) * 64]; }
+            const HFrag &ah = pa[t & 1][0], &al = pa[t & 1][1];
+            pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, ph.v, pacc[t], 0, 0, 0);
+            pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, pl.v, pacc[t], 0, 0, 0);
+            pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, ph.v, pacc[t], 0, 0, 0);
+            if (t >= 1) {                       // E's epilogue, one row per step (E's last MFMA retired during step 0): BN + ReLU6 -> planes
+                const int r = t - 1;
+                hp[r * kF4CS] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e0[r], m.eb[r].x, m.eb[r].y), 0.f, 6.f);
+                hp[r * kF4CS + kF4HP] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e1[r], m.eb[r].x, m.eb[r].y), 0.f, 6.f);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        F4_TIM(6);
+    };
+#endif
     auto stencil_phase = [&](int it) {          // S(it - 1): 3x3 on the 16 x 16 planes of group it - 1, + BN + ReLU6
         const int g = it - 1;
         if (g < 0 || g >= kF4Groups || (IVF_F4_ABL & 4)) return;
@@ -2087,24 +2140,16 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     };
 
     for (int it = 0; it < kF4Groups + 2; it++) {
-#if IVF_F4_STAGE
-        if (wave < 4) {
-            mfma_phase(it); F4_TIM(1);
-            F4_STAGE_LOAD(it + 2); __builtin_amdgcn_sched_barrier(0);
-            stencil_phase(it); __builtin_amdgcn_sched_barrier(0);
-            F4_STAGE_STORE(it + 2); F4_TIM(2);
-        } else {
-            F4_STAGE_LOAD(it + 2); __builtin_amdgcn_sched_barrier(0);
-            stencil_phase(it); __builtin_amdgcn_sched_barrier(0);
-            F4_STAGE_STORE(it + 2); F4_TIM(2);
-            mfma_phase(it); F4_TIM(1);
-        }
-        __syncthreads();
-        F4_TIM(3);
-#else
         if (!IVF_F4_LATE) dma(it + 1);          // lands during this interval, consumed in the next one
         F4_TIM(0);
-#if IVF_F4_ORDER == 1
+#if IVF_F4_IL
+        {
+            MPre m;
+            mfma_pre(it, m); __builtin_amdgcn_sched_barrier(0);
+            if (wave < 4) { mfma_main(it, m); F4_TIM(1); stencil_phase(it); F4_TIM(2); }
+            else { stencil_phase(it); F4_TIM(2); __builtin_amdgcn_sched_barrier(0); mfma_main(it, m); F4_TIM(1); }
+        }
+#elif IVF_F4_ORDER == 1
         mfma_phase(it); F4_TIM(1); stencil_phase(it); F4_TIM(2);
 #elif IVF_F4_ORDER == 2
         stencil_phase(it); F4_TIM(2); mfma_phase(it); F4_TIM(1);
@@ -2116,7 +2161,6 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
         if (IVF_F4_LATE) { dma_late(it + 2); F4_TIM(0); }        // land during it + 1; their slots were last read in it - 1
         __syncthreads();
         F4_TIM(3);
-#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef IVF_F4_TIMING
