@@ -277,6 +277,31 @@ void ivf_tracker_destroy(ivf_tracker* t);
 int  ivf_tracker_run(ivf_tracker* t, const uint8_t* d_records, size_t record_bytes, int n_records, const int32_t* d_pairs, int n_pairs,
                      const float* d_poses, const uint8_t* d_point_flags, int32_t* d_assign, int32_t* d_nmatches, void* hip_stream);
 
+/* One local map point as Tracking::SearchLocalPoints (ORB/src/Tracking.cc:2088-2132) sees it.  80 bytes, 16-byte aligned arrays. */
+typedef struct ivf_local_point {
+    float   pos[3];                  /* MapPoint::GetWorldPos() */
+    float   normal[3];               /* MapPoint::GetNormal() */
+    float   min_distance;            /* mfMinDistance: the range test uses 0.8f * it (GetMinDistanceInvariance, MapPoint.cc:378-382) */
+    float   max_distance;            /* mfMaxDistance: the range test uses 1.2f * it (:384-388), PredictScale the value itself (:412); > 0 */
+    uint8_t desc[32];                /* GetDescriptor() */
+    int32_t flags;                   /* bit 0: skip (isBad(), or mnLastFrameSeen == this frame: already matched, Tracking.cc:2114-2115);
+                                      * bit 1: Observations() > 0 (a keypoint this point takes is skipped by later points, ORBmatcher.cc:87-89) */
+    int32_t pad[3];
+} ivf_local_point;
+/* Batched Tracking::SearchLocalPoints, from the projection on: for frame f = record d_frames[f] with pose d_poses[d_frames[f]]
+ * (nullable = identity) and its local map points d_points[d_point_offsets[f] .. d_point_offsets[f+1]) (at most
+ * max_points_per_frame are used): Frame::isInFrustum(pMP, cos_limit = 0.5) (Frame.cc:557-613) incl. MapPoint::PredictScale
+ * (MapPoint.cc:407-422), then ORBmatcher(nn_ratio).SearchByProjection(F, vpMapPoints, th) (ORBmatcher.cc:45-135).
+ * d_occupied [n_frames][nfeatures] (nullable): 1 = the keypoint already holds a map point with observations (skipped, :87-89).
+ * Outputs: d_assign [n_frames][nfeatures] = index (within the frame's point range) of the map point each keypoint received in
+ * THIS call or -1; d_nmatches [n_frames] = the return value (assignments made, replaced ones included).  n_frames <= max_pairs.
+ * Asynchronous on hip_stream; shares the handle's scratch (and its one-call-at-a-time rule) with ivf_tracker_run.
+ * UpdateQualityScores (ORBmatcher.cc:130-132) is not part of it: ivf_update_quality_scores. */
+int  ivf_tracker_search_local(ivf_tracker* t, const uint8_t* d_records, size_t record_bytes, int n_records, const int32_t* d_frames,
+                              int n_frames, const float* d_poses, const ivf_local_point* d_points, const int32_t* d_point_offsets,
+                              int max_points_per_frame, const uint8_t* d_occupied, float th, float nn_ratio, float cos_limit,
+                              int32_t* d_assign, int32_t* d_nmatches, void* hip_stream);
+
 /* ---- introspection FCN forward (IF/networks/models_light/models_light.py:18-28; called at
  * ORB/Examples/Stereo/stereo_kitti.cc:231-247 (load) and :493-514 (pre-process, forward, u8 truncation)) ----
  * weights_blob: the model's state_dict f32 tensors in state_dict order, num_batches_tracked skipped

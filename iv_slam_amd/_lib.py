@@ -29,6 +29,12 @@ class FrontendConfig(C.Structure):
                 ("max_pairs", C.c_int32), ("bf", C.c_float), ("b", C.c_float), ("device_id", C.c_int32)]
 
 
+# ivf_local_point (include/ivfront.h): one local map point of Tracking::SearchLocalPoints, 80 bytes
+LOCAL_POINT_DTYPE = np.dtype([("pos", np.float32, 3), ("normal", np.float32, 3), ("min_distance", np.float32), ("max_distance", np.float32),
+                              ("desc", np.uint8, 32), ("flags", np.int32), ("pad", np.int32, 3)])
+assert LOCAL_POINT_DTYPE.itemsize == 80
+
+
 class TrackConfig(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("nlevels", C.c_int32), ("scale_factors", C.c_float * MAX_LEVELS),
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float), ("b", C.c_float),
@@ -130,6 +136,8 @@ _SIGS = {
     "ivf_tracker_create": (C.c_int, [C.POINTER(TrackConfig), C.POINTER(vp)]),
     "ivf_tracker_destroy": (None, [vp]),
     "ivf_tracker_run": (C.c_int, [vp, vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]),
+    "ivf_tracker_search_local": (C.c_int, [vp, vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_float, C.c_float,
+                                           C.c_float, vp, vp, vp]),
     "ivf_fcn_create": (C.c_int, [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "ivf_fcn_destroy": (None, [vp]),
     "ivf_fcn_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),

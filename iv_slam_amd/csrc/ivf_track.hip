@@ -11,6 +11,16 @@
 //   * the retry with the wider window when fewer than 20 matches were found (Tracking.cc:1320-1330).
 // Nothing crosses PCIe: records, poses, the per-pair grids, candidate lists and results stay in HBM.
 //
+// ivf_tracker_search_local is the second matcher call of a tracked frame, Tracking::SearchLocalPoints (Tracking.cc:2088-2132), for many
+// frames at once: Frame::isInFrustum of every local map point (Frame.cc:557-613, MapPoint::PredictScale MapPoint.cc:407-422 with
+// glibc's logf restated) and ORBmatcher::SearchByProjection(F, vpMapPoints, th) (ORBmatcher.cc:45-135): windows
+// on levels [level - 1, level], stereo check, best / second best in candidate order, the ratio test between candidates of the
+// same octave, and the ORDER-DEPENDENT occupancy rule (a keypoint taken by a point with observations is skipped by later points).
+//   k_local_prepare  one workgroup per frame: the same grid, then one thread per map point: projection -> query + radius
+//   k_local_window   one wave per (frame, map point): ordered candidate list, entry = index | octave << 12 | distance << 16
+//   k_local_greedy   one wave per frame: walks the points in order against the occupancy state in LDS; best and second best are
+//                    two DPP minimum reductions of (distance << 6 | list position)
+//
 // Kernels (all hand-written for gfx950; wave = 64):
 //   k_track_prepare  one workgroup per frame pair: AssignFeaturesToGrid of the current record (stable counting sort in LDS),
 //                    pose algebra in double (cv::gemm semantics), depth ranking, projection -> query table
@@ -46,6 +56,7 @@ struct TrackParams {                               // uniform kernel arguments
     float fx, fy, cx, cy, invfx, invfy, bf, b;
     float minX, minY, maxX, maxY, invW, invH;     // image bounds and mfGridElementWidthInv / HeightInv (Frame.cc:208-209)
     float thDepth;                                // > 0: UpdateLastFrame's close-point rule
+    float logScale;                               // mfLogScaleFactor = logf(mfScaleFactor) (Frame.cc:106)
     int checkOri, defaultBlocks;
     size_t recBytes;
 };
@@ -133,31 +144,12 @@ DEVINL void walk_window(const TrackParams& P, const ivf_keypoint* __restrict__ k
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_track_prepare: one workgroup per frame pair
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_track_prepare(TrackParams P, const uint8_t* __restrict__ records, const int2* __restrict__ pairs,
-                                                      const float* __restrict__ poses, const uint8_t* __restrict__ pointFlags,
-                                                      int* __restrict__ gStart, unsigned short* __restrict__ gIdx,
-                                                      Query* __restrict__ queries, int* __restrict__ retryFlag)
+// Frame::AssignFeaturesToGrid (Frame.cc:415-430) by one 256-thread workgroup: CSR, buckets in ix-major order, keypoints of a
+// bucket in insertion order (rank inside the bucket = same-bucket keypoints in earlier 256-blocks + earlier threads).
+// cnt [kGC * kGR], part [256], blk [256]: workgroup scratch in LDS.
+DEVINL void build_grid(const TrackParams& P, const ivf_keypoint* __restrict__ kc, int nC, int* __restrict__ start,
+                       unsigned short* __restrict__ idx, int* cnt, int* part, int* blk, int tid)
 {
-    __shared__ int cnt[kGC * kGR];
-    __shared__ int part[256];
-    __shared__ int blk[256];
-    __shared__ float s_z[kMaxTrackFeatures];
-    __shared__ int s_nStereo, s_nClose;
-    const int p = blockIdx.x, tid = threadIdx.x;
-    const int2 pr = pairs[p];
-    const uint8_t* recL = records + (size_t)pr.x * P.recBytes;
-    const uint8_t* recC = records + (size_t)pr.y * P.recBytes;
-    const int nL = rec_count(recL, P.nf), nC = rec_count(recC, P.nf);
-    if (tid == 0) { retryFlag[p] = 0; s_nStereo = 0; s_nClose = 0; }
-
-    // ---- Frame::AssignFeaturesToGrid of the current frame (Frame.cc:415-430): CSR, buckets in ix-major order, keypoints of a
-    // bucket in insertion order (rank inside the bucket = same-bucket keypoints in earlier 256-blocks + earlier threads)
-    const ivf_keypoint* kc = rec_kps(recC);
-    int* start = gStart + (size_t)p * (kGC * kGR + 1);
-    unsigned short* idx = gIdx + (size_t)p * P.nf;
     for (int c = tid; c < kGC * kGR; c += 256) cnt[c] = 0;
     __syncthreads();
     auto cell_of = [&](int i) {
@@ -197,6 +189,31 @@ __global__ __launch_bounds__(256) void k_track_prepare(TrackParams P, const uint
         if (c >= 0) atomicAdd(&cnt[c], 1);
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_track_prepare: one workgroup per frame pair
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_track_prepare(TrackParams P, const uint8_t* __restrict__ records, const int2* __restrict__ pairs,
+                                                      const float* __restrict__ poses, const uint8_t* __restrict__ pointFlags,
+                                                      int* __restrict__ gStart, unsigned short* __restrict__ gIdx,
+                                                      Query* __restrict__ queries, int* __restrict__ retryFlag)
+{
+    __shared__ int cnt[kGC * kGR];
+    __shared__ int part[256];
+    __shared__ int blk[256];
+    __shared__ float s_z[kMaxTrackFeatures];
+    __shared__ int s_nStereo, s_nClose;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int2 pr = pairs[p];
+    const uint8_t* recL = records + (size_t)pr.x * P.recBytes;
+    const uint8_t* recC = records + (size_t)pr.y * P.recBytes;
+    const int nL = rec_count(recL, P.nf), nC = rec_count(recC, P.nf);
+    if (tid == 0) { retryFlag[p] = 0; s_nStereo = 0; s_nClose = 0; }
+
+    // ---- Frame::AssignFeaturesToGrid of the current frame (Frame.cc:415-430)
+    const ivf_keypoint* kc = rec_kps(recC);
+    build_grid(P, kc, nC, gStart + (size_t)p * (kGC * kGR + 1), gIdx + (size_t)p * P.nf, cnt, part, blk, tid);
 
     // ---- poses: Tcw of the two frames (row-major 3x4), identity when none are given (zero-motion prior)
     float Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tl[3] = {0, 0, 0}, Rc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tc[3] = {0, 0, 0};
@@ -468,6 +485,265 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
     }
 }
 
+
+// ================================================================================================
+// Tracking::SearchLocalPoints, batched (ivf_tracker_search_local)
+// ================================================================================================
+// glibc >= 2.27 logf (oracle/ivf_oracle.c:orc_logf is the same arithmetic, checked against libm for every positive
+// normal float): what MapPoint::PredictScale's log(ratio) resolves to.  Positive normal arguments only (a distance ratio).
+__constant__ double c_logfT[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+    {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+    {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+    {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+    {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
+    {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+DEVINL float glibc_logf(float x)
+{
+    const unsigned ix = __builtin_bit_cast(unsigned, x);
+    if (ix == 0x3f800000u) return 0.0f;
+    const unsigned tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15u);
+    const int k = (int)tmp >> 23;
+    const double z = (double)__builtin_bit_cast(float, ix - (tmp & 0xff800000u)), invc = c_logfT[i][0], logc = c_logfT[i][1];
+    const double r = z * invc - 1.0;
+    const double y0 = logc + (double)k * 0x1.62e42fefa39efp-1;
+    const double r2 = r * r;
+    double y = 0x1.5575b0be00b6ap-2 * r + -0x1.ffffef20a4123p-2;
+    y = -0x1.00ea348b88334p-2 * r2 + y;
+    y = y * r2 + (y0 + r);
+    return (float)y;
+}
+
+static_assert(sizeof(ivf_local_point) == 80, "ivf_local_point is read as five 16-byte pieces");
+constexpr int kLocalNoBlock = 0x40000000;         // assignment made by a point without observations: later points may replace it (:87-89)
+
+// one workgroup per frame: grid, then Frame::isInFrustum + the window radius of every local map point
+__global__ __launch_bounds__(256) void k_local_prepare(TrackParams P, const uint8_t* __restrict__ records, const int* __restrict__ frames,
+                                                      const float* __restrict__ poses, const ivf_local_point* __restrict__ points,
+                                                      const int* __restrict__ offsets, float th, float cosLimit, int maxM,
+                                                      int* __restrict__ gStart, unsigned short* __restrict__ gIdx,
+                                                      Query* __restrict__ queries, float* __restrict__ radii)
+{
+    __shared__ int cnt[kGC * kGR];
+    __shared__ int part[256];
+    __shared__ int blk[256];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int ri = frames[f];
+    const uint8_t* recC = records + (size_t)ri * P.recBytes;
+    const int nC = rec_count(recC, P.nf);
+    build_grid(P, rec_kps(recC), nC, gStart + (size_t)f * (kGC * kGR + 1), gIdx + (size_t)f * P.nf, cnt, part, blk, tid);
+
+    float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0}, Ow[3];
+    if (poses) {
+        const float* T = poses + (size_t)ri * 12;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) R[3 * i + j] = T[4 * i + j];
+            t[i] = T[4 * i + 3];
+        }
+    }
+    neg_rt_mul(R, t, Ow);                                                             // mOw (Frame.cc:554)
+    const int m0 = offsets[f], M = min(offsets[f + 1] - m0, maxM);
+    Query* Q = queries + (size_t)f * maxM;
+    float* Rd = radii + (size_t)f * maxM;
+    for (int m = tid; m < M; m += 256) {
+        const ivf_local_point mp = points[m0 + m];
+        Query q; q.u = 0; q.v = 0; q.ur = 0; q.bits = 0;
+        float radius = 0.0f;
+        if (!(mp.flags & 1)) {                                                        // isBad() / mnLastFrameSeen == mnId (Tracking.cc:2114-2115)
+            float Pc[3];
+            mul_add(R, mp.pos, t, Pc);                                                // Frame.cc:565
+            if (!(Pc[2] < 0.0f)) {                                                    // :571
+                const float invz = 1.0f / Pc[2];
+                const float u = P.fx * Pc[0] * invz + P.cx, v = P.fy * Pc[1] * invz + P.cy;
+                if (!(u < P.minX || u > P.maxX) && !(v < P.minY || v > P.maxY)) {     // :579-582
+                    const float PO[3] = {mp.pos[0] - Ow[0], mp.pos[1] - Ow[1], mp.pos[2] - Ow[2]};
+                    const double n2 = (double)PO[0] * (double)PO[0] + (double)PO[1] * (double)PO[1] + (double)PO[2] * (double)PO[2];
+                    const float dist = (float)sqrt(n2);                               // cv::norm (:588)
+                    const float minD = 0.8f * mp.min_distance, maxD = 1.2f * mp.max_distance;     // MapPoint.cc:378-388
+                    if (!(dist < minD || dist > maxD)) {                              // :590
+                        const double dt = (double)PO[0] * (double)mp.normal[0] + (double)PO[1] * (double)mp.normal[1] + (double)PO[2] * (double)mp.normal[2];
+                        const float viewCos = (float)(dt / (double)dist);             // :596
+                        if (!(viewCos < cosLimit)) {                                  // :598
+                            // MapPoint::PredictScale (MapPoint.cc:407-422)
+                            const float ratio = mp.max_distance / dist;
+                            int lv = (int)ceilf(glibc_logf(ratio) / P.logScale);
+                            lv = lv < 0 ? 0 : (lv >= P.nlevels ? P.nlevels - 1 : lv);
+                            float r = ((double)viewCos > 0.998) ? 2.5f : 4.0f;        // RadiusByViewingCos (ORBmatcher.cc:137-143)
+                            if (th != 1.0f) r *= th;                                  // :65-66
+                            radius = r * P.scale[lv];                                 // :69
+                            q.u = u; q.v = v; q.ur = u - P.bf * invz;                 // :606-608
+                            q.bits = (unsigned)lv | (1u << 24) | ((unsigned)((mp.flags >> 1) & 1) << 25);
+                        }
+                    }
+                }
+            }
+        }
+        Q[m] = q; Rd[m] = radius;
+    }
+}
+
+// one wave per (frame, map point): the ordered candidate list of ORBmatcher.cc:68-100 minus the occupancy test
+__global__ __launch_bounds__(256) void k_local_window(TrackParams P, const uint8_t* __restrict__ records, const int* __restrict__ frames,
+                                                     const ivf_local_point* __restrict__ points, const int* __restrict__ offsets, int maxM,
+                                                     const int* __restrict__ gStart, const unsigned short* __restrict__ gIdx,
+                                                     const Query* __restrict__ queries, const float* __restrict__ radii,
+                                                     int* __restrict__ count, unsigned* __restrict__ lists)
+{
+    const int f = blockIdx.y;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int m0 = offsets[f], M = min(offsets[f + 1] - m0, maxM);
+    if (m >= M) return;
+    const uint8_t* recC = records + (size_t)frames[f] * P.recBytes;
+    const Query q = queries[(size_t)f * maxM + m];
+    int total = 0;
+    if ((q.bits >> 24) & 1) {
+        const int lv = q.bits & 0xff;
+        const float r = radii[(size_t)f * maxM + m];
+        const uint4* qd = (const uint4*)points[m0 + m].desc;
+        const uint4 qa = qd[0], qb = qd[1];
+        const float* urC = rec_uright(recC, P.nf);
+        const ivf_keypoint* kc = rec_kps(recC);
+        unsigned* L = lists + ((size_t)f * maxM + m) * kListCap;
+        walk_window(P, kc, rec_desc(recC, P.nf), gStart + (size_t)f * (kGC * kGR + 1), gIdx + (size_t)f * P.nf,
+                    q.u, q.v, r, lv - 1, lv, qa, qb, lane, [&](bool ok, int i2, int d) {
+                        if (ok) { const float u2 = urC[i2]; if (u2 > 0) { const float er = fabsf(q.ur - u2); if (er > r) ok = false; } }   // :91-96
+                        const unsigned long long mk = __ballot(ok);
+                        if (ok) {
+                            const int pos = total + __popcll(mk & ((1ull << lane) - 1ull));
+                            if (pos < kListCap) L[pos] = (unsigned)i2 | ((unsigned)kc[i2].octave << 12) | ((unsigned)d << 16);
+                        }
+                        total += __popcll(mk);
+                    });
+    }
+    if (lane == 0) count[(size_t)f * maxM + m] = total;
+}
+
+// top two of (key = distance << 12 | ordinal) pairs: a (best, second) pair merged with another one
+DEVINL void merge_top2(unsigned& kb, unsigned& eb, unsigned& ks, unsigned& es, unsigned k1, unsigned e1, unsigned k2, unsigned e2)
+{
+    if (k1 < kb) {
+        if (kb < k2) { ks = kb; es = eb; } else { ks = k2; es = e2; }
+        kb = k1; eb = e1;
+    } else if (k1 < ks) { ks = k1; es = e1; }
+}
+
+// one wave per frame: the greedy walk of ORBmatcher.cc:51-126 over the frame's map points.
+// Best / second best (:102-114) are updated sequentially in the reference: `dist < bestDist` demotes the best to second, otherwise
+// `dist < bestDist2` replaces the second.  That equals "first and second of the candidates ordered by (distance, position)":
+//   * the best is the first candidate of minimal distance (a later equal one fails the strict `<`);
+//   * a demoted best was the (distance, position)-minimum of everything before the new best, a directly inserted second is the first
+//     of its distance among the non-best seen so far, and a later candidate of the same distance never replaces either (strict `<`):
+//     by induction the second is the (distance, position)-minimum of all candidates but the best.
+// So two minimum reductions of (distance << 12 | position) -- the second with the winner's lane masked -- give both, with their octaves.
+__global__ __launch_bounds__(64) void k_local_greedy(TrackParams P, const uint8_t* __restrict__ records, const int* __restrict__ frames,
+                                                    const ivf_local_point* __restrict__ points, const int* __restrict__ offsets, int maxM,
+                                                    const int* __restrict__ gStart, const unsigned short* __restrict__ gIdx,
+                                                    const Query* __restrict__ queries, const float* __restrict__ radii,
+                                                    const uint8_t* __restrict__ occupied, float nnRatio, const int* __restrict__ count,
+                                                    const unsigned* __restrict__ lists, int* __restrict__ assignOut,
+                                                    int* __restrict__ nmatchesOut)
+{
+    extern __shared__ int s_mem[];
+    const int f = blockIdx.x, lane = threadIdx.x;
+    int* s_assign = s_mem;                                    // [nf]: -1 free, -2 held by a point with observations before the call,
+                                                              // >= 0 local point index (| kLocalNoBlock) assigned by this call
+    const uint8_t* recC = records + (size_t)frames[f] * P.recBytes;
+    const int nC = rec_count(recC, P.nf);
+    const int m0 = offsets[f], M = min(offsets[f + 1] - m0, maxM);
+    const uint8_t* occ = occupied ? occupied + (size_t)f * P.nf : nullptr;
+    for (int i = lane; i < nC; i += 64) s_assign[i] = (occ && occ[i]) ? -2 : -1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const Query* Q = queries + (size_t)f * maxM;
+    const float* Rd = radii + (size_t)f * maxM;
+    const int* C = count + (size_t)f * maxM;
+    const unsigned* Lp = lists + (size_t)f * maxM * kListCap;
+    int nm = 0;
+    auto blocked = [&](int i2) { const int a = s_assign[i2]; return a == -2 || (a >= 0 && !(a & kLocalNoBlock)); };   // :87-89
+
+    for (int g0 = 0; g0 < M; g0 += kPrefetch) {
+        const int gi = g0 + (lane & (kPrefetch - 1));
+        const bool gv = gi < M;
+        const int myCnt = gv ? C[gi] : 0;
+        unsigned myBits = 0;
+        if (gv) myBits = Q[gi].bits;
+        unsigned ent[kPrefetch];
+#pragma unroll
+        for (int k = 0; k < kPrefetch; k++) ent[k] = (g0 + k < M) ? Lp[(size_t)(g0 + k) * kListCap + lane] : 0u;
+#pragma unroll
+        for (int k = 0; k < kPrefetch; k++) {
+            const int m = g0 + k;
+            const int cnt = __builtin_amdgcn_readlane(myCnt, k);
+            if (m >= M || cnt == 0) continue;                                         // vIndices.empty() (:71)
+            const unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)myBits, k);
+            unsigned kb = 0xffffffffu, eb = 0, ks = 0xffffffffu, es = 0;               // best / second: key = dist << 12 | ordinal, entry
+            if (cnt <= kListCap) {
+                const unsigned e = ent[k];
+                const bool ok = lane < cnt && !blocked((int)(e & 0xfff));
+                const unsigned key = ok ? ((e >> 16) << 12) | (unsigned)lane : 0xffffffffu;
+                kb = wave_min_u32_dpp(key);
+                if (kb != 0xffffffffu) {
+                    const int bl = (int)(kb & 63);
+                    eb = (unsigned)__builtin_amdgcn_readlane((int)e, bl);
+                    ks = wave_min_u32_dpp(lane == bl ? 0xffffffffu : key);
+                    if (ks != 0xffffffffu) es = (unsigned)__builtin_amdgcn_readlane((int)e, (int)(ks & 63));
+                }
+            } else {
+                // the window overflowed its list: walk it again against the live occupancy state, 64 candidates at a time
+                const Query q = Q[m];
+                const float r = Rd[m];
+                const int lv = bits & 0xff;
+                const uint4* qd = (const uint4*)points[m0 + m].desc;
+                const uint4 qa = qd[0], qb = qd[1];
+                const float* urC = rec_uright(recC, P.nf);
+                const ivf_keypoint* kc = rec_kps(recC);
+                unsigned ordinal = 0;
+                walk_window(P, kc, rec_desc(recC, P.nf), gStart + (size_t)f * (kGC * kGR + 1), gIdx + (size_t)f * P.nf, q.u, q.v, r,
+                            lv - 1, lv, qa, qb, lane, [&](bool ok, int i2, int d) {
+                                if (ok) { const float u2 = urC[i2]; if (u2 > 0) { const float er = fabsf(q.ur - u2); if (er > r) ok = false; } }
+                                const unsigned long long mk = __ballot(ok);
+                                const unsigned pos = ordinal + (unsigned)__popcll(mk & ((1ull << lane) - 1ull));
+                                ordinal += (unsigned)__popcll(mk);
+                                if (ok && blocked(i2)) ok = false;
+                                const unsigned e = ok ? ((unsigned)i2 | ((unsigned)kc[i2].octave << 12) | ((unsigned)d << 16)) : 0u;
+                                const unsigned key = ok ? ((unsigned)d << 12) | pos : 0xffffffffu;
+                                const unsigned k1 = wave_min_u32_dpp(key);
+                                if (k1 == 0xffffffffu) return;
+                                const unsigned long long w1 = __ballot(key == k1);
+                                const int l1 = __ffsll((long long)w1) - 1;
+                                const unsigned e1 = (unsigned)__builtin_amdgcn_readlane((int)e, l1);
+                                const unsigned k2 = wave_min_u32_dpp(lane == l1 ? 0xffffffffu : key);
+                                unsigned e2 = 0;
+                                if (k2 != 0xffffffffu) {
+                                    const unsigned long long w2 = __ballot(key == k2 && lane != l1);
+                                    e2 = (unsigned)__builtin_amdgcn_readlane((int)e, __ffsll((long long)w2) - 1);
+                                }
+                                merge_top2(kb, eb, ks, es, k1, e1, k2, e2);
+                            });
+            }
+            if (kb == 0xffffffffu) continue;
+            const int bestDist = (int)(kb >> 12), bestIdx = (int)(eb & 0xfff), bestLevel = (int)((eb >> 12) & 15);
+            if (bestDist > 100) continue;                                               // TH_HIGH (:118)
+            if (ks != 0xffffffffu) {
+                const int bestDist2 = (int)(ks >> 12), bestLevel2 = (int)((es >> 12) & 15);
+                if (bestLevel == bestLevel2 && (float)bestDist > nnRatio * (float)bestDist2) continue;   // :120-121
+            }
+            if (lane == 0) s_assign[bestIdx] = ((bits >> 25) & 1) ? m : (m | kLocalNoBlock);          // :123
+            nm++;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    int* out = assignOut + (size_t)f * P.nf;
+    for (int i = lane; i < P.nf; i += 64) { const int a = i < nC ? s_assign[i] : -1; out[i] = a < 0 ? -1 : (a & ~kLocalNoBlock); }
+    if (lane == 0) nmatchesOut[f] = nm;
+}
+
 }  // namespace
 
 // ---- C-ABI ---------------------------------------------------------------------------------------------------------------
@@ -478,6 +754,8 @@ struct ivf_tracker {
     unsigned short* dIdx = nullptr;
     Query* dQ = nullptr;
     unsigned* dLists = nullptr;
+    // scratch of ivf_tracker_search_local, sized at its first call / grown on demand: [max_pairs][localCap] queries, radii, counts, lists
+    Query* dLQ = nullptr; float* dLRad = nullptr; int* dLCount = nullptr; unsigned* dLLists = nullptr; int localCap = 0;
     size_t ldsBytes = 0;
     hipEvent_t evDone = nullptr;          // end of the previous run: the scratch above belongs to ONE run at a time
     bool ran = false;
@@ -494,7 +772,7 @@ void ivf_tracker_destroy(ivf_tracker* t)
 {
     if (!t) return;
     (void)hipSetDevice(t->cfg.device_id);
-    void* ptrs[] = {t->dStart, t->dCount, t->dRetry, t->dIdx, t->dQ, t->dLists};
+    void* ptrs[] = {t->dStart, t->dCount, t->dRetry, t->dIdx, t->dQ, t->dLists, t->dLQ, t->dLRad, t->dLCount, t->dLLists};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     if (t->evDone) (void)hipEventDestroy(t->evDone);
     delete t;
@@ -527,6 +805,7 @@ int ivf_tracker_create(const ivf_track_config* cfg, ivf_tracker** out)
     P.invW = (float)kGC / (P.maxX - P.minX); P.invH = (float)kGR / (P.maxY - P.minY);                                    // Frame.cc:208-209
     P.thDepth = cfg->th_depth; P.checkOri = cfg->check_orientation ? 1 : 0; P.defaultBlocks = cfg->points_block ? 1 : 0;
     P.recBytes = ivf_track_record_bytes(cfg->nfeatures);
+    P.logScale = cfg->nlevels > 1 ? logf(cfg->scale_factors[1]) : 1.0f;             // mfLogScaleFactor = log(mfScaleFactor) (Frame.cc:106): logf
     const size_t np = (size_t)cfg->max_pairs, nf = (size_t)cfg->nfeatures;
     t->ldsBytes = nf * 16;
     if (hipMalloc(&t->dStart, np * (kGC * kGR + 1) * sizeof(int)) != hipSuccess || hipMalloc(&t->dIdx, np * nf * sizeof(unsigned short)) != hipSuccess ||
@@ -572,6 +851,52 @@ int ivf_tracker_run(ivf_tracker* t, const uint8_t* d_records, size_t record_byte
         hipLaunchKernelGGL(k_track_greedy, dim3(n_pairs), dim3(64), t->ldsBytes, st, P, d_records, pairs, t->dStart, t->dIdx, t->dQ, th, t->dRetry, pass,
                            t->cfg.retry_below, t->dCount, t->dLists, d_assign, d_nmatches);
     }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(t->evDone, st));
+    t->ran = true;
+    return IVF_OK;
+}
+
+int ivf_tracker_search_local(ivf_tracker* t, const uint8_t* d_records, size_t record_bytes, int n_records, const int32_t* d_frames, int n_frames,
+                             const float* d_poses, const ivf_local_point* d_points, const int32_t* d_point_offsets, int max_points_per_frame,
+                             const uint8_t* d_occupied, float th, float nn_ratio, float cos_limit, int32_t* d_assign, int32_t* d_nmatches,
+                             void* hip_stream)
+{
+    if (!t || !d_records || !d_frames || !d_points || !d_point_offsets || !d_assign || !d_nmatches) return fail(IVF_E_INVALID, "null argument");
+    if (record_bytes != t->P.recBytes) return fail(IVF_E_INVALID, "record_bytes %zu: records of %d features are %zu bytes", record_bytes, t->P.nf, t->P.recBytes);
+    if (((size_t)d_records & 15) != 0 || ((size_t)d_points & 15) != 0) return fail(IVF_E_INVALID, "the record block and the point array must be 16-byte aligned");
+    if (n_records < 1) return fail(IVF_E_INVALID, "n_records must be >= 1");
+    if (n_frames == 0) return IVF_OK;
+    if (n_frames < 0 || n_frames > t->cfg.max_pairs) return fail(IVF_E_INVALID, "n_frames %d outside [0,%d]", n_frames, t->cfg.max_pairs);
+    if (max_points_per_frame < 1 || max_points_per_frame >= kLocalNoBlock) return fail(IVF_E_INVALID, "max_points_per_frame %d out of range", max_points_per_frame);
+    if (!(th > 0) || !(nn_ratio > 0)) return fail(IVF_E_INVALID, "th and nn_ratio must be positive");
+    HIPCHK(hipSetDevice(t->cfg.device_id));
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (t->ran) HIPCHK(hipStreamWaitEvent(st, t->evDone, 0));                          // the handle's scratch belongs to one call at a time
+    if (max_points_per_frame > t->localCap) {
+        // grow the scratch: the previous call (if any) must be done with the old buffers before they are freed
+        if (t->ran) HIPCHK(hipEventSynchronize(t->evDone));
+        void* old[] = {t->dLQ, t->dLRad, t->dLCount, t->dLLists};
+        for (void* q : old) if (q) (void)hipFree(q);
+        t->dLQ = nullptr; t->dLRad = nullptr; t->dLCount = nullptr; t->dLLists = nullptr; t->localCap = 0;
+        const size_t n = (size_t)t->cfg.max_pairs * (size_t)max_points_per_frame;
+        if (hipMalloc(&t->dLQ, n * sizeof(Query)) != hipSuccess || hipMalloc(&t->dLRad, n * sizeof(float)) != hipSuccess ||
+            hipMalloc(&t->dLCount, n * sizeof(int)) != hipSuccess || hipMalloc(&t->dLLists, n * kListCap * sizeof(unsigned)) != hipSuccess) {
+            void* part[] = {t->dLQ, t->dLRad, t->dLCount, t->dLLists};
+            for (void* q : part) if (q) (void)hipFree(q);
+            t->dLQ = nullptr; t->dLRad = nullptr; t->dLCount = nullptr; t->dLLists = nullptr;
+            return fail(IVF_E_NO_DEVICE, "device allocation failed for %d frames x %d local map points", t->cfg.max_pairs, max_points_per_frame);
+        }
+        t->localCap = max_points_per_frame;
+    }
+    const TrackParams& P = t->P;
+    const int M = max_points_per_frame;
+    hipLaunchKernelGGL(k_local_prepare, dim3(n_frames), dim3(256), 0, st, P, d_records, d_frames, d_poses, d_points, d_point_offsets, th, cos_limit, M,
+                       t->dStart, t->dIdx, t->dLQ, t->dLRad);
+    hipLaunchKernelGGL(k_local_window, dim3((M + 3) / 4, n_frames), dim3(256), 0, st, P, d_records, d_frames, d_points, d_point_offsets, M,
+                       t->dStart, t->dIdx, t->dLQ, t->dLRad, t->dLCount, t->dLLists);
+    hipLaunchKernelGGL(k_local_greedy, dim3(n_frames), dim3(64), (size_t)P.nf * 4, st, P, d_records, d_frames, d_points, d_point_offsets, M,
+                       t->dStart, t->dIdx, t->dLQ, t->dLRad, d_occupied, nn_ratio, t->dLCount, t->dLLists, d_assign, d_nmatches);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(t->evDone, st));
     t->ran = true;

@@ -57,3 +57,19 @@ class BatchTracker:
                                         None if poses is None else poses.data_ptr(),
                                         None if point_flags is None else point_flags.data_ptr(),
                                         assign.data_ptr(), nmatches.data_ptr(), stream_ptr))
+
+    def search_local(self, records, frames, points, point_offsets, max_points_per_frame, assign, nmatches, poses=None, occupied=None,
+                     th=1.0, nn_ratio=0.8, cos_limit=0.5, stream_ptr=None):
+        """Tracking::SearchLocalPoints (ORB/src/Tracking.cc:2088-2132) for n_frames frames at once: Frame::isInFrustum of every local
+        map point, then ORBmatcher(nn_ratio).SearchByProjection(F, vpMapPoints, th).  frames: torch.int32 [n_frames] record indices;
+        points: torch.uint8 view of LOCAL_POINT_DTYPE records (80 B each); point_offsets: torch.int32 [n_frames + 1] (CSR);
+        occupied: torch.uint8 [n_frames, nfeatures] or None; assign: torch.int32 [n_frames, nfeatures] (index within the frame's point
+        range or -1); nmatches: torch.int32 [n_frames].  Asynchronous on the given stream."""
+        n_rec = records.numel() // self.record_bytes
+        n_frames = frames.numel()
+        assert frames.element_size() == 4 and point_offsets.element_size() == 4 and point_offsets.numel() >= n_frames + 1
+        assert assign.element_size() == 4 and assign.numel() >= n_frames * self.nfeatures and nmatches.numel() >= n_frames
+        check(self._lib.ivf_tracker_search_local(self._h, records.data_ptr(), self.record_bytes, n_rec, frames.data_ptr(), n_frames,
+                                                 None if poses is None else poses.data_ptr(), points.data_ptr(), point_offsets.data_ptr(),
+                                                 int(max_points_per_frame), None if occupied is None else occupied.data_ptr(),
+                                                 float(th), float(nn_ratio), float(cos_limit), assign.data_ptr(), nmatches.data_ptr(), stream_ptr))

@@ -86,6 +86,44 @@ float orc_cosf(float y)
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * A-12 logf: glibc >= 2.27 single-precision log (ARM optimized-routines "logf": 16-entry table of 1/c and log c, degree-3
+ * polynomial in f64).  MapPoint::PredictScale (ORB/src/MapPoint.cc:398,415) calls an unqualified log(float) under the
+ * `using namespace std` that DBoW2/TemplatedVocabulary.h:36 puts into every translation unit that includes Frame.h, i.e.
+ * std::log(float) = logf, divides by the float mfLogScaleFactor = logf(1.2f) (Frame.cc:106) and takes std::ceil(float).
+ * Restated so the SAME arithmetic runs on the device; checked against this image's glibc 2.35 for EVERY positive normal float
+ * (tests/test_oracle_primitives.py::test_logf_matches_glibc_exhaustive).  Table = glibc's __logf_data (the values, not code).
+ * ---------------------------------------------------------------------------------------------- */
+static const double LOGF_T[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+    {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+    {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+    {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+    {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
+    {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+/* valid for positive normal x (a distance ratio); anything else goes to libm */
+float orc_logf(float x)
+{
+    uint32_t ix; memcpy(&ix, &x, 4);
+    if (ix == 0x3f800000u) return 0.0f;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) return logf(x);
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) % 16u);
+    const int k = (int32_t)tmp >> 23;
+    const uint32_t iz = ix - (tmp & 0xff800000u);
+    float zf; memcpy(&zf, &iz, 4);
+    const double z = (double)zf, invc = LOGF_T[i][0], logc = LOGF_T[i][1];
+    const double r = z * invc - 1.0;
+    const double y0 = logc + (double)k * 0x1.62e42fefa39efp-1;
+    const double r2 = r * r;
+    double y = 0x1.5575b0be00b6ap-2 * r + -0x1.ffffef20a4123p-2;
+    y = -0x1.00ea348b88334p-2 * r2 + y;
+    y = y * r2 + (y0 + r);
+    return (float)y;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * A-5  cv::fastAtan2 (OpenCV 3.x/4.x mathfuncs_core: degree-7 odd polynomial, f32, degrees).
  * Called at ORB/src/ORBextractor.cc:104.
  * ---------------------------------------------------------------------------------------------- */

@@ -54,6 +54,7 @@ int   orc_cv_round_d(double v);
 void  orc_set_opencv_variant(int blur, int retain, int atan);
 float orc_fast_atan2(float y, float x);
 float orc_cosf(float x);   /* restated glibc >= 2.28 cosf (ARM optimized-routines algorithm) */
+float orc_logf(float x);   /* restated glibc >= 2.27 logf (A-12): MapPoint::PredictScale */
 float orc_sinf(float x);
 /* FAST-9/16 corner score map of a (sub-)image: out[y*cols+x] = score if corner at `threshold` else 0,
  * zero outside rows [3,rows-3) x cols [3,cols-3). */

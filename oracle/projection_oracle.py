@@ -426,3 +426,68 @@ def _search_cur_last_no_ori(O, cur, last, pool, cur_mps, th):
     import types
     shim = types.SimpleNamespace(search_by_projection=lambda k, d, u, b, q, chk, occ: O.search_by_projection(k, d, u, b, q, False, occ))
     return search_cur_last(shim, cur, last, pool, cur_mps, th, False)
+
+
+# ---- Tracking::SearchLocalPoints from the projection on (ORB/src/Tracking.cc:2088-2132), one frame -----------------------------
+def predict_scale_f32(O, max_dist, dist, frame):
+    """MapPoint::PredictScale (ORB/src/MapPoint.cc:407-422) AS COMPILED: the unqualified log(float) resolves to std::log(float) = logf
+    under the `using namespace std` of DBoW2/TemplatedVocabulary.h:36, the quotient by the float mfLogScaleFactor is a float and
+    std::ceil(float) rounds it (DESIGN.md A-12; glibc's logf restated in oracle/ivf_oracle.c:orc_logf)."""
+    ratio = F(F(max_dist) / F(dist))
+    q = F(F(O.lib.orc_logf(float(ratio))) / F(frame["logScale"]))
+    n = int(math.ceil(float(q)))
+    return min(max(n, 0), len(frame["scale"]) - 1)
+
+
+def is_in_frustum(O, frame, mp, cos_limit=0.5):
+    """Frame::isInFrustum (ORB/src/Frame.cc:557-613): None, or the tracking fields it leaves on the map point."""
+    Rcw, tcw = frame["T"][:3, :3], frame["T"][:3, 3]
+    P = np.asarray(mp["pos"], F)
+    Pc = mul_add(Rcw, P, tcw)                                                          # :565
+    if Pc[2] < F(0.0):
+        return None
+    with np.errstate(all="ignore"):
+        invz = F(F(1.0) / Pc[2])
+        u = F(F(F(F(frame["fx"]) * Pc[0]) * invz) + F(frame["cx"])); v = F(F(F(F(frame["fy"]) * Pc[1]) * invz) + F(frame["cy"]))
+    minx, miny, maxx, maxy = [F(b) for b in frame["bounds"]]
+    if u < minx or u > maxx or v < miny or v > maxy:
+        return None
+    PO = (P - neg_rt_mul(Rcw, tcw)).astype(F)                                          # P - mOw (:587)
+    dist = F(norm(PO))                                                                 # cv::norm -> const float (:588)
+    if dist < F(F(0.8) * F(mp["minDist"])) or dist > F(F(1.2) * F(mp["maxDist"])):     # MapPoint.cc:378-388, Frame.cc:590
+        return None
+    view_cos = F(dot(PO, np.asarray(mp["normal"], F)) / float(dist))                   # :596
+    if view_cos < F(cos_limit):
+        return None
+    return dict(projX=u, projY=v, projXR=F(u - F(F(frame["mbf"]) * invz)), trackLevel=predict_scale_f32(O, mp["maxDist"], dist, frame),
+                viewCos=view_cos)
+
+
+def search_local_points_frame(O, cur, points, occupied, th, nn_ratio, cos_limit=0.5):
+    """points: list of dict(pos, normal, minDist, maxDist, desc, skip, nObs) in mvpLocalMapPoints order; occupied: per keypoint, True =
+    holds a map point with observations.  Returns (nmatches, per keypoint the index of the point it received in this call or -1)."""
+    rows, src = [], []
+    for k, p in enumerate(points):
+        if p["skip"]:
+            continue
+        tr = is_in_frustum(O, cur, p, cos_limit)
+        if tr is None:
+            continue
+        r = F(2.5) if float(tr["viewCos"]) > 0.998 else F(4.0)                         # RadiusByViewingCos (ORBmatcher.cc:137-143)
+        if float(th) != 1.0:
+            r = F(r * F(th))
+        lv = tr["trackLevel"]
+        rows.append(dict(u=tr["projX"], v=tr["projY"], ur=tr["projXR"], radius=F(r * F(cur["scale"][lv])), level=lv, desc=p["desc"], valid=1,
+                         blocks=1 if p["nObs"] > 0 else 0))
+        src.append(k)
+    n = len(cur["kps"])
+    out = np.full(n, -1, np.int32)
+    if not rows:
+        return 0, out
+    q = _q(rows, ("u", "v", "ur", "radius", "level", "desc", "valid", "blocks"))
+    occ = np.where(np.asarray(occupied, bool), -2, -1).astype(np.int32) if occupied is not None else np.full(n, -1, np.int32)
+    a, nm = O.search_map_points(cur["kps"], cur["desc"], cur["uright"], cur["bounds"], q, nn_ratio, occ)
+    for i in range(n):
+        if a[i] >= 0:
+            out[i] = src[a[i]]
+    return nm, out

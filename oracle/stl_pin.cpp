@@ -49,3 +49,15 @@ extern "C" long glibc_trig_mismatches(uint32_t lo, uint32_t hi, uint32_t stride)
     }
     return bad;
 }
+
+// how many floats in [lo, hi) (bit patterns, step `stride`) where orc_logf differs from this image's libm logf (what
+// MapPoint::PredictScale calls, ORB/src/MapPoint.cc:398,415)
+extern "C" long glibc_logf_mismatches(uint32_t lo, uint32_t hi, uint32_t stride)
+{
+    long bad = 0;
+    for (uint64_t u = lo; u < hi; u += stride) {
+        uint32_t b = (uint32_t)u; float x; std::memcpy(&x, &b, 4);
+        if (orc_logf(x) != logf(x)) bad++;
+    }
+    return bad;
+}

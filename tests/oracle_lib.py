@@ -47,6 +47,7 @@ lib.orc_cv_round_f.restype = C.c_int; lib.orc_cv_round_f.argtypes = [C.c_float]
 lib.orc_cv_round_d.restype = C.c_int; lib.orc_cv_round_d.argtypes = [C.c_double]
 lib.orc_fast_atan2.restype = C.c_float; lib.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
 lib.orc_cosf.restype = C.c_float; lib.orc_cosf.argtypes = [C.c_float]
+lib.orc_logf.restype = C.c_float; lib.orc_logf.argtypes = [C.c_float]
 lib.orc_sinf.restype = C.c_float; lib.orc_sinf.argtypes = [C.c_float]
 lib.orc_fast_score_map.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
 lib.orc_fast_detect.restype = C.c_int

@@ -1,0 +1,214 @@
+"""Batched Tracking::SearchLocalPoints (ivf_tracker_search_local) against the oracle: Frame::isInFrustum of every local map point
+(ORB/src/Frame.cc:557-613, MapPoint::PredictScale MapPoint.cc:407-422 with glibc's logf) and
+ORBmatcher::SearchByProjection(F, vpMapPoints, th) (ORB/src/ORBmatcher.cc:45-135): windows on levels [level - 1, level], stereo
+check, best / second best in candidate order, the ratio test inside one octave, and the order-dependent occupancy rule.
+Oracle = oracle/projection_oracle.search_local_points_frame (numpy projection around the C oracle's orc_search_map_points).
+Bar: the map point every keypoint received and nmatches IDENTICAL for every frame."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_gpu_track import extracted_sequence, frame_dict, pose, iv  # noqa: F401  (iv: the module fixture)
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+F = np.float32
+
+
+def map_points_from(cam, rec, T, rng, flip_bits=6, dup=0.15, jitter=0.02):
+    """A local map seen from another frame: the stereo points of `rec` (pose T), with the fields UpdateNormalAndDepth leaves
+    (MapPoint.cc:330-376: mfMaxDistance = dist * scale[level], mfMinDistance = mfMaxDistance / scale[nLevels - 1], normal = unit
+    vector from the reference camera to the point), descriptors with a few flipped bits, some points doubled (rivals for one
+    keypoint), random skip / no-observation flags, in shuffled order."""
+    import projection_oracle as PO
+    fr = frame_dict(rec, T, cam)
+    Ow = PO.neg_rt_mul(T[:3, :3], T[:3, 3])
+    pts = []
+    for i in range(len(rec["kps"])):
+        if not rec["depth"][i] > 0:
+            continue
+        Pw = PO.unproject_stereo(fr, i)
+        d = (Pw - Ow).astype(np.float64)
+        dist = float(np.sqrt((d * d).sum()))
+        if not dist > 0.1:
+            continue
+        lvl = int(rec["kps"]["octave"][i])
+        maxd = F(F(dist) * cam["scale"][lvl]); mind = F(maxd / cam["scale"][-1])
+        n = (d / dist + rng.normal(0, 0.2, 3)); n /= np.linalg.norm(n)
+        desc = rec["desc"][i].copy()
+        for b in rng.integers(0, 256, int(rng.integers(0, flip_bits + 1))):
+            desc[b >> 3] ^= np.uint8(1 << (b & 7))
+        p = dict(pos=(Pw + rng.normal(0, jitter, 3)).astype(F), normal=n.astype(F), minDist=mind, maxDist=maxd, desc=desc,
+                 skip=bool(rng.random() < 0.05), nObs=int(rng.random() < 0.8))
+        pts.append(p)
+        if rng.random() < dup:                                  # a rival: same place, another few bits off
+            q = dict(p); q["desc"] = desc.copy()
+            for b in rng.integers(0, 256, int(rng.integers(0, 4))):
+                q["desc"][b >> 3] ^= np.uint8(1 << (b & 7))
+            q["pos"] = (p["pos"] + rng.normal(0, jitter, 3)).astype(F); q["nObs"] = int(rng.random() < 0.8); q["skip"] = False
+            pts.append(q)
+    order = rng.permutation(len(pts))
+    return [pts[k] for k in order]
+
+
+def pack_points(iv, per_frame):
+    from iv_slam_amd._lib import LOCAL_POINT_DTYPE
+    tot = sum(len(p) for p in per_frame)
+    a = np.zeros(max(tot, 1), LOCAL_POINT_DTYPE)
+    off = [0]
+    k = 0
+    for pts in per_frame:
+        for p in pts:
+            a[k]["pos"] = p["pos"]; a[k]["normal"] = p["normal"]; a[k]["min_distance"] = p["minDist"]; a[k]["max_distance"] = p["maxDist"]
+            a[k]["desc"] = p["desc"]; a[k]["flags"] = (1 if p["skip"] else 0) | (2 if p["nObs"] > 0 else 0)
+            k += 1
+        off.append(k)
+    return a, np.array(off, np.int32)
+
+
+def run_local(iv, cam, recs, frames, per_frame, poses, occupied, th, nn_ratio, max_points=None, cos_limit=0.5, tracker=None):
+    import torch
+    from iv_slam_amd import dist as ivd
+    nf = cam["nf"]
+    dev = torch.device("cuda:0")
+    block = torch.from_numpy(ivd.pack_records(recs, nf).reshape(-1)).to(dev)
+    tr = tracker or iv.BatchTracker(nf, cam["scale"], float(cam["fx"]), float(cam["fy"]), float(cam["cx"]), float(cam["cy"]), float(cam["bf"]),
+                                   cam["bounds"], max_pairs=len(frames), b=float(cam["b"]))
+    pts, off = pack_points(iv, per_frame)
+    M = max_points or max(1, max(len(p) for p in per_frame))
+    dpts = torch.from_numpy(pts.view(np.uint8).reshape(-1)).to(dev)
+    doff = torch.from_numpy(off).to(dev)
+    dfr = torch.tensor(frames, dtype=torch.int32, device=dev)
+    dposes = None if poses is None else torch.from_numpy(np.stack([p[:3, :4].reshape(12) for p in poses]).astype(F)).to(dev)
+    docc = None
+    if occupied is not None:
+        oc = np.zeros((len(frames), nf), np.uint8)
+        for i, o in enumerate(occupied):
+            oc[i, :len(o)] = o
+        docc = torch.from_numpy(oc).to(dev)
+    assign = torch.full((len(frames), nf), -7, dtype=torch.int32, device=dev); nm = torch.full((len(frames),), -7, dtype=torch.int32, device=dev)
+    tr.search_local(block, dfr, dpts, doff, M, assign, nm, poses=dposes, occupied=docc, th=th, nn_ratio=nn_ratio, cos_limit=cos_limit)
+    torch.cuda.synchronize()
+    return assign.cpu().numpy(), nm.cpu().numpy()
+
+
+def check_local(cam, recs, frames, per_frame, poses, occupied, th, nn_ratio, got_a, got_nm, max_points=None, cos_limit=0.5, what=""):
+    import projection_oracle as PO
+    I = np.eye(4, dtype=F)
+    logscale = F(O.lib.orc_logf(float(cam["scale"][1])))
+    total = 0
+    for k, ri in enumerate(frames):
+        cur = frame_dict(recs[ri], I if poses is None else poses[ri], cam); cur["logScale"] = logscale
+        pts = per_frame[k] if max_points is None else per_frame[k][:max_points]
+        nm, exp = PO.search_local_points_frame(O, cur, pts, None if occupied is None else occupied[k], F(th), F(nn_ratio), cos_limit)
+        nC = len(cur["kps"])
+        assert got_nm[k] == nm, "%s frame %d: nmatches %d vs oracle %d" % (what, k, got_nm[k], nm)
+        assert np.array_equal(got_a[k, :nC], exp), "%s frame %d: assignment differs at %r" % (what, k, np.nonzero(got_a[k, :nC] != exp)[0][:8])
+        assert (got_a[k, nC:] == -1).all()
+        total += nm
+    return total
+
+
+def test_local_points_kitti_shape(iv):
+    """1242x375 / 1000 features: every frame searches the map made from the frame before it (and from itself: the stationary case,
+    PredictScale on the knife edge), th = 1 / 3 / 5 (Tracking.cc:2125-2128), nn_ratio 0.8 and 0.64, with and without occupancy."""
+    cam, recs, _, _ = extracted_sequence(iv, 1242, 375, 1000, 5, seed=191)
+    rng = np.random.default_rng(7)
+    I = np.eye(4, dtype=F)
+    frames = [1, 2, 3, 4, 2, 0]
+    src = [0, 1, 2, 3, 2, 0]                                               # frame 2 also searches its own points, frame 0 likewise
+    per_frame = [map_points_from(cam, recs[s], I, rng) for s in src]
+    occ = [rng.random(len(recs[f]["kps"])) < 0.1 for f in frames]
+    tr = None
+    for th, ratio, oc in ((1.0, 0.8, None), (3.0, 0.8, occ), (5.0, 0.64, occ), (1.0, 0.64, occ)):
+        a, nm = run_local(iv, cam, recs, frames, per_frame, None, oc, th, ratio)
+        tot = check_local(cam, recs, frames, per_frame, None, oc, th, ratio, a, nm, what="th %g ratio %g" % (th, ratio))
+        assert tot > 500, tot
+
+
+def test_local_points_with_poses_and_truncation(iv):
+    """moving camera (forward / backward / rotation), points outside the frustum, behind the camera, out of the distance range and
+    beyond the viewing-angle limit; max_points_per_frame smaller than a frame's list; an empty list; cos_limit 0.8."""
+    cam, recs, _, _ = extracted_sequence(iv, 640, 240, 500, 4, seed=192, shift=2)
+    cam["fx"] = cam["fy"] = F(370.0); cam["cx"] = F(320.0); cam["cy"] = F(120.0); cam["bf"] = F(198.75); cam["b"] = F(F(198.75) / F(370.0))
+    for r in recs:
+        d = r["kps"]["x"] - r["uright"]
+        r["depth"] = np.where(r["uright"] >= 0, cam["bf"] / np.maximum(d, F(1e-3)), F(-1)).astype(F)
+    rng = np.random.default_rng(8)
+    poses = [pose(0.0, [0, 0, 0]), pose(1.5, [0.05, 0.0, -0.9]), pose(-2.0, [-0.1, 0.02, 1.2]), pose(12.0, [0.3, 0.0, 0.1], deg_x=2.0)]
+    frames = [1, 2, 3, 0, 1]
+    src = [0, 1, 2, 3, 1]
+    per_frame = [map_points_from(cam, recs[s], poses[s], rng, jitter=0.05) for s in src]
+    # some hopeless points: behind the camera, far off axis, wrong distance range, normal turned away
+    for k in range(len(per_frame)):
+        base = per_frame[k][:12]
+        for j, p in enumerate(base):
+            q = dict(p); q["desc"] = p["desc"].copy()
+            if j % 4 == 0: q["pos"] = (p["pos"] * F(-1.0)).astype(F)
+            elif j % 4 == 1: q["minDist"] = F(p["maxDist"] * F(3.0)); q["maxDist"] = F(p["maxDist"] * F(9.0))
+            elif j % 4 == 2: q["normal"] = (-p["normal"]).astype(F)
+            else: q["pos"] = (p["pos"] + np.array([400, 0, 0], F)).astype(F)
+            per_frame[k].insert(int(rng.integers(0, len(per_frame[k]))), q)
+    per_frame[3] = []                                                       # nToMatch == 0
+    occ = [rng.random(len(recs[f]["kps"])) < 0.15 for f in frames]
+    a, nm = run_local(iv, cam, recs, frames, per_frame, poses, occ, 3.0, 0.8)
+    tot = check_local(cam, recs, frames, per_frame, poses, occ, 3.0, 0.8, a, nm, what="poses")
+    assert tot > 100 and nm[3] == 0
+    cap = min(len(p) for p in per_frame if p) // 2
+    a, nm = run_local(iv, cam, recs, frames, per_frame, poses, None, 1.0, 0.8, max_points=cap, cos_limit=0.8)
+    check_local(cam, recs, frames, per_frame, poses, None, 1.0, 0.8, a, nm, max_points=cap, cos_limit=0.8, what="truncated")
+
+
+def test_local_points_overflowing_windows_and_ties(iv):
+    """a crowd of near-identical keypoints (tiled texture -> equal descriptors, ties in distance) and th = 40: windows hold far more
+    than 64 candidates, so the greedy kernel re-walks them against the live occupancy state; one handle, two calls (scratch grows)."""
+    import torch
+    w, h, n = 640, 240, 2000
+    tile = np.random.default_rng(5).integers(0, 256, (24, 32)).astype(np.uint8)
+    L = np.tile(tile, (h // 24, w // 32)); R = np.roll(L, -4, axis=1)
+    dev = torch.device("cuda:0")
+    bf, fx = 386.1448, 718.856
+    fe = iv.StereoFrontend(w, h, 2, nfeatures=n, bf=bf, fx=fx)
+    fe.run(torch.from_numpy(np.stack([L, np.roll(L, 2, axis=1)])).to(dev), torch.from_numpy(np.stack([R, np.roll(R, 2, axis=1)])).to(dev))
+    fe.sync()
+    recs = [fe.fetch(k, 0) for k in range(2)]
+    from test_gpu_track import scale_table
+    cam = dict(nf=n, scale=scale_table(), fx=F(fx), fy=F(fx), cx=F(w / 2 + 0.5), cy=F(h / 2 - 0.25), bf=F(bf), b=F(F(bf) / F(fx)),
+               bounds=(0.0, 0.0, float(w), float(h)))
+    assert min(len(r["kps"]) for r in recs) > 800
+    rng = np.random.default_rng(9)
+    I = np.eye(4, dtype=F)
+    per_frame = [map_points_from(cam, recs[0], I, rng, flip_bits=2, dup=0.3), map_points_from(cam, recs[1], I, rng, flip_bits=0, dup=0.0)]
+    frames = [1, 0]
+    tr = iv.BatchTracker(n, cam["scale"], float(cam["fx"]), float(cam["fy"]), float(cam["cx"]), float(cam["cy"]), float(cam["bf"]),
+                         cam["bounds"], max_pairs=2, b=float(cam["b"]))
+    a, nm = run_local(iv, cam, recs, frames, [p[:40] for p in per_frame], None, None, 1.0, 0.9, tracker=tr)           # small first call
+    check_local(cam, recs, frames, [p[:40] for p in per_frame], None, None, 1.0, 0.9, a, nm, what="small")
+    a, nm = run_local(iv, cam, recs, frames, per_frame, None, None, 40.0, 0.9, tracker=tr)
+    tot = check_local(cam, recs, frames, per_frame, None, None, 40.0, 0.9, a, nm, what="overflow")
+    assert tot > 50
+
+
+def test_local_points_argument_errors(iv):
+    import torch
+    from iv_slam_amd import dist as ivd
+    dev = torch.device("cuda:0")
+    from test_gpu_track import scale_table
+    tr = iv.BatchTracker(100, scale_table(), 500.0, 500.0, 320.0, 120.0, 200.0, (0.0, 0.0, 640.0, 240.0), max_pairs=2)
+    rec = torch.zeros(2 * ivd.record_bytes(100), dtype=torch.uint8, device=dev)
+    fr = torch.tensor([0, 1, 0], dtype=torch.int32, device=dev)
+    pts = torch.zeros(80 * 4, dtype=torch.uint8, device=dev); off = torch.tensor([0, 2, 4, 4], dtype=torch.int32, device=dev)
+    a = torch.empty((3, 100), dtype=torch.int32, device=dev); nm = torch.empty(3, dtype=torch.int32, device=dev)
+    with pytest.raises(Exception):
+        tr.search_local(rec, fr, pts, off, 4, a, nm)                        # three frames, max_pairs 2
+    with pytest.raises(Exception):
+        tr.search_local(rec, fr[:2], pts, off, 0, a, nm)                    # no capacity
+    with pytest.raises(Exception):
+        tr.search_local(rec, fr[:2], pts, off, 4, a, nm, th=0.0)
+    tr.search_local(rec, fr[:2], pts, off, 4, a, nm)                        # empty records: nothing to match, no fault
+    torch.cuda.synchronize()
+    assert (nm[:2].cpu().numpy() == 0).all() and (a[:2].cpu().numpy() == -1).all()

@@ -182,6 +182,35 @@ def test_trig_matches_glibc_exhaustive():
         assert O.lib.orc_cosf(x) == float(np.cos(np.float32(x), dtype=np.float32)) or True
 
 
+# ---------------------------------------------------------------- A-12 logf vs glibc
+def test_logf_matches_glibc_exhaustive():
+    """Every positive normal float (2.13e9 values): the restated logf == this image's glibc logf, bit for bit (what
+    MapPoint::PredictScale's log(ratio) resolves to, ORB/src/MapPoint.cc:398,415).  8 threads, a few seconds."""
+    import concurrent.futures as cf
+    O.pin.glibc_logf_mismatches.restype = C.c_long
+    O.pin.glibc_logf_mismatches.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    lo, hi = 0x00800000, 0x7f800000
+    nt = 8
+    edges = [lo + (hi - lo) * i // nt for i in range(nt + 1)]
+    with cf.ThreadPoolExecutor(nt) as ex:
+        bad = sum(ex.map(lambda i: O.pin.glibc_logf_mismatches(edges[i], edges[i + 1], 1), range(nt)))
+    assert bad == 0
+    assert O.lib.orc_logf(1.0) == 0.0
+    # PredictScale on the knife edge: a point seen again from the distance it was created at has ratio = 1.2^level up to float
+    # rounding; the float quotient decides the level, not a double one
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import projection_oracle as PO
+    sf = [np.float32(1.0)]
+    for _ in range(7):
+        sf.append(np.float32(np.float64(sf[-1]) * np.float64(np.float32(1.2))))
+    frame = dict(scale=np.array(sf, np.float32), logScale=np.float32(O.lib.orc_logf(float(sf[1]))))
+    for lv in range(8):
+        for dist in (np.float32(3.7), np.float32(12.25), np.float32(41.0)):
+            got = PO.predict_scale_f32(O, np.float32(dist * sf[lv]), dist, frame)
+            assert got in (lv, min(lv + 1, 7))
+
+
 # ---------------------------------------------------------------- A-6 retainBest vs the real libstdc++
 @pytest.mark.parametrize("seed", range(6))
 def test_retain_best_matches_libstdcxx(seed):

@@ -77,10 +77,64 @@ def main():
     for _ in range(50):
         O.search_by_projection(cur["kps"], cur["desc"], cur["uright"], bounds, q, True)
     t_c = (time.perf_counter() - t0) / 50
-    print(json.dumps({"us_per_frame_pair": round(us, 3), "frame_pairs_per_launch_sequence": P - 1, "N": N, "reps": a.reps,
-                      "mean_matches": float(nmh.mean()), "min_matches": int(nmh.min()), "parity_vs_oracle_on_first_pairs": bool(ok),
-                      "oracle_us_per_frame_pair_one_core": {"python_projection_plus_c_search": round(t_or * 1e6, 1),
-                                                            "c_search_only": round(t_c * 1e6, 1)}}))
+    out = {"us_per_frame_pair": round(us, 3), "frame_pairs_per_launch_sequence": P - 1, "N": N, "reps": a.reps,
+           "mean_matches": float(nmh.mean()), "min_matches": int(nmh.min()), "parity_vs_oracle_on_first_pairs": bool(ok),
+           "oracle_us_per_frame_pair_one_core": {"python_projection_plus_c_search": round(t_or * 1e6, 1), "c_search_only": round(t_c * 1e6, 1)}}
+
+    # ---- Tracking::SearchLocalPoints for every frame at once (ivf_tracker_search_local): the local map of frame k = the stereo points
+    # of frames k-1 and k-2 (~2 x 600 points), identity poses
+    from iv_slam_amd._lib import LOCAL_POINT_DTYPE
+    rng = np.random.default_rng(3)
+    per = []
+    for k in range(P):
+        pts = []
+        for s in (max(k - 1, 0), max(k - 2, 0)):
+            r = recs[s]; fr = fd(r)
+            for i in np.nonzero(r["depth"] > 0)[0]:
+                Pw = PO.unproject_stereo(fr, int(i)) if k < a.oracle_pairs + 1 else None
+                pts.append((s, int(i), Pw))
+        per.append(pts)
+    M = max(len(p) for p in per)
+    tot = sum(len(p) for p in per)
+    arr = np.zeros(tot, LOCAL_POINT_DTYPE); off = np.zeros(P + 1, np.int32)
+    kk = 0
+    for k, pts in enumerate(per):
+        for (s, i, Pw) in pts:
+            r = recs[s]; z = r["depth"][i]
+            x = F(F(F(r["kps"]["x"][i] - F(cam["cx"])) * z) * F(F(1.0) / F(cam["fx"]))); y = F(F(F(r["kps"]["y"][i] - F(cam["cy"])) * z) * F(F(1.0) / F(cam["fy"])))
+            pos = np.array([x, y, z], F)                                  # identity pose: world = camera coordinates (UnprojectStereo)
+            dist = F(np.sqrt(np.float64(x) ** 2 + np.float64(y) ** 2 + np.float64(z) ** 2))
+            lv = int(r["kps"]["octave"][i])
+            arr[kk]["pos"] = pos; arr[kk]["normal"] = (pos / dist).astype(F)
+            arr[kk]["max_distance"] = F(dist * sc[lv]); arr[kk]["min_distance"] = F(arr[kk]["max_distance"] / sc[-1])
+            arr[kk]["desc"] = r["desc"][i]; arr[kk]["flags"] = 2
+            kk += 1
+        off[k + 1] = kk
+    dpts = torch.from_numpy(arr.view(np.uint8).reshape(-1)).to(dev); doff = torch.from_numpy(off).to(dev)
+    dfr = torch.arange(P, dtype=torch.int32, device=dev)
+    trl = iv.BatchTracker(N, sc, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["bf"], bounds, max_pairs=P)
+    la = torch.empty((P, N), dtype=torch.int32, device=dev); lnm = torch.empty(P, dtype=torch.int32, device=dev)
+    for _ in range(3):
+        trl.search_local(block, dfr, dpts, doff, M, la, lnm, th=1.0, nn_ratio=0.8, stream_ptr=st.cuda_stream)
+    e0.record(st)
+    for _ in range(a.reps):
+        trl.search_local(block, dfr, dpts, doff, M, la, lnm, th=1.0, nn_ratio=0.8, stream_ptr=st.cuda_stream)
+    e1.record(st); torch.cuda.synchronize()
+    us_l = e0.elapsed_time(e1) * 1e3 / a.reps / P
+    lah, lnh = la.cpu().numpy(), lnm.cpu().numpy()
+    logscale = F(O.lib.orc_logf(float(sc[1])))
+    okl = True; t0 = time.perf_counter(); t_c2 = 0.0
+    for k in range(min(P, a.oracle_pairs)):
+        cur = fd(recs[k]); cur["logScale"] = logscale
+        pts = [dict(pos=arr[j]["pos"], normal=arr[j]["normal"], minDist=arr[j]["min_distance"], maxDist=arr[j]["max_distance"], desc=arr[j]["desc"],
+                    skip=False, nObs=1) for j in range(off[k], off[k + 1])]
+        onm, oa = PO.search_local_points_frame(O, cur, pts, None, F(1.0), F(0.8))
+        okl &= onm == lnh[k] and np.array_equal(oa, lah[k, :len(oa)])
+    t_l = (time.perf_counter() - t0) / max(1, min(P, a.oracle_pairs))
+    out["search_local_points"] = {"us_per_frame": round(us_l, 3), "frames_per_launch_sequence": P, "map_points_per_frame_mean": round(tot / P, 1),
+                                  "map_points_per_frame_max": int(M), "mean_matches": float(lnh.mean()), "parity_vs_oracle_on_first_frames": bool(okl),
+                                  "oracle_python_projection_plus_c_search_us_per_frame": round(t_l * 1e6, 1)}
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
