@@ -1827,11 +1827,18 @@ __global__ __launch_bounds__(512, 2) void k_fcn_dwpw8(const float* __restrict__ 
 //     ReLU6 -> LDS planes; S = the 3x3 stencil on the 16 x 16 planes (thread = channel x sub-row x half row, halo pixel by DPP) +
 //     BN + ReLU6 -> LDS; P = projection on v_mfma_f32_32x32x16_f16 (the group is one K step) into 5 resident accumulator tiles;
 //   * software pipeline over the groups, ONE barrier per interval: E(g), S(g - 1), P(g - 2) work on different LDS buffers;
-//   * the weights of the next interval (10 KB expansion + 10 KB projection fragments + 768 B of depthwise / BN parameters) arrive by
-//     LDS-DMA (global_load_lds_dwordx4), no registers, no VALU;
+//   * the weights of an interval (10 KB expansion + 10 KB projection fragments + 768 B of depthwise / BN parameters) arrive by
+//     LDS-DMA (global_load_lds_dwordx4), no registers, no VALU.  A piece of 1 KB holds the issuing wave for ~260 cycles (the path
+//     moves about one dword per clock and wave), so the 21 pieces of interval it + 2 are requested at the END of interval it, five
+//     per wave by the half of the workgroup that reaches the barrier first, into the third of three buffers;
 //   * waves 0-3 run [MFMA phase, stencil phase], waves 4-7 [stencil phase, MFMA phase]: wave w and w + 4 share a SIMD, so one
 //     partner's VALU issues under the other's MFMAs (tools/probe/issue_model.hip: 5 four-cycle VALU instructions hide per
-//     32-cycle MFMA slot, also across the two waves of a SIMD; packed-f32 VALU does not -- the stencil uses plain v_fma_f32).
+//     32-cycle MFMA slot, also across the two waves of a SIMD; packed-f32 VALU does not -- the stencil uses plain v_fma_f32);
+//   * inside the MFMA phase (branch-free: intervals 0, 1 and 60, 61 run on zeroed / unread operands) the f16 splits of P's B
+//     values sit one instruction behind each of E's MFMAs and E's BN + ReLU6 + stores two behind each of P's
+//     (sched_group_barrier); the phase's first LDS reads are requested before the stencil phase by waves 4-7.
+// Measured and removed: weights through registers, pieces spread over the MFMA steps, a three-deep fragment
+// ring, four 64-pixel waves, the chunked schedule.  Ablation switches of the first version: commit 0a06b2f.
 // Output / residual: the sub-image's pixels are 4 apart in x, so stores are 4-byte pieces of rows that the three sibling workgroups
 // (same image, same y phase, same XCD) complete in L2.
 #ifdef IVF_F4_TIMING
@@ -1841,30 +1848,18 @@ __device__ unsigned long long g_f4Tim[16];      // diagnostic build (make EXTRA=
 #else
 #define F4_TIM(i) do { } while (0)
 #endif
-#ifndef IVF_F4_ORDER
-#define IVF_F4_ORDER 0        // experiment: 1 = every wave runs [MFMA phase, stencil phase], 2 = [stencil, MFMA]; 0 = the two halves staggered
-#endif
-#ifndef IVF_F4_ABL
-#define IVF_F4_ABL 0          // timing-only ablations (results wrong): 1 A fragments read from LDS only for the first step of each product,
-#endif                        // 2 no weight DMA after the prologue, 4 no stencil phase, 8 no MFMAs
 constexpr int kF4Cin = 160, kF4Hid = 960, kF4Groups = 60;
-constexpr int kF4HP = 20;                         // floats per 16-pixel sub-row of a hidden plane in LDS (80 B: conflict-free b128 rows)
+constexpr int kF4HP = 20;                         // floats per 16-pixel sub-row of a hidden plane in LDS (80 B rows)
 #ifndef IVF_F4_CS
 #define IVF_F4_CS 324         // floats per channel plane of sH: 16 rows x kF4HP + 4, so that the four 16-lane groups of E's b32 stores hit different banks
 #endif
 constexpr int kF4CS = IVF_F4_CS;
 constexpr int kF4DP = 260;                        // floats per channel of the depthwise output in LDS
 constexpr int kF4ParB = 1024;                     // bytes per parameter slot (16 channels x 12 floats = 768 used)
-#ifndef IVF_F4_LATE
-#define IVF_F4_LATE 1         // 1: the weights of interval it + 2 are requested at the END of interval it (by the waves about to idle at the
-#endif                        // barrier) into a third buffer; 0: weights of it + 1 requested at the start of it (two buffers, r03-a)
 #ifndef IVF_F4_DMA_A
-#define IVF_F4_DMA_A 5        // pieces per wave of the half that finishes early (waves 0-3); the other half shares the rest
-#endif
-#ifndef IVF_F4_IL
-#define IVF_F4_IL 1           // 1: branch-free MFMA phase with the f16 splits and E's epilogue placed between its MFMAs; waves 4-7 request the
-#endif                        // phase's first LDS reads before their stencil phase
-constexpr int kF4WSlots = IVF_F4_LATE ? 3 : 2, kF4PSlots = IVF_F4_LATE ? 4 : 3;
+#define IVF_F4_DMA_A 5        // weight pieces per wave of the half that reaches the barrier first (waves 0-3); waves 4-7 share the rest.
+#endif                        // Measured 2 / 3 / 4 / 5 / 6: 100.5 / 99.9 / 99.1 / 97.4 / 98.0 us per image
+constexpr int kF4WSlots = 3, kF4PSlots = 4;  // weight / parameter buffers: consumed in interval it, landed for it + 1, arriving for it + 2
 constexpr size_t kF4Lds = (size_t)2 * 16 * kF4CS * 4 + (size_t)2 * 16 * kF4DP * 4 + 2 * kF4WSlots * 10240 + kF4PSlots * kF4ParB;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -1910,12 +1905,10 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
         }
     };
     auto dma = [&](int it) {                    // all 21 pieces (<= 1 KB each), piece c by wave c % 8
-        if ((IVF_F4_ABL & 2) && it > 1) return;
 #pragma unroll
         for (int r = 0; r < 3; r++) piece(it, uwave + 8 * r);
     };
     auto dma_late = [&](int it) {               // the same pieces, most of them by waves 0-3, which reach the barrier first
-        if ((IVF_F4_ABL & 2) && it > 1) return;
         constexpr int NA = IVF_F4_DMA_A, NB = 4 * NA >= 21 ? 0 : (21 - 4 * NA + 3) / 4;
         if (uwave < 4) {
 #pragma unroll
@@ -1926,7 +1919,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
         }
     };
     dma(0);
-    if (IVF_F4_LATE) dma(1);
+    dma(1);
 
     // ---- the input tile: this wave's 32 sub-image pixels (sub-rows 2w, 2w+1) x 160 channels as B fragments of the 16x16x32 MFMA
     // lane: column n = lane & 15 (sub-column), k = 8 (lane >> 4) + j
@@ -1959,88 +1952,14 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
               srow2 = sch * kF4CS + (ssr < 15 ? ssr + 1 : ssr) * kF4HP + 8 * sh_;
     const float mL = sh_ ? 1.f : 0.f, mR = sh_ ? 0.f : 1.f;          // the halo pixel comes from the row's other half (lane -1 / +1)
 
-#if IVF_F4_IL
     for (int i = tid; i < 2 * 16 * kF4DP / 4; i += 512) ((uint4*)sD)[i] = make_uint4(0u, 0u, 0u, 0u);      // P(-2), P(-1): zero operands
     for (int i = tid; i < 2 * 640; i += 512) sWP[i] = make_uint4(0u, 0u, 0u, 0u);
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
 #ifdef IVF_F4_TIMING
     unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
-    auto mfma_phase = [&](int it) {
-        const int cur = it & 1;
-        const bool doE = it < kF4Groups, doP = it >= 2;
-        // every LDS read of the phase that does not depend on an MFMA is requested up front: P's B values (8 dwords), E's BN
-        // parameters, the first A fragments of both products; later fragments are requested one step ahead of their MFMAs
-        const float* dB = sD + cur * (16 * kF4DP) + (8 * (lane >> 5)) * kF4DP + 32 * wave + (lane & 31);
-        float dv[8];
-        if (doP) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) dv[j] = dB[j * kF4DP];
-        }
-        const int ws = it % kF4WSlots;
-        const uint4* wE = sWE + ws * 640 + lane;
-        const uint4* wPq = sWP + ws * 640 + lane;
-        const float* pp = sPar + (it % kF4PSlots) * (kF4ParB / 4) + (4 * (lane >> 4)) * 12 + 10;
-        float2 eb[4];
-        HFrag ea[2][2], pa[2][2];
-        if (doE) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) eb[r] = *(const float2*)(pp + r * 12);
-            ea[0][0].q = wE[0]; ea[0][1].q = wE[64];
-        }
-        if (doP) { pa[0][0].q = wPq[0]; pa[0][1].q = wPq[64]; }
-        f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
-        F4_TIM(4);
-        if (doE) {                              // E(it): hidden group `it` = W_E[16 x 160] . X[160 x 32 pixels of this wave]
-#pragma unroll
-            for (int s5 = 0; s5 < 5; s5++) {
-                if (s5 + 1 < 5 && !(IVF_F4_ABL & 1)) { ea[(s5 + 1) & 1][0].q = wE[(2 * s5 + 2) * 64]; ea[(s5 + 1) & 1][1].q = wE[(2 * s5 + 3) * 64]; }
-                __builtin_amdgcn_sched_barrier(0);
-                const HFrag &ah = ea[(IVF_F4_ABL & 1) ? 0 : (s5 & 1)][0], &al = ea[(IVF_F4_ABL & 1) ? 0 : (s5 & 1)][1];
-                if (!(IVF_F4_ABL & 8)) {
-                    e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, bh[s5][0].v, e0, 0, 0, 0);
-                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, bh[s5][1].v, e1, 0, 0, 0);
-                    e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bl[s5][0].v, e0, 0, 0, 0);
-                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bl[s5][1].v, e1, 0, 0, 0);
-                    e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[s5][0].v, e0, 0, 0, 0);
-                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[s5][1].v, e1, 0, 0, 0);
-                } else { e0[0] += __builtin_bit_cast(float, ah.u[0] ^ bh[s5][0].u[1]); e1[0] += __builtin_bit_cast(float, al.u[1] ^ bl[s5][1].u[0]); }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        F4_TIM(5);
-        if (doP) {                              // P(it - 2): out[160 x 32 pixels] += W_P[160 x 16] . D[16 x 32 pixels]; its split and
-            HFrag ph, pl;                       // its MFMAs are issued while E's are still in the matrix pipe
-#pragma unroll
-            for (int jj = 0; jj < 4; jj++) split_pair(dv[2 * jj], dv[2 * jj + 1], ph.u[jj], pl.u[jj]);
-#pragma unroll
-            for (int t = 0; t < 5; t++) {
-                if (t + 1 < 5 && !(IVF_F4_ABL & 1)) { pa[(t + 1) & 1][0].q = wPq[(2 * t + 2) * 64]; pa[(t + 1) & 1][1].q = wPq[(2 * t + 3) * 64]; }
-                __builtin_amdgcn_sched_barrier(0);
-                const HFrag &ah = pa[(IVF_F4_ABL & 1) ? 0 : (t & 1)][0], &al = pa[(IVF_F4_ABL & 1) ? 0 : (t & 1)][1];
-                if (!(IVF_F4_ABL & 8)) {
-                    pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, ph.v, pacc[t], 0, 0, 0);
-                    pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, pl.v, pacc[t], 0, 0, 0);
-                    pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, ph.v, pacc[t], 0, 0, 0);
-                } else pacc[t][0] += __builtin_bit_cast(float, ah.u[0] ^ ph.u[1] ^ al.u[2] ^ pl.u[3]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        F4_TIM(6);
-        if (doE) {                              // E's epilogue under P's MFMAs: BN + ReLU6 -> hidden planes
-            // C layout: column = lane & 15 (sub-column), row = 4 (lane >> 4) + r (hidden channel of the group)
-            float* hp = sH + cur * (16 * kF4CS) + (4 * (lane >> 4)) * kF4CS + (2 * wave) * kF4HP + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                hp[r * kF4CS] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e0[r], eb[r].x, eb[r].y), 0.f, 6.f);
-                hp[r * kF4CS + kF4HP] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e1[r], eb[r].x, eb[r].y), 0.f, 6.f);
-            }
-        }
-    };
-#if IVF_F4_IL
     // ---- MFMA phase, branch-free form.  Intervals 0, 1 run P on zeroed operands (sD and the first two sWP slots are cleared in the
     // prologue), intervals 60, 61 run E into planes nobody reads: no `it`-dependent control flow inside the phase.
     struct MPre { float dv[8]; float2 eb[4]; HFrag ea0[2], pa0[2]; };
@@ -2105,10 +2024,9 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
         }
         F4_TIM(6);
     };
-#endif
     auto stencil_phase = [&](int it) {          // S(it - 1): 3x3 on the 16 x 16 planes of group it - 1, + BN + ReLU6
         const int g = it - 1;
-        if (g < 0 || g >= kF4Groups || (IVF_F4_ABL & 4)) return;
+        if (g < 0 || g >= kF4Groups) return;
         const float* hp = sH + (g & 1) * (16 * kF4CS);
         const float4* pq = (const float4*)(sPar + (g % kF4PSlots) * (kF4ParB / 4) + sch * 12);
         const float4 w03 = pq[0], w47 = pq[1], w8s = pq[2];          // taps 0-3 | 4-7 | tap 8, shift, (expansion BN)
@@ -2140,25 +2058,15 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     };
 
     for (int it = 0; it < kF4Groups + 2; it++) {
-        if (!IVF_F4_LATE) dma(it + 1);          // lands during this interval, consumed in the next one
         F4_TIM(0);
-#if IVF_F4_IL
         {
             MPre m;
             mfma_pre(it, m); __builtin_amdgcn_sched_barrier(0);
             if (wave < 4) { mfma_main(it, m); F4_TIM(1); stencil_phase(it); F4_TIM(2); }
             else { stencil_phase(it); F4_TIM(2); __builtin_amdgcn_sched_barrier(0); mfma_main(it, m); F4_TIM(1); }
         }
-#elif IVF_F4_ORDER == 1
-        mfma_phase(it); F4_TIM(1); stencil_phase(it); F4_TIM(2);
-#elif IVF_F4_ORDER == 2
-        stencil_phase(it); F4_TIM(2); mfma_phase(it); F4_TIM(1);
-#else
-        if (wave < 4) { mfma_phase(it); F4_TIM(1); stencil_phase(it); F4_TIM(2); }
-        else { stencil_phase(it); F4_TIM(2); mfma_phase(it); F4_TIM(1); }
-#endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // LATE: the pieces of it + 1, requested an interval ago
-        if (IVF_F4_LATE) { dma_late(it + 2); F4_TIM(0); }        // land during it + 1; their slots were last read in it - 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the pieces of it + 1, requested an interval ago
+        dma_late(it + 2); F4_TIM(0);                             // land during it + 1; their slots were last read in it - 1
         __syncthreads();
         F4_TIM(3);
     }
