@@ -212,3 +212,42 @@ def test_local_points_argument_errors(iv):
     tr.search_local(rec, fr[:2], pts, off, 4, a, nm)                        # empty records: nothing to match, no fault
     torch.cuda.synchronize()
     assert (nm[:2].cpu().numpy() == 0).all() and (a[:2].cpu().numpy() == -1).all()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_local_points_random_synthetic(iv, seed):
+    """keypoints that never came from the extractor: random positions (also outside the grid's rounding range), all eight octaves,
+    descriptors with few distinct values (many exact ties in distance), frames with no keypoints, frames with no points, a point
+    list far longer than the keypoint list; th 1 and 7 on one handle."""
+    from test_gpu_track import scale_table
+    rng = np.random.default_rng(500 + seed)
+    w, h, nf = 752, 480, int(rng.choice([64, 700, 2100]))
+    cam = dict(nf=nf, scale=scale_table(), fx=F(458.0), fy=F(457.0), cx=F(367.0), cy=F(248.0), bf=F(50.0), b=F(F(50.0) / F(458.0)),
+               bounds=(0.0, 0.0, float(w), float(h)))
+    base = rng.integers(0, 256, (6, 32)).astype(np.uint8)
+    recs = []
+    for k in range(4):
+        n = 0 if k == 2 else int(rng.integers(nf // 2, nf + 1))
+        kps = np.zeros(n, O.KP_DTYPE)
+        kps["x"] = rng.uniform(-0.4, w + 0.4, n).astype(F); kps["y"] = rng.uniform(-0.4, h + 0.4, n).astype(F)
+        kps["octave"] = rng.integers(0, 8, n); kps["angle"] = rng.uniform(0, 360, n).astype(F); kps["size"] = 31; kps["response"] = 20
+        desc = base[rng.integers(0, 6, n)].copy()
+        flip = rng.random(n) < 0.5
+        desc[flip, rng.integers(0, 32, flip.sum())] ^= np.uint8(1) << rng.integers(0, 8, flip.sum()).astype(np.uint8)
+        depth = np.where(rng.random(n) < 0.7, rng.uniform(2, 40, n), -1).astype(F)
+        ur = np.where(depth > 0, kps["x"] - cam["bf"] / np.maximum(depth, F(1e-3)), F(-1)).astype(F)
+        recs.append(dict(kps=kps, desc=desc, uright=ur, depth=depth))
+    poses = [pose(0.0, [0, 0, 0]), pose(3.0, [0.2, 0.0, -0.5]), pose(0.0, [0, 0, 0]), pose(-4.0, [0.0, 0.1, 0.8], deg_x=1.0)]
+    frames = [1, 0, 2, 3, 1]
+    per_frame = [map_points_from(cam, recs[0], poses[0], rng, flip_bits=3, dup=0.4, jitter=0.1),
+                 map_points_from(cam, recs[1], poses[1], rng, flip_bits=3, dup=0.4, jitter=0.1) * 3,      # list longer than the keypoints
+                 map_points_from(cam, recs[0], poses[0], rng),                                            # frame without keypoints
+                 [],                                                                                       # frame without points
+                 map_points_from(cam, recs[3], poses[3], rng, flip_bits=1, dup=0.5, jitter=0.2)]
+    occ = [rng.random(len(recs[f]["kps"])) < 0.2 for f in frames]
+    tr = iv.BatchTracker(nf, cam["scale"], float(cam["fx"]), float(cam["fy"]), float(cam["cx"]), float(cam["cy"]), float(cam["bf"]),
+                         cam["bounds"], max_pairs=len(frames), b=float(cam["b"]))
+    for th in (1.0, 7.0):
+        a, nm = run_local(iv, cam, recs, frames, per_frame, poses, occ, th, 0.8, tracker=tr)
+        check_local(cam, recs, frames, per_frame, poses, occ, th, 0.8, a, nm, what="synthetic th %g" % th)
+        assert nm[2] == 0 and nm[3] == 0
