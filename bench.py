@@ -221,6 +221,62 @@ def parity_spot_check(spot, introspect):
             "checker": "oracle/libivf_oracle.so"}
 
 
+def local_points_report(torch, iv, rec_buf, recs, tpairs_h, sc, cam, stream, O, PO):
+    """Tracking::SearchLocalPoints, batched (ivf_tracker_search_local): frame b of every (a, b) pair searches a local map made of
+    frame a's stereo points (world = camera frame, identity poses; mfMaxDistance = dist * scale[octave] as UpdateNormalAndDepth
+    leaves it).  Duration by HIP events over 10 launch sequences; 2 frames checked against the oracle."""
+    import numpy as np
+    from iv_slam_amd._lib import LOCAL_POINT_DTYPE
+    F = np.float32
+    dev = rec_buf.device
+    chunks, off = [], [0]
+    invfx = F(F(1.0) / F(cam["fx"])); invfy = F(F(1.0) / F(cam["fy"]))
+    for a, _ in tpairs_h:
+        r = recs[a]
+        sel = np.nonzero(r["depth"] > 0)[0]
+        z = r["depth"][sel].astype(F)
+        x = ((r["kps"]["x"][sel] - F(cam["cx"])) * z * invfx).astype(F); y = ((r["kps"]["y"][sel] - F(cam["cy"])) * z * invfy).astype(F)
+        pos = np.stack([x, y, z], 1).astype(F)
+        dist = np.sqrt((pos.astype(np.float64) ** 2).sum(1)).astype(F)
+        arr = np.zeros(len(sel), LOCAL_POINT_DTYPE)
+        arr["pos"] = pos; arr["normal"] = (pos / dist[:, None]).astype(F)
+        arr["max_distance"] = (dist * sc[r["kps"]["octave"][sel]]).astype(F); arr["min_distance"] = (arr["max_distance"] / sc[-1]).astype(F)
+        arr["desc"] = r["desc"][sel]; arr["flags"] = 2
+        chunks.append(arr); off.append(off[-1] + len(sel))
+    pts = np.concatenate(chunks) if chunks else np.zeros(1, LOCAL_POINT_DTYPE)
+    nfr = len(tpairs_h)
+    M = max(1, max(len(c) for c in chunks))
+    dpts = torch.from_numpy(pts.view(np.uint8).reshape(-1)).to(dev); doff = torch.tensor(off, dtype=torch.int32, device=dev)
+    dfr = torch.tensor([b for _, b in tpairs_h], dtype=torch.int32, device=dev)
+    trl = iv.BatchTracker(NFEAT, sc, cam["fx"], cam["fy"], cam["cx"], cam["cy"], BF, (0.0, 0.0, float(W), float(H)), max_pairs=nfr,
+                          device_id=dev.index or 0)
+    la = torch.empty((nfr, NFEAT), dtype=torch.int32, device=dev); ln = torch.empty(nfr, dtype=torch.int32, device=dev)
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    trl.search_local(rec_buf, dfr, dpts, doff, M, la, ln, th=1.0, nn_ratio=0.8, stream_ptr=stream.cuda_stream)
+    e0.record(stream)
+    for _ in range(10):
+        trl.search_local(rec_buf, dfr, dpts, doff, M, la, ln, th=1.0, nn_ratio=0.8, stream_ptr=stream.cuda_stream)
+    e1.record(stream); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 10 / max(nfr, 1)
+    lah, lnh = la.cpu().numpy(), ln.cpu().numpy()
+    ok = True
+    I = np.eye(4, dtype=F)
+    for k in sorted({0, nfr - 1}):
+        b = tpairs_h[k][1]; r = recs[b]
+        cur = dict(kps=r["kps"], desc=r["desc"], uright=r["uright"], depth=r["depth"], T=I, scale=sc, fx=F(cam["fx"]), fy=F(cam["fy"]),
+                   cx=F(cam["cx"]), cy=F(cam["cy"]), mbf=F(BF), mb=F(F(BF) / F(cam["fx"])), bounds=(0.0, 0.0, float(W), float(H)),
+                   logScale=F(O.lib.orc_logf(float(sc[1]))))
+        c = chunks[k]
+        plist = [dict(pos=c[j]["pos"], normal=c[j]["normal"], minDist=c[j]["min_distance"], maxDist=c[j]["max_distance"], desc=c[j]["desc"],
+                      skip=False, nObs=1) for j in range(len(c))]
+        onm, oa = PO.search_local_points_frame(O, cur, plist, None, F(1.0), F(0.8))
+        ok = ok and onm == int(lnh[k]) and np.array_equal(oa, lah[k, :len(oa)])
+    return {"us_per_frame": round(us, 3), "frames_per_launch_sequence": nfr, "map_points_per_frame": round(float(np.mean([len(c) for c in chunks])), 1),
+            "mean_matches": round(float(lnh.mean()), 1), "parity_ok": bool(ok), "frames_checked_vs_oracle": 2,
+            "what": "Tracking::SearchLocalPoints (isInFrustum + PredictScale + SearchByProjection(F, mapPoints), th 1, ratio 0.8) for every "
+                    "frame at once, device-resident (ivf_tracker_search_local)"}
+
+
 def track_report(torch, iv, tracker, rec_buf, tpairs, tpairs_h, assign_h, nm_h, sc, cam, stream):
     """The batched tracker step on the last timed sub-batch's records: (i) what it left in HBM inside the timed region against
     the oracle for 3 frame pairs (projection loops: oracle/projection_oracle.py; window search + greedy replay: the C oracle),
@@ -266,7 +322,8 @@ def track_report(torch, iv, tracker, rec_buf, tpairs, tpairs_h, assign_h, nm_h, 
         for _ in range(20):
             O.search_by_projection(cu["kps"], cu["desc"], cu["uright"], bounds, q, True)
         t_c.append((time.perf_counter() - t0) / 20)
-    return {"us_per_frame_pair": round(us, 3), "N": NFEAT, "frame_pairs_per_launch_sequence": len(tpairs_h),
+    local = local_points_report(torch, iv, rec_buf, recs, tpairs_h, sc, cam, stream, O, PO)
+    return {"search_local_points": local, "us_per_frame_pair": round(us, 3), "N": NFEAT, "frame_pairs_per_launch_sequence": len(tpairs_h),
             "mean_matches": round(float(nm_h[:len(tpairs_h)].mean()), 1), "parity_ok": bool(ok), "pairs_checked_vs_oracle": len(sample),
             "oracle_one_core_us_per_frame_pair": round(float(np.mean(t_c)) * 1e6, 1),
             "what": "Tracking::TrackWithMotionModel's matcher call (UpdateLastFrame stereo points -> SearchByProjection(cur, last), th 7, retry 14 "
@@ -567,7 +624,7 @@ def main():
         last = (nsub[0] - 1) % 3
         rec_buf = (gathered3[last] if exchange else blocks3[last]).clone()
         trk = track_report(torch, iv, tracker, rec_buf, tpairs, tpairs_h, assign3[last].cpu().numpy(), nm3[last].cpu().numpy(), sc, cam, stream)
-        if not trk["parity_ok"]:
+        if not (trk["parity_ok"] and trk["search_local_points"]["parity_ok"]):
             print("bench.py: rank %d: TRACKER PARITY CHECK FAILED: %s" % (rank, json.dumps(trk)), file=sys.stderr, flush=True)
             raise SystemExit(4)
         if exch is not None:
@@ -641,7 +698,7 @@ def main():
         torch.cuda.synchronize(dev)
         trk = track_report(torch, iv, tr1, blk, tp, tp_h, a1.cpu().numpy(), n1.cpu().numpy(), sc, cam, stream)
         trk["in_timed_region"] = False
-        if not trk["parity_ok"]:
+        if not (trk["parity_ok"] and trk["search_local_points"]["parity_ok"]):
             print("bench.py: rank %d: TRACKER PARITY CHECK FAILED: %s" % (rank, json.dumps(trk)), file=sys.stderr, flush=True)
             raise SystemExit(4)
     h2d = None
