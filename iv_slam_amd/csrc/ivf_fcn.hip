@@ -2102,6 +2102,267 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     }
 }
 
+// ---- blocks 8 - 14 (dilation 2) as ONE kernel each: expand CIN -> 6 CIN, depthwise 3x3 dilation 2, project -> COUT (+ residual) ----
+// The scheme of k_fcn_irbd4 one dilation down: a depthwise 3x3 with dilation 2 on a 64 x 64 map is four independent plain 3x3
+// convolutions on the 32 x 32 sub-images of equal (y mod 2, x mod 2).  A sub-image does not fit one workgroup's registers, so a
+// workgroup owns a STRIP of 8 rows x 32 columns of one sub-image (256 output pixels, the full width: no halo left or right) and
+// computes the expansion for the row above and the row below as well (10 rows: 25 % more expansion, 12 % more MFMA work overall --
+// against the 576- / 384-channel hidden tensors going to HBM and back).  Rows outside the sub-image are the depthwise layer's zero
+// padding: their hidden values are stored as zeros.
+//   * wave w: output row w of the strip (32 pixels: two 16-pixel expansion blocks, one 32-pixel projection block); waves 4-7 also own
+//     one 16-pixel block of a halo row each (waves 4, 5: the row above; 6, 7: the row below) -- every SIMD hosts one wave with three
+//     expansion blocks and one with two;
+//   * everything else as in k_fcn_irbd4: groups of 16 hidden channels, one barrier per interval, E(g) / S(g - 1) / P(g - 2) on
+//     different LDS buffers, weights by LDS-DMA requested two intervals ahead (most pieces by waves 0-3, which have no halo block),
+//     waves 0-3 [MFMA phase, stencil phase], waves 4-7 [stencil, MFMA], VALU placed behind the MFMAs.
+//   * stencil thread = (channel, row, 8-pixel segment): the pixel left / right of a segment comes from the neighbouring lane (DPP).
+constexpr int kD2CS = 10 * 36 + 4;                // floats per channel plane of sH: 10 rows x (32 + 4 pad), + 4: the four 16-lane groups of E's
+                                                  // stores (4 channels apart) start 16 banks apart
+template <int CIN, int COUT>
+struct D2Cfg {
+    static constexpr int KS = CIN / 32, TILES = COUT / 32, HID = 6 * CIN, NG = HID / 16;
+    static constexpr int NPE = 2 * KS, NPP = 2 * TILES, NP = NPE + NPP + 1;              // 1 KB pieces per interval (+ parameters)
+    static constexpr int WSLOT = (NPE + NPP) * 64;                                        // uint4 per weight slot
+    static constexpr size_t LDS = (size_t)2 * 16 * kD2CS * 4 + (size_t)2 * 16 * kF4DP * 4 + (size_t)3 * WSLOT * 16 + 4 * kF4ParB;
+};
+
+template <int CIN, int COUT, bool RES>
+__global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ X, const uint4* __restrict__ WE, const float* __restrict__ par,
+                                                     const uint4* __restrict__ WP, const float* __restrict__ scP, const float* __restrict__ shP,
+                                                     const float* __restrict__ res, float* __restrict__ Y)
+{
+    using C = D2Cfg<CIN, COUT>;
+    constexpr int KS = C::KS, TILES = C::TILES, NG = C::NG, NPE = C::NPE, NPP = C::NPP, NP = C::NP, WSLOT = C::WSLOT;
+    extern __shared__ __attribute__((aligned(16))) uint4 d2smem[];
+    float* const sH = (float*)d2smem;                               // [2][16 ch][kD2CS]
+    float* const sD = sH + 2 * 16 * kD2CS;                          // [2][16 ch][kF4DP]
+    uint4* const sW = (uint4*)(sD + 2 * 16 * kF4DP);                // [3 slots][E: KS x (hi, lo) | P: TILES x (hi, lo)][64 lanes]
+    float* const sPar = (float*)(sW + 3 * WSLOT);                   // [4 slots][16 ch][12]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;     // consecutive L on one XCD (grid x = 16 * images)
+    const int b = L >> 4, py = (L >> 3) & 1, px = (L >> 2) & 1, strip = L & 3;
+    constexpr int HW = 4096;
+    const unsigned ldsBase = (unsigned)(uintptr_t)d2smem;
+    const unsigned ldsW = ldsBase + (unsigned)((uint8_t*)sW - (uint8_t*)d2smem), ldsPar = ldsBase + (unsigned)((uint8_t*)sPar - (uint8_t*)d2smem);
+    auto dma16 = [](const void* src, unsigned ldsAddr) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(ldsAddr) : "memory");
+    };
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    auto piece = [&](int it, int c) {           // piece c of what interval `it` consumes: WE[it] (c < NPE), WP[it - 2] (c < NPE + NPP), par[it]
+        const int nb = it % 3;
+        if (c < NPE) {
+            if (it < NG) dma16(WE + ((size_t)it * NPE + c) * 64 + lane, ldsW + (unsigned)(nb * WSLOT + c * 64) * 16u);
+        } else if (c < NPE + NPP) {
+            const int gp = it - 2;
+            if (gp >= 0 && gp < NG) dma16(WP + ((size_t)gp * NPP + (c - NPE)) * 64 + lane, ldsW + (unsigned)(nb * WSLOT + c * 64) * 16u);
+        } else if (c == NPE + NPP) {
+            if (it < NG && lane < 48) dma16(par + (size_t)it * 192 + lane * 4, ldsPar + (unsigned)((it & 3) * kF4ParB));
+        }
+    };
+    auto dma_all = [&](int it) {
+#pragma unroll
+        for (int r = 0; r < (NP + 7) / 8; r++) { const int c = uwave + 8 * r; if (c < NP) piece(it, c); }
+    };
+    auto dma_late = [&](int it) {               // waves 0-3 (no halo block, first at the barrier) take NA pieces each, waves 4-7 the rest
+        constexpr int NA = NP / 4;
+        if (uwave < 4) {
+#pragma unroll
+            for (int r = 0; r < NA; r++) piece(it, uwave + 4 * r);
+        } else if (4 * NA + (uwave - 4) < NP) piece(it, 4 * NA + (uwave - 4));
+    };
+    dma_all(0);
+    dma_all(1);
+
+    // ---- input: blocks 0, 1 = this wave's row (columns 0-15, 16-31); block 2 (waves 4-7) = 16 pixels of a halo row
+    // lane: column n = lane & 15, k = 8 (lane >> 4) + j; rows outside the sub-image read as zeros
+    const int r0 = 8 * strip + wave;                                 // sub-image row of blocks 0, 1
+    const int rH = wave < 6 ? 8 * strip - 1 : 8 * strip + 8, cH = 16 * (wave & 1);    // halo block of waves 4-7
+    const bool haloIn = wave >= 4 && rH >= 0 && rH < 32;
+    HFrag bh[KS][3], bl[KS][3];
+    {
+        const float* Xb = X + (size_t)b * CIN * HW;
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int r = u < 2 ? r0 : rH, c = (u < 2 ? 16 * u : cH) + (lane & 15);
+            const bool ok = u < 2 || haloIn;
+            const int pix = ok ? (2 * r + py) * 64 + 2 * c + px : 0;
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { const float x = Xb[(size_t)(32 * s + 8 * (lane >> 4) + j) * HW + pix]; v[j] = ok ? x : 0.f; }
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) split_pair(v[2 * jj], v[2 * jj + 1], bh[s][u].u[jj], bl[s][u].u[jj]);
+            }
+        }
+    }
+    f32x16 pacc[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; t++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) pacc[t][q] = 0.f;
+
+    // stencil thread: channel sch, output row srw of the strip, segment sg (pixels 8 sg .. 8 sg + 7); tap rows = plane rows srw .. srw + 2
+    const int sch = tid >> 5, srw = (tid >> 2) & 7, sg = tid & 3;
+    const int sbase = sch * kD2CS + srw * 36 + 8 * sg;
+    const float mL = sg > 0 ? 1.f : 0.f, mR = sg < 3 ? 1.f : 0.f;      // the pixel beside a segment comes from lane -1 / +1; none at the row's ends
+
+    for (int i = tid; i < 2 * 16 * kF4DP / 4; i += 512) ((uint4*)sD)[i] = make_uint4(0u, 0u, 0u, 0u);      // P(-2), P(-1): zero operands
+    for (int i = tid; i < 2 * NPP * 64; i += 512) sW[(i / (NPP * 64)) * WSLOT + NPE * 64 + i % (NPP * 64)] = make_uint4(0u, 0u, 0u, 0u);   // P fragments of slots 0, 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // hidden rows outside the sub-image are zero padding of the depthwise layer
+    const float haloKeep = haloIn ? 1.f : 0.f;
+    const int lrowH = wave < 6 ? 0 : 9;
+
+    struct MPre { float dv[8]; float2 eb[4]; HFrag ea0[2], pa0[2]; };
+    auto mfma_pre = [&](int it, MPre& m) {      // every LDS read of the phase that depends on no MFMA
+        const int cur = it & 1, ws = it % 3;
+        const float* dB = sD + cur * (16 * kF4DP) + (8 * (lane >> 5)) * kF4DP + 32 * wave + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 8; j++) m.dv[j] = dB[j * kF4DP];
+        const float* pp = sPar + (it & 3) * (kF4ParB / 4) + (4 * (lane >> 4)) * 12 + 10;
+#pragma unroll
+        for (int r = 0; r < 4; r++) m.eb[r] = *(const float2*)(pp + r * 12);
+        const uint4* wE = sW + ws * WSLOT + lane;
+        const uint4* wPq = wE + NPE * 64;
+        m.ea0[0].q = wE[0]; m.ea0[1].q = wE[64];
+        m.pa0[0].q = wPq[0]; m.pa0[1].q = wPq[64];
+    };
+    auto mfma_main = [&](int it, MPre& m) {
+        const int cur = it & 1, ws = it % 3;
+        const uint4* wE = sW + ws * WSLOT + lane;
+        const uint4* wPq = wE + NPE * 64;
+        HFrag ea[2][2], pa[2][2], ph, pl;
+        ea[0][0] = m.ea0[0]; ea[0][1] = m.ea0[1]; pa[0][0] = m.pa0[0]; pa[0][1] = m.pa0[1];
+        f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; s++) {          // E(it), blocks 0 and 1: hidden group `it` = W_E[16 x CIN] . X[CIN x 32 pixels of this wave's row]
+            if (s + 1 < KS) { ea[(s + 1) & 1][0].q = wE[(2 * s + 2) * 64]; ea[(s + 1) & 1][1].q = wE[(2 * s + 3) * 64]; }
+            const HFrag &ah = ea[s & 1][0], &al = ea[s & 1][1];
+            e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, bh[s][0].v, e0, 0, 0, 0);
+            e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, bh[s][1].v, e1, 0, 0, 0);
+            e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bl[s][0].v, e0, 0, 0, 0);
+            e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bl[s][1].v, e1, 0, 0, 0);
+            e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[s][0].v, e0, 0, 0, 0);
+            e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[s][1].v, e1, 0, 0, 0);
+            // P's B fragment: the four f16 splits spread over the K steps, two VALU instructions behind each MFMA
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (j * KS / 4 == s) split_pair(m.dv[2 * j], m.dv[2 * j + 1], ph.u[j], pl.u[j]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int i = 0; i < 6; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // C layout of E: column = lane & 15, row = 4 (lane >> 4) + r (hidden channel of the group)
+        float* hpl = sH + cur * (16 * kD2CS) + (4 * (lane >> 4)) * kD2CS + (lane & 15);
+        if (uwave >= 4) {                       // E(it), block 2: this wave's 16 pixels of a halo row (its fragments are read once more)
+            f32x4 e2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                HFrag ah, al; ah.q = wE[(2 * s) * 64]; al.q = wE[(2 * s + 1) * 64];
+                e2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, bh[s][2].v, e2, 0, 0, 0);
+                e2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bl[s][2].v, e2, 0, 0, 0);
+                e2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[s][2].v, e2, 0, 0, 0);
+            }
+            float* hp2 = hpl + lrowH * 36 + cH;
+#pragma unroll
+            for (int r = 0; r < 4; r++) hp2[r * kD2CS] = haloKeep * __builtin_amdgcn_fmed3f(__builtin_fmaf(e2[r], m.eb[r].x, m.eb[r].y), 0.f, 6.f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float* hp = hpl + (wave + 1) * 36;
+        constexpr int RPS = TILES > 1 ? (4 + TILES - 2) / (TILES - 1) : 4;      // epilogue rows per projection step (steps 1 .. TILES - 1)
+#pragma unroll
+        for (int t = 0; t < TILES; t++) {       // P(it - 2): out[COUT x 32 pixels] += W_P[COUT x 16] . D[16 x 32 pixels]
+            if (t + 1 < TILES) { pa[(t + 1) & 1][0].q = wPq[(2 * t + 2) * 64]; pa[(t + 1) & 1][1].q = wPq[(2 * t + 3) * 64]; }
+            const HFrag &ah = pa[t & 1][0], &al = pa[t & 1][1];
+            pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, ph.v, pacc[t], 0, 0, 0);
+            pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, pl.v, pacc[t], 0, 0, 0);
+            pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, ph.v, pacc[t], 0, 0, 0);
+            if (t >= 1) {                       // E's epilogue of blocks 0, 1 under P's MFMAs: BN + ReLU6 -> planes
+#pragma unroll
+                for (int r = (t - 1) * RPS; r < t * RPS && r < 4; r++) {
+                    hp[r * kD2CS] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e0[r], m.eb[r].x, m.eb[r].y), 0.f, 6.f);
+                    hp[r * kD2CS + 16] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e1[r], m.eb[r].x, m.eb[r].y), 0.f, 6.f);
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2 * RPS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2 * RPS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 2 * RPS, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto stencil_phase = [&](int it) {          // S(it - 1): 3x3 on the 10 x 32 planes of group it - 1 -> 8 x 32, + BN + ReLU6
+        const int g = it - 1;
+        if (g < 0 || g >= NG) return;
+        const float* hp = sH + (g & 1) * (16 * kD2CS) + sbase;
+        const float4* pq = (const float4*)(sPar + (g & 3) * (kF4ParB / 4) + sch * 12);
+        const float4 w03 = pq[0], w47 = pq[1], w8s = pq[2];          // taps 0-3 | 4-7 | tap 8, shift, (expansion BN)
+        float o[8];
+#pragma unroll
+        for (int p8 = 0; p8 < 8; p8++) o[p8] = w8s.y;
+        const float wk[9] = {w03.x, w03.y, w03.z, w03.w, w47.x, w47.y, w47.z, w47.w, w8s.x};
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+            const float4 a = *(const float4*)(hp + ky * 36), c4 = *(const float4*)(hp + ky * 36 + 4);
+            const float own[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+            const float w0 = wk[3 * ky], w1 = wk[3 * ky + 1], w2 = wk[3 * ky + 2];
+            const float w0L = w0 * mL, w2R = w2 * mR;
+#pragma unroll
+            for (int p8 = 0; p8 < 8; p8++) {
+                o[p8] = __builtin_fmaf(own[p8], w1, o[p8]);
+                if (p8 > 0) o[p8] = __builtin_fmaf(own[p8 - 1], w0, o[p8]);
+                else asm("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(o[p8]) : "v"(own[7]), "v"(w0L));
+                if (p8 < 7) o[p8] = __builtin_fmaf(own[p8 + 1], w2, o[p8]);
+                else asm("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(o[p8]) : "v"(own[0]), "v"(w2R));
+            }
+        }
+        float* dp = sD + (g & 1) * (16 * kF4DP) + sch * kF4DP + srw * 32 + 8 * sg;
+        *(float4*)dp = make_float4(__builtin_amdgcn_fmed3f(o[0], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[1], 0.f, 6.f),
+                                   __builtin_amdgcn_fmed3f(o[2], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[3], 0.f, 6.f));
+        *(float4*)(dp + 4) = make_float4(__builtin_amdgcn_fmed3f(o[4], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[5], 0.f, 6.f),
+                                         __builtin_amdgcn_fmed3f(o[6], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[7], 0.f, 6.f));
+    };
+
+    for (int it = 0; it < NG + 2; it++) {
+        {
+            MPre m;
+            mfma_pre(it, m); __builtin_amdgcn_sched_barrier(0);
+            if (wave < 4) { mfma_main(it, m); stencil_phase(it); }
+            else { stencil_phase(it); __builtin_amdgcn_sched_barrier(0); mfma_main(it, m); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the pieces of it + 1, requested an interval ago
+        dma_late(it + 2);                                        // land during it + 1; their slots were last read in it - 1
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: BN (+ residual) of the projection; pixel n of the wave's row -> image (2 r0 + py, 2 n + px)
+    const int n = lane & 31;
+    const int pix = (2 * r0 + py) * 64 + 2 * n + px;
+#pragma unroll
+    for (int t = 0; t < TILES; t++) {
+        const int cb = t * 32 + 4 * (lane >> 5);
+        float4 sc4[4], sh4[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(scP + cb + 8 * g4); sh4[g4] = *(const float4*)(shP + cb + 8 * g4); }
+        const size_t ob = ((size_t)b * COUT + cb) * HW + pix;
+        float rv[16];
+        if (RES) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) rv[q] = res[ob + (size_t)((q & 3) + 8 * (q >> 2)) * HW];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            float v = pacc[t][q] * vget<4>(sc4[q >> 2], q & 3) + vget<4>(sh4[q >> 2], q & 3);
+            if (RES) v += rv[q];
+            Y[ob + (size_t)((q & 3) + 8 * (q >> 2)) * HW] = v;
+        }
+    }
+}
+
 // ---- conv_last 1x1 80 -> 1 + bias (models_light.py:196) ----
 __global__ void k_fcn_last(const float* __restrict__ X, const float* __restrict__ w, float bias, float* __restrict__ Y,
                            int C, int HW)
@@ -2378,6 +2639,7 @@ struct ivf_fcn {
     std::vector<Dw> dw;
     float* dLastW = nullptr; float lastBias = 0.f;
     struct Fused4 { uint4 *dWE = nullptr, *dWP = nullptr; float* dPar = nullptr; int cout = 0, tilesP = 0; } f4[3];   // blocks 15-17 (k_fcn_irbd4)
+    Fused4 f2[7];                                                                                                          // blocks 8-14 (k_fcn_irbd2)
     float *bufIn = nullptr, *bufA = nullptr, *bufB = nullptr, *bufH1 = nullptr, *bufH2 = nullptr, *bufLogits = nullptr;
     uint8_t *dStageIn = nullptr, *dStageU8 = nullptr; float* dStageF = nullptr;
     void* hPin = nullptr;        // pinned host staging of the per-call path (ivf_fcn_forward)
@@ -2475,26 +2737,27 @@ int make_gemm(ivf_fcn* f, const float* w, int cout, int cin, int taps, const std
 // channel 12 parameters: the nine depthwise taps times the depthwise BN scale, its shift, the expansion's BN scale and shift.
 // we / wp: the pre-scaled rows (prescale_rows), scE: the expansion's BN scale after the pre-scaling.
 int make_fused4(ivf_fcn* f, ivf_fcn::Fused4& F, const float* we, const std::vector<float>& scE, const std::vector<float>& shE, const float* wd,
-                const std::vector<float>& scD, const std::vector<float>& shD, const float* wp, int cout)
+                const std::vector<float>& scD, const std::vector<float>& shD, const float* wp, int cout, int cin = kF4Cin, int hid = kF4Hid)
 {
+    const int groups = hid / 16, ksteps = cin / 32;
     auto put = [](uint16_t* q, size_t frag, int lane, int j, float v) {
         const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
         q[((frag + 0) * 64 + lane) * 8 + j] = hi; q[((frag + 1) * 64 + lane) * 8 + j] = lo;
     };
     F.cout = cout; F.tilesP = cout / 32;
-    std::vector<float> qe((size_t)kF4Groups * 5 * 2 * 64 * 4, 0.f), qp((size_t)kF4Groups * F.tilesP * 2 * 64 * 4, 0.f), par((size_t)kF4Hid * 12, 0.f);
+    std::vector<float> qe((size_t)groups * ksteps * 2 * 64 * 4, 0.f), qp((size_t)groups * F.tilesP * 2 * 64 * 4, 0.f), par((size_t)hid * 12, 0.f);
     uint16_t* e16 = reinterpret_cast<uint16_t*>(qe.data()); uint16_t* p16 = reinterpret_cast<uint16_t*>(qp.data());
-    for (int g = 0; g < kF4Groups; g++) {
-        for (int s5 = 0; s5 < 5; s5++)
+    for (int g = 0; g < groups; g++) {
+        for (int s5 = 0; s5 < ksteps; s5++)
             for (int lane = 0; lane < 64; lane++)
                 for (int j = 0; j < 8; j++)
-                    put(e16, ((size_t)g * 5 + s5) * 2, lane, j, we[(size_t)(16 * g + (lane & 15)) * kF4Cin + 32 * s5 + 8 * (lane >> 4) + j]);
+                    put(e16, ((size_t)g * ksteps + s5) * 2, lane, j, we[(size_t)(16 * g + (lane & 15)) * cin + 32 * s5 + 8 * (lane >> 4) + j]);
         for (int t = 0; t < F.tilesP; t++)
             for (int lane = 0; lane < 64; lane++)
                 for (int j = 0; j < 8; j++)
-                    put(p16, ((size_t)g * F.tilesP + t) * 2, lane, j, wp[(size_t)(32 * t + (lane & 31)) * kF4Hid + 16 * g + 8 * (lane >> 5) + j]);
+                    put(p16, ((size_t)g * F.tilesP + t) * 2, lane, j, wp[(size_t)(32 * t + (lane & 31)) * hid + 16 * g + 8 * (lane >> 5) + j]);
     }
-    for (int c = 0; c < kF4Hid; c++) {
+    for (int c = 0; c < hid; c++) {
         for (int q = 0; q < 9; q++) par[(size_t)c * 12 + q] = wd[(size_t)c * 9 + q] * scD[c];
         par[(size_t)c * 12 + 9] = shD[c]; par[(size_t)c * 12 + 10] = scE[c]; par[(size_t)c * 12 + 11] = shE[c];
     }
@@ -2573,6 +2836,27 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             ip += 2; id++;
             H = (H - 1) / d.stride + 1; W = (W - 1) / d.stride + 1;
             snprintf(nm, sizeof nm, "block %d whole", i + 1); STAGE(nm);
+            std::swap(x, y);
+            continue;
+        }
+        static const int fused2 = getenv("IVF_FCN_NOFUSE") ? 0 : getenv("IVF_FCN_FUSED2") ? atoi(getenv("IVF_FCN_FUSED2")) : 0;
+        if (fused2 && i >= 7 && i <= 13 && f->f2[i - 7].dWE && H == 64 && W == 64) {           // blocks 8-14: one kernel, no hidden tensor in HBM
+            const ivf_fcn::Fused4& F = f->f2[i - 7];
+            const Gemm& pj = f->pw[ip + 1];
+            bool ok = true;
+            auto go = [&](auto kern, size_t lds) {
+                static bool attr = false;                                                      // one static per instantiation of this lambda
+                if (!attr) { ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess; attr = ok; }
+                if (ok) hipLaunchKernelGGL(kern, dim3(16 * n), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, bk.res ? x : (const float*)nullptr, y);
+            };
+            if (bk.inp == 64 && bk.oup == 64 && bk.res) go(&k_fcn_irbd2<64, 64, true>, D2Cfg<64, 64>::LDS);
+            else if (bk.inp == 64 && bk.oup == 96 && !bk.res) go(&k_fcn_irbd2<64, 96, false>, D2Cfg<64, 96>::LDS);
+            else if (bk.inp == 96 && bk.oup == 96 && bk.res) go(&k_fcn_irbd2<96, 96, true>, D2Cfg<96, 96>::LDS);
+            else if (bk.inp == 96 && bk.oup == 160 && !bk.res) go(&k_fcn_irbd2<96, 160, false>, D2Cfg<96, 160>::LDS);
+            else ok = false;
+            if (!ok) return ffail(IVF_E_NO_DEVICE, "block %d: no k_fcn_irbd2 instance / LDS reservation failed", i + 1);
+            ip += 2; id++;
+            snprintf(nm, sizeof nm, "block %d whole (dilation-2 strips)", i + 1); STAGE(nm);
             std::swap(x, y);
             continue;
         }
@@ -2720,6 +3004,7 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
         const Block& bk = kBlocks[i];
         const int hid = bk.inp * bk.t;
         const bool f4 = i >= 14 && bk.inp == kF4Cin && hid == kF4Hid && bk.dil == 4 && bk.stride == 1 && bk.oup % 160 == 0;   // blocks 15-17
+        const bool f2 = i >= 7 && i <= 13 && bk.dil == 2 && bk.stride == 1 && bk.t == 6 && (bk.inp == 64 || bk.inp == 96);        // blocks 8-14
         std::vector<float> f4we, f4scE, f4shE, f4scD, f4shD; const float* f4wd = nullptr;
         if (bk.t != 1) {
             const float* w = rd.take((size_t)hid * bk.inp);
@@ -2727,12 +3012,12 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
             const std::vector<float> ws = prescale_rows(w, hid, bk.inp, sc);
             Gemm g; if ((rc = make_gemm(f, ws.data(), hid, bk.inp, 1, sc, sh, 1, g))) { ivf_fcn_destroy(f); return rc; }
             f->pw.push_back(g);
-            if (f4) { f4we = ws; f4scE = sc; f4shE = sh; }
+            if (f4 || f2) { f4we = ws; f4scE = sc; f4shE = sh; }
         }
         {
             const float* w = rd.take((size_t)hid * 9);
             if (!w || !read_bn(hid)) return bad();
-            if (f4) { f4wd = w; f4scD = sc; f4shD = sh; }
+            if (f4 || f2) { f4wd = w; f4scD = sc; f4shD = sh; }
             Dw d; d.c = hid; d.stride = bk.stride; d.dil = bk.dil;
             std::vector<float> hw(w, w + (size_t)hid * 9);
             std::vector<float> pk((size_t)((hid + 31) / 32 * 32) * 12, 0.f);    // padded to whole 32-channel chunks
@@ -2752,6 +3037,7 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
             if (i == 0 && (rc = upload(f, ws, &f->dProj0W))) { ivf_fcn_destroy(f); return rc; }      // same pre-scaled rows, f32 (k_fcn_stem)
             f->pw.push_back(g);
             if (f4 && (rc = make_fused4(f, f->f4[i - 14], f4we.data(), f4scE, f4shE, f4wd, f4scD, f4shD, ws.data(), bk.oup))) { ivf_fcn_destroy(f); return rc; }
+            if (f2 && (rc = make_fused4(f, f->f2[i - 7], f4we.data(), f4scE, f4shE, f4wd, f4scD, f4shD, ws.data(), bk.oup, bk.inp, hid))) { ivf_fcn_destroy(f); return rc; }
         }
     }
     {   // decoder: cbr (3x3 320->80 + BN + ReLU), cbr_deepsup (unused at inference), conv_last, conv_last_deepsup (unused)
