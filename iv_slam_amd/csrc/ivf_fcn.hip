@@ -2839,7 +2839,7 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             std::swap(x, y);
             continue;
         }
-        static const int fused2 = getenv("IVF_FCN_NOFUSE") ? 0 : getenv("IVF_FCN_FUSED2") ? atoi(getenv("IVF_FCN_FUSED2")) : 0;
+        static const int fused2 = getenv("IVF_FCN_NOFUSE") ? 0 : getenv("IVF_FCN_FUSED2") ? atoi(getenv("IVF_FCN_FUSED2")) : 1;
         if (fused2 && i >= 7 && i <= 13 && f->f2[i - 7].dWE && H == 64 && W == 64) {           // blocks 8-14: one kernel, no hidden tensor in HBM
             const ivf_fcn::Fused4& F = f->f2[i - 7];
             const Gemm& pj = f->pw[ip + 1];
