@@ -2164,11 +2164,14 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
         for (int r = 0; r < (NP + 7) / 8; r++) { const int c = uwave + 8 * r; if (c < NP) piece(it, c); }
     };
     auto dma_late = [&](int it) {               // waves 0-3 (no halo block, first at the barrier) take NA pieces each, waves 4-7 the rest
-        constexpr int NA = NP / 4;
+        constexpr int NA = NP / 4;              // measured NA - 1 / NA / NA + 1: 85.8 / 84.3 / 84.1 us per image of the whole network
         if (uwave < 4) {
 #pragma unroll
             for (int r = 0; r < NA; r++) piece(it, uwave + 4 * r);
-        } else if (4 * NA + (uwave - 4) < NP) piece(it, 4 * NA + (uwave - 4));
+        } else {
+#pragma unroll
+            for (int r = 0; r < (NP - 4 * NA + 3) / 4; r++) { const int c = 4 * NA + (uwave - 4) + 4 * r; if (c < NP) piece(it, c); }
+        }
     };
     dma_all(0);
     dma_all(1);
