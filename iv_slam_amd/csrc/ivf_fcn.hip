@@ -2102,7 +2102,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     }
 }
 
-// ---- blocks 8 - 14 (dilation 2) as ONE kernel each: expand CIN -> 6 CIN, depthwise 3x3 dilation 2, project -> COUT (+ residual) ----
+// ---- blocks 5 - 14 (dilation 1 and 2 at 64 x 64) as ONE kernel each: expand CIN -> 6 CIN, depthwise 3x3, project -> COUT (+ residual) ----
 // The scheme of k_fcn_irbd4 one dilation down: a depthwise 3x3 with dilation 2 on a 64 x 64 map is four independent plain 3x3
 // convolutions on the 32 x 32 sub-images of equal (y mod 2, x mod 2).  A sub-image does not fit one workgroup's registers, so a
 // workgroup owns a STRIP of 8 rows x 32 columns of one sub-image (256 output pixels, the full width: no halo left or right) and
@@ -2116,22 +2116,26 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
 //     different LDS buffers, weights by LDS-DMA requested two intervals ahead (most pieces by waves 0-3, which have no halo block),
 //     waves 0-3 [MFMA phase, stencil phase], waves 4-7 [stencil, MFMA], VALU placed behind the MFMAs.
 //   * stencil thread = (channel, row, 8-pixel segment): the pixel left / right of a segment comes from the neighbouring lane (DPP).
-constexpr int kD2CS = 10 * 36 + 4;                // floats per channel plane of sH: 10 rows x (32 + 4 pad), + 4: the four 16-lane groups of E's
-                                                  // stores (4 channels apart) start 16 banks apart
-template <int CIN, int COUT>
+// Geometry by dilation.  DIL 2: strip = 8 rows x 32 columns of a 32 x 32 sub-image, wave w = row w, halo blocks on waves 4-7.
+// DIL 1 (blocks 5-7, ONE 64 x 64 "sub-image"): strip = 4 rows x 64 columns, wave w = half a row (row w >> 1, columns 32 (w & 1) ..),
+// the two halo rows are eight 16-pixel blocks, one per wave.  PITCH = floats per plane row (+ 4 pad), CS = floats per channel plane
+// (+ 4 / + 4: the four 16-lane groups of E's stores, 4 channels apart, start 16 banks apart).
+template <int CIN, int COUT, int DIL = 2>
 struct D2Cfg {
+    static constexpr int ROWS = DIL == 2 ? 8 : 4, COLS = DIL == 2 ? 32 : 64, PITCH = COLS + 4, CS = (ROWS + 2) * PITCH + 4;
     static constexpr int KS = CIN / 32, TILES = COUT / 32, HID = 6 * CIN, NG = HID / 16;
     static constexpr int NPE = 2 * KS, NPP = 2 * TILES, NP = NPE + NPP + 1;              // 1 KB pieces per interval (+ parameters)
     static constexpr int WSLOT = (NPE + NPP) * 64;                                        // uint4 per weight slot
-    static constexpr size_t LDS = (size_t)2 * 16 * kD2CS * 4 + (size_t)2 * 16 * kF4DP * 4 + (size_t)3 * WSLOT * 16 + 4 * kF4ParB;
+    static constexpr size_t LDS = (size_t)2 * 16 * CS * 4 + (size_t)2 * 16 * kF4DP * 4 + (size_t)3 * WSLOT * 16 + 4 * kF4ParB;
 };
 
-template <int CIN, int COUT, bool RES>
+template <int CIN, int COUT, bool RES, int DIL = 2>
 __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ X, const uint4* __restrict__ WE, const float* __restrict__ par,
                                                      const uint4* __restrict__ WP, const float* __restrict__ scP, const float* __restrict__ shP,
                                                      const float* __restrict__ res, float* __restrict__ Y)
 {
-    using C = D2Cfg<CIN, COUT>;
+    using C = D2Cfg<CIN, COUT, DIL>;
+    constexpr int kD2CS = C::CS, PITCH = C::PITCH, ROWS = C::ROWS, COLS = C::COLS;
     constexpr int KS = C::KS, TILES = C::TILES, NG = C::NG, NPE = C::NPE, NPP = C::NPP, NP = C::NP, WSLOT = C::WSLOT;
     extern __shared__ __attribute__((aligned(16))) uint4 d2smem[];
     float* const sH = (float*)d2smem;                               // [2][16 ch][kD2CS]
@@ -2140,7 +2144,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
     float* const sPar = (float*)(sW + 3 * WSLOT);                   // [4 slots][16 ch][12]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;     // consecutive L on one XCD (grid x = 16 * images)
-    const int b = L >> 4, py = (L >> 3) & 1, px = (L >> 2) & 1, strip = L & 3;
+    const int b = L >> 4, py = DIL == 2 ? (L >> 3) & 1 : 0, px = DIL == 2 ? (L >> 2) & 1 : 0, strip = DIL == 2 ? L & 3 : L & 15;
     constexpr int HW = 4096;
     const unsigned ldsBase = (unsigned)(uintptr_t)d2smem;
     const unsigned ldsW = ldsBase + (unsigned)((uint8_t*)sW - (uint8_t*)d2smem), ldsPar = ldsBase + (unsigned)((uint8_t*)sPar - (uint8_t*)d2smem);
@@ -2178,17 +2182,21 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
 
     // ---- input: blocks 0, 1 = this wave's row (columns 0-15, 16-31); block 2 (waves 4-7) = 16 pixels of a halo row
     // lane: column n = lane & 15, k = 8 (lane >> 4) + j; rows outside the sub-image read as zeros
-    const int r0 = 8 * strip + wave;                                 // sub-image row of blocks 0, 1
-    const int rH = wave < 6 ? 8 * strip - 1 : 8 * strip + 8, cH = 16 * (wave & 1);    // halo block of waves 4-7
-    const bool haloIn = wave >= 4 && rH >= 0 && rH < 32;
+    const int r0 = DIL == 2 ? 8 * strip + wave : 4 * strip + (wave >> 1);        // (sub-)image row of blocks 0, 1
+    const int c0 = DIL == 2 ? 0 : 32 * (wave & 1);                                // their first column
+    const bool hasHalo = DIL == 1 || wave >= 4;
+    const bool above = DIL == 2 ? wave < 6 : wave < 4;
+    const int rH = above ? ROWS * strip - 1 : ROWS * strip + ROWS, cH = DIL == 2 ? 16 * (wave & 1) : 16 * (wave & 3);   // halo block
+    constexpr int SUB = 64 / DIL;                                                 // rows / columns of a sub-image
+    const bool haloIn = hasHalo && rH >= 0 && rH < SUB;
     HFrag bh[KS][3], bl[KS][3];
     {
         const float* Xb = X + (size_t)b * CIN * HW;
 #pragma unroll
         for (int u = 0; u < 3; u++) {
-            const int r = u < 2 ? r0 : rH, c = (u < 2 ? 16 * u : cH) + (lane & 15);
+            const int r = u < 2 ? r0 : rH, c = (u < 2 ? c0 + 16 * u : cH) + (lane & 15);
             const bool ok = u < 2 || haloIn;
-            const int pix = ok ? (2 * r + py) * 64 + 2 * c + px : 0;
+            const int pix = ok ? (DIL * r + py) * 64 + DIL * c + px : 0;
 #pragma unroll
             for (int s = 0; s < KS; s++) {
                 float v[8];
@@ -2206,9 +2214,10 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
         for (int q = 0; q < 16; q++) pacc[t][q] = 0.f;
 
     // stencil thread: channel sch, output row srw of the strip, segment sg (pixels 8 sg .. 8 sg + 7); tap rows = plane rows srw .. srw + 2
-    const int sch = tid >> 5, srw = (tid >> 2) & 7, sg = tid & 3;
-    const int sbase = sch * kD2CS + srw * 36 + 8 * sg;
-    const float mL = sg > 0 ? 1.f : 0.f, mR = sg < 3 ? 1.f : 0.f;      // the pixel beside a segment comes from lane -1 / +1; none at the row's ends
+    constexpr int SEGS = COLS / 8;
+    const int sch = tid >> 5, srw = (tid & 31) / SEGS, sg = tid % SEGS;
+    const int sbase = sch * kD2CS + srw * PITCH + 8 * sg;
+    const float mL = sg > 0 ? 1.f : 0.f, mR = sg < SEGS - 1 ? 1.f : 0.f;   // the pixel beside a segment comes from lane -1 / +1; none at the row's ends
 
     for (int i = tid; i < 2 * 16 * kF4DP / 4; i += 512) ((uint4*)sD)[i] = make_uint4(0u, 0u, 0u, 0u);      // P(-2), P(-1): zero operands
     for (int i = tid; i < 2 * NPP * 64; i += 512) sW[(i / (NPP * 64)) * WSLOT + NPE * 64 + i % (NPP * 64)] = make_uint4(0u, 0u, 0u, 0u);   // P fragments of slots 0, 1
@@ -2217,7 +2226,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
 
     // hidden rows outside the sub-image are zero padding of the depthwise layer
     const float haloKeep = haloIn ? 1.f : 0.f;
-    const int lrowH = wave < 6 ? 0 : 9;
+    const int lrowH = above ? 0 : ROWS + 1;
 
     struct MPre { float dv[8]; float2 eb[4]; HFrag ea0[2], pa0[2]; };
     auto mfma_pre = [&](int it, MPre& m) {      // every LDS read of the phase that depends on no MFMA
@@ -2260,7 +2269,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
         }
         // C layout of E: column = lane & 15, row = 4 (lane >> 4) + r (hidden channel of the group)
         float* hpl = sH + cur * (16 * kD2CS) + (4 * (lane >> 4)) * kD2CS + (lane & 15);
-        if (uwave >= 4) {                       // E(it), block 2: this wave's 16 pixels of a halo row (its fragments are read once more)
+        if (DIL == 1 || uwave >= 4) {           // E(it), block 2: this wave's 16 pixels of a halo row (its fragments are read once more)
             f32x4 e2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KS; s++) {
@@ -2269,12 +2278,12 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
                 e2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bl[s][2].v, e2, 0, 0, 0);
                 e2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[s][2].v, e2, 0, 0, 0);
             }
-            float* hp2 = hpl + lrowH * 36 + cH;
+            float* hp2 = hpl + lrowH * PITCH + cH;
 #pragma unroll
             for (int r = 0; r < 4; r++) hp2[r * kD2CS] = haloKeep * __builtin_amdgcn_fmed3f(__builtin_fmaf(e2[r], m.eb[r].x, m.eb[r].y), 0.f, 6.f);
         }
         __builtin_amdgcn_sched_barrier(0);
-        float* hp = hpl + (wave + 1) * 36;
+        float* hp = hpl + ((DIL == 2 ? wave : wave >> 1) + 1) * PITCH + c0;
         constexpr int RPS = TILES > 1 ? (4 + TILES - 2) / (TILES - 1) : 4;      // epilogue rows per projection step (steps 1 .. TILES - 1)
 #pragma unroll
         for (int t = 0; t < TILES; t++) {       // P(it - 2): out[COUT x 32 pixels] += W_P[COUT x 16] . D[16 x 32 pixels]
@@ -2283,9 +2292,9 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
             pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, ph.v, pacc[t], 0, 0, 0);
             pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, pl.v, pacc[t], 0, 0, 0);
             pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, ph.v, pacc[t], 0, 0, 0);
-            if (t >= 1) {                       // E's epilogue of blocks 0, 1 under P's MFMAs: BN + ReLU6 -> planes
+            if (TILES == 1 || t >= 1) {         // E's epilogue of blocks 0, 1 under P's MFMAs: BN + ReLU6 -> planes
 #pragma unroll
-                for (int r = (t - 1) * RPS; r < t * RPS && r < 4; r++) {
+                for (int r = (TILES == 1 ? 0 : (t - 1) * RPS); r < (TILES == 1 ? 4 : t * RPS) && r < 4; r++) {
                     hp[r * kD2CS] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e0[r], m.eb[r].x, m.eb[r].y), 0.f, 6.f);
                     hp[r * kD2CS + 16] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e1[r], m.eb[r].x, m.eb[r].y), 0.f, 6.f);
                 }
@@ -2309,7 +2318,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
         const float wk[9] = {w03.x, w03.y, w03.z, w03.w, w47.x, w47.y, w47.z, w47.w, w8s.x};
 #pragma unroll
         for (int ky = 0; ky < 3; ky++) {
-            const float4 a = *(const float4*)(hp + ky * 36), c4 = *(const float4*)(hp + ky * 36 + 4);
+            const float4 a = *(const float4*)(hp + ky * PITCH), c4 = *(const float4*)(hp + ky * PITCH + 4);
             const float own[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
             const float w0 = wk[3 * ky], w1 = wk[3 * ky + 1], w2 = wk[3 * ky + 2];
             const float w0L = w0 * mL, w2R = w2 * mR;
@@ -2322,7 +2331,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
                 else asm("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(o[p8]) : "v"(own[0]), "v"(w2R));
             }
         }
-        float* dp = sD + (g & 1) * (16 * kF4DP) + sch * kF4DP + srw * 32 + 8 * sg;
+        float* dp = sD + (g & 1) * (16 * kF4DP) + sch * kF4DP + srw * COLS + 8 * sg;
         *(float4*)dp = make_float4(__builtin_amdgcn_fmed3f(o[0], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[1], 0.f, 6.f),
                                    __builtin_amdgcn_fmed3f(o[2], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[3], 0.f, 6.f));
         *(float4*)(dp + 4) = make_float4(__builtin_amdgcn_fmed3f(o[4], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[5], 0.f, 6.f),
@@ -2344,7 +2353,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
 
     // ---- epilogue: BN (+ residual) of the projection; pixel n of the wave's row -> image (2 r0 + py, 2 n + px)
     const int n = lane & 31;
-    const int pix = (2 * r0 + py) * 64 + 2 * n + px;
+    const int pix = (DIL * r0 + py) * 64 + DIL * (c0 + n) + px;
 #pragma unroll
     for (int t = 0; t < TILES; t++) {
         const int cb = t * 32 + 4 * (lane >> 5);
@@ -2643,6 +2652,7 @@ struct ivf_fcn {
     float* dLastW = nullptr; float lastBias = 0.f;
     struct Fused4 { uint4 *dWE = nullptr, *dWP = nullptr; float* dPar = nullptr; int cout = 0, tilesP = 0; } f4[3];   // blocks 15-17 (k_fcn_irbd4)
     Fused4 f2[7];                                                                                                          // blocks 8-14 (k_fcn_irbd2)
+    Fused4 f1[3];                                                                                                          // blocks 5-7 (k_fcn_irbd2, DIL = 1)
     float *bufIn = nullptr, *bufA = nullptr, *bufB = nullptr, *bufH1 = nullptr, *bufH2 = nullptr, *bufLogits = nullptr;
     uint8_t *dStageIn = nullptr, *dStageU8 = nullptr; float* dStageF = nullptr;
     void* hPin = nullptr;        // pinned host staging of the per-call path (ivf_fcn_forward)
@@ -2842,6 +2852,25 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             std::swap(x, y);
             continue;
         }
+        static const int fused1 = getenv("IVF_FCN_NOFUSE") ? 0 : getenv("IVF_FCN_FUSED1") ? atoi(getenv("IVF_FCN_FUSED1")) : 1;
+        if (fused1 && i >= 4 && i <= 6 && f->f1[i - 4].dWE && H == 64 && W == 64) {           // blocks 5-7: the same kernel on 4-row strips of the whole map
+            const ivf_fcn::Fused4& F = f->f1[i - 4];
+            const Gemm& pj = f->pw[ip + 1];
+            bool ok = true;
+            auto go = [&](auto kern, size_t lds) {
+                static bool attr = false;
+                if (!attr) { ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess; attr = ok; }
+                if (ok) hipLaunchKernelGGL(kern, dim3(16 * n), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, bk.res ? x : (const float*)nullptr, y);
+            };
+            if (bk.oup == 32 && bk.res) go(&k_fcn_irbd2<32, 32, true, 1>, D2Cfg<32, 32, 1>::LDS);
+            else if (bk.oup == 64 && !bk.res) go(&k_fcn_irbd2<32, 64, false, 1>, D2Cfg<32, 64, 1>::LDS);
+            else ok = false;
+            if (!ok) return ffail(IVF_E_NO_DEVICE, "block %d: no k_fcn_irbd2<DIL 1> instance / LDS reservation failed", i + 1);
+            ip += 2; id++;
+            snprintf(nm, sizeof nm, "block %d whole (4-row strips)", i + 1); STAGE(nm);
+            std::swap(x, y);
+            continue;
+        }
         static const int fused2 = getenv("IVF_FCN_NOFUSE") ? 0 : getenv("IVF_FCN_FUSED2") ? atoi(getenv("IVF_FCN_FUSED2")) : 1;
         if (fused2 && i >= 7 && i <= 13 && f->f2[i - 7].dWE && H == 64 && W == 64) {           // blocks 8-14: one kernel, no hidden tensor in HBM
             const ivf_fcn::Fused4& F = f->f2[i - 7];
@@ -3008,6 +3037,7 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
         const int hid = bk.inp * bk.t;
         const bool f4 = i >= 14 && bk.inp == kF4Cin && hid == kF4Hid && bk.dil == 4 && bk.stride == 1 && bk.oup % 160 == 0;   // blocks 15-17
         const bool f2 = i >= 7 && i <= 13 && bk.dil == 2 && bk.stride == 1 && bk.t == 6 && (bk.inp == 64 || bk.inp == 96);        // blocks 8-14
+        const bool f1 = i >= 4 && i <= 6 && bk.dil == 1 && bk.stride == 1 && bk.t == 6 && bk.inp == 32;                          // blocks 5-7
         std::vector<float> f4we, f4scE, f4shE, f4scD, f4shD; const float* f4wd = nullptr;
         if (bk.t != 1) {
             const float* w = rd.take((size_t)hid * bk.inp);
@@ -3015,12 +3045,12 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
             const std::vector<float> ws = prescale_rows(w, hid, bk.inp, sc);
             Gemm g; if ((rc = make_gemm(f, ws.data(), hid, bk.inp, 1, sc, sh, 1, g))) { ivf_fcn_destroy(f); return rc; }
             f->pw.push_back(g);
-            if (f4 || f2) { f4we = ws; f4scE = sc; f4shE = sh; }
+            if (f4 || f2 || f1) { f4we = ws; f4scE = sc; f4shE = sh; }
         }
         {
             const float* w = rd.take((size_t)hid * 9);
             if (!w || !read_bn(hid)) return bad();
-            if (f4 || f2) { f4wd = w; f4scD = sc; f4shD = sh; }
+            if (f4 || f2 || f1) { f4wd = w; f4scD = sc; f4shD = sh; }
             Dw d; d.c = hid; d.stride = bk.stride; d.dil = bk.dil;
             std::vector<float> hw(w, w + (size_t)hid * 9);
             std::vector<float> pk((size_t)((hid + 31) / 32 * 32) * 12, 0.f);    // padded to whole 32-channel chunks
@@ -3040,6 +3070,7 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
             if (i == 0 && (rc = upload(f, ws, &f->dProj0W))) { ivf_fcn_destroy(f); return rc; }      // same pre-scaled rows, f32 (k_fcn_stem)
             f->pw.push_back(g);
             if (f4 && (rc = make_fused4(f, f->f4[i - 14], f4we.data(), f4scE, f4shE, f4wd, f4scD, f4shD, ws.data(), bk.oup))) { ivf_fcn_destroy(f); return rc; }
+            if (f1 && (rc = make_fused4(f, f->f1[i - 4], f4we.data(), f4scE, f4shE, f4wd, f4scD, f4shD, ws.data(), bk.oup, bk.inp, hid))) { ivf_fcn_destroy(f); return rc; }
             if (f2 && (rc = make_fused4(f, f->f2[i - 7], f4we.data(), f4scE, f4shE, f4wd, f4scD, f4shD, ws.data(), bk.oup, bk.inp, hid))) { ivf_fcn_destroy(f); return rc; }
         }
     }

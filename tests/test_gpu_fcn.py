@@ -124,11 +124,12 @@ print("OK %.3g" % err)
     {"IVF_FCN_NW": "4"},
     # conv_last as its own kernel after the decoder 3x3 (default: folded into its epilogue)
     {"IVF_FCN_NOFUSELAST": "1"},
-    # blocks 8-14 / 15-17 as expand + depthwise-projection launches instead of k_fcn_irbd2 / k_fcn_irbd4 (the defaults)
+    # blocks 8-14 / 15-17 / 5-7 as expand + depthwise-projection launches instead of k_fcn_irbd2 / k_fcn_irbd4 (the defaults)
     {"IVF_FCN_FUSED2": "0"},
     {"IVF_FCN_FUSED4": "0"},
+    {"IVF_FCN_FUSED1": "0"},
 ], ids=["default", "layerwise", "expand-pxt2", "dwpw-256", "no-stride2-fusion", "no-stem-fusion", "irb-blocks-2-11",
-        "irb-none", "dwpw8-all", "dwpw8-none", "dwpw-4rows-all", "dwpw-4rows-none", "conv-last-unfused", "blocks-8-14-unfused", "blocks-15-17-unfused"])
+        "irb-none", "dwpw8-all", "dwpw8-none", "dwpw-4rows-all", "dwpw-4rows-none", "conv-last-unfused", "blocks-8-14-unfused", "blocks-15-17-unfused", "blocks-5-7-unfused"])
 def test_fcn_kernel_variants_match_goldens_and_are_deterministic(env):
     """The FCN picks between several kernels per layer (measured defaults, env overrides for tuning).  Every variant must
     meet the same bar, batch results must not depend on the batch slot, and repeated runs must be bit-identical (this is
