@@ -163,7 +163,13 @@ def run_cpu_baseline(introspect):
     flags = "-O3 -march=native -ffp-contract=off"
     try:
         os.makedirs(native, exist_ok=True)
-        subprocess.check_call(["gcc"] + flags.split() + ["-fPIC", "-std=gnu11", "-shared", "-o", so, os.path.join(ROOT, "oracle", "ivf_oracle.c"), "-lm"],
+        import hashlib
+        hid = hashlib.sha256()                   # same provenance stamp as oracle/Makefile (tests/oracle_lib.py refuses an unstamped checker)
+        for f in ("ivf_oracle.c", "ivf_oracle.h", "stl_pin.cpp", os.path.join("..", "include", "ivf_pattern31.inc")):
+            with open(os.path.join(ROOT, "oracle", f), "rb") as fh:
+                hid.update(fh.read())
+        subprocess.check_call(["gcc"] + flags.split() + ["-DORC_BUILD_ID=\"%s\"" % hid.hexdigest()[:16],
+                               "-fPIC", "-std=gnu11", "-shared", "-o", so, os.path.join(ROOT, "oracle", "ivf_oracle.c"), "-lm"],
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     except Exception:
         so, flags = None, "-O3 -march=x86-64-v2 -ffp-contract=off (no compiler on this host: the portable build)"

@@ -60,6 +60,14 @@ int         ivf_version(void);
 const char* ivf_last_error(void);
 int         ivf_device_count(void);                 /* number of visible HIP devices (0 if none) */
 long long   ivf_debug_launch_count(void);           /* measurement aid: kernel launches this process has issued through the library */
+/* Build provenance: the first 16 hex digits of sha256 over iv_slam_amd/csrc/{*.hip sorted, ivf_device.h} and include/{* sorted},
+ * taken when the library was linked (iv_slam_amd/csrc/Makefile).  iv_slam_amd/_lib.py recomputes it from the sources next to
+ * the library and refuses to load a library built from anything else: a stale .so cannot produce a test result or a bench line. */
+const char* ivf_build_id(void);
+/* Diagnostic: number of per-thread scratch slots (device + pinned host buffers of the per-call entry points) the process has
+ * ever created.  Slots are leased by a thread and handed back when it exits, so the count follows the peak number of
+ * CONCURRENT caller threads, not the number of threads ever started (ORB/src/Frame.cc:116-124 starts two per frame). */
+int         ivf_debug_scratch_slots(void);
 
 /* ---- ORBextractor ---- */
 /* ORBextractor::ORBextractor (ORB/src/ORBextractor.cc:411-476); constructed in Tracking (ORB/src/Tracking.cc:174-191) */
@@ -267,15 +275,28 @@ size_t ivf_track_record_bytes(int nfeatures);
 int  ivf_tracker_create(const ivf_track_config* cfg, ivf_tracker** out);
 void ivf_tracker_destroy(ivf_tracker* t);
 /* d_records: n_records gather records, record_bytes apart, 16-byte aligned (a packed block, or the all-gathered buffer);
- * d_pairs [n_pairs][2] int32 on the device = (last record, cur record) indices; d_poses [n_records][12] = Tcw of every
- * record's frame, row-major 3x4, or NULL = identity everywhere (zero-motion prior); d_point_flags [n_records][nfeatures]
- * (nullable): bit 0 = the keypoint has a map point, bit 1 = that point has observations (then th_depth is ignored).
+ * d_pairs [n_pairs][2] int32 on the device = (last record, cur record) indices -- an index outside [0, n_records) gives that
+ * pair d_nmatches = -1 and d_assign = -1 instead of a read outside the block;
+ * d_poses [n_pairs][2][12] = for every PAIR {LastFrame.mTcw, CurrentFrame.mTcw} row-major 3x4 -- the optimised pose of the last
+ * frame and the motion-model prior mVelocity * mLastFrame.mTcw of the current one (Tracking.cc:1311), so a frame that is "cur" in
+ * one pair and "last" in the next carries a different pose in each, as in the reference -- or NULL = identity everywhere
+ * (zero-motion prior);
+ * d_point_flags [n_records][nfeatures] (nullable), per keypoint of a record when it is the LAST frame of a pair: bit 0 = the
+ * keypoint carries a map point (0: it carries none, whatever its depth), bit 1 = that point has observations (it blocks the
+ * current keypoint it takes, :1447-1449).  With flags th_depth is ignored; without them UpdateLastFrame's rule (th_depth > 0)
+ * or "every stereo point" (th_depth <= 0) decides and points_block gives bit 1.
+ * d_point_quality / d_key_quality [n_pairs][nfeatures] (both or neither; in/out): ORBmatcher::UpdateQualityScores(CurrentFrame)
+ * (ORB/src/ORBmatcher.cc:1108-1121) as SearchByProjection runs it before returning under --ivslam_propagate_keyptqual
+ * (:1513-1515), on the device: d_point_quality[p][i] = MapPoint::GetQualityScore() of the point last keypoint i carries,
+ * d_key_quality[p][i2] = CurrentFrame.mvKeyQualScore[i2]; q = min of the two, the point's score is rewritten when it moves by
+ * more than 0.01, the keypoint's always.  A retried pair is updated twice, like the two calls of Tracking.cc:1319-1328.
  * Outputs: d_assign [n_pairs][nfeatures] = for every keypoint of the current frame the index of the last-frame keypoint whose
  * point it received (CurrentFrame.mvpMapPoints) or -1; d_nmatches [n_pairs] = the return value.  Asynchronous on hip_stream.
  * The handle owns the scratch of ONE run: a run enqueued on a different stream than the previous one waits for it (an event);
  * use one tracker per stream to let runs overlap. */
 int  ivf_tracker_run(ivf_tracker* t, const uint8_t* d_records, size_t record_bytes, int n_records, const int32_t* d_pairs, int n_pairs,
-                     const float* d_poses, const uint8_t* d_point_flags, int32_t* d_assign, int32_t* d_nmatches, void* hip_stream);
+                     const float* d_poses, const uint8_t* d_point_flags, float* d_point_quality, float* d_key_quality,
+                     int32_t* d_assign, int32_t* d_nmatches, void* hip_stream);
 
 /* One local map point as Tracking::SearchLocalPoints (ORB/src/Tracking.cc:2088-2132) sees it.  80 bytes, 16-byte aligned arrays. */
 typedef struct ivf_local_point {
@@ -288,19 +309,23 @@ typedef struct ivf_local_point {
                                       * bit 1: Observations() > 0 (a keypoint this point takes is skipped by later points, ORBmatcher.cc:87-89) */
     int32_t pad[3];
 } ivf_local_point;
-/* Batched Tracking::SearchLocalPoints, from the projection on: for frame f = record d_frames[f] with pose d_poses[d_frames[f]]
- * (nullable = identity) and its local map points d_points[d_point_offsets[f] .. d_point_offsets[f+1]) (at most
- * max_points_per_frame are used): Frame::isInFrustum(pMP, cos_limit = 0.5) (Frame.cc:557-613) incl. MapPoint::PredictScale
- * (MapPoint.cc:407-422), then ORBmatcher(nn_ratio).SearchByProjection(F, vpMapPoints, th) (ORBmatcher.cc:45-135).
+/* Batched Tracking::SearchLocalPoints, from the projection on: for frame slot f = record d_frames[f] with pose d_poses[f]
+ * ([n_frames][12], row-major 3x4 Tcw after TrackWithMotionModel's optimisation; NULL = identity) and its local map points
+ * d_points[d_point_offsets[f] .. d_point_offsets[f+1]) (at most max_points_per_frame are used): Frame::isInFrustum(pMP,
+ * cos_limit = 0.5) (Frame.cc:557-613) incl. MapPoint::PredictScale (MapPoint.cc:407-422), then
+ * ORBmatcher(nn_ratio).SearchByProjection(F, vpMapPoints, th) (ORBmatcher.cc:45-135).  A record index outside [0, n_records)
+ * or a decreasing / negative offset gives that frame d_nmatches = -1 and d_assign = -1.
  * d_occupied [n_frames][nfeatures] (nullable): 1 = the keypoint already holds a map point with observations (skipped, :87-89).
+ * d_point_quality (indexed like d_points) / d_key_quality [n_frames][nfeatures] (both or neither; in/out): UpdateQualityScores(F)
+ * (:128-132, :1108-1121) on the device for the keypoints that receive a point in THIS call; keypoints that held one before went
+ * through the same update when they got it, and a second pass over them changes nothing (min(q_mp, q_kp) == q_kp by then).
  * Outputs: d_assign [n_frames][nfeatures] = index (within the frame's point range) of the map point each keypoint received in
  * THIS call or -1; d_nmatches [n_frames] = the return value (assignments made, replaced ones included).  n_frames <= max_pairs.
- * Asynchronous on hip_stream; shares the handle's scratch (and its one-call-at-a-time rule) with ivf_tracker_run.
- * UpdateQualityScores (ORBmatcher.cc:130-132) is not part of it: ivf_update_quality_scores. */
+ * Asynchronous on hip_stream; shares the handle's scratch (and its one-call-at-a-time rule) with ivf_tracker_run. */
 int  ivf_tracker_search_local(ivf_tracker* t, const uint8_t* d_records, size_t record_bytes, int n_records, const int32_t* d_frames,
                               int n_frames, const float* d_poses, const ivf_local_point* d_points, const int32_t* d_point_offsets,
                               int max_points_per_frame, const uint8_t* d_occupied, float th, float nn_ratio, float cos_limit,
-                              int32_t* d_assign, int32_t* d_nmatches, void* hip_stream);
+                              float* d_point_quality, float* d_key_quality, int32_t* d_assign, int32_t* d_nmatches, void* hip_stream);
 
 /* ---- introspection FCN forward (IF/networks/models_light/models_light.py:18-28; called at
  * ORB/Examples/Stereo/stereo_kitti.cc:231-247 (load) and :493-514 (pre-process, forward, u8 truncation)) ----

@@ -55,6 +55,8 @@ _SIGS = {
     "ivf_last_error": (C.c_char_p, []),
     "ivf_device_count": (C.c_int, []),
     "ivf_debug_launch_count": (C.c_longlong, []),
+    "ivf_build_id": (C.c_char_p, []),
+    "ivf_debug_scratch_slots": (C.c_int, []),
     "ivf_extractor_create": (C.c_int, [C.POINTER(ExtractorParams), C.c_int, C.POINTER(vp)]),
     "ivf_extractor_destroy": (None, [vp]),
     "ivf_extractor_set_opencv_variant": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
@@ -135,9 +137,9 @@ _SIGS = {
     "ivf_track_record_bytes": (C.c_size_t, [C.c_int]),
     "ivf_tracker_create": (C.c_int, [C.POINTER(TrackConfig), C.POINTER(vp)]),
     "ivf_tracker_destroy": (None, [vp]),
-    "ivf_tracker_run": (C.c_int, [vp, vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]),
+    "ivf_tracker_run": (C.c_int, [vp, vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "ivf_tracker_search_local": (C.c_int, [vp, vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_float, C.c_float,
-                                           C.c_float, vp, vp, vp]),
+                                           C.c_float, vp, vp, vp, vp, vp]),
     "ivf_fcn_create": (C.c_int, [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "ivf_fcn_destroy": (None, [vp]),
     "ivf_fcn_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
@@ -149,6 +151,20 @@ _SIGS = {
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
 _lib = None
+
+
+def source_build_id():
+    """What ivf_build_id() must return for the sources on disk (same files, same order as iv_slam_amd/csrc/Makefile IDSRCS)."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip"))) + [os.path.join(csrc, "ivf_device.h")] + sorted(glob.glob(os.path.join(inc, "*")))
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def load():
@@ -171,6 +187,12 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        # provenance: a library built from other sources than the ones beside it must not produce a result
+        # (IVFRONT_LIB = an experiment build from tools/, compiled with other flags or sources on purpose: reported, not refused)
+        built, want = lib.ivf_build_id().decode(), source_build_id()
+        if built != want and not os.environ.get("IVFRONT_LIB"):
+            raise ImportError("libivfront.so is stale: built from sources %s, the sources on disk are %s -- rebuild with "
+                              "`make -C iv_slam_amd/csrc` (python -c 'import __graft_entry__ as g; g.build()')" % (built, want))
         _lib = lib
     return _lib
 

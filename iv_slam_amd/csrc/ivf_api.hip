@@ -186,7 +186,8 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
     auto sat = [](float v) { int i = cvRoundF(v); return (unsigned)(unsigned short)std::min(32767, std::max(-32768, i)); };
     for (int l = 1; l < c.nlevels; l++) {
         LevelGeom& D = c.lv[l]; const LevelGeom& S = c.lv[l - 1];
-        const double sx_ = (double)S.w / D.w, sy_ = (double)S.h / D.h;
+        // cv::resize: inv_scale = (double)dsize / ssize, scale = 1. / inv_scale (not the direct quotient: the doubles can differ in the last bit)
+        const double sx_ = 1. / ((double)D.w / S.w), sy_ = 1. / ((double)D.h / S.h);
         D.rtX = (int)tab.size();
         for (int dx = 0; dx < D.w; dx++) {
             float fx = (float)((dx + 0.5) * sx_ - 0.5);
@@ -322,17 +323,38 @@ int Context::check_status(int which)
     return fail(IVF_E_STATE, "batch context %d (run %lld): device-side consistency check failed (flags 0x%x)", which, nRuns - 1, s);
 }
 
-// One growable device scratch per host thread and device: the per-call entry points (ivf_stereo_match, ivf_hamming_pairs,
-// the matchers built on it, ivf_bow_transform, ivf_distinctive_descriptor) upload their inputs here instead of paying a
-// hipMalloc / hipFree set per call; nothing is left to leak on an error path.
+// Growable scratch per host thread: a device buffer (per-call entry points -- ivf_stereo_match, ivf_hamming_pairs, the matchers
+// built on it, ivf_bow_transform, ivf_distinctive_descriptor -- upload their inputs here instead of paying a hipMalloc /
+// hipFree set per call) and a pinned host buffer (row-wise unpacking of pitched device planes).
 // Ordering assumption: every user works on the NULL stream and ends with a BLOCKING copy of its results, so two users on
-// one thread can never overlap in the buffer.  The buffer is deliberately NOT freed by a thread_local destructor: for the
-// main thread that would run during static destruction, possibly after the HIP runtime has gone (it is released when the
-// buffer grows, and with the process).
+// one thread can never overlap in a buffer.
+// Ownership: the buffers live in slots of a process-wide pool.  A thread leases one slot on first use and its thread_local
+// destructor only RETURNS the slot to the pool -- no HIP call at thread exit (for the main thread that would run during
+// static destruction, possibly after the HIP runtime has gone) and no leak either: the reference starts two fresh
+// std::threads per Frame (ORB/src/Frame.cc:116-124), and those now reuse the slots their predecessors gave back instead of
+// pinning ~1 MB each for the life of the process.  The pool itself is never destroyed (freed with the process).
+struct ScratchSlot { int device = -1; uint8_t* buf = nullptr; size_t cap = 0; uint8_t* pin = nullptr; size_t pinCap = 0; };
+struct ScratchPool { std::mutex m; std::vector<ScratchSlot*> idle; int created = 0; };
+ScratchPool& scratch_pool() { static ScratchPool* p = new ScratchPool; return *p; }
+struct ScratchLease {
+    ScratchSlot* s = nullptr;
+    ~ScratchLease() { if (s) { ScratchPool& P = scratch_pool(); std::lock_guard<std::mutex> g(P.m); P.idle.push_back(s); s = nullptr; } }
+};
+ScratchSlot& my_scratch_slot()
+{
+    static thread_local ScratchLease lease;
+    if (!lease.s) {
+        ScratchPool& P = scratch_pool();
+        std::lock_guard<std::mutex> g(P.m);
+        if (!P.idle.empty()) { lease.s = P.idle.back(); P.idle.pop_back(); }
+        else { lease.s = new ScratchSlot; P.created++; }
+    }
+    return *lease.s;
+}
+
 int thread_scratch(int device, size_t need, uint8_t** out)
 {
-    struct Scratch { int device = -1; uint8_t* buf = nullptr; size_t cap = 0; };
-    static thread_local Scratch sc;
+    ScratchSlot& sc = my_scratch_slot();
     if (sc.device != device || sc.cap < need) {
         if (sc.buf) { (void)hipSetDevice(sc.device); (void)hipDeviceSynchronize(); (void)hipFree(sc.buf); sc.buf = nullptr; sc.cap = 0; }
         HIPCHK(hipSetDevice(device));
@@ -344,18 +366,16 @@ int thread_scratch(int device, size_t need, uint8_t** out)
     return IVF_OK;
 }
 
-// growable pinned host scratch per host thread (row-wise unpacking of pitched device planes)
 int thread_pinned(size_t need, uint8_t** out)
 {
-    struct Pin { uint8_t* p = nullptr; size_t cap = 0; };      // not freed at thread exit: see thread_scratch
-    static thread_local Pin pin;
-    if (pin.cap < need) {
-        if (pin.p) { (void)hipHostFree(pin.p); pin.p = nullptr; pin.cap = 0; }
+    ScratchSlot& sc = my_scratch_slot();
+    if (sc.pinCap < need) {
+        if (sc.pin) { (void)hipHostFree(sc.pin); sc.pin = nullptr; sc.pinCap = 0; }
         const size_t cap = std::max(need + need / 2, (size_t)1 << 20);
-        HIPCHK(hipHostMalloc((void**)&pin.p, cap, hipHostMallocDefault));
-        pin.cap = cap;
+        HIPCHK(hipHostMalloc((void**)&sc.pin, cap, hipHostMallocDefault));
+        sc.pinCap = cap;
     }
-    *out = pin.p;
+    *out = sc.pin;
     return IVF_OK;
 }
 
@@ -453,6 +473,7 @@ extern "C" {
 
 int ivf_version(void) { return 100; }
 long long ivf_debug_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
+int ivf_debug_scratch_slots(void) { ScratchPool& P = scratch_pool(); std::lock_guard<std::mutex> g(P.m); return P.created; }
 const char* ivf_last_error(void) { return g_err.c_str(); }
 int ivf_device_count(void)
 {

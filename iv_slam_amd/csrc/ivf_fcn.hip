@@ -2781,6 +2781,27 @@ int make_fused4(ivf_fcn* f, ivf_fcn::Fused4& F, const float* we, const std::vect
     return IVF_OK;
 }
 
+// Dynamic LDS above 64 KB must be reserved per KERNEL (hipFuncAttributeMaxDynamicSharedMemorySize).  Every instantiation of the
+// whole-block kernels is listed here once, at ivf_fcn_create: all k_fcn_irbd2<...> share one function-pointer type, so a flag inside a
+// generic launch lambda would cover only the first instance launched.
+int reserve_lds()
+{
+    struct { const void* fn; size_t lds; const char* name; } ks[] = {
+        {reinterpret_cast<const void*>(&k_fcn_irbd2<32, 32, true, 1>), D2Cfg<32, 32, 1>::LDS, "k_fcn_irbd2<32,32,true,1>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd2<32, 64, false, 1>), D2Cfg<32, 64, 1>::LDS, "k_fcn_irbd2<32,64,false,1>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd2<64, 64, true>), D2Cfg<64, 64>::LDS, "k_fcn_irbd2<64,64,true>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd2<64, 96, false>), D2Cfg<64, 96>::LDS, "k_fcn_irbd2<64,96,false>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd2<96, 96, true>), D2Cfg<96, 96>::LDS, "k_fcn_irbd2<96,96,true>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd2<96, 160, false>), D2Cfg<96, 160>::LDS, "k_fcn_irbd2<96,160,false>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd4<true>), kF4Lds, "k_fcn_irbd4<true>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd4<false>), kF4Lds, "k_fcn_irbd4<false>"},
+    };
+    for (auto& k : ks)
+        if (hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.lds) != hipSuccess)
+            return ffail(IVF_E_NO_DEVICE, "cannot reserve %zu bytes of LDS for %s", k.lds, k.name);
+    return IVF_OK;
+}
+
 // IVF_FCN_DEBUG=1: synchronise and check after every launch, naming the stage that failed
 #define STAGE(name)                                                                                          \
     do { if (dbg) { hipError_t e_ = hipStreamSynchronize(s); if (e_ == hipSuccess) e_ = hipGetLastError();   \
@@ -2857,10 +2878,8 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             const ivf_fcn::Fused4& F = f->f1[i - 4];
             const Gemm& pj = f->pw[ip + 1];
             bool ok = true;
-            auto go = [&](auto kern, size_t lds) {
-                static bool attr = false;
-                if (!attr) { ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess; attr = ok; }
-                if (ok) hipLaunchKernelGGL(kern, dim3(16 * n), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, bk.res ? x : (const float*)nullptr, y);
+            auto go = [&](auto kern, size_t lds) {                                               // LDS reserved per instantiation by reserve_lds()
+                hipLaunchKernelGGL(kern, dim3(16 * n), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, bk.res ? x : (const float*)nullptr, y);
             };
             if (bk.oup == 32 && bk.res) go(&k_fcn_irbd2<32, 32, true, 1>, D2Cfg<32, 32, 1>::LDS);
             else if (bk.oup == 64 && !bk.res) go(&k_fcn_irbd2<32, 64, false, 1>, D2Cfg<32, 64, 1>::LDS);
@@ -2876,10 +2895,8 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             const ivf_fcn::Fused4& F = f->f2[i - 7];
             const Gemm& pj = f->pw[ip + 1];
             bool ok = true;
-            auto go = [&](auto kern, size_t lds) {
-                static bool attr = false;                                                      // one static per instantiation of this lambda
-                if (!attr) { ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess; attr = ok; }
-                if (ok) hipLaunchKernelGGL(kern, dim3(16 * n), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, bk.res ? x : (const float*)nullptr, y);
+            auto go = [&](auto kern, size_t lds) {                                               // LDS reserved per instantiation by reserve_lds()
+                hipLaunchKernelGGL(kern, dim3(16 * n), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, bk.res ? x : (const float*)nullptr, y);
             };
             if (bk.inp == 64 && bk.oup == 64 && bk.res) go(&k_fcn_irbd2<64, 64, true>, D2Cfg<64, 64>::LDS);
             else if (bk.inp == 64 && bk.oup == 96 && !bk.res) go(&k_fcn_irbd2<64, 96, false>, D2Cfg<64, 96>::LDS);
@@ -2896,11 +2913,6 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
         if (fused4 && i >= 14 && f->f4[i - 14].dWE && H == 64 && W == 64) {      // blocks 15-17: one kernel, no hidden tensor in HBM
             const ivf_fcn::Fused4& F = f->f4[i - 14];
             const Gemm& pj = f->pw[ip + 1];
-            static const bool ldsOk = [] {
-                return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_irbd4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF4Lds) == hipSuccess &&
-                       hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_irbd4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF4Lds) == hipSuccess;
-            }();
-            if (!ldsOk) return ffail(IVF_E_NO_DEVICE, "cannot reserve %zu bytes of LDS for k_fcn_irbd4", kF4Lds);
             const bool probe4 = i == 14 && f->probe0[0];
             const int slot4 = (int)(f->probeCount % ivf_fcn::kProbe);
             if (probe4) FHIP(hipEventRecord(f->probe0[slot4], s));
@@ -3014,6 +3026,7 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
         return ffail(IVF_E_NO_DEVICE, "no HIP device available; libivfront has no CPU path");
     if (device_id < 0 || device_id >= ndev) return ffail(IVF_E_INVALID, "device_id %d outside [0,%d)", device_id, ndev);
     FHIP(hipSetDevice(device_id));
+    { const int lrc = reserve_lds(); if (lrc) return lrc; }
     ivf_fcn* f = new ivf_fcn();
     f->device = device_id; f->inW = in_width; f->inH = in_height; f->outW = out_width; f->outH = out_height; f->maxBatch = max_batch;
     Reader rd{weights_blob, n_floats};

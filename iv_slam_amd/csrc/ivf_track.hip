@@ -58,8 +58,12 @@ struct TrackParams {                               // uniform kernel arguments
     float thDepth;                                // > 0: UpdateLastFrame's close-point rule
     float logScale;                               // mfLogScaleFactor = logf(mfScaleFactor) (Frame.cc:106)
     int checkOri, defaultBlocks;
+    int nRecords;                                 // records in the block of THIS call: every index read from a pair / frame table is checked against it
     size_t recBytes;
 };
+// a pair / frame table built for another block (a different world size or batch) must not read outside this one: such an entry
+// gets nmatches = -1, assign = -1 and is otherwise skipped
+DEVINL bool rec_ok(const TrackParams& P, int r) { return (unsigned)r < (unsigned)P.nRecords; }
 
 // gather record: {int32 n; int32 pad[3]; ivf_keypoint kps[nf]; uint8 desc[nf][32]; float uright[nf]; float depth[nf]}
 DEVINL int rec_count(const uint8_t* r, int nf) { const int n = *(const int*)r; return n < 0 ? 0 : (n > nf ? nf : n); }
@@ -206,6 +210,7 @@ __global__ __launch_bounds__(256) void k_track_prepare(TrackParams P, const uint
     __shared__ int s_nStereo, s_nClose;
     const int p = blockIdx.x, tid = threadIdx.x;
     const int2 pr = pairs[p];
+    if (!rec_ok(P, pr.x) || !rec_ok(P, pr.y)) { if (tid == 0) retryFlag[p] = 0; return; }
     const uint8_t* recL = records + (size_t)pr.x * P.recBytes;
     const uint8_t* recC = records + (size_t)pr.y * P.recBytes;
     const int nL = rec_count(recL, P.nf), nC = rec_count(recC, P.nf);
@@ -215,10 +220,11 @@ __global__ __launch_bounds__(256) void k_track_prepare(TrackParams P, const uint
     const ivf_keypoint* kc = rec_kps(recC);
     build_grid(P, kc, nC, gStart + (size_t)p * (kGC * kGR + 1), gIdx + (size_t)p * P.nf, cnt, part, blk, tid);
 
-    // ---- poses: Tcw of the two frames (row-major 3x4), identity when none are given (zero-motion prior)
+    // ---- poses of THIS pair: {LastFrame.mTcw, CurrentFrame.mTcw = mVelocity * mLastFrame.mTcw (Tracking.cc:1311)}, row-major 3x4;
+    //      identity when none are given (zero-motion prior)
     float Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tl[3] = {0, 0, 0}, Rc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tc[3] = {0, 0, 0};
     if (poses) {
-        const float* Tl = poses + (size_t)pr.x * 12; const float* Tc = poses + (size_t)pr.y * 12;
+        const float* Tl = poses + (size_t)p * 24; const float* Tc = Tl + 12;
 #pragma unroll
         for (int i = 0; i < 3; i++) {
 #pragma unroll
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(256) void k_track_window(TrackParams P, const uint8
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (onlyFlagged && !retryFlag[p]) return;
     const int2 pr = pairs[p];
+    if (!rec_ok(P, pr.x) || !rec_ok(P, pr.y)) return;
     const uint8_t* recL = records + (size_t)pr.x * P.recBytes;
     const uint8_t* recC = records + (size_t)pr.y * P.recBytes;
     const int nL = rec_count(recL, P.nf);
@@ -332,7 +339,8 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
                                                     const int* __restrict__ gStart, const unsigned short* __restrict__ gIdx,
                                                     const Query* __restrict__ queries, float th, int* __restrict__ retryFlag,
                                                     int onlyFlagged, int retryBelow, const int* __restrict__ count,
-                                                    const unsigned* __restrict__ lists, int* __restrict__ assignOut,
+                                                    const unsigned* __restrict__ lists, float* __restrict__ pointQuality,
+                                                    float* __restrict__ keyQuality, int* __restrict__ assignOut,
                                                     int* __restrict__ nmatchesOut)
 {
     extern __shared__ int s_mem[];
@@ -343,6 +351,11 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
     float* s_ang = (float*)(s_mem + 2 * P.nf);                // [nf] CurrentFrame.mvKeysUn[].angle
     unsigned* s_match = (unsigned*)(s_mem + 3 * P.nf);        // [nf] matches in the order they were made: idx2 | bin << 16
     const int2 pr = pairs[p];
+    if (!rec_ok(P, pr.x) || !rec_ok(P, pr.y)) {
+        for (int i = lane; i < P.nf; i += 64) assignOut[(size_t)p * P.nf + i] = -1;
+        if (lane == 0) { nmatchesOut[p] = -1; retryFlag[p] = 0; }
+        return;
+    }
     const uint8_t* recL = records + (size_t)pr.x * P.recBytes;
     const uint8_t* recC = records + (size_t)pr.y * P.recBytes;
     const int nL = rec_count(recL, P.nf), nC = rec_count(recC, P.nf);
@@ -479,6 +492,21 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
     }
     int* out = assignOut + (size_t)p * P.nf;
     for (int i = lane; i < P.nf; i += 64) { const int a = i < nC ? s_assign[i] : -1; out[i] = a < 0 ? -1 : (a & 0xffff); }
+    if (pointQuality && keyQuality) {
+        // ORBmatcher::UpdateQualityScores(CurrentFrame) at the end of EVERY SearchByProjection call (:1108-1121, :1513-1515; the
+        // retry is a second call and updates again from what the first left).  A last-frame point ends on at most one current
+        // keypoint, so the sequential loop of the reference has no cross-iteration dependence here: one lane per keypoint.
+        float* pq = pointQuality + (size_t)p * P.nf;
+        float* kq = keyQuality + (size_t)p * P.nf;
+        for (int i = lane; i < nC; i += 64) {
+            const int a = s_assign[i];
+            if (a < 0) continue;
+            const int m = a & 0xffff;
+            const float mq = pq[m], upd = fminf(mq, kq[i]);
+            if (fabsf(upd - mq) > 0.01f) pq[m] = upd;                                  // kDeltaThresh
+            kq[i] = upd;
+        }
+    }
     if (lane == 0) {
         nmatchesOut[p] = nm;
         retryFlag[p] = (!onlyFlagged && nm < retryBelow) ? 1 : 0;                      // Tracking.cc:1320
@@ -532,13 +560,14 @@ __global__ __launch_bounds__(256) void k_local_prepare(TrackParams P, const uint
     __shared__ int blk[256];
     const int f = blockIdx.x, tid = threadIdx.x;
     const int ri = frames[f];
+    if (!rec_ok(P, ri) || offsets[f + 1] < offsets[f] || offsets[f] < 0) return;
     const uint8_t* recC = records + (size_t)ri * P.recBytes;
     const int nC = rec_count(recC, P.nf);
     build_grid(P, rec_kps(recC), nC, gStart + (size_t)f * (kGC * kGR + 1), gIdx + (size_t)f * P.nf, cnt, part, blk, tid);
 
     float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0}, Ow[3];
     if (poses) {
-        const float* T = poses + (size_t)ri * 12;
+        const float* T = poses + (size_t)f * 12;                                          // the pose of frame SLOT f (a record may appear in two slots)
 #pragma unroll
         for (int i = 0; i < 3; i++) {
 #pragma unroll
@@ -597,7 +626,7 @@ __global__ __launch_bounds__(256) void k_local_window(TrackParams P, const uint8
     const int f = blockIdx.y;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int m0 = offsets[f], M = min(offsets[f + 1] - m0, maxM);
-    if (m >= M) return;
+    if (m >= M || m0 < 0 || !rec_ok(P, frames[f])) return;
     const uint8_t* recC = records + (size_t)frames[f] * P.recBytes;
     const Query q = queries[(size_t)f * maxM + m];
     int total = 0;
@@ -645,11 +674,17 @@ __global__ __launch_bounds__(64) void k_local_greedy(TrackParams P, const uint8_
                                                     const int* __restrict__ gStart, const unsigned short* __restrict__ gIdx,
                                                     const Query* __restrict__ queries, const float* __restrict__ radii,
                                                     const uint8_t* __restrict__ occupied, float nnRatio, const int* __restrict__ count,
-                                                    const unsigned* __restrict__ lists, int* __restrict__ assignOut,
+                                                    const unsigned* __restrict__ lists, float* __restrict__ pointQuality,
+                                                    float* __restrict__ keyQuality, int* __restrict__ assignOut,
                                                     int* __restrict__ nmatchesOut)
 {
     extern __shared__ int s_mem[];
     const int f = blockIdx.x, lane = threadIdx.x;
+    if (!rec_ok(P, frames[f]) || offsets[f + 1] < offsets[f] || offsets[f] < 0) {
+        for (int i = lane; i < P.nf; i += 64) assignOut[(size_t)f * P.nf + i] = -1;
+        if (lane == 0) nmatchesOut[f] = -1;
+        return;
+    }
     int* s_assign = s_mem;                                    // [nf]: -1 free, -2 held by a point with observations before the call,
                                                               // >= 0 local point index (| kLocalNoBlock) assigned by this call
     const uint8_t* recC = records + (size_t)frames[f] * P.recBytes;
@@ -741,6 +776,21 @@ __global__ __launch_bounds__(64) void k_local_greedy(TrackParams P, const uint8_
     __builtin_amdgcn_wave_barrier();
     int* out = assignOut + (size_t)f * P.nf;
     for (int i = lane; i < P.nf; i += 64) { const int a = i < nC ? s_assign[i] : -1; out[i] = a < 0 ? -1 : (a & ~kLocalNoBlock); }
+    if (pointQuality && keyQuality) {
+        // UpdateQualityScores(F) (:128-132, :1108-1121) for the keypoints that received a point in THIS call (a map point ends on at
+        // most one keypoint: no cross-iteration dependence).  Keypoints that held a point before the call went through the same
+        // update at the end of the search that gave it to them, and the update is idempotent: min(q_mp, q_kp) == q_kp afterwards.
+        float* pq = pointQuality + m0;
+        float* kq = keyQuality + (size_t)f * P.nf;
+        for (int i = lane; i < nC; i += 64) {
+            const int a = s_assign[i];
+            if (a < 0) continue;
+            const int m = a & ~kLocalNoBlock;
+            const float mq = pq[m], upd = fminf(mq, kq[i]);
+            if (fabsf(upd - mq) > 0.01f) pq[m] = upd;
+            kq[i] = upd;
+        }
+    }
     if (lane == 0) nmatchesOut[f] = nm;
 }
 
@@ -828,7 +878,8 @@ int ivf_tracker_create(const ivf_track_config* cfg, ivf_tracker** out)
 }
 
 int ivf_tracker_run(ivf_tracker* t, const uint8_t* d_records, size_t record_bytes, int n_records, const int32_t* d_pairs, int n_pairs,
-                    const float* d_poses, const uint8_t* d_point_flags, int32_t* d_assign, int32_t* d_nmatches, void* hip_stream)
+                    const float* d_poses, const uint8_t* d_point_flags, float* d_point_quality, float* d_key_quality,
+                    int32_t* d_assign, int32_t* d_nmatches, void* hip_stream)
 {
     if (!t || !d_records || !d_pairs || !d_assign || !d_nmatches) return fail(IVF_E_INVALID, "null argument");
     if (record_bytes != t->P.recBytes) return fail(IVF_E_INVALID, "record_bytes %zu: records of %d features are %zu bytes", record_bytes, t->P.nf, t->P.recBytes);
@@ -837,8 +888,10 @@ int ivf_tracker_run(ivf_tracker* t, const uint8_t* d_records, size_t record_byte
     if (n_pairs == 0) return IVF_OK;
     if (n_pairs < 0 || n_pairs > t->cfg.max_pairs) return fail(IVF_E_INVALID, "n_pairs %d outside [0,%d]", n_pairs, t->cfg.max_pairs);
     HIPCHK(hipSetDevice(t->cfg.device_id));
+    if ((d_point_quality == nullptr) != (d_key_quality == nullptr)) return fail(IVF_E_INVALID, "d_point_quality and d_key_quality come together");
     hipStream_t st = (hipStream_t)hip_stream;
-    const TrackParams& P = t->P;
+    TrackParams P = t->P;
+    P.nRecords = n_records;
     const int2* pairs = (const int2*)d_pairs;
     // the per-pair grids, query tables and candidate lists are scratch of the HANDLE: a run enqueued on another stream than the
     // previous one queues behind it (use one tracker per stream to let runs overlap)
@@ -849,7 +902,7 @@ int ivf_tracker_run(ivf_tracker* t, const uint8_t* d_records, size_t record_byte
         const float th = pass ? t->cfg.th_retry : t->cfg.th;
         hipLaunchKernelGGL(k_track_window, wg, dim3(256), 0, st, P, d_records, pairs, t->dStart, t->dIdx, t->dQ, th, t->dRetry, pass, t->dCount, t->dLists);
         hipLaunchKernelGGL(k_track_greedy, dim3(n_pairs), dim3(64), t->ldsBytes, st, P, d_records, pairs, t->dStart, t->dIdx, t->dQ, th, t->dRetry, pass,
-                           t->cfg.retry_below, t->dCount, t->dLists, d_assign, d_nmatches);
+                           t->cfg.retry_below, t->dCount, t->dLists, d_point_quality, d_key_quality, d_assign, d_nmatches);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(t->evDone, st));
@@ -859,8 +912,8 @@ int ivf_tracker_run(ivf_tracker* t, const uint8_t* d_records, size_t record_byte
 
 int ivf_tracker_search_local(ivf_tracker* t, const uint8_t* d_records, size_t record_bytes, int n_records, const int32_t* d_frames, int n_frames,
                              const float* d_poses, const ivf_local_point* d_points, const int32_t* d_point_offsets, int max_points_per_frame,
-                             const uint8_t* d_occupied, float th, float nn_ratio, float cos_limit, int32_t* d_assign, int32_t* d_nmatches,
-                             void* hip_stream)
+                             const uint8_t* d_occupied, float th, float nn_ratio, float cos_limit, float* d_point_quality, float* d_key_quality,
+                             int32_t* d_assign, int32_t* d_nmatches, void* hip_stream)
 {
     if (!t || !d_records || !d_frames || !d_points || !d_point_offsets || !d_assign || !d_nmatches) return fail(IVF_E_INVALID, "null argument");
     if (record_bytes != t->P.recBytes) return fail(IVF_E_INVALID, "record_bytes %zu: records of %d features are %zu bytes", record_bytes, t->P.nf, t->P.recBytes);
@@ -870,6 +923,7 @@ int ivf_tracker_search_local(ivf_tracker* t, const uint8_t* d_records, size_t re
     if (n_frames < 0 || n_frames > t->cfg.max_pairs) return fail(IVF_E_INVALID, "n_frames %d outside [0,%d]", n_frames, t->cfg.max_pairs);
     if (max_points_per_frame < 1 || max_points_per_frame >= kLocalNoBlock) return fail(IVF_E_INVALID, "max_points_per_frame %d out of range", max_points_per_frame);
     if (!(th > 0) || !(nn_ratio > 0)) return fail(IVF_E_INVALID, "th and nn_ratio must be positive");
+    if ((d_point_quality == nullptr) != (d_key_quality == nullptr)) return fail(IVF_E_INVALID, "d_point_quality and d_key_quality come together");
     HIPCHK(hipSetDevice(t->cfg.device_id));
     hipStream_t st = (hipStream_t)hip_stream;
     if (t->ran) HIPCHK(hipStreamWaitEvent(st, t->evDone, 0));                          // the handle's scratch belongs to one call at a time
@@ -889,14 +943,16 @@ int ivf_tracker_search_local(ivf_tracker* t, const uint8_t* d_records, size_t re
         }
         t->localCap = max_points_per_frame;
     }
-    const TrackParams& P = t->P;
+    TrackParams P = t->P;
+    P.nRecords = n_records;
     const int M = max_points_per_frame;
     hipLaunchKernelGGL(k_local_prepare, dim3(n_frames), dim3(256), 0, st, P, d_records, d_frames, d_poses, d_points, d_point_offsets, th, cos_limit, M,
                        t->dStart, t->dIdx, t->dLQ, t->dLRad);
     hipLaunchKernelGGL(k_local_window, dim3((M + 3) / 4, n_frames), dim3(256), 0, st, P, d_records, d_frames, d_points, d_point_offsets, M,
                        t->dStart, t->dIdx, t->dLQ, t->dLRad, t->dLCount, t->dLLists);
     hipLaunchKernelGGL(k_local_greedy, dim3(n_frames), dim3(64), (size_t)P.nf * 4, st, P, d_records, d_frames, d_points, d_point_offsets, M,
-                       t->dStart, t->dIdx, t->dLQ, t->dLRad, d_occupied, nn_ratio, t->dLCount, t->dLLists, d_assign, d_nmatches);
+                       t->dStart, t->dIdx, t->dLQ, t->dLRad, d_occupied, nn_ratio, t->dLCount, t->dLLists, d_point_quality, d_key_quality,
+                       d_assign, d_nmatches);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(t->evDone, st));
     t->ran = true;

@@ -132,6 +132,12 @@ float orc_logf(float x)
  *   blur   0: [18,34,48,56,48,34,18]/256 (error-diffused fixed point)   1: cvRound(k*256) = [18,34,49,55,49,34,18] (<= 3.4.1)
  *   retain 0: nth_element(begin, begin + n - 1, end)                    1: nth_element(begin, begin + n, end) (2.4 / 3.x)
  *   atan   0: degree-7 polynomial (2.4.4+, 3.x, 4.x)                    1: x*y/(x^2 + 0.28 y^2) rational form (<= 2.4.3) */
+#ifndef ORC_BUILD_ID
+#define ORC_BUILD_ID "unstamped"
+#endif
+/* build provenance: hash of the checker's sources at compile time (oracle/Makefile); tests/oracle_lib.py compares it with the sources on disk */
+const char* orc_build_id(void) { return ORC_BUILD_ID; }
+
 static int g_var_blur = 0, g_var_retain = 0, g_var_atan = 0;
 void orc_set_opencv_variant(int blur, int retain, int atan) { g_var_blur = blur; g_var_retain = retain; g_var_atan = atan; }
 
@@ -283,9 +289,30 @@ static inline short sat_short_round(float v)
     int i = orc_cv_round_f(v);
     return (short)(i < -32768 ? -32768 : i > 32767 ? 32767 : i);
 }
+/* cv::resize with dsize given computes inv_scale = (double)dsize / ssize and then scale = 1. / inv_scale (imgproc/src/resize.cpp,
+ * cv::resize + hal::resize): NOT (double)ssize / dsize -- the two doubles differ in the last bit for some (ssize, dsize). */
+static inline double resize_scale(int ssize, int dsize) { const double inv_scale = (double)dsize / ssize; return 1. / inv_scale; }
+
+/* KAT hook (tests/test_oracle_primitives.py): number of destination indices of a ssize -> dsize axis whose (floor, 11-bit
+ * coefficient pair) differ between OpenCV's scale = 1. / ((double)dsize / ssize) and the direct quotient (double)ssize / dsize
+ * that rounds 1-3 of this repository used.  0 for every pair the pyramid can produce => goldens and fixtures of those rounds stand. */
+int orc_resize_coef_mismatches(int ssize, int dsize)
+{
+    const double s0 = resize_scale(ssize, dsize), s1 = (double)ssize / dsize;
+    int bad = 0;
+    for (int d = 0; d < dsize; d++) {
+        float f0 = (float)((d + 0.5) * s0 - 0.5), f1 = (float)((d + 0.5) * s1 - 0.5);
+        const int i0 = cv_floor_f(f0), i1 = cv_floor_f(f1);
+        f0 -= i0; f1 -= i1;
+        if (i0 != i1 || orc_cv_round_f((1.f - f0) * 2048.f) != orc_cv_round_f((1.f - f1) * 2048.f) ||
+            orc_cv_round_f(f0 * 2048.f) != orc_cv_round_f(f1 * 2048.f)) bad++;
+    }
+    return bad;
+}
+
 void orc_resize_linear_8u(const uint8_t* src, int sstride, int sw, int sh, uint8_t* dst, int dstride, int dw, int dh)
 {
-    double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    double scale_x = resize_scale(sw, dw), scale_y = resize_scale(sh, dh);
     int* xofs = (int*)malloc(sizeof(int) * dw);
     short* alpha = (short*)malloc(sizeof(short) * 2 * dw);
     int* row0 = (int*)malloc(sizeof(int) * dw);

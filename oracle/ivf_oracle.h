@@ -50,6 +50,7 @@ typedef struct orc_extractor orc_extractor;
 /* ---- frozen primitives (Appendix A of SURVEY.md) ---- */
 int   orc_cv_round_f(float v);
 int   orc_cv_round_d(double v);
+const char* orc_build_id(void);   /* sha256[:16] of the checker's sources at build time (oracle/Makefile) */
 /* OpenCV-version switches (process-wide; 0,0,0 = OpenCV >= 3.4.2 / 4.x, the default): see ivf_oracle.c */
 void  orc_set_opencv_variant(int blur, int retain, int atan);
 float orc_fast_atan2(float y, float x);
@@ -64,6 +65,8 @@ int   orc_fast_detect(const uint8_t* img, int stride, int cols, int rows, int th
                       orc_keypoint* out, int cap);
 void  orc_resize_linear_8u(const uint8_t* src, int sstride, int sw, int sh,
                            uint8_t* dst, int dstride, int dw, int dh);
+/* KAT hook: destination indices whose bilinear (offset, coefficient) triple differs between OpenCV's 1. / ((double)d / s) and (double)s / d */
+int   orc_resize_coef_mismatches(int ssize, int dsize);
 void  orc_gauss7_8u(const uint8_t* src, int sstride, int w, int h, uint8_t* dst, int dstride);
 /* libstdc++ std::nth_element(first, first+nth, first+n, response-greater) restated */
 void  orc_nth_element_resp(orc_keypoint* v, int n, int nth);

@@ -394,9 +394,11 @@ def update_last_frame_points(last, th_depth):
 
 
 def track_with_motion_model_matches(O, cur, last, th, th_retry, retry_below, check_orientation=True, th_depth=0.0, points_block=True,
-                                    point_flags=None):
+                                    point_flags=None, quality=None):
     """(nmatches, CurrentFrame.mvpMapPoints as last-frame keypoint indices or -1) of the matcher part of TrackWithMotionModel.
-    point_flags (per last keypoint: bit 0 = has a map point, bit 1 = Observations() > 0) overrides th_depth / points_block."""
+    point_flags (per last keypoint: bit 0 = has a map point, bit 1 = Observations() > 0) overrides th_depth / points_block.
+    quality = (point_q per LAST keypoint, key_q per CURRENT keypoint), float32 arrays updated IN PLACE the way every
+    SearchByProjection call ends under --ivslam_propagate_keyptqual (ORBmatcher.cc:1513-1515 -> UpdateQualityScores, :1108-1121)."""
     if point_flags is not None:
         sel = [i for i in range(len(last["kps"])) if last["depth"][i] > 0 and (int(point_flags[i]) & 1)]
         obs = {i: (int(point_flags[i]) >> 1) & 1 for i in sel}
@@ -415,9 +417,16 @@ def track_with_motion_model_matches(O, cur, last, th, th_retry, retry_below, che
         if check_orientation:
             return search_cur_last(O, cur, lm, pool, cur_mps, th_, False)
         return _search_cur_last_no_ori(O, cur, lm, pool, cur_mps, th_)
+    def propagate(out_):
+        if quality is not None:
+            pq, kq = quality
+            kq2, pq2 = update_quality_scores([sel[m] if m >= 0 else -1 for m in out_], kq, pq)
+            kq[:] = kq2; pq[:] = pq2
     nm, out = one(th)
+    propagate(out)
     if nm < retry_below:                                                               # Tracking.cc:1320-1330
         nm, out = one(th_retry)
+        propagate(out)
     return nm, np.array([sel[m] if m >= 0 else -1 for m in out], np.int32)
 
 

@@ -34,9 +34,24 @@ def _build():
     return so, pin
 
 
+def source_build_id():
+    """What orc_build_id() must return for the checker sources on disk (same files and order as oracle/Makefile IDSRCS)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("ivf_oracle.c", "ivf_oracle.h", "stl_pin.cpp", os.path.join("..", "include", "ivf_pattern31.inc")):
+        with open(os.path.join(ORACLE_DIR, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 _so, _pin = _build()
 lib = C.CDLL(_so)
 pin = C.CDLL(_pin)
+lib.orc_build_id.restype = C.c_char_p; lib.orc_build_id.argtypes = []
+BUILD_ID = lib.orc_build_id().decode()
+if BUILD_ID != source_build_id():
+    raise ImportError("oracle library %s is stale: built from sources %s, the sources on disk are %s -- rebuild with `make -C oracle`"
+                      % (_so, BUILD_ID, source_build_id()))
 
 u8p = C.POINTER(C.c_uint8)
 f32p = C.POINTER(C.c_float)

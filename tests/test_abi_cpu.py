@@ -27,6 +27,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.ivf_version() >= 100
 
 
+def test_build_provenance_is_checked_on_load(monkeypatch):
+    """ivf_build_id() = sha256[:16] of the sources the library was linked from; load() refuses a library whose id differs from the
+    sources beside it, so a stale .so can produce neither a test result nor a bench line.  Same for the oracle checker."""
+    from iv_slam_amd import _lib
+    lib = _lib.load()
+    assert lib.ivf_build_id().decode() == _lib.source_build_id() and len(_lib.source_build_id()) == 16
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "source_build_id", lambda: "0123456789abcdef")
+    monkeypatch.delenv("IVFRONT_LIB", raising=False)
+    with pytest.raises(ImportError, match="stale"):
+        _lib.load()
+    import oracle_lib as O
+    assert O.BUILD_ID == O.source_build_id() and O.BUILD_ID != "unstamped"
+
+
 def test_struct_layouts_match_header():
     from iv_slam_amd import _lib
     assert _lib.KP_DTYPE.itemsize == 24 and C.sizeof(_lib.ExtractorParams) == 24

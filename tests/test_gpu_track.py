@@ -29,7 +29,7 @@ def iv():
 def scale_table(nlevels=8, sf=1.2):
     s = [F(1.0)]
     for _ in range(1, nlevels):
-        s.append(F(np.float64(s[-1]) * np.float64(sf)))                    # ORBextractor.cc:419-425
+        s.append(F(np.float64(s[-1]) * np.float64(F(sf))))                 # ORBextractor.cc:419-425: scaleFactor = (double)(float)1.2
     return np.array(s, F)
 
 
@@ -46,8 +46,20 @@ def frame_dict(rec, T, cam):
                 fy=cam["fy"], cx=cam["cx"], cy=cam["cy"], mbf=cam["bf"], mb=cam["b"], bounds=cam["bounds"])
 
 
-def run_tracker(iv, cam, recs, pairs, poses=None, flags=None, **kw):
-    """recs: list of dict(kps, desc, uright, depth) -> (assign [n_pairs, nf], nmatches [n_pairs]) from the device."""
+def pair_poses(poses, pairs):
+    """poses: None, a list per RECORD (pair (a, b) then carries (poses[a], poses[b])) or a list per PAIR of (T_last, T_cur)
+    -> list per pair of (T_last, T_cur): the layout of ivf_tracker_run's d_poses [n_pairs][2][12]."""
+    if poses is None:
+        return None
+    if isinstance(poses[0], tuple):
+        assert len(poses) == len(pairs)
+        return list(poses)
+    return [(poses[a], poses[b]) for a, b in pairs]
+
+
+def run_tracker(iv, cam, recs, pairs, poses=None, flags=None, quality=None, **kw):
+    """recs: list of dict(kps, desc, uright, depth) -> (assign [n_pairs, nf], nmatches [n_pairs]) from the device.
+    quality = (point_q [n_pairs, nf], key_q [n_pairs, nf]) float32: updated on the device, returned as two more arrays."""
     import torch
     from iv_slam_amd import dist as ivd
     nf = cam["nf"]
@@ -58,27 +70,41 @@ def run_tracker(iv, cam, recs, pairs, poses=None, flags=None, **kw):
     assert tr.record_bytes == ivd.record_bytes(nf)
     dp = torch.tensor(pairs, dtype=torch.int32, device=dev).reshape(-1, 2)
     assign = torch.full((len(pairs), nf), -7, dtype=torch.int32, device=dev); nm = torch.full((len(pairs),), -7, dtype=torch.int32, device=dev)
-    dposes = None if poses is None else torch.from_numpy(np.stack([p[:3, :4].reshape(12) for p in poses]).astype(F)).to(dev)
+    pp = pair_poses(poses, pairs)
+    dposes = None if pp is None else torch.from_numpy(np.stack([np.stack([tl[:3, :4].reshape(12), tc[:3, :4].reshape(12)]) for tl, tc in pp]).astype(F)).to(dev)
     dflags = None
     if flags is not None:
         fl = np.zeros((len(recs), nf), np.uint8)
         for i, f in enumerate(flags):
             fl[i, :len(f)] = f
         dflags = torch.from_numpy(fl).to(dev)
-    tr.run(block, dp, assign, nm, poses=dposes, point_flags=dflags)
+    dpq = dkq = None
+    if quality is not None:
+        dpq = torch.from_numpy(np.ascontiguousarray(quality[0], F)).to(dev); dkq = torch.from_numpy(np.ascontiguousarray(quality[1], F)).to(dev)
+    tr.run(block, dp, assign, nm, poses=dposes, point_flags=dflags, point_quality=dpq, key_quality=dkq)
     torch.cuda.synchronize()
+    if quality is not None:
+        return assign.cpu().numpy(), nm.cpu().numpy(), dpq.cpu().numpy(), dkq.cpu().numpy()
     return assign.cpu().numpy(), nm.cpu().numpy()
 
 
 def check_pairs(cam, recs, pairs, got_assign, got_nm, poses=None, flags=None, th=7.0, th_retry=None, retry_below=20,
-                check_orientation=True, th_depth=0.0, points_block=True, what=""):
+                check_orientation=True, th_depth=0.0, points_block=True, what="", quality=None, got_quality=None):
     import projection_oracle as PO
     I = np.eye(4, dtype=F)
     total = 0
+    pp = pair_poses(poses, pairs)
     for k, (a, b) in enumerate(pairs):
-        last = frame_dict(recs[a], I if poses is None else poses[a], cam); cur = frame_dict(recs[b], I if poses is None else poses[b], cam)
+        last = frame_dict(recs[a], I if pp is None else pp[k][0], cam); cur = frame_dict(recs[b], I if pp is None else pp[k][1], cam)
+        q = None
+        if quality is not None:
+            q = (np.array(quality[0][k], F), np.array(quality[1][k], F))
         nm, exp = PO.track_with_motion_model_matches(O, cur, last, F(th), F(2 * th if th_retry is None else th_retry), retry_below,
-                                                     check_orientation, th_depth, points_block, None if flags is None else flags[a])
+                                                     check_orientation, th_depth, points_block, None if flags is None else flags[a], quality=q)
+        if q is not None:
+            nL = len(last["kps"])
+            assert got_quality[0][k].tobytes() == q[0].tobytes(), "%s pair %d: map-point quality differs at %r" % (what, k, np.nonzero(got_quality[0][k] != q[0])[0][:8])
+            assert got_quality[1][k].tobytes() == q[1].tobytes(), "%s pair %d: mvKeyQualScore differs at %r" % (what, k, np.nonzero(got_quality[1][k] != q[1])[0][:8])
         nC = len(cur["kps"])
         assert got_nm[k] == nm, "%s pair %d (%d -> %d): nmatches %d vs oracle %d" % (what, k, a, b, got_nm[k], nm)
         assert np.array_equal(got_assign[k, :nC], exp), "%s pair %d: assignment differs at %r" % (what, k, np.nonzero(got_assign[k, :nC] != exp)[0][:8])
@@ -147,6 +173,56 @@ def test_poses_forward_backward_and_flags(iv):
                    (dict(th=7.0), flags)):
         a, nm = run_tracker(iv, cam, recs, pairs, poses=poses, flags=fl, **kw)
         check_pairs(cam, recs, pairs, a, nm, poses=poses, flags=fl, what=str(kw), **kw)
+
+
+def test_per_pair_poses_prior_and_optimised(iv):
+    """INTEGRATION.md's example: d_poses[p] = {Tcw_last (optimised), Tcw_cur (motion-model prior)}.  Frame k is "cur" in pair
+    (k-1, k) under its PRIOR and "last" in pair (k, k+1) under its OPTIMISED pose -- two different poses for one record in one
+    call, which a per-record pose table could not express (ORB/src/Tracking.cc:1303-1311)."""
+    cam, recs, _, _ = extracted_sequence(iv, 640, 240, 500, 5, seed=93, shift=2)
+    opt = [pose(0.03 * k, [0.02 * k, 0.0, -0.25 * k]) for k in range(5)]
+    pri = [pose(0.03 * k + 0.02, [0.02 * k + 0.01, 0.005, -0.25 * k - 0.07]) for k in range(5)]
+    pairs = [(k - 1, k) for k in range(1, 5)]
+    pp = [(opt[a], pri[b]) for a, b in pairs]
+    a, nm = run_tracker(iv, cam, recs, pairs, poses=pp, th=7.0)
+    tot = check_pairs(cam, recs, pairs, a, nm, poses=pp, th=7.0, what="per-pair poses")
+    assert tot > 200
+    # and it matters: with the priors replaced by the optimised poses at least one pair matches differently
+    a2, nm2 = run_tracker(iv, cam, recs, pairs, poses=[(opt[x], opt[y]) for x, y in pairs], th=7.0)
+    assert not np.array_equal(a, a2)
+
+
+def test_quality_propagation_on_the_device(iv):
+    """--ivslam_propagate_keyptqual: UpdateQualityScores(CurrentFrame) at the end of every SearchByProjection call
+    (ORB/src/ORBmatcher.cc:1108-1121, :1513-1515) inside the batched tracker, incl. the second update of a retried pair."""
+    cam, recs, _, _ = extracted_sequence(iv, 640, 240, 500, 5, seed=94, shift=2)
+    pairs = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 3), (4, 4)]
+    rng = np.random.default_rng(11)
+    nf = cam["nf"]
+    # scores on a 0.004 lattice around each other: differences on both sides of kDeltaThresh = 0.01, exact ties included
+    pq = (rng.integers(0, 250, (len(pairs), nf)) * F(0.004)).astype(F); kq = (rng.integers(0, 250, (len(pairs), nf)) * F(0.004)).astype(F)
+    close = rng.uniform(size=pq.shape) < 0.5
+    kq[close] = (pq[close] + rng.integers(-4, 5, int(close.sum())) * F(0.004)).astype(F)
+    for kw in (dict(th=7.0), dict(th=3.0, retry_below=1000, th_retry=9.0), dict(th=7.0, points_block=False)):
+        a, nm, gpq, gkq = run_tracker(iv, cam, recs, pairs, quality=(pq, kq), **kw)
+        check_pairs(cam, recs, pairs, a, nm, what="quality %r" % kw, quality=(pq, kq), got_quality=(gpq, gkq), **kw)
+        assert (gkq != kq).any() and (gpq != pq).any()
+    # without matches nothing moves; padding beyond the keypoint count is never touched
+    a, nm, gpq, gkq = run_tracker(iv, cam, recs, [(4, 4)], quality=(pq[:1], kq[:1]), th=7.0, check_orientation=False)
+    n4 = len(recs[4]["kps"])
+    assert np.array_equal(gkq[0, n4:], kq[0, n4:])
+
+
+def test_pair_table_outside_the_block_is_refused_per_pair(iv):
+    """a pair table built for another block (more records) must not read outside this one: nmatches = -1, assign = -1 for
+    those pairs, the valid ones unaffected."""
+    cam, recs, _, _ = extracted_sequence(iv, 640, 240, 500, 3, seed=95, shift=2)
+    pairs = [(0, 1), (1, 7), (-1, 2), (1, 2), (3, 0)]
+    a, nm = run_tracker(iv, cam, recs, pairs, th=7.0)
+    good = [0, 3]
+    check_pairs(cam, recs, [pairs[k] for k in good], a[good], nm[good], th=7.0, what="valid pairs beside invalid ones")
+    for k in (1, 2, 4):
+        assert nm[k] == -1 and (a[k] == -1).all()
 
 
 def _random_records(rng, nf, n_frames, w, h, cluster):

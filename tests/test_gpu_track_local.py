@@ -70,7 +70,9 @@ def pack_points(iv, per_frame):
     return a, np.array(off, np.int32)
 
 
-def run_local(iv, cam, recs, frames, per_frame, poses, occupied, th, nn_ratio, max_points=None, cos_limit=0.5, tracker=None):
+def run_local(iv, cam, recs, frames, per_frame, poses, occupied, th, nn_ratio, max_points=None, cos_limit=0.5, tracker=None, quality=None):
+    """poses: list per RECORD (the test's world) -> uploaded per frame SLOT, the layout of ivf_tracker_search_local's d_poses.
+    quality = (point_q flat like the packed points, key_q [n_frames, nf]): updated on the device and returned as two more arrays."""
     import torch
     from iv_slam_amd import dist as ivd
     nf = cam["nf"]
@@ -83,7 +85,7 @@ def run_local(iv, cam, recs, frames, per_frame, poses, occupied, th, nn_ratio, m
     dpts = torch.from_numpy(pts.view(np.uint8).reshape(-1)).to(dev)
     doff = torch.from_numpy(off).to(dev)
     dfr = torch.tensor(frames, dtype=torch.int32, device=dev)
-    dposes = None if poses is None else torch.from_numpy(np.stack([p[:3, :4].reshape(12) for p in poses]).astype(F)).to(dev)
+    dposes = None if poses is None else torch.from_numpy(np.stack([poses[ri][:3, :4].reshape(12) for ri in frames]).astype(F)).to(dev)
     docc = None
     if occupied is not None:
         oc = np.zeros((len(frames), nf), np.uint8)
@@ -91,8 +93,14 @@ def run_local(iv, cam, recs, frames, per_frame, poses, occupied, th, nn_ratio, m
             oc[i, :len(o)] = o
         docc = torch.from_numpy(oc).to(dev)
     assign = torch.full((len(frames), nf), -7, dtype=torch.int32, device=dev); nm = torch.full((len(frames),), -7, dtype=torch.int32, device=dev)
-    tr.search_local(block, dfr, dpts, doff, M, assign, nm, poses=dposes, occupied=docc, th=th, nn_ratio=nn_ratio, cos_limit=cos_limit)
+    dpq = dkq = None
+    if quality is not None:
+        dpq = torch.from_numpy(np.ascontiguousarray(quality[0], F)).to(dev); dkq = torch.from_numpy(np.ascontiguousarray(quality[1], F)).to(dev)
+    tr.search_local(block, dfr, dpts, doff, M, assign, nm, poses=dposes, occupied=docc, th=th, nn_ratio=nn_ratio, cos_limit=cos_limit,
+                    point_quality=dpq, key_quality=dkq)
     torch.cuda.synchronize()
+    if quality is not None:
+        return assign.cpu().numpy(), nm.cpu().numpy(), dpq.cpu().numpy(), dkq.cpu().numpy()
     return assign.cpu().numpy(), nm.cpu().numpy()
 
 
@@ -161,6 +169,56 @@ def test_local_points_with_poses_and_truncation(iv):
     cap = min(len(p) for p in per_frame if p) // 2
     a, nm = run_local(iv, cam, recs, frames, per_frame, poses, None, 1.0, 0.8, max_points=cap, cos_limit=0.8)
     check_local(cam, recs, frames, per_frame, poses, None, 1.0, 0.8, a, nm, max_points=cap, cos_limit=0.8, what="truncated")
+
+
+def test_local_points_quality_propagation_on_the_device(iv):
+    """--ivslam_propagate_keyptqual: UpdateQualityScores(F) at the end of SearchByProjection(F, vpMapPoints, th)
+    (ORB/src/ORBmatcher.cc:128-132, :1108-1121) for the keypoints that received a point in the call, on the device."""
+    import projection_oracle as PO
+    cam, recs, _, _ = extracted_sequence(iv, 640, 240, 500, 4, seed=192, shift=2)
+    rng = np.random.default_rng(17)
+    I = np.eye(4, dtype=F)
+    frames = [1, 2, 3, 0]
+    per_frame = [map_points_from(cam, recs[s], I, rng) for s in (0, 1, 2, 0)]
+    off = np.cumsum([0] + [len(p) for p in per_frame])
+    nf = cam["nf"]
+    pq = (rng.integers(0, 250, int(off[-1])) * F(0.004)).astype(F); kq = (rng.integers(0, 250, (len(frames), nf)) * F(0.004)).astype(F)
+    occ = [rng.random(len(recs[f]["kps"])) < 0.1 for f in frames]
+    a, nm, gpq, gkq = run_local(iv, cam, recs, frames, per_frame, None, occ, 3.0, 0.8, quality=(pq, kq))
+    check_local(cam, recs, frames, per_frame, None, occ, 3.0, 0.8, a, nm, what="quality")
+    for k, ri in enumerate(frames):
+        nC = len(recs[ri]["kps"])
+        ekq, epq = PO.update_quality_scores([int(v) for v in a[k, :nC]], kq[k, :nC], pq[off[k]:off[k + 1]])
+        assert gkq[k, :nC].tobytes() == ekq.tobytes() and gpq[off[k]:off[k + 1]].tobytes() == epq.tobytes(), k
+        assert np.array_equal(gkq[k, nC:], kq[k, nC:])
+    assert (gkq != kq).any() and (gpq != pq).any()
+
+
+def test_local_frame_table_outside_the_block_is_refused_per_frame(iv):
+    """a record index outside the block or a decreasing offset: that frame reports nmatches = -1 / assign = -1, the others are served."""
+    import torch
+    from iv_slam_amd import dist as ivd
+    cam, recs, _, _ = extracted_sequence(iv, 640, 240, 500, 3, seed=193, shift=2)
+    rng = np.random.default_rng(3)
+    I = np.eye(4, dtype=F)
+    per_frame = [map_points_from(cam, recs[0], I, rng), map_points_from(cam, recs[1], I, rng), map_points_from(cam, recs[1], I, rng)]
+    nf = cam["nf"]; dev = torch.device("cuda:0")
+    block = torch.from_numpy(ivd.pack_records(recs, nf).reshape(-1)).to(dev)
+    pts, off = pack_points(iv, per_frame)
+    tr = iv.BatchTracker(nf, cam["scale"], float(cam["fx"]), float(cam["fy"]), float(cam["cx"]), float(cam["cy"]), float(cam["bf"]),
+                         cam["bounds"], max_pairs=3, b=float(cam["b"]))
+    dpts = torch.from_numpy(pts.view(np.uint8).reshape(-1)).to(dev)
+    a = torch.full((3, nf), -7, dtype=torch.int32, device=dev); nm = torch.full((3,), -7, dtype=torch.int32, device=dev)
+    tr.search_local(block, torch.tensor([1, 9, 2], dtype=torch.int32, device=dev), dpts, torch.from_numpy(off).to(dev), max(len(p) for p in per_frame), a, nm)
+    torch.cuda.synchronize()
+    a, nm = a.cpu().numpy(), nm.cpu().numpy()
+    assert nm[1] == -1 and (a[1] == -1).all()
+    check_local(cam, recs, [1, 2], [per_frame[0], per_frame[2]], None, None, 1.0, 0.8, a[[0, 2]], nm[[0, 2]], what="valid frames beside an invalid one")
+    bad_off = off.copy(); bad_off[2] = bad_off[1] - 5                       # frame 1's range runs backwards, frame 2 starts below frame 1's start
+    a2 = torch.full((3, nf), -7, dtype=torch.int32, device=dev); nm2 = torch.full((3,), -7, dtype=torch.int32, device=dev)
+    tr.search_local(block, torch.tensor([1, 2, 2], dtype=torch.int32, device=dev), dpts, torch.from_numpy(bad_off).to(dev), max(len(p) for p in per_frame), a2, nm2)
+    torch.cuda.synchronize()
+    assert int(nm2[1]) == -1 and int(nm2[0]) == int(nm[0])
 
 
 def test_local_points_overflowing_windows_and_ties(iv):

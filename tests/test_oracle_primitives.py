@@ -114,6 +114,33 @@ def test_resize_constant_and_identity_and_ramp():
     assert (out == out[0]).all()
 
 
+def test_resize_scale_written_as_opencv_leaves_every_pyramid_coefficient_unchanged():
+    """cv::resize computes scale = 1. / ((double)dsize / ssize); rounds 1-3 of this repository wrote (double)ssize / dsize in oracle AND
+    device.  The doubles differ in the last bit for some pairs; the packed (offset, 11-bit coefficient) triples must not, for every
+    (level l-1, level l) size pair the pyramid can produce: base sizes 16..4095 (the C-ABI's limit), the five scale factors of the
+    fuzz tests, up to 8 levels -- so the goldens and fixtures of those rounds stand."""
+    import ctypes as C
+    O.lib.orc_resize_coef_mismatches.restype = C.c_int; O.lib.orc_resize_coef_mismatches.argtypes = [C.c_int, C.c_int]
+    F = np.float32
+    seen = set()
+    differing_doubles = 0
+    for sf in (1.1, 1.2, 1.3, 1.5, 2.0):
+        scale = [F(1.0)]
+        for _ in range(7):
+            scale.append(F(np.float64(scale[-1]) * np.float64(F(sf))))         # ORBextractor.cc:419-425
+        inv = [F(F(1.0) / s) for s in scale]
+        for base in range(16, 4096):
+            dims = [O.lib.orc_cv_round_f(float(F(base) * i)) for i in inv]     # :1303
+            for a, b in zip(dims, dims[1:]):
+                if b >= 1 and (a, b) not in seen:
+                    seen.add((a, b))
+    assert len(seen) > 15000
+    for a, b in sorted(seen):
+        assert O.lib.orc_resize_coef_mismatches(a, b) == 0, (a, b)
+        differing_doubles += (1.0 / (b / a)) != (a / b)
+    assert differing_doubles > 100                      # the test really covers pairs where the two formulas give different doubles
+
+
 def test_resize_level_sizes_kitti():
     e = O.Extractor()
     inv = e.tables()["inv_scale"]
