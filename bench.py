@@ -27,9 +27,45 @@ sys.path.insert(0, ROOT)
 
 METRIC = "stereo pairs/s (extract+match+introspect) @1242×375, 1000 feat; 1/2/4/8 GPU"
 W, H, NFEAT = 1242, 375, 1000
+INI_TH, MIN_TH = 20, 7            # ORBextractor.iniThFAST / minThFAST (KITTI00-02.yaml:42-52)
 BF, FX = 386.1448, 718.856
 LEVEL_PX_SUM = 1441432            # sum of pixels over the 8 levels
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+# BASELINE.json configs[k] as bench workloads (--config k).  configs[2] is the configuration the metric is quoted on: the
+# default run.  configs[0] is the reference's CPU-runnable case (a parity-test case, not a bench line).
+#   3: 2000 features per frame on the batched 8-level pyramid (the 8-rank half: --gpus N)
+#   4: the un-binned Jackal stream: 1920x1200, 4000 features, FAST 12 / 7, introspection ON, cost map at the image size
+#      (ORB/Examples/Stereo/jackal_visual_odom_stereo_inference.yaml:91-105 holds the ORB keys; its camera is the 2x2-binned
+#      960x600 one, fx 528.955512 / bf 69.690815 (:8-27) -- doubled here for the full-resolution image)
+CONFIGS = {
+    1: dict(w=1242, h=375, n=1000, ini=20, mn=7, bf=386.1448, fx=718.856, introspect=False, pairs=128, stream=512,
+            name="configs[1]: 1242x375 stereo pair stream, ORB extract + L/R Hamming match, introspection OFF"),
+    2: dict(w=1242, h=375, n=1000, ini=20, mn=7, bf=386.1448, fx=718.856, introspect=True, pairs=128, stream=512,
+            name="configs[2]: 1242x375 stereo stream with introspection FCN cost-map forward (MFMA convs) gating keypoints, "
+                 "ORB extract + L/R Hamming match"),
+    3: dict(w=1242, h=375, n=2000, ini=20, mn=7, bf=386.1448, fx=718.856, introspect=True, pairs=128, stream=512,
+            name="configs[3]: batched 8-level pyramid, 2000 features/frame, 1242x375 stereo stream, introspection FCN + ORB extract + "
+                 "L/R Hamming match (frames shard across ranks with the RCCL descriptor all-gather under --gpus N)"),
+    4: dict(w=1920, h=1200, n=4000, ini=12, mn=7, bf=139.38163, fx=1057.911024, introspect=True, pairs=32, stream=128,
+            name="configs[4]: 1920x1200 Jackal stereo stream, 4000 features/frame, FAST 12/7, introspection ON (cost map 1920x1200), "
+                 "ORB extract + L/R Hamming match + tracker step (the Tracking loop's matcher calls)"),
+}
+WORKLOAD = CONFIGS[2]["name"]
+
+
+def apply_config(k):
+    """Select BASELINE.json configs[k]: sets the module-level workload constants every leg of the bench reads."""
+    global W, H, NFEAT, INI_TH, MIN_TH, BF, FX, LEVEL_PX_SUM, WORKLOAD
+    c = CONFIGS[k]
+    W, H, NFEAT, INI_TH, MIN_TH, BF, FX, WORKLOAD = c["w"], c["h"], c["n"], c["ini"], c["mn"], c["bf"], c["fx"], c["name"]
+    import numpy as np
+    F = np.float32
+    sc = [F(1.0)]
+    for _ in range(7):
+        sc.append(F(np.float64(sc[-1]) * np.float64(F(1.2))))                  # ORBextractor.cc:419-425
+    LEVEL_PX_SUM = sum(int(np.rint(F(W) * F(F(1.0) / v))) * int(np.rint(F(H) * F(F(1.0) / v))) for v in sc)   # :1303 (cvRound = rint)
+    return c
 
 
 RUN = 32                          # consecutive frames per visit of a scene
@@ -58,15 +94,8 @@ def make_device_stream(torch, dev, n_pairs, seed, base_pairs=16, rank=0, world=1
 
 
 def track_pairs(world, rank, P):
-    """(last, cur) record indices into the all-gathered buffer [world][P] for the frames THIS rank extracted: slot (r, j) holds
-    global frame j * world + r, so the frame before (r, j) is (r - 1, j), or (world - 1, j - 1) for r = 0."""
-    out = []
-    for j in range(P):
-        if rank > 0:
-            out.append(((rank - 1) * P + j, rank * P + j))
-        elif j > 0:
-            out.append(((world - 1) * P + j - 1, j))
-    return out
+    from iv_slam_amd import dist as ivd
+    return ivd.track_pairs(world, rank, P)
 
 
 def cpu_baseline(pairs_sample, cores, threads_per_pair=1):
@@ -84,7 +113,7 @@ def cpu_baseline(pairs_sample, cores, threads_per_pair=1):
 
     def work(i):
         L, R = imgs[i % len(imgs)]
-        eL = O.Extractor(NFEAT, 1.2, 8, 20, 7); eR = O.Extractor(NFEAT, 1.2, 8, 20, 7)
+        eL = O.Extractor(NFEAT, 1.2, 8, INI_TH, MIN_TH); eR = O.Extractor(NFEAT, 1.2, 8, INI_TH, MIN_TH)
         if inner is not None:
             fl = inner.submit(eL, L); fr = inner.submit(eR, R)
             (kL, dL), (kR, dR) = fl.result(), fr.result()
@@ -133,7 +162,7 @@ def oracle_checksum():
     import oracle_lib as O
     from iv_slam_amd import synth
     L, R = synth.make_pair(W, H, seed=900, idx=0)
-    eL = O.Extractor(NFEAT, 1.2, 8, 20, 7); eR = O.Extractor(NFEAT, 1.2, 8, 20, 7)
+    eL = O.Extractor(NFEAT, 1.2, 8, INI_TH, MIN_TH); eR = O.Extractor(NFEAT, 1.2, 8, INI_TH, MIN_TH)
     kL, dL = eL(L); kR, dR = eR(R)
     ur, dp = O.stereo_match(eL, eR, kL, dL, kR, dR, BF, BF / FX)
     return hashlib.sha1(kL.tobytes() + dL.tobytes() + kR.tobytes() + dR.tobytes() + ur.tobytes() + dp.tobytes()).hexdigest()
@@ -143,9 +172,10 @@ def cpu_baseline_worker(introspect):
     """Runs in a FRESH process (bench.py --cpu-baseline-worker): the oracle library named by IVF_ORACLE_SO -- the reference's
     own build flags, -O3 -march=native (ORB/CMakeLists.txt:16-17), compiled on this host -- and the frozen-TorchScript FCN leg."""
     cores = max(1, min(os.cpu_count() or 1, 32))
-    sample = max(256, 64 * cores)                 # ~4 s on 32 cores: with the FCN leg (~9 s) a bounded sample of 10-30 s of CPU work
+    # ~4 s on 32 cores at 1242x375: with the FCN leg (~9 s) a bounded sample of 10-30 s of CPU work; scaled by the pyramid size
+    sample = max(4 * cores, int(max(256, 64 * cores) * 1441432 / LEVEL_PX_SUM))
     v, secs = cpu_baseline(sample, cores)
-    v2, secs2 = cpu_baseline(max(64, 8 * cores), cores, threads_per_pair=2)
+    v2, secs2 = cpu_baseline(max(2 * cores, int(max(64, 8 * cores) * 1441432 / LEVEL_PX_SUM)), cores, threads_per_pair=2)
     out = {"cores": cores, "sample_pairs": sample, "extract_match_all_cores": v, "secs": secs, "extract_match_two_threads_per_pair": v2,
            "checksum": oracle_checksum(), "oracle_so": os.environ.get("IVF_ORACLE_SO", "oracle/libivf_oracle.so")}
     if introspect:
@@ -154,7 +184,7 @@ def cpu_baseline_worker(introspect):
     print("CPU_BASELINE " + json.dumps(out), flush=True)
 
 
-def run_cpu_baseline(introspect):
+def run_cpu_baseline(introspect, config=2):
     """cpu_baseline object of the JSON line: builds the oracle -march=native for THIS host (fallback: the portable -march=x86-64-v2
     library that travels with the repo), times it in a fresh process, checks the native build against the portable one."""
     import subprocess
@@ -176,16 +206,20 @@ def run_cpu_baseline(introspect):
     env = dict(os.environ)
     if so:
         env["IVF_ORACLE_SO"] = so
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"] + ([] if introspect else ["--no-introspect"]),
-                       env=env, capture_output=True, text=True, timeout=1200)
-    line = [l for l in r.stdout.splitlines() if l.startswith("CPU_BASELINE ")]
-    if r.returncode != 0 or not line:
-        raise RuntimeError("cpu baseline worker failed: " + r.stderr[-1500:])
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--config", str(config)] +
+                           ([] if introspect else ["--no-introspect"]), env=env, capture_output=True, text=True, timeout=1200)
+        line = [l for l in r.stdout.splitlines() if l.startswith("CPU_BASELINE ")]
+        if r.returncode != 0 or not line:
+            raise RuntimeError("worker exit code %d: %s" % (r.returncode, r.stderr[-1500:]))
+    except Exception as e:                       # the GPU measurements above must still be printed: report the failure in the line
+        return {"value": None, "unit": "pairs/s", "cores": None, "kind": "port", "sample": None,
+                "error": "cpu baseline worker failed: %s" % (str(e)[-1500:],)}
     w = json.loads(line[0][len("CPU_BASELINE "):])
     same = w["checksum"] == oracle_checksum()
     v = w["extract_match_all_cores"]
-    txt = ("%d pairs of the same 1242x375/1000-feature workload, one pair per thread, %.1f s wall (oracle/ivf_oracle.c, scalar C, %s)"
-           % (w["sample_pairs"], w["secs"], flags))
+    txt = ("%d pairs of the same %dx%d/%d-feature workload, one pair per thread, %.1f s wall (oracle/ivf_oracle.c, scalar C, %s)"
+           % (w["sample_pairs"], W, H, NFEAT, w["secs"], flags))
     extra = {"extract_match_all_cores": round(v, 2), "extract_match_two_threads_per_pair": round(w["extract_match_two_threads_per_pair"], 2),
              "oracle_build": flags, "native_build_equals_portable_build": bool(same)}
     if introspect:
@@ -208,7 +242,7 @@ def parity_spot_check(spot, introspect):
     b = BF / FX
     bad = []
     for s in spot:
-        oL = O.Extractor(NFEAT, 1.2, 8, 20, 7, introspection=bool(introspect)); oR = O.Extractor(NFEAT, 1.2, 8, 20, 7)
+        oL = O.Extractor(NFEAT, 1.2, 8, INI_TH, MIN_TH, introspection=bool(introspect)); oR = O.Extractor(NFEAT, 1.2, 8, INI_TH, MIN_TH)
         kL, dL = oL(s["L"], s["cost"]); kR, dR = oR(s["R"], None)
         ur, dp = O.stereo_match(oL, oR, kL, dL, kR, dR, BF, b)
         ok = (s["l"]["kps"].tobytes() == kL.tobytes() and s["r"]["kps"].tobytes() == kR.tobytes() and
@@ -349,7 +383,7 @@ def latency_batch1(iv, blob, introspect, iters=20):
     from iv_slam_amd import synth
     L, R = synth.make_pair(W, H, seed=77, idx=0)
     bgr = np.stack([L, L // 2 + 40, 255 - L // 2], axis=-1).astype(np.uint8)
-    eL = iv.ORBextractor(NFEAT, 1.2, 8, 20, 7, bool(introspect)); eR = iv.ORBextractor(NFEAT, 1.2, 8, 20, 7, False)
+    eL = iv.ORBextractor(NFEAT, 1.2, 8, INI_TH, MIN_TH, bool(introspect)); eR = iv.ORBextractor(NFEAT, 1.2, 8, INI_TH, MIN_TH, False)
     fcn1 = iv.IntrospectionFCN(blob, (H, W), (H, W), max_batch=1) if introspect else None
     ms = []
     for it in range(iters + 3):
@@ -427,9 +461,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=128, help="stereo pairs per launch sequence (sub-batch) per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[k]: 2 (default) = the configuration the "
+                    "metric is quoted on; 1 = the same without introspection; 3 = 2000 features; 4 = 1920x1200 / 4000 features / FAST 12/7")
+    ap.add_argument("--pairs", type=int, default=0, help="stereo pairs per launch sequence (sub-batch) per GPU (default: 128; 32 for --config 4)")
     ap.add_argument("--batches-per-step", type=int, default=0, help="sub-batches per step (default 16 with introspection, 64 without)")
-    ap.add_argument("--stream", type=int, default=512, help="distinct pairs resident per GPU")
+    ap.add_argument("--stream", type=int, default=0, help="distinct pairs resident per GPU (default: 512; 128 for --config 4)")
     ap.add_argument("--introspect", action="store_true", help="(default) configs[2]: run the introspection FCN on every left image and gate keypoints with it")
     ap.add_argument("--no-introspect", action="store_true", help="configs[1]: extract + match only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -437,12 +473,19 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the post-run latency / PCIe-inclusive / configs[1] measurements")
     ap.add_argument("--force-gather", action="store_true", help="test aid: run the multi-GPU exchange step (RCCL all-gather of "
                     "the descriptor records) even with one rank")
-    ap.add_argument("--track", action="store_true", help="run the batched tracker step (SearchByProjection(cur, last) for every consecutive "
-                    "frame pair, ivf_tracker_run) on every sub-batch's records inside the timed step; always on when the exchange runs")
+    ap.add_argument("--track", action="store_true", help=argparse.SUPPRESS)      # r03 flag, now the default
+    ap.add_argument("--no-track", action="store_true", help="leave the batched tracker step (pack of the result records + SearchByProjection(cur, last) "
+                    "for every consecutive frame pair, ivf_tracker_run) out of the timed step.  By default it runs inside it at EVERY rank count, "
+                    "so that the 1/2/4/8-GPU lines time the same work per frame (with ranks > 1 it consumes the all-gathered records)")
     ap.add_argument("--serial", action="store_true", help="profiling aid: wait for each batch before enqueuing the next, so "
                     "rocprofv3 kernel durations are not inflated by the overlap of consecutive batches")
     args = ap.parse_args()
-    args.introspect = not args.no_introspect
+    cfg = apply_config(args.config)
+    args.introspect = cfg["introspect"] and not args.no_introspect
+    if args.pairs <= 0:
+        args.pairs = cfg["pairs"]
+    if args.stream <= 0:
+        args.stream = cfg["stream"]
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args.introspect)
     BPS = args.batches_per_step if args.batches_per_step > 0 else (16 if args.introspect else 64)
@@ -462,11 +505,17 @@ def main():
                "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
-    import torch
-    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    numa = None
+    if world > 1 and backend != "gloo":
+        # one process per GPU: keep this rank's host threads on the NUMA node of ITS device.  Done here, in the fresh rank process,
+        # from sysfs alone -- before torch / HIP are imported or the GPU is touched.
+        from iv_slam_amd import dist as ivd
+        numa = ivd.bind_rank_to_numa(local_rank)
+    import torch
+    import torch.distributed as dist
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python -m torch.distributed.run "
                          "--nproc-per-node %d bench.py --gpus %d ...) or drop WORLD_SIZE and let bench.py spawn them"
@@ -504,7 +553,7 @@ def main():
         fcn.probe_enable()
         bgr = torch.stack([left, left // 2 + 40, 255 - left // 2], dim=-1).contiguous()      # [n,H,W,3] colour-ish
         cost = torch.empty((P, H, W), dtype=torch.uint8, device=dev)
-    fe = iv.StereoFrontend(W, H, P, nfeatures=NFEAT, enableIntrospection=args.introspect, bf=BF, fx=FX,
+    fe = iv.StereoFrontend(W, H, P, nfeatures=NFEAT, iniThFAST=INI_TH, minThFAST=MIN_TH, enableIntrospection=args.introspect, bf=BF, fx=FX,
                            device_id=local_rank)
     stream = torch.cuda.current_stream(dev)
     sptr = stream.cuda_stream
@@ -517,13 +566,13 @@ def main():
     blocks3 = [torch.zeros(P * rec, dtype=torch.uint8, device=dev) for _ in range(3)] if exchange else None
     gathered3 = [torch.zeros(world * P * rec, dtype=torch.uint8, device=dev) for _ in range(3)] if exchange else None
     nsub = [0]
-    track = args.track or exchange
+    track = exchange or not args.no_track
     tracker = None
     if track:
         # the exchange step's consumer: Tracking::TrackWithMotionModel's matcher call for every frame this rank extracted against
         # the frame before it, wherever that one was extracted (ivf_tracker_run on the gathered records; zero-motion prior,
         # th = 7, retry with 14 below 20 matches: Tracking.cc:1313-1330)
-        sc = iv.ORBextractor(NFEAT, 1.2, 8, 20, 7, device_id=local_rank).GetScaleFactors()
+        sc = iv.ORBextractor(NFEAT, 1.2, 8, INI_TH, MIN_TH, device_id=local_rank).GetScaleFactors()
         cam = dict(fx=FX, fy=FX, cx=W / 2 + 0.5, cy=H / 2 - 0.25)
         tpairs_h = track_pairs(world, rank, P)
         # one tracker per internal stream of the front end: a handle owns the scratch of one run at a time
@@ -536,7 +585,10 @@ def main():
         assign3 = [torch.full((max(len(tpairs_h), 1), NFEAT), -1, dtype=torch.int32, device=dev) for _ in range(3)]
         nm3 = [torch.zeros(max(len(tpairs_h), 1), dtype=torch.int32, device=dev) for _ in range(3)]
 
+    coll_stream = [None]                 # the HIP stream the last collective was enqueued on (reported in `exchange`)
+
     def all_gather_block(bs, k):
+        coll_stream[0] = bs.cuda_stream
         if backend == "gloo":
             # test aid: the block crosses the host (gloo has no device path); blocking, never a measured configuration
             bs.synchronize()
@@ -603,7 +655,7 @@ def main():
 
     # sanity on the last batch: keypoints were really produced and matched
     r0 = fe.fetch(0, 0)
-    assert len(r0["kps"]) > NFEAT // 2 and (r0["uright"] >= 0).sum() > 20, "degenerate output"
+    assert len(r0["kps"]) > NFEAT // 4 and (r0["uright"] >= 0).sum() > 20, "degenerate output"
     # parity spot check: 4 pairs of the LAST timed sub-batch -- results, inputs and (configs[2]) the cost maps that gated them
     # are copied out now, before anything else runs, and compared with the oracle below (never inside the timed region)
     s_last = ((nsub[0] - 1) % nslices) * P
@@ -619,9 +671,12 @@ def main():
         own = blocks3[last].cpu().numpy().reshape(P, rec)
         assert np.array_equal(g[rank], own), "all-gather: own slot differs from the packed block"
         counts = g[:, :, :4].copy().view(np.int32)[:, :, 0]
-        assert ((counts > NFEAT // 2) & (counts <= NFEAT)).all(), "all-gather: implausible keypoint counts %r" % counts
-        exch = {"world": world, "record_bytes": rec, "bytes_per_rank_per_batch": P * rec, "records_checked": int(counts.size),
-                "backend": backend, "consumed": False,
+        assert ((counts > NFEAT // 4) & (counts <= NFEAT)).all(), "all-gather: implausible keypoint counts %r" % counts
+        exch = {"world": world, "world_size_seen_by_backend": dist.get_world_size(), "record_bytes": rec, "bytes_per_rank_per_batch": P * rec,
+                "records_checked": int(counts.size), "backend": backend, "consumed": False,
+                "enqueued_on_stream": "0x%x" % coll_stream[0] if coll_stream[0] is not None else None,
+                "batch_stream_of_that_run": "0x%x" % fe.batch_stream(0),
+                "rank0_numa_binding": numa,
                 "collective": ("all_gather_into_tensor (RCCL) on the batch's own internal stream" if backend != "gloo" else
                                "TEST AID: gloo all_gather of host copies (ranks may share a device)")}
     trk = None
@@ -678,7 +733,7 @@ def main():
     # configs[1] (no introspection) on the same stream of pairs, for reference next to the headline number
     em_only = None
     if fcn is not None and extras:
-        fe1 = iv.StereoFrontend(W, H, P, nfeatures=NFEAT, enableIntrospection=False, bf=BF, fx=FX, device_id=local_rank)
+        fe1 = iv.StereoFrontend(W, H, P, nfeatures=NFEAT, iniThFAST=INI_TH, minThFAST=MIN_TH, enableIntrospection=False, bf=BF, fx=FX, device_id=local_rank)
         for i in range(3):
             s0 = (i % nslices) * P; fe1.run(left[s0:s0 + P], right[s0:s0 + P], None, sptr)
         fe1.sync(); torch.cuda.synchronize(dev)
@@ -691,7 +746,7 @@ def main():
     if trk is None and extras:
         # the tracker step on its own (not part of `value`): the records of the batch the front end holds, consecutive frames of the
         # stream, against the oracle and next to the oracle's search on one core
-        sc = iv.ORBextractor(NFEAT, 1.2, 8, 20, 7, device_id=local_rank).GetScaleFactors()
+        sc = iv.ORBextractor(NFEAT, 1.2, 8, INI_TH, MIN_TH, device_id=local_rank).GetScaleFactors()
         cam = dict(fx=FX, fy=FX, cx=W / 2 + 0.5, cy=H / 2 - 0.25)
         tp_h = track_pairs(1, 0, P)
         tr1 = iv.BatchTracker(NFEAT, sc, cam["fx"], cam["fy"], cam["cx"], cam["cy"], BF, (0.0, 0.0, float(W), float(H)), max_pairs=len(tp_h), device_id=local_rank)
@@ -724,7 +779,9 @@ def main():
             # entry is used only when it was recorded for the kernel the probe actually timed (name match); the source string
             # names the file, the commit it was collected at (when recorded) and the file's own hash.
             import hashlib
-            for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+            if (W, H) != (1242, 375):
+                return None, None                  # the committed counter passes were collected at 1242x375 only
+            for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
                 try:
                     path = os.path.join(ROOT, "profiles", name)
                     raw = open(path, "rb").read()
@@ -802,15 +859,16 @@ def main():
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 (ORB) + f32 via split-f16 MFMA (FCN)" if args.introspect else "u8",
             "data": "synthetic",
-            "config": {"workload": ("configs[2]: 1242x375 stereo stream with introspection FCN cost-map forward (MFMA convs) gating keypoints, "
-                                    "ORB extract + L/R Hamming match"
-                                    if args.introspect else
-                                    "configs[1]: 1242x375 stereo pair stream, ORB extract + L/R Hamming match, introspection OFF"),
+            "config": {"workload": (WORKLOAD if args.introspect == CONFIGS[args.config]["introspect"] else
+                                    CONFIGS[1]["name"] if args.config == 2 else WORKLOAD + " -- run with --no-introspect"),
+                       "baseline_config_index": args.config if (args.introspect or args.config != 2) else 1, "width": W, "height": H,
                        "pairs_per_step_per_gpu": P * BPS, "pairs_per_launch_sequence": P, "launch_sequences_per_step": BPS,
                        "distinct_pairs_per_gpu": n_stream, "nfeatures": NFEAT,
-                       "nlevels": 8, "scale_factor": 1.2, "fast_thresholds": [20, 7],
+                       "nlevels": 8, "scale_factor": 1.2, "fast_thresholds": [INI_TH, MIN_TH],
                        "parallelism": "frames sharded %d-way, RCCL all-gather of descriptor blocks" % world if world > 1 else "1 GPU"},
             "timed_region_s": round(dt, 3),
+            "track_in_timed_region": bool(track and len(tpairs_h)),
+            "build": {"libivfront": iv.load().ivf_build_id().decode(), "sources": iv._lib.source_build_id()},
             "roofline": roofline,
             "parity_spot_check": parity,
         }
@@ -831,7 +889,7 @@ def main():
         if h2d is not None:
             out["h2d_included"] = h2d
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = run_cpu_baseline(args.introspect)
+            out["cpu_baseline"] = run_cpu_baseline(args.introspect, args.config)
         print(json.dumps(out), flush=True)
     if exchange:
         dist.destroy_process_group()

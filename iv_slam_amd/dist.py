@@ -57,3 +57,99 @@ def frames_in_order(gathered, world, pairs_per_rank):
         for r in range(world):
             order.append((r + j * world, r, j))
     return order
+
+
+def track_pairs(world, rank, pairs_per_rank):
+    """(last, cur) record indices into the all-gathered buffer [world][pairs_per_rank] for the frames THIS rank extracted: slot
+    (r, j) holds global frame j * world + r, so the frame before (r, j) is (r - 1, j), or (world - 1, j - 1) for r = 0 (rank 0's
+    first frame of a batch has its predecessor in the previous batch: no pair)."""
+    P = pairs_per_rank
+    out = []
+    for j in range(P):
+        if rank > 0:
+            out.append(((rank - 1) * P + j, rank * P + j))
+        elif j > 0:
+            out.append(((world - 1) * P + j - 1, j))
+    return out
+
+
+def slot_frame(slot, world, pairs_per_rank):
+    """global frame index (within one batch) held by slot index `slot` = r * pairs_per_rank + j of the gathered buffer."""
+    r, j = divmod(slot, pairs_per_rank)
+    return j * world + r
+
+
+# ---- rank -> device -> NUMA node ------------------------------------------------------------------------------------------
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def gpu_numa_nodes(sysfs="/sys"):
+    """NUMA node of every GPU in KFD topology order (the order HIP enumerates devices in when HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES do not reorder them), read from sysfs only -- no HIP call, so a rank can use it before it touches the GPU.
+    Returns a list of (pci_bdf, numa_node or -1)."""
+    import os
+    base = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    out = []
+    try:
+        nodes = sorted((int(n) for n in os.listdir(base) if n.isdigit()))
+    except OSError:
+        return out
+    for n in nodes:
+        txt = _read(os.path.join(base, str(n), "properties"))
+        if not txt:
+            continue
+        props = dict(l.split(None, 1) for l in txt.splitlines() if len(l.split(None, 1)) == 2)
+        if int(props.get("simd_count", "0")) == 0:
+            continue                                   # a CPU node
+        loc = int(props.get("location_id", "0")); dom = int(props.get("domain", "0"))
+        bdf = "%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
+        numa = _read(os.path.join(sysfs, "bus", "pci", "devices", bdf, "numa_node"))
+        out.append((bdf, int(numa) if numa is not None and numa.lstrip("-").isdigit() else -1))
+    return out
+
+
+def parse_cpulist(txt):
+    cpus = set()
+    for part in (txt or "").split(","):
+        part = part.strip()
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def bind_rank_to_numa(local_rank, sysfs="/sys", apply=True):
+    """Pin this rank's host threads to the CPUs of the NUMA node its GPU hangs off (one process per GPU: the rank's enqueue loop
+    and its pinned staging buffers then sit next to the device).  Call it in a FRESH rank process before anything initialises
+    the GPU.  Best effort: returns a dict saying what was done or why nothing was."""
+    import os
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    gpus = gpu_numa_nodes(sysfs)
+    idx = local_rank
+    if vis:
+        try:
+            idx = [int(v) for v in vis.split(",")][local_rank]
+        except (ValueError, IndexError):
+            return {"bound": False, "why": "cannot map local rank %d through the visible-device list %r" % (local_rank, vis)}
+    if not (0 <= idx < len(gpus)):
+        return {"bound": False, "why": "no KFD topology entry for device %d (%d GPU nodes found)" % (idx, len(gpus))}
+    bdf, numa = gpus[idx]
+    if numa < 0:
+        return {"bound": False, "device": idx, "pci": bdf, "why": "the device reports no NUMA node"}
+    cpus = parse_cpulist(_read(os.path.join(sysfs, "devices", "system", "node", "node%d" % numa, "cpulist")))
+    if apply and hasattr(os, "sched_getaffinity"):
+        cpus &= os.sched_getaffinity(0)                # never widen what the launcher / container allows
+    if not cpus:
+        return {"bound": False, "device": idx, "pci": bdf, "numa_node": numa, "why": "no usable CPU on that node"}
+    if apply:
+        try:
+            os.sched_setaffinity(0, cpus)
+        except OSError as e:
+            return {"bound": False, "device": idx, "pci": bdf, "numa_node": numa, "why": "sched_setaffinity: %s" % e}
+    return {"bound": True, "device": idx, "pci": bdf, "numa_node": numa, "cpus": len(cpus)}

@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the N>1 path: frame sharding (frame k -> rank k mod G) and the all-gather of
+"""world_size-2 / -4 gloo tests of the N>1 path: frame sharding (frame k -> rank k mod G) and the all-gather of
 per-pair descriptor records, with the record layout the C-ABI packs on the device."""
 import os
 import socket
@@ -50,18 +50,73 @@ def _worker(rank, world, port, n_frames, q):
     q.put((rank, bool(ok), mine))
 
 
-def test_shard_and_all_gather_world2():
+@pytest.mark.parametrize("world", [2, 4])
+def test_shard_and_all_gather(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    world, n_frames = 2, 8
+    n_frames = 4 * world
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
     for p in procs: p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs: p.join(60)
-    assert [r[1] for r in res] == [True, True]
-    assert res[0][2] == [0, 2, 4, 6] and res[1][2] == [1, 3, 5, 7]        # round-robin, disjoint, complete
+    assert [r[1] for r in res] == [True] * world
+    for r in range(world):
+        assert res[r][2] == list(range(r, n_frames, world))                # round-robin, disjoint, complete
+    assert sorted(f for r in res for f in r[2]) == list(range(n_frames))
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+@pytest.mark.parametrize("P", [1, 2, 16, 128])
+def test_track_pairs_cover_every_consecutive_global_pair_exactly_once(world, P):
+    """bench.py's pair tables (iv_slam_amd.dist.track_pairs): over all ranks every consecutive pair (g - 1, g) of the world * P
+    global frames of one batch appears exactly once, each on the rank that extracted frame g (rank 0's wrap to the last rank's
+    previous slot included); frame 0 has no predecessor inside the batch; every index stays inside the gathered buffer."""
+    from iv_slam_amd import dist as ivd
+    seen = {}
+    for rank in range(world):
+        for last, cur in ivd.track_pairs(world, rank, P):
+            assert 0 <= last < world * P and 0 <= cur < world * P
+            assert cur // P == rank, "a rank tracks only frames it extracted itself"
+            g_last, g_cur = ivd.slot_frame(last, world, P), ivd.slot_frame(cur, world, P)
+            assert g_cur == g_last + 1, (world, P, rank, last, cur)
+            assert g_cur not in seen
+            seen[g_cur] = rank
+    assert sorted(seen) == list(range(1, world * P))
+    # slot_frame is the inverse of frames_in_order
+    for g, r, j in ivd.frames_in_order(None, world, P):
+        assert ivd.slot_frame(r * P + j, world, P) == g
+
+
+def test_rank_to_numa_binding_from_sysfs(tmp_path, monkeypatch):
+    """bind_rank_to_numa reads the KFD topology + PCI + node cpulists from sysfs only (no HIP call): a fake 2-socket tree with four
+    GPUs, two per socket; visible-device remapping; a device without a NUMA node; nothing applied to this process (apply=False)."""
+    from iv_slam_amd import dist as ivd
+    sysfs = tmp_path
+    nodes = sysfs / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    gpus = [(0x0500, 0), (0x2600, 0), (0x8500, 1), (0xa600, -1)]
+    for i in range(2):                                                     # CPU nodes first, like a real box
+        (nodes / str(i)).mkdir(parents=True); (nodes / str(i) / "properties").write_text("cpu_cores_count 64\nsimd_count 0\n")
+    for k, (loc, numa) in enumerate(gpus):
+        d = nodes / str(2 + k); d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count 0\nsimd_count 1024\nlocation_id %d\ndomain 0\n" % loc)
+        bdf = "0000:%02x:%02x.%x" % ((loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
+        pd = sysfs / "bus" / "pci" / "devices" / bdf; pd.mkdir(parents=True)
+        (pd / "numa_node").write_text("%d\n" % numa)
+    for n, cl in ((0, "0-3,64-67"), (1, "4-7")):
+        nd = sysfs / "devices" / "system" / "node" / ("node%d" % n); nd.mkdir(parents=True)
+        (nd / "cpulist").write_text(cl + "\n")
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False); monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    assert ivd.gpu_numa_nodes(str(sysfs)) == [("0000:05:00.0", 0), ("0000:26:00.0", 0), ("0000:85:00.0", 1), ("0000:a6:00.0", -1)]
+    r = ivd.bind_rank_to_numa(0, str(sysfs), apply=False)
+    assert r == {"bound": True, "device": 0, "pci": "0000:05:00.0", "numa_node": 0, "cpus": 8}
+    assert ivd.bind_rank_to_numa(2, str(sysfs), apply=False)["numa_node"] == 1
+    assert ivd.bind_rank_to_numa(3, str(sysfs), apply=False)["bound"] is False
+    assert ivd.bind_rank_to_numa(7, str(sysfs), apply=False)["bound"] is False
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0")
+    assert ivd.bind_rank_to_numa(0, str(sysfs), apply=False)["pci"] == "0000:85:00.0"
+    assert ivd.parse_cpulist("0-2,8,10-11") == {0, 1, 2, 8, 10, 11} and ivd.parse_cpulist("") == set()
 
 
 def test_record_layout_matches_c_abi_formula():

@@ -41,28 +41,49 @@ def test_exchange_step_single_rank():
     assert j["parity_spot_check"]["ok"] is True
 
 
-def test_track_flag_without_exchange():
-    j = _run("--pairs", "16", "--stream", "32", "--track")
-    assert "exchange" not in j and j["track"]["parity_ok"] is True and j["track"]["us_per_frame_pair"] > 0
+def test_tracker_step_is_timed_at_every_rank_count():
+    """the 1-GPU line times the same work per frame as the N-GPU lines: pack + tracker step inside the timed region by default."""
+    j = _run("--pairs", "16", "--stream", "32")
+    assert "exchange" not in j and j["track_in_timed_region"] is True
+    assert j["track"]["parity_ok"] is True and j["track"]["in_timed_region"] is True and j["track"]["us_per_frame_pair"] > 0
+    assert j["build"]["libivfront"] == j["build"]["sources"] and len(j["build"]["libivfront"]) == 16
+    j = _run("--pairs", "16", "--stream", "32", "--no-track", "--no-introspect")
+    assert j["track_in_timed_region"] is False and j["track"]["in_timed_region"] is False and j["track"]["parity_ok"] is True
 
 
-def test_two_ranks_on_one_gpu_through_gloo():
-    """The N > 1 path executes on a 1-GPU box: `bench.py --gpus 2` spawns two ranks that share device 0 (IVF_BENCH_BACKEND=gloo,
-    a test aid: blocks cross the host), all-gathers the record blocks, runs the tracker on frames extracted by the OTHER rank,
-    verifies the exchange and the MAX all-reduce, and prints ONE line with n_gpus == 2."""
+@pytest.mark.parametrize("cfg,pairs,w,h,n", [(3, 8, 1242, 375, 2000), (4, 4, 1920, 1200, 4000)])
+def test_other_baseline_configs_have_bench_lines(cfg, pairs, w, h, n):
+    """bench.py --config 3 / --config 4 (BASELINE.json configs[3] / configs[4]): one contract line each, oracle spot check of the last
+    timed launch sequence, tracker parity, both rooflines."""
+    j = _run("--config", str(cfg), "--pairs", str(pairs), "--stream", str(2 * pairs), "--batches-per-step", "2")
+    c = j["config"]
+    assert c["baseline_config_index"] == cfg and (c["width"], c["height"], c["nfeatures"]) == (w, h, n) and ("configs[%d]" % cfg) in c["workload"]
+    assert j["value"] > 0 and j["parity_spot_check"]["ok"] is True and j["track"]["parity_ok"] is True
+    assert j["roofline"]["bound"] == "mfma" and j["roofline_fast_nms"]["bound"] == "hbm" and j["roofline_fast_nms"]["frac"] > 0
+    if cfg == 4:
+        assert c["fast_thresholds"] == [12, 7]
+
+
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_ranks_on_one_gpu_through_gloo(ranks):
+    """The N > 1 path executes on a 1-GPU box: `bench.py --gpus N` spawns N ranks that share device 0 (IVF_BENCH_BACKEND=gloo,
+    a test aid: blocks cross the host), all-gathers the record blocks, runs the tracker on frames extracted by ANOTHER rank (rank 0
+    wraps to the last rank's previous slot), verifies the exchange and the MAX all-reduce, and prints ONE line with n_gpus == N."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", IVF_BENCH_BACKEND="gloo")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1",
                         "--no-cpu-baseline", "--pairs", "16", "--stream", "32"],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+                       env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["n_gpus"] == ranks and j["value"] > 0 and j["scaling"] == "weak" and j["track_in_timed_region"] is True
     ex = j["exchange"]
-    assert ex["world"] == 2 and ex["backend"] == "gloo" and ex["records_checked"] == 32 and ex["consumed"] is True
-    # rank 0 tracked its frames j >= 1 against rank 1's frames j - 1 (15 pairs); consecutive GLOBAL frames re-match
+    assert ex["world"] == ranks and ex["world_size_seen_by_backend"] == ranks and ex["backend"] == "gloo"
+    assert ex["records_checked"] == 16 * ranks and ex["consumed"] is True
+    assert ex["enqueued_on_stream"] == ex["batch_stream_of_that_run"]          # the collective sits on the batch's own stream, behind the pack
+    # rank 0 tracked its frames j >= 1 against the LAST rank's frames j - 1 (15 pairs); consecutive GLOBAL frames re-match
     assert j["track"]["parity_ok"] is True and j["track"]["frame_pairs_per_launch_sequence"] == 15 and j["track"]["mean_matches"] > 50
     assert j["parity_spot_check"]["ok"] is True
 
@@ -87,7 +108,9 @@ def test_bench_gpus_flag_spawns_ranks_nccl():
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
-    assert j["exchange"]["world"] == 2 and j["exchange"]["records_checked"] > 0
+    ex = j["exchange"]
+    assert ex["world"] == 2 and ex["world_size_seen_by_backend"] == 2 and ex["records_checked"] > 0 and ex["consumed"] is True
+    assert ex["enqueued_on_stream"] == ex["batch_stream_of_that_run"]
 
 
 def test_bench_refuses_world_size_mismatch():
