@@ -294,8 +294,7 @@ int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size
     launch_ingest(hc, dc, b, s0, s1, imageStride, rowStride, nImg, nSides, b.pyr, st);
     if (cost) launch_ingest(hc, dc, b, cost, cost, costStride, costRowStride, nImg, nSides, b.qpyr, st);
     if (inputsConsumed) HIPCHK(hipEventRecord(inputsConsumed, st));   // caller buffers are free from here on
-    launch_pyramid(hc, dc, dTab, b.pyr, nImg, st);
-    if (useQ) launch_pyramid(hc, dc, dTab, b.qpyr, nImg, st);       // ComputeQualityImagePyramid :1325-1357
+    launch_pyramid(hc, dc, dTab, b.pyr, useQ ? b.qpyr : nullptr, b.useCost, nImg, st);   // + ComputeQualityImagePyramid :1325-1357
     HIPCHK(hipMemsetAsync(b.cellCnt, 0, (size_t)nImg * hc.nCellsTotal * 2 * sizeof(int), st));
     HIPCHK(hipMemsetAsync(b.hugeCount, 0, sizeof(int), st));
     const int slot = (int)(nRuns % kEvRing);

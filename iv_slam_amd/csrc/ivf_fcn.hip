@@ -1863,11 +1863,16 @@ constexpr int kF4WSlots = 3, kF4PSlots = 4;  // weight / parameter buffers: cons
 constexpr size_t kF4Lds = (size_t)2 * 16 * kF4CS * 4 + (size_t)2 * 16 * kF4DP * 4 + 2 * kF4WSlots * 10240 + kF4PSlots * kF4ParB;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <bool RES>
+// SPLIT (small batches, r04): 16 workgroups per image leave most of the chip idle at batch 1 (the per-call drop-in path).  The hidden
+// groups are cut into gridDim.z contiguous ranges; a workgroup runs the same pipeline over its range only and stores its RAW projection
+// accumulators into `part` [gridDim.z][images][Cout][4096]; k_fcn_split_reduce adds the ranges in index order (deterministic) and applies
+// the projection's BN (+ residual).  The batched instantiation (SPLIT = false) is unchanged: g0 / g1 are constants there.
+template <bool RES, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ X, const uint4* __restrict__ WE, const float* __restrict__ par,
                                                      const uint4* __restrict__ WP, const float* __restrict__ scP, const float* __restrict__ shP,
-                                                     const float* __restrict__ res, float* __restrict__ Y, int Cout, int tilesP)
+                                                     const float* __restrict__ res, float* __restrict__ Y, int Cout, int tilesP, float* __restrict__ part)
 {
+    const int g0 = SPLIT ? (int)(blockIdx.z * kF4Groups / gridDim.z) : 0, g1 = SPLIT ? (int)((blockIdx.z + 1) * kF4Groups / gridDim.z) : kF4Groups;
     extern __shared__ __attribute__((aligned(16))) uint4 f4smem[];
     float* const sH = (float*)f4smem;                               // [2][16 ch][kF4CS >= 16 rows x kF4HP]
     float* const sD = sH + 2 * 16 * kF4CS;                          // [2][16 ch][kF4DP]
@@ -1895,13 +1900,13 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     auto piece = [&](int it, int c) {           // piece c of what interval `it` consumes: WE[it] (c < 10), WP[it - 2] (c < 20), par[it] (c = 20)
         const int nb = it % kF4WSlots;
         if (c < 10) {
-            if (it < kF4Groups) dma16(WE + ((size_t)it * 10 + c) * 64 + lane, ldsWE + (unsigned)(nb * 640 + c * 64) * 16u);
+            if (it < g1) dma16(WE + ((size_t)it * 10 + c) * 64 + lane, ldsWE + (unsigned)(nb * 640 + c * 64) * 16u);
         } else if (c < 20) {
             const int c2 = c - 10, gp = it - 2;
-            if (gp >= 0 && gp < kF4Groups)
+            if (gp >= g0 && gp < g1)
                 dma16(WP + (((size_t)gp * tilesP + tile0) * 2 + c2) * 64 + lane, ldsWP + (unsigned)(nb * 640 + c2 * 64) * 16u);
         } else if (c == 20) {
-            if (it < kF4Groups && lane < 48) dma16(par + (size_t)it * 192 + lane * 4, ldsPar + (unsigned)((it % kF4PSlots) * kF4ParB));
+            if (it < g1 && lane < 48) dma16(par + (size_t)it * 192 + lane * 4, ldsPar + (unsigned)((it % kF4PSlots) * kF4ParB));
         }
     };
     auto dma = [&](int it) {                    // all 21 pieces (<= 1 KB each), piece c by wave c % 8
@@ -1918,8 +1923,8 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
             for (int r = 0; r < NB; r++) { const int c = 4 * NA + (uwave - 4) + 4 * r; if (c < 21) piece(it, c); }
         }
     };
-    dma(0);
-    dma(1);
+    dma(g0);
+    dma(g0 + 1);
 
     // ---- the input tile: this wave's 32 sub-image pixels (sub-rows 2w, 2w+1) x 160 channels as B fragments of the 16x16x32 MFMA
     // lane: column n = lane & 15 (sub-column), k = 8 (lane >> 4) + j
@@ -1953,7 +1958,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     const float mL = sh_ ? 1.f : 0.f, mR = sh_ ? 0.f : 1.f;          // the halo pixel comes from the row's other half (lane -1 / +1)
 
     for (int i = tid; i < 2 * 16 * kF4DP / 4; i += 512) ((uint4*)sD)[i] = make_uint4(0u, 0u, 0u, 0u);      // P(-2), P(-1): zero operands
-    for (int i = tid; i < 2 * 640; i += 512) sWP[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < (SPLIT ? 3 : 2) * 640; i += 512) sWP[i] = make_uint4(0u, 0u, 0u, 0u);      // slots g0 % 3, (g0 + 1) % 3
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -2026,7 +2031,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     };
     auto stencil_phase = [&](int it) {          // S(it - 1): 3x3 on the 16 x 16 planes of group it - 1, + BN + ReLU6
         const int g = it - 1;
-        if (g < 0 || g >= kF4Groups) return;
+        if (g < g0 || g >= g1) return;
         const float* hp = sH + (g & 1) * (16 * kF4CS);
         const float4* pq = (const float4*)(sPar + (g % kF4PSlots) * (kF4ParB / 4) + sch * 12);
         const float4 w03 = pq[0], w47 = pq[1], w8s = pq[2];          // taps 0-3 | 4-7 | tap 8, shift, (expansion BN)
@@ -2057,7 +2062,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
                                          __builtin_amdgcn_fmed3f(o[6], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[7], 0.f, 6.f));
     };
 
-    for (int it = 0; it < kF4Groups + 2; it++) {
+    for (int it = g0; it < g1 + 2; it++) {
         F4_TIM(0);
         {
             MPre m;
@@ -2088,6 +2093,12 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
 #pragma unroll
         for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(scP + cb + 8 * g4); sh4[g4] = *(const float4*)(shP + cb + 8 * g4); }
         const size_t ob = ((size_t)b * Cout + cb) * HW + pix;
+        if (SPLIT) {                            // raw sums of this range of hidden groups
+            float* pp = part + (size_t)blockIdx.z * (nwg / 16) * Cout * HW;
+#pragma unroll
+            for (int q = 0; q < 16; q++) pp[ob + (size_t)((q & 3) + 8 * (q >> 2)) * HW] = pacc[t][q];
+            continue;
+        }
         float rv[16];
         if (RES) {
 #pragma unroll
@@ -2100,6 +2111,25 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
             Y[ob + (size_t)((q & 3) + 8 * (q >> 2)) * HW] = v;
         }
     }
+}
+
+// the second half of a SPLIT launch: Y = (sum over the ranges, in index order) * scale + shift (+ residual); 4 pixels per thread
+__global__ __launch_bounds__(256) void k_fcn_split_reduce(const float* __restrict__ part, int nSplit, size_t splitStride, int Cout,
+                                                          const float* __restrict__ scP, const float* __restrict__ shP,
+                                                          const float* __restrict__ res, float* __restrict__ Y, size_t total4)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int c = (int)((i / 1024) % (size_t)Cout);                  // 1024 float4 per 64 x 64 plane
+    float4 a = ((const float4*)part)[i];
+    for (int s = 1; s < nSplit; s++) {
+        const float4 v = ((const float4*)(part + (size_t)s * splitStride))[i];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    const float sc = scP[c], sh = shP[c];
+    float4 o = make_float4(a.x * sc + sh, a.y * sc + sh, a.z * sc + sh, a.w * sc + sh);
+    if (res) { const float4 r = ((const float4*)res)[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+    ((float4*)Y)[i] = o;
 }
 
 // ---- blocks 5 - 14 (dilation 1 and 2 at 64 x 64) as ONE kernel each: expand CIN -> 6 CIN, depthwise 3x3, project -> COUT (+ residual) ----
@@ -2129,14 +2159,16 @@ struct D2Cfg {
     static constexpr size_t LDS = (size_t)2 * 16 * CS * 4 + (size_t)2 * 16 * kF4DP * 4 + (size_t)3 * WSLOT * 16 + 4 * kF4ParB;
 };
 
-template <int CIN, int COUT, bool RES, int DIL = 2>
+template <int CIN, int COUT, bool RES, int DIL = 2, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ X, const uint4* __restrict__ WE, const float* __restrict__ par,
                                                      const uint4* __restrict__ WP, const float* __restrict__ scP, const float* __restrict__ shP,
-                                                     const float* __restrict__ res, float* __restrict__ Y)
+                                                     const float* __restrict__ res, float* __restrict__ Y, float* __restrict__ part)
 {
     using C = D2Cfg<CIN, COUT, DIL>;
     constexpr int kD2CS = C::CS, PITCH = C::PITCH, ROWS = C::ROWS, COLS = C::COLS;
     constexpr int KS = C::KS, TILES = C::TILES, NG = C::NG, NPE = C::NPE, NPP = C::NPP, NP = C::NP, WSLOT = C::WSLOT;
+    // SPLIT: this workgroup's contiguous range of hidden groups (see k_fcn_irbd4)
+    const int g0 = SPLIT ? (int)(blockIdx.z * NG / gridDim.z) : 0, g1 = SPLIT ? (int)((blockIdx.z + 1) * NG / gridDim.z) : NG;
     extern __shared__ __attribute__((aligned(16))) uint4 d2smem[];
     float* const sH = (float*)d2smem;                               // [2][16 ch][kD2CS]
     float* const sD = sH + 2 * 16 * kD2CS;                          // [2][16 ch][kF4DP]
@@ -2155,12 +2187,12 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
     auto piece = [&](int it, int c) {           // piece c of what interval `it` consumes: WE[it] (c < NPE), WP[it - 2] (c < NPE + NPP), par[it]
         const int nb = it % 3;
         if (c < NPE) {
-            if (it < NG) dma16(WE + ((size_t)it * NPE + c) * 64 + lane, ldsW + (unsigned)(nb * WSLOT + c * 64) * 16u);
+            if (it < g1) dma16(WE + ((size_t)it * NPE + c) * 64 + lane, ldsW + (unsigned)(nb * WSLOT + c * 64) * 16u);
         } else if (c < NPE + NPP) {
             const int gp = it - 2;
-            if (gp >= 0 && gp < NG) dma16(WP + ((size_t)gp * NPP + (c - NPE)) * 64 + lane, ldsW + (unsigned)(nb * WSLOT + c * 64) * 16u);
+            if (gp >= g0 && gp < g1) dma16(WP + ((size_t)gp * NPP + (c - NPE)) * 64 + lane, ldsW + (unsigned)(nb * WSLOT + c * 64) * 16u);
         } else if (c == NPE + NPP) {
-            if (it < NG && lane < 48) dma16(par + (size_t)it * 192 + lane * 4, ldsPar + (unsigned)((it & 3) * kF4ParB));
+            if (it < g1 && lane < 48) dma16(par + (size_t)it * 192 + lane * 4, ldsPar + (unsigned)((it & 3) * kF4ParB));
         }
     };
     auto dma_all = [&](int it) {
@@ -2177,8 +2209,8 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
             for (int r = 0; r < (NP - 4 * NA + 3) / 4; r++) { const int c = 4 * NA + (uwave - 4) + 4 * r; if (c < NP) piece(it, c); }
         }
     };
-    dma_all(0);
-    dma_all(1);
+    dma_all(g0);
+    dma_all(g0 + 1);
 
     // ---- input: blocks 0, 1 = this wave's row (columns 0-15, 16-31); block 2 (waves 4-7) = 16 pixels of a halo row
     // lane: column n = lane & 15, k = 8 (lane >> 4) + j; rows outside the sub-image read as zeros
@@ -2220,7 +2252,8 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
     const float mL = sg > 0 ? 1.f : 0.f, mR = sg < SEGS - 1 ? 1.f : 0.f;   // the pixel beside a segment comes from lane -1 / +1; none at the row's ends
 
     for (int i = tid; i < 2 * 16 * kF4DP / 4; i += 512) ((uint4*)sD)[i] = make_uint4(0u, 0u, 0u, 0u);      // P(-2), P(-1): zero operands
-    for (int i = tid; i < 2 * NPP * 64; i += 512) sW[(i / (NPP * 64)) * WSLOT + NPE * 64 + i % (NPP * 64)] = make_uint4(0u, 0u, 0u, 0u);   // P fragments of slots 0, 1
+    for (int i = tid; i < (SPLIT ? 3 : 2) * NPP * 64; i += 512)                                           // P fragments of slots g0 % 3, (g0 + 1) % 3
+        sW[(i / (NPP * 64)) * WSLOT + NPE * 64 + i % (NPP * 64)] = make_uint4(0u, 0u, 0u, 0u);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -2308,7 +2341,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
     };
     auto stencil_phase = [&](int it) {          // S(it - 1): 3x3 on the 10 x 32 planes of group it - 1 -> 8 x 32, + BN + ReLU6
         const int g = it - 1;
-        if (g < 0 || g >= NG) return;
+        if (g < g0 || g >= g1) return;
         const float* hp = sH + (g & 1) * (16 * kD2CS) + sbase;
         const float4* pq = (const float4*)(sPar + (g & 3) * (kF4ParB / 4) + sch * 12);
         const float4 w03 = pq[0], w47 = pq[1], w8s = pq[2];          // taps 0-3 | 4-7 | tap 8, shift, (expansion BN)
@@ -2338,7 +2371,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
                                          __builtin_amdgcn_fmed3f(o[6], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[7], 0.f, 6.f));
     };
 
-    for (int it = 0; it < NG + 2; it++) {
+    for (int it = g0; it < g1 + 2; it++) {
         {
             MPre m;
             mfma_pre(it, m); __builtin_amdgcn_sched_barrier(0);
@@ -2361,6 +2394,12 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
 #pragma unroll
         for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(scP + cb + 8 * g4); sh4[g4] = *(const float4*)(shP + cb + 8 * g4); }
         const size_t ob = ((size_t)b * COUT + cb) * HW + pix;
+        if (SPLIT) {
+            float* pp = part + (size_t)blockIdx.z * (nwg / 16) * COUT * HW;
+#pragma unroll
+            for (int q = 0; q < 16; q++) pp[ob + (size_t)((q & 3) + 8 * (q >> 2)) * HW] = pacc[t][q];
+            continue;
+        }
         float rv[16];
         if (RES) {
 #pragma unroll
@@ -2654,6 +2693,7 @@ struct ivf_fcn {
     Fused4 f2[7];                                                                                                          // blocks 8-14 (k_fcn_irbd2)
     Fused4 f1[3];                                                                                                          // blocks 5-7 (k_fcn_irbd2, DIL = 1)
     float *bufIn = nullptr, *bufA = nullptr, *bufB = nullptr, *bufH1 = nullptr, *bufH2 = nullptr, *bufLogits = nullptr;
+    float* bufPart = nullptr;             // partial projection sums of the small-batch (SPLIT) launches
     uint8_t *dStageIn = nullptr, *dStageU8 = nullptr; float* dStageF = nullptr;
     void* hPin = nullptr;        // pinned host staging of the per-call path (ivf_fcn_forward)
     std::vector<void*> allocs;
@@ -2795,11 +2835,37 @@ int reserve_lds()
         {reinterpret_cast<const void*>(&k_fcn_irbd2<96, 160, false>), D2Cfg<96, 160>::LDS, "k_fcn_irbd2<96,160,false>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd4<true>), kF4Lds, "k_fcn_irbd4<true>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd4<false>), kF4Lds, "k_fcn_irbd4<false>"},
+        // the small-batch (SPLIT) instances
+        {reinterpret_cast<const void*>(&k_fcn_irbd2<64, 64, true, 2, true>), D2Cfg<64, 64>::LDS, "k_fcn_irbd2<64,64,split>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd2<64, 96, false, 2, true>), D2Cfg<64, 96>::LDS, "k_fcn_irbd2<64,96,split>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd2<96, 96, true, 2, true>), D2Cfg<96, 96>::LDS, "k_fcn_irbd2<96,96,split>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd2<96, 160, false, 2, true>), D2Cfg<96, 160>::LDS, "k_fcn_irbd2<96,160,split>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd4<false, true>), kF4Lds, "k_fcn_irbd4<split>"},
     };
     for (auto& k : ks)
         if (hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.lds) != hipSuccess)
             return ffail(IVF_E_NO_DEVICE, "cannot reserve %zu bytes of LDS for %s", k.lds, k.name);
     return IVF_OK;
+}
+
+// Small batches (the per-call drop-in path runs ONE image): a whole-block kernel launches 16 workgroups per image, a sixteenth of the
+// chip at batch 1.  There the hidden groups of blocks 8-17 are cut into `ns` ranges over gridDim.z: ns ~ 16 / images, at least 4 groups
+// per range, partial sums within f->bufPart.  ns depends on the batch size only, so a cost map is reproducible for a given batch size; it
+// differs from the one computed in a large batch by the f32 summation order of the projection (1e-6 relative; tests bound it at 3e-4).
+constexpr size_t kPartFloats = (size_t)16 * 320 * 4096;         // bufPart: ns x images x Cout x 4096 <= this
+int split_ways(int n, int groups, int cout)
+{
+    static const int mode = getenv("IVF_FCN_SPLIT") ? atoi(getenv("IVF_FCN_SPLIT")) : 1;      // 0 = never (every batch through the batched form)
+    if (!mode || n >= 16) return 1;
+    int ns = std::min(16 / n, groups / 4);
+    while (ns > 1 && (size_t)ns * n * cout * 4096 > kPartFloats) ns--;
+    return std::max(ns, 1);
+}
+void launch_split_reduce(ivf_fcn* f, int ns, int n, int cout, const Gemm& pj, const float* res, float* y, hipStream_t s)
+{
+    const size_t total4 = (size_t)n * cout * 1024;
+    hipLaunchKernelGGL(k_fcn_split_reduce, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, (const float*)f->bufPart, ns, (size_t)n * cout * 4096, cout,
+                       (const float*)pj.dScale, (const float*)pj.dShift, res, y, total4);
 }
 
 // IVF_FCN_DEBUG=1: synchronise and check after every launch, naming the stage that failed
@@ -2879,7 +2945,8 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             const Gemm& pj = f->pw[ip + 1];
             bool ok = true;
             auto go = [&](auto kern, size_t lds) {                                               // LDS reserved per instantiation by reserve_lds()
-                hipLaunchKernelGGL(kern, dim3(16 * n), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, bk.res ? x : (const float*)nullptr, y);
+                hipLaunchKernelGGL(kern, dim3(16 * n), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, bk.res ? x : (const float*)nullptr, y,
+                                   (float*)nullptr);
             };
             if (bk.oup == 32 && bk.res) go(&k_fcn_irbd2<32, 32, true, 1>, D2Cfg<32, 32, 1>::LDS);
             else if (bk.oup == 64 && !bk.res) go(&k_fcn_irbd2<32, 64, false, 1>, D2Cfg<32, 64, 1>::LDS);
@@ -2895,13 +2962,21 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             const ivf_fcn::Fused4& F = f->f2[i - 7];
             const Gemm& pj = f->pw[ip + 1];
             bool ok = true;
-            auto go = [&](auto kern, size_t lds) {                                               // LDS reserved per instantiation by reserve_lds()
-                hipLaunchKernelGGL(kern, dim3(16 * n), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, bk.res ? x : (const float*)nullptr, y);
+            // small batches: the hidden groups are cut into `ns` ranges over gridDim.z, partial sums through f->bufPart (see k_fcn_irbd4)
+            const int ns = split_ways(n, hid / 16, bk.oup);
+            auto go = [&](auto kern, auto kernSplit, size_t lds) {                               // LDS reserved per instantiation by reserve_lds()
+                if (ns > 1) {
+                    hipLaunchKernelGGL(kernSplit, dim3(16 * n, 1, ns), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y,
+                                       f->bufPart);
+                    launch_split_reduce(f, ns, n, bk.oup, pj, bk.res ? x : nullptr, y, s);
+                } else
+                    hipLaunchKernelGGL(kern, dim3(16 * n), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, bk.res ? x : (const float*)nullptr, y,
+                                       (float*)nullptr);
             };
-            if (bk.inp == 64 && bk.oup == 64 && bk.res) go(&k_fcn_irbd2<64, 64, true>, D2Cfg<64, 64>::LDS);
-            else if (bk.inp == 64 && bk.oup == 96 && !bk.res) go(&k_fcn_irbd2<64, 96, false>, D2Cfg<64, 96>::LDS);
-            else if (bk.inp == 96 && bk.oup == 96 && bk.res) go(&k_fcn_irbd2<96, 96, true>, D2Cfg<96, 96>::LDS);
-            else if (bk.inp == 96 && bk.oup == 160 && !bk.res) go(&k_fcn_irbd2<96, 160, false>, D2Cfg<96, 160>::LDS);
+            if (bk.inp == 64 && bk.oup == 64 && bk.res) go(&k_fcn_irbd2<64, 64, true>, &k_fcn_irbd2<64, 64, true, 2, true>, D2Cfg<64, 64>::LDS);
+            else if (bk.inp == 64 && bk.oup == 96 && !bk.res) go(&k_fcn_irbd2<64, 96, false>, &k_fcn_irbd2<64, 96, false, 2, true>, D2Cfg<64, 96>::LDS);
+            else if (bk.inp == 96 && bk.oup == 96 && bk.res) go(&k_fcn_irbd2<96, 96, true>, &k_fcn_irbd2<96, 96, true, 2, true>, D2Cfg<96, 96>::LDS);
+            else if (bk.inp == 96 && bk.oup == 160 && !bk.res) go(&k_fcn_irbd2<96, 160, false>, &k_fcn_irbd2<96, 160, false, 2, true>, D2Cfg<96, 160>::LDS);
             else ok = false;
             if (!ok) return ffail(IVF_E_NO_DEVICE, "block %d: no k_fcn_irbd2 instance / LDS reservation failed", i + 1);
             ip += 2; id++;
@@ -2916,9 +2991,17 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             const bool probe4 = i == 14 && f->probe0[0];
             const int slot4 = (int)(f->probeCount % ivf_fcn::kProbe);
             if (probe4) FHIP(hipEventRecord(f->probe0[slot4], s));
-            const dim3 grid(16 * n, F.cout / 160);
-            if (bk.res) hipLaunchKernelGGL((k_fcn_irbd4<true>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, x, y, F.cout, F.tilesP);
-            else hipLaunchKernelGGL((k_fcn_irbd4<false>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y, F.cout, F.tilesP);
+            const int ns = split_ways(n, kF4Groups, F.cout);
+            const dim3 grid(16 * n, F.cout / 160, ns);
+            if (ns > 1) {
+                hipLaunchKernelGGL((k_fcn_irbd4<false, true>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y,
+                                   F.cout, F.tilesP, f->bufPart);
+                launch_split_reduce(f, ns, n, F.cout, pj, bk.res ? x : nullptr, y, s);
+            } else if (bk.res)
+                hipLaunchKernelGGL((k_fcn_irbd4<true>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, x, y, F.cout, F.tilesP, (float*)nullptr);
+            else
+                hipLaunchKernelGGL((k_fcn_irbd4<false>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y, F.cout, F.tilesP,
+                                   (float*)nullptr);
             if (probe4) {
                 FHIP(hipEventRecord(f->probe1[slot4], s)); f->probeBatch[slot4] = n; f->probeCount++;
                 snprintf(f->probeName, sizeof f->probeName, "ivffcn::k_fcn_irbd4<%s> %d->%d->%d", bk.res ? "true" : "false", bk.inp, hid, bk.oup);
@@ -3107,7 +3190,7 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
     const size_t big = (size_t)96 * 256 * 256;           // largest activation: 96 x 256 x 256
     if ((rc = dalloc(&f->bufIn, B * 3 * kEnc * kEnc)) || (rc = dalloc(&f->bufA, B * 32 * 256 * 256)) ||
         (rc = dalloc(&f->bufB, B * 32 * 256 * 256)) || (rc = dalloc(&f->bufH1, B * big)) || (rc = dalloc(&f->bufH2, B * big)) ||
-        (rc = dalloc(&f->bufLogits, B * 64 * 64))) { ivf_fcn_destroy(f); return rc; }
+        (rc = dalloc(&f->bufLogits, B * 64 * 64)) || (rc = dalloc(&f->bufPart, kPartFloats))) { ivf_fcn_destroy(f); return rc; }
     *out = f;
     return IVF_OK;
 }

@@ -130,8 +130,9 @@ def test_fcn_random_sizes_and_batches(iv, seed):
     assert err < 1e-3, "in %dx%d out %dx%d batch %d: %.3g" % (iw, ih, ow, oh, nb, err)
     d = np.abs(cu8.cpu().numpy().astype(int) - ou8.astype(int))
     assert d.max() <= 1 and (d != 0).mean() < 0.02
-    u8_single = fcn(imgs[0])                             # the per-call host path gives the batch's first slot
-    assert np.array_equal(u8_single, cu8[0].cpu().numpy())
+    u8_single = fcn(imgs[0])                             # the per-call host path = a batch of one: the first slot of this batch up to
+    ds = np.abs(u8_single.astype(int) - cu8[0].cpu().numpy().astype(int))      # the summation order of the small-batch schedule (nb > 1)
+    assert ds.max() <= (0 if nb == 1 else 1) and (ds != 0).mean() < 0.01
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("IVF_FUZZ_SEARCH", "4"))))

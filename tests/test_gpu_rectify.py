@@ -189,9 +189,16 @@ def test_replay_harness_online_network(iv, tmp_path):
     nf, sf, nl, ini, mn, _ = S.extractor_params(); bf, b = S.stereo()
     K, D, R, P, size = S.rectification("LEFT"); mL = O.init_undistort_rectify_map(K, D, R, P, size)
     K, D, R, P, size = S.rectification("RIGHT"); mR = O.init_undistort_rectify_map(K, D, R, P, size)
-    fcn = iv.IntrospectionFCN(blob, Ls[0].shape, Ls[0].shape)
+    # the cost maps the way the replay computed them: ONE batch of two images (the small-batch schedule depends on the batch size);
+    # the device network itself is checked in test_gpu_fcn.py
+    import torch
+    fcn = iv.IntrospectionFCN(blob, Ls[0].shape, Ls[0].shape, max_batch=2)
+    dcost = torch.empty((2,) + tuple(Ls[0].shape), dtype=torch.uint8, device="cuda:0")
+    fcn.forward_device(torch.from_numpy(np.stack([np.repeat(Ls[k][..., None], 3, axis=2) for k in range(2)])).to("cuda:0"), cost_u8=dcost)
+    torch.cuda.synchronize()
+    costs = dcost.cpu().numpy()
     for k in range(2):
-        cost = fcn(np.repeat(Ls[k][..., None], 3, axis=2))                 # u8 map; the device network itself is checked in test_gpu_fcn.py
+        cost = costs[k]
         oL = O.remap_bilinear(Ls[k], *mL); oR = O.remap_bilinear(Rs[k], *mR); oC = O.remap_bilinear(cost, *mL)
         eL = O.Extractor(nf, sf, nl, ini, mn, introspection=True); eR = O.Extractor(nf, sf, nl, ini, mn)
         okL, odL = eL(oL, oC); okR, odR = eR(oR)
