@@ -971,8 +971,12 @@ template <int NT>
 __global__ __launch_bounds__(256, 1) void k_fcn_conv3x3_all(const float* __restrict__ X, const uint4* __restrict__ Wq,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            float* __restrict__ Y, int Cin, int Cout,
-                                                           const float* __restrict__ lastW, float lastBias, float* __restrict__ logits)
+                                                           const float* __restrict__ lastW, float lastBias, float* __restrict__ logits,
+                                                           float* __restrict__ part)
 {
+    // part != nullptr (small batches, r04): 8 workgroups per image fill a thirty-second of the chip at batch 1.  The 3 x K16 (tap row,
+    // K step) pairs are cut into gridDim.y contiguous ranges; a workgroup stores its RAW sums into part [gridDim.y][images][Cout][4096],
+    // k_fcn_dec_reduce adds them in index order and applies BN + ReLU + conv_last.
     constexpr int HW = 64 * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kg = lane >> 5, col = lane & 31;
     // 1-D grid, renumbered so that the 8 workgroups of an image run on one XCD and share its L2 (tap rows of neighbouring row groups)
@@ -992,12 +996,13 @@ __global__ __launch_bounds__(256, 1) void k_fcn_conv3x3_all(const float* __restr
             for (int r = 0; r < 16; r++) acc[n][p][r] = 0.f;
     struct XSet { float4 x[8]; float m; };
     uint4 A[NT][3][2];                                               // [tile][dx][hi, lo] of the CURRENT step
-    int dyN = 0, sN = 0;                                             // (tap row, K step) the next x load belongs to
+    const int nSteps = 3 * K16 / (int)gridDim.y, i0 = (int)blockIdx.y * nSteps, i1 = i0 + nSteps;     // this workgroup's (tap row, K step) pairs
+    int dyN = i0 / K16, sN = i0 % K16;                               // (tap row, K step) the next x load belongs to
     auto load_x = [&](XSet& S) {
         const int yy = y + dyN - 1;
         const bool ok = yy >= 0 && yy < 64;
-        const float* P = Xb + (size_t)16 * sN * HW + (ok ? yy : y) * 64;
         S.m = ok ? 1.f : 0.f;
+        const float* P = Xb + (size_t)16 * sN * HW + (ok ? yy : y) * 64;
 #pragma unroll
         for (int j = 0; j < 8; j++) S.x[j] = *(const float4*)(P + (size_t)j * HW);
         if (++sN == K16) { sN = 0; if (dyN < 2) ++dyN; else sN = K16 - 1; }     // past the end: redundant re-load
@@ -1052,10 +1057,10 @@ __global__ __launch_bounds__(256, 1) void k_fcn_conv3x3_all(const float* __restr
     };
     XSet SP, SQ;
 #pragma unroll
-    for (int n = 0; n < NT; n++) load_a(n, 0);
+    for (int n = 0; n < NT; n++) load_a(n, i0);
     load_x(SP);
     load_x(SQ);
-    for (int i = 0; i < 3 * K16; i += 2) {          // 3*K16 is even (K16 = 20)
+    for (int i = i0; i < i1; i += 2) {              // ranges of an even number of steps (3 * K16 = 60: 1, 2, 3, 5, 6, 10, 15 ranges)
         step(SP, i);
         __builtin_amdgcn_sched_barrier(0);
         load_x(SP);
@@ -1064,6 +1069,17 @@ __global__ __launch_bounds__(256, 1) void k_fcn_conv3x3_all(const float* __restr
         __builtin_amdgcn_sched_barrier(0);
         load_x(SQ);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if (part) {
+        float* pb = part + ((size_t)blockIdx.y * (nwg / 8) + b) * Cout * HW + (size_t)y * 64 + x;
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int ch = n * 32 + 4 * kg + (r & 3) + 8 * (r >> 2);
+                if (ch < Cout) *(float4*)(pb + (size_t)ch * HW) = make_float4(acc[n][0][r], acc[n][1][r], acc[n][2][r], acc[n][3][r]);
+            }
+        return;
     }
     if (lastW) {
         // decoder: conv_last (1x1, Cout -> 1, + bias; models_light.py:196) folded into the epilogue.  A lane holds 16 channels per
@@ -1113,6 +1129,40 @@ __global__ __launch_bounds__(256, 1) void k_fcn_conv3x3_all(const float* __restr
             *(float4*)(yb + (size_t)ro * HW) = make_float4(fmaxf(acc[n][0][r] * sc + sh, 0.f), fmaxf(acc[n][1][r] * sc + sh, 0.f),
                                                            fmaxf(acc[n][2][r] * sc + sh, 0.f), fmaxf(acc[n][3][r] * sc + sh, 0.f));
         }
+    }
+}
+
+// second half of the decoder's small-batch schedule: sums of the ranges (index order) -> BN -> ReLU -> conv_last (+ bias) -> logits.
+// Workgroup = 16 pixel quads x 16 channel groups (all of a channel's ranges requested together); the groups meet in LDS.
+__global__ __launch_bounds__(256) void k_fcn_dec_reduce(const float* __restrict__ part, int nSplit, size_t splitStride, int Cout,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        const float* __restrict__ lastW, float lastBias, float* __restrict__ logits)
+{
+    constexpr int kMaxSplit = 15;
+    __shared__ float4 red[16][16];
+    const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int quad = blockIdx.x * 16 + q, b = blockIdx.y;            // 1024 quads per image
+    const int cPer = (Cout + 15) / 16;
+    float4 lg = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = g * cPer; c < min((g + 1) * cPer, Cout); c++) {
+        const float* p = part + ((size_t)b * Cout + c) * 4096 + 4 * quad;
+        float4 v[kMaxSplit];
+#pragma unroll
+        for (int s = 0; s < kMaxSplit; s++) v[s] = *(const float4*)(p + (size_t)(s < nSplit ? s : 0) * splitStride);
+        float4 a = v[0];
+#pragma unroll
+        for (int s = 1; s < kMaxSplit; s++) if (s < nSplit) { a.x += v[s].x; a.y += v[s].y; a.z += v[s].z; a.w += v[s].w; }
+        const float sc = scale[c], sh = shift[c], lw = lastW[c];
+        lg.x += lw * fmaxf(a.x * sc + sh, 0.f); lg.y += lw * fmaxf(a.y * sc + sh, 0.f);
+        lg.z += lw * fmaxf(a.z * sc + sh, 0.f); lg.w += lw * fmaxf(a.w * sc + sh, 0.f);
+    }
+    red[g][q] = lg;
+    __syncthreads();
+    if (g == 0) {
+        float4 o = red[0][q];
+#pragma unroll
+        for (int k = 1; k < 16; k++) { const float4 v = red[k][q]; o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; }
+        *(float4*)(logits + (size_t)b * 4096 + 4 * quad) = make_float4(o.x + lastBias, o.y + lastBias, o.z + lastBias, o.w + lastBias);
     }
 }
 
@@ -1843,11 +1893,44 @@ __global__ __launch_bounds__(512, 2) void k_fcn_dwpw8(const float* __restrict__ 
 // (same image, same y phase, same XCD) complete in L2.
 #ifdef IVF_F4_TIMING
 __device__ unsigned long long g_f4Tim[16];      // diagnostic build (make EXTRA=-DIVF_F4_TIMING): cycle sums per phase, waves 0 and 4
+__device__ unsigned long long g_f4Whole[8];     // wave 0: prologue (input gather ... first barrier), interval loop, epilogue; workgroups
 #define F4_TIM(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
                        tacc[i] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define F4_TIM(i) do { } while (0)
 #endif
+// Activation layout between the whole-block kernels of the 64 x 64 stage (r04): TILE-MAJOR.  Every workgroup of these kernels owns
+// a tile of 256 pixels of one image (16 tiles per image) for ALL channels.  In planes (NCHW) those 256 pixels are scattered over
+// each channel plane (dilation 4: every fourth pixel of every fourth row), so a lane's dword touches a 64-byte line of which the
+// workgroup uses 16 bytes: the input gather and the residual loads of k_fcn_irbd4 are bound by the 10,240 lines a workgroup pulls
+// through its L1 -- 10.7k cycles even when every line hits in L2, 13.8k from HBM (tools/probe/tile_gather.hip), 35k + 21k cycles of a
+// workgroup's 360k in the kernel (one workgroup per CU: nothing overlaps them).  With the tile contiguous ([image][tile][channel][256]:
+// 164 KB in one piece) the same gather takes 2.0k cycles from L2 and 9k when all CUs pull from HBM at once (4.5 TB/s: the chip's
+// limit).  Measured and rejected on the way: all loads in flight before the first use (no change), 8-channel interleaving with
+// dwordx4 accesses (NHWC8: 64 lines per instruction, + 7 %), staggered workgroup starts (no change while the lines are the bound).
+//   lay 0  planes [image][channel][64][64]                         (ends of the chain, every fallback switch)
+//   lay 1  tile = 4 rows x 64 columns (tile = y >> 2)               k_fcn_irbd2<DIL 1>, blocks 5-7
+//   lay 2  tile = 8 x 32 strip of a (y & 1, x & 1) sub-image        k_fcn_irbd2<DIL 2>, blocks 8-14
+//   lay 4  tile = the (y & 3, x & 3) sub-image, 16 x 16             k_fcn_irbd4, blocks 15-17
+// A kernel reads its input and residual in ITS OWN layout and writes in the layout of its consumer (plan_layouts on the host).
+// Element (channel c) of pixel (y, x) of image b at base + c * cs:
+__device__ __forceinline__ void lay_addr(int lay, int C, int b, int y, int x, size_t& base, int& cs)
+{
+    if (lay == 0) { base = (size_t)b * C * 4096 + y * 64 + x; cs = 4096; return; }
+    int tile, off;
+    if (lay == 1) { tile = y >> 2; off = (y & 3) * 64 + x; }
+    else if (lay == 2) { tile = ((y & 1) * 2 + (x & 1)) * 4 + (y >> 4); off = ((y >> 1) & 7) * 32 + (x >> 1); }
+    else { tile = (y & 3) * 4 + (x & 3); off = (y >> 2) * 16 + (x >> 2); }
+    base = ((size_t)(b * 16 + tile) * C) * 256 + off; cs = 256;
+}
+// inverse: pixel of (tile, offset inside the tile)
+__device__ __forceinline__ void lay_pixel(int lay, int tile, int off, int& y, int& x)
+{
+    if (lay == 1) { y = tile * 4 + (off >> 6); x = off & 63; }
+    else if (lay == 2) { const int sub = tile >> 2, r = (tile & 3) * 8 + (off >> 5); y = 2 * r + (sub >> 1); x = 2 * (off & 31) + (sub & 1); }
+    else { y = 4 * (off >> 4) + (tile >> 2); x = 4 * (off & 15) + (tile & 3); }
+}
+
 constexpr int kF4Cin = 160, kF4Hid = 960, kF4Groups = 60;
 constexpr int kF4HP = 20;                         // floats per 16-pixel sub-row of a hidden plane in LDS (80 B rows)
 #ifndef IVF_F4_CS
@@ -1860,7 +1943,8 @@ constexpr int kF4ParB = 1024;                     // bytes per parameter slot (1
 #define IVF_F4_DMA_A 5        // weight pieces per wave of the half that reaches the barrier first (waves 0-3); waves 4-7 share the rest.
 #endif                        // Measured 2 / 3 / 4 / 5 / 6: 100.5 / 99.9 / 99.1 / 97.4 / 98.0 us per image
 constexpr int kF4WSlots = 3, kF4PSlots = 4;  // weight / parameter buffers: consumed in interval it, landed for it + 1, arriving for it + 2
-constexpr size_t kF4Lds = (size_t)2 * 16 * kF4CS * 4 + (size_t)2 * 16 * kF4DP * 4 + 2 * kF4WSlots * 10240 + kF4PSlots * kF4ParB;
+constexpr size_t kF4Lds = (size_t)2 * 16 * kF4CS * 4 + (size_t)2 * 16 * kF4DP * 4 + 2 * kF4WSlots * 10240 + kF4PSlots * kF4ParB +
+                          2 * 160 * 4;        // + the projection's BN scale / shift of this workgroup's 160 output channels
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // SPLIT (small batches, r04): 16 workgroups per image leave most of the chip idle at batch 1 (the per-call drop-in path).  The hidden
@@ -1870,15 +1954,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <bool RES, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ X, const uint4* __restrict__ WE, const float* __restrict__ par,
                                                      const uint4* __restrict__ WP, const float* __restrict__ scP, const float* __restrict__ shP,
-                                                     const float* __restrict__ res, float* __restrict__ Y, int Cout, int tilesP, float* __restrict__ part)
+                                                     const float* __restrict__ res, float* __restrict__ Y, int Cout, int tilesP, float* __restrict__ part,
+                                                     int layIn, int layOut)
 {
     const int g0 = SPLIT ? (int)(blockIdx.z * kF4Groups / gridDim.z) : 0, g1 = SPLIT ? (int)((blockIdx.z + 1) * kF4Groups / gridDim.z) : kF4Groups;
     extern __shared__ __attribute__((aligned(16))) uint4 f4smem[];
+#ifdef IVF_F4_TIMING
+    const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+#endif
     float* const sH = (float*)f4smem;                               // [2][16 ch][kF4CS >= 16 rows x kF4HP]
     float* const sD = sH + 2 * 16 * kF4CS;                          // [2][16 ch][kF4DP]
     uint4* const sWE = (uint4*)(sD + 2 * 16 * kF4DP);               // [slots][5 K steps][hi, lo][64 lanes]
     uint4* const sWP = sWE + kF4WSlots * 640;                       // [slots][5 tiles][hi, lo][64 lanes]
     float* const sPar = (float*)(sWP + kF4WSlots * 640);            // [slots][16 ch][12]: 9 taps (x dw BN scale), dw BN shift, expansion BN scale, shift
+    float* const sBN = sPar + kF4PSlots * (kF4ParB / 4);            // [scale 160 | shift 160] of the projection (epilogue)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;     // consecutive L on one XCD (grid x = 16 * images)
     const int b = L >> 4, py = (L >> 2) & 3, px = L & 3;
@@ -1928,21 +2017,30 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
 
     // ---- the input tile: this wave's 32 sub-image pixels (sub-rows 2w, 2w+1) x 160 channels as B fragments of the 16x16x32 MFMA
     // lane: column n = lane & 15 (sub-column), k = 8 (lane >> 4) + j
+    // r04: all 80 loads of a lane are requested before the first value is used (the accumulators are not live yet, so the registers
+    // are there): one memory round trip instead of ten dependent ones -- with one workgroup per CU nothing else hides them
+    // (measured, batch 128: 36k of the workgroup's 360k cycles were this gather, 44k the epilogue's residual loads, tile by tile).
     HFrag bh[5][2], bl[5][2];
     {
-        const float* Xb = X + (size_t)b * kF4Cin * HW;
+        float xv[2][5][8];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            const int pix = (4 * (2 * wave + u) + py) * 64 + 4 * (lane & 15) + px;
+            size_t xb; int cs;
+            lay_addr(layIn, kF4Cin, b, 4 * (2 * wave + u) + py, 4 * (lane & 15) + px, xb, cs);
+            const float* Xp = X + xb + (size_t)(8 * (lane >> 4)) * cs;
 #pragma unroll
-            for (int s5 = 0; s5 < 5; s5++) {
-                float v[8];
+            for (int s5 = 0; s5 < 5; s5++)
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = Xb[(size_t)(32 * s5 + 8 * (lane >> 4) + j) * HW + pix];
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) split_pair(v[2 * jj], v[2 * jj + 1], bh[s5][u].u[jj], bl[s5][u].u[jj]);
-            }
+                for (int j = 0; j < 8; j++) xv[u][s5][j] = Xp[(size_t)(32 * s5 + j) * cs];
         }
+        if (tid < 160) { sBN[tid] = scP[tile0 * 32 + tid]; sBN[160 + tid] = shP[tile0 * 32 + tid]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int s5 = 0; s5 < 5; s5++)
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) split_pair(xv[u][s5][2 * jj], xv[u][s5][2 * jj + 1], bh[s5][u].u[jj], bl[s5][u].u[jj]);
     }
     f32x16 pacc[5];
 #pragma unroll
@@ -1964,6 +2062,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
 
 #ifdef IVF_F4_TIMING
     unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long tk1 = tlast;
 #endif
     // ---- MFMA phase, branch-free form.  Intervals 0, 1 run P on zeroed operands (sD and the first two sWP slots are cleared in the
     // prologue), intervals 60, 61 run E into planes nobody reads: no `it`-dependent control flow inside the phase.
@@ -2077,6 +2176,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef IVF_F4_TIMING
+    const unsigned long long tk2 = __builtin_amdgcn_s_memtime();
     if (lane == 0 && (wave == 0 || wave == 4)) {
         for (int i = 0; i < 7; i++) atomicAdd(&g_f4Tim[(wave ? 8 : 0) + i], tacc[i]);
         atomicAdd(&g_f4Tim[(wave ? 8 : 0) + 7], 1ull);
@@ -2085,50 +2185,94 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
 
     // ---- epilogue: BN (+ residual) of the projection, 4-byte pieces (the sub-image's pixels are 4 apart)
     const int n = lane & 31;
-    const int pix = (4 * (2 * wave + (n >> 4)) + py) * 64 + 4 * (n & 15) + px;
+    const int oy = 4 * (2 * wave + (n >> 4)) + py, ox = 4 * (n & 15) + px;      // this lane's pixel
+    // the residual values of all five tiles are requested at once (the input fragments are dead: 80 registers), BN parameters from LDS.
+    // Lane's channels of tile t: cb + (q & 3) + 8 (q >> 2), cb = 32 (tile0 + t) + 4 (lane >> 5)
+    float rvAll[5][16];
+    if (RES && !SPLIT) {
+        size_t rb; int rcs;
+        lay_addr(layIn, Cout, b, oy, ox, rb, rcs);
+        const float* rp = res + rb + (size_t)(tile0 * 32 + 4 * (lane >> 5)) * rcs;
+#pragma unroll
+        for (int t = 0; t < 5; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) rvAll[t][q] = rp[(size_t)(t * 32 + (q & 3) + 8 * (q >> 2)) * rcs];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#ifdef IVF_F4_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tkA = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    size_t ob; int ocs;
+    lay_addr(layOut, Cout, b, oy, ox, ob, ocs);
+    float* const yp = (SPLIT ? part + (size_t)blockIdx.z * (nwg / 16) * Cout * HW : Y) + ob + (size_t)(tile0 * 32 + 4 * (lane >> 5)) * ocs;
 #pragma unroll
     for (int t = 0; t < 5; t++) {
-        const int cb = (tile0 + t) * 32 + 4 * (lane >> 5);
         float4 sc4[4], sh4[4];
 #pragma unroll
-        for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(scP + cb + 8 * g4); sh4[g4] = *(const float4*)(shP + cb + 8 * g4); }
-        const size_t ob = ((size_t)b * Cout + cb) * HW + pix;
-        if (SPLIT) {                            // raw sums of this range of hidden groups
-            float* pp = part + (size_t)blockIdx.z * (nwg / 16) * Cout * HW;
-#pragma unroll
-            for (int q = 0; q < 16; q++) pp[ob + (size_t)((q & 3) + 8 * (q >> 2)) * HW] = pacc[t][q];
-            continue;
-        }
-        float rv[16];
-        if (RES) {
-#pragma unroll
-            for (int q = 0; q < 16; q++) rv[q] = res[ob + (size_t)((q & 3) + 8 * (q >> 2)) * HW];
-        }
+        for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(sBN + t * 32 + 4 * (lane >> 5) + 8 * g4); sh4[g4] = *(const float4*)(sBN + 160 + t * 32 + 4 * (lane >> 5) + 8 * g4); }
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            float v = pacc[t][q] * vget<4>(sc4[q >> 2], q & 3) + vget<4>(sh4[q >> 2], q & 3);
-            if (RES) v += rv[q];
-            Y[ob + (size_t)((q & 3) + 8 * (q >> 2)) * HW] = v;
+            float v = pacc[t][q];                   // SPLIT: the raw sums of this range of hidden groups, in the OUTPUT layout
+            if (!SPLIT) {
+                v = v * vget<4>(sc4[q >> 2], q & 3) + vget<4>(sh4[q >> 2], q & 3);
+                if (RES) v += rvAll[t][q];
+            }
+            yp[(size_t)(t * 32 + (q & 3) + 8 * (q >> 2)) * ocs] = v;
         }
     }
+#ifdef IVF_F4_TIMING
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long tkB = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {
+        const unsigned long long tk3 = __builtin_amdgcn_s_memtime();
+        atomicAdd(&g_f4Whole[0], tk1 - tk0); atomicAdd(&g_f4Whole[1], tk2 - tk1); atomicAdd(&g_f4Whole[2], tk3 - tk2); atomicAdd(&g_f4Whole[3], 1ull);
+        atomicAdd(&g_f4Whole[4], tkA - tk2); atomicAdd(&g_f4Whole[5], tkB - tkA); atomicAdd(&g_f4Whole[6], tk3 - tkB);
+    }
+#endif
 }
 
 // the second half of a SPLIT launch: Y = (sum over the ranges, in index order) * scale + shift (+ residual); 4 pixels per thread
+// part and Y are in the output layout `layOut`, the residual (the block's input) in `layIn`.  In every layout the four elements of
+// a float4 are four pixels of ONE channel.
 __global__ __launch_bounds__(256) void k_fcn_split_reduce(const float* __restrict__ part, int nSplit, size_t splitStride, int Cout,
                                                           const float* __restrict__ scP, const float* __restrict__ shP,
-                                                          const float* __restrict__ res, float* __restrict__ Y, size_t total4)
+                                                          const float* __restrict__ res, float* __restrict__ Y, size_t total4,
+                                                          int layIn, int layOut)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
-    const int c = (int)((i / 1024) % (size_t)Cout);                  // 1024 float4 per 64 x 64 plane
     float4 a = ((const float4*)part)[i];
     for (int s = 1; s < nSplit; s++) {
         const float4 v = ((const float4*)(part + (size_t)s * splitStride))[i];
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
+    const size_t e = 4 * i, perImg = (size_t)Cout * 4096;
+    const int b = (int)(e / perImg);
+    const size_t w = e % perImg;
+    const int c = layOut ? (int)((w >> 8) % (size_t)Cout) : (int)(w >> 12);
     const float sc = scP[c], sh = shP[c];
     float4 o = make_float4(a.x * sc + sh, a.y * sc + sh, a.z * sc + sh, a.w * sc + sh);
-    if (res) { const float4 r = ((const float4*)res)[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+    if (res) {
+        float4 r;
+        if (layIn == layOut) r = ((const float4*)res)[i];
+        else {                                                       // the four pixels one by one through the input layout
+            float rr[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int y, x;
+                if (layOut) lay_pixel(layOut, (int)(w / ((size_t)Cout * 256)), (int)(w & 255) + k, y, x);
+                else { y = (int)((w & 4095) >> 6); x = (int)(w & 63) + k; }
+                size_t rb; int rcs;
+                lay_addr(layIn, Cout, b, y, x, rb, rcs);
+                rr[k] = res[rb + (size_t)c * rcs];
+            }
+            r = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        }
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
     ((float4*)Y)[i] = o;
 }
 
@@ -2156,13 +2300,14 @@ struct D2Cfg {
     static constexpr int KS = CIN / 32, TILES = COUT / 32, HID = 6 * CIN, NG = HID / 16;
     static constexpr int NPE = 2 * KS, NPP = 2 * TILES, NP = NPE + NPP + 1;              // 1 KB pieces per interval (+ parameters)
     static constexpr int WSLOT = (NPE + NPP) * 64;                                        // uint4 per weight slot
-    static constexpr size_t LDS = (size_t)2 * 16 * CS * 4 + (size_t)2 * 16 * kF4DP * 4 + (size_t)3 * WSLOT * 16 + 4 * kF4ParB;
+    static constexpr size_t LDS = (size_t)2 * 16 * CS * 4 + (size_t)2 * 16 * kF4DP * 4 + (size_t)3 * WSLOT * 16 + 4 * kF4ParB + 2 * COUT * 4;
 };
 
 template <int CIN, int COUT, bool RES, int DIL = 2, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ X, const uint4* __restrict__ WE, const float* __restrict__ par,
                                                      const uint4* __restrict__ WP, const float* __restrict__ scP, const float* __restrict__ shP,
-                                                     const float* __restrict__ res, float* __restrict__ Y, float* __restrict__ part)
+                                                     const float* __restrict__ res, float* __restrict__ Y, float* __restrict__ part,
+                                                     int layIn, int layOut)
 {
     using C = D2Cfg<CIN, COUT, DIL>;
     constexpr int kD2CS = C::CS, PITCH = C::PITCH, ROWS = C::ROWS, COLS = C::COLS;
@@ -2174,6 +2319,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
     float* const sD = sH + 2 * 16 * kD2CS;                          // [2][16 ch][kF4DP]
     uint4* const sW = (uint4*)(sD + 2 * 16 * kF4DP);                // [3 slots][E: KS x (hi, lo) | P: TILES x (hi, lo)][64 lanes]
     float* const sPar = (float*)(sW + 3 * WSLOT);                   // [4 slots][16 ch][12]
+    float* const sBN = sPar + 4 * (kF4ParB / 4);                    // [scale COUT | shift COUT] of the projection (epilogue)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;     // consecutive L on one XCD (grid x = 16 * images)
     const int b = L >> 4, py = DIL == 2 ? (L >> 3) & 1 : 0, px = DIL == 2 ? (L >> 2) & 1 : 0, strip = DIL == 2 ? L & 3 : L & 15;
@@ -2221,22 +2367,32 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
     const int rH = above ? ROWS * strip - 1 : ROWS * strip + ROWS, cH = DIL == 2 ? 16 * (wave & 1) : 16 * (wave & 3);   // halo block
     constexpr int SUB = 64 / DIL;                                                 // rows / columns of a sub-image
     const bool haloIn = hasHalo && rH >= 0 && rH < SUB;
+    // all of a lane's loads are requested before the first value is used (see k_fcn_irbd4)
     HFrag bh[KS][3], bl[KS][3];
     {
-        const float* Xb = X + (size_t)b * CIN * HW;
+        float xv[3][KS][8];
 #pragma unroll
         for (int u = 0; u < 3; u++) {
             const int r = u < 2 ? r0 : rH, c = (u < 2 ? c0 + 16 * u : cH) + (lane & 15);
             const bool ok = u < 2 || haloIn;
-            const int pix = ok ? (DIL * r + py) * 64 + DIL * c + px : 0;
+            size_t xb; int cs;
+            lay_addr(layIn, CIN, b, ok ? DIL * r + py : 0, ok ? DIL * c + px : 0, xb, cs);
+            const float* Xp = X + xb + (size_t)(8 * (lane >> 4)) * cs;
 #pragma unroll
-            for (int s = 0; s < KS; s++) {
-                float v[8];
+            for (int s = 0; s < KS; s++)
 #pragma unroll
-                for (int j = 0; j < 8; j++) { const float x = Xb[(size_t)(32 * s + 8 * (lane >> 4) + j) * HW + pix]; v[j] = ok ? x : 0.f; }
+                for (int j = 0; j < 8; j++) xv[u][s][j] = Xp[(size_t)(32 * s + j) * cs];
+        }
+        if (tid < COUT) { sBN[tid] = scP[tid]; sBN[COUT + tid] = shP[tid]; }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) split_pair(v[2 * jj], v[2 * jj + 1], bh[s][u].u[jj], bl[s][u].u[jj]);
-            }
+        for (int u = 0; u < 3; u++) {
+            const bool ok = u < 2 || haloIn;
+#pragma unroll
+            for (int s = 0; s < KS; s++)
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++)
+                    split_pair(ok ? xv[u][s][2 * jj] : 0.f, ok ? xv[u][s][2 * jj + 1] : 0.f, bh[s][u].u[jj], bl[s][u].u[jj]);
         }
     }
     f32x16 pacc[TILES];
@@ -2386,30 +2542,36 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
 
     // ---- epilogue: BN (+ residual) of the projection; pixel n of the wave's row -> image (2 r0 + py, 2 n + px)
     const int n = lane & 31;
-    const int pix = (DIL * r0 + py) * 64 + DIL * (c0 + n) + px;
+    const int oy = DIL * r0 + py, ox = DIL * (c0 + n) + px;         // this lane's pixel
+    // the residual values of all tiles are requested at once (the input fragments are dead), BN parameters from LDS
+    float rvAll[TILES][16];
+    if (RES && !SPLIT) {
+        size_t rb; int rcs;
+        lay_addr(layIn, COUT, b, oy, ox, rb, rcs);
+        const float* rp = res + rb + (size_t)(4 * (lane >> 5)) * rcs;
+#pragma unroll
+        for (int t = 0; t < TILES; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) rvAll[t][q] = rp[(size_t)(t * 32 + (q & 3) + 8 * (q >> 2)) * rcs];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    size_t ob; int ocs;
+    lay_addr(layOut, COUT, b, oy, ox, ob, ocs);
+    float* const yp = (SPLIT ? part + (size_t)blockIdx.z * (nwg / 16) * COUT * HW : Y) + ob + (size_t)(4 * (lane >> 5)) * ocs;
 #pragma unroll
     for (int t = 0; t < TILES; t++) {
         const int cb = t * 32 + 4 * (lane >> 5);
         float4 sc4[4], sh4[4];
 #pragma unroll
-        for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(scP + cb + 8 * g4); sh4[g4] = *(const float4*)(shP + cb + 8 * g4); }
-        const size_t ob = ((size_t)b * COUT + cb) * HW + pix;
-        if (SPLIT) {
-            float* pp = part + (size_t)blockIdx.z * (nwg / 16) * COUT * HW;
-#pragma unroll
-            for (int q = 0; q < 16; q++) pp[ob + (size_t)((q & 3) + 8 * (q >> 2)) * HW] = pacc[t][q];
-            continue;
-        }
-        float rv[16];
-        if (RES) {
-#pragma unroll
-            for (int q = 0; q < 16; q++) rv[q] = res[ob + (size_t)((q & 3) + 8 * (q >> 2)) * HW];
-        }
+        for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(sBN + cb + 8 * g4); sh4[g4] = *(const float4*)(sBN + COUT + cb + 8 * g4); }
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            float v = pacc[t][q] * vget<4>(sc4[q >> 2], q & 3) + vget<4>(sh4[q >> 2], q & 3);
-            if (RES) v += rv[q];
-            Y[ob + (size_t)((q & 3) + 8 * (q >> 2)) * HW] = v;
+            float v = pacc[t][q];                   // SPLIT: raw sums of this range of hidden groups, in the OUTPUT layout
+            if (!SPLIT) {
+                v = v * vget<4>(sc4[q >> 2], q & 3) + vget<4>(sh4[q >> 2], q & 3);
+                if (RES) v += rvAll[t][q];
+            }
+            yp[(size_t)(t * 32 + (q & 3) + 8 * (q >> 2)) * ocs] = v;
         }
     }
 }
@@ -2560,7 +2722,7 @@ void launch_gemm(const Gemm& g, const float* X, const float* res, float* Y, int 
         static const bool split9 = getenv("IVF_FCN_3X3_SPLIT") != nullptr;      // the r01 kernel: one workgroup per output-channel tile
         if (!old9 && !split9 && H == 64 && W == 64 && g.cin % 32 == 0 && g.act == 2 && !res && g.nTiles == 3)
             hipLaunchKernelGGL((k_fcn_conv3x3_all<3>), dim3(8 * B), dim3(256), 0, s, X, g.dWq, g.dScale, g.dShift, Y, g.cin, g.cout,
-                               (const float*)nullptr, 0.f, (float*)nullptr);
+                               (const float*)nullptr, 0.f, (float*)nullptr, (float*)nullptr);
         else if (!old9 && H == 64 && W == 64 && g.cin % 32 == 0 && g.act == 2 && !res)
             hipLaunchKernelGGL(k_fcn_conv3x3, dim3(8 * g.nTiles * B), dim3(256), 0, s, X, g.dWq, g.dScale, g.dShift, Y, g.cin, g.cout, g.nTiles);
         else launch_gemm_t<1, 3, 9>(g, X, res, Y, H, W, B, s);
@@ -2861,11 +3023,11 @@ int split_ways(int n, int groups, int cout)
     while (ns > 1 && (size_t)ns * n * cout * 4096 > kPartFloats) ns--;
     return std::max(ns, 1);
 }
-void launch_split_reduce(ivf_fcn* f, int ns, int n, int cout, const Gemm& pj, const float* res, float* y, hipStream_t s)
+void launch_split_reduce(ivf_fcn* f, int ns, int n, int cout, const Gemm& pj, const float* res, float* y, int layIn, int layOut, hipStream_t s)
 {
     const size_t total4 = (size_t)n * cout * 1024;
     hipLaunchKernelGGL(k_fcn_split_reduce, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, (const float*)f->bufPart, ns, (size_t)n * cout * 4096, cout,
-                       (const float*)pj.dScale, (const float*)pj.dShift, res, y, total4);
+                       (const float*)pj.dScale, (const float*)pj.dShift, res, y, total4, layIn, layOut);
 }
 
 // IVF_FCN_DEBUG=1: synchronise and check after every launch, naming the stage that failed
@@ -2897,6 +3059,29 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
         hipLaunchKernelGGL(k_fcn_conv0, dim3(1, kEnc / 2, n), dim3(256), 0, s, f->bufIn, f->dConv0W, f->dConv0S, f->dConv0B, f->bufA);
         STAGE("conv0");
     }
+    // which blocks run as ONE whole-block kernel of the 64 x 64 stage (k_fcn_irbd2 / k_fcn_irbd4), and the layout of every tensor
+    // between them: lay[i] = layout of block i's OUTPUT (0 planes, 1 NHWC8: producer AND consumer are such kernels, or the decoder)
+    static const int fused1 = getenv("IVF_FCN_NOFUSE") ? 0 : getenv("IVF_FCN_FUSED1") ? atoi(getenv("IVF_FCN_FUSED1")) : 1;
+    static const int fused2 = getenv("IVF_FCN_NOFUSE") ? 0 : getenv("IVF_FCN_FUSED2") ? atoi(getenv("IVF_FCN_FUSED2")) : 1;
+    static const int fused4 = getenv("IVF_FCN_NOFUSE") ? 0 : getenv("IVF_FCN_FUSED4") ? atoi(getenv("IVF_FCN_FUSED4")) : 1;
+    static const bool fuseLast = getenv("IVF_FCN_NOFUSELAST") == nullptr && getenv("IVF_FCN_OLD3X3") == nullptr &&
+                                 getenv("IVF_FCN_3X3_SPLIT") == nullptr;
+    static const int tileMask = getenv("IVF_FCN_TILED") ? atoi(getenv("IVF_FCN_TILED")) : 6;      // bit 0: lay 1 (measured slower: off), bit 1: lay 2, bit 2: lay 4
+    auto whole = [&](int i) {
+        if (i >= 4 && i <= 10 && (irbMask >> (i - 1) & 1)) return false;           // k_fcn_irb64 (opt-in) takes the block
+        if (i >= 4 && i <= 6) return fused1 && f->f1[i - 4].dWE != nullptr;
+        if (i >= 7 && i <= 13) return fused2 && f->f2[i - 7].dWE != nullptr;
+        if (i >= 14 && i <= 16) return fused4 && f->f4[i - 14].dWE != nullptr;
+        return false;
+    };
+    // lay[i] = layout of block i's OUTPUT = the tile layout of block i + 1 when both are whole-block kernels, planes otherwise
+    // (block 17 writes planes for the decoder, block 5 reads the planes of block 4)
+    int lay[18] = {};
+    for (int i = 4; i <= 15; i++)
+        if (whole(i) && whole(i + 1)) {
+            const int want = i + 1 <= 6 ? 1 : i + 1 <= 13 ? 2 : 4;
+            if (tileMask & want) lay[i] = want;
+        }
     float *x = f->bufA, *y = f->bufB;
     int H = kEnc / 2, W = kEnc / 2;
     size_t ip = 0, id = 0;
@@ -2939,14 +3124,14 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             std::swap(x, y);
             continue;
         }
-        static const int fused1 = getenv("IVF_FCN_NOFUSE") ? 0 : getenv("IVF_FCN_FUSED1") ? atoi(getenv("IVF_FCN_FUSED1")) : 1;
+        const int layIn = i >= 1 ? lay[i - 1] : 0, layOut = lay[i];
         if (fused1 && i >= 4 && i <= 6 && f->f1[i - 4].dWE && H == 64 && W == 64) {           // blocks 5-7: the same kernel on 4-row strips of the whole map
             const ivf_fcn::Fused4& F = f->f1[i - 4];
             const Gemm& pj = f->pw[ip + 1];
             bool ok = true;
             auto go = [&](auto kern, size_t lds) {                                               // LDS reserved per instantiation by reserve_lds()
                 hipLaunchKernelGGL(kern, dim3(16 * n), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, bk.res ? x : (const float*)nullptr, y,
-                                   (float*)nullptr);
+                                   (float*)nullptr, layIn, layOut);
             };
             if (bk.oup == 32 && bk.res) go(&k_fcn_irbd2<32, 32, true, 1>, D2Cfg<32, 32, 1>::LDS);
             else if (bk.oup == 64 && !bk.res) go(&k_fcn_irbd2<32, 64, false, 1>, D2Cfg<32, 64, 1>::LDS);
@@ -2957,7 +3142,6 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             std::swap(x, y);
             continue;
         }
-        static const int fused2 = getenv("IVF_FCN_NOFUSE") ? 0 : getenv("IVF_FCN_FUSED2") ? atoi(getenv("IVF_FCN_FUSED2")) : 1;
         if (fused2 && i >= 7 && i <= 13 && f->f2[i - 7].dWE && H == 64 && W == 64) {           // blocks 8-14: one kernel, no hidden tensor in HBM
             const ivf_fcn::Fused4& F = f->f2[i - 7];
             const Gemm& pj = f->pw[ip + 1];
@@ -2967,11 +3151,11 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             auto go = [&](auto kern, auto kernSplit, size_t lds) {                               // LDS reserved per instantiation by reserve_lds()
                 if (ns > 1) {
                     hipLaunchKernelGGL(kernSplit, dim3(16 * n, 1, ns), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y,
-                                       f->bufPart);
-                    launch_split_reduce(f, ns, n, bk.oup, pj, bk.res ? x : nullptr, y, s);
+                                       f->bufPart, layIn, layOut);
+                    launch_split_reduce(f, ns, n, bk.oup, pj, bk.res ? x : nullptr, y, layIn, layOut, s);
                 } else
                     hipLaunchKernelGGL(kern, dim3(16 * n), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, bk.res ? x : (const float*)nullptr, y,
-                                       (float*)nullptr);
+                                       (float*)nullptr, layIn, layOut);
             };
             if (bk.inp == 64 && bk.oup == 64 && bk.res) go(&k_fcn_irbd2<64, 64, true>, &k_fcn_irbd2<64, 64, true, 2, true>, D2Cfg<64, 64>::LDS);
             else if (bk.inp == 64 && bk.oup == 96 && !bk.res) go(&k_fcn_irbd2<64, 96, false>, &k_fcn_irbd2<64, 96, false, 2, true>, D2Cfg<64, 96>::LDS);
@@ -2984,7 +3168,6 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             std::swap(x, y);
             continue;
         }
-        static const int fused4 = getenv("IVF_FCN_NOFUSE") ? 0 : getenv("IVF_FCN_FUSED4") ? atoi(getenv("IVF_FCN_FUSED4")) : 1;
         if (fused4 && i >= 14 && f->f4[i - 14].dWE && H == 64 && W == 64) {      // blocks 15-17: one kernel, no hidden tensor in HBM
             const ivf_fcn::Fused4& F = f->f4[i - 14];
             const Gemm& pj = f->pw[ip + 1];
@@ -2995,13 +3178,14 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             const dim3 grid(16 * n, F.cout / 160, ns);
             if (ns > 1) {
                 hipLaunchKernelGGL((k_fcn_irbd4<false, true>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y,
-                                   F.cout, F.tilesP, f->bufPart);
-                launch_split_reduce(f, ns, n, F.cout, pj, bk.res ? x : nullptr, y, s);
+                                   F.cout, F.tilesP, f->bufPart, layIn, layOut);
+                launch_split_reduce(f, ns, n, F.cout, pj, bk.res ? x : nullptr, y, layIn, layOut, s);
             } else if (bk.res)
-                hipLaunchKernelGGL((k_fcn_irbd4<true>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, x, y, F.cout, F.tilesP, (float*)nullptr);
+                hipLaunchKernelGGL((k_fcn_irbd4<true>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, x, y, F.cout, F.tilesP, (float*)nullptr,
+                                   layIn, layOut);
             else
                 hipLaunchKernelGGL((k_fcn_irbd4<false>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y, F.cout, F.tilesP,
-                                   (float*)nullptr);
+                                   (float*)nullptr, layIn, layOut);
             if (probe4) {
                 FHIP(hipEventRecord(f->probe1[slot4], s)); f->probeBatch[slot4] = n; f->probeCount++;
                 snprintf(f->probeName, sizeof f->probeName, "ivffcn::k_fcn_irbd4<%s> %d->%d->%d", bk.res ? "true" : "false", bk.inp, hid, bk.oup);
@@ -3073,11 +3257,19 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
     {
         // decoder cbr (3x3 320->80 + BN + ReLU) and conv_last: one kernel when the all-tiles 3x3 kernel applies
         const Gemm& g = f->pw[ip++];
-        static const bool fuseLast = getenv("IVF_FCN_NOFUSELAST") == nullptr && getenv("IVF_FCN_OLD3X3") == nullptr &&
-                                     getenv("IVF_FCN_3X3_SPLIT") == nullptr;
         if (fuseLast && g.taps == 9 && H == 64 && W == 64 && g.cin % 32 == 0 && g.act == 2 && g.nTiles == 3) {
-            hipLaunchKernelGGL((k_fcn_conv3x3_all<3>), dim3(8 * n), dim3(256), 0, s, x, g.dWq, g.dScale, g.dShift, f->bufH1, g.cin, g.cout,
-                               (const float*)f->dLastW, f->lastBias, f->bufLogits);
+            // small batches: the 60 (tap row, K step) pairs in `nd` ranges over gridDim.y + k_fcn_dec_reduce (same rule as split_ways)
+            static const int splitMode = getenv("IVF_FCN_SPLIT") ? atoi(getenv("IVF_FCN_SPLIT")) : 1;
+            int nd = 1;
+            if (splitMode && g.cin == 320) { const int ways[] = {15, 10, 6, 5, 3, 2}; for (int w : ways) if (w * n <= 16) { nd = w; break; } }
+            if (nd > 1) {
+                hipLaunchKernelGGL((k_fcn_conv3x3_all<3>), dim3(8 * n, nd), dim3(256), 0, s, x, g.dWq, g.dScale, g.dShift, f->bufH1, g.cin, g.cout,
+                                   (const float*)nullptr, 0.f, (float*)nullptr, f->bufPart);
+                hipLaunchKernelGGL(k_fcn_dec_reduce, dim3(64, n), dim3(256), 0, s, (const float*)f->bufPart, nd, (size_t)n * g.cout * 4096, g.cout,
+                                   (const float*)g.dScale, (const float*)g.dShift, (const float*)f->dLastW, f->lastBias, f->bufLogits);
+            } else
+                hipLaunchKernelGGL((k_fcn_conv3x3_all<3>), dim3(8 * n), dim3(256), 0, s, x, g.dWq, g.dScale, g.dShift, f->bufH1, g.cin, g.cout,
+                                   (const float*)f->dLastW, f->lastBias, f->bufLogits, (float*)nullptr);
             STAGE("decoder cbr + conv_last");
         } else {
             launch_gemm(g, x, nullptr, f->bufH1, H, W, n, s);
@@ -3211,6 +3403,12 @@ void ivf_fcn_destroy(ivf_fcn* f)
             }
             unsigned long long z[16] = {};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(ivffcn::g_f4Tim), z, sizeof z);
+            unsigned long long wv[8] = {};
+            if (hipMemcpyFromSymbol(wv, HIP_SYMBOL(ivffcn::g_f4Whole), sizeof wv) == hipSuccess && wv[3])
+                fprintf(stderr, "[irbd4 whole] workgroups %llu; s_memtime ticks per workgroup (wave 0): prologue %.0f  interval loop %.0f  epilogue %.0f "
+                                "(residual loads issued -> landed %.0f, BN + stores issued %.0f, stores drained %.0f)\n",
+                        wv[3], (double)wv[0] / wv[3], (double)wv[1] / wv[3], (double)wv[2] / wv[3], (double)wv[4] / wv[3], (double)wv[5] / wv[3], (double)wv[6] / wv[3]);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(ivffcn::g_f4Whole), z, sizeof wv);
         }
     }
 #endif
