@@ -997,7 +997,7 @@ __global__ __launch_bounds__(256, 1) void k_fcn_conv3x3_all(const float* __restr
     struct XSet { float4 x[8]; float m; };
     uint4 A[NT][3][2];                                               // [tile][dx][hi, lo] of the CURRENT step
     const int nSteps = 3 * K16 / (int)gridDim.y, i0 = (int)blockIdx.y * nSteps, i1 = i0 + nSteps;     // this workgroup's (tap row, K step) pairs
-    int dyN = i0 / K16, sN = i0 % K16;                               // (tap row, K step) the next x load belongs to
+    int dyN = i0 % 3, sN = i0 / 3;                                   // (tap row, K step) the next x load belongs to
     auto load_x = [&](XSet& S) {
         const int yy = y + dyN - 1;
         const bool ok = yy >= 0 && yy < 64;
@@ -1005,11 +1005,14 @@ __global__ __launch_bounds__(256, 1) void k_fcn_conv3x3_all(const float* __restr
         const float* P = Xb + (size_t)16 * sN * HW + (ok ? yy : y) * 64;
 #pragma unroll
         for (int j = 0; j < 8; j++) S.x[j] = *(const float4*)(P + (size_t)j * HW);
-        if (++sN == K16) { sN = 0; if (dyN < 2) ++dyN; else sN = K16 - 1; }     // past the end: redundant re-load
+        // r04: the three tap rows of a K step are consecutive steps (step = 3 s + dy).  With the tap row as the OUTER loop a row was
+        // re-read a whole sweep over the 320 channels later (26 MB per XCD in between: gone from L2), 3.0x the input from the
+        // memory side (profiles/r03_pmc_hbm_traffic.json); now rows y - 1, y, y + 1 of one channel chunk follow each other.
+        if (++dyN == 3) { dyN = 0; if (sN < K16 - 1) ++sN; else dyN = 2; }      // past the end: redundant re-load of the last step
     };
-    auto load_a = [&](int n, int step) {                             // step = dy * K16 + s, clamped at the last one
+    auto load_a = [&](int n, int step) {                             // step = 3 s + dy, clamped at the last one
         step = min(step, 3 * K16 - 1);
-        const int dy = step / K16, s_ = step % K16;
+        const int dy = step % 3, s_ = step / 3;
 #pragma unroll
         for (int dx = 0; dx < 3; dx++) {
             const uint4* w = wq + ((size_t)((dy * 3 + dx) * K16 + s_) * NT + n) * 128;
@@ -3504,7 +3507,7 @@ int ivf_fcn_forward(ivf_fcn* f, const uint8_t* bgr, int width, int height, int s
     uint8_t* hIn = (uint8_t*)f->hPin; uint8_t* hU8 = hIn + inBytes; float* hF = (float*)(hU8 + outPx);
     for (int y = 0; y < height; y++) memcpy(hIn + (size_t)y * width * 3, bgr + (size_t)y * stride, (size_t)width * 3);
     FHIP(hipMemcpyAsync(f->dStageIn, hIn, inBytes, hipMemcpyHostToDevice, nullptr));
-    int rc = forward_device(f, f->dStageIn, inBytes, width * 3, 1, f->dStageU8, f->dStageF, nullptr);
+    int rc = forward_device(f, f->dStageIn, inBytes, width * 3, 1, cost_u8 ? f->dStageU8 : nullptr, cost_f32 ? f->dStageF : nullptr, nullptr);
     if (rc) return rc;
     if (cost_u8) FHIP(hipMemcpyAsync(hU8, f->dStageU8, outPx, hipMemcpyDeviceToHost, nullptr));
     if (cost_f32) FHIP(hipMemcpyAsync(hF, f->dStageF, outPx * sizeof(float), hipMemcpyDeviceToHost, nullptr));

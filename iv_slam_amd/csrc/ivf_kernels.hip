@@ -108,11 +108,11 @@ __global__ __launch_bounds__(256) void k_ingest(const Config* __restrict__ cfg, 
 // ------------------------------------------------------------------------------------------------
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 constexpr int kPyrTW = 256, kPyrTH = 32, kPyrRPT = kPyrTH / 4;             // rows per thread (4 waves stacked vertically)
-constexpr int kPyrTPW = 4;                                                  // tiles per workgroup (a column strip of 128 output rows)
+constexpr int kPyrTPW = 4;                                                  // tiles per workgroup in large batches (a column strip of 128 output rows)
 constexpr int kPyrSrcP = 544, kPyrSrcR = 2 * kPyrTH + 4;                    // LDS: 68 rows x 544 B (scale <= 2)
 __global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg, int level, const ResizeCoef* __restrict__ tab,
                                                  uint8_t* __restrict__ blobI, uint8_t* __restrict__ blobQ,
-                                                 const uint8_t* __restrict__ useCost, int nImg)
+                                                 const uint8_t* __restrict__ useCost, int nImg, int tpw)
 {
     __shared__ __attribute__((aligned(16))) uint8_t src[kPyrSrcR * kPyrSrcP];
     const LevelGeom& D = cfg->lv[level];
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg
     const int nq = (wx1 - wx0) / 16 + 1;
     // source rows of tile k of this workgroup
     auto tile_rows = [&](int k, int& dy0, int& wy0, int& nr) {
-        dy0 = (blockIdx.y * kPyrTPW + k) * kPyrTH;
+        dy0 = (blockIdx.y * tpw + k) * kPyrTH;
         if (dy0 >= D.h) { nr = 0; wy0 = 0; return; }
         const int dyl = min(dy0 + kPyrTH, D.h) - 1;
         wy0 = (int)(ty[dy0] & 0xffff);
@@ -217,12 +217,12 @@ __global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg
         };
         const unsigned colMask = x4 + 3 < D.w ? 0xffffffffu : (x4 >= D.w ? 0u : (0xffffffffu >> (8 * (x4 + 4 - D.w))));
         const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
-        for (int tk = 0; tk < kPyrTPW && nr > 0; tk++) {
+        for (int tk = 0; tk < tpw && nr > 0; tk++) {
             PYR_PUBLISH(nr);
             __syncthreads();
             const int cdy0 = dy0, cwy0 = wy0;
             tile_rows(tk + 1, dy0, wy0, nr);
-            if (tk + 1 < kPyrTPW && nr > 0) PYR_REQUEST(wy0, nr);   // in flight while this tile is computed
+            if (tk + 1 < tpw && nr > 0) PYR_REQUEST(wy0, nr);       // in flight while this tile is computed
             if (colIn) {
                 // a thread takes 8 CONSECUTIVE output rows: the lower source row of one output row is usually the upper one of the
                 // next (scale 1.2), so its horizontal pass is reused.  The wave index, hence every row index and row coefficient
@@ -277,8 +277,8 @@ __global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg
         sxk[k] = (int)(cx & 0xffff); sx1k[k] = min(sxk[k] + 1, S.w - 1);
         a0k[k] = (int)((cx >> 16) & 0xffff); a1k[k] = (int)((cx >> 32) & 0xffff);
     }
-    for (int rr = 0; rr < kPyrTPW * kPyrTH / 4; rr++) {
-        const int dy = blockIdx.y * kPyrTPW * kPyrTH + (tid >> 6) + 4 * rr;
+    for (int rr = 0; rr < tpw * kPyrTH / 4; rr++) {
+        const int dy = blockIdx.y * tpw * kPyrTH + (tid >> 6) + 4 * rr;
         if (dy >= D.h) break;
         const ResizeCoef cy = ty[dy];
         const int y0 = (int)(cy & 0xffff), y1 = min(y0 + 1, S.h - 1);
@@ -1897,11 +1897,12 @@ void launch_ingest(const Config& hc, const Config* dc, const Buffers& b, const u
 void launch_pyramid(const Config& hc, const Config* dc, const ResizeCoef* dTab, uint8_t* blob, uint8_t* qblob, const uint8_t* useCost,
                     int nImg, hipStream_t s)
 {
+    const int tpw = nImg >= 32 ? kPyrTPW : 1;       // a single frame (the per-call path) needs every tile as its own workgroup to fill the chip
     for (int l = 1; l < hc.nlevels; l++) {
         const LevelGeom& G = hc.lv[l];
         if (G.w <= 0 || G.h <= 0) continue;
-        dim3 grid((G.pitch + kPyrTW - 1) / kPyrTW, (G.h + kPyrTH * kPyrTPW - 1) / (kPyrTH * kPyrTPW), qblob ? 2 * nImg : nImg);
-        hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, s, dc, l, dTab, blob, qblob, useCost, nImg);
+        dim3 grid((G.pitch + kPyrTW - 1) / kPyrTW, (G.h + kPyrTH * tpw - 1) / (kPyrTH * tpw), qblob ? 2 * nImg : nImg);
+        hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, s, dc, l, dTab, blob, qblob, useCost, nImg, tpw);
     }
 }
 void launch_fast(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s)

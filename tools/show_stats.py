@@ -5,7 +5,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 div = float(sys.argv[2]) if len(sys.argv) > 2 else None
 tot = 0.0
 for r in rows:
-    n = re.sub(r'\(.*', '', r['Name']).replace('void ', '').replace('(anonymous namespace)::', '')
+    n = re.sub(r'\(.*', '', r['Name'].replace('(anonymous namespace)::', '')).replace('void ', '')
     if 'at::' in n or 'rocclr' in n or 'rccl' in n.lower():
         continue
     t = float(r['TotalDurationNs']) / 1e6
