@@ -410,6 +410,11 @@ struct ivf_extractor {
     int w = 0, h = 0;
     bool lastHadCost = false, extracted = false;
     uint8_t* dOne = nullptr;            // device byte "1"
+    // r04: every handle extracts on a stream of its own.  The reference runs the left and the right extractor on two host threads
+    // (ORB/src/Frame.cc:116-124) so that they overlap; on the NULL stream the two launch sequences queued one behind the other
+    // (bench.py latency_ms_batch1: 0.35 + 0.31 ms back to back).  ivf_extract returns only after its stream has drained, so every
+    // later reader of the handle's buffers (ivf_stereo_match, pyramid copies: NULL stream) sees them complete.
+    hipStream_t st = nullptr;
 };
 
 // kPipe batch contexts on kPipe internal streams: run k uses context k % kPipe, so the latency-bound tail of one batch
@@ -501,6 +506,7 @@ void ivf_extractor_destroy(ivf_extractor* e)
     if (!e) return;
     if (e->haveCtx) e->ctx.release();
     if (e->dOne) (void)hipFree(e->dOne);
+    if (e->st) (void)hipStreamDestroy(e->st);
     delete e;
 }
 
@@ -559,11 +565,13 @@ int ivf_extract(ivf_extractor* e, const uint8_t* image, int width, int height, i
         e->ctx.stageBytes = ((size_t)width * height * 2 + 15) & ~(size_t)15;       // keypoints / counters behind it stay 16-byte aligned
         if (hipMalloc(&e->ctx.dStage, e->ctx.stageBytes) != hipSuccess ||
             hipHostMalloc((void**)&e->ctx.hStage, e->ctx.stageBytes + (size_t)e->t.p.nfeatures * (sizeof(ivf_keypoint) + 32) + 64, hipHostMallocDefault) != hipSuccess ||
-            (!e->dOne && (hipMalloc(&e->dOne, 1) != hipSuccess || hipMemset(e->dOne, 1, 1) != hipSuccess))) {
+            (!e->dOne && (hipMalloc(&e->dOne, 1) != hipSuccess || hipMemset(e->dOne, 1, 1) != hipSuccess)) ||
+            (!e->st && hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking) != hipSuccess)) {
             e->ctx.release();
             return fail(IVF_E_NO_DEVICE, "staging allocation failed for a %dx%d extractor", width, height);
         }
         e->haveCtx = true; e->w = width; e->h = height;
+        HIPCHK(hipDeviceSynchronize());      // the context's buffers were cleared on the NULL stream: done before the handle's own stream touches them
     }
     e->extracted = false;
     Context& c = e->ctx;
@@ -577,15 +585,15 @@ int ivf_extract(ivf_extractor* e, const uint8_t* image, int width, int height, i
     for (int y = 0; y < height; y++) memcpy(hImg + (size_t)y * width, image + (size_t)y * stride, (size_t)width);
     const bool useCost = cost && e->t.p.enable_introspection;
     if (useCost) for (int y = 0; y < height; y++) memcpy(hCost + (size_t)y * width, cost + (size_t)y * cost_stride, (size_t)width);
-    HIPCHK(hipMemcpyAsync(dImg, hImg, useCost ? 2 * px : px, hipMemcpyHostToDevice, nullptr));
-    rc = c.run(dImg, dImg, useCost ? dCost : nullptr, px, width, px, width, 1, e->dOne, nullptr);
+    HIPCHK(hipMemcpyAsync(dImg, hImg, useCost ? 2 * px : px, hipMemcpyHostToDevice, e->st));
+    rc = c.run(dImg, dImg, useCost ? dCost : nullptr, px, width, px, width, 1, e->dOne, e->st);
     if (rc) return rc;
     // counts are not known before the kernels finish: fetch the count and the full-capacity result arrays in one go (56 KB at N = 1000)
-    HIPCHK(hipMemcpyAsync(hN, c.b.count, sizeof(int), hipMemcpyDeviceToHost, nullptr));
-    HIPCHK(hipMemcpyAsync(hN + 1, c.b.status, sizeof(int), hipMemcpyDeviceToHost, nullptr));
-    HIPCHK(hipMemcpyAsync(hK, c.b.kps, nfe * sizeof(ivf_keypoint), hipMemcpyDeviceToHost, nullptr));
-    HIPCHK(hipMemcpyAsync(hD, c.b.desc, nfe * 32, hipMemcpyDeviceToHost, nullptr));
-    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(hipMemcpyAsync(hN, c.b.count, sizeof(int), hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipMemcpyAsync(hN + 1, c.b.status, sizeof(int), hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipMemcpyAsync(hK, c.b.kps, nfe * sizeof(ivf_keypoint), hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipMemcpyAsync(hD, c.b.desc, nfe * 32, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipStreamSynchronize(e->st));
     const int n = *hN;
     if (hN[1]) { rc = c.check_status(); if (rc) return rc; }      // device-side flags raised: read, clear and report them
     e->lastHadCost = useCost; e->extracted = true;
