@@ -94,91 +94,71 @@ __global__ __launch_bounds__(256) void k_ingest(const Config* __restrict__ cfg, 
 // ONE launch per level serves the image pyramid (planes 0 .. nImg-1) and, when the batch carries cost maps, the cost pyramid of
 // the images whose extraction it gates (planes nImg .. 2 nImg - 1; a plane whose useCost bit 0 is clear -- the right images of
 // a stereo batch -- is skipped: nothing reads its upper levels).
-// A workgroup walks kPyrTPW vertically adjacent tiles of 256 x 32 output pixels, software-pipelined: the source rows of tile
-// k + 1 are requested (16-byte loads into registers, all of a thread's loads in flight together) BEFORE tile k is computed out
-// of LDS, so that a workgroup always has a tile's worth of bytes in flight (r03 / early r04: load -> barrier -> compute ->
-// store per workgroup, nothing overlapped inside it: 2.3 TB/s of the level's read + write bytes; r03 also staged by dwords with
-// an integer division per dword: 20 of its 49 VALU lane-instructions per output pixel).
+// One workgroup = 256 x 32 output pixels.  The source rows it needs are staged in LDS by 16-byte loads, all of a thread's loads
+// in flight together (r03 staged by dwords with an integer division per dword: 20 of its 49 VALU lane-instructions per output
+// pixel).  The LDS tile is sized per level by the host (dynamic LDS: 14 KB at the 1.2 ratio instead of the 37 KB a ratio of 2
+// needs) and the kernel keeps 40 registers, so eight workgroups share a CU: the kernel is bound by its dependent global -> LDS ->
+// register round trips, not by issue (0.44 of the VALU rate) or HBM (2.8 TB/s), and occupancy is what hides them.  (Measured and
+// dropped: workgroups walking four tiles with the next tile's loads in flight -- 36 more registers, half the occupancy, same time.)
 // A thread produces 4 adjacent pixels of 8 CONSECUTIVE rows.  Per source row it reads three aligned dwords, funnels them into
 // the 8-byte window its four columns draw from (v_alignbyte), picks each column's two source bytes as a u16 pair (v_perm with
-// a per-column selector computed once per workgroup) and gets p0*a0 + p1*a1 from one v_dot2_u32_u16; the row shared by two
-// consecutive output rows is computed once; row indices and row coefficients are wave-uniform (scalar).  One dword store per
-// row.  The per-column / per-row coefficients (fx = (float)((dx+0.5)*scale - 0.5), cvRound(f*2048) ...) come from a packed
-// table the host builds once per geometry exactly as OpenCV's resize does.
+// a per-column selector computed once) and gets p0*a0 + p1*a1 from one v_dot2_u32_u16; the row shared by two consecutive output
+// rows is computed once; row indices and row coefficients are wave-uniform (scalar).  One dword store per row.  The per-column /
+// per-row coefficients (fx = (float)((dx+0.5)*scale - 0.5), cvRound(f*2048) ...) come from a packed table the host builds once
+// per geometry exactly as OpenCV's resize does.
 // ------------------------------------------------------------------------------------------------
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 constexpr int kPyrTW = 256, kPyrTH = 32, kPyrRPT = kPyrTH / 4;             // rows per thread (4 waves stacked vertically)
-constexpr int kPyrTPW = 4;                                                  // tiles per workgroup in large batches (a column strip of 128 output rows)
-constexpr int kPyrSrcP = 544, kPyrSrcR = 2 * kPyrTH + 4;                    // LDS: 68 rows x 544 B (scale <= 2)
+constexpr int kPyrMaxP = 544, kPyrMaxR = 2 * kPyrTH + 4;                    // largest LDS tile: 68 rows x 544 B (level ratio <= 2)
 __global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg, int level, const ResizeCoef* __restrict__ tab,
                                                  uint8_t* __restrict__ blobI, uint8_t* __restrict__ blobQ,
-                                                 const uint8_t* __restrict__ useCost, int nImg, int tpw)
+                                                 const uint8_t* __restrict__ useCost, int nImg, int ldsPitch, int ldsRows)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t src[kPyrSrcR * kPyrSrcP];
+    extern __shared__ __attribute__((aligned(16))) uint8_t src[];           // ldsRows x ldsPitch bytes (ldsPitch % 16 == 0)
     const LevelGeom& D = cfg->lv[level];
     const LevelGeom& S = cfg->lv[level - 1];
     int img = blockIdx.z;
     uint8_t* blob = blobI;
     if (img >= nImg) { img -= nImg; blob = blobQ; if (!(useCost[img] & 1u)) return; }
-    const int dx0 = blockIdx.x * kPyrTW;
+    const int dx0 = blockIdx.x * kPyrTW, dy0 = blockIdx.y * kPyrTH;
     uint8_t* base = blob + (size_t)img * cfg->pyrBytes;
     const uint8_t* SP = base + S.off;
     const ResizeCoef* tx = tab + D.rtX;
     const ResizeCoef* ty = tab + D.rtY;
     const int tid = threadIdx.x;
-    // source columns of this strip (table entries hold the clamped source index); rows start 64-byte aligned, the window at a
+    // source window of this tile (table entries hold the clamped source index); rows start 64-byte aligned, the window at a
     // multiple of 16 bytes, and a pitched row always holds the whole last 16-byte piece
-    const int dxl = min(dx0 + kPyrTW, D.w) - 1;
+    const int dxl = min(dx0 + kPyrTW, D.w) - 1, dyl = min(dy0 + kPyrTH, D.h) - 1;
     const int wx0 = (int)(tx[dx0] & 0xffff) & ~15, wx1 = min((int)(tx[dxl] & 0xffff) + 1, S.w - 1);
-    const int nq = (wx1 - wx0) / 16 + 1;
-    // source rows of tile k of this workgroup
-    auto tile_rows = [&](int k, int& dy0, int& wy0, int& nr) {
-        dy0 = (blockIdx.y * tpw + k) * kPyrTH;
-        if (dy0 >= D.h) { nr = 0; wy0 = 0; return; }
-        const int dyl = min(dy0 + kPyrTH, D.h) - 1;
-        wy0 = (int)(ty[dy0] & 0xffff);
-        nr = min((int)(ty[dyl] & 0xffff) + 1, S.h - 1) - wy0 + 1;
-    };
-    int dy0, wy0, nr;
-    tile_rows(0, dy0, wy0, nr);
-    const bool fits = nq * 16 <= kPyrSrcP && nr <= kPyrSrcR && nq <= 64;        // level ratio <= 2 (uniform over the level's tiles)
+    const int wy0 = (int)(ty[dy0] & 0xffff), wy1 = min((int)(ty[dyl] & 0xffff) + 1, S.h - 1);
+    const int nq = (wx1 - wx0) / 16 + 1, nr = wy1 - wy0 + 1;
+    const bool fits = nq * 16 <= ldsPitch && nr <= ldsRows && nq <= 64;
     if (fits) {
         // 8 rows x 32 pieces per pass; the 33rd / 34th piece of a row at ratios near 2 in a second, narrow sweep
-        constexpr int kIt = (kPyrSrcR + 7) / 8;
+        constexpr int kIt = (kPyrMaxR + 7) / 8;
         const int qc = tid & 31, r0 = tid >> 5;
-        static_assert(kIt == 9, "PYR_EACH lists the staging passes");
-        // nine named registers quads, not an array: an array that lives across the tile loop is left in scratch memory by the compiler
-        uint4 v0, v1, v2, v3, v4, v5, v6, v7, v8, vx0, vx1;
-#define PYR_EACH(X) X(0, v0) X(1, v1) X(2, v2) X(3, v3) X(4, v4) X(5, v5) X(6, v6) X(7, v7) X(8, v8)
-#define PYR_LOAD1(k_, v_) v_ = *(const uint4*)((qc < nq && r0 + 8 * k_ < nrq_) ? gp_ + (size_t)(r0 + 8 * k_) * S.pitch : SP);
-#define PYR_STORE1(k_, v_) if (qc < nq && r0 + 8 * k_ < nrq_) *(uint4*)(src + (r0 + 8 * k_) * kPyrSrcP + 16 * qc) = v_;
-#define PYR_REQUEST(wy0_, nr_)                                                                                           \
-        do {                                                                                                             \
-            const uint8_t* gp_ = SP + (size_t)(wy0_) * S.pitch + wx0 + 16 * qc;                                          \
-            const int nrq_ = (nr_);                                                                                      \
-            PYR_EACH(PYR_LOAD1)                                                                                          \
-            if (nq > 32) {                       /* pieces 32, 33: thread = (row tid >> 1 (+ 128), piece 32 + (tid & 1)) */ \
-                const int q_ = 32 + (tid & 1), ra_ = tid >> 1, rb_ = ra_ + 128;                                          \
-                vx0 = *(const uint4*)((q_ < nq && ra_ < nrq_) ? SP + (size_t)((wy0_) + ra_) * S.pitch + wx0 + 16 * q_ : SP);  \
-                vx1 = *(const uint4*)((q_ < nq && rb_ < nrq_ && rb_ < kPyrSrcR) ? SP + (size_t)((wy0_) + rb_) * S.pitch + wx0 + 16 * q_ : SP); \
-            }                                                                                                            \
-        } while (0)
-#define PYR_PUBLISH(nr_)                                                                                                 \
-        do {                                                                                                             \
-            const int nrq_ = (nr_);                                                                                      \
-            PYR_EACH(PYR_STORE1)                                                                                         \
-            if (nq > 32) {                                                                                               \
-                const int q_ = 32 + (tid & 1), ra_ = tid >> 1, rb_ = ra_ + 128;                                          \
-                if (q_ < nq && ra_ < nrq_) *(uint4*)(src + ra_ * kPyrSrcP + 16 * q_) = vx0;                              \
-                if (q_ < nq && rb_ < nrq_ && rb_ < kPyrSrcR) *(uint4*)(src + rb_ * kPyrSrcP + 16 * q_) = vx1;            \
-            }                                                                                                            \
-        } while (0)
-        vx0 = vx1 = make_uint4(0u, 0u, 0u, 0u);
-        PYR_REQUEST(wy0, nr);
+        uint4 v[kIt];
+        const uint8_t* gp = SP + (size_t)wy0 * S.pitch + wx0 + 16 * qc;
+#pragma unroll
+        for (int k = 0; k < kIt; k++) {
+            const bool ok = qc < nq && r0 + 8 * k < nr;
+            v[k] = *(const uint4*)(ok ? gp + (size_t)(r0 + 8 * k) * S.pitch : SP);
+        }
+#pragma unroll
+        for (int k = 0; k < kIt; k++)
+            if (qc < nq && r0 + 8 * k < nr) *(uint4*)(src + (r0 + 8 * k) * ldsPitch + 16 * qc) = v[k];
+        if (nq > 32)
+            for (int i = tid; i < (nq - 32) * nr; i += 256) {
+                const int r = i / (nq - 32), q = 32 + i % (nq - 32);
+                *(uint4*)(src + r * ldsPitch + 16 * q) = *(const uint4*)(SP + (size_t)(wy0 + r) * S.pitch + wx0 + 16 * q);
+            }
+    }
+    __syncthreads();
+    if (fits) {
+        const int x4 = dx0 + (tid & 63) * 4;
+        if (x4 >= D.pitch) return;
         // per column: the two source bytes as a zero-extended u16 pair picked out of the 8-byte window that starts at the first
         // column's source byte, and the coefficient pair
-        const int x4 = dx0 + (tid & 63) * 4;
-        const bool colIn = x4 < D.pitch;
         unsigned sel[4], coef[4];
         int sxs[4], sx1s[4];
 #pragma unroll
@@ -196,17 +176,18 @@ __global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg
             const int b = k < 2 ? sxs[0] : base2;
             sel[k] = (unsigned)(sxs[k] - b) | 0x0c00u | ((unsigned)(sx1s[k] - b) << 16) | 0x0c000000u;
         }
-        const int wbyte = colIn ? sxs[0] - wx0 : 0, wsh = wbyte & 3, wbyte2 = colIn ? base2 - wx0 : 0, wsh2 = wbyte2 & 3;
+        const int wbyte = sxs[0] - wx0, wsh = wbyte & 3, wbyte2 = base2 - wx0, wsh2 = wbyte2 & 3;
         const unsigned* wrow = (const unsigned*)(src + (wbyte & ~3));
         const unsigned* wrow2 = (const unsigned*)(src + (wbyte2 & ~3));
+        const int rowDw = ldsPitch / 4;
         // (h >> 4) of the four columns on staged row r
         auto hpass = [&](int r, unsigned (&h)[4]) {
-            const unsigned* w = wrow + r * (kPyrSrcP / 4);
+            const unsigned* w = wrow + r * rowDw;
             const unsigned d0 = w[0], d1 = w[1], d2 = w[2];
             const unsigned lo = __builtin_amdgcn_alignbyte(d1, d0, wsh), hi = __builtin_amdgcn_alignbyte(d2, d1, wsh);
             unsigned lo2 = lo, hi2 = hi;
             if (wide) {
-                const unsigned* w2 = wrow2 + r * (kPyrSrcP / 4);
+                const unsigned* w2 = wrow2 + r * rowDw;
                 const unsigned e0 = w2[0], e1 = w2[1], e2 = w2[2];
                 lo2 = __builtin_amdgcn_alignbyte(e1, e0, wsh2); hi2 = __builtin_amdgcn_alignbyte(e2, e1, wsh2);
             }
@@ -216,53 +197,37 @@ __global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg
                                               __builtin_bit_cast(u16x2, coef[k]), 0u, false) >> 4;
         };
         const unsigned colMask = x4 + 3 < D.w ? 0xffffffffu : (x4 >= D.w ? 0u : (0xffffffffu >> (8 * (x4 + 4 - D.w))));
-        const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
-        for (int tk = 0; tk < tpw && nr > 0; tk++) {
-            PYR_PUBLISH(nr);
-            __syncthreads();
-            const int cdy0 = dy0, cwy0 = wy0;
-            tile_rows(tk + 1, dy0, wy0, nr);
-            if (tk + 1 < tpw && nr > 0) PYR_REQUEST(wy0, nr);       // in flight while this tile is computed
-            if (colIn) {
-                // a thread takes 8 CONSECUTIVE output rows: the lower source row of one output row is usually the upper one of the
-                // next (scale 1.2), so its horizontal pass is reused.  The wave index, hence every row index and row coefficient
-                // below, is uniform: scalar registers and scalar branches
-                const int dyFirst = cdy0 + kPyrRPT * uw;
-                unsigned hA[4], hB[4];
-                int rowA = -1, rowB = -1;           // staged rows held in hA / hB
-                uint8_t* outp = base + D.off + (size_t)dyFirst * D.pitch + x4;
+        // a thread takes 8 CONSECUTIVE output rows: the lower source row of one output row is usually the upper one of the
+        // next (scale 1.2), so its horizontal pass is reused.  The wave index, hence every row index and row coefficient
+        // below, is uniform: scalar registers and scalar branches
+        const int dyFirst = dy0 + kPyrRPT * __builtin_amdgcn_readfirstlane(tid >> 6);
+        unsigned hA[4], hB[4];
+        int rowA = -1, rowB = -1;                   // staged rows held in hA / hB
+        uint8_t* outp = base + D.off + (size_t)dyFirst * D.pitch + x4;
 #pragma unroll
-                for (int rr = 0; rr < kPyrRPT; rr++) {
-                    const int dy = dyFirst + rr;
-                    if (dy >= D.h) break;
-                    const ResizeCoef cy = ty[dy];
-                    const int y0 = (int)(cy & 0xffff), y1 = min(y0 + 1, S.h - 1);
-                    const unsigned b0 = (unsigned)((cy >> 16) & 0xffff), b1 = (unsigned)((cy >> 32) & 0xffff);
-                    if (y0 - cwy0 == rowB) {
+        for (int rr = 0; rr < kPyrRPT; rr++) {
+            const int dy = dyFirst + rr;
+            if (dy >= D.h) break;
+            const ResizeCoef cy = ty[dy];
+            const int y0 = (int)(cy & 0xffff), y1 = min(y0 + 1, S.h - 1);
+            const unsigned b0 = (unsigned)((cy >> 16) & 0xffff), b1 = (unsigned)((cy >> 32) & 0xffff);
+            if (y0 - wy0 == rowB) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) hA[k] = hB[k];
-                        rowA = rowB;
-                    } else if (y0 - cwy0 != rowA) { hpass(y0 - cwy0, hA); rowA = y0 - cwy0; }
-                    if (y1 - cwy0 == rowA) {
+                for (int k = 0; k < 4; k++) hA[k] = hB[k];
+                rowA = rowB;
+            } else if (y0 - wy0 != rowA) { hpass(y0 - wy0, hA); rowA = y0 - wy0; }
+            if (y1 - wy0 == rowA) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) hB[k] = hA[k];
-                        rowB = rowA;
-                    } else if (y1 - cwy0 != rowB) { hpass(y1 - cwy0, hB); rowB = y1 - cwy0; }
-                    // every term is below 2^27 (coefficients <= 2048, h >> 4 <= 32640) and the result below 256: 24-bit multiplies, no masks
-                    unsigned out = 0;
+                for (int k = 0; k < 4; k++) hB[k] = hA[k];
+                rowB = rowA;
+            } else if (y1 - wy0 != rowB) { hpass(y1 - wy0, hB); rowB = y1 - wy0; }
+            // every term is below 2^27 (coefficients <= 2048, h >> 4 <= 32640) and the result below 256: 24-bit multiplies, no masks
+            unsigned out = 0;
 #pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        out |= (((__umul24(b0, hA[k]) >> 16) + (__umul24(b1, hB[k]) >> 16) + 2u) >> 2) << (8 * k);
-                    *(unsigned*)(outp + (size_t)rr * D.pitch) = out & colMask;
-                }
-            }
-            __syncthreads();                        // the tile has been read: the next one may overwrite it
+            for (int k = 0; k < 4; k++)
+                out |= (((__umul24(b0, hA[k]) >> 16) + (__umul24(b1, hB[k]) >> 16) + 2u) >> 2) << (8 * k);
+            *(unsigned*)(outp + (size_t)rr * D.pitch) = out & colMask;
         }
-#undef PYR_REQUEST
-#undef PYR_PUBLISH
-#undef PYR_EACH
-#undef PYR_LOAD1
-#undef PYR_STORE1
         return;
     }
     // level ratios above 2 (source window larger than the LDS tile): per-pixel evaluation straight from global memory
@@ -277,8 +242,8 @@ __global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg
         sxk[k] = (int)(cx & 0xffff); sx1k[k] = min(sxk[k] + 1, S.w - 1);
         a0k[k] = (int)((cx >> 16) & 0xffff); a1k[k] = (int)((cx >> 32) & 0xffff);
     }
-    for (int rr = 0; rr < tpw * kPyrTH / 4; rr++) {
-        const int dy = blockIdx.y * tpw * kPyrTH + (tid >> 6) + 4 * rr;
+    for (int rr = 0; rr < kPyrTH / 4; rr++) {
+        const int dy = dy0 + (tid >> 6) + 4 * rr;
         if (dy >= D.h) break;
         const ResizeCoef cy = ty[dy];
         const int y0 = (int)(cy & 0xffff), y1 = min(y0 + 1, S.h - 1);
@@ -1897,12 +1862,19 @@ void launch_ingest(const Config& hc, const Config* dc, const Buffers& b, const u
 void launch_pyramid(const Config& hc, const Config* dc, const ResizeCoef* dTab, uint8_t* blob, uint8_t* qblob, const uint8_t* useCost,
                     int nImg, hipStream_t s)
 {
-    const int tpw = nImg >= 32 ? kPyrTPW : 1;       // a single frame (the per-call path) needs every tile as its own workgroup to fill the chip
+    static const bool ldsOk = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_down), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  kPyrMaxR * kPyrMaxP) == hipSuccess;
+    (void)ldsOk;
     for (int l = 1; l < hc.nlevels; l++) {
         const LevelGeom& G = hc.lv[l];
+        const LevelGeom& S = hc.lv[l - 1];
         if (G.w <= 0 || G.h <= 0) continue;
-        dim3 grid((G.pitch + kPyrTW - 1) / kPyrTW, (G.h + kPyrTH * tpw - 1) / (kPyrTH * tpw), qblob ? 2 * nImg : nImg);
-        hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, s, dc, l, dTab, blob, qblob, useCost, nImg, tpw);
+        // LDS tile of this level: the source rows / bytes a 256 x 32 tile can draw from at this level ratio (+ alignment slack); a
+        // ratio above 2 does not fit kPyrMaxR x kPyrMaxP and takes the kernel's un-staged path
+        const int rows = std::min(kPyrMaxR, (int)((double)kPyrTH * S.h / G.h) + 4);
+        const int pitch = std::min(kPyrMaxP, (((int)((double)kPyrTW * S.w / G.w) + 2 + 15 + 16) / 16) * 16);
+        dim3 grid((G.pitch + kPyrTW - 1) / kPyrTW, (G.h + kPyrTH - 1) / kPyrTH, qblob ? 2 * nImg : nImg);
+        hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), (size_t)rows * pitch, s, dc, l, dTab, blob, qblob, useCost, nImg, pitch, rows);
     }
 }
 void launch_fast(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s)
