@@ -988,7 +988,7 @@ __global__ __launch_bounds__(256) void k_cell_qsum(const Config* __restrict__ cf
     if (lane == 0) cellInfo[(size_t)img * cfg->nCellsTotal + cell].nTotal = (int)qs;
 }
 
-constexpr int kCellCapSmall = 1024, kCellCapBig = 4096;
+constexpr int kCellCapTiny = 256, kCellCapSmall = 1024, kCellCapBig = 4096;
 __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, const int* __restrict__ cellCnt,
                                               const uint8_t* __restrict__ qpyr, const uint8_t* __restrict__ useCost,
                                               CellInfo* __restrict__ cellInfo, int* __restrict__ lvlTotal,
@@ -1084,7 +1084,7 @@ template <int CAP, int NTHR>
 __global__ __launch_bounds__(NTHR) void k_cell_select(const Config* __restrict__ cfg, const unsigned* __restrict__ tileList,
                                                    const int* __restrict__ tileCnt, const CellInfo* __restrict__ cellInfo,
                                                    const uint8_t* __restrict__ qpyr, const uint8_t* __restrict__ useCost,
-                                                   u64* __restrict__ lvlList, int* __restrict__ status, int pass)
+                                                   u64* __restrict__ lvlList, int* __restrict__ status, int nLo, int nHi)
 {
     __shared__ __attribute__((aligned(16))) unsigned keys[CAP];
     __shared__ __attribute__((aligned(16))) u64 ord[CAP];
@@ -1106,7 +1106,7 @@ __global__ __launch_bounds__(NTHR) void k_cell_select(const Config* __restrict__
     const CellInfo info = cellInfo[(size_t)img * cfg->nCellsTotal + gc];
     const int nT = info.nTotal, nR = info.nRetain;
     if (nT <= 0) return;
-    if (pass == 0 ? nT > kCellCapSmall : nT <= kCellCapSmall) return;
+    if (nT <= nLo || nT > nHi) return;                               // this launch's tier: cells with nLo < survivors <= nHi
     const int mode = (cfg->introspection && (useCost[img] & 1)) ? 1 : 0;
     const uint8_t* Q = mode ? qpyr + (size_t)img * cfg->pyrBytes + G.off : nullptr;
     const unsigned th = info.useMin ? 1u : (unsigned)cfg->iniTh;
@@ -1896,10 +1896,14 @@ void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nIm
         hipLaunchKernelGGL(k_cell_qsum, dim3((hc.nCellsTotal + 3) / 4, nImg), dim3(256), 0, s, dc, b.qpyr, b.useCost, (CellInfo*)b.cellInfo);
     hipLaunchKernelGGL(k_quota, dim3(hc.nlevels, nImg), dim3(256), 0, s, dc, b.cellCnt, b.qpyr, b.useCost,
                        (CellInfo*)b.cellInfo, b.lvlTotal, b.hugeCount, b.hugeList, b.status);
+    // three tiers by survivor count: the kernel is a chain of dependent LDS steps at one wave per cell, so its throughput is the
+    // number of cells in flight per CU = LDS per workgroup: 5 KB (<= 256 survivors), 14 KB (<= 1024), 51 KB (<= 4096, four waves; a 2048 tier of two waves measured slower: 77 + 42 vs 109 us)
+    hipLaunchKernelGGL((k_cell_select<kCellCapTiny, 64>), dim3(hc.nCellsTotal, nImg), dim3(64), 0, s, dc, b.tileList, b.tileCnt,
+                       (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, 0, kCellCapTiny);
     hipLaunchKernelGGL((k_cell_select<kCellCapSmall, 64>), dim3(hc.nCellsTotal, nImg), dim3(64), 0, s, dc, b.tileList, b.tileCnt,
-                       (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, 0);
+                       (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, kCellCapTiny, kCellCapSmall);
     hipLaunchKernelGGL((k_cell_select<kCellCapBig, 256>), dim3(hc.nCellsTotal, nImg), dim3(256), 0, s, dc, b.tileList, b.tileCnt,
-                       (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, 1);
+                       (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, kCellCapSmall, kCellCapBig);
     if (b.hugeScratch)       // geometry allows cells with more than kCellCapBig strict maxima: walk k_quota's (usually empty) list
         hipLaunchKernelGGL(k_cell_select_huge, dim3(kHugeSlots), dim3(1024), 0, s, dc, b.tileList, b.tileCnt, (const CellInfo*)b.cellInfo,
                            b.qpyr, b.useCost, b.lvl, b.status, b.hugeCount, b.hugeList, b.hugeScratch, hc.maxCandCap);
