@@ -2237,6 +2237,248 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
 #endif
 }
 
+// ---- k_fcn_irbd4w (r04): the same block with ROLE-SPECIALISED waves ----
+// k_fcn_irbd4 runs eight waves that each hold the input fragments (80 registers) AND the projection accumulators (80): two waves per
+// SIMD, whose MFMA phase, stencil phase and weight requests add up instead of overlapping (interval = MFMA cycles of ONE wave + ~2,200;
+// matrix pipe busy 0.41-0.48).  Here a 1,024-thread workgroup has sixteen waves of <= 128 registers, four per SIMD:
+//   waves 0-7   E role: hold the input fragments; per interval E(it) = 30 x v_mfma_f32_16x16x32_f16 + BN + ReLU6 -> sH
+//   waves 8-15  P role: hold the accumulators; per interval P(it - 2) = 15 x v_mfma_f32_32x32x16_f16; request the weights by LDS-DMA;
+//               prologue (LDS set-up) and epilogue (residual, BN, stores)
+//   all sixteen S(it - 1): wave w = hidden channel w of the group, lane = (sub-row, quarter row of 4 pixels)
+// Each role is its own loop (the register allocator sees the fragments and the accumulators in different branches); both loops meet at
+// ONE s_barrier per interval.  Every SIMD hosts two E and two P waves: each needs the matrix pipe for 480 of the interval's cycles, so
+// the pipe's 1,920 busy cycles come from four instruction streams instead of two, and the stencil's VALU work is spread over all of them.
+__device__ int g_wAbl = 0;      // timing experiments only (IVF_FCN_WABL; results wrong): 1 no stencil, 2 no weight DMA in the loop, 4 E fragments read once,
+                                // 8 no E MFMAs, 16 no P MFMAs, 32 no E epilogue, 64 P fragments read once, 128 no barrier in the loop
+template <bool RES, bool SPLIT = false>
+__global__ __launch_bounds__(1024) void k_fcn_irbd4w(const float* __restrict__ X, const uint4* __restrict__ WE, const float* __restrict__ par,
+                                                    const uint4* __restrict__ WP, const float* __restrict__ scP, const float* __restrict__ shP,
+                                                    const float* __restrict__ res, float* __restrict__ Y, int Cout, int tilesP, float* __restrict__ part,
+                                                    int layIn, int layOut)
+{
+    const int g0 = SPLIT ? (int)(blockIdx.z * kF4Groups / gridDim.z) : 0, g1 = SPLIT ? (int)((blockIdx.z + 1) * kF4Groups / gridDim.z) : kF4Groups;
+    extern __shared__ __attribute__((aligned(16))) uint4 f4smem[];
+    float* const sH = (float*)f4smem;                               // [2][16 ch][kF4CS >= 16 rows x kF4HP]
+    float* const sD = sH + 2 * 16 * kF4CS;                          // [2][16 ch][kF4DP]
+    uint4* const sWE = (uint4*)(sD + 2 * 16 * kF4DP);               // [slots][5 K steps][hi, lo][64 lanes]
+    uint4* const sWP = sWE + kF4WSlots * 640;                       // [slots][5 tiles][hi, lo][64 lanes]
+    float* const sPar = (float*)(sWP + kF4WSlots * 640);            // [slots][16 ch][12]
+    float* const sBN = sPar + kF4PSlots * (kF4ParB / 4);            // [scale 160 | shift 160] of the projection (epilogue)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6), w8 = uwave & 7;
+    const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;     // consecutive L on one XCD (grid x = 16 * images)
+    const int b = L >> 4, py = (L >> 2) & 3, px = L & 3;
+    const int tile0 = blockIdx.y * 5;
+    constexpr int HW = 4096;
+    const int abl = g_wAbl;
+
+    // ---- S(it - 1), all sixteen waves: 3x3 on the 16 x 16 plane of channel `uwave` of group it - 1, + BN + ReLU6.  Lane = (sub-row, quarter);
+    // a DPP row of 16 lanes = four sub-rows x four quarters: the pixel beside a quarter comes from lane -1 / +1, none at the row's ends
+    const int ssr = lane >> 2, sq = lane & 3;
+    const float rowM0 = ssr > 0 ? 1.f : 0.f, rowM2 = ssr < 15 ? 1.f : 0.f;
+    const int srow0 = uwave * kF4CS + (ssr > 0 ? ssr - 1 : ssr) * kF4HP + 4 * sq, srow1 = uwave * kF4CS + ssr * kF4HP + 4 * sq,
+              srow2 = uwave * kF4CS + (ssr < 15 ? ssr + 1 : ssr) * kF4HP + 4 * sq;
+    const float mL = sq > 0 ? 1.f : 0.f, mR = sq < 3 ? 1.f : 0.f;
+    auto stencil_phase = [&](int it) {
+        const int g = it - 1;
+        if (g < g0 || g >= g1 || (abl & 1)) return;
+        const float* hp = sH + (g & 1) * (16 * kF4CS);
+        const float4* pq = (const float4*)(sPar + (g % kF4PSlots) * (kF4ParB / 4) + uwave * 12);
+        const float4 w03 = pq[0], w47 = pq[1], w8s = pq[2];          // taps 0-3 | 4-7 | tap 8, shift, (expansion BN)
+        float o[4] = {w8s.y, w8s.y, w8s.y, w8s.y};
+        const int ro[3] = {srow0, srow1, srow2};
+        const float wk[9] = {w03.x * rowM0, w03.y * rowM0, w03.z * rowM0, w03.w, w47.x, w47.y, w47.z * rowM2, w47.w * rowM2, w8s.x * rowM2};
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+            const float4 a = *(const float4*)(hp + ro[ky]);
+            const float own[4] = {a.x, a.y, a.z, a.w};
+            const float w0 = wk[3 * ky], w1 = wk[3 * ky + 1], w2 = wk[3 * ky + 2];
+            const float w0L = w0 * mL, w2R = w2 * mR;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                o[p] = __builtin_fmaf(own[p], w1, o[p]);
+                if (p > 0) o[p] = __builtin_fmaf(own[p - 1], w0, o[p]);
+                else asm("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(o[p]) : "v"(own[3]), "v"(w0L));
+                if (p < 3) o[p] = __builtin_fmaf(own[p + 1], w2, o[p]);
+                else asm("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(o[p]) : "v"(own[0]), "v"(w2R));
+            }
+        }
+        *(float4*)(sD + (g & 1) * (16 * kF4DP) + uwave * kF4DP + ssr * 16 + 4 * sq) =
+            make_float4(__builtin_amdgcn_fmed3f(o[0], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[1], 0.f, 6.f),
+                        __builtin_amdgcn_fmed3f(o[2], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[3], 0.f, 6.f));
+    };
+
+    if (uwave < 8) {
+        // ================= E role =================
+        HFrag bh[5][2], bl[5][2];
+        {
+            float xv[2][5][8];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                size_t xb; int cs;
+                lay_addr(layIn, kF4Cin, b, 4 * (2 * w8 + u) + py, 4 * (lane & 15) + px, xb, cs);
+                const float* Xp = X + xb + (size_t)(8 * (lane >> 4)) * cs;
+#pragma unroll
+                for (int s5 = 0; s5 < 5; s5++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) xv[u][s5][j] = Xp[(size_t)(32 * s5 + j) * cs];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int s5 = 0; s5 < 5; s5++)
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) split_pair(xv[u][s5][2 * jj], xv[u][s5][2 * jj + 1], bh[s5][u].u[jj], bl[s5][u].u[jj]);
+        }
+        __syncthreads();
+        for (int it = g0; it < g1 + 2; it++) {
+            if (it < g1) {                      // E(it): hidden group `it` = W_E[16 x 160] . X[160 x 32 pixels of this wave]
+                const int cur = it & 1, ws = it % kF4WSlots;
+                const uint4* wE = sWE + ws * 640 + lane;
+                const float* pp = sPar + (it % kF4PSlots) * (kF4ParB / 4) + (4 * (lane >> 4)) * 12 + 10;
+                float2 eb[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) eb[r] = *(const float2*)(pp + r * 12);
+                HFrag ea[2][2];
+                ea[0][0].q = wE[0]; ea[0][1].q = wE[64];
+                f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s5 = 0; s5 < 5; s5++) {
+                    if (s5 + 1 < 5) {
+                        if (abl & 4) { ea[(s5 + 1) & 1][0] = ea[s5 & 1][0]; ea[(s5 + 1) & 1][1] = ea[s5 & 1][1]; }
+                        else { ea[(s5 + 1) & 1][0].q = wE[(2 * s5 + 2) * 64]; ea[(s5 + 1) & 1][1].q = wE[(2 * s5 + 3) * 64]; }
+                    }
+                    if (abl & 8) continue;
+                    const HFrag &ah = ea[s5 & 1][0], &al = ea[s5 & 1][1];
+                    e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, bh[s5][0].v, e0, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, bh[s5][1].v, e1, 0, 0, 0);
+                    e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bl[s5][0].v, e0, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bl[s5][1].v, e1, 0, 0, 0);
+                    e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[s5][0].v, e0, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[s5][1].v, e1, 0, 0, 0);
+                }
+                // C layout of E: column = lane & 15 (sub-column), row = 4 (lane >> 4) + r (hidden channel of the group)
+                float* hp = sH + cur * (16 * kF4CS) + (4 * (lane >> 4)) * kF4CS + (2 * w8) * kF4HP + (lane & 15);
+                if (!(abl & 32)) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        hp[r * kF4CS] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e0[r], eb[r].x, eb[r].y), 0.f, 6.f);
+                        hp[r * kF4CS + kF4HP] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e1[r], eb[r].x, eb[r].y), 0.f, 6.f);
+                    }
+                } else if (e0[0] + e1[0] == 123.25f) hp[0] = e0[1];
+            }
+            stencil_phase(it);
+            if (!(abl & 128)) __syncthreads();
+        }
+        return;
+    }
+
+    // ================= P role =================
+    const unsigned ldsBase = (unsigned)(uintptr_t)f4smem;
+    const unsigned ldsWE = ldsBase + (unsigned)((uint8_t*)sWE - (uint8_t*)f4smem), ldsWP = ldsBase + (unsigned)((uint8_t*)sWP - (uint8_t*)f4smem),
+                   ldsPar = ldsBase + (unsigned)((uint8_t*)sPar - (uint8_t*)f4smem);
+    auto dma16 = [](const void* src, unsigned ldsAddr) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(ldsAddr) : "memory");
+    };
+    // Every piece is ALWAYS issued (a group index outside [g0, g1) is clamped: its slot is one nobody reads in that interval), so a wave's
+    // count of outstanding requests is known: the three pieces of a wave are spread over its interval (before the stencil, before P, at
+    // the end) and the wait in front of the barrier lets exactly the two youngest stay in flight.
+    auto piece = [&](int it, int c) {           // piece c of what interval `it` consumes: WE[it] (c < 10), WP[it - 2] (c < 20), par[it] (c = 20)
+        const int nb = it % kF4WSlots;
+        if (c < 10) {
+            const int ge = min(it, g1 - 1);
+            dma16(WE + ((size_t)ge * 10 + c) * 64 + lane, ldsWE + (unsigned)(nb * 640 + c * 64) * 16u);
+        } else if (c < 20) {
+            const int c2 = c - 10, gp = min(max(it - 2, g0), g1 - 1);
+            dma16(WP + (((size_t)gp * tilesP + tile0) * 2 + c2) * 64 + lane, ldsWP + (unsigned)(nb * 640 + c2 * 64) * 16u);
+        } else if (c == 20) {
+            const int ge = min(it, g1 - 1);
+            if (lane < 48) dma16(par + (size_t)ge * 192 + lane * 4, ldsPar + (unsigned)((it % kF4PSlots) * kF4ParB));
+        }
+    };
+    auto dma = [&](int it) {                    // all 21 pieces (<= 1 KB each), piece c by P wave c % 8
+#pragma unroll
+        for (int r = 0; r < 3; r++) piece(it, w8 + 8 * r);
+    };
+    dma(g0);
+    dma(g0 + 1);
+    if (tid - 512 < 160) { sBN[tid - 512] = scP[tile0 * 32 + tid - 512]; sBN[160 + tid - 512] = shP[tile0 * 32 + tid - 512]; }
+    f32x16 pacc[5];
+#pragma unroll
+    for (int t = 0; t < 5; t++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) pacc[t][q] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int it = g0; it < g1 + 2; it++) {
+        if (!(abl & 2)) piece(it + 2, w8);                       // lands during it + 1; the slots were last read in it - 1
+        stencil_phase(it);
+        if (!(abl & 2)) piece(it + 2, w8 + 8);
+        if (it >= g0 + 2) {                     // P(it - 2): out[160 x 32 pixels] += W_P[160 x 16] . D[16 x 32 pixels]
+            const int cur = it & 1, ws = it % kF4WSlots;
+            const float* dB = sD + cur * (16 * kF4DP) + (8 * (lane >> 5)) * kF4DP + 32 * w8 + (lane & 31);
+            float dv[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) dv[j] = dB[j * kF4DP];
+            const uint4* wPq = sWP + ws * 640 + lane;
+            HFrag pa[2][2], ph, pl;
+            pa[0][0].q = wPq[0]; pa[0][1].q = wPq[64];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) split_pair(dv[2 * jj], dv[2 * jj + 1], ph.u[jj], pl.u[jj]);
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                if (t + 1 < 5) {
+                    if (abl & 64) { pa[(t + 1) & 1][0] = pa[t & 1][0]; pa[(t + 1) & 1][1] = pa[t & 1][1]; }
+                    else { pa[(t + 1) & 1][0].q = wPq[(2 * t + 2) * 64]; pa[(t + 1) & 1][1].q = wPq[(2 * t + 3) * 64]; }
+                }
+                if (abl & 16) continue;
+                const HFrag &ah = pa[t & 1][0], &al = pa[t & 1][1];
+                pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, ph.v, pacc[t], 0, 0, 0);
+                pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, pl.v, pacc[t], 0, 0, 0);
+                pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, ph.v, pacc[t], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // everything but this interval's two pieces: the pieces of it + 1 have landed
+        if (!(abl & 2)) piece(it + 2, w8 + 16);
+        if (!(abl & 128)) __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue (P waves): BN (+ residual) of the projection.  128 registers: the residual tile by tile (two tiles in flight), BN
+    // parameters straight from LDS
+    const int n = lane & 31;
+    const int oy = 4 * (2 * w8 + (n >> 4)) + py, ox = 4 * (n & 15) + px;      // this lane's pixel
+    size_t rb = 0; int rcs = 0;
+    if (RES && !SPLIT) lay_addr(layIn, Cout, b, oy, ox, rb, rcs);
+    const float* const rp = res + rb + (size_t)(tile0 * 32 + 4 * (lane >> 5)) * rcs;
+    size_t ob; int ocs;
+    lay_addr(layOut, Cout, b, oy, ox, ob, ocs);
+    float* const yp = (SPLIT ? part + (size_t)blockIdx.z * (nwg / 16) * Cout * HW : Y) + ob + (size_t)(tile0 * 32 + 4 * (lane >> 5)) * ocs;
+    float rv[2][16];
+    if (RES && !SPLIT) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) rv[0][q] = rp[(size_t)((q & 3) + 8 * (q >> 2)) * rcs];
+    }
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+        if (RES && !SPLIT && t + 1 < 5) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) rv[(t + 1) & 1][q] = rp[(size_t)((t + 1) * 32 + (q & 3) + 8 * (q >> 2)) * rcs];
+        }
+        const float* bn = sBN + t * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            float v = pacc[t][q];
+            if (!SPLIT) {
+                v = v * bn[(q & 3) + 8 * (q >> 2)] + bn[160 + (q & 3) + 8 * (q >> 2)];
+                if (RES) v += rv[t & 1][q];
+            }
+            yp[(size_t)(t * 32 + (q & 3) + 8 * (q >> 2)) * ocs] = v;
+        }
+    }
+}
+
 // the second half of a SPLIT launch: Y = (sum over the ranges, in index order) * scale + shift (+ residual); 4 pixels per thread
 // part and Y are in the output layout `layOut`, the residual (the block's input) in `layIn`.  In every layout the four elements of
 // a float4 are four pixels of ONE channel.
@@ -3006,10 +3248,14 @@ int reserve_lds()
         {reinterpret_cast<const void*>(&k_fcn_irbd2<96, 96, true, 2, true>), D2Cfg<96, 96>::LDS, "k_fcn_irbd2<96,96,split>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd2<96, 160, false, 2, true>), D2Cfg<96, 160>::LDS, "k_fcn_irbd2<96,160,split>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd4<false, true>), kF4Lds, "k_fcn_irbd4<split>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd4w<true>), kF4Lds, "k_fcn_irbd4w<true>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd4w<false>), kF4Lds, "k_fcn_irbd4w<false>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd4w<false, true>), kF4Lds, "k_fcn_irbd4w<split>"},
     };
     for (auto& k : ks)
         if (hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.lds) != hipSuccess)
             return ffail(IVF_E_NO_DEVICE, "cannot reserve %zu bytes of LDS for %s", k.lds, k.name);
+    if (const char* e = getenv("IVF_FCN_WABL")) { const int v = atoi(e); FHIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wAbl), &v, sizeof v)); }
     return IVF_OK;
 }
 
@@ -3179,7 +3425,19 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             if (probe4) FHIP(hipEventRecord(f->probe0[slot4], s));
             const int ns = split_ways(n, kF4Groups, F.cout);
             const dim3 grid(16 * n, F.cout / 160, ns);
-            if (ns > 1) {
+            static const int roles = getenv("IVF_FCN_ROLES") ? atoi(getenv("IVF_FCN_ROLES")) : 0;      // 1: role-specialised waves (k_fcn_irbd4w)
+            if (roles) {
+                if (ns > 1) {
+                    hipLaunchKernelGGL((k_fcn_irbd4w<false, true>), grid, dim3(1024), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y,
+                                       F.cout, F.tilesP, f->bufPart, layIn, layOut);
+                    launch_split_reduce(f, ns, n, F.cout, pj, bk.res ? x : nullptr, y, layIn, layOut, s);
+                } else if (bk.res)
+                    hipLaunchKernelGGL((k_fcn_irbd4w<true>), grid, dim3(1024), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, x, y, F.cout, F.tilesP, (float*)nullptr,
+                                       layIn, layOut);
+                else
+                    hipLaunchKernelGGL((k_fcn_irbd4w<false>), grid, dim3(1024), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y, F.cout, F.tilesP,
+                                       (float*)nullptr, layIn, layOut);
+            } else if (ns > 1) {
                 hipLaunchKernelGGL((k_fcn_irbd4<false, true>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y,
                                    F.cout, F.tilesP, f->bufPart, layIn, layOut);
                 launch_split_reduce(f, ns, n, F.cout, pj, bk.res ? x : nullptr, y, layIn, layOut, s);
