@@ -286,13 +286,19 @@ DEVINL s16x2 pair_at(unsigned lo, unsigned hi, int i)      // bytes W[i], W[i+1]
 // Cheap necessary condition on the 4 compass ring pixels only (rows -3, 0, +3): every 9-arc holds one pixel of each
 // opposite pair, in particular of (0,8) = (0,+-3) and (4,12) = (+-3,0).  Passes ~10 % of the pairs (the full 8-pair
 // test ~8 %) at a third of the cost.  loT/hiT = row -3, loC/hiC = centre row, loB/hiB = row +3 windows.
+// (dk.x > t) | (dk.y > t) | (br.x < -t) | (br.y < -t) on the packed halves: t - dk and br + t are negative exactly there (|values| <= 510)
+DEVINL bool over_threshold(s16x2 dk, s16x2 br, int t)
+{
+    const s16x2 T = {(short)t, (short)t};
+    return ((__builtin_bit_cast(unsigned, T - dk) | __builtin_bit_cast(unsigned, br + T)) & 0x80008000u) != 0u;
+}
 DEVINL bool fast_precheck_pair(unsigned loT, unsigned hiT, unsigned loC, unsigned hiC, unsigned loB, unsigned hiB, int t)
 {
     const s16x2 v = pair_at(loC, hiC, 3);
     const s16x2 d0 = v - pair_at(loB, hiB, 3), d8 = v - pair_at(loT, hiT, 3);
     const s16x2 d4 = v - pair_at(loC, hiC, 6), d12 = v - pair_at(loC, hiC, 0);
     const s16x2 dk = pkmin(pkmax(d0, d8), pkmax(d4, d12)), br = pkmax(pkmin(d0, d8), pkmin(d4, d12));
-    return (dk.x > t) | (dk.y > t) | (br.x < -t) | (br.y < -t);
+    return over_threshold(dk, br, t);
 }
 // the same test for the pixel pair at bytes 5, 6 of the 12-byte span (m0, m1, m2): x-3 = bytes 2, 3; x+3 = bytes 8, 9 = bytes 4, 5 of (m2:m1)
 DEVINL bool fast_precheck_pair_b(unsigned t0, unsigned t1, unsigned m0, unsigned m1, unsigned m2, unsigned b0, unsigned b1, int t)
@@ -301,7 +307,7 @@ DEVINL bool fast_precheck_pair_b(unsigned t0, unsigned t1, unsigned m0, unsigned
     const s16x2 d0 = v - pair_at(b0, b1, 5), d8 = v - pair_at(t0, t1, 5);
     const s16x2 d4 = v - pair_at(m1, m2, 4), d12 = v - pair_at(m0, m1, 2);
     const s16x2 dk = pkmin(pkmax(d0, d8), pkmax(d4, d12)), br = pkmax(pkmin(d0, d8), pkmin(d4, d12));
-    return (dk.x > t) | (dk.y > t) | (br.x < -t) | (br.y < -t);
+    return over_threshold(dk, br, t);
 }
 // rows: 7 windows (dy = -3..3), each as (lo, hi) dwords.  Returns the two scores packed (left | right << 16).
 DEVINL unsigned fast_score_pair(const unsigned (&lo)[7], const unsigned (&hi)[7], int t, bool quickOnly = false)
@@ -318,26 +324,31 @@ DEVINL unsigned fast_score_pair(const unsigned (&lo)[7], const unsigned (&hi)[7]
     s16x2 dk = pkmax(d[0], d[8]), br = pkmin(d[0], d[8]);
 #pragma unroll
     for (int k = 1; k < 8; k++) { dk = pkmin(dk, pkmax(d[k], d[k + 8])); br = pkmax(br, pkmin(d[k], d[k + 8])); }
-    const bool pass = (dk.x > t) | (dk.y > t) | (br.x < -t) | (br.y < -t);
-    if (!pass) return 0u;
+    if (!over_threshold(dk, br, t)) return 0u;
     if (quickOnly) return 0x00010001u;
-    s16x2 mn[8], mx[8];
+    // One polarity per pixel is enough (r04).  A 9-arc holds BOTH pixels of one opposite pair, so a pixel whose every pair holds a ring
+    // pixel with d < -t (br < -t) cannot have a 9-arc with d > t, and vice versa: where br < -t only the "brighter ring" polarity can
+    // make a corner, elsewhere only the "darker ring" one -- and the other polarity's arc value is <= t there, so it never is the maximum
+    // that counts.  e = +-d per half, then the arc minimum of one polarity: 16 + 47 packed operations instead of 94.
+    const s16x2 T = {(short)t, (short)t}, sg = ((br + T) >> 15) | (s16x2){1, 1};
+    s16x2 e[16];
 #pragma unroll
-    for (int q = 0; q < 8; q++) { const int j = 2 * q + 1; mn[q] = pkmin(d[j], d[(j + 1) & 15]); mx[q] = pkmax(d[j], d[(j + 1) & 15]); }
-    s16x2 m4[8], M4[8];
+    for (int k = 0; k < 16; k++) e[k] = d[k] * sg;
+    s16x2 mn[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) { m4[q] = pkmin(mn[q], mn[(q + 1) & 7]); M4[q] = pkmax(mx[q], mx[(q + 1) & 7]); }
-    s16x2 amax, bmin;
+    for (int q = 0; q < 8; q++) { const int j = 2 * q + 1; mn[q] = pkmin(e[j], e[(j + 1) & 15]); }
+    s16x2 m4[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) m4[q] = pkmin(mn[q], mn[(q + 1) & 7]);
+    s16x2 amax;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const int j = 2 * q + 1;
-        const s16x2 w8 = pkmin(m4[q], m4[(q + 2) & 7]), W8 = pkmax(M4[q], M4[(q + 2) & 7]);      // d[j..j+7]
-        const s16x2 a = pkmin(w8, pkmax(d[(j + 15) & 15], d[(j + 8) & 15]));
-        const s16x2 b = pkmax(W8, pkmin(d[(j + 15) & 15], d[(j + 8) & 15]));
+        const s16x2 w8 = pkmin(m4[q], m4[(q + 2) & 7]);                          // e[j..j+7]
+        const s16x2 a = pkmin(w8, pkmax(e[(j + 15) & 15], e[(j + 8) & 15]));     // arcs [j-1..j+7] and [j..j+8]
         amax = q ? pkmax(amax, a) : a;
-        bmin = q ? pkmin(bmin, b) : b;
     }
-    const int A0 = max((int)amax.x, -(int)bmin.x), A1 = max((int)amax.y, -(int)bmin.y);
+    const int A0 = (int)amax.x, A1 = (int)amax.y;
     const unsigned s0 = A0 > t ? (unsigned)(A0 - 1) : 0u, s1 = A1 > t ? (unsigned)(A1 - 1) : 0u;
     return s0 | (s1 << 16);
 }
@@ -367,11 +378,15 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     __shared__ __attribute__((aligned(16))) unsigned raw[(kFastTH + 8) * (kRawP / 4) + 4];   // +4: the funnel read touches one dword past a window
     __shared__ __attribute__((aligned(4))) uint8_t sc[kScH * kScP];
     __shared__ unsigned colInfo[kScW + 2], rowInfo[kScH + 2];
-    __shared__ int s_cnt[kLocalCells], s_ini[kLocalCells], s_n, s_nq;
+    __shared__ int s_cnt[kLocalCells], s_ini[kLocalCells], s_n;
     // s_queue: pairs that pass the quick test (sy << 8 | sx), dead after pass B; s_list (survivors, at most one strict
     // 3x3 maximum per 2x2 block) reuses its storage
-    constexpr int kQueueN = kScH * ((kScW + 3) / 4) * 2;
-    __shared__ unsigned s_qmem[(kQueueN + 1) / 2 > kFastTW * kFastTH / 4 ? (kQueueN + 1) / 2 : kFastTW * kFastTH / 4];
+    // (r04: one region per wave, filled through a wave-uniform running count -- no LDS atomic and no shuffle per step)
+    constexpr int kQuadsA = (kScW + 3) / 4, kRG = 256 / kQuadsA, kRPT = (kScH + kRG - 1) / kRG;   // pass A: thread = quad column x kRPT consecutive rows
+    constexpr int kQRegion = 64 * kRPT * 2;
+    static_assert(kRG * kRPT >= kScH && kRG >= 1, "pass A covers the score region");
+    __shared__ unsigned s_qmem[4 * kQRegion / 2 > kFastTW * kFastTH / 4 ? 4 * kQRegion / 2 : kFastTW * kFastTH / 4];
+    __shared__ int s_nqw[4];
     unsigned short* const s_queue = (unsigned short*)s_qmem;
     unsigned* const s_list = s_qmem;
     constexpr int kCandCap = 32 * kFastTH;
@@ -448,42 +463,51 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     constexpr int kQuads = (kScW + 3) / 4;
     // pass A (all pixels): compass pre-check only (3 of the 7 rows).  ~10 % of the pairs pass, but in most waves at
     // least one lane does, so nothing expensive runs here: passing pairs are queued in LDS and scored densely in pass B.
-    if (tid == 0) { s_nq = 0; s_nc = 0; }
-    __syncthreads();
-    for (int i = tid; i < kScH * kQuads; i += 256) {
-        const int sy = i / kQuads, sx = (i % kQuads) * 4;
-        const unsigned rv = rowInfo[sy] & 1u;
-        const unsigned c0 = colInfo[sx] & 1u, c1 = colInfo[sx + 1] & 1u, c2 = colInfo[sx + 2] & 1u, c3 = colInfo[sx + 3] & 1u;
-        bool pA = false, pB = false;
-        if ((rv & (c0 | c1 | c2 | c3)) && !(ablate & 1)) {
-            const unsigned* base = raw + (sy * kRawP + sx) / 4;
-            unsigned t0 = base[0], t1 = base[1];
-            unsigned m0 = base[3 * (kRawP / 4)], m1 = base[3 * (kRawP / 4) + 1], m2 = base[3 * (kRawP / 4) + 2];
-            unsigned b0 = base[6 * (kRawP / 4)], b1 = base[6 * (kRawP / 4) + 1];
-            if (c0 | c1) pA = fast_precheck_pair(t0, t1, m0, m1, b0, b1, minTh);
-            // pair B sits two bytes further: its five operands are picked straight out of the same dwords (only x+3 reaches the
-            // third one) instead of funnel-shifting six windows by two bytes first
-            if (c2 | c3) pB = fast_precheck_pair_b(t0, t1, m0, m1, m2, b0, b1, minTh);
+    if (tid == 0) s_nc = 0;
+    {
+        // thread = one quad column x kRPT consecutive rows: the column classes are read once, the 11 raw rows a thread's 5 steps touch are
+        // requested up front (each is the top row of one step, the centre row of another, the bottom row of a third)
+        const int q = tid % kQuads, rg = tid / kQuads, sx = 4 * q, sy0 = rg * kRPT;
+        const bool thr = rg < kRG;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        unsigned short* const myq = s_queue + wv * kQRegion;
+        const bool cA = thr && ((colInfo[sx] | colInfo[sx + 1]) & 1u), cB = thr && ((colInfo[sx + 2] | colInfo[sx + 3]) & 1u);
+        unsigned w0[kRPT + 6], w1[kRPT + 6], w2[kRPT + 6];
+#pragma unroll
+        for (int j = 0; j < kRPT + 6; j++) {
+            const unsigned* base = raw + min(sy0 + j, kFastTH + 7) * (kRawP / 4) + q;
+            w0[j] = base[0]; w1[j] = base[1];
+            w2[j] = (j >= 3 && j < kRPT + 3) ? base[2] : 0u;
         }
-        *(unsigned*)(sc + sy * kScP + sx) = 0u;
-        // wave-aggregated push: one LDS atomic per wave step instead of one per passing pair
-        const unsigned long long mA = __ballot(pA), mB = __ballot(pB);
-        if (mA | mB) {
-            const int lane = tid & 63;
-            const int nA = __popcll(mA), nB = __popcll(mB);
-            int qb = 0;
-            if (lane == __ffsll((long long)(mA | mB)) - 1) qb = atomicAdd(&s_nq, nA + nB);
-            qb = __shfl(qb, __ffsll((long long)(mA | mB)) - 1, 64);
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            if (pA) s_queue[qb + __popcll(mA & lt)] = (unsigned short)((sy << 8) | sx);
-            if (pB) s_queue[qb + nA + __popcll(mB & lt)] = (unsigned short)((sy << 8) | (sx + 2));
+        unsigned rvv[kRPT];
+#pragma unroll
+        for (int k = 0; k < kRPT; k++) rvv[k] = rowInfo[min(sy0 + k, kScH - 1)];
+        int nw = 0;                             // wave-uniform count of this wave's region
+        const int lane = tid & 63;
+#pragma unroll
+        for (int k = 0; k < kRPT; k++) {
+            const int sy = sy0 + k;
+            const bool in = thr && sy < kScH, rowOk = in && (rvv[k] & 1u) && !(ablate & 1);
+            bool pA = false, pB = false;
+            if (rowOk && cA) pA = fast_precheck_pair(w0[k], w1[k], w0[k + 3], w1[k + 3], w0[k + 6], w1[k + 6], minTh);
+            // pair B sits two bytes further: its five operands are picked straight out of the same dwords (only x+3 reaches the third one)
+            if (rowOk && cB) pB = fast_precheck_pair_b(w0[k], w1[k], w0[k + 3], w1[k + 3], w2[k + 3], w0[k + 6], w1[k + 6], minTh);
+            if (in) *(unsigned*)(sc + sy * kScP + sx) = 0u;
+            const unsigned long long mA = __ballot(pA), mB = __ballot(pB);
+            const int nA = __popcll(mA);
+            if (pA) myq[nw + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u))] = (unsigned short)((sy << 8) | sx);
+            if (pB) myq[nw + nA + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u))] = (unsigned short)((sy << 8) | (sx + 2));
+            nw += nA + __popcll(mB);
         }
+        if (lane == 0) s_nqw[wv] = nw;
     }
     __syncthreads();
     // pass B (queued pairs only): full score
-    const int nq = s_nq;
+    const int nq0 = s_nqw[0], nq1 = nq0 + s_nqw[1], nq2 = nq1 + s_nqw[2], nq = nq2 + s_nqw[3];
     for (int i = tid; i < nq; i += 256) {
-        const int sy = s_queue[i] >> 8, sx = s_queue[i] & 0xff;
+        const int qi = i < nq0 ? i : (i < nq1 ? kQRegion + i - nq0 : (i < nq2 ? 2 * kQRegion + i - nq1 : 3 * kQRegion + i - nq2));
+        const unsigned qe = s_queue[qi];
+        const int sy = qe >> 8, sx = qe & 0xff;
         unsigned lo[7], hi[7];
         const int sh = sx & 2;
         const unsigned* base = raw + (sy * kRawP + (sx & ~3)) / 4;
