@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
                                                  int* __restrict__ tileCnt, int* __restrict__ cellCnt, int nImg, int ablate)
 {
     __shared__ __attribute__((aligned(16))) unsigned raw[(kFastTH + 8) * (kRawP / 4) + 4];   // +4: the funnel read touches one dword past a window
-    __shared__ __attribute__((aligned(4))) uint8_t sc[kScH * kScP];
+    __shared__ __attribute__((aligned(16))) uint8_t sc[(kScH * kScP + 15) / 16 * 16];
     __shared__ unsigned colInfo[kScW + 2], rowInfo[kScH + 2];
     __shared__ int s_cnt[kLocalCells], s_ini[kLocalCells], s_n;
     // s_queue: pairs that pass the quick test (sy << 8 | sx), dead after pass B; s_list (survivors, at most one strict
@@ -416,18 +416,21 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     constexpr int kRawQ = kRawP / 4, kRawRPP = 256 / kRawQ, kRawIt = (kFastTH + 8 + kRawRPP - 1) / kRawRPP;
     const int rawQ = tid % kRawQ, rawR = tid / kRawQ;
     unsigned rv_[kRawIt];
-    bool rok[kRawIt];
     {
+        // buffer loads (r04): the plane is the buffer, so rows below the plane read as zero by the hardware's range check and a thread's
+        // address is one 32-bit offset advanced by a constant -- no clamps, no 64-bit address arithmetic, no select at the store
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, G.pitch * G.h, 0x00020000);
         const int gx = x0 - 4 + 4 * rawQ;
-        const bool colOk = rawR < kRawRPP && gx < G.pitch;
+        unsigned off = (rawR < kRawRPP && gx < G.pitch) ? (unsigned)((y0 - 4 + rawR) * G.pitch + gx) : 0x7fffffffu;   // gy >= 0: y0 >= kEdge
+        const unsigned step = (unsigned)(kRawRPP * G.pitch);
 #pragma unroll
         for (int k = 0; k < kRawIt; k++) {
-            const int ry = rawR + kRawRPP * k;
-            const int gy = y0 - 4 + ry;
-            rok[k] = colOk && ry < kFastTH + 8 && gy < G.h;        // gy >= 0: y0 >= kEdge
-            rv_[k] = *(const unsigned*)(src + (size_t)(rok[k] ? gy : 0) * G.pitch + (rok[k] ? gx : 0));
+            rv_[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
+            off += step;                        // an invalid thread stays far beyond the plane
         }
     }
+    // the score plane starts as zeros (pass B writes the scored pairs only): wide stores while the loads are in flight
+    for (int i = tid; i < (int)(sizeof(sc) / 16); i += 256) ((uint4*)sc)[i] = make_uint4(0u, 0u, 0u, 0u);
     const int mode = (cfg->introspection && (useC & 1u)) ? 1 : 0;
     const int domHm = mode ? G.domH[1] : G.domH[0];
     if (tid < kScW) {                               // column classes: x = x0-1+tid
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     }
 #pragma unroll
     for (int k = 0; k < kRawIt; k++)
-        if (rawR < kRawRPP && rawR + kRawRPP * k < kFastTH + 8) raw[(rawR + kRawRPP * k) * kRawQ + rawQ] = rok[k] ? rv_[k] : 0u;
+        if (rawR < kRawRPP && rawR + kRawRPP * k < kFastTH + 8) raw[(rawR + kRawRPP * k) * kRawQ + rawQ] = rv_[k];
     if (ablate & 32) return;
     __syncthreads();
     // 2. scores, four pixels (two packed pairs) per step sharing the three aligned dwords of each of the 7 rows:
@@ -492,7 +495,6 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
             if (rowOk && cA) pA = fast_precheck_pair(w0[k], w1[k], w0[k + 3], w1[k + 3], w0[k + 6], w1[k + 6], minTh);
             // pair B sits two bytes further: its five operands are picked straight out of the same dwords (only x+3 reaches the third one)
             if (rowOk && cB) pB = fast_precheck_pair_b(w0[k], w1[k], w0[k + 3], w1[k + 3], w2[k + 3], w0[k + 6], w1[k + 6], minTh);
-            if (in) *(unsigned*)(sc + sy * kScP + sx) = 0u;
             const unsigned long long mA = __ballot(pA), mB = __ballot(pB);
             const int nA = __popcll(mA);
             if (pA) myq[nw + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u))] = (unsigned short)((sy << 8) | sx);
@@ -558,17 +560,12 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
         const uint8_t* c = sc + sy * kScP + sx;
         const unsigned ci = colInfo[sx], ri = rowInfo[sy];
         if (!(ci & ri & 1u)) return;
-        const bool L = ci & 2u, R = ci & 4u, U = ri & 2u, D = ri & 4u;
-        bool ok = true;
-        ok &= s > ((L) ? c[-1] : 0);
-        ok &= s > ((R) ? c[1] : 0);
-        ok &= s > ((U && L) ? c[-kScP - 1] : 0);
-        ok &= s > ((U) ? c[-kScP] : 0);
-        ok &= s > ((U && R) ? c[-kScP + 1] : 0);
-        ok &= s > ((D && L) ? c[kScP - 1] : 0);
-        ok &= s > ((D) ? c[kScP] : 0);
-        ok &= s > ((D && R) ? c[kScP + 1] : 0);
-        if (!ok) return;
+        // strict maximum over the 8 neighbours, a neighbour in another cell counting as 0: all-ones / zero masks from the class bits and
+        // one max3 per row (sc has a zero column / row around the region, so every address is inside the array)
+        const int mL = -(int)((ci >> 1) & 1u), mR = -(int)((ci >> 2) & 1u), mU = -(int)((ri >> 1) & 1u), mD = -(int)((ri >> 2) & 1u);
+        const int up = max(max((int)c[-kScP - 1] & mL, (int)c[-kScP]), (int)c[-kScP + 1] & mR) & mU;
+        const int dn = max(max((int)c[kScP - 1] & mL, (int)c[kScP]), (int)c[kScP + 1] & mR) & mD;
+        if (!(s > max(max(up, dn), max((int)c[-1] & mL, (int)c[1] & mR)))) return;
         const int crow = (int)(ri >> 8), ccol = (int)(ci >> 8);
         const int lr = crow - firstRow, lc = ccol - firstCol;
         // kTileCap (one strict maximum per 2x2 block) is not a strict bound: maxima on both sides of a CELL border do not see each
