@@ -420,7 +420,10 @@ struct ivf_extractor {
 // kPipe batch contexts on kPipe internal streams: run k uses context k % kPipe, so the latency-bound tail of one batch
 // (per-cell selection, descriptors, stereo) overlaps the throughput-bound head (ingest, pyramid, FAST, blur) of the
 // next ones.  Results of a run stay valid until kPipe - 1 further runs have been enqueued.
-constexpr int kPipe = 3;                // batch contexts in flight
+#ifndef IVF_PIPE
+#define IVF_PIPE 3
+#endif
+constexpr int kPipe = IVF_PIPE;         // batch contexts in flight
 struct ivf_frontend {
     ivf_frontend_config cfg;
     Tables tl;

@@ -48,7 +48,7 @@ namespace {
 constexpr int kGC = 64, kGR = 48;                 // FRAME_GRID_COLS / ROWS (ORB/include/Frame.h:43-44)
 constexpr int kListCap = 64;                      // candidates listed per query (one per lane of the greedy wave)
 constexpr int kPrefetch = 16;                     // queries whose lists are in registers ahead of the greedy walk
-constexpr int kMaxTrackFeatures = 4096;           // LDS state of k_track_greedy: 16 B per keypoint
+constexpr int kMaxTrackFeatures = 4096;           // LDS state of k_track_greedy: 20 B per keypoint
 
 struct TrackParams {                               // uniform kernel arguments
     int nf, nlevels;
@@ -363,110 +363,208 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
     const ivf_keypoint* kl = rec_kps(recL);
     const float* urC = rec_uright(recC, P.nf);
     for (int i = lane; i < nC; i += 64) { s_assign[i] = -1; s_ur[i] = urC[i]; s_ang[i] = kc[i].angle; }
+    __shared__ float s_scale[kMaxLevels];
+    __shared__ int s_hist[32];                                // rotHist[b].size()
+    int* s_claim = s_mem + 4 * P.nf;                          // [nf] scratch of the group commit
+    if (lane < kMaxLevels) s_scale[lane] = P.scale[lane];
+    if (lane < 32) s_hist[lane] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const Query* Q = queries + (size_t)p * P.nf;
     const int* C = count + (size_t)p * P.nf;
     const unsigned* Lp = lists + (size_t)p * P.nf * kListCap;
-    int nm = 0, nMatch = 0, hist = 0;                          // hist: lane b counts rotHist[b].size()
+    int nm = 0, nMatch = 0;
     const float factor = 1.0f / 30.0f;                         // 1.0f / HISTO_LENGTH (:1380)
 
-    for (int g0 = 0; g0 < nL; g0 += kPrefetch) {
-        // the group's counts, query records, angles (lanes 0..15) and list entries (every lane, one per query) are requested
-        // together, so their latencies overlap instead of adding up query by query
+    // r04: a group of 16 queries is evaluated SPECULATIVELY against the state the group starts from -- four queries per pass, one per
+    // DPP row of 16 lanes (a window holds a handful of candidates: radius 7 px x the octave's scale) -- and committed in order.  The
+    // speculative first minimum of query k is also its first minimum under the state it would have seen in turn unless an earlier
+    // query OF THE SAME GROUP has taken exactly that keypoint as a blocking assignment (the candidates it would have seen are a subset
+    // of the ones evaluated, in the same order): only then, or when a list is longer than a row, is the query walked again against the
+    // live state.  The next group's lists are requested before the current group is evaluated.
+    struct Grp { unsigned ent[4]; int cnt[4]; float ur[4]; unsigned bits[4]; int myCnt; Query myQ; float myAng; };
+    auto load_group = [&](int g0, Grp& g) {
         const int gi = g0 + (lane & (kPrefetch - 1));
         const bool gv = gi < nL;
-        const int myCnt = gv ? C[gi] : 0;
-        Query myQ; myQ.u = 0; myQ.v = 0; myQ.ur = 0; myQ.bits = 0;
-        float myAng = 0.0f;
-        if (gv) { myQ = Q[gi]; myAng = kl[gi].angle; }
-        unsigned ent[kPrefetch];
+        g.myCnt = gv ? C[gi] : 0;
+        g.myQ.u = 0; g.myQ.v = 0; g.myQ.ur = 0; g.myQ.bits = 0; g.myAng = 0.0f;
+        if (gv) { g.myQ = Q[gi]; g.myAng = kl[gi].angle; }
 #pragma unroll
-        for (int k = 0; k < kPrefetch; k++) ent[k] = (g0 + k < nL) ? Lp[(size_t)(g0 + k) * kListCap + lane] : 0u;
+        for (int m = 0; m < 4; m++) {
+            const int qi = g0 + 4 * m + (lane >> 4);
+            const bool v = qi < nL;
+            g.ent[m] = v ? Lp[(size_t)qi * kListCap + (lane & 15)] : 0u;
+            g.cnt[m] = v ? C[qi] : 0;
+            const float2 ub = v ? *(const float2*)&Q[qi].ur : make_float2(0.f, 0.f);
+            g.ur[m] = ub.x; g.bits[m] = __builtin_bit_cast(unsigned, ub.y);
+        }
+    };
+    Grp cur;
+    load_group(0, cur);
+    for (int g0 = 0; g0 < nL; g0 += kPrefetch) {
+        Grp nxt;
+        load_group(g0 + kPrefetch, nxt);
+        // ---- speculative pass: row r of pass m = query 4 m + r
+        unsigned key[4]; int i2m[4];
 #pragma unroll
-        for (int k = 0; k < kPrefetch; k++) {
+        for (int m = 0; m < 4; m++) {
+            const unsigned e = cur.ent[m];
+            const int i2 = e & 0xffff, d = e >> 16, pos = lane & 15;
+            bool ok = pos < cur.cnt[m] && cur.cnt[m] <= 16;
+            if (ok) {
+                const int a = s_assign[i2];
+                if (a >= 0 && !(a & kNoBlock)) ok = false;
+                const float u2 = s_ur[i2];
+                if (u2 > 0) { const float er = fabsf(cur.ur[m] - u2); if (er > th * s_scale[cur.bits[m] & 0xff]) ok = false; }
+            }
+            i2m[m] = i2;
+            key[m] = ok ? ((unsigned)d << 6) | (unsigned)pos : 0xffffffffu;
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) {             // minimum of each row of 16 lanes, in its lane 15
+            unsigned v = key[m], t;
+            t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false); v = t < v ? t : v;
+            t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false); v = t < v ? t : v;
+            t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false); v = t < v ? t : v;
+            t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false); v = t < v ? t : v;
+            key[m] = v;
+        }
+        // ---- commit.  Lane k < 16 collects query k's result (row k & 3 of pass k >> 2); if no two matched queries of the group chose the
+        // same keypoint (each writes its lane into s_claim[keypoint] and reads it back) and no list is longer than a row, the sixteen
+        // commits are independent and are made at once; otherwise the group is committed query by query.
+        int taken = -1;                           // lane k: the keypoint query k of this group took as a BLOCKING assignment
+        int fb = -1;                              // lane k: the keypoint query k matched (-1: none)
+        const int myCnt = cur.myCnt;
+        const Query myQ = cur.myQ;
+        const int kEnd = min(kPrefetch, nL - g0);
+        bool serial;
+        {
+            const int src = 16 * (lane & 3) + 15, mSel = (lane >> 2) & 3;
+            unsigned kq[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) kq[m] = (unsigned)__builtin_amdgcn_ds_bpermute(4 * src, (int)key[m]);
+            const unsigned best = mSel == 0 ? kq[0] : (mSel == 1 ? kq[1] : (mSel == 2 ? kq[2] : kq[3]));
+            const int src2 = 16 * (lane & 3) + (int)(best & 15u);
+            int iq[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) iq[m] = __builtin_amdgcn_ds_bpermute(4 * src2, i2m[m]);
+            const int bi = mSel == 0 ? iq[0] : (mSel == 1 ? iq[1] : (mSel == 2 ? iq[2] : iq[3]));
+            const bool mine = lane < kEnd;
+            const bool mt = mine && myCnt != 0 && myCnt <= 16 && best != 0xffffffffu && (int)(best >> 6) <= 100;      // TH_HIGH (:1469)
+            if (mt) s_claim[bi] = lane;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const bool clash = (mt && s_claim[bi] != lane) || (mine && myCnt > 16);
+            serial = __ballot(clash) != 0ull;
+            if (!serial && mt) {
+                s_assign[bi] = ((myQ.bits >> 25) & 1u) ? (g0 + lane) : ((g0 + lane) | kNoBlock);
+                fb = bi;
+            }
+        }
+#pragma nounroll
+        for (int k = 0; serial && k < kEnd; k++) {          // not unrolled: the walk-again path below would be instantiated 16 times
             const int i = g0 + k;
             const int cnt = __builtin_amdgcn_readlane(myCnt, k);
-            if (i >= nL || cnt == 0) continue;                                        // vIndices2.empty() (:1439)
+            if (cnt == 0) continue;                                                   // vIndices2.empty() (:1439)
             const float qur = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myQ.ur), k));
             const unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)myQ.bits, k);
             const float radius = th * P.scale[bits & 0xff];
             int bestDist = 256, bestIdx2 = -1;
-            if (cnt <= kListCap) {
-                const unsigned e = ent[k];
-                const int i2 = e & 0xffff, d = e >> 16;
-                bool ok = lane < cnt;
-                if (ok) {
-                    const int a = s_assign[i2];
-                    if (a >= 0 && !(a & kNoBlock)) ok = false;                         // occupied by a point with observations (:1447-1449)
-                    const float u2 = s_ur[i2];
-                    if (u2 > 0) { const float er = fabsf(qur - u2); if (er > radius) ok = false; }   // :1451-1457
-                }
-                const unsigned key = ok ? ((unsigned)d << 6) | (unsigned)lane : 0xffffffffu;
-                const unsigned best = wave_min_u32_dpp(key);                            // first minimum in list order (:1463-1467)
+            bool again = cnt > 16;
+            if (!again) {
+                const int m = k >> 2;             // uniform selects instead of a dynamically indexed register array
+                const unsigned keyM = m == 0 ? key[0] : (m == 1 ? key[1] : (m == 2 ? key[2] : key[3]));
+                const int i2M = m == 0 ? i2m[0] : (m == 1 ? i2m[1] : (m == 2 ? i2m[2] : i2m[3]));
+                const unsigned best = (unsigned)__builtin_amdgcn_readlane((int)keyM, 16 * (k & 3) + 15);
                 if (best != 0xffffffffu) {
                     bestDist = best >> 6;
-                    bestIdx2 = __builtin_amdgcn_readlane(i2, best & 63);
+                    bestIdx2 = __builtin_amdgcn_readlane(i2M, 16 * (k & 3) + (int)(best & 15u));
+                    if (__ballot(taken == bestIdx2)) again = true;
                 }
-            } else {
-                // the window overflowed its list: walk it again, against the live assignment state
-                const float qu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myQ.u), k));
-                const float qv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myQ.v), k));
-                const int lo = (int)((bits >> 8) & 0xff) - 1, hi = (int)((bits >> 16) & 0xff) - 1;
-                const uint4* qd = (const uint4*)(rec_desc(recL, P.nf) + (size_t)i * 32);
-                const uint4 qa = qd[0], qb = qd[1];
-                unsigned long long bestKey = ~0ull;                                    // dist << 32 | ordinal
-                unsigned ordinal = 0;
-                walk_window(P, kc, rec_desc(recC, P.nf), gStart + (size_t)p * (kGC * kGR + 1), gIdx + (size_t)p * P.nf, qu, qv, radius,
-                            lo, hi, qa, qb, lane, [&](bool ok, int i2, int d) {
-                                const unsigned long long m = __ballot(ok);
-                                const unsigned pos = ordinal + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-                                ordinal += (unsigned)__popcll(m);
-                                if (ok) {
-                                    const int a = s_assign[i2];
-                                    if (a >= 0 && !(a & kNoBlock)) ok = false;
-                                    const float u2 = s_ur[i2];
-                                    if (u2 > 0) { const float er = fabsf(qur - u2); if (er > radius) ok = false; }
-                                }
-                                if (ok) {
-                                    const unsigned long long key = ((unsigned long long)(unsigned)d << 32) | (unsigned long long)pos;
-                                    if (key < bestKey) { bestKey = key; bestIdx2 = i2; }
-                                }
-                            });
-                // lanes hold their own best (key, i2): reduce to the smallest key
-                unsigned hiK = (unsigned)(bestKey >> 32), loK = (unsigned)bestKey;
-                const unsigned minHi = wave_min_u32_dpp(hiK);
-                const unsigned loC = hiK == minHi ? loK : 0xffffffffu;
-                const unsigned minLo = wave_min_u32_dpp(loC);
-                const unsigned long long who = __ballot(hiK == minHi && loK == minLo && bestKey != ~0ull);
-                if (who) { bestDist = (int)minHi; bestIdx2 = __builtin_amdgcn_readlane(bestIdx2, __ffsll((long long)who) - 1); }
-                else bestIdx2 = -1;
+            }
+            if (again) {
+                bestDist = 256; bestIdx2 = -1;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (cnt <= kListCap) {
+                    const unsigned e = Lp[(size_t)i * kListCap + lane];
+                    const int i2 = e & 0xffff, d = e >> 16;
+                    bool ok = lane < cnt;
+                    if (ok) {
+                        const int a = s_assign[i2];
+                        if (a >= 0 && !(a & kNoBlock)) ok = false;                         // occupied by a point with observations (:1447-1449)
+                        const float u2 = s_ur[i2];
+                        if (u2 > 0) { const float er = fabsf(qur - u2); if (er > radius) ok = false; }   // :1451-1457
+                    }
+                    const unsigned key1 = ok ? ((unsigned)d << 6) | (unsigned)lane : 0xffffffffu;
+                    const unsigned best = wave_min_u32_dpp(key1);                           // first minimum in list order (:1463-1467)
+                    if (best != 0xffffffffu) {
+                        bestDist = best >> 6;
+                        bestIdx2 = __builtin_amdgcn_readlane(i2, best & 63);
+                    }
+                } else {
+                    // the window overflowed its list: walk it again, against the live assignment state
+                    const float qu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myQ.u), k));
+                    const float qv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myQ.v), k));
+                    const int lo = (int)((bits >> 8) & 0xff) - 1, hi = (int)((bits >> 16) & 0xff) - 1;
+                    const uint4* qd = (const uint4*)(rec_desc(recL, P.nf) + (size_t)i * 32);
+                    const uint4 qa = qd[0], qb = qd[1];
+                    unsigned long long bestKey = ~0ull;                                    // dist << 32 | ordinal
+                    unsigned ordinal = 0;
+                    walk_window(P, kc, rec_desc(recC, P.nf), gStart + (size_t)p * (kGC * kGR + 1), gIdx + (size_t)p * P.nf, qu, qv, radius,
+                                lo, hi, qa, qb, lane, [&](bool ok, int i2, int d) {
+                                    const unsigned long long m = __ballot(ok);
+                                    const unsigned pos = ordinal + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                                    ordinal += (unsigned)__popcll(m);
+                                    if (ok) {
+                                        const int a = s_assign[i2];
+                                        if (a >= 0 && !(a & kNoBlock)) ok = false;
+                                        const float u2 = s_ur[i2];
+                                        if (u2 > 0) { const float er = fabsf(qur - u2); if (er > radius) ok = false; }
+                                    }
+                                    if (ok) {
+                                        const unsigned long long key2 = ((unsigned long long)(unsigned)d << 32) | (unsigned long long)pos;
+                                        if (key2 < bestKey) { bestKey = key2; bestIdx2 = i2; }
+                                    }
+                                });
+                    // lanes hold their own best (key, i2): reduce to the smallest key
+                    unsigned hiK = (unsigned)(bestKey >> 32), loK = (unsigned)bestKey;
+                    const unsigned minHi = wave_min_u32_dpp(hiK);
+                    const unsigned loC = hiK == minHi ? loK : 0xffffffffu;
+                    const unsigned minLo = wave_min_u32_dpp(loC);
+                    const unsigned long long who = __ballot(hiK == minHi && loK == minLo && bestKey != ~0ull);
+                    if (who) { bestDist = (int)minHi; bestIdx2 = __builtin_amdgcn_readlane(bestIdx2, __ffsll((long long)who) - 1); }
+                    else bestIdx2 = -1;
+                }
             }
             if (bestIdx2 >= 0 && bestDist <= 100) {                                     // TH_HIGH (:1469)
                 const int blocks = (bits >> 25) & 1;
-                int bin = 0;
-                if (P.checkOri) {
-                    const float qang = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myAng), k));
-                    float rot = qang - s_ang[bestIdx2];                                 // :1476-1484
-                    if (rot < 0.0f) rot += 360.0f;
-                    bin = (int)roundf(rot * factor);
-                    if (bin == 30) bin = 0;
-                    hist += (lane == bin) ? 1 : 0;
-                }
-                if (lane == 0) {
-                    s_assign[bestIdx2] = blocks ? i : (i | kNoBlock);
-                    s_match[nMatch] = (unsigned)bestIdx2 | ((unsigned)bin << 16);
-                }
-                nMatch++; nm++;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (lane == 0) s_assign[bestIdx2] = blocks ? i : (i | kNoBlock);
+                if (lane == k) { fb = bestIdx2; if (blocks) taken = bestIdx2; }
             }
         }
+        // ---- the group's matches: rotation bins (:1476-1484) and the match list, lane k = query k
+        {
+            const bool mt = fb >= 0;
+            int bin = 0;
+            if (P.checkOri && mt) {
+                float rot = cur.myAng - s_ang[fb];
+                if (rot < 0.0f) rot += 360.0f;
+                bin = (int)roundf(rot * factor);
+                if (bin == 30) bin = 0;
+            }
+            const unsigned long long mm = __ballot(mt);
+            if (mt) s_match[nMatch + __popcll(mm & ((1ull << lane) - 1ull))] = (unsigned)fb | ((unsigned)bin << 16);
+            if (P.checkOri && mt) atomicAdd(&s_hist[bin], 1);
+            const int n = __popcll(mm);
+            nMatch += n; nm += n;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        cur = nxt;
     }
     // ---- rotation consistency: ComputeThreeMaxima (:1654-1695) over the 30 bins, matches of every other bin are taken back
     if (P.checkOri) {
         int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
         for (int b = 0; b < 30; b++) {
-            const int s = __builtin_amdgcn_readlane(hist, b);
+            const int s = s_hist[b];
             if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = b; }
             else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = b; }
             else if (s > max3) { max3 = s; ind3 = b; }
@@ -833,7 +931,7 @@ int ivf_tracker_create(const ivf_track_config* cfg, ivf_tracker** out)
     if (!cfg || !out) return fail(IVF_E_INVALID, "null argument");
     *out = nullptr;
     if (cfg->nfeatures < 1 || cfg->nfeatures > kMaxTrackFeatures)
-        return fail(IVF_E_CAPACITY, "the batched tracker keeps 16 bytes of state per keypoint in LDS: nfeatures %d outside [1,%d]", cfg->nfeatures, kMaxTrackFeatures);
+        return fail(IVF_E_CAPACITY, "the batched tracker keeps 20 bytes of state per keypoint in LDS: nfeatures %d outside [1,%d]", cfg->nfeatures, kMaxTrackFeatures);
     if (cfg->nlevels < 1 || cfg->nlevels > kMaxLevels) return fail(IVF_E_INVALID, "nlevels %d outside [1,%d]", cfg->nlevels, kMaxLevels);
     if (cfg->max_pairs < 1) return fail(IVF_E_INVALID, "max_pairs must be >= 1");
     if (!(cfg->bounds.max_x > cfg->bounds.min_x) || !(cfg->bounds.max_y > cfg->bounds.min_y)) return fail(IVF_E_INVALID, "empty image bounds");
@@ -857,7 +955,7 @@ int ivf_tracker_create(const ivf_track_config* cfg, ivf_tracker** out)
     P.recBytes = ivf_track_record_bytes(cfg->nfeatures);
     P.logScale = cfg->nlevels > 1 ? logf(cfg->scale_factors[1]) : 1.0f;             // mfLogScaleFactor = log(mfScaleFactor) (Frame.cc:106): logf
     const size_t np = (size_t)cfg->max_pairs, nf = (size_t)cfg->nfeatures;
-    t->ldsBytes = nf * 16;
+    t->ldsBytes = nf * 20;
     if (hipMalloc(&t->dStart, np * (kGC * kGR + 1) * sizeof(int)) != hipSuccess || hipMalloc(&t->dIdx, np * nf * sizeof(unsigned short)) != hipSuccess ||
         hipMalloc(&t->dQ, np * nf * sizeof(Query)) != hipSuccess || hipMalloc(&t->dCount, np * nf * sizeof(int)) != hipSuccess ||
         hipMalloc(&t->dLists, np * nf * kListCap * sizeof(unsigned)) != hipSuccess || hipMalloc(&t->dRetry, np * sizeof(int)) != hipSuccess) {
