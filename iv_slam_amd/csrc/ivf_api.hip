@@ -246,9 +246,10 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
         HIPCHK(hipMalloc(&b.rowCnt, nP * (size_t)h * sizeof(int)));
         HIPCHK(hipMalloc(&b.rowList, nP * (size_t)h * kRowCap * sizeof(unsigned short)));
     }
-    HIPCHK(hipMalloc(&b.status, 2 * sizeof(int)));
-    HIPCHK(hipMemset(b.status, 0, 2 * sizeof(int)));
+    HIPCHK(hipMalloc(&b.status, 4 * sizeof(int)));
+    HIPCHK(hipMemset(b.status, 0, 4 * sizeof(int)));
     b.hugeCount = b.status + 1;
+    HIPCHK(hipMalloc(&b.tierList, 2 * nI * (size_t)c.nCellsTotal * sizeof(int)));
     if (c.maxCandCap > 4096) {          // kCellCapBig: cells of this geometry can outgrow the LDS selection paths
         HIPCHK(hipMalloc(&b.hugeList, (size_t)kHugeListCap * sizeof(int)));
         HIPCHK(hipMalloc(&b.hugeScratch, (size_t)kHugeSlots * 6 * c.maxCandCap * sizeof(unsigned)));
@@ -261,7 +262,7 @@ void Context::release()
 {
     (void)hipSetDevice(device);
     void* ptrs[] = {dc, dTab, b.pyr, b.qpyr, b.blur, b.tileList, b.tileCnt, b.cellCnt, b.cellInfo, b.lvlTotal, b.lvl, b.slotPos, b.slotResp, b.lvlCount,
-                    b.useCost, b.kps, b.desc, b.count, b.quality, b.uright, b.depth, b.sad, b.rowCnt, b.rowList, b.status, b.hugeList, b.hugeScratch, dStage};
+                    b.useCost, b.kps, b.desc, b.count, b.quality, b.uright, b.depth, b.sad, b.rowCnt, b.rowList, b.status, b.hugeList, b.hugeScratch, b.tierList, dStage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (hStage) (void)hipHostFree(hStage);
     for (int i = 0; i < kEvRing; i++) {
@@ -296,7 +297,7 @@ int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size
     if (inputsConsumed) HIPCHK(hipEventRecord(inputsConsumed, st));   // caller buffers are free from here on
     launch_pyramid(hc, dc, dTab, b.pyr, useQ ? b.qpyr : nullptr, b.useCost, nImg, st);   // + ComputeQualityImagePyramid :1325-1357
     HIPCHK(hipMemsetAsync(b.cellCnt, 0, (size_t)nImg * hc.nCellsTotal * 2 * sizeof(int), st));
-    HIPCHK(hipMemsetAsync(b.hugeCount, 0, sizeof(int), st));
+    HIPCHK(hipMemsetAsync(b.hugeCount, 0, 3 * sizeof(int), st));
     const int slot = (int)(nRuns % kEvRing);
     HIPCHK(hipEventRecord(evFast0[slot], st));
     launch_fast(hc, dc, b, nImg, st);

@@ -87,7 +87,8 @@ struct Buffers {            // device pointers of one batch context
     int* rowCnt;            // [nPairs][H]  right keypoints whose row band covers the row (k_stereo_rows)
     unsigned short* rowList;    // [nPairs][H][kRowCap]
     int* status;            // [1] device-side error flags, cleared by the host when read
-    int* hugeCount;         // [1] cells with more than 4096 survivors in this launch (k_quota -> k_cell_select_huge)
+    int* hugeCount;         // [3] cells with more than 4096 survivors in this launch (k_quota -> k_cell_select_huge); [1], [2]: lengths of the tier lists
+    int* tierList;          // [2][nImg * nCellsTotal] cells with 257..1024 / 1025..4096 survivors: img * nCellsTotal + cell (k_quota -> k_cell_select_list)
     int* hugeList;          // [kHugeListCap] img * nCellsTotal + cell
     unsigned* hugeScratch;  // [kHugeSlots][6 * maxCandCap] dwords, or nullptr when no cell can exceed 4096 maxima
 };

@@ -1013,7 +1013,8 @@ constexpr int kCellCapTiny = 256, kCellCapSmall = 1024, kCellCapBig = 4096;
 __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, const int* __restrict__ cellCnt,
                                               const uint8_t* __restrict__ qpyr, const uint8_t* __restrict__ useCost,
                                               CellInfo* __restrict__ cellInfo, int* __restrict__ lvlTotal,
-                                              int* __restrict__ hugeCount, int* __restrict__ hugeList, int* __restrict__ status)
+                                              int* __restrict__ hugeCount, int* __restrict__ hugeList, int* __restrict__ tierList,
+                                              int tierCap, int* __restrict__ status)
 {
     __shared__ int s_nIni[kMaxCells], s_nMin[kMaxCells], s_nTotal[kMaxCells], s_nRetain[kMaxCells], s_prefix[kMaxCells + 1];
     __shared__ unsigned s_qsum[kMaxCells];
@@ -1087,6 +1088,14 @@ __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, c
     __syncthreads();
     for (int c = tid; c < nCells; c += 256) {
         ci[c] = CellInfo{s_nTotal[c], s_nRetain[c], s_prefix[c], (int)s_useMin[c]};
+        // cells above the one-wave tier go on the work list of their tier (hugeCount[1], [2]: r04 -- their kernels walk the list
+        // instead of launching a workgroup per cell of every image that looks at its count and leaves)
+        if (s_nTotal[c] > kCellCapTiny && s_nTotal[c] <= kCellCapBig) {
+            const int tier = s_nTotal[c] > kCellCapSmall ? 1 : 0;
+            const int k = atomicAdd(hugeCount + 1 + tier, 1);
+            if (k < tierCap) tierList[(size_t)tier * tierCap + k] = img * cfg->nCellsTotal + G.cellBase + c;
+            else atomicOr(status, 4);
+        }
         if (s_nTotal[c] > kCellCapBig) {                 // too many survivors for the LDS selection: k_cell_select_huge's work list
             const int k = atomicAdd(hugeCount, 1);
             if (hugeList && k < kHugeListCap) hugeList[k] = img * cfg->nCellsTotal + G.cellBase + c;
@@ -1101,19 +1110,26 @@ __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, c
 // bitonic sort run on four waves (with the introspection quirk of overlapping cell domains most level-0/1 cells hold
 // 1-4 thousand candidates and a single wave spent ~100 us per cell in the sort); the introselect stays on wave 0.
 constexpr int kSelRows = 512;                            // tallest cell (rows) the counting sort of k_cell_select handles
+template <int CAP>
+struct __attribute__((aligned(16))) SelShared {
+    unsigned keys[CAP];
+    u64 ord[CAP];
+    int row[kSelRows + 2];                                    // per-row survivor counts, then their exclusive prefix
+    int m;
+};
 template <int CAP, int NTHR>
-__global__ __launch_bounds__(NTHR) void k_cell_select(const Config* __restrict__ cfg, const unsigned* __restrict__ tileList,
-                                                   const int* __restrict__ tileCnt, const CellInfo* __restrict__ cellInfo,
-                                                   const uint8_t* __restrict__ qpyr, const uint8_t* __restrict__ useCost,
-                                                   u64* __restrict__ lvlList, int* __restrict__ status, int nLo, int nHi)
+DEVINL void cell_select_one(const Config* __restrict__ cfg, const unsigned* __restrict__ tileList,
+                            const int* __restrict__ tileCnt, const CellInfo* __restrict__ cellInfo,
+                            const uint8_t* __restrict__ qpyr, const uint8_t* __restrict__ useCost,
+                            u64* __restrict__ lvlList, int* __restrict__ status, int nLo, int nHi, int img, int gc, int tid, SelShared<CAP>& S)
 {
-    __shared__ __attribute__((aligned(16))) unsigned keys[CAP];
-    __shared__ __attribute__((aligned(16))) u64 ord[CAP];
-    __shared__ int s_row[kSelRows + 2];                       // per-row survivor counts, then their exclusive prefix
+    unsigned* const keys = S.keys;
+    u64* const ord = S.ord;
+    int* const s_row = S.row;
+    int& s_m = S.m;
     unsigned short* stopA = (unsigned short*)keys;            // the sort keys are dead once `ord` is built:
     unsigned short* stopB = stopA + CAP;                      // their space holds the partition stop lists
-    __shared__ int s_m;
-    const int img = blockIdx.y, gc = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     auto sync = [&]() {
         if constexpr (NTHR == 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         else __syncthreads();
@@ -1151,45 +1167,61 @@ __global__ __launch_bounds__(NTHR) void k_cell_select(const Config* __restrict__
         const int ty0 = (cy0 - kEdge) / kFastTH, ty1 = (cy1 - 1 - kEdge) / kFastTH;
         const int ntx = tx1 - tx0 + 1, nt = ntx * (ty1 - ty0 + 1);
         const size_t tileBase = (size_t)img * cfg->nTiles + G.tileBase;
+        // r04: the lists of up to 64 tiles are read as ONE flattened sequence (a cell of a plain extraction spans 20-30 tiles with a few
+        // dozen survivors each: one round trip per tile was 30-40 us of dependent latency per cell).  Lane j holds tile j's count; the
+        // exclusive prefix and the tiles' list offsets go to LDS (s_row is free until the sort), every thread finds the tile of its
+        // flattened index by a 6-step binary search and U loads per thread are in flight together.
         constexpr int U = 4;
+        int* const s_pref = s_row;                // [65]
+        int* const s_toff = s_row + 80;           // [64] tile slot index
         for (int t0 = 0; t0 < nt; t0 += 64) {
-            int myCnt = 0;
+            int myCnt = 0, myTile = 0;
             if (t0 + lane < nt) {
                 const int t = t0 + lane;
-                myCnt = min(tileCnt[tileBase + (ty0 + t / ntx) * G.tilesX + tx0 + t % ntx], kTileCap);
+                myTile = (ty0 + t / ntx) * G.tilesX + tx0 + t % ntx;
+                myCnt = min(tileCnt[tileBase + myTile], kTileCap);
             }
-            const int ng = min(64, nt - t0);
-            for (int j = 0; j < ng; j++) {
-                const int nAll = __shfl(myCnt, j, 64);
-                if (nAll == 0) continue;
-                const int t = t0 + j;
-                const unsigned* in = tileList + (tileBase + (ty0 + t / ntx) * G.tilesX + tx0 + t % ntx) * kTileCap;
-                for (int b0 = 0; b0 < nAll; b0 += NTHR * U) {
-                    unsigned ev[U];
+            int incl = myCnt;
 #pragma unroll
-                    for (int u = 0; u < U; u++) { const int k = b0 + u * NTHR + tid; ev[u] = k < nAll ? in[k] : 0u; }   // score 0 < th: never kept
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            const int total = __shfl(incl, 63, 64);
+            sync();                               // the previous round's readers are done with s_pref / s_toff
+            if (tid < 64) { s_pref[lane] = incl - myCnt; s_toff[lane] = myTile; if (lane == 63) s_pref[64] = total; }
+            sync();
+            for (int f0 = 0; f0 < total; f0 += NTHR * U) {
+                unsigned ev[U];
 #pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        if (b0 + u * NTHR >= nAll) break;               // uniform
-                        const unsigned e = ev[u];
-                        const int ex = (e >> 8) & 0xfff, ey = e >> 20;
-                        const bool keep = (e & 0xffu) >= th && ex >= cx0 && ex < cx1 && ey >= cy0 && ey < cy1;
-                        const unsigned long long mask = __ballot(keep);
-                        if constexpr (NTHR == 64) {
-                            if (keep) {
-                                const int idx = m + __popcll(mask & ((1ull << lane) - 1ull));
-                                if (idx < CAP) keys[idx] = e;
-                            }
-                            m += __popcll(mask);
-                        } else {
-                            // order is irrelevant here (the sort restores it): one LDS atomic per wave reserves its slots
-                            int base = 0;
-                            if (lane == 0 && mask) base = atomicAdd(&s_m, __popcll(mask));
-                            base = __shfl(base, 0);
-                            if (keep) {
-                                const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
-                                if (idx < CAP) keys[idx] = e;
-                            }
+                for (int u = 0; u < U; u++) {
+                    const int f = f0 + u * NTHR + tid;
+                    ev[u] = 0u;                   // score 0 < th: never kept
+                    if (f < total) {
+                        int j = 0;
+#pragma unroll
+                        for (int st = 32; st > 0; st >>= 1) if (s_pref[j + st] <= f) j += st;      // s_pref[64] = total > f: j + st <= 63 always holds where it matters
+                        ev[u] = tileList[(tileBase + s_toff[j]) * kTileCap + (f - s_pref[j])];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (f0 + u * NTHR >= total) break;               // uniform
+                    const unsigned e = ev[u];
+                    const int ex = (e >> 8) & 0xfff, ey = e >> 20;
+                    const bool keep = (e & 0xffu) >= th && ex >= cx0 && ex < cx1 && ey >= cy0 && ey < cy1;
+                    const unsigned long long mask = __ballot(keep);
+                    if constexpr (NTHR == 64) {
+                        if (keep) {
+                            const int idx = m + __popcll(mask & ((1ull << lane) - 1ull));
+                            if (idx < CAP) keys[idx] = e;
+                        }
+                        m += __popcll(mask);
+                    } else {
+                        // order is irrelevant here (the sort restores it): one LDS atomic per wave reserves its slots
+                        int base = 0;
+                        if (lane == 0 && mask) base = atomicAdd(&s_m, __popcll(mask));
+                        base = __shfl(base, 0);
+                        if (keep) {
+                            const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+                            if (idx < CAP) keys[idx] = e;
                         }
                     }
                 }
@@ -1269,6 +1301,38 @@ __global__ __launch_bounds__(NTHR) void k_cell_select(const Config* __restrict__
         if (nR > 0 && nT > nR && tid < 64) sel_nth_element_wave(ord, nT, nR - 1 + cfg->varRetain, stopA, stopB, lane);
         sync();
         for (int k = tid; k < kept; k += NTHR) dst[k] = ord[k];
+    }
+}
+// tier 0 (<= kCellCapTiny survivors: in plain ORB extraction every cell): one wave per cell, WPB cells per workgroup -- a quarter of
+// the workgroups to dispatch for the same waves in flight
+template <int CAP, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_cell_select(const Config* __restrict__ cfg, const unsigned* __restrict__ tileList,
+                                                        const int* __restrict__ tileCnt, const CellInfo* __restrict__ cellInfo,
+                                                        const uint8_t* __restrict__ qpyr, const uint8_t* __restrict__ useCost,
+                                                        u64* __restrict__ lvlList, int* __restrict__ status, int nLo, int nHi)
+{
+    __shared__ SelShared<CAP> S[WPB];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gc = blockIdx.x * WPB + wave;
+    if (gc >= cfg->nCellsTotal) return;
+    cell_select_one<CAP, 64>(cfg, tileList, tileCnt, cellInfo, qpyr, useCost, lvlList, status, nLo, nHi, blockIdx.y, gc, threadIdx.x & 63, S[wave]);
+}
+// tiers 1, 2: the workgroups walk k_quota's work list of this tier (img * nCellsTotal + cell)
+template <int CAP, int NTHR>
+__global__ __launch_bounds__(NTHR) void k_cell_select_list(const Config* __restrict__ cfg, const unsigned* __restrict__ tileList,
+                                                        const int* __restrict__ tileCnt, const CellInfo* __restrict__ cellInfo,
+                                                        const uint8_t* __restrict__ qpyr, const uint8_t* __restrict__ useCost,
+                                                        u64* __restrict__ lvlList, int* __restrict__ status, int nLo, int nHi,
+                                                        const int* __restrict__ count, const int* __restrict__ list, int cap)
+{
+    __shared__ SelShared<CAP> S;
+    const int n = min(*count, cap);
+    for (int w = blockIdx.x; w < n; w += gridDim.x) {
+        const int e = list[w];
+        cell_select_one<CAP, NTHR>(cfg, tileList, tileCnt, cellInfo, qpyr, useCost, lvlList, status, nLo, nHi, e / cfg->nCellsTotal, e % cfg->nCellsTotal,
+                                   threadIdx.x, S);
+        if constexpr (NTHR == 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
     }
 }
 
@@ -1915,16 +1979,22 @@ void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nIm
 {
     if (hc.introspection)
         hipLaunchKernelGGL(k_cell_qsum, dim3((hc.nCellsTotal + 3) / 4, nImg), dim3(256), 0, s, dc, b.qpyr, b.useCost, (CellInfo*)b.cellInfo);
+    const int tierCap = nImg * hc.nCellsTotal;
     hipLaunchKernelGGL(k_quota, dim3(hc.nlevels, nImg), dim3(256), 0, s, dc, b.cellCnt, b.qpyr, b.useCost,
-                       (CellInfo*)b.cellInfo, b.lvlTotal, b.hugeCount, b.hugeList, b.status);
+                       (CellInfo*)b.cellInfo, b.lvlTotal, b.hugeCount, b.hugeList, b.tierList, tierCap, b.status);
     // three tiers by survivor count: the kernel is a chain of dependent LDS steps at one wave per cell, so its throughput is the
     // number of cells in flight per CU = LDS per workgroup: 5 KB (<= 256 survivors), 14 KB (<= 1024), 51 KB (<= 4096, four waves; a 2048 tier of two waves measured slower: 77 + 42 vs 109 us)
-    hipLaunchKernelGGL((k_cell_select<kCellCapTiny, 64>), dim3(hc.nCellsTotal, nImg), dim3(64), 0, s, dc, b.tileList, b.tileCnt,
-                       (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, 0, kCellCapTiny);
-    hipLaunchKernelGGL((k_cell_select<kCellCapSmall, 64>), dim3(hc.nCellsTotal, nImg), dim3(64), 0, s, dc, b.tileList, b.tileCnt,
-                       (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, kCellCapTiny, kCellCapSmall);
-    hipLaunchKernelGGL((k_cell_select<kCellCapBig, 256>), dim3(hc.nCellsTotal, nImg), dim3(256), 0, s, dc, b.tileList, b.tileCnt,
-                       (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, kCellCapSmall, kCellCapBig);
+    // r04: tier 0 four cells per workgroup; tiers 1 / 2 from k_quota's work lists with a fixed grid (a full grid per tier cost 80-110 us
+    // of workgroup dispatch per launch even when the tier was empty, as it is for every cell of a plain ORB extraction)
+    constexpr int kSelWPB = 4;
+    hipLaunchKernelGGL((k_cell_select<kCellCapTiny, kSelWPB>), dim3((hc.nCellsTotal + kSelWPB - 1) / kSelWPB, nImg), dim3(64 * kSelWPB), 0, s, dc,
+                       b.tileList, b.tileCnt, (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, 0, kCellCapTiny);
+    const int gridList = std::max(1, std::min(tierCap, 8192));
+    hipLaunchKernelGGL((k_cell_select_list<kCellCapSmall, 64>), dim3(gridList), dim3(64), 0, s, dc, b.tileList, b.tileCnt,
+                       (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, kCellCapTiny, kCellCapSmall, b.hugeCount + 1, b.tierList, tierCap);
+    hipLaunchKernelGGL((k_cell_select_list<kCellCapBig, 256>), dim3(std::min(gridList, 2048)), dim3(256), 0, s, dc, b.tileList, b.tileCnt,
+                       (const CellInfo*)b.cellInfo, b.qpyr, b.useCost, b.lvl, b.status, kCellCapSmall, kCellCapBig, b.hugeCount + 2,
+                       b.tierList + tierCap, tierCap);
     if (b.hugeScratch)       // geometry allows cells with more than kCellCapBig strict maxima: walk k_quota's (usually empty) list
         hipLaunchKernelGGL(k_cell_select_huge, dim3(kHugeSlots), dim3(1024), 0, s, dc, b.tileList, b.tileCnt, (const CellInfo*)b.cellInfo,
                            b.qpyr, b.useCost, b.lvl, b.status, b.hugeCount, b.hugeList, b.hugeScratch, hc.maxCandCap);
