@@ -25,11 +25,17 @@ static __device__ const int8_t __attribute__((aligned(16))) d_pattern[1024] = {
 #include "../../include/ivf_pattern31.inc"
 };
 
+// sum over the wave without the LDS crossbar (r04; was six ds_bpermute round trips): row_shr 1/2/4/8 fold each row of 16 lanes into
+// its lane 15, row_bcast15 / row_bcast31 fold the four rows into lane 63, which every lane then reads
 DEVINL int wave_sum_i32(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 // LDS operations of one wave execute in order: a wavefront-scope fence (compiler ordering) is all that one lane needs to
 // read what another lane of the same wave wrote
@@ -51,9 +57,14 @@ DEVINL bool xcd_tile_image(int nTiles, int nImg, int& tile, int& img)
 }
 DEVINL unsigned wave_min_u32(unsigned v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { unsigned t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
-    return v;
+    unsigned t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false); v = t < v ? t : v;   // row_shr:1
+    t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false); v = t < v ? t : v;   // row_shr:2
+    t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false); v = t < v ? t : v;   // row_shr:4
+    t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false); v = t < v ? t : v;   // row_shr:8
+    t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xa, 0xf, false); v = t < v ? t : v;   // row_bcast:15
+    t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xc, 0xf, false); v = t < v ? t : v;   // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -74,17 +85,28 @@ __global__ __launch_bounds__(256) void k_ingest(const Config* __restrict__ cfg, 
     uint8_t* dst = blob + (size_t)img * cfg->pyrBytes + G.off;
     const int q16 = G.pitch / 16;                                    // 16-byte pieces per pitched row (pitch % 64 == 0)
     const int rows = min(kIngestRows, G.h - y0);
-    for (int i = threadIdx.x; i < rows * q16; i += 256) {
-        const int r = i / q16, x = (i % q16) * 16;
-        const uint8_t* sp = src + (size_t)(y0 + r) * rowStride + x;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (x + 15 < G.w) __builtin_memcpy(&v, sp, 16);
-        else if (x < G.w) {                                          // the row's last piece: bytes, zero beyond the image
-            unsigned w[4] = {0u, 0u, 0u, 0u};
-            for (int k = 0; k < 16 && x + k < G.w; k++) w[k >> 2] |= (unsigned)sp[k] << (8 * (k & 3));
-            v = make_uint4(w[0], w[1], w[2], w[3]);
+    // four pieces per thread requested before the first is stored (r04: one load -> store round trip per piece was the kernel's time)
+    for (int i0 = threadIdx.x; i0 < rows * q16; i0 += 4 * 256) {
+        uint4 v[4];
+        size_t d[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + 256 * u;
+            const int r = min(i / q16, rows - 1), x = (i % q16) * 16;
+            const uint8_t* sp = src + (size_t)(y0 + r) * rowStride + x;
+            d[u] = (size_t)(y0 + r) * G.pitch + x;
+            v[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < rows * q16) {
+                if (x + 15 < G.w) __builtin_memcpy(&v[u], sp, 16);
+                else if (x < G.w) {                                  // the row's last piece: bytes, zero beyond the image
+                    unsigned w[4] = {0u, 0u, 0u, 0u};
+                    for (int k = 0; k < 16 && x + k < G.w; k++) w[k >> 2] |= (unsigned)sp[k] << (8 * (k & 3));
+                    v[u] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
         }
-        *(uint4*)(dst + (size_t)(y0 + r) * G.pitch + x) = v;
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (i0 + 256 * u < rows * q16) *(uint4*)(dst + d[u]) = v[u];
     }
 }
 
@@ -1771,6 +1793,11 @@ __global__ __launch_bounds__(256) void k_stereo_match(const Config* __restrict__
     const uint8_t* descR = A.descR + (size_t)pair * A.kpStride * 32;
     float outU = -1.0f, outD = -1.0f; int outS = -1;
 
+    // r04: the kernel is a chain of dependent memory round trips at one wave per keypoint (SQ counters: waves waiting 82 % of their
+    // cycles).  Everything whose ADDRESS is known after the left keypoint has arrived is requested at once -- the row's count, the
+    // row's first 64 list entries, the left SAD window -- a candidate's descriptor is requested together with its keypoint record
+    // (not after the band / octave / disparity tests), and the winner's x travels with the minimum instead of being read back:
+    // 4 round trips (keypoint -> row list -> candidates -> right windows) instead of 8.
     const ivf_keypoint kl = kpL[iL];
     const int levelL = kl.octave;
     const float vL = kl.y, uL = kl.x;
@@ -1778,65 +1805,82 @@ __global__ __launch_bounds__(256) void k_stereo_match(const Config* __restrict__
     const float minZ = A.bb, minD = 0, maxD = A.bf / minZ;
     const float minU = uL - maxD, maxU = uL - minD;
     const LevelGeom& G0 = cfg->lv[0];
-    bool live = row >= 0 && row < G0.h && !(maxU < 0);
+    const bool live = row >= 0 && row < G0.h && !(maxU < 0);
+    // left SAD window (depends on the left keypoint only)
+    const float scaleFactor = cfg->invScale[levelL];
+    const float scaleduL = roundf(kl.x * scaleFactor), scaledvL = roundf(kl.y * scaleFactor);
+    const int w = 5, L = 5;
+    const LevelGeom& G = cfg->lv[levelL];
+    const uint8_t* PL = A.pyrL + (size_t)pair * A.pyrStride + G.off;
+    const uint8_t* PR = A.pyrR + (size_t)pair * A.pyrStride + G.off;
+    const int yl = (int)(scaledvL - w), xl = (int)(scaleduL - w);
+    const bool okL = live && yl >= 0 && yl + 11 <= G.h && xl >= 0 && xl + 11 <= G.w;
+    const int p0y = lane / 11, p0x = lane % 11, p1y = (lane + 64) / 11, p1x = (lane + 64) % 11;
+    const bool has1 = lane + 64 < 121;
+    int cL = 0, dl0 = 0, dl1 = 0;
+    if (okL) {
+        cL = PL[(size_t)(yl + w) * G.pitch + xl + w];
+        dl0 = PL[(size_t)(yl + p0y) * G.pitch + xl + p0x];
+        if (has1) dl1 = PL[(size_t)(yl + p1y) * G.pitch + xl + p1x];
+    }
     unsigned best = (100u << 16) | 0xffffu;            // (dist << 16) | iR ; TH_HIGH start, strict <
+    float bestX = 0.0f;                                // kpR[iR].x of this lane's best
     if (live) {
         const uint4* dl = (const uint4*)(descL + (size_t)iL * 32);
         const uint4 l0 = dl[0], l1 = dl[1];
         // candidates: the row's list (vRowIndices[vL], Frame.cc:806) when it did not overflow, every right keypoint otherwise;
         // the band / octave / disparity tests below are the reference's and make both enumerations equivalent
+        const unsigned short* rl = A.rowCnt ? A.rowList + ((size_t)pair * G0.h + row) * kRowCap : nullptr;
         const int nRow = A.rowCnt ? A.rowCnt[(size_t)pair * G0.h + row] : kRowCap + 1;
+        const int first = rl ? (int)rl[lane] : 0;      // lane < 64 <= kRowCap: inside the row's slot whatever the count is
         const bool listed = nRow <= kRowCap;
-        const unsigned short* rl = listed ? A.rowList + ((size_t)pair * G0.h + row) * kRowCap : nullptr;
         const int nCand = listed ? nRow : nR;
         for (int base = 0; base < nCand; base += 64) {
             const int ci = base + lane;
-            const int iR = ci < nCand ? (listed ? (int)rl[ci] : ci) : nR;
+            const int iR = ci < nCand ? (listed ? (base == 0 ? first : (int)rl[ci]) : ci) : nR;
             if (iR < nR) {
                 const ivf_keypoint kr = kpR[iR];
+                const uint4* dr = (const uint4*)(descR + (size_t)iR * 32);
+                const uint4 r0 = dr[0], r1 = dr[1];
                 const float r = 2.0f * cfg->scale[kr.octave];
                 const int maxr = (int)ceilf(kr.y + r), minr = (int)floorf(kr.y - r);
                 if (row >= minr && row <= maxr && kr.octave >= levelL - 1 && kr.octave <= levelL + 1 &&
                     kr.x >= minU && kr.x <= maxU) {
-                    const uint4* dr = (const uint4*)(descR + (size_t)iR * 32);
-                    const unsigned d = (unsigned)hamming256(l0, l1, dr[0], dr[1]);
+                    const unsigned d = (unsigned)hamming256(l0, l1, r0, r1);
                     const unsigned key = (d << 16) | (unsigned)iR;
-                    if (d < 100u && key < best) best = key;
+                    if (d < 100u && key < best) { best = key; bestX = kr.x; }
                 }
             }
         }
     }
+    const unsigned mine = best;
     best = wave_min_u32(best);
     const int bestDist = best >> 16;
     const int bestIdxR = best & 0xffff;
     if (live && bestIdxR != 0xffff && bestDist < 75) {
-        const float uR0 = kpR[bestIdxR].x;
-        const float scaleFactor = cfg->invScale[levelL];
-        const float scaleduL = roundf(kl.x * scaleFactor), scaledvL = roundf(kl.y * scaleFactor);
+        // the key holds iR, so exactly the lanes that found this candidate hold it (one lane: a candidate is enumerated once)
+        const unsigned long long who = __ballot(mine == best);
+        const float uR0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bestX), __ffsll((long long)who) - 1));
         const float scaleduR0 = roundf(uR0 * scaleFactor);
-        const int w = 5, L = 5;
-        const LevelGeom& G = cfg->lv[levelL];
-        const uint8_t* PL = A.pyrL + (size_t)pair * A.pyrStride + G.off;
-        const uint8_t* PR = A.pyrR + (size_t)pair * A.pyrStride + G.off;
         const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
-        const int yl = (int)(scaledvL - w), xl = (int)(scaleduL - w);
-        const bool ok = !(iniu < 0 || endu >= (float)G.w) && yl >= 0 && yl + 11 <= G.h && xl >= 0 && xl + 11 <= G.w &&
-                        (int)(scaleduR0 - L - w) >= 0;
+        const bool ok = !(iniu < 0 || endu >= (float)G.w) && okL && (int)(scaleduR0 - L - w) >= 0;
         if (ok) {
-            const int cL = PL[(size_t)(yl + w) * G.pitch + xl + w];
-            // lane covers window pixels lane and lane+64 (121 total)
-            int dl0 = 0, dl1 = 0; int p0y = lane / 11, p0x = lane % 11, p1y = (lane + 64) / 11, p1x = (lane + 64) % 11;
-            const bool has1 = lane + 64 < 121;
-            dl0 = PL[(size_t)(yl + p0y) * G.pitch + xl + p0x] - cL;
-            if (has1) dl1 = PL[(size_t)(yl + p1y) * G.pitch + xl + p1x] - cL;
+            dl0 -= cL;
+            if (has1) dl1 -= cL;
+            int pc[11], pa[11], pb[11];                 // all 33 right-window reads in flight together
+#pragma unroll
+            for (int inc = -5; inc <= 5; inc++) {
+                const int xr = (int)(scaleduR0 + (float)inc - w);
+                pc[inc + 5] = PR[(size_t)(yl + w) * G.pitch + xr + w];
+                pa[inc + 5] = PR[(size_t)(yl + p0y) * G.pitch + xr + p0x];
+                pb[inc + 5] = has1 ? PR[(size_t)(yl + p1y) * G.pitch + xr + p1x] : 0;
+            }
             int bestD = 0x7fffffff, bestinc = 0;
             float vDists[11];
 #pragma unroll
             for (int inc = -5; inc <= 5; inc++) {
-                const int xr = (int)(scaleduR0 + (float)inc - w);
-                const int cR = PR[(size_t)(yl + w) * G.pitch + xr + w];
-                int acc = abs(dl0 - (PR[(size_t)(yl + p0y) * G.pitch + xr + p0x] - cR));
-                if (has1) acc += abs(dl1 - (PR[(size_t)(yl + p1y) * G.pitch + xr + p1x] - cR));
+                int acc = abs(dl0 - (pa[inc + 5] - pc[inc + 5]));
+                if (has1) acc += abs(dl1 - (pb[inc + 5] - pc[inc + 5]));
                 acc = wave_sum_i32(acc);
                 const float dist = (float)acc;
                 if (dist < (float)bestD) { bestD = (int)dist; bestinc = inc; }
