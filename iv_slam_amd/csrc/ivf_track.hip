@@ -376,12 +376,14 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
     int nm = 0, nMatch = 0;
     const float factor = 1.0f / 30.0f;                         // 1.0f / HISTO_LENGTH (:1380)
 
-    // r04: a group of 16 queries is evaluated SPECULATIVELY against the state the group starts from -- four queries per pass, one per
-    // DPP row of 16 lanes (a window holds a handful of candidates: radius 7 px x the octave's scale) -- and committed in order.  The
-    // speculative first minimum of query k is also its first minimum under the state it would have seen in turn unless an earlier
-    // query OF THE SAME GROUP has taken exactly that keypoint as a blocking assignment (the candidates it would have seen are a subset
-    // of the ones evaluated, in the same order): only then, or when a list is longer than a row, is the query walked again against the
-    // live state.  The next group's lists are requested before the current group is evaluated.
+    // r04: a group of 16 queries is evaluated SPECULATIVELY against the live state -- four queries per pass, one per DPP row of 16 lanes
+    // (a window holds a handful of candidates: radius 7 px x the octave's scale) -- and the longest PREFIX of the group in which no two
+    // matched queries chose the same keypoint is committed at once: for those queries the state they would have seen in turn differs
+    // from the evaluated one only by assignments to keypoints none of them chose, so the speculative first minimum is the serial one.
+    // The first query that lost a keypoint to an earlier one of the group (the same corner found at two pyramid levels: common) starts
+    // the next round, evaluated against the state that now holds the winner; a query whose list is longer than a row is walked alone
+    // against the live state (64 entries per step, or its window again when the list overflowed).  The next group's lists are
+    // requested before the current group is evaluated.
     struct Grp { unsigned ent[4]; int cnt[4]; float ur[4]; unsigned bits[4]; int myCnt; Query myQ; float myAng; };
     auto load_group = [&](int g0, Grp& g) {
         const int gi = g0 + (lane & (kPrefetch - 1));
@@ -399,91 +401,37 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
             g.ur[m] = ub.x; g.bits[m] = __builtin_bit_cast(unsigned, ub.y);
         }
     };
-    Grp cur;
+#ifdef IVF_TRACK_TIMING
+    const unsigned long long tt0 = __builtin_amdgcn_s_memtime();
+    int dbgRounds = 0, dbgBig = 0, dbgGroups = 0;
+#endif
+    Grp cur, nxt;                             // two groups ahead: a group's work (~1 us) is shorter than a trip to L2 / HBM under load
     load_group(0, cur);
+    load_group(kPrefetch, nxt);
     for (int g0 = 0; g0 < nL; g0 += kPrefetch) {
-        Grp nxt;
-        load_group(g0 + kPrefetch, nxt);
-        // ---- speculative pass: row r of pass m = query 4 m + r
-        unsigned key[4]; int i2m[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const unsigned e = cur.ent[m];
-            const int i2 = e & 0xffff, d = e >> 16, pos = lane & 15;
-            bool ok = pos < cur.cnt[m] && cur.cnt[m] <= 16;
-            if (ok) {
-                const int a = s_assign[i2];
-                if (a >= 0 && !(a & kNoBlock)) ok = false;
-                const float u2 = s_ur[i2];
-                if (u2 > 0) { const float er = fabsf(cur.ur[m] - u2); if (er > th * s_scale[cur.bits[m] & 0xff]) ok = false; }
-            }
-            i2m[m] = i2;
-            key[m] = ok ? ((unsigned)d << 6) | (unsigned)pos : 0xffffffffu;
-        }
-#pragma unroll
-        for (int m = 0; m < 4; m++) {             // minimum of each row of 16 lanes, in its lane 15
-            unsigned v = key[m], t;
-            t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false); v = t < v ? t : v;
-            t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false); v = t < v ? t : v;
-            t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false); v = t < v ? t : v;
-            t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false); v = t < v ? t : v;
-            key[m] = v;
-        }
-        // ---- commit.  Lane k < 16 collects query k's result (row k & 3 of pass k >> 2); if no two matched queries of the group chose the
-        // same keypoint (each writes its lane into s_claim[keypoint] and reads it back) and no list is longer than a row, the sixteen
-        // commits are independent and are made at once; otherwise the group is committed query by query.
-        int taken = -1;                           // lane k: the keypoint query k of this group took as a BLOCKING assignment
+        Grp nx2;
+        load_group(g0 + 2 * kPrefetch, nx2);
         int fb = -1;                              // lane k: the keypoint query k matched (-1: none)
         const int myCnt = cur.myCnt;
         const Query myQ = cur.myQ;
         const int kEnd = min(kPrefetch, nL - g0);
-        bool serial;
-        {
-            const int src = 16 * (lane & 3) + 15, mSel = (lane >> 2) & 3;
-            unsigned kq[4];
-#pragma unroll
-            for (int m = 0; m < 4; m++) kq[m] = (unsigned)__builtin_amdgcn_ds_bpermute(4 * src, (int)key[m]);
-            const unsigned best = mSel == 0 ? kq[0] : (mSel == 1 ? kq[1] : (mSel == 2 ? kq[2] : kq[3]));
-            const int src2 = 16 * (lane & 3) + (int)(best & 15u);
-            int iq[4];
-#pragma unroll
-            for (int m = 0; m < 4; m++) iq[m] = __builtin_amdgcn_ds_bpermute(4 * src2, i2m[m]);
-            const int bi = mSel == 0 ? iq[0] : (mSel == 1 ? iq[1] : (mSel == 2 ? iq[2] : iq[3]));
-            const bool mine = lane < kEnd;
-            const bool mt = mine && myCnt != 0 && myCnt <= 16 && best != 0xffffffffu && (int)(best >> 6) <= 100;      // TH_HIGH (:1469)
-            if (mt) s_claim[bi] = lane;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const bool clash = (mt && s_claim[bi] != lane) || (mine && myCnt > 16);
-            serial = __ballot(clash) != 0ull;
-            if (!serial && mt) {
-                s_assign[bi] = ((myQ.bits >> 25) & 1u) ? (g0 + lane) : ((g0 + lane) | kNoBlock);
-                fb = bi;
-            }
-        }
-#pragma nounroll
-        for (int k = 0; serial && k < kEnd; k++) {          // not unrolled: the walk-again path below would be instantiated 16 times
-            const int i = g0 + k;
-            const int cnt = __builtin_amdgcn_readlane(myCnt, k);
-            if (cnt == 0) continue;                                                   // vIndices2.empty() (:1439)
-            const float qur = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myQ.ur), k));
-            const unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)myQ.bits, k);
-            const float radius = th * P.scale[bits & 0xff];
-            int bestDist = 256, bestIdx2 = -1;
-            bool again = cnt > 16;
-            if (!again) {
-                const int m = k >> 2;             // uniform selects instead of a dynamically indexed register array
-                const unsigned keyM = m == 0 ? key[0] : (m == 1 ? key[1] : (m == 2 ? key[2] : key[3]));
-                const int i2M = m == 0 ? i2m[0] : (m == 1 ? i2m[1] : (m == 2 ? i2m[2] : i2m[3]));
-                const unsigned best = (unsigned)__builtin_amdgcn_readlane((int)keyM, 16 * (k & 3) + 15);
-                if (best != 0xffffffffu) {
-                    bestDist = best >> 6;
-                    bestIdx2 = __builtin_amdgcn_readlane(i2M, 16 * (k & 3) + (int)(best & 15u));
-                    if (__ballot(taken == bestIdx2)) again = true;
-                }
-            }
-            if (again) {
-                bestDist = 256; bestIdx2 = -1;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const unsigned bigMask = (unsigned)__ballot(lane < kEnd && myCnt > 16);
+        int kstart = 0;
+#ifdef IVF_TRACK_TIMING
+        dbgGroups++;
+#endif
+        while (kstart < kEnd) {
+#ifdef IVF_TRACK_TIMING
+            if ((bigMask >> kstart) & 1u) dbgBig++; else dbgRounds++;
+#endif
+            if ((bigMask >> kstart) & 1u) {
+                // ---- a long list: this query alone, against the live state
+                const int k = kstart, i = g0 + k;
+                const int cnt = __builtin_amdgcn_readlane(myCnt, k);
+                const float qur = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myQ.ur), k));
+                const unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)myQ.bits, k);
+                const float radius = th * P.scale[bits & 0xff];
+                int bestDist = 256, bestIdx2 = -1;
                 if (cnt <= kListCap) {
                     const unsigned e = Lp[(size_t)i * kListCap + lane];
                     const int i2 = e & 0xffff, d = e >> 16;
@@ -534,12 +482,66 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
                     if (who) { bestDist = (int)minHi; bestIdx2 = __builtin_amdgcn_readlane(bestIdx2, __ffsll((long long)who) - 1); }
                     else bestIdx2 = -1;
                 }
+                if (bestIdx2 >= 0 && bestDist <= 100) {                                     // TH_HIGH (:1469)
+                    if (lane == 0) s_assign[bestIdx2] = ((bits >> 25) & 1u) ? i : (i | kNoBlock);
+                    if (lane == k) fb = bestIdx2;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                kstart++;
+                continue;
             }
-            if (bestIdx2 >= 0 && bestDist <= 100) {                                     // TH_HIGH (:1469)
-                const int blocks = (bits >> 25) & 1;
-                if (lane == 0) s_assign[bestIdx2] = blocks ? i : (i | kNoBlock);
-                if (lane == k) { fb = bestIdx2; if (blocks) taken = bestIdx2; }
+            // ---- speculative pass: row r of pass m = query 4 m + r
+            unsigned key[4]; int i2m[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const unsigned e = cur.ent[m];
+                const int i2 = e & 0xffff, d = e >> 16, pos = lane & 15;
+                bool ok = pos < cur.cnt[m] && cur.cnt[m] <= 16;
+                if (ok) {
+                    const int a = s_assign[i2];
+                    if (a >= 0 && !(a & kNoBlock)) ok = false;
+                    const float u2 = s_ur[i2];
+                    if (u2 > 0) { const float er = fabsf(cur.ur[m] - u2); if (er > th * s_scale[cur.bits[m] & 0xff]) ok = false; }
+                }
+                i2m[m] = i2;
+                key[m] = ok ? ((unsigned)d << 6) | (unsigned)pos : 0xffffffffu;
             }
+#pragma unroll
+            for (int m = 0; m < 4; m++) {             // minimum of each row of 16 lanes, in its lane 15
+                unsigned v = key[m], t;
+                t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false); v = t < v ? t : v;
+                t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false); v = t < v ? t : v;
+                t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false); v = t < v ? t : v;
+                t = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false); v = t < v ? t : v;
+                key[m] = v;
+            }
+            // lane k < 16 collects query k's result (row k & 3 of pass k >> 2)
+            const int src = 16 * (lane & 3) + 15, mSel = (lane >> 2) & 3;
+            unsigned kq[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) kq[m] = (unsigned)__builtin_amdgcn_ds_bpermute(4 * src, (int)key[m]);
+            const unsigned best = mSel == 0 ? kq[0] : (mSel == 1 ? kq[1] : (mSel == 2 ? kq[2] : kq[3]));
+            const int src2 = 16 * (lane & 3) + (int)(best & 15u);
+            int iq[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) iq[m] = __builtin_amdgcn_ds_bpermute(4 * src2, i2m[m]);
+            const int bi = mSel == 0 ? iq[0] : (mSel == 1 ? iq[1] : (mSel == 2 ? iq[2] : iq[3]));
+            const bool mine = lane >= kstart && lane < kEnd;
+            const bool mt = mine && myCnt != 0 && myCnt <= 16 && best != 0xffffffffu && (int)(best >> 6) <= 100;      // TH_HIGH (:1469)
+            // the lowest query of every set that chose the same keypoint wins it; the others are losers
+            if (mt) s_claim[bi] = 64;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (mt) atomicMin(&s_claim[bi], lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const bool loser = mt && s_claim[bi] != lane;
+            const unsigned stopMask = ((unsigned)__ballot(loser) | bigMask) & (0xffffffffu << kstart);
+            const int kstop = stopMask ? min(__ffs((int)stopMask) - 1, kEnd) : kEnd;
+            if (mt && lane < kstop) {
+                s_assign[bi] = ((myQ.bits >> 25) & 1u) ? (g0 + lane) : ((g0 + lane) | kNoBlock);
+                fb = bi;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            kstart = kstop;
         }
         // ---- the group's matches: rotation bins (:1476-1484) and the match list, lane k = query k
         {
@@ -558,8 +560,11 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
             nMatch += n; nm += n;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        cur = nxt;
+        cur = nxt; nxt = nx2;
     }
+#ifdef IVF_TRACK_TIMING
+    const unsigned long long tt1 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- rotation consistency: ComputeThreeMaxima (:1654-1695) over the 30 bins, matches of every other bin are taken back
     if (P.checkOri) {
         int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
@@ -609,6 +614,12 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
         nmatchesOut[p] = nm;
         retryFlag[p] = (!onlyFlagged && nm < retryBelow) ? 1 : 0;                      // Tracking.cc:1320
     }
+#ifdef IVF_TRACK_TIMING
+    if (lane == 0 && (p == 1 || p == 40)) {
+        const unsigned long long tt2 = __builtin_amdgcn_s_memtime();
+        printf("pair %d pass %d: loop %llu epilogue %llu cycles(100MHz) groups %d rounds %d big %d nm %d\n", p, onlyFlagged, tt1 - tt0, tt2 - tt1, dbgGroups, dbgRounds, dbgBig, nm);
+    }
+#endif
 }
 
 
