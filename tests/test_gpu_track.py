@@ -285,6 +285,62 @@ def test_random_records_ties_and_overflowing_windows(iv, seed, nf, cluster, th):
         check_pairs(cam, recs, pairs, a, nm, poses=ps, what="seed %d %r" % (seed, kw), **kw)
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_consecutive_queries_claim_the_same_keypoints(iv, seed):
+    """k_track_greedy commits a group of 16 queries at once unless two of them chose the same keypoint: here runs of CONSECUTIVE last
+    keypoints sit on the same spot with near-identical descriptors (every member of a run wants the same few current keypoints), runs
+    straddle the 16-query groups, some points have no observations (their assignment does not block: the next query may take the same
+    keypoint), some windows hold more than 16 and more than 64 candidates.  Bar: identical to the serial oracle."""
+    from iv_slam_amd._lib import KP_DTYPE
+    rng = np.random.default_rng(seed)
+    w, h, nf = 640, 240, 512
+    cam = dict(nf=nf, scale=scale_table(), fx=F(370.0), fy=F(370.0), cx=F(320.0), cy=F(120.0), bf=F(198.75), b=F(F(198.75) / F(370.0)),
+               bounds=(0.0, 0.0, float(w), float(h)))
+
+    def make(n_spots, run_len, cand_per_spot):
+        sx = rng.uniform(40, w - 40, n_spots); sy = rng.uniform(30, h - 30, n_spots)
+        sd = rng.integers(0, 256, (n_spots, 32)).astype(np.uint8)
+        so = rng.integers(0, 4, n_spots)
+        # last frame: run_len consecutive keypoints per spot (same position up to 0.5 px, descriptor up to 2 flipped bits)
+        lx, ly, ld, lo = [], [], [], []
+        for s_ in range(n_spots):
+            for _ in range(int(run_len[s_])):
+                lx.append(sx[s_] + rng.uniform(-0.5, 0.5)); ly.append(sy[s_] + rng.uniform(-0.5, 0.5)); lo.append(so[s_])
+                d = sd[s_].copy()
+                for _b in range(int(rng.integers(0, 3))):
+                    bit = int(rng.integers(0, 256)); d[bit // 8] ^= np.uint8(1 << (bit % 8))
+                ld.append(d)
+        n = min(len(lx), nf)
+        kl = np.zeros(n, KP_DTYPE); kl["x"] = np.array(lx[:n], F); kl["y"] = np.array(ly[:n], F); kl["octave"] = np.array(lo[:n]); kl["angle"] = 10; kl["size"] = 31
+        disp = rng.uniform(4, 40, n)
+        last = dict(kps=kl, desc=np.array(ld[:n], np.uint8), uright=(kl["x"] - disp).astype(F), depth=(F(198.75) / disp.astype(F)).astype(F))
+        # current frame: cand_per_spot keypoints around every spot, descriptors at growing distance from the spot's
+        cx_, cy_, cd, co = [], [], [], []
+        for s_ in range(n_spots):
+            for j in range(int(cand_per_spot[s_])):
+                cx_.append(sx[s_] + rng.uniform(-3, 3)); cy_.append(sy[s_] + rng.uniform(-3, 3)); co.append(so[s_])
+                d = sd[s_].copy()
+                for bit in rng.choice(256, size=min(3 * (j % 9), 60), replace=False):
+                    d[bit // 8] ^= np.uint8(1 << (bit % 8))
+                cd.append(d)
+        order = rng.permutation(len(cx_))[:nf]
+        kc = np.zeros(len(order), KP_DTYPE); kc["x"] = np.array(cx_, F)[order]; kc["y"] = np.array(cy_, F)[order]; kc["octave"] = np.array(co)[order]
+        kc["angle"] = 12; kc["size"] = 31
+        cur = dict(kps=kc, desc=np.array(cd, np.uint8)[order], uright=np.full(len(order), -1, F), depth=np.full(len(order), -1, F))
+        return last, cur
+
+    a0, b0 = make(40, rng.integers(1, 12, 40), rng.integers(1, 9, 40))               # short runs, a handful of candidates: the row-packed path
+    a1, b1 = make(12, rng.integers(10, 40, 12), rng.integers(12, 30, 12))            # long runs over several groups, lists of 12..30 (> a row)
+    a2, b2 = make(4, rng.integers(30, 100, 4), rng.integers(70, 120, 4))             # lists beyond the 64-entry cap: re-walked windows
+    recs = [a0, b0, a1, b1, a2, b2]
+    pairs = [(0, 1), (2, 3), (4, 5), (0, 3), (2, 1)]
+    flags = [rng.choice(np.array([0, 1, 3, 3], np.uint8), size=len(r["kps"])) for r in recs]   # bit 0: a map point; bit 1: with observations (it blocks)
+    for kw, fl in ((dict(th=7.0), None), (dict(th=7.0, retry_below=0), flags), (dict(th=7.0, points_block=False, check_orientation=False), None)):
+        a, nm = run_tracker(iv, cam, recs, pairs, flags=fl, **kw)
+        total = check_pairs(cam, recs, pairs, a, nm, flags=fl, what="seed %d %r" % (seed, kw), **kw)
+        assert total > 50, total
+
+
 def test_tracker_argument_checks(iv):
     import torch
     sc = scale_table()
