@@ -82,6 +82,7 @@ struct Context {
     static constexpr int kEvRing = 64;  // HIP event pairs around the FAST+NMS launch of the last kEvRing runs
     hipEvent_t evFast0[kEvRing] = {}, evFast1[kEvRing] = {};
     long long nRuns = 0;
+    int pyrEpoch = 0;               // launches of k_pyr_multi so far: its barrier counters only grow
     hipStream_t lastStream = nullptr;
 
     int build(const Tables& t, int w, int h, int maxImages, int sides, int dev, bool withStereo, const int* variant = nullptr);
@@ -250,6 +251,8 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
     HIPCHK(hipMemset(b.status, 0, 4 * sizeof(int)));
     b.hugeCount = b.status + 1;
     HIPCHK(hipMalloc(&b.tierList, 2 * nI * (size_t)c.nCellsTotal * sizeof(int)));
+    HIPCHK(hipMalloc(&b.pyrBar, 4 * 2 * nI * 8 * sizeof(int)));
+    HIPCHK(hipMemset(b.pyrBar, 0, 4 * 2 * nI * 8 * sizeof(int)));
     if (c.maxCandCap > 4096) {          // kCellCapBig: cells of this geometry can outgrow the LDS selection paths
         HIPCHK(hipMalloc(&b.hugeList, (size_t)kHugeListCap * sizeof(int)));
         HIPCHK(hipMalloc(&b.hugeScratch, (size_t)kHugeSlots * 6 * c.maxCandCap * sizeof(unsigned)));
@@ -262,7 +265,7 @@ void Context::release()
 {
     (void)hipSetDevice(device);
     void* ptrs[] = {dc, dTab, b.pyr, b.qpyr, b.blur, b.tileList, b.tileCnt, b.cellCnt, b.cellInfo, b.lvlTotal, b.lvl, b.slotPos, b.slotResp, b.lvlCount,
-                    b.useCost, b.kps, b.desc, b.count, b.quality, b.uright, b.depth, b.sad, b.rowCnt, b.rowList, b.status, b.hugeList, b.hugeScratch, b.tierList, dStage};
+                    b.useCost, b.kps, b.desc, b.count, b.quality, b.uright, b.depth, b.sad, b.rowCnt, b.rowList, b.status, b.hugeList, b.hugeScratch, b.tierList, b.pyrBar, dStage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (hStage) (void)hipHostFree(hStage);
     for (int i = 0; i < kEvRing; i++) {
@@ -295,7 +298,7 @@ int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size
     launch_ingest(hc, dc, b, s0, s1, imageStride, rowStride, nImg, nSides, b.pyr, st);
     if (cost) launch_ingest(hc, dc, b, cost, cost, costStride, costRowStride, nImg, nSides, b.qpyr, st);
     if (inputsConsumed) HIPCHK(hipEventRecord(inputsConsumed, st));   // caller buffers are free from here on
-    launch_pyramid(hc, dc, dTab, b.pyr, useQ ? b.qpyr : nullptr, b.useCost, nImg, st);   // + ComputeQualityImagePyramid :1325-1357
+    launch_pyramid(hc, dc, dTab, b.pyr, useQ ? b.qpyr : nullptr, b.useCost, nImg, st, b.pyrBar, &pyrEpoch, 2 * maxImg);   // + ComputeQualityImagePyramid :1325-1357
     HIPCHK(hipMemsetAsync(b.cellCnt, 0, (size_t)nImg * hc.nCellsTotal * 2 * sizeof(int), st));
     HIPCHK(hipMemsetAsync(b.hugeCount, 0, 3 * sizeof(int), st));
     const int slot = (int)(nRuns % kEvRing);

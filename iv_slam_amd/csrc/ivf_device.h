@@ -88,6 +88,7 @@ struct Buffers {            // device pointers of one batch context
     unsigned short* rowList;    // [nPairs][H][kRowCap]
     int* status;            // [1] device-side error flags, cleared by the host when read
     int* hugeCount;         // [3] cells with more than 4096 survivors in this launch (k_quota -> k_cell_select_huge); [1], [2]: lengths of the tier lists
+    int* pyrBar;            // [4 ring slots][2 * maxImg planes][8] arrival word + level counters of k_pyr_multi (slot = launch % 4, zeroed two launches ahead)
     int* tierList;          // [2][nImg * nCellsTotal] cells with 257..1024 / 1025..4096 survivors: img * nCellsTotal + cell (k_quota -> k_cell_select_list)
     int* hugeList;          // [kHugeListCap] img * nCellsTotal + cell
     unsigned* hugeScratch;  // [kHugeSlots][6 * maxCandCap] dwords, or nullptr when no cell can exceed 4096 maxima
@@ -120,7 +121,7 @@ void launch_stereo_args(const Config& hc, const Config* dc, const StereoArgs& A,
 void launch_ingest(const Config& hc, const Config* dc, const Buffers& b, const uint8_t* src0, const uint8_t* src1,
                    size_t imageStride, int rowStride, int nImg, int nSides, uint8_t* dstBlob, hipStream_t s);
 void launch_pyramid(const Config& hc, const Config* dc, const ResizeCoef* dTab, uint8_t* blob, uint8_t* qblob, const uint8_t* useCost,
-                    int nImg, hipStream_t s);
+                    int nImg, hipStream_t s, int* bar, int* epoch, int maxPlanes);
 void launch_fast(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s);
 void launch_blur(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s);
 void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s);
