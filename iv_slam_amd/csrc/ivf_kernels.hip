@@ -769,6 +769,18 @@ __global__ __launch_bounds__(256) void k_blur7(const Config* __restrict__ cfg, c
         const int gx = x0 - 4 + 4 * rq;
         const bool inner = gx >= 0 && gx + 3 < gw;
         unsigned v[IT];
+        if (x0 - 4 >= 0 && x0 + kBlurTW + 4 <= gw) {
+            // r04: a tile whose window lies inside the plane horizontally (uniform: 8 of 10 tile columns at level 0) needs no
+            // per-byte reflection -- one buffer load per dword with a 32-bit offset (the staging of the general path below was
+            // ~300 of the kernel's ~510 VALU instructions per thread: clamps, selects and 64-bit addresses for six loads)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, pitch * gh, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < IT; k++) {
+                const int ry = min(r0 + RPP * k, RH - 1);
+                int gy = y0 - 3 + ry; gy = gy < 0 ? -gy : gy; gy = gy >= gh ? 2 * (gh - 1) - gy : gy; gy = max(gy, 0);
+                v[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, gy * pitch + gx, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int k = 0; k < IT; k++) {
             const int ry = min(r0 + RPP * k, RH - 1);

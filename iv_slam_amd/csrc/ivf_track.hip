@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
     };
 #ifdef IVF_TRACK_TIMING
     const unsigned long long tt0 = __builtin_amdgcn_s_memtime();
-    int dbgRounds = 0, dbgBig = 0, dbgGroups = 0;
+    int dbgRounds = 0, dbgBig = 0, dbgGroups = 0, dbgC4 = 0, dbgC8 = 0, dbgC0 = 0;
 #endif
     Grp cur, nxt;                             // two groups ahead: a group's work (~1 us) is shorter than a trip to L2 / HBM under load
     load_group(0, cur);
@@ -419,6 +419,8 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
         int kstart = 0;
 #ifdef IVF_TRACK_TIMING
         dbgGroups++;
+        dbgC4 += __popcll(__ballot(lane < kEnd && myCnt > 4)); dbgC8 += __popcll(__ballot(lane < kEnd && myCnt > 8));
+        dbgC0 += __popcll(__ballot(lane < kEnd && myCnt == 0));
 #endif
         while (kstart < kEnd) {
 #ifdef IVF_TRACK_TIMING
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
 #ifdef IVF_TRACK_TIMING
     if (lane == 0 && (p == 1 || p == 40)) {
         const unsigned long long tt2 = __builtin_amdgcn_s_memtime();
-        printf("pair %d pass %d: loop %llu epilogue %llu cycles(100MHz) groups %d rounds %d big %d nm %d\n", p, onlyFlagged, tt1 - tt0, tt2 - tt1, dbgGroups, dbgRounds, dbgBig, nm);
+        printf("pair %d pass %d: loop %llu epilogue %llu cycles groups %d rounds %d big(>16) %d nm %d | queries with no candidate %d, more than 4: %d, more than 8: %d\n", p, onlyFlagged, tt1 - tt0, tt2 - tt1, dbgGroups, dbgRounds, dbgBig, nm, dbgC0, dbgC4, dbgC8);
     }
 #endif
 }
