@@ -1262,6 +1262,9 @@ DEVINL void cell_select_one(const Config* __restrict__ cfg, const unsigned* __re
     const int kept = (nR >= 0 && nT > nR) ? nR : nT;
     u64* dst = lvlList + (size_t)img * cfg->candTotal + G.candBase + info.prefix;
     if (nT > CAP) return;                                            // > kCellCapBig survivors: k_cell_select_huge
+#ifdef IVF_SEL_TIMING
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
     // a) collect the cell's survivors from the FAST tiles it overlaps, filtered by its rectangle and threshold
     //    (order irrelevant here)
     const int ci = c / G.cols, cj = c % G.cols;
@@ -1341,6 +1344,9 @@ DEVINL void cell_select_one(const Config* __restrict__ cfg, const unsigned* __re
         }
     }
     if constexpr (NTHR != 64) { sync(); m = s_m; }
+#ifdef IVF_SEL_TIMING
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
     if (tid == 0 && m != nT) atomicOr(status, 1);                    // internal consistency
     if (m != nT) return;
     {
@@ -1397,6 +1403,9 @@ DEVINL void cell_select_one(const Config* __restrict__ cfg, const unsigned* __re
                     sync();
                 }
         }
+#ifdef IVF_SEL_TIMING
+        const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
         // c) 64-bit keys: response (x quality factor) | y | x
         for (int k = tid; k < m; k += NTHR) {
             const unsigned e = keys[k];
@@ -1409,9 +1418,17 @@ DEVINL void cell_select_one(const Config* __restrict__ cfg, const unsigned* __re
             ord[k] = ((u64)__float_as_uint(resp) << 32) | (y << 16) | x;
         }
         sync();
+#ifdef IVF_SEL_TIMING
+        const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+#endif
         // d) retainBest (wave 0; the stop lists overlay `keys`, which every wave has finished reading)
         if (nR > 0 && nT > nR && tid < 64) sel_nth_element_wave(ord, nT, nR - 1 + cfg->varRetain, stopA, stopB, lane);
         sync();
+#ifdef IVF_SEL_TIMING
+        const unsigned long long st4 = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && (img == 3 || img == 100) && (gc % 7) == 0)
+            printf("cell %d img %d CAP %d: nT %d nR %d rows %d | gather %llu sort %llu keys %llu select %llu cycles\n", gc, img, CAP, nT, nR, cy1 - cy0, st1 - st0, st2 - st1, st3 - st2, st4 - st3);
+#endif
         for (int k = tid; k < kept; k += NTHR) dst[k] = ord[k];
     }
 }
