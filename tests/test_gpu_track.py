@@ -285,6 +285,22 @@ def test_random_records_ties_and_overflowing_windows(iv, seed, nf, cluster, th):
         check_pairs(cam, recs, pairs, a, nm, poses=ps, what="seed %d %r" % (seed, kw), **kw)
 
 
+@pytest.mark.parametrize("seed", range(1000, 1000 + int(os.environ.get("IVF_FUZZ_TRACK", "3"))))
+def test_random_records_more_seeds(iv, seed):
+    """the random-record scenario of the test above with geometry drawn from the seed (IVF_FUZZ_TRACK = number of seeds for soak runs)"""
+    rng = np.random.default_rng(seed)
+    nf = int(rng.choice([100, 300, 700, 1200, 2500])); cluster = float(rng.choice([1.0, 0.5, 0.25, 0.15])); th = float(rng.choice([5.0, 7.0, 12.0, 20.0]))
+    w, h = 640, 240
+    cam = dict(nf=nf, scale=scale_table(), fx=F(370.0), fy=F(370.0), cx=F(320.0), cy=F(120.0), bf=F(198.75), b=F(F(198.75) / F(370.0)),
+               bounds=(0.0, 0.0, float(w), float(h)))
+    recs = _random_records(rng, nf, 4, w, h, cluster)
+    pairs = [(0, 1), (1, 2), (2, 3), (0, 3), (3, 1)]
+    flags = [rng.choice(np.array([0, 1, 3, 3], np.uint8), size=len(r["kps"])) for r in recs]
+    for kw, fl in ((dict(th=th), None), (dict(th=th, retry_below=0), flags)):
+        a, nm = run_tracker(iv, cam, recs, pairs, flags=fl, **kw)
+        check_pairs(cam, recs, pairs, a, nm, flags=fl, what="seed %d %r" % (seed, kw), **kw)
+
+
 @pytest.mark.parametrize("seed", [11, 12, 13])
 def test_consecutive_queries_claim_the_same_keypoints(iv, seed):
     """k_track_greedy commits a group of 16 queries at once unless two of them chose the same keypoint: here runs of CONSECUTIVE last
