@@ -1696,23 +1696,30 @@ __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg
     if (!xcd_tile_image((nf + kDescKP - 1) / kDescKP, nImg, grp, img)) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int* lc = lvlCount + img * kMaxLevels;
+#ifdef IVF_DESC_TIMING
+    const unsigned long long dt0 = __builtin_amdgcn_s_memtime();
+#endif
     // phase 0: slot -> (level, output index, position), one lane per slot
     if (threadIdx.x < kDescKP) {
         const int slot = grp * kDescKP + threadIdx.x;
         int level = -1, oi = 0;
         unsigned pos = 0;
         if (slot < nf) {
+            const unsigned myPos = slotPos[(size_t)img * nf + slot];      // requested together with the level counts (one round trip, not two)
             int lv = 0;
             for (int l = 1; l < nl; l++) if (slot >= cfg->lv[l].kpBase) lv = l;
             int before = 0, total = 0;
             for (int l = 0; l < nl; l++) { const int c = lc[l]; if (l < lv) before += c; total += c; }
             if (slot == 0) count[img] = total;
             const int k = slot - cfg->lv[lv].kpBase;
-            if (k < lc[lv]) { level = lv; oi = before + k; pos = slotPos[(size_t)img * nf + slot]; }
+            if (k < lc[lv]) { level = lv; oi = before + k; pos = myPos; }
         }
         s_level[threadIdx.x] = level; s_oi[threadIdx.x] = oi; s_pos[threadIdx.x] = pos;
     }
     __syncthreads();
+#ifdef IVF_DESC_TIMING
+    const unsigned long long dt1 = __builtin_amdgcn_s_memtime();
+#endif
     const uint8_t* Pimg = pyr + (size_t)img * cfg->pyrBytes;
     const uint8_t* Bimg = blur + (size_t)img * cfg->pyrBytes;
     // phase 1: IC_Angle.  umax (ORBextractor.cc:458-475) depends only on HALF_PATCH_SIZE = 15, so it is a packed constant
@@ -1763,6 +1770,9 @@ __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg
         }
     }
     __syncthreads();
+#ifdef IVF_DESC_TIMING
+    const unsigned long long dt2 = __builtin_amdgcn_s_memtime();
+#endif
     // phase 2: angle, cos, sin -- one lane per keypoint
     if (threadIdx.x < kDescKP && s_level[threadIdx.x] >= 0) {
         const float m01 = (float)s_m01[threadIdx.x], m10 = (float)s_m10[threadIdx.x];
@@ -1773,65 +1783,97 @@ __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg
         s_angle[threadIdx.x] = angle; s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
     }
     __syncthreads();
-    // phase 3: rBRIEF (lane handles tests 4*lane .. 4*lane+3): the 8 samples of every keypoint of the wave first, then the bits
+#ifdef IVF_DESC_TIMING
+    const unsigned long long dt3 = __builtin_amdgcn_s_memtime();
+#endif
+    // phase 3: rBRIEF (lane handles tests 4*lane .. 4*lane+3).  r04: the 512 samples of a keypoint were 512 single-byte gathers from the
+    // blurred plane -- 8 load instructions per lane and keypoint, each touching up to 64 different cache lines (measured with
+    // IVF_DESC_TIMING: 56k of a workgroup's 95k cycles, bound by the L1's line requests, not by latency).  Every rotated sample lies within
+    // 18.4 px of the keypoint (the pattern's values are in [-13, 13]), so the wave first copies the 39 x 39 patch of each keypoint into
+    // LDS with row-contiguous dword loads (39 rows x 11 dwords from the 4-byte boundary left of px - 19: 7 loads per lane instead of 8,
+    // and ~9 lines per instruction instead of up to 64) and gathers the samples from there.  Four keypoints of the wave at a time
+    // (27 KB of LDS per workgroup).  A keypoint is at least EDGE_THRESHOLD = 19 px inside its level, so the patch is inside the plane.
     const int4 pw = *(const int4*)(d_pattern + lane * 16);
     const int wv[4] = {pw.x, pw.y, pw.z, pw.w};
-    uint8_t smp[kDescPW][8];
+    constexpr int kPR = 19, kPRows = 2 * kPR + 1, kPDw = 11, kPItems = kPRows * kPDw, kPIt = (kPItems + 63) / 64, kPBytes = kPIt * 64 * 4;
+    static_assert(kPR >= kEdge - 0 && kPDw * 4 >= kPRows + 3, "patch row: 39 bytes from a 4-byte boundary at most 3 bytes to the left");
+    __shared__ __attribute__((aligned(16))) unsigned s_patch[4][4][kPBytes / 4];
+    int prow[kPIt], pcol[kPIt];                 // (row, dword) of this lane's patch items: the same for every keypoint
 #pragma unroll
-    for (int r = 0; r < kDescPW; r++) {
-        const int ls = wave * kDescPW + r;
-        const int level = s_level[ls];
+    for (int it = 0; it < kPIt; it++) { const int d = min(lane + 64 * it, kPItems - 1); prow[it] = d / kPDw; pcol[it] = d % kPDw; }
 #pragma unroll
-        for (int t = 0; t < 8; t++) smp[r][t] = 0;
-        if (level >= 0) {
+    for (int half = 0; half < kDescPW / 4; half++) {
+        unsigned pv[4][kPIt];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ls = wave * kDescPW + 4 * half + q;
+            const int level = s_level[ls];
+#pragma unroll
+            for (int it = 0; it < kPIt; it++) pv[q][it] = 0u;
+            if (level >= 0) {                       // uniform per wave
+                const LevelGeom& G = cfg->lv[level];
+                const unsigned pos = s_pos[ls];
+                const int px = pos & 0xffff, py = pos >> 16;
+                const uint8_t* B0 = Bimg + G.off + (size_t)(py - kPR) * G.pitch + ((px - kPR) & ~3);
+#pragma unroll
+                for (int it = 0; it < kPIt; it++) pv[q][it] = *(const unsigned*)(B0 + (size_t)prow[it] * G.pitch + 4 * pcol[it]);
+            }
+        }
+        wave_sync_lds();                            // the previous half's gathers are done with the patches
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int it = 0; it < kPIt; it++) s_patch[wave][q][lane + 64 * it] = pv[q][it];
+        wave_sync_lds();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ls = wave * kDescPW + 4 * half + q;
+            const int level = s_level[ls];
+            if (level < 0) continue;
             const LevelGeom& G = cfg->lv[level];
             const unsigned pos = s_pos[ls];
             const int px = pos & 0xffff, py = pos >> 16;
-            const uint8_t* B = Bimg + G.off;
-            const int pitch = G.pitch;
             const float a = s_a[ls], b = s_b[ls];
+            const uint8_t* P = (const uint8_t*)s_patch[wave][q] + kPR * (kPDw * 4) + kPR + ((px - kPR) & 3);      // the keypoint's own pixel
+            unsigned nib = 0;
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const float x0 = (float)(int8_t)(wv[t] & 0xff), y0 = (float)(int8_t)((wv[t] >> 8) & 0xff);
                 const float x1 = (float)(int8_t)((wv[t] >> 16) & 0xff), y1 = (float)(int8_t)((wv[t] >> 24) & 0xff);
-                smp[r][2 * t] = B[(size_t)(py + cv_round(x0 * b + y0 * a)) * pitch + px + cv_round(x0 * a - y0 * b)];
-                smp[r][2 * t + 1] = B[(size_t)(py + cv_round(x1 * b + y1 * a)) * pitch + px + cv_round(x1 * a - y1 * b)];
+                const unsigned t0 = P[cv_round(x0 * b + y0 * a) * (kPDw * 4) + cv_round(x0 * a - y0 * b)];
+                const unsigned t1 = P[cv_round(x1 * b + y1 * a) * (kPDw * 4) + cv_round(x1 * a - y1 * b)];
+                nib |= (unsigned)(t0 < t1) << t;
+            }
+            const int slot = grp * kDescKP + ls, oi = s_oi[ls];
+            unsigned byte = nib | (__shfl_down(nib, 1, 64) << 4);          // valid on even lanes
+            unsigned w = byte | (__shfl_down(byte, 2, 64) << 8) | (__shfl_down(byte, 4, 64) << 16) | (__shfl_down(byte, 6, 64) << 24);
+            if ((lane & 7) == 0) *(unsigned*)(desc + ((size_t)img * nf + oi) * 32 + (lane >> 3) * 4) = w;
+            if (lane == 0) {
+                ivf_keypoint kp;
+                float fx = (float)px, fy = (float)py;
+                if (level != 0) { fx *= G.scale; fy *= G.scale; }
+                kp.x = fx; kp.y = fy; kp.size = (float)G.scaledPatch; kp.angle = s_angle[ls];
+                kp.response = slotResp[(size_t)img * nf + slot]; kp.octave = level;
+                kps[(size_t)img * nf + oi] = kp;
+                float qv = 1.0f;
+                if (useCost[img] & 2) {          // Frame.cc:130-143: whenever a cost image came with the frame, whatever the extractor flag
+                    const int qx = (int)roundf(fx), qy = (int)roundf(fy);
+                    const LevelGeom& G0 = cfg->lv[0];
+                    const float cost = (float)qpyr[(size_t)img * cfg->pyrBytes + G0.off + (size_t)min(qy, G0.h - 1) * G0.pitch + min(qx, G0.w - 1)];
+                    const float qs = (float)(1.0 / (1.0 + (double)(cost / 256)));
+                    qv = 2 * qs - 1;
+                }
+                quality[(size_t)img * nf + oi] = qv;
             }
         }
     }
-#pragma unroll
-    for (int r = 0; r < kDescPW; r++) {
-        const int ls = wave * kDescPW + r;
-        const int level = s_level[ls];
-        if (level < 0) continue;
-        const LevelGeom& G = cfg->lv[level];
-        const unsigned pos = s_pos[ls];
-        const int px = pos & 0xffff, py = pos >> 16;
-        const int slot = grp * kDescKP + ls, oi = s_oi[ls];
-        unsigned nib = 0;
-#pragma unroll
-        for (int t = 0; t < 4; t++) nib |= (unsigned)(smp[r][2 * t] < smp[r][2 * t + 1]) << t;
-        unsigned byte = nib | (__shfl_down(nib, 1, 64) << 4);          // valid on even lanes
-        unsigned w = byte | (__shfl_down(byte, 2, 64) << 8) | (__shfl_down(byte, 4, 64) << 16) | (__shfl_down(byte, 6, 64) << 24);
-        if ((lane & 7) == 0) *(unsigned*)(desc + ((size_t)img * nf + oi) * 32 + (lane >> 3) * 4) = w;
-        if (lane == 0) {
-            ivf_keypoint kp;
-            float fx = (float)px, fy = (float)py;
-            if (level != 0) { fx *= G.scale; fy *= G.scale; }
-            kp.x = fx; kp.y = fy; kp.size = (float)G.scaledPatch; kp.angle = s_angle[ls];
-            kp.response = slotResp[(size_t)img * nf + slot]; kp.octave = level;
-            kps[(size_t)img * nf + oi] = kp;
-            float q = 1.0f;
-            if (useCost[img] & 2) {          // Frame.cc:130-143: whenever a cost image came with the frame, whatever the extractor flag
-                const int qx = (int)roundf(fx), qy = (int)roundf(fy);
-                const LevelGeom& G0 = cfg->lv[0];
-                const float cost = (float)qpyr[(size_t)img * cfg->pyrBytes + G0.off + (size_t)min(qy, G0.h - 1) * G0.pitch + min(qx, G0.w - 1)];
-                const float qs = (float)(1.0 / (1.0 + (double)(cost / 256)));
-                q = 2 * qs - 1;
-            }
-            quality[(size_t)img * nf + oi] = q;
-        }
+#ifdef IVF_DESC_TIMING
+    if (threadIdx.x == 0 && (img == 3 || img == 100) && grp == 5) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long dt4 = __builtin_amdgcn_s_memtime();
+        printf("describe img %d: lookup %llu disc+moments %llu angle %llu samples+bits+stores %llu cycles\n", img, dt1 - dt0, dt2 - dt1, dt3 - dt2, dt4 - dt3);
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
