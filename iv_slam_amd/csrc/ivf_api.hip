@@ -81,6 +81,10 @@ struct Context {
     size_t stageBytes = 0;
     static constexpr int kEvRing = 64;  // HIP event pairs around the FAST+NMS launch of the last kEvRing runs
     hipEvent_t evFast0[kEvRing] = {}, evFast1[kEvRing] = {};
+    // r04: the blur (throughput-bound, needs only the pyramid) runs on a side stream beside the selection chain (quota, three tier
+    // launches, level selection: latency-bound, ~285 us per 256 images) and joins in front of the descriptors
+    hipStream_t side = nullptr;
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
     long long nRuns = 0;
     int pyrEpoch = 0;               // launches of k_pyr_multi so far: its barrier counters only grow
     hipStream_t lastStream = nullptr;
@@ -258,6 +262,13 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
         HIPCHK(hipMalloc(&b.hugeScratch, (size_t)kHugeSlots * 6 * c.maxCandCap * sizeof(unsigned)));
     }
     for (int i = 0; i < kEvRing; i++) { HIPCHK(hipEventCreate(&evFast0[i])); HIPCHK(hipEventCreate(&evFast1[i])); }
+    {
+        int prLo = 0, prHi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prLo, &prHi);
+        HIPCHK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prHi));
+        HIPCHK(hipEventCreateWithFlags(&evFork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&evJoin, hipEventDisableTiming));
+    }
     return IVF_OK;
 }
 
@@ -272,6 +283,9 @@ void Context::release()
         if (evFast0[i]) (void)hipEventDestroy(evFast0[i]);
         if (evFast1[i]) (void)hipEventDestroy(evFast1[i]);
     }
+    if (side) (void)hipStreamDestroy(side);
+    if (evFork) (void)hipEventDestroy(evFork);
+    if (evJoin) (void)hipEventDestroy(evJoin);
     *this = Context();
 }
 
@@ -306,8 +320,20 @@ int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size
     launch_fast(hc, dc, b, nImg, st);
     HIPCHK(hipEventRecord(evFast1[slot], st));
     nRuns++;
-    launch_select(hc, dc, b, nImg, st);
-    launch_blur(hc, dc, b, nImg, st);
+    static const bool sideBlur = getenv("IVF_NO_SIDE_BLUR") == nullptr;
+    if (sideBlur && side && nImg > 2) {       // not for single frames: there the two event hand-overs cost more than the overlap gives (extraction 0.35 -> 0.63 ms)
+        // fork: the blur only needs the pyramid (in order behind it on st); the next run's blur cannot overtake this run's descriptors,
+        // because its fork event is recorded on st behind them
+        HIPCHK(hipEventRecord(evFork, st));
+        HIPCHK(hipStreamWaitEvent(side, evFork, 0));
+        launch_blur(hc, dc, b, nImg, side, false);
+        HIPCHK(hipEventRecord(evJoin, side));
+        launch_select(hc, dc, b, nImg, st);
+        HIPCHK(hipStreamWaitEvent(st, evJoin, 0));
+    } else {
+        launch_select(hc, dc, b, nImg, st);
+        launch_blur(hc, dc, b, nImg, st, true);
+    }
     launch_describe(hc, dc, b, nullptr, 0, 0, nImg, nSides, st);
     HIPCHK(hipGetLastError());
     return IVF_OK;

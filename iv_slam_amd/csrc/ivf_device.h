@@ -123,7 +123,7 @@ void launch_ingest(const Config& hc, const Config* dc, const Buffers& b, const u
 void launch_pyramid(const Config& hc, const Config* dc, const ResizeCoef* dTab, uint8_t* blob, uint8_t* qblob, const uint8_t* useCost,
                     int nImg, hipStream_t s, int* bar, int* epoch, int maxPlanes);
 void launch_fast(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s);
-void launch_blur(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s);
+void launch_blur(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s, bool skipEmptyLevels);
 void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s);
 void launch_describe(const Config& hc, const Config* dc, const Buffers& b, const uint8_t* cost0, size_t costStride,
                      int costPitch, int nImg, int nSides, hipStream_t s);

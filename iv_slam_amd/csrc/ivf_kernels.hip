@@ -2219,11 +2219,12 @@ void launch_fast(const Config& hc, const Config* dc, const Buffers& b, int nImg,
     hipLaunchKernelGGL(k_fast_nms, dim3((nImg + 7) / 8 * 8 * hc.nTiles), dim3(256), 0, s, dc, b.pyr, b.useCost, b.tileList, b.tileCnt, b.cellCnt,
                        nImg, ablate);
 }
-void launch_blur(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s)
+void launch_blur(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s, bool skipEmptyLevels)
 {
     const int tiles = hc.nBlurTiles;
     if (tiles <= 0) return;
-    hipLaunchKernelGGL(k_blur7, dim3((nImg + 7) / 8 * 8 * tiles), dim3(256), 0, s, dc, b.pyr, b.lvlCount, b.blur, nImg);
+    // skipEmptyLevels reads lvlCount, which k_level_select writes: only when the blur runs behind the selection
+    hipLaunchKernelGGL(k_blur7, dim3((nImg + 7) / 8 * 8 * tiles), dim3(256), 0, s, dc, b.pyr, skipEmptyLevels ? b.lvlCount : nullptr, b.blur, nImg);
 }
 void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s)
 {
