@@ -82,8 +82,10 @@ struct Context {
     static constexpr int kEvRing = 64;  // HIP event pairs around the FAST+NMS launch of the last kEvRing runs
     hipEvent_t evFast0[kEvRing] = {}, evFast1[kEvRing] = {};
     // r04: the blur (throughput-bound, needs only the pyramid) runs on a side stream beside the selection chain (quota, three tier
-    // launches, level selection: latency-bound, ~285 us per 256 images) and joins in front of the descriptors
-    hipStream_t side = nullptr;
+    // launches, level selection: latency-bound, ~285 us per 256 images) and joins in front of the descriptors.  The side stream is
+    // LENT by the caller (the batched front end passes the internal stream of its next context): a stream of its own per context
+    // cost configs[2] 15 % -- 10.4k -> 9.0k pairs/s just by existing, whether used or not: the runtime multiplexes streams onto a few
+    // hardware queues, and three more streams put the FCN's stream behind front-end work
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     long long nRuns = 0;
     int pyrEpoch = 0;               // launches of k_pyr_multi so far: its barrier counters only grow
@@ -94,7 +96,7 @@ struct Context {
     void release();
     int run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size_t imageStride, int rowStride,
             size_t costStride, int costRowStride, int nImg, const uint8_t* hUseCost, hipStream_t st,
-            hipEvent_t inputsConsumed = nullptr);
+            hipEvent_t inputsConsumed = nullptr, hipStream_t sideStream = nullptr);
     int check_status(int which = 0);
 };
 
@@ -263,9 +265,6 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
     }
     for (int i = 0; i < kEvRing; i++) { HIPCHK(hipEventCreate(&evFast0[i])); HIPCHK(hipEventCreate(&evFast1[i])); }
     {
-        int prLo = 0, prHi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prLo, &prHi);
-        HIPCHK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prHi));
         HIPCHK(hipEventCreateWithFlags(&evFork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&evJoin, hipEventDisableTiming));
     }
@@ -283,7 +282,6 @@ void Context::release()
         if (evFast0[i]) (void)hipEventDestroy(evFast0[i]);
         if (evFast1[i]) (void)hipEventDestroy(evFast1[i]);
     }
-    if (side) (void)hipStreamDestroy(side);
     if (evFork) (void)hipEventDestroy(evFork);
     if (evJoin) (void)hipEventDestroy(evJoin);
     *this = Context();
@@ -292,7 +290,7 @@ void Context::release()
 // Enqueue ORBextractor::operator() for nImg images (ORB/src/ORBextractor.cc:1224-1296)
 int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size_t imageStride, int rowStride,
                  size_t costStride, int costRowStride, int nImg, const uint8_t* dUseCostSrc, hipStream_t st,
-                 hipEvent_t inputsConsumed)
+                 hipEvent_t inputsConsumed, hipStream_t sideStream)
 {
     if (nImg < 1 || nImg > maxImg) return fail(IVF_E_INVALID, "batch of %d images outside [1,%d]", nImg, maxImg);
     HIPCHK(hipSetDevice(device));
@@ -321,7 +319,8 @@ int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size
     HIPCHK(hipEventRecord(evFast1[slot], st));
     nRuns++;
     static const bool sideBlur = getenv("IVF_NO_SIDE_BLUR") == nullptr;
-    if (sideBlur && side && nImg > 2) {       // not for single frames: there the two event hand-overs cost more than the overlap gives (extraction 0.35 -> 0.63 ms)
+    hipStream_t side = sideStream;
+    if (sideBlur && side && side != st && nImg > 2) {       // not for single frames: there the two event hand-overs cost more than the overlap gives (extraction 0.35 -> 0.63 ms)
         // fork: the blur only needs the pyramid (in order behind it on st); the next run's blur cannot overtake this run's descriptors,
         // because its fork event is recorded on st behind them
         HIPCHK(hipEventRecord(evFork, st));
@@ -2068,8 +2067,10 @@ int ivf_frontend_run(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_r
     // order: everything the caller enqueued so far (it produced the inputs) -> this batch
     HIPCHK(hipEventRecord(fe->evIn[k], caller));
     HIPCHK(hipStreamWaitEvent(st, fe->evIn[k], 0));
+    // the blur of this batch is lent the internal stream of the NEXT context: whatever older batch that stream still holds does not
+    // depend on this one, and the next batch queues behind the blur
     int rc = c.run(d_left, d_right, d_cost, image_stride, row_stride, image_stride, row_stride, 2 * n_pairs,
-                   fe->dFlags, st, fe->evConsumed[k]);
+                   fe->dFlags, st, fe->evConsumed[k], fe->stream[(k + 1) % kPipe]);
     if (rc) return rc;
     launch_stereo(c.hc, c.dc, c.b, n_pairs, fe->cfg.bf, fe->cfg.b, st);
     HIPCHK(hipGetLastError());
