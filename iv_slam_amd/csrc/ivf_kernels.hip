@@ -392,22 +392,24 @@ DEVINL bool over_threshold(s16x2 dk, s16x2 br, int t)
     const s16x2 T = {(short)t, (short)t};
     return ((__builtin_bit_cast(unsigned, T - dk) | __builtin_bit_cast(unsigned, br + T)) & 0x80008000u) != 0u;
 }
+// the compass test on the ring pixels themselves: with d = v - p,  min(max(d0, d8), max(d4, d12)) > t  <=>  max(min(p0, p8), min(p4, p12)) < v - t
+// and  max(min(d0, d8), min(d4, d12)) < -t  <=>  min(max(p0, p8), max(p4, p12)) > v + t: the four differences are never formed
+DEVINL bool compass_test(s16x2 v, s16x2 p0, s16x2 p8, s16x2 p4, s16x2 p12, int t)
+{
+    const s16x2 T = {(short)t, (short)t};
+    const s16x2 X = pkmax(pkmin(p0, p8), pkmin(p4, p12)), Y = pkmin(pkmax(p0, p8), pkmax(p4, p12));
+    return ((__builtin_bit_cast(unsigned, X - (v - T)) | __builtin_bit_cast(unsigned, (v + T) - Y)) & 0x80008000u) != 0u;
+}
 DEVINL bool fast_precheck_pair(unsigned loT, unsigned hiT, unsigned loC, unsigned hiC, unsigned loB, unsigned hiB, int t)
 {
     const s16x2 v = pair_at(loC, hiC, 3);
-    const s16x2 d0 = v - pair_at(loB, hiB, 3), d8 = v - pair_at(loT, hiT, 3);
-    const s16x2 d4 = v - pair_at(loC, hiC, 6), d12 = v - pair_at(loC, hiC, 0);
-    const s16x2 dk = pkmin(pkmax(d0, d8), pkmax(d4, d12)), br = pkmax(pkmin(d0, d8), pkmin(d4, d12));
-    return over_threshold(dk, br, t);
+    return compass_test(v, pair_at(loB, hiB, 3), pair_at(loT, hiT, 3), pair_at(loC, hiC, 6), pair_at(loC, hiC, 0), t);
 }
 // the same test for the pixel pair at bytes 5, 6 of the 12-byte span (m0, m1, m2): x-3 = bytes 2, 3; x+3 = bytes 8, 9 = bytes 4, 5 of (m2:m1)
 DEVINL bool fast_precheck_pair_b(unsigned t0, unsigned t1, unsigned m0, unsigned m1, unsigned m2, unsigned b0, unsigned b1, int t)
 {
     const s16x2 v = pair_at(m0, m1, 5);
-    const s16x2 d0 = v - pair_at(b0, b1, 5), d8 = v - pair_at(t0, t1, 5);
-    const s16x2 d4 = v - pair_at(m1, m2, 4), d12 = v - pair_at(m0, m1, 2);
-    const s16x2 dk = pkmin(pkmax(d0, d8), pkmax(d4, d12)), br = pkmax(pkmin(d0, d8), pkmin(d4, d12));
-    return over_threshold(dk, br, t);
+    return compass_test(v, pair_at(b0, b1, 5), pair_at(t0, t1, 5), pair_at(m1, m2, 4), pair_at(m0, m1, 2), t);
 }
 // rows: 7 windows (dy = -3..3), each as (lo, hi) dwords.  Returns the two scores packed (left | right << 16).
 DEVINL unsigned fast_score_pair(const unsigned (&lo)[7], const unsigned (&hi)[7], int t, bool quickOnly = false)
@@ -615,7 +617,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
         const unsigned* base = raw + (sy * kRawP + (sx & ~3)) / 4;
 #pragma unroll
         for (int r = 0; r < 7; r++) {
-            const unsigned w0 = base[r * (kRawP / 4)], w1 = base[r * (kRawP / 4) + 1], w2 = base[r * (kRawP / 4) + 2];
+            // rows +-3 are read at window bytes 2 .. 5 only (ring dx = -1, 0, 1): their third dword is never looked at
+            const unsigned w0 = base[r * (kRawP / 4)], w1 = base[r * (kRawP / 4) + 1], w2 = (r == 0 || r == 6) ? w1 : base[r * (kRawP / 4) + 2];
             lo[r] = __builtin_amdgcn_alignbyte(w1, w0, sh);
             hi[r] = __builtin_amdgcn_alignbyte(w2, w1, sh);
         }
