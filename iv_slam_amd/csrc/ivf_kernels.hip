@@ -386,12 +386,6 @@ DEVINL s16x2 pair_at(unsigned lo, unsigned hi, int i)      // bytes W[i], W[i+1]
 // Cheap necessary condition on the 4 compass ring pixels only (rows -3, 0, +3): every 9-arc holds one pixel of each
 // opposite pair, in particular of (0,8) = (0,+-3) and (4,12) = (+-3,0).  Passes ~10 % of the pairs (the full 8-pair
 // test ~8 %) at a third of the cost.  loT/hiT = row -3, loC/hiC = centre row, loB/hiB = row +3 windows.
-// (dk.x > t) | (dk.y > t) | (br.x < -t) | (br.y < -t) on the packed halves: t - dk and br + t are negative exactly there (|values| <= 510)
-DEVINL bool over_threshold(s16x2 dk, s16x2 br, int t)
-{
-    const s16x2 T = {(short)t, (short)t};
-    return ((__builtin_bit_cast(unsigned, T - dk) | __builtin_bit_cast(unsigned, br + T)) & 0x80008000u) != 0u;
-}
 // the compass test on the ring pixels themselves: with d = v - p,  min(max(d0, d8), max(d4, d12)) > t  <=>  max(min(p0, p8), min(p4, p12)) < v - t
 // and  max(min(d0, d8), min(d4, d12)) < -t  <=>  min(max(p0, p8), max(p4, p12)) > v + t: the four differences are never formed
 DEVINL bool compass_test(s16x2 v, s16x2 p0, s16x2 p8, s16x2 p4, s16x2 p12, int t)
@@ -414,42 +408,47 @@ DEVINL bool fast_precheck_pair_b(unsigned t0, unsigned t1, unsigned m0, unsigned
 // rows: 7 windows (dy = -3..3), each as (lo, hi) dwords.  Returns the two scores packed (left | right << 16).
 DEVINL unsigned fast_score_pair(const unsigned (&lo)[7], const unsigned (&hi)[7], int t, bool quickOnly = false)
 {
+    // r04: everything on the ring pixels p themselves instead of on the differences d = v - p (16 subtractions fewer per pair):
+    //   8-pair test:  min_k max(d_k, d_k+8) > t  <=>  max_k min(p_k, p_k+8) < v - t;   max_k min(d_k, d_k+8) < -t  <=>  min_k max(p_k, p_k+8) > v + t
+    //   one polarity per pixel (a 9-arc holds BOTH pixels of one opposite pair, so where every pair holds a ring pixel brighter than
+    //   v + t only the "brighter ring" polarity can make a corner, elsewhere only the "darker ring" one, and the other polarity's arc
+    //   value is <= t there): with sg = -1 / +1 and q = sg p, the arc minimum of e = sg d is  sg v - (maximum of q over the arc), so
+    //   A = sg v - min over the 16 arcs of the arc maximum of q: the same sliding network with min and max swapped.
     const s16x2 v = pair_at(lo[3], hi[3], 3);
-    s16x2 d[16];
+    s16x2 p[16];
     // ring order (dx,dy): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
-    d[0] = v - pair_at(lo[6], hi[6], 3);   d[1] = v - pair_at(lo[6], hi[6], 4);   d[2] = v - pair_at(lo[5], hi[5], 5);
-    d[3] = v - pair_at(lo[4], hi[4], 6);   d[4] = v - pair_at(lo[3], hi[3], 6);   d[5] = v - pair_at(lo[2], hi[2], 6);
-    d[6] = v - pair_at(lo[1], hi[1], 5);   d[7] = v - pair_at(lo[0], hi[0], 4);   d[8] = v - pair_at(lo[0], hi[0], 3);
-    d[9] = v - pair_at(lo[0], hi[0], 2);   d[10] = v - pair_at(lo[1], hi[1], 1);  d[11] = v - pair_at(lo[2], hi[2], 0);
-    d[12] = v - pair_at(lo[3], hi[3], 0);  d[13] = v - pair_at(lo[4], hi[4], 0);  d[14] = v - pair_at(lo[5], hi[5], 1);
-    d[15] = v - pair_at(lo[6], hi[6], 2);
-    s16x2 dk = pkmax(d[0], d[8]), br = pkmin(d[0], d[8]);
+    p[0] = pair_at(lo[6], hi[6], 3);   p[1] = pair_at(lo[6], hi[6], 4);   p[2] = pair_at(lo[5], hi[5], 5);
+    p[3] = pair_at(lo[4], hi[4], 6);   p[4] = pair_at(lo[3], hi[3], 6);   p[5] = pair_at(lo[2], hi[2], 6);
+    p[6] = pair_at(lo[1], hi[1], 5);   p[7] = pair_at(lo[0], hi[0], 4);   p[8] = pair_at(lo[0], hi[0], 3);
+    p[9] = pair_at(lo[0], hi[0], 2);   p[10] = pair_at(lo[1], hi[1], 1);  p[11] = pair_at(lo[2], hi[2], 0);
+    p[12] = pair_at(lo[3], hi[3], 0);  p[13] = pair_at(lo[4], hi[4], 0);  p[14] = pair_at(lo[5], hi[5], 1);
+    p[15] = pair_at(lo[6], hi[6], 2);
+    s16x2 X = pkmin(p[0], p[8]), Y = pkmax(p[0], p[8]);
 #pragma unroll
-    for (int k = 1; k < 8; k++) { dk = pkmin(dk, pkmax(d[k], d[k + 8])); br = pkmax(br, pkmin(d[k], d[k + 8])); }
-    if (!over_threshold(dk, br, t)) return 0u;
+    for (int k = 1; k < 8; k++) { X = pkmax(X, pkmin(p[k], p[k + 8])); Y = pkmin(Y, pkmax(p[k], p[k + 8])); }
+    const s16x2 T = {(short)t, (short)t};
+    const s16x2 u = X - (v - T), w = (v + T) - Y;                                // negative where the darker / brighter 8-pair test passes
+    if (((__builtin_bit_cast(unsigned, u) | __builtin_bit_cast(unsigned, w)) & 0x80008000u) == 0u) return 0u;
     if (quickOnly) return 0x00010001u;
-    // One polarity per pixel is enough (r04).  A 9-arc holds BOTH pixels of one opposite pair, so a pixel whose every pair holds a ring
-    // pixel with d < -t (br < -t) cannot have a 9-arc with d > t, and vice versa: where br < -t only the "brighter ring" polarity can
-    // make a corner, elsewhere only the "darker ring" one -- and the other polarity's arc value is <= t there, so it never is the maximum
-    // that counts.  e = +-d per half, then the arc minimum of one polarity: 16 + 47 packed operations instead of 94.
-    const s16x2 T = {(short)t, (short)t}, sg = ((br + T) >> 15) | (s16x2){1, 1};
-    s16x2 e[16];
+    const s16x2 sg = (w >> 15) | (s16x2){1, 1};
+    s16x2 q[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) e[k] = d[k] * sg;
-    s16x2 mn[8];
+    for (int k = 0; k < 16; k++) q[k] = p[k] * sg;
+    s16x2 mx[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) { const int j = 2 * q + 1; mn[q] = pkmin(e[j], e[(j + 1) & 15]); }
+    for (int i = 0; i < 8; i++) { const int j = 2 * i + 1; mx[i] = pkmax(q[j], q[(j + 1) & 15]); }
     s16x2 m4[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) m4[q] = pkmin(mn[q], mn[(q + 1) & 7]);
-    s16x2 amax;
+    for (int i = 0; i < 8; i++) m4[i] = pkmax(mx[i], mx[(i + 1) & 7]);
+    s16x2 wmin;
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const int j = 2 * q + 1;
-        const s16x2 w8 = pkmin(m4[q], m4[(q + 2) & 7]);                          // e[j..j+7]
-        const s16x2 a = pkmin(w8, pkmax(e[(j + 15) & 15], e[(j + 8) & 15]));     // arcs [j-1..j+7] and [j..j+8]
-        amax = q ? pkmax(amax, a) : a;
+    for (int i = 0; i < 8; i++) {
+        const int j = 2 * i + 1;
+        const s16x2 w8 = pkmax(m4[i], m4[(i + 2) & 7]);                          // q[j..j+7]
+        const s16x2 a = pkmax(w8, pkmin(q[(j + 15) & 15], q[(j + 8) & 15]));     // arcs [j-1..j+7] and [j..j+8]
+        wmin = i ? pkmin(wmin, a) : a;
     }
+    const s16x2 amax = v * sg - wmin;
     const int A0 = (int)amax.x, A1 = (int)amax.y;
     const unsigned s0 = A0 > t ? (unsigned)(A0 - 1) : 0u, s1 = A1 > t ? (unsigned)(A1 - 1) : 0u;
     return s0 | (s1 << 16);
