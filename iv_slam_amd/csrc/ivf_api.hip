@@ -224,8 +224,8 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
     HIPCHK(hipMalloc(&dTab, tab.size() * sizeof(ResizeCoef)));
     HIPCHK(hipMemcpy(dTab, tab.data(), tab.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice));
     const size_t nI = (size_t)maxImg, nf = (size_t)c.nfeatures, blob = (size_t)c.pyrBytes * nI;
-    HIPCHK(hipMalloc(&b.pyr, blob));
-    HIPCHK(hipMalloc(&b.blur, blob));
+    HIPCHK(hipMalloc(&b.pyr, blob + 256));          // + slack: k_stereo_match / k_describe read whole dwords that may end a few bytes past a plane's last row
+    HIPCHK(hipMalloc(&b.blur, blob + 256));
     HIPCHK(hipMemset(b.pyr, 0, blob));
     if (introspection) { HIPCHK(hipMalloc(&b.qpyr, blob)); HIPCHK(hipMemset(b.qpyr, 0, blob)); }
     HIPCHK(hipMalloc(&b.tileList, nI * std::max(c.nTiles, 1) * (size_t)kTileCap * sizeof(unsigned)));

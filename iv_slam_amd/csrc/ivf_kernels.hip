@@ -1995,14 +1995,16 @@ __global__ __launch_bounds__(256) void k_stereo_match(const Config* __restrict__
     const uint8_t* PR = A.pyrR + (size_t)pair * A.pyrStride + G.off;
     const int yl = (int)(scaledvL - w), xl = (int)(scaleduL - w);
     const bool okL = live && yl >= 0 && yl + 11 <= G.h && xl >= 0 && xl + 11 <= G.w;
+    // r04: both SAD windows travel as whole dwords into LDS -- the left one (11 rows x 4 dwords from the 4-byte boundary left of xl) now, with
+    // the keypoint; the right one (11 rows x 6 dwords: 21 pixels = 11 shifts x 11 columns) once the match is known -- one or two coalesced
+    // loads per lane instead of 2 + 33 single-byte gathers per keypoint; the 121 x 11 absolute differences then read bytes from LDS
+    __shared__ __attribute__((aligned(16))) unsigned s_win[4][128];        // per wave: [0, 44) left rows, [48, 114) right rows
+    unsigned* const winL = s_win[threadIdx.x >> 6];
+    unsigned* const winR = winL + 48;
     const int p0y = lane / 11, p0x = lane % 11, p1y = (lane + 64) / 11, p1x = (lane + 64) % 11;
     const bool has1 = lane + 64 < 121;
-    int cL = 0, dl0 = 0, dl1 = 0;
-    if (okL) {
-        cL = PL[(size_t)(yl + w) * G.pitch + xl + w];
-        dl0 = PL[(size_t)(yl + p0y) * G.pitch + xl + p0x];
-        if (has1) dl1 = PL[(size_t)(yl + p1y) * G.pitch + xl + p1x];
-    }
+    unsigned wl = 0u;
+    if (okL && lane < 44) wl = *(const unsigned*)(PL + (size_t)(yl + lane / 4) * G.pitch + (xl & ~3) + 4 * (lane % 4));
     unsigned best = (100u << 16) | 0xffffu;            // (dist << 16) | iR ; TH_HIGH start, strict <
     float bestX = 0.0f;                                // kpR[iR].x of this lane's best
     if (live) {
@@ -2045,22 +2047,30 @@ __global__ __launch_bounds__(256) void k_stereo_match(const Config* __restrict__
         const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
         const bool ok = !(iniu < 0 || endu >= (float)G.w) && okL && (int)(scaleduR0 - L - w) >= 0;
         if (ok) {
-            dl0 -= cL;
-            if (has1) dl1 -= cL;
-            int pc[11], pa[11], pb[11];                 // all 33 right-window reads in flight together
-#pragma unroll
-            for (int inc = -5; inc <= 5; inc++) {
-                const int xr = (int)(scaleduR0 + (float)inc - w);
-                pc[inc + 5] = PR[(size_t)(yl + w) * G.pitch + xr + w];
-                pa[inc + 5] = PR[(size_t)(yl + p0y) * G.pitch + xr + p0x];
-                pb[inc + 5] = has1 ? PR[(size_t)(yl + p1y) * G.pitch + xr + p1x] : 0;
+            const int x0R = (int)(scaleduR0 - (float)(L + w));                    // leftmost right-window column (>= 0: checked)
+            unsigned wr0 = 0u, wr1 = 0u;                                          // 66 dwords: lane, lane + 64
+            {
+                const uint8_t* rowp = PR + (size_t)yl * G.pitch + (x0R & ~3);
+                wr0 = *(const unsigned*)(rowp + (size_t)(lane / 6) * G.pitch + 4 * (lane % 6));
+                if (lane < 2) wr1 = *(const unsigned*)(rowp + (size_t)((lane + 64) / 6) * G.pitch + 4 * ((lane + 64) % 6));
             }
+            if (lane < 44) winL[lane] = wl;
+            winR[lane] = wr0;
+            if (lane < 2) winR[lane + 64] = wr1;
+            wave_sync_lds();
+            const uint8_t* bL = (const uint8_t*)winL + (xl & 3);                  // row pitch 16 bytes
+            const uint8_t* bR = (const uint8_t*)winR + (x0R & 3);                 // row pitch 24 bytes; shift inc = column offset inc + 5
+            const int cL = bL[w * 16 + w];
+            const int dl0 = (int)bL[p0y * 16 + p0x] - cL;
+            const int dl1 = has1 ? (int)bL[p1y * 16 + p1x] - cL : 0;
             int bestD = 0x7fffffff, bestinc = 0;
             float vDists[11];
 #pragma unroll
             for (int inc = -5; inc <= 5; inc++) {
-                int acc = abs(dl0 - (pa[inc + 5] - pc[inc + 5]));
-                if (has1) acc += abs(dl1 - (pb[inc + 5] - pc[inc + 5]));
+                const int o = inc + L;                                            // (int)(scaleduR0 + inc - w) - x0R: the values are integers
+                const int cR = bR[w * 24 + o + w];
+                int acc = abs(dl0 - ((int)bR[p0y * 24 + o + p0x] - cR));
+                if (has1) acc += abs(dl1 - ((int)bR[p1y * 24 + o + p1x] - cR));
                 acc = wave_sum_i32(acc);
                 const float dist = (float)acc;
                 if (dist < (float)bestD) { bestD = (int)dist; bestinc = inc; }
