@@ -1947,9 +1947,7 @@ constexpr int kF4ParB = 1024;                     // bytes per parameter slot (1
 #endif                        // Measured 2 / 3 / 4 / 5 / 6: 100.5 / 99.9 / 99.1 / 97.4 / 98.0 us per image
 constexpr int kF4WSlots = 3, kF4PSlots = 4;  // weight / parameter buffers: consumed in interval it, landed for it + 1, arriving for it + 2
 constexpr size_t kF4Lds = (size_t)2 * 16 * kF4CS * 4 + (size_t)2 * 16 * kF4DP * 4 + 2 * kF4WSlots * 10240 + kF4PSlots * kF4ParB +
-                          2 * 160 * 4 + 32;   // + the projection's BN scale / shift of this workgroup's 160 output channels + a zero row
-// position of pixel q inside its group of 8 in the LDS planes of k_fcn_irbd4: (p0, p4, p1, p5, p2, p6, p3, p7)
-__device__ __forceinline__ int f4perm(int q) { return (q & ~7) | ((q & 3) << 1) | ((q >> 2) & 1); }
+                          2 * 160 * 4;        // + the projection's BN scale / shift of this workgroup's 160 output channels
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // SPLIT (small batches, r04): 16 workgroups per image leave most of the chip idle at batch 1 (the per-call drop-in path).  The hidden
@@ -1973,7 +1971,6 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     uint4* const sWP = sWE + kF4WSlots * 640;                       // [slots][5 tiles][hi, lo][64 lanes]
     float* const sPar = (float*)(sWP + kF4WSlots * 640);            // [slots][16 ch][12]: 9 taps (x dw BN scale), dw BN shift, expansion BN scale, shift
     float* const sBN = sPar + kF4PSlots * (kF4ParB / 4);            // [scale 160 | shift 160] of the projection (epilogue)
-    float* const sZero = sBN + 320;                                 // 8 zeros: the stencil's padding row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;     // consecutive L on one XCD (grid x = 16 * images)
     const int b = L >> 4, py = (L >> 2) & 3, px = L & 3;
@@ -2054,15 +2051,12 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
 #pragma unroll
         for (int q = 0; q < 16; q++) pacc[t][q] = 0.f;
 
-    // stencil thread: channel sch (0..15), sub-row ssr, half row sh_.  The two halves of a sub-row sit 8 lanes apart in one DPP row of 16
-    // lanes, so the halo pixel across the half boundary is `row_shr:8` / `row_shl:8` and the lanes with no such neighbour read the DPP zero
-    // fill: no mask multiplies.  A half row is stored as (p0, p4, p1, p5 | p2, p6, p3, p7) in sH and sD (kF4Perm: the writers and readers
-    // on the MFMA side address single dwords, so the permutation is free there), which makes (p[k], p[k + 4]) an aligned register pair:
-    // every tap that stays inside the thread's 8 pixels is a v_pk_fma_f32, 14 VALU per tap row instead of 24.  Rows -1 / 16 of the sub-image
-    // are the zero padding: those threads read a zeroed 8-float row instead of multiplying their taps by a mask.
-    const int sch = tid >> 5, sh_ = (tid >> 3) & 1, ssr = 8 * ((tid >> 4) & 1) + (tid & 7);
-    const int srow1 = sch * kF4CS + ssr * kF4HP + 8 * sh_;
-    if (tid < 8) sZero[tid] = 0.f;
+    // stencil thread: channel sch (0..15), sub-row ssr, half row sh_
+    const int sch = tid >> 5, ssr = (tid >> 1) & 15, sh_ = tid & 1;
+    const float rowM0 = ssr > 0 ? 1.f : 0.f, rowM2 = ssr < 15 ? 1.f : 0.f;
+    const int srow0 = sch * kF4CS + (ssr > 0 ? ssr - 1 : ssr) * kF4HP + 8 * sh_, srow1 = sch * kF4CS + ssr * kF4HP + 8 * sh_,
+              srow2 = sch * kF4CS + (ssr < 15 ? ssr + 1 : ssr) * kF4HP + 8 * sh_;
+    const float mL = sh_ ? 1.f : 0.f, mR = sh_ ? 0.f : 1.f;          // the halo pixel comes from the row's other half (lane -1 / +1)
 
     for (int i = tid; i < 2 * 16 * kF4DP / 4; i += 512) ((uint4*)sD)[i] = make_uint4(0u, 0u, 0u, 0u);      // P(-2), P(-1): zero operands
     for (int i = tid; i < (SPLIT ? 3 : 2) * 640; i += 512) sWP[i] = make_uint4(0u, 0u, 0u, 0u);      // slots g0 % 3, (g0 + 1) % 3
@@ -2078,7 +2072,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     struct MPre { float dv[8]; float2 eb[4]; HFrag ea0[2], pa0[2]; };
     auto mfma_pre = [&](int it, MPre& m) {      // every LDS read of the phase that depends on no MFMA
         const int cur = it & 1, ws = it % kF4WSlots;
-        const float* dB = sD + cur * (16 * kF4DP) + (8 * (lane >> 5)) * kF4DP + 32 * wave + f4perm(lane & 31);
+        const float* dB = sD + cur * (16 * kF4DP) + (8 * (lane >> 5)) * kF4DP + 32 * wave + (lane & 31);
 #pragma unroll
         for (int j = 0; j < 8; j++) m.dv[j] = dB[j * kF4DP];
         const float* pp = sPar + (it % kF4PSlots) * (kF4ParB / 4) + (4 * (lane >> 4)) * 12 + 10;
@@ -2116,7 +2110,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
         }
         F4_TIM(5);
         // C layout of E: column = lane & 15 (sub-column), row = 4 (lane >> 4) + r (hidden channel of the group)
-        float* hp = sH + cur * (16 * kF4CS) + (4 * (lane >> 4)) * kF4CS + (2 * wave) * kF4HP + f4perm(lane & 15);
+        float* hp = sH + cur * (16 * kF4CS) + (4 * (lane >> 4)) * kF4CS + (2 * wave) * kF4HP + (lane & 15);
 #pragma unroll
         for (int t = 0; t < 5; t++) {           // P(it - 2): out[160 x 32 pixels] += W_P[160 x 16] . D[16 x 32 pixels]
             if (t + 1 < 5) { pa[(t + 1) & 1][0].q = wPq[(2 * t + 2) * 64]; pa[(t + 1) & 1][1].q = wPq[(2 * t + 3) * 64]; }
@@ -2143,41 +2137,31 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
         const float* hp = sH + (g & 1) * (16 * kF4CS);
         const float4* pq = (const float4*)(sPar + (g % kF4PSlots) * (kF4ParB / 4) + sch * 12);
         const float4 w03 = pq[0], w47 = pq[1], w8s = pq[2];          // taps 0-3 | 4-7 | tap 8, shift, (expansion BN)
-        f32x2 O[4];                             // O[k] = outputs (p[k], p[k + 4])
+        float o[8];
 #pragma unroll
-        for (int i = 0; i < 4; i++) O[i] = (f32x2){w8s.y, w8s.y};
-        const float* rp[3] = {ssr > 0 ? hp + srow1 - kF4HP : sZero, hp + srow1, ssr < 15 ? hp + srow1 + kF4HP : sZero};
-        const float wk[9] = {w03.x, w03.y, w03.z, w03.w, w47.x, w47.y, w47.z, w47.w, w8s.x};
+        for (int p8 = 0; p8 < 8; p8++) o[p8] = w8s.y;
+        const int ro[3] = {srow0, srow1, srow2};
+        const float wk[9] = {w03.x * rowM0, w03.y * rowM0, w03.z * rowM0, w03.w, w47.x, w47.y, w47.z * rowM2, w47.w * rowM2, w8s.x * rowM2};
 #pragma unroll
         for (int ky = 0; ky < 3; ky++) {
-            const float4 a = *(const float4*)rp[ky], c4 = *(const float4*)(rp[ky] + 4);      // (p0, p4, p1, p5), (p2, p6, p3, p7)
-            const f32x2 R[4] = {{a.x, a.y}, {a.z, a.w}, {c4.x, c4.y}, {c4.z, c4.w}};
+            const float4 a = *(const float4*)(hp + ro[ky]), c4 = *(const float4*)(hp + ro[ky] + 4);
+            const float own[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
             const float w0 = wk[3 * ky], w1 = wk[3 * ky + 1], w2 = wk[3 * ky + 2];
-            // per pixel the order centre, left, right of the scalar form (bit-identical sums)
+            const float w0L = w0 * mL, w2R = w2 * mR;
 #pragma unroll
-            for (int i = 0; i < 4; i++) O[i] = pkfma(R[i], w1, O[i]);
-            {
-                float t0 = O[0].x, t1 = O[0].y;         // p0 <- p7 of the row's other half (zero fill where there is none), p4 <- p3
-                asm("v_fmac_f32_dpp %0, %1, %2 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(t0) : "v"(c4.w), "v"(w0));
-                t1 = __builtin_fmaf(c4.z, w0, t1);
-                O[0] = (f32x2){t0, t1};
-            }
-#pragma unroll
-            for (int i = 1; i < 4; i++) O[i] = pkfma(R[i - 1], w0, O[i]);
-#pragma unroll
-            for (int i = 0; i < 3; i++) O[i] = pkfma(R[i + 1], w2, O[i]);
-            {
-                float t0 = O[3].x, t1 = O[3].y;         // p3 <- p4, p7 <- p0 of the other half
-                t0 = __builtin_fmaf(a.y, w2, t0);
-                asm("v_fmac_f32_dpp %0, %1, %2 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(t1) : "v"(a.x), "v"(w2));
-                O[3] = (f32x2){t0, t1};
+            for (int p8 = 0; p8 < 8; p8++) {
+                o[p8] = __builtin_fmaf(own[p8], w1, o[p8]);
+                if (p8 > 0) o[p8] = __builtin_fmaf(own[p8 - 1], w0, o[p8]);
+                else asm("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(o[p8]) : "v"(own[7]), "v"(w0L));
+                if (p8 < 7) o[p8] = __builtin_fmaf(own[p8 + 1], w2, o[p8]);
+                else asm("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(o[p8]) : "v"(own[0]), "v"(w2R));
             }
         }
         float* dp = sD + (g & 1) * (16 * kF4DP) + sch * kF4DP + ssr * 16 + 8 * sh_;
-        *(float4*)dp = make_float4(__builtin_amdgcn_fmed3f(O[0].x, 0.f, 6.f), __builtin_amdgcn_fmed3f(O[0].y, 0.f, 6.f),
-                                   __builtin_amdgcn_fmed3f(O[1].x, 0.f, 6.f), __builtin_amdgcn_fmed3f(O[1].y, 0.f, 6.f));
-        *(float4*)(dp + 4) = make_float4(__builtin_amdgcn_fmed3f(O[2].x, 0.f, 6.f), __builtin_amdgcn_fmed3f(O[2].y, 0.f, 6.f),
-                                         __builtin_amdgcn_fmed3f(O[3].x, 0.f, 6.f), __builtin_amdgcn_fmed3f(O[3].y, 0.f, 6.f));
+        *(float4*)dp = make_float4(__builtin_amdgcn_fmed3f(o[0], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[1], 0.f, 6.f),
+                                   __builtin_amdgcn_fmed3f(o[2], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[3], 0.f, 6.f));
+        *(float4*)(dp + 4) = make_float4(__builtin_amdgcn_fmed3f(o[4], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[5], 0.f, 6.f),
+                                         __builtin_amdgcn_fmed3f(o[6], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[7], 0.f, 6.f));
     };
 
     for (int it = g0; it < g1 + 2; it++) {
