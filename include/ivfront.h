@@ -62,8 +62,12 @@ int         ivf_device_count(void);                 /* number of visible HIP dev
 long long   ivf_debug_launch_count(void);           /* measurement aid: kernel launches this process has issued through the library */
 /* Build provenance: the first 16 hex digits of sha256 over iv_slam_amd/csrc/{*.hip sorted, ivf_device.h} and include/{* sorted},
  * taken when the library was linked (iv_slam_amd/csrc/Makefile).  iv_slam_amd/_lib.py recomputes it from the sources next to
- * the library and refuses to load a library built from anything else: a stale .so cannot produce a test result or a bench line. */
+ * the library and refuses to load a library built from anything else: a stale .so cannot produce a test result or a bench line.
+ * r05: the hash also covers the build's variant flags, returned by ivf_build_flags() -- "" for the product, "-DIVF_EXPERIMENT" for the
+ * experiment build (make EXPERIMENT=1 -> libivfront_exp.so: the kernel-variant selectors of the experiments in DESIGN.md exist only
+ * there), any EXTRA=-D... of a one-off build: a differently compiled library cannot pass as the measured one. */
 const char* ivf_build_id(void);
+const char* ivf_build_flags(void);
 /* Diagnostic: number of per-thread scratch slots (device + pinned host buffers of the per-call entry points) the process has
  * ever created.  Slots are leased by a thread and handed back when it exits, so the count follows the peak number of
  * CONCURRENT caller threads, not the number of threads ever started (ORB/src/Frame.cc:116-124 starts two per frame). */

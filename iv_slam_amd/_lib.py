@@ -56,6 +56,7 @@ _SIGS = {
     "ivf_device_count": (C.c_int, []),
     "ivf_debug_launch_count": (C.c_longlong, []),
     "ivf_build_id": (C.c_char_p, []),
+    "ivf_build_flags": (C.c_char_p, []),
     "ivf_debug_scratch_slots": (C.c_int, []),
     "ivf_extractor_create": (C.c_int, [C.POINTER(ExtractorParams), C.c_int, C.POINTER(vp)]),
     "ivf_extractor_destroy": (None, [vp]),
@@ -153,17 +154,28 @@ EXPORTED_SYMBOLS = tuple(_SIGS)
 _lib = None
 
 
-def source_build_id():
-    """What ivf_build_id() must return for the sources on disk (same files, same order as iv_slam_amd/csrc/Makefile IDSRCS)."""
+EXPERIMENT_LIB_PATH = os.path.join(_HERE, "libivfront_exp.so")     # make -C iv_slam_amd/csrc EXPERIMENT=1 (kernel-variant tests, tools/)
+
+
+def source_build_id(flags=""):
+    """What ivf_build_id() must return for the sources on disk (same files, same order as iv_slam_amd/csrc/Makefile IDSRCS) built
+    with the variant flags `flags` ("" = the product, "-DIVF_EXPERIMENT" = the experiment build).  None when the sources are
+    not beside the package (an installed / copied package: nothing to compare with)."""
     import glob
     import hashlib
     csrc = os.path.join(_HERE, "csrc")
     inc = os.path.join(os.path.dirname(_HERE), "include")
     files = sorted(glob.glob(os.path.join(csrc, "*.hip"))) + [os.path.join(csrc, "ivf_device.h")] + sorted(glob.glob(os.path.join(inc, "*")))
+    if not os.path.isfile(os.path.join(inc, "ivfront.h")) or not os.path.isfile(os.path.join(csrc, "ivf_device.h")):
+        return None
     h = hashlib.sha256()
-    for f in files:
-        with open(f, "rb") as fh:
-            h.update(fh.read())
+    try:
+        for f in files:
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    except OSError:
+        return None
+    h.update(flags.encode())
     return h.hexdigest()[:16]
 
 
@@ -187,12 +199,23 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        # provenance: a library built from other sources than the ones beside it must not produce a result
-        # (IVFRONT_LIB = an experiment build from tools/, compiled with other flags or sources on purpose: reported, not refused)
-        built, want = lib.ivf_build_id().decode(), source_build_id()
-        if built != want and not os.environ.get("IVFRONT_LIB"):
-            raise ImportError("libivfront.so is stale: built from sources %s, the sources on disk are %s -- rebuild with "
-                              "`make -C iv_slam_amd/csrc` (python -c 'import __graft_entry__ as g; g.build()')" % (built, want))
+        # provenance: a library built from other sources OR other flags than the product's must not produce a result.  The id covers
+        # the variant flags, so the default library must have been built with none.  IVFRONT_LIB = an experiment build, compiled with
+        # other flags on purpose: its id is checked against the sources + ITS OWN flags; a mismatch there is reported, not refused
+        # (A/B runs against an older library, tools/ab_old_lib.sh).  Sources absent (installed package): nothing to check against.
+        built, flags = lib.ivf_build_id().decode(), lib.ivf_build_flags().decode()
+        if not os.environ.get("IVFRONT_LIB"):
+            want = source_build_id("")
+            if want is not None and (built != want or flags):
+                raise ImportError("libivfront.so is stale or not the product build: built from sources+flags %s (flags %r), the sources on disk "
+                                  "give %s -- rebuild with `make -C iv_slam_amd/csrc` (python -c 'import __graft_entry__ as g; g.build()')"
+                                  % (built, flags, want))
+        else:
+            want = source_build_id(flags)
+            if want is not None and built != want:
+                import warnings
+                warnings.warn("IVFRONT_LIB=%s was built from other sources than the ones on disk (%s vs %s, flags %r): results are "
+                              "those of that build" % (LIB_PATH, built, want, flags))
         _lib = lib
     return _lib
 

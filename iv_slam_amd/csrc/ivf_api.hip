@@ -14,6 +14,28 @@
 
 using namespace ivf;
 
+#ifdef IVF_EXPERIMENT
+// ---- soak aid (tools/soak_frontend.py): host-visible progress words ----
+// A 1-thread marker launch behind every stage of Context::run / ivf_frontend_run writes (run << 8 | stage) into a word of
+// host-mapped memory the caller registered with ivf_debug_progress_words: when a child process of the soak sticks in
+// ivf_frontend_sync, its parent reads from these words which stage each internal stream reached.  Words:
+//   [k]      own batch on internal stream k:  1 ingest  2 pyramid  3 FAST  4 selection  5 join (blur awaited)  6 descriptors  7 stereo
+//   [3 + k]  a LENT blur on internal stream k (batch of context k - 1): 1 fork passed  2 blur done
+//   [6]      host: run << 8 | 1 enqueue entered, 2 enqueue done; [7] host: 0x10 + k = ivf_frontend_sync waits for stream k, 0x20 = returned
+// Experiment builds only: the product has neither the words nor the launches.
+namespace ivf {
+__global__ void k_mark(int* w, int v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+}
+static int* g_markDev = nullptr;
+static volatile int* g_markHost = nullptr;
+#define IVF_MARK(st, word, stage, run) \
+    do { if (g_markDev && (word) >= 0) hipLaunchKernelGGL(ivf::k_mark, dim3(1), dim3(1), 0, (st), g_markDev + (word), (int)(((run) << 8) | (stage))); } while (0)
+#define IVF_MARK_HOST(word, v) do { if (g_markHost) g_markHost[(word)] = (int)(v); } while (0)
+#else
+#define IVF_MARK(st, word, stage, run) do { } while (0)
+#define IVF_MARK_HOST(word, v) do { } while (0)
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -88,7 +110,7 @@ struct Context {
     // hardware queues, and three more streams put the FCN's stream behind front-end work
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     long long nRuns = 0;
-    int pyrEpoch = 0;               // launches of k_pyr_multi so far: its barrier counters only grow
+    int markOwn = -1, markSide = -1;    // progress words of this context's stream / of the stream its blur is lent (experiment builds: IVF_MARK)
     hipStream_t lastStream = nullptr;
 
     int build(const Tables& t, int w, int h, int maxImages, int sides, int dev, bool withStereo, const int* variant = nullptr);
@@ -257,8 +279,6 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
     HIPCHK(hipMemset(b.status, 0, 4 * sizeof(int)));
     b.hugeCount = b.status + 1;
     HIPCHK(hipMalloc(&b.tierList, 2 * nI * (size_t)c.nCellsTotal * sizeof(int)));
-    HIPCHK(hipMalloc(&b.pyrBar, 4 * 2 * nI * 8 * sizeof(int)));
-    HIPCHK(hipMemset(b.pyrBar, 0, 4 * 2 * nI * 8 * sizeof(int)));
     if (c.maxCandCap > 4096) {          // kCellCapBig: cells of this geometry can outgrow the LDS selection paths
         HIPCHK(hipMalloc(&b.hugeList, (size_t)kHugeListCap * sizeof(int)));
         HIPCHK(hipMalloc(&b.hugeScratch, (size_t)kHugeSlots * 6 * c.maxCandCap * sizeof(unsigned)));
@@ -275,7 +295,7 @@ void Context::release()
 {
     (void)hipSetDevice(device);
     void* ptrs[] = {dc, dTab, b.pyr, b.qpyr, b.blur, b.tileList, b.tileCnt, b.cellCnt, b.cellInfo, b.lvlTotal, b.lvl, b.slotPos, b.slotResp, b.lvlCount,
-                    b.useCost, b.kps, b.desc, b.count, b.quality, b.uright, b.depth, b.sad, b.rowCnt, b.rowList, b.status, b.hugeList, b.hugeScratch, b.tierList, b.pyrBar, dStage};
+                    b.useCost, b.kps, b.desc, b.count, b.quality, b.uright, b.depth, b.sad, b.rowCnt, b.rowList, b.status, b.hugeList, b.hugeScratch, b.tierList, dStage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (hStage) (void)hipHostFree(hStage);
     for (int i = 0; i < kEvRing; i++) {
@@ -310,13 +330,18 @@ int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size
     launch_ingest(hc, dc, b, s0, s1, imageStride, rowStride, nImg, nSides, b.pyr, st);
     if (cost) launch_ingest(hc, dc, b, cost, cost, costStride, costRowStride, nImg, nSides, b.qpyr, st);
     if (inputsConsumed) HIPCHK(hipEventRecord(inputsConsumed, st));   // caller buffers are free from here on
-    launch_pyramid(hc, dc, dTab, b.pyr, useQ ? b.qpyr : nullptr, b.useCost, nImg, st, b.pyrBar, &pyrEpoch, 2 * maxImg);   // + ComputeQualityImagePyramid :1325-1357
+    IVF_MARK(st, markOwn, 1, nRuns);
+    launch_pyramid(hc, dc, dTab, b.pyr, useQ ? b.qpyr : nullptr, b.useCost, nImg, st);   // + ComputeQualityImagePyramid :1325-1357
+    IVF_MARK(st, markOwn, 2, nRuns);
     HIPCHK(hipMemsetAsync(b.cellCnt, 0, (size_t)nImg * hc.nCellsTotal * 2 * sizeof(int), st));
     HIPCHK(hipMemsetAsync(b.hugeCount, 0, 3 * sizeof(int), st));
     const int slot = (int)(nRuns % kEvRing);
     HIPCHK(hipEventRecord(evFast0[slot], st));
     launch_fast(hc, dc, b, nImg, st);
     HIPCHK(hipEventRecord(evFast1[slot], st));
+    IVF_MARK(st, markOwn, 3, nRuns);
+    const long long thisRun = nRuns;
+    (void)thisRun;
     nRuns++;
     static const bool sideBlur = getenv("IVF_NO_SIDE_BLUR") == nullptr;
     hipStream_t side = sideStream;
@@ -325,15 +350,22 @@ int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size
         // because its fork event is recorded on st behind them
         HIPCHK(hipEventRecord(evFork, st));
         HIPCHK(hipStreamWaitEvent(side, evFork, 0));
+        IVF_MARK(side, markSide, 1, thisRun);
         launch_blur(hc, dc, b, nImg, side, false);
+        IVF_MARK(side, markSide, 2, thisRun);
         HIPCHK(hipEventRecord(evJoin, side));
         launch_select(hc, dc, b, nImg, st);
+        IVF_MARK(st, markOwn, 4, thisRun);
         HIPCHK(hipStreamWaitEvent(st, evJoin, 0));
+        IVF_MARK(st, markOwn, 5, thisRun);
     } else {
         launch_select(hc, dc, b, nImg, st);
+        IVF_MARK(st, markOwn, 4, thisRun);
         launch_blur(hc, dc, b, nImg, st, true);
+        IVF_MARK(st, markOwn, 5, thisRun);
     }
     launch_describe(hc, dc, b, nullptr, 0, 0, nImg, nSides, st);
+    IVF_MARK(st, markOwn, 6, thisRun);
     HIPCHK(hipGetLastError());
     return IVF_OK;
 }
@@ -2012,11 +2044,12 @@ int ivf_frontend_create(const ivf_frontend_config* cfg, ivf_frontend** out)
     for (int k = 0; k < kPipe; k++) {
         rc = fe->ctx[k].build(t, cfg->width, cfg->height, 2 * cfg->max_pairs, 2, cfg->device_id, true);
         if (rc) return cleanup(rc);
+        fe->ctx[k].markOwn = k; fe->ctx[k].markSide = 3 + (k + 1) % kPipe;
         // the front end's tail kernels are small and latency-bound: on high-priority streams they slot in beside whatever
         // large kernels the caller's stream is running (the FCN of the next batch) instead of queueing behind them
         int prLo = 0, prHi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prLo, &prHi);
-        static const bool noPrio = getenv("IVF_NO_STREAM_PRIORITY") != nullptr;
+        static const bool noPrio = IVF_EXP_ENV("IVF_NO_STREAM_PRIORITY") != nullptr;
         const unsigned evFlags = hipEventDisableTiming;
         if ((noPrio ? hipStreamCreateWithFlags(&fe->stream[k], hipStreamNonBlocking)
                     : hipStreamCreateWithPriority(&fe->stream[k], hipStreamNonBlocking, prHi)) != hipSuccess ||
@@ -2065,6 +2098,7 @@ int ivf_frontend_run(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_r
     hipStream_t st = fe->stream[k];
     HIPCHK(hipSetDevice(fe->cfg.device_id));
     // order: everything the caller enqueued so far (it produced the inputs) -> this batch
+    IVF_MARK_HOST(6, (fe->runs << 8) | 1);
     HIPCHK(hipEventRecord(fe->evIn[k], caller));
     HIPCHK(hipStreamWaitEvent(st, fe->evIn[k], 0));
     // the blur of this batch is lent the internal stream of the NEXT context: whatever older batch that stream still holds does not
@@ -2073,12 +2107,14 @@ int ivf_frontend_run(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_r
                    fe->dFlags, st, fe->evConsumed[k], fe->stream[(k + 1) % kPipe]);
     if (rc) return rc;
     launch_stereo(c.hc, c.dc, c.b, n_pairs, fe->cfg.bf, fe->cfg.b, st);
+    IVF_MARK(st, c.markOwn, 7, c.nRuns - 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(fe->evDone[k], st));
     // the caller's stream may overwrite its input buffers once they have been ingested
     HIPCHK(hipStreamWaitEvent(caller, fe->evConsumed[k], 0));
     fe->lastPairs = n_pairs;
     fe->pairsOf[k] = n_pairs;
+    IVF_MARK_HOST(6, (fe->runs << 8) | 2);
     fe->runs++;
     return IVF_OK;
 }
@@ -2088,12 +2124,31 @@ int ivf_frontend_sync(ivf_frontend* fe)
     if (!fe) return fail(IVF_E_INVALID, "null handle");
     HIPCHK(hipSetDevice(fe->cfg.device_id));
     for (int k = 0; k < kPipe; k++) {
+        IVF_MARK_HOST(7, 0x10 + k);
         HIPCHK(hipStreamSynchronize(fe->stream[k]));
         const int rc = fe->ctx[k].check_status(k);
         if (rc) return rc;
     }
+    IVF_MARK_HOST(7, 0x20);
     return IVF_OK;
 }
+
+#ifdef IVF_EXPERIMENT
+// soak aid, experiment builds only (not declared in include/ivfront.h): `words` = at least 8 ints of host memory the CALLER keeps
+// alive (e.g. a MAP_SHARED file mapping its parent process also maps); registered with the runtime here, written by the marker
+// launches from then on.  words == NULL switches the markers off again.
+extern "C" __attribute__((visibility("default"))) int ivf_debug_progress_words(int* words, int n_words, int device_id)
+{
+    if (!words) { g_markDev = nullptr; g_markHost = nullptr; return IVF_OK; }
+    if (n_words < 8) return fail(IVF_E_INVALID, "need at least 8 progress words");
+    HIPCHK(hipSetDevice(device_id));
+    HIPCHK(hipHostRegister(words, (size_t)n_words * sizeof(int), hipHostRegisterMapped));
+    void* d = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&d, words, 0));
+    g_markDev = (int*)d; g_markHost = words;
+    return IVF_OK;
+}
+#endif
 
 int ivf_frontend_device_results(const ivf_frontend* fe, int side, const ivf_keypoint** d_kps, const uint8_t** d_desc,
                                 const int32_t** d_count, const float** d_uright, const float** d_depth,

@@ -88,7 +88,6 @@ struct Buffers {            // device pointers of one batch context
     unsigned short* rowList;    // [nPairs][H][kRowCap]
     int* status;            // [1] device-side error flags, cleared by the host when read
     int* hugeCount;         // [3] cells with more than 4096 survivors in this launch (k_quota -> k_cell_select_huge); [1], [2]: lengths of the tier lists
-    int* pyrBar;            // [4 ring slots][2 * maxImg planes][8] arrival word + level counters of k_pyr_multi (slot = launch % 4, zeroed two launches ahead)
     int* tierList;          // [2][nImg * nCellsTotal] cells with 257..1024 / 1025..4096 survivors: img * nCellsTotal + cell (k_quota -> k_cell_select_list)
     int* hugeList;          // [kHugeListCap] img * nCellsTotal + cell
     unsigned* hugeScratch;  // [kHugeSlots][6 * maxCandCap] dwords, or nullptr when no cell can exceed 4096 maxima
@@ -106,6 +105,18 @@ struct StereoArgs {
     int* rowCnt; unsigned short* rowList;                  // [nPairs][H], [nPairs][H][kRowCap]: right keypoints per image row, or null
 };
 
+// Environment switches.  The shipped library reads exactly the switches listed in INTEGRATION.md (documented, result-preserving:
+// getenv is spelled out at those sites).  Every kernel-variant selector and tuning knob of the experiments behind DESIGN.md goes through
+// IVF_EXP_ENV, which is getenv only in an experiment build (`make EXPERIMENT=1` -> libivfront_exp.so, loaded through IVFRONT_LIB by
+// tools/ and by the kernel-variant tests) and a null constant in the product: the names are not even compiled in
+// (tests/test_abi_cpu.py asserts the list of IVF_* strings in libivfront.so).
+#ifdef IVF_EXPERIMENT
+#include <stdlib.h>
+#define IVF_EXP_ENV(name) getenv(name)
+#else
+#define IVF_EXP_ENV(name) ((const char*)nullptr)
+#endif
+
 // every kernel launch of the library goes through hipLaunchKernelGGL: counted for bench.py's launches_per_step
 void count_launch();
 }  // namespace ivf
@@ -121,7 +132,7 @@ void launch_stereo_args(const Config& hc, const Config* dc, const StereoArgs& A,
 void launch_ingest(const Config& hc, const Config* dc, const Buffers& b, const uint8_t* src0, const uint8_t* src1,
                    size_t imageStride, int rowStride, int nImg, int nSides, uint8_t* dstBlob, hipStream_t s);
 void launch_pyramid(const Config& hc, const Config* dc, const ResizeCoef* dTab, uint8_t* blob, uint8_t* qblob, const uint8_t* useCost,
-                    int nImg, hipStream_t s, int* bar, int* epoch, int maxPlanes);
+                    int nImg, hipStream_t s);
 void launch_fast(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s);
 void launch_blur(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s, bool skipEmptyLevels);
 void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s);

@@ -2237,6 +2237,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
 #endif
 }
 
+#ifdef IVF_EXPERIMENT      // opt-in variant (IVF_FCN_ROLES=1) with a run-time ablation mask: experiment builds only
 // ---- k_fcn_irbd4w (r04): the same block with ROLE-SPECIALISED waves ----
 // k_fcn_irbd4 runs eight waves that each hold the input fragments (80 registers) AND the projection accumulators (80): two waves per
 // SIMD, whose MFMA phase, stencil phase and weight requests add up instead of overlapping (interval = MFMA cycles of ONE wave + ~2,200;
@@ -2478,6 +2479,7 @@ __global__ __launch_bounds__(1024) void k_fcn_irbd4w(const float* __restrict__ X
         }
     }
 }
+#endif  // IVF_EXPERIMENT
 
 // the second half of a SPLIT launch: Y = (sum over the ranges, in index order) * scale + shift (+ residual); 4 pixels per thread
 // part and Y are in the output layout `layOut`, the residual (the block's input) in `layIn`.  In every layout the four elements of
@@ -2963,8 +2965,8 @@ void launch_gemm_t(const Gemm& g, const float* X, const float* res, float* Y, in
 void launch_gemm(const Gemm& g, const float* X, const float* res, float* Y, int H, int W, int B, hipStream_t s)
 {
     if (g.taps == 9) {
-        static const bool old9 = getenv("IVF_FCN_OLD3X3") != nullptr;
-        static const bool split9 = getenv("IVF_FCN_3X3_SPLIT") != nullptr;      // the r01 kernel: one workgroup per output-channel tile
+        static const bool old9 = IVF_EXP_ENV("IVF_FCN_OLD3X3") != nullptr;
+        static const bool split9 = IVF_EXP_ENV("IVF_FCN_3X3_SPLIT") != nullptr;      // the r01 kernel: one workgroup per output-channel tile
         if (!old9 && !split9 && H == 64 && W == 64 && g.cin % 32 == 0 && g.act == 2 && !res && g.nTiles == 3)
             hipLaunchKernelGGL((k_fcn_conv3x3_all<3>), dim3(8 * B), dim3(256), 0, s, X, g.dWq, g.dScale, g.dShift, Y, g.cin, g.cout,
                                (const float*)nullptr, 0.f, (float*)nullptr, (float*)nullptr);
@@ -2987,8 +2989,8 @@ void launch_gemm(const Gemm& g, const float* X, const float* res, float* Y, int 
 // expansion with the B tile stationary in LDS; false = not applicable, caller uses k_fcn_gemm
 bool launch_expand(const Gemm& g, const float* X, float* Y, int H, int W, int B, hipStream_t s)
 {
-    static const int mode = getenv("IVF_FCN_EXPAND") ? atoi(getenv("IVF_FCN_EXPAND")) : 4;     // 0 off, 2 / 4 = PXT
-    static const int minCin = getenv("IVF_FCN_EXPAND_MINCIN") ? atoi(getenv("IVF_FCN_EXPAND_MINCIN")) : 64;
+    static const int mode = IVF_EXP_ENV("IVF_FCN_EXPAND") ? atoi(IVF_EXP_ENV("IVF_FCN_EXPAND")) : 4;     // 0 off, 2 / 4 = PXT
+    static const int minCin = IVF_EXP_ENV("IVF_FCN_EXPAND_MINCIN") ? atoi(IVF_EXP_ENV("IVF_FCN_EXPAND_MINCIN")) : 64;
     const int tiles = (g.cout + 31) / 32, HW = H * W, K16 = (g.cin + 15) / 16;
     if (!mode || g.taps != 1 || g.act != 1 || g.nTiles != tiles || g.cin < minCin || tiles < 4) return false;
     int pxt = mode;
@@ -3001,7 +3003,7 @@ bool launch_expand(const Gemm& g, const float* X, float* Y, int H, int W, int B,
     // IVF_FCN_EXPAND_RING=1: full-depth A ring (a register slot per K step: every refill belongs to the NEXT tile).  It
     // helped the un-pipelined tile loop at 10 K steps (329 -> 314 us); with the epilogue folded into the next tile's K
     // loop the second accumulator set leaves no room for it (77 spills, 424 us), so the half-depth ring is the default.
-    static const bool fullRing = getenv("IVF_FCN_EXPAND_RING") && atoi(getenv("IVF_FCN_EXPAND_RING")) == 1;
+    static const bool fullRing = IVF_EXP_ENV("IVF_FCN_EXPAND_RING") && atoi(IVF_EXP_ENV("IVF_FCN_EXPAND_RING")) == 1;
     static const bool bigLdsR = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcn_expand<4, 10, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
     }();
@@ -3024,12 +3026,12 @@ static thread_local char g_lastDwpw[96] = "";
 // fused depthwise + projection for the 64x64 stride-1 stages; false = shape not covered, caller runs the two kernels
 bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, float* Y, int H, int W, int B, hipStream_t s)
 {
-    static const bool off = getenv("IVF_FCN_NOFUSE") != nullptr;
+    static const bool off = IVF_EXP_ENV("IVF_FCN_NOFUSE") != nullptr;
     const int abl = kAbl;                                                   // ablation builds keep the 4-wave kernels
     const int tiles = (g.cout + 31) / 32;
     if (off || H != W || (H != 64 && H != 128 && H != 256) || d.c % 16 || g.taps != 1 || g.nTiles != tiles || g.act != 0) return false;
     if (d.stride == 2) {                                                    // blocks 2 (256 -> 128) and 4 (128 -> 64)
-        static const bool s2 = getenv("IVF_FCN_NOSTRIDE2") == nullptr;
+        static const bool s2 = IVF_EXP_ENV("IVF_FCN_NOSTRIDE2") == nullptr;
         if (!s2 || d.dil != 1 || tiles != 1 || (H != 256 && H != 128)) return false;
         const int Ho = H / 2, wg = Ho * Ho / 128;
         if (Ho == 128)
@@ -3039,15 +3041,15 @@ bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, f
         return true;
     }
     if (d.stride != 1) return false;
-    static const bool wide = getenv("IVF_FCN_NOWIDE") == nullptr;           // 128-wide maps (block 3: 297 -> 114 us)
-    static const bool wide256 = getenv("IVF_FCN_WIDE256") != nullptr;       // block 1 has only two K chunks: the fused kernel is
+    static const bool wide = IVF_EXP_ENV("IVF_FCN_NOWIDE") == nullptr;           // 128-wide maps (block 3: 297 -> 114 us)
+    static const bool wide256 = IVF_EXP_ENV("IVF_FCN_WIDE256") != nullptr;       // block 1 has only two K chunks: the fused kernel is
                                                                             // slower there (335 vs 270 us), off unless asked for
     if (H != 64 && (!wide || d.dil != 1 || tiles != 1)) return false;
     const dim3 blk(256);
     const int wgpi = H * W / 128;
     // eight waves (four image rows) per workgroup on the 64 x 64 maps.  Measured per 128 images, 4 vs 8 waves: 1 tile 125 -> 117,
     // 2 tiles 263 -> 251 / 144 -> 128, 3 tiles 388 -> 395, 5 tiles 915 -> 919 us: on for <= 2 tiles; IVF_FCN_NW = 4 / 8 forces one
-    static const int nwEnv = getenv("IVF_FCN_NW") ? atoi(getenv("IVF_FCN_NW")) : 0;
+    static const int nwEnv = IVF_EXP_ENV("IVF_FCN_NW") ? atoi(IVF_EXP_ENV("IVF_FCN_NW")) : 0;
 #define DWPW(T, D, LWV, GY) do {                                                                                          \
     snprintf(g_lastDwpw, sizeof g_lastDwpw, "ivffcn::k_fcn_dwpw<" #T ", " #D "> %d->%d", d.c, g.cout);                      \
     if (LWV == 6 && (nwEnv == 8 || (nwEnv != 4 && T <= 2)))                                                                 \
@@ -3060,7 +3062,7 @@ bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, f
                        g.cout, g.nTiles); } while (0)
     // 8-wave kernel per shape (measured per 64 images, 4-wave vs 8-wave): 576->160 dil 2: 294 vs 258 (on by default);
     // 960->160 dil 4: 460 vs 472, 576->96: 213 vs 228, 384->64: 148 vs 167 (off).  IVF_FCN_DWPW8 = bit mask by tile count.
-    static const int w8 = getenv("IVF_FCN_DWPW8") ? (int)strtol(getenv("IVF_FCN_DWPW8"), nullptr, 0) : -1;
+    static const int w8 = IVF_EXP_ENV("IVF_FCN_DWPW8") ? (int)strtol(IVF_EXP_ENV("IVF_FCN_DWPW8"), nullptr, 0) : -1;
     if (H == 64 && !abl) {
         auto on = [&](bool dflt) { return w8 < 0 ? dflt : (w8 >> tiles & 1) != 0; };
         if (tiles == 5 && d.dil == 2 && on(true)) { DWPW8(2, 5); return true; }
@@ -3077,7 +3079,7 @@ bool launch_dwpw(const Dw& d, const Gemm& g, const float* X, const float* res, f
     else if (tiles == 5 && d.dil == 2) DWPW(5, 2, 6, 1);
     else if (tiles == 5 && d.dil == 4) DWPW(5, 4, 6, 1);
     else if (tiles == 10 && d.dil == 4) {
-        static const bool one = getenv("IVF_FCN_NODWPW10") == nullptr;      // one pass over the hidden tensor with an 8-wave workgroup
+        static const bool one = IVF_EXP_ENV("IVF_FCN_NODWPW10") == nullptr;      // one pass over the hidden tensor with an 8-wave workgroup
         if (one && !abl) DWPW8(4, 10); else DWPW(5, 4, 6, 2);
     }
     else return false;
@@ -3153,11 +3155,11 @@ int make_gemm(ivf_fcn* f, const float* w, int cout, int cin, int taps, const std
     // wave tile = 32*NT output channels x 32*PT pixels.  Few input channels (short K loop, output-write bound):
     // small accumulator tiles so several waves share a SIMD and hide the load/store latency; long K loops: bigger
     // tiles for operand reuse.  IVF_FCN_NT_SMALL / IVF_FCN_NT_BIG / IVF_FCN_USE25 override for tuning runs.
-    static const int ntSmall = getenv("IVF_FCN_NT_SMALL") ? atoi(getenv("IVF_FCN_NT_SMALL")) : 1;
-    static const int ntBig = getenv("IVF_FCN_NT_BIG") ? atoi(getenv("IVF_FCN_NT_BIG")) : 1;
-    static const int use25 = getenv("IVF_FCN_USE25") ? atoi(getenv("IVF_FCN_USE25")) : 0;
-    static const int ptSmall = getenv("IVF_FCN_PT_SMALL") ? atoi(getenv("IVF_FCN_PT_SMALL")) : 4;
-    static const int ptBig = getenv("IVF_FCN_PT_BIG") ? atoi(getenv("IVF_FCN_PT_BIG")) : 4;
+    static const int ntSmall = IVF_EXP_ENV("IVF_FCN_NT_SMALL") ? atoi(IVF_EXP_ENV("IVF_FCN_NT_SMALL")) : 1;
+    static const int ntBig = IVF_EXP_ENV("IVF_FCN_NT_BIG") ? atoi(IVF_EXP_ENV("IVF_FCN_NT_BIG")) : 1;
+    static const int use25 = IVF_EXP_ENV("IVF_FCN_USE25") ? atoi(IVF_EXP_ENV("IVF_FCN_USE25")) : 0;
+    static const int ptSmall = IVF_EXP_ENV("IVF_FCN_PT_SMALL") ? atoi(IVF_EXP_ENV("IVF_FCN_PT_SMALL")) : 4;
+    static const int ptBig = IVF_EXP_ENV("IVF_FCN_PT_BIG") ? atoi(IVF_EXP_ENV("IVF_FCN_PT_BIG")) : 4;
     if (taps == 9) { g.NT = 3; g.PT = 1; }
     else if (cin <= 32) { g.NT = std::min(tiles, ntSmall); g.PT = ptSmall; }
     else if (tiles == 5 && use25) { g.NT = 5; g.PT = 2; }
@@ -3248,14 +3250,18 @@ int reserve_lds()
         {reinterpret_cast<const void*>(&k_fcn_irbd2<96, 96, true, 2, true>), D2Cfg<96, 96>::LDS, "k_fcn_irbd2<96,96,split>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd2<96, 160, false, 2, true>), D2Cfg<96, 160>::LDS, "k_fcn_irbd2<96,160,split>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd4<false, true>), kF4Lds, "k_fcn_irbd4<split>"},
+#ifdef IVF_EXPERIMENT
         {reinterpret_cast<const void*>(&k_fcn_irbd4w<true>), kF4Lds, "k_fcn_irbd4w<true>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd4w<false>), kF4Lds, "k_fcn_irbd4w<false>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd4w<false, true>), kF4Lds, "k_fcn_irbd4w<split>"},
+#endif
     };
     for (auto& k : ks)
         if (hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.lds) != hipSuccess)
             return ffail(IVF_E_NO_DEVICE, "cannot reserve %zu bytes of LDS for %s", k.lds, k.name);
-    if (const char* e = getenv("IVF_FCN_WABL")) { const int v = atoi(e); FHIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wAbl), &v, sizeof v)); }
+#ifdef IVF_EXPERIMENT
+    if (const char* e = IVF_EXP_ENV("IVF_FCN_WABL")) { const int v = atoi(e); FHIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wAbl), &v, sizeof v)); }
+#endif
     return IVF_OK;
 }
 
@@ -3266,7 +3272,7 @@ int reserve_lds()
 constexpr size_t kPartFloats = (size_t)16 * 320 * 4096;         // bufPart: ns x images x Cout x 4096 <= this
 int split_ways(int n, int groups, int cout)
 {
-    static const int mode = getenv("IVF_FCN_SPLIT") ? atoi(getenv("IVF_FCN_SPLIT")) : 1;      // 0 = never (every batch through the batched form)
+    static const int mode = IVF_EXP_ENV("IVF_FCN_SPLIT") ? atoi(IVF_EXP_ENV("IVF_FCN_SPLIT")) : 1;      // 0 = never (every batch through the batched form)
     if (!mode || n >= 16) return 1;
     int ns = std::min(16 / n, groups / 4);
     while (ns > 1 && (size_t)ns * n * cout * 4096 > kPartFloats) ns--;
@@ -3295,10 +3301,10 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
     // whole-block kernels, bit i = block i + 2: blocks 2-4 (k_fcn_irb) by default; bits 3-9 = blocks 5-11 through k_fcn_irb64, which
     // is correct but measures slower than expand + dwpw there (337 vs 245 us for the 64->384->64 blocks): opt-in.  Off under the
     // layer-by-layer / other-kernel experiment switches
-    static const unsigned irbMask = (getenv("IVF_FCN_NOFUSE") || getenv("IVF_FCN_NOSTRIDE2")) ? 0u
-                                    : getenv("IVF_FCN_IRBMASK") ? (unsigned)strtoul(getenv("IVF_FCN_IRBMASK"), nullptr, 0) : 7u;
+    static const unsigned irbMask = (IVF_EXP_ENV("IVF_FCN_NOFUSE") || IVF_EXP_ENV("IVF_FCN_NOSTRIDE2")) ? 0u
+                                    : IVF_EXP_ENV("IVF_FCN_IRBMASK") ? (unsigned)strtoul(IVF_EXP_ENV("IVF_FCN_IRBMASK"), nullptr, 0) : 7u;
     // conv0 + block 1's depthwise layer in one kernel, unless an experiment switch asks for another kernel on block 1
-    static const bool stem = getenv("IVF_FCN_NOSTEM") == nullptr && getenv("IVF_FCN_WIDE256") == nullptr && getenv("IVF_FCN_NOFUSE") == nullptr;
+    static const bool stem = IVF_EXP_ENV("IVF_FCN_NOSTEM") == nullptr && IVF_EXP_ENV("IVF_FCN_WIDE256") == nullptr && IVF_EXP_ENV("IVF_FCN_NOFUSE") == nullptr;
     if (stem) {
         const Dw& d0 = f->dw[0];
         hipLaunchKernelGGL(k_fcn_stem, dim3(kEnc / 2 / kStemTW, kEnc / 2 / kStemTH, n), dim3(512), 0, s, f->bufIn, f->dConv0W, f->dConv0S,
@@ -3310,12 +3316,12 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
     }
     // which blocks run as ONE whole-block kernel of the 64 x 64 stage (k_fcn_irbd2 / k_fcn_irbd4), and the layout of every tensor
     // between them: lay[i] = layout of block i's OUTPUT (0 planes, 1 NHWC8: producer AND consumer are such kernels, or the decoder)
-    static const int fused1 = getenv("IVF_FCN_NOFUSE") ? 0 : getenv("IVF_FCN_FUSED1") ? atoi(getenv("IVF_FCN_FUSED1")) : 1;
-    static const int fused2 = getenv("IVF_FCN_NOFUSE") ? 0 : getenv("IVF_FCN_FUSED2") ? atoi(getenv("IVF_FCN_FUSED2")) : 1;
-    static const int fused4 = getenv("IVF_FCN_NOFUSE") ? 0 : getenv("IVF_FCN_FUSED4") ? atoi(getenv("IVF_FCN_FUSED4")) : 1;
-    static const bool fuseLast = getenv("IVF_FCN_NOFUSELAST") == nullptr && getenv("IVF_FCN_OLD3X3") == nullptr &&
-                                 getenv("IVF_FCN_3X3_SPLIT") == nullptr;
-    static const int tileMask = getenv("IVF_FCN_TILED") ? atoi(getenv("IVF_FCN_TILED")) : 6;      // bit 0: lay 1 (measured slower: off), bit 1: lay 2, bit 2: lay 4
+    static const int fused1 = IVF_EXP_ENV("IVF_FCN_NOFUSE") ? 0 : IVF_EXP_ENV("IVF_FCN_FUSED1") ? atoi(IVF_EXP_ENV("IVF_FCN_FUSED1")) : 1;
+    static const int fused2 = IVF_EXP_ENV("IVF_FCN_NOFUSE") ? 0 : IVF_EXP_ENV("IVF_FCN_FUSED2") ? atoi(IVF_EXP_ENV("IVF_FCN_FUSED2")) : 1;
+    static const int fused4 = IVF_EXP_ENV("IVF_FCN_NOFUSE") ? 0 : IVF_EXP_ENV("IVF_FCN_FUSED4") ? atoi(IVF_EXP_ENV("IVF_FCN_FUSED4")) : 1;
+    static const bool fuseLast = IVF_EXP_ENV("IVF_FCN_NOFUSELAST") == nullptr && IVF_EXP_ENV("IVF_FCN_OLD3X3") == nullptr &&
+                                 IVF_EXP_ENV("IVF_FCN_3X3_SPLIT") == nullptr;
+    static const int tileMask = IVF_EXP_ENV("IVF_FCN_TILED") ? atoi(IVF_EXP_ENV("IVF_FCN_TILED")) : 6;      // bit 0: lay 1 (measured slower: off), bit 1: lay 2, bit 2: lay 4
     auto whole = [&](int i) {
         if (i >= 4 && i <= 10 && (irbMask >> (i - 1) & 1)) return false;           // k_fcn_irb64 (opt-in) takes the block
         if (i >= 4 && i <= 6) return fused1 && f->f1[i - 4].dWE != nullptr;
@@ -3425,7 +3431,8 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             if (probe4) FHIP(hipEventRecord(f->probe0[slot4], s));
             const int ns = split_ways(n, kF4Groups, F.cout);
             const dim3 grid(16 * n, F.cout / 160, ns);
-            static const int roles = getenv("IVF_FCN_ROLES") ? atoi(getenv("IVF_FCN_ROLES")) : 0;      // 1: role-specialised waves (k_fcn_irbd4w)
+#ifdef IVF_EXPERIMENT
+            static const int roles = IVF_EXP_ENV("IVF_FCN_ROLES") ? atoi(IVF_EXP_ENV("IVF_FCN_ROLES")) : 0;      // 1: role-specialised waves (k_fcn_irbd4w)
             if (roles) {
                 if (ns > 1) {
                     hipLaunchKernelGGL((k_fcn_irbd4w<false, true>), grid, dim3(1024), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y,
@@ -3437,7 +3444,9 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
                 else
                     hipLaunchKernelGGL((k_fcn_irbd4w<false>), grid, dim3(1024), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y, F.cout, F.tilesP,
                                        (float*)nullptr, layIn, layOut);
-            } else if (ns > 1) {
+            } else
+#endif
+            if (ns > 1) {
                 hipLaunchKernelGGL((k_fcn_irbd4<false, true>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y,
                                    F.cout, F.tilesP, f->bufPart, layIn, layOut);
                 launch_split_reduce(f, ns, n, F.cout, pj, bk.res ? x : nullptr, y, layIn, layOut, s);
@@ -3460,7 +3469,7 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
         // IVF_FCN_CHUNK = images per chunk (0 = off): expansion and fused depthwise + projection of a 64 x 64 block run chunk by chunk,
         // back to back, through ONE hidden-tensor region of `chunk` images that every chunk reuses -- the region (8 images x 15.7 MB
         // for the 960-channel blocks) stays in the 256 MB Infinity Cache between its write and its read
-        static const int chunkEnv = getenv("IVF_FCN_CHUNK") ? atoi(getenv("IVF_FCN_CHUNK")) : 0;
+        static const int chunkEnv = IVF_EXP_ENV("IVF_FCN_CHUNK") ? atoi(IVF_EXP_ENV("IVF_FCN_CHUNK")) : 0;
         if (chunkEnv > 0 && bk.t != 1 && H == 64 && W == 64 && n > chunkEnv && bk.stride == 1) {
             const Dw& d = f->dw[id];
             bool ok = true;
@@ -3520,7 +3529,7 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
         const Gemm& g = f->pw[ip++];
         if (fuseLast && g.taps == 9 && H == 64 && W == 64 && g.cin % 32 == 0 && g.act == 2 && g.nTiles == 3) {
             // small batches: the 60 (tap row, K step) pairs in `nd` ranges over gridDim.y + k_fcn_dec_reduce (same rule as split_ways)
-            static const int splitMode = getenv("IVF_FCN_SPLIT") ? atoi(getenv("IVF_FCN_SPLIT")) : 1;
+            static const int splitMode = IVF_EXP_ENV("IVF_FCN_SPLIT") ? atoi(IVF_EXP_ENV("IVF_FCN_SPLIT")) : 1;
             int nd = 1;
             if (splitMode && g.cin == 320) { const int ways[] = {15, 10, 6, 5, 3, 2}; for (int w : ways) if (w * n <= 16) { nd = w; break; } }
             if (nd > 1) {

@@ -293,79 +293,6 @@ __global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg
     pyr_tile(cfg, level, tab, blob + (size_t)img * cfg->pyrBytes, blockIdx.x * kPyrTW, blockIdx.y * kPyrTH, ldsPitch, ldsRows, src);
 }
 
-// k_pyr_multi (r04): levels l0 .. l1 of every plane in ONE launch.  The upper levels are launch tails (15-26 us each for 23-59 MB per 256
-// planes; a single frame's seven launches are 110 us of a 380-us extraction): W workgroups per plane walk the levels in order, each
-// taking the tiles t = w, w + W, ... of a level, with a barrier among the W workgroups of the plane between levels (a counter per
-// (plane, level); the counters of launch e live in ring slot e % 4 and every launch zeroes slot (e + 2) % 4 -- launches of one context
-// are ordered on its stream).
-// What a level hands to the next must be visible across workgroups.  A device-scope release / acquire on gfx950 writes back and
-// invalidates the whole L2 of the XCD (buffer_wbl2 / buffer_inv sc1: measured 449 us for the launch that replaces 75 us of launches).
-// The W workgroups of a plane are consecutive ids of ONE XCD (ids are dealt round-robin over the 8 XCDs), so their exchange only has
-// to reach that XCD's L2: wait for the stores (the vector L1 writes through) and invalidate the reader's L1.  That placement is an
-// assumption about the dispatcher, so it is CHECKED: every workgroup ORs its HW_REG_XCC_ID into the plane's arrival word before it
-// counts itself in, and a plane whose workgroups report more than one XCD takes the device-scope fences instead.
-// Progress: a workgroup only waits for workgroups with neighbouring ids, which the in-order dispatcher has started or will start as
-// soon as a slot frees -- no cyclic wait whatever else occupies the chip; every wait is bounded anyway.
-struct PyrMulti { int l0, l1, W, planes; int pitch[kMaxLevels], rows[kMaxLevels]; };
-constexpr int kPyrBarRing = 4, kPyrBarWords = 8;          // per plane and ring slot: [0] arrival word (XCD mask << 8 | count), [l] level counters
-__global__ __launch_bounds__(256) void k_pyr_multi(const Config* __restrict__ cfg, PyrMulti M, const ResizeCoef* __restrict__ tab,
-                                                  uint8_t* __restrict__ blobI, uint8_t* __restrict__ blobQ,
-                                                  const uint8_t* __restrict__ useCost, int nImg, int* __restrict__ bar, int epoch, int maxPlanes)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t src[];
-    __shared__ int s_same;
-    const int id = blockIdx.x, k = id >> 3;
-    const int plane = (id & 7) + 8 * (k / M.W), w = k % M.W;
-    if (plane >= M.planes) return;
-    int* const mine = bar + ((size_t)(epoch & (kPyrBarRing - 1)) * maxPlanes + plane) * kPyrBarWords;
-    if (w == 0 && threadIdx.x < kPyrBarWords)       // the slot of launch epoch + 2
-        bar[((size_t)((epoch + 2) & (kPyrBarRing - 1)) * maxPlanes + plane) * kPyrBarWords + threadIdx.x] = 0;
-    int img = plane;
-    uint8_t* blob = blobI;
-    if (img >= nImg) { img -= nImg; blob = blobQ; if (!(useCost[img] & 1u)) return; }      // all W workgroups of the plane leave together
-    uint8_t* base = blob + (size_t)img * cfg->pyrBytes;
-    auto wait_for = [&](int* c, int mask, int want) {
-        for (int spins = 0; (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mask) != want && spins < (1 << 22); spins++)
-            __builtin_amdgcn_s_sleep(2);
-    };
-    if (M.W > 1) {
-        if (threadIdx.x == 0) {
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            // same address: the OR precedes the add in the word's modification order, so whoever sees the full count sees every bit
-            __hip_atomic_fetch_or(mine, 1 << (8 + (xcc & 7)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(mine, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            wait_for(mine, 0xff, M.W);
-            const int a = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_same = ((a & 0xff) == M.W && __popc((a >> 8) & 0xff) == 1) ? 1 : 0;
-        }
-        __syncthreads();
-    }
-    const bool same = M.W > 1 ? s_same != 0 : true;
-    for (int l = M.l0; l <= M.l1; l++) {
-        const LevelGeom& D = cfg->lv[l];
-        if (D.w > 0 && D.h > 0) {
-            const int tilesX = (D.pitch + kPyrTW - 1) / kPyrTW, nt = tilesX * ((D.h + kPyrTH - 1) / kPyrTH);
-            for (int t = w; t < nt; t += M.W) {
-                pyr_tile(cfg, l, tab, base, (t % tilesX) * kPyrTW, (t / tilesX) * kPyrTH, M.pitch[l], M.rows[l], src);
-                __syncthreads();                   // the LDS tile is reused
-            }
-        }
-        if (l < M.l1) {
-            if (same) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this thread's stores are in the XCD's L2
-            else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __syncthreads();
-            if (M.W > 1 && threadIdx.x == 0) {
-                __hip_atomic_fetch_add(mine + l, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                wait_for(mine + l, -1, M.W);
-            }
-            __syncthreads();
-            if (same) asm volatile("buffer_inv sc0" ::: "memory");                       // no stale line in this CU's L1
-            else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // FAST-9/16 score of TWO horizontally adjacent pixels, packed 2 x i16 per register (v_pk_*_i16).
 //   A = max over the 16 arcs of 9 contiguous ring pixels, both polarities, of the minimum signed
@@ -406,7 +333,7 @@ DEVINL bool fast_precheck_pair_b(unsigned t0, unsigned t1, unsigned m0, unsigned
     return compass_test(v, pair_at(b0, b1, 5), pair_at(t0, t1, 5), pair_at(m1, m2, 4), pair_at(m0, m1, 2), t);
 }
 // rows: 7 windows (dy = -3..3), each as (lo, hi) dwords.  Returns the two scores packed (left | right << 16).
-DEVINL unsigned fast_score_pair(const unsigned (&lo)[7], const unsigned (&hi)[7], int t, bool quickOnly = false)
+DEVINL unsigned fast_score_pair(const unsigned (&lo)[7], const unsigned (&hi)[7], int t)
 {
     // r04: everything on the ring pixels p themselves instead of on the differences d = v - p (16 subtractions fewer per pair):
     //   8-pair test:  min_k max(d_k, d_k+8) > t  <=>  max_k min(p_k, p_k+8) < v - t;   max_k min(d_k, d_k+8) < -t  <=>  min_k max(p_k, p_k+8) > v + t
@@ -429,7 +356,6 @@ DEVINL unsigned fast_score_pair(const unsigned (&lo)[7], const unsigned (&hi)[7]
     const s16x2 T = {(short)t, (short)t};
     const s16x2 u = X - (v - T), w = (v + T) - Y;                                // negative where the darker / brighter 8-pair test passes
     if (((__builtin_bit_cast(unsigned, u) | __builtin_bit_cast(unsigned, w)) & 0x80008000u) == 0u) return 0u;
-    if (quickOnly) return 0x00010001u;
     const s16x2 sg = (w >> 15) | (s16x2){1, 1};
     s16x2 q[16];
 #pragma unroll
@@ -474,7 +400,7 @@ constexpr int kScW = kFastTW + 2, kScH = kFastTH + 2, kScP = kFastTW + 4;   // s
 // in the same cell, bits 8.. = cell column / row index
 __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg, const uint8_t* __restrict__ pyr,
                                                  const uint8_t* __restrict__ useCost, unsigned* __restrict__ tileList,
-                                                 int* __restrict__ tileCnt, int* __restrict__ cellCnt, int nImg, int ablate)
+                                                 int* __restrict__ tileCnt, int* __restrict__ cellCnt, int nImg)
 {
     __shared__ __attribute__((aligned(16))) unsigned raw[(kFastTH + 8) * (kRawP / 4) + 4];   // +4: the funnel read touches one dword past a window
     __shared__ __attribute__((aligned(16))) uint8_t sc[(kScH * kScP + 15) / 16 * 16];
@@ -497,7 +423,6 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     int img, bx;
     if (!xcd_tile_image(cfg->nTiles, nImg, bx, img)) return;
     const int tid = threadIdx.x;
-    if (ablate & 16) return;
     // the prologue is latency: every load below is issued before anything waits on one.  Level lookup: all tile bases
     // in one wide load (INT_MAX past nlevels)
     const unsigned useC = useCost[img];
@@ -558,7 +483,6 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
 #pragma unroll
     for (int k = 0; k < kRawIt; k++)
         if (rawR < kRawRPP && rawR + kRawRPP * k < kFastTH + 8) raw[(rawR + kRawRPP * k) * kRawQ + rawQ] = rv_[k];
-    if (ablate & 32) return;
     __syncthreads();
     // 2. scores, four pixels (two packed pairs) per step sharing the three aligned dwords of each of the 7 rows:
     //    score columns sx..sx+3 (sx % 4 == 0); the window of pair A (sx, sx+1) is bytes 0..7 of the 12-byte span
@@ -591,7 +515,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
 #pragma unroll
         for (int k = 0; k < kRPT; k++) {
             const int sy = sy0 + k;
-            const bool in = thr && sy < kScH, rowOk = in && (rvv[k] & 1u) && !(ablate & 1);
+            const bool in = thr && sy < kScH, rowOk = in && (rvv[k] & 1u);
             bool pA = false, pB = false;
             if (rowOk && cA) pA = fast_precheck_pair(w0[k], w1[k], w0[k + 3], w1[k + 3], w0[k + 6], w1[k + 6], minTh);
             // pair B sits two bytes further: its five operands are picked straight out of the same dwords (only x+3 reaches the third one)
@@ -621,7 +545,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
             lo[r] = __builtin_amdgcn_alignbyte(w1, w0, sh);
             hi[r] = __builtin_amdgcn_alignbyte(w2, w1, sh);
         }
-        unsigned two = fast_score_pair(lo, hi, minTh, (ablate & 4) != 0);
+        unsigned two = fast_score_pair(lo, hi, minTh);
         if (!(colInfo[sx] & 1u)) two &= 0xffff0000u;
         if (!(colInfo[sx + 1] & 1u)) two &= 0x0000ffffu;
         const unsigned packed = (two & 0xffu) | ((two >> 8) & 0xff00u);
@@ -644,7 +568,6 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
         }
     }
     __syncthreads();
-    if (ablate & 2) { if (tid == 0) tileCnt[(size_t)img * cfg->nTiles + bx] = 0; return; }
     // 3. NMS, then publish.  Survivors are gathered in an LDS list and leave as ONE coalesced copy into the tile's own
     // slot of `tileList` (arbitrary order, count in `tileCnt`): no slot reservation, no returning atomics.  Only the
     // per-cell counters (needed by k_quota) use global atomics, non-returning, one per cell the tile touches.
@@ -685,7 +608,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
         }
     };
     const int nc = s_nc;
-    if (nc <= kCandCap && !(ablate & 8)) {
+    if (nc <= kCandCap) {
         // the usual case: dense over the scored pixels pass B listed, one per lane
         for (int i = tid; i < nc; i += 256) {
             const int sy = s_cand[i] >> 8, sx = s_cand[i] & 0xff;
@@ -2179,57 +2102,31 @@ void launch_ingest(const Config& hc, const Config* dc, const Buffers& b, const u
 }
 // one launch per level: planes of `blob` and (qblob != nullptr) of the cost blob, the latter only for images whose useCost bit 0 is set
 void launch_pyramid(const Config& hc, const Config* dc, const ResizeCoef* dTab, uint8_t* blob, uint8_t* qblob, const uint8_t* useCost,
-                    int nImg, hipStream_t s, int* bar, int* epoch, int maxPlanes)
+                    int nImg, hipStream_t s)
 {
     static const bool ldsOk = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_down), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  kPyrMaxR * kPyrMaxP) == hipSuccess &&
-                              hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_multi), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   kPyrMaxR * kPyrMaxP) == hipSuccess;
     (void)ldsOk;
     // LDS tile of a level: the source rows / bytes a 256 x 32 tile can draw from at this level ratio (+ alignment slack); a
     // ratio above 2 does not fit kPyrMaxR x kPyrMaxP and takes the kernel's un-staged path
     auto tile_rows = [&](int l) { return std::min(kPyrMaxR, (int)((double)kPyrTH * hc.lv[l - 1].h / hc.lv[l].h) + 4); };
     auto tile_pitch = [&](int l) { return std::min(kPyrMaxP, (((int)((double)kPyrTW * hc.lv[l - 1].w / hc.lv[l].w) + 2 + 15 + 16) / 16) * 16); };
-    // the upper levels in one launch (k_pyr_multi), OPT-IN: IVF_PYR_MULTI=n merges levels n .. nlevels - 1.  Measured (256 planes of
-    // 1242 x 375): levels 4-7 merged 83 us against 75 us for their four launches (5 workgroups per plane; 9 / 18 per plane: 112 / 173 us
-    // -- waiting workgroups hold the slots the working ones need); a single frame with levels 1-7 merged: extraction 0.39 vs 0.40 ms.
-    // Four launches instead of seven, but not faster: the default stays one launch per level.
-    static const int multiEnv = getenv("IVF_PYR_MULTI") ? atoi(getenv("IVF_PYR_MULTI")) : 0;
-    int multiFrom = multiEnv > 0 ? multiEnv : hc.nlevels;
-    if (!bar || multiFrom < 1 || multiFrom >= hc.nlevels - 1) multiFrom = hc.nlevels;      // nothing to merge
-    for (int l = 1; l < std::min(multiFrom, hc.nlevels); l++) {
+    // r04 measured the upper levels merged into ONE launch (k_pyr_multi, a counter barrier among the workgroups of a plane between
+    // levels): levels 4-7 merged 83 us against 75 us for their four launches -- not faster, and its barrier had open defects
+    // (r04 ADVICE): removed in r05; DESIGN.md section 5.r04 keeps the measurement.
+    for (int l = 1; l < hc.nlevels; l++) {
         const LevelGeom& G = hc.lv[l];
         if (G.w <= 0 || G.h <= 0) continue;
         const int rows = tile_rows(l), pitch = tile_pitch(l);
         dim3 grid((G.pitch + kPyrTW - 1) / kPyrTW, (G.h + kPyrTH - 1) / kPyrTH, qblob ? 2 * nImg : nImg);
         hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), (size_t)rows * pitch, s, dc, l, dTab, blob, qblob, useCost, nImg, pitch, rows);
     }
-    if (multiFrom < hc.nlevels) {
-        PyrMulti M{};
-        M.l0 = multiFrom; M.l1 = hc.nlevels - 1; M.planes = qblob ? 2 * nImg : nImg;
-        size_t lds = 0;
-        int tiles0 = 1;
-        for (int l = M.l0; l <= M.l1; l++) {
-            const LevelGeom& G = hc.lv[l];
-            if (G.w <= 0 || G.h <= 0) continue;
-            M.rows[l] = tile_rows(l); M.pitch[l] = tile_pitch(l);
-            lds = std::max(lds, (size_t)M.rows[l] * M.pitch[l]);
-            if (l == M.l0) tiles0 = ((G.pitch + kPyrTW - 1) / kPyrTW) * ((G.h + kPyrTH - 1) / kPyrTH);
-        }
-        // workgroups per plane: all tiles of the first merged level at once for a single frame, a quarter of them for batches
-        static const int wEnv = getenv("IVF_PYR_W") ? atoi(getenv("IVF_PYR_W")) : 0;       // experiments
-        M.W = std::max(1, std::min(wEnv > 0 && nImg > 2 ? wEnv : (nImg <= 2 ? tiles0 : (tiles0 + 3) / 4), 64));
-        const int groups = (M.planes + 7) / 8;                      // planes are dealt over the 8 XCDs
-        hipLaunchKernelGGL(k_pyr_multi, dim3(8 * groups * M.W), dim3(256), lds, s, dc, M, dTab, blob, qblob, useCost, nImg, bar, *epoch, maxPlanes);
-        *epoch += 1;
-    }
 }
 void launch_fast(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s)
 {
     if (hc.nTiles <= 0) return;
-    static const int ablate = getenv("IVF_FAST_ABLATE") ? atoi(getenv("IVF_FAST_ABLATE")) : 0;   // timing experiments only
     hipLaunchKernelGGL(k_fast_nms, dim3((nImg + 7) / 8 * 8 * hc.nTiles), dim3(256), 0, s, dc, b.pyr, b.useCost, b.tileList, b.tileCnt, b.cellCnt,
-                       nImg, ablate);
+                       nImg);
 }
 void launch_blur(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s, bool skipEmptyLevels)
 {

@@ -34,12 +34,32 @@ def test_build_provenance_is_checked_on_load(monkeypatch):
     lib = _lib.load()
     assert lib.ivf_build_id().decode() == _lib.source_build_id() and len(_lib.source_build_id()) == 16
     monkeypatch.setattr(_lib, "_lib", None)
-    monkeypatch.setattr(_lib, "source_build_id", lambda: "0123456789abcdef")
+    monkeypatch.setattr(_lib, "source_build_id", lambda flags="": "0123456789abcdef")
     monkeypatch.delenv("IVFRONT_LIB", raising=False)
     with pytest.raises(ImportError, match="stale"):
         _lib.load()
+    # the id covers the variant flags: the product was built with none
+    assert lib.ivf_build_flags().decode() == ""
     import oracle_lib as O
     assert O.BUILD_ID == O.source_build_id() and O.BUILD_ID != "unstamped"
+
+
+def test_product_library_reads_only_the_documented_environment_switches():
+    """r04 verdict: an environment variable must not be able to change what a drop-in ORBextractor returns.  The kernel-variant selectors
+    and tuning knobs of the experiments (IVF_FCN_*, IVF_PYR_*, IVF_FAST_ABLATE, ...) exist only in the experiment build
+    (make EXPERIMENT=1 -> libivfront_exp.so); the product carries exactly the switches INTEGRATION.md documents, all result-preserving."""
+    import re
+    from iv_slam_amd import _lib
+    blob = open(_lib.LIB_PATH if not os.environ.get("IVFRONT_LIB") else os.path.join(os.path.dirname(_lib.__file__), "libivfront.so"), "rb").read()
+    names = sorted(set(m.decode() for m in re.findall(rb"(?<![A-Za-z0-9_])IVF_[A-Z0-9_]{3,}(?![A-Za-z0-9_])", blob)))
+    allowed = {"IVF_NO_SIDE_BLUR", "IVF_FRAME_WINDOW_CAP", "IVF_FCN_DEBUG"}
+    assert set(names) <= allowed, "undocumented IVF_* strings in the product library: %r" % sorted(set(names) - allowed)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for n in allowed:
+        assert n in doc, "%s is read by the library but not documented in INTEGRATION.md" % n
+    if os.path.exists(_lib.EXPERIMENT_LIB_PATH):
+        exp = open(_lib.EXPERIMENT_LIB_PATH, "rb").read()
+        assert b"IVF_FCN_FUSED4" in exp and b"-DIVF_EXPERIMENT" in exp      # the selectors live there, and the build says what it is
 
 
 def test_struct_layouts_match_header():

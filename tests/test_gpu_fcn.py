@@ -148,7 +148,13 @@ def test_fcn_kernel_variants_match_goldens_and_are_deterministic(env):
     meet the same bar, batch results must not depend on the batch slot, and repeated runs must be bit-identical (this is
     the test that caught two co-resident workgroups of the stride-2 block kernel corrupting each other)."""
     import os, subprocess, sys
+    from iv_slam_amd import _lib
     e = dict(os.environ); e.update(env); e["IVF_REPO"] = FC.ROOT
+    if env:
+        # the selectors exist only in the experiment build (make EXPERIMENT=1; __graft_entry__.build() makes it): the product
+        # library ignores them (tests/test_abi_cpu.py), so a variant that silently ran the defaults would prove nothing
+        assert os.path.exists(_lib.EXPERIMENT_LIB_PATH), "libivfront_exp.so missing: make -C iv_slam_amd/csrc EXPERIMENT=1"
+        e["IVFRONT_LIB"] = _lib.EXPERIMENT_LIB_PATH
     r = subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert float(r.stdout.split("OK")[1]) < 3e-4
