@@ -93,9 +93,9 @@ def make_device_stream(torch, dev, n_pairs, seed, base_pairs=16, rank=0, world=1
     return left, right
 
 
-def track_pairs(world, rank, P):
+def track_pairs(world, rank, P, carry=False):
     from iv_slam_amd import dist as ivd
-    return ivd.track_pairs(world, rank, P)
+    return ivd.track_pairs(world, rank, P, carry=carry)
 
 
 def cpu_baseline(pairs_sample, cores, threads_per_pair=1):
@@ -489,6 +489,8 @@ def main():
     ap.add_argument("--no-track", action="store_true", help="leave the batched tracker step (pack of the result records + SearchByProjection(cur, last) "
                     "for every consecutive frame pair, ivf_tracker_run) out of the timed step.  By default it runs inside it at EVERY rank count, "
                     "so that the 1/2/4/8-GPU lines time the same work per frame (with ranks > 1 it consumes the all-gathered records)")
+    ap.add_argument("--no-carry", action="store_true", help="A/B aid: leave out the frame pair at every batch boundary (the r04 behaviour: world * P - 1 "
+                    "pairs per launch sequence).  Default: the last record of a batch is carried into the next batch's buffer and tracked (r05)")
     ap.add_argument("--serial", action="store_true", help="profiling aid: wait for each batch before enqueuing the next, so "
                     "rocprofv3 kernel durations are not inflated by the overlap of consecutive batches")
     args = ap.parse_args()
@@ -575,25 +577,33 @@ def main():
     # it, so no stream ever waits on a batch-completion event (a stream that does costs 8 % of configs[2]: DESIGN.md
     # section 6) and the batch that reuses the context three steps later simply queues behind the collective.  One block /
     # gather buffer per internal stream.
+    # every record buffer the tracker reads has ONE MORE record behind the world * P gathered ones: the carry record = the last global
+    # frame of the previous batch (iv_slam_amd.dist.BoundaryCarry), so that the pair at the batch boundary is tracked too
     blocks3 = [torch.zeros(P * rec, dtype=torch.uint8, device=dev) for _ in range(3)] if exchange else None
-    gathered3 = [torch.zeros(world * P * rec, dtype=torch.uint8, device=dev) for _ in range(3)] if exchange else None
+    gathered3 = [torch.zeros((world * P + 1) * rec, dtype=torch.uint8, device=dev) for _ in range(3)] if exchange else None
+    NG = world * P * rec                 # bytes of the gathered records proper
     nsub = [0]
     track = exchange or not args.no_track
     tracker = None
+    carry = None
     if track:
         # the exchange step's consumer: Tracking::TrackWithMotionModel's matcher call for every frame this rank extracted against
         # the frame before it, wherever that one was extracted (ivf_tracker_run on the gathered records; zero-motion prior,
         # th = 7, retry with 14 below 20 matches: Tracking.cc:1313-1330)
         sc = iv.ORBextractor(NFEAT, 1.2, 8, INI_TH, MIN_TH, device_id=local_rank).GetScaleFactors()
         cam = dict(fx=FX, fy=FX, cx=W / 2 + 0.5, cy=H / 2 - 0.25)
-        tpairs_h = track_pairs(world, rank, P)
+        use_carry = not args.no_carry
+        tpairs_h = track_pairs(world, rank, P, carry=use_carry)
         # one tracker per internal stream of the front end: a handle owns the scratch of one run at a time
         trackers = [iv.BatchTracker(NFEAT, sc, cam["fx"], cam["fy"], cam["cx"], cam["cy"], BF, (0.0, 0.0, float(W), float(H)),
                                     max_pairs=max(len(tpairs_h), 1), device_id=local_rank) for _ in range(3)]
         tracker = trackers[0]
         tpairs = torch.tensor(tpairs_h, dtype=torch.int32, device=dev).reshape(-1, 2)
         if blocks3 is None:
-            blocks3 = [torch.zeros(P * rec, dtype=torch.uint8, device=dev) for _ in range(3)]
+            blocks3 = [torch.zeros((P + 1) * rec, dtype=torch.uint8, device=dev) for _ in range(3)]
+        from iv_slam_amd import dist as ivd
+        # only rank 0 tracks a pair that reaches into the previous batch (frame k -> rank k mod world)
+        carry = ivd.BoundaryCarry(gathered3 if exchange else blocks3, world, P, rec) if (use_carry and rank == 0) else None
         assign3 = [torch.full((max(len(tpairs_h), 1), NFEAT), -1, dtype=torch.int32, device=dev) for _ in range(3)]
         nm3 = [torch.zeros(max(len(tpairs_h), 1), dtype=torch.int32, device=dev) for _ in range(3)]
 
@@ -608,10 +618,10 @@ def main():
             parts = [torch.empty_like(hb) for _ in range(world)]
             dist.all_gather(parts, hb)
             with torch.cuda.stream(bs):
-                gathered3[k % 3].copy_(torch.cat(parts), non_blocking=False)
+                gathered3[k % 3][:NG].copy_(torch.cat(parts), non_blocking=False)
         else:
             with torch.cuda.stream(bs):
-                dist.all_gather_into_tensor(gathered3[k % 3], blocks3[k % 3])
+                dist.all_gather_into_tensor(gathered3[k % 3][:NG], blocks3[k % 3])
 
     def sub_batch(i):
         s = (i % nslices) * P
@@ -626,8 +636,15 @@ def main():
             if exchange:
                 all_gather_block(bs, k)
             if track and len(tpairs_h):
-                # ... and its consumer, in order behind the collective on the batch's own stream
+                # ... and its consumer, in order behind the collective on the batch's own stream.  The last record of this batch goes
+                # into the carry slot of the NEXT batch's buffer; this batch's tracker waits for the previous batch's hand-over (the
+                # one cross-stream wait of a launch sequence: the boundary pair needs both batches)
+                if carry is not None:
+                    carry.publish(k, bs)
+                    carry.acquire(k, bs)
                 trackers[k % 3].run(gathered3[k % 3] if exchange else blocks3[k % 3], tpairs, assign3[k % 3], nm3[k % 3], stream_ptr=bs.cuda_stream)
+                if carry is not None:
+                    carry.release(k, bs)
         if args.serial:
             fe.sync()
 
@@ -679,8 +696,8 @@ def main():
         # the last collective really delivered every rank's records: own slot == own block, every count plausible
         import numpy as np
         last = (nsub[0] - 1) % 3
-        g = gathered3[last].cpu().numpy().reshape(world, P, rec)
-        own = blocks3[last].cpu().numpy().reshape(P, rec)
+        g = gathered3[last][:NG].cpu().numpy().reshape(world, P, rec)
+        own = blocks3[last][:P * rec].cpu().numpy().reshape(P, rec)
         assert np.array_equal(g[rank], own), "all-gather: own slot differs from the packed block"
         counts = g[:, :, :4].copy().view(np.int32)[:, :, 0]
         assert ((counts > NFEAT // 4) & (counts <= NFEAT)).all(), "all-gather: implausible keypoint counts %r" % counts
@@ -794,14 +811,15 @@ def main():
             import hashlib
             if (W, H) != (1242, 375):
                 return None, None                  # the committed counter passes were collected at 1242x375 only
-            for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+            for name in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
                 try:
                     path = os.path.join(ROOT, "profiles", name)
                     raw = open(path, "rb").read()
                     pmc = json.loads(raw)
                     k = pmc["kernels"][kernel_key]
                     src = "replayed from profiles/%s (sha1 %s%s): separate rocprofv3 --pmc passes, not measured in this run" % (
-                        name, hashlib.sha1(raw).hexdigest()[:12], ", collected at commit %s" % pmc["commit"] if "commit" in pmc else "")
+                        name, hashlib.sha1(raw).hexdigest()[:12], (", collected on build %s" % pmc["build"]["libivfront"]) if pmc.get("build", {}).get("libivfront") else
+                        (", collected at commit %s" % pmc["commit"] if "commit" in pmc else ""))
                     return (k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]) / k.get("images_per_launch", pmc["images_per_launch"]), src
                 except Exception:
                     continue

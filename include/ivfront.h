@@ -244,7 +244,13 @@ int  ivf_frontend_pack_gather_block_of(ivf_frontend* fe, int age, uint8_t* d_blo
                                        void* hip_stream);
 /* hip_stream value for the two functions above: pack on the internal stream the batch itself ran on (in order behind it,
  * no cross-stream wait); ivf_frontend_batch_stream returns that stream (a hipStream_t) so that the consumer of the block
- * -- bench.py's all-gather -- can be enqueued behind the pack. */
+ * -- bench.py's all-gather -- can be enqueued behind the pack.
+ * Ordering consequence (r04): the three internal streams are also LENT -- the 7x7 blur of the batch in context k runs on the internal
+ * stream of context k + 1 (beside its own selection chain; IVF_NO_SIDE_BLUR=1 keeps it at home).  Work a caller puts on
+ * batch_stream of batch n (a collective, the tracker step) therefore sits in front of the blur of batch n + 2 on that stream, and the
+ * descriptors of batch n + 2 wait for that blur: a slow peer in the collective of batch n delays the extraction of batch n + 2 -- not
+ * of batch n + 1.  Keep such work short (bench.py: pack + all-gather + tracker step, ~0.3 ms) or run it on a stream of your own behind
+ * ivf_frontend_pack_gather_block_of(..., your_stream). */
 #define IVF_STREAM_OF_BATCH ((void*)(intptr_t)-1)
 void* ivf_frontend_batch_stream(ivf_frontend* fe, int age);
 
@@ -349,6 +355,14 @@ int  ivf_fcn_forward(ivf_fcn* f, const uint8_t* bgr, int width, int height, int 
  * bytes); d_cost_u8 [n][out_h][out_w] and/or d_cost_f32 [n][out_h][out_w]; asynchronous on hip_stream. */
 int  ivf_fcn_forward_device(ivf_fcn* f, const uint8_t* d_bgr, size_t image_stride, int row_stride, int n,
                             uint8_t* d_cost_u8, float* d_cost_f32, void* hip_stream);
+/* Device-side flags of the handle (r05).  The convolutions run as split-f16 MFMA products (x = hi + lo in f16), exact to 22 bits
+ * while |x| < 65504.  Weights are pre-scaled per output channel and every hidden tensor is bounded by ReLU6 (mobilenet.py:44-62); the
+ * linear-bottleneck outputs are not, so the kernels that store them raise a flag when one reaches 65504 (libtorch's f32 convs,
+ * stereo_kitti.cc:508, have no such limit: the reference would simply go on).  ivf_fcn_forward checks the flag itself and returns
+ * IVF_E_STATE instead of a cost map; after ivf_fcn_forward_device call ivf_fcn_status(f, hip_stream): it waits for the stream, returns
+ * IVF_E_STATE if any forward of this handle since the last check raised the flag, and clears it.  Non-finite weights are refused by
+ * ivf_fcn_create (IVF_E_INVALID). */
+int  ivf_fcn_status(ivf_fcn* f, void* hip_stream);
 
 /* ---- next rows of SURVEY section 8(f) ----
  * ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORB/src/ORBmatcher.cc:410-519):

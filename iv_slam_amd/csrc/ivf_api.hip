@@ -353,10 +353,16 @@ int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size
         IVF_MARK(side, markSide, 1, thisRun);
         launch_blur(hc, dc, b, nImg, side, false);
         IVF_MARK(side, markSide, 2, thisRun);
-        HIPCHK(hipEventRecord(evJoin, side));
-        launch_select(hc, dc, b, nImg, st);
+        // whatever fails from here on, the owning stream joins the side stream's work before this call returns: an un-joined blur
+        // would still be writing b.blur when the context is reused or released
+        const hipError_t eRec = hipEventRecord(evJoin, side);
+        if (eRec == hipSuccess) launch_select(hc, dc, b, nImg, st);
         IVF_MARK(st, markOwn, 4, thisRun);
-        HIPCHK(hipStreamWaitEvent(st, evJoin, 0));
+        const hipError_t eWait = eRec == hipSuccess ? hipStreamWaitEvent(st, evJoin, 0) : eRec;
+        if (eWait != hipSuccess) {
+            (void)hipStreamSynchronize(side);
+            return fail(IVF_E_NO_DEVICE, "joining the side-stream blur failed: %s", hipGetErrorString(eWait));
+        }
         IVF_MARK(st, markOwn, 5, thisRun);
     } else {
         launch_select(hc, dc, b, nImg, st);
@@ -649,6 +655,10 @@ int ivf_extract(ivf_extractor* e, const uint8_t* image, int width, int height, i
     for (int y = 0; y < height; y++) memcpy(hImg + (size_t)y * width, image + (size_t)y * stride, (size_t)width);
     const bool useCost = cost && e->t.p.enable_introspection;
     if (useCost) for (int y = 0; y < height; y++) memcpy(hCost + (size_t)y * width, cost + (size_t)y * cost_stride, (size_t)width);
+    // from the first enqueue on, every way out of this call leaves the handle's stream DRAINED (r04 ADVICE): the next call memcpy's
+    // into hStage and the NULL-stream readers (ivf_stereo_match, the pyramid copies) touch the context's buffers -- work of a call
+    // that failed half-way must not still be in flight then (the stream is non-blocking: the NULL stream does not order it)
+    struct Drain { hipStream_t st; ~Drain() { (void)hipStreamSynchronize(st); } } drain{e->st};
     HIPCHK(hipMemcpyAsync(dImg, hImg, useCost ? 2 * px : px, hipMemcpyHostToDevice, e->st));
     rc = c.run(dImg, dImg, useCost ? dCost : nullptr, px, width, px, width, 1, e->dOne, e->st);
     if (rc) return rc;

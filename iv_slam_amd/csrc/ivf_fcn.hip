@@ -52,6 +52,17 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& hi, uin
     lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]));
 }
 
+// ---- f16 range guard (r05) ----
+// split_pair clamps |x| >= 65,504 to the largest f16, and the lo half with it: a silently wrong product, no flag.  Weights are pre-scaled
+// per output channel and every hidden tensor is bounded by ReLU6; the UN-CLAMPED activations are the linear-bottleneck outputs (BN, no
+// activation, + residual), which the next block's expansion splits.  Every kernel that stores one keeps the largest magnitude it stored
+// and ORs bit 0 into g_fcnRange when that reaches 65,504 (inf included; a NaN can only follow an inf, and the blob is checked for
+// non-finite weights at ivf_fcn_create).  k_fcn_out, the last kernel of every forward, moves the word into the HANDLE's status word;
+// ivf_fcn_forward / ivf_fcn_status report it as IVF_E_STATE -- like the front end's consistency flags.  Cost: one v_max per stored value.
+__device__ int g_fcnRange = 0;
+__device__ __forceinline__ void range_note(float& amax, float v) { amax = fmaxf(amax, fabsf(v)); }
+__device__ __forceinline__ void range_flag(float amax) { if (!(amax < 65504.f)) atomicOr(&g_fcnRange, 1); }
+
 constexpr int kEnc = 512;                      // encoder input size (IF/config: enc_input_size)
 
 // ---- pre-processing + bilinear resize to 512x512 (stereo_kitti.cc:494-506, models_light.py:19-21) ----
@@ -293,11 +304,15 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st].v, bl.v, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st].v, bh.v, acc, 0, 0, 0);
         }
+        float amax = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; r++) {                       // rows (r & 3) + 8 (r >> 2) + 4 hh < 16
             const int ch = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            Y[(((size_t)b * 16 + ch) * O + oy0 + wv) * O + ox0 + col] = __builtin_fmaf(acc[r], sp[ch], bp[ch]);
+            const float v = __builtin_fmaf(acc[r], sp[ch], bp[ch]);
+            range_note(amax, v);
+            Y[(((size_t)b * 16 + ch) * O + oy0 + wv) * O + ox0 + col] = v;
         }
+        range_flag(amax);
     }
 }
 
@@ -474,14 +489,17 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
     }
     if (wv < NTP) {   // C. BN (+ residual), store
         const int n = 32 * wv + col, y = oy0 + n / TW, x = ox0 + n % TW;
+        float amax = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int ch = (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (ch >= COUT) continue;
             float v = __builtin_fmaf(accO[r], sp[ch], bp[ch]);
             if (RES) v += Xb[((size_t)ch * WI + y) * WI + x];
+            range_note(amax, v);
             Y[(((size_t)b * COUT + ch) * WO + y) * WO + x] = v;
         }
+        range_flag(amax);
     }
 }
 
@@ -636,14 +654,17 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb64(const float* __restrict__ 
     }
     if (mtP < MT) {   // C. BN (+ residual), store
         const int m = 32 * ntP + col, y = oy0 + m / TW, x = ox0 + m % TW;
+        float amax = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int ch = 32 * mtP + (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (ch >= COUT) continue;
             float v = __builtin_fmaf(accO[r], sp[ch], bp[ch]);
             if (RES) v += Xb[((size_t)ch * WI + y) * WI + x];
+            range_note(amax, v);
             Y[(((size_t)b * COUT + ch) * WI + y) * WI + x] = v;
         }
+        range_flag(amax);
     }
 }
 
@@ -846,6 +867,7 @@ __global__ __launch_bounds__(256) void k_fcn_gemm(const float* __restrict__ X, c
                 if (act == 1) v = __builtin_amdgcn_fmed3f(v, 0.f, 6.f);
                 else if (act == 2) v = fmaxf(v, 0.f);
                 if (res) v += vget<PT>(rv[r], p);
+                if (act != 1 && !(fabsf(v) < 65504.f)) atomicOr(&g_fcnRange, 1);      // un-clamped output: f16 range guard (never taken in a sane network)
                 o[p] = v;
             }
             float* yo = Y + ob + (size_t)ro * HW;
@@ -1666,6 +1688,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (TILES >= 5 ? IVF_DWPW_OCC :
     // epilogue: per tile, BN scale/shift (float4 per row quad, arrays padded to whole tiles) and the residual are
     // loaded as one batch before the first use
     const int pix = PAIR ? (yPairA + (wave >> 1) * DIL) * Wd + 32 * (wave & 1) + col : 128 * p128 + 32 * wave + col;   // wave = pixel tile
+    float amaxOut = 0.f;
 #pragma unroll
     for (int t = 0; t < TILES; t++) {
         const int cb = (tile0 + t) * 32 + 4 * kg;
@@ -1687,9 +1710,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (TILES >= 5 ? IVF_DWPW_OCC :
             if (cb + ro >= Cout) continue;
             float v = acc[t][q] * vget<4>(sc4[q >> 2], q & 3) + vget<4>(sh4[q >> 2], q & 3);
             if (res) v += rv[q];
+            range_note(amaxOut, v);
             Y[ob + (size_t)ro * HW] = v;
         }
     }
+    range_flag(amaxOut);
 }
 
 // ---- k_fcn_dwpw with eight waves per workgroup (64 x 64 maps, stride 1) ----
@@ -1839,6 +1864,7 @@ __device__ __forceinline__ void dwpw8_body(float (&sD)[2][16 * 132], float* sWp,
         __syncthreads();
     }
     const int pix = 128 * p128 + 32 * pt + col;
+    float amaxOut = 0.f;
 #pragma unroll
     for (int t = 0; t < TILES; t++) {
         const int cb = (T0 * ts + t) * 32 + 4 * kg;
@@ -1852,9 +1878,11 @@ __device__ __forceinline__ void dwpw8_body(float (&sD)[2][16 * 132], float* sWp,
             if (cb + ro >= Cout) continue;
             float v = acc[t][q] * vget<4>(sc4[q >> 2], q & 3) + vget<4>(sh4[q >> 2], q & 3);
             if (res) v += res[ob + (size_t)ro * HW];
+            range_note(amaxOut, v);
             Y[ob + (size_t)ro * HW] = v;
         }
     }
+    range_flag(amaxOut);
 }
 
 template <int DIL, int TT>
@@ -2210,6 +2238,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     size_t ob; int ocs;
     lay_addr(layOut, Cout, b, oy, ox, ob, ocs);
     float* const yp = (SPLIT ? part + (size_t)blockIdx.z * (nwg / 16) * Cout * HW : Y) + ob + (size_t)(tile0 * 32 + 4 * (lane >> 5)) * ocs;
+    float amaxOut = 0.f;
 #pragma unroll
     for (int t = 0; t < 5; t++) {
         float4 sc4[4], sh4[4];
@@ -2221,10 +2250,12 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
             if (!SPLIT) {
                 v = v * vget<4>(sc4[q >> 2], q & 3) + vget<4>(sh4[q >> 2], q & 3);
                 if (RES) v += rvAll[t][q];
+                range_note(amaxOut, v);
             }
             yp[(size_t)(t * 32 + (q & 3) + 8 * (q >> 2)) * ocs] = v;
         }
     }
+    if (!SPLIT) range_flag(amaxOut);            // SPLIT: k_fcn_split_reduce checks the finished sums
 #ifdef IVF_F4_TIMING
     __builtin_amdgcn_sched_barrier(0);
     const unsigned long long tkB = __builtin_amdgcn_s_memtime();
@@ -2474,6 +2505,7 @@ __global__ __launch_bounds__(1024) void k_fcn_irbd4w(const float* __restrict__ X
             if (!SPLIT) {
                 v = v * bn[(q & 3) + 8 * (q >> 2)] + bn[160 + (q & 3) + 8 * (q >> 2)];
                 if (RES) v += rv[t & 1][q];
+                if (!(fabsf(v) < 65504.f)) atomicOr(&g_fcnRange, 1);
             }
             yp[(size_t)(t * 32 + (q & 3) + 8 * (q >> 2)) * ocs] = v;
         }
@@ -2520,6 +2552,7 @@ __global__ __launch_bounds__(256) void k_fcn_split_reduce(const float* __restric
         }
         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
+    range_flag(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
     ((float4*)Y)[i] = o;
 }
 
@@ -2805,6 +2838,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
     size_t ob; int ocs;
     lay_addr(layOut, COUT, b, oy, ox, ob, ocs);
     float* const yp = (SPLIT ? part + (size_t)blockIdx.z * (nwg / 16) * COUT * HW : Y) + ob + (size_t)(4 * (lane >> 5)) * ocs;
+    float amaxOut = 0.f;
 #pragma unroll
     for (int t = 0; t < TILES; t++) {
         const int cb = t * 32 + 4 * (lane >> 5);
@@ -2817,10 +2851,12 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
             if (!SPLIT) {
                 v = v * vget<4>(sc4[q >> 2], q & 3) + vget<4>(sh4[q >> 2], q & 3);
                 if (RES) v += rvAll[t][q];
+                range_note(amaxOut, v);
             }
             yp[(size_t)(t * 32 + (q & 3) + 8 * (q >> 2)) * ocs] = v;
         }
     }
+    if (!SPLIT) range_flag(amaxOut);            // SPLIT: k_fcn_split_reduce checks the finished sums
 }
 
 // ---- conv_last 1x1 80 -> 1 + bias (models_light.py:196) ----
@@ -2836,8 +2872,14 @@ __global__ void k_fcn_last(const float* __restrict__ X, const float* __restrict_
 
 // ---- bilinear to out_size, logistic, u8 truncation (models_light.py:198-199, :25-26; stereo_kitti.cc:511) ----
 __global__ __launch_bounds__(256) void k_fcn_out(const float* __restrict__ L, int lh, int lw, int oh, int ow, float sy_, float sx_,
-                                                float* __restrict__ costF, uint8_t* __restrict__ costU)
+                                                float* __restrict__ costF, uint8_t* __restrict__ costU, int* __restrict__ status)
 {
+    // the last kernel of a forward: every earlier kernel of it has finished (stream order), so one thread moves the f16 range flag
+    // they may have raised into the handle's status word
+    if ((blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) {
+        const int v = atomicExch(&g_fcnRange, 0);
+        if (v) atomicOr(status, v);
+    }
     // a workgroup = 1024 pixels of one output row (4 adjacent pixels per thread): they all read the same two logit rows, which
     // go through LDS once.  sy_ = (float)lh / (float)oh and sx_ come from the host (the same IEEE f32 quotient, computed once
     // instead of by two division sequences per thread); the u8 map leaves as one dword per thread where the row allows it.
@@ -3103,6 +3145,7 @@ struct ivf_fcn {
     Fused4 f1[3];                                                                                                          // blocks 5-7 (k_fcn_irbd2, DIL = 1)
     float *bufIn = nullptr, *bufA = nullptr, *bufB = nullptr, *bufH1 = nullptr, *bufH2 = nullptr, *bufLogits = nullptr;
     float* bufPart = nullptr;             // partial projection sums of the small-batch (SPLIT) launches
+    int* dStatus = nullptr;               // [1] device-side flags of this handle: bit 0 = an un-clamped activation left the f16 range (see g_fcnRange)
     uint8_t *dStageIn = nullptr, *dStageU8 = nullptr; float* dStageF = nullptr;
     void* hPin = nullptr;        // pinned host staging of the per-call path (ivf_fcn_forward)
     std::vector<void*> allocs;
@@ -3550,7 +3593,7 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
         }
     }
     hipLaunchKernelGGL(k_fcn_out, dim3((f->outW + 1023) / 1024, f->outH, n), dim3(256), 0, s, f->bufLogits, H, W, f->outH, f->outW,
-                       (float)H / (float)f->outH, (float)W / (float)f->outW, dF, dU8);
+                       (float)H / (float)f->outH, (float)W / (float)f->outW, dF, dU8, f->dStatus);
     FHIP(hipGetLastError());
     return IVF_OK;
 }
@@ -3574,6 +3617,8 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
     { const int lrc = reserve_lds(); if (lrc) return lrc; }
     ivf_fcn* f = new ivf_fcn();
     f->device = device_id; f->inW = in_width; f->inH = in_height; f->outW = out_width; f->outH = out_height; f->maxBatch = max_batch;
+    for (size_t i = 0; i < n_floats; i++)
+        if (!std::isfinite(weights_blob[i])) return ffail(IVF_E_INVALID, "weight blob holds a non-finite value at float %zu", i);
     Reader rd{weights_blob, n_floats};
     auto bad = [&]() { ivf_fcn_destroy(f); return ffail(IVF_E_INVALID, "weight blob too short for the architecture"); };
     std::vector<float> sc, sh;
@@ -3653,6 +3698,11 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
     if ((rc = dalloc(&f->bufIn, B * 3 * kEnc * kEnc)) || (rc = dalloc(&f->bufA, B * 32 * 256 * 256)) ||
         (rc = dalloc(&f->bufB, B * 32 * 256 * 256)) || (rc = dalloc(&f->bufH1, B * big)) || (rc = dalloc(&f->bufH2, B * big)) ||
         (rc = dalloc(&f->bufLogits, B * 64 * 64)) || (rc = dalloc(&f->bufPart, kPartFloats))) { ivf_fcn_destroy(f); return rc; }
+    if (hipMalloc(&f->dStatus, 4 * sizeof(int)) != hipSuccess || hipMemset(f->dStatus, 0, 4 * sizeof(int)) != hipSuccess) {
+        ivf_fcn_destroy(f);
+        return ffail(IVF_E_NO_DEVICE, "status word allocation failed");
+    }
+    f->allocs.push_back(f->dStatus);
     *out = f;
     return IVF_OK;
 }
@@ -3756,6 +3806,20 @@ int ivf_fcn_forward_device(ivf_fcn* f, const uint8_t* d_bgr, size_t image_stride
     return forward_device(f, d_bgr, image_stride, row_stride, n, d_cost_u8, d_cost_f32, (hipStream_t)hip_stream);
 }
 
+int ivf_fcn_status(ivf_fcn* f, void* hip_stream)
+{
+    if (!f) return ffail(IVF_E_INVALID, "null handle");
+    FHIP(hipSetDevice(f->device));
+    int s = 0;
+    FHIP(hipMemcpyAsync(&s, f->dStatus, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    FHIP(hipStreamSynchronize((hipStream_t)hip_stream));
+    if (!s) return IVF_OK;
+    FHIP(hipMemsetAsync(f->dStatus, 0, sizeof(int), (hipStream_t)hip_stream));
+    FHIP(hipStreamSynchronize((hipStream_t)hip_stream));
+    return ffail(IVF_E_STATE, "ivf_fcn: an un-clamped activation left the f16 range (|x| >= 65504, flags 0x%x) in a forward since the last "
+                              "check: cost maps computed since then are not to be trusted", s);
+}
+
 int ivf_fcn_forward(ivf_fcn* f, const uint8_t* bgr, int width, int height, int stride, uint8_t* cost_u8, int cost_stride,
                     float* cost_f32)
 {
@@ -3769,16 +3833,23 @@ int ivf_fcn_forward(ivf_fcn* f, const uint8_t* bgr, int width, int height, int s
     }
     // The caller's buffers are pageable: hipMemcpy2D from / to them runs row by row (measured 6.5 ms for this 1.4 MB image, against
     // 0.84 ms for the whole forward).  Rows go through a pinned staging buffer of the handle instead: one host memcpy + one DMA.
-    const size_t pinBytes = inBytes + outPx + outPx * sizeof(float);
+    const size_t pinBytes = inBytes + outPx + outPx * sizeof(float) + 16;
     if (!f->hPin) FHIP(hipHostMalloc(&f->hPin, pinBytes, hipHostMallocDefault));
     uint8_t* hIn = (uint8_t*)f->hPin; uint8_t* hU8 = hIn + inBytes; float* hF = (float*)(hU8 + outPx);
+    int* hSt = (int*)((uint8_t*)f->hPin + ((inBytes + outPx + outPx * sizeof(float) + 3) & ~(size_t)3));
     for (int y = 0; y < height; y++) memcpy(hIn + (size_t)y * width * 3, bgr + (size_t)y * stride, (size_t)width * 3);
     FHIP(hipMemcpyAsync(f->dStageIn, hIn, inBytes, hipMemcpyHostToDevice, nullptr));
     int rc = forward_device(f, f->dStageIn, inBytes, width * 3, 1, cost_u8 ? f->dStageU8 : nullptr, cost_f32 ? f->dStageF : nullptr, nullptr);
     if (rc) return rc;
     if (cost_u8) FHIP(hipMemcpyAsync(hU8, f->dStageU8, outPx, hipMemcpyDeviceToHost, nullptr));
     if (cost_f32) FHIP(hipMemcpyAsync(hF, f->dStageF, outPx * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    FHIP(hipMemcpyAsync(hSt, f->dStatus, sizeof(int), hipMemcpyDeviceToHost, nullptr));
     FHIP(hipStreamSynchronize(nullptr));
+    if (*hSt) {                                 // no plausible-looking cost map leaves the call (the output buffers are not written)
+        FHIP(hipMemset(f->dStatus, 0, sizeof(int)));
+        return ffail(IVF_E_STATE, "ivf_fcn_forward: an un-clamped activation left the f16 range (|x| >= 65504, flags 0x%x): the split-f16 "
+                                  "products of the next layer would be wrong; these weights need activations re-scaled", *hSt);
+    }
     if (cost_u8) for (int y = 0; y < f->outH; y++) memcpy(cost_u8 + (size_t)y * cost_stride, hU8 + (size_t)y * f->outW, (size_t)f->outW);
     if (cost_f32) memcpy(cost_f32, hF, outPx * sizeof(float));
     return IVF_OK;

@@ -2008,7 +2008,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const Config* __restrict__
                     float bestuR = cfg->scale[levelL] * ((float)scaleduR0 + (float)bestinc + deltaR);
                     float disparity = (uL - bestuR);
                     if (disparity >= minD && disparity < maxD) {
-                        if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+                        if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); }     // Frame.cc:909: uL-0.01 in double, then narrowed
                         outD = A.bf / disparity; outU = bestuR; outS = bestD;
                     }
                 }

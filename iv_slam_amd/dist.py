@@ -59,10 +59,14 @@ def frames_in_order(gathered, world, pairs_per_rank):
     return order
 
 
-def track_pairs(world, rank, pairs_per_rank):
+def track_pairs(world, rank, pairs_per_rank, carry=False):
     """(last, cur) record indices into the all-gathered buffer [world][pairs_per_rank] for the frames THIS rank extracted: slot
-    (r, j) holds global frame j * world + r, so the frame before (r, j) is (r - 1, j), or (world - 1, j - 1) for r = 0 (rank 0's
-    first frame of a batch has its predecessor in the previous batch: no pair)."""
+    (r, j) holds global frame j * world + r, so the frame before (r, j) is (r - 1, j), or (world - 1, j - 1) for r = 0.
+    Rank 0's first frame of a batch has its predecessor in the PREVIOUS batch.  carry = False: that pair is left out (world * P - 1
+    pairs per batch).  carry = True (r05; Tracking::TrackWithMotionModel runs for EVERY frame, Tracking.cc:1303-1330): the buffer
+    holds one more record at index carry_slot() = world * P -- the last global frame of the previous batch, put there by
+    BoundaryCarry -- and rank 0 tracks (carry, first): world * P pairs per batch over all ranks, every consecutive global pair of
+    the stream exactly once (the very first batch finds an empty carry record: no keypoints, no matches)."""
     P = pairs_per_rank
     out = []
     for j in range(P):
@@ -70,11 +74,73 @@ def track_pairs(world, rank, pairs_per_rank):
             out.append(((rank - 1) * P + j, rank * P + j))
         elif j > 0:
             out.append(((world - 1) * P + j - 1, j))
+        elif carry:
+            out.append((carry_slot(world, P), 0))
     return out
 
 
+def carry_slot(world, pairs_per_rank):
+    """index of the extra record behind the world * P gathered ones: the last global frame of the previous batch"""
+    return world * pairs_per_rank
+
+
+def carry_source_slot(world, pairs_per_rank):
+    """slot of a batch's LAST global frame (rank world - 1, j = P - 1): what the next batch needs as its carry record"""
+    return world * pairs_per_rank - 1
+
+
+class BoundaryCarry:
+    """Hands the last record of batch k to batch k + 1 across the batch contexts' streams (torch plumbing around one
+    device-to-device copy).  Batch k's records live in buffers[k % len(buffers)] = [world * P records | 1 carry record], complete on
+    the stream batch k ran on once its pack / all-gather is enqueued there.
+
+        carry.publish(k, stream_k)        # behind batch k's pack / all-gather, on batch k's stream
+        carry.acquire(k, stream_k)        # in front of batch k's tracker step (waits for batch k - 1's publish)
+        carry.release(k, stream_k)        # behind batch k's tracker step
+
+    publish copies record carry_source_slot of buffer k into the carry slot of buffer k + 1 ON BATCH k's STREAM and records an event;
+    acquire makes batch k + 1's stream wait for it -- the one real cross-stream wait per batch: the boundary pair needs both batches.
+    The carry slot it writes was last read by the tracker step of batch k + 1 - len(buffers), whose release event is long complete in
+    steady state: publish queries it on the host and inserts a wait only if it is not (formally safe, free in practice)."""
+
+    def __init__(self, buffers, world, pairs_per_rank, record_bytes):
+        import torch
+        self.torch = torch
+        self.buffers = buffers
+        self.n = len(buffers)
+        self.rec = record_bytes
+        self.src = carry_source_slot(world, pairs_per_rank) * record_bytes
+        self.dst = carry_slot(world, pairs_per_rank) * record_bytes
+        for b in buffers:
+            assert b.numel() >= self.dst + record_bytes, "record buffers need one carry record behind the world * P gathered ones"
+        self.published = [torch.cuda.Event() for _ in range(self.n)]      # [k % n]: carry slot of buffer k written (by batch k - 1)
+        self.released = [torch.cuda.Event() for _ in range(self.n)]       # [k % n]: tracker step of batch k has read buffer k
+        self.have_published = [False] * self.n
+        self.have_released = [False] * self.n
+
+    def publish(self, k, stream):
+        nxt = (k + 1) % self.n
+        if self.have_released[nxt] and not self.released[nxt].query():
+            stream.wait_event(self.released[nxt])
+        with self.torch.cuda.stream(stream):
+            self.buffers[nxt][self.dst:self.dst + self.rec].copy_(self.buffers[k % self.n][self.src:self.src + self.rec], non_blocking=True)
+        self.published[nxt].record(stream)
+        self.have_published[nxt] = True
+
+    def acquire(self, k, stream):
+        if self.have_published[k % self.n]:
+            stream.wait_event(self.published[k % self.n])
+
+    def release(self, k, stream):
+        self.released[k % self.n].record(stream)
+        self.have_released[k % self.n] = True
+
+
 def slot_frame(slot, world, pairs_per_rank):
-    """global frame index (within one batch) held by slot index `slot` = r * pairs_per_rank + j of the gathered buffer."""
+    """global frame index (within one batch) held by slot index `slot` = r * pairs_per_rank + j of the gathered buffer; the carry
+    slot holds frame -1 = the last frame of the previous batch."""
+    if slot == carry_slot(world, pairs_per_rank):
+        return -1
     r, j = divmod(slot, pairs_per_rank)
     return j * world + r
 
@@ -129,14 +195,20 @@ def bind_rank_to_numa(local_rank, sysfs="/sys", apply=True):
     and its pinned staging buffers then sit next to the device).  Call it in a FRESH rank process before anything initialises
     the GPU.  Best effort: returns a dict saying what was done or why nothing was."""
     import os
-    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
     gpus = gpu_numa_nodes(sysfs)
+    # the two lists COMPOSE (r04 ADVICE): ROCR_VISIBLE_DEVICES filters / reorders what the ROCr runtime exposes (indices into the
+    # KFD order), HIP_VISIBLE_DEVICES (or CUDA_VISIBLE_DEVICES) then indexes into what ROCr left.  Only integer lists are mapped
+    # (UUID entries: give up, unbound).  Assumption that remains: KFD topology order = ROCr enumeration order, which holds on the
+    # driver's boxes; bench.py reports the PCI address it bound to, so a mismatch with hipDeviceGetPCIBusId is visible in the line.
     idx = local_rank
-    if vis:
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):            # innermost mapping first
+        vis = os.environ.get(var) if var != "HIP_VISIBLE_DEVICES" else (os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES"))
+        if not vis:
+            continue
         try:
-            idx = [int(v) for v in vis.split(",")][local_rank]
+            idx = [int(v) for v in vis.split(",")][idx]
         except (ValueError, IndexError):
-            return {"bound": False, "why": "cannot map local rank %d through the visible-device list %r" % (local_rank, vis)}
+            return {"bound": False, "why": "cannot map local rank %d through %s=%r" % (local_rank, var, vis)}
     if not (0 <= idx < len(gpus)):
         return {"bound": False, "why": "no KFD topology entry for device %d (%d GPU nodes found)" % (idx, len(gpus))}
     bdf, numa = gpus[idx]

@@ -46,6 +46,11 @@ class IntrospectionFCN:
                                                None if cost_u8 is None else cost_u8.data_ptr(),
                                                None if cost_f32 is None else cost_f32.data_ptr(), stream_ptr))
 
+    def status(self, stream_ptr=None):
+        """waits for the stream and raises IvfError(IVF_E_STATE) if a forward of this handle since the last check drove an un-clamped
+        activation out of the f16 range (|x| >= 65504: the split-f16 products of the next layer would be wrong); clears the flag."""
+        check(self._lib.ivf_fcn_status(self._h, stream_ptr))
+
     # --- measurement aid (bench.py): HIP events around the 960 -> 160 fused depthwise+projection launch
     def probe_enable(self):
         check(self._lib.ivf_fcn_probe_enable(self._h))

@@ -98,6 +98,7 @@ def forward(W, bgr_u8, out_size, enc_size=(512, 512), return_taps=False):
             y = relu6(bn(conv2d(y, W[p + ".3.weight"], s, d, d, groups=inp * t), W, p + ".4"))
             y = bn(conv2d(y, W[p + ".6.weight"]), W, p + ".7")
         x = (x + y).astype(np.float32) if res else y
+        taps.setdefault("block_absmax", {})[i] = float(np.abs(x).max())     # the un-clamped activations (linear bottleneck + residual)
         if i in (7, 17):
             taps["f%d" % i] = x
     y = np.maximum(bn(conv2d(x, W["decoder.cbr.0.weight"], 1, 1), W, "decoder.cbr.1"), F(0))

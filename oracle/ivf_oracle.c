@@ -973,7 +973,7 @@ int orc_stereo_match(const orc_extractor* eL, const orc_extractor* eR,
             float bestuR = eL->scale[levelL] * ((float)scaleduR0 + (float)bestincR + deltaR);
             float disparity = (uL - bestuR);
             if (disparity >= minD && disparity < maxD) {
-                if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+                if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01);      /* Frame.cc:909 computes uL-0.01 in double and narrows */ }
                 depth[iL] = bf / disparity;
                 u_right[iL] = bestuR;
                 vDistIdx[nDist].dist = bestD; vDistIdx[nDist].idx = iL; nDist++;

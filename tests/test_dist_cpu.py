@@ -89,6 +89,37 @@ def test_track_pairs_cover_every_consecutive_global_pair_exactly_once(world, P):
         assert ivd.slot_frame(r * P + j, world, P) == g
 
 
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+@pytest.mark.parametrize("P", [1, 2, 16, 128])
+def test_track_pairs_with_carry_cover_every_pair_of_the_stream_across_batches(world, P):
+    """r05 (Tracking::TrackWithMotionModel runs for EVERY frame, Tracking.cc:1303-1330): with the carry record -- the last global
+    frame of the previous batch in the slot behind the gathered ones -- every consecutive pair (g - 1, g) of the whole STREAM is
+    produced exactly once over three consecutive batches, on the rank that extracted frame g; world * P pairs per batch over all
+    ranks; the carry's source is the slot of a batch's last global frame."""
+    from iv_slam_amd import dist as ivd
+    B = world * P
+    assert ivd.slot_frame(ivd.carry_source_slot(world, P), world, P) == B - 1
+    assert ivd.slot_frame(ivd.carry_slot(world, P), world, P) == -1
+    seen = {}
+    for batch in range(3):
+        per_batch = 0
+        for rank in range(world):
+            for last, cur in ivd.track_pairs(world, rank, P, carry=True):
+                assert 0 <= last <= B and 0 <= cur < B          # `last` may be the carry slot, `cur` never
+                assert cur // P == rank
+                g_last = batch * B + ivd.slot_frame(last, world, P); g_cur = batch * B + ivd.slot_frame(cur, world, P)
+                assert g_cur == g_last + 1, (world, P, rank, last, cur)
+                assert g_cur not in seen
+                seen[g_cur] = rank
+                assert rank == g_cur % world
+                per_batch += 1
+        assert per_batch == B
+    # frame 0's pair is (frame -1, frame 0): the first batch's carry record is empty (no keypoints, no matches)
+    assert sorted(seen) == list(range(0, 3 * B))
+    # and without the carry nothing changes for existing callers
+    assert ivd.track_pairs(world, 0, P) == [p for p in ivd.track_pairs(world, 0, P, carry=True) if p[0] != ivd.carry_slot(world, P)]
+
+
 def test_rank_to_numa_binding_from_sysfs(tmp_path, monkeypatch):
     """bind_rank_to_numa reads the KFD topology + PCI + node cpulists from sysfs only (no HIP call): a fake 2-socket tree with four
     GPUs, two per socket; visible-device remapping; a device without a NUMA node; nothing applied to this process (apply=False)."""
@@ -108,6 +139,7 @@ def test_rank_to_numa_binding_from_sysfs(tmp_path, monkeypatch):
         nd = sysfs / "devices" / "system" / "node" / ("node%d" % n); nd.mkdir(parents=True)
         (nd / "cpulist").write_text(cl + "\n")
     monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False); monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
     assert ivd.gpu_numa_nodes(str(sysfs)) == [("0000:05:00.0", 0), ("0000:26:00.0", 0), ("0000:85:00.0", 1), ("0000:a6:00.0", -1)]
     r = ivd.bind_rank_to_numa(0, str(sysfs), apply=False)
     assert r == {"bound": True, "device": 0, "pci": "0000:05:00.0", "numa_node": 0, "cpus": 8}
@@ -116,6 +148,14 @@ def test_rank_to_numa_binding_from_sysfs(tmp_path, monkeypatch):
     assert ivd.bind_rank_to_numa(7, str(sysfs), apply=False)["bound"] is False
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0")
     assert ivd.bind_rank_to_numa(0, str(sysfs), apply=False)["pci"] == "0000:85:00.0"
+    # the two lists compose: ROCr exposes KFD devices (3, 2, 0) as 0, 1, 2; HIP then takes (2, 0) of THOSE -> rank 0 = KFD 0, rank 1 = KFD 3
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "3,2,0")
+    assert ivd.bind_rank_to_numa(0, str(sysfs), apply=False)["pci"] == "0000:05:00.0"
+    assert ivd.bind_rank_to_numa(1, str(sysfs), apply=False)["pci"] == "0000:a6:00.0"
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    assert ivd.bind_rank_to_numa(1, str(sysfs), apply=False)["pci"] == "0000:85:00.0"      # ROCr list alone
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "GPU-deadbeef")
+    assert ivd.bind_rank_to_numa(0, str(sysfs), apply=False)["bound"] is False             # UUID entries: not mapped, unbound
     assert ivd.parse_cpulist("0-2,8,10-11") == {0, 1, 2, 8, 10, 11} and ivd.parse_cpulist("") == set()
 
 

@@ -37,8 +37,12 @@ def test_exchange_step_single_rank():
     assert j["value"] > 0
     # the exchange has a consumer: the batched tracker ran on the gathered records inside the timed region and equals the oracle
     assert j["exchange"]["consumed"] is True and j["track"]["parity_ok"] is True and j["track"]["in_timed_region"] is True
-    assert j["track"]["frame_pairs_per_launch_sequence"] == 15 and j["track"]["mean_matches"] > 50
+    # r05: 16 pairs per launch sequence of 16 frames -- the pair at the batch boundary comes through the carry record
+    assert j["track"]["frame_pairs_per_launch_sequence"] == 16 and j["track"]["mean_matches"] > 50
     assert j["parity_spot_check"]["ok"] is True
+    # the r04 behaviour stays selectable for A/B runs
+    j = _run("--pairs", "16", "--stream", "32", "--no-introspect", "--no-carry")
+    assert j["track"]["frame_pairs_per_launch_sequence"] == 15 and j["track"]["parity_ok"] is True
 
 
 def test_tracker_step_is_timed_at_every_rank_count():
@@ -64,7 +68,7 @@ def test_other_baseline_configs_have_bench_lines(cfg, pairs, w, h, n):
         assert c["fast_thresholds"] == [12, 7]
 
 
-@pytest.mark.parametrize("ranks", [2, 4])
+@pytest.mark.parametrize("ranks", [2, 4, 8])
 def test_ranks_on_one_gpu_through_gloo(ranks):
     """The N > 1 path executes on a 1-GPU box: `bench.py --gpus N` spawns N ranks that share device 0 (IVF_BENCH_BACKEND=gloo,
     a test aid: blocks cross the host), all-gathers the record blocks, runs the tracker on frames extracted by ANOTHER rank (rank 0
@@ -83,8 +87,9 @@ def test_ranks_on_one_gpu_through_gloo(ranks):
     assert ex["world"] == ranks and ex["world_size_seen_by_backend"] == ranks and ex["backend"] == "gloo"
     assert ex["records_checked"] == 16 * ranks and ex["consumed"] is True
     assert ex["enqueued_on_stream"] == ex["batch_stream_of_that_run"]          # the collective sits on the batch's own stream, behind the pack
-    # rank 0 tracked its frames j >= 1 against the LAST rank's frames j - 1 (15 pairs); consecutive GLOBAL frames re-match
-    assert j["track"]["parity_ok"] is True and j["track"]["frame_pairs_per_launch_sequence"] == 15 and j["track"]["mean_matches"] > 50
+    # rank 0 tracked its frames j >= 1 against the LAST rank's frames j - 1 and its frame 0 against the last rank's LAST frame of the
+    # previous batch (the carry record): 16 pairs; consecutive GLOBAL frames re-match
+    assert j["track"]["parity_ok"] is True and j["track"]["frame_pairs_per_launch_sequence"] == 16 and j["track"]["mean_matches"] > 50
     assert j["parity_spot_check"]["ok"] is True
 
 

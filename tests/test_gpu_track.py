@@ -157,6 +157,57 @@ def test_zero_motion_kitti_shape_from_a_frontend_batch(iv):
     check_pairs(cam, recs, pairs, assign.cpu().numpy(), nmm.cpu().numpy(), what="device block")
 
 
+def test_boundary_pair_between_two_batches_through_the_carry_record(iv):
+    """r05: the pair (last frame of batch k, first frame of batch k + 1) is tracked too (Tracking.cc:1303-1330 runs for every frame).
+    Three batches of 4 consecutive frames through ONE front end (three batch contexts, three internal streams): each batch is packed on
+    its own stream into [4 records | carry record], BoundaryCarry hands the last record over to the next batch's buffer, the tracker
+    step of batch k runs track_pairs(1, 0, 4, carry=True) on batch k's stream.  Every pair -- the boundary pairs first -- equals the
+    oracle on the same records; the first batch's carry record is empty (0 matches)."""
+    import torch
+    from iv_slam_amd import dist as ivd
+    from iv_slam_amd.frontend import unpack_gather_records
+    w, h, n, P, NB = 640, 240, 500, 4, 3
+    L, R = synth.make_pair(w, h, seed=95, idx=0)
+    lefts = np.stack([np.roll(L, 3 * k, axis=1) for k in range(P * NB)]); rights = np.stack([np.roll(R, 3 * k, axis=1) for k in range(P * NB)])
+    dev = torch.device("cuda:0")
+    bf, fx = 386.1448, 718.856
+    fe = iv.StereoFrontend(w, h, P, nfeatures=n, bf=bf, fx=fx)
+    rec = fe.gather_record_bytes()
+    cam = dict(nf=n, scale=scale_table(), fx=F(fx), fy=F(fx), cx=F(w / 2 + 0.5), cy=F(h / 2 - 0.25), bf=F(bf), b=F(F(bf) / F(fx)),
+               bounds=(0.0, 0.0, float(w), float(h)))
+    bufs = [torch.zeros((P + 1) * rec, dtype=torch.uint8, device=dev) for _ in range(3)]
+    carry = ivd.BoundaryCarry(bufs, 1, P, rec)
+    pairs = ivd.track_pairs(1, 0, P, carry=True)
+    assert len(pairs) == P and pairs[0] == (P, 0)
+    dp = torch.tensor(pairs, dtype=torch.int32, device=dev)
+    trackers = [iv.BatchTracker(n, cam["scale"], float(fx), float(fx), float(cam["cx"]), float(cam["cy"]), float(bf), cam["bounds"], max_pairs=P,
+                                b=float(cam["b"])) for _ in range(3)]
+    assign = [torch.full((P, n), -7, dtype=torch.int32, device=dev) for _ in range(NB)]
+    nm = [torch.full((P,), -7, dtype=torch.int32, device=dev) for _ in range(NB)]
+    dl = torch.from_numpy(lefts).to(dev); dr = torch.from_numpy(rights).to(dev)
+    for k in range(NB):                                            # enqueued back to back, nothing waits on the host
+        fe.run(dl[k * P:(k + 1) * P], dr[k * P:(k + 1) * P])
+        bs = torch.cuda.ExternalStream(fe.batch_stream(0), device=dev)
+        fe.pack_gather_block(bufs[k % 3], fe.STREAM_OF_BATCH)
+        carry.publish(k, bs)
+        carry.acquire(k, bs)
+        trackers[k % 3].run(bufs[k % 3], dp, assign[k], nm[k], stream_ptr=bs.cuda_stream)
+        carry.release(k, bs)
+    fe.sync(); torch.cuda.synchronize()
+    recs_b = [unpack_gather_records(bufs[k % 3].cpu().numpy(), n) for k in range(NB)]
+    for k in range(NB):
+        recs = recs_b[k]
+        if k == 0:
+            assert recs[P]["n"] == 0 and int(nm[0][0]) == 0 and (assign[0][0].cpu().numpy() == -1).all()     # nothing before the first frame
+        else:
+            assert recs[P]["n"] > 100 and recs[P]["kps"].tobytes() == recs_b[k - 1][P - 1]["kps"].tobytes()  # the carry IS the previous batch's last record
+            assert recs[P]["desc"].tobytes() == recs_b[k - 1][P - 1]["desc"].tobytes() and recs[P]["depth"].tobytes() == recs_b[k - 1][P - 1]["depth"].tobytes()
+        tot = check_pairs(cam, recs, pairs, assign[k].cpu().numpy(), nm[k].cpu().numpy(), what="batch %d" % k)
+        assert tot > 100 * (P - 1 if k == 0 else P)
+        if k > 0:
+            assert int(nm[k][0]) > 100                             # the boundary pair really re-matches the shifted scene
+
+
 def test_poses_forward_backward_and_flags(iv):
     """supplied poses: forward motion (levels [o, inf)), backward motion ([0, o]), small motion (+-1), rotations; explicit point flags."""
     cam, recs, _, _ = extracted_sequence(iv, 640, 240, 500, 5, seed=92, shift=2)

@@ -36,7 +36,20 @@ def main():
         commit = subprocess.check_output(["git", "-C", os.path.dirname(os.path.abspath(__file__)), "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
     except Exception:
         commit = os.environ.get("IVF_COMMIT", "unknown")          # the GPU box has no .git: tools/pmc_traffic.sh passes IVF_COMMIT
-    out = {"command": sys.argv[5], "images_per_launch": n_img, "commit": commit,
+    # the build the counters were collected on: ivf_build_id() hashes the sources + flags, and the same hash recomputed from the tree --
+    # always available, also on the GPU box (which has no .git) -- so the counter file is tied to a build like every bench line is
+    build = {}
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from iv_slam_amd import _lib
+        build = {"sources": _lib.source_build_id("")}
+        import ctypes
+        so = ctypes.CDLL(_lib.LIB_PATH)
+        so.ivf_build_id.restype = ctypes.c_char_p; so.ivf_build_flags.restype = ctypes.c_char_p
+        build["libivfront"] = so.ivf_build_id().decode(); build["flags"] = so.ivf_build_flags().decode()
+    except Exception as e:
+        build["error"] = str(e)
+    out = {"command": sys.argv[5], "images_per_launch": n_img, "commit": commit, "build": build,
            "note": "raw counter x 1024 bytes per launch; fetch_correction = 2.0: gfx950 FETCH_SIZE reports half of the bytes of a streaming read "
                    "(MI355X_MICROARCH.md HBM section; calibrated here for 4 / 8 / 16 B per lane by tools/probe/fetch_calib.hip: 512 MiB "
                    "reported for a 1 GiB read at every width); copies / fills of the runtime are left uncorrected",
