@@ -2031,6 +2031,34 @@ int ivf_test_retain_best(const float* responses, int n, int n_points, int32_t* o
 }
 
 // ---- batched stereo front end ----
+// The kPipe internal streams of a device: created on first use, shared by every ivf_frontend on that device, never destroyed (no HIP
+// call during static destruction).  The tail kernels of a batch are small and latency-bound: on high-priority streams they slot in
+// beside whatever large kernels the caller's stream is running (the FCN of the next batch) instead of queueing behind them.
+static int internal_streams(int device, hipStream_t (&out)[kPipe])
+{
+    struct Set { hipStream_t s[kPipe]; };
+    static std::mutex* m = new std::mutex();
+    static std::map<int, Set>* sets = new std::map<int, Set>();
+    std::lock_guard<std::mutex> g(*m);
+    auto it = sets->find(device);
+    if (it == sets->end()) {
+        HIPCHK(hipSetDevice(device));
+        int prLo = 0, prHi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prLo, &prHi);
+        static const bool noPrio = IVF_EXP_ENV("IVF_NO_STREAM_PRIORITY") != nullptr;
+        Set st{};
+        for (int k = 0; k < kPipe; k++)
+            if ((noPrio ? hipStreamCreateWithFlags(&st.s[k], hipStreamNonBlocking)
+                        : hipStreamCreateWithPriority(&st.s[k], hipStreamNonBlocking, prHi)) != hipSuccess) {
+                for (int j = 0; j < k; j++) (void)hipStreamDestroy(st.s[j]);
+                return fail(IVF_E_NO_DEVICE, "stream creation failed");
+            }
+        it = sets->emplace(device, st).first;
+    }
+    for (int k = 0; k < kPipe; k++) out[k] = it->second.s[k];
+    return IVF_OK;
+}
+
 int ivf_frontend_create(const ivf_frontend_config* cfg, ivf_frontend** out)
 {
     if (!cfg || !out) return fail(IVF_E_INVALID, "null argument");
@@ -2055,18 +2083,21 @@ int ivf_frontend_create(const ivf_frontend_config* cfg, ivf_frontend** out)
         rc = fe->ctx[k].build(t, cfg->width, cfg->height, 2 * cfg->max_pairs, 2, cfg->device_id, true);
         if (rc) return cleanup(rc);
         fe->ctx[k].markOwn = k; fe->ctx[k].markSide = 3 + (k + 1) % kPipe;
-        // the front end's tail kernels are small and latency-bound: on high-priority streams they slot in beside whatever
-        // large kernels the caller's stream is running (the FCN of the next batch) instead of queueing behind them
-        int prLo = 0, prHi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prLo, &prHi);
-        static const bool noPrio = IVF_EXP_ENV("IVF_NO_STREAM_PRIORITY") != nullptr;
+        // r05: the kPipe internal streams come from a process-wide pool per device (internal_streams above) and are SHARED by every
+        // front end on that device.  Streams are a scarce resource on this runtime -- it multiplexes them onto a few hardware queues
+        // (three more streams cost configs[2] 15 % just by existing) -- so a second front end in the process
+        // (bench.py's configs[1] leg beside the configs[2] one; Tracking's left / right / initialisation extractors) must not add any,
+        // and a create-run-destroy loop no longer creates and destroys streams at all.  Two front ends that share streams serialise
+        // against each other on them, which is what they would do on the GPU anyway.
+        hipStream_t pool[kPipe];
+        rc = internal_streams(cfg->device_id, pool);
+        if (rc) return cleanup(rc);
+        fe->stream[k] = pool[k];
         const unsigned evFlags = hipEventDisableTiming;
-        if ((noPrio ? hipStreamCreateWithFlags(&fe->stream[k], hipStreamNonBlocking)
-                    : hipStreamCreateWithPriority(&fe->stream[k], hipStreamNonBlocking, prHi)) != hipSuccess ||
-            hipEventCreateWithFlags(&fe->evIn[k], evFlags) != hipSuccess ||
+        if (hipEventCreateWithFlags(&fe->evIn[k], evFlags) != hipSuccess ||
             hipEventCreateWithFlags(&fe->evConsumed[k], evFlags) != hipSuccess ||
             hipEventCreateWithFlags(&fe->evDone[k], evFlags) != hipSuccess)
-            return cleanup(fail(IVF_E_NO_DEVICE, "stream/event creation failed"));
+            return cleanup(fail(IVF_E_NO_DEVICE, "event creation failed"));
     }
     std::vector<uint8_t> flags(2 * (size_t)cfg->max_pairs);
     // bit 0: the cost pyramid gates this image's extraction; bit 1: mvKeyQualScore of the LEFT keypoints reads the cost image
@@ -2087,7 +2118,7 @@ void ivf_frontend_destroy(ivf_frontend* fe)
     if (fe->dFlags) (void)hipFree(fe->dFlags);
     for (int k = 0; k < kPipe; k++) {
         fe->ctx[k].release();
-        if (fe->stream[k]) (void)hipStreamDestroy(fe->stream[k]);
+        // fe->stream[k] belongs to the process-wide pool: never destroyed
         if (fe->evIn[k]) (void)hipEventDestroy(fe->evIn[k]);
         if (fe->evConsumed[k]) (void)hipEventDestroy(fe->evConsumed[k]);
         if (fe->evDone[k]) (void)hipEventDestroy(fe->evDone[k]);

@@ -67,9 +67,20 @@ constexpr int kEnc = 512;                      // encoder input size (IF/config:
 
 // ---- pre-processing + bilinear resize to 512x512 (stereo_kitti.cc:494-506, models_light.py:19-21) ----
 __global__ void k_fcn_prep(const uint8_t* __restrict__ bgr, size_t imageStride, int rowStride, int w, int h,
-                           float* __restrict__ out)
+                           float* __restrict__ out, int nImg, int xcdMajor)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    // r05: XCD-aware block -> (image, row, half row).  Two output rows share an input row (375 -> 512 rows reads every input row ~2.7
+    // times), and consecutive block ids go to different XCDs: with the plain (x, y, image) grid every XCD's L2 pulled its own copy of
+    // the rows from HBM (FETCH_SIZE 2.9x the input, r04).  Batches of >= 8 images: XCD k takes images k, k + 8, ... whole, so an image's
+    // rows meet in ONE L2.  Smaller batches keep the plain order (one image on one XCD would leave seven idle).
+    int x, y, b;
+    if (xcdMajor) {
+        const int L = blockIdx.x, j = L >> 3;                           // 1-D grid of 8 * ceil(n / 8) * 2 * kEnc blocks
+        b = (L & 7) + 8 * (j / (2 * kEnc));
+        if (b >= nImg) return;
+        const int r = j % (2 * kEnc);
+        y = r >> 1; x = (r & 1) * 256 + threadIdx.x;
+    } else { x = blockIdx.x * blockDim.x + threadIdx.x; y = blockIdx.y; b = blockIdx.z; }
     if (x >= kEnc) return;
     const float sy_ = (float)h / (float)kEnc, sx_ = (float)w / (float)kEnc;
     float fy = sy_ * ((float)y + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
@@ -330,6 +341,16 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
 // Weights: the expansion's and the projection's A operands come as the f16 hi / lo fragments k_fcn_gemm uses (one
 // 16-byte load per lane and fragment, L2-resident; the projection's are fetched at the top of a group and used after two
 // barriers, the expansion's one group ahead); depthwise taps and all BN scale / shift pairs sit in an LDS table.
+// output rows per tile of blocks 2 / 3 / 4 (compile-time: tools/build_variant.sh measures others)
+#ifndef IVF_IRB_TH2
+#define IVF_IRB_TH2 2
+#endif
+#ifndef IVF_IRB_TH3
+#define IVF_IRB_TH3 4
+#endif
+#ifndef IVF_IRB_TH4
+#define IVF_IRB_TH4 1
+#endif
 template <int S, int CIN, int HID, int COUT, bool RES, int WI, int TH>
 __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X, const uint4* __restrict__ WqE,
                                                 const float* __restrict__ se, const float* __restrict__ be,
@@ -3339,7 +3360,10 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
 {
     static const bool dbg = getenv("IVF_FCN_DEBUG") != nullptr;
     char nm[64];
-    hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc, n), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn);
+    if (n >= 8)
+        hipLaunchKernelGGL(k_fcn_prep, dim3(8 * ((n + 7) / 8) * 2 * kEnc), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn, n, 1);
+    else
+        hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc, n), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn, n, 0);
     STAGE("prep");
     // whole-block kernels, bit i = block i + 2: blocks 2-4 (k_fcn_irb) by default; bits 3-9 = blocks 5-11 through k_fcn_irb64, which
     // is correct but measures slower than expand + dwpw there (337 vs 245 us for the 64->384->64 blocks): opt-in.  Off under the
@@ -3412,9 +3436,9 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
 #define IRB(S_, CIN_, HID_, COUT_, RES_, WI_, TH_)                                                                          \
             hipLaunchKernelGGL((k_fcn_irb<S_, CIN_, HID_, COUT_, RES_, WI_, TH_>), dim3(WI_ / S_ / 32, WI_ / S_ / TH_, n), dim3(512), 0, s, x, \
                                ex.dWq, ex.dScale, ex.dShift, d.dW, d.dScale, d.dShift, pj.dWq, pj.dScale, pj.dShift, y)
-            if (i == 1) IRB(2, 16, 96, 24, false, 256, 2);
-            else if (i == 2) IRB(1, 24, 144, 24, true, 128, 4);
-            else IRB(2, 24, 144, 32, false, 128, 1);
+            if (i == 1) IRB(2, 16, 96, 24, false, 256, IVF_IRB_TH2);
+            else if (i == 2) IRB(1, 24, 144, 24, true, 128, IVF_IRB_TH3);
+            else IRB(2, 24, 144, 32, false, 128, IVF_IRB_TH4);
 #undef IRB
             ip += 2; id++;
             H = (H - 1) / d.stride + 1; W = (W - 1) / d.stride + 1;
