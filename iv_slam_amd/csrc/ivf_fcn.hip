@@ -67,20 +67,12 @@ constexpr int kEnc = 512;                      // encoder input size (IF/config:
 
 // ---- pre-processing + bilinear resize to 512x512 (stereo_kitti.cc:494-506, models_light.py:19-21) ----
 __global__ void k_fcn_prep(const uint8_t* __restrict__ bgr, size_t imageStride, int rowStride, int w, int h,
-                           float* __restrict__ out, int nImg, int xcdMajor)
+                           float* __restrict__ out)
 {
-    // r05: XCD-aware block -> (image, row, half row).  Two output rows share an input row (375 -> 512 rows reads every input row ~2.7
-    // times), and consecutive block ids go to different XCDs: with the plain (x, y, image) grid every XCD's L2 pulled its own copy of
-    // the rows from HBM (FETCH_SIZE 2.9x the input, r04).  Batches of >= 8 images: XCD k takes images k, k + 8, ... whole, so an image's
-    // rows meet in ONE L2.  Smaller batches keep the plain order (one image on one XCD would leave seven idle).
-    int x, y, b;
-    if (xcdMajor) {
-        const int L = blockIdx.x, j = L >> 3;                           // 1-D grid of 8 * ceil(n / 8) * 2 * kEnc blocks
-        b = (L & 7) + 8 * (j / (2 * kEnc));
-        if (b >= nImg) return;
-        const int r = j % (2 * kEnc);
-        y = r >> 1; x = (r & 1) * 256 + threadIdx.x;
-    } else { x = blockIdx.x * blockDim.x + threadIdx.x; y = blockIdx.y; b = blockIdx.z; }
+    // (r05: an XCD-aware block order -- XCD k takes images k, k + 8, ... whole, so that the two output rows that share an input row
+    // meet in one L2 -- brings FETCH_SIZE down from 2.9x the input but not the time: 187 vs 180 us per 128 images; not kept.  The kernel
+    // is bound by its 403 MB of f32 stores and its VALU work, not by the u8 fetches.)
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
     if (x >= kEnc) return;
     const float sy_ = (float)h / (float)kEnc, sx_ = (float)w / (float)kEnc;
     float fy = sy_ * ((float)y + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
@@ -349,8 +341,9 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
 #define IVF_IRB_TH3 4
 #endif
 #ifndef IVF_IRB_TH4
-#define IVF_IRB_TH4 1
-#endif
+#define IVF_IRB_TH4 4         // r05, measured per 128 images: block 4 at 1 / 2 / 4 rows 387 / 404 / 327 us; block 3 at 2 / 4 / 8 rows 708 / 468 / 569;
+#endif                        // block 2 at 2 / 4 rows 610 / 730 (profiles/r05_irb_tile_heights.txt): 2, 4, 4
+
 template <int S, int CIN, int HID, int COUT, bool RES, int WI, int TH>
 __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X, const uint4* __restrict__ WqE,
                                                 const float* __restrict__ se, const float* __restrict__ be,
@@ -2289,6 +2282,266 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
 #endif
 }
 
+// ---- k_fcn_irbd4h (r05): block 17 (160 -> 960 -> 320, no residual) in ONE pass over the hidden groups ----
+// k_fcn_irbd4 holds the projection accumulators of 160 output channels (80 registers beside the 80 of the input fragments), so block 17
+// (320 outputs) ran it as TWO workgroups per 256-pixel tile, each computing the whole 160 -> 960 expansion and the 960-channel stencil for
+// its half of the outputs: a third of the block's matrix work and all of its stencil twice (r04 verdict: 0.098 of the f16 peak
+// algorithmic, the single most expensive launch).  A 256-pixel tile with 320 outputs does not fit a CU's register file (input 164 KB +
+// accumulators 328 KB of 512).  HALF a sub-image does: one workgroup = 8 of the 16 rows of a (y & 3, x & 3) sub-image (128 pixels) for
+// ALL 320 outputs,
+//   * E: wave w expands its own sub-row (15 x v_mfma_f32_16x16x32_f16 per group); the stencil also needs the sub-row just outside the
+//     half (row 8 for the upper half, row 7 for the lower one): its split input fragments sit in LDS (10 KB, written once) and wave 0
+//     expands it as well -- 9 row expansions per 128 pixels instead of 2 x 8 per 128;
+//   * S: thread = (channel, row, quarter row): 4 pixels, the pixel beside the quarter from the neighbouring lane (DPP);
+//   * P: wave w = pixel tile w & 3 (two sub-rows, 32 pixels) x output half w >> 2 (five 32-channel tiles, 80 accumulator registers);
+//   * the projection's A fragments (20 KB per group for 320 outputs) do NOT go through LDS: with only one sub-row of input in registers
+//     (40 instead of 80) a wave has room for its five tiles' fragments (40 registers), loaded straight from L2 one interval ahead -- tile t
+//     of interval it + 1 right behind the MFMAs that used tile t of interval it.  The LDS-DMA stream, the costliest part of the loop
+//     around the MFMAs in k_fcn_irbd4, shrinks from 21 pieces per 256 pixels and interval to 11 per 128
+//     (the expansion's fragments + the parameters); vmcnt retires in order, so the wait in front of the interval's barrier is
+//     vmcnt(10): everything older than this interval's ten fragment loads = the DMA pieces of the next interval.
+// Everything else is k_fcn_irbd4's: groups of 16 hidden channels, E(g) / S(g - 1) / P(g - 2) on different LDS buffers, one barrier per
+// interval, the two halves of the workgroup in opposite phase order.  Input in `lay 4` (tile-major), output in `layOut` (planes for the
+// decoder).  Batched form only (the small-batch schedule keeps the SPLIT instance of k_fcn_irbd4).
+constexpr int kH4Rows = 10;                       // row slots of a hidden plane: the 8 own sub-rows + the one above + the one below
+constexpr int kH4CS = kH4Rows * kF4HP + 4;        // floats per channel plane of sH (204: the four 16-lane groups of E's b32 stores hit different banks)
+constexpr int kH4DP = 128 + 4;                    // floats per channel of the depthwise output
+constexpr int kH4Cout = 320, kH4TilesP = 10;
+constexpr size_t kH4Lds = (size_t)2 * 16 * kH4CS * 4 + (size_t)2 * 16 * kH4DP * 4 + kF4WSlots * 10240 + kF4PSlots * kF4ParB + 2 * kH4Cout * 4 + 10240;
+#ifndef IVF_H4_DMA_A
+#define IVF_H4_DMA_A 2        // expansion-weight pieces per wave of the half that reaches the barrier first (waves 0-3); waves 4-7 share the rest of the 11
+#endif
+__global__ __launch_bounds__(512, 2) void k_fcn_irbd4h(const float* __restrict__ X, const uint4* __restrict__ WE, const float* __restrict__ par,
+                                                      const uint4* __restrict__ WP, const float* __restrict__ scP, const float* __restrict__ shP,
+                                                      float* __restrict__ Y, int layIn, int layOut)
+{
+    constexpr int g1 = kF4Groups;
+    extern __shared__ __attribute__((aligned(16))) uint4 f4smem[];
+    float* const sH = (float*)f4smem;                               // [2][16 ch][kH4CS]
+    float* const sD = sH + 2 * 16 * kH4CS;                          // [2][16 ch][kH4DP]
+    uint4* const sWE = (uint4*)(sD + 2 * 16 * kH4DP);               // [slots][5 K steps][hi, lo][64 lanes]
+    float* const sPar = (float*)(sWE + kF4WSlots * 640);            // [slots][16 ch][12]
+    float* const sBN = sPar + kF4PSlots * (kF4ParB / 4);            // [scale 320 | shift 320] of the projection (epilogue)
+    uint4* const sXH = (uint4*)(sBN + 2 * kH4Cout);                 // [5 K steps][hi, lo][64 lanes]: input fragments of the halo sub-row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;     // consecutive L on one XCD (grid x = 32 * images)
+    const int b = L >> 5, py = (L >> 3) & 3, px = (L >> 1) & 3, half = L & 1;
+    const int r0 = 8 * half;                                        // first own sub-row
+    const int haloRow = half ? 7 : 8, haloSlot = half ? 0 : 9;      // row slot s holds sub-row r0 - 1 + s
+
+    const unsigned ldsBase = (unsigned)(uintptr_t)f4smem;
+    const unsigned ldsWE = ldsBase + (unsigned)((uint8_t*)sWE - (uint8_t*)f4smem), ldsPar = ldsBase + (unsigned)((uint8_t*)sPar - (uint8_t*)f4smem);
+    auto dma16 = [](const void* src, unsigned ldsAddr) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(ldsAddr) : "memory");
+    };
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    auto piece = [&](int it, int c) {           // piece c of what interval `it` consumes: WE[it] (c < 10), par[it] (c = 10)
+        if (it >= g1) return;
+        if (c < 10) dma16(WE + ((size_t)it * 10 + c) * 64 + lane, ldsWE + (unsigned)((it % kF4WSlots) * 640 + c * 64) * 16u);
+        else if (c == 10 && lane < 48) dma16(par + (size_t)it * 192 + lane * 4, ldsPar + (unsigned)((it % kF4PSlots) * kF4ParB));
+    };
+    auto dma = [&](int it) { piece(it, uwave); if (uwave < 3) piece(it, uwave + 8); };
+    auto dma_late = [&](int it) {               // the same 11 pieces, most of them by waves 0-3, which reach the barrier first
+        constexpr int NA = IVF_H4_DMA_A, NB = 4 * NA >= 11 ? 0 : (11 - 4 * NA + 3) / 4;
+        if (uwave < 4) {
+#pragma unroll
+            for (int r = 0; r < NA; r++) { const int c = uwave + 4 * r; if (c < 11) piece(it, c); }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NB; r++) { const int c = 4 * NA + (uwave - 4) + 4 * r; if (c < 11) piece(it, c); }
+        }
+    };
+    dma(0);
+    dma(1);
+
+    // ---- input: this wave's own sub-row (r0 + wave) as B fragments of the 16x16x32 MFMA (lane: column n = lane & 15, k = 8 (lane >> 4) + j);
+    // wave 7 also gathers the halo sub-row and leaves its split fragments in LDS for wave 0
+    HFrag bh[5], bl[5];
+    {
+        float xv[5][8], xh[5][8];
+        size_t xb; int cs;
+        lay_addr(layIn, kF4Cin, b, 4 * (r0 + wave) + py, 4 * (lane & 15) + px, xb, cs);
+        const float* Xp = X + xb + (size_t)(8 * (lane >> 4)) * cs;
+#pragma unroll
+        for (int s5 = 0; s5 < 5; s5++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) xv[s5][j] = Xp[(size_t)(32 * s5 + j) * cs];
+        if (uwave == 7) {
+            lay_addr(layIn, kF4Cin, b, 4 * haloRow + py, 4 * (lane & 15) + px, xb, cs);
+            const float* Xq = X + xb + (size_t)(8 * (lane >> 4)) * cs;
+#pragma unroll
+            for (int s5 = 0; s5 < 5; s5++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) xh[s5][j] = Xq[(size_t)(32 * s5 + j) * cs];
+        }
+        for (int i = tid; i < 2 * kH4Cout; i += 512) sBN[i] = i < kH4Cout ? scP[i] : shP[i - kH4Cout];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s5 = 0; s5 < 5; s5++)
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) split_pair(xv[s5][2 * jj], xv[s5][2 * jj + 1], bh[s5].u[jj], bl[s5].u[jj]);
+        if (uwave == 7) {
+#pragma unroll
+            for (int s5 = 0; s5 < 5; s5++) {
+                HFrag h, l;
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) split_pair(xh[s5][2 * jj], xh[s5][2 * jj + 1], h.u[jj], l.u[jj]);
+                sXH[(2 * s5) * 64 + lane] = h.q; sXH[(2 * s5 + 1) * 64 + lane] = l.q;
+            }
+        }
+    }
+    f32x16 pacc[5];
+#pragma unroll
+    for (int t = 0; t < 5; t++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) pacc[t][q] = 0.f;
+    const int pt = wave & 3, oh = wave >> 2;                        // P: pixel tile (sub-rows r0 + 2 pt, + 1), output half (tiles 5 oh .. 5 oh + 4)
+
+    // projection fragments of this wave's five tiles, straight from L2: group gp's live in pw while P(gp) runs, then tile by tile those of gp + 1
+    HFrag pw[5][2];
+    const uint4* const wpBase = WP + ((size_t)(5 * oh) * 2) * 64 + lane;
+    auto wp_load = [&](int gp, int t) {
+        const int g = min(max(gp, 0), g1 - 1);                      // intervals outside [0, g1) load valid, unused fragments: the count per interval stays 10
+        const uint4* p = wpBase + ((size_t)g * kH4TilesP + t) * 2 * 64;
+        pw[t][0].q = p[0]; pw[t][1].q = p[64];
+    };
+#pragma unroll
+    for (int t = 0; t < 5; t++) wp_load(-2, t);                     // P(-2) runs on zeroed B operands: any finite fragments do
+
+    // stencil thread: channel sch (0..15), own row srow (0..7), quarter row sq (4 pixels)
+    const int sch = tid >> 5, srow = (tid >> 2) & 7, sq = tid & 3;
+    const bool topOk = !(half == 0 && srow == 0), botOk = !(half == 1 && srow == 7);          // sub-rows -1 / 16 are the depthwise layer's zero padding
+    const float rowM0 = topOk ? 1.f : 0.f, rowM2 = botOk ? 1.f : 0.f;
+    const int srowT = sch * kH4CS + (topOk ? srow : srow + 1) * kF4HP + 4 * sq, srowM = sch * kH4CS + (srow + 1) * kF4HP + 4 * sq,
+              srowB = sch * kH4CS + (botOk ? srow + 2 : srow + 1) * kF4HP + 4 * sq;
+    const float mL = sq > 0 ? 1.f : 0.f, mR = sq < 3 ? 1.f : 0.f;   // the pixel beside the quarter comes from lane -1 / +1 of the same image row
+
+    for (int i = tid; i < 2 * 16 * kH4DP / 4; i += 512) ((uint4*)sD)[i] = make_uint4(0u, 0u, 0u, 0u);      // P(-2), P(-1): zero operands
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    struct MPre { float dv[8]; float2 eb[4]; HFrag ea0[2]; };
+    auto mfma_pre = [&](int it, MPre& m) {      // every LDS read of the phase that depends on no MFMA
+        const int cur = it & 1, ws = it % kF4WSlots;
+        const float* dB = sD + cur * (16 * kH4DP) + (8 * (lane >> 5)) * kH4DP + 32 * pt + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 8; j++) m.dv[j] = dB[j * kH4DP];
+        const float* pp = sPar + (it % kF4PSlots) * (kF4ParB / 4) + (4 * (lane >> 4)) * 12 + 10;
+#pragma unroll
+        for (int r = 0; r < 4; r++) m.eb[r] = *(const float2*)(pp + r * 12);
+        const uint4* wE = sWE + ws * 640 + lane;
+        m.ea0[0].q = wE[0]; m.ea0[1].q = wE[64];
+    };
+    auto mfma_main = [&](int it, MPre& m) {
+        const int cur = it & 1, ws = it % kF4WSlots;
+        const uint4* wE = sWE + ws * 640 + lane;
+        HFrag ea[2][2], ph, pl;
+        ea[0][0] = m.ea0[0]; ea[0][1] = m.ea0[1];
+        f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
+        const bool haloWave = uwave == 0;
+#pragma unroll
+        for (int s5 = 0; s5 < 5; s5++) {        // E(it): hidden group `it` = W_E[16 x 160] . X[160 x 16 pixels of this wave's sub-row]
+            if (s5 + 1 < 5) { ea[(s5 + 1) & 1][0].q = wE[(2 * s5 + 2) * 64]; ea[(s5 + 1) & 1][1].q = wE[(2 * s5 + 3) * 64]; }
+            const HFrag &ah = ea[s5 & 1][0], &al = ea[s5 & 1][1];
+            e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, bh[s5].v, e0, 0, 0, 0);
+            e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bl[s5].v, e0, 0, 0, 0);
+            e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[s5].v, e0, 0, 0, 0);
+            if (haloWave) {                     // wave-uniform: the sub-row just outside the half, fragments from LDS
+                HFrag xh_, xl_;
+                xh_.q = sXH[(2 * s5) * 64 + lane]; xl_.q = sXH[(2 * s5 + 1) * 64 + lane];
+                e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, xh_.v, e1, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, xl_.v, e1, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, xh_.v, e1, 0, 0, 0);
+            }
+            if (s5 < 4) split_pair(m.dv[2 * s5], m.dv[2 * s5 + 1], ph.u[s5], pl.u[s5]);      // P's B fragment, one pair per step
+        }
+        // C layout of E: column = lane & 15 (sub-column), row = 4 (lane >> 4) + r (hidden channel of the group)
+        float* hp = sH + cur * (16 * kH4CS) + (4 * (lane >> 4)) * kH4CS + (lane & 15);
+        const int gp = it - 2;
+#pragma unroll
+        for (int t = 0; t < 5; t++) {           // P(it - 2): out[160 of this half x 32 pixels] += W_P[160 x 16] . D[16 x 32 pixels]
+            const HFrag &ah = pw[t][0], &al = pw[t][1];
+            pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, ph.v, pacc[t], 0, 0, 0);
+            pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, pl.v, pacc[t], 0, 0, 0);
+            pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, ph.v, pacc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            wp_load(gp + 1, t);                 // the same tile of the next group, behind the MFMAs that read this one
+            if (t >= 1) {                       // E's epilogue, one row per step: BN + ReLU6 -> planes
+                const int r = t - 1;
+                hp[r * kH4CS + (wave + 1) * kF4HP] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e0[r], m.eb[r].x, m.eb[r].y), 0.f, 6.f);
+                if (haloWave) hp[r * kH4CS + haloSlot * kF4HP] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e1[r], m.eb[r].x, m.eb[r].y), 0.f, 6.f);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto stencil_phase = [&](int it) {          // S(it - 1): 3x3 on the 8 own rows of group it - 1, + BN + ReLU6
+        const int g = it - 1;
+        if (g < 0 || g >= g1) return;
+        const float* hp = sH + (g & 1) * (16 * kH4CS);
+        const float4* pq = (const float4*)(sPar + (g % kF4PSlots) * (kF4ParB / 4) + sch * 12);
+        const float4 w03 = pq[0], w47 = pq[1], w8s = pq[2];          // taps 0-3 | 4-7 | tap 8, shift, (expansion BN)
+        float o[4];
+#pragma unroll
+        for (int p4 = 0; p4 < 4; p4++) o[p4] = w8s.y;
+        const int ro[3] = {srowT, srowM, srowB};
+        const float wk[9] = {w03.x * rowM0, w03.y * rowM0, w03.z * rowM0, w03.w, w47.x, w47.y, w47.z * rowM2, w47.w * rowM2, w8s.x * rowM2};
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+            const float4 a = *(const float4*)(hp + ro[ky]);
+            const float own[4] = {a.x, a.y, a.z, a.w};
+            const float w0 = wk[3 * ky], w1 = wk[3 * ky + 1], w2 = wk[3 * ky + 2];
+            const float w0L = w0 * mL, w2R = w2 * mR;
+#pragma unroll
+            for (int p4 = 0; p4 < 4; p4++) {
+                o[p4] = __builtin_fmaf(own[p4], w1, o[p4]);
+                if (p4 > 0) o[p4] = __builtin_fmaf(own[p4 - 1], w0, o[p4]);
+                else asm("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(o[p4]) : "v"(own[3]), "v"(w0L));
+                if (p4 < 3) o[p4] = __builtin_fmaf(own[p4 + 1], w2, o[p4]);
+                else asm("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(o[p4]) : "v"(own[0]), "v"(w2R));
+            }
+        }
+        float* dp = sD + (g & 1) * (16 * kH4DP) + sch * kH4DP + srow * 16 + 4 * sq;
+        *(float4*)dp = make_float4(__builtin_amdgcn_fmed3f(o[0], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[1], 0.f, 6.f),
+                                   __builtin_amdgcn_fmed3f(o[2], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[3], 0.f, 6.f));
+    };
+
+    for (int it = 0; it < g1 + 2; it++) {
+        {
+            MPre m;
+            mfma_pre(it, m); __builtin_amdgcn_sched_barrier(0);
+            if (wave < 4) { mfma_main(it, m); stencil_phase(it); }
+            else { stencil_phase(it); __builtin_amdgcn_sched_barrier(0); mfma_main(it, m); }
+        }
+        // everything older than this interval's ten projection-fragment loads has landed: the DMA pieces of it + 1, requested an interval ago
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        dma_late(it + 2);                                          // land during it + 1; their slots were last read in it - 1
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: BN of the projection; the sub-image's pixels are 4 apart in planes (layOut 0: the decoder reads planes)
+    const int n = lane & 31;
+    const int oy = 4 * (r0 + 2 * pt + (n >> 4)) + py, ox = 4 * (n & 15) + px;      // this lane's pixel
+    size_t ob; int ocs;
+    lay_addr(layOut, kH4Cout, b, oy, ox, ob, ocs);
+    float* const yp = Y + ob + (size_t)(160 * oh + 4 * (lane >> 5)) * ocs;
+    float amaxOut = 0.f;
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+        float4 sc4[4], sh4[4];
+        const int cb = 160 * oh + t * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(sBN + cb + 8 * g4); sh4[g4] = *(const float4*)(sBN + kH4Cout + cb + 8 * g4); }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const float v = pacc[t][q] * vget<4>(sc4[q >> 2], q & 3) + vget<4>(sh4[q >> 2], q & 3);
+            range_note(amaxOut, v);
+            yp[(size_t)(t * 32 + (q & 3) + 8 * (q >> 2)) * ocs] = v;
+        }
+    }
+    range_flag(amaxOut);
+}
+
 #ifdef IVF_EXPERIMENT      // opt-in variant (IVF_FCN_ROLES=1) with a run-time ablation mask: experiment builds only
 // ---- k_fcn_irbd4w (r04): the same block with ROLE-SPECIALISED waves ----
 // k_fcn_irbd4 runs eight waves that each hold the input fragments (80 registers) AND the projection accumulators (80): two waves per
@@ -3314,6 +3567,7 @@ int reserve_lds()
         {reinterpret_cast<const void*>(&k_fcn_irbd2<96, 96, true, 2, true>), D2Cfg<96, 96>::LDS, "k_fcn_irbd2<96,96,split>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd2<96, 160, false, 2, true>), D2Cfg<96, 160>::LDS, "k_fcn_irbd2<96,160,split>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd4<false, true>), kF4Lds, "k_fcn_irbd4<split>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd4h), kH4Lds, "k_fcn_irbd4h"},
 #ifdef IVF_EXPERIMENT
         {reinterpret_cast<const void*>(&k_fcn_irbd4w<true>), kF4Lds, "k_fcn_irbd4w<true>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd4w<false>), kF4Lds, "k_fcn_irbd4w<false>"},
@@ -3360,10 +3614,7 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
 {
     static const bool dbg = getenv("IVF_FCN_DEBUG") != nullptr;
     char nm[64];
-    if (n >= 8)
-        hipLaunchKernelGGL(k_fcn_prep, dim3(8 * ((n + 7) / 8) * 2 * kEnc), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn, n, 1);
-    else
-        hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc, n), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn, n, 0);
+    hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc, n), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn);
     STAGE("prep");
     // whole-block kernels, bit i = block i + 2: blocks 2-4 (k_fcn_irb) by default; bits 3-9 = blocks 5-11 through k_fcn_irb64, which
     // is correct but measures slower than expand + dwpw there (337 vs 245 us for the 64->384->64 blocks): opt-in.  Off under the
@@ -3513,11 +3764,15 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
                                        (float*)nullptr, layIn, layOut);
             } else
 #endif
+            static const int half4 = IVF_EXP_ENV("IVF_FCN_HALF4") ? atoi(IVF_EXP_ENV("IVF_FCN_HALF4")) : 1;     // 0: block 17 as two workgroups per 256-pixel tile (r03 / r04)
             if (ns > 1) {
                 hipLaunchKernelGGL((k_fcn_irbd4<false, true>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y,
                                    F.cout, F.tilesP, f->bufPart, layIn, layOut);
                 launch_split_reduce(f, ns, n, F.cout, pj, bk.res ? x : nullptr, y, layIn, layOut, s);
-            } else if (bk.res)
+            } else if (half4 && !bk.res && F.cout == kH4Cout && F.tilesP == kH4TilesP)
+                // block 17 in ONE pass: half a sub-image (128 pixels) x all 320 outputs per workgroup
+                hipLaunchKernelGGL(k_fcn_irbd4h, dim3(32 * n), dim3(512), kH4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, y, layIn, layOut);
+            else if (bk.res)
                 hipLaunchKernelGGL((k_fcn_irbd4<true>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, x, y, F.cout, F.tilesP, (float*)nullptr,
                                    layIn, layOut);
             else
