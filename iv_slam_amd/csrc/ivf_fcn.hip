@@ -2222,10 +2222,12 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef IVF_F4_TIMING
     const unsigned long long tk2 = __builtin_amdgcn_s_memtime();
+#ifndef IVF_F4_TIM_H4ONLY        // (a variant build that times k_fcn_irbd4h alone)
     if (lane == 0 && (wave == 0 || wave == 4)) {
         for (int i = 0; i < 7; i++) atomicAdd(&g_f4Tim[(wave ? 8 : 0) + i], tacc[i]);
         atomicAdd(&g_f4Tim[(wave ? 8 : 0) + 7], 1ull);
     }
+#endif
 #endif
 
     // ---- epilogue: BN (+ residual) of the projection, 4-byte pieces (the sub-image's pixels are 4 apart)
@@ -2308,8 +2310,12 @@ constexpr int kH4CS = kH4Rows * kF4HP + 4;        // floats per channel plane of
 constexpr int kH4DP = 128 + 4;                    // floats per channel of the depthwise output
 constexpr int kH4Cout = 320, kH4TilesP = 10;
 constexpr size_t kH4Lds = (size_t)2 * 16 * kH4CS * 4 + (size_t)2 * 16 * kH4DP * 4 + kF4WSlots * 10240 + kF4PSlots * kF4ParB + 2 * kH4Cout * 4 + 10240;
+#ifndef IVF_H4_ABL
+#define IVF_H4_ABL 0          // timing-only ablations (compile time; results wrong): 1 no projection-fragment loads in the loop, 2 E's A fragments read once,
+#endif                        // 4 no LDS-DMA in the loop, 8 no stencil, 16 no halo expansion, 32 no P MFMAs, 64 no E MFMAs
 #ifndef IVF_H4_DMA_A
-#define IVF_H4_DMA_A 2        // expansion-weight pieces per wave of the half that reaches the barrier first (waves 0-3); waves 4-7 share the rest of the 11
+#define IVF_H4_DMA_A 3        // expansion-weight pieces per wave of the half that reaches the barrier first (waves 0-3); waves 4-7 share the rest of the 11.
+                              // Measured 1 / 2 / 3: 1,905 / 1,881 / 1,849 us per 128 images
 #endif
 __global__ __launch_bounds__(512, 2) void k_fcn_irbd4h(const float* __restrict__ X, const uint4* __restrict__ WE, const float* __restrict__ par,
                                                       const uint4* __restrict__ WP, const float* __restrict__ scP, const float* __restrict__ shP,
@@ -2420,6 +2426,9 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4h(const float* __restrict__
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+#ifdef IVF_F4_TIMING
+    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
     struct MPre { float dv[8]; float2 eb[4]; HFrag ea0[2]; };
     auto mfma_pre = [&](int it, MPre& m) {      // every LDS read of the phase that depends on no MFMA
         const int cur = it & 1, ws = it % kF4WSlots;
@@ -2439,44 +2448,60 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4h(const float* __restrict__
         ea[0][0] = m.ea0[0]; ea[0][1] = m.ea0[1];
         f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
         const bool haloWave = uwave == 0;
-#pragma unroll
-        for (int s5 = 0; s5 < 5; s5++) {        // E(it): hidden group `it` = W_E[16 x 160] . X[160 x 16 pixels of this wave's sub-row]
-            if (s5 + 1 < 5) { ea[(s5 + 1) & 1][0].q = wE[(2 * s5 + 2) * 64]; ea[(s5 + 1) & 1][1].q = wE[(2 * s5 + 3) * 64]; }
-            const HFrag &ah = ea[s5 & 1][0], &al = ea[s5 & 1][1];
-            e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, bh[s5].v, e0, 0, 0, 0);
-            e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bl[s5].v, e0, 0, 0, 0);
-            e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[s5].v, e0, 0, 0, 0);
-            if (haloWave) {                     // wave-uniform: the sub-row just outside the half, fragments from LDS
-                HFrag xh_, xl_;
-                xh_.q = sXH[(2 * s5) * 64 + lane]; xl_.q = sXH[(2 * s5 + 1) * 64 + lane];
-                e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, xh_.v, e1, 0, 0, 0);
-                e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, xl_.v, e1, 0, 0, 0);
-                e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, xh_.v, e1, 0, 0, 0);
-            }
-            if (s5 < 4) split_pair(m.dv[2 * s5], m.dv[2 * s5 + 1], ph.u[s5], pl.u[s5]);      // P's B fragment, one pair per step
-        }
-        // C layout of E: column = lane & 15 (sub-column), row = 4 (lane >> 4) + r (hidden channel of the group)
-        float* hp = sH + cur * (16 * kH4CS) + (4 * (lane >> 4)) * kH4CS + (lane & 15);
         const int gp = it - 2;
+        F4_TIM(4);
 #pragma unroll
-        for (int t = 0; t < 5; t++) {           // P(it - 2): out[160 of this half x 32 pixels] += W_P[160 x 16] . D[16 x 32 pixels]
-            const HFrag &ah = pw[t][0], &al = pw[t][1];
-            pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, ph.v, pacc[t], 0, 0, 0);
-            pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, pl.v, pacc[t], 0, 0, 0);
-            pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, ph.v, pacc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            wp_load(gp + 1, t);                 // the same tile of the next group, behind the MFMAs that read this one
-            if (t >= 1) {                       // E's epilogue, one row per step: BN + ReLU6 -> planes
-                const int r = t - 1;
-                hp[r * kH4CS + (wave + 1) * kF4HP] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e0[r], m.eb[r].x, m.eb[r].y), 0.f, 6.f);
-                if (haloWave) hp[r * kH4CS + haloSlot * kF4HP] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e1[r], m.eb[r].x, m.eb[r].y), 0.f, 6.f);
+        for (int jj = 0; jj < 4; jj++) split_pair(m.dv[2 * jj], m.dv[2 * jj + 1], ph.u[jj], pl.u[jj]);      // P's B fragment
+        // E(it) and P(it - 2) step by step: K step s5 of the expansion, then output tile s5 of the projection -- the expansion's A
+        // fragments of step s5 + 1 (LDS, requested at the top of step s5) then have the projection tile's 96 matrix cycles to arrive
+        // (r05 phase timers: with the five E steps back to back, one step = 48 matrix cycles ahead, the E loop took 900-1200 cycles for
+        // its 240-480)
+#pragma unroll
+        for (int s5 = 0; s5 < 5; s5++) {
+            if (s5 + 1 < 5) {
+                if (IVF_H4_ABL & 2) { ea[(s5 + 1) & 1][0] = ea[s5 & 1][0]; ea[(s5 + 1) & 1][1] = ea[s5 & 1][1]; }
+                else { ea[(s5 + 1) & 1][0].q = wE[(2 * s5 + 2) * 64]; ea[(s5 + 1) & 1][1].q = wE[(2 * s5 + 3) * 64]; }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (!(IVF_H4_ABL & 64))
+            {   // E(it): hidden group `it` = W_E[16 x 160] . X[160 x 16 pixels of this wave's sub-row]
+                const HFrag &ah = ea[s5 & 1][0], &al = ea[s5 & 1][1];
+                e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, bh[s5].v, e0, 0, 0, 0);
+                e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bl[s5].v, e0, 0, 0, 0);
+                e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[s5].v, e0, 0, 0, 0);
+                if (haloWave && !(IVF_H4_ABL & 16)) {                     // wave-uniform: the sub-row just outside the half, fragments from LDS
+                    HFrag xh_, xl_;                 // (requested a K step ahead like the A fragments: 1,881-1,887 vs 1,841-1,868 us, not kept)
+                    xh_.q = sXH[(2 * s5) * 64 + lane]; xl_.q = sXH[(2 * s5 + 1) * 64 + lane];
+                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, xh_.v, e1, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, xl_.v, e1, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, xh_.v, e1, 0, 0, 0);
+                }
+            }
+            {   // P(it - 2), tile s5: out[32 channels x 32 pixels] += W_P[32 x 16] . D[16 x 32 pixels]
+                const int t = s5;
+                const HFrag &ah = pw[t][0], &al = pw[t][1];
+                if (!(IVF_H4_ABL & 32)) {
+                pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, ph.v, pacc[t], 0, 0, 0);
+                pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, pl.v, pacc[t], 0, 0, 0);
+                pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, ph.v, pacc[t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(IVF_H4_ABL & 1)) wp_load(gp + 1, t);                 // the same tile of the next group, behind the MFMAs that read this one
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        F4_TIM(5);
+        // E's epilogue: BN + ReLU6 -> planes.  C layout of E: column = lane & 15 (sub-column), row = 4 (lane >> 4) + r (hidden channel of the group)
+        float* hp = sH + cur * (16 * kH4CS) + (4 * (lane >> 4)) * kH4CS + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            hp[r * kH4CS + (wave + 1) * kF4HP] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e0[r], m.eb[r].x, m.eb[r].y), 0.f, 6.f);
+            if (haloWave) hp[r * kH4CS + haloSlot * kF4HP] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e1[r], m.eb[r].x, m.eb[r].y), 0.f, 6.f);
+        }
+        F4_TIM(6);
     };
     auto stencil_phase = [&](int it) {          // S(it - 1): 3x3 on the 8 own rows of group it - 1, + BN + ReLU6
         const int g = it - 1;
-        if (g < 0 || g >= g1) return;
+        if (g < 0 || g >= g1 || (IVF_H4_ABL & 8)) return;
         const float* hp = sH + (g & 1) * (16 * kH4CS);
         const float4* pq = (const float4*)(sPar + (g % kF4PSlots) * (kF4ParB / 4) + sch * 12);
         const float4 w03 = pq[0], w47 = pq[1], w8s = pq[2];          // taps 0-3 | 4-7 | tap 8, shift, (expansion BN)
@@ -2506,18 +2531,29 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4h(const float* __restrict__
     };
 
     for (int it = 0; it < g1 + 2; it++) {
+        F4_TIM(0);
         {
             MPre m;
             mfma_pre(it, m); __builtin_amdgcn_sched_barrier(0);
-            if (wave < 4) { mfma_main(it, m); stencil_phase(it); }
-            else { stencil_phase(it); __builtin_amdgcn_sched_barrier(0); mfma_main(it, m); }
+            if (wave < 4) { mfma_main(it, m); F4_TIM(1); stencil_phase(it); F4_TIM(2); }
+            else { stencil_phase(it); F4_TIM(2); __builtin_amdgcn_sched_barrier(0); mfma_main(it, m); F4_TIM(1); }
         }
         // everything older than this interval's ten projection-fragment loads has landed: the DMA pieces of it + 1, requested an interval ago
+        if (IVF_H4_ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else
         asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        dma_late(it + 2);                                          // land during it + 1; their slots were last read in it - 1
+        F4_TIM(3);
+        if (!(IVF_H4_ABL & 4)) dma_late(it + 2);
+        F4_TIM(0);                               // land during it + 1; their slots were last read in it - 1
         __syncthreads();
+        F4_TIM(3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef IVF_F4_TIMING
+    if (lane == 0 && (wave == 0 || wave == 4)) {
+        for (int i = 0; i < 7; i++) atomicAdd(&g_f4Tim[(wave ? 8 : 0) + i], tacc[i]);
+        atomicAdd(&g_f4Tim[(wave ? 8 : 0) + 7], 1ull);
+    }
+#endif
 
     // ---- epilogue: BN of the projection; the sub-image's pixels are 4 apart in planes (layOut 0: the decoder reads planes)
     const int n = lane & 31;
@@ -3749,6 +3785,7 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             if (probe4) FHIP(hipEventRecord(f->probe0[slot4], s));
             const int ns = split_ways(n, kF4Groups, F.cout);
             const dim3 grid(16 * n, F.cout / 160, ns);
+            static const int half4 = IVF_EXP_ENV("IVF_FCN_HALF4") ? atoi(IVF_EXP_ENV("IVF_FCN_HALF4")) : 1;     // 0: block 17 as two workgroups per 256-pixel tile (r03 / r04)
 #ifdef IVF_EXPERIMENT
             static const int roles = IVF_EXP_ENV("IVF_FCN_ROLES") ? atoi(IVF_EXP_ENV("IVF_FCN_ROLES")) : 0;      // 1: role-specialised waves (k_fcn_irbd4w)
             if (roles) {
@@ -3764,7 +3801,6 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
                                        (float*)nullptr, layIn, layOut);
             } else
 #endif
-            static const int half4 = IVF_EXP_ENV("IVF_FCN_HALF4") ? atoi(IVF_EXP_ENV("IVF_FCN_HALF4")) : 1;     // 0: block 17 as two workgroups per 256-pixel tile (r03 / r04)
             if (ns > 1) {
                 hipLaunchKernelGGL((k_fcn_irbd4<false, true>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y,
                                    F.cout, F.tilesP, f->bufPart, layIn, layOut);
