@@ -674,7 +674,11 @@ def main():
     n_timed = min(args.steps * BPS, 64)
     fast_sum_ms, fast_n = fe.fast_ms_stats(n_timed)
     if fcn is not None:
-        probe_sum_ms, probe_n, probe_batch = fcn.probe_stats(n_timed)
+        probe_sets = {}
+        for which in (0, 1):
+            fcn.probe_select(which); probe_sets[which] = fcn.probe_stats(n_timed)
+        fcn.probe_select(0)
+        probe_sum_ms, probe_n, probe_batch = probe_sets[0]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend != "gloo" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -741,7 +745,11 @@ def main():
         torch.cuda.synchronize(dev)
     iso_sum_ms, iso_n = fe.fast_ms_stats(5)
     if fcn is not None:
-        iso_probe_ms, iso_probe_n, _ = fcn.probe_stats(5)
+        iso_sets = {}
+        for which in (0, 1):
+            fcn.probe_select(which); iso_sets[which] = fcn.probe_stats(5)
+        fcn.probe_select(0)
+        iso_probe_ms, iso_probe_n, _ = iso_sets[0]
     extras = world == 1 and not args.no_extras
     # the network alone (MFMA leg of north_star): 3 forwards with nothing else on the GPU, HIP events on its stream
     fcn_alone = None
@@ -841,10 +849,32 @@ def main():
         fast_roof = roof("k_fast_nms", fast_algo, fast_sum_ms, fast_n, iso_sum_ms, iso_n,
                          None if per_img is None else int(per_img * imgs_per_launch), src)
         if fcn is not None:
-            pname, palgo = fcn.probe_info()
+            # r05: `roofline` names the kernel with the largest TOTAL time per forward among the probed ones: block 15's kernel runs twice
+            # (blocks 15 and 16), block 17's once; the other one is printed next to it as `roofline_other_block`
+            # (same pricing: frac_issued / frac_algorithmic of the f16 matrix peak)
+            cands = []
+            for which in (0, 1):
+                fcn.probe_select(which)
+                try:
+                    nm_, algo_ = fcn.probe_info()
+                except Exception:
+                    continue
+                cands.append(dict(which=which, name=nm_, algo=algo_, timed=probe_sets[which], iso=iso_sets[which],
+                                  launches_per_forward=2 if which == 0 else 1))
+            fcn.probe_select(0)
+            def total_ms(c):
+                s_, n_, _b = c["timed"]
+                return c["launches_per_forward"] * s_ / max(n_, 1)
+            cands.sort(key=total_ms, reverse=True)
+            top = cands[0]
+            pname, palgo = top["name"], top["algo"]
+            probe_sum_ms, probe_n, probe_batch = top["timed"]
+            iso_probe_ms, iso_probe_n = top["iso"][0], top["iso"][1]
             per_img, src = load_pmc(pname)
             roofline = roof("%s (%d images)" % (pname, probe_batch), int(palgo * probe_batch), probe_sum_ms, probe_n,
                             iso_probe_ms, iso_probe_n, None if per_img is None else int(per_img * probe_batch), src)
+            roofline["launches_per_forward"] = top["launches_per_forward"]
+            roofline["total_ms_per_forward"] = round(total_ms(top), 5)
             # The same launch priced two more ways (r01 verdict): (i) at the BLOCK's boundary -- the hidden tensor this kernel
             # reads is a product of the expand / depthwise split, not of the network: block input + residual + output is all an
             # ideal whole-block kernel would move; (ii) against the matrix pipe -- three f16 MFMAs per f32 product.
@@ -872,6 +902,20 @@ def main():
                                  "hbm": hbm})
                 roofline["isolated"].update({"achieved": round(fl / (ims * 1e-3) / 1e12, 1) if ims > 0 else 0.0,
                                              "frac": round(fl / (ims * 1e-3) / 1e12 / 2500.0, 5) if ims > 0 else 0.0})
+                if len(cands) > 1:
+                    o = cands[1]
+                    mo = re.search(r"(\d+)->(\d+)->(\d+)", o["name"])
+                    s_, n_, b_ = o["timed"]
+                    oms = s_ / max(n_, 1)
+                    if mo and oms > 0:
+                        ci, hi_, co = (int(v) for v in mo.groups())
+                        ofl = 2.0 * (ci * hi_ + hi_ * co) * 64 * 64 * 3 * b_
+                        out_other = {"kernel": "%s (%d images)" % (o["name"], b_), "bound": "mfma", "avg_launch_ms": round(oms, 5), "launches_timed": n_,
+                                     "launches_per_forward": o["launches_per_forward"], "total_ms_per_forward": round(total_ms(o), 5),
+                                     "achieved": round(ofl / (oms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                                     "frac_issued": round(ofl / (oms * 1e-3) / 1e12 / 2500.0, 5),
+                                     "frac_algorithmic": round(ofl / 3.0 / (oms * 1e-3) / 1e12 / 2500.0, 5)}
+                        roofline["other_block"] = out_other
             elif m and roofline["avg_launch_ms"] > 0:
                 hid, cout = int(m.group(1)), int(m.group(2))
                 cin = hid // 6                                     # MobileNetV2 expansion factor (mobilenet.py:36)

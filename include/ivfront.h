@@ -533,6 +533,9 @@ int  ivf_remap_get_fixed_maps(const ivf_remap* r, int16_t* xy, uint16_t* alpha);
  * projection 960 -> 160 of block 15, k_fcn_dwpw<5,4>) on the stream each forward runs on.  probe_stats returns the summed
  * duration of the last `last_n` probed forwards (0 = all kept, at most 64) and the batch size of the oldest of them. */
 int  ivf_fcn_probe_enable(ivf_fcn* f);
+/* r05: two probes -- 0 (default) = block 15 (k_fcn_irbd4<true>: launched twice per forward, blocks 15 and 16), 1 = block 17
+ * (k_fcn_irbd4h: the largest single launch); probe_info / probe_stats report the selected one. */
+int  ivf_fcn_probe_select(ivf_fcn* f, int which);
 int  ivf_fcn_probe_stats(ivf_fcn* f, int last_n, double* sum_ms, int* n_out, int* batch);
 /* which kernel the probe bracketed, as dispatched (e.g. "ivffcn::k_fcn_dwpw<5, 4> 960->160"), and its algorithmic HBM bytes
  * per image (hidden tensor read once + residual read + output written).  IVF_E_STATE before the first probed forward. */

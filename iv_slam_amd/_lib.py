@@ -147,6 +147,7 @@ _SIGS = {
     "ivf_fcn_forward_device": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp, vp]),
     "ivf_fcn_status": (C.c_int, [vp, vp]),
     "ivf_fcn_probe_enable": (C.c_int, [vp]),
+    "ivf_fcn_probe_select": (C.c_int, [vp, C.c_int]),
     "ivf_fcn_probe_info": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_double)]),
     "ivf_fcn_probe_stats": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }

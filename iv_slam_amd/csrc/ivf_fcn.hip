@@ -3467,6 +3467,12 @@ struct ivf_fcn {
     long probeCount = 0;
     char probeName[96] = "";       // the kernel the probe brackets, as dispatched
     double probeAlgoBytes = 0;     // its algorithmic HBM bytes per image: hidden tensor read + residual read + output written
+    // r05: a second probe around block 17 (the largest single launch); ivf_fcn_probe_select picks which one probe_info / probe_stats report
+    hipEvent_t probeB0[kProbe] = {}, probeB1[kProbe] = {};
+    long probeBCount = 0;
+    char probeBName[96] = "";
+    double probeBAlgoBytes = 0;
+    int probeSel = 0;
 };
 
 namespace {
@@ -3783,6 +3789,10 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             const bool probe4 = i == 14 && f->probe0[0];
             const int slot4 = (int)(f->probeCount % ivf_fcn::kProbe);
             if (probe4) FHIP(hipEventRecord(f->probe0[slot4], s));
+            const bool probeB = i == 16 && f->probeB0[0];
+            const int slotB = (int)(f->probeBCount % ivf_fcn::kProbe);
+            if (probeB) FHIP(hipEventRecord(f->probeB0[slotB], s));
+            const char* kname = "k_fcn_irbd4";
             const int ns = split_ways(n, kF4Groups, F.cout);
             const dim3 grid(16 * n, F.cout / 160, ns);
             static const int half4 = IVF_EXP_ENV("IVF_FCN_HALF4") ? atoi(IVF_EXP_ENV("IVF_FCN_HALF4")) : 1;     // 0: block 17 as two workgroups per 256-pixel tile (r03 / r04)
@@ -3806,9 +3816,10 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
                                    F.cout, F.tilesP, f->bufPart, layIn, layOut);
                 launch_split_reduce(f, ns, n, F.cout, pj, bk.res ? x : nullptr, y, layIn, layOut, s);
             } else if (half4 && !bk.res && F.cout == kH4Cout && F.tilesP == kH4TilesP)
-                // block 17 in ONE pass: half a sub-image (128 pixels) x all 320 outputs per workgroup
+            {   // block 17 in ONE pass: half a sub-image (128 pixels) x all 320 outputs per workgroup
                 hipLaunchKernelGGL(k_fcn_irbd4h, dim3(32 * n), dim3(512), kH4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, y, layIn, layOut);
-            else if (bk.res)
+                kname = "k_fcn_irbd4h";
+            } else if (bk.res)
                 hipLaunchKernelGGL((k_fcn_irbd4<true>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, x, y, F.cout, F.tilesP, (float*)nullptr,
                                    layIn, layOut);
             else
@@ -3818,6 +3829,12 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
                 FHIP(hipEventRecord(f->probe1[slot4], s)); f->probeBatch[slot4] = n; f->probeCount++;
                 snprintf(f->probeName, sizeof f->probeName, "ivffcn::k_fcn_irbd4<%s> %d->%d->%d", bk.res ? "true" : "false", bk.inp, hid, bk.oup);
                 f->probeAlgoBytes = (double)(bk.inp + bk.oup * (bk.res ? 2 : 1)) * H * W * sizeof(float);
+            }
+            if (probeB) {
+                FHIP(hipEventRecord(f->probeB1[slotB], s)); f->probeBCount++;
+                if (strcmp(kname, "k_fcn_irbd4h") == 0) snprintf(f->probeBName, sizeof f->probeBName, "ivffcn::k_fcn_irbd4h %d->%d->%d", bk.inp, hid, bk.oup);
+                else snprintf(f->probeBName, sizeof f->probeBName, "ivffcn::k_fcn_irbd4<%s> %d->%d->%d", bk.res ? "true" : "false", bk.inp, hid, bk.oup);
+                f->probeBAlgoBytes = (double)(bk.inp + bk.oup * (bk.res ? 2 : 1)) * H * W * sizeof(float);
             }
             ip += 2; id++;
             snprintf(nm, sizeof nm, "block %d whole (dilation-4 phases)", i + 1); STAGE(nm);
@@ -4062,6 +4079,8 @@ void ivf_fcn_destroy(ivf_fcn* f)
     for (int i = 0; i < ivf_fcn::kProbe; i++) {
         if (f->probe0[i]) (void)hipEventDestroy(f->probe0[i]);
         if (f->probe1[i]) (void)hipEventDestroy(f->probe1[i]);
+        if (f->probeB0[i]) (void)hipEventDestroy(f->probeB0[i]);
+        if (f->probeB1[i]) (void)hipEventDestroy(f->probeB1[i]);
     }
     for (void* p : f->allocs) (void)hipFree(p);
     if (f->dStageIn) (void)hipFree(f->dStageIn);
@@ -4078,17 +4097,27 @@ int ivf_fcn_probe_enable(ivf_fcn* f)
     for (int i = 0; i < ivf_fcn::kProbe; i++) {
         if (!f->probe0[i]) FHIP(hipEventCreate(&f->probe0[i]));
         if (!f->probe1[i]) FHIP(hipEventCreate(&f->probe1[i]));
+        if (!f->probeB0[i]) FHIP(hipEventCreate(&f->probeB0[i]));
+        if (!f->probeB1[i]) FHIP(hipEventCreate(&f->probeB1[i]));
     }
-    f->probeCount = 0;
+    f->probeCount = 0; f->probeBCount = 0;
+    return IVF_OK;
+}
+
+int ivf_fcn_probe_select(ivf_fcn* f, int which)
+{
+    if (!f || which < 0 || which > 1) return ffail(IVF_E_INVALID, "probe 0 = block 15, probe 1 = block 17");
+    f->probeSel = which;
     return IVF_OK;
 }
 
 int ivf_fcn_probe_info(const ivf_fcn* f, char* name, int name_cap, double* algorithmic_bytes_per_image)
 {
     if (!f || !name || name_cap < 1) return ffail(IVF_E_INVALID, "bad argument");
-    if (!f->probeName[0]) return ffail(IVF_E_STATE, "no probed forward has run");
-    snprintf(name, (size_t)name_cap, "%s", f->probeName);
-    if (algorithmic_bytes_per_image) *algorithmic_bytes_per_image = f->probeAlgoBytes;
+    const char* pn = f->probeSel ? f->probeBName : f->probeName;
+    if (!pn[0]) return ffail(IVF_E_STATE, "no probed forward has run");
+    snprintf(name, (size_t)name_cap, "%s", pn);
+    if (algorithmic_bytes_per_image) *algorithmic_bytes_per_image = f->probeSel ? f->probeBAlgoBytes : f->probeAlgoBytes;
     return IVF_OK;
 }
 
@@ -4096,16 +4125,19 @@ int ivf_fcn_probe_stats(ivf_fcn* f, int last_n, double* sum_ms, int* n_out, int*
 {
     if (!f || !sum_ms || !n_out) return ffail(IVF_E_INVALID, "null argument");
     FHIP(hipSetDevice(f->device));
-    const long have = std::min<long>(f->probeCount, ivf_fcn::kProbe);
+    const long count = f->probeSel ? f->probeBCount : f->probeCount;
+    hipEvent_t* const e0 = f->probeSel ? f->probeB0 : f->probe0;
+    hipEvent_t* const e1 = f->probeSel ? f->probeB1 : f->probe1;
+    const long have = std::min<long>(count, ivf_fcn::kProbe);
     const long take = last_n > 0 ? std::min<long>(last_n, have) : have;
     double sum = 0; int n = 0;
     for (long k = 0; k < take; k++) {
-        const int slot = (int)((f->probeCount - 1 - k) % ivf_fcn::kProbe);
-        FHIP(hipEventSynchronize(f->probe1[slot]));
+        const int slot = (int)((count - 1 - k) % ivf_fcn::kProbe);
+        FHIP(hipEventSynchronize(e1[slot]));
         float ms = 0.f;
-        FHIP(hipEventElapsedTime(&ms, f->probe0[slot], f->probe1[slot]));
+        FHIP(hipEventElapsedTime(&ms, e0[slot], e1[slot]));
         sum += ms; n++;
-        if (batch) *batch = f->probeBatch[slot];
+        if (batch) *batch = f->probeBatch[slot];      // both probes bracket a launch of every forward: their slots advance together
     }
     *sum_ms = sum; *n_out = n;
     return IVF_OK;

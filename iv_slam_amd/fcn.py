@@ -55,6 +55,10 @@ class IntrospectionFCN:
     def probe_enable(self):
         check(self._lib.ivf_fcn_probe_enable(self._h))
 
+    def probe_select(self, which):
+        """0 = block 15 (k_fcn_irbd4<true>, runs twice per forward), 1 = block 17 (k_fcn_irbd4h): what probe_stats / probe_info report"""
+        check(self._lib.ivf_fcn_probe_select(self._h, int(which)))
+
     def probe_stats(self, last_n=0):
         """(summed ms, launches, batch size) of the last `last_n` probed forwards (0 = all kept)."""
         s = C.c_double(0); n = C.c_int(0); b = C.c_int(0)

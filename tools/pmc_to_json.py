@@ -23,7 +23,8 @@ def per_launch(path, counter):
             wgs = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
             k += " 960->160" if wgs == 32 * (int(sys.argv[3]) // 2) else " 960->320"     # 32 row pairs per image (x2 channel halves)
         if k.endswith("k_fcn_irbd4<true>") or k.endswith("k_fcn_irbd4<true, false>"): k = "ivffcn::k_fcn_irbd4<true> 160->960->160"        # the probe's name for blocks 15 / 16
-        if k.endswith("k_fcn_irbd4<false>") or k.endswith("k_fcn_irbd4<false, false>"): k = "ivffcn::k_fcn_irbd4<false> 160->960->320"     # block 17
+        if k.endswith("k_fcn_irbd4<false>") or k.endswith("k_fcn_irbd4<false, false>"): k = "ivffcn::k_fcn_irbd4<false> 160->960->320"     # block 17 (r03 / r04 form)
+        if k.endswith("k_fcn_irbd4h"): k = "ivffcn::k_fcn_irbd4h 160->960->320"                                                              # block 17 (r05)
         acc[k] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
     return {k: (v * 1024 / len(disp[k]), len(disp[k])) for k, v in acc.items()}
 
