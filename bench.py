@@ -47,7 +47,8 @@ CONFIGS = {
     3: dict(w=1242, h=375, n=2000, ini=20, mn=7, bf=386.1448, fx=718.856, introspect=True, pairs=128, stream=512,
             name="configs[3]: batched 8-level pyramid, 2000 features/frame, 1242x375 stereo stream, introspection FCN + ORB extract + "
                  "L/R Hamming match (frames shard across ranks with the RCCL descriptor all-gather under --gpus N)"),
-    4: dict(w=1920, h=1200, n=4000, ini=12, mn=7, bf=139.38163, fx=1057.911024, introspect=True, pairs=64, stream=128,      # r05: 64 pairs per launch sequence (32: 6,343 pairs/s, 64: 6,711 on one box)
+    4: dict(w=1920, h=1200, n=4000, ini=12, mn=7, bf=139.38163, fx=1057.911024, introspect=True, pairs=128, stream=256,      # r05: 128 pairs per launch sequence
+            # (one box: 32 pairs 6,343 pairs/s and 35 us per frame pair in the tracker step, 64: 6,711-6,735 / 18.7, 128: 6,855 / 10.3 -- the tracker's greedy walk is one wave per pair)
             name="configs[4]: 1920x1200 Jackal stereo stream, 4000 features/frame, FAST 12/7, introspection ON (cost map 1920x1200), "
                  "ORB extract + L/R Hamming match + tracker step (the Tracking loop's matcher calls)"),
 }
@@ -672,6 +673,8 @@ def main():
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     n_timed = min(args.steps * BPS, 64)
+    if fcn is not None:
+        fcn.status(sptr)                 # raises if any forward of the timed region drove an un-clamped activation out of the f16 range
     fast_sum_ms, fast_n = fe.fast_ms_stats(n_timed)
     if fcn is not None:
         probe_sets = {}
