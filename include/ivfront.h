@@ -361,7 +361,9 @@ int  ivf_fcn_forward_device(ivf_fcn* f, const uint8_t* d_bgr, size_t image_strid
  * stereo_kitti.cc:508, have no such limit: the reference would simply go on).  ivf_fcn_forward checks the flag itself and returns
  * IVF_E_STATE instead of a cost map; after ivf_fcn_forward_device call ivf_fcn_status(f, hip_stream): it waits for the stream, returns
  * IVF_E_STATE if any forward of this handle since the last check raised the flag, and clears it.  Non-finite weights are refused by
- * ivf_fcn_create (IVF_E_INVALID). */
+ * ivf_fcn_create (IVF_E_INVALID).  The kernels raise the flag in a word of the DEVICE and the last kernel of a forward moves it into the
+ * handle: when two handles run forwards concurrently on one device (different streams) a flag can be reported by the other handle --
+ * it is never lost. */
 int  ivf_fcn_status(ivf_fcn* f, void* hip_stream);
 
 /* ---- next rows of SURVEY section 8(f) ----
