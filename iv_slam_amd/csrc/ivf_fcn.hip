@@ -164,8 +164,11 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
                                                  const float* __restrict__ s0, const float* __restrict__ b0,
                                                  const float* __restrict__ Wd, const float* __restrict__ sd,
                                                  const float* __restrict__ bd, const float* __restrict__ Wp,
-                                                 const float* __restrict__ sp, const float* __restrict__ bp, float* __restrict__ Y)
+                                                 const float* __restrict__ sp, const float* __restrict__ bp, float* __restrict__ Y,
+                                                 const uint4* __restrict__ Wf)
 {
+    // Wf (r05): the A operands of both GEMMs split into f16 hi / lo fragments ONCE on the host ([conv0 | projection][K step][hi, lo][64 lanes]):
+    // four 16-byte loads per GEMM instead of 16 scalar loads + 8 f16 splits per lane and workgroup (a sixth of this kernel's vector instructions)
     constexpr int O = kEnc / 2, NT = 512;
     __shared__ __attribute__((aligned(16))) float sIn[3 * kStemIH * kStemIP];
     __shared__ __attribute__((aligned(16))) float sC[32 * kStemCP];
@@ -174,13 +177,38 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
     const int cx0 = ox0 - 1, cy0 = oy0 - 1;                     // first conv0 position of the tile
     const int iy0 = 2 * cy0 - 1;                                // first input row (first input column: 2 * cx0 - 1 = LDS column 1)
     const float* Xb = X + (size_t)b * 3 * kEnc * kEnc;
+    // r05: every per-workgroup constant is requested HERE, before the window loads: each used to be a global round trip in the middle
+    // of the workgroup (the taps after the second barrier, the projection's BN in front of the final stores) with nothing to hide it --
+    // the 32 strided scalar loads + 16 splits of the two weight matrices alone were a third of this kernel's time (692 -> 468 us per 128
+    // images with host-made fragments, -> 450 with these)
+    const int dwc = tid >> 4;                                    // the stencil's channel of this thread
+    float wkS[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) wkS[k] = Wd[dwc * 9 + k];
+    const float dscS = sd[dwc], dshS = bd[dwc];
+    float spS[8], bpS[8];                                        // projection BN of this lane's 8 output rows: channels (r & 3) + 8 (r >> 2) + 4 hh
+    {
+        const int hh_ = (tid & 63) >> 5;
+        const float4 a0 = *(const float4*)(sp + 4 * hh_), a1 = *(const float4*)(sp + 8 + 4 * hh_);
+        const float4 c0 = *(const float4*)(bp + 4 * hh_), c1 = *(const float4*)(bp + 8 + 4 * hh_);
+        spS[0] = a0.x; spS[1] = a0.y; spS[2] = a0.z; spS[3] = a0.w; spS[4] = a1.x; spS[5] = a1.y; spS[6] = a1.z; spS[7] = a1.w;
+        bpS[0] = c0.x; bpS[1] = c0.y; bpS[2] = c0.z; bpS[3] = c0.w; bpS[4] = c1.x; bpS[5] = c1.y; bpS[6] = c1.z; bpS[7] = c1.w;
+    }
     {   // 1. aligned float4 loads, all of a thread's loads in flight before the first LDS store
         constexpr int Q4 = 18, N4 = 3 * kStemIH * Q4, IT = (N4 + NT - 1) / NT;
-        float4 v4[IT]; bool ok[IT]; int dst[IT];                // the index is decomposed once per item (three divisions by constants)
+        float4 v4[IT]; bool ok[IT]; int dst[IT];
+        // item i = tid + NT k -> (plane c, row r, float4 q4): decomposed ONCE (three divisions by constants), then advanced by the
+        // constant step NT = DC planes + DR rows + DQ float4s with two carries (r05: the divisions per item were 40 of this kernel's ~750
+        // vector instructions per wave)
+        constexpr int DC = NT / (kStemIH * Q4), DR = (NT % (kStemIH * Q4)) / Q4, DQ = NT % Q4;
+        int c = tid / (kStemIH * Q4), r = (tid / Q4) % kStemIH, q4 = tid % Q4;
 #pragma unroll
         for (int k = 0; k < IT; k++) {
-            const int i = min(tid + NT * k, N4 - 1);
-            const int c = i / (kStemIH * Q4), r = (i / Q4) % kStemIH, q4 = i % Q4;
+            if (k > 0) {
+                q4 += DQ; const int cq = q4 >= Q4 ? 1 : 0; q4 -= cq * Q4;
+                r += DR + cq; const int cr = r >= kStemIH ? 1 : 0; r -= cr * kStemIH;
+                c = min(c + DC + cr, 2);                           // items past the end (not stored) stay inside the three planes
+            }
             const int yy = iy0 + r, xx = 2 * ox0 - 4 + 4 * q4;
             ok[k] = yy >= 0 && yy < kEnc && xx >= 0 && xx < kEnc;
             dst[k] = (c * kStemIH + r) * kStemIP + 4 * q4;
@@ -201,16 +229,14 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
         auto tap_off = [](int k) { return k < 27 ? ((k / 9) * kStemIH + (k / 3) % 3) * kStemIP + k % 3 : 0; };
         HFrag ah[2], al[2];
 #pragma unroll
-        for (int st = 0; st < 2; st++)
+        for (int st = 0; st < 2; st++) { ah[st].q = Wf[((0 * 2 + st) * 2 + 0) * 64 + lane]; al[st].q = Wf[((0 * 2 + st) * 2 + 1) * 64 + lane]; }
+        float sc[16], sh[16];                       // channels (r & 3) + 8 (r >> 2) + 4 hh: four runs of four -> 16-byte loads
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
-                const int k0 = 16 * st + 8 * hh + 2 * jj;
-                const float w0 = k0 < 27 ? W0[col * 27 + k0] : 0.f, w1 = k0 + 1 < 27 ? W0[col * 27 + k0 + 1] : 0.f;
-                split_pair(w0, w1, ah[st].u[jj], al[st].u[jj]);
-            }
-        float sc[16], sh[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) { const int ch = (r & 3) + 8 * (r >> 2) + 4 * hh; sc[r] = s0[ch]; sh[r] = b0[ch]; }
+        for (int r4 = 0; r4 < 4; r4++) {
+            const float4 a = *(const float4*)(s0 + 8 * r4 + 4 * hh), c = *(const float4*)(b0 + 8 * r4 + 4 * hh);
+            sc[4 * r4] = a.x; sc[4 * r4 + 1] = a.y; sc[4 * r4 + 2] = a.z; sc[4 * r4 + 3] = a.w;
+            sh[4 * r4] = c.x; sh[4 * r4 + 1] = c.y; sh[4 * r4 + 2] = c.z; sh[4 * r4 + 3] = c.w;
+        }
         constexpr int NPOS = kStemCW * kStemCH, NTILE = (NPOS + 31) / 32;
         for (int t = wv; t < NTILE; t += 8) {
             const int p = 32 * t + col, pc = min(p, NPOS - 1);
@@ -233,12 +259,19 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st].v, bh.v, acc, 0, 0, 0);
             }
             if (p < NPOS) {
-                const bool inside = (unsigned)(cy0 + py) < (unsigned)O && (unsigned)(cx0 + px) < (unsigned)O;
+                // conv0 positions outside the 256 x 256 map are the depthwise layer's zero padding: only the workgroups on the map's edge have any
+                const bool edgeWg = cy0 < 0 || cx0 < 0 || cy0 + kStemCH > O || cx0 + kStemCW > O;      // workgroup-uniform
+                if (!edgeWg) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int ch = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    const float v = __builtin_amdgcn_fmed3f(__builtin_fmaf(acc[r], sc[r], sh[r]), 0.f, 6.f);
-                    sC[ch * kStemCP + p] = inside ? v : 0.f;
+                    for (int r = 0; r < 16; r++)
+                        sC[((r & 3) + 8 * (r >> 2) + 4 * hh) * kStemCP + p] = __builtin_amdgcn_fmed3f(__builtin_fmaf(acc[r], sc[r], sh[r]), 0.f, 6.f);
+                } else {
+                    const bool inside = (unsigned)(cy0 + py) < (unsigned)O && (unsigned)(cx0 + px) < (unsigned)O;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const float v = __builtin_amdgcn_fmed3f(__builtin_fmaf(acc[r], sc[r], sh[r]), 0.f, 6.f);
+                        sC[((r & 3) + 8 * (r >> 2) + 4 * hh) * kStemCP + p] = inside ? v : 0.f;
+                    }
                 }
             }
         }
@@ -247,11 +280,9 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
     // 3. depthwise 3x3 + BN + ReLU6: thread = channel x 4 adjacent pixels x 4 rows, rolling window down the rows.  The
     //    results return to LDS in place (plane rows 0..7, columns 0..31) once every thread has finished reading
     {
-        const int c = tid >> 4, x4 = (tid & 7) * 4, r0 = ((tid >> 3) & 1) * (kStemTH / 2);
-        float wk[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) wk[k] = Wd[c * 9 + k];
-        const float dsc = sd[c], dsh = bd[c];
+        const int c = dwc, x4 = (tid & 7) * 4, r0 = ((tid >> 3) & 1) * (kStemTH / 2);
+        const float (&wk)[9] = wkS;
+        const float dsc = dscS, dsh = dshS;
         const float* plane = sC + c * kStemCP + r0 * kStemCW + x4;      // conv0 position (row r, col x4 + k) = tile pixel (r - 1, x4 + k - 1)
         float win[3][6], o[kStemTH / 2][4];
 #pragma unroll
@@ -284,13 +315,7 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
     {
         HFrag ah[2], al[2];
 #pragma unroll
-        for (int st = 0; st < 2; st++)
-#pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
-                const int k0 = 16 * st + 8 * hh + 2 * jj;
-                const float w0 = col < 16 ? Wp[col * 32 + k0] : 0.f, w1 = col < 16 ? Wp[col * 32 + k0 + 1] : 0.f;
-                split_pair(w0, w1, ah[st].u[jj], al[st].u[jj]);
-            }
+        for (int st = 0; st < 2; st++) { ah[st].q = Wf[((1 * 2 + st) * 2 + 0) * 64 + lane]; al[st].q = Wf[((1 * 2 + st) * 2 + 1) * 64 + lane]; }
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[q] = 0.f;
@@ -311,7 +336,7 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
 #pragma unroll
         for (int r = 0; r < 8; r++) {                       // rows (r & 3) + 8 (r >> 2) + 4 hh < 16
             const int ch = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const float v = __builtin_fmaf(acc[r], sp[ch], bp[ch]);
+            const float v = __builtin_fmaf(acc[r], spS[r], bpS[r]);
             range_note(amax, v);
             Y[(((size_t)b * 16 + ch) * O + oy0 + wv) * O + ox0 + col] = v;
         }
@@ -361,6 +386,7 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
     __shared__ __attribute__((aligned(16))) float sH[32 * HPL];
     __shared__ __attribute__((aligned(16))) float sD[32 * DPL];
     __shared__ float sT[NG * 32 * TP];
+    __shared__ __attribute__((aligned(16))) float sPB[64];      // the projection's BN scale | shift (r05: fetched with the window, not in front of the final stores)
     const int tid = threadIdx.x, b = blockIdx.z;
     const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
     const int rx0 = ox0 * S - 1, ry0 = oy0 * S - 1;             // window origin in the input map
@@ -371,16 +397,24 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
     for (int st = 0; st < K16; st++) { eh[st].q = WqE[((st * NG + 0) * 2 + 0) * 64 + lane]; el[st].q = WqE[((st * NG + 0) * 2 + 1) * 64 + lane]; }
     {   // A. aligned float4 loads, all of a thread's loads in flight before the first LDS store
         constexpr int N4 = CIN * RH * Q4, IT = (N4 + NT - 1) / NT;
-        float4 v4[IT]; bool ok[IT]; int dst[IT];                // the index is decomposed once per item (three divisions by constants)
+        float4 v4[IT]; bool ok[IT]; int dst[IT];
+        // item i = tid + NT k -> (channel c, row r, float4 q4): decomposed once, then advanced by the constant step NT with two carries
+        // (r05, as in k_fcn_stem: block 4's 4-row tile has eight items per thread)
+        constexpr int DC = NT / (RH * Q4), DR = (NT % (RH * Q4)) / Q4, DQ = NT % Q4;
+        int c = tid / (RH * Q4), r = (tid / Q4) % RH, q4 = tid % Q4;
 #pragma unroll
         for (int k = 0; k < IT; k++) {
-            const int i = min(tid + NT * k, N4 - 1);
-            const int c = i / (RH * Q4), r = (i / Q4) % RH, q4 = i % Q4;
+            if (k > 0) {
+                q4 += DQ; const int cq = q4 >= Q4 ? 1 : 0; q4 -= cq * Q4;
+                r += DR + cq; const int cr = r >= RH ? 1 : 0; r -= cr * RH;
+                c = min(c + DC + cr, CIN - 1);                     // items past the end (not stored) stay inside the tensor
+            }
             const int yy = ry0 + r, xx = ox0 * S - 4 + 4 * q4;
             ok[k] = yy >= 0 && yy < WI && xx >= 0 && xx < WI;
             dst[k] = c * XPL + r * RP + 4 * q4;
             v4[k] = *(const float4*)(Xb + ((size_t)c * WI + (ok[k] ? yy : 0)) * WI + (ok[k] ? xx : 0));
         }
+        if (tid < 64) { const int ch = tid & 31; sPB[tid] = ch < COUT ? (tid < 32 ? sp[ch] : bp[ch]) : 0.f; }
         for (int i = tid; i < NG * 32; i += NT) {
             const bool v = i < HID;
             float* t = sT + i * TP;
@@ -443,11 +477,20 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh[st].v, xh[ti][st].v, acc, 0, 0, 0);
                 }
                 if (n < NPOS) {
-                    const bool inside = (unsigned)(ry0 + r_) < (unsigned)WI && (unsigned)(rx0 + q_) < (unsigned)WI;
+                    // window positions outside the map are the depthwise layer's zero padding: only workgroups on the map's edge have any (r05:
+                    // a workgroup-uniform branch instead of a select per stored value)
+                    const bool edgeWg = ry0 < 0 || rx0 < 0 || ry0 + RH > WI || rx0 + RW > WI;
+                    if (!edgeWg) {
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const float v = __builtin_amdgcn_fmed3f(__builtin_fmaf(acc[r], sc[r], sh[r]), 0.f, 6.f);
-                        sH[((r & 3) + 8 * (r >> 2) + 4 * hh) * HPL + n] = inside ? v : 0.f;
+                        for (int r = 0; r < 16; r++)
+                            sH[((r & 3) + 8 * (r >> 2) + 4 * hh) * HPL + n] = __builtin_amdgcn_fmed3f(__builtin_fmaf(acc[r], sc[r], sh[r]), 0.f, 6.f);
+                    } else {
+                        const bool inside = (unsigned)(ry0 + r_) < (unsigned)WI && (unsigned)(rx0 + q_) < (unsigned)WI;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const float v = __builtin_amdgcn_fmed3f(__builtin_fmaf(acc[r], sc[r], sh[r]), 0.f, 6.f);
+                            sH[((r & 3) + 8 * (r >> 2) + 4 * hh) * HPL + n] = inside ? v : 0.f;
+                        }
                     }
                 }
             }
@@ -508,8 +551,10 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
         for (int r = 0; r < 16; r++) {
             const int ch = (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (ch >= COUT) continue;
-            float v = __builtin_fmaf(accO[r], sp[ch], bp[ch]);
-            if (RES) v += Xb[((size_t)ch * WI + y) * WI + x];
+            float v = __builtin_fmaf(accO[r], sPB[ch], sPB[32 + ch]);
+            // the residual is the block's own input: the centre of the window this workgroup holds in LDS (stride 1, CIN == COUT) -- r05: it
+            // was 16 global loads per lane in front of the final stores, a round trip nothing hid
+            if (RES) v += sX[ch * XPL + (n / TW + 1) * RP + (n % TW + 1) + 3];
             range_note(amax, v);
             Y[(((size_t)b * COUT + ch) * WO + y) * WO + x] = v;
         }
@@ -3447,6 +3492,8 @@ struct ivf_fcn {
     int device = 0, inW = 0, inH = 0, outW = 0, outH = 0, maxBatch = 0;
     float *dConv0W = nullptr, *dConv0S = nullptr, *dConv0B = nullptr;
     float* dProj0W = nullptr;   // block 1's 16 x 32 projection in f32 (k_fcn_stem)
+    uint4* dStemFrag = nullptr; // conv0's and that projection's A operands as f16 hi / lo MFMA fragments (k_fcn_stem)
+    std::vector<float> hConv0W; // conv0's pre-scaled rows (host copy, until dStemFrag is built)
     std::vector<Gemm> pw;        // in forward order: per block expand (t>1), project; then decoder cbr
     std::vector<Dw> dw;
     float* dLastW = nullptr; float lastBias = 0.f;
@@ -3668,7 +3715,7 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
     if (stem) {
         const Dw& d0 = f->dw[0];
         hipLaunchKernelGGL(k_fcn_stem, dim3(kEnc / 2 / kStemTW, kEnc / 2 / kStemTH, n), dim3(512), 0, s, f->bufIn, f->dConv0W, f->dConv0S,
-                           f->dConv0B, d0.dW, d0.dScale, d0.dShift, f->dProj0W, f->pw[0].dScale, f->pw[0].dShift, f->bufB);
+                           f->dConv0B, d0.dW, d0.dScale, d0.dShift, f->dProj0W, f->pw[0].dScale, f->pw[0].dShift, f->bufB, f->dStemFrag);
         STAGE("stem (conv0 + block 1)");
     } else {
         hipLaunchKernelGGL(k_fcn_conv0, dim3(1, kEnc / 2, n), dim3(256), 0, s, f->bufIn, f->dConv0W, f->dConv0S, f->dConv0B, f->bufA);
@@ -3966,6 +4013,7 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
         if (!w || !read_bn(32)) return bad();
         std::vector<float> hw = prescale_rows(w, 32, 27, sc);
         if ((rc = upload(f, hw, &f->dConv0W)) || (rc = upload(f, sc, &f->dConv0S)) || (rc = upload(f, sh, &f->dConv0B))) { ivf_fcn_destroy(f); return rc; }
+        f->hConv0W = hw;
     }
     for (int i = 0; i < 17; i++) {
         const Block& bk = kBlocks[i];
@@ -4003,6 +4051,24 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
             const std::vector<float> ws = prescale_rows(w, bk.oup, hid, sc);
             Gemm g; if ((rc = make_gemm(f, ws.data(), bk.oup, hid, 1, sc, sh, 0, g))) { ivf_fcn_destroy(f); return rc; }
             if (i == 0 && (rc = upload(f, ws, &f->dProj0W))) { ivf_fcn_destroy(f); return rc; }      // same pre-scaled rows, f32 (k_fcn_stem)
+            if (i == 0) {
+                // k_fcn_stem's A fragments (32x32x16: lane = row col & 31, k = 16 st + 8 (lane >> 5) + j): conv0 [32][27 -> 32], projection [16 -> 32][32]
+                std::vector<float> q((size_t)2 * 2 * 2 * 64 * 4, 0.f);
+                uint16_t* q16 = reinterpret_cast<uint16_t*>(q.data());
+                for (int conv = 0; conv < 2; conv++)
+                    for (int st = 0; st < 2; st++)
+                        for (int lane = 0; lane < 64; lane++)
+                            for (int j = 0; j < 8; j++) {
+                                const int col = lane & 31, k = 16 * st + 8 * (lane >> 5) + j;
+                                const float v = conv == 0 ? (k < 27 ? f->hConv0W[(size_t)col * 27 + k] : 0.f) : (col < 16 ? ws[(size_t)col * 32 + k] : 0.f);
+                                const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
+                                const size_t frag = (size_t)(conv * 2 + st) * 2;
+                                q16[((frag + 0) * 64 + lane) * 8 + j] = hi; q16[((frag + 1) * 64 + lane) * 8 + j] = lo;
+                            }
+                float* dq = nullptr;
+                if ((rc = upload(f, q, &dq))) { ivf_fcn_destroy(f); return rc; }
+                f->dStemFrag = reinterpret_cast<uint4*>(dq);
+            }
             f->pw.push_back(g);
             if (f4 && (rc = make_fused4(f, f->f4[i - 14], f4we.data(), f4scE, f4shE, f4wd, f4scD, f4shD, ws.data(), bk.oup))) { ivf_fcn_destroy(f); return rc; }
             if (f1 && (rc = make_fused4(f, f->f1[i - 4], f4we.data(), f4scE, f4shE, f4wd, f4scD, f4shD, ws.data(), bk.oup, bk.inp, hid))) { ivf_fcn_destroy(f); return rc; }

@@ -24,6 +24,11 @@ def _case(rng):
 
 
 IVF_E_GEOMETRY = -3
+SEED0 = int(os.environ.get("IVF_FUZZ_SEED0", "0"))          # long runs on seeds no earlier round has seen: IVF_FUZZ_SEED0=100000 IVF_FUZZ_EXTRACT=2000 ...
+
+
+def _seeds(var, default):
+    return range(SEED0, SEED0 + int(os.environ.get(var, default)))
 
 
 def _valid_case(iv, rng, intro):
@@ -60,7 +65,7 @@ def _valid_case(iv, rng, intro):
     raise AssertionError("no valid geometry in 40 draws")
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("IVF_FUZZ_EXTRACT", "10"))))
+@pytest.mark.parametrize("seed", _seeds("IVF_FUZZ_EXTRACT", "10"))
 def test_extract_random_geometry(iv, seed):
     rng = np.random.default_rng(1000 + seed)
     intro = bool(seed & 1)
@@ -78,7 +83,7 @@ def test_extract_random_geometry(iv, seed):
         assert_kps_equal(gk, ok, what + " noisy"); assert np.array_equal(gd, od), what
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("IVF_FUZZ_FRONTEND", "4"))))
+@pytest.mark.parametrize("seed", _seeds("IVF_FUZZ_FRONTEND", "4"))
 def test_frontend_random_geometry(iv, seed):
     import torch
     rng = np.random.default_rng(2000 + seed)
@@ -105,7 +110,7 @@ def test_frontend_random_geometry(iv, seed):
         assert rl["uright"].tobytes() == our.tobytes() and rl["depth"].tobytes() == odp.tobytes(), what
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("IVF_FUZZ_FCN", "3"))))
+@pytest.mark.parametrize("seed", _seeds("IVF_FUZZ_FCN", "3"))
 def test_fcn_random_sizes_and_batches(iv, seed):
     """the FCN's input / output stages (bilinear to 512 x 512, bilinear to out_size, logistic, u8 truncation) at sizes other
     than the two benchmark shapes, batched, against the torch-CPU layer list (1e-3 bar; u8 within one LSB)."""
@@ -135,7 +140,7 @@ def test_fcn_random_sizes_and_batches(iv, seed):
     assert ds.max() <= (0 if nb == 1 else 1) and (ds != 0).mean() < 0.01
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("IVF_FUZZ_SEARCH", "4"))))
+@pytest.mark.parametrize("seed", _seeds("IVF_FUZZ_SEARCH", "4"))
 def test_window_searches_random_scenarios(iv, seed):
     """SearchByProjection(cur,last) / SearchByProjection(F, mapPoints) on a resident frame, through the host-grid entry point and in
     the oracle, on random frame sizes, feature counts, radii and level windows (incl. windows off the grid, dense windows that
@@ -177,7 +182,7 @@ def test_window_searches_random_scenarios(iv, seed):
         assert gn == on and np.array_equal(ga, oa), what
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("IVF_FUZZ_ALLSEARCH", "3"))))
+@pytest.mark.parametrize("seed", _seeds("IVF_FUZZ_ALLSEARCH", "3"))
 def test_remaining_searches_random_scenarios(iv, seed):
     """SearchForInitialization, ComputeDistinctiveDescriptors, SearchByProjection(KF, Scw), Fuse x2, SearchBySim3, SearchByBoW x2,
     SearchForTriangulation and the relocalisation search on two-frame scenarios of random size / feature count / seed: equality
@@ -270,7 +275,7 @@ def adapter_driver(tmp_path_factory):
     return AS.build_driver(tmp_path_factory.mktemp("adapter_fuzz") / "adapter_driver")
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("IVF_FUZZ_ADAPTER", "3"))))
+@pytest.mark.parametrize("seed", _seeds("IVF_FUZZ_ADAPTER", "3"))
 def test_adapter_random_scenarios(iv, adapter_driver, tmp_path, seed):
     """the compiled C++ adapter (all eleven ORBmatcher signatures on mock Frame / KeyFrame / MapPoint types) on further seeded
     scenarios: every result equal to the projection oracle (the yield checks belong to tests/test_gpu_adapter.py)"""

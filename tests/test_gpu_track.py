@@ -338,7 +338,7 @@ def test_random_records_ties_and_overflowing_windows(iv, seed, nf, cluster, th):
         check_pairs(cam, recs, pairs, a, nm, poses=ps, what="seed %d %r" % (seed, kw), **kw)
 
 
-@pytest.mark.parametrize("seed", range(1000, 1000 + int(os.environ.get("IVF_FUZZ_TRACK", "3"))))
+@pytest.mark.parametrize("seed", range(1000 + int(os.environ.get("IVF_FUZZ_SEED0", "0")), 1000 + int(os.environ.get("IVF_FUZZ_SEED0", "0")) + int(os.environ.get("IVF_FUZZ_TRACK", "3"))))
 def test_random_records_more_seeds(iv, seed):
     """the random-record scenario of the test above with geometry drawn from the seed (IVF_FUZZ_TRACK = number of seeds for soak runs)"""
     rng = np.random.default_rng(seed)
