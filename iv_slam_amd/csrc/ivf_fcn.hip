@@ -358,6 +358,16 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
 // Weights: the expansion's and the projection's A operands come as the f16 hi / lo fragments k_fcn_gemm uses (one
 // 16-byte load per lane and fragment, L2-resident; the projection's are fetched at the top of a group and used after two
 // barriers, the expansion's one group ahead); depthwise taps and all BN scale / shift pairs sit in an LDS table.
+// diagnostic build (tools/build_variant.sh x -DIVF_IRB_TIMING=<input width of the instance: 256 block 2, 128 blocks 3 and 4>): s_memtime sums of wave 0 per
+// phase -- [0] window / table loads issued -> landed in LDS (first barrier), [1] B fragments of the window, [2] B1 expansion, [3] wait at the first
+// barrier of a group, [4] B2 stencil, [5] wait at the second barrier, [6] B3 projection, [7] epilogue; printed by ivf_fcn_destroy
+#ifdef IVF_IRB_TIMING
+__device__ unsigned long long g_irbTim[10];
+#define IRB_TIM(i) do { if (WI == IVF_IRB_TIMING && S == IVF_IRB_TIMING_S) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    tacc[i] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define IRB_TIM(i) do { } while (0)
+#endif
 // output rows per tile of blocks 2 / 3 / 4 (compile-time: tools/build_variant.sh measures others)
 #ifndef IVF_IRB_TH2
 #define IVF_IRB_TH2 2
@@ -374,8 +384,13 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
                                                 const float* __restrict__ se, const float* __restrict__ be,
                                                 const float* __restrict__ Wd, const float* __restrict__ sd,
                                                 const float* __restrict__ bd, const uint4* __restrict__ WqP,
-                                                const float* __restrict__ sp, const float* __restrict__ bp, float* __restrict__ Y)
+                                                const float* __restrict__ sp, const float* __restrict__ bp, float* __restrict__ Y,
+                                                const float4* __restrict__ tab4)
 {
+    // tab4 (r05): the LDS image of sT | sPB ([NG * 32][TP] per-channel parameters, then the projection's BN scale[32] | shift[32]) packed ONCE on the
+    // host: one 16-byte load per thread, requested together with the window -- the thirteen strided scalar loads per channel and the
+    // conditional loads around them were two to three DEPENDENT global round trips in front of the first barrier (phase timers: 19-21k of a
+    // workgroup's 54-61k cycles in blocks 2 / 3)
     constexpr int NT = 512, WO = WI / S, TW = 32;
     constexpr int RW = (TW - 1) * S + 3, RH = (TH - 1) * S + 3, NPOS = RW * RH;       // window of hidden / input positions
     constexpr int Q4 = (RW + 3 + 3) / 4, RP = 4 * Q4, XPL = RH * RP + 4;                // input rows start 3 floats left of the window (16-byte aligned)
@@ -385,13 +400,19 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
     __shared__ __attribute__((aligned(16))) float sX[CIN * XPL];
     __shared__ __attribute__((aligned(16))) float sH[32 * HPL];
     __shared__ __attribute__((aligned(16))) float sD[32 * DPL];
-    __shared__ float sT[NG * 32 * TP];
-    __shared__ __attribute__((aligned(16))) float sPB[64];      // the projection's BN scale | shift (r05: fetched with the window, not in front of the final stores)
+    constexpr int NTAB = NG * 32 * TP + 64, NTAB4 = NTAB / 4, ITT = (NTAB4 + NT - 1) / NT;
+    static_assert(NTAB % 4 == 0, "table is copied in 16-byte pieces");
+    __shared__ __attribute__((aligned(16))) float sTP[NTAB];
+    float* const sT = sTP;                                      // [NG * 32][TP]
+    float* const sPB = sTP + NG * 32 * TP;                      // the projection's BN scale[32] | shift[32]
     const int tid = threadIdx.x, b = blockIdx.z;
     const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
     const int rx0 = ox0 * S - 1, ry0 = oy0 * S - 1;             // window origin in the input map
     const float* Xb = X + (size_t)b * CIN * WI * WI;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, hh = lane >> 5, col = lane & 31;
+#ifdef IVF_IRB_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
     HFrag eh[K16], el[K16];                                     // expansion fragments of the current group
 #pragma unroll
     for (int st = 0; st < K16; st++) { eh[st].q = WqE[((st * NG + 0) * 2 + 0) * 64 + lane]; el[st].q = WqE[((st * NG + 0) * 2 + 1) * 64 + lane]; }
@@ -414,14 +435,13 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
             dst[k] = c * XPL + r * RP + 4 * q4;
             v4[k] = *(const float4*)(Xb + ((size_t)c * WI + (ok[k] ? yy : 0)) * WI + (ok[k] ? xx : 0));
         }
-        if (tid < 64) { const int ch = tid & 31; sPB[tid] = ch < COUT ? (tid < 32 ? sp[ch] : bp[ch]) : 0.f; }
-        for (int i = tid; i < NG * 32; i += NT) {
-            const bool v = i < HID;
-            float* t = sT + i * TP;
-            t[0] = v ? se[i] : 0.f; t[1] = v ? be[i] : 0.f; t[11] = v ? sd[i] : 0.f; t[12] = v ? bd[i] : 0.f;
+        float4 t4[ITT];                                         // the parameter table: branch-free clamped loads, in flight with the window
 #pragma unroll
-            for (int k = 0; k < 9; k++) t[2 + k] = v ? Wd[i * 9 + k] : 0.f;
-        }
+        for (int k = 0; k < ITT; k++) t4[k] = tab4[min(tid + NT * k, NTAB4 - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < ITT; k++)
+            if (tid + NT * k < NTAB4) ((float4*)sTP)[tid + NT * k] = t4[k];
 #pragma unroll
         for (int k = 0; k < IT; k++)
             if (tid + NT * k < N4) *(float4*)&sX[dst[k]] = ok[k] ? v4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -430,6 +450,7 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
 #pragma unroll
     for (int q = 0; q < 16; q++) accO[q] = 0.f;
     __syncthreads();
+    IRB_TIM(0);
     // the expansion's B operand (the input window, split into f16 hi / lo) is the same for every hidden group: a wave
     // builds the fragments of its (at most TPW) position tiles once
     constexpr int TPW = (NTE + 7) / 8;
@@ -447,13 +468,10 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
                 split_pair(x0, x1, xh[ti][st].u[jj], xl[ti][st].u[jj]);
             }
     }
+    IRB_TIM(1);
 #pragma unroll 1
     for (int g = 0; g < NG; g++) {
         HFrag ph[2], pl[2];                                     // projection fragments of this group: needed two barriers from now
-        if (wv < NTP) {
-#pragma unroll
-            for (int st = 0; st < 2; st++) { ph[st].q = WqP[((2 * g + st) * 2 + 0) * 64 + lane]; pl[st].q = WqP[((2 * g + st) * 2 + 1) * 64 + lane]; }
-        }
         {   // B1. expansion of hidden channels 32g .. 32g+31 at every window position
             float sc[16], sh[16];
 #pragma unroll
@@ -494,12 +512,24 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
                     }
                 }
             }
-            if (g + 1 < NG) {                                    // next group's expansion fragments: in flight during B2 / B3
+            // r05: the projection's fragments of THIS group are requested here, behind the expansion's MFMAs: requested at the top of the
+            // group they made the compiler's wait in front of the first MFMA a vmcnt(0) (a control-flow join loses the count) -- a fresh global
+            // round trip at the start of every group, although the expansion's own fragments had been loaded a group earlier
+            // (inside `if (wv < NTP)` like their use: loaded unconditionally the compiler SINKS them into B3's block, two barriers down, right in
+            // front of the MFMAs that need them.  The conservative vmcnt(0) the join costs now falls on waits that have nothing young to wait for)
+            if (wv < NTP) {
 #pragma unroll
-                for (int st = 0; st < K16; st++) { eh[st].q = WqE[((st * NG + g + 1) * 2 + 0) * 64 + lane]; el[st].q = WqE[((st * NG + g + 1) * 2 + 1) * 64 + lane]; }
+                for (int st = 0; st < 2; st++) { ph[st].q = WqP[((2 * g + st) * 2 + 0) * 64 + lane]; pl[st].q = WqP[((2 * g + st) * 2 + 1) * 64 + lane]; }
+            }
+            {                                                    // next group's expansion fragments: in flight during B2 / B3 (past the end: group 0's again, unused)
+                const int gn = g + 1 < NG ? g + 1 : 0;
+#pragma unroll
+                for (int st = 0; st < K16; st++) { eh[st].q = WqE[((st * NG + gn) * 2 + 0) * 64 + lane]; el[st].q = WqE[((st * NG + gn) * 2 + 1) * 64 + lane]; }
             }
         }
+        IRB_TIM(2);
         __syncthreads();
+        IRB_TIM(3);
         {   // B2. depthwise 3x3 (stride S) + BN + ReLU6 of the group
             const int chl = tid >> 4, sub = tid & 15;
             constexpr int PX = TW * TH / 16;                    // pixels per thread: 2, 4 or 8
@@ -527,7 +557,9 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
 #pragma unroll
             for (int p = 0; p < PX; p++) dp[p] = __builtin_amdgcn_fmed3f(__builtin_fmaf(o[p], dsc, dsh), 0.f, 6.f);
         }
+        IRB_TIM(4);
         __syncthreads();
+        IRB_TIM(5);
         if (wv < NTP) {   // B3. projection: K slice = this group's 32 hidden channels, N tile = pixels 32 wv .. 32 wv + 31
             const float* src = sD + 32 * wv + col;
 #pragma unroll
@@ -543,6 +575,7 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
                 accO = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[st].v, bh.v, accO, 0, 0, 0);
             }
         }
+        IRB_TIM(6);
     }
     if (wv < NTP) {   // C. BN (+ residual), store
         const int n = 32 * wv + col, y = oy0 + n / TW, x = ox0 + n % TW;
@@ -560,6 +593,13 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
         }
         range_flag(amax);
     }
+#ifdef IVF_IRB_TIMING
+    if (WI == IVF_IRB_TIMING && S == IVF_IRB_TIMING_S) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        IRB_TIM(7);
+        if (tid == 0) { for (int i = 0; i < 8; i++) atomicAdd(&g_irbTim[i], tacc[i]); atomicAdd(&g_irbTim[8], 1ull); }
+    }
+#endif
 }
 
 // ---- blocks 5-11 (64 x 64 maps, stride 1, dilation 1 or 2, up to 64 input channels): whole block per launch ----
@@ -3493,6 +3533,7 @@ struct ivf_fcn {
     float *dConv0W = nullptr, *dConv0S = nullptr, *dConv0B = nullptr;
     float* dProj0W = nullptr;   // block 1's 16 x 32 projection in f32 (k_fcn_stem)
     uint4* dStemFrag = nullptr; // conv0's and that projection's A operands as f16 hi / lo MFMA fragments (k_fcn_stem)
+    float* dIrbTab[3] = {};     // blocks 2-4: the LDS parameter table of k_fcn_irb ([NG * 32][13] per hidden channel + projection BN scale[32] | shift[32])
     std::vector<float> hConv0W; // conv0's pre-scaled rows (host copy, until dStemFrag is built)
     std::vector<Gemm> pw;        // in forward order: per block expand (t>1), project; then decoder cbr
     std::vector<Dw> dw;
@@ -3775,7 +3816,7 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             const Gemm& ex = f->pw[ip]; const Gemm& pj = f->pw[ip + 1]; const Dw& d = f->dw[id];
 #define IRB(S_, CIN_, HID_, COUT_, RES_, WI_, TH_)                                                                          \
             hipLaunchKernelGGL((k_fcn_irb<S_, CIN_, HID_, COUT_, RES_, WI_, TH_>), dim3(WI_ / S_ / 32, WI_ / S_ / TH_, n), dim3(512), 0, s, x, \
-                               ex.dWq, ex.dScale, ex.dShift, d.dW, d.dScale, d.dShift, pj.dWq, pj.dScale, pj.dShift, y)
+                               ex.dWq, ex.dScale, ex.dShift, d.dW, d.dScale, d.dShift, pj.dWq, pj.dScale, pj.dShift, y, (const float4*)f->dIrbTab[i - 1])
             if (i == 1) IRB(2, 16, 96, 24, false, 256, IVF_IRB_TH2);
             else if (i == 2) IRB(1, 24, 144, 24, true, 128, IVF_IRB_TH3);
             else IRB(2, 24, 144, 32, false, 128, IVF_IRB_TH4);
@@ -4096,6 +4137,28 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
     if ((rc = dalloc(&f->bufIn, B * 3 * kEnc * kEnc)) || (rc = dalloc(&f->bufA, B * 32 * 256 * 256)) ||
         (rc = dalloc(&f->bufB, B * 32 * 256 * 256)) || (rc = dalloc(&f->bufH1, B * big)) || (rc = dalloc(&f->bufH2, B * big)) ||
         (rc = dalloc(&f->bufLogits, B * 64 * 64)) || (rc = dalloc(&f->bufPart, kPartFloats))) { ivf_fcn_destroy(f); return rc; }
+    {   // k_fcn_irb's parameter tables (blocks 2-4): gathered from the per-layer arrays uploaded above
+        size_t ipw = 1, idw = 1;                                // block 1 (t = 1) holds one pointwise and one depthwise layer
+        for (int i = 1; i <= 3; i++) {
+            const Block& bk = kBlocks[i];
+            const int hid = bk.inp * bk.t, ng = (hid + 31) / 32, tp = 13;
+            const Gemm& ex = f->pw[ipw]; const Gemm& pj = f->pw[ipw + 1]; const Dw& d = f->dw[idw];
+            std::vector<float> se(hid), be(hid), wd((size_t)hid * 9), sdv(hid), bdv(hid), spv(bk.oup), bpv(bk.oup);
+            if (hipMemcpy(se.data(), ex.dScale, hid * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(be.data(), ex.dShift, hid * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(wd.data(), d.dW, (size_t)hid * 36, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(sdv.data(), d.dScale, hid * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(bdv.data(), d.dShift, hid * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(spv.data(), pj.dScale, bk.oup * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(bpv.data(), pj.dShift, bk.oup * 4, hipMemcpyDeviceToHost) != hipSuccess) { ivf_fcn_destroy(f); return ffail(IVF_E_NO_DEVICE, "parameter table read-back failed"); }
+            std::vector<float> tab((size_t)ng * 32 * tp + 64, 0.f);
+            for (int c = 0; c < hid; c++) {
+                float* t = tab.data() + (size_t)c * tp;
+                t[0] = se[c]; t[1] = be[c]; t[11] = sdv[c]; t[12] = bdv[c];
+                for (int k = 0; k < 9; k++) t[2 + k] = wd[(size_t)c * 9 + k];
+            }
+            for (int c = 0; c < bk.oup && c < 32; c++) { tab[(size_t)ng * 32 * tp + c] = spv[c]; tab[(size_t)ng * 32 * tp + 32 + c] = bpv[c]; }
+            if ((rc = upload(f, tab, &f->dIrbTab[i - 1]))) { ivf_fcn_destroy(f); return rc; }
+            ipw += 2; idw++;
+        }
+    }
     if (hipMalloc(&f->dStatus, 4 * sizeof(int)) != hipSuccess || hipMemset(f->dStatus, 0, 4 * sizeof(int)) != hipSuccess) {
         ivf_fcn_destroy(f);
         return ffail(IVF_E_NO_DEVICE, "status word allocation failed");
@@ -4127,6 +4190,19 @@ void ivf_fcn_destroy(ivf_fcn* f)
                                 "(residual loads issued -> landed %.0f, BN + stores issued %.0f, stores drained %.0f)\n",
                         wv[3], (double)wv[0] / wv[3], (double)wv[1] / wv[3], (double)wv[2] / wv[3], (double)wv[4] / wv[3], (double)wv[5] / wv[3], (double)wv[6] / wv[3]);
             (void)hipMemcpyToSymbol(HIP_SYMBOL(ivffcn::g_f4Whole), z, sizeof wv);
+        }
+    }
+#endif
+#ifdef IVF_IRB_TIMING
+    {
+        unsigned long long t[10] = {};
+        if (hipMemcpyFromSymbol(t, HIP_SYMBOL(ivffcn::g_irbTim), sizeof t) == hipSuccess && t[8]) {
+            const double n = (double)t[8];
+            fprintf(stderr, "[irb timing WI=%d S=%d] workgroups %.0f; cycles per workgroup (wave 0): loads -> LDS %.0f  window fragments %.0f  B1 expansion %.0f  "
+                            "barrier-1 wait %.0f  B2 stencil %.0f  barrier-2 wait %.0f  B3 projection %.0f  epilogue %.0f\n", IVF_IRB_TIMING, IVF_IRB_TIMING_S, n,
+                    t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n, t[6] / n, t[7] / n);
+            unsigned long long z[10] = {};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(ivffcn::g_irbTim), z, sizeof z);
         }
     }
 #endif
