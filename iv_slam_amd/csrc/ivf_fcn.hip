@@ -375,15 +375,22 @@ __device__ unsigned long long g_irbTim[10];
 #ifndef IVF_IRB_TH3
 #define IVF_IRB_TH3 4
 #endif
+#ifndef IVF_FCN_HEADCHUNK_DEFAULT
+#define IVF_FCN_HEADCHUNK_DEFAULT 0
+#endif
 #ifndef IVF_IRB_TH4
 #define IVF_IRB_TH4 4         // r05, measured per 128 images: block 4 at 1 / 2 / 4 rows 387 / 404 / 327 us; block 3 at 2 / 4 / 8 rows 708 / 468 / 569;
 #endif                        // block 2 at 2 / 4 rows 610 / 730 (profiles/r05_irb_tile_heights.txt): 2, 4, 4
 
+#ifndef IVF_IRB_REP
+#define IVF_IRB_REP 16
+#endif
+constexpr int kIrbRep = IVF_IRB_REP;          // copies of the A fragments of blocks 2-4 in global memory
 template <int S, int CIN, int HID, int COUT, bool RES, int WI, int TH>
-__global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X, const uint4* __restrict__ WqE,
+__global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X, const uint4* __restrict__ WqE_,
                                                 const float* __restrict__ se, const float* __restrict__ be,
                                                 const float* __restrict__ Wd, const float* __restrict__ sd,
-                                                const float* __restrict__ bd, const uint4* __restrict__ WqP,
+                                                const float* __restrict__ bd, const uint4* __restrict__ WqP_,
                                                 const float* __restrict__ sp, const float* __restrict__ bp, float* __restrict__ Y,
                                                 const float4* __restrict__ tab4)
 {
@@ -413,6 +420,16 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
 #ifdef IVF_IRB_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
+    // r05: every wave of every resident workgroup reads the SAME few KB of A fragments per hidden group -- 512 waves per XCD on the same
+    // cache lines, i.e. on a few L2 channels: measured, the wait for fragments requested a whole B2 + B3 earlier was 19k of a workgroup's
+    // 61k cycles (block 3).  The host uploads kIrbRep copies; workgroups on one XCD (linear id = XCD mod 8) take different copies.
+    const uint4* WqE = WqE_; const uint4* WqP = WqP_;
+    {
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned rep_ = (lin >> 3) % (unsigned)kIrbRep;
+        WqE += (size_t)rep_ * (K16 * NG * 128);
+        WqP += (size_t)rep_ * (2 * NG * 128);
+    }
     HFrag eh[K16], el[K16];                                     // expansion fragments of the current group
 #pragma unroll
     for (int st = 0; st < K16; st++) { eh[st].q = WqE[((st * NG + 0) * 2 + 0) * 64 + lane]; el[st].q = WqE[((st * NG + 0) * 2 + 1) * 64 + lane]; }
@@ -433,7 +450,11 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
             const int yy = ry0 + r, xx = ox0 * S - 4 + 4 * q4;
             ok[k] = yy >= 0 && yy < WI && xx >= 0 && xx < WI;
             dst[k] = c * XPL + r * RP + 4 * q4;
+#ifdef IVF_IRB_ABL_PLANE      // timing-only probe (results wrong): every channel's window rows from plane 0 -- is the load phase bound by how many planes a window touches?
+            v4[k] = *(const float4*)(Xb + ((size_t)0 * WI + (ok[k] ? yy : 0)) * WI + (ok[k] ? xx : 0));
+#else
             v4[k] = *(const float4*)(Xb + ((size_t)c * WI + (ok[k] ? yy : 0)) * WI + (ok[k] ? xx : 0));
+#endif
         }
         float4 t4[ITT];                                         // the parameter table: branch-free clamped loads, in flight with the window
 #pragma unroll
@@ -517,15 +538,20 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
             // round trip at the start of every group, although the expansion's own fragments had been loaded a group earlier
             // (inside `if (wv < NTP)` like their use: loaded unconditionally the compiler SINKS them into B3's block, two barriers down, right in
             // front of the MFMAs that need them.  The conservative vmcnt(0) the join costs now falls on waits that have nothing young to wait for)
+#ifdef IVF_IRB_ABL_FRAG        // timing-only probe (results wrong): fragments of group 0 only, loaded once -- what do the per-group fragment loads cost?
+            if (g == 0)
+#endif
             if (wv < NTP) {
 #pragma unroll
                 for (int st = 0; st < 2; st++) { ph[st].q = WqP[((2 * g + st) * 2 + 0) * 64 + lane]; pl[st].q = WqP[((2 * g + st) * 2 + 1) * 64 + lane]; }
             }
+#ifndef IVF_IRB_ABL_FRAG
             {                                                    // next group's expansion fragments: in flight during B2 / B3 (past the end: group 0's again, unused)
                 const int gn = g + 1 < NG ? g + 1 : 0;
 #pragma unroll
                 for (int st = 0; st < K16; st++) { eh[st].q = WqE[((st * NG + gn) * 2 + 0) * 64 + lane]; el[st].q = WqE[((st * NG + gn) * 2 + 1) * 64 + lane]; }
             }
+#endif
         }
         IRB_TIM(2);
         __syncthreads();
@@ -3533,6 +3559,7 @@ struct ivf_fcn {
     float *dConv0W = nullptr, *dConv0S = nullptr, *dConv0B = nullptr;
     float* dProj0W = nullptr;   // block 1's 16 x 32 projection in f32 (k_fcn_stem)
     uint4* dStemFrag = nullptr; // conv0's and that projection's A operands as f16 hi / lo MFMA fragments (k_fcn_stem)
+    float *dIrbWE[3] = {}, *dIrbWP[3] = {};   // blocks 2-4: kIrbRep copies of the expansion's / projection's A fragments (k_fcn_irb)
     float* dIrbTab[3] = {};     // blocks 2-4: the LDS parameter table of k_fcn_irb ([NG * 32][13] per hidden channel + projection BN scale[32] | shift[32])
     std::vector<float> hConv0W; // conv0's pre-scaled rows (host copy, until dStemFrag is built)
     std::vector<Gemm> pw;        // in forward order: per block expand (t>1), project; then decoder cbr
@@ -3744,8 +3771,16 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
 {
     static const bool dbg = getenv("IVF_FCN_DEBUG") != nullptr;
     char nm[64];
-    hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc, n), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn);
-    STAGE("prep");
+    // r05: the 512^2 / 256^2 / 128^2 stage (prep, stem, blocks 2-4) runs in CHUNKS of images, back to back per chunk: a chunk's tensors
+    // (12.6 MB f32 input planes, 4.2 MB stem output, 1.6 MB block outputs per image) are written and read back while they are still in the
+    // 256 MB Infinity Cache instead of after the whole batch (403 MB + 537 MB + ... at 128 images) has gone through HBM
+    static const int headChunkEnv = IVF_EXP_ENV("IVF_FCN_HEADCHUNK") ? atoi(IVF_EXP_ENV("IVF_FCN_HEADCHUNK")) : IVF_FCN_HEADCHUNK_DEFAULT;
+    int headChunk = headChunkEnv;
+    if (headChunk <= 0 || headChunk >= n) headChunk = 0;
+    if (!headChunk) {
+        hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc, n), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn);
+        STAGE("prep");
+    }
     // whole-block kernels, bit i = block i + 2: blocks 2-4 (k_fcn_irb) by default; bits 3-9 = blocks 5-11 through k_fcn_irb64, which
     // is correct but measures slower than expand + dwpw there (337 vs 245 us for the 64->384->64 blocks): opt-in.  Off under the
     // layer-by-layer / other-kernel experiment switches
@@ -3753,7 +3788,34 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
                                     : IVF_EXP_ENV("IVF_FCN_IRBMASK") ? (unsigned)strtoul(IVF_EXP_ENV("IVF_FCN_IRBMASK"), nullptr, 0) : 7u;
     // conv0 + block 1's depthwise layer in one kernel, unless an experiment switch asks for another kernel on block 1
     static const bool stem = IVF_EXP_ENV("IVF_FCN_NOSTEM") == nullptr && IVF_EXP_ENV("IVF_FCN_WIDE256") == nullptr && IVF_EXP_ENV("IVF_FCN_NOFUSE") == nullptr;
-    if (stem) {
+    const bool chunkedHead = headChunk > 0 && stem && (irbMask & 7u) == 7u;
+    if (headChunk > 0 && !chunkedHead) {            // an experiment switch took a head kernel away: the plain schedule
+        hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc, n), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn);
+        STAGE("prep");
+    }
+    if (chunkedHead) {
+        const Dw& d0 = f->dw[0];
+        for (int c0 = 0; c0 < n; c0 += headChunk) {
+            const int nb = std::min(headChunk, n - c0);
+            float* in = f->bufIn + (size_t)c0 * 3 * kEnc * kEnc;
+            float* o1 = f->bufB + (size_t)c0 * 16 * 256 * 256;          // stem (conv0 + block 1)
+            float* o2 = f->bufA + (size_t)c0 * 24 * 128 * 128;          // block 2
+            float* o3 = f->bufB + (size_t)c0 * 24 * 128 * 128;          // block 3 (its chunk's stem output is dead by then; other chunks' live regions lie elsewhere)
+            float* o4 = f->bufA + (size_t)c0 * 32 * 64 * 64;            // block 4: the layout the 64 x 64 stage expects
+            hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc, nb), dim3(256), 0, s, dBgr + (size_t)c0 * imageStride, imageStride, rowStride, f->inW, f->inH, in);
+            hipLaunchKernelGGL(k_fcn_stem, dim3(kEnc / 2 / kStemTW, kEnc / 2 / kStemTH, nb), dim3(512), 0, s, (const float*)in, f->dConv0W, f->dConv0S,
+                               f->dConv0B, d0.dW, d0.dScale, d0.dShift, f->dProj0W, f->pw[0].dScale, f->pw[0].dShift, o1, f->dStemFrag);
+#define IRBC(S_, CIN_, HID_, COUT_, RES_, WI_, TH_, IP_, ID_, X_, Y_, T_)                                                                          \
+            hipLaunchKernelGGL((k_fcn_irb<S_, CIN_, HID_, COUT_, RES_, WI_, TH_>), dim3(WI_ / S_ / 32, WI_ / S_ / TH_, nb), dim3(512), 0, s, (const float*)(X_), \
+                               (const uint4*)f->dIrbWE[T_], f->pw[IP_].dScale, f->pw[IP_].dShift, f->dw[ID_].dW, f->dw[ID_].dScale, f->dw[ID_].dShift, (const uint4*)f->dIrbWP[T_], \
+                               f->pw[IP_ + 1].dScale, f->pw[IP_ + 1].dShift, (Y_), (const float4*)f->dIrbTab[T_])
+            IRBC(2, 16, 96, 24, false, 256, IVF_IRB_TH2, 1, 1, o1, o2, 0);
+            IRBC(1, 24, 144, 24, true, 128, IVF_IRB_TH3, 3, 2, o2, o3, 1);
+            IRBC(2, 24, 144, 32, false, 128, IVF_IRB_TH4, 5, 3, o3, o4, 2);
+#undef IRBC
+        }
+        STAGE("prep + stem + blocks 2-4, chunked");
+    } else if (stem) {
         const Dw& d0 = f->dw[0];
         hipLaunchKernelGGL(k_fcn_stem, dim3(kEnc / 2 / kStemTW, kEnc / 2 / kStemTH, n), dim3(512), 0, s, f->bufIn, f->dConv0W, f->dConv0S,
                            f->dConv0B, d0.dW, d0.dScale, d0.dShift, f->dProj0W, f->pw[0].dScale, f->pw[0].dShift, f->bufB, f->dStemFrag);
@@ -3788,7 +3850,9 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
     float *x = f->bufA, *y = f->bufB;
     int H = kEnc / 2, W = kEnc / 2;
     size_t ip = 0, id = 0;
-    for (int i = 0; i < 17; i++) {
+    int iFirst = 0;
+    if (chunkedHead) { iFirst = 4; ip = 7; id = 4; H = W = 64; }      // blocks 1-4 are done: block 4's output is in bufA = x
+    for (int i = iFirst; i < 17; i++) {
         const Block& bk = kBlocks[i];
         const int hid = bk.inp * bk.t;
         const float* h = x;
@@ -3816,7 +3880,8 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             const Gemm& ex = f->pw[ip]; const Gemm& pj = f->pw[ip + 1]; const Dw& d = f->dw[id];
 #define IRB(S_, CIN_, HID_, COUT_, RES_, WI_, TH_)                                                                          \
             hipLaunchKernelGGL((k_fcn_irb<S_, CIN_, HID_, COUT_, RES_, WI_, TH_>), dim3(WI_ / S_ / 32, WI_ / S_ / TH_, n), dim3(512), 0, s, x, \
-                               ex.dWq, ex.dScale, ex.dShift, d.dW, d.dScale, d.dShift, pj.dWq, pj.dScale, pj.dShift, y, (const float4*)f->dIrbTab[i - 1])
+                               (const uint4*)f->dIrbWE[i - 1], ex.dScale, ex.dShift, d.dW, d.dScale, d.dShift, (const uint4*)f->dIrbWP[i - 1], pj.dScale, pj.dShift, y, \
+                               (const float4*)f->dIrbTab[i - 1])
             if (i == 1) IRB(2, 16, 96, 24, false, 256, IVF_IRB_TH2);
             else if (i == 2) IRB(1, 24, 144, 24, true, 128, IVF_IRB_TH3);
             else IRB(2, 24, 144, 32, false, 128, IVF_IRB_TH4);
@@ -4156,6 +4221,16 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
             }
             for (int c = 0; c < bk.oup && c < 32; c++) { tab[(size_t)ng * 32 * tp + c] = spv[c]; tab[(size_t)ng * 32 * tp + 32 + c] = bpv[c]; }
             if ((rc = upload(f, tab, &f->dIrbTab[i - 1]))) { ivf_fcn_destroy(f); return rc; }
+            {   // replicated A fragments: [kIrbRep][K16 * NG * 128] / [kIrbRep][2 * NG * 128] uint4
+                const int k16 = (bk.inp + 15) / 16;
+                const size_t ne = (size_t)k16 * ng * 128 * 4, np = (size_t)2 * ng * 128 * 4;       // floats
+                std::vector<float> he(ne), hp(np), re(ne * kIrbRep), rp(np * kIrbRep);
+                if (hipMemcpy(he.data(), ex.dWq, ne * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(hp.data(), pj.dWq, np * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+                    ivf_fcn_destroy(f); return ffail(IVF_E_NO_DEVICE, "fragment read-back failed");
+                }
+                for (int r = 0; r < kIrbRep; r++) { memcpy(re.data() + (size_t)r * ne, he.data(), ne * 4); memcpy(rp.data() + (size_t)r * np, hp.data(), np * 4); }
+                if ((rc = upload(f, re, &f->dIrbWE[i - 1])) || (rc = upload(f, rp, &f->dIrbWP[i - 1]))) { ivf_fcn_destroy(f); return rc; }
+            }
             ipw += 2; idw++;
         }
     }
