@@ -2424,6 +2424,9 @@ constexpr size_t kH4Lds = (size_t)2 * 16 * kH4CS * 4 + (size_t)2 * 16 * kH4DP * 
 #ifndef IVF_H4_ABL
 #define IVF_H4_ABL 0          // timing-only ablations (compile time; results wrong): 1 no projection-fragment loads in the loop, 2 E's A fragments read once,
 #endif                        // 4 no LDS-DMA in the loop, 8 no stencil, 16 no halo expansion, 32 no P MFMAs, 64 no E MFMAs
+#ifndef IVF_H4_DMA_SKIP0
+#define IVF_H4_DMA_SKIP0 0
+#endif
 #ifndef IVF_H4_DMA_A
 #define IVF_H4_DMA_A 3        // expansion-weight pieces per wave of the half that reaches the barrier first (waves 0-3); waves 4-7 share the rest of the 11.
                               // Measured 1 / 2 / 3: 1,905 / 1,881 / 1,849 us per 128 images
@@ -2459,6 +2462,13 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4h(const float* __restrict__
     };
     auto dma = [&](int it) { piece(it, uwave); if (uwave < 3) piece(it, uwave + 8); };
     auto dma_late = [&](int it) {               // the same 11 pieces, most of them by waves 0-3, which reach the barrier first
+#if IVF_H4_DMA_SKIP0            // wave 0 also expands the halo row: the pieces go to waves 1-3 (4 + 4 + 3)
+        if (uwave >= 1 && uwave < 4) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const int c = __builtin_amdgcn_readfirstlane((uwave - 1) + 3 * r); if (c < 11) piece(it, c); }
+        }
+        return;
+#endif
         constexpr int NA = IVF_H4_DMA_A, NB = 4 * NA >= 11 ? 0 : (11 - 4 * NA + 3) / 4;
         if (uwave < 4) {
 #pragma unroll
