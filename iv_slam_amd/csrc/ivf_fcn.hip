@@ -2425,7 +2425,10 @@ constexpr size_t kH4Lds = (size_t)2 * 16 * kH4CS * 4 + (size_t)2 * 16 * kH4DP * 
 #define IVF_H4_ABL 0          // timing-only ablations (compile time; results wrong): 1 no projection-fragment loads in the loop, 2 E's A fragments read once,
 #endif                        // 4 no LDS-DMA in the loop, 8 no stencil, 16 no halo expansion, 32 no P MFMAs, 64 no E MFMAs
 #ifndef IVF_H4_DMA_SKIP0
-#define IVF_H4_DMA_SKIP0 0
+#define IVF_H4_DMA_SKIP0 1    // the wave that also expands the halo row (wave 0) issues no LDS-DMA pieces: 1,846 / 1,861 vs 1,874 / 1,911 us per 128 images
+#endif
+#ifndef IVF_H4_HALO_WAVE
+#define IVF_H4_HALO_WAVE 0
 #endif
 #ifndef IVF_H4_DMA_A
 #define IVF_H4_DMA_A 3        // expansion-weight pieces per wave of the half that reaches the barrier first (waves 0-3); waves 4-7 share the rest of the 11.
@@ -2568,7 +2571,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4h(const float* __restrict__
         HFrag ea[2][2], ph, pl;
         ea[0][0] = m.ea0[0]; ea[0][1] = m.ea0[1];
         f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
-        const bool haloWave = uwave == 0;
+        const bool haloWave = uwave == IVF_H4_HALO_WAVE;
         const int gp = it - 2;
         F4_TIM(4);
 #pragma unroll
