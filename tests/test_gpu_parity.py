@@ -731,7 +731,7 @@ def test_frontend_strided_inputs(iv):
 
 def test_two_front_ends_from_two_host_threads(iv):
     """two independent handles driven concurrently from two host threads (a two-camera rig): same results as one after the
-    other (per-thread scratch, per-handle streams, no shared mutable state in the library)"""
+    other (per-thread scratch, no shared mutable state in the library; r05: both handles enqueue on the SAME three pooled internal streams)"""
     import threading
     import torch
     w, h, n, pairs = 640, 240, 500, 2
