@@ -165,7 +165,7 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
                                                  const float* __restrict__ Wd, const float* __restrict__ sd,
                                                  const float* __restrict__ bd, const float* __restrict__ Wp,
                                                  const float* __restrict__ sp, const float* __restrict__ bp, float* __restrict__ Y,
-                                                 const uint4* __restrict__ Wf)
+                                                 const uint4* __restrict__ Wf, int ilOut)
 {
     // Wf (r05): the A operands of both GEMMs split into f16 hi / lo fragments ONCE on the host ([conv0 | projection][K step][hi, lo][64 lanes]):
     // four 16-byte loads per GEMM instead of 16 scalar loads + 8 f16 splits per lane and workgroup (a sixth of this kernel's vector instructions)
@@ -338,7 +338,8 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
             const int ch = (r & 3) + 8 * (r >> 2) + 4 * hh;
             const float v = __builtin_fmaf(acc[r], spS[r], bpS[r]);
             range_note(amax, v);
-            Y[(((size_t)b * 16 + ch) * O + oy0 + wv) * O + ox0 + col] = v;
+            // ilOut: rows of all channels interleaved ([y][channel][x]) -- the consumer's window then touches a few contiguous regions instead of one per plane
+            Y[(size_t)b * 16 * O * O + (ilOut ? ((size_t)(oy0 + wv) * 16 + ch) * O : ((size_t)ch * O + oy0 + wv) * O) + ox0 + col] = v;
         }
         range_flag(amax);
     }
@@ -375,6 +376,9 @@ __device__ unsigned long long g_irbTim[10];
 #ifndef IVF_IRB_TH3
 #define IVF_IRB_TH3 4
 #endif
+#ifndef IVF_FCN_HEAD_IL_DEFAULT
+#define IVF_FCN_HEAD_IL_DEFAULT 0
+#endif
 #ifndef IVF_FCN_HEADCHUNK_DEFAULT
 #define IVF_FCN_HEADCHUNK_DEFAULT 0
 #endif
@@ -392,8 +396,9 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
                                                 const float* __restrict__ Wd, const float* __restrict__ sd,
                                                 const float* __restrict__ bd, const uint4* __restrict__ WqP_,
                                                 const float* __restrict__ sp, const float* __restrict__ bp, float* __restrict__ Y,
-                                                const float4* __restrict__ tab4)
+                                                const float4* __restrict__ tab4, int ilIn, int ilOut)
 {
+    // ilIn / ilOut: the input / output tensor is row-interleaved ([y][channel][x]) instead of planes ([channel][y][x])
     // tab4 (r05): the LDS image of sT | sPB ([NG * 32][TP] per-channel parameters, then the projection's BN scale[32] | shift[32]) packed ONCE on the
     // host: one 16-byte load per thread, requested together with the window -- the thirteen strided scalar loads per channel and the
     // conditional loads around them were two to three DEPENDENT global round trips in front of the first barrier (phase timers: 19-21k of a
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
 #ifdef IVF_IRB_ABL_PLANE      // timing-only probe (results wrong): every channel's window rows from plane 0 -- is the load phase bound by how many planes a window touches?
             v4[k] = *(const float4*)(Xb + ((size_t)0 * WI + (ok[k] ? yy : 0)) * WI + (ok[k] ? xx : 0));
 #else
-            v4[k] = *(const float4*)(Xb + ((size_t)c * WI + (ok[k] ? yy : 0)) * WI + (ok[k] ? xx : 0));
+            v4[k] = *(const float4*)(Xb + (ilIn ? ((size_t)(ok[k] ? yy : 0) * CIN + c) * WI : ((size_t)c * WI + (ok[k] ? yy : 0)) * WI) + (ok[k] ? xx : 0));
 #endif
         }
         float4 t4[ITT];                                         // the parameter table: branch-free clamped loads, in flight with the window
@@ -615,7 +620,7 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
             // was 16 global loads per lane in front of the final stores, a round trip nothing hid
             if (RES) v += sX[ch * XPL + (n / TW + 1) * RP + (n % TW + 1) + 3];
             range_note(amax, v);
-            Y[(((size_t)b * COUT + ch) * WO + y) * WO + x] = v;
+            Y[(size_t)b * COUT * WO * WO + (ilOut ? ((size_t)y * COUT + ch) * WO : ((size_t)ch * WO + y) * WO) + x] = v;
         }
         range_flag(amax);
     }
@@ -3801,6 +3806,9 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
                                     : IVF_EXP_ENV("IVF_FCN_IRBMASK") ? (unsigned)strtoul(IVF_EXP_ENV("IVF_FCN_IRBMASK"), nullptr, 0) : 7u;
     // conv0 + block 1's depthwise layer in one kernel, unless an experiment switch asks for another kernel on block 1
     static const bool stem = IVF_EXP_ENV("IVF_FCN_NOSTEM") == nullptr && IVF_EXP_ENV("IVF_FCN_WIDE256") == nullptr && IVF_EXP_ENV("IVF_FCN_NOFUSE") == nullptr;
+    // r05: the three tensors between the stem and block 4 row-interleaved ([y][channel][x]) when all four kernels are the whole-block ones
+    static const int headIlEnv = IVF_EXP_ENV("IVF_FCN_HEAD_IL") ? atoi(IVF_EXP_ENV("IVF_FCN_HEAD_IL")) : IVF_FCN_HEAD_IL_DEFAULT;
+    const int headIl = (headIlEnv && stem && (irbMask & 7u) == 7u) ? 1 : 0;
     const bool chunkedHead = headChunk > 0 && stem && (irbMask & 7u) == 7u;
     if (headChunk > 0 && !chunkedHead) {            // an experiment switch took a head kernel away: the plain schedule
         hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc, n), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn);
@@ -3817,11 +3825,11 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             float* o4 = f->bufA + (size_t)c0 * 32 * 64 * 64;            // block 4: the layout the 64 x 64 stage expects
             hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc, nb), dim3(256), 0, s, dBgr + (size_t)c0 * imageStride, imageStride, rowStride, f->inW, f->inH, in);
             hipLaunchKernelGGL(k_fcn_stem, dim3(kEnc / 2 / kStemTW, kEnc / 2 / kStemTH, nb), dim3(512), 0, s, (const float*)in, f->dConv0W, f->dConv0S,
-                               f->dConv0B, d0.dW, d0.dScale, d0.dShift, f->dProj0W, f->pw[0].dScale, f->pw[0].dShift, o1, f->dStemFrag);
+                               f->dConv0B, d0.dW, d0.dScale, d0.dShift, f->dProj0W, f->pw[0].dScale, f->pw[0].dShift, o1, f->dStemFrag, headIl);
 #define IRBC(S_, CIN_, HID_, COUT_, RES_, WI_, TH_, IP_, ID_, X_, Y_, T_)                                                                          \
             hipLaunchKernelGGL((k_fcn_irb<S_, CIN_, HID_, COUT_, RES_, WI_, TH_>), dim3(WI_ / S_ / 32, WI_ / S_ / TH_, nb), dim3(512), 0, s, (const float*)(X_), \
                                (const uint4*)f->dIrbWE[T_], f->pw[IP_].dScale, f->pw[IP_].dShift, f->dw[ID_].dW, f->dw[ID_].dScale, f->dw[ID_].dShift, (const uint4*)f->dIrbWP[T_], \
-                               f->pw[IP_ + 1].dScale, f->pw[IP_ + 1].dShift, (Y_), (const float4*)f->dIrbTab[T_])
+                               f->pw[IP_ + 1].dScale, f->pw[IP_ + 1].dShift, (Y_), (const float4*)f->dIrbTab[T_], headIl, (T_ < 2 ? headIl : 0))
             IRBC(2, 16, 96, 24, false, 256, IVF_IRB_TH2, 1, 1, o1, o2, 0);
             IRBC(1, 24, 144, 24, true, 128, IVF_IRB_TH3, 3, 2, o2, o3, 1);
             IRBC(2, 24, 144, 32, false, 128, IVF_IRB_TH4, 5, 3, o3, o4, 2);
@@ -3831,7 +3839,7 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
     } else if (stem) {
         const Dw& d0 = f->dw[0];
         hipLaunchKernelGGL(k_fcn_stem, dim3(kEnc / 2 / kStemTW, kEnc / 2 / kStemTH, n), dim3(512), 0, s, f->bufIn, f->dConv0W, f->dConv0S,
-                           f->dConv0B, d0.dW, d0.dScale, d0.dShift, f->dProj0W, f->pw[0].dScale, f->pw[0].dShift, f->bufB, f->dStemFrag);
+                           f->dConv0B, d0.dW, d0.dScale, d0.dShift, f->dProj0W, f->pw[0].dScale, f->pw[0].dShift, f->bufB, f->dStemFrag, headIl);
         STAGE("stem (conv0 + block 1)");
     } else {
         hipLaunchKernelGGL(k_fcn_conv0, dim3(1, kEnc / 2, n), dim3(256), 0, s, f->bufIn, f->dConv0W, f->dConv0S, f->dConv0B, f->bufA);
@@ -3894,7 +3902,7 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
 #define IRB(S_, CIN_, HID_, COUT_, RES_, WI_, TH_)                                                                          \
             hipLaunchKernelGGL((k_fcn_irb<S_, CIN_, HID_, COUT_, RES_, WI_, TH_>), dim3(WI_ / S_ / 32, WI_ / S_ / TH_, n), dim3(512), 0, s, x, \
                                (const uint4*)f->dIrbWE[i - 1], ex.dScale, ex.dShift, d.dW, d.dScale, d.dShift, (const uint4*)f->dIrbWP[i - 1], pj.dScale, pj.dShift, y, \
-                               (const float4*)f->dIrbTab[i - 1])
+                               (const float4*)f->dIrbTab[i - 1], headIl, (i < 3 ? headIl : 0))
             if (i == 1) IRB(2, 16, 96, 24, false, 256, IVF_IRB_TH2);
             else if (i == 2) IRB(1, 24, 144, 24, true, 128, IVF_IRB_TH3);
             else IRB(2, 24, 144, 32, false, 128, IVF_IRB_TH4);

@@ -30,6 +30,13 @@ def test_bench_line_contract():
     rf = j["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["peak"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 * max(rf["frac"], 1e-9) + 1e-6
     assert "workload" in j["config"]
+    # r05: the line names the FCN kernel with the largest TOTAL time per forward and prints the other whole-block probe beside it, both priced
+    # against the f16 matrix peak as issued and as algorithmic flops; the tracker step covers every frame pair of the launch sequence
+    assert rf["launches_per_forward"] in (1, 2) and rf["total_ms_per_forward"] > 0 and 0 < rf["frac_algorithmic"] < rf["frac_issued"] < 1
+    ob = rf["other_block"]
+    assert ob["kernel"] != rf["kernel"] and 0 < ob["frac_algorithmic"] < ob["frac_issued"] < 1 and ob["total_ms_per_forward"] <= rf["total_ms_per_forward"]
+    assert {rf["kernel"].split(" ")[0], ob["kernel"].split(" ")[0]} == {"ivffcn::k_fcn_irbd4<true>", "ivffcn::k_fcn_irbd4h"}
+    assert j["track"]["frame_pairs_per_launch_sequence"] == 16
 
 
 def test_exchange_step_single_rank():

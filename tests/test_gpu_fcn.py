@@ -141,10 +141,14 @@ print("OK %.3g" % err)
     {"IVF_FCN_FUSED1": "0"},
     # block 17 as two workgroups per 256-pixel tile (k_fcn_irbd4<false>, r03 / r04) instead of the one-pass half-tile kernel k_fcn_irbd4h (r05 default)
     {"IVF_FCN_HALF4": "0"},
+    # r05 experiments kept as paths: the 512 / 256 / 128 stage in chunks of 8 images back to back; its three inner tensors row-interleaved ([y][channel][x])
+    {"IVF_FCN_HEADCHUNK": "8"},
+    {"IVF_FCN_HEAD_IL": "1"},
+    {"IVF_FCN_HEAD_IL": "1", "IVF_FCN_HEADCHUNK": "8"},
     # no small-batch schedule: a single image runs the batched whole-block kernels (16 workgroups per launch) and equals its batch slot bit for bit
     {"IVF_FCN_SPLIT": "0"},
 ], ids=["default", "layerwise", "expand-pxt2", "dwpw-256", "no-stride2-fusion", "no-stem-fusion", "irb-blocks-2-11",
-        "irb-none", "dwpw8-all", "dwpw8-none", "dwpw-4rows-all", "dwpw-4rows-none", "conv-last-unfused", "blocks-8-14-unfused", "blocks-15-17-unfused", "blocks-5-7-unfused", "block-17-two-workgroups", "no-small-batch-split"])
+        "irb-none", "dwpw8-all", "dwpw8-none", "dwpw-4rows-all", "dwpw-4rows-none", "conv-last-unfused", "blocks-8-14-unfused", "blocks-15-17-unfused", "blocks-5-7-unfused", "block-17-two-workgroups", "head-chunked", "head-row-interleaved", "head-chunked-and-interleaved", "no-small-batch-split"])
 def test_fcn_kernel_variants_match_goldens_and_are_deterministic(env):
     """The FCN picks between several kernels per layer (measured defaults, env overrides for tuning).  Every variant must
     meet the same bar, batch results must not depend on the batch slot, and repeated runs must be bit-identical (this is
