@@ -2052,9 +2052,11 @@ __global__ __launch_bounds__(512, 2) void k_fcn_dwpw8(const float* __restrict__ 
 // ring, four 64-pixel waves, the chunked schedule.  Ablation switches of the first version: commit 0a06b2f.
 // Output / residual: the sub-image's pixels are 4 apart in x, so stores are 4-byte pieces of rows that the three sibling workgroups
 // (same image, same y phase, same XCD) complete in L2.
-#ifdef IVF_F4_TIMING
+#if defined(IVF_F4_TIMING) || defined(IVF_D2_TIMING)
 __device__ unsigned long long g_f4Tim[16];      // diagnostic build (make EXTRA=-DIVF_F4_TIMING): cycle sums per phase, waves 0 and 4
 __device__ unsigned long long g_f4Whole[8];     // wave 0: prologue (input gather ... first barrier), interval loop, epilogue; workgroups
+#endif
+#ifdef IVF_F4_TIMING
 #define F4_TIM(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
                        tacc[i] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -2677,7 +2679,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4h(const float* __restrict__
         F4_TIM(3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef IVF_F4_TIMING
+#if defined(IVF_F4_TIMING) && !defined(IVF_F4_TIM_D4ONLY)
     if (lane == 0 && (wave == 0 || wave == 4)) {
         for (int i = 0; i < 7; i++) atomicAdd(&g_f4Tim[(wave ? 8 : 0) + i], tacc[i]);
         atomicAdd(&g_f4Tim[(wave ? 8 : 0) + 7], 1ull);
@@ -3013,6 +3015,9 @@ __global__ __launch_bounds__(256) void k_fcn_split_reduce(const float* __restric
 // DIL 1 (blocks 5-7, ONE 64 x 64 "sub-image"): strip = 4 rows x 64 columns, wave w = half a row (row w >> 1, columns 32 (w & 1) ..),
 // the two halo rows are eight 16-pixel blocks, one per wave.  PITCH = floats per plane row (+ 4 pad), CS = floats per channel plane
 // (+ 4 / + 4: the four 16-lane groups of E's stores, 4 channels apart, start 16 banks apart).
+#ifndef IVF_D2_HALO_LOW
+#define IVF_D2_HALO_LOW 1     // r05: 542 / 330 / 622 / 348 -> 524 / 315 / 609 / 338 us per 128 images (<96,96> / <64,64> / <96,160> / <64,96>)
+#endif
 template <int CIN, int COUT, int DIL = 2>
 struct D2Cfg {
     static constexpr int ROWS = DIL == 2 ? 8 : 4, COLS = DIL == 2 ? 32 : 64, PITCH = COLS + 4, CS = (ROWS + 2) * PITCH + 4;
@@ -3034,6 +3039,15 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
     // SPLIT: this workgroup's contiguous range of hidden groups (see k_fcn_irbd4)
     const int g0 = SPLIT ? (int)(blockIdx.z * NG / gridDim.z) : 0, g1 = SPLIT ? (int)((blockIdx.z + 1) * NG / gridDim.z) : NG;
     extern __shared__ __attribute__((aligned(16))) uint4 d2smem[];
+#ifdef IVF_D2_TIMING      // diagnostic build: -DIVF_D2_TIMING=<CIN * 1000 + COUT> times that instance like IVF_F4_TIMING times k_fcn_irbd4
+    constexpr bool kTimed = CIN * 1000 + COUT == IVF_D2_TIMING && !SPLIT;
+    const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = tk0, tk1 = 0;
+#define D2_TIM(i) do { if (kTimed) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    tacc[i] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define D2_TIM(i) do { } while (0)
+#endif
     float* const sH = (float*)d2smem;                               // [2][16 ch][kD2CS]
     float* const sD = sH + 2 * 16 * kD2CS;                          // [2][16 ch][kF4DP]
     uint4* const sW = (uint4*)(sD + 2 * 16 * kF4DP);                // [3 slots][E: KS x (hi, lo) | P: TILES x (hi, lo)][64 lanes]
@@ -3081,8 +3095,10 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
     // lane: column n = lane & 15, k = 8 (lane >> 4) + j; rows outside the sub-image read as zeros
     const int r0 = DIL == 2 ? 8 * strip + wave : 4 * strip + (wave >> 1);        // (sub-)image row of blocks 0, 1
     const int c0 = DIL == 2 ? 0 : 32 * (wave & 1);                                // their first column
-    const bool hasHalo = DIL == 1 || wave >= 4;
-    const bool above = DIL == 2 ? wave < 6 : wave < 4;
+    // r05: which half of the workgroup expands the four halo blocks (DIL 2).  Phase timers: with waves 4-7 (stencil first, MFMA phase last -- the half that
+    // reaches the barrier last) waves 0-3 idled 960 of an interval's 3,040 cycles at the barrier (k_fcn_irbd2<64,64>); with waves 0-3 the halves arrive together
+    const bool hasHalo = DIL == 1 || (IVF_D2_HALO_LOW ? wave < 4 : wave >= 4);
+    const bool above = DIL == 2 ? (IVF_D2_HALO_LOW ? wave < 2 : wave < 6) : wave < 4;
     const int rH = above ? ROWS * strip - 1 : ROWS * strip + ROWS, cH = DIL == 2 ? 16 * (wave & 1) : 16 * (wave & 3);   // halo block
     constexpr int SUB = 64 / DIL;                                                 // rows / columns of a sub-image
     const bool haloIn = hasHalo && rH >= 0 && rH < SUB;
@@ -3177,7 +3193,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
         }
         // C layout of E: column = lane & 15, row = 4 (lane >> 4) + r (hidden channel of the group)
         float* hpl = sH + cur * (16 * kD2CS) + (4 * (lane >> 4)) * kD2CS + (lane & 15);
-        if (DIL == 1 || uwave >= 4) {           // E(it), block 2: this wave's 16 pixels of a halo row (its fragments are read once more)
+        if (DIL == 1 || (IVF_D2_HALO_LOW ? uwave < 4 : uwave >= 4)) {           // E(it), block 2: this wave's 16 pixels of a halo row (its fragments are read once more)
             f32x4 e2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KS; s++) {
@@ -3246,18 +3262,32 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
                                          __builtin_amdgcn_fmed3f(o[6], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[7], 0.f, 6.f));
     };
 
+#ifdef IVF_D2_TIMING
+    tk1 = tlast = __builtin_amdgcn_s_memtime();
+#endif
     for (int it = g0; it < g1 + 2; it++) {
+        D2_TIM(0);
         {
             MPre m;
             mfma_pre(it, m); __builtin_amdgcn_sched_barrier(0);
-            if (wave < 4) { mfma_main(it, m); stencil_phase(it); }
-            else { stencil_phase(it); __builtin_amdgcn_sched_barrier(0); mfma_main(it, m); }
+            if (wave < 4) { mfma_main(it, m); D2_TIM(1); stencil_phase(it); D2_TIM(2); }
+            else { stencil_phase(it); D2_TIM(2); __builtin_amdgcn_sched_barrier(0); mfma_main(it, m); D2_TIM(1); }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the pieces of it + 1, requested an interval ago
+        D2_TIM(3);
         dma_late(it + 2);                                        // land during it + 1; their slots were last read in it - 1
+        D2_TIM(0);
         __syncthreads();
+        D2_TIM(3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef IVF_D2_TIMING
+    const unsigned long long tk2 = __builtin_amdgcn_s_memtime();
+    if (kTimed && lane == 0 && (wave == 0 || wave == 4)) {
+        for (int i = 0; i < 7; i++) atomicAdd(&g_f4Tim[(wave ? 8 : 0) + i], tacc[i]);
+        atomicAdd(&g_f4Tim[(wave ? 8 : 0) + 7], 1ull);
+    }
+#endif
 
     // ---- epilogue: BN (+ residual) of the projection; pixel n of the wave's row -> image (2 r0 + py, 2 n + px)
     const int n = lane & 31;
@@ -3296,6 +3326,15 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
         }
     }
     if (!SPLIT) range_flag(amaxOut);            // SPLIT: k_fcn_split_reduce checks the finished sums
+#ifdef IVF_D2_TIMING
+    if (kTimed) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            const unsigned long long tk3 = __builtin_amdgcn_s_memtime();
+            atomicAdd(&g_f4Whole[0], tk1 - tk0); atomicAdd(&g_f4Whole[1], tk2 - tk1); atomicAdd(&g_f4Whole[2], tk3 - tk2); atomicAdd(&g_f4Whole[3], 1ull);
+        }
+    }
+#endif
 }
 
 // ---- conv_last 1x1 80 -> 1 + bias (models_light.py:196) ----
@@ -4269,7 +4308,7 @@ void ivf_fcn_destroy(ivf_fcn* f)
     if (!f) return;
     (void)hipSetDevice(f->device);
     (void)hipDeviceSynchronize();
-#ifdef IVF_F4_TIMING
+#if defined(IVF_F4_TIMING) || defined(IVF_D2_TIMING)
     {
         unsigned long long t[16] = {};
         if (hipMemcpyFromSymbol(t, HIP_SYMBOL(ivffcn::g_f4Tim), sizeof t) == hipSuccess && t[7]) {
