@@ -2096,6 +2096,9 @@ __device__ __forceinline__ void lay_pixel(int lay, int tile, int off, int& y, in
 
 constexpr int kF4Cin = 160, kF4Hid = 960, kF4Groups = 60;
 constexpr int kF4HP = 20;                         // floats per 16-pixel sub-row of a hidden plane in LDS (80 B rows)
+#ifndef IVF_RES_FROM_FRAGS
+#define IVF_RES_FROM_FRAGS 1
+#endif
 #ifndef IVF_F4_CS
 #define IVF_F4_CS 324         // floats per channel plane of sH: 16 rows x kF4HP + 4, so that the four 16-lane groups of E's b32 stores hit different banks
 #endif
@@ -2353,8 +2356,14 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     const int oy = 4 * (2 * wave + (n >> 4)) + py, ox = 4 * (n & 15) + px;      // this lane's pixel
     // the residual values of all five tiles are requested at once (the input fragments are dead: 80 registers), BN parameters from LDS.
     // Lane's channels of tile t: cb + (q & 3) + 8 (q >> 2), cb = 32 (tile0 + t) + 4 (lane >> 5)
+    // r05 (IVF_RES_FROM_FRAGS): the residual IS the block's input, which this wave still holds as split-f16 B fragments of the same 32 pixels
+    // (hi + lo = the 22-bit value the expansion multiplied; the residual add then differs from the exact f32 by <= 2^-22 relative).  Re-reading
+    // it from memory cost the epilogue a round trip with every CU of the chip asking at once (phase timers: 34k of a workgroup's ~230k cycles).
+    // The fragments are transposed to the accumulator layout tile by tile through a wave-private 4.6 KB piece of the (now idle) hidden planes.
+    constexpr bool kResFrags = RES && !SPLIT && IVF_RES_FROM_FRAGS;
+    float* const sxw = (float*)f4smem + wave * (32 * 36);
     float rvAll[5][16];
-    if (RES && !SPLIT) {
+    if (RES && !SPLIT && !kResFrags) {
         size_t rb; int rcs;
         lay_addr(layIn, Cout, b, oy, ox, rb, rcs);
         const float* rp = res + rb + (size_t)(tile0 * 32 + 4 * (lane >> 5)) * rcs;
@@ -2378,12 +2387,37 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
         float4 sc4[4], sh4[4];
 #pragma unroll
         for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(sBN + t * 32 + 4 * (lane >> 5) + 8 * g4); sh4[g4] = *(const float4*)(sBN + 160 + t * 32 + 4 * (lane >> 5) + 8 * g4); }
+        float rvT[16];
+        if (kResFrags) {
+            // channels 32 t .. 32 t + 31 of this wave's 32 pixels: fragment lane (column lane & 15, channel group lane >> 4) -> [pixel][channel] in LDS
+            // -> accumulator lane (pixel lane & 31, channels 4 (lane >> 5) + (q & 3) + 8 (q >> 2)).  LDS executes a wave's instructions in order;
+            // the fences only keep the compiler from moving the reads above the writes (and the next tile's writes above these reads)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                float f[8];
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    uint32_t hu = bh[t][u].u[jj], lu = bl[t][u].u[jj];
+                    asm volatile("" : "+v"(hu), "+v"(lu));      // opaque: otherwise the compiler computes these sums in the PROLOGUE (they depend on nothing
+                                                                // in the loop) and parks all 80 in scratch across it -- 360 B per lane spilled and reloaded
+                    const f16x2 h = __builtin_bit_cast(f16x2, hu), l = __builtin_bit_cast(f16x2, lu);
+                    f[2 * jj] = (float)h[0] + (float)l[0]; f[2 * jj + 1] = (float)h[1] + (float)l[1];
+                }
+                float* d = sxw + (16 * u + (lane & 15)) * 36 + 8 * (lane >> 4);
+                *(float4*)d = make_float4(f[0], f[1], f[2], f[3]); *(float4*)(d + 4) = make_float4(f[4], f[5], f[6], f[7]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            const float* sr = sxw + n * 36 + 4 * (lane >> 5);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) { const float4 r = *(const float4*)(sr + 8 * g4); rvT[4 * g4] = r.x; rvT[4 * g4 + 1] = r.y; rvT[4 * g4 + 2] = r.z; rvT[4 * g4 + 3] = r.w; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             float v = pacc[t][q];                   // SPLIT: the raw sums of this range of hidden groups, in the OUTPUT layout
             if (!SPLIT) {
                 v = v * vget<4>(sc4[q >> 2], q & 3) + vget<4>(sh4[q >> 2], q & 3);
-                if (RES) v += rvAll[t][q];
+                if (RES) v += kResFrags ? rvT[q] : rvAll[t][q];
                 range_note(amaxOut, v);
             }
             yp[(size_t)(t * 32 + (q & 3) + 8 * (q >> 2)) * ocs] = v;
@@ -2433,6 +2467,8 @@ constexpr size_t kH4Lds = (size_t)2 * 16 * kH4CS * 4 + (size_t)2 * 16 * kH4DP * 
 #endif                        // 4 no LDS-DMA in the loop, 8 no stencil, 16 no halo expansion, 32 no P MFMAs, 64 no E MFMAs
 #ifndef IVF_H4_DMA_SKIP0
 #define IVF_H4_DMA_SKIP0 1    // the wave that also expands the halo row (wave 0) issues no LDS-DMA pieces: 1,846 / 1,861 vs 1,874 / 1,911 us per 128 images
+                              // (a wave's pieces consecutive, one M0 + one address per wave and the instruction's immediate offset for the rest -- the offset
+                              // moves the LDS address too -- is no faster: 1,823 / 1,842 vs 1,812 / 1,829: the cost of a piece is not its scalar set-up)
 #endif
 #ifndef IVF_H4_HALO_WAVE
 #define IVF_H4_HALO_WAVE 0
