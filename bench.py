@@ -886,13 +886,13 @@ def main():
             m = re.search(r"(\d+)->(\d+)", pname)
             if m3 and roofline["avg_launch_ms"] > 0:
                 # a whole inverted-residual block in one kernel (k_fcn_irbd4): the hidden tensor never reaches HBM, the launch moves
-                # only the block's input, residual and output (a few percent of the HBM roofline by construction) -- it is priced
+                # only the block's input and output (r05: the residual is rebuilt from the input fragments) (a few percent of the HBM roofline by construction) -- it is priced
                 # against the MATRIX pipe: both 1x1 convolutions, three f16 MFMAs per f32 product (hi*hi + hi*lo + lo*hi).
                 cin, hid, cout = (int(v) for v in m3.groups())
                 ms = roofline["avg_launch_ms"]; ims = roofline["isolated"]["avg_launch_ms"]
                 fl = 2.0 * (cin * hid + hid * cout) * 64 * 64 * 3 * probe_batch
                 hbm = {k: roofline[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")}
-                hbm["note"] = "block input + residual + output at 64x64 f32: what this launch moves algorithmically"
+                hbm["note"] = "block input + output at 64x64 f32 (the residual is the input, held in registers): what this launch moves algorithmically"
                 roofline.update({"bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
                                  "frac": round(fl / (ms * 1e-3) / 1e12 / 2500.0, 5), "flops_per_launch": fl,
                                  # both prices of the same launch: `frac` = frac_issued counts the three f16 MFMAs every f32 product

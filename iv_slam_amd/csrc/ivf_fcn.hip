@@ -2099,6 +2099,9 @@ constexpr int kF4HP = 20;                         // floats per 16-pixel sub-row
 #ifndef IVF_RES_FROM_FRAGS
 #define IVF_RES_FROM_FRAGS 1
 #endif
+#ifndef IVF_D2_RES_FROM_FRAGS
+#define IVF_D2_RES_FROM_FRAGS IVF_RES_FROM_FRAGS       // the same for k_fcn_irbd2's residual instances (blocks 6, 7, 9-11, 13, 14)
+#endif
 #ifndef IVF_F4_CS
 #define IVF_F4_CS 324         // floats per channel plane of sH: 16 rows x kF4HP + 4, so that the four 16-lane groups of E's b32 stores hit different banks
 #endif
@@ -3329,8 +3332,13 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
     const int n = lane & 31;
     const int oy = DIL * r0 + py, ox = DIL * (c0 + n) + px;         // this lane's pixel
     // the residual values of all tiles are requested at once (the input fragments are dead), BN parameters from LDS
+    // r05 (IVF_RES_FROM_FRAGS, see k_fcn_irbd4): the residual is this wave's own input fragments (blocks 0, 1 = its 32 pixels, CIN = COUT), transposed per tile
+    // through a wave-private 4.6 KB piece of the hidden planes, which nobody touches after the loop's last barrier
+    constexpr bool kResFrags = RES && !SPLIT && IVF_D2_RES_FROM_FRAGS && CIN == COUT;
+    float* const sxw = (float*)d2smem + wave * (32 * 36);
+    static_assert(!kResFrags || (size_t)2 * 16 * kD2CS * 4 >= (size_t)8 * 32 * 36 * 4, "the transposition scratch lives in the hidden planes");
     float rvAll[TILES][16];
-    if (RES && !SPLIT) {
+    if (RES && !SPLIT && !kResFrags) {
         size_t rb; int rcs;
         lay_addr(layIn, COUT, b, oy, ox, rb, rcs);
         const float* rp = res + rb + (size_t)(4 * (lane >> 5)) * rcs;
@@ -3350,12 +3358,36 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
         float4 sc4[4], sh4[4];
 #pragma unroll
         for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(sBN + cb + 8 * g4); sh4[g4] = *(const float4*)(sBN + COUT + cb + 8 * g4); }
+        float rvT[16];
+        if (kResFrags) {
+            // fragment lane (column lane & 15 of block u, channels 32 t + 8 (lane >> 4) + j) -> [pixel][channel] -> accumulator lane (pixel lane & 31,
+            // channels 32 t + 4 (lane >> 5) + (q & 3) + 8 (q >> 2)); a wave's LDS instructions execute in order, the fences only stop the compiler
+            constexpr int tt = kResFrags ? 1 : 0;   // (keeps bh / bl out of instances that do not use them here)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                float f[8];
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    uint32_t hu = bh[t * tt][u].u[jj], lu = bl[t * tt][u].u[jj];
+                    asm volatile("" : "+v"(hu), "+v"(lu));      // opaque: pins these sums to the epilogue (see k_fcn_irbd4)
+                    const f16x2 h = __builtin_bit_cast(f16x2, hu), l = __builtin_bit_cast(f16x2, lu);
+                    f[2 * jj] = (float)h[0] + (float)l[0]; f[2 * jj + 1] = (float)h[1] + (float)l[1];
+                }
+                float* d = sxw + (16 * u + (lane & 15)) * 36 + 8 * (lane >> 4);
+                *(float4*)d = make_float4(f[0], f[1], f[2], f[3]); *(float4*)(d + 4) = make_float4(f[4], f[5], f[6], f[7]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            const float* sr = sxw + n * 36 + 4 * (lane >> 5);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) { const float4 r = *(const float4*)(sr + 8 * g4); rvT[4 * g4] = r.x; rvT[4 * g4 + 1] = r.y; rvT[4 * g4 + 2] = r.z; rvT[4 * g4 + 3] = r.w; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             float v = pacc[t][q];                   // SPLIT: raw sums of this range of hidden groups, in the OUTPUT layout
             if (!SPLIT) {
                 v = v * vget<4>(sc4[q >> 2], q & 3) + vget<4>(sh4[q >> 2], q & 3);
-                if (RES) v += rvAll[t][q];
+                if (RES) v += kResFrags ? rvT[q] : rvAll[t][q];
                 range_note(amaxOut, v);
             }
             yp[(size_t)(t * 32 + (q & 3) + 8 * (q >> 2)) * ocs] = v;
@@ -3674,7 +3706,7 @@ struct ivf_fcn {
     int probeBatch[kProbe] = {};
     long probeCount = 0;
     char probeName[96] = "";       // the kernel the probe brackets, as dispatched
-    double probeAlgoBytes = 0;     // its algorithmic HBM bytes per image: hidden tensor read + residual read + output written
+    double probeAlgoBytes = 0;     // its algorithmic HBM bytes per image (whole-block kernels: block input + output; the 960 -> 160 kernel: hidden tensor + residual + output)
     // r05: a second probe around block 17 (the largest single launch); ivf_fcn_probe_select picks which one probe_info / probe_stats report
     hipEvent_t probeB0[kProbe] = {}, probeB1[kProbe] = {};
     long probeBCount = 0;
@@ -4077,13 +4109,13 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             if (probe4) {
                 FHIP(hipEventRecord(f->probe1[slot4], s)); f->probeBatch[slot4] = n; f->probeCount++;
                 snprintf(f->probeName, sizeof f->probeName, "ivffcn::k_fcn_irbd4<%s> %d->%d->%d", bk.res ? "true" : "false", bk.inp, hid, bk.oup);
-                f->probeAlgoBytes = (double)(bk.inp + bk.oup * (bk.res ? 2 : 1)) * H * W * sizeof(float);
+                f->probeAlgoBytes = (double)(bk.inp + bk.oup) * H * W * sizeof(float);       // the residual IS the input (read once: r05)
             }
             if (probeB) {
                 FHIP(hipEventRecord(f->probeB1[slotB], s)); f->probeBCount++;
                 if (strcmp(kname, "k_fcn_irbd4h") == 0) snprintf(f->probeBName, sizeof f->probeBName, "ivffcn::k_fcn_irbd4h %d->%d->%d", bk.inp, hid, bk.oup);
                 else snprintf(f->probeBName, sizeof f->probeBName, "ivffcn::k_fcn_irbd4<%s> %d->%d->%d", bk.res ? "true" : "false", bk.inp, hid, bk.oup);
-                f->probeBAlgoBytes = (double)(bk.inp + bk.oup * (bk.res ? 2 : 1)) * H * W * sizeof(float);
+                f->probeBAlgoBytes = (double)(bk.inp + bk.oup) * H * W * sizeof(float);
             }
             ip += 2; id++;
             snprintf(nm, sizeof nm, "block %d whole (dilation-4 phases)", i + 1); STAGE(nm);
