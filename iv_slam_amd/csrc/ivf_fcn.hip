@@ -2094,6 +2094,14 @@ __device__ __forceinline__ void lay_pixel(int lay, int tile, int off, int& y, in
     else { y = 4 * (off >> 4) + (tile >> 2); x = 4 * (off & 15) + (tile & 3); }
 }
 
+// issue priority of the two halves of a whole-block workgroup (waves w and w + 4 share a SIMD; its vector issue is arbitrated by priority, then age):
+//   0 none   1 / 2 static: waves 4-7 / waves 0-3 at priority 1   3 / 4 per phase: priority 1 during the MFMA phase / during the stencil phase
+#ifndef IVF_PRIO
+#define IVF_PRIO 0
+#endif
+#define IVF_PRIO_STATIC() do { if (IVF_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1); if (IVF_PRIO == 2 && wave < 4) __builtin_amdgcn_s_setprio(1); } while (0)
+#define IVF_PRIO_MFMA(on) do { if (IVF_PRIO == 3) __builtin_amdgcn_s_setprio(on); } while (0)
+#define IVF_PRIO_STEN(on) do { if (IVF_PRIO == 4) __builtin_amdgcn_s_setprio(on); } while (0)
 constexpr int kF4Cin = 160, kF4Hid = 960, kF4Groups = 60;
 constexpr int kF4HP = 20;                         // floats per 16-pixel sub-row of a hidden plane in LDS (80 B rows)
 #ifndef IVF_RES_FROM_FRAGS
@@ -2330,13 +2338,14 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
                                          __builtin_amdgcn_fmed3f(o[6], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[7], 0.f, 6.f));
     };
 
+    IVF_PRIO_STATIC();
     for (int it = g0; it < g1 + 2; it++) {
         F4_TIM(0);
         {
             MPre m;
             mfma_pre(it, m); __builtin_amdgcn_sched_barrier(0);
-            if (wave < 4) { mfma_main(it, m); F4_TIM(1); stencil_phase(it); F4_TIM(2); }
-            else { stencil_phase(it); F4_TIM(2); __builtin_amdgcn_sched_barrier(0); mfma_main(it, m); F4_TIM(1); }
+            if (wave < 4) { IVF_PRIO_MFMA(1); mfma_main(it, m); IVF_PRIO_MFMA(0); F4_TIM(1); IVF_PRIO_STEN(1); stencil_phase(it); IVF_PRIO_STEN(0); F4_TIM(2); }
+            else { IVF_PRIO_STEN(1); stencil_phase(it); IVF_PRIO_STEN(0); F4_TIM(2); __builtin_amdgcn_sched_barrier(0); IVF_PRIO_MFMA(1); mfma_main(it, m); IVF_PRIO_MFMA(0); F4_TIM(1); }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the pieces of it + 1, requested an interval ago
         dma_late(it + 2); F4_TIM(0);                             // land during it + 1; their slots were last read in it - 1
@@ -2700,13 +2709,14 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4h(const float* __restrict__
                                    __builtin_amdgcn_fmed3f(o[2], 0.f, 6.f), __builtin_amdgcn_fmed3f(o[3], 0.f, 6.f));
     };
 
+    IVF_PRIO_STATIC();
     for (int it = 0; it < g1 + 2; it++) {
         F4_TIM(0);
         {
             MPre m;
             mfma_pre(it, m); __builtin_amdgcn_sched_barrier(0);
-            if (wave < 4) { mfma_main(it, m); F4_TIM(1); stencil_phase(it); F4_TIM(2); }
-            else { stencil_phase(it); F4_TIM(2); __builtin_amdgcn_sched_barrier(0); mfma_main(it, m); F4_TIM(1); }
+            if (wave < 4) { IVF_PRIO_MFMA(1); mfma_main(it, m); IVF_PRIO_MFMA(0); F4_TIM(1); IVF_PRIO_STEN(1); stencil_phase(it); IVF_PRIO_STEN(0); F4_TIM(2); }
+            else { IVF_PRIO_STEN(1); stencil_phase(it); IVF_PRIO_STEN(0); F4_TIM(2); __builtin_amdgcn_sched_barrier(0); IVF_PRIO_MFMA(1); mfma_main(it, m); IVF_PRIO_MFMA(0); F4_TIM(1); }
         }
         // everything older than this interval's ten projection-fragment loads has landed: the DMA pieces of it + 1, requested an interval ago
         if (IVF_H4_ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else
@@ -3304,13 +3314,14 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
 #ifdef IVF_D2_TIMING
     tk1 = tlast = __builtin_amdgcn_s_memtime();
 #endif
+    IVF_PRIO_STATIC();
     for (int it = g0; it < g1 + 2; it++) {
         D2_TIM(0);
         {
             MPre m;
             mfma_pre(it, m); __builtin_amdgcn_sched_barrier(0);
-            if (wave < 4) { mfma_main(it, m); D2_TIM(1); stencil_phase(it); D2_TIM(2); }
-            else { stencil_phase(it); D2_TIM(2); __builtin_amdgcn_sched_barrier(0); mfma_main(it, m); D2_TIM(1); }
+            if (wave < 4) { IVF_PRIO_MFMA(1); mfma_main(it, m); IVF_PRIO_MFMA(0); D2_TIM(1); IVF_PRIO_STEN(1); stencil_phase(it); IVF_PRIO_STEN(0); D2_TIM(2); }
+            else { IVF_PRIO_STEN(1); stencil_phase(it); IVF_PRIO_STEN(0); D2_TIM(2); __builtin_amdgcn_sched_barrier(0); IVF_PRIO_MFMA(1); mfma_main(it, m); IVF_PRIO_MFMA(0); D2_TIM(1); }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the pieces of it + 1, requested an interval ago
         D2_TIM(3);
