@@ -2104,8 +2104,14 @@ __device__ __forceinline__ void lay_pixel(int lay, int tile, int off, int& y, in
 #define IVF_PRIO_STEN(on) do { if (IVF_PRIO == 4) __builtin_amdgcn_s_setprio(on); } while (0)
 constexpr int kF4Cin = 160, kF4Hid = 960, kF4Groups = 60;
 constexpr int kF4HP = 20;                         // floats per 16-pixel sub-row of a hidden plane in LDS (80 B rows)
+#ifndef IVF_F4_WALK
+#define IVF_F4_WALK 0         // blocks 15 / 16 as a persistent grid (see k_fcn_irbd2): 953 -> 1,138 us, the tile loop makes the 256-register body spill; off
+#endif
 #ifndef IVF_RES_FROM_FRAGS
 #define IVF_RES_FROM_FRAGS 1
+#endif
+#ifndef IVF_D2_WALK_ALL
+#define IVF_D2_WALK_ALL 0
 #endif
 #ifndef IVF_D2_RES_FROM_FRAGS
 #define IVF_D2_RES_FROM_FRAGS IVF_RES_FROM_FRAGS       // the same for k_fcn_irbd2's residual instances (blocks 6, 7, 9-11, 13, 14)
@@ -2132,10 +2138,15 @@ template <bool RES, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ X, const uint4* __restrict__ WE, const float* __restrict__ par,
                                                      const uint4* __restrict__ WP, const float* __restrict__ scP, const float* __restrict__ shP,
                                                      const float* __restrict__ res, float* __restrict__ Y, int Cout, int tilesP, float* __restrict__ part,
-                                                     int layIn, int layOut)
+                                                     int layIn, int layOut, int nT)
 {
     const int g0 = SPLIT ? (int)(blockIdx.z * kF4Groups / gridDim.z) : 0, g1 = SPLIT ? (int)((blockIdx.z + 1) * kF4Groups / gridDim.z) : kF4Groups;
     extern __shared__ __attribute__((aligned(16))) uint4 f4smem[];
+    // nT = tiles of the launch (16 per image); blocks 15 / 16 may run as a persistent grid that walks them (see k_fcn_irbd2)
+    constexpr bool kWalk = IVF_F4_WALK && RES && !SPLIT;
+    const int perX_ = nT >> 3, strideX_ = (int)gridDim.x >> 3;
+    int slot_ = (int)blockIdx.x >> 3;
+    do {
 #ifdef IVF_F4_TIMING
     const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -2145,8 +2156,14 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     uint4* const sWP = sWE + kF4WSlots * 640;                       // [slots][5 tiles][hi, lo][64 lanes]
     float* const sPar = (float*)(sWP + kF4WSlots * 640);            // [slots][16 ch][12]: 9 taps (x dw BN scale), dw BN shift, expansion BN scale, shift
     float* const sBN = sPar + kF4PSlots * (kF4ParB / 4);            // [scale 160 | shift 160] of the projection (epilogue)
+#if IVF_F4_WALK
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));      // opaque per tile: otherwise every lane-dependent constant of the body is hoisted out of the tile walk and kept live across it (spills)
+    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
+#else
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;     // consecutive L on one XCD (grid x = 16 * images)
+#endif
+    const int nwg = nT, L = (int)(blockIdx.x & 7) * perX_ + slot_;                    // consecutive L on one XCD (nT = 16 * images)
     const int b = L >> 4, py = (L >> 2) & 3, px = L & 3;
     const int tile0 = blockIdx.y * 5;
     constexpr int HW = 4096;
@@ -2446,6 +2463,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
         atomicAdd(&g_f4Whole[4], tkA - tk2); atomicAdd(&g_f4Whole[5], tkB - tkA); atomicAdd(&g_f4Whole[6], tk3 - tkB);
     }
 #endif
+    } while (kWalk && (slot_ += strideX_) < perX_);      // tiles of this workgroup
 }
 
 // ---- k_fcn_irbd4h (r05): block 17 (160 -> 960 -> 320, no residual) in ONE pass over the hidden groups ----
@@ -2485,24 +2503,37 @@ constexpr size_t kH4Lds = (size_t)2 * 16 * kH4CS * 4 + (size_t)2 * 16 * kH4DP * 
 #ifndef IVF_H4_HALO_WAVE
 #define IVF_H4_HALO_WAVE 0
 #endif
+#ifndef IVF_H4_WALK
+#define IVF_H4_WALK 0         // block 17 as a persistent grid: 1,785 -> 1,888 us (the tile loop around a 242-register body spills 104 B per lane); off
+#endif
 #ifndef IVF_H4_DMA_A
 #define IVF_H4_DMA_A 3        // expansion-weight pieces per wave of the half that reaches the barrier first (waves 0-3); waves 4-7 share the rest of the 11.
                               // Measured 1 / 2 / 3: 1,905 / 1,881 / 1,849 us per 128 images
 #endif
 __global__ __launch_bounds__(512, 2) void k_fcn_irbd4h(const float* __restrict__ X, const uint4* __restrict__ WE, const float* __restrict__ par,
                                                       const uint4* __restrict__ WP, const float* __restrict__ scP, const float* __restrict__ shP,
-                                                      float* __restrict__ Y, int layIn, int layOut)
+                                                      float* __restrict__ Y, int layIn, int layOut, int nT)
 {
     constexpr int g1 = kF4Groups;
     extern __shared__ __attribute__((aligned(16))) uint4 f4smem[];
+    // nT = tiles of the launch (32 per image); the grid may be one workgroup per CU that walks them (see k_fcn_irbd2)
+    const int perX_ = nT >> 3, strideX_ = (int)gridDim.x >> 3;
+    int slot_ = (int)blockIdx.x >> 3;
+    do {
     float* const sH = (float*)f4smem;                               // [2][16 ch][kH4CS]
     float* const sD = sH + 2 * 16 * kH4CS;                          // [2][16 ch][kH4DP]
     uint4* const sWE = (uint4*)(sD + 2 * 16 * kH4DP);               // [slots][5 K steps][hi, lo][64 lanes]
     float* const sPar = (float*)(sWE + kF4WSlots * 640);            // [slots][16 ch][12]
     float* const sBN = sPar + kF4PSlots * (kF4ParB / 4);            // [scale 320 | shift 320] of the projection (epilogue)
     uint4* const sXH = (uint4*)(sBN + 2 * kH4Cout);                 // [5 K steps][hi, lo][64 lanes]: input fragments of the halo sub-row
+#if IVF_H4_WALK
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));      // opaque per tile: otherwise every lane-dependent constant of the body is hoisted out of the tile walk and kept live across it (spills)
+    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
+#else
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;     // consecutive L on one XCD (grid x = 32 * images)
+#endif
+    const int L = (int)(blockIdx.x & 7) * perX_ + slot_;                              // consecutive L on one XCD (nT = 32 * images)
     const int b = L >> 5, py = (L >> 3) & 3, px = (L >> 1) & 3, half = L & 1;
     const int r0 = 8 * half;                                        // first own sub-row
     const int haloRow = half ? 7 : 8, haloSlot = half ? 0 : 9;      // row slot s holds sub-row r0 - 1 + s
@@ -2756,6 +2787,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4h(const float* __restrict__
         }
     }
     range_flag(amaxOut);
+    } while (IVF_H4_WALK && (slot_ += strideX_) < perX_);      // tiles of this workgroup
 }
 
 #ifdef IVF_EXPERIMENT      // opt-in variant (IVF_FCN_ROLES=1) with a run-time ablation mask: experiment builds only
@@ -3073,6 +3105,7 @@ struct D2Cfg {
     static constexpr int KS = CIN / 32, TILES = COUT / 32, HID = 6 * CIN, NG = HID / 16;
     static constexpr int NPE = 2 * KS, NPP = 2 * TILES, NP = NPE + NPP + 1;              // 1 KB pieces per interval (+ parameters)
     static constexpr int WSLOT = (NPE + NPP) * 64;                                        // uint4 per weight slot
+    static constexpr bool WALK = IVF_D2_WALK_ALL || !(CIN == 96 && COUT == 160);                          // may run as a persistent grid (k_fcn_irbd2)
     static constexpr size_t LDS = (size_t)2 * 16 * CS * 4 + (size_t)2 * 16 * kF4DP * 4 + (size_t)3 * WSLOT * 16 + 4 * kF4ParB + 2 * COUT * 4;
 };
 
@@ -3080,14 +3113,23 @@ template <int CIN, int COUT, bool RES, int DIL = 2, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ X, const uint4* __restrict__ WE, const float* __restrict__ par,
                                                      const uint4* __restrict__ WP, const float* __restrict__ scP, const float* __restrict__ shP,
                                                      const float* __restrict__ res, float* __restrict__ Y, float* __restrict__ part,
-                                                     int layIn, int layOut)
+                                                     int layIn, int layOut, int nT)
 {
+    // nT = tiles of the launch (16 per image).  r05: the grid may be SMALLER than that -- one workgroup per CU that walks its share of the tiles (persistent form):
+    // the stores of a tile's epilogue drain while the next tile's input gather and first LDS-DMA pieces are already in flight, and the per-tile dispatch of a
+    // fresh 8-wave workgroup (register file + LDS of a whole CU) disappears.  grid = nT is the one-tile-per-workgroup form of r03 / r04.
     using C = D2Cfg<CIN, COUT, DIL>;
     constexpr int kD2CS = C::CS, PITCH = C::PITCH, ROWS = C::ROWS, COLS = C::COLS;
     constexpr int KS = C::KS, TILES = C::TILES, NG = C::NG, NPE = C::NPE, NPP = C::NPP, NP = C::NP, WSLOT = C::WSLOT;
     // SPLIT: this workgroup's contiguous range of hidden groups (see k_fcn_irbd4)
     const int g0 = SPLIT ? (int)(blockIdx.z * NG / gridDim.z) : 0, g1 = SPLIT ? (int)((blockIdx.z + 1) * NG / gridDim.z) : NG;
     extern __shared__ __attribute__((aligned(16))) uint4 d2smem[];
+    // tiles of XCD x (= blockIdx % 8: consecutive tiles of an image share an L2): [x * nT / 8, (x + 1) * nT / 8), walked with the stride of the XCD's workgroups
+    // (compile-time off for the SPLIT instances -- their grid is always nT -- and for <96,160>, whose 240 registers spill with the loop around them: 600 -> 671 us)
+    constexpr bool kWalk = D2Cfg<CIN, COUT, DIL>::WALK && !SPLIT;
+    const int perX_ = nT >> 3, strideX_ = (int)gridDim.x >> 3;
+    int slot_ = (int)blockIdx.x >> 3;
+    do {
 #ifdef IVF_D2_TIMING      // diagnostic build: -DIVF_D2_TIMING=<CIN * 1000 + COUT> times that instance like IVF_F4_TIMING times k_fcn_irbd4
     constexpr bool kTimed = CIN * 1000 + COUT == IVF_D2_TIMING && !SPLIT;
     const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
@@ -3102,8 +3144,10 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
     uint4* const sW = (uint4*)(sD + 2 * 16 * kF4DP);                // [3 slots][E: KS x (hi, lo) | P: TILES x (hi, lo)][64 lanes]
     float* const sPar = (float*)(sW + 3 * WSLOT);                   // [4 slots][16 ch][12]
     float* const sBN = sPar + 4 * (kF4ParB / 4);                    // [scale COUT | shift COUT] of the projection (epilogue)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;     // consecutive L on one XCD (grid x = 16 * images)
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));      // opaque per tile: otherwise every lane-dependent constant of the body is hoisted out of the tile walk and kept live across it (spills)
+    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
+    const int nwg = nT, L = (int)(blockIdx.x & 7) * perX_ + slot_;                    // consecutive L on one XCD (nT = 16 * images)
     const int b = L >> 4, py = DIL == 2 ? (L >> 3) & 1 : 0, px = DIL == 2 ? (L >> 2) & 1 : 0, strip = DIL == 2 ? L & 3 : L & 15;
     constexpr int HW = 4096;
     const unsigned ldsBase = (unsigned)(uintptr_t)d2smem;
@@ -3414,6 +3458,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
         }
     }
 #endif
+    } while (kWalk && (slot_ += strideX_) < perX_);      // tiles of this workgroup
 }
 
 // ---- conv_last 1x1 80 -> 1 + bias (models_light.py:196) ----
@@ -3692,6 +3737,7 @@ using namespace ivffcn;
 
 struct ivf_fcn {
     int device = 0, inW = 0, inH = 0, outW = 0, outH = 0, maxBatch = 0;
+    int numCU = 0;              // compute units of the device (persistent grids of the whole-block kernels)
     float *dConv0W = nullptr, *dConv0S = nullptr, *dConv0B = nullptr;
     float* dProj0W = nullptr;   // block 1's 16 x 32 projection in f32 (k_fcn_stem)
     uint4* dStemFrag = nullptr; // conv0's and that projection's A operands as f16 hi / lo MFMA fragments (k_fcn_stem)
@@ -3889,6 +3935,16 @@ int split_ways(int n, int groups, int cout)
     while (ns > 1 && (size_t)ns * n * cout * 4096 > kPartFloats) ns--;
     return std::max(ns, 1);
 }
+// Persistent form of a whole-block kernel (r05): one workgroup per CU that walks its XCD's tiles, when every workgroup gets at least two.
+#ifndef IVF_PERSIST
+#define IVF_PERSIST 1
+#endif
+int persistent_grid(const ivf_fcn* f, int tiles)
+{
+    static const int mode = IVF_EXP_ENV("IVF_FCN_PERSIST") ? atoi(IVF_EXP_ENV("IVF_FCN_PERSIST")) : IVF_PERSIST;      // 0 = one tile per workgroup
+    const int g = f->numCU & ~7;                                                                                       // whole XCD slots
+    return (mode && g >= 8 && tiles >= 2 * g && tiles % 8 == 0) ? g : tiles;
+}
 void launch_split_reduce(ivf_fcn* f, int ns, int n, int cout, const Gemm& pj, const float* res, float* y, int layIn, int layOut, hipStream_t s)
 {
     const size_t total4 = (size_t)n * cout * 1024;
@@ -4037,8 +4093,8 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             const Gemm& pj = f->pw[ip + 1];
             bool ok = true;
             auto go = [&](auto kern, size_t lds) {                                               // LDS reserved per instantiation by reserve_lds()
-                hipLaunchKernelGGL(kern, dim3(16 * n), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, bk.res ? x : (const float*)nullptr, y,
-                                   (float*)nullptr, layIn, layOut);
+                hipLaunchKernelGGL(kern, dim3(persistent_grid(f, 16 * n)), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, bk.res ? x : (const float*)nullptr, y,
+                                   (float*)nullptr, layIn, layOut, 16 * n);
             };
             if (bk.oup == 32 && bk.res) go(&k_fcn_irbd2<32, 32, true, 1>, D2Cfg<32, 32, 1>::LDS);
             else if (bk.oup == 64 && !bk.res) go(&k_fcn_irbd2<32, 64, false, 1>, D2Cfg<32, 64, 1>::LDS);
@@ -4055,19 +4111,19 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             bool ok = true;
             // small batches: the hidden groups are cut into `ns` ranges over gridDim.z, partial sums through f->bufPart (see k_fcn_irbd4)
             const int ns = split_ways(n, hid / 16, bk.oup);
-            auto go = [&](auto kern, auto kernSplit, size_t lds) {                               // LDS reserved per instantiation by reserve_lds()
+            auto go = [&](auto kern, auto kernSplit, size_t lds, bool walk = true) {             // LDS reserved per instantiation by reserve_lds()
                 if (ns > 1) {
                     hipLaunchKernelGGL(kernSplit, dim3(16 * n, 1, ns), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y,
-                                       f->bufPart, layIn, layOut);
+                                       f->bufPart, layIn, layOut, 16 * n);
                     launch_split_reduce(f, ns, n, bk.oup, pj, bk.res ? x : nullptr, y, layIn, layOut, s);
                 } else
-                    hipLaunchKernelGGL(kern, dim3(16 * n), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, bk.res ? x : (const float*)nullptr, y,
-                                       (float*)nullptr, layIn, layOut);
+                    hipLaunchKernelGGL(kern, dim3(walk ? persistent_grid(f, 16 * n) : 16 * n), dim3(512), lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift,
+                                       bk.res ? x : (const float*)nullptr, y, (float*)nullptr, layIn, layOut, 16 * n);
             };
             if (bk.inp == 64 && bk.oup == 64 && bk.res) go(&k_fcn_irbd2<64, 64, true>, &k_fcn_irbd2<64, 64, true, 2, true>, D2Cfg<64, 64>::LDS);
             else if (bk.inp == 64 && bk.oup == 96 && !bk.res) go(&k_fcn_irbd2<64, 96, false>, &k_fcn_irbd2<64, 96, false, 2, true>, D2Cfg<64, 96>::LDS);
             else if (bk.inp == 96 && bk.oup == 96 && bk.res) go(&k_fcn_irbd2<96, 96, true>, &k_fcn_irbd2<96, 96, true, 2, true>, D2Cfg<96, 96>::LDS);
-            else if (bk.inp == 96 && bk.oup == 160 && !bk.res) go(&k_fcn_irbd2<96, 160, false>, &k_fcn_irbd2<96, 160, false, 2, true>, D2Cfg<96, 160>::LDS);
+            else if (bk.inp == 96 && bk.oup == 160 && !bk.res) go(&k_fcn_irbd2<96, 160, false>, &k_fcn_irbd2<96, 160, false, 2, true>, D2Cfg<96, 160>::LDS, D2Cfg<96, 160>::WALK);
             else ok = false;
             if (!ok) return ffail(IVF_E_NO_DEVICE, "block %d: no k_fcn_irbd2 instance / LDS reservation failed", i + 1);
             ip += 2; id++;
@@ -4105,18 +4161,19 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
 #endif
             if (ns > 1) {
                 hipLaunchKernelGGL((k_fcn_irbd4<false, true>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y,
-                                   F.cout, F.tilesP, f->bufPart, layIn, layOut);
+                                   F.cout, F.tilesP, f->bufPart, layIn, layOut, 16 * n);
                 launch_split_reduce(f, ns, n, F.cout, pj, bk.res ? x : nullptr, y, layIn, layOut, s);
             } else if (half4 && !bk.res && F.cout == kH4Cout && F.tilesP == kH4TilesP)
             {   // block 17 in ONE pass: half a sub-image (128 pixels) x all 320 outputs per workgroup
-                hipLaunchKernelGGL(k_fcn_irbd4h, dim3(32 * n), dim3(512), kH4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, y, layIn, layOut);
+                hipLaunchKernelGGL(k_fcn_irbd4h, dim3(IVF_H4_WALK ? persistent_grid(f, 32 * n) : 32 * n), dim3(512), kH4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, y,
+                                   layIn, layOut, 32 * n);
                 kname = "k_fcn_irbd4h";
             } else if (bk.res)
-                hipLaunchKernelGGL((k_fcn_irbd4<true>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, x, y, F.cout, F.tilesP, (float*)nullptr,
-                                   layIn, layOut);
+                hipLaunchKernelGGL((k_fcn_irbd4<true>), dim3(IVF_F4_WALK && grid.y == 1 ? persistent_grid(f, 16 * n) : 16 * n, grid.y, 1), dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale,
+                                   pj.dShift, x, y, F.cout, F.tilesP, (float*)nullptr, layIn, layOut, 16 * n);
             else
                 hipLaunchKernelGGL((k_fcn_irbd4<false>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y, F.cout, F.tilesP,
-                                   (float*)nullptr, layIn, layOut);
+                                   (float*)nullptr, layIn, layOut, 16 * n);
             if (probe4) {
                 FHIP(hipEventRecord(f->probe1[slot4], s)); f->probeBatch[slot4] = n; f->probeCount++;
                 snprintf(f->probeName, sizeof f->probeName, "ivffcn::k_fcn_irbd4<%s> %d->%d->%d", bk.res ? "true" : "false", bk.inp, hid, bk.oup);
@@ -4240,6 +4297,7 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
     FHIP(hipSetDevice(device_id));
     { const int lrc = reserve_lds(); if (lrc) return lrc; }
     ivf_fcn* f = new ivf_fcn();
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess) f->numCU = cus; }
     f->device = device_id; f->inW = in_width; f->inH = in_height; f->outW = out_width; f->outH = out_height; f->maxBatch = max_batch;
     for (size_t i = 0; i < n_floats; i++)
         if (!std::isfinite(weights_blob[i])) return ffail(IVF_E_INVALID, "weight blob holds a non-finite value at float %zu", i);
