@@ -180,13 +180,17 @@ def test_fcn_small_batch_schedule_agrees_with_the_batched_one(iv):
     assert np.array_equal(c1, c1b)
     flipped = bgr[:, ::-1].copy()
     ref = None
-    for nb in (128, 8, 4, 2):
+    # 48 / 33: k_fcn_irbd2 as a persistent grid (r05: one workgroup per CU walks 3 / 2-or-3 tiles -- the ragged walk); 16: the last batch on the one-tile grid
+    for nb in (128, 48, 33, 16, 8, 4, 2):
         batch = torch.from_numpy(np.stack([bgr if i % 2 == 0 else flipped for i in range(nb)])).to(dev)
         cf = torch.empty((nb,) + tuple(out_size), dtype=torch.float32, device=dev); cu = torch.empty((nb,) + tuple(out_size), dtype=torch.uint8, device=dev)
         fcn.forward_device(batch, cost_u8=cu, cost_f32=cf)
         torch.cuda.synchronize()
         c = cf.cpu().numpy()
-        assert np.array_equal(c[0], c[nb - 2]) and np.array_equal(c[1], c[nb - 1])           # slot-independent
+        assert np.array_equal(c[0], c[nb - 2 - nb % 2]) and np.array_equal(c[1], c[nb - 1 - nb % 2])           # slot-independent
+        if nb >= 16:
+            for i in range(nb): assert np.array_equal(c[i], c[i % 2]), "batch %d: slot %d differs from slot %d (same input)" % (nb, i, i % 2)
+            if ref is not None: assert np.array_equal(c[0], ref), "batch %d differs from batch 128 (same kernels, no split)" % nb
         if ref is None:
             ref = c[0]
             assert FC.check_against_golden(g, ref, cu[0].cpu().numpy(), tol=1e-3) < 3e-4
