@@ -2104,6 +2104,20 @@ __device__ __forceinline__ void lay_pixel(int lay, int tile, int off, int& y, in
 #define IVF_PRIO_STEN(on) do { if (IVF_PRIO == 4) __builtin_amdgcn_s_setprio(on); } while (0)
 constexpr int kF4Cin = 160, kF4Hid = 960, kF4Groups = 60;
 constexpr int kF4HP = 20;                         // floats per 16-pixel sub-row of a hidden plane in LDS (80 B rows)
+// LDS-DMA addressing per kernel: 1 = wave-uniform base in an SGPR pair + one 32-bit lane offset, 0 = a 64-bit pointer per lane.  Measured (us per 128 images, alternated): k_fcn_irbd4<true>
+// 961 / 966 -> 946 / 946 (its 24 B of scratch go); k_fcn_irbd4h 1,790 / 1,796 -> 1,813 / 1,827; k_fcn_irbd2 +-0.5 %.
+#ifndef IVF_F4_DMA_SADDR
+#define IVF_F4_DMA_SADDR 1
+#endif
+#ifndef IVF_H4_DMA_SADDR
+#define IVF_H4_DMA_SADDR 0
+#endif
+#ifndef IVF_W4_DMA_SADDR
+#define IVF_W4_DMA_SADDR 0
+#endif
+#ifndef IVF_D2_DMA_SADDR
+#define IVF_D2_DMA_SADDR 0
+#endif
 #ifndef IVF_F4_WALK
 #define IVF_F4_WALK 0         // blocks 15 / 16 as a persistent grid (see k_fcn_irbd2): 953 -> 1,138 us, the tile loop makes the 256-register body spill; off
 #endif
@@ -2176,20 +2190,32 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     const unsigned ldsBase = (unsigned)(uintptr_t)f4smem;
     const unsigned ldsWE = ldsBase + (unsigned)((uint8_t*)sWE - (uint8_t*)f4smem), ldsWP = ldsBase + (unsigned)((uint8_t*)sWP - (uint8_t*)f4smem),
                    ldsPar = ldsBase + (unsigned)((uint8_t*)sPar - (uint8_t*)f4smem);
+#if IVF_F4_DMA_SADDR      // r05: wave-uniform base in an SGPR pair + ONE 32-bit lane offset (16 lane): the per-lane 64-bit pointers of WE / WP / par (6 registers, kept live across the
+                       // whole kernel) and their 64-bit vector adds per piece are gone
+    const unsigned voff16 = (unsigned)lane * 16u;
+    auto dma16 = [voff16](const void* sbase, unsigned ldsAddr) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff16), "s"(sbase), "s"(ldsAddr) : "memory");
+    };
+#undef IVF_DMA_LANE
+#define IVF_DMA_LANE(x) 0
+#else
     auto dma16 = [](const void* src, unsigned ldsAddr) {
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(ldsAddr) : "memory");
     };
+#undef IVF_DMA_LANE
+#define IVF_DMA_LANE(x) (x)
+#endif
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     auto piece = [&](int it, int c) {           // piece c of what interval `it` consumes: WE[it] (c < 10), WP[it - 2] (c < 20), par[it] (c = 20)
         const int nb = it % kF4WSlots;
         if (c < 10) {
-            if (it < g1) dma16(WE + ((size_t)it * 10 + c) * 64 + lane, ldsWE + (unsigned)(nb * 640 + c * 64) * 16u);
+            if (it < g1) dma16(WE + ((size_t)it * 10 + c) * 64 + IVF_DMA_LANE(lane), ldsWE + (unsigned)(nb * 640 + c * 64) * 16u);
         } else if (c < 20) {
             const int c2 = c - 10, gp = it - 2;
             if (gp >= g0 && gp < g1)
-                dma16(WP + (((size_t)gp * tilesP + tile0) * 2 + c2) * 64 + lane, ldsWP + (unsigned)(nb * 640 + c2 * 64) * 16u);
+                dma16(WP + (((size_t)gp * tilesP + tile0) * 2 + c2) * 64 + IVF_DMA_LANE(lane), ldsWP + (unsigned)(nb * 640 + c2 * 64) * 16u);
         } else if (c == 20) {
-            if (it < g1 && lane < 48) dma16(par + (size_t)it * 192 + lane * 4, ldsPar + (unsigned)((it % kF4PSlots) * kF4ParB));
+            if (it < g1 && lane < 48) dma16(par + (size_t)it * 192 + IVF_DMA_LANE(lane * 4), ldsPar + (unsigned)((it % kF4PSlots) * kF4ParB));
         }
     };
     auto dma = [&](int it) {                    // all 21 pieces (<= 1 KB each), piece c by wave c % 8
@@ -2540,14 +2566,26 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4h(const float* __restrict__
 
     const unsigned ldsBase = (unsigned)(uintptr_t)f4smem;
     const unsigned ldsWE = ldsBase + (unsigned)((uint8_t*)sWE - (uint8_t*)f4smem), ldsPar = ldsBase + (unsigned)((uint8_t*)sPar - (uint8_t*)f4smem);
+#if IVF_H4_DMA_SADDR      // r05: wave-uniform base in an SGPR pair + ONE 32-bit lane offset (16 lane): the per-lane 64-bit pointers of WE / WP / par (6 registers, kept live across the
+                       // whole kernel) and their 64-bit vector adds per piece are gone
+    const unsigned voff16 = (unsigned)lane * 16u;
+    auto dma16 = [voff16](const void* sbase, unsigned ldsAddr) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff16), "s"(sbase), "s"(ldsAddr) : "memory");
+    };
+#undef IVF_DMA_LANE
+#define IVF_DMA_LANE(x) 0
+#else
     auto dma16 = [](const void* src, unsigned ldsAddr) {
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(ldsAddr) : "memory");
     };
+#undef IVF_DMA_LANE
+#define IVF_DMA_LANE(x) (x)
+#endif
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     auto piece = [&](int it, int c) {           // piece c of what interval `it` consumes: WE[it] (c < 10), par[it] (c = 10)
         if (it >= g1) return;
-        if (c < 10) dma16(WE + ((size_t)it * 10 + c) * 64 + lane, ldsWE + (unsigned)((it % kF4WSlots) * 640 + c * 64) * 16u);
-        else if (c == 10 && lane < 48) dma16(par + (size_t)it * 192 + lane * 4, ldsPar + (unsigned)((it % kF4PSlots) * kF4ParB));
+        if (c < 10) dma16(WE + ((size_t)it * 10 + c) * 64 + IVF_DMA_LANE(lane), ldsWE + (unsigned)((it % kF4WSlots) * 640 + c * 64) * 16u);
+        else if (c == 10 && lane < 48) dma16(par + (size_t)it * 192 + IVF_DMA_LANE(lane * 4), ldsPar + (unsigned)((it % kF4PSlots) * kF4ParB));
     };
     auto dma = [&](int it) { piece(it, uwave); if (uwave < 3) piece(it, uwave + 8); };
     auto dma_late = [&](int it) {               // the same 11 pieces, most of them by waves 0-3, which reach the barrier first
@@ -2932,9 +2970,21 @@ __global__ __launch_bounds__(1024) void k_fcn_irbd4w(const float* __restrict__ X
     const unsigned ldsBase = (unsigned)(uintptr_t)f4smem;
     const unsigned ldsWE = ldsBase + (unsigned)((uint8_t*)sWE - (uint8_t*)f4smem), ldsWP = ldsBase + (unsigned)((uint8_t*)sWP - (uint8_t*)f4smem),
                    ldsPar = ldsBase + (unsigned)((uint8_t*)sPar - (uint8_t*)f4smem);
+#if IVF_W4_DMA_SADDR      // r05: wave-uniform base in an SGPR pair + ONE 32-bit lane offset (16 lane): the per-lane 64-bit pointers of WE / WP / par (6 registers, kept live across the
+                       // whole kernel) and their 64-bit vector adds per piece are gone
+    const unsigned voff16 = (unsigned)lane * 16u;
+    auto dma16 = [voff16](const void* sbase, unsigned ldsAddr) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff16), "s"(sbase), "s"(ldsAddr) : "memory");
+    };
+#undef IVF_DMA_LANE
+#define IVF_DMA_LANE(x) 0
+#else
     auto dma16 = [](const void* src, unsigned ldsAddr) {
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(ldsAddr) : "memory");
     };
+#undef IVF_DMA_LANE
+#define IVF_DMA_LANE(x) (x)
+#endif
     // Every piece is ALWAYS issued (a group index outside [g0, g1) is clamped: its slot is one nobody reads in that interval), so a wave's
     // count of outstanding requests is known: the three pieces of a wave are spread over its interval (before the stencil, before P, at
     // the end) and the wait in front of the barrier lets exactly the two youngest stay in flight.
@@ -2942,13 +2992,13 @@ __global__ __launch_bounds__(1024) void k_fcn_irbd4w(const float* __restrict__ X
         const int nb = it % kF4WSlots;
         if (c < 10) {
             const int ge = min(it, g1 - 1);
-            dma16(WE + ((size_t)ge * 10 + c) * 64 + lane, ldsWE + (unsigned)(nb * 640 + c * 64) * 16u);
+            dma16(WE + ((size_t)ge * 10 + c) * 64 + IVF_DMA_LANE(lane), ldsWE + (unsigned)(nb * 640 + c * 64) * 16u);
         } else if (c < 20) {
             const int c2 = c - 10, gp = min(max(it - 2, g0), g1 - 1);
-            dma16(WP + (((size_t)gp * tilesP + tile0) * 2 + c2) * 64 + lane, ldsWP + (unsigned)(nb * 640 + c2 * 64) * 16u);
+            dma16(WP + (((size_t)gp * tilesP + tile0) * 2 + c2) * 64 + IVF_DMA_LANE(lane), ldsWP + (unsigned)(nb * 640 + c2 * 64) * 16u);
         } else if (c == 20) {
             const int ge = min(it, g1 - 1);
-            if (lane < 48) dma16(par + (size_t)ge * 192 + lane * 4, ldsPar + (unsigned)((it % kF4PSlots) * kF4ParB));
+            if (lane < 48) dma16(par + (size_t)ge * 192 + IVF_DMA_LANE(lane * 4), ldsPar + (unsigned)((it % kF4PSlots) * kF4ParB));
         }
     };
     auto dma = [&](int it) {                    // all 21 pieces (<= 1 KB each), piece c by P wave c % 8
@@ -3152,19 +3202,31 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd2(const float* __restrict__ 
     constexpr int HW = 4096;
     const unsigned ldsBase = (unsigned)(uintptr_t)d2smem;
     const unsigned ldsW = ldsBase + (unsigned)((uint8_t*)sW - (uint8_t*)d2smem), ldsPar = ldsBase + (unsigned)((uint8_t*)sPar - (uint8_t*)d2smem);
+#if IVF_D2_DMA_SADDR      // r05: wave-uniform base in an SGPR pair + ONE 32-bit lane offset (16 lane): the per-lane 64-bit pointers of WE / WP / par (6 registers, kept live across the
+                       // whole kernel) and their 64-bit vector adds per piece are gone
+    const unsigned voff16 = (unsigned)lane * 16u;
+    auto dma16 = [voff16](const void* sbase, unsigned ldsAddr) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff16), "s"(sbase), "s"(ldsAddr) : "memory");
+    };
+#undef IVF_DMA_LANE
+#define IVF_DMA_LANE(x) 0
+#else
     auto dma16 = [](const void* src, unsigned ldsAddr) {
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(ldsAddr) : "memory");
     };
+#undef IVF_DMA_LANE
+#define IVF_DMA_LANE(x) (x)
+#endif
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     auto piece = [&](int it, int c) {           // piece c of what interval `it` consumes: WE[it] (c < NPE), WP[it - 2] (c < NPE + NPP), par[it]
         const int nb = it % 3;
         if (c < NPE) {
-            if (it < g1) dma16(WE + ((size_t)it * NPE + c) * 64 + lane, ldsW + (unsigned)(nb * WSLOT + c * 64) * 16u);
+            if (it < g1) dma16(WE + ((size_t)it * NPE + c) * 64 + IVF_DMA_LANE(lane), ldsW + (unsigned)(nb * WSLOT + c * 64) * 16u);
         } else if (c < NPE + NPP) {
             const int gp = it - 2;
-            if (gp >= g0 && gp < g1) dma16(WP + ((size_t)gp * NPP + (c - NPE)) * 64 + lane, ldsW + (unsigned)(nb * WSLOT + c * 64) * 16u);
+            if (gp >= g0 && gp < g1) dma16(WP + ((size_t)gp * NPP + (c - NPE)) * 64 + IVF_DMA_LANE(lane), ldsW + (unsigned)(nb * WSLOT + c * 64) * 16u);
         } else if (c == NPE + NPP) {
-            if (it < g1 && lane < 48) dma16(par + (size_t)it * 192 + lane * 4, ldsPar + (unsigned)((it & 3) * kF4ParB));
+            if (it < g1 && lane < 48) dma16(par + (size_t)it * 192 + IVF_DMA_LANE(lane * 4), ldsPar + (unsigned)((it & 3) * kF4ParB));
         }
     };
     auto dma_all = [&](int it) {
