@@ -3535,8 +3535,12 @@ __global__ void k_fcn_last(const float* __restrict__ X, const float* __restrict_
 }
 
 // ---- bilinear to out_size, logistic, u8 truncation (models_light.py:198-199, :25-26; stereo_kitti.cc:511) ----
+#ifndef IVF_OUT_ROWS
+#define IVF_OUT_ROWS 8
+#endif
+constexpr int kOutRows = IVF_OUT_ROWS;        // output rows per workgroup of k_fcn_out
 __global__ __launch_bounds__(256) void k_fcn_out(const float* __restrict__ L, int lh, int lw, int oh, int ow, float sy_, float sx_,
-                                                float* __restrict__ costF, uint8_t* __restrict__ costU, int* __restrict__ status)
+                                                float* __restrict__ costF, uint8_t* __restrict__ costU, int* __restrict__ status, int rowsPerWg)
 {
     // the last kernel of a forward: every earlier kernel of it has finished (stream order), so one thread moves the f16 range flag
     // they may have raised into the handle's status word
@@ -3544,47 +3548,61 @@ __global__ __launch_bounds__(256) void k_fcn_out(const float* __restrict__ L, in
         const int v = atomicExch(&g_fcnRange, 0);
         if (v) atomicOr(status, v);
     }
-    // a workgroup = 1024 pixels of one output row (4 adjacent pixels per thread): they all read the same two logit rows, which
-    // go through LDS once.  sy_ = (float)lh / (float)oh and sx_ come from the host (the same IEEE f32 quotient, computed once
-    // instead of by two division sequences per thread); the u8 map leaves as one dword per thread where the row allows it.
-    // r01 / early r02: 88 VALU lane-instructions per output pixel.
-    __shared__ float rowT[kEnc / 8], rowB[kEnc / 8];
-    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y, b = blockIdx.z;
-    float fy = sy_ * ((float)y + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
-    int y0 = (int)fy; if (y0 > lh - 1) y0 = lh - 1;
-    const int y1 = y0 + (y0 < lh - 1);
-    const float* P = L + (size_t)b * lh * lw;
-    if ((int)threadIdx.x < lw) rowT[threadIdx.x] = P[y0 * lw + threadIdx.x];
-    else if ((int)threadIdx.x < 2 * lw) rowB[threadIdx.x - lw] = P[y1 * lw + threadIdx.x - lw];
+    // a workgroup = 1024 pixels (4 adjacent per thread) of rowsPerWg consecutive output rows (kOutRows = 8 for batches; 98 -> 73 us per 128 images; 2 for the per-call path, which has a chip to fill with one image) (r05; one row before): the logit rows they read go through LDS once,
+    // a thread's horizontal taps and weights are computed once for all its rows, and the launch has an eighth of the workgroups.  sy_ = (float)lh / (float)oh and
+    // sx_ come from the host (the same IEEE f32 quotient, computed once instead of by two division sequences per thread); the u8 map leaves as one dword per
+    // thread where the row allows it.  Per pixel the arithmetic and its order are those of the one-row form (bit-identical maps).
+    __shared__ float rows[(kEnc / 8) * (kEnc / 8)];                  // at most the whole logit map (lh, lw <= kEnc / 8)
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, yA = blockIdx.y * rowsPerWg, yB = min(yA + rowsPerWg, oh), b = blockIdx.z;
+    auto src_row = [&](int y, int& y0, int& y1, float& fy) {
+        fy = sy_ * ((float)y + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
+        y0 = (int)fy; if (y0 > lh - 1) y0 = lh - 1;
+        y1 = y0 + (y0 < lh - 1);
+    };
+    int rFirst, rLast, t0, t1; float tf;
+    src_row(yA, rFirst, t1, tf); src_row(yB - 1, t0, rLast, tf);
+    if (rLast < rFirst) rLast = rFirst;
+    const float* P = L + (size_t)b * lh * lw + (size_t)rFirst * lw;
+    for (int i = threadIdx.x; i < (rLast - rFirst + 1) * lw; i += blockDim.x) rows[i] = P[i];
     __syncthreads();
     if (x4 >= ow) return;
-    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
-    float c[4];
+    int x0[4], x1[4]; float lx0[4], lx1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int x = x4 + k;
         float fx = sx_ * ((float)x + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
-        int x0 = (int)fx; if (x0 > lw - 1) x0 = lw - 1;
-        const int x1 = x0 + (x0 < lw - 1);
-        const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
-        const float top = rowT[x0] * lx0 + rowT[x1] * lx1;
-        const float bot = rowB[x0] * lx0 + rowB[x1] * lx1;
-        const float v = top * ly0 + bot * ly1;
-        const float z = 20.f * (v - 0.5f);
-        // logistic through the hardware exp2 / rcp (1 ulp each; the libm expf + IEEE division were most of this kernel's instructions)
-        c[k] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-z * 1.44269504088896341f));
+        x0[k] = (int)fx; if (x0[k] > lw - 1) x0[k] = lw - 1;
+        x1[k] = x0[k] + (x0[k] < lw - 1);
+        lx1[k] = fx - (float)x0[k]; lx0[k] = 1.f - lx1[k];
     }
-    const size_t o = ((size_t)b * oh + y) * ow + x4;
     const int nv = min(4, ow - x4);
-    if (costF) {
-        if (nv == 4 && (o & 3) == 0) *(float4*)(costF + o) = make_float4(c[0], c[1], c[2], c[3]);
-        else for (int k = 0; k < nv; k++) costF[o + k] = c[k];
-    }
-    if (costU) {
-        const unsigned u0 = (unsigned)(uint8_t)(c[0] * 255.0f), u1 = (unsigned)(uint8_t)(c[1] * 255.0f),
-                       u2 = (unsigned)(uint8_t)(c[2] * 255.0f), u3 = (unsigned)(uint8_t)(c[3] * 255.0f);
-        if (nv == 4 && (o & 3) == 0) *(unsigned*)(costU + o) = u0 | (u1 << 8) | (u2 << 16) | (u3 << 24);
-        else { const unsigned u[4] = {u0, u1, u2, u3}; for (int k = 0; k < nv; k++) costU[o + k] = (uint8_t)u[k]; }
+    for (int y = yA; y < yB; y++) {
+        int y0, y1; float fy;
+        src_row(y, y0, y1, fy);
+        const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+        const float* rowT = rows + (y0 - rFirst) * lw;
+        const float* rowB = rows + (y1 - rFirst) * lw;
+        float c[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float top = rowT[x0[k]] * lx0[k] + rowT[x1[k]] * lx1[k];
+            const float bot = rowB[x0[k]] * lx0[k] + rowB[x1[k]] * lx1[k];
+            const float v = top * ly0 + bot * ly1;
+            const float z = 20.f * (v - 0.5f);
+            // logistic through the hardware exp2 / rcp (1 ulp each; the libm expf + IEEE division were most of this kernel's instructions)
+            c[k] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-z * 1.44269504088896341f));
+        }
+        const size_t o = ((size_t)b * oh + y) * ow + x4;
+        if (costF) {
+            if (nv == 4 && (o & 3) == 0) *(float4*)(costF + o) = make_float4(c[0], c[1], c[2], c[3]);
+            else for (int k = 0; k < nv; k++) costF[o + k] = c[k];
+        }
+        if (costU) {
+            const unsigned u0 = (unsigned)(uint8_t)(c[0] * 255.0f), u1 = (unsigned)(uint8_t)(c[1] * 255.0f),
+                           u2 = (unsigned)(uint8_t)(c[2] * 255.0f), u3 = (unsigned)(uint8_t)(c[3] * 255.0f);
+            if (nv == 4 && (o & 3) == 0) *(unsigned*)(costU + o) = u0 | (u1 << 8) | (u2 << 16) | (u3 << 24);
+            else { const unsigned u[4] = {u0, u1, u2, u3}; for (int k = 0; k < nv; k++) costU[o + k] = (uint8_t)u[k]; }
+        }
     }
 }
 
@@ -4335,8 +4353,9 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             STAGE("conv_last");
         }
     }
-    hipLaunchKernelGGL(k_fcn_out, dim3((f->outW + 1023) / 1024, f->outH, n), dim3(256), 0, s, f->bufLogits, H, W, f->outH, f->outW,
-                       (float)H / (float)f->outH, (float)W / (float)f->outW, dF, dU8, f->dStatus);
+    const int outRows = n >= 4 ? kOutRows : 2;
+    hipLaunchKernelGGL(k_fcn_out, dim3((f->outW + 1023) / 1024, (f->outH + outRows - 1) / outRows, n), dim3(256), 0, s, f->bufLogits, H, W, f->outH, f->outW,
+                       (float)H / (float)f->outH, (float)W / (float)f->outW, dF, dU8, f->dStatus, outRows);
     FHIP(hipGetLastError());
     return IVF_OK;
 }
