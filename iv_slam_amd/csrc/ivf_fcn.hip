@@ -66,53 +66,67 @@ __device__ __forceinline__ void range_flag(float amax) { if (!(amax < 65504.f)) 
 constexpr int kEnc = 512;                      // encoder input size (IF/config: enc_input_size)
 
 // ---- pre-processing + bilinear resize to 512x512 (stereo_kitti.cc:494-506, models_light.py:19-21) ----
+#ifndef IVF_PREP_ROWS
+#define IVF_PREP_ROWS 2          // measured 1 / 2 / 4 / 8: 176-178 / 151-154 / 153-157 / 161-170 us per 128 images
+#endif
+constexpr int kPrepRows = IVF_PREP_ROWS;       // output rows per thread of k_fcn_prep (grid y = kEnc / kPrepRows)
 __global__ void k_fcn_prep(const uint8_t* __restrict__ bgr, size_t imageStride, int rowStride, int w, int h,
                            float* __restrict__ out)
 {
     // (r05: an XCD-aware block order -- XCD k takes images k, k + 8, ... whole, so that the two output rows that share an input row
     // meet in one L2 -- brings FETCH_SIZE down from 2.9x the input but not the time: 187 vs 180 us per 128 images; not kept.  The kernel
     // is bound by its 403 MB of f32 stores and its VALU work, not by the u8 fetches.)
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    // r05: a thread walks kPrepRows consecutive output rows at its column: the horizontal taps, weights and byte offsets are computed once,
+    // and consecutive output rows share source rows (h < kEnc: 0.73 source rows per output row at 375) in this workgroup's L1.  Per element
+    // the arithmetic and its order are unchanged.
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, yA = blockIdx.y * kPrepRows, b = blockIdx.z;
     if (x >= kEnc) return;
     const float sy_ = (float)h / (float)kEnc, sx_ = (float)w / (float)kEnc;
-    float fy = sy_ * ((float)y + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
     float fx = sx_ * ((float)x + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
-    int y0 = (int)fy; if (y0 > h - 1) y0 = h - 1;
     int x0 = (int)fx; if (x0 > w - 1) x0 = w - 1;
-    const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
-    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+    const int x1 = x0 + (x0 < w - 1);
+    const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
     const uint8_t* I = bgr + (size_t)b * imageStride;
     const float mean[3] = {0.485f, 0.456f, 0.406f}, istd[3] = {1.0f / 0.229f, 1.0f / 0.224f, 1.0f / 0.225f};
-    // the four taps' three bytes each, loaded once; the normalisation `(p/255 - mean) / std` multiplies by the reciprocal of the
-    // constant (one ulp from the true quotient, far inside the 1e-3 bar): the IEEE division sequence was most of this kernel
-    // (r01: 80 VALU lane-instructions per output element, VALU-bound)
-    const uint8_t *p00 = I + (size_t)y0 * rowStride + x0 * 3, *p01 = I + (size_t)y0 * rowStride + x1 * 3;
-    const uint8_t *p10 = I + (size_t)y1 * rowStride + x0 * 3, *p11 = I + (size_t)y1 * rowStride + x1 * 3;
-    // r02: twelve single-byte gathers per element made this kernel address-rate-bound (4 lane addresses per clock and CU).  The
-    // two taps of a row are 6 adjacent bytes (B G R B G R) whenever x1 = x0 + 1: two unaligned dword loads per row, except in
-    // the last columns, where the second dword would run past the row
-    unsigned t0[3], t1[3], b0[3], b1[3];            // taps (row, column) per colour byte
-    if (x0 + 3 <= w - 1) {
-        unsigned a0, a1, c0, c1;
-        __builtin_memcpy(&a0, p00, 4); __builtin_memcpy(&a1, p00 + 4, 4);
-        __builtin_memcpy(&c0, p10, 4); __builtin_memcpy(&c1, p10 + 4, 4);
-        const unsigned a01 = __builtin_amdgcn_alignbyte(a1, a0, 3), c01 = __builtin_amdgcn_alignbyte(c1, c0, 3);   // bytes 3 .. 6
+    const bool wide = x0 + 3 <= w - 1;
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            t0[k] = (a0 >> (8 * k)) & 0xffu; t1[k] = (a01 >> (8 * k)) & 0xffu;
-            b0[k] = (c0 >> (8 * k)) & 0xffu; b1[k] = (c01 >> (8 * k)) & 0xffu;
+    for (int r = 0; r < kPrepRows; r++) {
+        const int y = yA + r;
+        float fy = sy_ * ((float)y + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
+        int y0 = (int)fy; if (y0 > h - 1) y0 = h - 1;
+        const int y1 = y0 + (y0 < h - 1);
+        const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+        // the four taps' three bytes each, loaded once; the normalisation `(p/255 - mean) / std` multiplies by the reciprocal of the
+        // constant (one ulp from the true quotient, far inside the 1e-3 bar): the IEEE division sequence was most of this kernel
+        // (r01: 80 VALU lane-instructions per output element, VALU-bound)
+        const uint8_t *p00 = I + (size_t)y0 * rowStride + x0 * 3, *p01 = I + (size_t)y0 * rowStride + x1 * 3;
+        const uint8_t *p10 = I + (size_t)y1 * rowStride + x0 * 3, *p11 = I + (size_t)y1 * rowStride + x1 * 3;
+        // r02: twelve single-byte gathers per element made this kernel address-rate-bound (4 lane addresses per clock and CU).  The
+        // two taps of a row are 6 adjacent bytes (B G R B G R) whenever x1 = x0 + 1: two unaligned dword loads per row, except in
+        // the last columns, where the second dword would run past the row
+        unsigned t0[3], t1[3], b0[3], b1[3];            // taps (row, column) per colour byte
+        if (wide) {
+            unsigned a0, a1, c0, c1;
+            __builtin_memcpy(&a0, p00, 4); __builtin_memcpy(&a1, p00 + 4, 4);
+            __builtin_memcpy(&c0, p10, 4); __builtin_memcpy(&c1, p10 + 4, 4);
+            const unsigned a01 = __builtin_amdgcn_alignbyte(a1, a0, 3), c01 = __builtin_amdgcn_alignbyte(c1, c0, 3);   // bytes 3 .. 6
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                t0[k] = (a0 >> (8 * k)) & 0xffu; t1[k] = (a01 >> (8 * k)) & 0xffu;
+                b0[k] = (c0 >> (8 * k)) & 0xffu; b1[k] = (c01 >> (8 * k)) & 0xffu;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { t0[k] = p00[k]; t1[k] = p01[k]; b0[k] = p10[k]; b1[k] = p11[k]; }
         }
-    } else {
 #pragma unroll
-        for (int k = 0; k < 3; k++) { t0[k] = p00[k]; t1[k] = p01[k]; b0[k] = p10[k]; b1[k] = p11[k]; }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const int sc = 2 - c;                       // BGR -> RGB
-        auto nz = [&](unsigned q) { return ((float)q * (1.0f / 255.0f) - mean[c]) * istd[c]; };
-        const float top = nz(t0[sc]) * lx0 + nz(t1[sc]) * lx1;
-        const float bot = nz(b0[sc]) * lx0 + nz(b1[sc]) * lx1;
-        out[(((size_t)b * 3 + c) * kEnc + y) * kEnc + x] = top * ly0 + bot * ly1;
+        for (int c = 0; c < 3; c++) {
+            const int sc = 2 - c;                       // BGR -> RGB
+            auto nz = [&](unsigned q) { return ((float)q * (1.0f / 255.0f) - mean[c]) * istd[c]; };
+            const float top = nz(t0[sc]) * lx0 + nz(t1[sc]) * lx1;
+            const float bot = nz(b0[sc]) * lx0 + nz(b1[sc]) * lx1;
+            out[(((size_t)b * 3 + c) * kEnc + y) * kEnc + x] = top * ly0 + bot * ly1;
+        }
     }
 }
 
@@ -4050,7 +4064,7 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
     int headChunk = headChunkEnv;
     if (headChunk <= 0 || headChunk >= n) headChunk = 0;
     if (!headChunk) {
-        hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc, n), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn);
+        hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc / kPrepRows, n), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn);
         STAGE("prep");
     }
     // whole-block kernels, bit i = block i + 2: blocks 2-4 (k_fcn_irb) by default; bits 3-9 = blocks 5-11 through k_fcn_irb64, which
@@ -4065,7 +4079,7 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
     const int headIl = (headIlEnv && stem && (irbMask & 7u) == 7u) ? 1 : 0;
     const bool chunkedHead = headChunk > 0 && stem && (irbMask & 7u) == 7u;
     if (headChunk > 0 && !chunkedHead) {            // an experiment switch took a head kernel away: the plain schedule
-        hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc, n), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn);
+        hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc / kPrepRows, n), dim3(256), 0, s, dBgr, imageStride, rowStride, f->inW, f->inH, f->bufIn);
         STAGE("prep");
     }
     if (chunkedHead) {
@@ -4077,7 +4091,7 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             float* o2 = f->bufA + (size_t)c0 * 24 * 128 * 128;          // block 2
             float* o3 = f->bufB + (size_t)c0 * 24 * 128 * 128;          // block 3 (its chunk's stem output is dead by then; other chunks' live regions lie elsewhere)
             float* o4 = f->bufA + (size_t)c0 * 32 * 64 * 64;            // block 4: the layout the 64 x 64 stage expects
-            hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc, nb), dim3(256), 0, s, dBgr + (size_t)c0 * imageStride, imageStride, rowStride, f->inW, f->inH, in);
+            hipLaunchKernelGGL(k_fcn_prep, dim3(kEnc / 256, kEnc / kPrepRows, nb), dim3(256), 0, s, dBgr + (size_t)c0 * imageStride, imageStride, rowStride, f->inW, f->inH, in);
             hipLaunchKernelGGL(k_fcn_stem, dim3(kEnc / 2 / kStemTW, kEnc / 2 / kStemTH, nb), dim3(512), 0, s, (const float*)in, f->dConv0W, f->dConv0S,
                                f->dConv0B, d0.dW, d0.dScale, d0.dShift, f->dProj0W, f->pw[0].dScale, f->pw[0].dShift, o1, f->dStemFrag, headIl);
 #define IRBC(S_, CIN_, HID_, COUT_, RES_, WI_, TH_, IP_, ID_, X_, Y_, T_)                                                                          \
