@@ -33,6 +33,8 @@ def test_bench_line_contract():
     # r05: the line names the FCN kernel with the largest TOTAL time per forward and prints the other whole-block probe beside it, both priced
     # against the f16 matrix peak as issued and as algorithmic flops; the tracker step covers every frame pair of the launch sequence
     assert rf["launches_per_forward"] in (1, 2) and rf["total_ms_per_forward"] > 0 and 0 < rf["frac_algorithmic"] < rf["frac_issued"] < 1
+    # r06: `frac` IS SURVEY 8(d)'s algorithmic fraction (2 x MAC counted once); the three split-f16 products are `frac_issued` beside it
+    assert rf["frac"] == rf["frac_algorithmic"] and abs(rf["frac_issued"] - 3 * rf["frac"]) < 1e-3
     ob = rf["other_block"]
     assert ob["kernel"] != rf["kernel"] and 0 < ob["frac_algorithmic"] < ob["frac_issued"] < 1 and ob["total_ms_per_forward"] <= rf["total_ms_per_forward"]
     assert {rf["kernel"].split(" ")[0], ob["kernel"].split(" ")[0]} == {"ivffcn::k_fcn_irbd4<true>", "ivffcn::k_fcn_irbd4h"}

@@ -1,0 +1,128 @@
+"""Gate (i) of the r05 verdict's item 1 (host only): what does the cost map lose when the two CORRECTION products of the split-f16
+scheme, a_hi*w_lo + a_lo*w_hi, of the pointwise convolutions of blocks 15-17 are computed from fp8 operands (one K-concatenated
+product [a_hi | a_lo] . [w_lo ; w_hi] on the double-rate v_mfma_scale_f32_32x32x64_f8f6f4) instead of from f16 operands?
+The hi*hi product stays f16 x f16 -> f32.  Everything outside those pointwise convolutions is f32 (torch CPU), so the printed
+number is the reference error of the scheme, not of the device kernels.
+    python tools/fcn_fp8_corrections.py
+Formats: e4m3 (3 mantissa bits, |v| <= 448) and e5m2 (2 bits, |v| <= 57344) with a fixed power-of-two scale per operand class
+(what the MFMA's E8M0 block-scale operand gives for free), saturating like v_cvt_scalef32_pk_fp8_f32."""
+import os, sys
+import numpy as np
+import torch
+import torch.nn.functional as F
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import fcn_common
+import fcn_oracle_torch as O
+from iv_slam_amd.fcn_weights import BLOCKS
+
+FMT = {"e4m3": (torch.float8_e4m3fn, 448.0), "e5m2": (torch.float8_e5m2, 57344.0), "e2m3": (None, 7.5), "e3m2": (None, 28.0)}
+
+
+def rtz16(v):
+    """f32 -> f16 round-toward-zero (v_cvt_pkrtz_f16_f32), returned as f32; f16 subnormals: RNE (immaterial here)."""
+    b = v.contiguous().view(torch.int32)
+    t = (b & ~0x1FFF).view(torch.float32)
+    return torch.where(v.abs() >= 2.0 ** -14, t, v.half().float()).clamp(-65504.0, 65504.0)
+
+
+def q8(v, fmt, log2scale):
+    dt, mx = FMT[fmt]
+    s = 2.0 ** log2scale
+    x = (v * s).clamp(-mx, mx)
+    if dt is not None:
+        return x.to(dt).float() / s
+    # the 6-bit formats of the f8f6f4 MFMA (four times the f16 rate): fixed step per binade, subnormals below the first normal, RNE
+    a = x.abs()
+    if fmt == "e2m3":      # 1 + 2 + 3 bits, bias 1: steps 1/8 below 2, 1/4 in [2, 4), 1/2 in [4, 7.5]
+        step = torch.where(a < 2.0, 0.125, torch.where(a < 4.0, 0.25, 0.5))
+    else:                  # e3m2: 1 + 3 + 2 bits, bias 3: 1/16 below 0.5, then doubling per binade up to 4 in [16, 28]
+        step = 0.0625 * torch.clamp(torch.floor(torch.log2(a.clamp_min(2.0 ** -10))) + 2.0, min=0.0).exp2()
+    return (torch.round(x / step) * step).clamp(-mx, mx) / s
+
+
+def pointwise(x, w, mode, act_range):
+    """x [1,C,H,W] f32, w [Co,C,1,1] f32.  mode: 'f32' | 'f16x3' | (fmt_act, fmt_w).  act_range: largest |x| the scale is set for."""
+    if mode == "f32":
+        return F.conv2d(x, w)
+    co = w.shape[0]
+    e = -torch.floor(torch.log2(w.abs().reshape(co, -1).max(dim=1).values.clamp_min(1e-30)))      # prescale_rows: max |w| -> [1, 2)
+    ws = w * (2.0 ** e).view(co, 1, 1, 1)
+    w_hi = ws.half().float(); w_lo = (ws - w_hi).half().float()
+    x_hi = rtz16(x); x_lo = rtz16(x - x_hi)
+    y = F.conv2d(x_hi, w_hi)
+    if mode == "f16x3":
+        y = y + F.conv2d(x_hi, w_lo) + F.conv2d(x_lo, w_hi)
+    elif mode == "f16x2":
+        y = y + F.conv2d(x_hi, w_lo)
+    else:
+        fa, fw = mode
+        mxa, mxw = FMT[fa][1], FMT[fw][1]
+        la = int(np.floor(np.log2(mxa / act_range)))              # x_hi * 2^la <= max
+        lal = la + 10                                             # rtz: 0 <= x_lo < ulp(x_hi) = 2^-10 * 2^floor(log2 x)
+        lw = int(np.floor(np.log2(mxw / 2.0)))                    # |w_hi| < 2
+        lwl = lw + 11                                             # RNE: |w_lo| <= 2^-11 * 2^floor(log2 w)
+        y = y + F.conv2d(q8(x_hi, fa, la), q8(w_lo, fw, lwl)) + F.conv2d(q8(x_lo, fa, lal), q8(w_hi, fw, lw))
+    return y * (2.0 ** -e).view(1, co, 1, 1)
+
+
+@torch.no_grad()
+def forward(T, bgr, out_size, first_q, mode_e, mode_p, stats=None):
+    a = np.asarray(bgr)[None]
+    x = torch.from_numpy(np.ascontiguousarray(a[..., ::-1])).to(torch.float32).permute(0, 3, 1, 2) * (1.0 / 255.0)
+    x = (x - torch.tensor(O.MEAN).view(1, 3, 1, 1)) / torch.tensor(O.STD).view(1, 3, 1, 1)
+    x = F.interpolate(x, size=(512, 512), mode="bilinear", align_corners=False)
+    x = F.relu6(O._bn(F.conv2d(x, T["encoder.features.0.0.weight"], None, 2, 1), T, "encoder.features.0.1"))
+    for i, (inp, oup, t, s, d, res) in enumerate(BLOCKS, start=1):
+        p = "encoder.features.%d.conv" % i
+        y = x
+        if t == 1:
+            y = F.relu6(O._bn(F.conv2d(y, T[p + ".0.weight"], None, s, d, d, inp * t), T, p + ".1"))
+            y = O._bn(F.conv2d(y, T[p + ".3.weight"]), T, p + ".4")
+        else:
+            on = i >= first_q
+            if stats is not None and i >= 15:
+                stats[i] = float(y.abs().max())
+            # the expansion's activation operand is the block input: unbounded in principle (range guard: < 65504)
+            y = pointwise(y, T[p + ".0.weight"], mode_e[0] if on else "f32", mode_e[1])
+            y = F.relu6(O._bn(y, T, p + ".1"))
+            y = F.relu6(O._bn(F.conv2d(y, T[p + ".3.weight"], None, s, d, d, inp * t), T, p + ".4"))
+            y = pointwise(y, T[p + ".6.weight"], mode_p if on else "f32", 6.0)
+            y = O._bn(y, T, p + ".7")
+        x = x + y if res else y
+    y = F.relu(O._bn(F.conv2d(x, T["decoder.cbr.0.weight"], None, 1, 1), T, "decoder.cbr.1"))
+    y = F.conv2d(y, T["decoder.conv_last.weight"], T["decoder.conv_last.bias"])
+    y = F.interpolate(y, size=tuple(out_size), mode="bilinear", align_corners=False)
+    return torch.sigmoid(20.0 * (y - 0.5))[0, 0].numpy()
+
+
+VARIANTS = (
+    ("f32 everywhere", 99, ("f32", 0), "f32"),
+    ("f16x3 E+P 15-17", 15, ("f16x3", 0), "f16x3"),
+    ("f16x2 P 15-17 (r02)", 15, ("f16x3", 0), "f16x2"),
+    ("P e4m3/e4m3", 15, ("f16x3", 0), ("e4m3", "e4m3")),
+    ("P e5m2/e5m2", 15, ("f16x3", 0), ("e5m2", "e5m2")),
+    ("E+P e4m3, E range 448", 15, (("e4m3", "e4m3"), 448.0), ("e4m3", "e4m3")),
+    ("E+P e4m3, E range 64", 15, (("e4m3", "e4m3"), 64.0), ("e4m3", "e4m3")),
+    ("E e5m2 (range 32768) + P e4m3", 15, (("e5m2", "e4m3"), 32768.0), ("e4m3", "e4m3")),
+    ("E+P e4m3 from block 8", 8, (("e4m3", "e4m3"), 64.0), ("e4m3", "e4m3")),
+    ("P e2m3/e2m3 (fp6)", 15, ("f16x3", 0), ("e2m3", "e2m3")),
+    ("P e3m2/e3m2 (bf6)", 15, ("f16x3", 0), ("e3m2", "e3m2")),
+    ("P e2m3 act / e3m2 w", 15, ("f16x3", 0), ("e2m3", "e3m2")),
+    ("E (range 28) + P e3m2", 15, (("e3m2", "e3m2"), 28.0), ("e3m2", "e3m2")),
+)
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    for tag in ("kitti", "jackal", "kitti_smallw", "jackal_smallw", "kitti_bigw", "jackal_full"):
+        g, W, bgr, (h, w) = fcn_common.load_case(tag)
+        T = O.prepare(W)
+        sub = int(g["sub"][0]) if "sub" in g.files else 6
+        ref = g["cost_sub"] if "cost_sub" in g.files else g["cost"]
+        st = {}
+        print("%s" % tag, flush=True)
+        for name, first_q, me, mp in VARIANTS:
+            c = forward(T, bgr, (h, w), first_q, me, mp, st)
+            got = c[::sub, ::sub] if "cost_sub" in g.files else c
+            print("   %-34s max |cost - reference| = %.2e" % (name, float(np.abs(got - ref).max())), flush=True)
+        print("   largest |block input| of blocks 15/16/17: %s" % ", ".join("%.1f" % st[k] for k in sorted(st)), flush=True)
