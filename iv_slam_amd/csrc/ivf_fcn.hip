@@ -32,6 +32,7 @@
 
 // kernels live in a NAMED namespace: __global__ functions with internal linkage (anonymous namespace)
 // failed to resolve at launch on ROCm 7 when the .so holds several HIP translation units
+#include <type_traits>
 namespace ivffcn {
 
 #define FHIP(expr)                                                                                   \
@@ -2157,18 +2158,45 @@ constexpr int kF4WSlots = 3, kF4PSlots = 4;  // weight / parameter buffers: cons
 constexpr size_t kF4Lds = (size_t)2 * 16 * kF4CS * 4 + (size_t)2 * 16 * kF4DP * 4 + 2 * kF4WSlots * 10240 + kF4PSlots * kF4ParB +
                           2 * 160 * 4;        // + the projection's BN scale / shift of this workgroup's 160 output channels
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr size_t kF6Lds = kF4Lds + (size_t)kF4WSlots * 3 * 1024;      // FP6: 13 instead of 10 pieces per projection slot
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x6 __attribute__((ext_vector_type(6)));
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+
+// FP6 (r06): the two CORRECTION products of the split-f16 scheme on the block-scaled matrix instruction at four times the f16 rate.
+//   x . w = x_hi w_hi + (x_hi w_lo + x_lo w_hi) + O(2^-22): the bracket is 2^-11 of the result, so its operands need ~4 bits -- it is ONE product
+//   [x_hi | x_lo 2^10] . [w_lo 2^13 ; w_hi 2^3] 2^-13 of twice the K, B in fp6 (e2m3), A in bf6 (e3m2), on v_mfma_scale_f32_16x16x128_f8f6f4 into the
+//   SAME accumulators as the f16 hi * hi product (tools/probe/mfma_fp8_mix.hip: lane maps, scale semantics, 17.6 cycles per K = 128 against 15.0 for
+//   v_mfma_f32_16x16x32_f16).  Expansion: the B operand is the block's input (unbounded), converted ONCE per workgroup in the prologue with a
+//   power-of-two scale per lane block (pixel, 16 channels: hi and lo of 2 x 8) from the block's largest |x_hi| -- the instruction's E8M0 scale
+//   operand undoes it; the A operand is packed on the host (make_fused4: 6-bit codes, element e at bits [6 e, 6 e + 6) of 6 dwords).
+//   Reference error of the scheme against the six goldens, host emulation (tools/fcn_fp8_corrections.py): <= 1.7e-4 with f32 everywhere else.
+#ifndef IVF_F4_FP6
+#define IVF_F4_FP6 1
+#endif
+#ifndef IVF_F6_FENCES
+#define IVF_F6_FENCES 0
+#endif
+#if IVF_F6_FENCES
+#define F6_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define F6_FENCE() do { } while (0)
+#endif
+constexpr int kF6SH = 3;                          // weights: w_hi 2^3 (< 16), w_lo 2^13 (<= 4) in e3m2 (largest 28)
+constexpr int kF6PSlotQ = 13 * 64;                // uint4 per projection slot of the FP6 form: 5 hi fragments + 5 x dwords 0-3 + 2.5 (3) pieces of dwords 4-5
 
 // SPLIT (small batches, r04): 16 workgroups per image leave most of the chip idle at batch 1 (the per-call drop-in path).  The hidden
 // groups are cut into gridDim.z contiguous ranges; a workgroup runs the same pipeline over its range only and stores its RAW projection
 // accumulators into `part` [gridDim.z][images][Cout][4096]; k_fcn_split_reduce adds the ranges in index order (deterministic) and applies
 // the projection's BN (+ residual).  The batched instantiation (SPLIT = false) is unchanged: g0 / g1 are constants there.
-template <bool RES, bool SPLIT = false>
+template <bool RES, bool SPLIT = false, int FP6_ = 0>      // FP6_: 0 = f16 x 3, 1 = the expansion's corrections on bf6 x fp6, 2 = the projection's too
 __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ X, const uint4* __restrict__ WE, const float* __restrict__ par,
                                                      const uint4* __restrict__ WP, const float* __restrict__ scP, const float* __restrict__ shP,
                                                      const float* __restrict__ res, float* __restrict__ Y, int Cout, int tilesP, float* __restrict__ part,
                                                      int layIn, int layOut, int nT)
 {
     const int g0 = SPLIT ? (int)(blockIdx.z * kF4Groups / gridDim.z) : 0, g1 = SPLIT ? (int)((blockIdx.z + 1) * kF4Groups / gridDim.z) : kF4Groups;
+    constexpr bool FP6 = FP6_ >= 1, P6 = FP6_ >= 2;
     extern __shared__ __attribute__((aligned(16))) uint4 f4smem[];
     // nT = tiles of the launch (16 per image); blocks 15 / 16 may run as a persistent grid that walks them (see k_fcn_irbd2)
     constexpr bool kWalk = IVF_F4_WALK && RES && !SPLIT;
@@ -2181,8 +2209,9 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     float* const sH = (float*)f4smem;                               // [2][16 ch][kF4CS >= 16 rows x kF4HP]
     float* const sD = sH + 2 * 16 * kF4CS;                          // [2][16 ch][kF4DP]
     uint4* const sWE = (uint4*)(sD + 2 * 16 * kF4DP);               // [slots][5 K steps][hi, lo][64 lanes]
-    uint4* const sWP = sWE + kF4WSlots * 640;                       // [slots][5 tiles][hi, lo][64 lanes]
-    float* const sPar = (float*)(sWP + kF4WSlots * 640);            // [slots][16 ch][12]: 9 taps (x dw BN scale), dw BN shift, expansion BN scale, shift
+    uint4* const sWP = sWE + kF4WSlots * 640;                       // [slots][5 tiles][hi, lo][64 lanes]; FP6: [slots][5 hi | 5 x dwords 0-3 | 5 x dwords 4-5 (2.5 pieces)]
+    constexpr int kPQ = P6 ? kF6PSlotQ : 640;                      // uint4 per projection slot
+    float* const sPar = (float*)(sWP + kF4WSlots * kPQ);            // [slots][16 ch][12]: 9 taps (x dw BN scale), dw BN shift, expansion BN scale, shift
     float* const sBN = sPar + kF4PSlots * (kF4ParB / 4);            // [scale 160 | shift 160] of the projection (epilogue)
 #if IVF_F4_WALK
     int tid_ = threadIdx.x;
@@ -2208,7 +2237,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
                        // whole kernel) and their 64-bit vector adds per piece are gone
     const unsigned voff16 = (unsigned)lane * 16u;
     auto dma16 = [voff16](const void* sbase, unsigned ldsAddr) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff16), "s"(sbase), "s"(ldsAddr) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff16), "s"(sbase), "s"(P6 ? __builtin_amdgcn_readfirstlane(ldsAddr) : ldsAddr) : "memory");
     };
 #undef IVF_DMA_LANE
 #define IVF_DMA_LANE(x) 0
@@ -2220,30 +2249,46 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
 #define IVF_DMA_LANE(x) (x)
 #endif
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
-    auto piece = [&](int it, int c) {           // piece c of what interval `it` consumes: WE[it] (c < 10), WP[it - 2] (c < 20), par[it] (c = 20)
+    // FP6: the projection's correction product joins TWO hidden groups (K = 2 x [d_hi | d_lo] of 16 channels = 64): it is issued in the interval of the
+    // pair's ODD group -- or of a range's last group when that is even (SPLIT: the missing half is zero) -- and its operands travel with that interval
+    auto pair_now = [&](int gp) { return (gp & 1) || (SPLIT && gp == g1 - 1); };
+    constexpr int kNP = P6 ? 24 : 21;          // pieces per interval
+    auto piece = [&](int it, int c) {           // piece c of what interval `it` consumes: WE[it] (c < 10), WP[it - 2] (c < 20 / 23), par[it] (the last one)
         const int nb = it % kF4WSlots;
         if (c < 10) {
             if (it < g1) dma16(WE + ((size_t)it * 10 + c) * 64 + IVF_DMA_LANE(lane), ldsWE + (unsigned)(nb * 640 + c * 64) * 16u);
-        } else if (c < 20) {
+        } else if (c < kNP - 1) {
             const int c2 = c - 10, gp = it - 2;
-            if (gp >= g0 && gp < g1)
-                dma16(WP + (((size_t)gp * tilesP + tile0) * 2 + c2) * 64 + IVF_DMA_LANE(lane), ldsWP + (unsigned)(nb * 640 + c2 * 64) * 16u);
-        } else if (c == 20) {
+            if (gp >= g0 && gp < g1) {
+                if constexpr (P6) {
+                    // WP6 (make_fused4): [groups][tilesP] hi fragments, then per pair [tilesP] dwords 0-3 and [tilesP] dwords 4-5 (uint2) of the bf6 operand
+                    const uint4* hiB = WP + ((size_t)gp * tilesP + tile0) * 64;
+                    const uint4* p0B = WP + ((size_t)kF4Groups * tilesP + (size_t)(gp >> 1) * tilesP + tile0) * 64;
+                    const uint4* p1B = WP + ((size_t)kF4Groups * tilesP + (size_t)(kF4Groups / 2) * tilesP) * 64 + ((size_t)(gp >> 1) * tilesP + tile0) * 32;
+                    if (c2 < 5) dma16(hiB + c2 * 64 + IVF_DMA_LANE(lane), ldsWP + (unsigned)(nb * kPQ + c2 * 64) * 16u);
+                    else if (pair_now(gp)) {
+                        if (c2 < 10) dma16(p0B + (c2 - 5) * 64 + IVF_DMA_LANE(lane), ldsWP + (unsigned)(nb * kPQ + c2 * 64) * 16u);
+                        else dma16(p1B + (c2 - 10) * 64 + IVF_DMA_LANE(lane), ldsWP + (unsigned)(nb * kPQ + c2 * 64) * 16u);      // the third is half padding
+                    }
+                } else
+                dma16(WP + (((size_t)gp * tilesP + tile0) * 2 + c2) * 64 + IVF_DMA_LANE(lane), ldsWP + (unsigned)(nb * kPQ + c2 * 64) * 16u);
+            }
+        } else if (c == kNP - 1) {
             if (it < g1 && lane < 48) dma16(par + (size_t)it * 192 + IVF_DMA_LANE(lane * 4), ldsPar + (unsigned)((it % kF4PSlots) * kF4ParB));
         }
     };
-    auto dma = [&](int it) {                    // all 21 pieces (<= 1 KB each), piece c by wave c % 8
+    auto dma = [&](int it) {                    // all 21 / 24 pieces (<= 1 KB each), piece c by wave c % 8
 #pragma unroll
         for (int r = 0; r < 3; r++) piece(it, uwave + 8 * r);
     };
     auto dma_late = [&](int it) {               // the same pieces, most of them by waves 0-3, which reach the barrier first
-        constexpr int NA = IVF_F4_DMA_A, NB = 4 * NA >= 21 ? 0 : (21 - 4 * NA + 3) / 4;
+        constexpr int NA = IVF_F4_DMA_A, NB = 4 * NA >= kNP ? 0 : (kNP - 4 * NA + 3) / 4;
         if (uwave < 4) {
 #pragma unroll
-            for (int r = 0; r < NA; r++) { const int c = uwave + 4 * r; if (c < 21) piece(it, c); }
+            for (int r = 0; r < NA; r++) { const int c = uwave + 4 * r; if (c < kNP) piece(it, c); }
         } else {
 #pragma unroll
-            for (int r = 0; r < NB; r++) { const int c = 4 * NA + (uwave - 4) + 4 * r; if (c < 21) piece(it, c); }
+            for (int r = 0; r < NB; r++) { const int c = 4 * NA + (uwave - 4) + 4 * r; if (c < kNP) piece(it, c); }
         }
     };
     dma(g0);
@@ -2276,11 +2321,35 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
 #pragma unroll
                 for (int jj = 0; jj < 4; jj++) split_pair(xv[u][s5][2 * jj], xv[u][s5][2 * jj + 1], bh[s5][u].u[jj], bl[s5][u].u[jj]);
     }
+    // FP6: the correction operand of the expansion, made once: instruction c (K = 128: 4 lane groups x 32 elements) holds, per lane,
+    // [x_hi (8 channels of K step 2c) | x_lo 2^10 | x_hi (K step 2c + 1) | x_lo 2^10] / 2^sb; c = 2 has K step 4 only (the rest zero).
+    // x_lo < ulp(x_hi) = 2^-10 2^floor(log2 x_hi), so the block's largest element is an x_hi: sb = floor(log2 max |x_hi|) - 2 puts it in [4, 8).
+    i32x6 xq[3][2]; int sbB[2] = {0, 0};
+    if constexpr (FP6) {
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                const f16x8 k1024 = {1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024};
+                const f16x8 h0 = bh[2 * c][u].v, l0 = bl[2 * c][u].v * k1024;
+                const f16x8 h1 = c < 2 ? bh[c < 2 ? 2 * c + 1 : 0][u].v : z8, l1 = c < 2 ? bl[c < 2 ? 2 * c + 1 : 0][u].v * k1024 : z8;
+                float amax = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; j++) amax = fmaxf(amax, fmaxf(fabsf((float)h0[j]), fabsf((float)h1[j])));
+                const int sb = min(max(__builtin_amdgcn_frexp_expf(amax) - 3, -40), 20);
+                const f16x32 src = {h0[0], h0[1], h0[2], h0[3], h0[4], h0[5], h0[6], h0[7], l0[0], l0[1], l0[2], l0[3], l0[4], l0[5], l0[6], l0[7],
+                                    h1[0], h1[1], h1[2], h1[3], h1[4], h1[5], h1[6], h1[7], l1[0], l1[1], l1[2], l1[3], l1[4], l1[5], l1[6], l1[7]};
+                xq[c][u] = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(src, __builtin_bit_cast(float, (127 + sb) << 23));
+                sbB[u] |= (127 + sb) << (8 * c);
+            }
+    }
     f32x16 pacc[5];
 #pragma unroll
     for (int t = 0; t < 5; t++)
 #pragma unroll
         for (int q = 0; q < 16; q++) pacc[t][q] = 0.f;
+    f16x8 pcarH = {0, 0, 0, 0, 0, 0, 0, 0}, pcarL = {0, 0, 0, 0, 0, 0, 0, 0};      // FP6: the even group's [d_hi | d_lo 2^10], carried to the odd group's interval
 
     // stencil thread: channel sch (0..15), sub-row ssr, half row sh_
     const int sch = tid >> 5, ssr = (tid >> 1) & 15, sh_ = tid & 1;
@@ -2290,7 +2359,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     const float mL = sh_ ? 1.f : 0.f, mR = sh_ ? 0.f : 1.f;          // the halo pixel comes from the row's other half (lane -1 / +1)
 
     for (int i = tid; i < 2 * 16 * kF4DP / 4; i += 512) ((uint4*)sD)[i] = make_uint4(0u, 0u, 0u, 0u);      // P(-2), P(-1): zero operands
-    for (int i = tid; i < (SPLIT ? 3 : 2) * 640; i += 512) sWP[i] = make_uint4(0u, 0u, 0u, 0u);      // slots g0 % 3, (g0 + 1) % 3
+    for (int i = tid; i < (SPLIT || P6 ? 3 : 2) * kPQ; i += 512) sWP[i] = make_uint4(0u, 0u, 0u, 0u);      // slots g0 % 3, (g0 + 1) % 3 (FP6: all -- an interval without a pair leaves its operand pieces untouched)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -2310,14 +2379,14 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 4; r++) m.eb[r] = *(const float2*)(pp + r * 12);
         const uint4* wE = sWE + ws * 640 + lane;
-        const uint4* wPq = sWP + ws * 640 + lane;
+        const uint4* wPq = sWP + ws * kPQ + lane;
         m.ea0[0].q = wE[0]; m.ea0[1].q = wE[64];
         m.pa0[0].q = wPq[0]; m.pa0[1].q = wPq[64];
     };
     auto mfma_main = [&](int it, MPre& m) {
         const int cur = it & 1, ws = it % kF4WSlots;
         const uint4* wE = sWE + ws * 640 + lane;
-        const uint4* wPq = sWP + ws * 640 + lane;
+        const uint4* wPq = sWP + ws * kPQ + lane;
         HFrag ea[2][2], pa[2][2], ph, pl;
         ea[0][0] = m.ea0[0]; ea[0][1] = m.ea0[1]; pa[0][0] = m.pa0[0]; pa[0][1] = m.pa0[1];
         f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
@@ -2362,6 +2431,105 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
         }
         F4_TIM(6);
     };
+    // FP6 form of the MFMA phase: E = 10 x 16x16x32 f16 (hi * hi; P's B splits behind them) + 6 x 16x16x128 bf6 x fp6 (both corrections);
+    // P = per tile the hi * hi product and -- in the pair's odd interval -- one 32x32x64 bf6 x fp6, E's BN + ReLU6 + stores behind them.
+    auto mfma_main6 = [&](int it, MPre& m) {
+        const int cur = it & 1, ws = it % kF4WSlots, gp = it - 2;
+        const uint4* wE = sWE + ws * 640 + lane;
+        const uint2* wE2 = (const uint2*)(sWE + ws * 640 + 8 * 64) + lane;
+        const uint4* wPq = sWP + ws * kPQ + lane;
+        HFrag ea[2], ph, pl;
+        ea[0] = m.ea0[0];
+        uint4 q6[3]; uint2 r6[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { q6[c] = wE[(5 + c) * 64]; r6[c] = wE2[c * 64]; }
+        f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
+        F4_TIM(4);
+#pragma unroll
+        for (int s5 = 0; s5 < 5; s5++) {
+            if (s5 + 1 < 5) ea[(s5 + 1) & 1].q = wE[(s5 + 1) * 64];
+            e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ea[s5 & 1].v, bh[s5][0].v, e0, 0, 0, 0);
+            e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ea[s5 & 1].v, bh[s5][1].v, e1, 0, 0, 0);
+            if (s5 < 4) split_pair(m.dv[2 * s5], m.dv[2 * s5 + 1], ph.u[s5], pl.u[s5]);
+        }
+        auto ecorr = [&](int c, auto OPS) {
+            constexpr int OP = decltype(OPS)::value;
+            const i32x8 a6 = {(int)q6[c].x, (int)q6[c].y, (int)q6[c].z, (int)q6[c].w, (int)r6[c].x, (int)r6[c].y, 0, 0};
+            const i32x8 b0 = {xq[c][0][0], xq[c][0][1], xq[c][0][2], xq[c][0][3], xq[c][0][4], xq[c][0][5], 0, 0};
+            const i32x8 b1 = {xq[c][1][0], xq[c][1][1], xq[c][1][2], xq[c][1][3], xq[c][1][4], xq[c][1][5], 0, 0};
+            e0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a6, b0, e0, 3, 2, 0, 127 - 10 - kF6SH, OP, sbB[0]);
+            e1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a6, b1, e1, 3, 2, 0, 127 - 10 - kF6SH, OP, sbB[1]);
+        };
+        ecorr(0, std::integral_constant<int, 0>{});
+        ecorr(1, std::integral_constant<int, 1>{});
+        ecorr(2, std::integral_constant<int, 2>{});
+        F4_TIM(5);
+        float* hp = sH + cur * (16 * kF4CS) + (4 * (lane >> 4)) * kF4CS + (2 * wave) * kF4HP + (lane & 15);
+        auto eepi = [&](int r) {                // E's epilogue, one row: BN + ReLU6 -> planes
+            hp[r * kF4CS] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e0[r], m.eb[r].x, m.eb[r].y), 0.f, 6.f);
+            hp[r * kF4CS + kF4HP] = __builtin_amdgcn_fmed3f(__builtin_fmaf(e1[r], m.eb[r].x, m.eb[r].y), 0.f, 6.f);
+        };
+        if constexpr (!P6) {                    // FP6_ == 1: the projection as three f16 products (the r05 loop)
+            HFrag pa[2][2];
+            pa[0][0] = m.pa0[0]; pa[0][1] = m.pa0[1];
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                if (t + 1 < 5) { pa[(t + 1) & 1][0].q = wPq[(2 * t + 2) * 64]; pa[(t + 1) & 1][1].q = wPq[(2 * t + 3) * 64]; }
+                const HFrag &ah = pa[t & 1][0], &al = pa[t & 1][1];
+                pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, ph.v, pacc[t], 0, 0, 0);
+                pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, pl.v, pacc[t], 0, 0, 0);
+                pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, ph.v, pacc[t], 0, 0, 0);
+                if (t >= 1) eepi(t - 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            const uint2* wP2 = (const uint2*)(sWP + ws * kPQ + 10 * 64) + lane;
+            const f16x8 k1024 = {1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024};
+            const f16x8 plS = pl.v * k1024;
+            HFrag pa[2];
+            pa[0] = m.pa0[0];
+            uint4 pq[2]; uint2 pr[2];
+            pq[0] = wPq[5 * 64]; pr[0] = wP2[0];     // requested in every interval (an even one reads a stale slot and drops it): the branch would expose the latency
+            if (pair_now(gp)) {                 // wave-uniform
+                const bool odd = gp & 1;
+                const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                const f16x8 a0 = odd ? pcarH : ph.v, a1 = odd ? pcarL : plS, b0 = odd ? ph.v : z8, b1 = odd ? plS : z8;
+                const f16x32 src = __builtin_shufflevector(__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15),
+                                                           __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15),
+                                                           0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
+                const i32x6 cq = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(src, 1.0f);
+                const i32x8 b6 = {cq[0], cq[1], cq[2], cq[3], cq[4], cq[5], 0, 0};
+#pragma unroll
+                for (int t = 0; t < 5; t++) {
+                    if (t + 1 < 5) { pa[(t + 1) & 1].q = wPq[(t + 1) * 64]; pq[(t + 1) & 1] = wPq[(6 + t) * 64]; pr[(t + 1) & 1] = wP2[(t + 1) * 64]; }
+                    const i32x8 a6 = {(int)pq[t & 1].x, (int)pq[t & 1].y, (int)pq[t & 1].z, (int)pq[t & 1].w, (int)pr[t & 1].x, (int)pr[t & 1].y, 0, 0};
+                    pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[t & 1].v, ph.v, pacc[t], 0, 0, 0);
+                    pacc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a6, b6, pacc[t], 3, 2, 0, 127 - 10 - kF6SH, 0, 127);
+                    if (t >= 1) eepi(t - 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 5; t++) {
+                    if (t + 1 < 5) pa[(t + 1) & 1].q = wPq[(t + 1) * 64];
+                    pacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[t & 1].v, ph.v, pacc[t], 0, 0, 0);
+                    if (t >= 1) eepi(t - 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            pcarH = ph.v; pcarL = plS;
+        }
+        F4_TIM(6);
+    };
     auto stencil_phase = [&](int it) {          // S(it - 1): 3x3 on the 16 x 16 planes of group it - 1, + BN + ReLU6
         const int g = it - 1;
         if (g < g0 || g >= g1) return;
@@ -2401,8 +2569,9 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
         {
             MPre m;
             mfma_pre(it, m); __builtin_amdgcn_sched_barrier(0);
-            if (wave < 4) { IVF_PRIO_MFMA(1); mfma_main(it, m); IVF_PRIO_MFMA(0); F4_TIM(1); IVF_PRIO_STEN(1); stencil_phase(it); IVF_PRIO_STEN(0); F4_TIM(2); }
-            else { IVF_PRIO_STEN(1); stencil_phase(it); IVF_PRIO_STEN(0); F4_TIM(2); __builtin_amdgcn_sched_barrier(0); IVF_PRIO_MFMA(1); mfma_main(it, m); IVF_PRIO_MFMA(0); F4_TIM(1); }
+            auto mm = [&]() { if constexpr (FP6) mfma_main6(it, m); else mfma_main(it, m); };
+            if (wave < 4) { IVF_PRIO_MFMA(1); mm(); IVF_PRIO_MFMA(0); F4_TIM(1); IVF_PRIO_STEN(1); stencil_phase(it); IVF_PRIO_STEN(0); F4_TIM(2); }
+            else { IVF_PRIO_STEN(1); stencil_phase(it); IVF_PRIO_STEN(0); F4_TIM(2); __builtin_amdgcn_sched_barrier(0); IVF_PRIO_MFMA(1); mm(); IVF_PRIO_MFMA(0); F4_TIM(1); }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the pieces of it + 1, requested an interval ago
         dma_late(it + 2); F4_TIM(0);                             // land during it + 1; their slots were last read in it - 1
@@ -2429,7 +2598,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4(const float* __restrict__ 
     // (hi + lo = the 22-bit value the expansion multiplied; the residual add then differs from the exact f32 by <= 2^-22 relative).  Re-reading
     // it from memory cost the epilogue a round trip with every CU of the chip asking at once (phase timers: 34k of a workgroup's ~230k cycles).
     // The fragments are transposed to the accumulator layout tile by tile through a wave-private 4.6 KB piece of the (now idle) hidden planes.
-    constexpr bool kResFrags = RES && !SPLIT && IVF_RES_FROM_FRAGS;
+    constexpr bool kResFrags = RES && !SPLIT && IVF_RES_FROM_FRAGS && !FP6;      // FP6: the exact lo halves are gone after the prologue
     float* const sxw = (float*)f4smem + wave * (32 * 36);
     float rvAll[5][16];
     if (RES && !SPLIT && !kResFrags) {
@@ -3841,7 +4010,8 @@ struct ivf_fcn {
     std::vector<Gemm> pw;        // in forward order: per block expand (t>1), project; then decoder cbr
     std::vector<Dw> dw;
     float* dLastW = nullptr; float lastBias = 0.f;
-    struct Fused4 { uint4 *dWE = nullptr, *dWP = nullptr; float* dPar = nullptr; int cout = 0, tilesP = 0; } f4[3];   // blocks 15-17 (k_fcn_irbd4)
+    struct Fused4 { uint4 *dWE = nullptr, *dWP = nullptr; float* dPar = nullptr; int cout = 0, tilesP = 0;
+                    uint4 *dWE6 = nullptr, *dWP6 = nullptr; } f4[3];   // blocks 15-17 (k_fcn_irbd4); dWE6: the expansion's operands in the FP6 form (r06)
     Fused4 f2[7];                                                                                                          // blocks 8-14 (k_fcn_irbd2)
     Fused4 f1[3];                                                                                                          // blocks 5-7 (k_fcn_irbd2, DIL = 1)
     float *bufIn = nullptr, *bufA = nullptr, *bufB = nullptr, *bufH1 = nullptr, *bufH2 = nullptr, *bufLogits = nullptr;
@@ -3943,6 +4113,37 @@ int make_gemm(ivf_fcn* f, const float* w, int cout, int cin, int taps, const std
     return upload(f, shp, &g.dShift);
 }
 
+// 6-bit operand codes of v_mfma_scale_f32_*_f8f6f4 (OCP MX element formats): e3m2 ("bf6": 1 + 3 + 2 bits, bias 3, largest 28) and e2m3 ("fp6":
+// 1 + 2 + 3 bits, bias 1, largest 7.5), no inf / NaN.  enc6: nearest code, ties to the even code, saturating -- what v_cvt_scalef32_pk32_*6_f16
+// does on the device (tools/probe/mfma_fp8_mix.hip checks host-packed operands against device-converted ones).
+float dec6(int code, bool bf6)
+{
+    const int sgn = code & 32; code &= 31;
+    float v;
+    if (bf6) { const int e = code >> 2, m = code & 3; v = e ? (1.f + m * 0.25f) * std::ldexp(1.f, e - 3) : m * 0.0625f; }
+    else     { const int e = code >> 3, m = code & 7; v = e ? (1.f + m * 0.125f) * std::ldexp(1.f, e - 1) : m * 0.125f; }
+    return sgn ? -v : v;
+}
+int enc6(float x, bool bf6)
+{
+    const float a = std::fabs(x);
+    int best = 0; float bd = 1e30f;
+    for (int c = 0; c < 32; c++) {
+        const float d = std::fabs(dec6(c, bf6) - a);
+        if (d < bd || (d == bd && !(c & 1))) { bd = d; best = c; }
+    }
+    return best | (x < 0.f ? 32 : 0);
+}
+void pack6(uint32_t* dst6, const int* codes32)         // element i at bits [6 i, 6 i + 6) of 6 dwords
+{
+    for (int i = 0; i < 6; i++) dst6[i] = 0;
+    for (int i = 0; i < 32; i++) {
+        const unsigned bit = 6 * i, w = bit >> 5, sft = bit & 31;
+        dst6[w] |= (uint32_t)codes32[i] << sft;
+        if (sft > 26) dst6[w + 1] |= (uint32_t)codes32[i] >> (32 - sft);
+    }
+}
+
 // Operands of k_fcn_irbd4 (blocks 15-17): expansion rows as A fragments of v_mfma_f32_16x16x32_f16 (lane: row = lane & 15,
 // k = 8 (lane >> 4) + j) per group of 16 hidden channels and K step of 32 input channels; projection rows as A fragments of
 // v_mfma_f32_32x32x16_f16 (lane: row = lane & 31, k = 8 (lane >> 5) + j) per group (= one K step) and output tile; per hidden
@@ -3977,6 +4178,75 @@ int make_fused4(ivf_fcn* f, ivf_fcn::Fused4& F, const float* we, const std::vect
     int rc;
     if ((rc = upload(f, qe, &de)) || (rc = upload(f, qp, &dp)) || (rc = upload(f, par, &F.dPar))) return rc;
     F.dWE = reinterpret_cast<uint4*>(de); F.dWP = reinterpret_cast<uint4*>(dp);
+    if (cin == kF4Cin && hid == kF4Hid) {
+        // FP6 form of the expansion (k_fcn_irbd4<.., FP6>): per group ten 1 KB pieces -- 0-4: the hi fragments of the five K steps; 5-7: dwords 0-3 of
+        // the bf6 correction operand of instruction c (lane (row m = lane & 15, kq = lane >> 4), element e = 8 seg + j: channel 32 (2c + (seg >> 1)) +
+        // 8 kq + j; seg even -> w_lo 2^(SH + 10) (meets x_hi), seg odd -> w_hi 2^SH (meets x_lo 2^10); K step 5 does not exist: zero); 8-9: dwords 4-5
+        // as [c][lane] uint2 (the last half piece is padding)
+        std::vector<float> q6((size_t)groups * 10 * 64 * 4, 0.f);
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(q6.data());
+        uint16_t* d16 = reinterpret_cast<uint16_t*>(q6.data());
+        for (int g = 0; g < groups; g++) {
+            const size_t base = (size_t)g * 10 * 64 * 4;                 // dwords
+            for (int s5 = 0; s5 < 5; s5++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++)
+                        d16[(base + ((size_t)s5 * 64 + lane) * 4) * 2 + j] = f32_to_f16(we[(size_t)(16 * g + (lane & 15)) * cin + 32 * s5 + 8 * (lane >> 4) + j]);
+            for (int c = 0; c < 3; c++)
+                for (int lane = 0; lane < 64; lane++) {
+                    int codes[32];
+                    for (int e = 0; e < 32; e++) {
+                        const int seg = e >> 3, j = e & 7, s5 = 2 * c + (seg >> 1);
+                        float v = 0.f;
+                        if (s5 < 5) {
+                            const float w = we[(size_t)(16 * g + (lane & 15)) * cin + 32 * s5 + 8 * (lane >> 4) + j];
+                            const float hi = f16_to_f32(f32_to_f16(w)), lo = f16_to_f32(f32_to_f16(w - hi));
+                            v = (seg & 1) ? std::ldexp(hi, kF6SH) : std::ldexp(lo, kF6SH + 10);
+                        }
+                        codes[e] = enc6(v, true);
+                    }
+                    uint32_t six[6]; pack6(six, codes);
+                    for (int q = 0; q < 4; q++) d32[base + ((size_t)(5 + c) * 64 + lane) * 4 + q] = six[q];
+                    d32[base + (size_t)8 * 64 * 4 + ((size_t)c * 64 + lane) * 2 + 0] = six[4];
+                    d32[base + (size_t)8 * 64 * 4 + ((size_t)c * 64 + lane) * 2 + 1] = six[5];
+                }
+        }
+        float* d6 = nullptr;
+        if ((rc = upload(f, q6, &d6))) return rc;
+        F.dWE6 = reinterpret_cast<uint4*>(d6);
+        // FP6 form of the projection: [groups][tilesP][64 lanes] hi fragments (uint4), then per PAIR of groups (2p, 2p + 1) and tile the bf6 correction
+        // operand of v_mfma_scale_f32_32x32x64_f8f6f4 -- lane (row = lane & 31, h = lane >> 5), element e = 8 seg + j: hidden channel 16 (2p + (seg >> 1)) +
+        // 8 h + j; seg even -> w_lo 2^(SH + 10), seg odd -> w_hi 2^SH -- as [pairs][tilesP][64] dwords 0-3 and [pairs][tilesP][64] dwords 4-5 (+ 1 KB padding:
+        // the last DMA piece of a workgroup's five tiles is half used)
+        const int T = F.tilesP, pairs = groups / 2;
+        const size_t hiQ = (size_t)groups * T * 64, p0Q = (size_t)pairs * T * 64, p1Q = (size_t)pairs * T * 32 + 64;      // in uint4
+        std::vector<float> p6((hiQ + p0Q + p1Q) * 4, 0.f);
+        uint32_t* w32 = reinterpret_cast<uint32_t*>(p6.data());
+        uint16_t* w16 = reinterpret_cast<uint16_t*>(p6.data());
+        for (int g = 0; g < groups; g++)
+            for (int t = 0; t < T; t++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++)
+                        w16[(((size_t)g * T + t) * 64 + lane) * 8 + j] = f32_to_f16(wp[(size_t)(32 * t + (lane & 31)) * hid + 16 * g + 8 * (lane >> 5) + j]);
+        for (int pr = 0; pr < pairs; pr++)
+            for (int t = 0; t < T; t++)
+                for (int lane = 0; lane < 64; lane++) {
+                    int codes[32];
+                    for (int e = 0; e < 32; e++) {
+                        const int seg = e >> 3, j = e & 7, g = 2 * pr + (seg >> 1);
+                        const float w = wp[(size_t)(32 * t + (lane & 31)) * hid + 16 * g + 8 * (lane >> 5) + j];
+                        const float hi = f16_to_f32(f32_to_f16(w)), lo = f16_to_f32(f32_to_f16(w - hi));
+                        codes[e] = enc6((seg & 1) ? std::ldexp(hi, kF6SH) : std::ldexp(lo, kF6SH + 10), true);
+                    }
+                    uint32_t six[6]; pack6(six, codes);
+                    for (int q = 0; q < 4; q++) w32[(hiQ + ((size_t)pr * T + t) * 64 + lane) * 4 + q] = six[q];
+                    w32[(hiQ + p0Q) * 4 + (((size_t)pr * T + t) * 64 + lane) * 2 + 0] = six[4];
+                    w32[(hiQ + p0Q) * 4 + (((size_t)pr * T + t) * 64 + lane) * 2 + 1] = six[5];
+                }
+        float* dp6 = nullptr;
+        if ((rc = upload(f, p6, &dp6))) return rc;
+        F.dWP6 = reinterpret_cast<uint4*>(dp6);
+    }
     return IVF_OK;
 }
 
@@ -3994,12 +4264,18 @@ int reserve_lds()
         {reinterpret_cast<const void*>(&k_fcn_irbd2<96, 160, false>), D2Cfg<96, 160>::LDS, "k_fcn_irbd2<96,160,false>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd4<true>), kF4Lds, "k_fcn_irbd4<true>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd4<false>), kF4Lds, "k_fcn_irbd4<false>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd4<true, false, 1>), kF4Lds, "k_fcn_irbd4<true,fp6 E>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd4<false, false, 1>), kF4Lds, "k_fcn_irbd4<false,fp6 E>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd4<false, true, 1>), kF4Lds, "k_fcn_irbd4<split,fp6 E>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd4<true, false, 2>), kF6Lds, "k_fcn_irbd4<true,fp6>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd4<false, false, 2>), kF6Lds, "k_fcn_irbd4<false,fp6>"},
         // the small-batch (SPLIT) instances
         {reinterpret_cast<const void*>(&k_fcn_irbd2<64, 64, true, 2, true>), D2Cfg<64, 64>::LDS, "k_fcn_irbd2<64,64,split>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd2<64, 96, false, 2, true>), D2Cfg<64, 96>::LDS, "k_fcn_irbd2<64,96,split>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd2<96, 96, true, 2, true>), D2Cfg<96, 96>::LDS, "k_fcn_irbd2<96,96,split>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd2<96, 160, false, 2, true>), D2Cfg<96, 160>::LDS, "k_fcn_irbd2<96,160,split>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd4<false, true>), kF4Lds, "k_fcn_irbd4<split>"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd4<false, true, 2>), kF6Lds, "k_fcn_irbd4<split,fp6>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd4h), kH4Lds, "k_fcn_irbd4h"},
 #ifdef IVF_EXPERIMENT
         {reinterpret_cast<const void*>(&k_fcn_irbd4w<true>), kF4Lds, "k_fcn_irbd4w<true>"},
@@ -4237,6 +4513,7 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             const char* kname = "k_fcn_irbd4";
             const int ns = split_ways(n, kF4Groups, F.cout);
             const dim3 grid(16 * n, F.cout / 160, ns);
+            static const int fp6 = IVF_EXP_ENV("IVF_FCN_FP6") ? atoi(IVF_EXP_ENV("IVF_FCN_FP6")) : IVF_F4_FP6;     // 0: the f16 x 3 expansion (r05)
             static const int half4 = IVF_EXP_ENV("IVF_FCN_HALF4") ? atoi(IVF_EXP_ENV("IVF_FCN_HALF4")) : 1;     // 0: block 17 as two workgroups per 256-pixel tile (r03 / r04)
 #ifdef IVF_EXPERIMENT
             static const int roles = IVF_EXP_ENV("IVF_FCN_ROLES") ? atoi(IVF_EXP_ENV("IVF_FCN_ROLES")) : 0;      // 1: role-specialised waves (k_fcn_irbd4w)
@@ -4254,6 +4531,13 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             } else
 #endif
             if (ns > 1) {
+                if (fp6 == 1 && F.dWE6)
+                    hipLaunchKernelGGL((k_fcn_irbd4<false, true, 1>), grid, dim3(512), kF4Lds, s, x, F.dWE6, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y,
+                                       F.cout, F.tilesP, f->bufPart, layIn, layOut, 16 * n);
+                else if (fp6 && F.dWE6 && F.dWP6)      // the same arithmetic as the batched form: a batch of 1 and a batch of 128 differ by summation order only
+                    hipLaunchKernelGGL((k_fcn_irbd4<false, true, 2>), grid, dim3(512), kF6Lds, s, x, F.dWE6, F.dPar, F.dWP6, pj.dScale, pj.dShift, (const float*)nullptr, y,
+                                       F.cout, F.tilesP, f->bufPart, layIn, layOut, 16 * n);
+                else
                 hipLaunchKernelGGL((k_fcn_irbd4<false, true>), grid, dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y,
                                    F.cout, F.tilesP, f->bufPart, layIn, layOut, 16 * n);
                 launch_split_reduce(f, ns, n, F.cout, pj, bk.res ? x : nullptr, y, layIn, layOut, s);
@@ -4262,7 +4546,19 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
                 hipLaunchKernelGGL(k_fcn_irbd4h, dim3(IVF_H4_WALK ? persistent_grid(f, 32 * n) : 32 * n), dim3(512), kH4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, y,
                                    layIn, layOut, 32 * n);
                 kname = "k_fcn_irbd4h";
-            } else if (bk.res)
+            } else if (fp6 == 1 && F.dWE6 && bk.res)
+                hipLaunchKernelGGL((k_fcn_irbd4<true, false, 1>), dim3(16 * n, grid.y, 1), dim3(512), kF4Lds, s, x, F.dWE6, F.dPar, F.dWP, pj.dScale,
+                                   pj.dShift, x, y, F.cout, F.tilesP, (float*)nullptr, layIn, layOut, 16 * n);
+            else if (fp6 == 1 && F.dWE6)
+                hipLaunchKernelGGL((k_fcn_irbd4<false, false, 1>), grid, dim3(512), kF4Lds, s, x, F.dWE6, F.dPar, F.dWP, pj.dScale, pj.dShift, (const float*)nullptr, y, F.cout, F.tilesP,
+                                   (float*)nullptr, layIn, layOut, 16 * n);
+            else if (fp6 && F.dWE6 && bk.res)
+                hipLaunchKernelGGL((k_fcn_irbd4<true, false, 2>), dim3(16 * n, grid.y, 1), dim3(512), kF6Lds, s, x, F.dWE6, F.dPar, F.dWP6, pj.dScale,
+                                   pj.dShift, x, y, F.cout, F.tilesP, (float*)nullptr, layIn, layOut, 16 * n);
+            else if (fp6 && F.dWE6 && F.dWP6)
+                hipLaunchKernelGGL((k_fcn_irbd4<false, false, 2>), grid, dim3(512), kF6Lds, s, x, F.dWE6, F.dPar, F.dWP6, pj.dScale, pj.dShift, (const float*)nullptr, y, F.cout, F.tilesP,
+                                   (float*)nullptr, layIn, layOut, 16 * n);
+            else if (bk.res)
                 hipLaunchKernelGGL((k_fcn_irbd4<true>), dim3(IVF_F4_WALK && grid.y == 1 ? persistent_grid(f, 16 * n) : 16 * n, grid.y, 1), dim3(512), kF4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale,
                                    pj.dShift, x, y, F.cout, F.tilesP, (float*)nullptr, layIn, layOut, 16 * n);
             else

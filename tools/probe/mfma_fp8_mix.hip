@@ -286,9 +286,194 @@ static void rates()
     }
 }
 
-int main()
+// ------------------------------------------------------------------------------------------------------------ part 3: the form the kernel uses
+// v_mfma_scale_f32_16x16x128_f8f6f4 with A = host-packed bf6 (e3m2) rows, B = fp6 (e2m3) made by v_cvt_scalef32_pk32_fp6_f16 with a
+// PER-LANE scale (the lane's own 2^sb, from its largest element), scale bytes selected by opsel from a packed register.
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+static float dec6(int code, bool bf6)                         // value of a 6-bit code
+{
+    const int sgn = code & 32; code &= 31;
+    float v;
+    if (bf6) { const int e = code >> 2, m = code & 3; v = e ? (1.f + m * 0.25f) * std::ldexp(1.f, e - 3) : m * 0.0625f; }
+    else     { const int e = code >> 3, m = code & 7; v = e ? (1.f + m * 0.125f) * std::ldexp(1.f, e - 1) : m * 0.125f; }
+    return sgn ? -v : v;
+}
+static int enc6(float x, bool bf6)                            // nearest code, ties to the even code, saturating
+{
+    const float a = std::fabs(x);
+    int best = 0; float bd = 1e30f;
+    for (int c = 0; c < 32; c++) {
+        const float d = std::fabs(dec6(c, bf6) - a);
+        if (d < bd || (d == bd && !(c & 1))) { bd = d; best = c; }
+    }
+    return best | (x < 0.f ? 32 : 0);
+}
+static void pack6(uint32_t* dst6, const int* codes32)         // element i at bits [6 i, 6 i + 6) of 6 dwords
+{
+    for (int i = 0; i < 6; i++) dst6[i] = 0;
+    for (int i = 0; i < 32; i++) {
+        const unsigned bit = 6 * i, w = bit >> 5, sft = bit & 31;
+        dst6[w] |= (uint32_t)codes32[i] << sft;
+        if (sft > 26) dst6[w + 1] |= (uint32_t)codes32[i] >> (32 - sft);
+    }
+}
+// one wave: D[16][16] = sum_k A[m][k] B[k][n], K = 128; lane (r = l & 15, kq = l >> 4) holds k = 32 kq + e of row / column r
+__global__ void k_mfma6x128(float* d, const int* A6, const _Float16* B, int* sbOut, int scaleA)
+{
+    const int l = threadIdx.x;
+    i32x8 a = {A6[l * 6], A6[l * 6 + 1], A6[l * 6 + 2], A6[l * 6 + 3], A6[l * 6 + 4], A6[l * 6 + 5], 0, 0};
+    f16x32 y; float amax = 0.f;
+    for (int i = 0; i < 32; i++) { y[i] = B[l * 32 + i]; amax = fmaxf(amax, fabsf((float)y[i])); }
+    const int sb = __builtin_amdgcn_frexp_expf(amax) - 3;                  // amax / 2^sb in [4, 8)
+    const float scl = __builtin_bit_cast(float, (127 + sb) << 23);
+    i32x6 pb = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(y, scl);
+    i32x8 b = {pb[0], pb[1], pb[2], pb[3], pb[4], pb[5], 0, 0};
+    const int sbReg = (77 << 0) | ((127 + sb) << 16) | (55 << 24);         // the lane's byte sits in byte 2: opsel 2
+    f32x4_ c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 3, 2, 0, scaleA, 2, sbReg);
+    for (int i = 0; i < 4; i++) d[l * 4 + i] = c[i];
+    sbOut[l] = sb;
+}
+template <int CB, int BL>
+__global__ __launch_bounds__(256) void k_rate128(float* out, int iters)
+{
+    i32x8 a, b;
+    for (int i = 0; i < 8; i++) { a[i] = 0x08208208 + threadIdx.x; b[i] = 0x10410410 + i; }
+    f32x4_ acc[8];
+    for (int t = 0; t < 8; t++) acc[t] = f32x4_{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; it++)
+#pragma unroll
+        for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc[t], CB, BL, 0, 120, 0, 127);
+    float s = 0.f;
+    for (int t = 0; t < 8; t++) for (int q = 0; q < 4; q++) s += acc[t][q];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int CB, int BL>
+static void rate128(const char* name)
+{
+    float* d; (void)hipMalloc(&d, 256 * 256 * sizeof(float));
+    const int iters = 20000;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((k_rate128<CB, BL>), dim3(256), dim3(256), 0, 0, d, 100);
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((k_rate128<CB, BL>), dim3(256), dim3(256), 0, 0, d, iters);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("   v_mfma_scale_f32_16x16x128_f8f6f4 %-28s %.1f cycles per instruction @2.0GHz (one wave per SIMD, 8 independent accumulators)\n", name, ms * 1e-3 * 2.0e9 / iters / 8);
+    (void)hipFree(d);
+}
+static void kernel_form()
+{
+    std::vector<float> Af(16 * 128), Bf(128 * 16);
+    uint32_t seed = 12345u;
+    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (float)((seed >> 8) & 0xffff) / 65536.f; };
+    for (auto& v : Af) v = (rnd() - 0.5f) * 30.f;                                   // weights-like, in +-15: bf6 range (28)
+    for (int k = 0; k < 128; k++) for (int n = 0; n < 16; n++) Bf[k * 16 + n] = (rnd() - 0.3f) * std::ldexp(1.f, (n * 3 + k / 32 * 5) % 19 - 6);   // magnitudes differ per (column, K block)
+    std::vector<uint32_t> A6(64 * 6); std::vector<_Float16> Bh(64 * 32);
+    std::vector<float> Aq(16 * 128);
+    for (int l = 0; l < 64; l++) {
+        int codes[32];
+        for (int e = 0; e < 32; e++) { const int m = l & 15, k = 32 * (l >> 4) + e; codes[e] = enc6(Af[m * 128 + k], true); Aq[m * 128 + k] = dec6(codes[e], true); }
+        pack6(&A6[l * 6], codes);
+        for (int e = 0; e < 32; e++) Bh[l * 32 + e] = (_Float16)Bf[(32 * (l >> 4) + e) * 16 + (l & 15)];
+    }
+    int* dA; _Float16* dB; float* dD; int* dS;
+    (void)hipMalloc(&dA, 64 * 24); (void)hipMalloc(&dB, 64 * 64); (void)hipMalloc(&dD, 1024); (void)hipMalloc(&dS, 256);
+    (void)hipMemcpy(dA, A6.data(), 64 * 24, hipMemcpyHostToDevice); (void)hipMemcpy(dB, Bh.data(), 64 * 64, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_mfma6x128, dim3(1), dim3(64), 0, 0, dD, dA, dB, dS, 127 - 3);
+    std::vector<float> D(256); std::vector<int> S(64);
+    (void)hipMemcpy(D.data(), dD, 1024, hipMemcpyDeviceToHost); (void)hipMemcpy(S.data(), dS, 256, hipMemcpyDeviceToHost);
+    // reference: A dequantised (host codes), B quantised per lane block with the lane's scale (host enc6 = the device conversion?), x 2^-3
+    double worst = 0, big = 0;
+    for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) {
+        const int n = l & 15, m = 4 * (l >> 4) + r;
+        double ref = 0;
+        for (int k = 0; k < 128; k++) {
+            const int sb = S[(k >> 5) * 16 + n];
+            const float bq = dec6(enc6((float)(_Float16)Bf[k * 16 + n] * std::ldexp(1.f, -sb), false), false) * std::ldexp(1.f, sb);
+            ref += (double)Aq[m * 128 + k] * bq;
+        }
+        ref *= 0.125;
+        worst = std::fmax(worst, std::fabs(D[l * 4 + r] - ref)); big = std::fmax(big, std::fabs(ref));
+    }
+    printf("16x16x128: A bf6 host-packed (lane (m, kq): k = 32 kq + e), B fp6 by the device conversion with PER-LANE scales (opsel 2), scale_a 2^-3:\n"
+           "   max |D - ref| = %g (largest |ref| %g; f32 accumulation order only)   lane scales sb: %d %d %d %d ... %d\n", worst, big, S[0], S[1], S[2], S[3], S[63]);
+    rate128<0, 0>("fp8 x fp8:"); rate128<2, 2>("fp6 x fp6:"); rate128<3, 2>("bf6 (A) x fp6 (B):"); rate128<3, 3>("bf6 x bf6:"); rate128<0, 2>("fp8 (A) x fp6 (B):");
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dD); (void)hipFree(dS);
+}
+
+// the same harness for every matrix instruction in question: NACC independent accumulators, back to back, one wave per SIMD
+template <int KIND, int NACC>
+__global__ __launch_bounds__(256) void k_rate_any(float* out, int iters)
+{
+    i32x8 a, b;
+    for (int i = 0; i < 8; i++) { a[i] = 0x08208208 + threadIdx.x; b[i] = 0x10410410 + i; }
+    f16x8 ha, hb;
+    for (int i = 0; i < 8; i++) { ha[i] = (_Float16)(1.f + i); hb[i] = (_Float16)(0.5f * i); }
+    const int sa = 120, sb = 127;
+    float s = 0.f;
+    if (KIND == 0 || (KIND >= 2 && KIND <= 4)) {
+        f32x16 acc[NACC];
+        for (int t = 0; t < NACC; t++) for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
+        for (int it = 0; it < iters; it++)
+#pragma unroll
+            for (int t = 0; t < NACC; t++) {
+                if (KIND == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, acc[t], 0, 0, 0);
+                if (KIND == 2) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[t], 0, 0, 0, sa, 0, sb);
+                if (KIND == 3) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[t], 2, 2, 0, sa, 0, sb);
+                if (KIND == 4) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[t], 3, 2, 0, sa, 0, sb);
+            }
+        for (int t = 0; t < NACC; t++) for (int q = 0; q < 16; q++) s += acc[t][q];
+    } else {
+        // the 16 x 16 forms through inline asm: the compiler's allocation of the four-register accumulators shuffled them through
+        // v_accvgpr moves every iteration (measured 35 cycles for v_mfma_f32_16x16x32_f16)
+        f32x4_ acc4[NACC];
+        for (int t = 0; t < NACC; t++) acc4[t] = f32x4_{0.f, 0.f, 0.f, 0.f};
+        const i32x6 a6 = {a[0], a[1], a[2], a[3], a[4], a[5]}, b6 = {b[0], b[1], b[2], b[3], b[4], b[5]};
+        for (int it = 0; it < iters; it++)
+#pragma unroll
+            for (int t = 0; t < NACC; t++) {
+                if (KIND == 1) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc4[t]) : "v"(ha), "v"(hb));
+                if (KIND == 5) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc4[t]) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+                if (KIND == 6) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2" : "+v"(acc4[t]) : "v"(a6), "v"(b6), "v"(sa), "v"(sb));
+                if (KIND == 7) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:3 blgp:2" : "+v"(acc4[t]) : "v"(a6), "v"(b6), "v"(sa), "v"(sb));
+            }
+        for (int t = 0; t < NACC; t++) for (int q = 0; q < 4; q++) s += acc4[t][q];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int KIND, int NACC>
+static void rate_any(const char* name, double macs)
+{
+    float* d; (void)hipMalloc(&d, 256 * 256 * sizeof(float));
+    const int iters = 20000;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((k_rate_any<KIND, NACC>), dim3(256), dim3(256), 0, 0, d, 100);
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((k_rate_any<KIND, NACC>), dim3(256), dim3(256), 0, 0, d, iters);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double cyc = ms * 1e-3 * 2.0e9 / iters / NACC;
+    printf("   %-44s %d accumulators: %6.1f cycles @2.0GHz per instruction = %6.0f MAC per cycle and SIMD\n", name, NACC, cyc, macs / cyc);
+    (void)hipFree(d);
+}
+static void rates_plain()
+{
+    printf("matrix instruction issue, back to back (one wave per SIMD):\n");
+    rate_any<0, 4>("v_mfma_f32_32x32x16_f16", 16384); rate_any<0, 8>("v_mfma_f32_32x32x16_f16", 16384);
+    rate_any<1, 4>("v_mfma_f32_16x16x32_f16", 8192); rate_any<1, 8>("v_mfma_f32_16x16x32_f16", 8192);
+    rate_any<2, 4>("scale 32x32x64 fp8 x fp8", 65536); rate_any<3, 4>("scale 32x32x64 fp6 x fp6", 65536); rate_any<3, 8>("scale 32x32x64 fp6 x fp6", 65536);
+    rate_any<4, 4>("scale 32x32x64 bf6 x fp6", 65536);
+    rate_any<5, 4>("scale 16x16x128 fp8 x fp8", 32768); rate_any<6, 2>("scale 16x16x128 fp6 x fp6", 32768); rate_any<6, 4>("scale 16x16x128 fp6 x fp6", 32768);
+    rate_any<6, 8>("scale 16x16x128 fp6 x fp6", 32768); rate_any<7, 8>("scale 16x16x128 bf6 x fp6", 32768);
+}
+
+int main(int argc, char** argv)
 {
     semantics();
+    kernel_form();
+    rates_plain();
+    if (argc > 1) return 0;
     rates<0>();
     rates<200>();
     rates<420>();       // block 15 / 16's mix: matrix pipe busy 0.50, VALU issue 0.43 of the kernel's time => ~84 VALU per 12 MFMAs
