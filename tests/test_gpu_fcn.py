@@ -147,8 +147,12 @@ print("OK %.3g" % err)
     {"IVF_FCN_HEAD_IL": "1", "IVF_FCN_HEADCHUNK": "8"},
     # no small-batch schedule: a single image runs the batched whole-block kernels (16 workgroups per launch) and equals its batch slot bit for bit
     {"IVF_FCN_SPLIT": "0"},
+    # r06: the expansion's two correction products of blocks 15 / 16 (and block 17's two-workgroup form) on the block-scaled bf6 x fp6 matrix instruction
+    # (k_fcn_irbd4<.., FP6>; not the default: DESIGN.md section 7.r06) -- with and without the small-batch schedule, so the batched instance runs too
+    {"IVF_FCN_FP6": "1"},
+    {"IVF_FCN_FP6": "1", "IVF_FCN_SPLIT": "0", "IVF_FCN_HALF4": "0"},
 ], ids=["default", "layerwise", "expand-pxt2", "dwpw-256", "no-stride2-fusion", "no-stem-fusion", "irb-blocks-2-11",
-        "irb-none", "dwpw8-all", "dwpw8-none", "dwpw-4rows-all", "dwpw-4rows-none", "conv-last-unfused", "blocks-8-14-unfused", "blocks-15-17-unfused", "blocks-5-7-unfused", "block-17-two-workgroups", "head-chunked", "head-row-interleaved", "head-chunked-and-interleaved", "no-small-batch-split"])
+        "irb-none", "dwpw8-all", "dwpw8-none", "dwpw-4rows-all", "dwpw-4rows-none", "conv-last-unfused", "blocks-8-14-unfused", "blocks-15-17-unfused", "blocks-5-7-unfused", "block-17-two-workgroups", "head-chunked", "head-row-interleaved", "head-chunked-and-interleaved", "no-small-batch-split", "fp6-expansion", "fp6-expansion-batched-kernels"])
 def test_fcn_kernel_variants_match_goldens_and_are_deterministic(env):
     """The FCN picks between several kernels per layer (measured defaults, env overrides for tuning).  Every variant must
     meet the same bar, batch results must not depend on the batch slot, and repeated runs must be bit-identical (this is
