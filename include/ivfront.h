@@ -199,6 +199,17 @@ typedef struct ivf_frontend_config {
     int32_t device_id;
 } ivf_frontend_config;
 
+/* Threads and streams (r05 / r06): a handle may be used from any thread, one call at a time; different handles may be used from different threads
+ * at once.  But every front end of a process on ONE device runs its batches on the same three internal streams (a per-device pool, created once,
+ * never destroyed -- six more streams for a second front end cost the first one a quarter of its throughput on this runtime): two front ends on
+ * one device are executed IN TURN, not side by side, and they are coupled through those streams:
+ *   - ivf_frontend_sync(A) also waits for what B has enqueued so far;
+ *   - work a caller puts on ivf_frontend_batch_stream(A) (a collective, the tracker step) sits in front of B's next batches too -- a slow peer
+ *     in A's all-gather stalls an unrelated front end, e.g. the second camera of a rig.  Keep such work short, or run it on a stream of your own
+ *     behind ivf_frontend_pack_gather_block_of(..., your_stream) (see IVF_STREAM_OF_BATCH below);
+ *   - ivf_frontend_destroy(A) waits for A's own batches only (their completion events); finish what you enqueued behind them on a lent
+ *     stream before destroying the handle.
+ * Front ends on different devices share nothing. */
 int  ivf_frontend_create(const ivf_frontend_config* cfg, ivf_frontend** out);
 void ivf_frontend_destroy(ivf_frontend* fe);
 /* Enqueue one batch; asynchronous.  The batch is ordered after everything already enqueued on `hip_stream`
@@ -210,7 +221,8 @@ void ivf_frontend_destroy(ivf_frontend* fe);
  * d_cost: device pointer to n_pairs u8 cost maps (same layout) or NULL. */
 int  ivf_frontend_run(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_right, const uint8_t* d_cost,
                       size_t image_stride, int row_stride, int n_pairs, void* hip_stream);
-/* Block until every ivf_frontend_run on this handle has finished; reports device-side consistency errors. */
+/* Block until every ivf_frontend_run on this handle has finished (and, the internal streams being shared per device, whatever other front ends of
+ * the process have enqueued on that device so far); reports device-side consistency errors. */
 int  ivf_frontend_sync(ivf_frontend* fe);
 /* Device-resident results of the last run (valid until the next run).  side 0 = left, 1 = right.
  * d_kps: [max_pairs][cap] ivf_keypoint, d_desc: [max_pairs][cap][32], d_count: [max_pairs] int32, cap = nfeatures;
@@ -362,8 +374,10 @@ int  ivf_fcn_forward_device(ivf_fcn* f, const uint8_t* d_bgr, size_t image_strid
  * IVF_E_STATE instead of a cost map; after ivf_fcn_forward_device call ivf_fcn_status(f, hip_stream): it waits for the stream, returns
  * IVF_E_STATE if any forward of this handle since the last check raised the flag, and clears it.  Non-finite weights are refused by
  * ivf_fcn_create (IVF_E_INVALID).  The kernels raise the flag in a word of the DEVICE and the last kernel of a forward moves it into the
- * handle: when two handles run forwards concurrently on one device (different streams) a flag can be reported by the other handle --
- * it is never lost. */
+ * handle: when two handles run forwards CONCURRENTLY on one device (different streams) handle A's overflow can be collected by handle B's
+ * forward -- B then reports IVF_E_STATE and A reports IVF_OK for a wrong cost map.  The flag is never lost for the DEVICE, but it can be lost for
+ * the handle that raised it: callers that overlap forwards of several handles on one device must treat IVF_E_STATE from ANY of them as
+ * invalidating the forwards of ALL of them since their last checks (bench.py and the reference's one-network-per-process use a single handle). */
 int  ivf_fcn_status(ivf_fcn* f, void* hip_stream);
 
 /* ---- next rows of SURVEY section 8(f) ----

@@ -2114,7 +2114,12 @@ void ivf_frontend_destroy(ivf_frontend* fe)
 {
     if (!fe) return;
     (void)hipSetDevice(fe->cfg.device_id);
-    (void)hipDeviceSynchronize();
+    // r06: wait for THIS handle's batches (their completion events), not for the device: the internal streams are shared by every front end of
+    // the process on this device (internal_streams), so a device-wide wait made one camera's tear-down wait for the other's work.  Work the caller
+    // put behind a batch on a lent stream (ivf_frontend_batch_stream) is the caller's to finish first, as ivfront.h says; the buffer releases below
+    // go through hipFree, which itself does not return while the device still uses the allocation.
+    for (int k = 0; k < kPipe; k++)
+        if (fe->evDone[k]) (void)hipEventSynchronize(fe->evDone[k]);      // never recorded = complete
     if (fe->dFlags) (void)hipFree(fe->dFlags);
     for (int k = 0; k < kPipe; k++) {
         fe->ctx[k].release();

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>      // getenv behind IVF_EXP_ENV (experiment builds)
 #include "../../include/ivfront.h"
 
 namespace ivf {
@@ -111,7 +112,6 @@ struct StereoArgs {
 // tools/ and by the kernel-variant tests) and a null constant in the product: the names are not even compiled in
 // (tests/test_abi_cpu.py asserts the list of IVF_* strings in libivfront.so).
 #ifdef IVF_EXPERIMENT
-#include <stdlib.h>
 #define IVF_EXP_ENV(name) getenv(name)
 #else
 #define IVF_EXP_ENV(name) ((const char*)nullptr)

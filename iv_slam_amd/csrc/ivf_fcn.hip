@@ -4588,11 +4588,11 @@ int ivf_fcn_create(const float* weights_blob, size_t n_floats, int in_width, int
     if (device_id < 0 || device_id >= ndev) return ffail(IVF_E_INVALID, "device_id %d outside [0,%d)", device_id, ndev);
     FHIP(hipSetDevice(device_id));
     { const int lrc = reserve_lds(); if (lrc) return lrc; }
+    for (size_t i = 0; i < n_floats; i++)      // before the handle exists: nothing to release on this way out
+        if (!std::isfinite(weights_blob[i])) return ffail(IVF_E_INVALID, "weight blob holds a non-finite value at float %zu", i);
     ivf_fcn* f = new ivf_fcn();
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess) f->numCU = cus; }
     f->device = device_id; f->inW = in_width; f->inH = in_height; f->outW = out_width; f->outH = out_height; f->maxBatch = max_batch;
-    for (size_t i = 0; i < n_floats; i++)
-        if (!std::isfinite(weights_blob[i])) return ffail(IVF_E_INVALID, "weight blob holds a non-finite value at float %zu", i);
     Reader rd{weights_blob, n_floats};
     auto bad = [&]() { ivf_fcn_destroy(f); return ffail(IVF_E_INVALID, "weight blob too short for the architecture"); };
     std::vector<float> sc, sh;

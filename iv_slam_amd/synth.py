@@ -87,3 +87,29 @@ def make_stream(n_pairs, width=1242, height=375, seed=0):
     for i in range(n_pairs):
         out[i, 0], out[i, 1] = make_pair(width, height, seed, i)
     return out
+
+
+def make_natural(width=1242, height=375, seed=0, idx=0, beta=1.0, foliage=False):
+    """Natural-image statistics (r06: the generators above are rectangles, dots and noise): a random-phase field whose amplitude
+    spectrum falls as 1 / f^beta (beta = 1: the 1 / f^2 POWER law of natural scenes -- corners at every scale, smooth large-scale
+    shading, no flat regions), histogram-stretched to u8.  foliage=True multiplies in occlusion structure: a second, thresholded
+    low-frequency field switches between two differently lit copies (sharp leaf-like boundaries at many scales, the corner
+    density of vegetation).  numpy FFT in float64; deterministic for a given (seed, idx, size)."""
+    r = _rng(seed + 15485863, idx)
+
+    def field(b):
+        white = r.standard_normal((height, width))
+        fy = np.fft.fftfreq(height)[:, None]; fx = np.fft.rfftfreq(width)[None, :]
+        f = np.sqrt(fx * fx + fy * fy); f[0, 0] = 1.0
+        spec = np.fft.rfft2(white) / f ** b
+        spec[0, 0] = 0.0
+        out = np.fft.irfft2(spec, s=(height, width))
+        return (out - out.mean()) / max(float(out.std()), 1e-12)
+
+    img = field(beta)
+    if foliage:
+        mask = field(1.6) > 0.0
+        other = field(beta)
+        img = np.where(mask, 0.6 * img + 0.9, 0.9 * other - 0.7)
+    lo, hi = np.percentile(img, [0.5, 99.5])
+    return np.clip(np.rint((img - lo) / max(hi - lo, 1e-12) * 255.0), 0, 255).astype(np.uint8)

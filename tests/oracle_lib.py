@@ -461,3 +461,10 @@ def remap_weight_table():
     lib.orc_remap_weight_table.restype = None
     lib.orc_remap_weight_table(ptr(t))
     return t.reshape(1024, 4)
+
+
+def c_round(v):
+    """std::round of a float array (Frame.cc:130-131 rounds the keypoint position with it): halves AWAY from zero --
+    np.rint rounds them to even, which differs on x.5 coordinates (levels > 0 produce them)."""
+    v = np.asarray(v, dtype=np.float64)
+    return (np.sign(v) * np.floor(np.abs(v) + 0.5)).astype(np.int64)

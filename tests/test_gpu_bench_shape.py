@@ -35,7 +35,7 @@ def iv():
 
 def quality_from_cost(kps, cost):
     """mvKeyQualScore (Frame.cc:130-143): cost/256, double division narrowed to float, 2q - 1."""
-    px = np.rint(kps["x"]).astype(int); py = np.rint(kps["y"]).astype(int)
+    px = O.c_round(kps["x"]); py = O.c_round(kps["y"])
     c = cost[py, px].astype(np.float32)
     q = (np.float64(1.0) / (np.float64(1.0) + (c / np.float32(256)).astype(np.float64))).astype(np.float32)
     return (np.float32(2) * q - np.float32(1)).astype(np.float32)

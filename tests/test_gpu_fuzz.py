@@ -200,11 +200,13 @@ def test_remaining_searches_random_scenarios(iv, seed):
     raise AssertionError("no usable scenario in 40 draws")
 
 
-@pytest.mark.parametrize("pattern", ["noise", "checker2", "checker3", "stripes", "ramp", "blobs", "salt"])
+@pytest.mark.parametrize("pattern", ["noise", "checker2", "checker3", "stripes", "ramp", "blobs", "salt", "pink", "foliage", "pink-steep", "foliage-jackal"])
 def test_extract_stress_patterns(iv, pattern):
     """image content at the extremes: dense corners (survivor-list / cell capacities, the plane-scan NMS path, ties everywhere),
-    none at all, saturated blobs -- KITTI-sized, 1000 and 4000 features, with and without a cost map"""
-    w, h = 1242, 375
+    none at all, saturated blobs -- KITTI-sized, 1000 and 4000 features, with and without a cost map.  r06: natural-image statistics
+    (synth.make_natural: 1 / f amplitude spectrum = corners at every scale and no flat region; thresholded occlusion structure = the corner
+    density of foliage), also at the Jackal size of configs[4]"""
+    w, h = (1920, 1200) if pattern.endswith("jackal") else (1242, 375)
     rng = np.random.default_rng(7)
     yy, xx = np.mgrid[0:h, 0:w]
     if pattern == "noise":
@@ -222,6 +224,12 @@ def test_extract_stress_patterns(iv, pattern):
         for _ in range(300):
             cy, cx, r = rng.integers(0, h), rng.integers(0, w), rng.integers(2, 9)
             img[max(cy - r, 0):cy + r, max(cx - r, 0):cx + r] = 255
+    elif pattern == "pink":
+        img = synth.make_natural(w, h, seed=21, idx=0, beta=1.0)
+    elif pattern == "pink-steep":
+        img = synth.make_natural(w, h, seed=22, idx=0, beta=1.5)
+    elif pattern.startswith("foliage"):
+        img = synth.make_natural(w, h, seed=23, idx=0, beta=1.0, foliage=True)
     else:
         img = np.full((h, w), 128, np.uint8)
         idx = rng.integers(0, h * w, 20000)
@@ -237,7 +245,7 @@ def test_extract_stress_patterns(iv, pattern):
         assert np.array_equal(gd, od), (pattern, n)
 
 
-@pytest.mark.parametrize("pattern", ["noise", "checker3", "blobs"])
+@pytest.mark.parametrize("pattern", ["noise", "checker3", "blobs", "foliage"])
 def test_stereo_stress_patterns(iv, pattern):
     """the stereo matcher on repetitive / noisy content (Hamming ties, many candidates per row, SAD plateaus): the batched front end
     against the oracle chain, right image = left shifted by a few pixels"""
@@ -249,6 +257,8 @@ def test_stereo_stress_patterns(iv, pattern):
         base = rng.integers(0, 256, (h, w + 16)).astype(np.uint8)
     elif pattern == "checker3":
         base = ((((yy // 3) + (xx // 3)) & 1) * 200 + 20).astype(np.uint8)
+    elif pattern == "foliage":
+        base = synth.make_natural(w + 16, h, seed=24, idx=0, beta=1.0, foliage=True)
     else:
         base = np.zeros((h, w + 16), np.uint8)
         for _ in range(400):

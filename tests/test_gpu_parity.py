@@ -178,7 +178,7 @@ def test_frontend_with_cost_maps(iv):
         assert_kps_equal(rl["kps"], okL, "L"); assert_kps_equal(rr["kps"], okR, "R")
         assert np.array_equal(rl["desc"], odL) and np.array_equal(rr["desc"], odR)
         # mvKeyQualScore (Frame.cc:130-143): cost/256, double division narrowed to float
-        px = np.rint(okL["x"]).astype(int); py = np.rint(okL["y"]).astype(int)
+        px = O.c_round(okL["x"]); py = O.c_round(okL["y"])
         c = cost[p][py, px].astype(np.float32)
         q = (np.float64(1.0) / (np.float64(1.0) + (c / np.float32(256)).astype(np.float64))).astype(np.float32)
         assert np.array_equal(rl["quality"], (np.float32(2) * q - np.float32(1)).astype(np.float32))
@@ -619,7 +619,7 @@ def test_config4_jackal_stereo_frontend_4000_features_introspection(iv):
         assert np.array_equal(rl["desc"], odL) and np.array_equal(rr["desc"], odR)
         assert rl["uright"].tobytes() == our.tobytes() and rl["depth"].tobytes() == odp.tobytes()
         assert len(okL) > 3000 and (our >= 0).sum() > 200
-        px = np.rint(okL["x"]).astype(int); py = np.rint(okL["y"]).astype(int)
+        px = O.c_round(okL["x"]); py = O.c_round(okL["y"])
         c = cost[p][py, px].astype(np.float32)
         q = (np.float64(1.0) / (np.float64(1.0) + (c / np.float32(256)).astype(np.float64))).astype(np.float32)
         assert np.array_equal(rl["quality"], (np.float32(2) * q - np.float32(1)).astype(np.float32))
@@ -659,7 +659,7 @@ def test_quality_scores_without_extractor_introspection(iv):
     okL, odL = O.Extractor(n, 1.2, 8, 20, 7)(stream[0, 0])
     rl = fe.fetch(0, 0)
     assert_kps_equal(rl["kps"], okL, "plain keypoints")
-    px = np.rint(okL["x"]).astype(int); py = np.rint(okL["y"]).astype(int)
+    px = O.c_round(okL["x"]); py = O.c_round(okL["y"])
     c = cost[0][py, px].astype(np.float32)
     q = (np.float64(1.0) / (np.float64(1.0) + (c / np.float32(256)).astype(np.float64))).astype(np.float32)
     assert np.array_equal(rl["quality"], (np.float32(2) * q - np.float32(1)).astype(np.float32))

@@ -210,6 +210,77 @@ def test_boundary_pair_between_two_batches_through_the_carry_record(iv):
             assert int(nm[k][0]) > 100                             # the boundary pair really re-matches the shifted scene
 
 
+def test_cpp_exchange_step_against_the_c_abi(iv, tmp_path):
+    """r06 (the r05 verdict's item 7): the exchange step a C++ host writes -- tests/adapter/exchange_rccl.cpp = INTEGRATION.md section 6: pack on
+    the batch's stream, ncclAllGather into [G * P records | carry], the carry hand-over, ivf_tracker_run -- built with g++ against
+    include/ivfront.h + <rccl/rccl.h>, linked with libivfront / libamdhip64 / librccl and RUN at world = 1 (the collective is skipped,
+    everything else is the multi-rank code): three batches of four frames through one front end; every pair incl. the two boundary pairs
+    equals the oracle on the records the C++ side holds."""
+    import ctypes as C
+    import subprocess
+    import torch
+    from iv_slam_amd.frontend import unpack_gather_records
+    so = str(tmp_path / "libivx.so")
+    lib_dir = os.path.join(ROOT, "iv_slam_amd")
+    rccl = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(rccl):
+        pytest.skip("no RCCL headers on this box")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-shared", "-fPIC", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "adapter", "exchange_rccl.cpp"), "-o", so, "-L", lib_dir, "-livfront", "-L", "/opt/rocm/lib", "-lamdhip64", "-lrccl",
+                           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    X = C.CDLL(so)
+    X.ivx_c_create.restype = C.c_void_p; X.ivx_c_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    X.ivx_c_step.restype = C.c_int; X.ivx_c_step.argtypes = [C.c_void_p] * 6
+    X.ivx_c_records.restype = C.c_void_p; X.ivx_c_records.argtypes = [C.c_void_p, C.c_int]
+    X.ivx_c_pairs.restype = C.c_int; X.ivx_c_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    X.ivx_c_destroy.argtypes = [C.c_void_p]
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    w, h, n, P, NB = 640, 240, 500, 4, 3
+    L, R = synth.make_pair(w, h, seed=96, idx=0)
+    lefts = np.stack([np.roll(L, 3 * k, axis=1) for k in range(P * NB)]); rights = np.stack([np.roll(R, 3 * k, axis=1) for k in range(P * NB)])
+    dev = torch.device("cuda:0")
+    bf, fx = 386.1448, 718.856
+    fe = iv.StereoFrontend(w, h, P, nfeatures=n, bf=bf, fx=fx)
+    rec = fe.gather_record_bytes()
+    cam = dict(nf=n, scale=scale_table(), fx=F(fx), fy=F(fx), cx=F(w / 2 + 0.5), cy=F(h / 2 - 0.25), bf=F(bf), b=F(F(bf) / F(fx)),
+               bounds=(0.0, 0.0, float(w), float(h)))
+    trackers = [iv.BatchTracker(n, cam["scale"], float(fx), float(fx), float(cam["cx"]), float(cam["cy"]), float(bf), cam["bounds"], max_pairs=P,
+                                b=float(cam["b"])) for _ in range(3)]
+    x = X.ivx_c_create(1, 0, P, n, None)
+    assert x
+    hp = np.zeros((P, 2), np.int32)
+    assert X.ivx_c_pairs(x, hp.ctypes.data, hp.size) == P
+    pairs = [tuple(int(v) for v in r) for r in hp]
+    from iv_slam_amd import dist as ivd
+    assert pairs == ivd.track_pairs(1, 0, P, carry=True)                  # the C++ pair table IS dist.track_pairs
+    assign = [torch.full((P, n), -7, dtype=torch.int32, device=dev) for _ in range(NB)]
+    nm = [torch.full((P,), -7, dtype=torch.int32, device=dev) for _ in range(NB)]
+    dl = torch.from_numpy(lefts).to(dev); dr = torch.from_numpy(rights).to(dev)
+    snaps = []
+    for k in range(NB):
+        fe.run(dl[k * P:(k + 1) * P], dr[k * P:(k + 1) * P])
+        assert X.ivx_c_step(x, fe._h, trackers[k % 3]._h, None, assign[k].data_ptr(), nm[k].data_ptr()) == 0
+        # snapshot of batch k's record buffer on its own stream, behind the tracker step (the ring of three is reused by batch k + 2's hand-over)
+        bs = torch.cuda.ExternalStream(fe.batch_stream(0), device=dev)
+        snap = torch.empty((P + 1) * rec, dtype=torch.uint8, device=dev)
+        snaps.append((snap, bs))
+        assert hip.hipMemcpyAsync(snap.data_ptr(), X.ivx_c_records(x, k), (P + 1) * rec, 3, bs.cuda_stream) == 0      # 3 = hipMemcpyDeviceToDevice
+    fe.sync(); torch.cuda.synchronize()
+    recs_b = [unpack_gather_records(s.cpu().numpy(), n) for s, _ in snaps]
+    for k in range(NB):
+        recs = recs_b[k]
+        if k == 0:
+            assert recs[P]["n"] == 0 and int(nm[0][0]) == 0 and (assign[0][0].cpu().numpy() == -1).all()
+        else:
+            assert recs[P]["n"] > 100 and recs[P]["kps"].tobytes() == recs_b[k - 1][P - 1]["kps"].tobytes()      # the carry IS the previous batch's last record
+        tot = check_pairs(cam, recs, pairs, assign[k].cpu().numpy(), nm[k].cpu().numpy(), what="C++ exchange, batch %d" % k)
+        assert tot > 100 * (P - 1 if k == 0 else P)
+        if k > 0:
+            assert int(nm[k][0]) > 100
+    X.ivx_c_destroy(x)
+
+
 def test_poses_forward_backward_and_flags(iv):
     """supplied poses: forward motion (levels [o, inf)), backward motion ([0, o]), small motion (+-1), rotations; explicit point flags."""
     cam, recs, _, _ = extracted_sequence(iv, 640, 240, 500, 5, seed=92, shift=2)
