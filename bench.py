@@ -418,40 +418,87 @@ def latency_batch1(iv, blob, introspect, iters=30):
                     "ivf_extract x2 (two host threads, each handle on its own HIP stream) + ivf_stereo_match; blocking copies included"}
 
 
-def h2d_included(torch, iv, fe, fcn, dev, P, n_batches, left, right, bgr, cost, rec):
-    """Throughput with the inputs coming from PINNED HOST memory: per batch the grey L / R images (+ the left colour image
-    for the FCN) cross PCIe on a copy stream into one of two staging sets while the previous batch computes; the packed
-    result records {n, kps, desc, uRight} go back to pinned host memory.  Never the headline `value`."""
+def link_probe(torch, dev, nbytes=256 << 20, reps=4):
+    """what the host link itself does, next to `pcie_gb_s` (r06): plain pinned hipMemcpyAsync, H2D, D2H and both at once on two streams"""
+    hp = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True); hq = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    dp = torch.empty(nbytes, dtype=torch.uint8, device=dev); dq = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    s1 = torch.cuda.Stream(dev); s2 = torch.cuda.Stream(dev)
+
+    def timed(fn):
+        fn(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / reps
+
+    def h2d():
+        with torch.cuda.stream(s1):
+            dp.copy_(hp, non_blocking=True)
+
+    def d2h():
+        with torch.cuda.stream(s2):
+            hq.copy_(dq, non_blocking=True)
+
+    def both():
+        h2d(); d2h()
+    th, td, tb = timed(h2d), timed(d2h), timed(both)
+    return {"h2d_gb_s": round(nbytes / th / 1e9, 2), "d2h_gb_s": round(nbytes / td / 1e9, 2), "both_directions_gb_s": round(2 * nbytes / tb / 1e9, 2),
+            "bytes": nbytes, "note": "pinned host memory, one hipMemcpyAsync of 256 MiB per direction, nothing else running"}
+
+
+def h2d_included(torch, iv, fe, fcn, dev, P, n_batches, left, right, bgr, cost, rec, sets=2, nocopy=False, two_streams=False):
+    """Throughput with the inputs coming from PINNED HOST memory: per batch the images cross PCIe on a copy stream into one of two staging
+    sets while the previous batch computes; the packed result records {n, kps, desc, uRight} go back to pinned host memory.  Never the
+    headline `value`.  r06: with the FCN the left image crosses ONCE, as the colour image the FCN reads; the extractor's grey left image is
+    made from it on the device (ivf_frontend_run_color = Tracking::GrabImageStereo's cvtColor, Tracking.cc:272-295, fused into the ingest):
+    4 planes per pair instead of 5.  The colour image of this leg is B = G = R = the resident grey left image, whose conversion is that grey
+    image again (the coefficients sum to 2^15), so the extraction works on the same pixels as the timed region."""
     n_host = min(left.shape[0], 2 * P)
-    hl = torch.empty((n_host, H, W), dtype=torch.uint8, pin_memory=True); hl.copy_(left[:n_host])
     hr = torch.empty((n_host, H, W), dtype=torch.uint8, pin_memory=True); hr.copy_(right[:n_host])
-    hb = None
+    hl = hb = None
     if fcn is not None:
-        hb = torch.empty((n_host, H, W, 3), dtype=torch.uint8, pin_memory=True); hb.copy_(bgr[:n_host])
-    stage = [dict(l=torch.empty((P, H, W), dtype=torch.uint8, device=dev), r=torch.empty((P, H, W), dtype=torch.uint8, device=dev),
-                  b=torch.empty((P, H, W, 3), dtype=torch.uint8, device=dev) if fcn is not None else None) for _ in range(2)]
+        hb = torch.empty((n_host, H, W, 3), dtype=torch.uint8, pin_memory=True); hb.copy_(left[:n_host].unsqueeze(-1).expand(-1, -1, -1, 3))
+    else:
+        hl = torch.empty((n_host, H, W), dtype=torch.uint8, pin_memory=True); hl.copy_(left[:n_host])
+    stage = [dict(l=torch.empty((P, H, W), dtype=torch.uint8, device=dev) if fcn is None else None, r=torch.empty((P, H, W), dtype=torch.uint8, device=dev),
+                  b=torch.empty((P, H, W, 3), dtype=torch.uint8, device=dev) if fcn is not None else None) for _ in range(sets)]
     out_dev = [torch.empty(P * rec, dtype=torch.uint8, device=dev) for _ in range(3)]
     out_host = [torch.empty(P * rec, dtype=torch.uint8, pin_memory=True) for _ in range(3)]
-    copy = torch.cuda.Stream(dev)
+    copy = torch.cuda.Stream(dev); copy2 = torch.cuda.Stream(dev) if two_streams else None
     main = torch.cuda.current_stream(dev)
-    ready = [torch.cuda.Event() for _ in range(2)]; free = [torch.cuda.Event() for _ in range(2)]
+    ready = [torch.cuda.Event() for _ in range(sets)]; ready2 = [torch.cuda.Event() for _ in range(sets)]; free = [torch.cuda.Event() for _ in range(sets)]
     nsl = n_host // P
 
     def run(nb):
         for k in range(nb):
-            st = stage[k % 2]; s0 = (k % nsl) * P
+            st = stage[k % sets]; s0 = (k % nsl) * P
             with torch.cuda.stream(copy):
-                if k >= 2:
-                    copy.wait_event(free[k % 2])
-                st["l"].copy_(hl[s0:s0 + P], non_blocking=True); st["r"].copy_(hr[s0:s0 + P], non_blocking=True)
-                if hb is not None:
-                    st["b"].copy_(hb[s0:s0 + P], non_blocking=True)
-                ready[k % 2].record(copy)
-            main.wait_event(ready[k % 2])
+                if k >= sets:
+                    copy.wait_event(free[k % sets])
+                if not nocopy:
+                    if copy2 is None:
+                        st["r"].copy_(hr[s0:s0 + P], non_blocking=True)
+                    if hb is not None:
+                        st["b"].copy_(hb[s0:s0 + P], non_blocking=True)
+                    else:
+                        st["l"].copy_(hl[s0:s0 + P], non_blocking=True)
+                ready[k % sets].record(copy)
+            if copy2 is not None:
+                with torch.cuda.stream(copy2):
+                    if k >= sets:
+                        copy2.wait_event(free[k % sets])
+                    if not nocopy:
+                        st["r"].copy_(hr[s0:s0 + P], non_blocking=True)
+                    ready2[k % sets].record(copy2)
+                main.wait_event(ready2[k % sets])
+            main.wait_event(ready[k % sets])
             if fcn is not None:
                 fcn.forward_device(st["b"], cost_u8=cost, stream_ptr=main.cuda_stream)
-            fe.run(st["l"], st["r"], cost if fcn is not None else None, main.cuda_stream)
-            free[k % 2].record(main)                       # fe.run made `main` wait until the inputs were ingested
+                fe.run_color(st["b"], st["r"], cost, main.cuda_stream)
+            else:
+                fe.run(st["l"], st["r"], None, main.cuda_stream)
+            free[k % sets].record(main)                    # fe.run made `main` wait until the inputs were ingested
             bs = torch.cuda.ExternalStream(fe.batch_stream(0), device=dev)
             fe.pack_gather_block(out_dev[k % 3], fe.STREAM_OF_BATCH)
             with torch.cuda.stream(bs):
@@ -462,11 +509,13 @@ def h2d_included(torch, iv, fe, fcn, dev, P, n_batches, left, right, bgr, cost, 
     t0 = time.perf_counter()
     run(n_batches)
     dt = time.perf_counter() - t0
-    in_bytes = P * H * W * (2 + (3 if fcn is not None else 0))
+    in_bytes = P * H * W * (1 + (3 if fcn is not None else 1))
     return {"value": round(P * n_batches / dt, 2), "unit": "pairs/s", "batches": n_batches, "pairs_per_batch": P,
-            "h2d_bytes_per_pair": in_bytes // P, "d2h_bytes_per_pair": rec,
+            "h2d_bytes_per_pair": in_bytes // P, "d2h_bytes_per_pair": rec, "planes_per_pair": 4 if fcn is not None else 2,
             "pcie_gb_s": round((in_bytes + P * rec) * n_batches / dt / 1e9, 2),
-            "note": "inputs in pinned host memory, H2D on a copy stream double-buffered against compute, packed result records D2H"}
+            "link": link_probe(torch, dev),
+            "note": "inputs in pinned host memory, H2D on a copy stream double-buffered against compute, packed result records D2H; with the FCN the left "
+                    "image crosses once, as colour (grey conversion on the device: ivf_frontend_run_color)"}
 
 
 def main():
@@ -807,6 +856,12 @@ def main():
     lat = None
     if extras:
         h2d = h2d_included(torch, iv, fe, fcn, dev, P, 16 if args.introspect else 48, left, right, bgr, cost, rec)
+        if os.environ.get("IVF_BENCH_H2D_AB"):        # A/B aid (r06): the same leg without its copies, with three staging sets, with two copy streams
+            h2d["ab"] = {"nocopy": h2d_included(torch, iv, fe, fcn, dev, P, 16 if args.introspect else 48, left, right, bgr, cost, rec, nocopy=True)["value"],
+                         "three_sets": h2d_included(torch, iv, fe, fcn, dev, P, 16 if args.introspect else 48, left, right, bgr, cost, rec, sets=3)["value"],
+                         "two_streams": h2d_included(torch, iv, fe, fcn, dev, P, 16 if args.introspect else 48, left, right, bgr, cost, rec, two_streams=True)["value"],
+                         "three_sets_two_streams": h2d_included(torch, iv, fe, fcn, dev, P, 16 if args.introspect else 48, left, right, bgr, cost, rec, sets=3, two_streams=True)["value"],
+                         "again": h2d_included(torch, iv, fe, fcn, dev, P, 16 if args.introspect else 48, left, right, bgr, cost, rec)["value"]}
         lat = latency_batch1(iv, blob, args.introspect)
 
     parity = parity_spot_check(spot, args.introspect)

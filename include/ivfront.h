@@ -221,6 +221,22 @@ void ivf_frontend_destroy(ivf_frontend* fe);
  * d_cost: device pointer to n_pairs u8 cost maps (same layout) or NULL. */
 int  ivf_frontend_run(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_right, const uint8_t* d_cost,
                       size_t image_stride, int row_stride, int n_pairs, void* hip_stream);
+/* The same with the grey conversion in front of the extractor fused into the ingest (r06): Tracking::GrabImageStereo converts a 3-channel image with
+ * cvtColor(mImGray, mImGray, CV_RGB2GRAY or CV_BGR2GRAY) by mbRGB = Camera.RGB (ORB/src/Tracking.cc:272-295; the right image likewise, :296-311).
+ * A side is IVF_COLOR_GRAY (8UC1 as in ivf_frontend_run), IVF_COLOR_BGR (8UC3, bytes B,G,R: what cv::imread gives; CV_BGR2GRAY) or IVF_COLOR_RGB
+ * (bytes R,G,B; CV_RGB2GRAY), each side with its own strides (bytes).  cv::cvtColor on 8-bit data is fixed point; the coefficients are those of
+ * OpenCV 4.x -- (9798 R + 19235 G + 3735 B + 2^14) >> 15 -- like every other OpenCV primitive of this library; OR IVF_COLOR_CV3 into a code for
+ * OpenCV <= 3.x's (4899 R + 9617 G + 1868 B + 2^13) >> 14.  A PCIe-fed pipeline with the introspection FCN ships the left COLOUR image once (the FCN
+ * reads the same buffer, ivf_fcn_forward_device) instead of the colour image and a grey copy of it.  d_cost / its strides as in ivf_frontend_run.
+ * stereo_kitti.cc:494-495 swaps R and B of the FCN's input IN PLACE; without rectification that is the very buffer GrabImageStereo converts afterwards
+ * (SURVEY Appendix D-9): a host that reproduces the reference there hands over the swapped buffer, i.e. the other byte-order code. */
+#define IVF_COLOR_GRAY 0
+#define IVF_COLOR_BGR  1
+#define IVF_COLOR_RGB  2
+#define IVF_COLOR_CV3  4
+int  ivf_frontend_run_color(ivf_frontend* fe, const uint8_t* d_left, int left_code, size_t left_image_stride, int left_row_stride,
+                            const uint8_t* d_right, int right_code, size_t right_image_stride, int right_row_stride,
+                            const uint8_t* d_cost, size_t cost_image_stride, int cost_row_stride, int n_pairs, void* hip_stream);
 /* Block until every ivf_frontend_run on this handle has finished (and, the internal streams being shared per device, whatever other front ends of
  * the process have enqueued on that device so far); reports device-side consistency errors. */
 int  ivf_frontend_sync(ivf_frontend* fe);

@@ -125,6 +125,7 @@ _SIGS = {
     "ivf_frontend_create": (C.c_int, [C.POINTER(FrontendConfig), C.POINTER(vp)]),
     "ivf_frontend_destroy": (None, [vp]),
     "ivf_frontend_run": (C.c_int, [vp, vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]),
+    "ivf_frontend_run_color": (C.c_int, [vp, vp, C.c_int, C.c_size_t, C.c_int, vp, C.c_int, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_int, C.c_int, vp]),
     "ivf_frontend_sync": (C.c_int, [vp]),
     "ivf_frontend_device_results": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                               C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]),

@@ -119,6 +119,9 @@ struct Context {
     int run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size_t imageStride, int rowStride,
             size_t costStride, int costRowStride, int nImg, const uint8_t* hUseCost, hipStream_t st,
             hipEvent_t inputsConsumed = nullptr, hipStream_t sideStream = nullptr);
+    // r06: per-side source override of the NEXT run (ivf_frontend_run_color): code 0 = grey with its own strides, 1 / 2 (| 4) = B,G,R / R,G,B interleaved
+    // (k_ingest_color).  Consumed by run().
+    struct SideSrc { const uint8_t* src = nullptr; size_t imageStride = 0; int rowStride = 0; int code = 0; } sideSrc[2];
     int check_status(int which = 0);
 };
 
@@ -327,6 +330,15 @@ int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size
     }
     if (cost) HIPCHK(hipMemcpyAsync(b.useCost, dUseCostSrc, nImg, hipMemcpyDeviceToDevice, st));
     else HIPCHK(hipMemsetAsync(b.useCost, 0, nImg, st));
+    if (sideSrc[0].src || sideSrc[1].src) {
+        for (int sd = 0; sd < nSides; sd++) {
+            const SideSrc& q = sideSrc[sd];
+            if (q.src && (q.code & 3)) launch_ingest_color(hc, dc, q.src, q.imageStride, q.rowStride, q.code, nImg, nSides, sd, b.pyr, st);
+            else if (q.src) launch_ingest(hc, dc, b, q.src, q.src, q.imageStride, q.rowStride, nImg, nSides, b.pyr, st, 1 << sd);
+            else launch_ingest(hc, dc, b, s0, s1, imageStride, rowStride, nImg, nSides, b.pyr, st, 1 << sd);
+        }
+        sideSrc[0] = SideSrc(); sideSrc[1] = SideSrc();
+    } else
     launch_ingest(hc, dc, b, s0, s1, imageStride, rowStride, nImg, nSides, b.pyr, st);
     if (cost) launch_ingest(hc, dc, b, cost, cost, costStride, costRowStride, nImg, nSides, b.qpyr, st);
     if (inputsConsumed) HIPCHK(hipEventRecord(inputsConsumed, st));   // caller buffers are free from here on
@@ -2131,6 +2143,9 @@ void ivf_frontend_destroy(ivf_frontend* fe)
     delete fe;
 }
 
+static int frontend_run_common(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_right, const uint8_t* d_cost,
+                               size_t image_stride, int row_stride, int n_pairs, void* hip_stream, const Context::SideSrc* sides);
+
 int ivf_frontend_run(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_right, const uint8_t* d_cost,
                      size_t image_stride, int row_stride, int n_pairs, void* hip_stream)
 {
@@ -2138,9 +2153,39 @@ int ivf_frontend_run(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_r
     if (n_pairs < 1 || n_pairs > fe->cfg.max_pairs) return fail(IVF_E_INVALID, "n_pairs %d outside [1,%d]", n_pairs, fe->cfg.max_pairs);
     if (row_stride < fe->cfg.width || image_stride < (size_t)row_stride * (fe->cfg.height - 1) + fe->cfg.width)
         return fail(IVF_E_INVALID, "strides too small for %dx%d", fe->cfg.width, fe->cfg.height);
+    return frontend_run_common(fe, d_left, d_right, d_cost, image_stride, row_stride, n_pairs, hip_stream, nullptr);
+}
+
+int ivf_frontend_run_color(ivf_frontend* fe, const uint8_t* d_left, int left_code, size_t left_image_stride, int left_row_stride,
+                           const uint8_t* d_right, int right_code, size_t right_image_stride, int right_row_stride,
+                           const uint8_t* d_cost, size_t cost_image_stride, int cost_row_stride, int n_pairs, void* hip_stream)
+{
+    if (!fe || !d_left || !d_right) return fail(IVF_E_INVALID, "null argument");
+    if (n_pairs < 1 || n_pairs > fe->cfg.max_pairs) return fail(IVF_E_INVALID, "n_pairs %d outside [1,%d]", n_pairs, fe->cfg.max_pairs);
+    Context::SideSrc sides[2];
+    const uint8_t* ptr[2] = {d_left, d_right}; const int code[2] = {left_code, right_code};
+    const size_t ist[2] = {left_image_stride, right_image_stride}; const int rst[2] = {left_row_stride, right_row_stride};
+    for (int sd = 0; sd < 2; sd++) {
+        if (code[sd] < 0 || (code[sd] & 3) == 3 || code[sd] > 7 || (!(code[sd] & 3) && code[sd]))
+            return fail(IVF_E_INVALID, "side %d: colour code %d is not 0 (grey), 1 (bytes B,G,R) or 2 (bytes R,G,B), the last two optionally + 4 (OpenCV <= 3 coefficients)", sd, code[sd]);
+        const int ch = (code[sd] & 3) ? 3 : 1;
+        if (rst[sd] < ch * fe->cfg.width || ist[sd] < (size_t)rst[sd] * (fe->cfg.height - 1) + (size_t)ch * fe->cfg.width)
+            return fail(IVF_E_INVALID, "side %d: strides too small for %dx%d x %d channel(s)", sd, fe->cfg.width, fe->cfg.height, ch);
+        sides[sd].src = ptr[sd]; sides[sd].imageStride = ist[sd]; sides[sd].rowStride = rst[sd]; sides[sd].code = code[sd];
+    }
+    if (d_cost && (cost_row_stride < fe->cfg.width || cost_image_stride < (size_t)cost_row_stride * (fe->cfg.height - 1) + fe->cfg.width))
+        return fail(IVF_E_INVALID, "cost strides too small for %dx%d", fe->cfg.width, fe->cfg.height);
+    return frontend_run_common(fe, d_left, d_right, d_cost, cost_image_stride, cost_row_stride, n_pairs, hip_stream, sides);
+}
+
+// sides != nullptr: the images come from sides[0 / 1] (own strides, grey or colour); image_stride / row_stride then describe the cost maps only
+static int frontend_run_common(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_right, const uint8_t* d_cost,
+                               size_t image_stride, int row_stride, int n_pairs, void* hip_stream, const Context::SideSrc* sides)
+{
     hipStream_t caller = (hipStream_t)hip_stream;
     const int k = (int)(fe->runs % kPipe);
     Context& c = fe->ctx[k];
+    if (sides) { c.sideSrc[0] = sides[0]; c.sideSrc[1] = sides[1]; }
     hipStream_t st = fe->stream[k];
     HIPCHK(hipSetDevice(fe->cfg.device_id));
     // order: everything the caller enqueued so far (it produced the inputs) -> this batch

@@ -130,7 +130,9 @@ int set_error(int code, const char* fmt, ...);
 // launchers (ivf_kernels.hip)
 void launch_stereo_args(const Config& hc, const Config* dc, const StereoArgs& A, int nPairs, hipStream_t s);
 void launch_ingest(const Config& hc, const Config* dc, const Buffers& b, const uint8_t* src0, const uint8_t* src1,
-                   size_t imageStride, int rowStride, int nImg, int nSides, uint8_t* dstBlob, hipStream_t s);
+                   size_t imageStride, int rowStride, int nImg, int nSides, uint8_t* dstBlob, hipStream_t s, int sideMask = 3);
+void launch_ingest_color(const Config& hc, const Config* dc, const uint8_t* src, size_t imageStride, int rowStride, int code, int nImg, int nSides, int side,
+                         uint8_t* dstBlob, hipStream_t s);
 void launch_pyramid(const Config& hc, const Config* dc, const ResizeCoef* dTab, uint8_t* blob, uint8_t* qblob, const uint8_t* useCost,
                     int nImg, hipStream_t s);
 void launch_fast(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s);

@@ -76,11 +76,12 @@ DEVINL unsigned wave_min_u32(unsigned v)
 constexpr int kIngestRows = 8;
 __global__ __launch_bounds__(256) void k_ingest(const Config* __restrict__ cfg, const uint8_t* __restrict__ src0,
                                                const uint8_t* __restrict__ src1, size_t imageStride, int rowStride, int nSides,
-                                               uint8_t* __restrict__ blob, const uint8_t* __restrict__ onlyFlagged)
+                                               uint8_t* __restrict__ blob, const uint8_t* __restrict__ onlyFlagged, int sideMask)
 {
     const LevelGeom& G = cfg->lv[0];
     const int img = blockIdx.y, y0 = blockIdx.x * kIngestRows;
     if (onlyFlagged && !(onlyFlagged[img] & 3u)) return;            // a cost plane nothing reads (the right image of a stereo pair)
+    if (!((sideMask >> (img % nSides)) & 1)) return;                // this side arrives in colour: k_ingest_color writes its plane
     const uint8_t* src = ((nSides == 2 && (img & 1)) ? src1 : src0) + (size_t)(img / nSides) * imageStride;
     uint8_t* dst = blob + (size_t)img * cfg->pyrBytes + G.off;
     const int q16 = G.pitch / 16;                                    // 16-byte pieces per pitched row (pitch % 64 == 0)
@@ -107,6 +108,42 @@ __global__ __launch_bounds__(256) void k_ingest(const Config* __restrict__ cfg, 
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) if (i0 + 256 * u < rows * q16) *(uint4*)(dst + d[u]) = v[u];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_ingest_color (r06): the same for a side that arrives as 8-bit 3-channel interleaved images -- the grey conversion in front of the extractor,
+// Tracking::GrabImageStereo's cvtColor(mImGray, mImGray, CV_RGB2GRAY / CV_BGR2GRAY) (ORB/src/Tracking.cc:272-295, by mbRGB) fused into the ingest, so a
+// PCIe-fed pipeline ships the left COLOUR image once (the FCN reads it too) instead of the colour image and a grey copy of it.
+// cv::cvtColor 8UC3 -> 8UC1 is fixed point: OpenCV 4.x (R 9798 + G 19235 + B 3735 + 2^14) >> 15; OpenCV <= 3.x (R 4899 + G 9617 + B 1868 + 2^13) >> 14
+// (code bit 2: IVF_COLOR_CV3).  code & 3: 1 = B,G,R byte order (CV_BGR2GRAY), 2 = R,G,B (CV_RGB2GRAY).
+// One thread = 16 output pixels = 48 source bytes (three unaligned 16-byte loads).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ingest_color(const Config* __restrict__ cfg, const uint8_t* __restrict__ src, size_t imageStride, int rowStride,
+                                                     int code, int nSides, int side, uint8_t* __restrict__ blob)
+{
+    const LevelGeom& G = cfg->lv[0];
+    const int img = blockIdx.y * nSides + side, y0 = blockIdx.x * kIngestRows;
+    const uint8_t* sI = src + (size_t)blockIdx.y * imageStride;
+    uint8_t* dst = blob + (size_t)img * cfg->pyrBytes + G.off;
+    const bool cv3 = (code & 4) != 0, rgb = (code & 3) == 2;
+    const unsigned kR = cv3 ? 4899u : 9798u, kG = cv3 ? 9617u : 19235u, kB = cv3 ? 1868u : 3735u, half = cv3 ? 8192u : 16384u, sh = cv3 ? 14u : 15u;
+    const unsigned k0 = rgb ? kR : kB, k2 = rgb ? kB : kR;
+    const int q16 = G.pitch / 16;
+    const int rows = min(kIngestRows, G.h - y0);
+    for (int i = threadIdx.x; i < rows * q16; i += 256) {
+        const int r = i / q16, x = (i % q16) * 16;
+        const uint8_t* sp = sI + (size_t)(y0 + r) * rowStride + 3 * x;
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+        if (x + 15 < G.w) {
+            unsigned char px[48];
+            __builtin_memcpy(px, sp, 48);
+#pragma unroll
+            for (int k = 0; k < 16; k++) w[k >> 2] |= ((px[3 * k] * k0 + px[3 * k + 1] * kG + px[3 * k + 2] * k2 + half) >> sh) << (8 * (k & 3));
+        } else if (x < G.w) {
+            for (int k = 0; k < 16 && x + k < G.w; k++) w[k >> 2] |= ((sp[3 * k] * k0 + sp[3 * k + 1] * kG + sp[3 * k + 2] * k2 + half) >> sh) << (8 * (k & 3));
+        }
+        *(uint4*)(dst + (size_t)(y0 + r) * G.pitch + x) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -2093,12 +2130,20 @@ void launch_test_retain_best(const float* dResp, int n, int nPoints, int* dOrder
 // dstBlob == b.qpyr: the cost images; only the planes something reads are written (useCost bit 0: the cost pyramid gates the
 // extraction, bit 1: mvKeyQualScore samples level 0)
 void launch_ingest(const Config& hc, const Config* dc, const Buffers& b, const uint8_t* src0, const uint8_t* src1,
-                   size_t imageStride, int rowStride, int nImg, int nSides, uint8_t* dstBlob, hipStream_t s)
+                   size_t imageStride, int rowStride, int nImg, int nSides, uint8_t* dstBlob, hipStream_t s, int sideMask)
 {
     const LevelGeom& G = hc.lv[0];
     dim3 grid((G.h + kIngestRows - 1) / kIngestRows, nImg);
     hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, dc, src0, src1, imageStride, rowStride, nSides, dstBlob,
-                       dstBlob == b.qpyr && b.qpyr ? b.useCost : (const uint8_t*)nullptr);
+                       dstBlob == b.qpyr && b.qpyr ? b.useCost : (const uint8_t*)nullptr, sideMask);
+}
+// side `side` of every pair (nImg / nSides images) from 3-channel interleaved images: level 0 = cvtColor(..., GRAY)
+void launch_ingest_color(const Config& hc, const Config* dc, const uint8_t* src, size_t imageStride, int rowStride, int code, int nImg, int nSides, int side,
+                         uint8_t* dstBlob, hipStream_t s)
+{
+    const LevelGeom& G = hc.lv[0];
+    dim3 grid((G.h + kIngestRows - 1) / kIngestRows, nImg / nSides);
+    hipLaunchKernelGGL(k_ingest_color, grid, dim3(256), 0, s, dc, src, imageStride, rowStride, code, nSides, side, dstBlob);
 }
 // one launch per level: planes of `blob` and (qblob != nullptr) of the cost blob, the latter only for images whose useCost bit 0 is set
 void launch_pyramid(const Config& hc, const Config* dc, const ResizeCoef* dTab, uint8_t* blob, uint8_t* qblob, const uint8_t* useCost,

@@ -49,6 +49,30 @@ class StereoFrontend:
         check(self._lib.ivf_frontend_run(self._h, left.data_ptr(), right.data_ptr(), cp, st[0], st[1], n, stream_ptr))
         self._n = n
 
+    COLOR_GRAY, COLOR_BGR, COLOR_RGB, COLOR_CV3 = 0, 1, 2, 4        # include/ivfront.h: IVF_COLOR_*
+
+    def run_color(self, left, right, cost=None, stream_ptr=None, rgb=False, cv3=False):
+        """Like run(), with the grey conversion of Tracking::GrabImageStereo (Tracking.cc:272-295) fused into the ingest: a side given as
+        [n,H,W,3] u8 (interleaved; rgb=False: bytes B,G,R -> CV_BGR2GRAY, True: R,G,B -> CV_RGB2GRAY; cv3: OpenCV <= 3.x coefficients) is
+        converted on the device, a side given as [n,H,W] is grey.  Each side and the cost maps carry their own strides."""
+        n = left.shape[0]
+
+        def side(t):
+            assert t.shape[0] == n and t.shape[1] == self.height and t.shape[2] == self.width
+            st = t.stride()
+            if t.dim() == 4:
+                assert t.shape[3] == 3 and st[3] == 1 and st[2] == 3, "interleaved 3-channel pixels"
+                return t.data_ptr(), (self.COLOR_RGB if rgb else self.COLOR_BGR) | (self.COLOR_CV3 if cv3 else 0), st[0], st[1]
+            assert st[2] == 1
+            return t.data_ptr(), self.COLOR_GRAY, st[0], st[1]
+        lp, lc, li, lr = side(left); rp, rc, ri, rr = side(right)
+        cp, ci, cr = None, 0, 0
+        if cost is not None:
+            assert cost.dim() == 3 and cost.shape[0] == n and cost.stride()[2] == 1
+            cp, ci, cr = cost.data_ptr(), cost.stride()[0], cost.stride()[1]
+        check(self._lib.ivf_frontend_run_color(self._h, lp, lc, li, lr, rp, rc, ri, rr, cp, ci, cr, n, stream_ptr))
+        self._n = n
+
     def set_opencv_variant(self, blur=0, retain_best=0, atan2=0):
         check(self._lib.ivf_frontend_set_opencv_variant(self._h, int(blur), int(retain_best), int(atan2)))
 

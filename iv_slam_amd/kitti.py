@@ -217,12 +217,15 @@ def imwrite(path, img):
                 chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
-def to_gray(img, rgb):
-    """cvtColor(img, CV_RGB2GRAY) when Camera.RGB = 1, CV_BGR2GRAY otherwise (Tracking.cc:278-291), OpenCV's 8-bit fixed
-    point: (R*4899 + G*9617 + B*1868 + 8192) >> 14.  Grey images pass through."""
+def to_gray(img, rgb, cv3=False):
+    """cvtColor(img, CV_RGB2GRAY) when Camera.RGB = 1, CV_BGR2GRAY otherwise (Tracking.cc:278-291), OpenCV's 8-bit fixed point:
+    (R*9798 + G*19235 + B*3735 + 16384) >> 15 as OpenCV 4.x computes it (the semantics every other primitive here is frozen to), or with
+    cv3=True OpenCV <= 3.x's (R*4899 + G*9617 + B*1868 + 8192) >> 14.  Grey images pass through.  The device form: ivf_frontend_run_color."""
     if img.ndim == 2:
         return img
     a = img.astype(np.int32)
     c0, c1, c2 = a[..., 0], a[..., 1], a[..., 2]
     r, b = (c0, c2) if rgb else (c2, c0)
-    return ((r * 4899 + c1 * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
+    if cv3:
+        return ((r * 4899 + c1 * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
+    return ((r * 9798 + c1 * 19235 + b * 3735 + 16384) >> 15).astype(np.uint8)

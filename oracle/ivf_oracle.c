@@ -1847,3 +1847,23 @@ void orc_remap_bilinear_u8(const uint8_t* src, int sw, int sh, int sstride, int 
             }
         }
 }
+
+
+/* A-12  cv::cvtColor(src, dst, CV_BGR2GRAY / CV_RGB2GRAY) on 8UC3 (ORB/src/Tracking.cc:272-295: GrabImageStereo converts mImGray by mbRGB).
+ * "parity unpinned" like A-1 .. A-11: restated from OpenCV's published RGB2Gray<uchar>.  Fixed point:
+ *   OpenCV 4.x  (color.hpp: gray_shift = 15, RY15 = 9798, GY15 = 19235, BY15 = 3735):  (R*9798 + G*19235 + B*3735 + (1 << 14)) >> 15
+ *   OpenCV <= 3.x (yuv_shift = 14, R2Y = 4899, G2Y = 9617, B2Y = 1868):                (R*4899 + G*9617  + B*1868 + (1 << 13)) >> 14
+ * rgb: 0 = bytes B,G,R (CV_BGR2GRAY), 1 = bytes R,G,B (CV_RGB2GRAY); cv3: 1 = the <= 3.x coefficients. */
+void orc_gray_from_color(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride, int rgb, int cv3)
+{
+    const int kR = cv3 ? 4899 : 9798, kG = cv3 ? 9617 : 19235, kB = cv3 ? 1868 : 3735, sh = cv3 ? 14 : 15;
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = src + (size_t)y * sstride;
+        uint8_t* d = dst + (size_t)y * dstride;
+        for (int x = 0; x < w; x++) {
+            const int c0 = s[3 * x], g = s[3 * x + 1], c2 = s[3 * x + 2];
+            const int r = rgb ? c0 : c2, b = rgb ? c2 : c0;
+            d[x] = (uint8_t)((r * kR + g * kG + b * kB + (1 << (sh - 1))) >> sh);
+        }
+    }
+}

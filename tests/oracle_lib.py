@@ -463,6 +463,15 @@ def remap_weight_table():
     return t.reshape(1024, 4)
 
 
+def gray_from_color(img, rgb, cv3=False):
+    """cvtColor(img, CV_RGB2GRAY if rgb else CV_BGR2GRAY) on an [H, W, 3] u8 image (Tracking.cc:272-295; A-12)"""
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty(img.shape[:2], np.uint8)
+    lib.orc_gray_from_color.restype = None
+    lib.orc_gray_from_color(ptr(img), img.shape[1], img.shape[0], img.strides[0], ptr(out), out.strides[0], int(bool(rgb)), int(bool(cv3)))
+    return out
+
+
 def c_round(v):
     """std::round of a float array (Frame.cc:130-131 rounds the keypoint position with it): halves AWAY from zero --
     np.rint rounds them to even, which differs on x.5 coordinates (levels > 0 produce them)."""

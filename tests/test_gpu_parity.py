@@ -729,6 +729,66 @@ def test_frontend_strided_inputs(iv):
         assert fe.fetch(p, 0)["uright"].tobytes() == ref[p][0]["uright"].tobytes()
 
 
+@pytest.mark.parametrize("rgb,cv3", [(False, False), (True, False), (False, True), (True, True)])
+def test_frontend_color_inputs_gray_conversion_fused_into_the_ingest(iv, rgb, cv3):
+    """r06: ivf_frontend_run_color = Tracking::GrabImageStereo's cvtColor (Tracking.cc:272-295, by mbRGB) + ivf_frontend_run.  The left side arrives as
+    interleaved colour (what the FCN reads too), the right side grey or colour, with different strides per side, odd widths (the row's last 16-byte piece),
+    padded views; level 0 must equal the oracle's cvtColor byte for byte, i.e. keypoints / descriptors / stereo matches / quality equal the oracle chain on
+    the converted images -- for both byte orders and both OpenCV coefficient generations."""
+    import torch
+    w, h, n, pairs = 637, 241, 400, 3
+    rng = np.random.default_rng(5 + 2 * int(rgb) + int(cv3))
+    stream = synth.make_stream(pairs, w, h, seed=78)
+    cost = np.stack([synth.make_cost_map(w, h, seed=78, idx=i) for i in range(pairs)])
+
+    def colourise(g):          # a colour image whose grey conversion is textured like g: channels = g +- small, clipped
+        c = np.stack([np.clip(g.astype(int) + rng.integers(-40, 41, g.shape), 0, 255) for _ in range(3)], axis=-1)
+        return c.astype(np.uint8)
+    Lc = np.stack([colourise(stream[p, 0]) for p in range(pairs)]); Rc = np.stack([colourise(stream[p, 1]) for p in range(pairs)])
+    Lg = np.stack([O.gray_from_color(Lc[p], rgb, cv3) for p in range(pairs)]); Rg = np.stack([O.gray_from_color(Rc[p], rgb, cv3) for p in range(pairs)])
+    assert np.array_equal(Lg[0], kitti_to_gray(Lc[0], rgb, cv3))                   # the host loader's conversion is the same function
+    dev = torch.device("cuda:0")
+    fe = iv.StereoFrontend(w, h, pairs, nfeatures=n, enableIntrospection=True, bf=BF, b=B)
+    dLc = torch.from_numpy(Lc).to(dev); dRc = torch.from_numpy(Rc).to(dev); dRg = torch.from_numpy(Rg).to(dev); dC = torch.from_numpy(cost).to(dev)
+    # reference: the plain run on the oracle-converted grey images
+    fe.run(torch.from_numpy(Lg).to(dev), dRg, dC); fe.sync()
+    ref = [(fe.fetch(p, 0), fe.fetch(p, 1)) for p in range(pairs)]
+    oL = O.Extractor(n, 1.2, 8, 20, 7, introspection=True); oR = O.Extractor(n, 1.2, 8, 20, 7)
+    okL, odL = oL(Lg[1], cost[1]); okR, odR = oR(Rg[1], cost[1])
+    assert_kps_equal(ref[1][0]["kps"], okL, "grey L vs oracle"); assert np.array_equal(ref[1][0]["desc"], odL)
+    assert_kps_equal(ref[1][1]["kps"], okR, "grey R vs oracle"); assert np.array_equal(ref[1][1]["desc"], odR)
+
+    def same(tag):
+        for p in range(pairs):
+            for side in (0, 1):
+                a = fe.fetch(p, side); b_ = ref[p][side]
+                assert_kps_equal(a["kps"], b_["kps"], "%s pair %d side %d" % (tag, p, side))
+                assert np.array_equal(a["desc"], b_["desc"]) and np.array_equal(a["quality"], b_["quality"])
+            assert fe.fetch(p, 0)["uright"].tobytes() == ref[p][0]["uright"].tobytes() and fe.fetch(p, 0)["depth"].tobytes() == ref[p][0]["depth"].tobytes()
+    fe.run_color(dLc, dRg, dC, rgb=rgb, cv3=cv3); fe.sync(); same("colour left, grey right")
+    fe.run_color(dLc, dRc, dC, rgb=rgb, cv3=cv3); fe.sync(); same("colour left and right")
+    # padded views with different strides per side, odd byte offsets
+    bigL = torch.zeros((pairs, h + 3, w + 11, 3), dtype=torch.uint8, device=dev); vL = bigL[:, 1:1 + h, 5:5 + w]; vL.copy_(dLc)
+    bigR = torch.zeros((pairs, h + 7, w + 29), dtype=torch.uint8, device=dev); vR = bigR[:, 4:4 + h, 3:3 + w]; vR.copy_(dRg)
+    bigC = torch.zeros((pairs, h + 2, w + 1), dtype=torch.uint8, device=dev); vC = bigC[:, 1:1 + h, :w]; vC.copy_(dC)
+    fe.run_color(vL, vR, vC, rgb=rgb, cv3=cv3); fe.sync(); same("padded views")
+    # argument checks
+    with pytest.raises(Exception):
+        fe._lib.ivf_frontend_run_color.restype
+        from iv_slam_amd._lib import check
+        check(fe._lib.ivf_frontend_run_color(fe._h, dLc.data_ptr(), 3, dLc.stride()[0], dLc.stride()[1], dRg.data_ptr(), 0, dRg.stride()[0], dRg.stride()[1],
+                                             None, 0, 0, pairs, None))
+    with pytest.raises(Exception):
+        from iv_slam_amd._lib import check
+        check(fe._lib.ivf_frontend_run_color(fe._h, dLc.data_ptr(), 1, dLc.stride()[0], w, dRg.data_ptr(), 0, dRg.stride()[0], dRg.stride()[1],
+                                             None, 0, 0, pairs, None))          # a colour row needs 3 w bytes
+
+
+def kitti_to_gray(img, rgb, cv3):
+    from iv_slam_amd import kitti
+    return kitti.to_gray(img, rgb, cv3)
+
+
 def test_two_front_ends_from_two_host_threads(iv):
     """two independent handles driven concurrently from two host threads (a two-camera rig): same results as one after the
     other (per-thread scratch, no shared mutable state in the library; r05: both handles enqueue on the SAME three pooled internal streams)"""

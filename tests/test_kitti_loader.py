@@ -74,10 +74,13 @@ def test_to_gray_fixed_point():
     rng = np.random.default_rng(4)
     bgr = rng.integers(0, 256, size=(9, 11, 3)).astype(np.uint8)
     b, g, r = [bgr[..., k].astype(np.int64) for k in range(3)]
-    assert np.array_equal(kitti.to_gray(bgr, rgb=False), ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8))
-    assert np.array_equal(kitti.to_gray(bgr, rgb=True), ((b * 4899 + g * 9617 + r * 1868 + 8192) >> 14).astype(np.uint8))
+    # OpenCV <= 3.x: 14-bit coefficients; OpenCV 4.x (the default, like every other frozen primitive): 15-bit
+    assert np.array_equal(kitti.to_gray(bgr, rgb=False, cv3=True), ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8))
+    assert np.array_equal(kitti.to_gray(bgr, rgb=True, cv3=True), ((b * 4899 + g * 9617 + r * 1868 + 8192) >> 14).astype(np.uint8))
+    assert np.array_equal(kitti.to_gray(bgr, rgb=False), ((r * 9798 + g * 19235 + b * 3735 + 16384) >> 15).astype(np.uint8))
+    assert np.array_equal(kitti.to_gray(bgr, rgb=True), ((b * 9798 + g * 19235 + r * 3735 + 16384) >> 15).astype(np.uint8))
     white = np.full((2, 2, 3), 255, np.uint8)
-    assert (kitti.to_gray(white, True) == 255).all()
+    assert (kitti.to_gray(white, True) == 255).all() and (kitti.to_gray(white, False, cv3=True) == 255).all()
     grey = rng.integers(0, 256, size=(5, 5)).astype(np.uint8)
     assert kitti.to_gray(grey, True) is grey
 

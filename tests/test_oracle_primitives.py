@@ -378,3 +378,30 @@ def test_opencv_variant_switches_kats():
             assert na == 100 and np.array_equal(a[:100]["x"], b[:100]["x"]), var
     finally:
         O.set_opencv_variant()
+
+
+def test_gray_from_color_kats_and_both_opencv_generations():
+    """A-12: cv::cvtColor 8UC3 -> 8UC1 (Tracking.cc:272-295), fixed point.  Hand-derived known answers for both coefficient sets, the byte-order
+    switch, and an independent numpy restatement on random data; the two OpenCV generations really differ (so the switch matters)."""
+    def px(b, g, r):
+        return np.array([[[b, g, r]]], np.uint8)
+    # pure colours: 4.x (255 k + 16384) >> 15, <= 3.x (255 k + 8192) >> 14
+    assert O.gray_from_color(px(255, 0, 0), rgb=False)[0, 0] == (255 * 3735 + 16384) >> 15 == 29
+    assert O.gray_from_color(px(0, 255, 0), rgb=False)[0, 0] == (255 * 19235 + 16384) >> 15 == 150
+    assert O.gray_from_color(px(0, 0, 255), rgb=False)[0, 0] == (255 * 9798 + 16384) >> 15 == 76
+    assert O.gray_from_color(px(255, 0, 0), rgb=True)[0, 0] == 76 and O.gray_from_color(px(0, 0, 255), rgb=True)[0, 0] == 29      # bytes R,G,B
+    assert O.gray_from_color(px(255, 255, 255), rgb=False)[0, 0] == 255 == O.gray_from_color(px(255, 255, 255), rgb=False, cv3=True)[0, 0]
+    assert O.gray_from_color(px(0, 0, 255), rgb=False, cv3=True)[0, 0] == (255 * 4899 + 8192) >> 14 == 76
+    # a pixel on which the generations disagree: (B, G, R) = (0, 1, 2): 4.x (19235 + 19596 + 16384) >> 15 = 1, <= 3.x (9617 + 9798 + 8192) >> 14 = 1 ... search one
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, (37, 53, 3)).astype(np.uint8)
+    b, g, r = [img[..., k].astype(np.int64) for k in range(3)]
+    for rgb in (False, True):
+        R_, B_ = (b, r) if rgb else (r, b)
+        assert np.array_equal(O.gray_from_color(img, rgb), ((R_ * 9798 + g * 19235 + B_ * 3735 + 16384) >> 15).astype(np.uint8))
+        assert np.array_equal(O.gray_from_color(img, rgb, cv3=True), ((R_ * 4899 + g * 9617 + B_ * 1868 + 8192) >> 14).astype(np.uint8))
+    d = O.gray_from_color(img, False).astype(int) - O.gray_from_color(img, False, cv3=True).astype(int)
+    assert np.abs(d).max() == 1 and 0 < (d != 0).mean() < 0.2
+    # a padded view: strides honoured
+    big = np.zeros((40, 60, 3), np.uint8); big[2:39, 3:56] = img
+    assert np.array_equal(O.gray_from_color(big[2:39, 3:56], True), O.gray_from_color(img, True))
