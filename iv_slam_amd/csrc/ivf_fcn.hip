@@ -65,6 +65,7 @@ __device__ __forceinline__ void range_note(float& amax, float v) { amax = fmaxf(
 __device__ __forceinline__ void range_flag(float amax) { if (!(amax < 65504.f)) atomicOr(&g_fcnRange, 1); }
 
 constexpr int kEnc = 512;                      // encoder input size (IF/config: enc_input_size)
+constexpr int kSubBatch = 64;                  // images per launch sequence of ivf_fcn_forward_device (r06: see there)
 
 // ---- pre-processing + bilinear resize to 512x512 (stereo_kitti.cc:494-506, models_light.py:19-21) ----
 #ifndef IVF_PREP_ROWS
@@ -4856,7 +4857,18 @@ int ivf_fcn_forward_device(ivf_fcn* f, const uint8_t* d_bgr, size_t image_stride
     if (n < 1 || n > f->maxBatch) return ffail(IVF_E_INVALID, "batch %d outside [1,%d]", n, f->maxBatch);
     if (row_stride < 3 * f->inW) return ffail(IVF_E_INVALID, "row_stride too small");
     FHIP(hipSetDevice(f->device));
-    return forward_device(f, d_bgr, image_stride, row_stride, n, d_cost_u8, d_cost_f32, (hipStream_t)hip_stream);
+    // r06: a large batch runs as sub-batches of 64 images, back to back on the same stream.  The tensors between two launches of a 64-image forward (up to
+    // 2 x 64 x 1.3 MB at the 64 x 64 stage, 4 x that at the head) then fit the 256 MB Infinity Cache; measured 75.0 / 75.5 vs 75.5 / 76.2 us per image
+    // for 64 vs 128 images per launch sequence on one box (tools/time_fcn_batch.py; 32: 76.2-76.5, 16: 80.3), results identical (images are independent).
+    static const int sub = IVF_EXP_ENV("IVF_FCN_SUBBATCH") ? std::max(1, atoi(IVF_EXP_ENV("IVF_FCN_SUBBATCH"))) : kSubBatch;
+    const size_t outPx = (size_t)f->outW * f->outH;
+    for (int i0 = 0; i0 < n; i0 += sub) {
+        const int nb = std::min(sub, n - i0);
+        const int rc = forward_device(f, d_bgr + (size_t)i0 * image_stride, image_stride, row_stride, nb, d_cost_u8 ? d_cost_u8 + (size_t)i0 * outPx : nullptr,
+                                      d_cost_f32 ? d_cost_f32 + (size_t)i0 * outPx : nullptr, (hipStream_t)hip_stream);
+        if (rc) return rc;
+    }
+    return IVF_OK;
 }
 
 int ivf_fcn_status(ivf_fcn* f, void* hip_stream)
