@@ -2185,6 +2185,30 @@ typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
 #endif
 constexpr int kF6SH = 3;                          // weights: w_hi 2^3 (< 16), w_lo 2^13 (<= 4) in e3m2 (largest 28)
 
+// one sub-row's split input fragments (five K steps of 32 channels: lane (column, kq) holds 8 channels of each) -> the three fp6 (e2m3) B operands of
+// v_mfma_scale_f32_16x16x128_f8f6f4 for the correction product, [x_hi (K step 2c) | x_lo 2^10 | x_hi (K step 2c + 1) | x_lo 2^10] / 2^sb per lane, and the
+// lane's three E8M0 scale bytes (byte c = 127 + sb of operand c).  x_lo < ulp(x_hi) = 2^-10 2^floor(log2 x_hi), so a block's largest element is an x_hi:
+// sb = floor(log2 max |x_hi|) - 2 puts it in [4, 8) (e2m3: largest 7.5).  Operand 2 has K step 4 only (the rest zero).
+__device__ __forceinline__ void fp6_pack(const HFrag (&bh)[5], const HFrag (&bl)[5], i32x6 (&xq)[3], int& sbBytes)
+{
+    sbBytes = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        const f16x8 k1024 = {1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024};
+        const f16x8 h0 = bh[2 * c].v, l0 = bl[2 * c].v * k1024;
+        const f16x8 h1 = c < 2 ? bh[c < 2 ? 2 * c + 1 : 0].v : z8, l1 = c < 2 ? bl[c < 2 ? 2 * c + 1 : 0].v * k1024 : z8;
+        float amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) amax = fmaxf(amax, fmaxf(fabsf((float)h0[j]), fabsf((float)h1[j])));
+        const int sb = min(max(__builtin_amdgcn_frexp_expf(amax) - 3, -40), 20);
+        const f16x32 src = {h0[0], h0[1], h0[2], h0[3], h0[4], h0[5], h0[6], h0[7], l0[0], l0[1], l0[2], l0[3], l0[4], l0[5], l0[6], l0[7],
+                            h1[0], h1[1], h1[2], h1[3], h1[4], h1[5], h1[6], h1[7], l1[0], l1[1], l1[2], l1[3], l1[4], l1[5], l1[6], l1[7]};
+        xq[c] = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(src, __builtin_bit_cast(float, (127 + sb) << 23));
+        sbBytes |= (127 + sb) << (8 * c);
+    }
+}
+
 // SPLIT (small batches, r04): 16 workgroups per image leave most of the chip idle at batch 1 (the per-call drop-in path).  The hidden
 // groups are cut into gridDim.z contiguous ranges; a workgroup runs the same pipeline over its range only and stores its RAW projection
 // accumulators into `part` [gridDim.z][images][Cout][4096]; k_fcn_split_reduce adds the ranges in index order (deterministic) and applies
@@ -2658,6 +2682,7 @@ constexpr size_t kH4Lds = (size_t)2 * 16 * kH4CS * 4 + (size_t)2 * 16 * kH4DP * 
 #define IVF_H4_DMA_A 3        // expansion-weight pieces per wave of the half that reaches the barrier first (waves 0-3); waves 4-7 share the rest of the 11.
                               // Measured 1 / 2 / 3: 1,905 / 1,881 / 1,849 us per 128 images
 #endif
+template <bool FP6 = false>      // FP6 (r06): the expansion's correction products on bf6 x fp6, see k_fcn_irbd4; WE then points to the FP6 form (make_fused4: dWE6)
 __global__ __launch_bounds__(512, 2) void k_fcn_irbd4h(const float* __restrict__ X, const uint4* __restrict__ WE, const float* __restrict__ par,
                                                       const uint4* __restrict__ WP, const float* __restrict__ scP, const float* __restrict__ shP,
                                                       float* __restrict__ Y, int layIn, int layOut, int nT)
@@ -2757,15 +2782,31 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4h(const float* __restrict__
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) split_pair(xv[s5][2 * jj], xv[s5][2 * jj + 1], bh[s5].u[jj], bl[s5].u[jj]);
         if (uwave == 7) {
+            HFrag hh[5], hl[5];
 #pragma unroll
             for (int s5 = 0; s5 < 5; s5++) {
-                HFrag h, l;
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) split_pair(xh[s5][2 * jj], xh[s5][2 * jj + 1], h.u[jj], l.u[jj]);
-                sXH[(2 * s5) * 64 + lane] = h.q; sXH[(2 * s5 + 1) * 64 + lane] = l.q;
+                for (int jj = 0; jj < 4; jj++) split_pair(xh[s5][2 * jj], xh[s5][2 * jj + 1], hh[s5].u[jj], hl[s5].u[jj]);
+                if constexpr (!FP6) { sXH[(2 * s5) * 64 + lane] = hh[s5].q; sXH[(2 * s5 + 1) * 64 + lane] = hl[s5].q; }
+            }
+            if constexpr (FP6) {
+                // halo sub-row in the FP6 form: slots 0-4 the hi fragments, 5-7 dwords 0-3 of the three fp6 operands, then [c][lane] uint2 (dwords 4-5),
+                // then the lane's three scale bytes
+                i32x6 q[3]; int sb = 0;
+                fp6_pack(hh, hl, q, sb);
+#pragma unroll
+                for (int s5 = 0; s5 < 5; s5++) sXH[s5 * 64 + lane] = hh[s5].q;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    sXH[(5 + c) * 64 + lane] = make_uint4((unsigned)q[c][0], (unsigned)q[c][1], (unsigned)q[c][2], (unsigned)q[c][3]);
+                    ((uint2*)(sXH + 8 * 64))[c * 64 + lane] = make_uint2((unsigned)q[c][4], (unsigned)q[c][5]);
+                }
+                ((int*)(sXH + 9 * 64 + 32))[lane] = sb;
             }
         }
     }
+    i32x6 xq[3]; int sbB = 0;
+    if constexpr (FP6) fp6_pack(bh, bl, xq, sbB);
     f32x16 pacc[5];
 #pragma unroll
     for (int t = 0; t < 5; t++)
@@ -2816,6 +2857,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4h(const float* __restrict__
         const uint4* wE = sWE + ws * 640 + lane;
         HFrag ea[2][2], ph, pl;
         ea[0][0] = m.ea0[0]; ea[0][1] = m.ea0[1];
+        uint4 q6[2]; uint2 r6[2];                   // FP6: the correction operands of the current / next step
         f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
         const bool haloWave = uwave == IVF_H4_HALO_WAVE;
         const int gp = it - 2;
@@ -2828,6 +2870,35 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4h(const float* __restrict__
         // its 240-480)
 #pragma unroll
         for (int s5 = 0; s5 < 5; s5++) {
+            if constexpr (FP6) {
+                // slot layout (make_fused4, dWE6): pieces 0-4 the hi fragments of the five K steps, 5-7 dwords 0-3 of the three bf6 correction operands,
+                // 8-9 their dwords 4-5 ([c][lane] uint2).  Step s5 < 3 also issues correction c = s5 (operand requested a step ahead)
+                const uint2* wE2 = (const uint2*)(sWE + ws * 640 + 8 * 64) + lane;
+                if (s5 + 1 < 5) ea[(s5 + 1) & 1][0].q = wE[(s5 + 1) * 64];
+                if (s5 == 0) { q6[0] = wE[5 * 64]; r6[0] = wE2[0]; }
+                if (s5 + 1 < 3) { q6[(s5 + 1) & 1] = wE[(6 + s5) * 64]; r6[(s5 + 1) & 1] = wE2[(s5 + 1) * 64]; }
+                e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ea[s5 & 1][0].v, bh[s5].v, e0, 0, 0, 0);
+                if (haloWave) {
+                    HFrag xh_; xh_.q = sXH[s5 * 64 + lane];
+                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ea[s5 & 1][0].v, xh_.v, e1, 0, 0, 0);
+                }
+                if (s5 < 3) {
+                    const int c = s5;
+                    const i32x8 a6 = {(int)q6[c & 1].x, (int)q6[c & 1].y, (int)q6[c & 1].z, (int)q6[c & 1].w, (int)r6[c & 1].x, (int)r6[c & 1].y, 0, 0};
+                    const i32x8 b0 = {xq[c][0], xq[c][1], xq[c][2], xq[c][3], xq[c][4], xq[c][5], 0, 0};
+                    if (c == 0) e0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a6, b0, e0, 3, 2, 0, 127 - 10 - kF6SH, 0, sbB);
+                    if (c == 1) e0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a6, b0, e0, 3, 2, 0, 127 - 10 - kF6SH, 1, sbB);
+                    if (c == 2) e0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a6, b0, e0, 3, 2, 0, 127 - 10 - kF6SH, 2, sbB);
+                    if (haloWave) {
+                        const uint4 hq = sXH[(5 + c) * 64 + lane]; const uint2 hr = ((const uint2*)(sXH + 8 * 64))[c * 64 + lane];
+                        const int hsb = ((const int*)(sXH + 9 * 64 + 32))[lane];
+                        const i32x8 b1 = {(int)hq.x, (int)hq.y, (int)hq.z, (int)hq.w, (int)hr.x, (int)hr.y, 0, 0};
+                        if (c == 0) e1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a6, b1, e1, 3, 2, 0, 127 - 10 - kF6SH, 0, hsb);
+                        if (c == 1) e1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a6, b1, e1, 3, 2, 0, 127 - 10 - kF6SH, 1, hsb);
+                        if (c == 2) e1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a6, b1, e1, 3, 2, 0, 127 - 10 - kF6SH, 2, hsb);
+                    }
+                }
+            } else {
             if (s5 + 1 < 5) {
                 if (IVF_H4_ABL & 2) { ea[(s5 + 1) & 1][0] = ea[s5 & 1][0]; ea[(s5 + 1) & 1][1] = ea[s5 & 1][1]; }
                 else { ea[(s5 + 1) & 1][0].q = wE[(2 * s5 + 2) * 64]; ea[(s5 + 1) & 1][1].q = wE[(2 * s5 + 3) * 64]; }
@@ -2845,6 +2916,7 @@ __global__ __launch_bounds__(512, 2) void k_fcn_irbd4h(const float* __restrict__
                     e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, xl_.v, e1, 0, 0, 0);
                     e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, xh_.v, e1, 0, 0, 0);
                 }
+            }
             }
             {   // P(it - 2), tile s5: out[32 channels x 32 pixels] += W_P[32 x 16] . D[16 x 32 pixels]
                 const int t = s5;
@@ -4182,7 +4254,10 @@ int reserve_lds()
         {reinterpret_cast<const void*>(&k_fcn_irbd2<96, 96, true, 2, true>), D2Cfg<96, 96>::LDS, "k_fcn_irbd2<96,96,split>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd2<96, 160, false, 2, true>), D2Cfg<96, 160>::LDS, "k_fcn_irbd2<96,160,split>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd4<false, true>), kF4Lds, "k_fcn_irbd4<split>"},
-        {reinterpret_cast<const void*>(&k_fcn_irbd4h), kH4Lds, "k_fcn_irbd4h"},
+        {reinterpret_cast<const void*>(&k_fcn_irbd4h<false>), kH4Lds, "k_fcn_irbd4h"},
+#if IVF_F4_FP6_BUILT
+        {reinterpret_cast<const void*>(&k_fcn_irbd4h<true>), kH4Lds, "k_fcn_irbd4h<fp6>"},
+#endif
 #ifdef IVF_EXPERIMENT
         {reinterpret_cast<const void*>(&k_fcn_irbd4w<true>), kF4Lds, "k_fcn_irbd4w<true>"},
         {reinterpret_cast<const void*>(&k_fcn_irbd4w<false>), kF4Lds, "k_fcn_irbd4w<false>"},
@@ -4448,7 +4523,12 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
                 launch_split_reduce(f, ns, n, F.cout, pj, bk.res ? x : nullptr, y, layIn, layOut, s);
             } else if (half4 && !bk.res && F.cout == kH4Cout && F.tilesP == kH4TilesP)
             {   // block 17 in ONE pass: half a sub-image (128 pixels) x all 320 outputs per workgroup
-                hipLaunchKernelGGL(k_fcn_irbd4h, dim3(IVF_H4_WALK ? persistent_grid(f, 32 * n) : 32 * n), dim3(512), kH4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, y,
+#if IVF_F4_FP6_BUILT
+                if (fp6 && F.dWE6)
+                    hipLaunchKernelGGL(k_fcn_irbd4h<true>, dim3(32 * n), dim3(512), kH4Lds, s, x, F.dWE6, F.dPar, F.dWP, pj.dScale, pj.dShift, y, layIn, layOut, 32 * n);
+                else
+#endif
+                hipLaunchKernelGGL(k_fcn_irbd4h<false>, dim3(IVF_H4_WALK ? persistent_grid(f, 32 * n) : 32 * n), dim3(512), kH4Lds, s, x, F.dWE, F.dPar, F.dWP, pj.dScale, pj.dShift, y,
                                    layIn, layOut, 32 * n);
                 kname = "k_fcn_irbd4h";
             }

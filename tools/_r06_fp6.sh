@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r06; mkdir -p $O
 export IVFRONT_LIB=$R/iv_slam_amd/libivfront_exp.so
-LEVELS=${LEVELS:-"0 1 2"}
+LEVELS=${LEVELS:-"0 1"}
 for v in $LEVELS; do
   IVF_FCN_FP6=$v python3 $R/tools/fcn_golden_errors_batched.py > $O/gold_fp6_$v.txt 2>&1
   tail -1 $O/gold_fp6_$v.txt
