@@ -373,7 +373,6 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
     const Query* Q = queries + (size_t)p * P.nf;
     const int* C = count + (size_t)p * P.nf;
     const unsigned* Lp = lists + (size_t)p * P.nf * kListCap;
-    int nm = 0, nMatch = 0;
     const float factor = 1.0f / 30.0f;                         // 1.0f / HISTO_LENGTH (:1380)
 
     // r04: a group of 16 queries is evaluated SPECULATIVELY against the live state -- four queries per pass, one per DPP row of 16 lanes
@@ -384,37 +383,40 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
     // the next round, evaluated against the state that now holds the winner; a query whose list is longer than a row is walked alone
     // against the live state (64 entries per step, or its window again when the list overflowed).  The next group's lists are
     // requested before the current group is evaluated.
-    struct Grp { unsigned ent[4]; int cnt[4]; float ur[4]; unsigned bits[4]; int myCnt; Query myQ; float myAng; };
+    // r06: the loads of a group are UNCONDITIONAL (index clamped into the frame's own arrays) and their results are touched for the first time when the group is
+    // evaluated, two groups later; validity is re-derived from the indices there.  The r04 form -- `valid ? load : 0` per field, then `cur = nxt; nxt = nx2` --
+    // compiled to branches around the loads with PHI copies behind them and register moves of the newest group at the loop's end: an s_waitcnt vmcnt(0) at the
+    // head of EVERY group, i.e. no prefetch at all (phase timers: 56 % of the walk was that wait).  The three groups now rotate by unrolling, not by copies.
+    struct Grp { unsigned ent[4]; int cnt[4]; float2 urb[4]; int myCnt; Query myQ; float myAng; };
+    const int nLc = max(nL - 1, 0);
     auto load_group = [&](int g0, Grp& g) {
-        const int gi = g0 + (lane & (kPrefetch - 1));
-        const bool gv = gi < nL;
-        g.myCnt = gv ? C[gi] : 0;
-        g.myQ.u = 0; g.myQ.v = 0; g.myQ.ur = 0; g.myQ.bits = 0; g.myAng = 0.0f;
-        if (gv) { g.myQ = Q[gi]; g.myAng = kl[gi].angle; }
+        const int gi = min(g0 + (lane & (kPrefetch - 1)), nLc);
+        g.myCnt = C[gi]; g.myQ = Q[gi]; g.myAng = kl[gi].angle;
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-            const int qi = g0 + 4 * m + (lane >> 4);
-            const bool v = qi < nL;
-            g.ent[m] = v ? Lp[(size_t)qi * kListCap + (lane & 15)] : 0u;
-            g.cnt[m] = v ? C[qi] : 0;
-            const float2 ub = v ? *(const float2*)&Q[qi].ur : make_float2(0.f, 0.f);
-            g.ur[m] = ub.x; g.bits[m] = __builtin_bit_cast(unsigned, ub.y);
+            const int qi = min(g0 + 4 * m + (lane >> 4), nLc);
+            g.ent[m] = Lp[(size_t)qi * kListCap + (lane & 15)];
+            g.cnt[m] = C[qi];
+            g.urb[m] = *(const float2*)&Q[qi].ur;
         }
     };
 #ifdef IVF_TRACK_TIMING
     const unsigned long long tt0 = __builtin_amdgcn_s_memtime();
     int dbgRounds = 0, dbgBig = 0, dbgGroups = 0, dbgC4 = 0, dbgC8 = 0, dbgC0 = 0;
+    // r06: where a round's time goes -- [0] group loads + loop head, [1] speculative evaluation (candidate tests, row minima, gathers: the part four waves
+    // could share), [2] claim / commit (LDS claims, ballots, the prefix: serial by construction), [3] a long list walked alone, [4] the group's bins + match list
+    unsigned long long tph[5] = {0, 0, 0, 0, 0}, tlast = tt0;
+#define TRK_TIM(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tph[i] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TRK_TIM(i) do { } while (0)
 #endif
-    Grp cur, nxt;                             // two groups ahead: a group's work (~1 us) is shorter than a trip to L2 / HBM under load
-    load_group(0, cur);
-    load_group(kPrefetch, nxt);
-    for (int g0 = 0; g0 < nL; g0 += kPrefetch) {
-        Grp nx2;
-        load_group(g0 + 2 * kPrefetch, nx2);
+    int nmAcc = 0, nMatchAcc = 0;
+    auto process = [&](const int g0, const Grp& cur) {
+        int nm = nmAcc, nMatch = nMatchAcc;
         int fb = -1;                              // lane k: the keypoint query k matched (-1: none)
-        const int myCnt = cur.myCnt;
-        const Query myQ = cur.myQ;
         const int kEnd = min(kPrefetch, nL - g0);
+        const int myCnt = (g0 + (lane & (kPrefetch - 1))) < nL ? cur.myCnt : 0;
+        const Query myQ = cur.myQ;
         const unsigned bigMask = (unsigned)__ballot(lane < kEnd && myCnt > 16);
         int kstart = 0;
 #ifdef IVF_TRACK_TIMING
@@ -422,6 +424,7 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
         dbgC4 += __popcll(__ballot(lane < kEnd && myCnt > 4)); dbgC8 += __popcll(__ballot(lane < kEnd && myCnt > 8));
         dbgC0 += __popcll(__ballot(lane < kEnd && myCnt == 0));
 #endif
+        TRK_TIM(0);
         while (kstart < kEnd) {
 #ifdef IVF_TRACK_TIMING
             if ((bigMask >> kstart) & 1u) dbgBig++; else dbgRounds++;
@@ -490,6 +493,7 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 kstart++;
+                TRK_TIM(3);
                 continue;
             }
             // ---- speculative pass: row r of pass m = query 4 m + r
@@ -498,12 +502,14 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
             for (int m = 0; m < 4; m++) {
                 const unsigned e = cur.ent[m];
                 const int i2 = e & 0xffff, d = e >> 16, pos = lane & 15;
-                bool ok = pos < cur.cnt[m] && cur.cnt[m] <= 16;
+                const int cntm = (g0 + 4 * m + (lane >> 4)) < nL ? cur.cnt[m] : 0;
+                const float urm = cur.urb[m].x; const unsigned bitsm = __builtin_bit_cast(unsigned, cur.urb[m].y);
+                bool ok = pos < cntm && cntm <= 16;
                 if (ok) {
                     const int a = s_assign[i2];
                     if (a >= 0 && !(a & kNoBlock)) ok = false;
                     const float u2 = s_ur[i2];
-                    if (u2 > 0) { const float er = fabsf(cur.ur[m] - u2); if (er > th * s_scale[cur.bits[m] & 0xff]) ok = false; }
+                    if (u2 > 0) { const float er = fabsf(urm - u2); if (er > th * s_scale[bitsm & 0xff]) ok = false; }
                 }
                 i2m[m] = i2;
                 key[m] = ok ? ((unsigned)d << 6) | (unsigned)pos : 0xffffffffu;
@@ -530,6 +536,7 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
             const int bi = mSel == 0 ? iq[0] : (mSel == 1 ? iq[1] : (mSel == 2 ? iq[2] : iq[3]));
             const bool mine = lane >= kstart && lane < kEnd;
             const bool mt = mine && myCnt != 0 && myCnt <= 16 && best != 0xffffffffu && (int)(best >> 6) <= 100;      // TH_HIGH (:1469)
+            TRK_TIM(1);
             // the lowest query of every set that chose the same keypoint wins it; the others are losers
             if (mt) s_claim[bi] = 64;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -544,6 +551,7 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             kstart = kstop;
+            TRK_TIM(2);
         }
         // ---- the group's matches: rotation bins (:1476-1484) and the match list, lane k = query k
         {
@@ -562,8 +570,20 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
             nMatch += n; nm += n;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        cur = nxt; nxt = nx2;
+        nmAcc = nm; nMatchAcc = nMatch;
+        TRK_TIM(4);
+    };
+    {
+        Grp gA, gB, gC;                       // two groups ahead: a group's work (~1 us) is shorter than a trip to L2 / HBM under load
+        load_group(0, gA);
+        load_group(kPrefetch, gB);
+        for (int g0 = 0; g0 < nL; g0 += 3 * kPrefetch) {
+            load_group(g0 + 2 * kPrefetch, gC); process(g0, gA);
+            if (g0 + kPrefetch < nL) { load_group(g0 + 3 * kPrefetch, gA); process(g0 + kPrefetch, gB); }
+            if (g0 + 2 * kPrefetch < nL) { load_group(g0 + 4 * kPrefetch, gB); process(g0 + 2 * kPrefetch, gC); }
+        }
     }
+    int nm = nmAcc, nMatch = nMatchAcc;
 #ifdef IVF_TRACK_TIMING
     const unsigned long long tt1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -620,6 +640,8 @@ __global__ __launch_bounds__(64) void k_track_greedy(TrackParams P, const uint8_
     if (lane == 0 && (p == 1 || p == 40)) {
         const unsigned long long tt2 = __builtin_amdgcn_s_memtime();
         printf("pair %d pass %d: loop %llu epilogue %llu cycles groups %d rounds %d big(>16) %d nm %d | queries with no candidate %d, more than 4: %d, more than 8: %d\n", p, onlyFlagged, tt1 - tt0, tt2 - tt1, dbgGroups, dbgRounds, dbgBig, nm, dbgC0, dbgC4, dbgC8);
+        printf("pair %d pass %d: of the loop: group loads + head %llu, speculative evaluation %llu, claim / commit %llu, long lists %llu, bins + match list %llu (100 MHz ticks)\n", p, onlyFlagged,
+               tph[0], tph[1], tph[2], tph[3], tph[4]);
     }
 #endif
 }

@@ -18,24 +18,27 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--oracle-pairs", type=int, default=8)
+    ap.add_argument("--width", type=int, default=0, help="image size (default: the benchmark's 1242 x 375; configs[4]: 1920 x 1200 with --nfeatures 4000 --fast 12 7)")
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--fast", type=int, nargs=2, default=[20, 7])
     a = ap.parse_args()
     import numpy as np
     import torch
     import bench
     import iv_slam_amd as iv
     from iv_slam_amd.frontend import unpack_gather_records
-    W, H, N, P = bench.W, bench.H, a.nfeatures, a.pairs
+    W, H, N, P = a.width or bench.W, a.height or bench.H, a.nfeatures, a.pairs
     dev = torch.device("cuda:0")
     from iv_slam_amd import synth
     L0, R0 = synth.make_pair(W, H, seed=100, idx=0)                                   # one scene moving 3 px per frame: consecutive frames
     bl = torch.from_numpy(L0).to(dev); br = torch.from_numpy(R0).to(dev)
     left = torch.stack([torch.roll(bl, 3 * k, dims=1) for k in range(P)]); right = torch.stack([torch.roll(br, 3 * k, dims=1) for k in range(P)])
-    fe = iv.StereoFrontend(W, H, P, nfeatures=N, bf=bench.BF, fx=bench.FX)
+    fe = iv.StereoFrontend(W, H, P, nfeatures=N, iniThFAST=a.fast[0], minThFAST=a.fast[1], bf=bench.BF, fx=bench.FX)
     fe.run(left, right)
     rec = fe.gather_record_bytes()
     block = torch.zeros(P * rec, dtype=torch.uint8, device=dev)
     fe.pack_gather_block(block); fe.sync(); torch.cuda.synchronize()
-    sc = iv.ORBextractor(N, 1.2, 8, 20, 7).GetScaleFactors()
+    sc = iv.ORBextractor(N, 1.2, 8, a.fast[0], a.fast[1]).GetScaleFactors()
     cam = dict(fx=bench.FX, fy=bench.FX, cx=W / 2 + 0.5, cy=H / 2 - 0.25, bf=bench.BF)
     bounds = (0.0, 0.0, float(W), float(H))
     tr = iv.BatchTracker(N, sc, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["bf"], bounds, max_pairs=P - 1)
