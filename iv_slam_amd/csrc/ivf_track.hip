@@ -834,15 +834,20 @@ __global__ __launch_bounds__(64) void k_local_greedy(TrackParams P, const uint8_
     int nm = 0;
     auto blocked = [&](int i2) { const int a = s_assign[i2]; return a == -2 || (a >= 0 && !(a & kLocalNoBlock)); };   // :87-89
 
-    for (int g0 = 0; g0 < M; g0 += kPrefetch) {
-        const int gi = g0 + (lane & (kPrefetch - 1));
-        const bool gv = gi < M;
-        const int myCnt = gv ? C[gi] : 0;
-        unsigned myBits = 0;
-        if (gv) myBits = Q[gi].bits;
-        unsigned ent[kPrefetch];
+    // r06: the next group's lists are in flight while this one is walked (unconditional loads at clamped indices, two register sets that alternate
+    // by unrolling -- see k_track_greedy); before, every group of 16 queries started with a full trip to memory
+    struct LGrp { unsigned ent[kPrefetch]; int myCnt; unsigned myBits; };
+    const int Mc = max(M - 1, 0);
+    auto load_group = [&](int g0, LGrp& g) {
+        const int gi = min(g0 + (lane & (kPrefetch - 1)), Mc);
+        g.myCnt = C[gi]; g.myBits = Q[gi].bits;
 #pragma unroll
-        for (int k = 0; k < kPrefetch; k++) ent[k] = (g0 + k < M) ? Lp[(size_t)(g0 + k) * kListCap + lane] : 0u;
+        for (int k = 0; k < kPrefetch; k++) g.ent[k] = Lp[(size_t)min(g0 + k, Mc) * kListCap + lane];
+    };
+    auto process = [&](const int g0, const LGrp& grp) {
+        const int myCnt = (g0 + (lane & (kPrefetch - 1))) < M ? grp.myCnt : 0;
+        const unsigned myBits = grp.myBits;
+        const unsigned (&ent)[kPrefetch] = grp.ent;
 #pragma unroll
         for (int k = 0; k < kPrefetch; k++) {
             const int m = g0 + k;
@@ -904,6 +909,14 @@ __global__ __launch_bounds__(64) void k_local_greedy(TrackParams P, const uint8_
             if (lane == 0) s_assign[bestIdx] = ((bits >> 25) & 1) ? m : (m | kLocalNoBlock);          // :123
             nm++;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    };
+    if (M > 0) {
+        LGrp gA, gB;
+        load_group(0, gA);
+        for (int g0 = 0; g0 < M; g0 += 2 * kPrefetch) {
+            load_group(g0 + kPrefetch, gB); process(g0, gA);
+            if (g0 + kPrefetch < M) { load_group(g0 + 2 * kPrefetch, gA); process(g0 + kPrefetch, gB); }
         }
     }
     __builtin_amdgcn_wave_barrier();
