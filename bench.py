@@ -877,7 +877,7 @@ def main():
             import hashlib
             if (W, H) != (1242, 375):
                 return None, None                  # the committed counter passes were collected at 1242x375 only
-            for name in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+            for name in ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
                 try:
                     path = os.path.join(ROOT, "profiles", name)
                     raw = open(path, "rb").read()

@@ -2,7 +2,7 @@
 # copy what tools/round_evidence.sh left under gpurun_out/ into profiles/ under this round's names.  usage: collect_profiles.sh [tag]
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R
-T=${1:-r04}; G=gpurun_out
+T=${1:-r06}; G=gpurun_out
 for c in 1 2 3 4; do [ -s $G/evidence/bench_config$c.json ] && cp $G/evidence/bench_config$c.json profiles/${T}_bench_config$c.json; done
 for c in 1 2 3 4; do [ -s $G/prof/c${c}s_kernel_stats.csv ] && cp $G/prof/c${c}s_kernel_stats.csv profiles/${T}_kernel_stats_config${c}_serial.csv; done
 [ -s $G/prof/c2p_kernel_stats.csv ] && cp $G/prof/c2p_kernel_stats.csv profiles/${T}_kernel_stats_config2_pipelined.csv

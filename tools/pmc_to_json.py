@@ -22,9 +22,9 @@ def per_launch(path, counter):
             k = "ivffcn::k_fcn_dwpw<5, 4>"
             wgs = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
             k += " 960->160" if wgs == 32 * (int(sys.argv[3]) // 2) else " 960->320"     # 32 row pairs per image (x2 channel halves)
-        if k.endswith("k_fcn_irbd4<true>") or k.endswith("k_fcn_irbd4<true, false>"): k = "ivffcn::k_fcn_irbd4<true> 160->960->160"        # the probe's name for blocks 15 / 16
-        if k.endswith("k_fcn_irbd4<false>") or k.endswith("k_fcn_irbd4<false, false>"): k = "ivffcn::k_fcn_irbd4<false> 160->960->320"     # block 17 (r03 / r04 form)
-        if k.endswith("k_fcn_irbd4h"): k = "ivffcn::k_fcn_irbd4h 160->960->320"                                                              # block 17 (r05)
+        if k.endswith("k_fcn_irbd4<true>") or k.endswith("k_fcn_irbd4<true, false>") or k.endswith("k_fcn_irbd4<true, false, false>"): k = "ivffcn::k_fcn_irbd4<true> 160->960->160"        # the probe's name for blocks 15 / 16
+        if k.endswith("k_fcn_irbd4<false>") or k.endswith("k_fcn_irbd4<false, false>") or k.endswith("k_fcn_irbd4<false, false, false>"): k = "ivffcn::k_fcn_irbd4<false> 160->960->320"     # block 17 (r03 / r04 form)
+        if k.endswith("k_fcn_irbd4h") or k.endswith("k_fcn_irbd4h<false>"): k = "ivffcn::k_fcn_irbd4h 160->960->320"                                                              # block 17 (r05)
         acc[k] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
     return {k: (v * 1024 / len(disp[k]), len(disp[k])) for k, v in acc.items()}
 
@@ -32,11 +32,17 @@ def per_launch(path, counter):
 def main():
     fetch = per_launch(sys.argv[1], "FETCH_SIZE"); write = per_launch(sys.argv[2], "WRITE_SIZE")
     n_img = int(sys.argv[3])
+    fcn_img = int(sys.argv[6]) if len(sys.argv) > 6 else n_img // 2
     import subprocess, os
     try:
         commit = subprocess.check_output(["git", "-C", os.path.dirname(os.path.abspath(__file__)), "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
     except Exception:
-        commit = os.environ.get("IVF_COMMIT", "unknown")          # the GPU box has no .git: tools/pmc_traffic.sh passes IVF_COMMIT
+        # the GPU box has no .git: the snapshot carries the commit it was cut from in .ivf_commit (written by tools/stamp_commit.sh before gpurun)
+        commit = os.environ.get("IVF_COMMIT") or "unknown"
+        try:
+            commit = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".ivf_commit")).read().strip() or commit
+        except OSError:
+            pass
     # the build the counters were collected on: ivf_build_id() hashes the sources + flags, and the same hash recomputed from the tree --
     # always available, also on the GPU box (which has no .git) -- so the counter file is tied to a build like every bench line is
     build = {}
@@ -60,7 +66,7 @@ def main():
         corr = 2.0 if any(t in k for t in WIDE) else 1.0
         e = {"fetch_bytes_per_launch": int(f * corr), "fetch_raw_bytes_per_launch": int(f), "fetch_correction": corr,
              "write_bytes_per_launch": int(w), "launches": max(nf, nw)}
-        if "k_fcn" in k: e["images_per_launch"] = n_img // 2          # the FCN sees the left images only
+        if "k_fcn" in k: e["images_per_launch"] = fcn_img             # the FCN sees the left images only, in sub-batches (r06: 64 per launch sequence)
         out["kernels"][k] = e
     json.dump(out, open(sys.argv[4], "w"), indent=1)
     print("wrote", sys.argv[4], len(out["kernels"]), "kernels")

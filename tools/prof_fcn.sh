@@ -10,7 +10,7 @@ import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "fcn" in r["Name"]]
 calls = max(int(r["Calls"]) for r in rows if "k_fcn_stem" in r["Name"])
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print("== %s: FCN kernels at batch 128: %.1f us per image in kernels" % (sys.argv[2], tot / calls / 128 / 1e3))
+print("== %s: FCN kernels, forward of 128 images = 2 launch sequences of 64 (r06): %.1f us per image in kernels; per-launch figures below are for 64 images" % (sys.argv[2], tot / calls / 64 / 1e3))
 for r in rows[:16]:
     print("%-66s x%d %9.1f us  %5.1f%%" % (r["Name"][8:74], int(r["Calls"]) // calls, float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
 P

@@ -5,7 +5,7 @@ import json, sys
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
 tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 out = {"command": "rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --batches-per-step 4 --no-cpu-baseline --no-extras --serial ; second pass --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE",
-       "note": "per-launch averages (configs[2]: 256 images per front-end launch, 128 per FCN launch). SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are in quad-cycles summed over waves; SQ_BUSY_CU_CYCLES summed over 256 CUs; SQ_VALU_MFMA_BUSY_CYCLES summed over 1024 SIMDs (32 per v_mfma_f32_32x32x16_f16); GRBM_GUI_ACTIVE summed over 8 XCDs. valu_issue_frac_at_4cyc = SQ_INSTS_VALU * 4 / (GRBM_GUI_ACTIVE / 8 * 1024): 1.0 = every SIMD issues a vector instruction every 4 cycles",
+       "note": "per-launch averages (configs[2]: 256 images per front-end launch, 64 per FCN launch since r06 (128 before)). SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are in quad-cycles summed over waves; SQ_BUSY_CU_CYCLES summed over 256 CUs; SQ_VALU_MFMA_BUSY_CYCLES summed over 1024 SIMDs (32 per v_mfma_f32_32x32x16_f16); GRBM_GUI_ACTIVE summed over 8 XCDs. valu_issue_frac_at_4cyc = SQ_INSTS_VALU * 4 / (GRBM_GUI_ACTIVE / 8 * 1024): 1.0 = every SIMD issues a vector instruction every 4 cycles",
        "per_launch_avg": {}}
 d = {}
 for f in ("sq1", "sq2"):
