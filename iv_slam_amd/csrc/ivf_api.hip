@@ -241,23 +241,6 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
             tab.push_back((ResizeCoef)y0 | (b0 << 16) | (b1 << 32));
         }
     }
-    // r06: LDS plan of every fused level pair (k_pyr_down2): the largest rectangles any tile cuts, found by cutting them all with the kernel's own function
-    for (int l = 0; l < kMaxLevels; l++) c.pyr2[l] = Config::Pyr2Plan{0, 0, 0, 0};
-    static const bool fusePyr = IVF_EXP_ENV("IVF_PYR_FUSE") ? atoi(IVF_EXP_ENV("IVF_PYR_FUSE")) != 0 : true;
-    for (int l = 1; fusePyr && l + 1 < c.nlevels; l += 2) {
-        const LevelGeom &L0 = c.lv[l - 1], &L1 = c.lv[l], &L2 = c.lv[l + 1];
-        if (L1.w <= 0 || L1.h <= 0 || L2.w <= 0 || L2.h <= 0) break;
-        if ((double)L0.w / L1.w > 1.5 || (double)L0.h / L1.h > 1.5 || (double)L1.w / L2.w > 1.5 || (double)L1.h / L2.h > 1.5) continue;      // k_pyr_down's un-staged path covers such ratios
-        int aP = 0, aR = 0, bP = 0, bR = 0;
-        const int nTX = (L2.w + kP2TW - 1) / kP2TW, nTY = (L2.h + kP2TH - 1) / kP2TH;
-        for (int iy = 0; iy < nTY; iy++)
-            for (int ix = 0; ix < nTX; ix++) {
-                const Pyr2Rect R = pyr2_rect(L0, L1, L2, tab.data() + L1.rtX, tab.data() + L1.rtY, tab.data() + L2.rtX, tab.data() + L2.rtY, ix, iy);
-                aP = std::max(aP, ((R.wx1 - R.wx0) / 16 + 1) * 16 + 16); aR = std::max(aR, R.wy1 - R.wy0 + 1);
-                bP = std::max(bP, ((R.rx1 - R.rx0 + 1 + 15) / 16) * 16 + 16); bR = std::max(bR, R.ry1 - R.ry0 + 1);
-            }
-        if ((size_t)aP * aR + (size_t)bP * bR <= 60 * 1024) c.pyr2[l] = Config::Pyr2Plan{aP, aR, bP, bR};
-    }
     if (tab.empty()) tab.push_back(0);
 
     HIPCHK(hipSetDevice(device));

@@ -49,11 +49,7 @@ struct Config {
     int tileBases[kMaxLevels], btileBases[kMaxLevels];   // lv[l].tileBase / btileBase side by side (INT_MAX past nlevels):
                                                          // a tile finds its level with one wide uniform load
     LevelGeom lv[kMaxLevels];
-    // r06: levels l and l + 1 in ONE launch (k_pyr_down2, l odd): LDS tile of level l - 1 (a) and of level l (b) per workgroup, sized by the host over all
-    // tiles exactly as the kernel cuts them; aPitch == 0: this pair takes two k_pyr_down launches (level ratio too large for the LDS)
-    struct Pyr2Plan { int aPitch, aRows, bPitch, bRows; } pyr2[kMaxLevels];
 };
-constexpr int kP2TW = 208, kP2TH = 22;   // k_pyr_down2: tile of the SECOND level; its footprint on the first is ~252 x 29 at the 1.2 ratio: one 256 x 32 pass
 
 // cv::resize coefficient table entry: src index | coef0 << 16 | coef1 << 32 (11-bit fixed point, A-3)
 typedef unsigned long long ResizeCoef;
@@ -137,39 +133,6 @@ void launch_ingest(const Config& hc, const Config* dc, const Buffers& b, const u
                    size_t imageStride, int rowStride, int nImg, int nSides, uint8_t* dstBlob, hipStream_t s, int sideMask = 3);
 void launch_ingest_color(const Config& hc, const Config* dc, const uint8_t* src, size_t imageStride, int rowStride, int code, int nImg, int nSides, int side,
                          uint8_t* dstBlob, hipStream_t s);
-struct Pyr2Rect { int rx0, rx1, ry0, ry1, wx0, wx1, wy0, wy1, exEnd, eyEnd; };
-// the rectangles of tile (ix, iy) of the pair (l1, l1 + 1): host (LDS sizing) and device (the kernel) cut them with this one function.
-// tabX1 / tabY1 / tabX2 / tabY2: the coefficient tables of the two levels (entry & 0xffff = clamped source index)
-template <typename T>
-__host__ __device__ inline Pyr2Rect pyr2_rect(const LevelGeom& L0, const LevelGeom& L1, const LevelGeom& L2, const T* tabX1, const T* tabY1, const T* tabX2,
-                                              const T* tabY2, int ix, int iy)
-{
-    Pyr2Rect R;
-    const int nTX = (L2.w + kP2TW - 1) / kP2TW, nTY = (L2.h + kP2TH - 1) / kP2TH;
-    const int ex0 = ix * kP2TW, ey0 = iy * kP2TH;
-    const bool lastX = ix == nTX - 1, lastY = iy == nTY - 1;
-    R.exEnd = lastX ? L2.pitch : ex0 + kP2TW;
-    R.eyEnd = lastY ? L2.h : ey0 + kP2TH;
-    const int exl = (lastX ? L2.w : ex0 + kP2TW) - 1, eyl = R.eyEnd - 1;
-    // first-level rectangle: what the tile draws from; the last tile also takes the rest of the level (incl. the zeroed columns up to the pitch)
-    R.rx0 = (int)(tabX2[ex0] & 0xffff) & ~15;
-    int rx1 = lastX ? L1.pitch - 1 : (int)(tabX2[exl] & 0xffff) + 1;
-    rx1 = ((rx1 + 4) & ~3) - 1;                                   // whole 4-pixel groups
-    R.rx1 = rx1 < L1.pitch - 1 ? rx1 : L1.pitch - 1;
-    R.ry0 = (int)(tabY2[ey0] & 0xffff);
-    const int ry1 = lastY ? L1.h - 1 : (int)(tabY2[eyl] & 0xffff) + 1;
-    R.ry1 = ry1 < L1.h - 1 ? ry1 : L1.h - 1;
-    // zeroth-level window under that rectangle
-    const int cx1 = R.rx1 < L1.w - 1 ? R.rx1 : L1.w - 1;
-    R.wx0 = (int)(tabX1[R.rx0 < L1.w - 1 ? R.rx0 : L1.w - 1] & 0xffff) & ~15;
-    const int wx1 = (int)(tabX1[cx1] & 0xffff) + 1;
-    R.wx1 = wx1 < L0.w - 1 ? wx1 : L0.w - 1;
-    R.wy0 = (int)(tabY1[R.ry0] & 0xffff);
-    const int wy1 = (int)(tabY1[R.ry1] & 0xffff) + 1;
-    R.wy1 = wy1 < L0.h - 1 ? wy1 : L0.h - 1;
-    return R;
-}
-
 void launch_pyramid(const Config& hc, const Config* dc, const ResizeCoef* dTab, uint8_t* blob, uint8_t* qblob, const uint8_t* useCost,
                     int nImg, hipStream_t s);
 void launch_fast(const Config& hc, const Config* dc, const Buffers& b, int nImg, hipStream_t s);

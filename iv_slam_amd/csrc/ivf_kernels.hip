@@ -319,138 +319,6 @@ DEVINL void pyr_tile(const Config* __restrict__ cfg, int level, const ResizeCoef
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_pyr_down2 (r06): TWO pyramid levels per launch.  A workgroup owns a kP2TW x kP2TH tile of level l + 1; it stages the level l - 1 window
-// that tile draws from (through level l) in LDS, computes the level l rectangle under the tile -- stored to the plane AND kept in LDS -- and
-// then the tile itself from that LDS image: level l is never read back from memory, and seven dependent launches become four.  The arithmetic
-// is k_pyr_down's (same tables, same funnel / dot / 24-bit multiplies): pyr_rect below is pyr_tile's staged branch with an output rectangle
-// that need not be a whole 256 x 32 tile and an optional second store into LDS.  Rectangles of neighbouring workgroups overlap by the few
-// columns / rows both tiles draw from (and by the 16-byte alignment of the LDS image): those pixels are computed twice and stored twice
-// with identical values.  The last tile of a row / column extends its rectangle to the first level's pitch / last row, so every pixel of
-// level l is produced whether level l + 1 reads it or not.
-// ------------------------------------------------------------------------------------------------
-// rectangle [dx0, xEnd) x [dy0, yEnd) of level `level` (at most 256 x 32 from (dx0, dy0); dx0 % 4 == 0) from the LDS image `src` of level - 1 whose
-// byte (0, 0) is source pixel (wx0, wy0), wx0 % 16 == 0; out = base + D.off; ldsOut (nullable) = LDS image of THIS level with origin (ox0, oy0)
-DEVINL void pyr_rect(const Config* __restrict__ cfg, int level, const ResizeCoef* __restrict__ tab, uint8_t* __restrict__ out, int dx0, int dy0,
-                     int xEnd, int yEnd, const uint8_t* src, int ldsPitch, int wx0, int wy0, uint8_t* ldsOut, int ox0, int oy0, int ldsOutPitch)
-{
-    const LevelGeom& D = cfg->lv[level];
-    const LevelGeom& S = cfg->lv[level - 1];
-    const ResizeCoef* tx = tab + D.rtX;
-    const ResizeCoef* ty = tab + D.rtY;
-    const int tid = threadIdx.x;
-    const int x4 = dx0 + (tid & 63) * 4;
-    if (x4 >= xEnd) return;
-    unsigned sel[4], coef[4];
-    int sxs[4], sx1s[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const ResizeCoef cx = tx[min(x4 + k, D.w - 1)];
-        sxs[k] = (int)(cx & 0xffff); sx1s[k] = min(sxs[k] + 1, S.w - 1);
-        coef[k] = (unsigned)((cx >> 16) & 0xffff) | ((unsigned)((cx >> 32) & 0xffff) << 16);      // a0 | a1 << 16
-    }
-    const bool wide = sx1s[3] - sxs[0] > 7;
-    const int base2 = wide ? sxs[2] : sxs[0];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int b = k < 2 ? sxs[0] : base2;
-        sel[k] = (unsigned)(sxs[k] - b) | 0x0c00u | ((unsigned)(sx1s[k] - b) << 16) | 0x0c000000u;
-    }
-    const int wbyte = sxs[0] - wx0, wsh = wbyte & 3, wbyte2 = base2 - wx0, wsh2 = wbyte2 & 3;
-    const unsigned* wrow = (const unsigned*)(src + (wbyte & ~3));
-    const unsigned* wrow2 = (const unsigned*)(src + (wbyte2 & ~3));
-    const int rowDw = ldsPitch / 4;
-    auto hpass = [&](int r, unsigned (&h)[4]) {
-        const unsigned* w = wrow + r * rowDw;
-        const unsigned d0 = w[0], d1 = w[1], d2 = w[2];
-        const unsigned lo = __builtin_amdgcn_alignbyte(d1, d0, wsh), hi = __builtin_amdgcn_alignbyte(d2, d1, wsh);
-        unsigned lo2 = lo, hi2 = hi;
-        if (wide) {
-            const unsigned* w2 = wrow2 + r * rowDw;
-            const unsigned e0 = w2[0], e1 = w2[1], e2 = w2[2];
-            lo2 = __builtin_amdgcn_alignbyte(e1, e0, wsh2); hi2 = __builtin_amdgcn_alignbyte(e2, e1, wsh2);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            h[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(k < 2 ? hi : hi2, k < 2 ? lo : lo2, sel[k])),
-                                          __builtin_bit_cast(u16x2, coef[k]), 0u, false) >> 4;
-    };
-    const unsigned colMask = x4 + 3 < D.w ? 0xffffffffu : (x4 >= D.w ? 0u : (0xffffffffu >> (8 * (x4 + 4 - D.w))));
-    const int dyFirst = dy0 + kPyrRPT * __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned hA[4], hB[4];
-    int rowA = -1, rowB = -1;
-    uint8_t* outp = out + (size_t)dyFirst * D.pitch + x4;
-#pragma unroll
-    for (int rr = 0; rr < kPyrRPT; rr++) {
-        const int dy = dyFirst + rr;
-        if (dy >= yEnd) break;
-        const ResizeCoef cy = ty[dy];
-        const int y0 = (int)(cy & 0xffff), y1 = min(y0 + 1, S.h - 1);
-        const unsigned b0 = (unsigned)((cy >> 16) & 0xffff), b1 = (unsigned)((cy >> 32) & 0xffff);
-        if (y0 - wy0 == rowB) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) hA[k] = hB[k];
-            rowA = rowB;
-        } else if (y0 - wy0 != rowA) { hpass(y0 - wy0, hA); rowA = y0 - wy0; }
-        if (y1 - wy0 == rowA) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) hB[k] = hA[k];
-            rowB = rowA;
-        } else if (y1 - wy0 != rowB) { hpass(y1 - wy0, hB); rowB = y1 - wy0; }
-        unsigned o = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            o |= (((__umul24(b0, hA[k]) >> 16) + (__umul24(b1, hB[k]) >> 16) + 2u) >> 2) << (8 * k);
-        o &= colMask;
-        *(unsigned*)(outp + (size_t)rr * D.pitch) = o;
-        if (ldsOut) *(unsigned*)(ldsOut + (dy - oy0) * ldsOutPitch + (x4 - ox0)) = o;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_pyr_down2(const Config* __restrict__ cfg, int l1, const ResizeCoef* __restrict__ tab,
-                                                  uint8_t* __restrict__ blobI, uint8_t* __restrict__ blobQ, const uint8_t* __restrict__ useCost, int nImg)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t src[];           // a: level l1 - 1 window, then b: level l1 rectangle
-    int img = blockIdx.z;
-    uint8_t* blob = blobI;
-    if (img >= nImg) { img -= nImg; blob = blobQ; if (!(useCost[img] & 1u)) return; }
-    uint8_t* base = blob + (size_t)img * cfg->pyrBytes;
-    const LevelGeom& L0 = cfg->lv[l1 - 1];
-    const LevelGeom& L1 = cfg->lv[l1];
-    const LevelGeom& L2 = cfg->lv[l1 + 1];
-    const int aPitch = cfg->pyr2[l1].aPitch, aRows = cfg->pyr2[l1].aRows, bPitch = cfg->pyr2[l1].bPitch;
-    uint8_t* const la = src;
-    uint8_t* const lb = src + aPitch * aRows;
-    const Pyr2Rect R = pyr2_rect(L0, L1, L2, tab + L1.rtX, tab + L1.rtY, tab + L2.rtX, tab + L2.rtY, (int)blockIdx.x, (int)blockIdx.y);
-    const int tid = threadIdx.x;
-    {   // stage the level l1 - 1 window: 16-byte pieces, a thread's pieces requested before the first is stored
-        const uint8_t* SP = base + L0.off;
-        const int nq = (R.wx1 - R.wx0) / 16 + 1, nr = R.wy1 - R.wy0 + 1, n = nq * nr;
-        for (int i0 = tid; i0 < n; i0 += 4 * 256) {
-            uint4 v[4]; int d[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int i = min(i0 + 256 * u, n - 1), r = i / nq, q = i - r * nq;
-                v[u] = *(const uint4*)(SP + (size_t)(R.wy0 + r) * L0.pitch + R.wx0 + 16 * q);
-                d[u] = r * aPitch + 16 * q;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) if (i0 + 256 * u < n) *(uint4*)(la + d[u]) = v[u];
-        }
-    }
-    __syncthreads();
-    // level l1: the rectangle, to the plane and to LDS
-    for (int cy = R.ry0; cy <= R.ry1; cy += kPyrTH)
-        for (int cx = R.rx0; cx <= R.rx1; cx += kPyrTW)
-            pyr_rect(cfg, l1, tab, base + L1.off, cx, cy, R.rx1 + 1, R.ry1 + 1, la, aPitch, R.wx0, R.wy0, lb, R.rx0, R.ry0, bPitch);
-    __syncthreads();
-    // level l1 + 1: the tile, from LDS
-    const int ex0 = (int)blockIdx.x * kP2TW, ey0 = (int)blockIdx.y * kP2TH;
-    for (int cy = ey0; cy < R.eyEnd; cy += kPyrTH)
-        for (int cx = ex0; cx < R.exEnd; cx += kPyrTW)
-            pyr_rect(cfg, l1 + 1, tab, base + L2.off, cx, cy, R.exEnd, R.eyEnd, lb, bPitch, R.rx0, R.ry0, nullptr, 0, 0, 0);
-}
-
 __global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg, int level, const ResizeCoef* __restrict__ tab,
                                                  uint8_t* __restrict__ blobI, uint8_t* __restrict__ blobQ,
                                                  const uint8_t* __restrict__ useCost, int nImg, int ldsPitch, int ldsRows)
@@ -2291,18 +2159,9 @@ void launch_pyramid(const Config& hc, const Config* dc, const ResizeCoef* dTab, 
     // r04 measured the upper levels merged into ONE launch (k_pyr_multi, a counter barrier among the workgroups of a plane between
     // levels): levels 4-7 merged 83 us against 75 us for their four launches -- not faster, and its barrier had open defects
     // (r04 ADVICE): removed in r05; DESIGN.md section 5.r04 keeps the measurement.
-    static const bool lds2Ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pyr_down2), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess;
     for (int l = 1; l < hc.nlevels; l++) {
         const LevelGeom& G = hc.lv[l];
         if (G.w <= 0 || G.h <= 0) continue;
-        if (lds2Ok && l + 1 < hc.nlevels && hc.pyr2[l].aPitch > 0) {      // this level and the next in one launch (r06)
-            const LevelGeom& G2 = hc.lv[l + 1];
-            const Config::Pyr2Plan& pl = hc.pyr2[l];
-            dim3 grid((G2.w + kP2TW - 1) / kP2TW, (G2.h + kP2TH - 1) / kP2TH, qblob ? 2 * nImg : nImg);
-            hipLaunchKernelGGL(k_pyr_down2, grid, dim3(256), (size_t)pl.aPitch * pl.aRows + (size_t)pl.bPitch * pl.bRows, s, dc, l, dTab, blob, qblob, useCost, nImg);
-            l++;
-            continue;
-        }
         const int rows = tile_rows(l), pitch = tile_pitch(l);
         dim3 grid((G.pitch + kPyrTW - 1) / kPyrTW, (G.h + kPyrTH - 1) / kPyrTH, qblob ? 2 * nImg : nImg);
         hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), (size_t)rows * pitch, s, dc, l, dTab, blob, qblob, useCost, nImg, pitch, rows);
