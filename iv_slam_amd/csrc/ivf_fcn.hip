@@ -44,6 +44,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 union HFrag { f16x8 v; uint4 q; uint32_t u[4]; };       // one lane's 8 f16 of an MFMA 32x32x16 A or B operand
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x6 __attribute__((ext_vector_type(6)));
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
 
 // two f32 -> packed f16 hi pair + packed f16 lo pair, x = hi + lo (hi, lo rounded toward zero; x - hi is exact)
 __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& hi, uint32_t& lo)
@@ -1303,6 +1306,199 @@ __global__ __launch_bounds__(256, 1) void k_fcn_conv3x3_all(const float* __restr
     }
 }
 
+// ---- the decoder's 3x3 with the CORRECTION products on the block-scaled 6-bit matrix instruction (r06) ----
+// k_fcn_conv3x3_all is the one FCN kernel that is bound by the matrix pipe (0.69 busy, r05 counters), and two of its three split-f16 products --
+// x_hi w_lo + x_lo w_hi, 2^-11 of the result -- need only ~4 bits.  Two K steps of 16 channels make ONE K = 64 product
+//   [x_hi | x_lo 2^10]_s [x_hi | x_lo 2^10]_{s+1}  .  [w_lo 2^13 ; w_hi 2^3]_s [w_lo 2^13 ; w_hi 2^3]_{s+1}  x 2^-13
+// on v_mfma_scale_f32_32x32x64_f8f6f4 (A bf6 / e3m2 packed on the host, B fp6 / e2m3 converted here with a power-of-two scale per lane = per
+// (pixel, 16 channels) from the block's largest |x|; the instruction's E8M0 operands undo both scales) at ~31 cycles against 4 x 27 for the four
+// f16 products it replaces (tools/probe/mfma_fp8_mix.hip): per unit (two K steps, one tap row) 72 f16 + 36 scaled instructions instead of 216 f16.
+// Reference error of the scheme against the six goldens, host emulation: + 4e-5 at most (tools/fcn_fp8_corrections.py, profiles/r06_*).
+// Geometry, epilogues and the small-batch ranges are k_fcn_conv3x3_all<3>'s; a unit's x window is loaded while the previous unit's MFMAs run, the A
+// operands of a (tile, dx) group two groups ahead.  Wq6 (make_gemm): per unit u = 3 s2 + dy, tile n, dx: [hi of step 2 s2][hi of step 2 s2 + 1][bf6
+// dwords 0-3][bf6 dwords 4-5 in .x .y], 64 lanes x uint4 each.
+#ifndef IVF_DEC_FP6
+#define IVF_DEC_FP6 1
+#endif
+#ifndef IVF_DEC6_ABL
+#define IVF_DEC6_ABL 0       // timing-only ablations (results wrong): 1 no x loads in the loop, 2 no A loads, 4 no f16 MFMAs, 8 no scaled MFMAs
+#endif
+constexpr int kDecSH = 3;                      // weights of the correction operand: w_hi 2^3 (< 16), w_lo 2^13 (<= 4) in e3m2 (largest 28)
+__global__ __launch_bounds__(256, 1) void k_fcn_conv3x3_f6(const float* __restrict__ X, const uint4* __restrict__ Wq6,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float* __restrict__ Y, int Cin, int Cout,
+                                                          const float* __restrict__ lastW, float lastBias, float* __restrict__ logits,
+                                                          float* __restrict__ part)
+{
+    constexpr int HW = 64 * 64, NT = 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kg = lane >> 5, col = lane & 31;
+    const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
+    const int b = L / 8;
+    const int rp = (L % 8) * 4 + wave;                               // row pair of the image
+    const int y = 2 * rp + (col >> 4), x = 4 * (col & 15);
+    const int K32 = Cin / 32;
+    const float* Xb = X + (size_t)b * Cin * HW + (size_t)8 * kg * HW + x;
+    const uint4* wq = Wq6 + lane;
+    f32x16 acc[NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[n][p][r] = 0.f;
+    const int nUnits = 3 * K32 / (int)gridDim.y, u0 = (int)blockIdx.y * nUnits, u1 = u0 + nUnits;     // unit = (pair of K steps s2, tap row dy), u = 3 s2 + dy
+    struct XSet2 { float4 x[2][8]; float m; };
+    auto load_x = [&](XSet2& S, int u) {
+        u = min(u, 3 * K32 - 1);                                     // past the end: a redundant re-load of the last unit
+        const int dy = u % 3, s2 = u / 3;
+        const int yy = y + dy - 1;
+        const bool ok = yy >= 0 && yy < 64;
+        S.m = ok ? 1.f : 0.f;
+        const float* P = Xb + (size_t)32 * s2 * HW + (ok ? yy : y) * 64;
+#pragma unroll
+        for (int st = 0; st < 2; st++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) S.x[st][j] = *(const float4*)(P + (size_t)(16 * st + j) * HW);
+    };
+    struct AGrp { HFrag h0, h1; uint4 q; uint4 r; };               // A operands of one (tile, dx) group of a unit
+    // (r06b measured: the four waves' common A operands staged through LDS -- a quarter fetched per wave, a barrier per unit -- 375 us per 64 images against
+    // 257 with every wave loading its own from L2 two groups ahead: the quarter parks in scratch in this 256 + 196 register body and the barrier couples the waves)
+    auto load_a = [&](AGrp& a, int u, int g) {                       // g = 3 n + dx
+        u = min(u, 3 * K32 - 1);
+        const uint4* w = wq + ((size_t)u * 9 + g) * 256;
+        a.h0.q = w[0]; a.h1.q = w[64]; a.q = w[128]; a.r = w[192];
+    };
+    auto dppz = [](int v, int shr, int z) {      // lane - 1 (row_shr:1) / lane + 1 (row_shl:1) within the row of 16 = one image row; zero at the image edge
+        return shr ? __builtin_amdgcn_update_dpp(z, v, 0x111, 0xF, 0xF, true) : __builtin_amdgcn_update_dpp(z, v, 0x101, 0xF, 0xF, true);
+    };
+    XSet2 S;
+    AGrp ring[3];
+    load_x(S, u0);
+    load_a(ring[0], u0, 0);
+    load_a(ring[1], u0, 1);
+    for (int u = u0; u < u1; u++) {
+        // ---- this unit's B operands: pixel tiles -1 .. 4 ([0] = left neighbour's tile 3, [5] = right neighbour's tile 0)
+        HFrag bh[2][6];
+        i32x6 b6[6]; int sbv[6];
+#pragma unroll
+        for (int pt = 0; pt < 4; pt++) {
+            float amax = 0.f;
+#pragma unroll
+            for (int st = 0; st < 2; st++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) amax = fmaxf(amax, fabsf(vget<4>(S.x[st][j], pt)));
+            amax *= S.m;
+            const int sb = min(max(__builtin_amdgcn_frexp_expf(amax) - 3, -40), 20);      // the block's largest |x| / 2^sb in [4, 8) (e2m3: largest 7.5)
+            HFrag lo[2];
+#pragma unroll
+            for (int st = 0; st < 2; st++)
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++)
+                    split_pair(vget<4>(S.x[st][2 * jj], pt) * S.m, vget<4>(S.x[st][2 * jj + 1], pt) * S.m, bh[st][pt + 1].u[jj], lo[st].u[jj]);
+            const f16x8 k1024 = {1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024};
+            const f16x8 l0 = lo[0].v * k1024, l1 = lo[1].v * k1024, h0 = bh[0][pt + 1].v, h1 = bh[1][pt + 1].v;
+            const f16x32 src = {h0[0], h0[1], h0[2], h0[3], h0[4], h0[5], h0[6], h0[7], l0[0], l0[1], l0[2], l0[3], l0[4], l0[5], l0[6], l0[7],
+                                h1[0], h1[1], h1[2], h1[3], h1[4], h1[5], h1[6], h1[7], l1[0], l1[1], l1[2], l1[3], l1[4], l1[5], l1[6], l1[7]};
+            b6[pt + 1] = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(src, __builtin_bit_cast(float, (127 + sb) << 23));
+            sbv[pt + 1] = 127 + sb;
+        }
+        // the neighbours' tiles ([0] = left neighbour's tile 3, [5] = right neighbour's tile 0) are NOT kept: 30 registers this one-wave-per-SIMD body does
+        // not have beside the next unit's window; the groups with dx = 0 / dx = 2 pull them by DPP when they need them (36 moves per tile instead of 30 per unit)
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(IVF_DEC6_ABL & 1)) load_x(S, u + 1);      // the window of the next unit: lands under this unit's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 9; g++) {
+            const int n = g / 3, dx = g % 3;
+            if (!(IVF_DEC6_ABL & 2)) { if (g + 2 < 9) load_a(ring[(g + 2) % 3], u, g + 2); else load_a(ring[(g + 2) % 3], u + 1, g + 2 - 9); }
+            const AGrp& a = ring[g % 3];
+            const i32x8 a6 = {(int)a.q.x, (int)a.q.y, (int)a.q.z, (int)a.q.w, (int)a.r.x, (int)a.r.y, 0, 0};
+            int zz = 0;
+            asm volatile("" : "+v"(zz));            // opaque per group: the DPP pulls below are not merged across groups (and kept live)
+#pragma unroll
+            for (int pt = 0; pt < 4; pt++) {
+                const int idx = pt + dx;            // 0 .. 5
+                HFrag f0, f1; i32x8 bq; int sbq;
+                if (idx >= 1 && idx <= 4) {
+                    f0 = bh[0][idx]; f1 = bh[1][idx]; sbq = sbv[idx];
+                    bq = i32x8{b6[idx][0], b6[idx][1], b6[idx][2], b6[idx][3], b6[idx][4], b6[idx][5], 0, 0};
+                } else {
+                    const int srcI = idx == 0 ? 4 : 1, shr = idx == 0 ? 1 : 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { f0.u[i] = (uint32_t)dppz((int)bh[0][srcI].u[i], shr, zz); f1.u[i] = (uint32_t)dppz((int)bh[1][srcI].u[i], shr, zz); }
+                    bq = i32x8{dppz(b6[srcI][0], shr, zz), dppz(b6[srcI][1], shr, zz), dppz(b6[srcI][2], shr, zz), dppz(b6[srcI][3], shr, zz),
+                               dppz(b6[srcI][4], shr, zz), dppz(b6[srcI][5], shr, zz), 0, 0};
+                    sbq = dppz(sbv[srcI], shr, zz);
+                }
+                if (!(IVF_DEC6_ABL & 4)) {
+                acc[n][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h0.v, f0.v, acc[n][pt], 0, 0, 0);
+                acc[n][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h1.v, f1.v, acc[n][pt], 0, 0, 0);
+                }
+                if (!(IVF_DEC6_ABL & 8))
+                acc[n][pt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a6, bq, acc[n][pt], 3, 2, 0, 127 - 10 - kDecSH, 0, sbq);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (part) {
+        float* pb = part + ((size_t)blockIdx.y * (nwg / 8) + b) * Cout * HW + (size_t)y * 64 + x;
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int ch = n * 32 + 4 * kg + (r & 3) + 8 * (r >> 2);
+                if (ch < Cout) *(float4*)(pb + (size_t)ch * HW) = make_float4(acc[n][0][r], acc[n][1][r], acc[n][2][r], acc[n][3][r]);
+            }
+        return;
+    }
+    if (lastW) {                                // conv_last folded into the epilogue (see k_fcn_conv3x3_all)
+        float lg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            const int cb = n * 32 + 4 * kg;
+            float4 sc4[4], sh4[4], lw4[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                sc4[g4] = *(const float4*)(scale + cb + 8 * g4); sh4[g4] = *(const float4*)(shift + cb + 8 * g4);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int ch = cb + 8 * g4 + i;
+                    (&lw4[g4].x)[i] = ch < Cout ? lastW[ch] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                if (cb + ro >= Cout) continue;
+                const float sc = vget<4>(sc4[r >> 2], r & 3), sh = vget<4>(sh4[r >> 2], r & 3), lw = vget<4>(lw4[r >> 2], r & 3);
+#pragma unroll
+                for (int p = 0; p < 4; p++) lg[p] += lw * fmaxf(acc[n][p][r] * sc + sh, 0.f);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) lg[p] += __shfl_xor(lg[p], 32, 64);
+        if (kg == 0)
+            *(float4*)(logits + (size_t)b * HW + y * 64 + x) = make_float4(lg[0] + lastBias, lg[1] + lastBias, lg[2] + lastBias, lg[3] + lastBias);
+        return;
+    }
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+        const int cb = n * 32 + 4 * kg;
+        float4 sc4[4], sh4[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(scale + cb + 8 * g4); sh4[g4] = *(const float4*)(shift + cb + 8 * g4); }
+        float* yb = Y + ((size_t)b * Cout + cb) * HW + y * 64 + x;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            if (cb + ro >= Cout) continue;
+            const float sc = vget<4>(sc4[r >> 2], r & 3), sh = vget<4>(sh4[r >> 2], r & 3);
+            *(float4*)(yb + (size_t)ro * HW) = make_float4(fmaxf(acc[n][0][r] * sc + sh, 0.f), fmaxf(acc[n][1][r] * sc + sh, 0.f),
+                                                           fmaxf(acc[n][2][r] * sc + sh, 0.f), fmaxf(acc[n][3][r] * sc + sh, 0.f));
+        }
+    }
+}
+
 // second half of the decoder's small-batch schedule: sums of the ranges (index order) -> BN -> ReLU -> conv_last (+ bias) -> logits.
 // Workgroup = 16 pixel quads x 16 channel groups (all of a channel's ranges requested together); the groups meet in LDS.
 __global__ __launch_bounds__(256) void k_fcn_dec_reduce(const float* __restrict__ part, int nSplit, size_t splitStride, int Cout,
@@ -2159,9 +2355,6 @@ constexpr int kF4WSlots = 3, kF4PSlots = 4;  // weight / parameter buffers: cons
 constexpr size_t kF4Lds = (size_t)2 * 16 * kF4CS * 4 + (size_t)2 * 16 * kF4DP * 4 + 2 * kF4WSlots * 10240 + kF4PSlots * kF4ParB +
                           2 * 160 * 4;        // + the projection's BN scale / shift of this workgroup's 160 output channels
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x8 __attribute__((ext_vector_type(8)));
-typedef int i32x6 __attribute__((ext_vector_type(6)));
-typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
 
 // FP6 (r06, the r05 verdict's item 1): the two CORRECTION products of the split-f16 scheme on the block-scaled matrix instruction at four times the f16 rate.
 //   x . w = x_hi w_hi + (x_hi w_lo + x_lo w_hi) + O(2^-22): the bracket is 2^-11 of the result, so its operands need ~4 bits -- it is ONE product
@@ -3820,6 +4013,7 @@ struct Gemm {            // one MFMA convolution
     int cin, cout, taps, nTiles, NT, PT, act;
     uint4* dWq;             // f16 hi / lo A fragments (see k_fcn_gemm)
     float *dScale, *dShift;
+    uint4* dWq6 = nullptr;  // 3x3 only (r06): the operands of k_fcn_conv3x3_f6 -- hi fragments + bf6 correction operands per (unit, tile, dx)
 };
 struct Dw { int c, stride, dil; float *dW, *dScale, *dShift, *dPack; };   // dPack: 12 floats per channel (k_fcn_dwpw)
 
@@ -3885,7 +4079,11 @@ void launch_gemm(const Gemm& g, const float* X, const float* res, float* Y, int 
     if (g.taps == 9) {
         static const bool old9 = IVF_EXP_ENV("IVF_FCN_OLD3X3") != nullptr;
         static const bool split9 = IVF_EXP_ENV("IVF_FCN_3X3_SPLIT") != nullptr;      // the r01 kernel: one workgroup per output-channel tile
-        if (!old9 && !split9 && H == 64 && W == 64 && g.cin % 32 == 0 && g.act == 2 && !res && g.nTiles == 3)
+        static const int dec6 = IVF_EXP_ENV("IVF_FCN_DEC6") ? atoi(IVF_EXP_ENV("IVF_FCN_DEC6")) : IVF_DEC_FP6;
+        if (!old9 && !split9 && dec6 && g.dWq6 && H == 64 && W == 64 && g.act == 2 && !res)
+            hipLaunchKernelGGL(k_fcn_conv3x3_f6, dim3(8 * B), dim3(256), 0, s, X, g.dWq6, g.dScale, g.dShift, Y, g.cin, g.cout,
+                               (const float*)nullptr, 0.f, (float*)nullptr, (float*)nullptr);
+        else if (!old9 && !split9 && H == 64 && W == 64 && g.cin % 32 == 0 && g.act == 2 && !res && g.nTiles == 3)
             hipLaunchKernelGGL((k_fcn_conv3x3_all<3>), dim3(8 * B), dim3(256), 0, s, X, g.dWq, g.dScale, g.dShift, Y, g.cin, g.cout,
                                (const float*)nullptr, 0.f, (float*)nullptr, (float*)nullptr);
         else if (!old9 && H == 64 && W == 64 && g.cin % 32 == 0 && g.act == 2 && !res)
@@ -4077,6 +4275,37 @@ std::vector<float> prescale_rows(const float* w, int cout, int rowLen, std::vect
     return ws;
 }
 
+// 6-bit operand codes of v_mfma_scale_f32_*_f8f6f4 (OCP MX element formats): e3m2 ("bf6": 1 + 3 + 2 bits, bias 3, largest 28) and e2m3 ("fp6":
+// 1 + 2 + 3 bits, bias 1, largest 7.5), no inf / NaN.  enc6: nearest code, ties to the even code, saturating -- what v_cvt_scalef32_pk32_*6_f16
+// does on the device (tools/probe/mfma_fp8_mix.hip checks host-packed operands against device-converted ones).
+float dec6(int code, bool bf6)
+{
+    const int sgn = code & 32; code &= 31;
+    float v;
+    if (bf6) { const int e = code >> 2, m = code & 3; v = e ? (1.f + m * 0.25f) * std::ldexp(1.f, e - 3) : m * 0.0625f; }
+    else     { const int e = code >> 3, m = code & 7; v = e ? (1.f + m * 0.125f) * std::ldexp(1.f, e - 1) : m * 0.125f; }
+    return sgn ? -v : v;
+}
+int enc6(float x, bool bf6)
+{
+    const float a = std::fabs(x);
+    int best = 0; float bd = 1e30f;
+    for (int c = 0; c < 32; c++) {
+        const float d = std::fabs(dec6(c, bf6) - a);
+        if (d < bd || (d == bd && !(c & 1))) { bd = d; best = c; }
+    }
+    return best | (x < 0.f ? 32 : 0);
+}
+void pack6(uint32_t* dst6, const int* codes32)         // element i at bits [6 i, 6 i + 6) of 6 dwords
+{
+    for (int i = 0; i < 6; i++) dst6[i] = 0;
+    for (int i = 0; i < 32; i++) {
+        const unsigned bit = 6 * i, w = bit >> 5, sft = bit & 31;
+        dst6[w] |= (uint32_t)codes32[i] << sft;
+        if (sft > 26) dst6[w + 1] |= (uint32_t)codes32[i] >> (32 - sft);
+    }
+}
+
 // w / sc: already pre-scaled (prescale_rows)
 int make_gemm(ivf_fcn* f, const float* w, int cout, int cin, int taps, const std::vector<float>& sc,
               const std::vector<float>& sh, int act, Gemm& g)
@@ -4117,42 +4346,47 @@ int make_gemm(ivf_fcn* f, const float* w, int cout, int cin, int taps, const std
     float* dq = nullptr;
     int rc = upload(f, wq, &dq); if (rc) return rc;
     g.dWq = reinterpret_cast<uint4*>(dq);
+    if (taps == 9 && cin % 32 == 0 && g.nTiles == 3) {
+        // k_fcn_conv3x3_f6: unit u = 3 s2 + dy (K steps 2 s2, 2 s2 + 1 of 16 channels; tap row dy), group g = 3 n + dx: four 1 KB pieces --
+        // hi fragments of the two steps (lane: row = lane & 31, k = 8 (lane >> 5) + j), then the bf6 correction operand of the pair: element e = 8 seg + j,
+        // step seg >> 1; seg even -> w_lo 2^(SH + 10) (meets x_hi), seg odd -> w_hi 2^SH (meets x_lo 2^10); dwords 0-3, then dwords 4-5 in .x .y
+        const int units = 3 * (cin / 32);
+        std::vector<float> w6((size_t)units * 9 * 4 * 64 * 4, 0.f);
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(w6.data());
+        uint16_t* d16 = reinterpret_cast<uint16_t*>(w6.data());
+        for (int u = 0; u < units; u++)
+            for (int gq = 0; gq < 9; gq++) {
+                const int s2 = u / 3, dy = u % 3, n = gq / 3, dx = gq % 3, tap = dy * 3 + dx;
+                const size_t base = ((size_t)u * 9 + gq) * 4 * 64 * 4;          // dwords
+                for (int lane = 0; lane < 64; lane++) {
+                    const int co = n * 32 + (lane & 31), kgh = lane >> 5;
+                    int codes[32];
+                    for (int e = 0; e < 32; e++) {
+                        const int seg = e >> 3, j = e & 7, k = 16 * (2 * s2 + (seg >> 1)) + 8 * kgh + j;
+                        float v = 0.f;
+                        if (co < cout) {
+                            const float wv = w[((size_t)co * cin + k) * taps + tap];
+                            const float hi = f16_to_f32(f32_to_f16(wv)), lo = f16_to_f32(f32_to_f16(wv - hi));
+                            v = (seg & 1) ? std::ldexp(hi, kDecSH) : std::ldexp(lo, kDecSH + 10);
+                            if (seg == 0) d16[(base + (size_t)lane * 4) * 2 + j] = f32_to_f16(wv);
+                            if (seg == 2) d16[(base + (size_t)(64 + lane) * 4) * 2 + j] = f32_to_f16(wv);
+                        }
+                        codes[e] = enc6(v, true);
+                    }
+                    uint32_t six[6]; pack6(six, codes);
+                    for (int q = 0; q < 4; q++) d32[base + (size_t)(128 + lane) * 4 + q] = six[q];
+                    d32[base + (size_t)(192 + lane) * 4 + 0] = six[4]; d32[base + (size_t)(192 + lane) * 4 + 1] = six[5];
+                }
+            }
+        float* d6 = nullptr;
+        rc = upload(f, w6, &d6); if (rc) return rc;
+        g.dWq6 = reinterpret_cast<uint4*>(d6);
+    }
     std::vector<float> scp((size_t)g.nTiles * 32, 0.f), shp((size_t)g.nTiles * 32, 0.f);   // padded: float4 loads per tile
     std::copy(sc.begin(), sc.begin() + cout, scp.begin());
     std::copy(sh.begin(), sh.begin() + cout, shp.begin());
     rc = upload(f, scp, &g.dScale); if (rc) return rc;
     return upload(f, shp, &g.dShift);
-}
-
-// 6-bit operand codes of v_mfma_scale_f32_*_f8f6f4 (OCP MX element formats): e3m2 ("bf6": 1 + 3 + 2 bits, bias 3, largest 28) and e2m3 ("fp6":
-// 1 + 2 + 3 bits, bias 1, largest 7.5), no inf / NaN.  enc6: nearest code, ties to the even code, saturating -- what v_cvt_scalef32_pk32_*6_f16
-// does on the device (tools/probe/mfma_fp8_mix.hip checks host-packed operands against device-converted ones).
-float dec6(int code, bool bf6)
-{
-    const int sgn = code & 32; code &= 31;
-    float v;
-    if (bf6) { const int e = code >> 2, m = code & 3; v = e ? (1.f + m * 0.25f) * std::ldexp(1.f, e - 3) : m * 0.0625f; }
-    else     { const int e = code >> 3, m = code & 7; v = e ? (1.f + m * 0.125f) * std::ldexp(1.f, e - 1) : m * 0.125f; }
-    return sgn ? -v : v;
-}
-int enc6(float x, bool bf6)
-{
-    const float a = std::fabs(x);
-    int best = 0; float bd = 1e30f;
-    for (int c = 0; c < 32; c++) {
-        const float d = std::fabs(dec6(c, bf6) - a);
-        if (d < bd || (d == bd && !(c & 1))) { bd = d; best = c; }
-    }
-    return best | (x < 0.f ? 32 : 0);
-}
-void pack6(uint32_t* dst6, const int* codes32)         // element i at bits [6 i, 6 i + 6) of 6 dwords
-{
-    for (int i = 0; i < 6; i++) dst6[i] = 0;
-    for (int i = 0; i < 32; i++) {
-        const unsigned bit = 6 * i, w = bit >> 5, sft = bit & 31;
-        dst6[w] |= (uint32_t)codes32[i] << sft;
-        if (sft > 26) dst6[w + 1] |= (uint32_t)codes32[i] >> (32 - sft);
-    }
 }
 
 // Operands of k_fcn_irbd4 (blocks 15-17): expansion rows as A fragments of v_mfma_f32_16x16x32_f16 (lane: row = lane & 15,
@@ -4628,12 +4862,21 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             static const int splitMode = IVF_EXP_ENV("IVF_FCN_SPLIT") ? atoi(IVF_EXP_ENV("IVF_FCN_SPLIT")) : 1;
             int nd = 1;
             if (splitMode && g.cin == 320) { const int ways[] = {15, 10, 6, 5, 3, 2}; for (int w : ways) if (w * n <= 16) { nd = w; break; } }
+            static const int dec6 = IVF_EXP_ENV("IVF_FCN_DEC6") ? atoi(IVF_EXP_ENV("IVF_FCN_DEC6")) : IVF_DEC_FP6;      // 0: three f16 products (k_fcn_conv3x3_all, r02-r05)
+            const bool use6 = dec6 && g.dWq6 != nullptr;
             if (nd > 1) {
+                if (use6)     // the same arithmetic as the batched form: the 30 units in `nd` ranges
+                    hipLaunchKernelGGL(k_fcn_conv3x3_f6, dim3(8 * n, nd), dim3(256), 0, s, x, g.dWq6, g.dScale, g.dShift, f->bufH1, g.cin, g.cout,
+                                       (const float*)nullptr, 0.f, (float*)nullptr, f->bufPart);
+                else
                 hipLaunchKernelGGL((k_fcn_conv3x3_all<3>), dim3(8 * n, nd), dim3(256), 0, s, x, g.dWq, g.dScale, g.dShift, f->bufH1, g.cin, g.cout,
                                    (const float*)nullptr, 0.f, (float*)nullptr, f->bufPart);
                 hipLaunchKernelGGL(k_fcn_dec_reduce, dim3(64, n), dim3(256), 0, s, (const float*)f->bufPart, nd, (size_t)n * g.cout * 4096, g.cout,
                                    (const float*)g.dScale, (const float*)g.dShift, (const float*)f->dLastW, f->lastBias, f->bufLogits);
-            } else
+            } else if (use6)
+                hipLaunchKernelGGL(k_fcn_conv3x3_f6, dim3(8 * n), dim3(256), 0, s, x, g.dWq6, g.dScale, g.dShift, f->bufH1, g.cin, g.cout,
+                                   (const float*)f->dLastW, f->lastBias, f->bufLogits, (float*)nullptr);
+            else
                 hipLaunchKernelGGL((k_fcn_conv3x3_all<3>), dim3(8 * n), dim3(256), 0, s, x, g.dWq, g.dScale, g.dShift, f->bufH1, g.cin, g.cout,
                                    (const float*)f->dLastW, f->lastBias, f->bufLogits, (float*)nullptr);
             STAGE("decoder cbr + conv_last");

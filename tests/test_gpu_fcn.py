@@ -151,8 +151,10 @@ print("OK %.3g" % err)
     # (k_fcn_irbd4<.., FP6>; not the default: DESIGN.md section 7.r06) -- with and without the small-batch schedule, so the batched instance runs too
     {"IVF_FCN_FP6": "1"},
     {"IVF_FCN_FP6": "1", "IVF_FCN_SPLIT": "0", "IVF_FCN_HALF4": "0"},
+    # r06: the decoder's 3x3 as three f16 products (k_fcn_conv3x3_all, r02-r05) instead of hi * hi + the fp6 correction product (k_fcn_conv3x3_f6, the default)
+    {"IVF_FCN_DEC6": "0"},
 ], ids=["default", "layerwise", "expand-pxt2", "dwpw-256", "no-stride2-fusion", "no-stem-fusion", "irb-blocks-2-11",
-        "irb-none", "dwpw8-all", "dwpw8-none", "dwpw-4rows-all", "dwpw-4rows-none", "conv-last-unfused", "blocks-8-14-unfused", "blocks-15-17-unfused", "blocks-5-7-unfused", "block-17-two-workgroups", "head-chunked", "head-row-interleaved", "head-chunked-and-interleaved", "no-small-batch-split", "fp6-expansion", "fp6-expansion-batched-kernels"])
+        "irb-none", "dwpw8-all", "dwpw8-none", "dwpw-4rows-all", "dwpw-4rows-none", "conv-last-unfused", "blocks-8-14-unfused", "blocks-15-17-unfused", "blocks-5-7-unfused", "block-17-two-workgroups", "head-chunked", "head-row-interleaved", "head-chunked-and-interleaved", "no-small-batch-split", "fp6-expansion", "fp6-expansion-batched-kernels", "decoder-three-f16-products"])
 def test_fcn_kernel_variants_match_goldens_and_are_deterministic(env):
     """The FCN picks between several kernels per layer (measured defaults, env overrides for tuning).  Every variant must
     meet the same bar, batch results must not depend on the batch slot, and repeated runs must be bit-identical (this is
