@@ -200,10 +200,13 @@ def test_fcn_small_batch_schedule_agrees_with_the_batched_one(iv):
         if ref is None:
             ref = c[0]
             assert FC.check_against_golden(g, ref, cu[0].cpu().numpy(), tol=1e-3) < 3e-4
+        # r06: 2e-5 -> 5e-5.  The decoder's correction product quantises block 17's output to 6-bit operands with a scale per (pixel, 16 channels) taken from
+        # the data: where two schedules' activations differ in the last bit (summation order of the split ranges), a code can fall the other way -- a step of
+        # 2^-4 of a term that is 2^-11 of the sum.  Measured 3.3e-5 (batch 8 vs 128; 1.1e-5 with three f16 products); each schedule stays within 3e-4 of the golden
         d = float(np.abs(c[0] - ref).max())
-        assert d < 2e-5, "batch %d vs batch 128: %.3g" % (nb, d)
+        assert d < 5e-5, "batch %d vs batch 128: %.3g" % (nb, d)
     d1 = float(np.abs(c1 - ref).max())
-    assert d1 < 2e-5, "batch 1 vs batch 128: %.3g" % d1
+    assert d1 < 5e-5, "batch 1 vs batch 128: %.3g" % d1
     du = np.abs(u8_1.astype(int) - (ref * np.float32(255.0)).astype(np.uint8).astype(int))
     assert du.max() <= 1 and (du != 0).mean() < 0.01
 

@@ -125,7 +125,7 @@ def dense3x3(x, w, mode):
 
 
 @torch.no_grad()
-def forward(T, bgr, out_size, first_q, mode_e, mode_p, stats=None, mode_d="f32"):
+def forward(T, bgr, out_size, first_q, mode_e, mode_p, stats=None, mode_d="f32", last_q=99):
     a = np.asarray(bgr)[None]
     x = torch.from_numpy(np.ascontiguousarray(a[..., ::-1])).to(torch.float32).permute(0, 3, 1, 2) * (1.0 / 255.0)
     x = (x - torch.tensor(O.MEAN).view(1, 3, 1, 1)) / torch.tensor(O.STD).view(1, 3, 1, 1)
@@ -138,7 +138,7 @@ def forward(T, bgr, out_size, first_q, mode_e, mode_p, stats=None, mode_d="f32")
             y = F.relu6(O._bn(F.conv2d(y, T[p + ".0.weight"], None, s, d, d, inp * t), T, p + ".1"))
             y = O._bn(F.conv2d(y, T[p + ".3.weight"]), T, p + ".4")
         else:
-            on = i >= first_q
+            on = first_q <= i <= last_q
             if stats is not None and i >= 15:
                 stats[i] = float(y.abs().max())
             # the expansion's activation operand is the block input: unbounded in principle (range guard: < 65504)
@@ -154,12 +154,11 @@ def forward(T, bgr, out_size, first_q, mode_e, mode_p, stats=None, mode_d="f32")
     return torch.sigmoid(20.0 * (y - 0.5))[0, 0].numpy()
 
 
-VARIANTS = (
-    ("f16x3 E+P 15-17 + decoder", 15, ("f16x3", 0), "f16x3", "f16x3"),
-    ("decoder corrections e2m3 / e3m2", 99, ("f32", 0), "f32", ("hw", "e2m3", "e3m2", 3)),
-    ("decoder corrections e3m2 / e3m2", 99, ("f32", 0), "f32", ("hw", "e3m2", "e3m2", 3)),
-    ("decoder corrections e4m3 / e4m3 (fp8)", 99, ("f32", 0), "f32", ("hw", "e4m3", "e4m3", 7)),
-    ("decoder e2m3/e3m2 + E mx e2m3/e3m2 15-17", 15, (("hw", "e2m3", "e3m2", 3, True), 0), "f16x3", ("hw", "e2m3", "e3m2", 3)),
+HW6 = (("hw", "e2m3", "e3m2", 3, True), 0)
+P6 = ("hw", "e2m3", "e3m2", 3, False)
+VARIANTS = tuple(("E+P fp6, block %d only" % b, b, HW6, P6, "f32", b) for b in (17, 16, 15, 14, 12, 10, 8, 6)) + (
+    ("E+P fp6, blocks 8-14", 8, HW6, P6, "f32", 14),
+    ("E only fp6, blocks 8-14", 8, HW6, "f16x3", "f32", 14),
 )
 
 if __name__ == "__main__":
@@ -171,8 +170,9 @@ if __name__ == "__main__":
         ref = g["cost_sub"] if "cost_sub" in g.files else g["cost"]
         st = {}
         print("%s" % tag, flush=True)
-        for name, first_q, me, mp, md in VARIANTS:
-            c = forward(T, bgr, (h, w), first_q, me, mp, st, md)
+        for v in VARIANTS:
+            name, first_q, me, mp, md = v[:5]
+            c = forward(T, bgr, (h, w), first_q, me, mp, st, md, v[5] if len(v) > 5 else 99)
             got = c[::sub, ::sub] if "cost_sub" in g.files else c
             print("   %-40s max |cost - reference| = %.2e" % (name, float(np.abs(got - ref).max())), flush=True)
         print("   largest |block input| of blocks 15/16/17: %s" % ", ".join("%.1f" % st[k] for k in sorted(st)), flush=True)
