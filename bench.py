@@ -494,8 +494,9 @@ def h2d_included(torch, iv, fe, fcn, dev, P, n_batches, left, right, bgr, cost, 
                 main.wait_event(ready2[k % sets])
             main.wait_event(ready[k % sets])
             if fcn is not None:
-                fcn.forward_device(st["b"], cost_u8=cost, stream_ptr=main.cuda_stream)
-                fe.run_color(st["b"], st["r"], cost, main.cuda_stream)
+                plane = fe.cost_plane(P, main.cuda_stream)              # the FCN writes its maps into the front end's own cost plane: no ingest copy
+                fcn.forward_device(st["b"], cost_u8=plane, stream_ptr=main.cuda_stream)
+                fe.run_color(st["b"], st["r"], plane, main.cuda_stream)
             else:
                 fe.run(st["l"], st["r"], None, main.cuda_stream)
             free[k % sets].record(main)                    # fe.run made `main` wait until the inputs were ingested
@@ -539,6 +540,8 @@ def main():
     ap.add_argument("--no-track", action="store_true", help="leave the batched tracker step (pack of the result records + SearchByProjection(cur, last) "
                     "for every consecutive frame pair, ivf_tracker_run) out of the timed step.  By default it runs inside it at EVERY rank count, "
                     "so that the 1/2/4/8-GPU lines time the same work per frame (with ranks > 1 it consumes the all-gathered records)")
+    ap.add_argument("--no-cost-plane", action="store_true", help="A/B aid: the FCN writes its cost maps into a buffer of the caller and ivf_frontend_run ingests them (a copy "
+                    "into the pitched plane, the r01-r05 path) instead of writing them into the front end's plane itself (r06 default)")
     ap.add_argument("--no-carry", action="store_true", help="A/B aid: leave out the frame pair at every batch boundary (the r04 behaviour: world * P - 1 "
                     "pairs per launch sequence).  Default: the last record of a batch is carried into the next batch's buffer and tracked (r05)")
     ap.add_argument("--serial", action="store_true", help="profiling aid: wait for each batch before enqueuing the next, so "
@@ -673,12 +676,22 @@ def main():
             with torch.cuda.stream(bs):
                 dist.all_gather_into_tensor(gathered3[k % 3][:NG], blocks3[k % 3])
 
+    cost_plane_mode = fcn is not None and not args.no_cost_plane
+    last_plane = [None]
+
     def sub_batch(i):
         s = (i % nslices) * P
         k = nsub[0]; nsub[0] += 1
-        if fcn is not None:
-            fcn.forward_device(bgr[s:s + P], cost_u8=cost, stream_ptr=sptr)
-        fe.run(left[s:s + P], right[s:s + P], cost, sptr)
+        if fcn is not None and cost_plane_mode:
+            # r06: the FCN writes its u8 maps straight into the level-0 cost plane of the batch context this run uses; the run skips their ingest
+            plane = fe.cost_plane(P, sptr)
+            last_plane[0] = plane
+            fcn.forward_device(bgr[s:s + P], cost_u8=plane, stream_ptr=sptr)
+            fe.run_color(left[s:s + P], right[s:s + P], plane, sptr)
+        else:
+            if fcn is not None:
+                fcn.forward_device(bgr[s:s + P], cost_u8=cost, stream_ptr=sptr)
+            fe.run(left[s:s + P], right[s:s + P], cost, sptr)
         if exchange or track:
             # the path's one exchange step: all-gather of {n, kps, desc, uRight, depth} for cross-frame matching ...
             bs = torch.cuda.ExternalStream(fe.batch_stream(0), device=dev)
@@ -745,6 +758,8 @@ def main():
     # are copied out now, before anything else runs, and compared with the oracle below (never inside the timed region)
     s_last = ((nsub[0] - 1) % nslices) * P
     spot_pairs = sorted({0, 1, P // 2, P - 1})
+    if last_plane[0] is not None:
+        cost.copy_(last_plane[0])                  # the maps that gated the last sub-batch, out of the context's plane (after the timed region)
     spot = [dict(pair=p, L=left[s_last + p].cpu().numpy(), R=right[s_last + p].cpu().numpy(),
                  cost=cost[p].cpu().numpy() if fcn is not None else None, l=fe.fetch(p, 0), r=fe.fetch(p, 1)) for p in spot_pairs]
     exch = None
@@ -1011,6 +1026,8 @@ def main():
                        "parallelism": "frames sharded %d-way, RCCL all-gather of descriptor blocks" % world if world > 1 else "1 GPU"},
             "timed_region_s": round(dt, 3),
             "track_in_timed_region": bool(track and len(tpairs_h)),
+            "cost_maps": ("written by the FCN into the front end's level-0 cost plane (ivf_frontend_cost_plane): no ingest copy" if cost_plane_mode else
+                          "FCN -> caller's buffer -> ingest copy" if fcn is not None else None),
             "build": {"libivfront": iv.load().ivf_build_id().decode(), "sources": iv._lib.source_build_id()},
             "roofline": roofline,
             "parity_spot_check": parity,

@@ -237,6 +237,13 @@ int  ivf_frontend_run(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_
 int  ivf_frontend_run_color(ivf_frontend* fe, const uint8_t* d_left, int left_code, size_t left_image_stride, int left_row_stride,
                             const uint8_t* d_right, int right_code, size_t right_image_stride, int right_row_stride,
                             const uint8_t* d_cost, size_t cost_image_stride, int cost_row_stride, int n_pairs, void* hip_stream);
+/* Cost maps without a copy (r06).  ivf_frontend_run ingests the cost maps like the images: a copy into the pitched level-0 plane of the batch context
+ * (the reference has no such step: extractor and FCN share one cv::Mat, stereo_kitti.cc:508-521 -> Tracking.cc).  A producer on the device -- the FCN --
+ * can write there directly: ivf_frontend_cost_plane returns the plane of the context the NEXT ivf_frontend_run / _run_color of this handle will use
+ * (pair i's map at d_plane + i * image_stride, rows of row_stride bytes, only the first `width` bytes of a row may be written) and makes hip_stream wait
+ * until that context's previous batch is done with it; pass exactly this pointer and these strides as d_cost / cost strides to ivf_frontend_run_color
+ * and the ingest of the cost maps is skipped.  ivf_fcn_forward_device_strided writes such a plane. */
+int  ivf_frontend_cost_plane(ivf_frontend* fe, uint8_t** d_plane, size_t* image_stride, int* row_stride, void* hip_stream);
 /* Block until every ivf_frontend_run on this handle has finished (and, the internal streams being shared per device, whatever other front ends of
  * the process have enqueued on that device so far); reports device-side consistency errors. */
 int  ivf_frontend_sync(ivf_frontend* fe);
@@ -383,6 +390,10 @@ int  ivf_fcn_forward(ivf_fcn* f, const uint8_t* bgr, int width, int height, int 
  * bytes); d_cost_u8 [n][out_h][out_w] and/or d_cost_f32 [n][out_h][out_w]; asynchronous on hip_stream. */
 int  ivf_fcn_forward_device(ivf_fcn* f, const uint8_t* d_bgr, size_t image_stride, int row_stride, int n,
                             uint8_t* d_cost_u8, float* d_cost_f32, void* hip_stream);
+/* the same with the u8 maps written through the caller's strides (r06): map i at d_cost_u8 + i * cost_image_stride, rows of cost_row_stride bytes
+ * (>= out_width), e.g. the front end's own cost plane (ivf_frontend_cost_plane above) */
+int  ivf_fcn_forward_device_strided(ivf_fcn* f, const uint8_t* d_bgr, size_t image_stride, int row_stride, int n,
+                                    uint8_t* d_cost_u8, size_t cost_image_stride, int cost_row_stride, void* hip_stream);
 /* Device-side flags of the handle (r05).  The convolutions run as split-f16 MFMA products (x = hi + lo in f16), exact to 22 bits
  * while |x| < 65504.  Weights are pre-scaled per output channel and every hidden tensor is bounded by ReLU6 (mobilenet.py:44-62); the
  * linear-bottleneck outputs are not, so the kernels that store them raise a flag when one reaches 65504 (libtorch's f32 convs,

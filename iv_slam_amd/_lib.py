@@ -125,6 +125,8 @@ _SIGS = {
     "ivf_frontend_create": (C.c_int, [C.POINTER(FrontendConfig), C.POINTER(vp)]),
     "ivf_frontend_destroy": (None, [vp]),
     "ivf_frontend_run": (C.c_int, [vp, vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]),
+    "ivf_frontend_cost_plane": (C.c_int, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int), vp]),
+    "ivf_fcn_forward_device_strided": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, C.c_size_t, C.c_int, vp]),
     "ivf_frontend_run_color": (C.c_int, [vp, vp, C.c_int, C.c_size_t, C.c_int, vp, C.c_int, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_int, C.c_int, vp]),
     "ivf_frontend_sync": (C.c_int, [vp]),
     "ivf_frontend_device_results": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
@@ -230,3 +232,15 @@ def check(rc):
 
 def ptr(a):
     return a.ctypes.data_as(vp) if a is not None else None
+
+
+class _DeviceArray:
+    """a raw device pointer with shape / byte strides, as the CUDA array interface torch.as_tensor understands"""
+    def __init__(self, ptr, shape, strides):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "strides": tuple(strides), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
+
+
+def device_view_u8(ptr, shape, strides, device_id=0):
+    """torch u8 view (no copy, no ownership) of device memory the library owns -- e.g. the front end's cost plane (ivf_frontend_cost_plane)"""
+    import torch
+    return torch.as_tensor(_DeviceArray(ptr, shape, strides), device=torch.device("cuda", device_id))

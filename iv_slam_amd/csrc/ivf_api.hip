@@ -340,7 +340,9 @@ int Context::run(const uint8_t* s0, const uint8_t* s1, const uint8_t* cost, size
         sideSrc[0] = SideSrc(); sideSrc[1] = SideSrc();
     } else
     launch_ingest(hc, dc, b, s0, s1, imageStride, rowStride, nImg, nSides, b.pyr, st);
-    if (cost) launch_ingest(hc, dc, b, cost, cost, costStride, costRowStride, nImg, nSides, b.qpyr, st);
+    // r06: a cost map that already sits in the level-0 cost plane (ivf_frontend_cost_plane: the FCN wrote it there) needs no copy
+    const bool costInPlace = cost && b.qpyr && cost == b.qpyr + hc.lv[0].off && costStride == (size_t)nSides * hc.pyrBytes && costRowStride == hc.lv[0].pitch;
+    if (cost && !costInPlace) launch_ingest(hc, dc, b, cost, cost, costStride, costRowStride, nImg, nSides, b.qpyr, st);
     if (inputsConsumed) HIPCHK(hipEventRecord(inputsConsumed, st));   // caller buffers are free from here on
     IVF_MARK(st, markOwn, 1, nRuns);
     launch_pyramid(hc, dc, dTab, b.pyr, useQ ? b.qpyr : nullptr, b.useCost, nImg, st);   // + ComputeQualityImagePyramid :1325-1357
@@ -2154,6 +2156,25 @@ int ivf_frontend_run(ivf_frontend* fe, const uint8_t* d_left, const uint8_t* d_r
     if (row_stride < fe->cfg.width || image_stride < (size_t)row_stride * (fe->cfg.height - 1) + fe->cfg.width)
         return fail(IVF_E_INVALID, "strides too small for %dx%d", fe->cfg.width, fe->cfg.height);
     return frontend_run_common(fe, d_left, d_right, d_cost, image_stride, row_stride, n_pairs, hip_stream, nullptr);
+}
+
+int ivf_frontend_cost_plane(ivf_frontend* fe, uint8_t** d_plane, size_t* image_stride, int* row_stride, void* hip_stream)
+{
+    if (!fe || !d_plane || !image_stride || !row_stride) return fail(IVF_E_INVALID, "null argument");
+    const int k = (int)(fe->runs % kPipe);
+    Context& c = fe->ctx[k];
+    HIPCHK(hipSetDevice(fe->cfg.device_id));
+    if (!c.b.qpyr) {            // extractors that ignore the map (enableIntrospection = 0) allocate the plane on first use
+        const size_t blob = (size_t)c.hc.pyrBytes * c.maxImg;
+        HIPCHK(hipMalloc(&c.b.qpyr, blob));
+        HIPCHK(hipMemset(c.b.qpyr, 0, blob));
+    }
+    // the context's previous batch (three runs ago) read this plane: the caller's stream may write it once that batch is done
+    if (fe->runs >= kPipe) HIPCHK(hipStreamWaitEvent((hipStream_t)hip_stream, fe->evDone[k], 0));
+    *d_plane = c.b.qpyr + c.hc.lv[0].off;
+    *image_stride = (size_t)2 * c.hc.pyrBytes;
+    *row_stride = c.hc.lv[0].pitch;
+    return IVF_OK;
 }
 
 int ivf_frontend_run_color(ivf_frontend* fe, const uint8_t* d_left, int left_code, size_t left_image_stride, int left_row_stride,

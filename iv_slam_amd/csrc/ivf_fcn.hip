@@ -3927,7 +3927,8 @@ __global__ void k_fcn_last(const float* __restrict__ X, const float* __restrict_
 #endif
 constexpr int kOutRows = IVF_OUT_ROWS;        // output rows per workgroup of k_fcn_out
 __global__ __launch_bounds__(256) void k_fcn_out(const float* __restrict__ L, int lh, int lw, int oh, int ow, float sy_, float sx_,
-                                                float* __restrict__ costF, uint8_t* __restrict__ costU, int* __restrict__ status, int rowsPerWg)
+                                                float* __restrict__ costF, uint8_t* __restrict__ costU, int* __restrict__ status, int rowsPerWg,
+                                                size_t uImageStride, int uRowStride)       // the u8 map's strides (r06: it may be a pitched plane of the front end)
 {
     // the last kernel of a forward: every earlier kernel of it has finished (stream order), so one thread moves the f16 range flag
     // they may have raised into the handle's status word
@@ -3987,8 +3988,9 @@ __global__ __launch_bounds__(256) void k_fcn_out(const float* __restrict__ L, in
         if (costU) {
             const unsigned u0 = (unsigned)(uint8_t)(c[0] * 255.0f), u1 = (unsigned)(uint8_t)(c[1] * 255.0f),
                            u2 = (unsigned)(uint8_t)(c[2] * 255.0f), u3 = (unsigned)(uint8_t)(c[3] * 255.0f);
-            if (nv == 4 && (o & 3) == 0) *(unsigned*)(costU + o) = u0 | (u1 << 8) | (u2 << 16) | (u3 << 24);
-            else { const unsigned u[4] = {u0, u1, u2, u3}; for (int k = 0; k < nv; k++) costU[o + k] = (uint8_t)u[k]; }
+            const size_t ou = (size_t)b * uImageStride + (size_t)y * uRowStride + x4;
+            if (nv == 4 && (ou & 3) == 0) *(unsigned*)(costU + ou) = u0 | (u1 << 8) | (u2 << 16) | (u3 << 24);
+            else { const unsigned u[4] = {u0, u1, u2, u3}; for (int k = 0; k < nv; k++) costU[ou + k] = (uint8_t)u[k]; }
         }
     }
 }
@@ -4544,8 +4546,9 @@ void launch_split_reduce(ivf_fcn* f, int ns, int n, int cout, const Gemm& pj, co
                     if (e_ != hipSuccess) return ffail(IVF_E_NO_DEVICE, "stage %s: %s", name, hipGetErrorString(e_)); } } while (0)
 
 int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowStride, int n, uint8_t* dU8, float* dF,
-                   hipStream_t s)
+                   hipStream_t s, size_t uImageStride = 0, int uRowStride = 0)
 {
+    if (!uRowStride) { uRowStride = f->outW; uImageStride = (size_t)f->outW * f->outH; }
     static const bool dbg = getenv("IVF_FCN_DEBUG") != nullptr;
     char nm[64];
     // r05: the 512^2 / 256^2 / 128^2 stage (prep, stem, blocks 2-4) runs in CHUNKS of images, back to back per chunk: a chunk's tensors
@@ -4890,7 +4893,7 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
     }
     const int outRows = n >= 4 ? kOutRows : 2;
     hipLaunchKernelGGL(k_fcn_out, dim3((f->outW + 1023) / 1024, (f->outH + outRows - 1) / outRows, n), dim3(256), 0, s, f->bufLogits, H, W, f->outH, f->outW,
-                       (float)H / (float)f->outH, (float)W / (float)f->outW, dF, dU8, f->dStatus, outRows);
+                       (float)H / (float)f->outH, (float)W / (float)f->outW, dF, dU8, f->dStatus, outRows, uImageStride, uRowStride);
     FHIP(hipGetLastError());
     return IVF_OK;
 }
@@ -5189,6 +5192,24 @@ int ivf_fcn_forward_device(ivf_fcn* f, const uint8_t* d_bgr, size_t image_stride
         const int nb = std::min(sub, n - i0);
         const int rc = forward_device(f, d_bgr + (size_t)i0 * image_stride, image_stride, row_stride, nb, d_cost_u8 ? d_cost_u8 + (size_t)i0 * outPx : nullptr,
                                       d_cost_f32 ? d_cost_f32 + (size_t)i0 * outPx : nullptr, (hipStream_t)hip_stream);
+        if (rc) return rc;
+    }
+    return IVF_OK;
+}
+
+int ivf_fcn_forward_device_strided(ivf_fcn* f, const uint8_t* d_bgr, size_t image_stride, int row_stride, int n,
+                                   uint8_t* d_cost_u8, size_t cost_image_stride, int cost_row_stride, void* hip_stream)
+{
+    if (!f || !d_bgr || !d_cost_u8) return ffail(IVF_E_INVALID, "null argument");
+    if (n < 1 || n > f->maxBatch) return ffail(IVF_E_INVALID, "batch %d outside [1,%d]", n, f->maxBatch);
+    if (row_stride < 3 * f->inW) return ffail(IVF_E_INVALID, "row_stride too small");
+    if (cost_row_stride < f->outW || cost_image_stride < (size_t)cost_row_stride * (f->outH - 1) + f->outW) return ffail(IVF_E_INVALID, "cost strides too small for %dx%d", f->outW, f->outH);
+    FHIP(hipSetDevice(f->device));
+    static const int sub = IVF_EXP_ENV("IVF_FCN_SUBBATCH") ? std::max(1, atoi(IVF_EXP_ENV("IVF_FCN_SUBBATCH"))) : kSubBatch;
+    for (int i0 = 0; i0 < n; i0 += sub) {
+        const int nb = std::min(sub, n - i0);
+        const int rc = forward_device(f, d_bgr + (size_t)i0 * image_stride, image_stride, row_stride, nb, d_cost_u8 + (size_t)i0 * cost_image_stride, nullptr,
+                                      (hipStream_t)hip_stream, cost_image_stride, cost_row_stride);
         if (rc) return rc;
     }
     return IVF_OK;

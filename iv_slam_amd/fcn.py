@@ -42,6 +42,12 @@ class IntrospectionFCN:
         assert tuple(bgr.shape[1:]) == (self.in_h, self.in_w, 3)
         st = bgr.stride()
         assert st[3] == 1 and st[2] == 3, "interleaved BGR pixels; rows and images may be padded (a view of a larger tensor)"
+        if cost_u8 is not None and not cost_u8.is_contiguous():
+            # a padded view, e.g. the front end's own cost plane (StereoFrontend.cost_plane): the maps are written through its strides
+            cs = cost_u8.stride()
+            assert cost_f32 is None and cs[2] == 1 and tuple(cost_u8.shape) == (n, self.out_h, self.out_w)
+            check(self._lib.ivf_fcn_forward_device_strided(self._h, bgr.data_ptr(), st[0], st[1], n, cost_u8.data_ptr(), cs[0], cs[1], stream_ptr))
+            return
         check(self._lib.ivf_fcn_forward_device(self._h, bgr.data_ptr(), st[0], st[1], n,
                                                None if cost_u8 is None else cost_u8.data_ptr(),
                                                None if cost_f32 is None else cost_f32.data_ptr(), stream_ptr))

@@ -73,6 +73,21 @@ class StereoFrontend:
         check(self._lib.ivf_frontend_run_color(self._h, lp, lc, li, lr, rp, rc, ri, rr, cp, ci, cr, n, stream_ptr))
         self._n = n
 
+    def cost_plane(self, n, stream_ptr=None):
+        """The pitched level-0 cost plane of the batch context the NEXT run uses, as a torch u8 view [n, height, width] (rows / images padded): a producer on
+        the device (IntrospectionFCN.forward_device(..., cost_u8=view)) writes the maps there and run_color(..., cost=view) skips their ingest.
+        `stream_ptr` waits until that context's previous batch is done with the plane."""
+        import torch
+        p = C.c_void_p(); ist = C.c_size_t(); rst = C.c_int()
+        check(self._lib.ivf_frontend_cost_plane(self._h, C.byref(p), C.byref(ist), C.byref(rst), stream_ptr))
+        key = (p.value, n)
+        if getattr(self, "_plane_views", None) is None:
+            self._plane_views = {}
+        if key not in self._plane_views:
+            from ._lib import device_view_u8
+            self._plane_views[key] = device_view_u8(p.value, (n, self.height, self.width), (ist.value, rst.value, 1), self.device_id)
+        return self._plane_views[key]
+
     def set_opencv_variant(self, blur=0, retain_best=0, atan2=0):
         check(self._lib.ivf_frontend_set_opencv_variant(self._h, int(blur), int(retain_best), int(atan2)))
 

@@ -789,6 +789,45 @@ def kitti_to_gray(img, rgb, cv3):
     return kitti.to_gray(img, rgb, cv3)
 
 
+def test_cost_maps_written_into_the_front_ends_plane_skip_the_ingest(iv):
+    """r06: ivf_frontend_cost_plane + ivf_fcn_forward_device_strided -- the FCN writes its u8 cost maps into the pitched level-0 cost plane of the batch
+    context the next run uses, and the run skips their ingest.  Five runs through the three contexts (every plane is reused) give exactly the results of the
+    plain path (FCN -> contiguous buffer -> ivf_frontend_run ingests it) on the same inputs, and equal the oracle chain on the FCN's map."""
+    import torch
+    from iv_slam_amd import fcn_weights
+    w, h, n, pairs = 640, 240, 400, 3
+    dev = torch.device("cuda:0")
+    fcn = iv.IntrospectionFCN(fcn_weights.pack_blob(fcn_weights.make_seeded_weights(11)), (h, w), (h, w), max_batch=pairs)
+    fe = iv.StereoFrontend(w, h, pairs, nfeatures=n, enableIntrospection=True, bf=BF, b=B)
+    ref_fe = iv.StereoFrontend(w, h, pairs, nfeatures=n, enableIntrospection=True, bf=BF, b=B)
+    st = torch.cuda.current_stream(dev)
+    for it in range(5):
+        stream = synth.make_stream(pairs, w, h, seed=200 + it)
+        L = torch.from_numpy(stream[:, 0].copy()).to(dev); R = torch.from_numpy(stream[:, 1].copy()).to(dev)
+        bgr = torch.stack([L, L // 2 + 40, 255 - L // 2], dim=-1).contiguous()
+        plane = fe.cost_plane(pairs, st.cuda_stream)
+        assert not plane.is_contiguous() and tuple(plane.shape) == (pairs, h, w)
+        fcn.forward_device(bgr, cost_u8=plane, stream_ptr=st.cuda_stream)
+        fe.run_color(L, R, plane, st.cuda_stream)
+        cost = torch.empty((pairs, h, w), dtype=torch.uint8, device=dev)
+        fcn.forward_device(bgr, cost_u8=cost, stream_ptr=st.cuda_stream)
+        ref_fe.run(L, R, cost, st.cuda_stream)
+        fe.sync(); ref_fe.sync(); torch.cuda.synchronize()
+        assert torch.equal(plane, cost)                                   # the same map, through the strides
+        for p in range(pairs):
+            for side in (0, 1):
+                a = fe.fetch(p, side); b_ = ref_fe.fetch(p, side)
+                assert_kps_equal(a["kps"], b_["kps"], "run %d pair %d side %d" % (it, p, side))
+                assert np.array_equal(a["desc"], b_["desc"]) and np.array_equal(a["quality"], b_["quality"])
+            assert fe.fetch(p, 0)["uright"].tobytes() == ref_fe.fetch(p, 0)["uright"].tobytes()
+        if it == 4:
+            hc = cost.cpu().numpy()
+            okL, odL = O.Extractor(n, 1.2, 8, 20, 7, introspection=True)(stream[1, 0], hc[1])
+            r = fe.fetch(1, 0)
+            assert_kps_equal(r["kps"], okL, "vs oracle"); assert np.array_equal(r["desc"], odL)
+            assert len(okL) > 100
+
+
 def test_two_front_ends_from_two_host_threads(iv):
     """two independent handles driven concurrently from two host threads (a two-camera rig): same results as one after the
     other (per-thread scratch, no shared mutable state in the library; r05: both handles enqueue on the SAME three pooled internal streams)"""
