@@ -1849,7 +1849,7 @@ void orc_remap_bilinear_u8(const uint8_t* src, int sw, int sh, int sstride, int 
 }
 
 
-/* A-12  cv::cvtColor(src, dst, CV_BGR2GRAY / CV_RGB2GRAY) on 8UC3 (ORB/src/Tracking.cc:272-295: GrabImageStereo converts mImGray by mbRGB).
+/* A-13  cv::cvtColor(src, dst, CV_BGR2GRAY / CV_RGB2GRAY) on 8UC3 (ORB/src/Tracking.cc:272-295: GrabImageStereo converts mImGray by mbRGB).
  * "parity unpinned" like A-1 .. A-11: restated from OpenCV's published RGB2Gray<uchar>.  Fixed point:
  *   OpenCV 4.x  (color.hpp: gray_shift = 15, RY15 = 9798, GY15 = 19235, BY15 = 3735):  (R*9798 + G*19235 + B*3735 + (1 << 14)) >> 15
  *   OpenCV <= 3.x (yuv_shift = 14, R2Y = 4899, G2Y = 9617, B2Y = 1868):                (R*4899 + G*9617  + B*1868 + (1 << 13)) >> 14

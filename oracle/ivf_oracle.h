@@ -184,7 +184,7 @@ void  orc_remap_bilinear_u8(const uint8_t* src, int sw, int sh, int sstride, int
                             int w, int h, uint8_t* dst, int dstride);
 /* the 1024 x 4 fixed-point bilinear table exactly as OpenCV's initInterTab2D leaves it (A-10) */
 void  orc_remap_weight_table(int16_t* tab4096);
-/* cv::cvtColor 8UC3 -> 8UC1 (Tracking.cc:272-295): rgb 0 = CV_BGR2GRAY, 1 = CV_RGB2GRAY; cv3 0 = OpenCV 4.x's 15-bit coefficients, 1 = <= 3.x's 14-bit (A-12) */
+/* cv::cvtColor 8UC3 -> 8UC1 (Tracking.cc:272-295): rgb 0 = CV_BGR2GRAY, 1 = CV_RGB2GRAY; cv3 0 = OpenCV 4.x's 15-bit coefficients, 1 = <= 3.x's 14-bit (A-13) */
 void  orc_gray_from_color(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride, int rgb, int cv3);
 
 #ifdef __cplusplus

@@ -464,7 +464,7 @@ def remap_weight_table():
 
 
 def gray_from_color(img, rgb, cv3=False):
-    """cvtColor(img, CV_RGB2GRAY if rgb else CV_BGR2GRAY) on an [H, W, 3] u8 image (Tracking.cc:272-295; A-12)"""
+    """cvtColor(img, CV_RGB2GRAY if rgb else CV_BGR2GRAY) on an [H, W, 3] u8 image (Tracking.cc:272-295; A-13)"""
     img = np.ascontiguousarray(img, np.uint8)
     out = np.empty(img.shape[:2], np.uint8)
     lib.orc_gray_from_color.restype = None

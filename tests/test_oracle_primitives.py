@@ -381,7 +381,7 @@ def test_opencv_variant_switches_kats():
 
 
 def test_gray_from_color_kats_and_both_opencv_generations():
-    """A-12: cv::cvtColor 8UC3 -> 8UC1 (Tracking.cc:272-295), fixed point.  Hand-derived known answers for both coefficient sets, the byte-order
+    """A-13: cv::cvtColor 8UC3 -> 8UC1 (Tracking.cc:272-295), fixed point.  Hand-derived known answers for both coefficient sets, the byte-order
     switch, and an independent numpy restatement on random data; the two OpenCV generations really differ (so the switch matters)."""
     def px(b, g, r):
         return np.array([[[b, g, r]]], np.uint8)
