@@ -1318,7 +1318,7 @@ __global__ __launch_bounds__(256, 1) void k_fcn_conv3x3_all(const float* __restr
 // operands of a (tile, dx) group two groups ahead.  Wq6 (make_gemm): per unit u = 3 s2 + dy, tile n, dx: [hi of step 2 s2][hi of step 2 s2 + 1][bf6
 // dwords 0-3][bf6 dwords 4-5 in .x .y], 64 lanes x uint4 each.
 #ifndef IVF_DEC_FP6
-#define IVF_DEC_FP6 1
+#define IVF_DEC_FP6 2       // 0: three f16 products (k_fcn_conv3x3_all); 1: k_fcn_conv3x3_f6; 2: k_fcn_conv3x3_f6r where the ranges are whole K-step pairs, k_fcn_conv3x3_f6 elsewhere
 #endif
 #ifndef IVF_DEC6_ABL
 #define IVF_DEC6_ABL 0       // timing-only ablations (results wrong): 1 no x loads in the loop, 2 no A loads, 4 no f16 MFMAs, 8 no scaled MFMAs
@@ -1495,6 +1495,224 @@ __global__ __launch_bounds__(256, 1) void k_fcn_conv3x3_f6(const float* __restri
             const float sc = vget<4>(sc4[r >> 2], r & 3), sh = vget<4>(sh4[r >> 2], r & 3);
             *(float4*)(yb + (size_t)ro * HW) = make_float4(fmaxf(acc[n][0][r] * sc + sh, 0.f), fmaxf(acc[n][1][r] * sc + sh, 0.f),
                                                            fmaxf(acc[n][2][r] * sc + sh, 0.f), fmaxf(acc[n][3][r] * sc + sh, 0.f));
+        }
+    }
+}
+
+// ---- k_fcn_conv3x3_f6r (r06c): the same arithmetic with the two output rows of a wave sharing their input rows ----
+// k_fcn_conv3x3_f6 is bound by its window loads (983 MB per launch through L2 -> L1: every input row is fetched for three tap rows; timing ablations above).  There a
+// lane's column is (row of the pair, 4-pixel group), so the lanes of one B fragment sit on two input rows and each (unit, row) loads its own.  Here a lane is a
+// TWO-pixel group of ONE row (32 lanes x 2 pixels = the 64 pixels of a row) and the wave keeps the accumulators of both output rows side by side: input row r serves
+// output row r with tap row 1 and output row r - 1 with tap row 2 ... -- in unit (s2, dy) output row y0 draws from input row y0 + dy - 1 and output row y0 + 1 from
+// y0 + dy: the second is the first of the next unit.  Two fragment sets alternate (by unrolling the three tap rows of a K-step pair); per pair of K steps FOUR input
+// rows are loaded, split and converted instead of SIX.  The neighbour pixel of a group comes from the next lane: DPP wave shifts (the 32 lanes of a row span two DPP
+// rows), zeroed at the image edge.  Per accumulator the products arrive in the order of k_fcn_conv3x3_f6 with the same operands: the maps are bit-identical.
+// Batched form and ranges that are whole K-step pairs (gridDim.y 1, 2, 5, 10); other ranges run k_fcn_conv3x3_f6.
+__global__ __launch_bounds__(256, 1) void k_fcn_conv3x3_f6r(const float* __restrict__ X, const uint4* __restrict__ Wq6,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           float* __restrict__ Y, int Cin, int Cout,
+                                                           const float* __restrict__ lastW, float lastBias, float* __restrict__ logits,
+                                                           float* __restrict__ part)
+{
+    constexpr int HW = 64 * 64, NT = 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kg = lane >> 5, col = lane & 31;
+    const int nwg = gridDim.x, L = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
+    const int b = L / 8;
+    const int y0 = 2 * ((L % 8) * 4 + wave), x = 2 * col;           // the wave's output rows y0, y0 + 1; this lane's pixels x, x + 1 of both
+    const int K32 = Cin / 32;
+    const float* Xb = X + (size_t)b * Cin * HW + (size_t)8 * kg * HW + x;
+    const uint4* wq = Wq6 + lane;
+    f32x16 acc[NT][2][2];                                            // [tile][output row][pixel of the pair]
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[n][p >> 1][p & 1][r] = 0.f;
+    const int nUnits = 3 * K32 / (int)gridDim.y, u0 = (int)blockIdx.y * nUnits, u1 = u0 + nUnits;     // whole K-step pairs: u0 % 3 == 0, nUnits % 3 == 0
+    struct XRow { float2 x[2][8]; float m; };                       // one input row of a K-step pair: 2 steps x 8 channels x 2 pixels
+    auto load_row = [&](XRow& S, int s2, int yy) __attribute__((always_inline)) {
+        s2 = min(s2, K32 - 1);
+        const bool ok = yy >= 0 && yy < 64;
+        S.m = ok ? 1.f : 0.f;
+        const float* P = Xb + (size_t)32 * s2 * HW + (ok ? yy : y0) * 64;
+#pragma unroll
+        for (int st = 0; st < 2; st++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) S.x[st][j] = *(const float2*)(P + (size_t)(16 * st + j) * HW);
+    };
+    struct FSet { uint32_t bh[2][2][4]; int b6[2][6]; int sbv[2]; };      // (plain scalars: with HFrag / i32x6 members the sets went through scratch)       // the B operands of one input row: [K step][pixel], fp6 image + scale byte per pixel
+    auto build = [&](FSet& F, const XRow& S) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++) {
+            float amax = 0.f;
+#pragma unroll
+            for (int st = 0; st < 2; st++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) amax = fmaxf(amax, fabsf(pt ? S.x[st][j].y : S.x[st][j].x));
+            amax *= S.m;
+            const int sb = min(max(__builtin_amdgcn_frexp_expf(amax) - 3, -40), 20);
+            HFrag lo[2];
+#pragma unroll
+            for (int st = 0; st < 2; st++)
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++)
+                    split_pair((pt ? S.x[st][2 * jj].y : S.x[st][2 * jj].x) * S.m, (pt ? S.x[st][2 * jj + 1].y : S.x[st][2 * jj + 1].x) * S.m, F.bh[st][pt][jj], lo[st].u[jj]);
+            const f16x8 k1024 = {1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024};
+            HFrag hh0, hh1;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { hh0.u[i] = F.bh[0][pt][i]; hh1.u[i] = F.bh[1][pt][i]; }
+            const f16x8 l0 = lo[0].v * k1024, l1 = lo[1].v * k1024, h0 = hh0.v, h1 = hh1.v;
+            const f16x32 src = {h0[0], h0[1], h0[2], h0[3], h0[4], h0[5], h0[6], h0[7], l0[0], l0[1], l0[2], l0[3], l0[4], l0[5], l0[6], l0[7],
+                                h1[0], h1[1], h1[2], h1[3], h1[4], h1[5], h1[6], h1[7], l1[0], l1[1], l1[2], l1[3], l1[4], l1[5], l1[6], l1[7]};
+            const i32x6 cq = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(src, __builtin_bit_cast(float, (127 + sb) << 23));
+#pragma unroll
+            for (int i = 0; i < 6; i++) F.b6[pt][i] = cq[i];
+            F.sbv[pt] = 127 + sb;
+        }
+    };
+    struct AGrp { HFrag h0, h1; uint4 q; uint4 r; };
+    auto load_a = [&](AGrp& a, int u, int g) {
+        u = min(u, 3 * K32 - 1);
+        const uint4* w = wq + ((size_t)u * 9 + g) * 256;
+        a.h0.q = w[0]; a.h1.q = w[64]; a.q = w[128]; a.r = w[192];
+    };
+    // the pixel left of a lane's pair is the previous lane's second pixel, the one right of it the next lane's first: shifts over the whole wave (a row of the image is two
+    // DPP rows), zero where the neighbour would be outside the image (col 0 / col 31: the shift would bring the other channel half's lane, or nothing)
+    const int edgeL = col == 0 ? 0 : -1, edgeR = col == 31 ? 0 : -1;
+    auto nbL = [&](int v, int z) { return __builtin_amdgcn_update_dpp(z, v, 0x138, 0xF, 0xF, true) & edgeL; };      // wave_shr:1
+    auto nbR = [&](int v, int z) { return __builtin_amdgcn_update_dpp(z, v, 0x130, 0xF, 0xF, true) & edgeR; };      // wave_shl:1
+    AGrp ring[3];
+    // one unit: output row 0 from FA, output row 1 from FB
+    auto unit = [&](int u, const FSet& FA, const FSet& FB) __attribute__((always_inline)) {      // (called three times per loop trip: not inlined on its own, and then both sets live in scratch)
+#pragma unroll
+        for (int g = 0; g < 9; g++) {
+            const int n = g / 3, dx = g % 3;
+            if (g + 2 < 9) load_a(ring[(g + 2) % 3], u, g + 2); else load_a(ring[(g + 2) % 3], u + 1, g + 2 - 9);
+            const AGrp& a = ring[g % 3];
+            const i32x8 a6 = {(int)a.q.x, (int)a.q.y, (int)a.q.z, (int)a.q.w, (int)a.r.x, (int)a.r.y, 0, 0};
+            int zz = 0;
+            asm volatile("" : "+v"(zz));
+            auto do_row = [&](auto ROW, const FSet& F) __attribute__((always_inline)) {      // (no `row ? FB : FA`: a select of references keeps both sets in scratch)
+                constexpr int row = decltype(ROW)::value;
+#pragma unroll
+                for (int pt = 0; pt < 2; pt++) {
+                    const int idx = pt + dx - 1;    // -1 .. 2: pixel of the pair, or the neighbour lane's
+                    HFrag f0, f1; i32x8 bq; int sbq;
+                    if (idx == 0 || idx == 1) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { f0.u[i] = F.bh[0][idx][i]; f1.u[i] = F.bh[1][idx][i]; }
+                        sbq = F.sbv[idx];
+                        bq = i32x8{F.b6[idx][0], F.b6[idx][1], F.b6[idx][2], F.b6[idx][3], F.b6[idx][4], F.b6[idx][5], 0, 0};
+                    } else if (idx < 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { f0.u[i] = (uint32_t)nbL((int)F.bh[0][1][i], zz); f1.u[i] = (uint32_t)nbL((int)F.bh[1][1][i], zz); }
+                        bq = i32x8{nbL(F.b6[1][0], zz), nbL(F.b6[1][1], zz), nbL(F.b6[1][2], zz), nbL(F.b6[1][3], zz), nbL(F.b6[1][4], zz), nbL(F.b6[1][5], zz), 0, 0};
+                        sbq = nbL(F.sbv[1], zz);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { f0.u[i] = (uint32_t)nbR((int)F.bh[0][0][i], zz); f1.u[i] = (uint32_t)nbR((int)F.bh[1][0][i], zz); }
+                        bq = i32x8{nbR(F.b6[0][0], zz), nbR(F.b6[0][1], zz), nbR(F.b6[0][2], zz), nbR(F.b6[0][3], zz), nbR(F.b6[0][4], zz), nbR(F.b6[0][5], zz), 0, 0};
+                        sbq = nbR(F.sbv[0], zz);
+                    }
+                    acc[n][row][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h0.v, f0.v, acc[n][row][pt], 0, 0, 0);
+                    acc[n][row][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h1.v, f1.v, acc[n][row][pt], 0, 0, 0);
+                    acc[n][row][pt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a6, bq, acc[n][row][pt], 3, 2, 0, 127 - 10 - kDecSH, 0, sbq);
+                }
+            };
+            do_row(std::integral_constant<int, 0>{}, FA);
+            do_row(std::integral_constant<int, 1>{}, FB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    XRow R0, R1;                                 // raw rows in flight
+    FSet F0, F1;
+    load_row(R0, u0 / 3, y0 - 1);
+    load_row(R1, u0 / 3, y0);
+    load_a(ring[0], u0, 0);
+    load_a(ring[1], u0, 1);
+    for (int u = u0; u < u1; u += 3) {
+        const int s2 = u / 3;
+        // tap row 0: output row y0 <- input row y0 - 1 (F0), output row y0 + 1 <- input row y0 (F1)
+        build(F0, R0); build(F1, R1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_row(R0, s2, y0 + 1);                // lands under this unit's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        unit(u, F0, F1);
+        // tap row 1: y0 <- input row y0 (F1), y0 + 1 <- input row y0 + 1 (into F0)
+        build(F0, R0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_row(R0, s2, y0 + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        unit(u + 1, F1, F0);
+        // tap row 2: y0 <- input row y0 + 1 (F0), y0 + 1 <- input row y0 + 2 (into F1)
+        build(F1, R0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_row(R0, s2 + 1, y0 - 1); load_row(R1, s2 + 1, y0);      // the next K-step pair's first two rows
+        __builtin_amdgcn_sched_barrier(0);
+        unit(u + 2, F0, F1);
+    }
+    // ---- epilogues: k_fcn_conv3x3_all's with this kernel's pixel map (row y0 + p / 2, pixels x + (p & 1))
+    if (part) {
+        float* pb = part + ((size_t)blockIdx.y * (nwg / 8) + b) * Cout * HW + (size_t)y0 * 64 + x;
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int ch = n * 32 + 4 * kg + (r & 3) + 8 * (r >> 2);
+                if (ch < Cout) {
+                    *(float2*)(pb + (size_t)ch * HW) = make_float2(acc[n][0][0][r], acc[n][0][1][r]);
+                    *(float2*)(pb + (size_t)ch * HW + 64) = make_float2(acc[n][1][0][r], acc[n][1][1][r]);
+                }
+            }
+        return;
+    }
+    if (lastW) {
+        float lg[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            const int cb = n * 32 + 4 * kg;
+            float4 sc4[4], sh4[4], lw4[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                sc4[g4] = *(const float4*)(scale + cb + 8 * g4); sh4[g4] = *(const float4*)(shift + cb + 8 * g4);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int ch = cb + 8 * g4 + i;
+                    (&lw4[g4].x)[i] = ch < Cout ? lastW[ch] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                if (cb + ro >= Cout) continue;
+                const float sc = vget<4>(sc4[r >> 2], r & 3), sh = vget<4>(sh4[r >> 2], r & 3), lw = vget<4>(lw4[r >> 2], r & 3);
+#pragma unroll
+                for (int p = 0; p < 4; p++) lg[p >> 1][p & 1] += lw * fmaxf(acc[n][p >> 1][p & 1][r] * sc + sh, 0.f);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) lg[p >> 1][p & 1] += __shfl_xor(lg[p >> 1][p & 1], 32, 64);
+        if (kg == 0) {
+            *(float2*)(logits + (size_t)b * HW + y0 * 64 + x) = make_float2(lg[0][0] + lastBias, lg[0][1] + lastBias);
+            *(float2*)(logits + (size_t)b * HW + (y0 + 1) * 64 + x) = make_float2(lg[1][0] + lastBias, lg[1][1] + lastBias);
+        }
+        return;
+    }
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+        const int cb = n * 32 + 4 * kg;
+        float4 sc4[4], sh4[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) { sc4[g4] = *(const float4*)(scale + cb + 8 * g4); sh4[g4] = *(const float4*)(shift + cb + 8 * g4); }
+        float* yb = Y + ((size_t)b * Cout + cb) * HW + y0 * 64 + x;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            if (cb + ro >= Cout) continue;
+            const float sc = vget<4>(sc4[r >> 2], r & 3), sh = vget<4>(sh4[r >> 2], r & 3);
+            *(float2*)(yb + (size_t)ro * HW) = make_float2(fmaxf(acc[n][0][0][r] * sc + sh, 0.f), fmaxf(acc[n][0][1][r] * sc + sh, 0.f));
+            *(float2*)(yb + (size_t)ro * HW + 64) = make_float2(fmaxf(acc[n][1][0][r] * sc + sh, 0.f), fmaxf(acc[n][1][1][r] * sc + sh, 0.f));
         }
     }
 }
@@ -4082,7 +4300,10 @@ void launch_gemm(const Gemm& g, const float* X, const float* res, float* Y, int 
         static const bool old9 = IVF_EXP_ENV("IVF_FCN_OLD3X3") != nullptr;
         static const bool split9 = IVF_EXP_ENV("IVF_FCN_3X3_SPLIT") != nullptr;      // the r01 kernel: one workgroup per output-channel tile
         static const int dec6 = IVF_EXP_ENV("IVF_FCN_DEC6") ? atoi(IVF_EXP_ENV("IVF_FCN_DEC6")) : IVF_DEC_FP6;
-        if (!old9 && !split9 && dec6 && g.dWq6 && H == 64 && W == 64 && g.act == 2 && !res)
+        if (!old9 && !split9 && dec6 >= 2 && g.dWq6 && H == 64 && W == 64 && g.act == 2 && !res)
+            hipLaunchKernelGGL(k_fcn_conv3x3_f6r, dim3(8 * B), dim3(256), 0, s, X, g.dWq6, g.dScale, g.dShift, Y, g.cin, g.cout,
+                               (const float*)nullptr, 0.f, (float*)nullptr, (float*)nullptr);
+        else if (!old9 && !split9 && dec6 && g.dWq6 && H == 64 && W == 64 && g.act == 2 && !res)
             hipLaunchKernelGGL(k_fcn_conv3x3_f6, dim3(8 * B), dim3(256), 0, s, X, g.dWq6, g.dScale, g.dShift, Y, g.cin, g.cout,
                                (const float*)nullptr, 0.f, (float*)nullptr, (float*)nullptr);
         else if (!old9 && !split9 && H == 64 && W == 64 && g.cin % 32 == 0 && g.act == 2 && !res && g.nTiles == 3)
@@ -4868,7 +5089,10 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
             static const int dec6 = IVF_EXP_ENV("IVF_FCN_DEC6") ? atoi(IVF_EXP_ENV("IVF_FCN_DEC6")) : IVF_DEC_FP6;      // 0: three f16 products (k_fcn_conv3x3_all, r02-r05)
             const bool use6 = dec6 && g.dWq6 != nullptr;
             if (nd > 1) {
-                if (use6)     // the same arithmetic as the batched form: the 30 units in `nd` ranges
+                if (use6 && dec6 >= 2 && (30 / nd) % 3 == 0)      // ranges of whole K-step pairs
+                    hipLaunchKernelGGL(k_fcn_conv3x3_f6r, dim3(8 * n, nd), dim3(256), 0, s, x, g.dWq6, g.dScale, g.dShift, f->bufH1, g.cin, g.cout,
+                                       (const float*)nullptr, 0.f, (float*)nullptr, f->bufPart);
+                else if (use6)     // the same arithmetic as the batched form: the 30 units in `nd` ranges
                     hipLaunchKernelGGL(k_fcn_conv3x3_f6, dim3(8 * n, nd), dim3(256), 0, s, x, g.dWq6, g.dScale, g.dShift, f->bufH1, g.cin, g.cout,
                                        (const float*)nullptr, 0.f, (float*)nullptr, f->bufPart);
                 else
@@ -4876,7 +5100,10 @@ int forward_device(ivf_fcn* f, const uint8_t* dBgr, size_t imageStride, int rowS
                                    (const float*)nullptr, 0.f, (float*)nullptr, f->bufPart);
                 hipLaunchKernelGGL(k_fcn_dec_reduce, dim3(64, n), dim3(256), 0, s, (const float*)f->bufPart, nd, (size_t)n * g.cout * 4096, g.cout,
                                    (const float*)g.dScale, (const float*)g.dShift, (const float*)f->dLastW, f->lastBias, f->bufLogits);
-            } else if (use6)
+            } else if (use6 && dec6 >= 2)
+                hipLaunchKernelGGL(k_fcn_conv3x3_f6r, dim3(8 * n), dim3(256), 0, s, x, g.dWq6, g.dScale, g.dShift, f->bufH1, g.cin, g.cout,
+                                   (const float*)f->dLastW, f->lastBias, f->bufLogits, (float*)nullptr);
+            else if (use6)
                 hipLaunchKernelGGL(k_fcn_conv3x3_f6, dim3(8 * n), dim3(256), 0, s, x, g.dWq6, g.dScale, g.dShift, f->bufH1, g.cin, g.cout,
                                    (const float*)f->dLastW, f->lastBias, f->bufLogits, (float*)nullptr);
             else

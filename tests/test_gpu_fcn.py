@@ -153,8 +153,10 @@ print("OK %.3g" % err)
     {"IVF_FCN_FP6": "1", "IVF_FCN_SPLIT": "0", "IVF_FCN_HALF4": "0"},
     # r06: the decoder's 3x3 as three f16 products (k_fcn_conv3x3_all, r02-r05) instead of hi * hi + the fp6 correction product (k_fcn_conv3x3_f6, the default)
     {"IVF_FCN_DEC6": "0"},
+    # ... and the first fp6 form (four-pixel lanes: every (unit, row) loads its own input row) instead of the row-sharing one
+    {"IVF_FCN_DEC6": "1"},
 ], ids=["default", "layerwise", "expand-pxt2", "dwpw-256", "no-stride2-fusion", "no-stem-fusion", "irb-blocks-2-11",
-        "irb-none", "dwpw8-all", "dwpw8-none", "dwpw-4rows-all", "dwpw-4rows-none", "conv-last-unfused", "blocks-8-14-unfused", "blocks-15-17-unfused", "blocks-5-7-unfused", "block-17-two-workgroups", "head-chunked", "head-row-interleaved", "head-chunked-and-interleaved", "no-small-batch-split", "fp6-expansion", "fp6-expansion-batched-kernels", "decoder-three-f16-products"])
+        "irb-none", "dwpw8-all", "dwpw8-none", "dwpw-4rows-all", "dwpw-4rows-none", "conv-last-unfused", "blocks-8-14-unfused", "blocks-15-17-unfused", "blocks-5-7-unfused", "block-17-two-workgroups", "head-chunked", "head-row-interleaved", "head-chunked-and-interleaved", "no-small-batch-split", "fp6-expansion", "fp6-expansion-batched-kernels", "decoder-three-f16-products", "decoder-fp6-without-row-sharing"])
 def test_fcn_kernel_variants_match_goldens_and_are_deterministic(env):
     """The FCN picks between several kernels per layer (measured defaults, env overrides for tuning).  Every variant must
     meet the same bar, batch results must not depend on the batch slot, and repeated runs must be bit-identical (this is
@@ -170,6 +172,45 @@ def test_fcn_kernel_variants_match_goldens_and_are_deterministic(env):
     r = subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert float(r.stdout.split("OK")[1]) < 3e-4
+
+
+_DEC_SCRIPT = r"""
+import sys, os
+sys.path.insert(0, os.environ["IVF_REPO"]); sys.path.insert(0, os.path.join(os.environ["IVF_REPO"], "tests"))
+import numpy as np, torch
+import fcn_common as FC, iv_slam_amd as iv
+from iv_slam_amd import fcn_weights
+g, W, bgr, out = FC.load_case("jackal")
+dev = torch.device("cuda:0")
+outs = []
+for nb in (16, 3, 1):          # the batched kernel; ranges of whole K-step pairs (5 ways); ranges that are not (15 ways: the four-pixel form runs)
+    f = iv.IntrospectionFCN(fcn_weights.pack_blob(W), bgr.shape[:2], out, max_batch=nb)
+    batch = torch.from_numpy(np.stack([bgr] * nb)).to(dev)
+    cf = torch.empty((nb,) + tuple(out), dtype=torch.float32, device=dev)
+    f.forward_device(batch, cost_f32=cf); f.status()
+    outs.append(cf[nb - 1].cpu().numpy())
+np.save(os.environ["IVF_OUT"], np.stack(outs))
+print("OK")
+"""
+
+
+def test_decoder_row_sharing_form_is_bit_identical_to_the_four_pixel_form(tmp_path):
+    """r06: k_fcn_conv3x3_f6r (two-pixel lanes, the two output rows of a wave share their input rows: four row loads / conversions per K-step pair instead of six) issues,
+    per accumulator, the products of k_fcn_conv3x3_f6 in the same order with the same operands -- the cost maps must be EQUAL bit for bit at every batch size
+    (batched kernel, ranges of whole pairs, ranges that fall back)."""
+    import os, subprocess, sys
+    from iv_slam_amd import _lib
+    assert os.path.exists(_lib.EXPERIMENT_LIB_PATH), "libivfront_exp.so missing: make -C iv_slam_amd/csrc EXPERIMENT=1"
+    res = {}
+    for v in ("1", "2"):
+        e = dict(os.environ); e.update({"IVF_FCN_DEC6": v, "IVF_REPO": FC.ROOT, "IVFRONT_LIB": _lib.EXPERIMENT_LIB_PATH, "IVF_OUT": str(tmp_path / ("dec%s.npy" % v))})
+        r = subprocess.run([sys.executable, "-c", _DEC_SCRIPT], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        res[v] = np.load(e["IVF_OUT"])
+    assert np.array_equal(res["1"], res["2"]), "max |d| %.3g" % float(np.abs(res["1"] - res["2"]).max())
+    g, W, bgr, out = FC.load_case("jackal")
+    sub = int(g["sub"][0]) if "sub" in g.files else 6
+    assert float(np.abs(res["2"][0][::sub, ::sub] - g["cost_sub"]).max()) < 3e-4
 
 
 def test_fcn_small_batch_schedule_agrees_with_the_batched_one(iv):
