@@ -1652,6 +1652,12 @@ __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg
     __shared__ int s_m10[kDescKP], s_m01[kDescKP], s_level[kDescKP], s_oi[kDescKP];      // s_level < 0: empty slot
     __shared__ unsigned s_pos[kDescKP];
     __shared__ float s_angle[kDescKP], s_a[kDescKP], s_b[kDescKP];
+    // r06: the level's plane offset / pitch / scale / patch size per slot.  `cfg->lv[level]` with `level` read back from LDS is a VECTOR load (the compiler cannot
+    // know the wave agrees on it) with an s_waitcnt vmcnt(0) behind it, in front of every keypoint's disc / patch loads: the eight keypoints of a wave, whose loads
+    // were meant to be in flight together, went one round trip at a time.  The lane that resolves the slot reads the geometry once.
+    __shared__ int s_goff[kDescKP], s_gpitch[kDescKP], s_gpatch[kDescKP];
+    __shared__ float s_gscale[kDescKP], s_resp[kDescKP], s_qual[kDescKP];      // + the slot's response and mvKeyQualScore: fetched by the resolving lane too, not
+                                                                               // by lane 0 of the wave behind a wait in front of every keypoint's stores
     // image i is described by XCD i % 8 only (its two pyramids, 3.8 MB at 1242 x 375, stay in that XCD's L2)
     const int nf = cfg->nfeatures, nl = cfg->nlevels;
     int img, grp;
@@ -1675,6 +1681,20 @@ __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg
             if (slot == 0) count[img] = total;
             const int k = slot - cfg->lv[lv].kpBase;
             if (k < lc[lv]) { level = lv; oi = before + k; pos = myPos; }
+            const LevelGeom& Gl = cfg->lv[lv];
+            s_goff[threadIdx.x] = Gl.off; s_gpitch[threadIdx.x] = Gl.pitch; s_gpatch[threadIdx.x] = Gl.scaledPatch; s_gscale[threadIdx.x] = Gl.scale;
+            s_resp[threadIdx.x] = slotResp[(size_t)img * nf + slot];
+            float qv = 1.0f;
+            if (level >= 0 && (useCost[img] & 2)) {          // Frame.cc:130-143: whenever a cost image came with the frame, whatever the extractor flag
+                float fx = (float)(myPos & 0xffff), fy = (float)(myPos >> 16);
+                if (lv != 0) { fx *= Gl.scale; fy *= Gl.scale; }
+                const int qx = (int)roundf(fx), qy = (int)roundf(fy);
+                const LevelGeom& G0 = cfg->lv[0];
+                const float cost = (float)qpyr[(size_t)img * cfg->pyrBytes + G0.off + (size_t)min(qy, G0.h - 1) * G0.pitch + min(qx, G0.w - 1)];
+                const float qs = (float)(1.0 / (1.0 + (double)(cost / 256)));
+                qv = 2 * qs - 1;
+            }
+            s_qual[threadIdx.x] = qv;
         }
         s_level[threadIdx.x] = level; s_oi[threadIdx.x] = oi; s_pos[threadIdx.x] = pos;
     }
@@ -1700,12 +1720,12 @@ __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg
 #pragma unroll
             for (int q = 0; q < 4; q++) w4[r][q] = 0;
             if (level >= 0) {                                           // uniform per wave
-                const LevelGeom& G = cfg->lv[level];
-                const uint8_t* c0 = Pimg + G.off + (size_t)(pos >> 16) * G.pitch + (pos & 0xffff) + u0;
+                const int goff = s_goff[ls], gpitch = s_gpitch[ls];
+                const uint8_t* c0 = Pimg + goff + (size_t)(pos >> 16) * gpitch + (pos & 0xffff) + u0;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int v = -15 + (lane >> 3) + 8 * q;
-                    if (v <= 15) __builtin_memcpy(&w4[r][q], c0 + (ptrdiff_t)v * G.pitch, 4);
+                    if (v <= 15) __builtin_memcpy(&w4[r][q], c0 + (ptrdiff_t)v * gpitch, 4);
                 }
             }
         }
@@ -1773,12 +1793,12 @@ __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg
 #pragma unroll
             for (int it = 0; it < kPIt; it++) pv[q][it] = 0u;
             if (level >= 0) {                       // uniform per wave
-                const LevelGeom& G = cfg->lv[level];
+                const int goff = s_goff[ls], gpitch = s_gpitch[ls];
                 const unsigned pos = s_pos[ls];
                 const int px = pos & 0xffff, py = pos >> 16;
-                const uint8_t* B0 = Bimg + G.off + (size_t)(py - kPR) * G.pitch + ((px - kPR) & ~3);
+                const uint8_t* B0 = Bimg + goff + (size_t)(py - kPR) * gpitch + ((px - kPR) & ~3);
 #pragma unroll
-                for (int it = 0; it < kPIt; it++) pv[q][it] = *(const unsigned*)(B0 + (size_t)prow[it] * G.pitch + 4 * pcol[it]);
+                for (int it = 0; it < kPIt; it++) pv[q][it] = *(const unsigned*)(B0 + (size_t)prow[it] * gpitch + 4 * pcol[it]);
             }
         }
         wave_sync_lds();                            // the previous half's gathers are done with the patches
@@ -1792,7 +1812,6 @@ __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg
             const int ls = wave * kDescPW + 4 * half + q;
             const int level = s_level[ls];
             if (level < 0) continue;
-            const LevelGeom& G = cfg->lv[level];
             const unsigned pos = s_pos[ls];
             const int px = pos & 0xffff, py = pos >> 16;
             const float a = s_a[ls], b = s_b[ls];
@@ -1813,18 +1832,12 @@ __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg
             if (lane == 0) {
                 ivf_keypoint kp;
                 float fx = (float)px, fy = (float)py;
-                if (level != 0) { fx *= G.scale; fy *= G.scale; }
-                kp.x = fx; kp.y = fy; kp.size = (float)G.scaledPatch; kp.angle = s_angle[ls];
-                kp.response = slotResp[(size_t)img * nf + slot]; kp.octave = level;
+                const float gscale = s_gscale[ls];
+                if (level != 0) { fx *= gscale; fy *= gscale; }
+                kp.x = fx; kp.y = fy; kp.size = (float)s_gpatch[ls]; kp.angle = s_angle[ls];
+                kp.response = s_resp[ls]; kp.octave = level;
                 kps[(size_t)img * nf + oi] = kp;
-                float qv = 1.0f;
-                if (useCost[img] & 2) {          // Frame.cc:130-143: whenever a cost image came with the frame, whatever the extractor flag
-                    const int qx = (int)roundf(fx), qy = (int)roundf(fy);
-                    const LevelGeom& G0 = cfg->lv[0];
-                    const float cost = (float)qpyr[(size_t)img * cfg->pyrBytes + G0.off + (size_t)min(qy, G0.h - 1) * G0.pitch + min(qx, G0.w - 1)];
-                    const float qs = (float)(1.0 / (1.0 + (double)(cost / 256)));
-                    qv = 2 * qs - 1;
-                }
+                const float qv = s_qual[ls];
                 quality[(size_t)img * nf + oi] = qv;
             }
         }
