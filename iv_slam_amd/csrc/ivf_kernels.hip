@@ -1951,8 +1951,17 @@ __global__ __launch_bounds__(256) void k_stereo_match(const Config* __restrict__
     // row's first 64 list entries, the left SAD window -- a candidate's descriptor is requested together with its keypoint record
     // (not after the band / octave / disparity tests), and the winner's x travels with the minimum instead of being read back:
     // 4 round trips (keypoint -> row list -> candidates -> right windows) instead of 8.
+    // r06: the pyramid scales as scalars up front (independent of everything), and the keypoint's level as a scalar: `cfg->lv[kl.octave]` and
+    // `cfg->scale[kr.octave]` behind loaded octaves were vector loads -- two more dependent round trips in a kernel that is a chain of them
+    float sc8[kMaxLevels];
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; l++) sc8[l] = cfg->scale[l];
+    auto scale_of = [&](int oct) { float v = sc8[0];
+#pragma unroll
+        for (int l = 1; l < kMaxLevels; l++) v = oct == l ? sc8[l] : v;
+        return v; };
     const ivf_keypoint kl = kpL[iL];
-    const int levelL = kl.octave;
+    const int levelL = __builtin_amdgcn_readfirstlane(kl.octave);      // one wave = one left keypoint: uniform
     const float vL = kl.y, uL = kl.x;
     const int row = (int)vL;
     const float minZ = A.bb, minD = 0, maxD = A.bf / minZ;
@@ -1997,7 +2006,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const Config* __restrict__
                 const ivf_keypoint kr = kpR[iR];
                 const uint4* dr = (const uint4*)(descR + (size_t)iR * 32);
                 const uint4 r0 = dr[0], r1 = dr[1];
-                const float r = 2.0f * cfg->scale[kr.octave];
+                const float r = 2.0f * scale_of(kr.octave);
                 const int maxr = (int)ceilf(kr.y + r), minr = (int)floorf(kr.y - r);
                 if (row >= minr && row <= maxr && kr.octave >= levelL - 1 && kr.octave <= levelL + 1 &&
                     kr.x >= minU && kr.x <= maxU) {
