@@ -263,8 +263,8 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
     HIPCHK(hipMalloc(&b.slotResp, nI * nf * sizeof(float)));
     HIPCHK(hipMalloc(&b.lvlCount, nI * kMaxLevels * sizeof(int)));
     HIPCHK(hipMemset(b.lvlCount, 0, nI * kMaxLevels * sizeof(int)));
-    HIPCHK(hipMalloc(&b.useCost, nI));
-    HIPCHK(hipMemset(b.useCost, 0, nI));
+    HIPCHK(hipMalloc(&b.useCost, (nI + 3) & ~(size_t)3));                // whole dwords: the kernels read the flags with scalar dword loads
+    HIPCHK(hipMemset(b.useCost, 0, (nI + 3) & ~(size_t)3));
     HIPCHK(hipMalloc(&b.kps, nI * nf * sizeof(ivf_keypoint)));
     HIPCHK(hipMalloc(&b.desc, nI * nf * 32));
     HIPCHK(hipMalloc(&b.count, nI * sizeof(int)));

@@ -25,6 +25,14 @@ static __device__ const int8_t __attribute__((aligned(16))) d_pattern[1024] = {
 #include "../../include/ivf_pattern31.inc"
 };
 
+// The per-image flag byte through the scalar cache: gfx950 has no scalar byte load, so a plain `useCost [img]` is a vector load with an `s_waitcnt vmcnt(0)` in
+// front of every scalar load that follows it at the head of a workgroup.  The flag array is allocated in whole dwords (Context::build).
+DEVINL unsigned use_cost_of(const uint8_t* __restrict__ useCost, int img)
+{
+    const unsigned w = ((const unsigned*)useCost)[img >> 2];
+    return (w >> (8 * (img & 3))) & 0xffu;
+}
+
 // sum over the wave without the LDS crossbar (r04; was six ds_bpermute round trips): row_shr 1/2/4/8 fold each row of 16 lanes into
 // its lane 15, row_bcast15 / row_bcast31 fold the four rows into lane 63, which every lane then reads
 DEVINL int wave_sum_i32(int v)
@@ -80,34 +88,46 @@ __global__ __launch_bounds__(256) void k_ingest(const Config* __restrict__ cfg, 
 {
     const LevelGeom& G = cfg->lv[0];
     const int img = blockIdx.y, y0 = blockIdx.x * kIngestRows;
-    if (onlyFlagged && !(onlyFlagged[img] & 3u)) return;            // a cost plane nothing reads (the right image of a stereo pair)
+    if (onlyFlagged && !(use_cost_of(onlyFlagged, img) & 3u)) return;            // a cost plane nothing reads (the right image of a stereo pair)
     if (!((sideMask >> (img % nSides)) & 1)) return;                // this side arrives in colour: k_ingest_color writes its plane
     const uint8_t* src = ((nSides == 2 && (img & 1)) ? src1 : src0) + (size_t)(img / nSides) * imageStride;
     uint8_t* dst = blob + (size_t)img * cfg->pyrBytes + G.off;
     const int q16 = G.pitch / 16;                                    // 16-byte pieces per pitched row (pitch % 64 == 0)
     const int rows = min(kIngestRows, G.h - y0);
-    // four pieces per thread requested before the first is stored (r04: one load -> store round trip per piece was the kernel's time)
-    for (int i0 = threadIdx.x; i0 < rows * q16; i0 += 4 * 256) {
-        uint4 v[4];
-        size_t d[4];
+    if (G.w >= 16) {
+        // four pieces per thread requested before the first is stored (r04: one load -> store round trip per piece was the kernel's time).
+        // r06: branch-free.  Every piece is the 16 bytes that END at min(x + 16, w) of its row, shifted down by the bytes that belong to the piece before
+        // (0 for a whole piece, everything for a piece past the image): the row's last piece used to be a byte loop with a wait per byte -- up to 15
+        // dependent round trips for one lane of EVERY wave at widths that are not a multiple of 16 (1242: 10), in front of the wave's other loads
+        for (int i0 = threadIdx.x; i0 < rows * q16; i0 += 4 * 256) {
+            unsigned __int128 t[4];
+            size_t d[4];
+            int nv[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int i = i0 + 256 * u;
-            const int r = min(i / q16, rows - 1), x = (i % q16) * 16;
-            const uint8_t* sp = src + (size_t)(y0 + r) * rowStride + x;
-            d[u] = (size_t)(y0 + r) * G.pitch + x;
-            v[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (i < rows * q16) {
-                if (x + 15 < G.w) __builtin_memcpy(&v[u], sp, 16);      // (dword-aligned loads + a funnel shift measured slower: 95 vs 90 us)
-                else if (x < G.w) {                                  // the row's last piece: bytes, zero beyond the image
-                    unsigned w[4] = {0u, 0u, 0u, 0u};
-                    for (int k = 0; k < 16 && x + k < G.w; k++) w[k >> 2] |= (unsigned)sp[k] << (8 * (k & 3));
-                    v[u] = make_uint4(w[0], w[1], w[2], w[3]);
-                }
+            for (int u = 0; u < 4; u++) {
+                const int i = min(i0 + 256 * u, rows * q16 - 1);
+                const int r = i / q16, x = (i % q16) * 16;
+                const int xe = min(x + 16, G.w);
+                nv[u] = max(xe - x, 0);                              // bytes of this piece that are image: 16, 1..15 (the row's last), 0 (past it)
+                d[u] = (size_t)(y0 + r) * G.pitch + x;
+                __builtin_memcpy(&t[u], src + (size_t)(y0 + r) * rowStride + xe - 16, 16);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                // (a slot past the workgroup's last piece was clamped to that piece: it stores the same bytes again -- a conditional store would let the
+                // compiler sink that slot's load into the branch, behind a wait of its own)
+                const unsigned __int128 v = (t[u] >> (4 * (16 - nv[u]))) >> (4 * (16 - nv[u]));   // two halves: a shift by all 128 bits (nv = 0) is not defined, a select is a branch
+                __builtin_memcpy(dst + d[u], &v, 16);
             }
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++) if (i0 + 256 * u < rows * q16) *(uint4*)(dst + d[u]) = v[u];
+        return;
+    }
+    for (int i = threadIdx.x; i < rows * q16; i += 256) {            // narrower than one piece: bytes
+        const int r = i / q16, x = (i % q16) * 16;
+        const uint8_t* sp = src + (size_t)(y0 + r) * rowStride + x;
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+        for (int k = 0; k < 16 && x + k < G.w; k++) w[k >> 2] |= (unsigned)sp[k] << (8 * (k & 3));
+        *(uint4*)(dst + (size_t)(y0 + r) * G.pitch + x) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -141,7 +161,14 @@ __global__ __launch_bounds__(256) void k_ingest_color(const Config* __restrict__
 #pragma unroll
             for (int k = 0; k < 16; k++) w[k >> 2] |= ((px[3 * k] * k0 + px[3 * k + 1] * kG + px[3 * k + 2] * k2 + half) >> sh) << (8 * (k & 3));
         } else if (x < G.w) {
-            for (int k = 0; k < 16 && x + k < G.w; k++) w[k >> 2] |= ((sp[3 * k] * k0 + sp[3 * k + 1] * kG + sp[3 * k + 2] * k2 + half) >> sh) << (8 * (k & 3));
+            // the row's last piece (1..15 pixels): every load at a clamped index, all in flight at once (a loop with a data-dependent bound waits per iteration)
+            const int nv = G.w - x;
+#pragma unroll
+            for (int k = 0; k < 15; k++) {
+                const int kk = min(k, nv - 1);
+                const unsigned g = (sp[3 * kk] * k0 + sp[3 * kk + 1] * kG + sp[3 * kk + 2] * k2 + half) >> sh;
+                w[k >> 2] |= (k < nv ? g : 0u) << (8 * (k & 3));
+            }
         }
         *(uint4*)(dst + (size_t)(y0 + r) * G.pitch + x) = make_uint4(w[0], w[1], w[2], w[3]);
     }
@@ -326,7 +353,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(const Config* __restrict__ cfg
     extern __shared__ __attribute__((aligned(16))) uint8_t src[];           // ldsRows x ldsPitch bytes (ldsPitch % 16 == 0)
     int img = blockIdx.z;
     uint8_t* blob = blobI;
-    if (img >= nImg) { img -= nImg; blob = blobQ; if (!(useCost[img] & 1u)) return; }
+    if (img >= nImg) { img -= nImg; blob = blobQ; if (!(use_cost_of(useCost, img) & 1u)) return; }
     pyr_tile(cfg, level, tab, blob + (size_t)img * cfg->pyrBytes, blockIdx.x * kPyrTW, blockIdx.y * kPyrTH, ldsPitch, ldsRows, src);
 }
 
@@ -462,7 +489,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Config* __restrict__ cfg
     const int tid = threadIdx.x;
     // the prologue is latency: every load below is issued before anything waits on one.  Level lookup: all tile bases
     // in one wide load (INT_MAX past nlevels)
-    const unsigned useC = useCost[img];
+    const unsigned useC = use_cost_of(useCost, img);
     int level = 0;
 #pragma unroll
     for (int l = 1; l < kMaxLevels; l++) level += bx >= cfg->tileBases[l] ? 1 : 0;   // bases ascend
@@ -1055,8 +1082,8 @@ __global__ __launch_bounds__(256) void k_cell_qsum(const Config* __restrict__ cf
                                                   const uint8_t* __restrict__ useCost, CellInfo* __restrict__ cellInfo)
 {
     const int img = blockIdx.y, lane = threadIdx.x & 63;
-    const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (cell >= cfg->nCellsTotal || !(cfg->introspection && (useCost[img] & 1))) return;
+    const int cell = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // a scalar: the level geometry below then comes through scalar loads
+    if (cell >= cfg->nCellsTotal || !(cfg->introspection && (use_cost_of(useCost, img) & 1))) return;
     int level = 0;
     for (int l = 1; l < cfg->nlevels; l++)
         if (cfg->lv[l].valid && cell >= cfg->lv[l].cellBase) level = l;
@@ -1097,7 +1124,7 @@ __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, c
     const LevelGeom& G = cfg->lv[level];
     const int tid = threadIdx.x;
     if (!G.valid) { if (tid == 0) lvlTotal[img * kMaxLevels + level] = 0; return; }
-    const int mode = (cfg->introspection && (useCost[img] & 1)) ? 1 : 0;
+    const int mode = (cfg->introspection && (use_cost_of(useCost, img) & 1)) ? 1 : 0;
     const int nCells = G.nCells, cols = G.cols, rows = G.rows;
     const int* cnt = cellCnt + ((size_t)img * cfg->nCellsTotal + G.cellBase) * 2;
     CellInfo* ci = cellInfo + (size_t)img * cfg->nCellsTotal + G.cellBase;
@@ -1218,7 +1245,7 @@ DEVINL void cell_select_one(const Config* __restrict__ cfg, const unsigned* __re
     const int nT = info.nTotal, nR = info.nRetain;
     if (nT <= 0) return;
     if (nT <= nLo || nT > nHi) return;                               // this launch's tier: cells with nLo < survivors <= nHi
-    const int mode = (cfg->introspection && (useCost[img] & 1)) ? 1 : 0;
+    const int mode = (cfg->introspection && (use_cost_of(useCost, img) & 1)) ? 1 : 0;
     const uint8_t* Q = mode ? qpyr + (size_t)img * cfg->pyrBytes + G.off : nullptr;
     const unsigned th = info.useMin ? 1u : (unsigned)cfg->iniTh;
     const int kept = (nR >= 0 && nT > nR) ? nR : nT;
@@ -1453,7 +1480,7 @@ __global__ __launch_bounds__(1024) void k_cell_select_huge(const Config* __restr
         const int c = gc - G.cellBase;
         const CellInfo info = cellInfo[(size_t)img * cfg->nCellsTotal + gc];
         const int nT = info.nTotal, nR = info.nRetain;
-        const int mode = (cfg->introspection && (useCost[img] & 1)) ? 1 : 0;
+        const int mode = (cfg->introspection && (use_cost_of(useCost, img) & 1)) ? 1 : 0;
         const uint8_t* Q = mode ? qpyr + (size_t)img * cfg->pyrBytes + G.off : nullptr;
         const unsigned th = info.useMin ? 1u : (unsigned)cfg->iniTh;
         const int kept = (nR >= 0 && nT > nR) ? nR : nT;
@@ -1685,7 +1712,7 @@ __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg
             s_goff[threadIdx.x] = Gl.off; s_gpitch[threadIdx.x] = Gl.pitch; s_gpatch[threadIdx.x] = Gl.scaledPatch; s_gscale[threadIdx.x] = Gl.scale;
             s_resp[threadIdx.x] = slotResp[(size_t)img * nf + slot];
             float qv = 1.0f;
-            if (level >= 0 && (useCost[img] & 2)) {          // Frame.cc:130-143: whenever a cost image came with the frame, whatever the extractor flag
+            if (level >= 0 && (use_cost_of(useCost, img) & 2)) {          // Frame.cc:130-143: whenever a cost image came with the frame, whatever the extractor flag
                 float fx = (float)(myPos & 0xffff), fy = (float)(myPos >> 16);
                 if (lv != 0) { fx *= Gl.scale; fy *= Gl.scale; }
                 const int qx = (int)roundf(fx), qy = (int)roundf(fy);
@@ -1869,6 +1896,20 @@ __global__ void k_hamming_pairs(const uint8_t* __restrict__ a, const uint8_t* __
     dist[i] = hamming256(pa[0], pa[1], pb[0], pb[1]);
 }
 
+// The pyramid scales of a wave in LDS (r06).  `cfg->scale[octave]` with an octave that came out of a keypoint record is a vector load BEHIND that record -- one
+// more dependent round trip per candidate in kernels that are chains of them.  Lane 0 copies the table from scalar loads into the wave's own LDS row (LDS
+// operations of one wave execute in order: no workgroup barrier); the lookup is then a conflict-free `ds_read`.  (A local array + a select chain was tried
+// first: the compiler promotes it to a per-THREAD LDS copy with 64-byte stride -- 16 KB per workgroup and 16-way bank conflicts on every access.)
+DEVINL void stage_scales(const Config* __restrict__ cfg, float* __restrict__ tab, int lane)
+{
+    if (lane == 0) {
+#pragma unroll
+        for (int l = 0; l < kMaxLevels; l++) tab[l] = cfg->scale[l];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_stereo_match: one wave = one left keypoint (Frame.cc:788-915).
 //   candidates = right keypoints whose row band [floor(y-r), ceil(y+r)], r = 2*scale[octave], holds
@@ -1888,6 +1929,9 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const Config* __restrict__ 
     int* cnt = A.rowCnt + (size_t)pair * H;
     unsigned short* list = A.rowList + (size_t)pair * H * kRowCap;
     const ivf_keypoint* kpR = A.kpR + (size_t)pair * A.kpStride;
+    __shared__ float s_scaleW[4][kMaxLevels];
+    float* sc8 = s_scaleW[threadIdx.x >> 6];
+    stage_scales(cfg, sc8, threadIdx.x & 63);
     if (inLds) {
         // r04: the table of one pair (H x (4 + 2 kRowCap) bytes: 73 KB at H = 375) is built in LDS -- ~5 LDS atomics per right keypoint
         // instead of global ones (39 -> 13 us per 128 pairs) -- and leaves as one pass of coalesced dword stores; the order of a row's
@@ -1898,7 +1942,7 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const Config* __restrict__ 
         __syncthreads();
         for (int iR = tid; iR < nR; iR += 256) {
             const ivf_keypoint kr = kpR[iR];
-            const float r = 2.0f * cfg->scale[kr.octave];
+            const float r = 2.0f * sc8[kr.octave];
             const int maxr = min((int)ceilf(kr.y + r), H - 1), minr = max((int)floorf(kr.y - r), 0);
             for (int yi = minr; yi <= maxr; yi++) {
                 const int pos = atomicAdd(&cs[yi], 1);
@@ -1920,7 +1964,7 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const Config* __restrict__ 
     __syncthreads();
     for (int iR = tid; iR < nR; iR += 256) {
         const ivf_keypoint kr = kpR[iR];
-        const float r = 2.0f * cfg->scale[kr.octave];
+        const float r = 2.0f * sc8[kr.octave];
         const int maxr = min((int)ceilf(kr.y + r), H - 1), minr = max((int)floorf(kr.y - r), 0);
         for (int yi = minr; yi <= maxr; yi++) {
             const int pos = atomicAdd(&cnt[yi], 1);
@@ -1951,16 +1995,12 @@ __global__ __launch_bounds__(256) void k_stereo_match(const Config* __restrict__
     // row's first 64 list entries, the left SAD window -- a candidate's descriptor is requested together with its keypoint record
     // (not after the band / octave / disparity tests), and the winner's x travels with the minimum instead of being read back:
     // 4 round trips (keypoint -> row list -> candidates -> right windows) instead of 8.
-    // r06: the pyramid scales as scalars up front (independent of everything), and the keypoint's level as a scalar: `cfg->lv[kl.octave]` and
+    // r06: the pyramid scales in the wave's LDS row up front (stage_scales), and the keypoint's level as a scalar: `cfg->lv[kl.octave]` and
     // `cfg->scale[kr.octave]` behind loaded octaves were vector loads -- two more dependent round trips in a kernel that is a chain of them
-    float sc8[kMaxLevels];
-#pragma unroll
-    for (int l = 0; l < kMaxLevels; l++) sc8[l] = cfg->scale[l];
-    auto scale_of = [&](int oct) { float v = sc8[0];
-#pragma unroll
-        for (int l = 1; l < kMaxLevels; l++) v = oct == l ? sc8[l] : v;
-        return v; };
     const ivf_keypoint kl = kpL[iL];
+    __shared__ float s_scaleW[4][kMaxLevels];
+    float* sc8 = s_scaleW[threadIdx.x >> 6];
+    stage_scales(cfg, sc8, lane);                                     // (scalar loads + four LDS writes of one lane, under the keypoint's round trip)
     const int levelL = __builtin_amdgcn_readfirstlane(kl.octave);      // one wave = one left keypoint: uniform
     const float vL = kl.y, uL = kl.x;
     const int row = (int)vL;
@@ -2006,7 +2046,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const Config* __restrict__
                 const ivf_keypoint kr = kpR[iR];
                 const uint4* dr = (const uint4*)(descR + (size_t)iR * 32);
                 const uint4 r0 = dr[0], r1 = dr[1];
-                const float r = 2.0f * scale_of(kr.octave);
+                const float r = 2.0f * sc8[kr.octave];
                 const int maxr = (int)ceilf(kr.y + r), minr = (int)floorf(kr.y - r);
                 if (row >= minr && row <= maxr && kr.octave >= levelL - 1 && kr.octave <= levelL + 1 &&
                     kr.x >= minU && kr.x <= maxU) {
