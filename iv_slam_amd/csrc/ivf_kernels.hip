@@ -224,6 +224,11 @@ DEVINL void pyr_tile(const Config* __restrict__ cfg, int level, const ResizeCoef
             const bool ok = qc < nq && r0 + 8 * k < nr;
             v[k] = *(const uint4*)(ok ? gp + (size_t)(r0 + 8 * k) * S.pitch : SP);
         }
+        // r06: every loaded value passes through an empty asm HERE.  The stores below are conditional on the same test as the address select, so the compiler
+        // moved each load into its store's branch: `if (ok) { load; s_waitcnt vmcnt(0); ds_write }` nine times in a row -- five or six SEQUENTIAL round trips per
+        // thread at the 1.2 ratio, which is what "bound by its dependent round trips" (r04) really was.  The asm makes all of them live before the first store.
+#pragma unroll
+        for (int k = 0; k < kIt; k++) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));
 #pragma unroll
         for (int k = 0; k < kIt; k++)
             if (qc < nq && r0 + 8 * k < nr) *(uint4*)(src + (r0 + 8 * k) * ldsPitch + 16 * qc) = v[k];
@@ -284,11 +289,20 @@ DEVINL void pyr_tile(const Config* __restrict__ cfg, int level, const ResizeCoef
         unsigned hA[4], hB[4];
         int rowA = -1, rowB = -1;                   // staged rows held in hA / hB
         uint8_t* outp = base + D.off + (size_t)dyFirst * D.pitch + x4;
+        // r06: the eight row coefficients up front (scalar loads at clamped indices, one wait) instead of one scalar round trip at the head of every row
+        unsigned cyl[kPyrRPT], cyh[kPyrRPT];
+#pragma unroll
+        for (int rr = 0; rr < kPyrRPT; rr++) {
+            const ResizeCoef c = ty[min(dyFirst + rr, D.h - 1)];
+            cyl[rr] = (unsigned)c; cyh[rr] = (unsigned)(c >> 32);
+        }
+#pragma unroll
+        for (int rr = 0; rr < kPyrRPT; rr++) asm volatile("" : "+s"(cyl[rr]), "+s"(cyh[rr]));
 #pragma unroll
         for (int rr = 0; rr < kPyrRPT; rr++) {
             const int dy = dyFirst + rr;
             if (dy >= D.h) break;
-            const ResizeCoef cy = ty[dy];
+            const ResizeCoef cy = (ResizeCoef)cyl[rr] | ((ResizeCoef)cyh[rr] << 32);
             const int y0 = (int)(cy & 0xffff), y1 = min(y0 + 1, S.h - 1);
             const unsigned b0 = (unsigned)((cy >> 16) & 0xffff), b1 = (unsigned)((cy >> 32) & 0xffff);
             if (y0 - wy0 == rowB) {
@@ -756,7 +770,6 @@ __global__ __launch_bounds__(256) void k_blur7(const Config* __restrict__ cfg, c
         constexpr int RPP = 256 / RQ, IT = (RH + RPP - 1) / RPP;     // 7 rows per pass, 6 passes
         const int rq = tid % RQ, r0 = tid / RQ;
         const int gx = x0 - 4 + 4 * rq;
-        const bool inner = gx >= 0 && gx + 3 < gw;
         unsigned v[IT];
         if (x0 - 4 >= 0 && x0 + kBlurTW + 4 <= gw) {
             // r04: a tile whose window lies inside the plane horizontally (uniform: 8 of 10 tile columns at level 0) needs no
@@ -769,22 +782,26 @@ __global__ __launch_bounds__(256) void k_blur7(const Config* __restrict__ cfg, c
                 int gy = y0 - 3 + ry; gy = gy < 0 ? -gy : gy; gy = gy >= gh ? 2 * (gh - 1) - gy : gy; gy = max(gy, 0);
                 v[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, gy * pitch + gx, 0, 0);
             }
-        } else
+        } else {
+            // an edge tile (the first / last tile column of a level: 2 of 10 at level 0, 2 of 3 at level 7).  r06: branch-free -- EVERY lane gathers its four bytes at
+            // reflected columns (for an inner lane they are its dword), all rows at once.  The form this replaces (`inner ? dword load : four reflected byte loads` per row)
+            // compiled to two waits per row: up to twelve sequential round trips per wave in an edge tile against one in an inner tile
+            int xb[4];
 #pragma unroll
-        for (int k = 0; k < IT; k++) {
-            const int ry = min(r0 + RPP * k, RH - 1);
-            int gy = y0 - 3 + ry; gy = gy < 0 ? -gy : gy; gy = gy >= gh ? 2 * (gh - 1) - gy : gy; gy = max(gy, 0);
-            const uint8_t* row = src + (size_t)gy * pitch;
-            if (inner) v[k] = *(const unsigned*)(row + gx);
-            else {                                                   // first / last dword of an edge tile: bytes, reflected
-                unsigned w = 0;
+            for (int b = 0; b < 4; b++) { int x = gx + b; x = x < 0 ? -x : x; x = x >= gw ? 2 * (gw - 1) - x : x; xb[b] = min(max(x, 0), gw - 1); }
+            unsigned bt[IT][4];
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    int x = gx + b; x = x < 0 ? -x : x; x = x >= gw ? 2 * (gw - 1) - x : x; x = min(max(x, 0), gw - 1);
-                    w |= (unsigned)row[x] << (8 * b);
-                }
-                v[k] = w;
+            for (int k = 0; k < IT; k++) {
+                const int ry = min(r0 + RPP * k, RH - 1);
+                int gy = y0 - 3 + ry; gy = gy < 0 ? -gy : gy; gy = gy >= gh ? 2 * (gh - 1) - gy : gy; gy = max(gy, 0);
+                const uint8_t* row = src + (size_t)gy * pitch;
+#pragma unroll
+                for (int b = 0; b < 4; b++) bt[k][b] = row[xb[b]];
             }
+#pragma unroll
+            for (int k = 0; k < IT; k++) asm volatile("" : "+v"(bt[k][0]), "+v"(bt[k][1]), "+v"(bt[k][2]), "+v"(bt[k][3]));     // (all in flight before the first use)
+#pragma unroll
+            for (int k = 0; k < IT; k++) v[k] = bt[k][0] | (bt[k][1] << 8) | (bt[k][2] << 16) | (bt[k][3] << 24);
         }
 #pragma unroll
         for (int k = 0; k < IT; k++) if (r0 < RPP && r0 + RPP * k < RH) raw[(r0 + RPP * k) * RQ + rq] = v[k];
@@ -1852,7 +1869,7 @@ __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg
                 const unsigned t1 = P[cv_round(x1 * b + y1 * a) * (kPDw * 4) + cv_round(x1 * a - y1 * b)];
                 nib |= (unsigned)(t0 < t1) << t;
             }
-            const int slot = grp * kDescKP + ls, oi = s_oi[ls];
+            const int oi = s_oi[ls];
             unsigned byte = nib | (__shfl_down(nib, 1, 64) << 4);          // valid on even lanes
             unsigned w = byte | (__shfl_down(byte, 2, 64) << 8) | (__shfl_down(byte, 4, 64) << 16) | (__shfl_down(byte, 6, 64) << 24);
             if ((lane & 7) == 0) *(unsigned*)(desc + ((size_t)img * nf + oi) * 32 + (lane >> 3) * 4) = w;
