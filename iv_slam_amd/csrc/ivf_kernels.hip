@@ -1115,13 +1115,33 @@ __global__ __launch_bounds__(256) void k_cell_qsum(const Config* __restrict__ cf
     // aligned dwords covering [wx0, wx1); bytes outside the window are masked; v_sad_u8 sums 4 bytes per op
     const int a0 = wx0 & ~3, nq = (wx1 - a0 + 3) / 4, nrow = wy1 - wy0;
     unsigned acc = 0;
-    for (int t = lane; t < nq * nrow; t += 64) {
-        const int y = wy0 + t / nq, q = t % nq;
-        unsigned v = *(const unsigned*)(Q + (size_t)y * G.pitch + a0 + 4 * q);
-        const int bx = a0 + 4 * q;
-        if (bx < wx0) v &= 0xffffffffu << (8 * (wx0 - bx));
-        if (bx + 4 > wx1) v &= 0xffffffffu >> (8 * (bx + 4 - wx1));
-        acc = __builtin_amdgcn_sad_u8(v, 0u, acc);
+    // r06: eight dwords per lane in flight.  One load per iteration with its use right behind it is one round trip per iteration: a level-0 cell's window is
+    // ~4,500 dwords = 70 SEQUENTIAL round trips per wave, which was the kernel's whole time (87 us per 128 cost images, 325 at 1920 x 1200)
+    constexpr int U = 8;
+    const int total = nq * nrow;
+    const int dr = 64 / nq, dq = 64 % nq;                                      // (row, dword) of item t + 64 from those of item t: one division per wave, not one per item
+    int rr = lane / nq, qq = lane % nq;
+    for (int t0 = lane; t0 < total; t0 += 64 * U) {
+        unsigned v[U]; int bxs[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool in = t0 + 64 * u < total;
+            const int r = in ? rr : nrow - 1, q = in ? qq : nq - 1;             // past the end: the last item again (not counted)
+            bxs[u] = a0 + 4 * q;
+            v[u] = *(const unsigned*)(Q + (size_t)(wy0 + r) * G.pitch + bxs[u]);
+            qq += dq; rr += dr;
+            if (qq >= nq) { qq -= nq; rr++; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) asm volatile("" : "+v"(v[u]));            // (keeps the compiler from sinking a load into the branch of its use)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            unsigned w = v[u];
+            const int bx = bxs[u];
+            if (bx < wx0) w &= 0xffffffffu << (8 * (wx0 - bx));
+            if (bx + 4 > wx1) w &= 0xffffffffu >> (8 * (bx + 4 - wx1));
+            if (t0 + 64 * u < total) acc = __builtin_amdgcn_sad_u8(w, 0u, acc);
+        }
     }
     const unsigned qs = (unsigned)wave_sum_i32((int)acc);
     if (lane == 0) cellInfo[(size_t)img * cfg->nCellsTotal + cell].nTotal = (int)qs;
@@ -1949,6 +1969,18 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const Config* __restrict__ 
     __shared__ float s_scaleW[4][kMaxLevels];
     float* sc8 = s_scaleW[threadIdx.x >> 6];
     stage_scales(cfg, sc8, threadIdx.x & 63);
+    // r06: four right keypoints per thread in flight (y and octave only), instead of one record per iteration with its use behind it
+    auto for_each_right = [&](auto&& f) {
+        for (int i0 = tid; i0 < nR; i0 += 4 * 256) {
+            float ky[4]; int ko[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const ivf_keypoint* k = kpR + min(i0 + 256 * j, nR - 1); ky[j] = k->y; ko[j] = k->octave; }
+#pragma unroll
+            for (int j = 0; j < 4; j++) asm volatile("" : "+v"(ky[j]), "+v"(ko[j]));
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (i0 + 256 * j < nR) f(i0 + 256 * j, ky[j], ko[j]);
+        }
+    };
     if (inLds) {
         // r04: the table of one pair (H x (4 + 2 kRowCap) bytes: 73 KB at H = 375) is built in LDS -- ~5 LDS atomics per right keypoint
         // instead of global ones (39 -> 13 us per 128 pairs) -- and leaves as one pass of coalesced dword stores; the order of a row's
@@ -1957,15 +1989,14 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const Config* __restrict__ 
         unsigned short* ls = (unsigned short*)(s_rows + ((H + 3) & ~3));
         for (int y = tid; y < H; y += 256) cs[y] = 0;
         __syncthreads();
-        for (int iR = tid; iR < nR; iR += 256) {
-            const ivf_keypoint kr = kpR[iR];
-            const float r = 2.0f * sc8[kr.octave];
-            const int maxr = min((int)ceilf(kr.y + r), H - 1), minr = max((int)floorf(kr.y - r), 0);
+        for_each_right([&](int iR, float ky, int koct) {
+            const float r = 2.0f * sc8[koct];
+            const int maxr = min((int)ceilf(ky + r), H - 1), minr = max((int)floorf(ky - r), 0);
             for (int yi = minr; yi <= maxr; yi++) {
                 const int pos = atomicAdd(&cs[yi], 1);
                 if (pos < kRowCap) ls[yi * kRowCap + pos] = (unsigned short)iR;
             }
-        }
+        });
         __syncthreads();
         for (int y = tid; y < H; y += 256) cnt[y] = cs[y];
         static_assert(kRowCap % 2 == 0, "rows are copied as dwords");
@@ -1979,15 +2010,14 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const Config* __restrict__ 
     }
     for (int y = tid; y < H; y += 256) cnt[y] = 0;
     __syncthreads();
-    for (int iR = tid; iR < nR; iR += 256) {
-        const ivf_keypoint kr = kpR[iR];
-        const float r = 2.0f * sc8[kr.octave];
-        const int maxr = min((int)ceilf(kr.y + r), H - 1), minr = max((int)floorf(kr.y - r), 0);
+    for_each_right([&](int iR, float ky, int koct) {
+        const float r = 2.0f * sc8[koct];
+        const int maxr = min((int)ceilf(ky + r), H - 1), minr = max((int)floorf(ky - r), 0);
         for (int yi = minr; yi <= maxr; yi++) {
             const int pos = atomicAdd(&cnt[yi], 1);
             if (pos < kRowCap) list[(size_t)yi * kRowCap + pos] = (unsigned short)iR;
         }
-    }
+    });
 }
 
 __global__ __launch_bounds__(256) void k_stereo_match(const Config* __restrict__ cfg, StereoArgs A)
@@ -2152,7 +2182,19 @@ __global__ __launch_bounds__(256) void k_stereo_gate(const Config* __restrict__ 
     if (tid == 0) { s_n = 0; s_median = -1; }
     __syncthreads();
     int local = 0;
-    for (int i = tid; i < nL; i += 256) { const int d = S[i]; if (d >= 0) { local++; atomicAdd(&s_hist[min(d >> 8, 255)], 1); } }
+    // r06: four distances per thread in flight in each of the three passes (one load per iteration with its use behind it = one round trip per iteration)
+    auto for_each_dist = [&](auto&& f) {
+        for (int i0 = tid; i0 < nL; i0 += 4 * 256) {
+            int dv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) dv[j] = S[min(i0 + 256 * j, nL - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; j++) asm volatile("" : "+v"(dv[j]));
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (i0 + 256 * j < nL) f(i0 + 256 * j, dv[j]);
+        }
+    };
+    for_each_dist([&](int, int d) { if (d >= 0) { local++; atomicAdd(&s_hist[min(d >> 8, 255)], 1); } });
     if (local) atomicAdd(&s_n, local);
     __syncthreads();
     const int n = s_n;
@@ -2167,7 +2209,7 @@ __global__ __launch_bounds__(256) void k_stereo_gate(const Config* __restrict__ 
     const int bin = s_bin, below = s_below;
     s_hist[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < nL; i += 256) { const int d = S[i]; if (d >= 0 && min(d >> 8, 255) == bin) atomicAdd(&s_hist[d & 255], 1); }
+    for_each_dist([&](int, int d) { if (d >= 0 && min(d >> 8, 255) == bin) atomicAdd(&s_hist[d & 255], 1); });
     __syncthreads();
     if (tid == 0) {
         int acc = below, b = 0;
@@ -2177,13 +2219,12 @@ __global__ __launch_bounds__(256) void k_stereo_gate(const Config* __restrict__ 
     __syncthreads();
     const float median = (float)s_median;
     const float thDist = 1.5f * 1.4f * median;
-    for (int i = tid; i < nL; i += 256) {
-        const int d = S[i];
+    for_each_dist([&](int i, int d) {
         if (d >= 0 && !((float)d < thDist)) {
             uright[(size_t)pair * outStride + i] = -1;
             depth[(size_t)pair * outStride + i] = -1;
         }
-    }
+    });
 }
 
 // testing hook: the device's retainBest on caller-supplied responses (one wave, LDS), so the wave-cooperative
@@ -2408,10 +2449,22 @@ __global__ __launch_bounds__(256) void k_pack_gather(const int* __restrict__ cou
     const unsigned* u = (const unsigned*)(uright + (size_t)p * nf);
     const unsigned* z = (const unsigned*)(depth + (size_t)p * nf);
     const int nk = nf * (int)(sizeof(ivf_keypoint) / 4), nd = nf * 8;
-    for (int i = threadIdx.x; i < nk; i += 256) out[4 + i] = k[i];
-    for (int i = threadIdx.x; i < nd; i += 256) out[4 + nk + i] = d[i];
-    for (int i = threadIdx.x; i < nf; i += 256) out[4 + nk + nd + i] = u[i];
-    for (int i = threadIdx.x; i < nf; i += 256) out[4 + nk + nd + nf + i] = z[i];
+    // r06: eight dwords per thread in flight (a plain `out[i] = in[i]` loop is one round trip per iteration: 64 of them per pair at N = 1000)
+    auto copy = [&](unsigned* __restrict__ o, const unsigned* __restrict__ in, int n) {
+        for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 256) {
+            unsigned v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = in[min(i0 + 256 * j, n - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; j++) asm volatile("" : "+v"(v[j]));
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (i0 + 256 * j < n) o[i0 + 256 * j] = v[j];
+        }
+    };
+    copy(out + 4, k, nk);
+    copy(out + 4 + nk, d, nd);
+    copy(out + 4 + nk + nd, u, nf);
+    copy(out + 4 + nk + nd + nf, z, nf);
 }
 
 void launch_pack_gather(const Buffers& b, int nf, int nPairs, uint8_t* block, size_t recBytes, hipStream_t s)
