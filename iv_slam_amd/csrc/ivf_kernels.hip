@@ -1152,11 +1152,17 @@ __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, c
                                               const uint8_t* __restrict__ qpyr, const uint8_t* __restrict__ useCost,
                                               CellInfo* __restrict__ cellInfo, int* __restrict__ lvlTotal,
                                               int* __restrict__ hugeCount, int* __restrict__ hugeList, int* __restrict__ tierList,
-                                              int tierCap, int* __restrict__ status)
+                                              int tierCap, int* __restrict__ status, int cap)
 {
-    __shared__ int s_nIni[kMaxCells], s_nMin[kMaxCells], s_nTotal[kMaxCells], s_nRetain[kMaxCells], s_prefix[kMaxCells + 1];
-    __shared__ unsigned s_qsum[kMaxCells];
-    __shared__ unsigned char s_useMin[kMaxCells];
+    // r06: the bookkeeping arrays are sized by the launch (cap = the largest level's cell count, rounded up) instead of kMaxCells = 2048 each: 51 KB per workgroup
+    // meant three workgroups per CU for 2,048 (level, image) workgroups -- three rounds of a kernel whose time is one thread's sequential pass
+    extern __shared__ __attribute__((aligned(16))) int s_quota[];
+    int* const s_nIni = s_quota; int* const s_nMin = s_nIni + cap; int* const s_nTotal = s_nMin + cap; int* const s_nRetain = s_nTotal + cap;
+    int* const s_prefix = s_nRetain + cap;                    // [cap + 1]
+    unsigned* const s_qsum = (unsigned*)(s_prefix + cap + 4);
+    float* const s_diff = (float*)(s_qsum + cap);             // nfeatures_cell - nKeys of the cells that keep all their keypoints
+    unsigned char* const s_useMin = (unsigned char*)(s_diff + cap);
+    __shared__ float s_wsum;
     const int img = blockIdx.y, level = blockIdx.x;
     const LevelGeom& G = cfg->lv[level];
     const int tid = threadIdx.x;
@@ -1177,21 +1183,25 @@ __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, c
         s_qsum[c] = mode ? (unsigned)ci[c].nTotal : 0u;       // window sums from k_cell_qsum
     }
     __syncthreads();
-    if (tid == 0) {                                   // sequential bookkeeping exactly in (i,j) order
-        float wsum = 0.0f;
-        if (mode)
-            for (int c = 0; c < nCells; c++) {
-                const int i = c / cols, j = c % cols;
-                const float hX = (j == cols - 1) ? (float)(G.maxBX + 3 - (16 + j * G.cellW)) : (float)(G.cellW + 6);
-                const float hY = (i == rows - 1) ? (float)G.winHLast : (float)(G.cellH + 6);
-                const float cost = (float)s_qsum[c] / (float)(hX * hY);
-                const float q = (float)(1.0 / (1.0 + (double)(cost / 255)));
-                const float wn = 2 * q - 1;
-                s_qsum[c] = __float_as_uint(wn);
-                wsum += wn;
-            }
-        int nToDistribute = 0, nNoMore = 0;
-        for (int c = 0; c < nCells; c++) {
+    // r06: everything that is a function of ONE cell runs on all threads (the window weight with its f64 division, nfeatures_cell with its division and ceil,
+    // the keep-all / retain decision); thread 0 keeps only what the reference's order defines: the float sum of the weights in (i, j) order, the int / float
+    // accumulation of nToDistribute, the redistribution pass and the prefix.  (Was: all of it on thread 0 -- ~600 cycles per cell with 255 threads idle.)
+    if (mode) {
+        for (int c = tid; c < nCells; c += 256) {
+            const int i = c / cols, j = c % cols;
+            const float hX = (j == cols - 1) ? (float)(G.maxBX + 3 - (16 + j * G.cellW)) : (float)(G.cellW + 6);
+            const float hY = (i == rows - 1) ? (float)G.winHLast : (float)(G.cellH + 6);
+            const float cost = (float)s_qsum[c] / (float)(hX * hY);
+            const float q = (float)(1.0 / (1.0 + (double)(cost / 255)));
+            s_qsum[c] = __float_as_uint(2 * q - 1);
+        }
+        __syncthreads();
+        if (tid == 0) { float wsum = 0.0f; for (int c = 0; c < nCells; c++) wsum += __uint_as_float(s_qsum[c]); s_wsum = wsum; }
+        __syncthreads();
+    }
+    {
+        const float wsum = mode ? s_wsum : 1.0f;
+        for (int c = tid; c < nCells; c += 256) {
             const float nfc = mode ? fmaxf(1.0f, ceilf((float)G.nDesired * __uint_as_float(s_qsum[c]) / wsum))
                                    : (float)G.nfeaturesCell;
             const bool useMin = s_nIni[c] <= 3;
@@ -1199,13 +1209,15 @@ __global__ __launch_bounds__(256) void k_quota(const Config* __restrict__ cfg, c
             s_useMin[c] = useMin;
             s_nTotal[c] = nKeys;
             if ((float)nKeys > nfc) { s_nRetain[c] = (int)nfc; s_prefix[c] = 0; }
-            else {
-                s_nRetain[c] = nKeys;
-                nToDistribute = (int)((float)nToDistribute + (nfc - (float)nKeys));
-                s_prefix[c] = 1; nNoMore++;             // s_prefix doubles as bNoMore here
-            }
+            else { s_nRetain[c] = nKeys; s_diff[c] = nfc - (float)nKeys; s_prefix[c] = 1; }      // s_prefix doubles as bNoMore here
             s_nIni[c] = __float_as_int(nfc);            // keep nfeatures_cell for the redistribution pass
         }
+    }
+    __syncthreads();
+    if (tid == 0) {                                   // the order-dependent rest, exactly in (i,j) order
+        int nToDistribute = 0, nNoMore = 0;
+        for (int c = 0; c < nCells; c++)
+            if (s_prefix[c]) { nToDistribute = (int)((float)nToDistribute + s_diff[c]); nNoMore++; }
         if (nToDistribute > 0 && nNoMore < nCells) {
             for (int c = 0; c < nCells; c++) {
                 if (!s_prefix[c]) {
@@ -2305,8 +2317,11 @@ void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nIm
     if (hc.introspection)
         hipLaunchKernelGGL(k_cell_qsum, dim3((hc.nCellsTotal + 3) / 4, nImg), dim3(256), 0, s, dc, b.qpyr, b.useCost, (CellInfo*)b.cellInfo);
     const int tierCap = nImg * hc.nCellsTotal;
-    hipLaunchKernelGGL(k_quota, dim3(hc.nlevels, nImg), dim3(256), 0, s, dc, b.cellCnt, b.qpyr, b.useCost,
-                       (CellInfo*)b.cellInfo, b.lvlTotal, b.hugeCount, b.hugeList, b.tierList, tierCap, b.status);
+    int cap = 4;
+    for (int l = 0; l < hc.nlevels; l++) cap = std::max(cap, (hc.lv[l].nCells + 3) & ~3);
+    const size_t quotaLds = (size_t)cap * (7 * 4 + 1) + 64;                     // six int / float arrays + the prefix's tail + the byte flags (k_quota)
+    hipLaunchKernelGGL(k_quota, dim3(hc.nlevels, nImg), dim3(256), quotaLds, s, dc, b.cellCnt, b.qpyr, b.useCost,
+                       (CellInfo*)b.cellInfo, b.lvlTotal, b.hugeCount, b.hugeList, b.tierList, tierCap, b.status, cap);
     // three tiers by survivor count: the kernel is a chain of dependent LDS steps at one wave per cell, so its throughput is the
     // number of cells in flight per CU = LDS per workgroup: 5 KB (<= 256 survivors), 14 KB (<= 1024), 51 KB (<= 4096, four waves; a 2048 tier of two waves measured slower: 77 + 42 vs 109 us)
     // r04: tier 0 four cells per workgroup; tiers 1 / 2 from k_quota's work lists with a fixed grid (a full grid per tier cost 80-110 us
