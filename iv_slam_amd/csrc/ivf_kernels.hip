@@ -1600,11 +1600,13 @@ __global__ __launch_bounds__(1024) void k_cell_select_huge(const Config* __restr
 
 __global__ __launch_bounds__(256) void k_level_select(const Config* __restrict__ cfg, const int* __restrict__ lvlTotal,
                                                      u64* __restrict__ lvlList, unsigned* __restrict__ slotPos,
-                                                     float* __restrict__ slotResp, int* __restrict__ lvlCount)
+                                                     float* __restrict__ slotResp, int* __restrict__ lvlCount, int LCAP)
 {
-    constexpr int LCAP = 4096;
-    __shared__ __attribute__((aligned(16))) u64 s_list[LCAP];
-    __shared__ unsigned short s_stopA[LCAP], s_stopB[LCAP];
+    // r06: the LDS copy of a level's list is sized by the launch (LCAP = four times the largest nDesired of the geometry, at most 4096; a longer list takes the
+    // global path below as before) instead of 4096 entries = 49 KB per workgroup = three workgroups per CU for 2,048 (level, image) workgroups
+    extern __shared__ __attribute__((aligned(16))) u64 s_list[];
+    unsigned short* const s_stopA = (unsigned short*)(s_list + LCAP);
+    unsigned short* const s_stopB = s_stopA + LCAP;
     const int img = blockIdx.y, level = blockIdx.x, tid = threadIdx.x;
     const LevelGeom& G = cfg->lv[level];
     if (!G.valid) { if (tid == 0) lvlCount[img * kMaxLevels + level] = 0; return; }
@@ -2338,8 +2340,11 @@ void launch_select(const Config& hc, const Config* dc, const Buffers& b, int nIm
     if (b.hugeScratch)       // geometry allows cells with more than kCellCapBig strict maxima: walk k_quota's (usually empty) list
         hipLaunchKernelGGL(k_cell_select_huge, dim3(kHugeSlots), dim3(1024), 0, s, dc, b.tileList, b.tileCnt, (const CellInfo*)b.cellInfo,
                            b.qpyr, b.useCost, b.lvl, b.status, b.hugeCount, b.hugeList, b.hugeScratch, hc.maxCandCap);
-    hipLaunchKernelGGL(k_level_select, dim3(hc.nlevels, nImg), dim3(256), 0, s, dc, b.lvlTotal, b.lvl, b.slotPos, b.slotResp,
-                       b.lvlCount);
+    int maxDesired = 1;
+    for (int l = 0; l < hc.nlevels; l++) maxDesired = std::max(maxDesired, hc.lv[l].nDesired);
+    const int lcap = std::min(4096, (4 * maxDesired + 256 + 63) & ~63);
+    hipLaunchKernelGGL(k_level_select, dim3(hc.nlevels, nImg), dim3(256), (size_t)lcap * 12, s, dc, b.lvlTotal, b.lvl, b.slotPos, b.slotResp,
+                       b.lvlCount, lcap);
 }
 void launch_describe(const Config& hc, const Config* dc, const Buffers& b, const uint8_t*, size_t, int, int nImg, int,
                      hipStream_t s)
