@@ -208,6 +208,7 @@ int Context::build(const Tables& t, int w, int h, int maxImages, int sides, int 
     c.nTiles = tileBase;
     c.nBlurTiles = btileBase;
     for (int l = 0; l < kMaxLevels; l++) {
+        c.cellBases[l] = (l < c.nlevels && c.lv[l].valid) ? c.lv[l].cellBase : INT_MAX;
         c.tileBases[l] = l < c.nlevels ? c.lv[l].tileBase : INT_MAX;
         c.btileBases[l] = l < c.nlevels ? c.lv[l].btileBase : INT_MAX;
     }

@@ -46,6 +46,7 @@ struct Config {
     int maxCandCap;         // largest per-cell bound on strict 3x3 maxima over the levels (k_cell_select_huge slot size)
     int umax[16];
     float scale[kMaxLevels], invScale[kMaxLevels];
+    int cellBases[kMaxLevels];                           // lv[l].cellBase of the VALID levels side by side (INT_MAX for an invalid level and past nlevels): one wide scalar load
     int tileBases[kMaxLevels], btileBases[kMaxLevels];   // lv[l].tileBase / btileBase side by side (INT_MAX past nlevels):
                                                          // a tile finds its level with one wide uniform load
     LevelGeom lv[kMaxLevels];

@@ -94,6 +94,47 @@ __global__ void k_fcn_prep(const uint8_t* __restrict__ bgr, size_t imageStride, 
     const uint8_t* I = bgr + (size_t)b * imageStride;
     const float mean[3] = {0.485f, 0.456f, 0.406f}, istd[3] = {1.0f / 0.229f, 1.0f / 0.224f, 1.0f / 0.225f};
     const bool wide = x0 + 3 <= w - 1;
+    if (w >= 3) {
+        // r06: branch-free taps, every row of the thread in flight at once.  A row's two taps are the 6 bytes from 3 x0 (3 when x1 = x0, the last column): ONE unaligned
+        // 8-byte load at min(3 x0, 3 w - 8) -- never past the row's end -- shifted down by the bytes in front of 3 x0.  The form below (`wide ? two dwords : twelve byte
+        // loads`, row after row) was a load -> wait -> compute -> store round trip per output row; the bytes, the arithmetic and its order are the same.
+        const int xb = min(3 * x0, 3 * w - 8), sh = 8 * (3 * x0 - xb), o1 = 24 * (x1 - x0);
+        unsigned long long wt[kPrepRows], wb[kPrepRows];
+        float ly0s[kPrepRows], ly1s[kPrepRows];
+#pragma unroll
+        for (int r = 0; r < kPrepRows; r++) {
+            const int y = yA + r;
+            float fy = sy_ * ((float)y + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
+            int y0 = (int)fy; if (y0 > h - 1) y0 = h - 1;
+            const int y1 = y0 + (y0 < h - 1);
+            ly1s[r] = fy - (float)y0; ly0s[r] = 1.f - ly1s[r];
+            __builtin_memcpy(&wt[r], I + (size_t)y0 * rowStride + xb, 8);
+            __builtin_memcpy(&wb[r], I + (size_t)y1 * rowStride + xb, 8);
+        }
+#pragma unroll
+        for (int r = 0; r < kPrepRows; r++) {
+            unsigned tl = (unsigned)wt[r], th = (unsigned)(wt[r] >> 32), bl = (unsigned)wb[r], bh = (unsigned)(wb[r] >> 32);
+            asm volatile("" : "+v"(tl), "+v"(th), "+v"(bl), "+v"(bh));            // (all rows requested before the first is consumed)
+            wt[r] = ((unsigned long long)th << 32) | tl; wb[r] = ((unsigned long long)bh << 32) | bl;
+        }
+#pragma unroll
+        for (int r = 0; r < kPrepRows; r++) {
+            const int y = yA + r;
+            const unsigned long long T = wt[r] >> sh, B = wb[r] >> sh;
+            const float ly0 = ly0s[r], ly1 = ly1s[r];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int sc = 2 - c;                       // BGR -> RGB
+                auto nz = [&](unsigned q) { return ((float)q * (1.0f / 255.0f) - mean[c]) * istd[c]; };
+                const unsigned t0 = (unsigned)(T >> (8 * sc)) & 0xffu, t1 = (unsigned)(T >> (o1 + 8 * sc)) & 0xffu;
+                const unsigned b0 = (unsigned)(B >> (8 * sc)) & 0xffu, b1 = (unsigned)(B >> (o1 + 8 * sc)) & 0xffu;
+                const float top = nz(t0) * lx0 + nz(t1) * lx1;
+                const float bot = nz(b0) * lx0 + nz(b1) * lx1;
+                out[(((size_t)b * 3 + c) * kEnc + y) * kEnc + x] = top * ly0 + bot * ly1;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < kPrepRows; r++) {
         const int y = yA + r;

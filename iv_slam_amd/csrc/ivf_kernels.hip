@@ -1091,6 +1091,16 @@ DEVINL void sel_nth_element_wave(PTR v, int n, int nth, IDX A, IDX B, int lane)
 // Candidate counts per cell are heavy-tailed (tens typically, >1000 on repetitive texture); one wave per cell lets
 // the hardware balance that, and keeps every sequential replay in LDS (~64-cycle steps instead of L2 round trips).
 // ------------------------------------------------------------------------------------------------
+// level of a global cell index: the last VALID level whose cellBase is <= gc, from one wide scalar load (r06: the loop over cfg->lv[l].valid / .cellBase was two
+// dependent scalar round trips per level at the head of every cell's wave)
+DEVINL int level_of_cell(const Config* __restrict__ cfg, int gc)
+{
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; l++) level = gc >= cfg->cellBases[l] ? l : level;
+    return level;
+}
+
 struct CellInfo { int nTotal, nRetain, prefix, useMin; };
 
 // cv::sum over every cell WINDOW of the cost pyramid (:977), one wave per cell; the sums are parked in cellInfo[].x
@@ -1101,9 +1111,7 @@ __global__ __launch_bounds__(256) void k_cell_qsum(const Config* __restrict__ cf
     const int img = blockIdx.y, lane = threadIdx.x & 63;
     const int cell = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // a scalar: the level geometry below then comes through scalar loads
     if (cell >= cfg->nCellsTotal || !(cfg->introspection && (use_cost_of(useCost, img) & 1))) return;
-    int level = 0;
-    for (int l = 1; l < cfg->nlevels; l++)
-        if (cfg->lv[l].valid && cell >= cfg->lv[l].cellBase) level = l;
+    const int level = level_of_cell(cfg, cell);
     const LevelGeom& G = cfg->lv[level];
     const int c = cell - G.cellBase, cols = G.cols, rows = G.rows;
     if (!G.valid || c >= G.nCells) return;
@@ -1284,9 +1292,7 @@ DEVINL void cell_select_one(const Config* __restrict__ cfg, const unsigned* __re
         if constexpr (NTHR == 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         else __syncthreads();
     };
-    int level = 0;
-    const int nl = cfg->nlevels;
-    for (int l = 1; l < nl; l++) if (cfg->lv[l].valid && gc >= cfg->lv[l].cellBase) level = l;
+    const int level = level_of_cell(cfg, gc);
     const LevelGeom& G = cfg->lv[level];
     const int c = gc - G.cellBase;
     if (!G.valid || c < 0 || c >= G.nCells) return;
@@ -1523,8 +1529,7 @@ __global__ __launch_bounds__(1024) void k_cell_select_huge(const Config* __restr
     unsigned* stopB = stopA + slotCap;
     for (int w = blockIdx.x; w < nHuge; w += gridDim.x) {
         const int img = hugeList[w] / cfg->nCellsTotal, gc = hugeList[w] % cfg->nCellsTotal;
-        int level = 0;
-        for (int l = 1; l < cfg->nlevels; l++) if (cfg->lv[l].valid && gc >= cfg->lv[l].cellBase) level = l;
+        const int level = level_of_cell(cfg, gc);
         const LevelGeom& G = cfg->lv[level];
         const int c = gc - G.cellBase;
         const CellInfo info = cellInfo[(size_t)img * cfg->nCellsTotal + gc];
@@ -1863,6 +1868,8 @@ __global__ __launch_bounds__(256) void k_describe(const Config* __restrict__ cfg
     for (int it = 0; it < kPIt; it++) { const int d = min(lane + 64 * it, kPItems - 1); prow[it] = d / kPDw; pcol[it] = d % kPDw; }
 #pragma unroll
     for (int half = 0; half < kDescPW / 4; half++) {
+        // (r06, measured and dropped: the patches of all eight keypoints requested at once -- 20 more registers, 220 vs 217-220 us: the second request's round trip
+        // is already covered by the other waves' gathers)
         unsigned pv[4][kPIt];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -2214,21 +2221,35 @@ __global__ __launch_bounds__(256) void k_stereo_gate(const Config* __restrict__ 
     const int n = s_n;
     if (n == 0) return;
     const int target = n / 2;
-    if (tid == 0) {
-        int acc = 0, b = 0;
-        for (; b < 256; b++) { if (acc + s_hist[b] > target) break; acc += s_hist[b]; }
-        s_bin = b; s_below = acc;
-    }
+    // r06: the first bin whose running count exceeds the target, by a 256-thread inclusive scan (8 steps) instead of thread 0 walking up to 256 LDS reads twice
+    // (most of this kernel's 17 us).  Exactly one thread sees incl > t >= excl; it is the bin the sequential walk stops at and excl is what the walk had summed.
+    __shared__ int s_scan[256];
+    auto first_exceed = [&](int t, int& bin, int& below) {
+        const int v = s_hist[tid];
+        s_scan[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int a = tid >= off ? s_scan[tid - off] : 0;
+            __syncthreads();
+            s_scan[tid] += a;
+            __syncthreads();
+        }
+        const int incl = s_scan[tid], excl = incl - v;
+        if (incl > t && excl <= t) { s_bin = tid; s_below = excl; }
+        __syncthreads();
+        bin = s_bin; below = s_below;
+    };
+    int bin, below;
+    first_exceed(target, bin, below);
     __syncthreads();
-    const int bin = s_bin, below = s_below;
     s_hist[tid] = 0;
     __syncthreads();
     for_each_dist([&](int, int d) { if (d >= 0 && min(d >> 8, 255) == bin) atomicAdd(&s_hist[d & 255], 1); });
     __syncthreads();
-    if (tid == 0) {
-        int acc = below, b = 0;
-        for (; b < 256; b++) { if (acc + s_hist[b] > target) break; acc += s_hist[b]; }
-        s_median = (bin << 8) | b;
+    {
+        int b2, below2;
+        first_exceed(target - below, b2, below2);
+        if (tid == 0) s_median = (bin << 8) | b2;
     }
     __syncthreads();
     const float median = (float)s_median;
