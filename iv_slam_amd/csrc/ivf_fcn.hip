@@ -274,6 +274,8 @@ __global__ __launch_bounds__(512, 4) void k_fcn_stem(const float* __restrict__ X
             dst[k] = (c * kStemIH + r) * kStemIP + 4 * q4;
             v4[k] = *(const float4*)(Xb + ((size_t)c * kEnc + (ok[k] ? yy : 0)) * kEnc + (ok[k] ? xx : 0));
         }
+#pragma unroll
+        for (int k = 0; k < IT; k++) asm volatile("" : "+v"(v4[k].x), "+v"(v4[k].y), "+v"(v4[k].z), "+v"(v4[k].w));      // r06: see k_fcn_irb -- the last item's load had been sunk into its store's branch
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < IT; k++)
@@ -524,6 +526,13 @@ __global__ __launch_bounds__(512, 4) void k_fcn_irb(const float* __restrict__ X,
         float4 t4[ITT];                                         // the parameter table: branch-free clamped loads, in flight with the window
 #pragma unroll
         for (int k = 0; k < ITT; k++) t4[k] = tab4[min(tid + NT * k, NTAB4 - 1)];
+        // r06: every loaded value passes through an empty asm before the first store.  sched_barrier does not stop the compiler's IR passes from moving a load into the
+        // branch of its conditional store: the table's second piece (blocks 3 / 4: ITT = 2, stored by 24 threads) was loaded AFTER the first piece's wait -- a second
+        // round trip at the head of every workgroup
+#pragma unroll
+        for (int k = 0; k < ITT; k++) asm volatile("" : "+v"(t4[k].x), "+v"(t4[k].y), "+v"(t4[k].z), "+v"(t4[k].w));
+#pragma unroll
+        for (int k = 0; k < IT; k++) asm volatile("" : "+v"(v4[k].x), "+v"(v4[k].y), "+v"(v4[k].z), "+v"(v4[k].w));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < ITT; k++)
